@@ -1,0 +1,171 @@
+"""ctypes mirror of include/imsim_hip.h and loader of libimsim_hip.so.
+
+The product path has no CPU fallback: if the HIP library is missing, or a compute entry point is
+called without a GPU, this raises.  Struct layouts are self-checked against ims_struct_size().
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+IMS_OBJ_FAINT = 1
+IMS_PSF_GAUSSIAN, IMS_PSF_RADIAL = 1, 2
+IMS_MAX_PSF = 4
+(IMS_OP_TIME_SAMPLER, IMS_OP_PUPIL_ANNULUS_SAMPLER, IMS_OP_PHOTON_DCR, IMS_OP_RUBIN_OPTICS,
+ IMS_OP_RUBIN_DIFFRACTION, IMS_OP_RUBIN_DIFFRACTION_OPTICS, IMS_OP_FOCUS_DEPTH, IMS_OP_REFRACTION,
+ IMS_OP_BANDPASS_RATIO) = range(1, 10)
+IMS_MAX_OPS = 12
+IMS_SENSOR_NONE, IMS_SENSOR_SILICON = 0, 1
+IMS_SURF_MIRROR, IMS_SURF_REFRACT, IMS_SURF_DETECTOR, IMS_SURF_BAFFLE = 1, 2, 3, 4
+IMS_MEDIUM_CONST, IMS_MEDIUM_SELLMEIER, IMS_MEDIUM_AIR = 0, 1, 2
+(IMS_OBSC_NONE, IMS_OBSC_CLEAR_ANNULUS, IMS_OBSC_CLEAR_CIRCLE, IMS_OBSC_OBSC_CIRCLE,
+ IMS_OBSC_OBSC_ANNULUS) = range(5)
+IMS_MAX_SURFACES = 24
+
+c_d, c_i32, c_i64, c_u64, c_vp = C.c_double, C.c_int32, C.c_int64, C.c_uint64, C.c_void_p
+
+
+class Object(C.Structure):
+    _fields_ = [("obj_id", c_i64), ("phot_first", c_i64), ("n_phot", c_i64),
+                ("x0", c_d), ("y0", c_d), ("flux_per_photon", c_d), ("prof_scale", c_d),
+                ("jac", c_d * 4), ("winv", c_d * 4),
+                ("dcr_tanz", c_d), ("dcr_sinp", c_d), ("dcr_cosp", c_d),
+                ("prof_table", c_i32), ("sed_table", c_i32), ("flags", c_i32),
+                ("stamp_xmin", c_i32), ("stamp_xmax", c_i32), ("stamp_ymin", c_i32), ("stamp_ymax", c_i32),
+                ("bf_state", c_i32), ("sed_wave", c_d), ("reserved", c_d * 9)]
+
+
+# numpy view of the same 256-byte row, for vectorised object-table construction
+OBJECT_DTYPE = np.dtype([
+    ("obj_id", "<i8"), ("phot_first", "<i8"), ("n_phot", "<i8"),
+    ("x0", "<f8"), ("y0", "<f8"), ("flux_per_photon", "<f8"), ("prof_scale", "<f8"),
+    ("jac", "<f8", (4,)), ("winv", "<f8", (4,)),
+    ("dcr_tanz", "<f8"), ("dcr_sinp", "<f8"), ("dcr_cosp", "<f8"),
+    ("prof_table", "<i4"), ("sed_table", "<i4"), ("flags", "<i4"),
+    ("stamp_xmin", "<i4"), ("stamp_xmax", "<i4"), ("stamp_ymin", "<i4"), ("stamp_ymax", "<i4"),
+    ("bf_state", "<i4"), ("sed_wave", "<f8"), ("reserved", "<f8", (9,))], align=True)
+assert OBJECT_DTYPE.itemsize == 256
+
+
+class RadialTables(C.Structure):
+    _fields_ = [("n_tables", c_i32), ("n_bins", c_i32), ("r2", c_vp), ("cdf", c_vp)]
+
+
+class LinTables(C.Structure):
+    _fields_ = [("n_tables", c_i32), ("n_pts", c_i32), ("arg_min", c_d), ("arg_step", c_d), ("val", c_vp)]
+
+
+class PsfComponent(C.Structure):
+    _fields_ = [("kind", c_i32), ("table", c_i32), ("p0", c_d), ("chrom_alpha", c_d), ("chrom_base", c_d)]
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", c_i32), ("table", c_i32), ("p", c_d * 6)]
+
+
+class Surface(C.Structure):
+    _fields_ = [("kind", c_i32), ("obsc_kind", c_i32), ("medium_kind", c_i32), ("n_asphere", c_i32),
+                ("z0", c_d), ("R", c_d), ("conic", c_d), ("asph", c_d * 4),
+                ("obsc_inner", c_d), ("obsc_outer", c_d), ("medium_c", c_d * 6)]
+
+
+class TanSip(C.Structure):
+    _fields_ = [("crpix", c_d * 2), ("cd", c_d * 4), ("cdinv", c_d * 4), ("rot", c_d * 9),
+                ("order", c_i32), ("pad", c_i32), ("a", c_d * 25), ("b", c_d * 25)]
+
+
+class Optics(C.Structure):
+    _fields_ = [("img_wcs", TanSip), ("icrf_to_field", TanSip),
+                ("in_medium_kind", c_i32), ("n_surfaces", c_i32), ("in_medium_c", c_d * 6),
+                ("stop_z", c_d), ("surf", Surface * IMS_MAX_SURFACES),
+                ("cam_rot", c_d * 2), ("fp_to_pix", c_d * 6), ("slope_jac", c_d * 4),
+                ("n_lines", c_i32), ("n_circles", c_i32), ("lines", (c_d * 4) * 8), ("circles", (c_d * 3) * 4),
+                ("e_z0", c_d * 3), ("e_focal", c_d * 3), ("cos_lat", c_d), ("sin_lat", c_d), ("omega", c_d)]
+
+
+class BfSlot(C.Structure):
+    _fields_ = [("xmin", c_i32), ("ymin", c_i32), ("nx", c_i32), ("ny", c_i32), ("offset", c_i64)]
+
+
+BFSLOT_DTYPE = np.dtype([("xmin", "<i4"), ("ymin", "<i4"), ("nx", "<i4"), ("ny", "<i4"), ("offset", "<i8")], align=True)
+
+
+class Sensor(C.Structure):
+    _fields_ = [("kind", c_i32), ("num_vertices", c_i32), ("nx", c_i32), ("ny", c_i32), ("qdist", c_i32),
+                ("n_abs", c_i32), ("n_tr", c_i32), ("pad", c_i32),
+                ("num_elec", c_d), ("pixel_size", c_d), ("thickness", c_d), ("diff_step", c_d),
+                ("abs_wl_min", c_d), ("abs_wl_step", c_d), ("tr_dr", c_d), ("tr_cx", c_d), ("tr_cy", c_d),
+                ("abs_len", c_vp), ("tr_table", c_vp), ("distortions", c_vp), ("emptypoly", c_vp),
+                ("n_bf_slots", c_i32), ("pad2", c_i32), ("bf_slots", c_vp),
+                ("bf_boundary", c_vp), ("bf_bounds", c_vp), ("bf_delta", c_vp)]
+
+
+class Photons(C.Structure):
+    _fields_ = [("n", c_i64)] + [(f, c_vp) for f in
+                                 ("x", "y", "flux", "dxdz", "dydz", "wavelength", "pupil_u", "pupil_v", "time", "obj_index")]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("seed", c_u64), ("objects", c_vp), ("n_objects", c_i64), ("seg_prefix", c_vp),
+                ("n_segments", c_i64), ("seg_size", c_i32), ("n_psf", c_i32),
+                ("psf", PsfComponent * IMS_MAX_PSF), ("n_ops", c_i32), ("track_static_delta", c_i32),
+                ("ops", Op * IMS_MAX_OPS), ("radial", RadialTables), ("sed", LinTables), ("ratio", LinTables),
+                ("optics", c_vp), ("sensor", c_vp), ("image", c_vp),
+                ("nx", c_i32), ("ny", c_i32), ("xmin", c_i32), ("ymin", c_i32), ("realized_flux", c_vp)]
+
+
+STRUCTS = [Object, RadialTables, LinTables, PsfComponent, Op, Surface, TanSip, Optics, BfSlot, Sensor, Photons,
+           RenderParams]
+
+# every symbol include/imsim_hip.h declares
+EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_info", "ims_shoot_accumulate",
+           "ims_shoot_photons", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
+           "ims_sensor_update_distortions", "ims_image_add", "ims_last_kernel_ms", "ims_enable_timing",
+           "ims_struct_size", "ims_test_math"]
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libimsim_hip.so")
+_lib = None
+
+
+class ImsimHipError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load libimsim_hip.so (built in-tree by __graft_entry__.build()).  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImsimHipError(f"{_LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(there is no CPU fallback)")
+    lib = C.CDLL(_LIB_PATH)
+    lib.ims_last_error.restype = C.c_char_p
+    for k, st in enumerate(STRUCTS):
+        got = lib.ims_struct_size(k)
+        if got != C.sizeof(st):
+            raise ImsimHipError(f"ABI mismatch for {st.__name__}: library {got} bytes, binding {C.sizeof(st)}")
+    lib.ims_shoot_accumulate.argtypes = [C.POINTER(RenderParams), c_vp]
+    lib.ims_shoot_photons.argtypes = [C.POINTER(RenderParams), c_vp, C.POINTER(Photons), c_vp]
+    lib.ims_apply_ops.argtypes = [C.POINTER(RenderParams), c_vp, C.POINTER(Photons), c_vp]
+    lib.ims_accumulate.argtypes = [C.POINTER(RenderParams), c_vp, C.POINTER(Photons), c_vp, c_vp]
+    lib.ims_sensor_init_boundaries.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_vp]
+    lib.ims_sensor_update_distortions.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_vp]
+    lib.ims_image_add.argtypes = [c_vp, c_vp, c_i64, c_vp]
+    lib.ims_last_kernel_ms.argtypes = [C.POINTER(C.c_float)]
+    lib.ims_enable_timing.argtypes = [C.c_int]
+    lib.ims_device_count.argtypes = [C.POINTER(C.c_int)]
+    lib.ims_device_info.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(c_i64), C.POINTER(c_i64)]
+    lib.ims_test_math.argtypes = [C.c_int, c_vp, c_vp, c_i64, c_u64, c_i64, C.c_uint32, c_vp]
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().ims_last_error()
+        raise ImsimHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

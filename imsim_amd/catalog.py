@@ -1,0 +1,192 @@
+"""Synthetic instance catalog and vectorised object-table construction.
+
+This is the host-side stand-in for the per-object Python of LSST_SiliconBuilder.setup
+(imsim/stamp.py:109-249): flux realisation, stamp size, faint/phot classification and the
+per-object geometry the kernels need, done in bulk with numpy instead of once per object.
+"""
+import math
+
+import numpy as np
+
+from . import tables
+from ._abi import OBJECT_DTYPE, IMS_OBJ_FAINT
+
+PIXEL_SCALE = 0.2          # arcsec / pixel (LSST_SiliconBuilder._pixel_scale, stamp.py:102)
+NMAX = 4096                # stamp.py:106
+TINY_FLUX = 10             # stamp.py:105
+FT_DEFAULT = 5.0e-3        # galsim.GSParams().folding_threshold
+STEPK_MIN_HLR = 5.0        # galsim.GSParams().stepk_minimum_hlr
+SERSIC_N = (1.0, 4.0)
+
+
+def synthetic_catalog(n, seed=20261001, nx=4096, ny=4096, mag_min=16.0, mag_max=27.0):
+    """The seeded synthetic catalog of SURVEY.md 8(d): uniform positions, dN/dm ~ 10^(0.35 m),
+    nominal_flux = 30 s * 10^(0.4 (28.13 - m)) e-, 50 % point / 30 % Sersic n=1 / 20 % Sersic n=4
+    (the mix of examples/example_instance_catalog.txt), hlr log-uniform 0.05-1", q~U(0.2,1),
+    PA~U(0,180)."""
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0.5, nx + 0.5, n)
+    y = rng.uniform(0.5, ny + 0.5, n)
+    a = 0.35 * math.log(10.0)
+    u = rng.uniform(0.0, 1.0, n)
+    mag = np.log(np.exp(a * mag_min) + u * (np.exp(a * mag_max) - np.exp(a * mag_min))) / a
+    flux = 30.0 * 10.0 ** (0.4 * (28.13 - mag))
+    t = rng.uniform(0.0, 1.0, n)
+    kind = np.where(t < 0.5, 0, np.where(t < 0.8, 1, 2)).astype(np.int32)   # 0 point, 1 sersic n=1, 2 sersic n=4
+    hlr = np.exp(rng.uniform(math.log(0.05), math.log(1.0), n))
+    q = rng.uniform(0.2, 1.0, n)
+    pa = rng.uniform(0.0, 180.0, n)
+    return dict(x=x, y=y, mag=mag, nominal_flux=flux, kind=kind, hlr=hlr, q=q, pa=pa,
+                obj_id=np.arange(n, dtype=np.int64))
+
+
+def realize_fluxes(nominal_flux, seed):
+    """phot_flux ~ Poisson(nominal_flux) per object (stamp.py:190)."""
+    rng = np.random.default_rng([int(seed), 0x5151])
+    return rng.poisson(nominal_flux).astype(np.int64)
+
+
+def shear_matrix(q, beta_deg):
+    """galsim.Shear(q=, beta=) as the area-preserving 2x2 used by GSObject._shear (instcat.py:519-520)."""
+    g = (1.0 - q) / (1.0 + q)
+    b = np.deg2rad(beta_deg)
+    g1, g2 = g * np.cos(2 * b), g * np.sin(2 * b)
+    f = 1.0 / np.sqrt(1.0 - g * g)
+    return np.stack([f * (1 + g1), f * g2, f * g2, f * (1 - g1)], axis=-1)
+
+
+def lens_matrix(g1, g2, mu):
+    """GSObject._lens(g1, g2, mu): shear by the reduced shear then magnify (instcat.py:521-522)."""
+    g = np.sqrt(g1 * g1 + g2 * g2)
+    f = np.sqrt(mu) / np.sqrt(1.0 - g * g)
+    return np.stack([f * (1 + g1), f * g2, f * g2, f * (1 - g1)], axis=-1)
+
+
+def _mat2(a, b):
+    return np.stack([a[..., 0] * b[..., 0] + a[..., 1] * b[..., 2], a[..., 0] * b[..., 1] + a[..., 1] * b[..., 3],
+                     a[..., 2] * b[..., 0] + a[..., 3] * b[..., 2], a[..., 2] * b[..., 1] + a[..., 3] * b[..., 3]], axis=-1)
+
+
+# ---------------- stamp sizes (imsim/stamp_utils.py restated, vectorised) ----------------
+def _good_size(stepk, pixel_scale=PIXEL_SCALE):
+    """GSObject.getGoodImageSize: N = ceil(2 pi / (stepk * scale)) rounded up to even."""
+    n = np.ceil(2.0 * np.pi / (stepk * pixel_scale)).astype(np.int64)
+    return 2 * ((n + 1) // 2)
+
+
+def gaussian_stepk(sigma, ft):
+    r = np.maximum(np.sqrt(-2.0 * np.log(ft)), STEPK_MIN_HLR * 1.1774100225154747)
+    return np.pi / (r * sigma)
+
+
+def _radius_enclosing(table, frac):
+    r2, cdf = table
+    return np.sqrt(np.interp(frac, cdf, r2))
+
+
+def kolmogorov_stepk(fwhm, ft):
+    """pi / R with R the radius enclosing (1 - ft) of the flux, at least stepk_minimum_hlr half-light radii."""
+    tab = tables.kolmogorov_table()
+    hlr = _radius_enclosing(tab, 0.5)
+    # beyond the tabulated radius use the r^(-5/3) tail: 1 - F = ft
+    r_tab = _radius_enclosing(tab, np.minimum(1.0 - ft * (1.0 - tables.SHOOT_ACCURACY), 1.0))
+    r_last = math.sqrt(tab[0][-1])
+    r_tail = r_last * (tables.SHOOT_ACCURACY / np.maximum(ft, 1e-300)) ** 0.6
+    r = np.where(ft < tables.SHOOT_ACCURACY, r_tail, r_tab)
+    r = np.maximum(r, STEPK_MIN_HLR * hlr)
+    return np.pi / (r * fwhm)
+
+
+def kolmogorov_gaussian_fwhm(airmass=1.2, raw_seeing=0.7, band="r"):
+    """make_kolmogorov_and_gaussian_psf / BuildKolmogorovPSF (psf_utils.py:42-91, atmPSF.py:524-536)."""
+    wlen_eff = dict(u=365.49, g=480.03, r=622.20, i=754.06, z=868.21, y=991.66)[band]
+    fwhm_atm = raw_seeing * (wlen_eff / 500.0) ** -0.3 * airmass ** 0.6
+    fwhm_sys = math.sqrt(0.25 ** 2 + 0.3 ** 2 + 0.08 ** 2) * airmass ** 0.6
+    return fwhm_atm, fwhm_sys
+
+
+def star_stamp_size(nominal_flux, noise_var, airmass=1.2, raw_seeing=0.7, band="r", nmax=NMAX):
+    """get_star_stamp_size (stamp_utils.py:79-155)."""
+    nominal_flux = np.asarray(nominal_flux, dtype=np.float64)
+    ft = noise_var / nominal_flux
+    use_default = (ft >= FT_DEFAULT) | (ft == 0)
+    ft = np.where(use_default, FT_DEFAULT, np.exp(np.floor(np.log(np.where(use_default, 1.0, ft)))))
+    fwhm_atm, fwhm_sys = kolmogorov_gaussian_fwhm(airmass, raw_seeing, band)
+    sk = kolmogorov_stepk(fwhm_atm, ft)
+    sg = gaussian_stepk(fwhm_sys / 2.3548200450309493, ft)
+    stepk = 1.0 / np.sqrt(1.0 / sk ** 2 + 1.0 / sg ** 2)
+    return np.minimum(_good_size(stepk), nmax)
+
+
+def gal_stamp_size(kind, hlr, max_scale, nmax=NMAX):
+    """get_gal_stamp_size, first branch (stamp_utils.py:183-189): GoodImageSize of the object
+    convolved with the DoubleGaussian proxy PSF.  (The surface-brightness growth loop of
+    :196-220 only triggers above 10 photons per stamp pixel and is not restated yet.)"""
+    sizes = np.zeros(len(hlr), dtype=np.int64)
+    dg_stepk = min(gaussian_stepk(0.6 / 2.355, FT_DEFAULT), gaussian_stepk(0.12 / 2.355, FT_DEFAULT))
+    for k, n in enumerate(SERSIC_N):
+        sel = kind == k + 1
+        if not sel.any():
+            continue
+        r = max(_radius_enclosing(tables.sersic_table(n), 1.0 - FT_DEFAULT), STEPK_MIN_HLR)
+        stepk_gal = np.pi / (r * hlr[sel] * max_scale[sel])
+        stepk = 1.0 / np.sqrt(1.0 / stepk_gal ** 2 + 1.0 / dg_stepk ** 2)
+        sizes[sel] = _good_size(stepk)
+    return np.minimum(sizes, nmax)
+
+
+def build_object_table(cat, phot_flux, noise_var=800.0, sed_table=0, max_flux_simple=100.0,
+                       winv=(1.0 / PIXEL_SCALE, 0.0, 0.0, 1.0 / PIXEL_SCALE), airmass=1.2, raw_seeing=0.7,
+                       band="r", image_bounds=None, dcr=(0.0, 0.0, 1.0), stamp_size=None):
+    """Vectorised LSST_SiliconBuilder.setup for a whole catalog -> OBJECT_DTYPE rows.
+
+    Objects with phot_flux == 0 are dropped (SkipThisObject, stamp.py:199-202)."""
+    n = len(cat["x"])
+    kind = cat["kind"]
+    nominal = cat["nominal_flux"]
+    keep = phot_flux > 0
+    obj = np.zeros(n, dtype=OBJECT_DTYPE)
+    obj["obj_id"] = cat["obj_id"]
+    obj["phot_first"] = 0
+    obj["n_phot"] = phot_flux
+    obj["x0"], obj["y0"] = cat["x"], cat["y"]
+    obj["flux_per_photon"] = 1.0
+    obj["prof_table"] = np.where(kind == 0, -1, kind - 1)
+    obj["prof_scale"] = np.where(kind == 0, 0.0, cat["hlr"])
+    beta = 90.0 - cat["pa"]                                     # flip_g2 convention, instcat.py:503-508
+    jac = shear_matrix(cat["q"], beta)
+    if "g1" in cat:
+        jac = _mat2(lens_matrix(cat["g1"], cat["g2"], cat["mu"]), jac)
+    jac[kind == 0] = (1.0, 0.0, 0.0, 1.0)
+    obj["jac"] = jac
+    obj["winv"] = np.broadcast_to(np.asarray(winv, dtype=np.float64), (n, 4))
+    obj["dcr_tanz"], obj["dcr_sinp"], obj["dcr_cosp"] = dcr
+    obj["sed_table"] = sed_table
+    obj["sed_wave"] = 0.0
+    obj["flags"] = np.where(nominal < max_flux_simple, IMS_OBJ_FAINT, 0)
+    obj["bf_state"] = 0
+    # stamp size: given -> 32 for tiny flux -> get_stamp_size (stamp.py:205-232)
+    if stamp_size is None:
+        size = np.zeros(n, dtype=np.int64)
+        star = kind == 0
+        if star.any():
+            size[star] = star_stamp_size(nominal[star], noise_var, airmass, raw_seeing, band)
+        gal = ~star
+        if gal.any():
+            # largest singular value of the profile affine scales the real-space extent
+            a, b, c, d = jac[gal, 0], jac[gal, 1], jac[gal, 2], jac[gal, 3]
+            s1 = a * a + b * b + c * c + d * d
+            s2 = np.sqrt(np.maximum((a * a + b * b - c * c - d * d) ** 2 + 4 * (a * c + b * d) ** 2, 0.0))
+            max_scale = np.sqrt(0.5 * (s1 + s2))
+            size[gal] = gal_stamp_size(kind[gal], cat["hlr"][gal], max_scale)
+        size[nominal < TINY_FLUX] = 32
+    else:
+        size = np.broadcast_to(np.asarray(stamp_size, dtype=np.int64), (n,)).copy()
+    # stamp bounds centred on the integer pixel nearest image_pos (GalSim locateStamp for even sizes)
+    icx = np.floor(cat["x"] + 0.5).astype(np.int64)
+    icy = np.floor(cat["y"] + 0.5).astype(np.int64)
+    obj["stamp_xmin"] = icx - size // 2
+    obj["stamp_xmax"] = icx - size // 2 + size - 1
+    obj["stamp_ymin"] = icy - size // 2
+    obj["stamp_ymax"] = icy - size // 2 + size - 1
+    return obj[keep], size[keep]

@@ -1,0 +1,212 @@
+// ims_math.h -- device statement of the numerics spec (DESIGN.md "Numerics spec") for gfx950.
+//
+// Philox4x32-10 and binary64 elementary functions written only with + - * / fma sqrt and integer
+// ops, evaluated in a fixed order, so every photon gets the same bits on any launch geometry and
+// on any GPU.  Build with -ffp-contract=off: the only fused operations are the explicit fma()s.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define IMS_DEV __device__ __forceinline__
+
+namespace ims {
+
+struct Draw { uint64_t a, b; };
+
+IMS_DEV void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]);
+        const uint32_t lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]);
+        const uint32_t lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0;
+        const uint32_t n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// draw addressed by (seed, object id, photon index, slot)
+IMS_DEV Draw draw(uint64_t seed, int64_t obj_id, int64_t photon, uint32_t slot)
+{
+    uint32_t c[4];
+    c[0] = (uint32_t)((uint64_t)photon);
+    c[1] = (uint32_t)((uint64_t)photon >> 32);
+    c[2] = slot;
+    c[3] = (uint32_t)((uint64_t)obj_id);
+    const uint32_t k0 = (uint32_t)seed;
+    const uint32_t k1 = (uint32_t)(seed >> 32) ^ (uint32_t)((uint64_t)obj_id >> 32);
+    philox4x32_10(c, k0, k1);
+    Draw d;
+    d.a = (((uint64_t)c[0] << 32) | c[1]) >> 11;
+    d.b = (((uint64_t)c[2] << 32) | c[3]) >> 11;
+    return d;
+}
+IMS_DEV double u01(uint64_t k) { return (double)k * 0x1.0p-53; }
+IMS_DEV double u01_open(uint64_t k) { return (double)(k + 1) * 0x1.0p-53; }
+
+constexpr double LN2_HI = 6.93147180369123816490e-01;
+constexpr double LN2_LO = 1.90821492927058770002e-10;
+constexpr double INV_LN2 = 1.44269504088896338700e+00;
+constexpr double TWO_PI = 6.283185307179586476925;
+constexpr double INV_TWO_PI = 0.15915494309189533577;
+constexpr double PI_2 = 1.57079632679489661923;
+constexpr double PI_4 = 0.78539816339744830962;
+
+IMS_DEV double dlog(double x)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(x);
+    int64_t e = (int64_t)((b >> 52) & 0x7FF) - 1023;
+    double m = __longlong_as_double((long long)((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull));
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double s = (m - 1.0) / (m + 1.0);
+    const double z = s * s;
+    double p = 1.0 / 25.0;
+    p = fma(p, z, 1.0 / 23.0);
+    p = fma(p, z, 1.0 / 21.0);
+    p = fma(p, z, 1.0 / 19.0);
+    p = fma(p, z, 1.0 / 17.0);
+    p = fma(p, z, 1.0 / 15.0);
+    p = fma(p, z, 1.0 / 13.0);
+    p = fma(p, z, 1.0 / 11.0);
+    p = fma(p, z, 1.0 / 9.0);
+    p = fma(p, z, 1.0 / 7.0);
+    p = fma(p, z, 1.0 / 5.0);
+    p = fma(p, z, 1.0 / 3.0);
+    p = fma(p, z, 1.0);
+    const double lm = 2.0 * s * p;
+    const double de = (double)e;
+    return fma(de, LN2_HI, fma(de, LN2_LO, lm));
+}
+
+IMS_DEV double dexp(double x)
+{
+    const double kf = floor(fma(x, INV_LN2, 0.5));
+    double r = fma(-kf, LN2_HI, x);
+    r = fma(-kf, LN2_LO, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    int64_t k = (int64_t)kf;
+    if (k < -1000) return 0.0;
+    if (k > 1000) k = 1000;
+    const double scale = __longlong_as_double((long long)((uint64_t)(k + 1023) << 52));
+    return p * scale;
+}
+
+IMS_DEV double sin_kernel(double t)
+{
+    const double z = t * t;
+    double p = 1.0 / 355687428096000.0;
+    p = fma(p, z, -1.0 / 1307674368000.0);
+    p = fma(p, z, 1.0 / 6227020800.0);
+    p = fma(p, z, -1.0 / 39916800.0);
+    p = fma(p, z, 1.0 / 362880.0);
+    p = fma(p, z, -1.0 / 5040.0);
+    p = fma(p, z, 1.0 / 120.0);
+    p = fma(p, z, -1.0 / 6.0);
+    return fma(t * z, p, t);
+}
+IMS_DEV double cos_kernel(double t)
+{
+    const double z = t * t;
+    double p = -1.0 / 6402373705728000.0;
+    p = fma(p, z, 1.0 / 20922789888000.0);
+    p = fma(p, z, -1.0 / 87178291200.0);
+    p = fma(p, z, 1.0 / 479001600.0);
+    p = fma(p, z, -1.0 / 3628800.0);
+    p = fma(p, z, 1.0 / 40320.0);
+    p = fma(p, z, -1.0 / 720.0);
+    p = fma(p, z, 1.0 / 24.0);
+    p = fma(p, z, -0.5);
+    return fma(z, p, 1.0);
+}
+// sin, cos of 2*pi*u, u in [0,1]: the quadrant reduction is exact in binary
+IMS_DEV void sincos2pi(double u, double& s, double& c)
+{
+    const double qf = floor(fma(4.0, u, 0.5));
+    const double r = fma(-0.25, qf, u);
+    const double t = r * TWO_PI;
+    const double sk = sin_kernel(t), ck = cos_kernel(t);
+    const int q = (int)qf & 3;
+    if (q == 0) { s = sk; c = ck; }
+    else if (q == 1) { s = ck; c = -sk; }
+    else if (q == 2) { s = -sk; c = -ck; }
+    else { s = -ck; c = sk; }
+}
+IMS_DEV void dsincos(double x, double& s, double& c)
+{
+    double u = x * INV_TWO_PI;
+    u = u - floor(u);
+    sincos2pi(u, s, c);
+}
+
+IMS_DEV double datan(double x)
+{
+    const double ax = x < 0.0 ? -x : x;
+    double base = 0.0, sign = 1.0, a = ax;
+    if (ax > 1.0) { a = 1.0 / ax; base = PI_2; sign = -1.0; }
+    double off = 0.0, b = a;
+    if (a > 0.41421356237309503) { b = (a - 1.0) / (a + 1.0); off = PI_4; }
+    const double cc = b / (1.0 + sqrt(fma(b, b, 1.0)));
+    const double z = cc * cc;
+    double p = 1.0 / 27.0;
+    p = fma(p, z, -1.0 / 25.0);
+    p = fma(p, z, 1.0 / 23.0);
+    p = fma(p, z, -1.0 / 21.0);
+    p = fma(p, z, 1.0 / 19.0);
+    p = fma(p, z, -1.0 / 17.0);
+    p = fma(p, z, 1.0 / 15.0);
+    p = fma(p, z, -1.0 / 13.0);
+    p = fma(p, z, 1.0 / 11.0);
+    p = fma(p, z, -1.0 / 9.0);
+    p = fma(p, z, 1.0 / 7.0);
+    p = fma(p, z, -1.0 / 5.0);
+    p = fma(p, z, 1.0 / 3.0);
+    p = fma(p, z, -1.0);
+    const double at = -(cc * p);
+    double res = fma(2.0, at, off);
+    res = fma(sign, res, base);
+    return x < 0.0 ? -res : res;
+}
+
+IMS_DEV double dtanh_pos(double x)
+{
+    if (x > 20.0) return 1.0;
+    const double e = dexp(-2.0 * x);
+    return (1.0 - e) / (1.0 + e);
+}
+IMS_DEV double dpow(double x, double y) { return dexp(y * dlog(x)); }
+
+IMS_DEV void gauss_pair(Draw d, double& g0, double& g1)
+{
+    const double u1 = u01_open(d.a);
+    const double u2 = u01(d.b);
+    const double r = sqrt(-2.0 * dlog(u1));
+    double s, c;
+    sincos2pi(u2, s, c);
+    g0 = r * c; g1 = r * s;
+}
+
+// RNG slots
+constexpr uint32_t SLOT_WAVE_PROF = 0;
+constexpr uint32_t SLOT_PROF_ANG = 1;
+constexpr uint32_t SLOT_PSF = 2;
+constexpr uint32_t SLOT_OP = 8;
+constexpr uint32_t SLOT_SENSOR_DIFF = 24;
+constexpr uint32_t SLOT_SENSOR_CONV = 25;
+
+}  // namespace ims

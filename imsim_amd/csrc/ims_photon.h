@@ -1,0 +1,584 @@
+// ims_photon.h -- per-photon device functions of the stamp-rendering hot path (gfx950).
+//
+// One photon lives in registers from profile sampling to the pixel it lands in; nothing in here
+// touches memory except read-only tables, the pixel-boundary state and the final atomics.
+// Reference behaviour restated (imSim tree): stamp.py:527-573 (phot branch), photon_ops.py
+// (RubinOptics/RubinDiffraction/RubinDiffractionOptics, XyToV, ray_vector_to_photon_array),
+// diffraction.py (spider kick), config/imsim-config.yaml:281-320 (op chain), and GalSim's
+// SiliconSensor as described in doc/validation/{brighter-fatter,diffusion,tree-ring}.rst.
+#pragma once
+#include "ims_math.h"
+#include "../../include/imsim_hip.h"
+
+namespace ims {
+
+struct Photon {
+    double x, y, flux, dxdz, dydz, wl, pu, pv, t;
+};
+
+// ---------------- tables ----------------
+IMS_DEV double lin_lookup(const ims_lin_tables_t& t, int table, double arg)
+{
+    const double* v = t.val + (int64_t)table * t.n_pts;
+    const double f = (arg - t.arg_min) / t.arg_step;
+    if (!(f > 0.0)) return v[0];
+    const int n = t.n_pts;
+    if (f >= (double)(n - 1)) return v[n - 1];
+    const int i = (int)f;
+    const double a = f - (double)i;
+    return v[i] + a * (v[i + 1] - v[i]);
+}
+
+IMS_DEV double radial_r2(const ims_radial_tables_t& t, int table, double u)
+{
+    const int nb = t.n_bins;
+    const double* cdf = t.cdf + (int64_t)table * (nb + 1);
+    const double* r2 = t.r2 + (int64_t)table * (nb + 1);
+    int lo = 0, hi = nb;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cdf[mid] <= u) lo = mid; else hi = mid;
+    }
+    const double c0 = cdf[lo];
+    const double w = cdf[lo + 1] - c0;
+    const double f = (w > 0.0) ? (u - c0) / w : 0.0;
+    const double a = r2[lo];
+    return a + f * (r2[lo + 1] - a);
+}
+
+// ---------------- shooting ----------------
+// photon k of object `o`: wavelength + profile sample, relative to image_pos, in pixels
+IMS_DEV void shoot(const ims_render_params_t& P, const ims_object_t& o, int64_t k, Photon& ph)
+{
+    const Draw d0 = draw(P.seed, o.obj_id, k, SLOT_WAVE_PROF);
+    double wl = o.sed_wave;
+    if (o.sed_table >= 0) wl = lin_lookup(P.sed, o.sed_table, u01(d0.a));
+    double pu = 0.0, pv = 0.0;
+    if (o.prof_table >= 0) {
+        const double r2 = radial_r2(P.radial, o.prof_table, u01(d0.b));
+        const double r = sqrt(r2) * o.prof_scale;
+        const Draw d1 = draw(P.seed, o.obj_id, k, SLOT_PROF_ANG);
+        double s, c;
+        sincos2pi(u01(d1.a), s, c);
+        const double gu = r * c, gv = r * s;
+        pu = o.jac[0] * gu + o.jac[1] * gv;
+        pv = o.jac[2] * gu + o.jac[3] * gv;
+    }
+    ph.x = o.winv[0] * pu + o.winv[1] * pv;
+    ph.y = o.winv[2] * pu + o.winv[3] * pv;
+    ph.flux = o.flux_per_photon;
+    ph.dxdz = 0.0; ph.dydz = 0.0;
+    ph.wl = wl;
+    ph.pu = 0.0; ph.pv = 0.0; ph.t = 0.0;
+}
+
+IMS_DEV void apply_psf(const ims_render_params_t& P, const ims_object_t& o, int comp, int64_t k, Photon& ph)
+{
+    const ims_psf_component_t& c = P.psf[comp];
+    const Draw d = draw(P.seed, o.obj_id, k, SLOT_PSF + (uint32_t)comp);
+    double scale = c.p0;
+    if (c.chrom_alpha != 0.0) scale = scale * dpow(ph.wl / c.chrom_base, c.chrom_alpha);
+    double ku, kv;
+    if (c.kind == IMS_PSF_GAUSSIAN) {
+        double g0, g1;
+        gauss_pair(d, g0, g1);
+        ku = scale * g0; kv = scale * g1;
+    } else {
+        const double r2 = radial_r2(P.radial, c.table, u01(d.a));
+        const double r = sqrt(r2) * scale;
+        double s, cc;
+        sincos2pi(u01(d.b), s, cc);
+        ku = r * cc; kv = r * s;
+    }
+    ph.x = ph.x + (o.winv[0] * ku + o.winv[1] * kv);
+    ph.y = ph.y + (o.winv[2] * ku + o.winv[3] * kv);
+}
+
+// ---------------- media / air ----------------
+IMS_DEV double air_n_minus_one(double wave_nm, double p_kpa, double t_k, double h2o_kpa)
+{
+    const double Pm = p_kpa * 7.50061683;
+    const double T = t_k - 273.15;
+    const double W = h2o_kpa * 7.50061683;
+    const double wm = wave_nm * 1.0e-3;
+    const double sig2 = 1.0 / (wm * wm);
+    double n1 = (64.328 + 29498.1 / (146.0 - sig2) + 255.4 / (41.0 - sig2)) * 1.0e-6;
+    n1 = n1 * (Pm * (1.0 + (1.049 - 0.0157 * T) * 1.0e-6 * Pm) / (720.883 * (1.0 + 0.003661 * T)));
+    n1 = n1 - (0.0624 - 0.000680 * sig2) / (1.0 + 0.003661 * T) * W * 1.0e-6;
+    return n1;
+}
+IMS_DEV double refraction_r0(double nm1) { return nm1 * (nm1 + 2.0) / 2.0 / (nm1 * nm1 + 2.0 * nm1 + 1.0); }
+
+IMS_DEV double medium_n(int kind, const double* c, double wave_nm)
+{
+    if (kind == IMS_MEDIUM_CONST) return c[0];
+    if (kind == IMS_MEDIUM_SELLMEIER) {
+        const double l = wave_nm * 1.0e-3;
+        const double l2 = l * l;
+        const double n2 = 1.0 + c[0] * l2 / (l2 - c[3]) + c[1] * l2 / (l2 - c[4]) + c[2] * l2 / (l2 - c[5]);
+        return sqrt(n2);
+    }
+    return 1.0 + air_n_minus_one(wave_nm, c[0], c[1], c[2]);
+}
+
+// ---------------- TAN-SIP, trig-free ----------------
+IMS_DEV void sip_eval(const ims_tansip_t& w, double u, double v, double& F, double& G,
+                      double& Fu, double& Fv, double& Gu, double& Gv)
+{
+    double up[5], vp[5];
+    up[0] = 1.0; vp[0] = 1.0;
+#pragma unroll
+    for (int k = 1; k <= 4; ++k) { up[k] = up[k - 1] * u; vp[k] = vp[k - 1] * v; }
+    F = 0.0; G = 0.0; Fu = 0.0; Fv = 0.0; Gu = 0.0; Gv = 0.0;
+#pragma unroll
+    for (int p = 0; p <= 4; ++p)
+#pragma unroll
+        for (int q = 0; q <= 4; ++q) {
+            if (p + q > w.order) continue;
+            const double a = w.a[p * 5 + q], b = w.b[p * 5 + q];
+            if (a == 0.0 && b == 0.0) continue;
+            const double m = up[p] * vp[q];
+            F = F + a * m; G = G + b * m;
+            if (p > 0) { const double d = (double)p * up[p - 1] * vp[q]; Fu = Fu + a * d; Gu = Gu + b * d; }
+            if (q > 0) { const double d = (double)q * up[p] * vp[q - 1]; Fv = Fv + a * d; Gv = Gv + b * d; }
+        }
+}
+
+IMS_DEV void wcs_pix_to_vec(const ims_tansip_t& w, double x, double y, double (&p)[3])
+{
+    double u = x - w.crpix[0], v = y - w.crpix[1];
+    if (w.order > 0) {
+        double f, g, fu, fv, gu, gv;
+        sip_eval(w, u, v, f, g, fu, fv, gu, gv);
+        u = u + f; v = v + g;
+    }
+    const double xi = w.cd[0] * u + w.cd[1] * v;
+    const double eta = w.cd[2] * u + w.cd[3] * v;
+    const double inv = 1.0 / sqrt(1.0 + xi * xi + eta * eta);
+    const double t0 = inv, t1 = xi * inv, t2 = eta * inv;
+    p[0] = w.rot[0] * t0 + w.rot[3] * t1 + w.rot[6] * t2;
+    p[1] = w.rot[1] * t0 + w.rot[4] * t1 + w.rot[7] * t2;
+    p[2] = w.rot[2] * t0 + w.rot[5] * t1 + w.rot[8] * t2;
+}
+
+IMS_DEV void wcs_vec_to_pix(const ims_tansip_t& w, const double (&p)[3], double& x, double& y)
+{
+    const double t0 = w.rot[0] * p[0] + w.rot[1] * p[1] + w.rot[2] * p[2];
+    const double t1 = w.rot[3] * p[0] + w.rot[4] * p[1] + w.rot[5] * p[2];
+    const double t2 = w.rot[6] * p[0] + w.rot[7] * p[1] + w.rot[8] * p[2];
+    const double xi = t1 / t0, eta = t2 / t0;
+    const double U = w.cdinv[0] * xi + w.cdinv[1] * eta;
+    const double V = w.cdinv[2] * xi + w.cdinv[3] * eta;
+    double u = U, v = V;
+    if (w.order > 0) {
+        for (int it = 0; it < 6; ++it) {
+            double f, g, fu, fv, gu, gv;
+            sip_eval(w, u, v, f, g, fu, fv, gu, gv);
+            const double r0 = u + f - U, r1 = v + g - V;
+            const double j00 = 1.0 + fu, j01 = fv, j10 = gu, j11 = 1.0 + gv;
+            const double det = j00 * j11 - j01 * j10;
+            u = u - (j11 * r0 - j01 * r1) / det;
+            v = v - (j00 * r1 - j10 * r0) / det;
+        }
+    }
+    x = u + w.crpix[0]; y = v + w.crpix[1];
+}
+
+IMS_DEV void xy_to_v(const ims_optics_t& o, double x, double y, double wave_nm, double (&v)[3])
+{
+    double p[3], thx, thy;
+    wcs_pix_to_vec(o.img_wcs, x, y, p);
+    wcs_vec_to_pix(o.icrf_to_field, p, thx, thy);
+    const double gamma = 1.0 / sqrt(1.0 + thx * thx + thy * thy);
+    const double n = medium_n(o.in_medium_kind, o.in_medium_c, wave_nm);
+    v[0] = thx * gamma / n; v[1] = thy * gamma / n; v[2] = -gamma / n;
+}
+IMS_DEV void v_to_xy(const ims_optics_t& o, const double (&v)[3], double& x, double& y)
+{
+    const double thx = -v[0] / v[2], thy = -v[1] / v[2];
+    double p[3];
+    wcs_pix_to_vec(o.icrf_to_field, thx, thy, p);
+    wcs_vec_to_pix(o.img_wcs, p, x, y);
+}
+
+// ---------------- spider diffraction ----------------
+IMS_DEV void field_rotation(const ims_optics_t& o, double t, double& c, double& s)
+{
+    double sn, cs;
+    dsincos(o.omega * t, sn, cs);
+    const double ez0 = o.cos_lat * cs, ez1 = o.cos_lat * sn, ez2 = o.sin_lat;
+    const double* ef = o.e_focal;
+    const double eh0_ = ef[1] * ez2 - ef[2] * ez1, eh1_ = ef[2] * ez0 - ef[0] * ez2, eh2_ = ef[0] * ez1 - ef[1] * ez0;
+    const double* z0 = o.e_z0;
+    const double g0 = ef[1] * z0[2] - ef[2] * z0[1], g1 = ef[2] * z0[0] - ef[0] * z0[2], g2 = ef[0] * z0[1] - ef[1] * z0[0];
+    const double nrm = sqrt(eh0_ * eh0_ + eh1_ * eh1_ + eh2_ * eh2_) * sqrt(g0 * g0 + g1 * g1 + g2 * g2);
+    c = (eh0_ * g0 + eh1_ * g1 + eh2_ * g2) / nrm;
+    s = (ez0 * g0 + ez1 * g1 + ez2 * g2) / nrm;
+}
+
+IMS_DEV void directed_dist(const ims_optics_t& o, double px, double py, double& dist, double& nx, double& ny)
+{
+    double dl = 0.0; int il = -1;
+    for (int l = 0; l < o.n_lines; ++l) {
+        const double* L = o.lines[l];
+        const double d = fabs(fabs(L[0] * px + L[1] * py - L[2]) - L[3]);
+        if (il < 0 || d < dl) { dl = d; il = l; }
+    }
+    double dc = 0.0; int ic = -1;
+    for (int c = 0; c < o.n_circles; ++c) {
+        const double* C = o.circles[c];
+        const double ex = px - C[0], ey = py - C[1];
+        const double d = fabs(sqrt(ex * ex + ey * ey) - C[2]);
+        if (ic < 0 || d < dc) { dc = d; ic = c; }
+    }
+    if (il >= 0 && (ic < 0 || dl < dc)) {
+        dist = dl; nx = o.lines[il][0]; ny = o.lines[il][1];
+    } else {
+        const double ex = o.circles[ic][0] - px, ey = o.circles[ic][1] - py;
+        const double nr = sqrt(ex * ex + ey * ey);
+        dist = dc; nx = ex / nr; ny = ey / nr;
+    }
+}
+
+IMS_DEV void diffract(const ims_optics_t& o, bool field_rot, double pu, double pv, double t,
+                      double wavelength_m, double gauss, double (&v)[3])
+{
+    double c = 1.0, s = 0.0;
+    if (field_rot) field_rotation(o, t, c, s);
+    const double qx = c * pu - s * pv;
+    const double qy = s * pu + c * pv;
+    double d, nx, ny;
+    directed_dist(o, qx, qy, d, nx, ny);
+    const double k = TWO_PI / wavelength_m;
+    const double dtp = gauss * datan(1.0 / (2.0 * k * d));
+    const double vz = -v[2];
+    const double sx = dtp * vz * nx, sy = dtp * vz * ny;
+    const double rx = c * sx + s * sy;
+    const double ry = -s * sx + c * sy;
+    const double before = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    v[0] = v[0] + rx; v[1] = v[1] + ry;
+    const double after = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const double fs = before / after;
+    v[0] = v[0] * fs; v[1] = v[1] * fs; v[2] = v[2] * fs;
+}
+
+// ---------------- sequential ray trace ----------------
+IMS_DEV void surf_sag(const ims_surface_t& S, double r2, double& sag, double& dsag, bool& ok)
+{
+    double z = 0.0, dz = 0.0;
+    ok = true;
+    if (S.R != 0.0) {
+        const double c = 1.0 / S.R;
+        double arg = 1.0 - (1.0 + S.conic) * c * c * r2;
+        if (arg < 0.0) { ok = false; arg = 0.0; }
+        const double sq = sqrt(arg);
+        z = c * r2 / (1.0 + sq);
+        dz = (sq > 0.0) ? c / (2.0 * sq) : 0.0;
+    }
+    double rp = r2;
+    for (int k = 0; k < S.n_asphere; ++k) {
+        const double m = (double)(k + 2);
+        dz = dz + S.asph[k] * m * rp;
+        rp = rp * r2;
+        z = z + S.asph[k] * rp;
+    }
+    sag = z; dsag = dz;
+}
+
+IMS_DEV bool obscured(const ims_surface_t& S, double x, double y)
+{
+    if (S.obsc_kind == IMS_OBSC_NONE) return false;
+    const double r = sqrt(x * x + y * y);
+    switch (S.obsc_kind) {
+    case IMS_OBSC_CLEAR_ANNULUS: return !(r >= S.obsc_inner && r <= S.obsc_outer);
+    case IMS_OBSC_CLEAR_CIRCLE:  return !(r <= S.obsc_outer);
+    case IMS_OBSC_OBSC_CIRCLE:   return r < S.obsc_outer;
+    case IMS_OBSC_OBSC_ANNULUS:  return (r >= S.obsc_inner && r < S.obsc_outer);
+    }
+    return false;
+}
+
+// returns 0 ok, 1 vignetted, 2 failed
+IMS_DEV int trace(const ims_optics_t& o, double (&pos)[3], double (&vel)[3], double wave_nm)
+{
+    int vignetted = 0;
+    double n_cur = medium_n(o.in_medium_kind, o.in_medium_c, wave_nm);
+    for (int k = 0; k < o.n_surfaces; ++k) {
+        const ims_surface_t& S = o.surf[k];
+        double t = (S.z0 - pos[2]) / vel[2];
+        double x = 0.0, y = 0.0, sag = 0.0, ds = 0.0;
+        bool ok = true;
+        const int niter = (S.R == 0.0 && S.n_asphere == 0) ? 1 : 6;
+        for (int it = 0; it < niter; ++it) {
+            x = pos[0] + vel[0] * t; y = pos[1] + vel[1] * t;
+            const double z = pos[2] + vel[2] * t;
+            surf_sag(S, x * x + y * y, sag, ds, ok);
+            if (!ok) return 2;
+            const double f = z - S.z0 - sag;
+            const double fp = vel[2] - 2.0 * ds * (x * vel[0] + y * vel[1]);
+            t = t - f / fp;
+        }
+        x = pos[0] + vel[0] * t; y = pos[1] + vel[1] * t;
+        surf_sag(S, x * x + y * y, sag, ds, ok);
+        if (!ok) return 2;
+        pos[0] = x; pos[1] = y; pos[2] = S.z0 + sag;
+        if (obscured(S, x, y)) vignetted = 1;
+        if (S.kind == IMS_SURF_BAFFLE || S.kind == IMS_SURF_DETECTOR) continue;
+        double nx = -2.0 * ds * x, ny = -2.0 * ds * y, nz = 1.0;
+        const double ninv = 1.0 / sqrt(nx * nx + ny * ny + 1.0);
+        nx = nx * ninv; ny = ny * ninv; nz = nz * ninv;
+        if (S.kind == IMS_SURF_MIRROR) {
+            const double d = vel[0] * nx + vel[1] * ny + vel[2] * nz;
+            vel[0] = vel[0] - 2.0 * d * nx; vel[1] = vel[1] - 2.0 * d * ny; vel[2] = vel[2] - 2.0 * d * nz;
+        } else {
+            const double n2 = medium_n(S.medium_kind, S.medium_c, wave_nm);
+            const double dx = vel[0] * n_cur, dy = vel[1] * n_cur, dzz = vel[2] * n_cur;
+            double alpha = dx * nx + dy * ny + dzz * nz;
+            if (alpha > 0.0) { nx = -nx; ny = -ny; nz = -nz; alpha = -alpha; }
+            const double eta = n_cur / n2;
+            const double sinsqr = eta * eta * (1.0 - alpha * alpha);
+            if (sinsqr > 1.0) return 2;
+            const double nfac = eta * alpha + sqrt(1.0 - sinsqr);
+            vel[0] = (eta * dx - nfac * nx) / n2;
+            vel[1] = (eta * dy - nfac * ny) / n2;
+            vel[2] = (eta * dzz - nfac * nz) / n2;
+            n_cur = n2;
+        }
+    }
+    return vignetted;
+}
+
+IMS_DEV void rubin_op(const ims_render_params_t& P, const ims_op_t& op, int op_index,
+                      const ims_object_t& o, int64_t k, Photon& ph)
+{
+    const ims_optics_t& opt = *P.optics;
+    const bool do_diff = (op.kind != IMS_OP_RUBIN_OPTICS);
+    const bool do_trace = (op.kind != IMS_OP_RUBIN_DIFFRACTION);
+    const bool frot = !(op.p[1] != 0.0);
+    double v[3];
+    xy_to_v(opt, ph.x, ph.y, ph.wl, v);
+    if (do_diff) {
+        double g0, g1;
+        gauss_pair(draw(P.seed, o.obj_id, k, SLOT_OP + (uint32_t)op_index), g0, g1);
+        diffract(opt, frot, ph.pu, ph.pv, ph.t, ph.wl * 1.0e-9, g0, v);
+    }
+    if (!do_trace) { v_to_xy(opt, v, ph.x, ph.y); return; }
+    double pos[3] = { ph.pu, ph.pv, opt.stop_z };
+    const int st = trace(opt, pos, v, ph.wl);
+    if (st == 2) { ph.x = 0.0; ph.y = 0.0; ph.dxdz = 0.0; ph.dydz = 0.0; ph.flux = 0.0; return; }
+    const double c = opt.cam_rot[0], s = opt.cam_rot[1];
+    const double rx = c * pos[0] + s * pos[1], ry = -s * pos[0] + c * pos[1];
+    const double rvx = c * v[0] + s * v[1], rvy = -s * v[0] + c * v[1];
+    const double fpx = ry * 1.0e3, fpy = rx * 1.0e3;
+    ph.x = opt.fp_to_pix[0] * fpx + opt.fp_to_pix[1] * fpy + opt.fp_to_pix[2];
+    ph.y = opt.fp_to_pix[3] * fpx + opt.fp_to_pix[4] * fpy + opt.fp_to_pix[5];
+    ph.dxdz = (opt.slope_jac[0] * rvx + opt.slope_jac[1] * rvy) / v[2];
+    ph.dydz = (opt.slope_jac[2] * rvx + opt.slope_jac[3] * rvy) / v[2];
+    if (st == 1) ph.flux = 0.0;
+}
+
+// one configured photon operator (config/imsim-config.yaml:281-320)
+IMS_DEV void apply_op(const ims_render_params_t& P, int op_index, const ims_object_t& o, int64_t k, Photon& ph)
+{
+    const ims_op_t& op = P.ops[op_index];
+    const uint32_t slot = SLOT_OP + (uint32_t)op_index;
+    if (op.kind == IMS_OP_BANDPASS_RATIO) {
+        ph.flux = ph.flux * lin_lookup(P.ratio, op.table, ph.wl);
+        return;
+    }
+    if (o.flags & IMS_OBJ_FAINT) return;
+    switch (op.kind) {
+    case IMS_OP_TIME_SAMPLER: {
+        const Draw d = draw(P.seed, o.obj_id, k, slot);
+        ph.t = op.p[0] + u01(d.a) * op.p[1];
+        break; }
+    case IMS_OP_PUPIL_ANNULUS_SAMPLER: {
+        const double ro2 = op.p[0] * op.p[0], ri2 = op.p[1] * op.p[1];
+        const Draw d = draw(P.seed, o.obj_id, k, slot);
+        const double r = sqrt(ri2 + u01(d.a) * (ro2 - ri2));
+        double s, c;
+        sincos2pi(u01(d.b), s, c);
+        ph.pu = r * c; ph.pv = r * s;
+        break; }
+    case IMS_OP_PHOTON_DCR: {
+        const double base_r0 = refraction_r0(air_n_minus_one(op.p[0], op.p[1], op.p[2], op.p[3]));
+        const double r0 = refraction_r0(air_n_minus_one(ph.wl, op.p[1], op.p[2], op.p[3]));
+        const double shift = (r0 - base_r0) * o.dcr_tanz * op.p[4];
+        const double du = -shift * o.dcr_sinp;
+        const double dv = shift * o.dcr_cosp;
+        ph.x = ph.x + (o.winv[0] * du + o.winv[1] * dv);
+        ph.y = ph.y + (o.winv[2] * du + o.winv[3] * dv);
+        break; }
+    case IMS_OP_FOCUS_DEPTH:
+        ph.x = ph.x + ph.dxdz * op.p[0];
+        ph.y = ph.y + ph.dydz * op.p[0];
+        break;
+    case IMS_OP_REFRACTION: {
+        const double nn = op.p[0] * op.p[0];
+        const double a = ph.dxdz, b = ph.dydz;
+        const double rho2 = a * a + b * b;
+        const double f = 1.0 / sqrt(nn + (nn - 1.0) * rho2);
+        ph.dxdz = a * f; ph.dydz = b * f;
+        break; }
+    case IMS_OP_RUBIN_OPTICS:
+    case IMS_OP_RUBIN_DIFFRACTION:
+    case IMS_OP_RUBIN_DIFFRACTION_OPTICS:
+        rubin_op(P, op, op_index, o, k, ph);
+        break;
+    default: break;
+    }
+}
+
+// ---------------- Silicon sensor ----------------
+struct SlotView {
+    int xmin, ymin, nx, ny;
+    int64_t offset;
+};
+IMS_DEV int64_t cell_index(const SlotView& sl, int i, int j) { return sl.offset + (int64_t)j * (sl.nx + 1) + i; }
+
+// vertex k (0..nv-1) of pixel (i,j), counter-clockwise from the lower-left corner
+IMS_DEV void polygon_vertex(const ims_sensor_t& s, const SlotView& sl, int i, int j, int k, double zfactor,
+                            double& vx, double& vy)
+{
+    const int nV = s.num_vertices, npo = 2 * nV + 1;
+    int ci = i, cj = j, q;
+    double ax = 0.0, ay = 0.0;
+    if (k <= nV) { q = k; }                                                   // LL corner, bottom points
+    else if (k <= 2 * nV + 1) { ci = i + 1; ax = 1.0; q = (k == nV + 1) ? 0 : nV + 1 + (k - nV - 2); }   // LR corner, right edge
+    else if (k == 2 * nV + 2) { ci = i + 1; cj = j + 1; ax = 1.0; ay = 1.0; q = 0; }                     // UR corner
+    else if (k <= 3 * nV + 2) { cj = j + 1; ay = 1.0; q = 1 + (nV - 1 - (k - 2 * nV - 3)); }             // top edge, right->left
+    else if (k == 3 * nV + 3) { cj = j + 1; ay = 1.0; q = 0; }                                           // UL corner
+    else { q = nV + 1 + (nV - 1 - (k - 3 * nV - 4)); }                                                   // left edge, top->bottom
+    const double* pt = s.bf_boundary + (cell_index(sl, ci, cj) * npo + q) * 2;
+    vx = pt[0] + ax; vy = pt[1] + ay;
+    if (zfactor != 1.0) {
+        const double ex = s.emptypoly[2 * k], ey = s.emptypoly[2 * k + 1];
+        vx = ex + (vx - ex) * zfactor;
+        vy = ey + (vy - ey) * zfactor;
+    }
+}
+
+IMS_DEV bool inside_pixel(const ims_sensor_t& s, const SlotView& sl, int ix, int iy, double x, double y,
+                          double zconv, bool want_edge, bool& off_edge)
+{
+    const int i = ix - sl.xmin, j = iy - sl.ymin;
+    if (i < 0 || i >= sl.nx || j < 0 || j >= sl.ny) {
+        if (want_edge) off_edge = true;
+        return false;
+    }
+    const double* b = s.bf_bounds + cell_index(sl, i, j) * 8;
+    const double b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+    bool inside;
+    if (x > b0 && x < b1 && y > b2 && y < b3) inside = true;
+    else if (!(x >= b[4] && x <= b[5] && y >= b[6] && y <= b[7])) inside = false;
+    else {
+        const double zfactor = dtanh_pos(zconv / 12.0);
+        const int nv = 4 * s.num_vertices + 4;
+        double lx, ly;
+        polygon_vertex(s, sl, i, j, nv - 1, zfactor, lx, ly);
+        inside = false;
+        for (int k = 0; k < nv; ++k) {
+            double kx, ky;
+            polygon_vertex(s, sl, i, j, k, zfactor, kx, ky);
+            if ((ky > y) != (ly > y)) {
+                const double xc = (lx - kx) * (y - ky) / (ly - ky) + kx;
+                if (x < xc) inside = !inside;
+            }
+            lx = kx; ly = ky;
+        }
+    }
+    if (!inside && want_edge) {
+        off_edge = false;
+        if (i == 0 && x < b0) off_edge = true;
+        if (i == sl.nx - 1 && x > b1) off_edge = true;
+        if (j == 0 && y < b2) off_edge = true;
+        if (j == sl.ny - 1 && y > b3) off_edge = true;
+    }
+    return inside;
+}
+
+__device__ const int XOFF[9] = {0, 1, 1, 0, -1, -1, -1, 0, 1};
+__device__ const int YOFF[9] = {0, 0, 1, 1, 1, 0, -1, -1, -1};
+
+// Decide the landing pixel.  Returns false when the photon is lost.  has_angles: the chain
+// contains a ray-tracing op, so dxdz/dydz are meaningful.
+IMS_DEV bool land(const ims_render_params_t& P, const ims_object_t& o, int64_t k, const Photon& ph,
+                  bool silicon, bool has_angles, int& ix, int& iy)
+{
+    double x0 = ph.x, y0 = ph.y;
+    if (!silicon || (o.flags & IMS_OBJ_FAINT)) {
+        ix = (int)floor(x0 + 0.5); iy = (int)floor(y0 + 0.5);
+        return !(ix < o.stamp_xmin || ix > o.stamp_xmax || iy < o.stamp_ymin || iy > o.stamp_ymax);
+    }
+    const ims_sensor_t& s = *P.sensor;
+    const ims_bf_slot_t bs = s.bf_slots[o.bf_state];
+    const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
+    const Draw dc = draw(P.seed, o.obj_id, k, SLOT_SENSOR_CONV);
+    double g0, g1;
+    gauss_pair(draw(P.seed, o.obj_id, k, SLOT_SENSOR_DIFF), g0, g1);
+    const double f = (ph.wl - s.abs_wl_min) / s.abs_wl_step;
+    double abs_len;
+    if (!(f > 0.0)) abs_len = s.abs_len[0];
+    else if (f >= (double)(s.n_abs - 1)) abs_len = s.abs_len[s.n_abs - 1];
+    else { const int t = (int)f; const double a = f - (double)t; const double v0 = s.abs_len[t]; abs_len = v0 + a * (s.abs_len[t + 1] - v0); }
+    const double si_length = -abs_len * dlog(1.0 - u01(dc.a));
+    double dz = si_length;
+    if (has_angles) {
+        dz = si_length / sqrt(1.0 + ph.dxdz * ph.dxdz + ph.dydz * ph.dydz);
+        if (dz > s.thickness - 1.0) dz = s.thickness - 1.0;
+        const double dzp = dz / s.pixel_size;
+        x0 = x0 + ph.dxdz * dzp;
+        y0 = y0 + ph.dydz * dzp;
+    }
+    const double zconv = s.thickness - dz;
+    if (zconv < 0.0) return false;
+    if (s.diff_step != 0.0) {
+        double ds = s.diff_step / (s.thickness * s.pixel_size) * sqrt(zconv * s.thickness);
+        if (ds < 0.0) ds = 0.0;
+        x0 = x0 + ds * g0;
+        y0 = y0 + ds * g1;
+    }
+    ix = (int)floor(x0 + 0.5); iy = (int)floor(y0 + 0.5);
+    if (ix < o.stamp_xmin || ix > o.stamp_xmax || iy < o.stamp_ymin || iy > o.stamp_ymax) return false;
+    const double x = x0 - (double)ix + 0.5, y = y0 - (double)iy + 0.5;
+    bool off_edge = false;
+    bool found = inside_pixel(s, sl, ix, iy, x, y, zconv, true, off_edge);
+    if (!found && off_edge) return false;
+    int step = 0;
+    if (!found) {
+        if ((x > y) && (x > 1.0 - y)) step = 1;
+        else if ((x > y) && (x < 1.0 - y)) step = 7;
+        else if ((x < y) && (x > 1.0 - y)) step = 3;
+        else step = 5;
+        int n = step;
+        for (int m = 1; m < 9; ++m) {
+            const int jx = ix + XOFF[n], jy = iy + YOFF[n];
+            bool dummy;
+            if (inside_pixel(s, sl, jx, jy, x - (double)XOFF[n], y - (double)YOFF[n], zconv, false, dummy)) {
+                ix = jx; iy = jy; found = true; break;
+            }
+            n = ((n - 1) + step) % 8 + 1;
+        }
+    }
+    if (!found) {
+        const int n = (u01(dc.b) > 0.5) ? 0 : step;
+        ix = ix + XOFF[n]; iy = iy + YOFF[n];
+    }
+    if (ix < o.stamp_xmin || ix > o.stamp_xmax || iy < o.stamp_ymin || iy > o.stamp_ymax) return false;
+    if (o.bf_state > 0 || P.track_static_delta) {
+        const int di = ix - sl.xmin, dj = iy - sl.ymin;
+        if (di >= 0 && di < sl.nx && dj >= 0 && dj < sl.ny)
+            unsafeAtomicAdd(s.bf_delta + cell_index(sl, di, dj), (float)ph.flux);
+    }
+    return true;
+}
+
+IMS_DEV bool chain_has_angles(const ims_render_params_t& P)
+{
+    bool r = false;
+    for (int k = 0; k < P.n_ops; ++k)
+        if (P.ops[k].kind == IMS_OP_RUBIN_OPTICS || P.ops[k].kind == IMS_OP_RUBIN_DIFFRACTION_OPTICS) r = true;
+    return r;
+}
+
+}  // namespace ims

@@ -1,0 +1,561 @@
+// imsim_hip.hip -- kernels and C-ABI entry points of libimsim_hip.so (gfx950 / MI355X only).
+//
+// Launch geometry: one 256-thread workgroup (4 wavefronts of 64) per *segment* = up to seg_size
+// photons of ONE object, so the object row, its stamp and its tables are wave-uniform (scalar
+// loads) and the per-object flux reduction is a wavefront shuffle + one atomic per wave.
+// Segments are dealt to the 8 XCDs in contiguous ranges (block b runs on XCD b%8 on this part),
+// so that objects that are neighbours in the (spatially sorted) table share an XCD's L2 for the
+// pixel-boundary state and the image lines they touch.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include "ims_photon.h"
+
+using namespace ims;
+
+static thread_local char g_err[512] = "";
+static int set_err(int code, const char* msg)
+{
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+static int hip_err(hipError_t e, const char* what)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return IMS_ERR_HIP;
+}
+#define HIP_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_err(e_, #call); } while (0)
+
+static bool g_timing = false;
+static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+static bool g_ev_valid = false;
+
+struct LaunchTimer {
+    hipStream_t st;
+    explicit LaunchTimer(hipStream_t s) : st(s)
+    {
+        if (g_timing) {
+            if (!g_ev0) { (void)hipEventCreate(&g_ev0); (void)hipEventCreate(&g_ev1); }
+            (void)hipEventRecord(g_ev0, st);
+        }
+    }
+    ~LaunchTimer() { if (g_timing) { (void)hipEventRecord(g_ev1, st); g_ev_valid = true; } }
+};
+
+// ---------------- segment -> (object, first photon) ----------------
+constexpr int N_XCD = 8;
+
+__device__ __forceinline__ int64_t xcd_segment(int64_t b, int64_t n_segments)
+{
+    // block b runs on XCD (b % 8): give each XCD one contiguous range of segments
+    const int64_t per = (n_segments + N_XCD - 1) / N_XCD;
+    return (b % N_XCD) * per + (b / N_XCD);
+}
+
+__device__ __forceinline__ int64_t find_object(const int64_t* __restrict__ prefix, int64_t n_objects, int64_t seg)
+{
+    int64_t lo = 0, hi = n_objects;
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (prefix[mid] <= seg) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// run one photon through shoot -> psf -> shift -> ops
+__device__ __forceinline__ void make_photon(const ims_render_params_t& P, const ims_object_t& o, int64_t k, Photon& ph)
+{
+    shoot(P, o, k, ph);
+    for (int c = 0; c < P.n_psf; ++c) apply_psf(P, o, c, k, ph);
+    ph.x = o.x0 + ph.x;
+    ph.y = o.y0 + ph.y;
+}
+
+// ---------------- fused kernel: LSST_Silicon draw (phot) + stamp->CCD add ----------------
+__global__ __launch_bounds__(256) void k_shoot_accumulate(const ims_render_params_t P)
+{
+    const int64_t per = (P.n_segments + N_XCD - 1) / N_XCD;
+    const int64_t b = blockIdx.x;
+    if ((b / N_XCD) >= per) return;
+    const int64_t seg = xcd_segment(b, P.n_segments);
+    if (seg >= P.n_segments) return;
+    const int64_t oi = find_object(P.seg_prefix, P.n_objects, seg);
+    const ims_object_t& o = P.objects[oi];
+    const int64_t seg_in_obj = seg - P.seg_prefix[oi];
+    const int64_t j0 = seg_in_obj * P.seg_size;
+    int64_t j1 = j0 + P.seg_size;
+    if (j1 > o.n_phot) j1 = o.n_phot;
+    const bool silicon = (P.sensor != nullptr) && (P.sensor->kind == IMS_SENSOR_SILICON);
+    const bool has_angles = chain_has_angles(P);
+    double added = 0.0;
+    for (int64_t j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+        const int64_t k = o.phot_first + j;
+        Photon ph;
+        make_photon(P, o, k, ph);
+        for (int q = 0; q < P.n_ops; ++q) apply_op(P, q, o, k, ph);
+        if (ph.flux == 0.0) continue;
+        int ix, iy;
+        if (!land(P, o, k, ph, silicon, has_angles, ix, iy)) continue;
+        added += ph.flux;
+        const int px = ix - P.xmin, py = iy - P.ymin;
+        if (px < 0 || px >= P.nx || py < 0 || py >= P.ny) continue;
+        unsafeAtomicAdd(P.image + ((int64_t)py * P.nx + px), (float)ph.flux);
+    }
+    if (P.realized_flux != nullptr) {
+        const double tot = wave_sum(added);
+        if ((threadIdx.x & 63) == 0 && tot != 0.0) unsafeAtomicAdd(P.realized_flux + oi, tot);
+    }
+}
+
+// ---------------- pooled path ----------------
+// LSST_PhotonsBuilder.draw for all objects of a sub-batch, written straight into the merged pool
+__global__ __launch_bounds__(256) void k_shoot_photons(const ims_render_params_t P, const int64_t* __restrict__ photon_offset,
+                                                       const ims_photons_t pool)
+{
+    const int64_t per = (P.n_segments + N_XCD - 1) / N_XCD;
+    const int64_t b = blockIdx.x;
+    if ((b / N_XCD) >= per) return;
+    const int64_t seg = xcd_segment(b, P.n_segments);
+    if (seg >= P.n_segments) return;
+    const int64_t oi = find_object(P.seg_prefix, P.n_objects, seg);
+    const ims_object_t& o = P.objects[oi];
+    const int64_t j0 = (seg - P.seg_prefix[oi]) * P.seg_size;
+    int64_t j1 = j0 + P.seg_size;
+    if (j1 > o.n_phot) j1 = o.n_phot;
+    const int64_t base = photon_offset[oi];
+    for (int64_t j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+        Photon ph;
+        make_photon(P, o, o.phot_first + j, ph);
+        const int64_t i = base + j;
+        pool.x[i] = ph.x; pool.y[i] = ph.y; pool.flux[i] = ph.flux;
+        pool.dxdz[i] = ph.dxdz; pool.dydz[i] = ph.dydz; pool.wavelength[i] = ph.wl;
+        pool.pupil_u[i] = ph.pu; pool.pupil_v[i] = ph.pv; pool.time[i] = ph.t;
+        pool.obj_index[i] = (int32_t)oi;
+    }
+}
+
+__device__ __forceinline__ void load_photon(const ims_photons_t& pool, int64_t i, Photon& ph)
+{
+    ph.x = pool.x[i]; ph.y = pool.y[i]; ph.flux = pool.flux[i]; ph.dxdz = pool.dxdz[i]; ph.dydz = pool.dydz[i];
+    ph.wl = pool.wavelength[i]; ph.pu = pool.pupil_u[i]; ph.pv = pool.pupil_v[i]; ph.t = pool.time[i];
+}
+
+// `for op in photon_ops: op.applyTo(photons, ...)` (photon_pooling.py:154-155): one pass, all ops
+__global__ __launch_bounds__(256) void k_apply_ops(const ims_render_params_t P, const int64_t* __restrict__ photon_offset,
+                                                   const ims_photons_t pool)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pool.n; i += stride) {
+        const int32_t oi = pool.obj_index[i];
+        const ims_object_t& o = P.objects[oi];
+        const int64_t k = o.phot_first + (i - photon_offset[oi]);
+        Photon ph;
+        load_photon(pool, i, ph);
+        for (int q = 0; q < P.n_ops; ++q) apply_op(P, q, o, k, ph);
+        pool.x[i] = ph.x; pool.y[i] = ph.y; pool.flux[i] = ph.flux;
+        pool.dxdz[i] = ph.dxdz; pool.dydz[i] = ph.dydz;
+        pool.pupil_u[i] = ph.pu; pool.pupil_v[i] = ph.pv; pool.time[i] = ph.t;
+    }
+}
+
+// sensor.accumulate(photons, full_image, ...) (photon_pooling.py:195-225)
+__global__ __launch_bounds__(256) void k_accumulate(const ims_render_params_t P, const int64_t* __restrict__ photon_offset,
+                                                    const ims_photons_t pool, int32_t* __restrict__ pixel_index_out)
+{
+    const bool silicon = (P.sensor != nullptr) && (P.sensor->kind == IMS_SENSOR_SILICON);
+    const bool has_angles = chain_has_angles(P);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pool.n; i += stride) {
+        const int32_t oi = pool.obj_index[i];
+        const ims_object_t& o = P.objects[oi];
+        const int64_t k = o.phot_first + (i - photon_offset[oi]);
+        if (pixel_index_out) pixel_index_out[i] = -1;
+        Photon ph;
+        load_photon(pool, i, ph);
+        if (ph.flux == 0.0) continue;
+        int ix, iy;
+        if (!land(P, o, k, ph, silicon, has_angles, ix, iy)) continue;
+        if (P.realized_flux != nullptr) unsafeAtomicAdd(P.realized_flux + oi, ph.flux);
+        const int px = ix - P.xmin, py = iy - P.ymin;
+        if (px < 0 || px >= P.nx || py < 0 || py >= P.ny) continue;
+        const int64_t pidx = (int64_t)py * P.nx + px;
+        unsafeAtomicAdd(P.image + pidx, (float)ph.flux);
+        if (pixel_index_out) pixel_index_out[i] = (int32_t)pidx;
+    }
+}
+
+// ---------------- Silicon boundary state ----------------
+__device__ __forceinline__ void empty_owned(const ims_sensor_t& s, int n, double& x, double& y)
+{
+    const int nV = s.num_vertices;
+    if (n == 0) { x = 0.0; y = 0.0; return; }
+    if (n <= nV) { x = s.emptypoly[2 * n]; y = 0.0; return; }
+    const int m = n - nV - 1;
+    x = 0.0; y = s.emptypoly[2 * (1 + m)];
+}
+
+__device__ __forceinline__ double treering_shift(const ims_sensor_t& s, double r)
+{
+    if (s.n_tr <= 0) return 0.0;
+    const double f = r / s.tr_dr;
+    if (!(f > 0.0) || f >= (double)(s.n_tr - 1)) return 0.0;
+    const int i = (int)f;
+    const double a = f - (double)i;
+    const double v0 = s.tr_table[i];
+    return v0 + a * (s.tr_table[i + 1] - v0);
+}
+
+// one thread per owner cell of a slot
+__global__ __launch_bounds__(256) void k_init_boundaries(const ims_sensor_t* __restrict__ sp, int slot)
+{
+    const ims_sensor_t& s = *sp;
+    const ims_bf_slot_t bs = s.bf_slots[slot];
+    const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
+    const int64_t ncell = (int64_t)(sl.nx + 1) * (sl.ny + 1);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncell) return;
+    const int i = (int)(c % (sl.nx + 1)), j = (int)(c / (sl.nx + 1));
+    const int npo = 2 * s.num_vertices + 1;
+    double* pts = s.bf_boundary + (sl.offset + c) * npo * 2;
+    for (int n = 0; n < npo; ++n) {
+        double ex, ey;
+        empty_owned(s, n, ex, ey);
+        const double tx = ((double)(sl.xmin + i) - 0.5 + ex) - s.tr_cx;
+        const double ty = ((double)(sl.ymin + j) - 0.5 + ey) - s.tr_cy;
+        const double r = sqrt(tx * tx + ty * ty);
+        const double sh = treering_shift(s, r);
+        double px = ex, py = ey;
+        if (r > 0.0 && sh != 0.0) { px = ex + sh * tx / r; py = ey + sh * ty / r; }
+        pts[2 * n] = px; pts[2 * n + 1] = py;
+    }
+    s.bf_delta[sl.offset + c] = 0.0f;
+}
+
+__global__ __launch_bounds__(256) void k_refresh_bounds(const ims_sensor_t* __restrict__ sp, int slot)
+{
+    const ims_sensor_t& s = *sp;
+    const ims_bf_slot_t bs = s.bf_slots[slot];
+    const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)(sl.nx + 1) * (sl.ny + 1)) return;
+    const int i = (int)(c % (sl.nx + 1)), j = (int)(c / (sl.nx + 1));
+    if (i >= sl.nx || j >= sl.ny) return;
+    const int nV = s.num_vertices, nv = 4 * nV + 4;
+    double ixmin = 0.0, ixmax = 1.0, iymin = 0.0, iymax = 1.0;
+    double oxmin = 0.0, oxmax = 1.0, oymin = 0.0, oymax = 1.0;
+    double v0x = 0.0;
+    for (int k = 0; k < nv; ++k) {
+        double vx, vy;
+        polygon_vertex(s, sl, i, j, k, 1.0, vx, vy);
+        if (k == 0) v0x = vx;
+        if (vx < oxmin) oxmin = vx;
+        if (vx > oxmax) oxmax = vx;
+        if (vy < oymin) oymin = vy;
+        if (vy > oymax) oymax = vy;
+        if (k <= nV + 1) { if (vy > iymin) iymin = vy; }
+        if (k >= nV + 1 && k <= 2 * nV + 2) { if (vx < ixmax) ixmax = vx; }
+        if (k >= 2 * nV + 2 && k <= 3 * nV + 3) { if (vy < iymax) iymax = vy; }
+        if (k >= 3 * nV + 3) { if (vx > ixmin) ixmin = vx; }
+    }
+    if (v0x > ixmin) ixmin = v0x;
+    double* b = s.bf_bounds + (sl.offset + c) * 8;
+    b[0] = ixmin; b[1] = ixmax; b[2] = iymin; b[3] = iymax;
+    b[4] = oxmin; b[5] = oxmax; b[6] = oymin; b[7] = oymax;
+}
+
+__device__ __forceinline__ int owned_to_vertex(int nV, int n)
+{
+    if (n <= nV) return n;
+    const int m = n - nV - 1;
+    return 3 * nV + 4 + (nV - 1 - m);
+}
+
+// Silicon::updatePixelDistortions: one thread per owner cell gathers the charged neighbours in
+// a fixed order (so the result is bit-reproducible) and adds the scaled tabulated displacements.
+__global__ __launch_bounds__(256) void k_update_distortions(const ims_sensor_t* __restrict__ sp, int slot)
+{
+    const ims_sensor_t& s = *sp;
+    const ims_bf_slot_t bs = s.bf_slots[slot];
+    const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)(sl.nx + 1) * (sl.ny + 1)) return;
+    const int i = (int)(c % (sl.nx + 1)), j = (int)(c / (sl.nx + 1));
+    const int nV = s.num_vertices, npo = 2 * nV + 1, nv = 4 * nV + 4, q = s.qdist;
+    const int cx = (s.nx - 1) / 2, cy = (s.ny - 1) / 2;
+    double* pts = s.bf_boundary + (sl.offset + c) * npo * 2;
+    for (int dj = -q; dj <= q + 1; ++dj) {
+        const int sj = j - dj;
+        if (sj < 0 || sj >= sl.ny) continue;
+        for (int di = -q; di <= q + 1; ++di) {
+            const int si = i - di;
+            if (si < 0 || si >= sl.nx) continue;
+            const double charge = (double)s.bf_delta[cell_index(sl, si, sj)];
+            if (charge == 0.0) continue;
+            const double w = charge / s.num_elec;
+            const double* dist = s.distortions + ((int64_t)(di + cx) * s.ny + (dj + cy)) * nv * 2;
+            for (int n = 0; n < npo; ++n) {
+                if (n >= 1 && n <= nV && di == q + 1) continue;
+                if (n > nV && dj == q + 1) continue;
+                const int vtx = owned_to_vertex(nV, n);
+                pts[2 * n] = pts[2 * n] + dist[2 * vtx] * w;
+                pts[2 * n + 1] = pts[2 * n + 1] + dist[2 * vtx + 1] * w;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_zero_delta(const ims_sensor_t* __restrict__ sp, int slot)
+{
+    const ims_sensor_t& s = *sp;
+    const ims_bf_slot_t bs = s.bf_slots[slot];
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)(bs.nx + 1) * (bs.ny + 1)) return;
+    s.bf_delta[bs.offset + c] = 0.0f;
+}
+
+__global__ __launch_bounds__(256) void k_image_add(float* __restrict__ dst, const float* __restrict__ src, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] += src[i];
+}
+
+// device math probe for the parity tests (which: 0 log,1 exp,2 sincos2pi,3 atan,4 sincos,5 tanh,6 gauss)
+__global__ void k_test_math(int which, const double* __restrict__ in, double* __restrict__ out, int64_t n,
+                            uint64_t seed, int64_t obj, uint32_t slot)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s, c;
+    switch (which) {
+    case 0: out[i] = dlog(in[i]); break;
+    case 1: out[i] = dexp(in[i]); break;
+    case 2: sincos2pi(in[i], s, c); out[2 * i] = s; out[2 * i + 1] = c; break;
+    case 3: out[i] = datan(in[i]); break;
+    case 4: dsincos(in[i], s, c); out[2 * i] = s; out[2 * i + 1] = c; break;
+    case 5: out[i] = dtanh_pos(in[i]); break;
+    case 6: gauss_pair(draw(seed, obj, i, slot), s, c); out[2 * i] = s; out[2 * i + 1] = c; break;
+    }
+}
+
+// ---------------- host side of the C-ABI ----------------
+static int check_params(const ims_render_params_t* p)
+{
+    if (!p) return set_err(IMS_ERR_ARG, "params is NULL");
+    if (p->n_objects < 0 || p->n_segments < 0) return set_err(IMS_ERR_ARG, "negative object/segment count");
+    if (p->n_objects > 0 && (!p->objects || !p->seg_prefix)) return set_err(IMS_ERR_ARG, "objects/seg_prefix is NULL");
+    if (p->seg_size <= 0) return set_err(IMS_ERR_ARG, "seg_size must be > 0");
+    if (p->n_psf < 0 || p->n_psf > IMS_MAX_PSF) return set_err(IMS_ERR_ARG, "n_psf out of range");
+    if (p->n_ops < 0 || p->n_ops > IMS_MAX_OPS) return set_err(IMS_ERR_ARG, "n_ops out of range");
+    for (int k = 0; k < p->n_ops; ++k) {
+        const int kind = p->ops[k].kind;
+        if ((kind == IMS_OP_RUBIN_OPTICS || kind == IMS_OP_RUBIN_DIFFRACTION || kind == IMS_OP_RUBIN_DIFFRACTION_OPTICS) && !p->optics)
+            return set_err(IMS_ERR_ARG, "Rubin optics op without optics descriptor");
+    }
+    return IMS_OK;
+}
+
+static unsigned grid_for_segments(int64_t n_segments)
+{
+    const int64_t per = (n_segments + N_XCD - 1) / N_XCD;
+    return (unsigned)(per * N_XCD);
+}
+
+extern "C" {
+
+int ims_abi_version(void) { return IMS_ABI_VERSION; }
+const char* ims_last_error(void) { return g_err; }
+
+int ims_device_count(int* count)
+{
+    if (!count) return set_err(IMS_ERR_ARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return hip_err(e, "hipGetDeviceCount"); }
+    *count = n;
+    return IMS_OK;
+}
+
+int ims_device_info(int device, int* n_cu, int* n_xcd, int64_t* lds_bytes, int64_t* hbm_bytes)
+{
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (n_xcd) *n_xcd = N_XCD;
+    if (lds_bytes) *lds_bytes = (int64_t)prop.sharedMemPerMultiprocessor;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return IMS_OK;
+}
+
+int ims_enable_timing(int on) { g_timing = (on != 0); g_ev_valid = false; return IMS_OK; }
+
+int ims_last_kernel_ms(float* ms)
+{
+    if (!ms) return set_err(IMS_ERR_ARG, "ms is NULL");
+    if (!g_ev_valid) return set_err(IMS_ERR_ARG, "no timed launch recorded");
+    HIP_TRY(hipEventSynchronize(g_ev1));
+    HIP_TRY(hipEventElapsedTime(ms, g_ev0, g_ev1));
+    return IMS_OK;
+}
+
+int ims_shoot_accumulate(const ims_render_params_t* params, void* stream)
+{
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (!params->image) return set_err(IMS_ERR_ARG, "image is NULL");
+    if (params->n_segments == 0) return IMS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        LaunchTimer tm(st);
+        hipLaunchKernelGGL(k_shoot_accumulate, dim3(grid_for_segments(params->n_segments)), dim3(256), 0, st, *params);
+    }
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+int ims_shoot_photons(const ims_render_params_t* params, const int64_t* photon_offset,
+                      const ims_photons_t* pool, void* stream)
+{
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (!photon_offset || !pool) return set_err(IMS_ERR_ARG, "photon_offset/pool is NULL");
+    if (params->n_segments == 0) return IMS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        LaunchTimer tm(st);
+        hipLaunchKernelGGL(k_shoot_photons, dim3(grid_for_segments(params->n_segments)), dim3(256), 0, st,
+                           *params, photon_offset, *pool);
+    }
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+static unsigned grid_for_pool(int64_t n)
+{
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+int ims_apply_ops(const ims_render_params_t* params, const int64_t* photon_offset, const ims_photons_t* pool, void* stream)
+{
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (!photon_offset || !pool) return set_err(IMS_ERR_ARG, "photon_offset/pool is NULL");
+    if (pool->n == 0 || params->n_ops == 0) return IMS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        LaunchTimer tm(st);
+        hipLaunchKernelGGL(k_apply_ops, dim3(grid_for_pool(pool->n)), dim3(256), 0, st, *params, photon_offset, *pool);
+    }
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+int ims_accumulate(const ims_render_params_t* params, const int64_t* photon_offset, const ims_photons_t* pool,
+                   int32_t* pixel_index_out, void* stream)
+{
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (!photon_offset || !pool) return set_err(IMS_ERR_ARG, "photon_offset/pool is NULL");
+    if (!params->image) return set_err(IMS_ERR_ARG, "image is NULL");
+    if (pool->n == 0) return IMS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        LaunchTimer tm(st);
+        hipLaunchKernelGGL(k_accumulate, dim3(grid_for_pool(pool->n)), dim3(256), 0, st, *params, photon_offset, *pool,
+                           pixel_index_out);
+    }
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+static int slot_cells(const ims_sensor_t* host, int slot, int64_t* cells)
+{
+    if (!host || !host->bf_slots) return set_err(IMS_ERR_ARG, "sensor_host/bf_slots is NULL (host copy of the slot table required)");
+    if (slot < 0 || slot >= host->n_bf_slots) return set_err(IMS_ERR_ARG, "slot out of range");
+    *cells = (int64_t)(host->bf_slots[slot].nx + 1) * (host->bf_slots[slot].ny + 1);
+    return IMS_OK;
+}
+
+int ims_sensor_init_boundaries(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host,
+                               int32_t first_slot, int32_t n_slots, void* stream)
+{
+    if (!sensor_dev) return set_err(IMS_ERR_ARG, "sensor_dev is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    for (int k = first_slot; k < first_slot + n_slots; ++k) {
+        int64_t cells;
+        int rc = slot_cells(sensor_host, k, &cells);
+        if (rc) return rc;
+        const unsigned g = (unsigned)((cells + 255) / 256);
+        hipLaunchKernelGGL(k_init_boundaries, dim3(g), dim3(256), 0, st, sensor_dev, k);
+        hipLaunchKernelGGL(k_refresh_bounds, dim3(g), dim3(256), 0, st, sensor_dev, k);
+    }
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+int ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host,
+                                  int32_t first_slot, int32_t n_slots, void* stream)
+{
+    if (!sensor_dev) return set_err(IMS_ERR_ARG, "sensor_dev is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    for (int k = first_slot; k < first_slot + n_slots; ++k) {
+        int64_t cells;
+        int rc = slot_cells(sensor_host, k, &cells);
+        if (rc) return rc;
+        const unsigned g = (unsigned)((cells + 255) / 256);
+        hipLaunchKernelGGL(k_update_distortions, dim3(g), dim3(256), 0, st, sensor_dev, k);
+        hipLaunchKernelGGL(k_zero_delta, dim3(g), dim3(256), 0, st, sensor_dev, k);
+        hipLaunchKernelGGL(k_refresh_bounds, dim3(g), dim3(256), 0, st, sensor_dev, k);
+    }
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+int ims_image_add(float* dst, const float* src, int64_t n, void* stream)
+{
+    if (!dst || !src) return set_err(IMS_ERR_ARG, "dst/src is NULL");
+    if (n <= 0) return IMS_OK;
+    hipLaunchKernelGGL(k_image_add, dim3(grid_for_pool(n)), dim3(256), 0, (hipStream_t)stream, dst, src, n);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+int ims_struct_size(int which)
+{
+    switch (which) {
+    case 0: return (int)sizeof(ims_object_t);
+    case 1: return (int)sizeof(ims_radial_tables_t);
+    case 2: return (int)sizeof(ims_lin_tables_t);
+    case 3: return (int)sizeof(ims_psf_component_t);
+    case 4: return (int)sizeof(ims_op_t);
+    case 5: return (int)sizeof(ims_surface_t);
+    case 6: return (int)sizeof(ims_tansip_t);
+    case 7: return (int)sizeof(ims_optics_t);
+    case 8: return (int)sizeof(ims_bf_slot_t);
+    case 9: return (int)sizeof(ims_sensor_t);
+    case 10: return (int)sizeof(ims_photons_t);
+    case 11: return (int)sizeof(ims_render_params_t);
+    }
+    return -1;
+}
+
+int ims_test_math(int which, const double* in_dev, double* out_dev, int64_t n, uint64_t seed, int64_t obj,
+                  uint32_t slot, void* stream)
+{
+    if (n <= 0) return IMS_OK;
+    hipLaunchKernelGGL(k_test_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       which, in_dev, out_dev, n, seed, obj, slot);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,331 @@
+"""Host engine: owns device memory (torch tensors = plumbing only) and drives libimsim_hip.so.
+
+`Scene` is a pure-host description of everything one CCD needs (tables, PSF, op chain, optics,
+sensor); `Renderer` uploads it once and then renders object tables into the CCD image by calling
+the C-ABI.  There is no CPU fallback here: without the HIP library or a GPU this raises.
+"""
+import ctypes as C
+import dataclasses
+from typing import List, Optional
+
+import numpy as np
+
+from . import _abi
+from ._abi import (OBJECT_DTYPE, BFSLOT_DTYPE, RenderParams, Photons, Sensor, Optics, Op, PsfComponent)
+
+
+@dataclasses.dataclass
+class SensorSetup:
+    """Silicon sensor description (host).  slots[0] is the whole-CCD region (static tree-ring
+    boundaries in LSST_Image mode, live brighter-fatter state in pooling mode); further slots are
+    private regions of bright objects."""
+    model: "object"                       # sensor.SiliconModel
+    abs_wl: np.ndarray                    # nm, uniform grid
+    abs_len: np.ndarray                   # micron
+    tr_table: Optional[np.ndarray] = None  # f(r) on a uniform grid starting at 0
+    tr_dr: float = 3.0
+    tr_center: tuple = (0.0, 0.0)
+    slots: Optional[np.ndarray] = None    # BFSLOT_DTYPE array
+
+    def owned_points(self):
+        return 2 * self.model.num_vertices + 1
+
+    def total_cells(self):
+        s = self.slots
+        return int(s["offset"][-1] + (int(s["nx"][-1]) + 1) * (int(s["ny"][-1]) + 1)) if len(s) else 0
+
+
+def make_slots(regions):
+    """regions: list of (xmin, ymin, nx, ny) -> BFSLOT_DTYPE array with packed owner-cell offsets."""
+    out = np.zeros(len(regions), dtype=BFSLOT_DTYPE)
+    off = 0
+    for k, (xmin, ymin, nx, ny) in enumerate(regions):
+        out[k] = (xmin, ymin, nx, ny, off)
+        off += (nx + 1) * (ny + 1)
+    return out
+
+
+@dataclasses.dataclass
+class Scene:
+    nx: int
+    ny: int
+    xmin: int = 1
+    ymin: int = 1
+    seed: int = 0
+    psf: List[tuple] = dataclasses.field(default_factory=list)     # (kind, table, p0, chrom_alpha, chrom_base)
+    ops: List[tuple] = dataclasses.field(default_factory=list)     # (kind, table, [p0..p5])
+    radial_r2: Optional[np.ndarray] = None
+    radial_cdf: Optional[np.ndarray] = None
+    sed_tables: Optional[np.ndarray] = None      # [n][n_pts] inverse CDFs uniform in u
+    ratio_tables: Optional[np.ndarray] = None    # [n][n_pts] uniform in wavelength
+    ratio_wl_min: float = 0.0
+    ratio_wl_step: float = 1.0
+    optics: Optional[Optics] = None
+    sensor: Optional[SensorSetup] = None
+    seg_size: int = 256
+    track_static_delta: int = 0
+
+
+class HostMem:
+    """Pointer provider over numpy arrays (used by the test-side oracle binding, never by the product)."""
+    def __init__(self):
+        self.keep = []
+
+    def put(self, arr, dtype=None):
+        a = np.ascontiguousarray(arr, dtype=dtype)
+        self.keep.append(a)
+        return a, a.ctypes.data
+
+    def put_struct(self, st):
+        self.keep.append(st)
+        return st, C.addressof(st)
+
+    def zeros(self, n, dtype):
+        return self.put(np.zeros(n, dtype=dtype))
+
+
+class DeviceMem:
+    """Pointer provider over torch device tensors."""
+    def __init__(self, device):
+        import torch
+        if not torch.cuda.is_available():
+            raise _abi.ImsimHipError("no GPU visible: the imsim_amd render path is HIP-only (no CPU fallback)")
+        self.torch = torch
+        self.device = torch.device(device)
+        self.keep = []
+
+    def put(self, arr, dtype=None):
+        a = np.ascontiguousarray(arr, dtype=dtype)
+        t = self.torch.from_numpy(a.view(np.uint8).reshape(-1)).to(self.device)
+        self.keep.append(t)
+        return t, t.data_ptr()
+
+    def put_struct(self, st):
+        raw = np.frombuffer(bytes(st), dtype=np.uint8).copy()
+        return self.put(raw)
+
+    def zeros(self, n, dtype):
+        nbytes = int(n) * np.dtype(dtype).itemsize
+        t = self.torch.zeros(max(nbytes, 8), dtype=self.torch.uint8, device=self.device)
+        self.keep.append(t)
+        return t, t.data_ptr()
+
+
+def segment_prefix(n_phot, seg_size):
+    segs = (np.asarray(n_phot, dtype=np.int64) + seg_size - 1) // seg_size
+    return np.concatenate([[0], np.cumsum(segs)]).astype(np.int64)
+
+
+class BoundScene:
+    """A Scene whose tables live behind pointers of one memory provider; builds RenderParams."""
+
+    def __init__(self, scene: Scene, mem):
+        self.scene = scene
+        self.mem = mem
+        P = RenderParams()
+        P.seed = scene.seed
+        P.seg_size = scene.seg_size
+        P.track_static_delta = scene.track_static_delta
+        if len(scene.psf) > _abi.IMS_MAX_PSF:
+            raise ValueError("too many PSF components")
+        P.n_psf = len(scene.psf)
+        for k, (kind, table, p0, alpha, base) in enumerate(scene.psf):
+            P.psf[k] = PsfComponent(kind, table, p0, alpha, base)
+        if len(scene.ops) > _abi.IMS_MAX_OPS:
+            raise ValueError("too many photon ops")
+        P.n_ops = len(scene.ops)
+        for k, (kind, table, p) in enumerate(scene.ops):
+            pp = list(p) + [0.0] * (6 - len(p))
+            P.ops[k] = Op(kind, table, (C.c_double * 6)(*pp))
+        if scene.radial_r2 is not None:
+            r2 = np.atleast_2d(scene.radial_r2)
+            P.radial.n_tables, P.radial.n_bins = r2.shape[0], r2.shape[1] - 1
+            _, P.radial.r2 = mem.put(r2, np.float64)
+            _, P.radial.cdf = mem.put(np.atleast_2d(scene.radial_cdf), np.float64)
+        if scene.sed_tables is not None:
+            t = np.atleast_2d(scene.sed_tables)
+            P.sed.n_tables, P.sed.n_pts = t.shape
+            P.sed.arg_min, P.sed.arg_step = 0.0, 1.0 / (t.shape[1] - 1)
+            _, P.sed.val = mem.put(t, np.float64)
+        if scene.ratio_tables is not None:
+            t = np.atleast_2d(scene.ratio_tables)
+            P.ratio.n_tables, P.ratio.n_pts = t.shape
+            P.ratio.arg_min, P.ratio.arg_step = scene.ratio_wl_min, scene.ratio_wl_step
+            _, P.ratio.val = mem.put(t, np.float64)
+        if scene.optics is not None:
+            _, P.optics = mem.put_struct(scene.optics)
+        self.sensor_host = None
+        self.sensor_arrays = {}
+        if scene.sensor is not None:
+            self._bind_sensor(P, scene.sensor)
+        P.nx, P.ny, P.xmin, P.ymin = scene.nx, scene.ny, scene.xmin, scene.ymin
+        self.base_params = P
+
+    def _bind_sensor(self, P, ss: SensorSetup):
+        m = ss.model
+        S = Sensor()
+        S.kind = _abi.IMS_SENSOR_SILICON
+        S.num_vertices, S.nx, S.ny, S.qdist = m.num_vertices, m.nx, m.ny, m.qdist
+        S.num_elec, S.pixel_size, S.thickness, S.diff_step = m.num_elec, m.pixel_size, m.thickness, m.diff_step
+        S.n_abs = len(ss.abs_len)
+        S.abs_wl_min = float(ss.abs_wl[0])
+        S.abs_wl_step = float(ss.abs_wl[1] - ss.abs_wl[0])
+        _, S.abs_len = self.mem.put(ss.abs_len, np.float64)
+        if ss.tr_table is not None:
+            S.n_tr, S.tr_dr = len(ss.tr_table), ss.tr_dr
+            S.tr_cx, S.tr_cy = float(ss.tr_center[0]), float(ss.tr_center[1])
+            _, S.tr_table = self.mem.put(ss.tr_table, np.float64)
+        else:
+            S.n_tr, S.tr_dr = 0, 1.0
+        _, S.distortions = self.mem.put(m.distortions, np.float64)
+        _, S.emptypoly = self.mem.put(m.emptypoly, np.float64)
+        slots = ss.slots if ss.slots is not None else make_slots([])
+        S.n_bf_slots = len(slots)
+        cells = ss.total_cells()
+        npo = ss.owned_points()
+        slots_host = np.ascontiguousarray(slots)
+        _, S.bf_slots = self.mem.put(slots_host.view(np.uint8))
+        self.sensor_arrays["boundary"], S.bf_boundary = self.mem.zeros(cells * npo * 2, np.float64)
+        self.sensor_arrays["bounds"], S.bf_bounds = self.mem.zeros(cells * 8, np.float64)
+        self.sensor_arrays["delta"], S.bf_delta = self.mem.zeros(cells, np.float32)
+        # host copy whose slot table is a host pointer (sizes the launches)
+        Sh = Sensor.from_buffer_copy(bytes(S))
+        self._slots_host = slots_host
+        Sh.bf_slots = slots_host.ctypes.data
+        self.sensor_host = Sh
+        self.sensor_struct = S
+        _, P.sensor = self.mem.put_struct(S)
+        self.sensor_dev_ptr = P.sensor
+
+    def params(self, objects_ptr, n_objects, seg_prefix_ptr, n_segments, image_ptr, realized_ptr=None):
+        P = RenderParams.from_buffer_copy(bytes(self.base_params))
+        P.objects, P.n_objects = objects_ptr, n_objects
+        P.seg_prefix, P.n_segments = seg_prefix_ptr, n_segments
+        P.image = image_ptr
+        P.realized_flux = realized_ptr
+        return P
+
+
+class PhotonPool:
+    """Device photon pool (the fields of galsim.PhotonArray) + the object offsets of the sub-batch."""
+    FIELDS = ("x", "y", "flux", "dxdz", "dydz", "wavelength", "pupil_u", "pupil_v", "time")
+
+    def __init__(self, torch, device, n, photon_offset_dev, objects_dev, n_objects, seg_prefix_dev, n_segments):
+        self.n = int(n)
+        self.t = {f: torch.empty(max(self.n, 1), dtype=torch.float64, device=device) for f in self.FIELDS}
+        self.obj_index = torch.empty(max(self.n, 1), dtype=torch.int32, device=device)
+        self.photon_offset_dev = photon_offset_dev
+        self.objects_dev, self.n_objects = objects_dev, n_objects
+        self.seg_prefix_dev, self.n_segments = seg_prefix_dev, n_segments
+
+    def struct(self):
+        ph = Photons()
+        ph.n = self.n
+        for f in self.FIELDS:
+            setattr(ph, f, self.t[f].data_ptr())
+        ph.obj_index = self.obj_index.data_ptr()
+        return ph
+
+    def to_host(self):
+        out = {f: self.t[f][:self.n].cpu().numpy() for f in self.FIELDS}
+        out["obj_index"] = self.obj_index[:self.n].cpu().numpy()
+        return out
+
+
+class Renderer:
+    """One CCD on one GPU."""
+
+    def __init__(self, scene: Scene, device="cuda:0"):
+        self.lib = _abi.load()
+        self.mem = DeviceMem(device)
+        self.torch = self.mem.torch
+        self.device = self.mem.device
+        self.torch.cuda.set_device(self.device)
+        self.scene = scene
+        self.bound = BoundScene(scene, self.mem)
+        self.image = self.torch.zeros((scene.ny, scene.nx), dtype=self.torch.float32, device=self.device)
+        if scene.sensor is not None:
+            self.init_boundaries(0, len(scene.sensor.slots))
+
+    # -- helpers --
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _upload_objects(self, objects):
+        objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
+        obj_t = self.torch.from_numpy(objects.view(np.uint8).reshape(-1)).to(self.device)
+        prefix = segment_prefix(objects["n_phot"], self.scene.seg_size)
+        pre_t = self.torch.from_numpy(prefix).to(self.device)
+        return objects, obj_t, prefix, pre_t
+
+    # -- fused path (LSST_Image / LSST_Silicon) --
+    def render(self, objects, realized=None):
+        """Shoot every object of the table and accumulate into self.image.  `realized`: optional
+        float64 device tensor [n_objects] receiving base['realized_flux'] per object."""
+        objects, obj_t, prefix, pre_t = self._upload_objects(objects)
+        if len(objects) == 0:
+            return
+        P = self.bound.params(obj_t.data_ptr(), len(objects), pre_t.data_ptr(), int(prefix[-1]),
+                              self.image.data_ptr(), realized.data_ptr() if realized is not None else None)
+        _abi.check(self.lib.ims_shoot_accumulate(C.byref(P), self._stream()), "ims_shoot_accumulate")
+        self._keep = (obj_t, pre_t)
+
+    def prepared(self, objects):
+        """Upload an object table once; returns a zero-argument callable that launches the fused
+        kernel (used by bench.py so that the timed region has its inputs resident in HBM)."""
+        objects, obj_t, prefix, pre_t = self._upload_objects(objects)
+        P = self.bound.params(obj_t.data_ptr(), len(objects), pre_t.data_ptr(), int(prefix[-1]),
+                              self.image.data_ptr(), None)
+        ref = C.byref(P)
+        keep = (obj_t, pre_t, P)
+
+        def launch():
+            _abi.check(self.lib.ims_shoot_accumulate(ref, self._stream()), "ims_shoot_accumulate")
+        launch.keep = keep
+        return launch
+
+    # -- pooled path (LSST_PhotonPoolingImage / LSST_Photons) --
+    def shoot_photons(self, objects):
+        objects, obj_t, prefix, pre_t = self._upload_objects(objects)
+        offs = np.concatenate([[0], np.cumsum(objects["n_phot"])]).astype(np.int64)
+        off_t = self.torch.from_numpy(offs).to(self.device)
+        pool = PhotonPool(self.torch, self.device, offs[-1], off_t, obj_t, len(objects), pre_t, int(prefix[-1]))
+        P = self.bound.params(obj_t.data_ptr(), len(objects), pre_t.data_ptr(), int(prefix[-1]), self.image.data_ptr())
+        ph = pool.struct()
+        _abi.check(self.lib.ims_shoot_photons(C.byref(P), off_t.data_ptr(), C.byref(ph), self._stream()), "ims_shoot_photons")
+        return pool
+
+    def _pool_params(self, pool, realized=None):
+        return self.bound.params(pool.objects_dev.data_ptr(), pool.n_objects, pool.seg_prefix_dev.data_ptr(),
+                                 pool.n_segments, self.image.data_ptr(),
+                                 realized.data_ptr() if realized is not None else None)
+
+    def apply_ops(self, pool):
+        P = self._pool_params(pool)
+        ph = pool.struct()
+        _abi.check(self.lib.ims_apply_ops(C.byref(P), pool.photon_offset_dev.data_ptr(), C.byref(ph), self._stream()), "ims_apply_ops")
+
+    def accumulate(self, pool, realized=None, want_pixel_index=False):
+        P = self._pool_params(pool, realized)
+        ph = pool.struct()
+        pix = None
+        if want_pixel_index:
+            pix = self.torch.empty(max(pool.n, 1), dtype=self.torch.int32, device=self.device)
+        _abi.check(self.lib.ims_accumulate(C.byref(P), pool.photon_offset_dev.data_ptr(), C.byref(ph),
+                                           pix.data_ptr() if pix is not None else None, self._stream()), "ims_accumulate")
+        return pix[:pool.n] if pix is not None else None
+
+    # -- sensor state --
+    def init_boundaries(self, first_slot, n_slots):
+        _abi.check(self.lib.ims_sensor_init_boundaries(self.bound.sensor_dev_ptr, C.byref(self.bound.sensor_host),
+                                                       first_slot, n_slots, self._stream()), "ims_sensor_init_boundaries")
+
+    def update_distortions(self, first_slot, n_slots):
+        _abi.check(self.lib.ims_sensor_update_distortions(self.bound.sensor_dev_ptr, C.byref(self.bound.sensor_host),
+                                                          first_slot, n_slots, self._stream()), "ims_sensor_update_distortions")
+
+    def image_numpy(self):
+        return self.image.cpu().numpy()
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.device)

@@ -1,0 +1,304 @@
+/*
+ * imsim_hip.h -- C-ABI of libimsim_hip.so, the MI355X (gfx950) stamp-rendering hot path.
+ *
+ * This is the drop-in boundary for imSim's per-object draw loop.  Every entry point takes plain
+ * pointers, sizes and POD structs (no torch / C++ types).  Device pointers are HIP device
+ * addresses; `stream` is a hipStream_t passed as void*.  All functions return 0 (IMS_OK) or a
+ * negative error code; ims_last_error() returns a thread-local message.
+ *
+ * Reference interfaces replaced (paths relative to the imSim reference tree):
+ *   ims_shoot_accumulate   <- LSST_SiliconBuilder.draw, phot branch: gal.drawImage(method='phot',
+ *                             n_photons=phot_flux, sensor=..., photon_ops=psfs+ops)
+ *                             imsim/stamp.py:527-573, and the stamp->CCD add imsim/lsst_image.py:353-368
+ *   ims_shoot_photons      <- LSST_PhotonsBuilder.draw (save_photons=True, NullSensor)
+ *                             imsim/stamp.py:708-743
+ *   ims_apply_ops          <- `for op in photon_ops: op.applyTo(photons, local_wcs, rng)`
+ *                             imsim/photon_pooling.py:154-155 ; PhotonOp.applyTo imsim/photon_ops.py:81,304,520
+ *   ims_accumulate         <- accumulate_photons -> sensor.accumulate(photons, image, resume, recalc)
+ *                             imsim/photon_pooling.py:195-225
+ *   ims_sensor_*           <- galsim SiliconSensor as configured by imsim/lsst_image.py:93-103 and
+ *                             config/imsim-config.yaml:230-235 (tree rings imsim/treerings.py:169-195)
+ *   ims_fft_*              <- LSST_SiliconBuilder.draw, fft branch imsim/stamp.py:482-525
+ *
+ * Numerics contract: all photon arithmetic is IEEE binary64 built only from + - * / fma sqrt and
+ * integer ops (DESIGN.md "numerics spec"), so the HIP kernels and the CPU oracle produce the same
+ * bits.  Random numbers are Philox4x32-10, counter-addressed by (object id, photon index, slot):
+ * results do not depend on batching, launch geometry or the number of GPUs.
+ */
+#ifndef IMSIM_HIP_H
+#define IMSIM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMS_OK              0
+#define IMS_ERR_ARG        -1
+#define IMS_ERR_HIP        -2
+#define IMS_ERR_NO_DEVICE  -3
+#define IMS_ERR_UNSUPPORTED -4
+
+#define IMS_ABI_VERSION 1
+
+/* ---- object flags ---- */
+#define IMS_OBJ_FAINT   1   /* nominal_flux < max_flux_simple: no photon ops, no sensor (stamp.py:435-465,555-556) */
+
+/* ---- PSF component kinds (psfs are applied as the first photon ops, stamp.py:553) ---- */
+#define IMS_PSF_GAUSSIAN 1  /* p0 = sigma [arcsec] */
+#define IMS_PSF_RADIAL   2  /* table = radial table id, p0 = scale [arcsec per table unit] */
+#define IMS_MAX_PSF 4
+
+/* ---- photon-op kinds (names follow the registered PhotonOp types) ---- */
+#define IMS_OP_TIME_SAMPLER              1  /* p0=t0, p1=exptime                      (config/imsim-config.yaml:282-285) */
+#define IMS_OP_PUPIL_ANNULUS_SAMPLER     2  /* p0=R_outer, p1=R_inner                 (:286-289) */
+#define IMS_OP_PHOTON_DCR                3  /* p0=base_wavelength [nm], p1=pressure kPa, p2=temperature K, p3=H2O kPa, p4=scale (rad->arcsec) (:290-296) */
+#define IMS_OP_RUBIN_OPTICS              4  /* p0=shift_photons (0/1)                 (imsim/photon_ops.py:24-127) */
+#define IMS_OP_RUBIN_DIFFRACTION         5  /* p0=shift_photons, p1=disable_field_rotation (imsim/photon_ops.py:211-358) */
+#define IMS_OP_RUBIN_DIFFRACTION_OPTICS  6  /* p0=shift_photons, p1=disable_field_rotation (imsim/photon_ops.py:151-208) */
+#define IMS_OP_FOCUS_DEPTH               7  /* p0=depth [pixels]                      (:309-315) */
+#define IMS_OP_REFRACTION                8  /* p0=index_ratio                         (:317-318) */
+#define IMS_OP_BANDPASS_RATIO            9  /* table = ratio table id                 (imsim/photon_ops.py:506-521) */
+#define IMS_MAX_OPS 12
+
+/* ---- sensor kinds ---- */
+#define IMS_SENSOR_NONE    0  /* photons.addTo(image): pixel = floor(x+0.5) */
+#define IMS_SENSOR_SILICON 1  /* galsim SiliconSensor restated */
+
+/* ---- surface kinds for the sequential ray trace (batoid Optic.trace restated) ---- */
+#define IMS_SURF_MIRROR   1
+#define IMS_SURF_REFRACT  2
+#define IMS_SURF_DETECTOR 3
+#define IMS_SURF_BAFFLE   4   /* plane that only applies its obscuration */
+#define IMS_MEDIUM_CONST     0   /* n = c0 */
+#define IMS_MEDIUM_SELLMEIER 1   /* n^2 = 1 + sum B_i l^2/(l^2 - C_i), l in micron; c0..c5 = B1,B2,B3,C1,C2,C3 */
+#define IMS_MEDIUM_AIR       2   /* Filippenko/Edlen air; c0=pressure kPa, c1=temperature K, c2=H2O kPa */
+#define IMS_OBSC_NONE          0
+#define IMS_OBSC_CLEAR_ANNULUS 1  /* vignetted unless inner <= r <= outer */
+#define IMS_OBSC_CLEAR_CIRCLE  2  /* vignetted unless r <= outer */
+#define IMS_OBSC_OBSC_CIRCLE   3  /* vignetted if r < outer */
+#define IMS_OBSC_OBSC_ANNULUS  4  /* vignetted if inner <= r < outer */
+#define IMS_MAX_SURFACES 24
+
+/* One catalog source for one call.  256 bytes, 64-byte aligned rows. */
+typedef struct ims_object {
+    int64_t obj_id;        /* RNG stream id = catalog object number (per-object rng, stamp.py:166) */
+    int64_t phot_first;    /* index of the first photon of this call within the object's stream */
+    int64_t n_phot;        /* photons to shoot in this call (phot_flux, or one pooling-batch share) */
+    double  x0, y0;        /* image_pos: CCD pixel coordinates of the object (GalSim convention) */
+    double  flux_per_photon; /* +1 for n_photons=phot_flux, poisson_flux=False (stamp.py:562-572) */
+    double  prof_scale;    /* arcsec per radial-table unit (e.g. half-light radius) */
+    double  jac[4];        /* profile affine a,b,c,d: (u,v)' = (a u + b v, c u + d v) [arcsec]; shear/lens/rot (instcat.py:498-527) */
+    double  winv[4];       /* local WCS inverse jacobian: (dx,dy) = winv * (du,dv), arcsec -> pixels */
+    double  dcr_tanz;      /* PhotonDCR: tan(zenith angle) of this object */
+    double  dcr_sinp;      /* PhotonDCR: sin(parallactic angle) */
+    double  dcr_cosp;      /* PhotonDCR: cos(parallactic angle) */
+    int32_t prof_table;    /* radial profile table id; -1 = DeltaFunction (point source) */
+    int32_t sed_table;     /* wavelength inverse-CDF table id; -1 = monochromatic at sed_wave */
+    int32_t flags;         /* IMS_OBJ_* */
+    int32_t stamp_xmin, stamp_xmax, stamp_ymin, stamp_ymax; /* stamp bounds, inclusive; photons outside are lost */
+    int32_t bf_state;      /* >=0: index into ims_sensor.bf_slots (private pixel boundaries); -1: static CCD boundaries */
+    double  sed_wave;      /* wavelength [nm] when sed_table < 0 */
+    double  reserved[9];   /* pads the row to 256 bytes */
+} ims_object_t;
+
+/* Tabulated circular profiles sampled by inverse CDF with uniform density inside each annulus:
+ * r^2 = r2[i] + (u - cdf[i])/(cdf[i+1]-cdf[i]) * (r2[i+1]-r2[i]).  Table units are scaled per use. */
+typedef struct ims_radial_tables {
+    int32_t n_tables;
+    int32_t n_bins;          /* each table has n_bins+1 knots */
+    const double* r2;        /* [n_tables][n_bins+1] squared radii, increasing */
+    const double* cdf;       /* [n_tables][n_bins+1] enclosed flux fraction, cdf[0]=0, cdf[n_bins]=1 */
+} ims_radial_tables_t;
+
+/* Generic 1-D tables uniform in their argument, linear interpolation, clamped at the ends.
+ * Used for: wavelength inverse CDFs (argument u in [0,1]), bandpass ratios (argument wavelength). */
+typedef struct ims_lin_tables {
+    int32_t n_tables;
+    int32_t n_pts;
+    double  arg_min;
+    double  arg_step;
+    const double* val;       /* [n_tables][n_pts] */
+} ims_lin_tables_t;
+
+typedef struct ims_psf_component {
+    int32_t kind;            /* IMS_PSF_* */
+    int32_t table;           /* radial table id for IMS_PSF_RADIAL */
+    double  p0;              /* sigma or scale [arcsec] */
+    double  chrom_alpha;     /* size scales as (wavelength/chrom_base)^alpha; 0 = achromatic */
+    double  chrom_base;      /* nm */
+} ims_psf_component_t;
+
+typedef struct ims_op {
+    int32_t kind;            /* IMS_OP_* */
+    int32_t table;
+    double  p[6];
+} ims_op_t;
+
+typedef struct ims_surface {
+    int32_t kind;            /* IMS_SURF_* */
+    int32_t obsc_kind;       /* IMS_OBSC_* */
+    int32_t medium_kind;     /* medium AFTER this surface (refractive surfaces) */
+    int32_t n_asphere;       /* number of even asphere coefficients used (0..4): r^4, r^6, r^8, r^10 */
+    double  z0;              /* vertex z in telescope coordinates [m] */
+    double  R;               /* radius of curvature [m]; 0 = plane */
+    double  conic;
+    double  asph[4];
+    double  obsc_inner, obsc_outer;   /* [m] */
+    double  medium_c[6];
+} ims_surface_t;
+
+/* TAN-SIP world coordinate system, trig-free vector form:
+ * pixel -> (u,v)=pix-crpix -> +SIP(A,B) -> CD -> tangent plane (xi,eta) [rad] -> unit vector
+ *   p = rot^T (1, xi, eta)/norm.  Inverse solves the SIP by Newton iteration. */
+typedef struct ims_tansip {
+    double crpix[2];
+    double cd[4];            /* rad per pixel */
+    double cdinv[4];
+    double rot[9];           /* rows: unit vectors of the tangent point (e0), +xi (e1), +eta (e2) in ICRF */
+    int32_t order;           /* SIP order, 0 = pure TAN; <= 4 */
+    int32_t pad;
+    double a[25];            /* a[p*5+q] u^p v^q */
+    double b[25];
+} ims_tansip_t;
+
+/* Everything RubinOptics / RubinDiffraction / RubinDiffractionOptics need (imsim/photon_ops.py). */
+typedef struct ims_optics {
+    ims_tansip_t img_wcs;        /* base['current_image'].wcs: pixel <-> ICRF */
+    ims_tansip_t icrf_to_field;  /* base['_icrf_to_field']: field angle [rad] <-> ICRF */
+    int32_t in_medium_kind;      /* telescope.inMedium */
+    int32_t n_surfaces;
+    double  in_medium_c[6];
+    double  stop_z;              /* z of the stop surface plane (rays start at (pupil_u, pupil_v, stop_z)) */
+    ims_surface_t surf[IMS_MAX_SURFACES];
+    double  cam_rot[2];          /* cos, sin of the camera rotator angle applied to the detector-plane hit (telescope_loader.py:242-246) */
+    double  fp_to_pix[6];        /* focal_to_pixel affine (imsim/utils.py:42-59): x = m0*fpx + m1*fpy + m2 ; y = m3*fpx + m4*fpy + m5, fp in mm;
+                                    called as focal_to_pixel(ray.y*1e3, ray.x*1e3) (imsim/photon_ops.py:495) */
+    double  slope_jac[4];        /* normalised M @ jac_focal_to_pixel (imsim/photon_ops.py:497-500): dxdz = (s0 vx + s1 vy)/vz, dydz = (s2 vx + s3 vy)/vz */
+    /* spider diffraction (imsim/diffraction.py:32-42) */
+    int32_t n_lines, n_circles;
+    double  lines[8][4];         /* nx, ny, d, thickness */
+    double  circles[4][3];       /* cx, cy, r */
+    double  e_z0[3];             /* zenith at t=0, equatorial frame (diffraction.py:284-304) */
+    double  e_focal[3];          /* pointing in equatorial frame (diffraction.py:387-415) */
+    double  cos_lat, sin_lat;
+    double  omega;               /* Earth rotation rate [rad/s] (diffraction.py:280) */
+} ims_optics_t;
+
+/* Private pixel-boundary state of one brighter-fatter active region (a bright object's stamp in
+ * LSST_Image mode, or the whole CCD in photon-pooling mode). */
+typedef struct ims_bf_slot {
+    int32_t xmin, ymin, nx, ny;   /* region in CCD pixel coordinates */
+    int64_t offset;               /* owner-cell offset of this region; a region has (nx+1)*(ny+1) owner cells, row-major, x fastest */
+} ims_bf_slot_t;
+
+typedef struct ims_sensor {
+    int32_t kind;                /* IMS_SENSOR_* */
+    int32_t num_vertices;        /* NumVertices per edge (cfg); nv = 4*num_vertices+4 */
+    int32_t nx, ny;              /* PixelBoundaryNx/Ny of the model (9) */
+    int32_t qdist;               /* neighbour range for superposition (GalSim default 3) */
+    int32_t n_abs;               /* absorption-length table points */
+    int32_t n_tr;                /* tree-ring table points (0 = no tree rings) */
+    int32_t pad;
+    double  num_elec;            /* CollectedCharge_0_0 / strength */
+    double  pixel_size;          /* micron */
+    double  thickness;           /* micron */
+    double  diff_step;           /* micron; 0 = no diffusion */
+    double  abs_wl_min, abs_wl_step;   /* nm */
+    double  tr_dr;               /* tree-ring table step [pixels] (imsim/treerings.py:100-103) */
+    double  tr_cx, tr_cy;        /* tree-ring centre in CCD pixel coordinates (imsim/treerings.py:174-189) */
+    const double* abs_len;       /* [n_abs] micron */
+    const double* tr_table;      /* [n_tr] radial shift f(r) [pixels] */
+    const double* distortions;   /* [nx][ny][nv][2] vertex displacement (pixel units) per num_elec of charge in the centre pixel */
+    const double* emptypoly;     /* [nv][2] undistorted polygon, counter-clockwise */
+    /* brighter-fatter state */
+    int32_t n_bf_slots;
+    int32_t pad2;
+    const ims_bf_slot_t* bf_slots;
+    double* bf_boundary;         /* per owner cell of every slot: [2*num_vertices+1][2] owned boundary points (LL corner, bottom pts, left pts) */
+    double* bf_bounds;           /* per owner cell (one 64-byte line): inner xmin,xmax,ymin,ymax, outer xmin,xmax,ymin,ymax */
+    float*  bf_delta;            /* per owner cell: charge accumulated since the last recalc */
+} ims_sensor_t;
+
+/* A photon pool in device memory, SoA, the fields of galsim.PhotonArray (imsim/photon_ops.py:81). */
+typedef struct ims_photons {
+    int64_t n;
+    double *x, *y, *flux, *dxdz, *dydz, *wavelength, *pupil_u, *pupil_v, *time;
+    int32_t *obj_index;          /* row in the object table that produced the photon (for stamp clipping / truth) */
+} ims_photons_t;
+
+typedef struct ims_render_params {
+    uint64_t seed;
+    const ims_object_t* objects;     /* device, n_objects rows */
+    int64_t  n_objects;
+    const int64_t* seg_prefix;       /* device, [n_objects+1]: prefix sum of ceil(n_phot/seg_size) */
+    int64_t  n_segments;
+    int32_t  seg_size;               /* photons per workgroup segment */
+    int32_t  n_psf;
+    ims_psf_component_t psf[IMS_MAX_PSF];
+    int32_t  n_ops;
+    int32_t  track_static_delta;     /* 1 in photon-pooling mode: charge landing in slot 0 (whole CCD) is kept for the next recalc */
+    ims_op_t ops[IMS_MAX_OPS];
+    ims_radial_tables_t radial;
+    ims_lin_tables_t    sed;         /* wavelength inverse CDFs */
+    ims_lin_tables_t    ratio;       /* BandpassRatio tables */
+    const ims_optics_t* optics;      /* device pointer or NULL */
+    const ims_sensor_t* sensor;      /* device pointer (struct itself lives in device memory) or NULL = IMS_SENSOR_NONE */
+    /* target image */
+    float*   image;                  /* device, row-major [ny][nx], pixel (ix,iy) at image[(iy-ymin)*nx + (ix-xmin)] */
+    int32_t  nx, ny, xmin, ymin;
+    double*  realized_flux;          /* device [n_objects] or NULL: flux added per object (base['realized_flux'], stamp.py:573) */
+} ims_render_params_t;
+
+/* ---- library ---- */
+int  ims_abi_version(void);
+const char* ims_last_error(void);
+int  ims_device_count(int* count);
+/* device properties used by the host scheduler: cus, xcds, lds bytes */
+int  ims_device_info(int device, int* n_cu, int* n_xcd, int64_t* lds_bytes, int64_t* hbm_bytes);
+
+/* ---- fused path: shoot -> PSF -> ops -> sensor -> CCD image (LSST_Silicon / LSST_Image) ---- */
+int  ims_shoot_accumulate(const ims_render_params_t* params, void* stream);
+
+/* ---- pooled path (LSST_Photons / LSST_PhotonPoolingImage) ---- */
+/* photon_offset[n_objects+1] (device): where each object's photons live in the pool */
+int  ims_shoot_photons(const ims_render_params_t* params, const int64_t* photon_offset,
+                       const ims_photons_t* pool, void* stream);
+int  ims_apply_ops(const ims_render_params_t* params, const int64_t* photon_offset,
+                   const ims_photons_t* pool, void* stream);
+/* pixel_index_out (device, [pool->n], may be NULL): flat image index each photon landed in, -1 = lost */
+int  ims_accumulate(const ims_render_params_t* params, const int64_t* photon_offset,
+                    const ims_photons_t* pool, int32_t* pixel_index_out, void* stream);
+
+/* ---- Silicon sensor state ---- */
+/* `sensor_dev` = the struct in device memory (all its pointers are device pointers);
+ * `sensor_host` = a host copy whose bf_slots points to a HOST copy of the slot table (sizes the launches). */
+/* boundary points = undistorted + tree rings, bounds refreshed, delta = 0 (Silicon::initialize) */
+int  ims_sensor_init_boundaries(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host,
+                                int32_t first_slot, int32_t n_slots, void* stream);
+/* boundaries += distortions (x) delta / num_elec over the qdist neighbourhood; refresh bounds; delta = 0
+ * (Silicon::updatePixelDistortions; the `recalc` of imsim/photon_pooling.py:159) */
+int  ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host,
+                                   int32_t first_slot, int32_t n_slots, void* stream);
+
+/* ---- image helpers ---- */
+int  ims_image_add(float* dst, const float* src, int64_t n, void* stream);
+
+/* ---- last-launch timing (hipEvent pair recorded around the most recent hot-path launch) ---- */
+int  ims_last_kernel_ms(float* ms);
+int  ims_enable_timing(int on);
+
+/* ---- numerics probe used by the parity tests: evaluates the spec's elementary functions on device ----
+ * which: 0 log, 1 exp, 2 sincos2pi (2 outputs), 3 atan, 4 sincos (2), 5 tanh, 6 gaussian pair of draw(seed,obj,i,slot) (2) */
+/* sizeof() of the ABI structs as compiled, for binding self-checks:
+ * 0 object, 1 radial_tables, 2 lin_tables, 3 psf_component, 4 op, 5 surface, 6 tansip, 7 optics, 8 bf_slot,
+ * 9 sensor, 10 photons, 11 render_params */
+int  ims_struct_size(int which);
+int  ims_test_math(int which, const double* in_dev, double* out_dev, int64_t n, uint64_t seed, int64_t obj,
+                   uint32_t slot, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMSIM_HIP_H */

@@ -1,0 +1,151 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+Python binding of oracle/liboracle.so (the CPU restatement).  Imported only by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg; never by anything under imsim_amd/.
+It reuses the product's pure-host struct builders (imsim_amd.engine.BoundScene over HostMem) so
+both sides are fed byte-identical parameter blocks.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from imsim_amd import _abi
+from imsim_amd.engine import BoundScene, HostMem, segment_prefix
+from imsim_amd._abi import OBJECT_DTYPE, Photons
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+PHOTON_FIELDS = ("x", "y", "flux", "dxdz", "dydz", "wavelength", "pupil_u", "pupil_v", "time")
+
+
+def build():
+    subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        lib = C.CDLL(_LIB)
+        for k, st in enumerate(_abi.STRUCTS):
+            assert lib.orc_struct_size(k) == C.sizeof(st), st.__name__
+        lib.orc_render_objects.argtypes = [C.POINTER(_abi.RenderParams), C.c_int64, C.c_void_p, C.c_void_p]
+        lib.orc_shoot_pool.argtypes = [C.POINTER(_abi.RenderParams), C.c_void_p, C.POINTER(Photons)]
+        lib.orc_apply_op.argtypes = [C.POINTER(_abi.RenderParams), C.c_int, C.POINTER(Photons), C.c_void_p]
+        lib.orc_accumulate_range.argtypes = [C.POINTER(_abi.RenderParams), C.POINTER(Photons), C.c_void_p,
+                                             C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.orc_sensor_init_boundaries.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.orc_sensor_update_distortions.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.orc_test_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]
+        lib.orc_test_gauss.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_uint32, C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def math_probe(which, x):
+    """Evaluate the spec's elementary function `which` (see ims_test_math) on the CPU."""
+    lib = load()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    m = 2 if which in (2, 4) else 1
+    out = np.empty(x.size * m)
+    lib.orc_test_math(which, x.ctypes.data, out.ctypes.data, x.size)
+    return out
+
+
+def gauss_probe(seed, obj, n, slot):
+    lib = load()
+    out = np.empty(2 * n)
+    lib.orc_test_gauss(seed, obj, 0, n, slot, out.ctypes.data)
+    return out
+
+
+class HostPool:
+    def __init__(self, n):
+        self.n = int(n)
+        self.a = {f: np.zeros(max(self.n, 1)) for f in PHOTON_FIELDS}
+        self.obj_index = np.zeros(max(self.n, 1), dtype=np.int32)
+
+    def struct(self):
+        ph = Photons()
+        ph.n = self.n
+        for f in PHOTON_FIELDS:
+            setattr(ph, f, self.a[f].ctypes.data)
+        ph.obj_index = self.obj_index.ctypes.data
+        return ph
+
+    def to_host(self):
+        out = {f: self.a[f][:self.n].copy() for f in PHOTON_FIELDS}
+        out["obj_index"] = self.obj_index[:self.n].copy()
+        return out
+
+
+class OracleScene:
+    """CPU counterpart of imsim_amd.engine.Renderer."""
+
+    def __init__(self, scene):
+        self.lib = load()
+        self.scene = scene
+        self.mem = HostMem()
+        self.bound = BoundScene(scene, self.mem)
+        self.image = np.zeros((scene.ny, scene.nx), dtype=np.float32)
+        if scene.sensor is not None:
+            self.init_boundaries(0, len(scene.sensor.slots))
+
+    def _objects(self, objects):
+        objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
+        prefix = segment_prefix(objects["n_phot"], self.scene.seg_size)
+        return objects, prefix
+
+    def render(self, objects, nrecalc=0, realized=None):
+        objects, prefix = self._objects(objects)
+        P = self.bound.params(objects.ctypes.data, len(objects), prefix.ctypes.data, int(prefix[-1]),
+                              self.image.ctypes.data)
+        rc = self.lib.orc_render_objects(C.byref(P), int(nrecalc), self.image.ctypes.data,
+                                         realized.ctypes.data if realized is not None else None)
+        assert rc == 0
+
+    def shoot_pool(self, objects):
+        objects, prefix = self._objects(objects)
+        offs = np.concatenate([[0], np.cumsum(objects["n_phot"])]).astype(np.int64)
+        pool = HostPool(offs[-1])
+        pool.objects, pool.prefix, pool.offs = objects, prefix, offs
+        P = self._pool_params(pool)
+        ph = pool.struct()
+        self.lib.orc_shoot_pool(C.byref(P), offs.ctypes.data, C.byref(ph))
+        return pool
+
+    def _pool_params(self, pool, image_ptr=None):
+        return self.bound.params(pool.objects.ctypes.data, len(pool.objects), pool.prefix.ctypes.data,
+                                 int(pool.prefix[-1]), image_ptr)
+
+    def apply_ops(self, pool):
+        P = self._pool_params(pool)
+        ph = pool.struct()
+        for k in range(len(self.scene.ops)):
+            self.lib.orc_apply_op(C.byref(P), k, C.byref(ph), pool.offs.ctypes.data)
+
+    def accumulate(self, pool, realized=None, want_pixel_index=False):
+        img = np.zeros((self.scene.ny, self.scene.nx), dtype=np.float64)
+        P = self._pool_params(pool, img.ctypes.data)
+        ph = pool.struct()
+        pix = np.empty(max(pool.n, 1), dtype=np.int32) if want_pixel_index else None
+        self.lib.orc_accumulate_range(C.byref(P), C.byref(ph), pool.offs.ctypes.data, 0, pool.n, img.ctypes.data,
+                                      realized.ctypes.data if realized is not None else None,
+                                      pix.ctypes.data if pix is not None else None)
+        self.image += img.astype(np.float32)
+        return pix[:pool.n] if pix is not None else None
+
+    def init_boundaries(self, first_slot, n_slots):
+        self.lib.orc_sensor_init_boundaries(self.bound.sensor_dev_ptr, first_slot, n_slots)
+
+    def update_distortions(self, first_slot, n_slots):
+        self.lib.orc_sensor_update_distortions(self.bound.sensor_dev_ptr, first_slot, n_slots)
+
+    def sensor_array(self, name):
+        dt = np.float32 if name == "delta" else np.float64
+        return self.bound.sensor_arrays[name].view(dt)

@@ -1,0 +1,242 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY (see orc_math.h).
+ *
+ * orc_photon.c: CPU restatement of photon shooting and the simple photon operators, written the
+ * way the reference runs them: one operator at a time over a whole photon array
+ * (GalSim drawImage(method='phot') as driven by imsim/stamp.py:527-573 -- recalled call order in
+ * shoot -> each photon_op.applyTo -> sensor.accumulate).
+ *
+ * Third-party algorithms restated here (GalSim is unpinned in the reference, setup.py:21; absent
+ * from /root/reference): WavelengthSampler, GSObject.shoot for DeltaFunction/Sersic/Gaussian,
+ * PSF-as-PhotonOp (PhotonArray.convolve), TimeSampler, PupilAnnulusSampler, PhotonDCR,
+ * FocusDepth, Refraction.  Parity unpinned at the bit level (no golden photon arrays exist in the
+ * reference); distributions are pinned by the reference tests' statistical criteria in tests/.
+ */
+#include <stdlib.h>
+#include "orc.h"
+
+/* ---------- table helpers ---------- */
+double orc_lin_lookup(const ims_lin_tables_t* t, int table, double arg)
+{
+    const double* v = t->val + (int64_t)table * t->n_pts;
+    double f = (arg - t->arg_min) / t->arg_step;
+    if (!(f > 0.0)) return v[0];
+    int n = t->n_pts;
+    if (f >= (double)(n - 1)) return v[n - 1];
+    int i = (int)f;
+    double a = f - (double)i;
+    return v[i] + a * (v[i + 1] - v[i]);
+}
+
+/* inverse-CDF sample of a radial table: returns r^2 in table units */
+double orc_radial_r2(const ims_radial_tables_t* t, int table, double u)
+{
+    int nb = t->n_bins;
+    const double* cdf = t->cdf + (int64_t)table * (nb + 1);
+    const double* r2 = t->r2 + (int64_t)table * (nb + 1);
+    /* largest i in [0, nb-1] with cdf[i] <= u */
+    int lo = 0, hi = nb;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (cdf[mid] <= u) lo = mid; else hi = mid;
+    }
+    double w = cdf[lo + 1] - cdf[lo];
+    double f = (w > 0.0) ? (u - cdf[lo]) / w : 0.0;
+    return r2[lo] + f * (r2[lo + 1] - r2[lo]);
+}
+
+/* ---------- photon array ---------- */
+int orc_photons_alloc(ims_photons_t* p, int64_t n)
+{
+    p->n = n;
+    size_t b = (size_t)(n > 0 ? n : 1) * sizeof(double);
+    p->x = malloc(b); p->y = malloc(b); p->flux = malloc(b); p->dxdz = malloc(b); p->dydz = malloc(b);
+    p->wavelength = malloc(b); p->pupil_u = malloc(b); p->pupil_v = malloc(b); p->time = malloc(b);
+    p->obj_index = malloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
+    return (p->x && p->y && p->flux && p->dxdz && p->dydz && p->wavelength && p->pupil_u && p->pupil_v
+            && p->time && p->obj_index) ? 0 : -1;
+}
+void orc_photons_free(ims_photons_t* p)
+{
+    free(p->x); free(p->y); free(p->flux); free(p->dxdz); free(p->dydz);
+    free(p->wavelength); free(p->pupil_u); free(p->pupil_v); free(p->time); free(p->obj_index);
+    memset(p, 0, sizeof(*p));
+}
+
+/* ---------- shooting (stamp.py:562-572 -> GalSim drawImage phot) ---------- */
+/* Photon j (j = 0..n_phot-1) of `obj` is written at pool index base+j; its stream index is
+ * obj->phot_first + j.  Positions are left RELATIVE to the object's image_pos, in pixels. */
+void orc_shoot_object(const ims_render_params_t* P, const ims_object_t* obj, int32_t obj_index,
+                      ims_photons_t* ph, int64_t base)
+{
+    const double j0 = obj->jac[0], j1 = obj->jac[1], j2 = obj->jac[2], j3 = obj->jac[3];
+    const double w0 = obj->winv[0], w1 = obj->winv[1], w2 = obj->winv[2], w3 = obj->winv[3];
+    for (int64_t j = 0; j < obj->n_phot; ++j) {
+        int64_t i = base + j, k = obj->phot_first + j;
+        orc_draw_t d0 = orc_draw(P->seed, obj->obj_id, k, ORC_SLOT_WAVE_PROF);
+        /* WavelengthSampler */
+        double wl = obj->sed_wave;
+        if (obj->sed_table >= 0) wl = orc_lin_lookup(&P->sed, obj->sed_table, orc_u01(d0.a));
+        /* profile */
+        double pu = 0.0, pv = 0.0;
+        if (obj->prof_table >= 0) {
+            double r2 = orc_radial_r2(&P->radial, obj->prof_table, orc_u01(d0.b));
+            double r = orc_sqrt(r2) * obj->prof_scale;
+            orc_draw_t d1 = orc_draw(P->seed, obj->obj_id, k, ORC_SLOT_PROF_ANG);
+            double s, c;
+            orc_sincos2pi(orc_u01(d1.a), &s, &c);
+            double gu = r * c, gv = r * s;
+            pu = j0 * gu + j1 * gv;
+            pv = j2 * gu + j3 * gv;
+        }
+        ph->x[i] = w0 * pu + w1 * pv;
+        ph->y[i] = w2 * pu + w3 * pv;
+        ph->flux[i] = obj->flux_per_photon;
+        ph->dxdz[i] = 0.0; ph->dydz[i] = 0.0;
+        ph->wavelength[i] = wl;
+        ph->pupil_u[i] = 0.0; ph->pupil_v[i] = 0.0; ph->time[i] = 0.0;
+        ph->obj_index[i] = obj_index;
+    }
+}
+
+/* PSF components act as photon ops: shoot the same number of photons and add positions
+ * (GSObject.applyTo -> PhotonArray.convolve; stamp.py:553 `photon_ops = psfs + photon_ops`). */
+void orc_apply_psf(const ims_render_params_t* P, const ims_object_t* obj, int comp,
+                   ims_photons_t* ph, int64_t base)
+{
+    const ims_psf_component_t* c = &P->psf[comp];
+    const double w0 = obj->winv[0], w1 = obj->winv[1], w2 = obj->winv[2], w3 = obj->winv[3];
+    for (int64_t j = 0; j < obj->n_phot; ++j) {
+        int64_t i = base + j, k = obj->phot_first + j;
+        orc_draw_t d = orc_draw(P->seed, obj->obj_id, k, ORC_SLOT_PSF + (uint32_t)comp);
+        double scale = c->p0;
+        if (c->chrom_alpha != 0.0) scale = scale * orc_pow(ph->wavelength[i] / c->chrom_base, c->chrom_alpha);
+        double ku, kv;
+        if (c->kind == IMS_PSF_GAUSSIAN) {
+            double g0, g1;
+            orc_gauss_pair(d, &g0, &g1);
+            ku = scale * g0; kv = scale * g1;
+        } else {
+            double r2 = orc_radial_r2(&P->radial, c->table, orc_u01(d.a));
+            double r = orc_sqrt(r2) * scale;
+            double s, cc;
+            orc_sincos2pi(orc_u01(d.b), &s, &cc);
+            ku = r * cc; kv = r * s;
+        }
+        ph->x[i] = ph->x[i] + (w0 * ku + w1 * kv);
+        ph->y[i] = ph->y[i] + (w2 * ku + w3 * kv);
+    }
+}
+
+/* move to CCD coordinates: x += image_pos (the `shift_photons` of photon_ops.py:100-102 and the
+ * stamp_center shift of stamp.py:740-742, done once here because everything downstream works in
+ * full-image coordinates) */
+void orc_shift_to_image(const ims_object_t* obj, ims_photons_t* ph, int64_t base)
+{
+    for (int64_t j = 0; j < obj->n_phot; ++j) {
+        ph->x[base + j] = obj->x0 + ph->x[base + j];
+        ph->y[base + j] = obj->y0 + ph->y[base + j];
+    }
+}
+
+/* ---------- simple photon ops; `k` is the photon's stream index, looked up through obj_index ---------- */
+static inline int64_t stream_index(const ims_render_params_t* P, const ims_photons_t* ph,
+                                   const int64_t* photon_offset, int64_t i, const ims_object_t** obj)
+{
+    int32_t oi = ph->obj_index[i];
+    *obj = &P->objects[oi];
+    return (*obj)->phot_first + (i - photon_offset[oi]);
+}
+
+/* Filippenko (1982) air index as used by GalSim's dcr module (recalled). */
+double orc_air_n_minus_one(double wave_nm, double p_kpa, double t_k, double h2o_kpa)
+{
+    double Pm = p_kpa * 7.50061683;
+    double T = t_k - 273.15;
+    double W = h2o_kpa * 7.50061683;
+    double wm = wave_nm * 1.0e-3;
+    double sig2 = 1.0 / (wm * wm);
+    double n1 = (64.328 + 29498.1 / (146.0 - sig2) + 255.4 / (41.0 - sig2)) * 1.0e-6;
+    n1 = n1 * (Pm * (1.0 + (1.049 - 0.0157 * T) * 1.0e-6 * Pm) / (720.883 * (1.0 + 0.003661 * T)));
+    n1 = n1 - (0.0624 - 0.000680 * sig2) / (1.0 + 0.003661 * T) * W * 1.0e-6;
+    return n1;
+}
+static double refraction_r0(double nm1)
+{
+    return nm1 * (nm1 + 2.0) / 2.0 / (nm1 * nm1 + 2.0 * nm1 + 1.0);
+}
+
+void orc_apply_op(const ims_render_params_t* P, int op_index, ims_photons_t* ph,
+                  const int64_t* photon_offset)
+{
+    const ims_op_t* op = &P->ops[op_index];
+    const uint32_t slot = ORC_SLOT_OP + (uint32_t)op_index;
+    const int64_t n = ph->n;
+    switch (op->kind) {
+    case IMS_OP_TIME_SAMPLER:
+        for (int64_t i = 0; i < n; ++i) {
+            const ims_object_t* obj; int64_t k = stream_index(P, ph, photon_offset, i, &obj);
+            if (obj->flags & IMS_OBJ_FAINT) continue;
+            orc_draw_t d = orc_draw(P->seed, obj->obj_id, k, slot);
+            ph->time[i] = op->p[0] + orc_u01(d.a) * op->p[1];
+        }
+        break;
+    case IMS_OP_PUPIL_ANNULUS_SAMPLER: {
+        double ro2 = op->p[0] * op->p[0], ri2 = op->p[1] * op->p[1];
+        for (int64_t i = 0; i < n; ++i) {
+            const ims_object_t* obj; int64_t k = stream_index(P, ph, photon_offset, i, &obj);
+            if (obj->flags & IMS_OBJ_FAINT) continue;
+            orc_draw_t d = orc_draw(P->seed, obj->obj_id, k, slot);
+            double r = orc_sqrt(ri2 + orc_u01(d.a) * (ro2 - ri2));
+            double s, c;
+            orc_sincos2pi(orc_u01(d.b), &s, &c);
+            ph->pupil_u[i] = r * c;
+            ph->pupil_v[i] = r * s;
+        }
+        break; }
+    case IMS_OP_PHOTON_DCR: {
+        double base_r0 = refraction_r0(orc_air_n_minus_one(op->p[0], op->p[1], op->p[2], op->p[3]));
+        for (int64_t i = 0; i < n; ++i) {
+            const ims_object_t* obj; (void)stream_index(P, ph, photon_offset, i, &obj);
+            if (obj->flags & IMS_OBJ_FAINT) continue;
+            double r0 = refraction_r0(orc_air_n_minus_one(ph->wavelength[i], op->p[1], op->p[2], op->p[3]));
+            double shift = (r0 - base_r0) * obj->dcr_tanz * op->p[4];   /* arcsec */
+            double du = -shift * obj->dcr_sinp;
+            double dv = shift * obj->dcr_cosp;
+            ph->x[i] = ph->x[i] + (obj->winv[0] * du + obj->winv[1] * dv);
+            ph->y[i] = ph->y[i] + (obj->winv[2] * du + obj->winv[3] * dv);
+        }
+        break; }
+    case IMS_OP_FOCUS_DEPTH:
+        for (int64_t i = 0; i < n; ++i) {
+            const ims_object_t* obj; (void)stream_index(P, ph, photon_offset, i, &obj);
+            if (obj->flags & IMS_OBJ_FAINT) continue;
+            ph->x[i] = ph->x[i] + ph->dxdz[i] * op->p[0];
+            ph->y[i] = ph->y[i] + ph->dydz[i] * op->p[0];
+        }
+        break;
+    case IMS_OP_REFRACTION: {
+        double nn = op->p[0] * op->p[0];
+        for (int64_t i = 0; i < n; ++i) {
+            const ims_object_t* obj; (void)stream_index(P, ph, photon_offset, i, &obj);
+            if (obj->flags & IMS_OBJ_FAINT) continue;
+            double a = ph->dxdz[i], b = ph->dydz[i];
+            double rho2 = a * a + b * b;
+            double f = 1.0 / orc_sqrt(nn + (nn - 1.0) * rho2);
+            ph->dxdz[i] = a * f;
+            ph->dydz[i] = b * f;
+        }
+        break; }
+    case IMS_OP_BANDPASS_RATIO:
+        for (int64_t i = 0; i < n; ++i)
+            ph->flux[i] = ph->flux[i] * orc_lin_lookup(&P->ratio, op->table, ph->wavelength[i]);
+        break;
+    case IMS_OP_RUBIN_OPTICS:
+    case IMS_OP_RUBIN_DIFFRACTION:
+    case IMS_OP_RUBIN_DIFFRACTION_OPTICS:
+        orc_apply_rubin_op(P, op_index, ph, photon_offset);
+        break;
+    default:
+        break;
+    }
+}

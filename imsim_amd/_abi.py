@@ -143,6 +143,10 @@ def load():
     if not os.path.exists(_LIB_PATH):
         raise ImsimHipError(f"{_LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(there is no CPU fallback)")
+    # Device pointers and stream handles are exchanged with torch (which only does memory /
+    # stream / RCCL plumbing), so both must sit on ONE HIP runtime instance: torch ships its own
+    # libamdhip64 and must be loaded first, so that this library binds to the same copy.
+    import torch  # noqa: F401
     lib = C.CDLL(_LIB_PATH)
     lib.ims_last_error.restype = C.c_char_p
     for k, st in enumerate(STRUCTS):

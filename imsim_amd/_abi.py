@@ -95,7 +95,7 @@ class Sensor(C.Structure):
                 ("n_abs", c_i32), ("n_tr", c_i32), ("pad", c_i32),
                 ("num_elec", c_d), ("pixel_size", c_d), ("thickness", c_d), ("diff_step", c_d),
                 ("abs_wl_min", c_d), ("abs_wl_step", c_d), ("tr_dr", c_d), ("tr_cx", c_d), ("tr_cy", c_d),
-                ("abs_len", c_vp), ("tr_table", c_vp), ("distortions", c_vp), ("emptypoly", c_vp),
+                ("abs_len", c_vp), ("tr_table", c_vp), ("tr_table2", c_vp), ("distortions", c_vp), ("emptypoly", c_vp),
                 ("n_bf_slots", c_i32), ("pad2", c_i32), ("bf_slots", c_vp),
                 ("bf_boundary", c_vp), ("bf_bounds", c_vp), ("bf_delta", c_vp)]
 
@@ -160,7 +160,7 @@ def load():
     lib.ims_sensor_init_boundaries.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_vp]
     lib.ims_sensor_update_distortions.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_vp]
     lib.ims_image_add.argtypes = [c_vp, c_vp, c_i64, c_vp]
-    lib.ims_last_kernel_ms.argtypes = [C.POINTER(C.c_float)]
+    lib.ims_last_kernel_ms.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.ims_enable_timing.argtypes = [C.c_int]
     lib.ims_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.ims_device_info.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(c_i64), C.POINTER(c_i64)]

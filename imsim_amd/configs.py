@@ -46,3 +46,133 @@ BENCH_CONFIGS = {
         cpu_step=lambda orc, sample: orc.render(sample),
     ),
 }
+
+
+# ---------------------------------------------------------------------------------------------
+# C3: the full photon chain of config/imsim-config.yaml:281-320 + Silicon sensor
+# ---------------------------------------------------------------------------------------------
+import functools
+import math
+import os
+
+from . import optics as opticsmod, sensor as sensormod, treerings, diffraction
+from .engine import SensorSetup, make_slots
+
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+# visit metadata = header of examples/example_instance_catalog.txt:1-20
+VISIT = dict(ra=60.4927, dec=-38.1626, altitude=53.1637, azimuth=114.3933, rottelpos=40.04, rotskypos=200.0,
+             seed=398414, raw_seeing=0.75, airmass=1.2489, exptime=30.0, band="r", latitude=-30.24463,
+             hour_angle=-20.0)
+
+
+@functools.lru_cache(maxsize=4)
+def rubin_optics_struct(nx=4096, ny=4096):
+    """Approximate Rubin telescope + WCS pair fitted to it + spider geometry -> _abi.Optics."""
+    tel = opticsmod.rubin_like_telescope(VISIT["band"])
+    fp = (100.0, 0.0, (nx - 1) / 2.0 + 1.0 - 0.5, 0.0, 100.0, (ny - 1) / 2.0 + 1.0 - 0.5)
+    o = _abi.Optics()
+    rot_tel = math.radians(VISIT["rottelpos"])
+    opticsmod.fill_optics(o, tel, fp, rot_tel)
+    img_wcs, i2f, _ = opticsmod.build_wcs_pair(tel, fp, math.radians(VISIT["ra"]), math.radians(VISIT["dec"]),
+                                               rot_sky=math.radians(VISIT["rotskypos"]), rot_tel_pos=rot_tel,
+                                               nx=nx, ny=ny)
+    o.img_wcs, o.icrf_to_field = img_wcs, i2f
+    diffraction.fill_optics(o, math.radians(VISIT["latitude"]), math.radians(VISIT["azimuth"]),
+                            math.radians(VISIT["altitude"]))
+    return o
+
+
+def local_wcs_inverse(img_wcs, x, y):
+    """Per-object inverse local-WCS jacobian [pixels/arcsec] in GalSim's (u = +west, v = +north)
+    convention, by central differences of the TAN-SIP (what `wcs.local(image_pos)` provides)."""
+    from . import wcs as wcsmod
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    h = 0.5
+    p0 = wcsmod.tansip_pix_to_vec(img_wcs, x, y)
+    z = np.array([0.0, 0.0, 1.0])
+    east = np.cross(z, p0)
+    east /= np.linalg.norm(east, axis=1)[:, None]
+    north = np.cross(p0, east)
+    rad2as = 180.0 / math.pi * 3600.0
+
+    def uv(xx, yy):
+        p = wcsmod.tansip_pix_to_vec(img_wcs, xx, yy)
+        t0 = np.sum(p * p0, axis=1)
+        return -np.sum(p * east, axis=1) / t0 * rad2as, np.sum(p * north, axis=1) / t0 * rad2as
+    ux1, vx1 = uv(x + h, y)
+    ux0, vx0 = uv(x - h, y)
+    uy1, vy1 = uv(x, y + h)
+    uy0, vy0 = uv(x, y - h)
+    dudx, dvdx = (ux1 - ux0) / (2 * h), (vx1 - vx0) / (2 * h)
+    dudy, dvdy = (uy1 - uy0) / (2 * h), (vy1 - vy0) / (2 * h)
+    det = dudx * dvdy - dudy * dvdx
+    return np.stack([dvdy / det, -dudy / det, -dvdx / det, dudx / det], axis=1), p0
+
+
+def dcr_angles(p0, latitude, hour_angle_center, ra_center):
+    """Per-object zenith and parallactic angles (galsim.dcr.zenith_parallactic_angles restated)."""
+    ra = np.arctan2(p0[:, 1], p0[:, 0])
+    dec = np.arcsin(np.clip(p0[:, 2], -1, 1))
+    ha = hour_angle_center + (ra_center - ra)
+    cosz = np.sin(latitude) * np.sin(dec) + np.cos(latitude) * np.cos(dec) * np.cos(ha)
+    zen = np.arccos(np.clip(cosz, -1, 1))
+    q = np.arctan2(np.sin(ha), np.tan(latitude) * np.cos(dec) - np.sin(dec) * np.cos(ha))
+    return np.tan(zen), np.sin(q), np.cos(q)
+
+
+def silicon_setup(nx, ny, xmin=1, ymin=1, model_name="lsst_e2v_50_4", tree_rings=True, extra_regions=(),
+                  det_name="R22_S11", nrecalc=10000, strength=1.0):
+    model = sensormod.load_silicon_model(os.path.join(DATA_DIR, "sensor_models", model_name),
+                                         strength=strength, nrecalc=nrecalc)
+    wl, al = tables.silicon_abs_length_table()
+    kw = {}
+    if tree_rings:
+        tr = treerings.TreeRings(os.path.join(DATA_DIR, "tree_ring_data", "tree_ring_parameters_2026-04-02_R22_S11.txt"))
+        func = tr.get_func(det_name)
+        kw = dict(tr_table=func.f, tr_table2=func.f2, tr_dr=func.dr, tr_center=tr.get_center(det_name))
+    slots = make_slots([(xmin, ymin, nx, ny)] + list(extra_regions))
+    return SensorSetup(model=model, abs_wl=wl, abs_len=al, slots=slots, **kw)
+
+
+def c3_ops(exptime=30.0, base_wavelength=620.0, shift_photons=1.0):
+    """The default photon_ops chain, config/imsim-config.yaml:281-320 (r band: FocusDepth depth 0)."""
+    rad2as = 180.0 / math.pi * 3600.0
+    return [
+        (_abi.IMS_OP_TIME_SAMPLER, 0, [0.0, exptime]),
+        (_abi.IMS_OP_PUPIL_ANNULUS_SAMPLER, 0, [4.18, 2.55]),
+        (_abi.IMS_OP_PHOTON_DCR, 0, [base_wavelength, 69.328, 293.15, 1.067, rad2as]),
+        (_abi.IMS_OP_RUBIN_DIFFRACTION_OPTICS, 0, [shift_photons, 0.0]),
+        (_abi.IMS_OP_FOCUS_DEPTH, 0, [0.0]),
+        (_abi.IMS_OP_REFRACTION, 0, [3.9]),
+    ]
+
+
+def scene_c3(nx=4096, ny=4096, seed=398414, sensor=True, tree_rings=True, extra_regions=()):
+    """C3: phot + TimeSampler/PupilAnnulusSampler/PhotonDCR/RubinDiffractionOptics/FocusDepth/
+    Refraction, Kolmogorov (+) Gaussian analytic PSF (atmPSF.py:490-538), Silicon lsst_e2v_50_4 with
+    brighter-fatter and the R22_S11 tree rings."""
+    r2, cdf = standard_tables()
+    sed, wl_eff = r_band_sed_table()
+    fwhm_atm, fwhm_sys = catalog.kolmogorov_gaussian_fwhm(VISIT["airmass"], VISIT["raw_seeing"], VISIT["band"])
+    psf = [(_abi.IMS_PSF_RADIAL, 2, fwhm_atm, 0.0, 1.0),
+           (_abi.IMS_PSF_GAUSSIAN, 0, fwhm_sys / 2.3548200450309493, 0.0, 1.0)]
+    sc = Scene(nx=nx, ny=ny, seed=seed, psf=psf, ops=c3_ops(VISIT["exptime"], wl_eff), radial_r2=r2, radial_cdf=cdf,
+               sed_tables=sed, optics=rubin_optics_struct(nx, ny))
+    if sensor:
+        sc.sensor = silicon_setup(nx, ny, tree_rings=tree_rings, extra_regions=extra_regions)
+    return sc
+
+
+def c3_objects(cat, phot, scene, nrecalc=10000, bf_private=True):
+    """Object table for C3: per-object local WCS, DCR angles, and a private brighter-fatter region
+    for every object whose own charge will trigger a pixel-boundary recalculation (> nrecalc)."""
+    winv, p0 = local_wcs_inverse(scene.optics.img_wcs, cat["x"], cat["y"])
+    tanz, sinp, cosp = dcr_angles(p0, math.radians(VISIT["latitude"]), math.radians(VISIT["hour_angle"]),
+                                  math.radians(VISIT["ra"]))
+    objects, sizes = catalog.build_object_table(cat, phot, airmass=VISIT["airmass"], raw_seeing=VISIT["raw_seeing"])
+    keep = phot > 0
+    objects["winv"] = winv[keep]
+    objects["dcr_tanz"], objects["dcr_sinp"], objects["dcr_cosp"] = tanz[keep], sinp[keep], cosp[keep]
+    return objects, sizes

@@ -436,19 +436,18 @@ struct SlotView {
 };
 IMS_DEV int64_t cell_index(const SlotView& sl, int i, int j) { return sl.offset + (int64_t)j * (sl.nx + 1) + i; }
 
-// vertex k (0..nv-1) of pixel (i,j), counter-clockwise from the lower-left corner
+// vertex k (0..nv-1) of pixel (i,j), counter-clockwise from the lower-left corner.  A cell owns
+// its bottom row (LL corner, bottom points, LR corner) and its left-edge points.
 IMS_DEV void polygon_vertex(const ims_sensor_t& s, const SlotView& sl, int i, int j, int k, double zfactor,
                             double& vx, double& vy)
 {
-    const int nV = s.num_vertices, npo = 2 * nV + 1;
+    const int nV = s.num_vertices, npo = 2 * nV + 2;
     int ci = i, cj = j, q;
     double ax = 0.0, ay = 0.0;
-    if (k <= nV) { q = k; }                                                   // LL corner, bottom points
-    else if (k <= 2 * nV + 1) { ci = i + 1; ax = 1.0; q = (k == nV + 1) ? 0 : nV + 1 + (k - nV - 2); }   // LR corner, right edge
-    else if (k == 2 * nV + 2) { ci = i + 1; cj = j + 1; ax = 1.0; ay = 1.0; q = 0; }                     // UR corner
-    else if (k <= 3 * nV + 2) { cj = j + 1; ay = 1.0; q = 1 + (nV - 1 - (k - 2 * nV - 3)); }             // top edge, right->left
-    else if (k == 3 * nV + 3) { cj = j + 1; ay = 1.0; q = 0; }                                           // UL corner
-    else { q = nV + 1 + (nV - 1 - (k - 3 * nV - 4)); }                                                   // left edge, top->bottom
+    if (k <= nV + 1) { q = k; }                                                     // own bottom row
+    else if (k <= 2 * nV + 1) { ci = i + 1; ax = 1.0; q = nV + 2 + (k - nV - 2); }  // right edge = left edge of the cell to the right
+    else if (k <= 3 * nV + 3) { cj = j + 1; ay = 1.0; q = nV + 1 - (k - 2 * nV - 2); }  // top row = bottom row of the cell above, reversed
+    else { q = nV + 2 + (nV - 1 - (k - 3 * nV - 4)); }                              // own left edge, top->bottom
     const double* pt = s.bf_boundary + (cell_index(sl, ci, cj) * npo + q) * 2;
     vx = pt[0] + ax; vy = pt[1] + ay;
     if (zfactor != 1.0) {

@@ -26,20 +26,30 @@ static int hip_err(hipError_t e, const char* what)
 }
 #define HIP_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_err(e_, #call); } while (0)
 
+// Timing of the dominant kernel: every ims_shoot_accumulate launch between ims_enable_timing(1)
+// and the query is bracketed by a hipEvent pair on the launch stream.
+#include <vector>
 static bool g_timing = false;
-static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
-static bool g_ev_valid = false;
+static std::vector<hipEvent_t> g_events;   // pairs
+static size_t g_events_used = 0;
 
 struct LaunchTimer {
     hipStream_t st;
-    explicit LaunchTimer(hipStream_t s) : st(s)
+    size_t slot;
+    explicit LaunchTimer(hipStream_t s) : st(s), slot(0)
     {
         if (g_timing) {
-            if (!g_ev0) { (void)hipEventCreate(&g_ev0); (void)hipEventCreate(&g_ev1); }
-            (void)hipEventRecord(g_ev0, st);
+            if (g_events_used + 2 > g_events.size()) {
+                hipEvent_t a, b;
+                (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+                g_events.push_back(a); g_events.push_back(b);
+            }
+            slot = g_events_used;
+            g_events_used += 2;
+            (void)hipEventRecord(g_events[slot], st);
         }
     }
-    ~LaunchTimer() { if (g_timing) { (void)hipEventRecord(g_ev1, st); g_ev_valid = true; } }
+    ~LaunchTimer() { if (g_timing) (void)hipEventRecord(g_events[slot + 1], st); }
 };
 
 // ---------------- segment -> (object, first photon) ----------------
@@ -197,7 +207,8 @@ __device__ __forceinline__ void empty_owned(const ims_sensor_t& s, int n, double
     const int nV = s.num_vertices;
     if (n == 0) { x = 0.0; y = 0.0; return; }
     if (n <= nV) { x = s.emptypoly[2 * n]; y = 0.0; return; }
-    const int m = n - nV - 1;
+    if (n == nV + 1) { x = 1.0; y = 0.0; return; }
+    const int m = n - nV - 2;
     x = 0.0; y = s.emptypoly[2 * (1 + m)];
 }
 
@@ -207,45 +218,70 @@ __device__ __forceinline__ double treering_shift(const ims_sensor_t& s, double r
     const double f = r / s.tr_dr;
     if (!(f > 0.0) || f >= (double)(s.n_tr - 1)) return 0.0;
     const int i = (int)f;
-    const double a = f - (double)i;
-    const double v0 = s.tr_table[i];
-    return v0 + a * (s.tr_table[i + 1] - v0);
+    const double b = f - (double)i;
+    const double v0 = s.tr_table[i], v1 = s.tr_table[i + 1];
+    if (s.tr_table2 == nullptr) return v0 + b * (v1 - v0);
+    const double a = 1.0 - b;
+    const double h2 = s.tr_dr * s.tr_dr / 6.0;
+    return a * v0 + b * v1 + ((a * a * a - a) * s.tr_table2[i] + (b * b * b - b) * s.tr_table2[i + 1]) * h2;
 }
 
-// one thread per owner cell of a slot
-__global__ __launch_bounds__(256) void k_init_boundaries(const ims_sensor_t* __restrict__ sp, int slot)
+// The boundary kernels run over a RANGE of slots in one launch: thread -> global owner cell ->
+// slot by binary search over the packed cell offsets (wave-uniform except at slot seams).
+struct CellRef { SlotView sl; int i, j; int64_t c; bool valid; };
+
+__device__ __forceinline__ CellRef locate_cell(const ims_sensor_t& s, int first_slot, int n_slots, int64_t cell_begin,
+                                               int64_t cell_count)
+{
+    CellRef r;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    r.valid = t < cell_count;
+    if (!r.valid) return r;
+    const int64_t g = cell_begin + t;
+    int lo = first_slot, hi = first_slot + n_slots;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s.bf_slots[mid].offset <= g) lo = mid; else hi = mid;
+    }
+    const ims_bf_slot_t bs = s.bf_slots[lo];
+    r.sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
+    r.c = g - bs.offset;
+    r.i = (int)(r.c % (bs.nx + 1));
+    r.j = (int)(r.c / (bs.nx + 1));
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_init_boundaries(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
+                                                         int64_t cell_begin, int64_t cell_count)
 {
     const ims_sensor_t& s = *sp;
-    const ims_bf_slot_t bs = s.bf_slots[slot];
-    const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
-    const int64_t ncell = (int64_t)(sl.nx + 1) * (sl.ny + 1);
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncell) return;
-    const int i = (int)(c % (sl.nx + 1)), j = (int)(c / (sl.nx + 1));
-    const int npo = 2 * s.num_vertices + 1;
-    double* pts = s.bf_boundary + (sl.offset + c) * npo * 2;
+    const CellRef r = locate_cell(s, first_slot, n_slots, cell_begin, cell_count);
+    if (!r.valid) return;
+    const SlotView& sl = r.sl;
+    const int npo = 2 * s.num_vertices + 2;
+    double* pts = s.bf_boundary + (sl.offset + r.c) * npo * 2;
     for (int n = 0; n < npo; ++n) {
         double ex, ey;
         empty_owned(s, n, ex, ey);
-        const double tx = ((double)(sl.xmin + i) - 0.5 + ex) - s.tr_cx;
-        const double ty = ((double)(sl.ymin + j) - 0.5 + ey) - s.tr_cy;
-        const double r = sqrt(tx * tx + ty * ty);
-        const double sh = treering_shift(s, r);
+        const double tx = ((double)(sl.xmin + r.i) - 0.5 + ex) - s.tr_cx;
+        const double ty = ((double)(sl.ymin + r.j) - 0.5 + ey) - s.tr_cy;
+        const double rr = sqrt(tx * tx + ty * ty);
+        const double sh = treering_shift(s, rr);
         double px = ex, py = ey;
-        if (r > 0.0 && sh != 0.0) { px = ex + sh * tx / r; py = ey + sh * ty / r; }
+        if (rr > 0.0 && sh != 0.0) { px = ex + sh * tx / rr; py = ey + sh * ty / rr; }
         pts[2 * n] = px; pts[2 * n + 1] = py;
     }
-    s.bf_delta[sl.offset + c] = 0.0f;
+    s.bf_delta[sl.offset + r.c] = 0.0f;
 }
 
-__global__ __launch_bounds__(256) void k_refresh_bounds(const ims_sensor_t* __restrict__ sp, int slot)
+__global__ __launch_bounds__(256) void k_refresh_bounds(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
+                                                        int64_t cell_begin, int64_t cell_count)
 {
     const ims_sensor_t& s = *sp;
-    const ims_bf_slot_t bs = s.bf_slots[slot];
-    const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= (int64_t)(sl.nx + 1) * (sl.ny + 1)) return;
-    const int i = (int)(c % (sl.nx + 1)), j = (int)(c / (sl.nx + 1));
+    const CellRef r = locate_cell(s, first_slot, n_slots, cell_begin, cell_count);
+    if (!r.valid) return;
+    const SlotView& sl = r.sl;
+    const int i = r.i, j = r.j;
     if (i >= sl.nx || j >= sl.ny) return;
     const int nV = s.num_vertices, nv = 4 * nV + 4;
     double ixmin = 0.0, ixmax = 1.0, iymin = 0.0, iymax = 1.0;
@@ -265,31 +301,31 @@ __global__ __launch_bounds__(256) void k_refresh_bounds(const ims_sensor_t* __re
         if (k >= 3 * nV + 3) { if (vx > ixmin) ixmin = vx; }
     }
     if (v0x > ixmin) ixmin = v0x;
-    double* b = s.bf_bounds + (sl.offset + c) * 8;
+    double* b = s.bf_bounds + (sl.offset + r.c) * 8;
     b[0] = ixmin; b[1] = ixmax; b[2] = iymin; b[3] = iymax;
     b[4] = oxmin; b[5] = oxmax; b[6] = oymin; b[7] = oymax;
 }
 
 __device__ __forceinline__ int owned_to_vertex(int nV, int n)
 {
-    if (n <= nV) return n;
-    const int m = n - nV - 1;
+    if (n <= nV + 1) return n;
+    const int m = n - nV - 2;
     return 3 * nV + 4 + (nV - 1 - m);
 }
 
 // Silicon::updatePixelDistortions: one thread per owner cell gathers the charged neighbours in
 // a fixed order (so the result is bit-reproducible) and adds the scaled tabulated displacements.
-__global__ __launch_bounds__(256) void k_update_distortions(const ims_sensor_t* __restrict__ sp, int slot)
+__global__ __launch_bounds__(256) void k_update_distortions(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
+                                                            int64_t cell_begin, int64_t cell_count)
 {
     const ims_sensor_t& s = *sp;
-    const ims_bf_slot_t bs = s.bf_slots[slot];
-    const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= (int64_t)(sl.nx + 1) * (sl.ny + 1)) return;
-    const int i = (int)(c % (sl.nx + 1)), j = (int)(c / (sl.nx + 1));
-    const int nV = s.num_vertices, npo = 2 * nV + 1, nv = 4 * nV + 4, q = s.qdist;
+    const CellRef r = locate_cell(s, first_slot, n_slots, cell_begin, cell_count);
+    if (!r.valid) return;
+    const SlotView& sl = r.sl;
+    const int i = r.i, j = r.j;
+    const int nV = s.num_vertices, npo = 2 * nV + 2, nv = 4 * nV + 4, q = s.qdist;
     const int cx = (s.nx - 1) / 2, cy = (s.ny - 1) / 2;
-    double* pts = s.bf_boundary + (sl.offset + c) * npo * 2;
+    double* pts = s.bf_boundary + (sl.offset + r.c) * npo * 2;
     for (int dj = -q; dj <= q + 1; ++dj) {
         const int sj = j - dj;
         if (sj < 0 || sj >= sl.ny) continue;
@@ -301,8 +337,8 @@ __global__ __launch_bounds__(256) void k_update_distortions(const ims_sensor_t* 
             const double w = charge / s.num_elec;
             const double* dist = s.distortions + ((int64_t)(di + cx) * s.ny + (dj + cy)) * nv * 2;
             for (int n = 0; n < npo; ++n) {
-                if (n >= 1 && n <= nV && di == q + 1) continue;
-                if (n > nV && dj == q + 1) continue;
+                if (n <= nV + 1 && di == q + 1) continue;
+                if (n > nV + 1 && dj == q + 1) continue;
                 const int vtx = owned_to_vertex(nV, n);
                 pts[2 * n] = pts[2 * n] + dist[2 * vtx] * w;
                 pts[2 * n + 1] = pts[2 * n + 1] + dist[2 * vtx + 1] * w;
@@ -311,13 +347,11 @@ __global__ __launch_bounds__(256) void k_update_distortions(const ims_sensor_t* 
     }
 }
 
-__global__ __launch_bounds__(256) void k_zero_delta(const ims_sensor_t* __restrict__ sp, int slot)
+__global__ __launch_bounds__(256) void k_zero_delta(const ims_sensor_t* __restrict__ sp, int64_t cell_begin, int64_t cell_count)
 {
-    const ims_sensor_t& s = *sp;
-    const ims_bf_slot_t bs = s.bf_slots[slot];
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= (int64_t)(bs.nx + 1) * (bs.ny + 1)) return;
-    s.bf_delta[bs.offset + c] = 0.0f;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= cell_count) return;
+    sp->bf_delta[cell_begin + t] = 0.0f;
 }
 
 __global__ __launch_bounds__(256) void k_image_add(float* __restrict__ dst, const float* __restrict__ src, int64_t n)
@@ -393,14 +427,22 @@ int ims_device_info(int device, int* n_cu, int* n_xcd, int64_t* lds_bytes, int64
     return IMS_OK;
 }
 
-int ims_enable_timing(int on) { g_timing = (on != 0); g_ev_valid = false; return IMS_OK; }
+int ims_enable_timing(int on) { g_timing = (on != 0); g_events_used = 0; return IMS_OK; }
 
-int ims_last_kernel_ms(float* ms)
+int ims_last_kernel_ms(float* ms, int* n_launches)
 {
     if (!ms) return set_err(IMS_ERR_ARG, "ms is NULL");
-    if (!g_ev_valid) return set_err(IMS_ERR_ARG, "no timed launch recorded");
-    HIP_TRY(hipEventSynchronize(g_ev1));
-    HIP_TRY(hipEventElapsedTime(ms, g_ev0, g_ev1));
+    if (g_events_used == 0) return set_err(IMS_ERR_ARG, "no timed launch recorded");
+    float total = 0.0f;
+    for (size_t k = 0; k < g_events_used; k += 2) {
+        float t = 0.0f;
+        HIP_TRY(hipEventSynchronize(g_events[k + 1]));
+        HIP_TRY(hipEventElapsedTime(&t, g_events[k], g_events[k + 1]));
+        total += t;
+    }
+    *ms = total;
+    if (n_launches) *n_launches = (int)(g_events_used / 2);
+    g_events_used = 0;
     return IMS_OK;
 }
 
@@ -428,7 +470,6 @@ int ims_shoot_photons(const ims_render_params_t* params, const int64_t* photon_o
     if (params->n_segments == 0) return IMS_OK;
     hipStream_t st = (hipStream_t)stream;
     {
-        LaunchTimer tm(st);
         hipLaunchKernelGGL(k_shoot_photons, dim3(grid_for_segments(params->n_segments)), dim3(256), 0, st,
                            *params, photon_offset, *pool);
     }
@@ -452,7 +493,6 @@ int ims_apply_ops(const ims_render_params_t* params, const int64_t* photon_offse
     if (pool->n == 0 || params->n_ops == 0) return IMS_OK;
     hipStream_t st = (hipStream_t)stream;
     {
-        LaunchTimer tm(st);
         hipLaunchKernelGGL(k_apply_ops, dim3(grid_for_pool(pool->n)), dim3(256), 0, st, *params, photon_offset, *pool);
     }
     HIP_TRY(hipGetLastError());
@@ -469,7 +509,6 @@ int ims_accumulate(const ims_render_params_t* params, const int64_t* photon_offs
     if (pool->n == 0) return IMS_OK;
     hipStream_t st = (hipStream_t)stream;
     {
-        LaunchTimer tm(st);
         hipLaunchKernelGGL(k_accumulate, dim3(grid_for_pool(pool->n)), dim3(256), 0, st, *params, photon_offset, *pool,
                            pixel_index_out);
     }
@@ -477,11 +516,14 @@ int ims_accumulate(const ims_render_params_t* params, const int64_t* photon_offs
     return IMS_OK;
 }
 
-static int slot_cells(const ims_sensor_t* host, int slot, int64_t* cells)
+static int slot_range_cells(const ims_sensor_t* host, int first, int n, int64_t* begin, int64_t* count)
 {
     if (!host || !host->bf_slots) return set_err(IMS_ERR_ARG, "sensor_host/bf_slots is NULL (host copy of the slot table required)");
-    if (slot < 0 || slot >= host->n_bf_slots) return set_err(IMS_ERR_ARG, "slot out of range");
-    *cells = (int64_t)(host->bf_slots[slot].nx + 1) * (host->bf_slots[slot].ny + 1);
+    if (n <= 0 || first < 0 || first + n > host->n_bf_slots) return set_err(IMS_ERR_ARG, "slot range out of bounds");
+    const ims_bf_slot_t& a = host->bf_slots[first];
+    const ims_bf_slot_t& z = host->bf_slots[first + n - 1];
+    *begin = a.offset;
+    *count = z.offset + (int64_t)(z.nx + 1) * (z.ny + 1) - a.offset;
     return IMS_OK;
 }
 
@@ -489,15 +531,14 @@ int ims_sensor_init_boundaries(const ims_sensor_t* sensor_dev, const ims_sensor_
                                int32_t first_slot, int32_t n_slots, void* stream)
 {
     if (!sensor_dev) return set_err(IMS_ERR_ARG, "sensor_dev is NULL");
+    if (n_slots == 0) return IMS_OK;
+    int64_t begin, count;
+    int rc = slot_range_cells(sensor_host, first_slot, n_slots, &begin, &count);
+    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    for (int k = first_slot; k < first_slot + n_slots; ++k) {
-        int64_t cells;
-        int rc = slot_cells(sensor_host, k, &cells);
-        if (rc) return rc;
-        const unsigned g = (unsigned)((cells + 255) / 256);
-        hipLaunchKernelGGL(k_init_boundaries, dim3(g), dim3(256), 0, st, sensor_dev, k);
-        hipLaunchKernelGGL(k_refresh_bounds, dim3(g), dim3(256), 0, st, sensor_dev, k);
-    }
+    const unsigned g = (unsigned)((count + 255) / 256);
+    hipLaunchKernelGGL(k_init_boundaries, dim3(g), dim3(256), 0, st, sensor_dev, first_slot, n_slots, begin, count);
+    hipLaunchKernelGGL(k_refresh_bounds, dim3(g), dim3(256), 0, st, sensor_dev, first_slot, n_slots, begin, count);
     HIP_TRY(hipGetLastError());
     return IMS_OK;
 }
@@ -506,15 +547,16 @@ int ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sens
                                   int32_t first_slot, int32_t n_slots, void* stream)
 {
     if (!sensor_dev) return set_err(IMS_ERR_ARG, "sensor_dev is NULL");
+    if (n_slots == 0) return IMS_OK;
+    int64_t begin, count;
+    int rc = slot_range_cells(sensor_host, first_slot, n_slots, &begin, &count);
+    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    for (int k = first_slot; k < first_slot + n_slots; ++k) {
-        int64_t cells;
-        int rc = slot_cells(sensor_host, k, &cells);
-        if (rc) return rc;
-        const unsigned g = (unsigned)((cells + 255) / 256);
-        hipLaunchKernelGGL(k_update_distortions, dim3(g), dim3(256), 0, st, sensor_dev, k);
-        hipLaunchKernelGGL(k_zero_delta, dim3(g), dim3(256), 0, st, sensor_dev, k);
-        hipLaunchKernelGGL(k_refresh_bounds, dim3(g), dim3(256), 0, st, sensor_dev, k);
+    const unsigned g = (unsigned)((count + 255) / 256);
+    {
+        hipLaunchKernelGGL(k_update_distortions, dim3(g), dim3(256), 0, st, sensor_dev, first_slot, n_slots, begin, count);
+        hipLaunchKernelGGL(k_zero_delta, dim3(g), dim3(256), 0, st, sensor_dev, begin, count);
+        hipLaunchKernelGGL(k_refresh_bounds, dim3(g), dim3(256), 0, st, sensor_dev, first_slot, n_slots, begin, count);
     }
     HIP_TRY(hipGetLastError());
     return IMS_OK;

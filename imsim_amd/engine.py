@@ -23,12 +23,15 @@ class SensorSetup:
     abs_wl: np.ndarray                    # nm, uniform grid
     abs_len: np.ndarray                   # micron
     tr_table: Optional[np.ndarray] = None  # f(r) on a uniform grid starting at 0
+    tr_table2: Optional[np.ndarray] = None  # spline second derivatives (None -> linear interpolation)
     tr_dr: float = 3.0
     tr_center: tuple = (0.0, 0.0)
-    slots: Optional[np.ndarray] = None    # BFSLOT_DTYPE array
+    slots: Optional[np.ndarray] = None    # BFSLOT_DTYPE array of the static regions (slot 0 = whole CCD)
+    scratch_cells: int = 0                # owner-cell capacity for private regions of bright objects
+    max_slots: int = 4096
 
     def owned_points(self):
-        return 2 * self.model.num_vertices + 1
+        return 2 * self.model.num_vertices + 2
 
     def total_cells(self):
         s = self.slots
@@ -66,10 +69,48 @@ class Scene:
     track_static_delta: int = 0
 
 
+def plan_bf_groups(objects, nrecalc, n_static, static_cells, scratch_cells, max_slots):
+    """LSST_Image mode: objects whose own charge triggers pixel-boundary recalculations
+    (n_phot > nrecalc) need a private boundary region the size of their stamp.  Returns
+    (normal_index, groups) with groups = [(index_array sorted by n_phot desc, slots_array)], each
+    group fitting the scratch capacity."""
+    n = objects["n_phot"]
+    bright = (n > nrecalc) & ((objects["flags"] & _abi.IMS_OBJ_FAINT) == 0) if nrecalc > 0 else np.zeros(len(n), bool)
+    normal = np.flatnonzero(~bright)
+    idx = np.flatnonzero(bright)
+    idx = idx[np.argsort(-n[idx], kind="stable")]
+    groups = []
+    start = 0
+    while start < len(idx):
+        cells, k = 0, start
+        regions = []
+        while k < len(idx) and len(regions) < max_slots - n_static:
+            o = objects[idx[k]]
+            nx = int(o["stamp_xmax"]) - int(o["stamp_xmin"]) + 1
+            ny = int(o["stamp_ymax"]) - int(o["stamp_ymin"]) + 1
+            c = (nx + 1) * (ny + 1)
+            if cells + c > scratch_cells:
+                break
+            regions.append((int(o["stamp_xmin"]), int(o["stamp_ymin"]), nx, ny))
+            cells += c
+            k += 1
+        if k == start:
+            raise ValueError("brighter-fatter scratch capacity too small for one stamp; raise SensorSetup.scratch_cells")
+        slots = make_slots(regions)
+        slots["offset"] += static_cells
+        groups.append((idx[start:k], slots))
+        start = k
+    return normal, groups
+
+
 class HostMem:
     """Pointer provider over numpy arrays (used by the test-side oracle binding, never by the product)."""
     def __init__(self):
         self.keep = []
+
+    def write(self, handle, raw):
+        flat = handle.view(np.uint8).reshape(-1)
+        flat[:raw.size] = raw
 
     def put(self, arr, dtype=None):
         a = np.ascontiguousarray(arr, dtype=dtype)
@@ -109,6 +150,9 @@ class DeviceMem:
         t = self.torch.zeros(max(nbytes, 8), dtype=self.torch.uint8, device=self.device)
         self.keep.append(t)
         return t, t.data_ptr()
+
+    def write(self, handle, raw):
+        handle[:raw.size].copy_(self.torch.from_numpy(raw))
 
 
 def segment_prefix(n_phot, seg_size):
@@ -175,16 +219,22 @@ class BoundScene:
             S.n_tr, S.tr_dr = len(ss.tr_table), ss.tr_dr
             S.tr_cx, S.tr_cy = float(ss.tr_center[0]), float(ss.tr_center[1])
             _, S.tr_table = self.mem.put(ss.tr_table, np.float64)
+            if ss.tr_table2 is not None:
+                _, S.tr_table2 = self.mem.put(ss.tr_table2, np.float64)
         else:
             S.n_tr, S.tr_dr = 0, 1.0
         _, S.distortions = self.mem.put(m.distortions, np.float64)
         _, S.emptypoly = self.mem.put(m.emptypoly, np.float64)
         slots = ss.slots if ss.slots is not None else make_slots([])
+        self.n_static_slots = len(slots)
+        self.static_cells = ss.total_cells()
+        self.slot_capacity = max(len(slots), ss.max_slots)
         S.n_bf_slots = len(slots)
-        cells = ss.total_cells()
+        cells = self.static_cells + int(ss.scratch_cells)
         npo = ss.owned_points()
-        slots_host = np.ascontiguousarray(slots)
-        _, S.bf_slots = self.mem.put(slots_host.view(np.uint8))
+        slots_host = np.zeros(self.slot_capacity, dtype=BFSLOT_DTYPE)
+        slots_host[:len(slots)] = slots
+        self._slots_buf, S.bf_slots = self.mem.put(slots_host.view(np.uint8))
         self.sensor_arrays["boundary"], S.bf_boundary = self.mem.zeros(cells * npo * 2, np.float64)
         self.sensor_arrays["bounds"], S.bf_bounds = self.mem.zeros(cells * 8, np.float64)
         self.sensor_arrays["delta"], S.bf_delta = self.mem.zeros(cells, np.float32)
@@ -194,8 +244,22 @@ class BoundScene:
         Sh.bf_slots = slots_host.ctypes.data
         self.sensor_host = Sh
         self.sensor_struct = S
-        _, P.sensor = self.mem.put_struct(S)
+        self._sensor_buf, P.sensor = self.mem.put_struct(S)
         self.sensor_dev_ptr = P.sensor
+
+    def set_private_slots(self, slots):
+        """Replace the private (non-static) part of the slot table."""
+        n0 = self.n_static_slots
+        if n0 + len(slots) > self.slot_capacity:
+            raise ValueError("too many brighter-fatter slots")
+        self._slots_host[n0:n0 + len(slots)] = slots
+        self.mem.write(self._slots_buf, self._slots_host.view(np.uint8).reshape(-1))
+        self.sensor_struct.n_bf_slots = n0 + len(slots)
+        self.sensor_host.n_bf_slots = n0 + len(slots)
+        if isinstance(self._sensor_buf, Sensor):
+            self._sensor_buf.n_bf_slots = n0 + len(slots)
+        else:
+            self.mem.write(self._sensor_buf, np.frombuffer(bytes(self.sensor_struct), dtype=np.uint8).copy())
 
     def params(self, objects_ptr, n_objects, seg_prefix_ptr, n_segments, image_ptr, realized_ptr=None):
         P = RenderParams.from_buffer_copy(bytes(self.base_params))
@@ -269,6 +333,53 @@ class Renderer:
                               self.image.data_ptr(), realized.data_ptr() if realized is not None else None)
         _abi.check(self.lib.ims_shoot_accumulate(C.byref(P), self._stream()), "ims_shoot_accumulate")
         self._keep = (obj_t, pre_t)
+
+    def render_lsst_image(self, objects, nrecalc=None, realized=None):
+        """LSST_Image + LSST_Silicon semantics (imsim/lsst_image.py:342-368, imsim/stamp.py:558-573):
+        every object accumulates on its own stamp, so brighter-fatter only sees the object's own
+        charge.  Objects below `nrecalc` photons never trigger a boundary update and share the
+        static (tree-ring) CCD boundaries in ONE launch; brighter objects get a private boundary
+        region and are advanced together in rounds of `nrecalc` photons, with one batched
+        updatePixelDistortions between rounds."""
+        ss = self.scene.sensor
+        objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
+        if ss is None:
+            return self.render(objects, realized)
+        if nrecalc is None:
+            nrecalc = ss.model.nrecalc
+        b = self.bound
+        normal, groups = plan_bf_groups(objects, nrecalc, b.n_static_slots, b.static_cells, ss.scratch_cells,
+                                        b.slot_capacity)
+
+        def run(part, index):
+            tmp = None
+            if realized is not None:
+                tmp = self.torch.zeros(len(part), dtype=self.torch.float64, device=self.device)
+            self.render(part, tmp)
+            if realized is not None:
+                realized.index_add_(0, self.torch.from_numpy(np.asarray(index, dtype=np.int64)).to(self.device), tmp)
+
+        if len(normal):
+            part = objects[normal].copy()
+            part["bf_state"] = 0
+            run(part, normal)
+        for idx, slots in groups:
+            b.set_private_slots(slots)
+            n0 = b.n_static_slots
+            self.init_boundaries(n0, len(slots))
+            grp = objects[idx]
+            total = grp["n_phot"].copy()
+            rounds = int((total.max() + nrecalc - 1) // nrecalc)
+            for r in range(rounds):
+                n_act = int(np.count_nonzero(total > r * nrecalc))
+                part = grp[:n_act].copy()
+                part["phot_first"] = grp["phot_first"][:n_act] + r * nrecalc
+                part["n_phot"] = np.minimum(nrecalc, total[:n_act] - r * nrecalc)
+                part["bf_state"] = n0 + np.arange(n_act)
+                run(part, idx[:n_act])
+                n_cont = int(np.count_nonzero(total > (r + 1) * nrecalc))
+                if n_cont:
+                    self.update_distortions(n0, n_cont)
 
     def prepared(self, objects):
         """Upload an object table once; returns a zero-argument callable that launches the fused

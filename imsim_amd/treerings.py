@@ -101,15 +101,20 @@ class TreeRings:
 
 
 class TreeRingTable:
-    """Uniform lookup table with linear interpolation (the LookupTable the sensor consumes)."""
+    """Uniform lookup table with natural-cubic-spline interpolation: what
+    `galsim.LookupTable.from_func` builds by default (interpolant='spline') and the sensor consumes.
+    `f2` holds the spline's second derivatives at the knots for the device-side evaluation."""
 
     def __init__(self, r, f):
+        from scipy.interpolate import CubicSpline
         self.r = np.asarray(r, dtype=np.float64)
         self.f = np.ascontiguousarray(f, dtype=np.float64)
         self.dr = float(self.r[1] - self.r[0])
+        self._spline = CubicSpline(self.r, self.f, bc_type="natural")
+        self.f2 = np.ascontiguousarray(self._spline(self.r, 2), dtype=np.float64)
 
     def __call__(self, r):
-        return np.interp(r, self.r, self.f)
+        return self._spline(r)
 
 
 def simple_treerings(amplitude=0.5, period=100.0, r_max=8000.0, dr=3.0):

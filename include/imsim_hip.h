@@ -210,13 +210,15 @@ typedef struct ims_sensor {
     double  tr_cx, tr_cy;        /* tree-ring centre in CCD pixel coordinates (imsim/treerings.py:174-189) */
     const double* abs_len;       /* [n_abs] micron */
     const double* tr_table;      /* [n_tr] radial shift f(r) [pixels] */
+    const double* tr_table2;     /* [n_tr] second derivatives of the natural cubic spline through tr_table (galsim.LookupTable.from_func
+                                    default interpolant, imsim/treerings.py:192-194); NULL = linear interpolation */
     const double* distortions;   /* [nx][ny][nv][2] vertex displacement (pixel units) per num_elec of charge in the centre pixel */
     const double* emptypoly;     /* [nv][2] undistorted polygon, counter-clockwise */
     /* brighter-fatter state */
     int32_t n_bf_slots;
     int32_t pad2;
     const ims_bf_slot_t* bf_slots;
-    double* bf_boundary;         /* per owner cell of every slot: [2*num_vertices+1][2] owned boundary points (LL corner, bottom pts, left pts) */
+    double* bf_boundary;         /* per owner cell of every slot: [2*num_vertices+2][2] owned boundary points (LL corner, bottom pts, LR corner, left pts) */
     double* bf_bounds;           /* per owner cell (one 64-byte line): inner xmin,xmax,ymin,ymax, outer xmin,xmax,ymin,ymax */
     float*  bf_delta;            /* per owner cell: charge accumulated since the last recalc */
 } ims_sensor_t;
@@ -285,8 +287,11 @@ int  ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sen
 /* ---- image helpers ---- */
 int  ims_image_add(float* dst, const float* src, int64_t n, void* stream);
 
-/* ---- last-launch timing (hipEvent pair recorded around the most recent hot-path launch) ---- */
-int  ims_last_kernel_ms(float* ms);
+/* ---- timing of the dominant kernel ----
+ * After ims_enable_timing(1) every ims_shoot_accumulate launch is bracketed by a hipEvent pair on its
+ * stream.  ims_last_kernel_ms returns the SUM of their durations and their count since the last query
+ * (and resets the accumulation). */
+int  ims_last_kernel_ms(float* ms, int* n_launches);
 int  ims_enable_timing(int on);
 
 /* ---- numerics probe used by the parity tests: evaluates the spec's elementary functions on device ----

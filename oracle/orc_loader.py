@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 from imsim_amd import _abi
-from imsim_amd.engine import BoundScene, HostMem, segment_prefix
+from imsim_amd.engine import BoundScene, HostMem, segment_prefix, plan_bf_groups
 from imsim_amd._abi import OBJECT_DTYPE, Photons
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -108,6 +108,37 @@ class OracleScene:
         rc = self.lib.orc_render_objects(C.byref(P), int(nrecalc), self.image.ctypes.data,
                                          realized.ctypes.data if realized is not None else None)
         assert rc == 0
+
+    def render_lsst_image(self, objects, nrecalc=None, realized=None):
+        """CPU counterpart of Renderer.render_lsst_image: the reference's order, one object at a
+        time, recalculating that object's pixel boundaries every `nrecalc` photons."""
+        ss = self.scene.sensor
+        objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
+        if ss is None:
+            return self.render(objects, 0, realized)
+        if nrecalc is None:
+            nrecalc = ss.model.nrecalc
+        b = self.bound
+        normal, groups = plan_bf_groups(objects, nrecalc, b.n_static_slots, b.static_cells, ss.scratch_cells,
+                                        b.slot_capacity)
+
+        def run(part, index):
+            tmp = np.zeros(len(part)) if realized is not None else None
+            self.render(part, nrecalc, tmp)
+            if realized is not None:
+                np.add.at(realized, index, tmp)
+
+        if len(normal):
+            part = objects[normal].copy()
+            part["bf_state"] = 0
+            run(part, normal)
+        for idx, slots in groups:
+            b.set_private_slots(slots)
+            n0 = b.n_static_slots
+            self.init_boundaries(n0, len(slots))
+            part = objects[idx].copy()
+            part["bf_state"] = n0 + np.arange(len(idx))
+            run(part, idx)
 
     def shoot_pool(self, objects):
         objects, prefix = self._objects(objects)

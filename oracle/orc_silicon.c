@@ -10,15 +10,18 @@
  * Pinned statistically by tests/test_sensor_models.py and tests/test_flats.py criteria of the
  * reference (SURVEY.md 8c i, vii).  Bit level: parity unpinned.
  *
- * Pixel-boundary storage: every owner cell (i,j) of a region owns its lower-left corner, the
- * num_vertices interior points of its bottom edge (left to right) and of its left edge (bottom to
- * top), in pixel-local coordinates (undistorted lower-left corner = (0,0)).  A region of nx*ny
- * pixels has (nx+1)*(ny+1) owner cells so that every pixel finds its top and right edges.
+ * Pixel-boundary storage: every owner cell (i,j) of a region owns its bottom row (lower-left
+ * corner, the num_vertices interior points of the bottom edge left to right, lower-right corner)
+ * and the num_vertices interior points of its left edge (bottom to top), in pixel-local
+ * coordinates (undistorted lower-left corner = (0,0)).  A pixel's top row is the bottom row of the
+ * cell above and its right edge the left edge of the cell to the right, so the two copies of a
+ * corner that the Poisson model tabulates for horizontally adjacent pixels are both kept, as in
+ * GalSim's horizontal/vertical boundary arrays.  A region of nx*ny pixels has (nx+1)*(ny+1) cells.
  */
 #include <stdlib.h>
 #include "orc.h"
 
-int orc_owned_points(const ims_sensor_t* s) { return 2 * s->num_vertices + 1; }
+int orc_owned_points(const ims_sensor_t* s) { return 2 * s->num_vertices + 2; }
 
 static inline int64_t cell_index(const ims_bf_slot_t* sl, int i, int j)
 {
@@ -31,7 +34,8 @@ static void empty_owned(const ims_sensor_t* s, int n, double* x, double* y)
     int nV = s->num_vertices;
     if (n == 0) { *x = 0.0; *y = 0.0; return; }
     if (n <= nV) { *x = s->emptypoly[2 * n]; *y = 0.0; return; }           /* bottom point m = n-1 */
-    int m = n - nV - 1;                                                     /* left point, bottom->top */
+    if (n == nV + 1) { *x = 1.0; *y = 0.0; return; }                        /* lower-right corner */
+    int m = n - nV - 2;                                                     /* left point, bottom->top */
     *x = 0.0; *y = s->emptypoly[2 * (1 + m)];                               /* same abscissa set as the bottom edge */
 }
 
@@ -41,8 +45,13 @@ static double treering_shift(const ims_sensor_t* s, double r)
     double f = r / s->tr_dr;
     if (!(f > 0.0) || f >= (double)(s->n_tr - 1)) return 0.0;
     int i = (int)f;
-    double a = f - (double)i;
-    return s->tr_table[i] + a * (s->tr_table[i + 1] - s->tr_table[i]);
+    double b = f - (double)i;
+    if (s->tr_table2 == NULL) return s->tr_table[i] + b * (s->tr_table[i + 1] - s->tr_table[i]);
+    /* natural cubic spline (the LookupTable 'spline' interpolant) */
+    double a = 1.0 - b;
+    double h2 = s->tr_dr * s->tr_dr / 6.0;
+    return a * s->tr_table[i] + b * s->tr_table[i + 1]
+         + ((a * a * a - a) * s->tr_table2[i] + (b * b * b - b) * s->tr_table2[i + 1]) * h2;
 }
 
 /* assemble the nv-vertex polygon of pixel (i,j) of a slot, scaled by zfactor towards the
@@ -50,20 +59,15 @@ static double treering_shift(const ims_sensor_t* s, double r)
 static void assemble_polygon(const ims_sensor_t* s, const ims_bf_slot_t* sl, int i, int j,
                              double zfactor, double* vx, double* vy)
 {
-    const int nV = s->num_vertices, npo = 2 * nV + 1;
+    const int nV = s->num_vertices, npo = 2 * nV + 2;
     const double* own = s->bf_boundary + cell_index(sl, i, j) * npo * 2;
     const double* rgt = s->bf_boundary + cell_index(sl, i + 1, j) * npo * 2;
     const double* up  = s->bf_boundary + cell_index(sl, i, j + 1) * npo * 2;
-    const double* ur  = s->bf_boundary + cell_index(sl, i + 1, j + 1) * npo * 2;
     int n = 0;
-    vx[n] = own[0]; vy[n] = own[1]; ++n;
-    for (int m = 0; m < nV; ++m, ++n) { vx[n] = own[2 * (1 + m)]; vy[n] = own[2 * (1 + m) + 1]; }
-    vx[n] = rgt[0] + 1.0; vy[n] = rgt[1]; ++n;
-    for (int m = 0; m < nV; ++m, ++n) { vx[n] = rgt[2 * (nV + 1 + m)] + 1.0; vy[n] = rgt[2 * (nV + 1 + m) + 1]; }
-    vx[n] = ur[0] + 1.0; vy[n] = ur[1] + 1.0; ++n;
-    for (int m = 0; m < nV; ++m, ++n) { int q = 1 + (nV - 1 - m); vx[n] = up[2 * q]; vy[n] = up[2 * q + 1] + 1.0; }
-    vx[n] = up[0]; vy[n] = up[1] + 1.0; ++n;
-    for (int m = 0; m < nV; ++m, ++n) { int q = nV + 1 + (nV - 1 - m); vx[n] = own[2 * q]; vy[n] = own[2 * q + 1]; }
+    for (int m = 0; m <= nV + 1; ++m, ++n) { vx[n] = own[2 * m]; vy[n] = own[2 * m + 1]; }              /* LL, bottom, LR */
+    for (int m = 0; m < nV; ++m, ++n) { vx[n] = rgt[2 * (nV + 2 + m)] + 1.0; vy[n] = rgt[2 * (nV + 2 + m) + 1]; }
+    for (int m = 0; m <= nV + 1; ++m, ++n) { int q = nV + 1 - m; vx[n] = up[2 * q]; vy[n] = up[2 * q + 1] + 1.0; }  /* UR, top, UL */
+    for (int m = 0; m < nV; ++m, ++n) { int q = nV + 2 + (nV - 1 - m); vx[n] = own[2 * q]; vy[n] = own[2 * q + 1]; }
     if (zfactor != 1.0) {
         const int nv = 4 * nV + 4;
         for (int k = 0; k < nv; ++k) {
@@ -129,8 +133,8 @@ void orc_sensor_init_boundaries(const ims_sensor_t* s, int first_slot, int n_slo
 static int owned_to_vertex(const ims_sensor_t* s, int n)
 {
     int nV = s->num_vertices;
-    if (n <= nV) return n;                       /* LL corner and bottom points */
-    int m = n - nV - 1;                          /* left point, bottom->top */
+    if (n <= nV + 1) return n;                   /* LL corner, bottom points, LR corner */
+    int m = n - nV - 2;                          /* left point, bottom->top */
     return 3 * nV + 4 + (nV - 1 - m);            /* left edge is stored top->bottom in the polygon */
 }
 
@@ -139,7 +143,7 @@ static int owned_to_vertex(const ims_sensor_t* s, int n)
  * charge accumulated since the previous update. */
 void orc_sensor_update_distortions(const ims_sensor_t* s, int first_slot, int n_slots)
 {
-    const int nV = s->num_vertices, npo = 2 * nV + 1, nv = 4 * nV + 4, q = s->qdist;
+    const int nV = s->num_vertices, npo = 2 * nV + 2, nv = 4 * nV + 4, q = s->qdist;
     const int cx = (s->nx - 1) / 2, cy = (s->ny - 1) / 2;
     for (int k = first_slot; k < first_slot + n_slots; ++k) {
         const ims_bf_slot_t* sl = &s->bf_slots[k];
@@ -158,9 +162,10 @@ void orc_sensor_update_distortions(const ims_sensor_t* s, int first_slot, int n_
                         double w = charge / s->num_elec;
                         const double* dist = s->distortions + ((int64_t)(di + cx) * s->ny + (dj + cy)) * nv * 2;
                         for (int n = 0; n < npo; ++n) {
-                            /* bottom points do not take the extra column, left points not the extra row */
-                            if (n >= 1 && n <= nV && di == q + 1) continue;
-                            if (n > nV && dj == q + 1) continue;
+                            /* the bottom row (shared with the pixel below) takes the extra row but not the
+                               extra column; the left edge (shared with the pixel to the left) the reverse */
+                            if (n <= nV + 1 && di == q + 1) continue;
+                            if (n > nV + 1 && dj == q + 1) continue;
                             int vtx = owned_to_vertex(s, n);
                             pts[2 * n] = pts[2 * n] + dist[2 * vtx] * w;
                             pts[2 * n + 1] = pts[2 * n + 1] + dist[2 * vtx + 1] * w;

@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default=os.environ.get("IMSIM_BENCH_CONFIG", "c2"))
+    ap.add_argument("--config", default=os.environ.get("IMSIM_BENCH_CONFIG", "c3"))
     ap.add_argument("--n-objects", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="objects in the CPU-baseline sample")
@@ -60,7 +60,7 @@ def main():
     scene = cfg["scene"]()
     cat = catalog.synthetic_catalog(n_obj, nx=scene.nx, ny=scene.ny)
     phot = catalog.realize_fluxes(cat["nominal_flux"], scene.seed)
-    objects, sizes = cfg["objects"](cat, phot)
+    objects, sizes = cfg["objects"](cat, phot, scene)
     # shard: sort by flux, deal round-robin; then order each shard spatially so
     # that neighbouring segments share an XCD's L2 lines
     order = np.argsort(-objects["n_phot"], kind="stable")
@@ -85,18 +85,16 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     lib.ims_enable_timing(1)
-    kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         full_step()
-        ms = _abi.C.c_float()
-        if lib.ims_last_kernel_ms(_abi.C.byref(ms)) == 0:
-            kernel_ms.append(ms.value)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    ms, nl = _abi.C.c_float(), _abi.C.c_int()
+    have_ms = lib.ims_last_kernel_ms(_abi.C.byref(ms), _abi.C.byref(nl)) == 0
     lib.ims_enable_timing(0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -109,14 +107,18 @@ def main():
     value = n_total_obj * args.steps / elapsed
 
     # roofline of the dominant kernel (the fused shoot->ops->accumulate launch of this rank)
-    my_phot = int(mine["n_phot"].sum())
-    algo_bytes = my_phot * cfg["bytes_per_photon"] + len(mine) * OBJECT_ROW_BYTES
-    k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-    achieved = algo_bytes / (k_ms * 1e-3) / 1e9 if kernel_ms else float("nan")
+    # The step issues n_render_launches launches of the fused kernel (1 for the ordinary objects
+    # + one per brighter-fatter round); achieved = algorithmic bytes per launch / mean launch time.
+    n_launch = max(int(nl.value), 1) if have_ms else 1
+    algo_bytes_step = step.photons * cfg["bytes_per_photon"] + step.object_rows * OBJECT_ROW_BYTES
+    bytes_per_launch = algo_bytes_step * args.steps / n_launch
+    k_ms = float(ms.value) / n_launch if have_ms else float("nan")
+    achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9 if have_ms else float("nan")
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": cfg["kernel"], "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo_bytes,
-                "photons_per_launch": my_phot}
+                "kernel": cfg["kernel"], "mean_launch_ms": k_ms, "launches_per_step": step.n_render_launches,
+                "kernel_ms_per_step": float(ms.value) / args.steps if have_ms else None,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "photons_per_step": step.photons}
 
     out = {
         "metric": "objects/sec into one 4k x 4k LSST CCD (photon-shooting path)",

@@ -28,11 +28,37 @@ def scene_c2(nx=4096, ny=4096, seed=398414, airmass=1.2, raw_seeing=0.75):
     return Scene(nx=nx, ny=ny, seed=seed, psf=psf, ops=[], radial_r2=r2, radial_cdf=cdf, sed_tables=sed)
 
 
-def _c2_objects(cat, phot):
+def _c2_objects(cat, phot, scene=None):
     return catalog.build_object_table(cat, phot)
 
 
+def _c3_scene_bench():
+    sc = scene_c3()
+    sc.sensor.scratch_cells = 24_000_000      # private brighter-fatter regions of the bright objects
+    sc.sensor.max_slots = 8192
+    return sc
+
+
+def _c3_cpu_scene(scene):
+    """Same physics on a detector-sized image for the CPU sample (the oracle allocates like the GPU)."""
+    return scene
+
+
 BENCH_CONFIGS = {
+    "c3": dict(
+        n_objects=100000,
+        workload="C3: 100k-source synthetic instcat, photon_shooting + TimeSampler/PupilAnnulusSampler/PhotonDCR/"
+                 "RubinDiffractionOptics/FocusDepth/Refraction + Silicon (lsst_e2v_50_4) brighter-fatter + tree rings, "
+                 "LSST_Image semantics (nrecalc=10000), Kolmogorov+Gaussian PSF, 4096x4096 CCD",
+        scene=_c3_scene_bench,
+        objects=None,
+        make_step=lambda renderer, objects: renderer.prepared_lsst_image(objects),
+        bytes_per_photon=8,
+        kernel="k_shoot_accumulate",
+        cpu_sample=1500,
+        cpu_scene=_c3_cpu_scene,
+        cpu_step=lambda orc, sample: orc.render_lsst_image(sample),
+    ),
     "c2": dict(
         n_objects=10000,
         workload="C2: 10k-source synthetic instcat, photon_shooting, Gaussian atmPSF, Silicon sensor off, 4096x4096 CCD",
@@ -176,3 +202,5 @@ def c3_objects(cat, phot, scene, nrecalc=10000, bf_private=True):
     objects["winv"] = winv[keep]
     objects["dcr_tanz"], objects["dcr_sinp"], objects["dcr_cosp"] = tanz[keep], sinp[keep], cosp[keep]
     return objects, sizes
+
+BENCH_CONFIGS["c3"]["objects"] = lambda cat, phot, scene: c3_objects(cat, phot, scene)

@@ -313,38 +313,201 @@ __device__ __forceinline__ int owned_to_vertex(int nV, int n)
     return 3 * nV + 4 + (nV - 1 - m);
 }
 
-// Silicon::updatePixelDistortions: one thread per owner cell gathers the charged neighbours in
-// a fixed order (so the result is bit-reproducible) and adds the scaled tabulated displacements.
+// Silicon::updatePixelDistortions.  One 16x16 workgroup per tile of owner cells of one slot: the
+// delta-charge halo tile ((16+2q+1)^2 floats) is staged in LDS once, then every thread gathers its
+// charged neighbours from LDS in a FIXED order (so the result is bit-reproducible) and adds the
+// scaled tabulated displacements to the boundary points it owns.  A per-cell `changed` byte lets
+// k_refresh_bounds skip pixels whose polygon did not move.
+constexpr int UT = 16;            // tile edge
+constexpr int UQMAX = 4;          // largest supported qdist
+constexpr int UH = UT + 2 * UQMAX + 1;
+
 __global__ __launch_bounds__(256) void k_update_distortions(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
-                                                            int64_t cell_begin, int64_t cell_count)
+                                                            const int64_t* __restrict__ tile_prefix,
+                                                            unsigned char* __restrict__ changed)
 {
+    __shared__ float tile[UH * UH];
     const ims_sensor_t& s = *sp;
-    const CellRef r = locate_cell(s, first_slot, n_slots, cell_begin, cell_count);
-    if (!r.valid) return;
-    const SlotView& sl = r.sl;
-    const int i = r.i, j = r.j;
-    const int nV = s.num_vertices, npo = 2 * nV + 2, nv = 4 * nV + 4, q = s.qdist;
+    // block -> (slot, tile)
+    const int64_t b = blockIdx.x;
+    int lo = 0, hi = n_slots;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (tile_prefix[mid] <= b) lo = mid; else hi = mid;
+    }
+    const ims_bf_slot_t bs = s.bf_slots[first_slot + lo];
+    const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
+    const int tiles_x = (sl.nx + 1 + UT - 1) / UT;
+    const int t = (int)(b - tile_prefix[lo]);
+    const int tx0 = (t % tiles_x) * UT, ty0 = (t / tiles_x) * UT;
+    const int q = s.qdist;
+    const int hw = UT + 2 * q + 1;                 // halo tile edge
+    const int sx0 = tx0 - (q + 1), sy0 = ty0 - (q + 1);
+    for (int e = threadIdx.x; e < hw * hw; e += 256) {
+        const int hx = e % hw, hy = e / hw;
+        const int si = sx0 + hx, sj = sy0 + hy;
+        float v = 0.0f;
+        if (si >= 0 && si < sl.nx && sj >= 0 && sj < sl.ny) v = s.bf_delta[cell_index(sl, si, sj)];
+        tile[hy * hw + hx] = v;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % UT, ly = threadIdx.x / UT;
+    const int i = tx0 + lx, j = ty0 + ly;
+    if (i > sl.nx || j > sl.ny) return;
+    const int nV = s.num_vertices, npo = 2 * nV + 2, nv = 4 * nV + 4;
     const int cx = (s.nx - 1) / 2, cy = (s.ny - 1) / 2;
-    double* pts = s.bf_boundary + (sl.offset + r.c) * npo * 2;
+    const int64_t c = cell_index(sl, i, j);
+    double* pts = s.bf_boundary + c * npo * 2;
+    bool any = false;
     for (int dj = -q; dj <= q + 1; ++dj) {
         const int sj = j - dj;
         if (sj < 0 || sj >= sl.ny) continue;
         for (int di = -q; di <= q + 1; ++di) {
             const int si = i - di;
             if (si < 0 || si >= sl.nx) continue;
-            const double charge = (double)s.bf_delta[cell_index(sl, si, sj)];
+            const double charge = (double)tile[(sj - sy0) * hw + (si - sx0)];
             if (charge == 0.0) continue;
+            any = true;
             const double w = charge / s.num_elec;
             const double* dist = s.distortions + ((int64_t)(di + cx) * s.ny + (dj + cy)) * nv * 2;
             for (int n = 0; n < npo; ++n) {
                 if (n <= nV + 1 && di == q + 1) continue;
                 if (n > nV + 1 && dj == q + 1) continue;
                 const int vtx = owned_to_vertex(nV, n);
-                pts[2 * n] = pts[2 * n] + dist[2 * vtx] * w;
-                pts[2 * n + 1] = pts[2 * n + 1] + dist[2 * vtx + 1] * w;
+                pts[2 * n] = fma(dist[2 * vtx], w, pts[2 * n]);
+                pts[2 * n + 1] = fma(dist[2 * vtx + 1], w, pts[2 * n + 1]);
             }
         }
     }
+    changed[c] = any ? 1 : 0;
+}
+
+// Fast path for qdist == 3 (the GalSim default): the 8x8 source window of a cell is a 64-bit
+// occupancy mask cut out of per-row LDS bitmaps, so a lane only iterates over its OWN charged
+// neighbours (in the spec's order: dj ascending, then di ascending) instead of testing all 64.
+// Sparse stamp wings cost max-over-lanes(nnz) iterations per wave; the dense core stays dense.
+// Boundary points are accumulated in registers (NV is a template parameter) and the displacement
+// table and the scaled charges w = delta / num_elec live in LDS.
+template <int NV>
+__global__ __launch_bounds__(256) void k_update_distortions_q3(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
+                                                               const int64_t* __restrict__ tile_prefix,
+                                                               unsigned char* __restrict__ changed)
+{
+    constexpr int Q = 3, HW = UT + 2 * Q + 1, NPO = 2 * NV + 2, NVV = 4 * NV + 4;
+    __shared__ double wt[HW * HW];
+    __shared__ unsigned int occ[HW];
+    __shared__ double dl[8 * 8 * NPO * 2];       // [dj+Q][di+Q][owned point][x,y]
+    const ims_sensor_t& s = *sp;
+    const int64_t b = blockIdx.x;
+    int lo = 0, hi = n_slots;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (tile_prefix[mid] <= b) lo = mid; else hi = mid;
+    }
+    const ims_bf_slot_t bs = s.bf_slots[first_slot + lo];
+    const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
+    const int tiles_x = (sl.nx + 1 + UT - 1) / UT;
+    const int t = (int)(b - tile_prefix[lo]);
+    const int tx0 = (t % tiles_x) * UT, ty0 = (t / tiles_x) * UT;
+    const int sx0 = tx0 - (Q + 1), sy0 = ty0 - (Q + 1);
+    if (threadIdx.x < HW) occ[threadIdx.x] = 0u;
+    const int cx = (s.nx - 1) / 2, cy = (s.ny - 1) / 2;
+    for (int e = threadIdx.x; e < 8 * 8 * NPO * 2; e += 256) {
+        const int comp = e & 1, n = (e >> 1) % NPO, cell = (e >> 1) / NPO;
+        const int di = (cell & 7) - Q, dj = (cell >> 3) - Q;
+        const int vtx = owned_to_vertex(NV, n);
+        dl[e] = s.distortions[(((int64_t)(di + cx) * s.ny + (dj + cy)) * NVV + vtx) * 2 + comp];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < HW * HW; e += 256) {
+        const int hx = e % HW, hy = e / HW;
+        const int si = sx0 + hx, sj = sy0 + hy;
+        double w = 0.0;
+        if (si >= 0 && si < sl.nx && sj >= 0 && sj < sl.ny) {
+            const double charge = (double)s.bf_delta[cell_index(sl, si, sj)];
+            if (charge != 0.0) { w = charge / s.num_elec; atomicOr(&occ[hy], 1u << hx); }
+        }
+        wt[e] = w;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % UT, ly = threadIdx.x / UT;
+    const int i = tx0 + lx, j = ty0 + ly;
+    if (i > sl.nx || j > sl.ny) return;
+    // 64-bit window: byte a <-> dj = -Q + a (row hy = ly + 2Q + 1 - a); inside a byte bit bb <-> di = -Q + bb
+    // (column hx = lx + 2Q + 1 - bb), i.e. the row bitmap reversed.
+    unsigned long long mask = 0ull;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const unsigned int row = (occ[ly + 2 * Q + 1 - a] >> lx) & 0xFFu;
+        const unsigned int rev = __brev(row) >> 24;
+        mask |= (unsigned long long)rev << (8 * a);
+    }
+    const int64_t c = cell_index(sl, i, j);
+    changed[c] = mask ? 1 : 0;
+    if (!mask) return;
+    double* pts = s.bf_boundary + c * NPO * 2;
+    double acc[NPO * 2];
+#pragma unroll
+    for (int n = 0; n < NPO * 2; ++n) acc[n] = pts[n];
+    while (mask) {
+        const int p = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const int a = p >> 3, bb = p & 7;          // dj = a - Q, di = bb - Q
+        const double w = wt[(ly + 2 * Q + 1 - a) * HW + (lx + 2 * Q + 1 - bb)];
+        const double* d = dl + (a * 8 + bb) * NPO * 2;
+        const bool extra_col = (bb == 7), extra_row = (a == 7);
+        if (!extra_col) {
+#pragma unroll
+            for (int n = 0; n <= NV + 1; ++n) {
+                acc[2 * n] = fma(d[2 * n], w, acc[2 * n]);
+                acc[2 * n + 1] = fma(d[2 * n + 1], w, acc[2 * n + 1]);
+            }
+        }
+        if (!extra_row) {
+#pragma unroll
+            for (int n = NV + 2; n < NPO; ++n) {
+                acc[2 * n] = fma(d[2 * n], w, acc[2 * n]);
+                acc[2 * n + 1] = fma(d[2 * n + 1], w, acc[2 * n + 1]);
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NPO * 2; ++n) pts[n] = acc[n];
+}
+
+// bounds of the pixels whose polygon moved (own cell, right cell or upper cell changed)
+__global__ __launch_bounds__(256) void k_refresh_changed(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
+                                                         int64_t cell_begin, int64_t cell_count,
+                                                         const unsigned char* __restrict__ changed)
+{
+    const ims_sensor_t& s = *sp;
+    const CellRef r = locate_cell(s, first_slot, n_slots, cell_begin, cell_count);
+    if (!r.valid) return;
+    const SlotView& sl = r.sl;
+    const int i = r.i, j = r.j;
+    if (i >= sl.nx || j >= sl.ny) return;
+    if (!(changed[cell_index(sl, i, j)] | changed[cell_index(sl, i + 1, j)] | changed[cell_index(sl, i, j + 1)])) return;
+    const int nV = s.num_vertices, nv = 4 * nV + 4;
+    double ixmin = 0.0, ixmax = 1.0, iymin = 0.0, iymax = 1.0;
+    double oxmin = 0.0, oxmax = 1.0, oymin = 0.0, oymax = 1.0;
+    double v0x = 0.0;
+    for (int k = 0; k < nv; ++k) {
+        double vx, vy;
+        polygon_vertex(s, sl, i, j, k, 1.0, vx, vy);
+        if (k == 0) v0x = vx;
+        if (vx < oxmin) oxmin = vx;
+        if (vx > oxmax) oxmax = vx;
+        if (vy < oymin) oymin = vy;
+        if (vy > oymax) oymax = vy;
+        if (k <= nV + 1) { if (vy > iymin) iymin = vy; }
+        if (k >= nV + 1 && k <= 2 * nV + 2) { if (vx < ixmax) ixmax = vx; }
+        if (k >= 2 * nV + 2 && k <= 3 * nV + 3) { if (vy < iymax) iymax = vy; }
+        if (k >= 3 * nV + 3) { if (vx > ixmin) ixmin = vx; }
+    }
+    if (v0x > ixmin) ixmin = v0x;
+    double* bb = s.bf_bounds + (sl.offset + r.c) * 8;
+    bb[0] = ixmin; bb[1] = ixmax; bb[2] = iymin; bb[3] = iymax;
+    bb[4] = oxmin; bb[5] = oxmax; bb[6] = oymin; bb[7] = oymax;
 }
 
 __global__ __launch_bounds__(256) void k_zero_delta(const ims_sensor_t* __restrict__ sp, int64_t cell_begin, int64_t cell_count)
@@ -544,20 +707,32 @@ int ims_sensor_init_boundaries(const ims_sensor_t* sensor_dev, const ims_sensor_
 }
 
 int ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host,
-                                  int32_t first_slot, int32_t n_slots, void* stream)
+                                  int32_t first_slot, int32_t n_slots, const int64_t* tile_prefix_dev,
+                                  int64_t n_tiles, unsigned char* changed_dev, void* stream)
 {
     if (!sensor_dev) return set_err(IMS_ERR_ARG, "sensor_dev is NULL");
     if (n_slots == 0) return IMS_OK;
+    if (!tile_prefix_dev || !changed_dev) return set_err(IMS_ERR_ARG, "tile_prefix/changed is NULL");
+    if (sensor_host && sensor_host->qdist > UQMAX) return set_err(IMS_ERR_UNSUPPORTED, "qdist > 4 not supported");
     int64_t begin, count;
     int rc = slot_range_cells(sensor_host, first_slot, n_slots, &begin, &count);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const unsigned g = (unsigned)((count + 255) / 256);
-    {
-        hipLaunchKernelGGL(k_update_distortions, dim3(g), dim3(256), 0, st, sensor_dev, first_slot, n_slots, begin, count);
-        hipLaunchKernelGGL(k_zero_delta, dim3(g), dim3(256), 0, st, sensor_dev, begin, count);
-        hipLaunchKernelGGL(k_refresh_bounds, dim3(g), dim3(256), 0, st, sensor_dev, first_slot, n_slots, begin, count);
-    }
+    const int nV = sensor_host ? sensor_host->num_vertices : 0;
+    const int q = sensor_host ? sensor_host->qdist : 0;
+    if (q == 3 && nV == 4)
+        hipLaunchKernelGGL(k_update_distortions_q3<4>, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot,
+                           n_slots, tile_prefix_dev, changed_dev);
+    else if (q == 3 && nV == 8)
+        hipLaunchKernelGGL(k_update_distortions_q3<8>, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot,
+                           n_slots, tile_prefix_dev, changed_dev);
+    else
+        hipLaunchKernelGGL(k_update_distortions, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot, n_slots,
+                           tile_prefix_dev, changed_dev);
+    hipLaunchKernelGGL(k_zero_delta, dim3(g), dim3(256), 0, st, sensor_dev, begin, count);
+    hipLaunchKernelGGL(k_refresh_changed, dim3(g), dim3(256), 0, st, sensor_dev, first_slot, n_slots, begin, count,
+                       (const unsigned char*)changed_dev);
     HIP_TRY(hipGetLastError());
     return IMS_OK;
 }

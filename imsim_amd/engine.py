@@ -483,9 +483,28 @@ class Renderer:
         _abi.check(self.lib.ims_sensor_init_boundaries(self.bound.sensor_dev_ptr, C.byref(self.bound.sensor_host),
                                                        first_slot, n_slots, self._stream()), "ims_sensor_init_boundaries")
 
+    def _tile_prefix(self, first_slot):
+        """Device prefix sum of 16x16 owner-cell tiles over slots [first_slot, n_bf_slots) (cached
+        until the slot table changes)."""
+        b = self.bound
+        sl = b._slots_host[first_slot:b.sensor_host.n_bf_slots]
+        key = (first_slot, sl.tobytes())
+        cache = getattr(self, "_tile_cache", None)
+        if cache is None or cache[0] != key:
+            tiles = ((sl["nx"].astype(np.int64) + 1 + 15) // 16) * ((sl["ny"].astype(np.int64) + 1 + 15) // 16)
+            prefix = np.concatenate([[0], np.cumsum(tiles)]).astype(np.int64)
+            self._tile_cache = (key, prefix, self.torch.from_numpy(prefix).to(self.device))
+        return self._tile_cache[1], self._tile_cache[2]
+
     def update_distortions(self, first_slot, n_slots):
+        if not hasattr(self, "_changed"):
+            cells = self.bound.static_cells + int(self.scene.sensor.scratch_cells)
+            self._changed = self.torch.zeros(max(cells, 1), dtype=self.torch.uint8, device=self.device)
+        prefix, prefix_t = self._tile_prefix(first_slot)
         _abi.check(self.lib.ims_sensor_update_distortions(self.bound.sensor_dev_ptr, C.byref(self.bound.sensor_host),
-                                                          first_slot, n_slots, self._stream()), "ims_sensor_update_distortions")
+                                                          first_slot, n_slots, prefix_t.data_ptr(), int(prefix[n_slots]),
+                                                          self._changed.data_ptr(), self._stream()),
+                   "ims_sensor_update_distortions")
 
     def image_numpy(self):
         return self.image.cpu().numpy()

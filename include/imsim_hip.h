@@ -280,9 +280,13 @@ int  ims_accumulate(const ims_render_params_t* params, const int64_t* photon_off
 int  ims_sensor_init_boundaries(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host,
                                 int32_t first_slot, int32_t n_slots, void* stream);
 /* boundaries += distortions (x) delta / num_elec over the qdist neighbourhood; refresh bounds; delta = 0
- * (Silicon::updatePixelDistortions; the `recalc` of imsim/photon_pooling.py:159) */
+ * (Silicon::updatePixelDistortions; the `recalc` of imsim/photon_pooling.py:159).
+ * tile_prefix_dev[n_slots+1] (device): prefix sum of ceil((nx+1)/16)*ceil((ny+1)/16) over the slots of the
+ * range (16x16 owner-cell tiles); n_tiles = its last entry.  changed_dev (device): one byte per owner
+ * cell of the sensor, scratch. */
 int  ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host,
-                                   int32_t first_slot, int32_t n_slots, void* stream);
+                                   int32_t first_slot, int32_t n_slots, const int64_t* tile_prefix_dev,
+                                   int64_t n_tiles, unsigned char* changed_dev, void* stream);
 
 /* ---- image helpers ---- */
 int  ims_image_add(float* dst, const float* src, int64_t n, void* stream);

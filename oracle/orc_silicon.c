@@ -167,8 +167,8 @@ void orc_sensor_update_distortions(const ims_sensor_t* s, int first_slot, int n_
                             if (n <= nV + 1 && di == q + 1) continue;
                             if (n > nV + 1 && dj == q + 1) continue;
                             int vtx = owned_to_vertex(s, n);
-                            pts[2 * n] = pts[2 * n] + dist[2 * vtx] * w;
-                            pts[2 * n + 1] = pts[2 * n + 1] + dist[2 * vtx + 1] * w;
+                            pts[2 * n] = orc_fma(dist[2 * vtx], w, pts[2 * n]);
+                            pts[2 * n + 1] = orc_fma(dist[2 * vtx + 1], w, pts[2 * n + 1]);
                         }
                     }
                 }

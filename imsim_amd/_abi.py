@@ -64,8 +64,8 @@ class Op(C.Structure):
 
 
 class Surface(C.Structure):
-    _fields_ = [("kind", c_i32), ("obsc_kind", c_i32), ("medium_kind", c_i32), ("n_asphere", c_i32),
-                ("z0", c_d), ("R", c_d), ("conic", c_d), ("asph", c_d * 4),
+    _fields_ = [("kind", c_i32), ("obsc_kind", c_i32), ("medium_kind", c_i32), ("n_asphere", c_i32), ("medium_id", c_i32), ("pad", c_i32),
+                ("z0", c_d), ("R", c_d), ("inv_R", c_d), ("conic", c_d), ("asph", c_d * 4),
                 ("obsc_inner", c_d), ("obsc_outer", c_d), ("medium_c", c_d * 6)]
 
 
@@ -123,7 +123,7 @@ EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_
            "ims_sensor_update_distortions", "ims_image_add", "ims_last_kernel_ms", "ims_enable_timing",
            "ims_struct_size", "ims_test_math"]
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libimsim_hip.so")
+_LIB_PATH = os.environ.get("IMSIM_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libimsim_hip.so")
 _lib = None
 
 

@@ -166,7 +166,8 @@ IMS_DEV void wcs_vec_to_pix(const ims_tansip_t& w, const double (&p)[3], double&
     const double t0 = w.rot[0] * p[0] + w.rot[1] * p[1] + w.rot[2] * p[2];
     const double t1 = w.rot[3] * p[0] + w.rot[4] * p[1] + w.rot[5] * p[2];
     const double t2 = w.rot[6] * p[0] + w.rot[7] * p[1] + w.rot[8] * p[2];
-    const double xi = t1 / t0, eta = t2 / t0;
+    const double it0 = 1.0 / t0;
+    const double xi = t1 * it0, eta = t2 * it0;
     const double U = w.cdinv[0] * xi + w.cdinv[1] * eta;
     const double V = w.cdinv[2] * xi + w.cdinv[3] * eta;
     double u = U, v = V;
@@ -191,11 +192,13 @@ IMS_DEV void xy_to_v(const ims_optics_t& o, double x, double y, double wave_nm, 
     wcs_vec_to_pix(o.icrf_to_field, p, thx, thy);
     const double gamma = 1.0 / sqrt(1.0 + thx * thx + thy * thy);
     const double n = medium_n(o.in_medium_kind, o.in_medium_c, wave_nm);
-    v[0] = thx * gamma / n; v[1] = thy * gamma / n; v[2] = -gamma / n;
+    const double gn = gamma / n;
+    v[0] = thx * gn; v[1] = thy * gn; v[2] = -gn;
 }
 IMS_DEV void v_to_xy(const ims_optics_t& o, const double (&v)[3], double& x, double& y)
 {
-    const double thx = -v[0] / v[2], thy = -v[1] / v[2];
+    const double ivz = 1.0 / v[2];
+    const double thx = -v[0] * ivz, thy = -v[1] * ivz;
     double p[3];
     wcs_pix_to_vec(o.icrf_to_field, thx, thy, p);
     wcs_vec_to_pix(o.img_wcs, p, x, y);
@@ -268,12 +271,13 @@ IMS_DEV void surf_sag(const ims_surface_t& S, double r2, double& sag, double& ds
     double z = 0.0, dz = 0.0;
     ok = true;
     if (S.R != 0.0) {
-        const double c = 1.0 / S.R;
+        const double c = S.inv_R;
         double arg = 1.0 - (1.0 + S.conic) * c * c * r2;
         if (arg < 0.0) { ok = false; arg = 0.0; }
         const double sq = sqrt(arg);
-        z = c * r2 / (1.0 + sq);
-        dz = (sq > 0.0) ? c / (2.0 * sq) : 0.0;
+        const double inv = 1.0 / (sq * (1.0 + sq));
+        z = c * r2 * sq * inv;
+        dz = (sq > 0.0) ? 0.5 * c * (1.0 + sq) * inv : 0.0;
     }
     double rp = r2;
     for (int k = 0; k < S.n_asphere; ++k) {
@@ -285,15 +289,53 @@ IMS_DEV void surf_sag(const ims_surface_t& S, double r2, double& sag, double& ds
     sag = z; dsag = dz;
 }
 
+// time of flight to the surface (spec v2: plane exact, conic closed form, asphere Newton from the conic root)
+IMS_DEV bool surf_intersect(const ims_surface_t& S, const double (&pos)[3], const double (&vel)[3], double& t_out)
+{
+    const double pz = pos[2] - S.z0;
+    if (S.R == 0.0 && S.n_asphere == 0) { t_out = -pz / vel[2]; return true; }
+    double t;
+    if (S.R != 0.0) {
+        const double k1 = 1.0 + S.conic;
+        const double A = vel[0] * vel[0] + vel[1] * vel[1] + k1 * vel[2] * vel[2];
+        const double B = 2.0 * (pos[0] * vel[0] + pos[1] * vel[1] + k1 * pz * vel[2] - S.R * vel[2]);
+        const double C = pos[0] * pos[0] + pos[1] * pos[1] + k1 * pz * pz - 2.0 * S.R * pz;
+        const double disc = B * B - 4.0 * A * C;
+        if (disc < 0.0) return false;
+        const double sq = sqrt(disc);
+        const double q = -0.5 * (B + (B < 0.0 ? -sq : sq));
+        const double lhs = fabs(pz * q + vel[2] * C) * fabs(A);
+        const double rhs = fabs(pz * A + vel[2] * q) * fabs(q);
+        t = (lhs <= rhs) ? C / q : q / A;
+    } else {
+        t = -pz / vel[2];
+    }
+    if (S.n_asphere > 0) {
+        for (int it = 0; it < 5; ++it) {
+            const double x = pos[0] + vel[0] * t, y = pos[1] + vel[1] * t, z = pz + vel[2] * t;
+            double sag, ds; bool ok;
+            surf_sag(S, x * x + y * y, sag, ds, ok);
+            if (!ok) return false;
+            const double f = z - sag;
+            if (fabs(f) <= 1.0e-14) break;
+            const double fp = vel[2] - 2.0 * ds * (x * vel[0] + y * vel[1]);
+            t = t - f / fp;
+        }
+    }
+    t_out = t;
+    return true;
+}
+
 IMS_DEV bool obscured(const ims_surface_t& S, double x, double y)
 {
     if (S.obsc_kind == IMS_OBSC_NONE) return false;
-    const double r = sqrt(x * x + y * y);
+    const double r2 = x * x + y * y;
+    const double i2 = S.obsc_inner * S.obsc_inner, o2 = S.obsc_outer * S.obsc_outer;
     switch (S.obsc_kind) {
-    case IMS_OBSC_CLEAR_ANNULUS: return !(r >= S.obsc_inner && r <= S.obsc_outer);
-    case IMS_OBSC_CLEAR_CIRCLE:  return !(r <= S.obsc_outer);
-    case IMS_OBSC_OBSC_CIRCLE:   return r < S.obsc_outer;
-    case IMS_OBSC_OBSC_ANNULUS:  return (r >= S.obsc_inner && r < S.obsc_outer);
+    case IMS_OBSC_CLEAR_ANNULUS: return !(r2 >= i2 && r2 <= o2);
+    case IMS_OBSC_CLEAR_CIRCLE:  return !(r2 <= o2);
+    case IMS_OBSC_OBSC_CIRCLE:   return r2 < o2;
+    case IMS_OBSC_OBSC_ANNULUS:  return (r2 >= i2 && r2 < o2);
     }
     return false;
 }
@@ -303,21 +345,13 @@ IMS_DEV int trace(const ims_optics_t& o, double (&pos)[3], double (&vel)[3], dou
 {
     int vignetted = 0;
     double n_cur = medium_n(o.in_medium_kind, o.in_medium_c, wave_nm);
+    int glass_id = -1;
+    double glass_n = 0.0;
     for (int k = 0; k < o.n_surfaces; ++k) {
         const ims_surface_t& S = o.surf[k];
-        double t = (S.z0 - pos[2]) / vel[2];
-        double x = 0.0, y = 0.0, sag = 0.0, ds = 0.0;
+        double t, x, y, sag = 0.0, ds = 0.0;
         bool ok = true;
-        const int niter = (S.R == 0.0 && S.n_asphere == 0) ? 1 : 6;
-        for (int it = 0; it < niter; ++it) {
-            x = pos[0] + vel[0] * t; y = pos[1] + vel[1] * t;
-            const double z = pos[2] + vel[2] * t;
-            surf_sag(S, x * x + y * y, sag, ds, ok);
-            if (!ok) return 2;
-            const double f = z - S.z0 - sag;
-            const double fp = vel[2] - 2.0 * ds * (x * vel[0] + y * vel[1]);
-            t = t - f / fp;
-        }
+        if (!surf_intersect(S, pos, vel, t)) return 2;
         x = pos[0] + vel[0] * t; y = pos[1] + vel[1] * t;
         surf_sag(S, x * x + y * y, sag, ds, ok);
         if (!ok) return 2;
@@ -331,17 +365,26 @@ IMS_DEV int trace(const ims_optics_t& o, double (&pos)[3], double (&vel)[3], dou
             const double d = vel[0] * nx + vel[1] * ny + vel[2] * nz;
             vel[0] = vel[0] - 2.0 * d * nx; vel[1] = vel[1] - 2.0 * d * ny; vel[2] = vel[2] - 2.0 * d * nz;
         } else {
-            const double n2 = medium_n(S.medium_kind, S.medium_c, wave_nm);
+            // the index of a medium is a pure function of (medium, wavelength): reuse the last one
+            // computed when the same medium recurs (all Rubin lenses and filters are fused silica)
+            double n2;
+            if (S.medium_id == glass_id) {
+                n2 = glass_n;
+            } else {
+                n2 = medium_n(S.medium_kind, S.medium_c, wave_nm);
+                if (S.medium_kind != IMS_MEDIUM_CONST) { glass_id = S.medium_id; glass_n = n2; }
+            }
+            const double in2 = 1.0 / n2;
             const double dx = vel[0] * n_cur, dy = vel[1] * n_cur, dzz = vel[2] * n_cur;
             double alpha = dx * nx + dy * ny + dzz * nz;
             if (alpha > 0.0) { nx = -nx; ny = -ny; nz = -nz; alpha = -alpha; }
-            const double eta = n_cur / n2;
+            const double eta = n_cur * in2;
             const double sinsqr = eta * eta * (1.0 - alpha * alpha);
             if (sinsqr > 1.0) return 2;
             const double nfac = eta * alpha + sqrt(1.0 - sinsqr);
-            vel[0] = (eta * dx - nfac * nx) / n2;
-            vel[1] = (eta * dy - nfac * ny) / n2;
-            vel[2] = (eta * dzz - nfac * nz) / n2;
+            vel[0] = (eta * dx - nfac * nx) * in2;
+            vel[1] = (eta * dy - nfac * ny) * in2;
+            vel[2] = (eta * dzz - nfac * nz) * in2;
             n_cur = n2;
         }
     }
@@ -372,8 +415,9 @@ IMS_DEV void rubin_op(const ims_render_params_t& P, const ims_op_t& op, int op_i
     const double fpx = ry * 1.0e3, fpy = rx * 1.0e3;
     ph.x = opt.fp_to_pix[0] * fpx + opt.fp_to_pix[1] * fpy + opt.fp_to_pix[2];
     ph.y = opt.fp_to_pix[3] * fpx + opt.fp_to_pix[4] * fpy + opt.fp_to_pix[5];
-    ph.dxdz = (opt.slope_jac[0] * rvx + opt.slope_jac[1] * rvy) / v[2];
-    ph.dydz = (opt.slope_jac[2] * rvx + opt.slope_jac[3] * rvy) / v[2];
+    const double ivz = 1.0 / v[2];
+    ph.dxdz = (opt.slope_jac[0] * rvx + opt.slope_jac[1] * rvy) * ivz;
+    ph.dydz = (opt.slope_jac[2] * rvx + opt.slope_jac[3] * rvy) * ivz;
     if (st == 1) ph.flux = 0.0;
 }
 

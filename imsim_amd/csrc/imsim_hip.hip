@@ -89,7 +89,10 @@ __device__ __forceinline__ void make_photon(const ims_render_params_t& P, const 
 }
 
 // ---------------- fused kernel: LSST_Silicon draw (phot) + stamp->CCD add ----------------
-__global__ __launch_bounds__(256) void k_shoot_accumulate(const ims_render_params_t P)
+#ifndef IMS_FUSED_WAVES
+#define IMS_FUSED_WAVES 4
+#endif
+__global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_accumulate(const ims_render_params_t P)
 {
     const int64_t per = (P.n_segments + N_XCD - 1) / N_XCD;
     const int64_t b = blockIdx.x;
@@ -105,18 +108,21 @@ __global__ __launch_bounds__(256) void k_shoot_accumulate(const ims_render_param
     const bool silicon = (P.sensor != nullptr) && (P.sensor->kind == IMS_SENSOR_SILICON);
     const bool has_angles = chain_has_angles(P);
     double added = 0.0;
-    for (int64_t j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+    // exactly one photon per thread (seg_size == workgroup size): no photon loop, so the compiler
+    // cannot hoist the chain's uniform operands across iterations into registers
+    const int64_t j = j0 + threadIdx.x;
+    if (j < j1) {
         const int64_t k = o.phot_first + j;
         Photon ph;
         make_photon(P, o, k, ph);
         for (int q = 0; q < P.n_ops; ++q) apply_op(P, q, o, k, ph);
-        if (ph.flux == 0.0) continue;
         int ix, iy;
-        if (!land(P, o, k, ph, silicon, has_angles, ix, iy)) continue;
-        added += ph.flux;
-        const int px = ix - P.xmin, py = iy - P.ymin;
-        if (px < 0 || px >= P.nx || py < 0 || py >= P.ny) continue;
-        unsafeAtomicAdd(P.image + ((int64_t)py * P.nx + px), (float)ph.flux);
+        if (ph.flux != 0.0 && land(P, o, k, ph, silicon, has_angles, ix, iy)) {
+            added += ph.flux;
+            const int px = ix - P.xmin, py = iy - P.ymin;
+            if (px >= 0 && px < P.nx && py >= 0 && py < P.ny)
+                unsafeAtomicAdd(P.image + ((int64_t)py * P.nx + px), (float)ph.flux);
+        }
     }
     if (P.realized_flux != nullptr) {
         const double tot = wave_sum(added);
@@ -547,7 +553,7 @@ static int check_params(const ims_render_params_t* p)
     if (!p) return set_err(IMS_ERR_ARG, "params is NULL");
     if (p->n_objects < 0 || p->n_segments < 0) return set_err(IMS_ERR_ARG, "negative object/segment count");
     if (p->n_objects > 0 && (!p->objects || !p->seg_prefix)) return set_err(IMS_ERR_ARG, "objects/seg_prefix is NULL");
-    if (p->seg_size <= 0) return set_err(IMS_ERR_ARG, "seg_size must be > 0");
+    if (p->seg_size != 256) return set_err(IMS_ERR_ARG, "seg_size must be 256 (one photon per thread of a 256-thread workgroup)");
     if (p->n_psf < 0 || p->n_psf > IMS_MAX_PSF) return set_err(IMS_ERR_ARG, "n_psf out of range");
     if (p->n_ops < 0 || p->n_ops > IMS_MAX_OPS) return set_err(IMS_ERR_ARG, "n_ops out of range");
     for (int k = 0; k < p->n_ops; ++k) {

@@ -102,17 +102,31 @@ def trace_numpy(tel: Telescope, pos, vel, wave_nm):
     fail = np.zeros(len(pos), dtype=bool)
     n_cur = medium_n(tel.in_medium, wave_nm)
     for S in tel.surfaces:
-        t = (S.z0 - pos[:, 2]) / vel[:, 2]
-        niter = 1 if (S.R == 0.0 and not S.asph) else 6
-        for _ in range(niter):
+        pz = pos[:, 2] - S.z0
+        if S.R != 0.0:
+            k1 = 1.0 + S.conic
+            A = vel[:, 0] ** 2 + vel[:, 1] ** 2 + k1 * vel[:, 2] ** 2
+            B = 2.0 * (pos[:, 0] * vel[:, 0] + pos[:, 1] * vel[:, 1] + k1 * pz * vel[:, 2] - S.R * vel[:, 2])
+            Cq = pos[:, 0] ** 2 + pos[:, 1] ** 2 + k1 * pz * pz - 2.0 * S.R * pz
+            disc = B * B - 4.0 * A * Cq
+            fail |= disc < 0
+            sq = np.sqrt(np.clip(disc, 0.0, None))
+            q = -0.5 * (B + np.where(B < 0, -sq, sq))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t1, t2 = q / A, Cq / q
+            z1, z2 = pz + vel[:, 2] * t1, pz + vel[:, 2] * t2
+            t = np.where((np.abs(z2) <= np.abs(z1)) | ~(np.abs(z1) < 1e300), t2, t1)
+        else:
+            t = -pz / vel[:, 2]
+        for _ in range(5 if S.asph else 0):
             x = pos[:, 0] + vel[:, 0] * t
             y = pos[:, 1] + vel[:, 1] * t
-            z = pos[:, 2] + vel[:, 2] * t
+            z = pz + vel[:, 2] * t
             sag, ds, ok = _sag(S, x * x + y * y)
             fail |= ~ok
-            f = z - S.z0 - sag
+            f = z - sag
             fp = vel[:, 2] - 2.0 * ds * (x * vel[:, 0] + y * vel[:, 1])
-            t = t - f / fp
+            t = np.where(np.abs(f) <= 1e-14, t, t - f / fp)
         x = pos[:, 0] + vel[:, 0] * t
         y = pos[:, 1] + vel[:, 1] * t
         sag, ds, ok = _sag(S, x * x + y * y)
@@ -340,13 +354,16 @@ def fill_optics(o: "_abi.Optics", tel: Telescope, fp_to_pix, rot_tel_pos=0.0):
         o.in_medium_c[k] = float(tel.in_medium[1][k])
     o.n_surfaces = len(tel.surfaces)
     o.stop_z = tel.stop_z
+    media = {}
     for k, S in enumerate(tel.surfaces):
         s = o.surf[k]
+        s.medium_id = media.setdefault((S.medium[0], tuple(float(c) for c in S.medium[1])), len(media))
         s.kind, s.obsc_kind, s.medium_kind = S.kind, S.obsc_kind, S.medium[0]
         if len(S.asph) > 4:
             raise ValueError("at most 4 asphere coefficients")
         s.n_asphere = len(S.asph)
         s.z0, s.R, s.conic = S.z0, S.R, S.conic
+        s.inv_R = (1.0 / S.R) if S.R != 0.0 else 0.0
         for m in range(4):
             s.asph[m] = float(S.asph[m]) if m < len(S.asph) else 0.0
         s.obsc_inner, s.obsc_outer = S.obsc_inner, S.obsc_outer

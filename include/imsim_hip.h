@@ -141,8 +141,11 @@ typedef struct ims_surface {
     int32_t obsc_kind;       /* IMS_OBSC_* */
     int32_t medium_kind;     /* medium AFTER this surface (refractive surfaces) */
     int32_t n_asphere;       /* number of even asphere coefficients used (0..4): r^4, r^6, r^8, r^10 */
+    int32_t medium_id;       /* host-assigned: equal ids <=> identical medium (lets the kernel reuse n(lambda)) */
+    int32_t pad;
     double  z0;              /* vertex z in telescope coordinates [m] */
     double  R;               /* radius of curvature [m]; 0 = plane */
+    double  inv_R;           /* 1/R (0 for a plane), precomputed on the host */
     double  conic;
     double  asph[4];
     double  obsc_inner, obsc_outer;   /* [m] */
@@ -236,7 +239,7 @@ typedef struct ims_render_params {
     int64_t  n_objects;
     const int64_t* seg_prefix;       /* device, [n_objects+1]: prefix sum of ceil(n_phot/seg_size) */
     int64_t  n_segments;
-    int32_t  seg_size;               /* photons per workgroup segment */
+    int32_t  seg_size;               /* photons per workgroup segment; must be 256 (= workgroup size) */
     int32_t  n_psf;
     ims_psf_component_t psf[IMS_MAX_PSF];
     int32_t  n_ops;

@@ -42,7 +42,7 @@ def main():
     args = parse()
     import torch
     import torch.distributed as dist
-    from imsim_amd import configs, catalog, _abi
+    from imsim_amd import configs, catalog, _abi, parallel
     from imsim_amd.engine import Renderer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -61,12 +61,7 @@ def main():
     cat = catalog.synthetic_catalog(n_obj, nx=scene.nx, ny=scene.ny)
     phot = catalog.realize_fluxes(cat["nominal_flux"], scene.seed)
     objects, sizes = cfg["objects"](cat, phot, scene)
-    # shard: sort by flux, deal round-robin; then order each shard spatially so
-    # that neighbouring segments share an XCD's L2 lines
-    order = np.argsort(-objects["n_phot"], kind="stable")
-    mine = objects[order[rank::world]]
-    tile = (mine["y0"] // 256).astype(np.int64) * 64 + (mine["x0"] // 256).astype(np.int64)
-    mine = mine[np.argsort(tile, kind="stable")]
+    mine = parallel.shard_objects(objects, rank, world)
 
     renderer = Renderer(scene, device)
     step = cfg["make_step"](renderer, mine)
@@ -75,8 +70,7 @@ def main():
     def full_step():
         renderer.image.zero_()
         step()
-        if world > 1:
-            dist.reduce(renderer.image, dst=0, op=dist.ReduceOp.SUM)
+        parallel.reduce_image(renderer.image, dst=0)
 
     for _ in range(args.warmup):
         full_step()

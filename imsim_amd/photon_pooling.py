@@ -1,0 +1,133 @@
+"""Photon pooling: host logic of LSST_PhotonPoolingImageBuilder (imsim/photon_pooling.py) over the
+GPU engine.
+
+The batching helpers keep the reference's names and semantics (they are pure bookkeeping and are
+tested against the expectations of the reference's tests/test_photon_pooling.py); `build_image`
+replaces the per-object stamp loop + merge + per-op passes by three launches per sub-batch
+(shoot into the pool, one pass applying every op, accumulate) with the whole CCD as ONE
+brighter-fatter region recalculated at the first sub-batch of each batch.
+"""
+import dataclasses
+import itertools
+
+import numpy as np
+
+from ._abi import OBJECT_DTYPE, IMS_OBJ_FAINT
+from .stamp import ProcessingMode, ObjectInfo
+
+
+def make_batches(objects, nbatch):
+    """Split `objects` into nbatch consecutive batches, earlier batches taking the remainder
+    (imsim/photon_pooling.py:228-247)."""
+    base, extra = divmod(len(objects), nbatch)
+    start = 0
+    for i in range(nbatch):
+        n = base + 1 if i < extra else base
+        yield list(objects[start:start + n])
+        start += n
+
+
+def make_photon_batches(phot_objects, faint_objects, nbatch, rng=None):
+    """Every bright object appears in all nbatch batches with the integer flux share
+    (F(i+1))//nbatch - (F i)//nbatch; every faint object lands whole in one random batch
+    (imsim/photon_pooling.py:279-313).  `rng`: callable returning a uniform deviate in [0,1)."""
+    if not phot_objects and not faint_objects:
+        return []
+    batches = [[dataclasses.replace(obj, phot_flux=(obj.phot_flux * (i + 1)) // nbatch - (obj.phot_flux * i) // nbatch)
+                for obj in phot_objects] for i in range(nbatch)]
+    if rng is None:
+        gen = np.random.default_rng(0)
+        rng = gen.random
+    for obj in faint_objects:
+        batches[int(rng() * nbatch)].append(obj)
+    return batches
+
+
+def make_photon_subbatches(batch, nsubbatch):
+    """Split a batch into nsubbatch nearly equal consecutive sub-batches (imsim/photon_pooling.py:316-331)."""
+    per, extra = divmod(len(batch), nsubbatch)
+    sizes = extra * [per + 1] + (nsubbatch - extra) * [per]
+    edges = [0] + list(itertools.accumulate(sizes))
+    return [batch[edges[i]:edges[i + 1]] for i in range(nsubbatch)]
+
+
+def partition_objects(objects, nbatch):
+    """(fft, phot, faint) lists; PHOT objects with fewer photons than batches are demoted to
+    FAINT handling (imsim/photon_pooling.py:356-386)."""
+    by_mode = {ProcessingMode.FFT: [], ProcessingMode.PHOT: [], ProcessingMode.FAINT: []}
+    for obj in objects:
+        mode = ProcessingMode.FAINT if (obj.phot_flux < nbatch and obj.mode == ProcessingMode.PHOT) else obj.mode
+        by_mode[mode].append(obj)
+    return by_mode[ProcessingMode.FFT], by_mode[ProcessingMode.PHOT], by_mode[ProcessingMode.FAINT]
+
+
+class GalSimConfigValueError(ValueError):
+    pass
+
+
+def check_stamp_type(stamp_type):
+    """LSST_PhotonPoolingImage requires stamp.type == LSST_Photons (imsim/photon_pooling.py:25-26)."""
+    if stamp_type != "LSST_Photons":
+        raise GalSimConfigValueError(f"Must use stamp.type = LSST_Photons with LSST_PhotonPoolingImage. ({stamp_type})")
+
+
+def build_image(renderer, objects, modes, nbatch=10, nsubbatch=50, seed=0, realized=None):
+    """LSST_PhotonPoolingImageBuilder.buildImage for the photon-shooting objects
+    (imsim/photon_pooling.py:116-168).
+
+    objects: OBJECT_DTYPE table (n_phot = phot_flux of the whole object); modes: ProcessingMode per row.
+    Photon index ranges follow the integer flux split, so the union over batches is exactly the
+    object's photon stream.  Returns the number of photons accumulated."""
+    objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
+    infos = [ObjectInfo(i, int(objects["n_phot"][i]), modes[i]) for i in range(len(objects))]
+    _, phot, faint = partition_objects(infos, nbatch)
+    nb = max(min(nbatch, len(phot)), 1)
+    gen = np.random.default_rng([int(seed), 0xFA17])
+    # batch membership: bright objects in every batch with their flux share; faint in one batch
+    faint_batch = {o.index: int(gen.random() * nb) for o in faint}
+    phot_idx = np.array([o.index for o in phot], dtype=np.int64)
+    faint_idx = np.array([o.index for o in faint], dtype=np.int64)
+    F = objects["n_phot"][phot_idx].astype(np.int64) if len(phot_idx) else np.zeros(0, np.int64)
+    total = 0
+    sensor_on = renderer.scene.sensor is not None
+    len_smallest = None
+    batch_tables = []
+    for i in range(nb):
+        part = objects[phot_idx].copy()
+        lo, hi = (F * i) // nb, (F * (i + 1)) // nb
+        part["phot_first"] = objects["phot_first"][phot_idx] + lo
+        part["n_phot"] = hi - lo
+        fsel = faint_idx[[faint_batch[j] == i for j in faint_idx]] if len(faint_idx) else faint_idx
+        fpart = objects[fsel].copy()
+        table = np.concatenate([part, fpart])
+        index = np.concatenate([phot_idx, fsel])
+        batch_tables.append((table, index))
+        len_smallest = len(table) if len_smallest is None else min(len_smallest, len(table))
+    nsub = max(min(nsubbatch, len_smallest or 1), 1)
+    for i, (table, index) in enumerate(batch_tables):
+        if len(table) == 0:
+            continue
+        table["bf_state"] = 0
+        table["flags"] &= ~IMS_OBJ_FAINT     # in pooling mode the ops and the sensor see every photon (photon_pooling.py:154-159)
+        rows = np.arange(len(table))
+        for s, sub in enumerate(make_photon_subbatches(list(rows), nsub)):
+            if not sub:
+                continue
+            sub = np.asarray(sub)
+            t = table[sub]
+            keep = t["n_phot"] > 0
+            t, idx = t[keep], index[sub][keep]
+            if len(t) == 0:
+                continue
+            if sensor_on and s == 0 and i > 0:
+                renderer.update_distortions(0, 1)          # recalc=(subbatch_num == 0), resume afterwards
+            pool = renderer.shoot_photons(t)
+            renderer.apply_ops(pool)
+            tmp = None
+            if realized is not None:
+                tmp = renderer.torch.zeros(len(t), dtype=renderer.torch.float64, device=renderer.device)
+            renderer.accumulate(pool, realized=tmp)
+            if realized is not None:
+                realized.index_add_(0, renderer.torch.from_numpy(idx).to(renderer.device), tmp)
+            total += int(t["n_phot"].sum())
+    return total

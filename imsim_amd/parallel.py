@@ -7,12 +7,33 @@ addressed by (object id, photon index), the reduced image does not depend on the
 import numpy as np
 
 
+def assign_ranks(n_phot, world):
+    """Longest-processing-time-first: objects sorted by photon count, each given to the currently
+    least-loaded rank.  Objects stay whole (in LSST_Image mode an object's brighter-fatter state is
+    sequential in its own photons)."""
+    n_phot = np.asarray(n_phot, dtype=np.int64)
+    owner = np.zeros(len(n_phot), dtype=np.int32)
+    if world == 1:
+        return owner
+    order = np.argsort(-n_phot, kind="stable")
+    # the few heavy objects decide the balance: place them exactly, deal the light tail round-robin
+    heavy = order[: min(len(order), 64 * world)]
+    load = np.zeros(world, dtype=np.int64)
+    for i in heavy:
+        r = int(np.argmin(load))
+        owner[i] = r
+        load[r] += n_phot[i]
+    tail = order[len(heavy):]
+    start = int(np.argmin(load))
+    owner[tail] = (start + np.arange(len(tail))) % world
+    return owner
+
+
 def shard_objects(objects, rank, world):
-    """Sort by photon count (descending) and deal round-robin to the ranks so photon counts
-    balance; then order the shard by 256-pixel tiles so neighbouring workgroups touch nearby image
-    lines and boundary state (XCD-local L2 reuse)."""
-    order = np.argsort(-objects["n_phot"], kind="stable")
-    mine = objects[order[rank::world]]
+    """This rank's share of the object table (balanced by photon count), ordered by 256-pixel
+    tiles so neighbouring workgroups touch nearby image lines and boundary state (XCD-local L2
+    reuse)."""
+    mine = objects[assign_ranks(objects["n_phot"], world) == rank]
     tile = (mine["y0"] // 256).astype(np.int64) * 4096 + (mine["x0"] // 256).astype(np.int64)
     return mine[np.argsort(tile, kind="stable")]
 

@@ -119,7 +119,7 @@ STRUCTS = [Object, RadialTables, LinTables, PsfComponent, Op, Surface, TanSip, O
 
 # every symbol include/imsim_hip.h declares
 EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_info", "ims_shoot_accumulate",
-           "ims_shoot_photons", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
+           "ims_shoot_photons", "ims_shoot_ops_photons", "ims_accumulate_segments", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
            "ims_sensor_update_distortions", "ims_image_add", "ims_last_kernel_ms", "ims_enable_timing",
            "ims_struct_size", "ims_test_math"]
 
@@ -156,6 +156,8 @@ def load():
     lib.ims_shoot_accumulate.argtypes = [C.POINTER(RenderParams), c_vp]
     lib.ims_shoot_photons.argtypes = [C.POINTER(RenderParams), c_vp, C.POINTER(Photons), c_vp]
     lib.ims_apply_ops.argtypes = [C.POINTER(RenderParams), c_vp, C.POINTER(Photons), c_vp]
+    lib.ims_shoot_ops_photons.argtypes = [C.POINTER(RenderParams), c_vp, C.POINTER(Photons), c_vp]
+    lib.ims_accumulate_segments.argtypes = [C.POINTER(RenderParams), C.POINTER(Photons), c_vp, c_vp]
     lib.ims_accumulate.argtypes = [C.POINTER(RenderParams), c_vp, C.POINTER(Photons), c_vp, c_vp]
     lib.ims_sensor_init_boundaries.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_vp]
     lib.ims_sensor_update_distortions.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]

@@ -154,11 +154,10 @@ IMS_DEV void wcs_pix_to_vec(const ims_tansip_t& w, double x, double y, double (&
     }
     const double xi = w.cd[0] * u + w.cd[1] * v;
     const double eta = w.cd[2] * u + w.cd[3] * v;
-    const double inv = 1.0 / sqrt(1.0 + xi * xi + eta * eta);
-    const double t0 = inv, t1 = xi * inv, t2 = eta * inv;
-    p[0] = w.rot[0] * t0 + w.rot[3] * t1 + w.rot[6] * t2;
-    p[1] = w.rot[1] * t0 + w.rot[4] * t1 + w.rot[7] * t2;
-    p[2] = w.rot[2] * t0 + w.rot[5] * t1 + w.rot[8] * t2;
+    // not normalised: every consumer projects the direction onto a tangent plane, where the norm cancels
+    p[0] = w.rot[0] + w.rot[3] * xi + w.rot[6] * eta;
+    p[1] = w.rot[1] + w.rot[4] * xi + w.rot[7] * eta;
+    p[2] = w.rot[2] + w.rot[5] * xi + w.rot[8] * eta;
 }
 
 IMS_DEV void wcs_vec_to_pix(const ims_tansip_t& w, const double (&p)[3], double& x, double& y)
@@ -190,9 +189,8 @@ IMS_DEV void xy_to_v(const ims_optics_t& o, double x, double y, double wave_nm, 
     double p[3], thx, thy;
     wcs_pix_to_vec(o.img_wcs, x, y, p);
     wcs_vec_to_pix(o.icrf_to_field, p, thx, thy);
-    const double gamma = 1.0 / sqrt(1.0 + thx * thx + thy * thy);
     const double n = medium_n(o.in_medium_kind, o.in_medium_c, wave_nm);
-    const double gn = gamma / n;
+    const double gn = 1.0 / (n * sqrt(1.0 + thx * thx + thy * thy));
     v[0] = thx * gn; v[1] = thy * gn; v[2] = -gn;
 }
 IMS_DEV void v_to_xy(const ims_optics_t& o, const double (&v)[3], double& x, double& y)
@@ -266,37 +264,35 @@ IMS_DEV void diffract(const ims_optics_t& o, bool field_rot, double pu, double p
 }
 
 // ---------------- sequential ray trace ----------------
-IMS_DEV void surf_sag(const ims_surface_t& S, double r2, double& sag, double& dsag, bool& ok)
+IMS_DEV bool obscured(const ims_surface_t& S, double r2)
 {
-    double z = 0.0, dz = 0.0;
-    ok = true;
-    if (S.R != 0.0) {
-        const double c = S.inv_R;
-        double arg = 1.0 - (1.0 + S.conic) * c * c * r2;
-        if (arg < 0.0) { ok = false; arg = 0.0; }
-        const double sq = sqrt(arg);
-        const double inv = 1.0 / (sq * (1.0 + sq));
-        z = c * r2 * sq * inv;
-        dz = (sq > 0.0) ? 0.5 * c * (1.0 + sq) * inv : 0.0;
+    if (S.obsc_kind == IMS_OBSC_NONE) return false;
+    const double i2 = S.obsc_inner * S.obsc_inner, o2 = S.obsc_outer * S.obsc_outer;
+    switch (S.obsc_kind) {
+    case IMS_OBSC_CLEAR_ANNULUS: return !(r2 >= i2 && r2 <= o2);
+    case IMS_OBSC_CLEAR_CIRCLE:  return !(r2 <= o2);
+    case IMS_OBSC_OBSC_CIRCLE:   return r2 < o2;
+    case IMS_OBSC_OBSC_ANNULUS:  return (r2 >= i2 && r2 < o2);
     }
-    double rp = r2;
-    for (int k = 0; k < S.n_asphere; ++k) {
-        const double m = (double)(k + 2);
-        dz = dz + S.asph[k] * m * rp;
-        rp = rp * r2;
-        z = z + S.asph[k] * rp;
-    }
-    sag = z; dsag = dz;
+    return false;
 }
 
-// time of flight to the surface (spec v2: plane exact, conic closed form, asphere Newton from the conic root)
-IMS_DEV bool surf_intersect(const ims_surface_t& S, const double (&pos)[3], const double (&vel)[3], double& t_out)
+// Propagate to surface S (spec v3): plane exact; conic by the closed-form root nearest
+// the vertex plane, with the un-normalised normal (-c x, -c y, 1-(1+k) c z) that needs no sqrt;
+// even-asphere terms by Newton from the conic root until |f| <= 1e-11 m.
+IMS_DEV bool surf_hit(const ims_surface_t& S, double (&pos)[3], const double (&vel)[3], double (&N)[3], double& nn, double& r2_out)
 {
     const double pz = pos[2] - S.z0;
-    if (S.R == 0.0 && S.n_asphere == 0) { t_out = -pz / vel[2]; return true; }
     double t;
+    if (S.R == 0.0 && S.n_asphere == 0) {
+        t = -pz / vel[2];
+        pos[0] = pos[0] + vel[0] * t; pos[1] = pos[1] + vel[1] * t; pos[2] = S.z0;
+        N[0] = 0.0; N[1] = 0.0; N[2] = 1.0; nn = 1.0;
+        r2_out = pos[0] * pos[0] + pos[1] * pos[1];
+        return true;
+    }
+    const double c = S.inv_R, k1 = 1.0 + S.conic;
     if (S.R != 0.0) {
-        const double k1 = 1.0 + S.conic;
         const double A = vel[0] * vel[0] + vel[1] * vel[1] + k1 * vel[2] * vel[2];
         const double B = 2.0 * (pos[0] * vel[0] + pos[1] * vel[1] + k1 * pz * vel[2] - S.R * vel[2]);
         const double C = pos[0] * pos[0] + pos[1] * pos[1] + k1 * pz * pz - 2.0 * S.R * pz;
@@ -310,81 +306,89 @@ IMS_DEV bool surf_intersect(const ims_surface_t& S, const double (&pos)[3], cons
     } else {
         t = -pz / vel[2];
     }
-    if (S.n_asphere > 0) {
-        for (int it = 0; it < 5; ++it) {
-            const double x = pos[0] + vel[0] * t, y = pos[1] + vel[1] * t, z = pz + vel[2] * t;
-            double sag, ds; bool ok;
-            surf_sag(S, x * x + y * y, sag, ds, ok);
-            if (!ok) return false;
-            const double f = z - sag;
-            if (fabs(f) <= 1.0e-14) break;
-            const double fp = vel[2] - 2.0 * ds * (x * vel[0] + y * vel[1]);
-            t = t - f / fp;
+    if (S.n_asphere == 0) {
+        const double x = pos[0] + vel[0] * t, y = pos[1] + vel[1] * t, z = pz + vel[2] * t;
+        const double sqv = 1.0 - k1 * c * z;
+        if (!(sqv > 0.0)) return false;
+        pos[0] = x; pos[1] = y; pos[2] = S.z0 + z;
+        N[0] = -c * x; N[1] = -c * y; N[2] = sqv;
+        r2_out = x * x + y * y;
+        nn = c * c * r2_out + sqv * sqv;
+        return true;
+    }
+    double x = 0.0, y = 0.0, z = 0.0, r2 = 0.0, ds = 0.0;
+    for (int it = 0; it < 6; ++it) {
+        x = pos[0] + vel[0] * t; y = pos[1] + vel[1] * t; z = pz + vel[2] * t;
+        r2 = x * x + y * y;
+        double sag = 0.0;
+        ds = 0.0;
+        if (S.R != 0.0) {
+            const double arg = 1.0 - k1 * c * c * r2;
+            if (arg <= 0.0) return false;
+            const double sqv = sqrt(arg);
+            const double inv = 1.0 / (sqv * (1.0 + sqv));
+            sag = c * r2 * sqv * inv;
+            ds = 0.5 * c * (1.0 + sqv) * inv;
         }
+        double rp = r2;
+        for (int k = 0; k < S.n_asphere; ++k) {
+            ds = ds + S.asph[k] * (double)(k + 2) * rp;
+            rp = rp * r2;
+            sag = sag + S.asph[k] * rp;
+        }
+        const double f = z - sag;
+        if (fabs(f) <= 1.0e-11 || it == 5) break;
+        const double fp = vel[2] - 2.0 * ds * (x * vel[0] + y * vel[1]);
+        t = t - f / fp;
     }
-    t_out = t;
+    pos[0] = x; pos[1] = y; pos[2] = S.z0 + z;
+    N[0] = -2.0 * ds * x; N[1] = -2.0 * ds * y; N[2] = 1.0;
+    r2_out = r2;
+    nn = 4.0 * ds * ds * r2 + 1.0;
     return true;
-}
-
-IMS_DEV bool obscured(const ims_surface_t& S, double x, double y)
-{
-    if (S.obsc_kind == IMS_OBSC_NONE) return false;
-    const double r2 = x * x + y * y;
-    const double i2 = S.obsc_inner * S.obsc_inner, o2 = S.obsc_outer * S.obsc_outer;
-    switch (S.obsc_kind) {
-    case IMS_OBSC_CLEAR_ANNULUS: return !(r2 >= i2 && r2 <= o2);
-    case IMS_OBSC_CLEAR_CIRCLE:  return !(r2 <= o2);
-    case IMS_OBSC_OBSC_CIRCLE:   return r2 < o2;
-    case IMS_OBSC_OBSC_ANNULUS:  return (r2 >= i2 && r2 < o2);
-    }
-    return false;
 }
 
 // returns 0 ok, 1 vignetted, 2 failed
 IMS_DEV int trace(const ims_optics_t& o, double (&pos)[3], double (&vel)[3], double wave_nm)
 {
     int vignetted = 0;
-    double n_cur = medium_n(o.in_medium_kind, o.in_medium_c, wave_nm);
+    double n_cur;
+    if (o.in_medium_kind == IMS_MEDIUM_CONST) n_cur = o.in_medium_c[0];
+    else n_cur = medium_n(o.in_medium_kind, o.in_medium_c, wave_nm);
+    // the index of a medium is a pure function of (medium, wavelength): computed once per photon and
+    // reused when the same medium recurs (all Rubin lenses and filters are fused silica)
     int glass_id = -1;
-    double glass_n = 0.0;
+    double glass_n = 0.0, glass_in = 0.0;
     for (int k = 0; k < o.n_surfaces; ++k) {
         const ims_surface_t& S = o.surf[k];
-        double t, x, y, sag = 0.0, ds = 0.0;
-        bool ok = true;
-        if (!surf_intersect(S, pos, vel, t)) return 2;
-        x = pos[0] + vel[0] * t; y = pos[1] + vel[1] * t;
-        surf_sag(S, x * x + y * y, sag, ds, ok);
-        if (!ok) return 2;
-        pos[0] = x; pos[1] = y; pos[2] = S.z0 + sag;
-        if (obscured(S, x, y)) vignetted = 1;
+        double N[3], nn, r2;
+        if (!surf_hit(S, pos, vel, N, nn, r2)) return 2;
+        if (obscured(S, r2)) vignetted = 1;
         if (S.kind == IMS_SURF_BAFFLE || S.kind == IMS_SURF_DETECTOR) continue;
-        double nx = -2.0 * ds * x, ny = -2.0 * ds * y, nz = 1.0;
-        const double ninv = 1.0 / sqrt(nx * nx + ny * ny + 1.0);
-        nx = nx * ninv; ny = ny * ninv; nz = nz * ninv;
         if (S.kind == IMS_SURF_MIRROR) {
-            const double d = vel[0] * nx + vel[1] * ny + vel[2] * nz;
-            vel[0] = vel[0] - 2.0 * d * nx; vel[1] = vel[1] - 2.0 * d * ny; vel[2] = vel[2] - 2.0 * d * nz;
+            const double d = 2.0 * (vel[0] * N[0] + vel[1] * N[1] + vel[2] * N[2]) / nn;
+            vel[0] = vel[0] - d * N[0]; vel[1] = vel[1] - d * N[1]; vel[2] = vel[2] - d * N[2];
         } else {
-            // the index of a medium is a pure function of (medium, wavelength): reuse the last one
-            // computed when the same medium recurs (all Rubin lenses and filters are fused silica)
-            double n2;
-            if (S.medium_id == glass_id) {
-                n2 = glass_n;
-            } else {
+            double n2, in2;
+            if (S.medium_kind == IMS_MEDIUM_CONST) { n2 = S.medium_c[0]; in2 = S.medium_c[1]; }
+            else if (S.medium_id == glass_id) { n2 = glass_n; in2 = glass_in; }
+            else {
                 n2 = medium_n(S.medium_kind, S.medium_c, wave_nm);
-                if (S.medium_kind != IMS_MEDIUM_CONST) { glass_id = S.medium_id; glass_n = n2; }
+                in2 = 1.0 / n2;
+                glass_id = S.medium_id; glass_n = n2; glass_in = in2;
             }
-            const double in2 = 1.0 / n2;
-            const double dx = vel[0] * n_cur, dy = vel[1] * n_cur, dzz = vel[2] * n_cur;
-            double alpha = dx * nx + dy * ny + dzz * nz;
-            if (alpha > 0.0) { nx = -nx; ny = -ny; nz = -nz; alpha = -alpha; }
+            const double dx = vel[0] * n_cur, dy = vel[1] * n_cur, dz = vel[2] * n_cur;
+            double a = dx * N[0] + dy * N[1] + dz * N[2];
+            double sgn = 1.0;
+            if (a > 0.0) { sgn = -1.0; a = -a; }
             const double eta = n_cur * in2;
-            const double sinsqr = eta * eta * (1.0 - alpha * alpha);
+            const double inn = 1.0 / nn;
+            const double sinsqr = eta * eta * (1.0 - a * a * inn);
             if (sinsqr > 1.0) return 2;
-            const double nfac = eta * alpha + sqrt(1.0 - sinsqr);
-            vel[0] = (eta * dx - nfac * nx) * in2;
-            vel[1] = (eta * dy - nfac * ny) * in2;
-            vel[2] = (eta * dzz - nfac * nz) * in2;
+            const double nfac = sgn * (eta * a * inn + sqrt((1.0 - sinsqr) * inn));
+            vel[0] = (eta * dx - nfac * N[0]) * in2;
+            vel[1] = (eta * dy - nfac * N[1]) * in2;
+            vel[2] = (eta * dz - nfac * N[2]) * in2;
             n_cur = n2;
         }
     }

@@ -131,9 +131,14 @@ __global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_accumulate(const
 }
 
 // ---------------- pooled path ----------------
-// LSST_PhotonsBuilder.draw for all objects of a sub-batch, written straight into the merged pool
-__global__ __launch_bounds__(256) void k_shoot_photons(const ims_render_params_t P, const int64_t* __restrict__ photon_offset,
-                                                       const ims_photons_t pool)
+// LSST_PhotonsBuilder.draw for all objects of a sub-batch, written straight into the merged pool.
+// WITH_OPS additionally runs the configured photon-op chain before storing (used to pre-compute the
+// sensor-independent part of bright objects' photons, see Renderer.plan_lsst_image).
+// pool.pupil_u / pupil_v / time / obj_index may be NULL (not stored).
+template <bool WITH_OPS>
+__global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_photons(const ims_render_params_t P,
+                                                                        const int64_t* __restrict__ photon_offset,
+                                                                        const ims_photons_t pool)
 {
     const int64_t per = (P.n_segments + N_XCD - 1) / N_XCD;
     const int64_t b = blockIdx.x;
@@ -142,19 +147,18 @@ __global__ __launch_bounds__(256) void k_shoot_photons(const ims_render_params_t
     if (seg >= P.n_segments) return;
     const int64_t oi = find_object(P.seg_prefix, P.n_objects, seg);
     const ims_object_t& o = P.objects[oi];
-    const int64_t j0 = (seg - P.seg_prefix[oi]) * P.seg_size;
-    int64_t j1 = j0 + P.seg_size;
-    if (j1 > o.n_phot) j1 = o.n_phot;
-    const int64_t base = photon_offset[oi];
-    for (int64_t j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
-        Photon ph;
-        make_photon(P, o, o.phot_first + j, ph);
-        const int64_t i = base + j;
-        pool.x[i] = ph.x; pool.y[i] = ph.y; pool.flux[i] = ph.flux;
-        pool.dxdz[i] = ph.dxdz; pool.dydz[i] = ph.dydz; pool.wavelength[i] = ph.wl;
-        pool.pupil_u[i] = ph.pu; pool.pupil_v[i] = ph.pv; pool.time[i] = ph.t;
-        pool.obj_index[i] = (int32_t)oi;
-    }
+    const int64_t j = (seg - P.seg_prefix[oi]) * P.seg_size + threadIdx.x;
+    if (j >= o.n_phot) return;
+    const int64_t k = o.phot_first + j;
+    Photon ph;
+    make_photon(P, o, k, ph);
+    if (WITH_OPS)
+        for (int q = 0; q < P.n_ops; ++q) apply_op(P, q, o, k, ph);
+    const int64_t i = photon_offset[oi] + j;
+    pool.x[i] = ph.x; pool.y[i] = ph.y; pool.flux[i] = ph.flux;
+    pool.dxdz[i] = ph.dxdz; pool.dydz[i] = ph.dydz; pool.wavelength[i] = ph.wl;
+    if (pool.pupil_u) { pool.pupil_u[i] = ph.pu; pool.pupil_v[i] = ph.pv; pool.time[i] = ph.t; }
+    if (pool.obj_index) pool.obj_index[i] = (int32_t)oi;
 }
 
 __device__ __forceinline__ void load_photon(const ims_photons_t& pool, int64_t i, Photon& ph)
@@ -204,6 +208,41 @@ __global__ __launch_bounds__(256) void k_accumulate(const ims_render_params_t P,
         const int64_t pidx = (int64_t)py * P.nx + px;
         unsafeAtomicAdd(P.image + pidx, (float)ph.flux);
         if (pixel_index_out) pixel_index_out[i] = (int32_t)pidx;
+    }
+}
+
+// sensor.accumulate for one ROUND of the bright objects: segment-mapped like the fused kernel, but
+// the photon (already through the op chain) is loaded from the pool at pool_start[object] + j.
+__global__ __launch_bounds__(256) void k_accumulate_segments(const ims_render_params_t P, const ims_photons_t pool,
+                                                             const int64_t* __restrict__ pool_start)
+{
+    const int64_t per = (P.n_segments + N_XCD - 1) / N_XCD;
+    const int64_t b = blockIdx.x;
+    if ((b / N_XCD) >= per) return;
+    const int64_t seg = xcd_segment(b, P.n_segments);
+    if (seg >= P.n_segments) return;
+    const int64_t oi = find_object(P.seg_prefix, P.n_objects, seg);
+    const ims_object_t& o = P.objects[oi];
+    const int64_t j = (seg - P.seg_prefix[oi]) * P.seg_size + threadIdx.x;
+    const bool silicon = (P.sensor != nullptr) && (P.sensor->kind == IMS_SENSOR_SILICON);
+    const bool has_angles = chain_has_angles(P);
+    double added = 0.0;
+    if (j < o.n_phot) {
+        const int64_t i = pool_start[oi] + j;
+        Photon ph;
+        ph.x = pool.x[i]; ph.y = pool.y[i]; ph.flux = pool.flux[i]; ph.dxdz = pool.dxdz[i]; ph.dydz = pool.dydz[i];
+        ph.wl = pool.wavelength[i]; ph.pu = 0.0; ph.pv = 0.0; ph.t = 0.0;
+        int ix, iy;
+        if (ph.flux != 0.0 && land(P, o, o.phot_first + j, ph, silicon, has_angles, ix, iy)) {
+            added = ph.flux;
+            const int px = ix - P.xmin, py = iy - P.ymin;
+            if (px >= 0 && px < P.nx && py >= 0 && py < P.ny)
+                unsafeAtomicAdd(P.image + ((int64_t)py * P.nx + px), (float)ph.flux);
+        }
+    }
+    if (P.realized_flux != nullptr) {
+        const double tot = wave_sum(added);
+        if ((threadIdx.x & 63) == 0 && tot != 0.0) unsafeAtomicAdd(P.realized_flux + oi, tot);
     }
 }
 
@@ -491,6 +530,7 @@ __global__ __launch_bounds__(256) void k_refresh_changed(const ims_sensor_t* __r
     if (!r.valid) return;
     const SlotView& sl = r.sl;
     const int i = r.i, j = r.j;
+    s.bf_delta[sl.offset + r.c] = 0.0f;       // the update kernel has consumed the delta charge
     if (i >= sl.nx || j >= sl.ny) return;
     if (!(changed[cell_index(sl, i, j)] | changed[cell_index(sl, i + 1, j)] | changed[cell_index(sl, i, j + 1)])) return;
     const int nV = s.num_vertices, nv = 4 * nV + 4;
@@ -639,8 +679,43 @@ int ims_shoot_photons(const ims_render_params_t* params, const int64_t* photon_o
     if (params->n_segments == 0) return IMS_OK;
     hipStream_t st = (hipStream_t)stream;
     {
-        hipLaunchKernelGGL(k_shoot_photons, dim3(grid_for_segments(params->n_segments)), dim3(256), 0, st,
+        hipLaunchKernelGGL(k_shoot_photons<false>, dim3(grid_for_segments(params->n_segments)), dim3(256), 0, st,
                            *params, photon_offset, *pool);
+    }
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+int ims_shoot_ops_photons(const ims_render_params_t* params, const int64_t* photon_offset,
+                          const ims_photons_t* pool, void* stream)
+{
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (!photon_offset || !pool) return set_err(IMS_ERR_ARG, "photon_offset/pool is NULL");
+    if (params->n_segments == 0) return IMS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        LaunchTimer tm(st);
+        hipLaunchKernelGGL(k_shoot_photons<true>, dim3(grid_for_segments(params->n_segments)), dim3(256), 0, st,
+                           *params, photon_offset, *pool);
+    }
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+int ims_accumulate_segments(const ims_render_params_t* params, const ims_photons_t* pool, const int64_t* pool_start,
+                            void* stream)
+{
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (!pool || !pool_start) return set_err(IMS_ERR_ARG, "pool/pool_start is NULL");
+    if (!params->image) return set_err(IMS_ERR_ARG, "image is NULL");
+    if (params->n_segments == 0) return IMS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        LaunchTimer tm(st);
+        hipLaunchKernelGGL(k_accumulate_segments, dim3(grid_for_segments(params->n_segments)), dim3(256), 0, st,
+                           *params, *pool, pool_start);
     }
     HIP_TRY(hipGetLastError());
     return IMS_OK;
@@ -736,7 +811,6 @@ int ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sens
     else
         hipLaunchKernelGGL(k_update_distortions, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot, n_slots,
                            tile_prefix_dev, changed_dev);
-    hipLaunchKernelGGL(k_zero_delta, dim3(g), dim3(256), 0, st, sensor_dev, begin, count);
     hipLaunchKernelGGL(k_refresh_changed, dim3(g), dim3(256), 0, st, sensor_dev, first_slot, n_slots, begin, count,
                        (const unsigned char*)changed_dev);
     HIP_TRY(hipGetLastError());

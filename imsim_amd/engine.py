@@ -69,7 +69,7 @@ class Scene:
     track_static_delta: int = 0
 
 
-def plan_bf_groups(objects, nrecalc, n_static, static_cells, scratch_cells, max_slots):
+def plan_bf_groups(objects, nrecalc, n_static, static_cells, scratch_cells, max_slots, max_photons=1 << 62):
     """LSST_Image mode: objects whose own charge triggers pixel-boundary recalculations
     (n_phot > nrecalc) need a private boundary region the size of their stamp.  Returns
     (normal_index, groups) with groups = [(index_array sorted by n_phot desc, slots_array)], each
@@ -82,15 +82,16 @@ def plan_bf_groups(objects, nrecalc, n_static, static_cells, scratch_cells, max_
     groups = []
     start = 0
     while start < len(idx):
-        cells, k = 0, start
+        cells, k, photons = 0, start, 0
         regions = []
         while k < len(idx) and len(regions) < max_slots - n_static:
             o = objects[idx[k]]
             nx = int(o["stamp_xmax"]) - int(o["stamp_xmin"]) + 1
             ny = int(o["stamp_ymax"]) - int(o["stamp_ymin"]) + 1
             c = (nx + 1) * (ny + 1)
-            if cells + c > scratch_cells:
+            if cells + c > scratch_cells or (k > start and photons + int(o["n_phot"]) > max_photons):
                 break
+            photons += int(o["n_phot"])
             regions.append((int(o["stamp_xmin"]), int(o["stamp_ymin"]), nx, ny))
             cells += c
             k += 1
@@ -308,12 +309,28 @@ class Renderer:
         self.scene = scene
         self.bound = BoundScene(scene, self.mem)
         self.image = self.torch.zeros((scene.ny, scene.nx), dtype=self.torch.float32, device=self.device)
+        # two side streams: the sequential brighter-fatter chain of the bright objects runs at high
+        # priority while the wide single-launch work fills the CUs it leaves idle
+        self.s_chain = self.torch.cuda.Stream(self.device, priority=-1)
+        self.s_bulk = self.torch.cuda.Stream(self.device, priority=0)
+        self.max_pool_photons = 300_000_000      # 48 B each
         if scene.sensor is not None:
             self.init_boundaries(0, len(scene.sensor.slots))
 
     # -- helpers --
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    POOL6 = ("x", "y", "flux", "dxdz", "dydz", "wavelength")
+
+    def _pool6(self, n):
+        """A compact pool holding only what the sensor needs of a photon."""
+        t = {f: self.torch.empty(max(int(n), 1), dtype=self.torch.float64, device=self.device) for f in self.POOL6}
+        ph = Photons()
+        ph.n = int(n)
+        for f in self.POOL6:
+            setattr(ph, f, t[f].data_ptr())
+        return ph, t
 
     def _upload_objects(self, objects):
         objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
@@ -338,24 +355,30 @@ class Renderer:
         """Build the launch plan of LSST_Image + LSST_Silicon semantics (imsim/lsst_image.py:342-368,
         imsim/stamp.py:558-573): every object accumulates on its own stamp, so brighter-fatter only
         sees the object's own charge.  Objects below `nrecalc` photons never trigger a boundary
-        update and share the static (tree-ring) CCD boundaries in ONE launch; brighter objects get
-        a private boundary region and are advanced together in rounds of `nrecalc` photons, with
-        one batched updatePixelDistortions between rounds.  All object tables of the plan are
-        uploaded here, so executing the plan touches no host data."""
+        update and share the static (tree-ring) CCD boundaries in ONE fused launch (bulk stream).
+        Brighter objects get a private boundary region; the sensor-independent part of ALL their
+        photons (shoot, PSF, op chain) is computed by one wide launch into a compact pool, and only
+        the sensor step is advanced in rounds of `nrecalc` photons with one batched
+        updatePixelDistortions between rounds (chain stream, high priority).  All object tables of
+        the plan are uploaded here, so executing the plan touches no host data."""
         ss = self.scene.sensor
         objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
         plan = []
         realized_parts = []
 
-        def add_render(part, index):
+        def upload(part, index, kind, extra=None):
             part, obj_t, prefix, pre_t = self._upload_objects(part)
             tmp = None
-            if want_realized:
+            if want_realized and kind != "shoot_pool":
                 tmp = self.torch.zeros(len(part), dtype=self.torch.float64, device=self.device)
                 realized_parts.append((self.torch.from_numpy(np.asarray(index, dtype=np.int64)).to(self.device), tmp))
             P = self.bound.params(obj_t.data_ptr(), len(part), pre_t.data_ptr(), int(prefix[-1]),
                                   self.image.data_ptr(), tmp.data_ptr() if tmp is not None else None)
-            plan.append(("render", P, (obj_t, pre_t), int(part["n_phot"].sum()), len(part)))
+            return P, (obj_t, pre_t, tmp)
+
+        def add_render(part, index, stream="bulk"):
+            P, keep = upload(part, index, "render")
+            plan.append(("render", P, keep, int(part["n_phot"].sum()), len(part), stream))
 
         if ss is None:
             if len(objects):
@@ -365,42 +388,109 @@ class Renderer:
             nrecalc = ss.model.nrecalc
         b = self.bound
         normal, groups = plan_bf_groups(objects, nrecalc, b.n_static_slots, b.static_cells, ss.scratch_cells,
-                                        b.slot_capacity)
+                                        b.slot_capacity, self.max_pool_photons)
         if len(normal):
             part = objects[normal].copy()
             part["bf_state"] = 0
-            add_render(part, normal)
+            add_render(part, normal, "bulk")
         for idx, slots in groups:
             plan.append(("slots", slots))
             n0 = b.n_static_slots
             plan.append(("init", n0, len(slots)))
-            grp = objects[idx]
+            grp = objects[idx].copy()
+            grp["bf_state"] = n0 + np.arange(len(grp))
             total = grp["n_phot"].copy()
+            # 1. everything of the photons that does not depend on the sensor state, in ONE wide launch
+            offs = np.concatenate([[0], np.cumsum(total)]).astype(np.int64)
+            offs_t = self.torch.from_numpy(offs).to(self.device)
+            pool, pool_t = self._pool6(offs[-1])
+            P, keep = upload(grp, idx, "shoot_pool")
+            plan.append(("shoot_pool", P, (keep, offs_t, pool_t), pool, offs_t, int(total.sum()), len(grp)))
+            # 2. the sequential part: rounds of nrecalc photons per object through the sensor
             rounds = int((total.max() + nrecalc - 1) // nrecalc)
             for r in range(rounds):
                 n_act = int(np.count_nonzero(total > r * nrecalc))
                 part = grp[:n_act].copy()
                 part["phot_first"] = grp["phot_first"][:n_act] + r * nrecalc
                 part["n_phot"] = np.minimum(nrecalc, total[:n_act] - r * nrecalc)
-                part["bf_state"] = n0 + np.arange(n_act)
-                add_render(part, idx[:n_act])
+                start_t = self.torch.from_numpy(offs[:n_act] + r * nrecalc).to(self.device)
+                P, keep = upload(part, idx[:n_act], "acc_pool")
+                plan.append(("acc_pool", P, (keep, start_t), pool, start_t, int(part["n_phot"].sum()), n_act))
                 n_cont = int(np.count_nonzero(total > (r + 1) * nrecalc))
                 if n_cont:
                     plan.append(("update", n0, n_cont))
         return plan, realized_parts
 
-    def execute_plan(self, plan):
-        st = self._stream()
+    def _compile_plan(self, plan):
+        """Turn plan items into (c_function, argument tuple) pairs so that replaying the plan costs
+        one ctypes call per launch (the brighter-fatter chain is launch-rate bound on the host)."""
+        lib = self.lib
+        chain = C.c_void_p(self.s_chain.cuda_stream)
+        bulk = C.c_void_p(self.s_bulk.cuda_stream)
+        b = self.bound
+        if self.scene.sensor is not None and not hasattr(self, "_changed"):
+            cells = b.static_cells + int(self.scene.sensor.scratch_cells)
+            self._changed = self.torch.zeros(max(cells, 1), dtype=self.torch.uint8, device=self.device)
+        out = []
+        keep = []
+        cur_slots = None
         for item in plan:
             kind = item[0]
             if kind == "render":
-                _abi.check(self.lib.ims_shoot_accumulate(C.byref(item[1]), st), "ims_shoot_accumulate")
-            elif kind == "update":
-                self.update_distortions(item[1], item[2])
-            elif kind == "init":
-                self.init_boundaries(item[1], item[2])
+                out.append((lib.ims_shoot_accumulate, (C.byref(item[1]), bulk if item[5] == "bulk" else chain)))
+            elif kind == "acc_pool":
+                out.append((lib.ims_accumulate_segments, (C.byref(item[1]), C.byref(item[3]), item[4].data_ptr(), chain)))
+            elif kind == "shoot_pool":
+                out.append((lib.ims_shoot_ops_photons, (C.byref(item[1]), item[4].data_ptr(), C.byref(item[3]), chain)))
             elif kind == "slots":
-                self.bound.set_private_slots(item[1])
+                cur_slots = item[1]
+                tiles = ((cur_slots["nx"].astype(np.int64) + 1 + 15) // 16) * ((cur_slots["ny"].astype(np.int64) + 1 + 15) // 16)
+                prefix = np.concatenate([[0], np.cumsum(tiles)]).astype(np.int64)
+                prefix_t = self.torch.from_numpy(prefix).to(self.device)
+                keep.append(prefix_t)
+                cur_prefix = (prefix, prefix_t)
+                out.append(("slots", item[1]))
+            elif kind == "init":
+                out.append((lib.ims_sensor_init_boundaries, (b.sensor_dev_ptr, C.byref(b.sensor_host), item[1], item[2], chain)))
+            elif kind == "update":
+                first, n = item[1], item[2]
+                if first == b.n_static_slots and cur_slots is not None:
+                    prefix, prefix_t = cur_prefix
+                else:
+                    prefix, prefix_t = self._tile_prefix(first)
+                out.append((lib.ims_sensor_update_distortions,
+                            (b.sensor_dev_ptr, C.byref(b.sensor_host), first, n, prefix_t.data_ptr(), int(prefix[n]),
+                             self._changed.data_ptr(), chain)))
+        return out, keep
+
+    def execute_plan(self, plan, compiled=None):
+        """Run a launch plan.  Items tagged "bulk" go to the bulk stream, everything else (the
+        brighter-fatter chain) to the high-priority chain stream; both are joined back into the
+        caller's stream."""
+        torch = self.torch
+        if compiled is None:
+            compiled = self._compile_plan(plan)
+        calls, _ = compiled
+        main = torch.cuda.current_stream(self.device)
+        ev0 = torch.cuda.Event()
+        ev0.record(main)
+        self.s_chain.wait_event(ev0)
+        self.s_bulk.wait_event(ev0)
+        for f, args in calls:
+            if f == "slots":
+                # the slot table is host-written: order it after everything queued so far
+                self.s_chain.synchronize()
+                with torch.cuda.stream(self.s_chain):
+                    self.bound.set_private_slots(args)
+                continue
+            rc = f(*args)
+            if rc:
+                _abi.check(rc, getattr(f, "__name__", "launch"))
+        ev1, ev2 = torch.cuda.Event(), torch.cuda.Event()
+        ev1.record(self.s_chain)
+        ev2.record(self.s_bulk)
+        main.wait_event(ev1)
+        main.wait_event(ev2)
 
     def render_lsst_image(self, objects, nrecalc=None, realized=None):
         plan, parts = self.plan_lsst_image(objects, nrecalc, want_realized=realized is not None)
@@ -422,12 +512,15 @@ class Renderer:
                     self.bound.set_private_slots(it[1])
             plan = [it for it in plan if it[0] != "slots"]
 
+        compiled = self._compile_plan(plan)
+
         def launch():
-            self.execute_plan(plan)
+            self.execute_plan(plan, compiled)
         launch.plan = plan
-        launch.photons = sum(it[3] for it in plan if it[0] == "render")
-        launch.object_rows = sum(it[4] for it in plan if it[0] == "render")
-        launch.n_render_launches = sum(1 for it in plan if it[0] == "render")
+        launch.photons = sum(it[3] for it in plan if it[0] == "render") + sum(it[5] for it in plan if it[0] == "shoot_pool")
+        launch.object_rows = sum(it[4] for it in plan if it[0] == "render") + sum(it[6] for it in plan if it[0] in ("shoot_pool", "acc_pool"))
+        launch.pool_photons = sum(it[5] for it in plan if it[0] == "shoot_pool")
+        launch.n_render_launches = sum(1 for it in plan if it[0] in ("render", "shoot_pool", "acc_pool"))
         return launch
 
     def prepared(self, objects):
@@ -479,9 +572,10 @@ class Renderer:
         return pix[:pool.n] if pix is not None else None
 
     # -- sensor state --
-    def init_boundaries(self, first_slot, n_slots):
+    def init_boundaries(self, first_slot, n_slots, stream=None):
         _abi.check(self.lib.ims_sensor_init_boundaries(self.bound.sensor_dev_ptr, C.byref(self.bound.sensor_host),
-                                                       first_slot, n_slots, self._stream()), "ims_sensor_init_boundaries")
+                                                       first_slot, n_slots, stream if stream is not None else self._stream()),
+                   "ims_sensor_init_boundaries")
 
     def _tile_prefix(self, first_slot):
         """Device prefix sum of 16x16 owner-cell tiles over slots [first_slot, n_bf_slots) (cached
@@ -496,14 +590,15 @@ class Renderer:
             self._tile_cache = (key, prefix, self.torch.from_numpy(prefix).to(self.device))
         return self._tile_cache[1], self._tile_cache[2]
 
-    def update_distortions(self, first_slot, n_slots):
+    def update_distortions(self, first_slot, n_slots, stream=None):
         if not hasattr(self, "_changed"):
             cells = self.bound.static_cells + int(self.scene.sensor.scratch_cells)
             self._changed = self.torch.zeros(max(cells, 1), dtype=self.torch.uint8, device=self.device)
         prefix, prefix_t = self._tile_prefix(first_slot)
         _abi.check(self.lib.ims_sensor_update_distortions(self.bound.sensor_dev_ptr, C.byref(self.bound.sensor_host),
                                                           first_slot, n_slots, prefix_t.data_ptr(), int(prefix[n_slots]),
-                                                          self._changed.data_ptr(), self._stream()),
+                                                          self._changed.data_ptr(),
+                                                          stream if stream is not None else self._stream()),
                    "ims_sensor_update_distortions")
 
     def image_numpy(self):

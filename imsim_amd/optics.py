@@ -349,9 +349,15 @@ def fill_optics(o: "_abi.Optics", tel: Telescope, fp_to_pix, rot_tel_pos=0.0):
     (imsim/utils.py:42-59; e.g. R22_S11: (100, 0, 2047.5, 0, 100, 2001.5), tests/test_photon_ops.py:668-691)."""
     if len(tel.surfaces) > _abi.IMS_MAX_SURFACES:
         raise ValueError("too many surfaces")
+    def medium_coeffs(medium):
+        c = [float(v) for v in medium[1]]
+        if medium[0] == _abi.IMS_MEDIUM_CONST:
+            c[1] = 1.0 / c[0]            # constant media carry 1/n for the kernel (include/imsim_hip.h)
+        return c
+
     o.in_medium_kind = tel.in_medium[0]
-    for k in range(6):
-        o.in_medium_c[k] = float(tel.in_medium[1][k])
+    for k, v in enumerate(medium_coeffs(tel.in_medium)):
+        o.in_medium_c[k] = v
     o.n_surfaces = len(tel.surfaces)
     o.stop_z = tel.stop_z
     media = {}
@@ -367,8 +373,8 @@ def fill_optics(o: "_abi.Optics", tel: Telescope, fp_to_pix, rot_tel_pos=0.0):
         for m in range(4):
             s.asph[m] = float(S.asph[m]) if m < len(S.asph) else 0.0
         s.obsc_inner, s.obsc_outer = S.obsc_inner, S.obsc_outer
-        for m in range(6):
-            s.medium_c[m] = float(S.medium[1][m])
+        for m, v in enumerate(medium_coeffs(S.medium)):
+            s.medium_c[m] = v
     o.cam_rot[0], o.cam_rot[1] = math.cos(rot_tel_pos), math.sin(rot_tel_pos)
     for k in range(6):
         o.fp_to_pix[k] = float(fp_to_pix[k])

@@ -71,7 +71,7 @@ extern "C" {
 #define IMS_SURF_REFRACT  2
 #define IMS_SURF_DETECTOR 3
 #define IMS_SURF_BAFFLE   4   /* plane that only applies its obscuration */
-#define IMS_MEDIUM_CONST     0   /* n = c0 */
+#define IMS_MEDIUM_CONST     0   /* n = c0; c1 must hold 1/c0 */
 #define IMS_MEDIUM_SELLMEIER 1   /* n^2 = 1 + sum B_i l^2/(l^2 - C_i), l in micron; c0..c5 = B1,B2,B3,C1,C2,C3 */
 #define IMS_MEDIUM_AIR       2   /* Filippenko/Edlen air; c0=pressure kPa, c1=temperature K, c2=H2O kPa */
 #define IMS_OBSC_NONE          0
@@ -270,6 +270,14 @@ int  ims_shoot_accumulate(const ims_render_params_t* params, void* stream);
 /* photon_offset[n_objects+1] (device): where each object's photons live in the pool */
 int  ims_shoot_photons(const ims_render_params_t* params, const int64_t* photon_offset,
                        const ims_photons_t* pool, void* stream);
+/* shoot + PSF + the whole photon-op chain, stored to the pool (everything of a photon that does not
+ * depend on the sensor state); pool->pupil_u/pupil_v/time/obj_index may be NULL */
+int  ims_shoot_ops_photons(const ims_render_params_t* params, const int64_t* photon_offset,
+                           const ims_photons_t* pool, void* stream);
+/* sensor.accumulate for the objects of `params` (segment-mapped like ims_shoot_accumulate): photon j of
+ * object row i is read from the pool at pool_start[i] + j; its random stream index is phot_first + j */
+int  ims_accumulate_segments(const ims_render_params_t* params, const ims_photons_t* pool,
+                             const int64_t* pool_start, void* stream);
 int  ims_apply_ops(const ims_render_params_t* params, const int64_t* photon_offset,
                    const ims_photons_t* pool, void* stream);
 /* pixel_index_out (device, [pool->n], may be NULL): flat image index each photon landed in, -1 = lost */
@@ -295,7 +303,7 @@ int  ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sen
 int  ims_image_add(float* dst, const float* src, int64_t n, void* stream);
 
 /* ---- timing of the dominant kernel ----
- * After ims_enable_timing(1) every ims_shoot_accumulate launch is bracketed by a hipEvent pair on its
+ * After ims_enable_timing(1) every ims_shoot_accumulate / ims_shoot_ops_photons / ims_accumulate_segments launch is bracketed by a hipEvent pair on its
  * stream.  ims_last_kernel_ms returns the SUM of their durations and their count since the last query
  * (and resets the accumulation). */
 int  ims_last_kernel_ms(float* ms, int* n_launches);

@@ -114,12 +114,20 @@ class RenderParams(C.Structure):
                 ("nx", c_i32), ("ny", c_i32), ("xmin", c_i32), ("ymin", c_i32), ("realized_flux", c_vp)]
 
 
+class PlanItem(C.Structure):
+    _fields_ = [("kind", c_i32), ("stream", c_i32), ("params", c_vp), ("pool", c_vp), ("aux", c_vp),
+                ("first_slot", c_i32), ("n_slots", c_i32), ("n_tiles", c_i64)]
+
+
+(IMS_PLAN_RENDER, IMS_PLAN_SHOOT_POOL, IMS_PLAN_ACC_POOL, IMS_PLAN_UPDATE, IMS_PLAN_INIT, IMS_PLAN_RECORD,
+ IMS_PLAN_WAIT) = range(1, 8)
+
 STRUCTS = [Object, RadialTables, LinTables, PsfComponent, Op, Surface, TanSip, Optics, BfSlot, Sensor, Photons,
-           RenderParams]
+           RenderParams, PlanItem]
 
 # every symbol include/imsim_hip.h declares
 EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_info", "ims_shoot_accumulate",
-           "ims_shoot_photons", "ims_shoot_ops_photons", "ims_accumulate_segments", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
+           "ims_shoot_photons", "ims_shoot_ops_photons", "ims_accumulate_segments", "ims_run_plan", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
            "ims_sensor_update_distortions", "ims_image_add", "ims_last_kernel_ms", "ims_enable_timing",
            "ims_struct_size", "ims_test_math"]
 
@@ -162,6 +170,7 @@ def load():
     lib.ims_sensor_init_boundaries.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_vp]
     lib.ims_sensor_update_distortions.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]
     lib.ims_image_add.argtypes = [c_vp, c_vp, c_i64, c_vp]
+    lib.ims_run_plan.argtypes = [C.POINTER(PlanItem), c_i64, c_vp, C.POINTER(Sensor), c_vp, c_vp, c_vp]
     lib.ims_last_kernel_ms.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.ims_enable_timing.argtypes = [C.c_int]
     lib.ims_device_count.argtypes = [C.POINTER(C.c_int)]

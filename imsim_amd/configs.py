@@ -54,7 +54,7 @@ BENCH_CONFIGS = {
         objects=None,
         make_step=lambda renderer, objects: renderer.prepared_lsst_image(objects),
         bytes_per_photon=8,
-        kernel="k_shoot_accumulate",
+        kernel="k_shoot_accumulate + k_shoot_photons<true> (photon pipeline)",
         cpu_sample=1500,
         cpu_scene=_c3_cpu_scene,
         cpu_step=lambda orc, sample: orc.render_lsst_image(sample),

@@ -611,13 +611,8 @@ IMS_DEV bool land(const ims_render_params_t& P, const ims_object_t& o, int64_t k
         const int n = (u01(dc.b) > 0.5) ? 0 : step;
         ix = ix + XOFF[n]; iy = iy + YOFF[n];
     }
-    if (ix < o.stamp_xmin || ix > o.stamp_xmax || iy < o.stamp_ymin || iy > o.stamp_ymax) return false;
-    if (o.bf_state > 0 || P.track_static_delta) {
-        const int di = ix - sl.xmin, dj = iy - sl.ymin;
-        if (di >= 0 && di < sl.nx && dj >= 0 && dj < sl.ny)
-            unsafeAtomicAdd(s.bf_delta + cell_index(sl, di, dj), (float)ph.flux);
-    }
-    return true;
+    // the caller deposits the charge (CCD image and, for tracked regions, the delta-charge image)
+    return !(ix < o.stamp_xmin || ix > o.stamp_xmax || iy < o.stamp_ymin || iy > o.stamp_ymax);
 }
 
 IMS_DEV bool chain_has_angles(const ims_render_params_t& P)

@@ -88,6 +88,61 @@ __device__ __forceinline__ void make_photon(const ims_render_params_t& P, const 
     ph.y = o.y0 + ph.y;
 }
 
+// ---------------- per-workgroup charge tile ----------------
+// All photons of a workgroup belong to ONE object, and a bright star puts thousands of photons per
+// round into a few dozen pixels: global atomics on those hot addresses serialise in L2.  Each
+// workgroup therefore first sums its photons into a 32x32-pixel LDS tile centred on the object
+// (ds_add_f32), then flushes each non-empty tile cell with ONE global atomic to the CCD image (and
+// to the delta-charge image when the object's region is brighter-fatter tracked).  Photons outside
+// the tile go straight to global memory.  Unit fluxes keep every partial sum an exact integer, so
+// the result stays independent of the order of the atomics.
+constexpr int CT = 32;
+
+struct ChargeTile {
+    int x0, y0;                // pixel coordinates of tile cell (0,0)
+    bool track;                // also add to the slot's delta image
+    ims_bf_slot_t slot;
+};
+
+__device__ __forceinline__ void tile_begin(float* tile, ChargeTile& ct, const ims_render_params_t& P, const ims_object_t& o,
+                                           bool silicon)
+{
+    for (int e = threadIdx.x; e < CT * CT; e += 256) tile[e] = 0.0f;
+    ct.x0 = (int)floor(o.x0 + 0.5) - CT / 2;
+    ct.y0 = (int)floor(o.y0 + 0.5) - CT / 2;
+    ct.track = silicon && !(o.flags & IMS_OBJ_FAINT) && (o.bf_state > 0 || P.track_static_delta);
+    if (ct.track) ct.slot = P.sensor->bf_slots[o.bf_state];
+    __syncthreads();
+}
+
+__device__ __forceinline__ void deposit_global(const ims_render_params_t& P, const ChargeTile& ct, int ix, int iy, float flux)
+{
+    const int px = ix - P.xmin, py = iy - P.ymin;
+    if (px >= 0 && px < P.nx && py >= 0 && py < P.ny) unsafeAtomicAdd(P.image + ((int64_t)py * P.nx + px), flux);
+    if (ct.track) {
+        const int di = ix - ct.slot.xmin, dj = iy - ct.slot.ymin;
+        if (di >= 0 && di < ct.slot.nx && dj >= 0 && dj < ct.slot.ny)
+            unsafeAtomicAdd(P.sensor->bf_delta + (ct.slot.offset + (int64_t)dj * (ct.slot.nx + 1) + di), flux);
+    }
+}
+
+__device__ __forceinline__ void tile_deposit(float* tile, const ChargeTile& ct, const ims_render_params_t& P, int ix, int iy,
+                                             float flux)
+{
+    const int tx = ix - ct.x0, ty = iy - ct.y0;
+    if (tx >= 0 && tx < CT && ty >= 0 && ty < CT) atomicAdd(&tile[ty * CT + tx], flux);
+    else deposit_global(P, ct, ix, iy, flux);
+}
+
+__device__ __forceinline__ void tile_flush(float* tile, const ChargeTile& ct, const ims_render_params_t& P)
+{
+    __syncthreads();
+    for (int e = threadIdx.x; e < CT * CT; e += 256) {
+        const float v = tile[e];
+        if (v != 0.0f) deposit_global(P, ct, ct.x0 + e % CT, ct.y0 + e / CT, v);
+    }
+}
+
 // ---------------- fused kernel: LSST_Silicon draw (phot) + stamp->CCD add ----------------
 #ifndef IMS_FUSED_WAVES
 #define IMS_FUSED_WAVES 4
@@ -107,6 +162,9 @@ __global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_accumulate(const
     if (j1 > o.n_phot) j1 = o.n_phot;
     const bool silicon = (P.sensor != nullptr) && (P.sensor->kind == IMS_SENSOR_SILICON);
     const bool has_angles = chain_has_angles(P);
+    __shared__ float tile[CT * CT];
+    ChargeTile ct;
+    tile_begin(tile, ct, P, o, silicon);
     double added = 0.0;
     // exactly one photon per thread (seg_size == workgroup size): no photon loop, so the compiler
     // cannot hoist the chain's uniform operands across iterations into registers
@@ -119,11 +177,10 @@ __global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_accumulate(const
         int ix, iy;
         if (ph.flux != 0.0 && land(P, o, k, ph, silicon, has_angles, ix, iy)) {
             added += ph.flux;
-            const int px = ix - P.xmin, py = iy - P.ymin;
-            if (px >= 0 && px < P.nx && py >= 0 && py < P.ny)
-                unsafeAtomicAdd(P.image + ((int64_t)py * P.nx + px), (float)ph.flux);
+            tile_deposit(tile, ct, P, ix, iy, (float)ph.flux);
         }
     }
+    tile_flush(tile, ct, P);
     if (P.realized_flux != nullptr) {
         const double tot = wave_sum(added);
         if ((threadIdx.x & 63) == 0 && tot != 0.0) unsafeAtomicAdd(P.realized_flux + oi, tot);
@@ -203,6 +260,12 @@ __global__ __launch_bounds__(256) void k_accumulate(const ims_render_params_t P,
         int ix, iy;
         if (!land(P, o, k, ph, silicon, has_angles, ix, iy)) continue;
         if (P.realized_flux != nullptr) unsafeAtomicAdd(P.realized_flux + oi, ph.flux);
+        if (silicon && !(o.flags & IMS_OBJ_FAINT) && (o.bf_state > 0 || P.track_static_delta)) {
+            const ims_bf_slot_t bs = P.sensor->bf_slots[o.bf_state];
+            const int di = ix - bs.xmin, dj = iy - bs.ymin;
+            if (di >= 0 && di < bs.nx && dj >= 0 && dj < bs.ny)
+                unsafeAtomicAdd(P.sensor->bf_delta + (bs.offset + (int64_t)dj * (bs.nx + 1) + di), (float)ph.flux);
+        }
         const int px = ix - P.xmin, py = iy - P.ymin;
         if (px < 0 || px >= P.nx || py < 0 || py >= P.ny) continue;
         const int64_t pidx = (int64_t)py * P.nx + px;
@@ -226,6 +289,9 @@ __global__ __launch_bounds__(256) void k_accumulate_segments(const ims_render_pa
     const int64_t j = (seg - P.seg_prefix[oi]) * P.seg_size + threadIdx.x;
     const bool silicon = (P.sensor != nullptr) && (P.sensor->kind == IMS_SENSOR_SILICON);
     const bool has_angles = chain_has_angles(P);
+    __shared__ float tile[CT * CT];
+    ChargeTile ct;
+    tile_begin(tile, ct, P, o, silicon);
     double added = 0.0;
     if (j < o.n_phot) {
         const int64_t i = pool_start[oi] + j;
@@ -235,11 +301,10 @@ __global__ __launch_bounds__(256) void k_accumulate_segments(const ims_render_pa
         int ix, iy;
         if (ph.flux != 0.0 && land(P, o, o.phot_first + j, ph, silicon, has_angles, ix, iy)) {
             added = ph.flux;
-            const int px = ix - P.xmin, py = iy - P.ymin;
-            if (px >= 0 && px < P.nx && py >= 0 && py < P.ny)
-                unsafeAtomicAdd(P.image + ((int64_t)py * P.nx + px), (float)ph.flux);
+            tile_deposit(tile, ct, P, ix, iy, (float)ph.flux);
         }
     }
+    tile_flush(tile, ct, P);
     if (P.realized_flux != nullptr) {
         const double tot = wave_sum(added);
         if ((threadIdx.x & 63) == 0 && tot != 0.0) unsafeAtomicAdd(P.realized_flux + oi, tot);
@@ -455,7 +520,27 @@ __global__ __launch_bounds__(256) void k_update_distortions_q3(const ims_sensor_
     const int t = (int)(b - tile_prefix[lo]);
     const int tx0 = (t % tiles_x) * UT, ty0 = (t / tiles_x) * UT;
     const int sx0 = tx0 - (Q + 1), sy0 = ty0 - (Q + 1);
+    __shared__ int any_charge;
     if (threadIdx.x < HW) occ[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) any_charge = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < HW * HW; e += 256) {
+        const int hx = e % HW, hy = e / HW;
+        const int si = sx0 + hx, sj = sy0 + hy;
+        double w = 0.0;
+        if (si >= 0 && si < sl.nx && sj >= 0 && sj < sl.ny) {
+            const double charge = (double)s.bf_delta[cell_index(sl, si, sj)];
+            if (charge != 0.0) { w = charge / s.num_elec; atomicOr(&occ[hy], 1u << hx); any_charge = 1; }
+        }
+        wt[e] = w;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % UT, ly = threadIdx.x / UT;
+    const int i = tx0 + lx, j = ty0 + ly;
+    if (!any_charge) {                       // nothing landed near this tile: nothing moves
+        if (i <= sl.nx && j <= sl.ny) changed[cell_index(sl, i, j)] = 0;
+        return;
+    }
     const int cx = (s.nx - 1) / 2, cy = (s.ny - 1) / 2;
     for (int e = threadIdx.x; e < 8 * 8 * NPO * 2; e += 256) {
         const int comp = e & 1, n = (e >> 1) % NPO, cell = (e >> 1) / NPO;
@@ -464,19 +549,6 @@ __global__ __launch_bounds__(256) void k_update_distortions_q3(const ims_sensor_
         dl[e] = s.distortions[(((int64_t)(di + cx) * s.ny + (dj + cy)) * NVV + vtx) * 2 + comp];
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < HW * HW; e += 256) {
-        const int hx = e % HW, hy = e / HW;
-        const int si = sx0 + hx, sj = sy0 + hy;
-        double w = 0.0;
-        if (si >= 0 && si < sl.nx && sj >= 0 && sj < sl.ny) {
-            const double charge = (double)s.bf_delta[cell_index(sl, si, sj)];
-            if (charge != 0.0) { w = charge / s.num_elec; atomicOr(&occ[hy], 1u << hx); }
-        }
-        wt[e] = w;
-    }
-    __syncthreads();
-    const int lx = threadIdx.x % UT, ly = threadIdx.x / UT;
-    const int i = tx0 + lx, j = ty0 + ly;
     if (i > sl.nx || j > sl.ny) return;
     // 64-bit window: byte a <-> dj = -Q + a (row hy = ly + 2Q + 1 - a); inside a byte bit bb <-> di = -Q + bb
     // (column hx = lx + 2Q + 1 - bb), i.e. the row bitmap reversed.
@@ -713,7 +785,6 @@ int ims_accumulate_segments(const ims_render_params_t* params, const ims_photons
     if (params->n_segments == 0) return IMS_OK;
     hipStream_t st = (hipStream_t)stream;
     {
-        LaunchTimer tm(st);
         hipLaunchKernelGGL(k_accumulate_segments, dim3(grid_for_segments(params->n_segments)), dim3(256), 0, st,
                            *params, *pool, pool_start);
     }
@@ -817,6 +888,39 @@ int ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sens
     return IMS_OK;
 }
 
+int ims_run_plan(const ims_plan_item_t* items, int64_t n_items, const ims_sensor_t* sensor_dev,
+                 const ims_sensor_t* sensor_host, unsigned char* changed_dev, void* stream_chain, void* stream_bulk)
+{
+    if (!items && n_items > 0) return set_err(IMS_ERR_ARG, "items is NULL");
+    for (int64_t k = 0; k < n_items; ++k) {
+        const ims_plan_item_t& it = items[k];
+        void* st = it.stream == 1 ? stream_bulk : stream_chain;
+        int rc = IMS_OK;
+        switch (it.kind) {
+        case IMS_PLAN_RENDER:     rc = ims_shoot_accumulate(it.params, st); break;
+        case IMS_PLAN_SHOOT_POOL: rc = ims_shoot_ops_photons(it.params, it.aux, it.pool, st); break;
+        case IMS_PLAN_ACC_POOL:   rc = ims_accumulate_segments(it.params, it.pool, it.aux, st); break;
+        case IMS_PLAN_UPDATE:     rc = ims_sensor_update_distortions(sensor_dev, sensor_host, it.first_slot, it.n_slots, it.aux,
+                                                                     it.n_tiles, changed_dev, st); break;
+        case IMS_PLAN_INIT:       rc = ims_sensor_init_boundaries(sensor_dev, sensor_host, it.first_slot, it.n_slots, st); break;
+        case IMS_PLAN_RECORD:
+        case IMS_PLAN_WAIT: {
+            static std::vector<hipEvent_t> evs;
+            while ((int)evs.size() <= it.n_slots) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                evs.push_back(e);
+            }
+            if (it.kind == IMS_PLAN_RECORD) HIP_TRY(hipEventRecord(evs[it.n_slots], (hipStream_t)st));
+            else HIP_TRY(hipStreamWaitEvent((hipStream_t)st, evs[it.n_slots], 0));
+            break; }
+        default: return set_err(IMS_ERR_ARG, "unknown plan item kind");
+        }
+        if (rc) return rc;
+    }
+    return IMS_OK;
+}
+
 int ims_image_add(float* dst, const float* src, int64_t n, void* stream)
 {
     if (!dst || !src) return set_err(IMS_ERR_ARG, "dst/src is NULL");
@@ -841,6 +945,7 @@ int ims_struct_size(int which)
     case 9: return (int)sizeof(ims_sensor_t);
     case 10: return (int)sizeof(ims_photons_t);
     case 11: return (int)sizeof(ims_render_params_t);
+    case 12: return (int)sizeof(ims_plan_item_t);
     }
     return -1;
 }

@@ -389,10 +389,7 @@ class Renderer:
         b = self.bound
         normal, groups = plan_bf_groups(objects, nrecalc, b.n_static_slots, b.static_cells, ss.scratch_cells,
                                         b.slot_capacity, self.max_pool_photons)
-        if len(normal):
-            part = objects[normal].copy()
-            part["bf_state"] = 0
-            add_render(part, normal, "bulk")
+        n_events = 0
         for idx, slots in groups:
             plan.append(("slots", slots))
             n0 = b.n_static_slots
@@ -400,15 +397,40 @@ class Renderer:
             grp = objects[idx].copy()
             grp["bf_state"] = n0 + np.arange(len(grp))
             total = grp["n_phot"].copy()
-            # 1. everything of the photons that does not depend on the sensor state, in ONE wide launch
+            # 1. everything of the photons that does not depend on the sensor state goes into a
+            #    compact pool, produced in slices of rounds: the first slice (round 0) on the chain
+            #    stream so the chain can start at once, the later ones on the bulk stream; round r
+            #    waits for the event of the slice that holds its photons.
             offs = np.concatenate([[0], np.cumsum(total)]).astype(np.int64)
-            offs_t = self.torch.from_numpy(offs).to(self.device)
             pool, pool_t = self._pool6(offs[-1])
-            P, keep = upload(grp, idx, "shoot_pool")
-            plan.append(("shoot_pool", P, (keep, offs_t, pool_t), pool, offs_t, int(total.sum()), len(grp)))
-            # 2. the sequential part: rounds of nrecalc photons per object through the sensor
             rounds = int((total.max() + nrecalc - 1) // nrecalc)
+            edges = [0] + [e for e in (1, 3, 8, 20, 60) if e < rounds] + [rounds]
+            slice_of_round = np.zeros(rounds, dtype=np.int64)
+            ev_base = n_events
+            for k in range(len(edges) - 1):
+                ra, rb = edges[k], edges[k + 1]
+                slice_of_round[ra:rb] = k
+                lo = np.minimum(total, ra * nrecalc)
+                hi = np.minimum(total, rb * nrecalc)
+                act = hi > lo
+                part = grp[act].copy()
+                part["phot_first"] = grp["phot_first"][act] + lo[act]
+                part["n_phot"] = (hi - lo)[act]
+                offs_t = self.torch.from_numpy((offs[:-1] + lo)[act]).to(self.device)
+                P, keep = upload(part, idx[act], "shoot_pool")
+                stream = "chain" if k == 0 else "bulk"
+                plan.append(("shoot_pool", P, (keep, offs_t, pool_t), pool, offs_t, int(part["n_phot"].sum()),
+                             len(part), stream))
+                if k > 0:
+                    plan.append(("record", ev_base + k, stream))
+                    n_events = max(n_events, ev_base + k + 1)
+            # 2. the sequential part: rounds of nrecalc photons per object through the sensor
+            waited = 0
             for r in range(rounds):
+                k = int(slice_of_round[r])
+                if k > waited:
+                    plan.append(("wait", ev_base + k, "chain"))
+                    waited = k
                 n_act = int(np.count_nonzero(total > r * nrecalc))
                 part = grp[:n_act].copy()
                 part["phot_first"] = grp["phot_first"][:n_act] + r * nrecalc
@@ -419,49 +441,63 @@ class Renderer:
                 n_cont = int(np.count_nonzero(total > (r + 1) * nrecalc))
                 if n_cont:
                     plan.append(("update", n0, n_cont))
+        if len(normal):
+            part = objects[normal].copy()
+            part["bf_state"] = 0
+            add_render(part, normal, "bulk")
         return plan, realized_parts
 
     def _compile_plan(self, plan):
-        """Turn plan items into (c_function, argument tuple) pairs so that replaying the plan costs
-        one ctypes call per launch (the brighter-fatter chain is launch-rate bound on the host)."""
-        lib = self.lib
-        chain = C.c_void_p(self.s_chain.cuda_stream)
-        bulk = C.c_void_p(self.s_bulk.cuda_stream)
+        """Turn a plan into ims_plan_item_t arrays (one per stretch between host-side slot-table
+        writes) so that replaying it is ONE C call per stretch: the brighter-fatter chain is
+        hundreds of short dependent launches and would otherwise be bound by the host launch rate."""
         b = self.bound
         if self.scene.sensor is not None and not hasattr(self, "_changed"):
             cells = b.static_cells + int(self.scene.sensor.scratch_cells)
             self._changed = self.torch.zeros(max(cells, 1), dtype=self.torch.uint8, device=self.device)
-        out = []
-        keep = []
-        cur_slots = None
+        stretches, keep, cur = [], [], []
+        cur_prefix = None
+
+        def close():
+            if cur:
+                arr = (_abi.PlanItem * len(cur))(*cur)
+                stretches.append(("run", arr, len(cur)))
+                cur.clear()
+
         for item in plan:
             kind = item[0]
+            it = _abi.PlanItem()
             if kind == "render":
-                out.append((lib.ims_shoot_accumulate, (C.byref(item[1]), bulk if item[5] == "bulk" else chain)))
+                it.kind, it.stream, it.params = _abi.IMS_PLAN_RENDER, (1 if item[5] == "bulk" else 0), C.addressof(item[1])
             elif kind == "acc_pool":
-                out.append((lib.ims_accumulate_segments, (C.byref(item[1]), C.byref(item[3]), item[4].data_ptr(), chain)))
+                it.kind, it.params, it.pool, it.aux = _abi.IMS_PLAN_ACC_POOL, C.addressof(item[1]), C.addressof(item[3]), item[4].data_ptr()
             elif kind == "shoot_pool":
-                out.append((lib.ims_shoot_ops_photons, (C.byref(item[1]), item[4].data_ptr(), C.byref(item[3]), chain)))
+                it.kind, it.params, it.pool, it.aux = _abi.IMS_PLAN_SHOOT_POOL, C.addressof(item[1]), C.addressof(item[3]), item[4].data_ptr()
+                it.stream = 1 if item[7] == "bulk" else 0
+            elif kind == "record":
+                it.kind, it.n_slots, it.stream = _abi.IMS_PLAN_RECORD, item[1], (1 if item[2] == "bulk" else 0)
+            elif kind == "wait":
+                it.kind, it.n_slots, it.stream = _abi.IMS_PLAN_WAIT, item[1], (1 if item[2] == "bulk" else 0)
             elif kind == "slots":
-                cur_slots = item[1]
-                tiles = ((cur_slots["nx"].astype(np.int64) + 1 + 15) // 16) * ((cur_slots["ny"].astype(np.int64) + 1 + 15) // 16)
+                close()
+                sl = item[1]
+                tiles = ((sl["nx"].astype(np.int64) + 1 + 15) // 16) * ((sl["ny"].astype(np.int64) + 1 + 15) // 16)
                 prefix = np.concatenate([[0], np.cumsum(tiles)]).astype(np.int64)
                 prefix_t = self.torch.from_numpy(prefix).to(self.device)
                 keep.append(prefix_t)
                 cur_prefix = (prefix, prefix_t)
-                out.append(("slots", item[1]))
+                stretches.append(("slots", sl, 0))
+                continue
             elif kind == "init":
-                out.append((lib.ims_sensor_init_boundaries, (b.sensor_dev_ptr, C.byref(b.sensor_host), item[1], item[2], chain)))
+                it.kind, it.first_slot, it.n_slots = _abi.IMS_PLAN_INIT, item[1], item[2]
             elif kind == "update":
                 first, n = item[1], item[2]
-                if first == b.n_static_slots and cur_slots is not None:
-                    prefix, prefix_t = cur_prefix
-                else:
-                    prefix, prefix_t = self._tile_prefix(first)
-                out.append((lib.ims_sensor_update_distortions,
-                            (b.sensor_dev_ptr, C.byref(b.sensor_host), first, n, prefix_t.data_ptr(), int(prefix[n]),
-                             self._changed.data_ptr(), chain)))
-        return out, keep
+                prefix, prefix_t = cur_prefix if (cur_prefix is not None and first == b.n_static_slots) else self._tile_prefix(first)
+                it.kind, it.first_slot, it.n_slots = _abi.IMS_PLAN_UPDATE, first, n
+                it.aux, it.n_tiles = prefix_t.data_ptr(), int(prefix[n])
+            cur.append(it)
+        close()
+        return stretches, keep
 
     def execute_plan(self, plan, compiled=None):
         """Run a launch plan.  Items tagged "bulk" go to the bulk stream, everything else (the
@@ -470,22 +506,25 @@ class Renderer:
         torch = self.torch
         if compiled is None:
             compiled = self._compile_plan(plan)
-        calls, _ = compiled
+        stretches, _ = compiled
         main = torch.cuda.current_stream(self.device)
         ev0 = torch.cuda.Event()
         ev0.record(main)
         self.s_chain.wait_event(ev0)
         self.s_bulk.wait_event(ev0)
-        for f, args in calls:
-            if f == "slots":
+        b = self.bound
+        sensor_dev = b.sensor_dev_ptr if self.scene.sensor is not None else None
+        sensor_host = C.byref(b.sensor_host) if self.scene.sensor is not None else None
+        changed = self._changed.data_ptr() if hasattr(self, "_changed") else None
+        chain, bulk = C.c_void_p(self.s_chain.cuda_stream), C.c_void_p(self.s_bulk.cuda_stream)
+        for kind, payload, n in stretches:
+            if kind == "slots":
                 # the slot table is host-written: order it after everything queued so far
                 self.s_chain.synchronize()
                 with torch.cuda.stream(self.s_chain):
-                    self.bound.set_private_slots(args)
+                    b.set_private_slots(payload)
                 continue
-            rc = f(*args)
-            if rc:
-                _abi.check(rc, getattr(f, "__name__", "launch"))
+            _abi.check(self.lib.ims_run_plan(payload, n, sensor_dev, sensor_host, changed, chain, bulk), "ims_run_plan")
         ev1, ev2 = torch.cuda.Event(), torch.cuda.Event()
         ev1.record(self.s_chain)
         ev2.record(self.s_bulk)
@@ -520,7 +559,12 @@ class Renderer:
         launch.photons = sum(it[3] for it in plan if it[0] == "render") + sum(it[5] for it in plan if it[0] == "shoot_pool")
         launch.object_rows = sum(it[4] for it in plan if it[0] == "render") + sum(it[6] for it in plan if it[0] in ("shoot_pool", "acc_pool"))
         launch.pool_photons = sum(it[5] for it in plan if it[0] == "shoot_pool")
-        launch.n_render_launches = sum(1 for it in plan if it[0] in ("render", "shoot_pool", "acc_pool"))
+        # launches bracketed by the library's timing events: fused renders and pool shoots
+        launch.n_render_launches = sum(1 for it in plan if it[0] in ("render", "shoot_pool"))
+        # algorithmic bytes of those launches: fused = fp32 image RMW (8 B/photon); pool shoot = the six
+        # f64 fields it writes (48 B/photon); both + one 256-B object row per object
+        launch.timed_bytes = (sum(it[3] * 8 + it[4] * 256 for it in plan if it[0] == "render")
+                              + sum(it[5] * 48 + it[6] * 256 for it in plan if it[0] == "shoot_pool"))
         return launch
 
     def prepared(self, objects):
@@ -538,6 +582,7 @@ class Renderer:
         launch.photons = int(objects["n_phot"].sum())
         launch.object_rows = len(objects)
         launch.n_render_launches = 1
+        launch.timed_bytes = launch.photons * 8 + launch.object_rows * 256
         return launch
 
     # -- pooled path (LSST_PhotonPoolingImage / LSST_Photons) --

@@ -299,11 +299,34 @@ int  ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sen
                                    int32_t first_slot, int32_t n_slots, const int64_t* tile_prefix_dev,
                                    int64_t n_tiles, unsigned char* changed_dev, void* stream);
 
+/* ---- launch plans ----
+ * The brighter-fatter chain of LSST_Image mode is hundreds of short dependent launches; ims_run_plan
+ * issues a whole prepared list from C so the host cost per launch is one hipLaunchKernel.
+ * Items with stream == 1 go to stream_bulk, the others to stream_chain (in list order per stream). */
+#define IMS_PLAN_RENDER     1   /* ims_shoot_accumulate(params) */
+#define IMS_PLAN_SHOOT_POOL 2   /* ims_shoot_ops_photons(params, aux = photon_offset, pool) */
+#define IMS_PLAN_ACC_POOL   3   /* ims_accumulate_segments(params, pool, aux = pool_start) */
+#define IMS_PLAN_UPDATE     4   /* ims_sensor_update_distortions(first_slot, n_slots, aux = tile_prefix, n_tiles) */
+#define IMS_PLAN_INIT       5   /* ims_sensor_init_boundaries(first_slot, n_slots) */
+#define IMS_PLAN_RECORD     6   /* record library event number n_slots on the item's stream */
+#define IMS_PLAN_WAIT       7   /* make the item's stream wait for library event number n_slots */
+typedef struct ims_plan_item {
+    int32_t kind;
+    int32_t stream;
+    const ims_render_params_t* params;   /* host pointer */
+    const ims_photons_t* pool;           /* host pointer */
+    const int64_t* aux;                  /* device pointer, see kinds */
+    int32_t first_slot, n_slots;
+    int64_t n_tiles;
+} ims_plan_item_t;
+int  ims_run_plan(const ims_plan_item_t* items, int64_t n_items, const ims_sensor_t* sensor_dev,
+                  const ims_sensor_t* sensor_host, unsigned char* changed_dev, void* stream_chain, void* stream_bulk);
+
 /* ---- image helpers ---- */
 int  ims_image_add(float* dst, const float* src, int64_t n, void* stream);
 
 /* ---- timing of the dominant kernel ----
- * After ims_enable_timing(1) every ims_shoot_accumulate / ims_shoot_ops_photons / ims_accumulate_segments launch is bracketed by a hipEvent pair on its
+ * After ims_enable_timing(1) every ims_shoot_accumulate / ims_shoot_ops_photons launch is bracketed by a hipEvent pair on its
  * stream.  ims_last_kernel_ms returns the SUM of their durations and their count since the last query
  * (and resets the accumulation). */
 int  ims_last_kernel_ms(float* ms, int* n_launches);
@@ -313,7 +336,7 @@ int  ims_enable_timing(int on);
  * which: 0 log, 1 exp, 2 sincos2pi (2 outputs), 3 atan, 4 sincos (2), 5 tanh, 6 gaussian pair of draw(seed,obj,i,slot) (2) */
 /* sizeof() of the ABI structs as compiled, for binding self-checks:
  * 0 object, 1 radial_tables, 2 lin_tables, 3 psf_component, 4 op, 5 surface, 6 tansip, 7 optics, 8 bf_slot,
- * 9 sensor, 10 photons, 11 render_params */
+ * 9 sensor, 10 photons, 11 render_params, 12 plan_item */
 int  ims_struct_size(int which);
 int  ims_test_math(int which, const double* in_dev, double* out_dev, int64_t n, uint64_t seed, int64_t obj,
                    uint32_t slot, void* stream);

@@ -109,6 +109,7 @@ int orc_struct_size(int which)
     case 9: return (int)sizeof(ims_sensor_t);
     case 10: return (int)sizeof(ims_photons_t);
     case 11: return (int)sizeof(ims_render_params_t);
+    case 12: return (int)sizeof(ims_plan_item_t);
     }
     return -1;
 }

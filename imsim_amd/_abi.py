@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 IMS_OBJ_FAINT = 1
-IMS_PSF_GAUSSIAN, IMS_PSF_RADIAL = 1, 2
+IMS_PSF_GAUSSIAN, IMS_PSF_RADIAL, IMS_PSF_SCREENS = 1, 2, 3
+IMS_MAX_LAYERS = 8
 IMS_MAX_PSF = 4
 (IMS_OP_TIME_SAMPLER, IMS_OP_PUPIL_ANNULUS_SAMPLER, IMS_OP_PHOTON_DCR, IMS_OP_RUBIN_OPTICS,
  IMS_OP_RUBIN_DIFFRACTION, IMS_OP_RUBIN_DIFFRACTION_OPTICS, IMS_OP_FOCUS_DEPTH, IMS_OP_REFRACTION,
@@ -32,7 +33,7 @@ class Object(C.Structure):
                 ("dcr_tanz", c_d), ("dcr_sinp", c_d), ("dcr_cosp", c_d),
                 ("prof_table", c_i32), ("sed_table", c_i32), ("flags", c_i32),
                 ("stamp_xmin", c_i32), ("stamp_xmax", c_i32), ("stamp_ymin", c_i32), ("stamp_ymax", c_i32),
-                ("bf_state", c_i32), ("sed_wave", c_d), ("reserved", c_d * 9)]
+                ("bf_state", c_i32), ("sed_wave", c_d), ("atm_tan_x", c_d), ("atm_tan_y", c_d), ("reserved", c_d * 7)]
 
 
 # numpy view of the same 256-byte row, for vectorised object-table construction
@@ -43,7 +44,8 @@ OBJECT_DTYPE = np.dtype([
     ("dcr_tanz", "<f8"), ("dcr_sinp", "<f8"), ("dcr_cosp", "<f8"),
     ("prof_table", "<i4"), ("sed_table", "<i4"), ("flags", "<i4"),
     ("stamp_xmin", "<i4"), ("stamp_xmax", "<i4"), ("stamp_ymin", "<i4"), ("stamp_ymax", "<i4"),
-    ("bf_state", "<i4"), ("sed_wave", "<f8"), ("reserved", "<f8", (9,))], align=True)
+    ("bf_state", "<i4"), ("sed_wave", "<f8"), ("atm_tan_x", "<f8"), ("atm_tan_y", "<f8"),
+    ("reserved", "<f8", (7,))], align=True)
 assert OBJECT_DTYPE.itemsize == 256
 
 
@@ -57,6 +59,12 @@ class LinTables(C.Structure):
 
 class PsfComponent(C.Structure):
     _fields_ = [("kind", c_i32), ("table", c_i32), ("p0", c_d), ("chrom_alpha", c_d), ("chrom_base", c_d)]
+
+
+class Atmosphere(C.Structure):
+    _fields_ = [("n_layers", c_i32), ("npix", c_i32), ("scale", c_d), ("x0", c_d), ("t0", c_d), ("exptime", c_d),
+                ("aper_r_outer", c_d), ("aper_r_inner", c_d), ("vx", c_d * 8), ("vy", c_d * 8), ("alt", c_d * 8),
+                ("screens", c_vp)]
 
 
 class Op(C.Structure):
@@ -110,7 +118,7 @@ class RenderParams(C.Structure):
                 ("n_segments", c_i64), ("seg_size", c_i32), ("n_psf", c_i32),
                 ("psf", PsfComponent * IMS_MAX_PSF), ("n_ops", c_i32), ("track_static_delta", c_i32),
                 ("ops", Op * IMS_MAX_OPS), ("radial", RadialTables), ("sed", LinTables), ("ratio", LinTables),
-                ("optics", c_vp), ("sensor", c_vp), ("image", c_vp),
+                ("atm", c_vp), ("optics", c_vp), ("sensor", c_vp), ("image", c_vp),
                 ("nx", c_i32), ("ny", c_i32), ("xmin", c_i32), ("ymin", c_i32), ("realized_flux", c_vp)]
 
 
@@ -123,7 +131,7 @@ class PlanItem(C.Structure):
  IMS_PLAN_WAIT) = range(1, 8)
 
 STRUCTS = [Object, RadialTables, LinTables, PsfComponent, Op, Surface, TanSip, Optics, BfSlot, Sensor, Photons,
-           RenderParams, PlanItem]
+           RenderParams, PlanItem, Atmosphere]
 
 # every symbol include/imsim_hip.h declares
 EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_info", "ims_shoot_accumulate",

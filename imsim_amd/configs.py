@@ -204,3 +204,37 @@ def c3_objects(cat, phot, scene, nrecalc=10000, bf_private=True):
     return objects, sizes
 
 BENCH_CONFIGS["c3"]["objects"] = lambda cat, phot, scene: c3_objects(cat, phot, scene)
+
+
+def field_angles(scene, x, y):
+    """Field angle (tangent-plane coordinates, rad) of pixel positions relative to the boresight:
+    the `theta` handed to atm.makePSF (imsim/atmPSF.py:304, :435)."""
+    from . import wcs as wcsmod
+    p = wcsmod.tansip_pix_to_vec(scene.optics.img_wcs, x, y)
+    thx, thy = wcsmod.tansip_vec_to_pix(scene.optics.icrf_to_field, p)
+    return thx, thy
+
+
+def scene_c3b(nx=4096, ny=4096, seed=398414, sensor=True, screen_size=819.2, screen_scale=0.1, device=None, **kw):
+    """C3b: C3 with the default config's 6-screen AtmosphericPSF (config/imsim-config.yaml:239-256):
+    Convolve[AtmosphericPSF (phase screens + second kick), Gaussian fwhm 0.3]."""
+    from . import atm_psf
+    sc = scene_c3(nx=nx, ny=ny, seed=seed, sensor=sensor, **kw)
+    atm = atm_psf.AtmosphericPSF(VISIT["airmass"], VISIT["raw_seeing"], VISIT["band"], seed=seed,
+                                 exptime=VISIT["exptime"], screen_size=screen_size, screen_scale=screen_scale,
+                                 device=device)
+    r2, cdf = sc.radial_r2, sc.radial_cdf
+    sk = atm.second_kick
+    sc.radial_r2 = np.concatenate([r2, sk[0][None, :]])
+    sc.radial_cdf = np.concatenate([cdf, sk[1][None, :]])
+    sc.atm = atm
+    sc.psf = atm.psf_components(second_kick_table_id=len(r2)) + [(_abi.IMS_PSF_GAUSSIAN, 0, 0.3 / 2.3548200450309493, 0.0, 1.0)]
+    return sc
+
+
+def c3b_objects(cat, phot, scene, **kw):
+    objects, sizes = c3_objects(cat, phot, scene, **kw)
+    keep = phot > 0
+    thx, thy = field_angles(scene, cat["x"][keep], cat["y"][keep])
+    objects["atm_tan_x"], objects["atm_tan_y"] = thx, thy
+    return objects, sizes

@@ -206,6 +206,7 @@ constexpr uint32_t SLOT_WAVE_PROF = 0;
 constexpr uint32_t SLOT_PROF_ANG = 1;
 constexpr uint32_t SLOT_PSF = 2;
 constexpr uint32_t SLOT_OP = 8;
+constexpr uint32_t SLOT_PSF_TIME = 20;
 constexpr uint32_t SLOT_SENSOR_DIFF = 24;
 constexpr uint32_t SLOT_SENSOR_CONV = 25;
 

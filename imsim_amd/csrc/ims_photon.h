@@ -72,6 +72,30 @@ IMS_DEV void shoot(const ims_render_params_t& P, const ims_object_t& o, int64_t 
     ph.pu = 0.0; ph.pv = 0.0; ph.t = 0.0;
 }
 
+// sum over layers of the gradient of the bilinear interpolant of the periodic phase screens [nm/m]
+IMS_DEV void screen_gradient(const ims_atmosphere_t& A, double pu, double pv, double t, double tanx, double tany,
+                             double& gx, double& gy)
+{
+    double sx = 0.0, sy = 0.0;
+    const int n = A.npix;
+    for (int l = 0; l < A.n_layers; ++l) {
+        const double x = pu - t * A.vx[l] + A.alt[l] * tanx;
+        const double y = pv - t * A.vy[l] + A.alt[l] * tany;
+        const double fx = (x - A.x0) / A.scale, fy = (y - A.x0) / A.scale;
+        const double flx = floor(fx), fly = floor(fy);
+        const double ax = fx - flx, ay = fy - fly;
+        int64_t ix = (int64_t)flx % n, iy = (int64_t)fly % n;
+        if (ix < 0) ix += n;
+        if (iy < 0) iy += n;
+        const int64_t ix1 = ix + 1 == n ? 0 : ix + 1, iy1 = iy + 1 == n ? 0 : iy + 1;
+        const double* S = A.screens + (int64_t)l * n * n;
+        const double f00 = S[iy * n + ix], f10 = S[iy * n + ix1], f01 = S[iy1 * n + ix], f11 = S[iy1 * n + ix1];
+        sx = sx + ((f10 - f00) * (1.0 - ay) + (f11 - f01) * ay) / A.scale;
+        sy = sy + ((f01 - f00) * (1.0 - ax) + (f11 - f10) * ax) / A.scale;
+    }
+    gx = sx; gy = sy;
+}
+
 IMS_DEV void apply_psf(const ims_render_params_t& P, const ims_object_t& o, int comp, int64_t k, Photon& ph)
 {
     const ims_psf_component_t& c = P.psf[comp];
@@ -83,6 +107,19 @@ IMS_DEV void apply_psf(const ims_render_params_t& P, const ims_object_t& o, int 
         double g0, g1;
         gauss_pair(d, g0, g1);
         ku = scale * g0; kv = scale * g1;
+    } else if (c.kind == IMS_PSF_SCREENS) {
+        const ims_atmosphere_t& A = *P.atm;
+        const double ro2 = A.aper_r_outer * A.aper_r_outer, ri2 = A.aper_r_inner * A.aper_r_inner;
+        const double r = sqrt(ri2 + u01(d.a) * (ro2 - ri2));
+        double s, cc;
+        sincos2pi(u01(d.b), s, cc);
+        const double pu = r * cc, pv = r * s;
+        const Draw dt = draw(P.seed, o.obj_id, k, SLOT_PSF_TIME + (uint32_t)comp);
+        const double t = A.t0 + u01(dt.a) * A.exptime;
+        double gx, gy;
+        screen_gradient(A, pu, pv, t, o.atm_tan_x, o.atm_tan_y, gx, gy);
+        ku = scale * gx; kv = scale * gy;
+        ph.pu = pu; ph.pv = pv; ph.t = t;
     } else {
         const double r2 = radial_r2(P.radial, c.table, u01(d.a));
         const double r = sqrt(r2) * scale;

@@ -668,6 +668,8 @@ static int check_params(const ims_render_params_t* p)
     if (p->seg_size != 256) return set_err(IMS_ERR_ARG, "seg_size must be 256 (one photon per thread of a 256-thread workgroup)");
     if (p->n_psf < 0 || p->n_psf > IMS_MAX_PSF) return set_err(IMS_ERR_ARG, "n_psf out of range");
     if (p->n_ops < 0 || p->n_ops > IMS_MAX_OPS) return set_err(IMS_ERR_ARG, "n_ops out of range");
+    for (int k = 0; k < p->n_psf; ++k)
+        if (p->psf[k].kind == IMS_PSF_SCREENS && !p->atm) return set_err(IMS_ERR_ARG, "phase-screen PSF without atmosphere descriptor");
     for (int k = 0; k < p->n_ops; ++k) {
         const int kind = p->ops[k].kind;
         if ((kind == IMS_OP_RUBIN_OPTICS || kind == IMS_OP_RUBIN_DIFFRACTION || kind == IMS_OP_RUBIN_DIFFRACTION_OPTICS) && !p->optics)
@@ -946,6 +948,7 @@ int ims_struct_size(int which)
     case 10: return (int)sizeof(ims_photons_t);
     case 11: return (int)sizeof(ims_render_params_t);
     case 12: return (int)sizeof(ims_plan_item_t);
+    case 13: return (int)sizeof(ims_atmosphere_t);
     }
     return -1;
 }

@@ -65,6 +65,7 @@ class Scene:
     ratio_wl_step: float = 1.0
     optics: Optional[Optics] = None
     sensor: Optional[SensorSetup] = None
+    atm: Optional[object] = None                 # atm_psf.AtmosphericPSF (needed by IMS_PSF_SCREENS components)
     seg_size: int = 256
     track_static_delta: int = 0
 
@@ -199,6 +200,18 @@ class BoundScene:
             _, P.ratio.val = mem.put(t, np.float64)
         if scene.optics is not None:
             _, P.optics = mem.put_struct(scene.optics)
+        if scene.atm is not None:
+            A = scene.atm.atmosphere_struct()
+            scr = scene.atm.screens
+            if isinstance(scr, np.ndarray):
+                _, A.screens = mem.put(scr, np.float64)
+            elif isinstance(mem, DeviceMem):
+                mem.keep.append(scr)                      # already a device tensor
+                A.screens = scr.data_ptr()
+            else:
+                _, A.screens = mem.put(scr.cpu().numpy(), np.float64)
+            self.atm_struct = A
+            _, P.atm = mem.put_struct(A)
         self.sensor_host = None
         self.sensor_arrays = {}
         if scene.sensor is not None:

@@ -48,6 +48,8 @@ extern "C" {
 /* ---- PSF component kinds (psfs are applied as the first photon ops, stamp.py:553) ---- */
 #define IMS_PSF_GAUSSIAN 1  /* p0 = sigma [arcsec] */
 #define IMS_PSF_RADIAL   2  /* table = radial table id, p0 = scale [arcsec per table unit] */
+#define IMS_PSF_SCREENS  3  /* PhaseScreenPSF, geometric photon shooting through ims_atmosphere (imsim/atmPSF.py:298-320);
+                               p0 = arcsec per (nm/m) of wavefront gradient = 1e-9 * 206265; also samples pupil_u/v and time */
 #define IMS_MAX_PSF 4
 
 /* ---- photon-op kinds (names follow the registered PhotonOp types) ---- */
@@ -100,7 +102,8 @@ typedef struct ims_object {
     int32_t stamp_xmin, stamp_xmax, stamp_ymin, stamp_ymax; /* stamp bounds, inclusive; photons outside are lost */
     int32_t bf_state;      /* >=0: index into ims_sensor.bf_slots (private pixel boundaries); -1: static CCD boundaries */
     double  sed_wave;      /* wavelength [nm] when sed_table < 0 */
-    double  reserved[9];   /* pads the row to 256 bytes */
+    double  atm_tan_x, atm_tan_y; /* tan of the field angle of the object from the boresight (theta of atm.makePSF, atmPSF.py:304) */
+    double  reserved[7];   /* pads the row to 256 bytes */
 } ims_object_t;
 
 /* Tabulated circular profiles sampled by inverse CDF with uniform density inside each annulus:
@@ -129,6 +132,24 @@ typedef struct ims_psf_component {
     double  chrom_alpha;     /* size scales as (wavelength/chrom_base)^alpha; 0 = achromatic */
     double  chrom_base;      /* nm */
 } ims_psf_component_t;
+
+/* The frozen-flow atmosphere of one visit (galsim.Atmosphere as built by imsim/atmPSF.py:164-205):
+ * n_layers periodic von Karman phase screens of npix x npix samples (optical path difference, nm),
+ * each drifting with its wind.  A photon entering the pupil at (u,v) [m] at time t sees layer l at
+ * (u - t vx_l + h_l tan(theta_x), v - t vy_l + h_l tan(theta_y)); its position kick is the sum of the
+ * bilinear-interpolant gradients there. */
+#define IMS_MAX_LAYERS 8
+typedef struct ims_atmosphere {
+    int32_t n_layers;
+    int32_t npix;
+    double  scale;                 /* m per screen sample */
+    double  x0;                    /* coordinate of sample 0 [m] (= -0.5 * npix * scale) */
+    double  t0, exptime;           /* s */
+    double  aper_r_outer, aper_r_inner;   /* pupil sampling annulus [m] (diam 8.36, obscuration 0.61: atmPSF.py:168) */
+    double  vx[IMS_MAX_LAYERS], vy[IMS_MAX_LAYERS];   /* m/s */
+    double  alt[IMS_MAX_LAYERS];   /* m */
+    const double* screens;         /* [n_layers][npix][npix] */
+} ims_atmosphere_t;
 
 typedef struct ims_op {
     int32_t kind;            /* IMS_OP_* */
@@ -248,6 +269,7 @@ typedef struct ims_render_params {
     ims_radial_tables_t radial;
     ims_lin_tables_t    sed;         /* wavelength inverse CDFs */
     ims_lin_tables_t    ratio;       /* BandpassRatio tables */
+    const ims_atmosphere_t* atm;     /* device pointer or NULL (needed by IMS_PSF_SCREENS) */
     const ims_optics_t* optics;      /* device pointer or NULL */
     const ims_sensor_t* sensor;      /* device pointer (struct itself lives in device memory) or NULL = IMS_SENSOR_NONE */
     /* target image */
@@ -336,7 +358,7 @@ int  ims_enable_timing(int on);
  * which: 0 log, 1 exp, 2 sincos2pi (2 outputs), 3 atan, 4 sincos (2), 5 tanh, 6 gaussian pair of draw(seed,obj,i,slot) (2) */
 /* sizeof() of the ABI structs as compiled, for binding self-checks:
  * 0 object, 1 radial_tables, 2 lin_tables, 3 psf_component, 4 op, 5 surface, 6 tansip, 7 optics, 8 bf_slot,
- * 9 sensor, 10 photons, 11 render_params, 12 plan_item */
+ * 9 sensor, 10 photons, 11 render_params, 12 plan_item, 13 atmosphere */
 int  ims_struct_size(int which);
 int  ims_test_math(int which, const double* in_dev, double* out_dev, int64_t n, uint64_t seed, int64_t obj,
                    uint32_t slot, void* stream);

@@ -20,6 +20,8 @@ void   orc_apply_op(const ims_render_params_t* P, int op_index, ims_photons_t* p
                     const int64_t* photon_offset);
 void   orc_apply_rubin_op(const ims_render_params_t* P, int op_index, ims_photons_t* ph,
                           const int64_t* photon_offset);
+void   orc_screen_gradient(const ims_atmosphere_t* A, double pu, double pv, double t, double tanx, double tany,
+                           double* gx, double* gy);
 double orc_air_n_minus_one(double wave_nm, double p_kpa, double t_k, double h2o_kpa);
 
 /* sensor */

@@ -226,6 +226,7 @@ static inline void orc_gauss_pair(orc_draw_t d, double* g0, double* g1)
 #define ORC_SLOT_PROF_ANG  1   /* a: profile angle */
 #define ORC_SLOT_PSF       2   /* +component */
 #define ORC_SLOT_OP        8   /* +op index in chain */
+#define ORC_SLOT_PSF_TIME 20   /* +component: arrival time drawn by a phase-screen PSF */
 #define ORC_SLOT_SENSOR_DIFF 24  /* gaussian pair: diffusion */
 #define ORC_SLOT_SENSOR_CONV 25  /* a: conversion depth, b: pixel-not-found coin */
 

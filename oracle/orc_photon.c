@@ -99,6 +99,32 @@ void orc_shoot_object(const ims_render_params_t* P, const ims_object_t* obj, int
     }
 }
 
+/* Sum over layers of the gradient of the bilinear interpolant of the (periodic) screen
+ * (galsim AtmosphericScreen._wavefront_gradient over LookupTable2D(..., edge_mode='wrap'), recalled;
+ * call site imsim/atmPSF.py:306-315).  Returns d(OPD)/du, d(OPD)/dv in nm/m. */
+void orc_screen_gradient(const ims_atmosphere_t* A, double pu, double pv, double t, double tanx, double tany,
+                         double* gx, double* gy)
+{
+    double sx = 0.0, sy = 0.0;
+    const int n = A->npix;
+    for (int l = 0; l < A->n_layers; ++l) {
+        double x = pu - t * A->vx[l] + A->alt[l] * tanx;
+        double y = pv - t * A->vy[l] + A->alt[l] * tany;
+        double fx = (x - A->x0) / A->scale, fy = (y - A->x0) / A->scale;
+        double flx = floor(fx), fly = floor(fy);
+        double ax = fx - flx, ay = fy - fly;
+        int64_t ix = (int64_t)flx % n, iy = (int64_t)fly % n;
+        if (ix < 0) ix += n;
+        if (iy < 0) iy += n;
+        int64_t ix1 = ix + 1 == n ? 0 : ix + 1, iy1 = iy + 1 == n ? 0 : iy + 1;
+        const double* S = A->screens + (int64_t)l * n * n;
+        double f00 = S[iy * n + ix], f10 = S[iy * n + ix1], f01 = S[iy1 * n + ix], f11 = S[iy1 * n + ix1];
+        sx = sx + ((f10 - f00) * (1.0 - ay) + (f11 - f01) * ay) / A->scale;
+        sy = sy + ((f01 - f00) * (1.0 - ax) + (f11 - f10) * ax) / A->scale;
+    }
+    *gx = sx; *gy = sy;
+}
+
 /* PSF components act as photon ops: shoot the same number of photons and add positions
  * (GSObject.applyTo -> PhotonArray.convolve; stamp.py:553 `photon_ops = psfs + photon_ops`). */
 void orc_apply_psf(const ims_render_params_t* P, const ims_object_t* obj, int comp,
@@ -116,6 +142,21 @@ void orc_apply_psf(const ims_render_params_t* P, const ims_object_t* obj, int co
             double g0, g1;
             orc_gauss_pair(d, &g0, &g1);
             ku = scale * g0; kv = scale * g1;
+        } else if (c->kind == IMS_PSF_SCREENS) {
+            /* PhaseScreenPSF geometric shooting: random pupil position and arrival time, kick =
+             * wavefront gradient; the photon keeps (pupil_u, pupil_v, time) for later operators */
+            const ims_atmosphere_t* A = P->atm;
+            double ro2 = A->aper_r_outer * A->aper_r_outer, ri2 = A->aper_r_inner * A->aper_r_inner;
+            double r = orc_sqrt(ri2 + orc_u01(d.a) * (ro2 - ri2));
+            double s, cc;
+            orc_sincos2pi(orc_u01(d.b), &s, &cc);
+            double pu = r * cc, pv = r * s;
+            orc_draw_t dt = orc_draw(P->seed, obj->obj_id, k, ORC_SLOT_PSF_TIME + (uint32_t)comp);
+            double t = A->t0 + orc_u01(dt.a) * A->exptime;
+            double gx, gy;
+            orc_screen_gradient(A, pu, pv, t, obj->atm_tan_x, obj->atm_tan_y, &gx, &gy);
+            ku = scale * gx; kv = scale * gy;
+            ph->pupil_u[i] = pu; ph->pupil_v[i] = pv; ph->time[i] = t;
         } else {
             double r2 = orc_radial_r2(&P->radial, c->table, orc_u01(d.a));
             double r = orc_sqrt(r2) * scale;

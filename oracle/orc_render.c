@@ -110,6 +110,7 @@ int orc_struct_size(int which)
     case 10: return (int)sizeof(ims_photons_t);
     case 11: return (int)sizeof(ims_render_params_t);
     case 12: return (int)sizeof(ims_plan_item_t);
+    case 13: return (int)sizeof(ims_atmosphere_t);
     }
     return -1;
 }

@@ -1,0 +1,49 @@
+"""AtmosphericPSF host side: the reference's r0_500 inversion test (tests/test_psf.py:228-246) and
+physical sanity of the synthesised screens / second kick."""
+import numpy as np
+
+from imsim_amd import atm_psf
+
+
+def test_r0_500_inversion_matches_target_seeing():
+    """Inversion of the Tokovinin fitting formula (tests/test_psf.py:228-246, atol 1e-3)."""
+    rs = np.random.RandomState(57721)
+    for _ in range(10):
+        airmass = rs.uniform(1.001, 1.5)
+        raw = rs.uniform(0.5, 1.5)
+        band = "ugrizy"[rs.randint(6)]
+        a = atm_psf.AtmosphericPSF(airmass, raw, band, seed=int(rs.randint(2 ** 31)), screen_size=6.4, no2k=True)
+        wlen = atm_psf.WLEN_EFF[band]
+        target = raw * airmass ** 0.6 * (wlen / 500) ** (-0.3)
+        assert a.targetFWHM == target
+        np.testing.assert_allclose(atm_psf.vk_seeing(a.r0_500, wlen, a.L0), target, atol=1e-3, rtol=0)
+        assert 10.0 <= a.L0 <= 100.0
+        assert np.all(a.speeds <= 20.0) and len(a.altitudes) == 6
+        np.testing.assert_allclose(a.r0_weights.sum(), 1.0)
+
+
+def test_screen_structure_function_is_von_karman():
+    """The synthesised screen has the von Karman phase structure function
+    D(r) = 6.88 (r/r0)^(5/3) at r << L0 (in rad^2 at 500 nm; the screen is in nm of path)."""
+    rng = np.random.default_rng(5)
+    npix, scale, r0, L0 = 1024, 0.1, 0.15, 1.0e4
+    acc = []
+    for _ in range(4):
+        s = atm_psf.von_karman_screen(npix, scale, r0, L0, rng) * (2 * np.pi / 500.0)    # rad at 500 nm
+        for lag in (2, 4, 8):
+            acc.append((lag, np.mean((s[:, lag:] - s[:, :-lag]) ** 2)))
+    for lag in (2, 4, 8):
+        d = np.mean([v for l, v in acc if l == lag])
+        expect = 6.8839 * (lag * scale / r0) ** (5.0 / 3.0)
+        # discretisation and the periodic 102 m box bias D by up to ~15 % either way
+        assert 0.8 * expect < d < 1.25 * expect, (lag, d, expect)
+
+
+def test_second_kick_table_is_a_proper_cdf():
+    r2, cdf = atm_psf.second_kick_table(622.2, 0.17, 8.36, 0.61, 0.2)
+    assert cdf[0] == 0.0 and cdf[-1] == 1.0 and np.all(np.diff(cdf) >= 0) and np.all(np.diff(r2) > 0)
+    hlr = np.sqrt(np.interp(0.5, cdf, r2))
+    assert 0.1 < hlr < 0.6          # arcsec: a sizeable part of 0.8" seeing lives above kcrit = 0.2/r0
+    # a larger kcrit leaves less turbulence for the second kick
+    r2b, cdfb = atm_psf.second_kick_table(622.2, 0.17, 8.36, 0.61, 1.0)
+    assert np.sqrt(np.interp(0.5, cdfb, r2b)) < hlr

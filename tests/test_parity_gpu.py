@@ -221,3 +221,28 @@ def test_pooling_mode_brighter_fatter_is_bit_exact(torch_cuda):
     ga = _sensor_arrays_gpu(r)
     for name in ("boundary", "bounds", "delta"):
         assert_bits_equal(ga[name], orc.sensor_array(name), f"sensor {name}")
+
+
+def test_c3b_atmospheric_psf_is_bit_exact(torch_cuda):
+    """C3b: the 6-screen AtmosphericPSF (phase-screen gradient gather, chromatic dilation, second
+    kick) in front of the full op chain and the Silicon sensor."""
+    from imsim_amd import configs, catalog
+    from imsim_amd.engine import Renderer
+    from oracle import orc_loader
+    scene = configs.scene_c3b(nx=256, ny=256, screen_size=102.4, screen_scale=0.1)
+    scene.sensor.scratch_cells = 500_000
+    cat = catalog.synthetic_catalog(120, nx=256, ny=256)
+    phot = catalog.realize_fluxes(cat["nominal_flux"], 2)
+    objects, _ = configs.c3b_objects(cat, phot, scene)
+    r = Renderer(scene)
+    pool = r.shoot_photons(objects)
+    orc = orc_loader.OracleScene(scene)
+    opool = orc.shoot_pool(objects)
+    g, o = pool.to_host(), opool.to_host()
+    assert np.ptp(g["time"]) > 20 and np.all(np.hypot(g["pupil_u"], g["pupil_v"]) <= 4.18 + 1e-9)
+    for f in g:
+        assert_bits_equal(g[f], o[f], f"photon field {f}")
+    r.render_lsst_image(objects)
+    r.synchronize()
+    orc.render_lsst_image(objects)
+    assert_bits_equal(r.image_numpy(), orc.image, "C3b image")

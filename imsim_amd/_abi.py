@@ -67,6 +67,31 @@ class Atmosphere(C.Structure):
                 ("screens", c_vp)]
 
 
+class KPsf(C.Structure):
+    _fields_ = [("kind", c_i32), ("table", c_i32), ("p0", c_d)]
+
+
+IMS_KPSF_GAUSSIAN, IMS_KPSF_KOLMOGOROV, IMS_KPSF_TABLE = 1, 2, 3
+
+FFT_OBJECT_DTYPE = np.dtype([
+    ("obj_id", "<i8"), ("k_offset", "<i8"), ("r_offset", "<i8"), ("flux", "<f8"), ("cx", "<f8"), ("cy", "<f8"),
+    ("prof_scale", "<f8"), ("jac", "<f8", (4,)), ("nfft", "<i4"), ("prof_ktable", "<i4"), ("x0", "<i4"), ("y0", "<i4"),
+    ("stamp_xmin", "<i4"), ("stamp_xmax", "<i4"), ("stamp_ymin", "<i4"), ("stamp_ymax", "<i4"), ("pad", "<i4", (2,))],
+    align=True)
+
+
+class FftObject(C.Structure):
+    _fields_ = [("obj_id", c_i64), ("k_offset", c_i64), ("r_offset", c_i64), ("flux", c_d), ("cx", c_d), ("cy", c_d),
+                ("prof_scale", c_d), ("jac", c_d * 4), ("nfft", c_i32), ("prof_ktable", c_i32), ("x0", c_i32), ("y0", c_i32),
+                ("stamp_xmin", c_i32), ("stamp_xmax", c_i32), ("stamp_ymin", c_i32), ("stamp_ymax", c_i32), ("pad", c_i32 * 2)]
+
+
+class FftParams(C.Structure):
+    _fields_ = [("seed", c_u64), ("pixel_scale", c_d), ("n_kpsf", c_i32), ("add_noise", c_i32),
+                ("kpsf", KPsf * IMS_MAX_PSF), ("ktables", LinTables), ("image", c_vp),
+                ("nx", c_i32), ("ny", c_i32), ("xmin", c_i32), ("ymin", c_i32), ("realized_flux", c_vp)]
+
+
 class Op(C.Structure):
     _fields_ = [("kind", c_i32), ("table", c_i32), ("p", c_d * 6)]
 
@@ -131,11 +156,12 @@ class PlanItem(C.Structure):
  IMS_PLAN_WAIT) = range(1, 8)
 
 STRUCTS = [Object, RadialTables, LinTables, PsfComponent, Op, Surface, TanSip, Optics, BfSlot, Sensor, Photons,
-           RenderParams, PlanItem, Atmosphere]
+           RenderParams, PlanItem, Atmosphere, FftObject, FftParams]
 
 # every symbol include/imsim_hip.h declares
 EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_info", "ims_shoot_accumulate",
-           "ims_shoot_photons", "ims_shoot_ops_photons", "ims_accumulate_segments", "ims_run_plan", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
+           "ims_shoot_photons", "ims_shoot_ops_photons", "ims_accumulate_segments", "ims_run_plan",
+           "ims_fft_kspace_fill", "ims_fft_finish", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
            "ims_sensor_update_distortions", "ims_image_add", "ims_last_kernel_ms", "ims_enable_timing",
            "ims_struct_size", "ims_test_math"]
 
@@ -178,6 +204,8 @@ def load():
     lib.ims_sensor_init_boundaries.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_vp]
     lib.ims_sensor_update_distortions.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]
     lib.ims_image_add.argtypes = [c_vp, c_vp, c_i64, c_vp]
+    lib.ims_fft_kspace_fill.argtypes = [C.POINTER(FftParams), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]
+    lib.ims_fft_finish.argtypes = [C.POINTER(FftParams), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]
     lib.ims_run_plan.argtypes = [C.POINTER(PlanItem), c_i64, c_vp, C.POINTER(Sensor), c_vp, c_vp, c_vp]
     lib.ims_last_kernel_ms.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.ims_enable_timing.argtypes = [C.c_int]

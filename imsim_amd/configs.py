@@ -238,3 +238,21 @@ def c3b_objects(cat, phot, scene, **kw):
     thx, thy = field_angles(scene, cat["x"][keep], cat["y"][keep])
     objects["atm_tan_x"], objects["atm_tan_y"] = thx, thy
     return objects, sizes
+
+
+def _c3b_scene_bench():
+    import torch
+    sc = scene_c3b(device=torch.device("cuda", torch.cuda.current_device()))
+    sc.sensor.scratch_cells = 24_000_000
+    sc.sensor.max_slots = 8192
+    return sc
+
+
+BENCH_CONFIGS["c3b"] = dict(BENCH_CONFIGS["c3"])
+BENCH_CONFIGS["c3b"].update(
+    workload=BENCH_CONFIGS["c3"]["workload"].replace("C3:", "C3b:").replace(
+        "Kolmogorov+Gaussian PSF", "6-screen AtmosphericPSF (8192^2 von Karman screens) + second kick + Gaussian(0.3) PSF"),
+    scene=_c3b_scene_bench,
+    objects=lambda cat, phot, scene: c3b_objects(cat, phot, scene),
+    cpu_sample=600,
+)

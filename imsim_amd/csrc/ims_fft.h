@@ -1,0 +1,106 @@
+// ims_fft.h -- device functions of the FFT branch (LSST_SiliconBuilder.draw, method 'fft',
+// imsim/stamp.py:482-525): analytic k-space values and the Poisson deviate of the noise step.
+#pragma once
+#include "ims_math.h"
+#include "../../include/imsim_hip.h"
+
+namespace ims {
+
+// radial k-table: linear interpolation, 0 beyond the tabulated range
+IMS_DEV double ktable_lookup(const ims_lin_tables_t& t, int table, double arg)
+{
+    const double* v = t.val + (int64_t)table * t.n_pts;
+    const double f = (arg - t.arg_min) / t.arg_step;
+    if (!(f > 0.0)) return v[0];
+    if (f >= (double)(t.n_pts - 1)) return 0.0;
+    const int i = (int)f;
+    const double a = f - (double)i;
+    return v[i] + a * (v[i + 1] - v[i]);
+}
+
+// value of the half spectrum of object o at grid index (i = ky index, j = kx index)
+IMS_DEV void kspace_value(const ims_fft_params_t& P, const ims_fft_object_t& o, int i, int j, double& re, double& im)
+{
+    const int n = o.nfft;
+    const double dk = TWO_PI / ((double)n * P.pixel_scale);          // rad / arcsec
+    const double kx = (double)j * dk;
+    const double ky = (double)(i < n / 2 ? i : i - n) * dk;
+    // profile: transformed k-vector J^T k
+    double amp = o.flux;
+    if (o.prof_ktable >= 0) {
+        const double qx = o.jac[0] * kx + o.jac[2] * ky;
+        const double qy = o.jac[1] * kx + o.jac[3] * ky;
+        amp = amp * ktable_lookup(P.ktables, o.prof_ktable, sqrt(qx * qx + qy * qy) * o.prof_scale);
+    }
+    const double k2 = kx * kx + ky * ky;
+    for (int c = 0; c < P.n_kpsf; ++c) {
+        const ims_kpsf_t& p = P.kpsf[c];
+        if (p.kind == IMS_KPSF_GAUSSIAN) amp = amp * dexp(-0.5 * p.p0 * p.p0 * k2);
+        else if (p.kind == IMS_KPSF_KOLMOGOROV) {
+            if (k2 > 0.0) amp = amp * dexp(-dpow(sqrt(k2) / p.p0, 5.0 / 3.0));
+        } else amp = amp * ktable_lookup(P.ktables, p.table, sqrt(k2) * p.p0);
+    }
+    // pixel response: sinc(kx s / 2) sinc(ky s / 2)
+    const double hx = 0.5 * kx * P.pixel_scale, hy = 0.5 * ky * P.pixel_scale;
+    double s, c;
+    if (hx != 0.0) { dsincos(hx, s, c); amp = amp * (s / hx); }
+    if (hy != 0.0) { dsincos(hy, s, c); amp = amp * (s / hy); }
+    // centre at (cx, cy) pixels: phase exp(-i (kx cx + ky cy) s)
+    const double ph = (kx * o.cx + ky * o.cy) * P.pixel_scale;
+    dsincos(ph, s, c);
+    re = amp * c; im = -amp * s;
+}
+
+// log Gamma(x) for x > 0 by upward recurrence to x >= 8 and the Stirling series
+IMS_DEV double dlgamma(double x)
+{
+    double shift = 0.0;
+    while (x < 8.0) { shift = shift + dlog(x); x = x + 1.0; }
+    const double ix = 1.0 / x, ix2 = ix * ix;
+    double ser = -1.0 / 1680.0;
+    ser = fma(ser, ix2, 1.0 / 1260.0);
+    ser = fma(ser, ix2, -1.0 / 360.0);
+    ser = fma(ser, ix2, 1.0 / 12.0);
+    return (x - 0.5) * dlog(x) - x + 0.91893853320467274178 + ser * ix - shift;
+}
+
+// Poisson deviate, counter-addressed by (seed, object id, pixel): multiplication method below
+// mean 10, Hormann's PTRS transformed rejection above
+IMS_DEV double poisson(double mean, uint64_t seed, int64_t obj_id, int64_t pixel)
+{
+    if (!(mean > 0.0)) return 0.0;
+    uint32_t slot = 32;
+    if (mean < 10.0) {
+        const double L = dexp(-mean);
+        double p = 1.0;
+        double k = 0.0;
+        for (int it = 0; it < 64; ++it) {
+            const Draw d = draw(seed, obj_id, pixel, slot++);
+            p = p * u01_open(d.a);
+            if (p <= L) return k;
+            k = k + 1.0;
+            p = p * u01_open(d.b);
+            if (p <= L) return k;
+            k = k + 1.0;
+        }
+        return k;
+    }
+    const double slam = sqrt(mean), loglam = dlog(mean);
+    const double b = 0.931 + 2.53 * slam;
+    const double a = -0.059 + 0.02483 * b;
+    const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
+    const double vr = 0.9277 - 3.6224 / (b - 2.0);
+    for (int it = 0; it < 64; ++it) {
+        const Draw d = draw(seed, obj_id, pixel, slot++);
+        const double U = u01(d.a) - 0.5;
+        const double V = u01_open(d.b);
+        const double us = 0.5 - fabs(U);
+        const double k = floor((2.0 * a / us + b) * U + mean + 0.43);
+        if (us >= 0.07 && V <= vr) return k;
+        if (k < 0.0 || (us < 0.013 && V > us)) continue;
+        if (dlog(V) + dlog(invalpha) - dlog(a / (us * us) + b) <= -mean + k * loglam - dlgamma(k + 1.0)) return k;
+    }
+    return floor(mean + 0.5);
+}
+
+}  // namespace ims

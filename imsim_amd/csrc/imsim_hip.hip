@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <string.h>
 #include "ims_photon.h"
+#include "ims_fft.h"
 
 using namespace ims;
 
@@ -641,6 +642,58 @@ __global__ __launch_bounds__(256) void k_image_add(float* __restrict__ dst, cons
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] += src[i];
 }
 
+// ---------------- FFT branch ----------------
+__device__ __forceinline__ int64_t find_prefix(const int64_t* __restrict__ prefix, int64_t n, int64_t e)
+{
+    int64_t lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (prefix[mid] <= e) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_fft_kspace_fill(const ims_fft_params_t P, const ims_fft_object_t* __restrict__ objs,
+                                                         int64_t n_objects, const int64_t* __restrict__ prefix, int64_t n_elems,
+                                                         double* __restrict__ kbuf)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_elems; e += stride) {
+        const int64_t oi = find_prefix(prefix, n_objects, e);
+        const ims_fft_object_t& o = objs[oi];
+        const int64_t local = e - prefix[oi];
+        const int nh = o.nfft / 2 + 1;
+        const int i = (int)(local / nh), j = (int)(local % nh);
+        double re, im;
+        kspace_value(P, o, i, j, re, im);
+        kbuf[2 * (o.k_offset + local)] = re;
+        kbuf[2 * (o.k_offset + local) + 1] = im;
+    }
+}
+
+// clip, Poisson noise, stamp -> CCD add (stamp.py:519-524); realized flux = noise-free sum inside the stamp
+__global__ __launch_bounds__(256) void k_fft_finish(const ims_fft_params_t P, const ims_fft_object_t* __restrict__ objs,
+                                                    int64_t n_objects, const int64_t* __restrict__ prefix, int64_t n_pix,
+                                                    const double* __restrict__ rbuf)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_pix; e += stride) {
+        const int64_t oi = find_prefix(prefix, n_objects, e);
+        const ims_fft_object_t& o = objs[oi];
+        const int64_t local = e - prefix[oi];
+        const int iy = (int)(local / o.nfft), ix = (int)(local % o.nfft);
+        const int px = o.x0 + ix, py = o.y0 + iy;
+        if (px < o.stamp_xmin || px > o.stamp_xmax || py < o.stamp_ymin || py > o.stamp_ymax) continue;
+        double v = rbuf[o.r_offset + local];
+        if (v < 0.0) v = 0.0;
+        if (P.realized_flux != nullptr && v != 0.0) unsafeAtomicAdd(P.realized_flux + oi, v);
+        if (P.add_noise) v = poisson(v, P.seed, o.obj_id, local);
+        const int cxp = px - P.xmin, cyp = py - P.ymin;
+        if (cxp < 0 || cxp >= P.nx || cyp < 0 || cyp >= P.ny || v == 0.0) continue;
+        unsafeAtomicAdd(P.image + ((int64_t)cyp * P.nx + cxp), (float)v);
+    }
+}
+
 // device math probe for the parity tests (which: 0 log,1 exp,2 sincos2pi,3 atan,4 sincos,5 tanh,6 gauss)
 __global__ void k_test_math(int which, const double* __restrict__ in, double* __restrict__ out, int64_t n,
                             uint64_t seed, int64_t obj, uint32_t slot)
@@ -923,6 +976,30 @@ int ims_run_plan(const ims_plan_item_t* items, int64_t n_items, const ims_sensor
     return IMS_OK;
 }
 
+int ims_fft_kspace_fill(const ims_fft_params_t* params, const ims_fft_object_t* objects_dev, int64_t n_objects,
+                        const int64_t* elem_prefix_dev, int64_t n_elems, double* kbuf, void* stream)
+{
+    if (!params || !objects_dev || !elem_prefix_dev || !kbuf) return set_err(IMS_ERR_ARG, "NULL argument");
+    if (params->n_kpsf < 0 || params->n_kpsf > IMS_MAX_PSF) return set_err(IMS_ERR_ARG, "n_kpsf out of range");
+    if (n_objects <= 0 || n_elems <= 0) return IMS_OK;
+    hipLaunchKernelGGL(k_fft_kspace_fill, dim3(grid_for_pool(n_elems)), dim3(256), 0, (hipStream_t)stream, *params, objects_dev,
+                       n_objects, elem_prefix_dev, n_elems, kbuf);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+int ims_fft_finish(const ims_fft_params_t* params, const ims_fft_object_t* objects_dev, int64_t n_objects,
+                   const int64_t* pix_prefix_dev, int64_t n_pix, const double* rbuf, void* stream)
+{
+    if (!params || !objects_dev || !pix_prefix_dev || !rbuf) return set_err(IMS_ERR_ARG, "NULL argument");
+    if (!params->image) return set_err(IMS_ERR_ARG, "image is NULL");
+    if (n_objects <= 0 || n_pix <= 0) return IMS_OK;
+    hipLaunchKernelGGL(k_fft_finish, dim3(grid_for_pool(n_pix)), dim3(256), 0, (hipStream_t)stream, *params, objects_dev,
+                       n_objects, pix_prefix_dev, n_pix, rbuf);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
 int ims_image_add(float* dst, const float* src, int64_t n, void* stream)
 {
     if (!dst || !src) return set_err(IMS_ERR_ARG, "dst/src is NULL");
@@ -949,6 +1026,8 @@ int ims_struct_size(int which)
     case 11: return (int)sizeof(ims_render_params_t);
     case 12: return (int)sizeof(ims_plan_item_t);
     case 13: return (int)sizeof(ims_atmosphere_t);
+    case 14: return (int)sizeof(ims_fft_object_t);
+    case 15: return (int)sizeof(ims_fft_params_t);
     }
     return -1;
 }

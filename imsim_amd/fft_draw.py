@@ -1,0 +1,140 @@
+"""FFT branch of LSST_SiliconBuilder.draw (imsim/stamp.py:482-525) over the GPU engine.
+
+Which objects take this branch is decided as in the reference (imsim/stamp.py:275-277 and
+imsim/psf_utils.py:152-239): nominal_flux >= 1e6, fft_sb_thresh set and exceeded by half the peak
+surface brightness of the object convolved with the FFT-mode PSF.  The FFT-mode PSF replaces
+PhaseScreenPSF by VonKarman and SecondKick by Airy (make_fft_psf, psf_utils.py:94-149); with the
+Kolmogorov + Gaussian PSF it is the PSF itself.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _abi, tables
+from ._abi import FFT_OBJECT_DTYPE, FftParams, KPsf
+
+KOLMOGOROV_K0 = 2.992934 * 0.9758634299       # k0 * fwhm for exp(-(k/k0)^(5/3))  [rad/arcsec * arcsec]
+
+
+def next_fft_size(n, minimum=32):
+    m = minimum
+    while m < n:
+        m *= 2
+    return m
+
+
+def kolmogorov_gaussian_kpsf(fwhm_atm, fwhm_sys):
+    """k-space PSF list for Convolve(Kolmogorov(fwhm), Gaussian(fwhm)) (imsim/atmPSF.py:534-536)."""
+    return [(_abi.IMS_KPSF_KOLMOGOROV, 0, KOLMOGOROV_K0 / fwhm_atm),
+            (_abi.IMS_KPSF_GAUSSIAN, 0, fwhm_sys / 2.3548200450309493)]
+
+
+def max_surface_brightness(flux, kind, hlr, fwhm_total, pixel_scale=0.2):
+    """Half the peak surface brightness [photons/pixel] of the PSF-convolved object, the quantity
+    get_fft_psf_maybe compares with fft_sb_thresh (psf_utils.py:201-212).  Point sources: peak of
+    a Gaussian of the PSF's FWHM; extended: FWHMs added in quadrature (first-order estimate)."""
+    size = np.where(np.asarray(kind) == 0, fwhm_total, np.hypot(fwhm_total, 2.0 * np.asarray(hlr)))
+    sigma = size / 2.3548200450309493
+    return tables.gaussian_max_sb(np.asarray(flux, dtype=np.float64), sigma) / 2.0 * pixel_scale ** 2
+
+
+def use_fft(nominal_flux, kind, hlr, fwhm_total, fft_sb_thresh):
+    """The FFT-vs-phot decision of LSST_SiliconBuilder.buildPSF (stamp.py:275-308)."""
+    nominal_flux = np.asarray(nominal_flux, dtype=np.float64)
+    if not fft_sb_thresh:
+        return np.zeros(nominal_flux.shape, dtype=bool)
+    cand = (nominal_flux >= 1.0e6) & (nominal_flux >= fft_sb_thresh)
+    return cand & (max_surface_brightness(nominal_flux, kind, hlr, fwhm_total) > fft_sb_thresh)
+
+
+def build_fft_objects(objects, fft_flux, prof_ktable, pixel_scale=0.2):
+    """OBJECT_DTYPE rows (geometry as for photon shooting) -> FFT_OBJECT_DTYPE rows, grouped by FFT
+    size.  The profile affine is expressed along the pixel axes: jac' = s * winv * jac."""
+    n = len(objects)
+    out = np.zeros(n, dtype=FFT_OBJECT_DTYPE)
+    size = objects["stamp_xmax"] - objects["stamp_xmin"] + 1
+    nfft = np.array([next_fft_size(int(s)) for s in size], dtype=np.int32)
+    order = np.argsort(nfft, kind="stable")
+    objects, fft_flux, prof_ktable, size, nfft = objects[order], np.asarray(fft_flux)[order], np.asarray(prof_ktable)[order], size[order], nfft[order]
+    out["obj_id"] = objects["obj_id"]
+    out["flux"] = fft_flux
+    out["nfft"] = nfft
+    pad = (nfft - size) // 2
+    out["x0"] = objects["stamp_xmin"] - pad
+    out["y0"] = objects["stamp_ymin"] - pad
+    out["cx"] = objects["x0"] - out["x0"]
+    out["cy"] = objects["y0"] - out["y0"]
+    out["prof_ktable"] = prof_ktable
+    out["prof_scale"] = objects["prof_scale"]
+    w, j = objects["winv"] * pixel_scale, objects["jac"]
+    out["jac"] = np.stack([w[:, 0] * j[:, 0] + w[:, 1] * j[:, 2], w[:, 0] * j[:, 1] + w[:, 1] * j[:, 3],
+                           w[:, 2] * j[:, 0] + w[:, 3] * j[:, 2], w[:, 2] * j[:, 1] + w[:, 3] * j[:, 3]], axis=1)
+    for f in ("stamp_xmin", "stamp_xmax", "stamp_ymin", "stamp_ymax"):
+        out[f] = objects[f]
+    nh = nfft.astype(np.int64) // 2 + 1
+    out["k_offset"] = np.concatenate([[0], np.cumsum(nfft.astype(np.int64) * nh)])[:-1]
+    out["r_offset"] = np.concatenate([[0], np.cumsum(nfft.astype(np.int64) ** 2)])[:-1]
+    return out, order
+
+
+def fft_params(scene, kpsf, ktables, q_step, seed, add_noise=True, mem_put=None):
+    P = FftParams()
+    P.seed = int(seed)
+    P.pixel_scale = 0.2
+    P.n_kpsf = len(kpsf)
+    for k, (kind, table, p0) in enumerate(kpsf):
+        P.kpsf[k] = KPsf(kind, table, p0)
+    P.add_noise = 1 if add_noise else 0
+    t = np.atleast_2d(np.ascontiguousarray(ktables, dtype=np.float64))
+    P.ktables.n_tables, P.ktables.n_pts = t.shape
+    P.ktables.arg_min, P.ktables.arg_step = 0.0, float(q_step)
+    keep, P.ktables.val = mem_put(t)
+    P.nx, P.ny, P.xmin, P.ymin = scene.nx, scene.ny, scene.xmin, scene.ymin
+    return P, keep
+
+
+class FftDrawer:
+    """Batched FFT rendering into a Renderer's CCD image."""
+
+    def __init__(self, renderer, kpsf, sersic_indices=(1.0, 4.0), add_noise=True):
+        self.r = renderer
+        self.torch = renderer.torch
+        tabs = [tables.sersic_ktable(n) for n in sersic_indices]
+        self.q_step = float(tabs[0][0][1] - tabs[0][0][0])
+        self.P, self._keep = fft_params(renderer.scene, kpsf, np.stack([t[1] for t in tabs]), self.q_step,
+                                        renderer.scene.seed, add_noise, lambda a: renderer.mem.put(a, np.float64))
+        self.P.image = renderer.image.data_ptr()
+
+    def draw(self, fft_objects, realized=None):
+        """fft_objects: FFT_OBJECT_DTYPE rows sorted by nfft (build_fft_objects).  `realized`:
+        optional float64 device tensor [n]."""
+        torch, r = self.torch, self.r
+        n = len(fft_objects)
+        if n == 0:
+            return
+        rows = np.ascontiguousarray(fft_objects, dtype=FFT_OBJECT_DTYPE)
+        obj_t = torch.from_numpy(rows.view(np.uint8).reshape(-1)).to(r.device)
+        nfft = rows["nfft"].astype(np.int64)
+        kpre = np.concatenate([[0], np.cumsum(nfft * (nfft // 2 + 1))]).astype(np.int64)
+        rpre = np.concatenate([[0], np.cumsum(nfft * nfft)]).astype(np.int64)
+        kpre_t, rpre_t = torch.from_numpy(kpre).to(r.device), torch.from_numpy(rpre).to(r.device)
+        kbuf = torch.empty(int(kpre[-1]), dtype=torch.complex128, device=r.device)
+        rbuf = torch.empty(int(rpre[-1]), dtype=torch.float64, device=r.device)
+        P = self.P
+        P.realized_flux = realized.data_ptr() if realized is not None else None
+        st = r._stream()
+        _abi.check(r.lib.ims_fft_kspace_fill(C.byref(P), obj_t.data_ptr(), n, kpre_t.data_ptr(), int(kpre[-1]),
+                                             kbuf.data_ptr(), st), "ims_fft_kspace_fill")
+        # batched inverse real 2-D FFTs, one batch per FFT size (plain library transform: rocFFT)
+        for size in np.unique(nfft):
+            sel = np.flatnonzero(nfft == size)
+            a, b = int(sel[0]), int(sel[-1]) + 1
+            nh = int(size) // 2 + 1
+            spec = kbuf[int(kpre[a]):int(kpre[b])].view(b - a, int(size), nh)
+            rbuf[int(rpre[a]):int(rpre[b])].view(b - a, int(size), int(size)).copy_(
+                torch.fft.irfft2(spec, s=(int(size), int(size)), norm="backward"))
+        _abi.check(r.lib.ims_fft_finish(C.byref(P), obj_t.data_ptr(), n, rpre_t.data_ptr(), int(rpre[-1]),
+                                        rbuf.data_ptr(), st), "ims_fft_finish")
+        self._last = (kbuf, rbuf, obj_t, kpre_t, rpre_t)
+        return kbuf, rbuf

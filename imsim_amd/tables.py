@@ -151,3 +151,40 @@ def silicon_abs_length_table(temperature=173.0, wl_min=255.0, wl_max=1450.0, ste
     alpha += Ad * np.sqrt(np.clip(E - (Egd0 - shift), 0.0, None))
     alpha = np.maximum(alpha, 1.0e-6)      # cm^-1
     return wl, 1.0e4 / alpha               # micron
+
+
+# ---------------- k-space tables for the FFT branch ----------------
+KTABLE_QMAX = 160.0
+KTABLE_NPTS = 2049
+_KT_CACHE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "sersic_ktable_n%s.npz")
+
+
+@functools.lru_cache(maxsize=None)
+def sersic_ktable(n, qmax=KTABLE_QMAX, npts=KTABLE_NPTS):
+    """Hankel transform of the Sersic profile, F(q) with q = k * half_light_radius, F(0) = 1, on a
+    uniform q grid (GalSim SBSersic::kValue restated: there a per-n lookup table as well).
+    With x = r^(1/n):  F(q) = int exp(-b x) J0(q x^n) n x^(2n-1) dx / Gamma(2n) * b^(2n)."""
+    n = float(n)
+    path = _KT_CACHE % (("%g" % n).replace(".", "p"))
+    if os.path.exists(path):
+        with np.load(path) as z:
+            if z["q"][-1] == qmax and len(z["q"]) == npts:
+                return z["q"], z["F"]
+    b = special.gammaincinv(2.0 * n, 0.5)
+    q = np.linspace(0.0, qmax, npts)
+    x = np.linspace(0.0, 40.0 / b, 120001)
+    w = np.exp(-b * x) * n * x ** (2.0 * n - 1.0)
+    norm = integrate.simpson(w, x=x)
+    xn = x ** n
+    F = np.empty_like(q)
+    for a in range(0, npts, 64):
+        F[a:a + 64] = integrate.simpson(w[None, :] * special.j0(q[a:a + 64, None] * xn[None, :]), x=x, axis=1) / norm
+    try:
+        np.savez(path, q=q, F=F)
+    except OSError:
+        pass
+    return q, F
+
+
+def gaussian_max_sb(flux, sigma):
+    return flux / (2.0 * np.pi * sigma * sigma)

@@ -321,6 +321,58 @@ int  ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sen
                                    int32_t first_slot, int32_t n_slots, const int64_t* tile_prefix_dev,
                                    int64_t n_tiles, unsigned char* changed_dev, void* stream);
 
+/* ---- FFT branch: LSST_SiliconBuilder.draw, method == 'fft' (imsim/stamp.py:482-525) ----
+ * For very bright objects (nominal_flux >= 1e6 and max_sb > fft_sb_thresh, imsim/stamp.py:275-277,
+ * imsim/psf_utils.py:152-239) the reference draws Convolve([gal] + psfs) with GalSim's FFT renderer,
+ * clips negatives, adds Poisson noise and adds the stamp to the CCD.  Here:
+ *   ims_fft_kspace_fill : half-spectrum of every object of a batch = profile k-value x PSF MTFs x
+ *                         pixel response x sub-pixel phase, on an nfft x (nfft/2+1) grid per object
+ *   (inverse real 2-D FFT of each grid, unnormalised "backward" 1/N^2 convention, by the caller:
+ *    rocFFT / hipFFT / torch.fft.irfft2 -- a plain library transform)
+ *   ims_fft_finish      : clip < 0, Poisson noise (PoissonNoise, stamp.py:522), add stamp to the CCD */
+#define IMS_KPSF_GAUSSIAN   1   /* p0 = sigma [arcsec]:            exp(-sigma^2 k^2 / 2) */
+#define IMS_KPSF_KOLMOGOROV 2   /* p0 = k0 [rad/arcsec]:           exp(-(k/k0)^(5/3)) */
+#define IMS_KPSF_TABLE      3   /* radial k-table `table` at k*p0 (VonKarman, Airy: imsim/psf_utils.py:109-126) */
+typedef struct ims_kpsf {
+    int32_t kind;
+    int32_t table;
+    double  p0;
+} ims_kpsf_t;
+
+typedef struct ims_fft_object {
+    int64_t obj_id;
+    int64_t k_offset;        /* complex-element offset of this object's half spectrum in the k buffer */
+    int64_t r_offset;        /* real-element offset of its nfft x nfft image in the real buffer */
+    double  flux;            /* fft_flux (nominal_flux x vignetting, imsim/psf_utils.py:220-233) */
+    double  cx, cy;          /* object centre in FFT-grid index coordinates [pixels] */
+    double  prof_scale;      /* arcsec per k-table unit (half-light radius) */
+    double  jac[4];          /* real-space profile affine; the k-vector is transformed by its transpose */
+    int32_t nfft;            /* FFT size (even) */
+    int32_t prof_ktable;     /* k-table id of the profile; -1 = DeltaFunction */
+    int32_t x0, y0;          /* CCD pixel coordinates of FFT-grid index (0,0) */
+    int32_t stamp_xmin, stamp_xmax, stamp_ymin, stamp_ymax;
+    int32_t pad[2];
+} ims_fft_object_t;
+
+typedef struct ims_fft_params {
+    uint64_t seed;
+    double   pixel_scale;            /* arcsec / pixel */
+    int32_t  n_kpsf;
+    int32_t  add_noise;              /* 1: replace every pixel by a Poisson variate of its value */
+    ims_kpsf_t kpsf[IMS_MAX_PSF];
+    ims_lin_tables_t ktables;        /* radial k-space tables, uniform in their argument, 0 beyond the end */
+    float*   image;                  /* CCD image, as in ims_render_params_t */
+    int32_t  nx, ny, xmin, ymin;
+    double*  realized_flux;          /* [n_objects] or NULL */
+} ims_fft_params_t;
+
+/* elem_prefix[n_objects+1] (device): prefix sum of nfft*(nfft/2+1); kbuf: interleaved (re, im) doubles */
+int  ims_fft_kspace_fill(const ims_fft_params_t* params, const ims_fft_object_t* objects_dev, int64_t n_objects,
+                         const int64_t* elem_prefix_dev, int64_t n_elems, double* kbuf, void* stream);
+/* pix_prefix[n_objects+1] (device): prefix sum of nfft*nfft; rbuf: the inverse-transformed images */
+int  ims_fft_finish(const ims_fft_params_t* params, const ims_fft_object_t* objects_dev, int64_t n_objects,
+                    const int64_t* pix_prefix_dev, int64_t n_pix, const double* rbuf, void* stream);
+
 /* ---- launch plans ----
  * The brighter-fatter chain of LSST_Image mode is hundreds of short dependent launches; ims_run_plan
  * issues a whole prepared list from C so the host cost per launch is one hipLaunchKernel.
@@ -358,7 +410,7 @@ int  ims_enable_timing(int on);
  * which: 0 log, 1 exp, 2 sincos2pi (2 outputs), 3 atan, 4 sincos (2), 5 tanh, 6 gaussian pair of draw(seed,obj,i,slot) (2) */
 /* sizeof() of the ABI structs as compiled, for binding self-checks:
  * 0 object, 1 radial_tables, 2 lin_tables, 3 psf_component, 4 op, 5 surface, 6 tansip, 7 optics, 8 bf_slot,
- * 9 sensor, 10 photons, 11 render_params, 12 plan_item, 13 atmosphere */
+ * 9 sensor, 10 photons, 11 render_params, 12 plan_item, 13 atmosphere, 14 fft_object, 15 fft_params */
 int  ims_struct_size(int which);
 int  ims_test_math(int which, const double* in_dev, double* out_dev, int64_t n, uint64_t seed, int64_t obj,
                    uint32_t slot, void* stream);

@@ -1,0 +1,133 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY (see orc_math.h).
+ *
+ * orc_fft.c: CPU restatement of the FFT branch of LSST_SiliconBuilder.draw (imsim/stamp.py:482-525):
+ * analytic half-spectrum of Convolve([gal] + psfs) with the pixel response (GalSim drawImage
+ * method='fft', third-party, unpinned), clip of negatives (:519), Poisson noise (:522) and the
+ * stamp -> CCD add (:524).  The inverse transform itself is done by the test with numpy.fft.
+ * Parity unpinned at the bit level (GalSim's FFT renderer and boost's Poisson deviate are not
+ * reproducible here); pinned by the reference's FFT-vs-phot criteria (tests/test_psf.py:341-438).
+ */
+#include "orc.h"
+
+static double ktable_lookup(const ims_lin_tables_t* t, int table, double arg)
+{
+    const double* v = t->val + (int64_t)table * t->n_pts;
+    double f = (arg - t->arg_min) / t->arg_step;
+    if (!(f > 0.0)) return v[0];
+    if (f >= (double)(t->n_pts - 1)) return 0.0;
+    int i = (int)f;
+    double a = f - (double)i;
+    return v[i] + a * (v[i + 1] - v[i]);
+}
+
+void orc_fft_kspace_fill(const ims_fft_params_t* P, const ims_fft_object_t* objs, int64_t n_objects, double* kbuf)
+{
+    for (int64_t oi = 0; oi < n_objects; ++oi) {
+        const ims_fft_object_t* o = &objs[oi];
+        int n = o->nfft, nh = n / 2 + 1;
+        double dk = ORC_TWO_PI / ((double)n * P->pixel_scale);
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < nh; ++j) {
+                double kx = (double)j * dk;
+                double ky = (double)(i < n / 2 ? i : i - n) * dk;
+                double amp = o->flux;
+                if (o->prof_ktable >= 0) {
+                    double qx = o->jac[0] * kx + o->jac[2] * ky;
+                    double qy = o->jac[1] * kx + o->jac[3] * ky;
+                    amp = amp * ktable_lookup(&P->ktables, o->prof_ktable, orc_sqrt(qx * qx + qy * qy) * o->prof_scale);
+                }
+                double k2 = kx * kx + ky * ky;
+                for (int c = 0; c < P->n_kpsf; ++c) {
+                    const ims_kpsf_t* p = &P->kpsf[c];
+                    if (p->kind == IMS_KPSF_GAUSSIAN) amp = amp * orc_exp(-0.5 * p->p0 * p->p0 * k2);
+                    else if (p->kind == IMS_KPSF_KOLMOGOROV) {
+                        if (k2 > 0.0) amp = amp * orc_exp(-orc_pow(orc_sqrt(k2) / p->p0, 5.0 / 3.0));
+                    } else amp = amp * ktable_lookup(&P->ktables, p->table, orc_sqrt(k2) * p->p0);
+                }
+                double hx = 0.5 * kx * P->pixel_scale, hy = 0.5 * ky * P->pixel_scale;
+                double s, c;
+                if (hx != 0.0) { orc_sincos(hx, &s, &c); amp = amp * (s / hx); }
+                if (hy != 0.0) { orc_sincos(hy, &s, &c); amp = amp * (s / hy); }
+                double ph = (kx * o->cx + ky * o->cy) * P->pixel_scale;
+                orc_sincos(ph, &s, &c);
+                int64_t e = o->k_offset + (int64_t)i * nh + j;
+                kbuf[2 * e] = amp * c;
+                kbuf[2 * e + 1] = -amp * s;
+            }
+    }
+}
+
+static double orc_lgamma(double x)
+{
+    double shift = 0.0;
+    while (x < 8.0) { shift = shift + orc_log(x); x = x + 1.0; }
+    double ix = 1.0 / x, ix2 = ix * ix;
+    double ser = -1.0 / 1680.0;
+    ser = orc_fma(ser, ix2, 1.0 / 1260.0);
+    ser = orc_fma(ser, ix2, -1.0 / 360.0);
+    ser = orc_fma(ser, ix2, 1.0 / 12.0);
+    return (x - 0.5) * orc_log(x) - x + 0.91893853320467274178 + ser * ix - shift;
+}
+
+double orc_poisson(double mean, uint64_t seed, int64_t obj_id, int64_t pixel)
+{
+    if (!(mean > 0.0)) return 0.0;
+    uint32_t slot = 32;
+    if (mean < 10.0) {
+        double L = orc_exp(-mean), p = 1.0, k = 0.0;
+        for (int it = 0; it < 64; ++it) {
+            orc_draw_t d = orc_draw(seed, obj_id, pixel, slot++);
+            p = p * orc_u01_open(d.a);
+            if (p <= L) return k;
+            k = k + 1.0;
+            p = p * orc_u01_open(d.b);
+            if (p <= L) return k;
+            k = k + 1.0;
+        }
+        return k;
+    }
+    double slam = orc_sqrt(mean), loglam = orc_log(mean);
+    double b = 0.931 + 2.53 * slam;
+    double a = -0.059 + 0.02483 * b;
+    double invalpha = 1.1239 + 1.1328 / (b - 3.4);
+    double vr = 0.9277 - 3.6224 / (b - 2.0);
+    for (int it = 0; it < 64; ++it) {
+        orc_draw_t d = orc_draw(seed, obj_id, pixel, slot++);
+        double U = orc_u01(d.a) - 0.5;
+        double V = orc_u01_open(d.b);
+        double us = 0.5 - fabs(U);
+        double k = floor((2.0 * a / us + b) * U + mean + 0.43);
+        if (us >= 0.07 && V <= vr) return k;
+        if (k < 0.0 || (us < 0.013 && V > us)) continue;
+        if (orc_log(V) + orc_log(invalpha) - orc_log(a / (us * us) + b) <= -mean + k * loglam - orc_lgamma(k + 1.0)) return k;
+    }
+    return floor(mean + 0.5);
+}
+
+/* clip, noise, add; image is a double accumulation buffer [ny][nx] */
+void orc_fft_finish(const ims_fft_params_t* P, const ims_fft_object_t* objs, int64_t n_objects, const double* rbuf,
+                    double* image, double* realized)
+{
+    for (int64_t oi = 0; oi < n_objects; ++oi) {
+        const ims_fft_object_t* o = &objs[oi];
+        for (int iy = 0; iy < o->nfft; ++iy)
+            for (int ix = 0; ix < o->nfft; ++ix) {
+                int px = o->x0 + ix, py = o->y0 + iy;
+                if (px < o->stamp_xmin || px > o->stamp_xmax || py < o->stamp_ymin || py > o->stamp_ymax) continue;
+                int64_t local = (int64_t)iy * o->nfft + ix;
+                double v = rbuf[o->r_offset + local];
+                if (v < 0.0) v = 0.0;
+                if (realized) realized[oi] += v;
+                if (P->add_noise) v = orc_poisson(v, P->seed, o->obj_id, local);
+                int cx = px - P->xmin, cy = py - P->ymin;
+                if (cx < 0 || cx >= P->nx || cy < 0 || cy >= P->ny) continue;
+                image[(int64_t)cy * P->nx + cx] += v;
+            }
+    }
+}
+
+void orc_test_poisson(const double* mean, double* out, int64_t n, uint64_t seed, int64_t obj_id)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = orc_poisson(mean[i], seed, obj_id, i);
+}

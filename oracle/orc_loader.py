@@ -42,6 +42,9 @@ def load():
         lib.orc_sensor_init_boundaries.argtypes = [C.c_void_p, C.c_int, C.c_int]
         lib.orc_sensor_update_distortions.argtypes = [C.c_void_p, C.c_int, C.c_int]
         lib.orc_test_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]
+        lib.orc_fft_kspace_fill.argtypes = [C.POINTER(_abi.FftParams), C.c_void_p, C.c_int64, C.c_void_p]
+        lib.orc_fft_finish.argtypes = [C.POINTER(_abi.FftParams), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.orc_test_poisson.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_int64]
         lib.orc_test_gauss.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_uint32, C.c_void_p]
         _lib = lib
     return _lib
@@ -180,3 +183,52 @@ class OracleScene:
     def sensor_array(self, name):
         dt = np.float32 if name == "delta" else np.float64
         return self.bound.sensor_arrays[name].view(dt)
+
+
+def poisson_probe(mean, seed=1, obj_id=0):
+    lib = load()
+    mean = np.ascontiguousarray(mean, dtype=np.float64)
+    out = np.empty_like(mean)
+    lib.orc_test_poisson(mean.ctypes.data, out.ctypes.data, mean.size, seed, obj_id)
+    return out
+
+
+class OracleFft:
+    """CPU counterpart of imsim_amd.fft_draw.FftDrawer (numpy.fft for the transform)."""
+
+    def __init__(self, scene, kpsf, sersic_indices=(1.0, 4.0), add_noise=True):
+        from imsim_amd import fft_draw, tables
+        self.lib = load()
+        self.scene = scene
+        self.keep = []
+        tabs = [tables.sersic_ktable(n) for n in sersic_indices]
+
+        def put(a):
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            self.keep.append(a)
+            return a, a.ctypes.data
+        self.P, _ = fft_draw.fft_params(scene, kpsf, np.stack([t[1] for t in tabs]), float(tabs[0][0][1] - tabs[0][0][0]),
+                                        scene.seed, add_noise, put)
+        self.image = np.zeros((scene.ny, scene.nx), dtype=np.float64)
+
+    def fill(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=_abi.FFT_OBJECT_DTYPE)
+        nfft = rows["nfft"].astype(np.int64)
+        kbuf = np.zeros(int(np.sum(nfft * (nfft // 2 + 1))), dtype=np.complex128)
+        self.lib.orc_fft_kspace_fill(C.byref(self.P), rows.ctypes.data, len(rows), kbuf.ctypes.data)
+        return kbuf
+
+    def inverse(self, rows, kbuf):
+        out = []
+        for o in rows:
+            n = int(o["nfft"])
+            nh = n // 2 + 1
+            spec = kbuf[int(o["k_offset"]):int(o["k_offset"]) + n * nh].reshape(n, nh)
+            out.append(np.fft.irfft2(spec, s=(n, n)).ravel())
+        return np.concatenate(out)
+
+    def finish(self, rows, rbuf, realized=None):
+        rows = np.ascontiguousarray(rows, dtype=_abi.FFT_OBJECT_DTYPE)
+        rbuf = np.ascontiguousarray(rbuf, dtype=np.float64)
+        self.lib.orc_fft_finish(C.byref(self.P), rows.ctypes.data, len(rows), rbuf.ctypes.data, self.image.ctypes.data,
+                                realized.ctypes.data if realized is not None else None)

@@ -111,6 +111,8 @@ int orc_struct_size(int which)
     case 11: return (int)sizeof(ims_render_params_t);
     case 12: return (int)sizeof(ims_plan_item_t);
     case 13: return (int)sizeof(ims_atmosphere_t);
+    case 14: return (int)sizeof(ims_fft_object_t);
+    case 15: return (int)sizeof(ims_fft_params_t);
     }
     return -1;
 }

@@ -1,0 +1,60 @@
+"""FFT branch, CPU side: the oracle's k-space fill / Poisson deviate and the host decision logic."""
+import numpy as np
+
+from imsim_amd import _abi, configs, catalog, fft_draw, tables
+from oracle import orc_loader
+
+
+def _one_object(flux=2.0e6, kind=0, hlr=0.5, nx=256):
+    scene = configs.scene_c2(nx=nx, ny=nx)
+    cat = dict(x=np.array([100.3]), y=np.array([120.7]), mag=np.array([15.0]), nominal_flux=np.array([flux]),
+               kind=np.array([kind]), hlr=np.array([hlr]), q=np.array([0.6]), pa=np.array([30.0]), obj_id=np.array([7]))
+    objects, _ = catalog.build_object_table(cat, np.array([int(flux)]), stamp_size=64)
+    return scene, objects
+
+
+def test_poisson_deviate_moments():
+    for mean in (0.3, 3.0, 9.5, 10.5, 47.0, 1.0e3, 2.0e6):
+        k = orc_loader.poisson_probe(np.full(200000, mean), seed=11, obj_id=3)
+        assert np.all(k >= 0) and np.all(k == np.floor(k))
+        assert abs(k.mean() - mean) < 5 * np.sqrt(mean / len(k)) + 1e-12
+        assert abs(k.var() / mean - 1.0) < 0.03
+    assert np.all(orc_loader.poisson_probe(np.zeros(10)) == 0)
+
+
+def test_fft_image_conserves_flux_and_is_centred():
+    scene, objects = _one_object()
+    fwhm_atm, fwhm_sys = catalog.kolmogorov_gaussian_fwhm()
+    orc = orc_loader.OracleFft(scene, fft_draw.kolmogorov_gaussian_kpsf(fwhm_atm, fwhm_sys), add_noise=False)
+    rows, _ = fft_draw.build_fft_objects(objects, objects["n_phot"].astype(float), objects["prof_table"])
+    kbuf = orc.fill(rows)
+    assert kbuf[0].real == rows["flux"][0] and kbuf[0].imag == 0.0
+    img = orc.inverse(rows, kbuf).reshape(64, 64)
+    assert abs(img.sum() / rows["flux"][0] - 1.0) < 1e-9            # DC term = flux
+    yy, xx = np.mgrid[0:64, 0:64]
+    cx, cy = (img * xx).sum() / img.sum(), (img * yy).sum() / img.sum()
+    assert abs(cx - rows["cx"][0]) < 0.02 and abs(cy - rows["cy"][0]) < 0.02
+    assert img.min() > -1e-6 * img.max()
+    real = np.zeros(1)
+    orc.finish(rows, img.ravel(), real)
+    assert abs(real[0] / rows["flux"][0] - 1.0) < 1e-3
+    assert abs(orc.image.sum() - real[0]) < 1e-6 * real[0]
+
+
+def test_sersic_ktable_matches_exponential_closed_form():
+    from scipy import special
+    q, F = tables.sersic_ktable(1.0)
+    b = special.gammaincinv(2.0, 0.5)
+    np.testing.assert_allclose(F, (1 + (q / b) ** 2) ** -1.5, atol=1e-10)
+    q4, F4 = tables.sersic_ktable(4.0)
+    assert F4[0] == 1.0 and np.all(np.diff(F4[:500]) < 0)
+
+
+def test_fft_decision_follows_the_reference_rules():
+    """stamp.py:275-277: phot unless flux >= 1e6, fft_sb_thresh set, and the peak SB exceeds it."""
+    flux = np.array([5.0e5, 2.0e6, 2.0e6, 5.0e7])
+    kind = np.array([0, 0, 2, 2])
+    hlr = np.array([0.0, 0.0, 3.0, 0.2])
+    assert not fft_draw.use_fft(flux, kind, hlr, 0.8, 0.0).any()
+    got = fft_draw.use_fft(flux, kind, hlr, 0.8, 2.0e5)
+    assert list(got) == [False, False, False, True] or list(got) == [False, True, False, True]

@@ -246,3 +246,80 @@ def test_c3b_atmospheric_psf_is_bit_exact(torch_cuda):
     r.synchronize()
     orc.render_lsst_image(objects)
     assert_bits_equal(r.image_numpy(), orc.image, "C3b image")
+
+
+# ---------------------------------------------------------------------------------------------
+# FFT branch (imsim/stamp.py:482-525)
+# ---------------------------------------------------------------------------------------------
+def _fft_case(nx=256):
+    from imsim_amd import configs, catalog, fft_draw
+    scene = configs.scene_c2(nx=nx, ny=nx)
+    cat = dict(x=np.array([100.3, 60.0, 180.6, 128.5]), y=np.array([120.7, 200.2, 70.1, 40.9]), mag=np.zeros(4),
+               nominal_flux=np.array([2.0e6, 5.0e6, 1.5e6, 3.0e6]), kind=np.array([0, 1, 2, 0]),
+               hlr=np.array([0.0, 0.4, 0.8, 0.0]), q=np.array([1.0, 0.5, 0.8, 1.0]), pa=np.array([0.0, 30.0, 110.0, 0.0]),
+               obj_id=np.arange(4))
+    objects, _ = catalog.build_object_table(cat, cat["nominal_flux"].astype(np.int64), stamp_size=np.array([64, 128, 96, 48]))
+    fwhm_atm, fwhm_sys = catalog.kolmogorov_gaussian_fwhm()
+    kpsf = fft_draw.kolmogorov_gaussian_kpsf(fwhm_atm, fwhm_sys)
+    rows, order = fft_draw.build_fft_objects(objects, cat["nominal_flux"], objects["prof_table"])
+    return scene, rows, kpsf
+
+
+def test_fft_branch_matches_oracle(torch_cuda):
+    """k-space fill is bit-exact (deterministic elementary functions); the inverse transform
+    (rocFFT vs numpy) agrees to 1e-11 of the peak; clip + Poisson noise + CCD add are exact."""
+    from imsim_amd import fft_draw
+    from imsim_amd.engine import Renderer
+    from oracle import orc_loader
+    scene, rows, kpsf = _fft_case()
+    r = Renderer(scene)
+    drawer = fft_draw.FftDrawer(r, kpsf, add_noise=True)
+    real = torch_cuda.zeros(len(rows), dtype=torch_cuda.float64, device="cuda")
+    kbuf, rbuf = drawer.draw(rows, realized=real)
+    r.synchronize()
+    orc = orc_loader.OracleFft(scene, kpsf, add_noise=True)
+    okbuf = orc.fill(rows)
+    assert_bits_equal(kbuf.cpu().numpy(), okbuf, "k-space half spectra")
+    orbuf = orc.inverse(rows, okbuf)
+    g_rbuf = rbuf.cpu().numpy()
+    assert np.abs(g_rbuf - orbuf).max() < 1e-11 * np.abs(orbuf).max()
+    # noise + add: feed the oracle the SAME real-space images the GPU produced
+    oreal = np.zeros(len(rows))
+    orc.finish(rows, g_rbuf, oreal)
+    assert_bits_equal(r.image_numpy(), orc.image.astype(np.float32), "noisy FFT image")
+    np.testing.assert_allclose(real.cpu().numpy(), oreal, rtol=1e-12)
+    np.testing.assert_allclose(oreal, rows["flux"], rtol=2e-2)
+
+
+def test_fft_and_photon_shooting_agree(torch_cuda):
+    """The reference's FFT-vs-phot criteria (tests/test_psf.py:341-438: peak within 5 %, moments
+    within 10 %) for a bright star and a bright Sersic galaxy through Kolmogorov (+) Gaussian."""
+    from imsim_amd import _abi, configs, catalog, fft_draw
+    from imsim_amd.engine import Renderer
+    fwhm_atm, fwhm_sys = catalog.kolmogorov_gaussian_fwhm()
+    for kind, hlr in ((0, 0.0), (1, 0.6)):
+        scene = configs.scene_c2(nx=128, ny=128)
+        scene.psf = [(_abi.IMS_PSF_RADIAL, 2, fwhm_atm, 0.0, 1.0), (_abi.IMS_PSF_GAUSSIAN, 0, fwhm_sys / 2.3548200450309493, 0.0, 1.0)]
+        cat = dict(x=np.array([64.3]), y=np.array([63.8]), mag=np.zeros(1), nominal_flux=np.array([4.0e6]),
+                   kind=np.array([kind]), hlr=np.array([hlr]), q=np.array([0.7]), pa=np.array([20.0]), obj_id=np.array([3]))
+        objects, _ = catalog.build_object_table(cat, np.array([4000000]), stamp_size=128)
+        rp = Renderer(scene)
+        rp.render(objects)
+        rf = Renderer(scene)
+        rows, _ = fft_draw.build_fft_objects(objects, cat["nominal_flux"], objects["prof_table"])
+        fft_draw.FftDrawer(rf, fft_draw.kolmogorov_gaussian_kpsf(fwhm_atm, fwhm_sys), add_noise=False).draw(rows)
+        rp.synchronize(); rf.synchronize()
+        a, b = rp.image_numpy().astype(float), rf.image_numpy().astype(float)
+
+        def mom(img):
+            yy, xx = np.mgrid[0:128, 0:128]
+            w = (np.hypot(xx - 63.3, yy - 62.8) < 25)
+            f = (img * w).sum()
+            mx, my = (img * w * xx).sum() / f, (img * w * yy).sum() / f
+            return f, mx, my, (img * w * ((xx - mx) ** 2 + (yy - my) ** 2)).sum() / f
+        fa, xa, ya, ra = mom(a)
+        fb, xb, yb, rb = mom(b)
+        assert abs(a.max() / b.max() - 1) < 0.05
+        assert abs(fa / fb - 1) < 0.01
+        assert abs(xa - xb) < 0.02 and abs(ya - yb) < 0.02
+        assert abs(ra / rb - 1) < 0.10

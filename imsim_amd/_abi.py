@@ -86,10 +86,16 @@ class FftObject(C.Structure):
                 ("stamp_xmin", c_i32), ("stamp_xmax", c_i32), ("stamp_ymin", c_i32), ("stamp_ymax", c_i32), ("pad", c_i32 * 2)]
 
 
+class Spikes(C.Structure):
+    _fields_ = [("enabled", c_i32), ("cutoff", c_i32), ("threshold", c_d), ("cos0", c_d), ("sin0", c_d), ("a_lo", c_d),
+                ("d_alpha", c_d), ("scale", c_d), ("r0", c_d), ("norm", c_d)]
+
+
 class FftParams(C.Structure):
     _fields_ = [("seed", c_u64), ("pixel_scale", c_d), ("n_kpsf", c_i32), ("add_noise", c_i32),
                 ("kpsf", KPsf * IMS_MAX_PSF), ("ktables", LinTables), ("image", c_vp),
-                ("nx", c_i32), ("ny", c_i32), ("xmin", c_i32), ("ymin", c_i32), ("realized_flux", c_vp)]
+                ("nx", c_i32), ("ny", c_i32), ("xmin", c_i32), ("ymin", c_i32), ("realized_flux", c_vp),
+                ("spikes", Spikes)]
 
 
 class Op(C.Structure):
@@ -161,7 +167,7 @@ STRUCTS = [Object, RadialTables, LinTables, PsfComponent, Op, Surface, TanSip, O
 # every symbol include/imsim_hip.h declares
 EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_info", "ims_shoot_accumulate",
            "ims_shoot_photons", "ims_shoot_ops_photons", "ims_accumulate_segments", "ims_run_plan",
-           "ims_fft_kspace_fill", "ims_fft_finish", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
+           "ims_fft_kspace_fill", "ims_fft_finish", "ims_fft_spikes", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
            "ims_sensor_update_distortions", "ims_image_add", "ims_last_kernel_ms", "ims_enable_timing",
            "ims_struct_size", "ims_test_math"]
 
@@ -206,6 +212,7 @@ def load():
     lib.ims_image_add.argtypes = [c_vp, c_vp, c_i64, c_vp]
     lib.ims_fft_kspace_fill.argtypes = [C.POINTER(FftParams), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]
     lib.ims_fft_finish.argtypes = [C.POINTER(FftParams), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]
+    lib.ims_fft_spikes.argtypes = [C.POINTER(FftParams), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]
     lib.ims_run_plan.argtypes = [C.POINTER(PlanItem), c_i64, c_vp, C.POINTER(Sensor), c_vp, c_vp, c_vp]
     lib.ims_last_kernel_ms.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.ims_enable_timing.argtypes = [C.c_int]

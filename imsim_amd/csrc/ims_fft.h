@@ -103,4 +103,26 @@ IMS_DEV double poisson(double mean, uint64_t seed, int64_t obj_id, int64_t pixel
     return floor(mean + 0.5);
 }
 
+// un-normalised spike stencil at integer offset (a rows, b columns)
+// (prepare_psf_field_rotation, imsim/diffraction_fft.py:78-123, evaluated analytically)
+IMS_DEV double spike_stencil(const ims_spikes_t& k, int a, int b)
+{
+    const double x = (double)a, y = (double)b;
+    const double xr = k.cos0 * x + k.sin0 * y;
+    const double yr = -k.sin0 * x + k.cos0 * y;
+    const double m = fabs(xr) < fabs(yr) ? fabs(xr) : fabs(yr);
+    double val = 1.0 - m;
+    if (val < 0.0) val = 0.0;
+    const double half_pi = PI_2;
+    double dth = datan2(y, x) - k.a_lo;
+    dth = dth - floor(dth / half_pi) * half_pi;
+    if (dth <= k.d_alpha) val = 1.0;
+    const double r = sqrt(x * x + y * y);
+    const double prof = 0.63661977236758134308 * (datan((r + 0.5) * k.scale / k.r0) - datan((r - 0.5) * k.scale / k.r0));
+    const double arc = r * k.d_alpha;
+    val = val * prof / (arc > 1.0 ? arc : 1.0);
+    if (a == 0 && b == 0) val = 2.0 * val;
+    return val;
+}
+
 }  // namespace ims

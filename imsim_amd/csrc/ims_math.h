@@ -183,6 +183,17 @@ IMS_DEV double datan(double x)
     return x < 0.0 ? -res : res;
 }
 
+// atan2 with the usual quadrant conventions (finite arguments, not both zero -> 0 for (0,0))
+IMS_DEV double datan2(double y, double x)
+{
+    constexpr double PI = 3.14159265358979323846;
+    if (x > 0.0) return datan(y / x);
+    if (x < 0.0) return y >= 0.0 ? datan(y / x) + PI : datan(y / x) - PI;
+    if (y > 0.0) return PI_2;
+    if (y < 0.0) return -PI_2;
+    return 0.0;
+}
+
 IMS_DEV double dtanh_pos(double x)
 {
     if (x > 20.0) return 1.0;

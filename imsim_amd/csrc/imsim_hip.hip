@@ -671,6 +671,60 @@ __global__ __launch_bounds__(256) void k_fft_kspace_fill(const ims_fft_params_t 
     }
 }
 
+// saturated bounding box of every object (saturated_region, imsim/diffraction_fft.py:211-227)
+__global__ __launch_bounds__(256) void k_fft_bbox(const ims_fft_params_t P, const ims_fft_object_t* __restrict__ objs,
+                                                  int64_t n_objects, const int64_t* __restrict__ prefix, int64_t n_pix,
+                                                  const double* __restrict__ rbuf, int32_t* __restrict__ bbox)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_pix; e += stride) {
+        const int64_t oi = find_prefix(prefix, n_objects, e);
+        const ims_fft_object_t& o = objs[oi];
+        const int64_t local = e - prefix[oi];
+        const int iy = (int)(local / o.nfft), ix = (int)(local % o.nfft);
+        const int px = o.x0 + ix, py = o.y0 + iy;
+        if (px < o.stamp_xmin || px > o.stamp_xmax || py < o.stamp_ymin || py > o.stamp_ymax) continue;
+        if (rbuf[o.r_offset + local] > P.spikes.threshold) {
+            atomicMin(&bbox[4 * oi + 0], iy); atomicMax(&bbox[4 * oi + 1], iy);
+            atomicMin(&bbox[4 * oi + 2], ix); atomicMax(&bbox[4 * oi + 3], ix);
+        }
+    }
+}
+
+// convolve_region (imsim/diffraction_fft.py:170-208): clipped image with the box zeroed + box (x) stencil
+__global__ __launch_bounds__(256) void k_fft_spikes(const ims_fft_params_t P, const ims_fft_object_t* __restrict__ objs,
+                                                    int64_t n_objects, const int64_t* __restrict__ prefix, int64_t n_pix,
+                                                    const double* __restrict__ rin, double* __restrict__ rout,
+                                                    const int32_t* __restrict__ bbox)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_pix; e += stride) {
+        const int64_t oi = find_prefix(prefix, n_objects, e);
+        const ims_fft_object_t& o = objs[oi];
+        const int64_t local = e - prefix[oi];
+        const int iy = (int)(local / o.nfft), ix = (int)(local % o.nfft);
+        double v = rin[o.r_offset + local];
+        if (v < 0.0) v = 0.0;
+        const int px = o.x0 + ix, py = o.y0 + iy;
+        const bool in_stamp = !(px < o.stamp_xmin || px > o.stamp_xmax || py < o.stamp_ymin || py > o.stamp_ymax);
+        const int r0 = bbox[4 * oi + 0], r1 = bbox[4 * oi + 1], c0 = bbox[4 * oi + 2], c1 = bbox[4 * oi + 3];
+        if (P.spikes.enabled && in_stamp && r1 >= r0) {
+            if (iy >= r0 && iy <= r1 && ix >= c0 && ix <= c1) v = 0.0;
+            double acc = 0.0;
+            for (int ry = r0; ry <= r1; ++ry)
+                for (int rx = c0; rx <= c1; ++rx) {
+                    const int a = iy - ry, b = ix - rx;
+                    if (a < -P.spikes.cutoff || a > P.spikes.cutoff || b < -P.spikes.cutoff || b > P.spikes.cutoff) continue;
+                    double src = rin[o.r_offset + (int64_t)ry * o.nfft + rx];
+                    if (src < 0.0) src = 0.0;
+                    acc = acc + spike_stencil(P.spikes, a, b) / P.spikes.norm * src;
+                }
+            v = v + acc;
+        }
+        rout[o.r_offset + local] = v;
+    }
+}
+
 // clip, Poisson noise, stamp -> CCD add (stamp.py:519-524); realized flux = noise-free sum inside the stamp
 __global__ __launch_bounds__(256) void k_fft_finish(const ims_fft_params_t P, const ims_fft_object_t* __restrict__ objs,
                                                     int64_t n_objects, const int64_t* __restrict__ prefix, int64_t n_pix,
@@ -984,6 +1038,29 @@ int ims_fft_kspace_fill(const ims_fft_params_t* params, const ims_fft_object_t* 
     if (n_objects <= 0 || n_elems <= 0) return IMS_OK;
     hipLaunchKernelGGL(k_fft_kspace_fill, dim3(grid_for_pool(n_elems)), dim3(256), 0, (hipStream_t)stream, *params, objects_dev,
                        n_objects, elem_prefix_dev, n_elems, kbuf);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+__global__ void k_fill_bbox(int32_t* bbox, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { bbox[4 * i + 0] = 0x7fffffff; bbox[4 * i + 1] = -1; bbox[4 * i + 2] = 0x7fffffff; bbox[4 * i + 3] = -1; }
+}
+
+int ims_fft_spikes(const ims_fft_params_t* params, const ims_fft_object_t* objects_dev, int64_t n_objects,
+                   const int64_t* pix_prefix_dev, int64_t n_pix, const double* rbuf_in, double* rbuf_out,
+                   int32_t* bbox_dev, void* stream)
+{
+    if (!params || !objects_dev || !pix_prefix_dev || !rbuf_in || !rbuf_out || !bbox_dev) return set_err(IMS_ERR_ARG, "NULL argument");
+    if (n_objects <= 0 || n_pix <= 0) return IMS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_fill_bbox, dim3((unsigned)((n_objects + 255) / 256)), dim3(256), 0, st, bbox_dev, n_objects);
+    if (params->spikes.enabled)
+        hipLaunchKernelGGL(k_fft_bbox, dim3(grid_for_pool(n_pix)), dim3(256), 0, st, *params, objects_dev, n_objects,
+                           pix_prefix_dev, n_pix, rbuf_in, bbox_dev);
+    hipLaunchKernelGGL(k_fft_spikes, dim3(grid_for_pool(n_pix)), dim3(256), 0, st, *params, objects_dev, n_objects,
+                       pix_prefix_dev, n_pix, rbuf_in, rbuf_out, (const int32_t*)bbox_dev);
     HIP_TRY(hipGetLastError());
     return IMS_OK;
 }

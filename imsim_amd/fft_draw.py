@@ -78,6 +78,19 @@ def build_fft_objects(objects, fft_flux, prof_ktable, pixel_scale=0.2):
     return out, order
 
 
+def set_spikes(P, diffraction_fft, wavelength):
+    """Fill the spikes block of an FftParams from a DiffractionFFT config (None = disabled)."""
+    from . import diffraction_fft as dfft
+    if diffraction_fft is None or not diffraction_fft.enabled:
+        P.spikes.enabled = 0
+        return None
+    k = diffraction_fft.constants(wavelength)
+    S = P.spikes
+    S.enabled, S.cutoff, S.threshold = 1, k.cutoff, float(diffraction_fft.brightness_threshold)
+    S.cos0, S.sin0, S.a_lo, S.d_alpha, S.scale, S.r0, S.norm = k.cos0, k.sin0, k.a_lo, k.d_alpha, k.scale, dfft.SPIKE_R0, k.norm
+    return k
+
+
 def fft_params(scene, kpsf, ktables, q_step, seed, add_noise=True, mem_put=None):
     P = FftParams()
     P.seed = int(seed)
@@ -97,7 +110,7 @@ def fft_params(scene, kpsf, ktables, q_step, seed, add_noise=True, mem_put=None)
 class FftDrawer:
     """Batched FFT rendering into a Renderer's CCD image."""
 
-    def __init__(self, renderer, kpsf, sersic_indices=(1.0, 4.0), add_noise=True):
+    def __init__(self, renderer, kpsf, sersic_indices=(1.0, 4.0), add_noise=True, diffraction_fft=None, wavelength=622.2):
         self.r = renderer
         self.torch = renderer.torch
         tabs = [tables.sersic_ktable(n) for n in sersic_indices]
@@ -105,6 +118,7 @@ class FftDrawer:
         self.P, self._keep = fft_params(renderer.scene, kpsf, np.stack([t[1] for t in tabs]), self.q_step,
                                         renderer.scene.seed, add_noise, lambda a: renderer.mem.put(a, np.float64))
         self.P.image = renderer.image.data_ptr()
+        set_spikes(self.P, diffraction_fft, wavelength)
 
     def draw(self, fft_objects, realized=None):
         """fft_objects: FFT_OBJECT_DTYPE rows sorted by nfft (build_fft_objects).  `realized`:
@@ -134,7 +148,14 @@ class FftDrawer:
             spec = kbuf[int(kpre[a]):int(kpre[b])].view(b - a, int(size), nh)
             rbuf[int(rpre[a]):int(rpre[b])].view(b - a, int(size), int(size)).copy_(
                 torch.fft.irfft2(spec, s=(int(size), int(size)), norm="backward"))
+        final = rbuf
+        if P.spikes.enabled:
+            # DiffractionFFT.apply between the clip and the noise (stamp.py:519-522)
+            final = torch.empty_like(rbuf)
+            bbox = torch.empty(4 * n, dtype=torch.int32, device=r.device)
+            _abi.check(r.lib.ims_fft_spikes(C.byref(P), obj_t.data_ptr(), n, rpre_t.data_ptr(), int(rpre[-1]),
+                                            rbuf.data_ptr(), final.data_ptr(), bbox.data_ptr(), st), "ims_fft_spikes")
         _abi.check(r.lib.ims_fft_finish(C.byref(P), obj_t.data_ptr(), n, rpre_t.data_ptr(), int(rpre[-1]),
-                                        rbuf.data_ptr(), st), "ims_fft_finish")
-        self._last = (kbuf, rbuf, obj_t, kpre_t, rpre_t)
+                                        final.data_ptr(), st), "ims_fft_finish")
+        self._last = (kbuf, rbuf, final, obj_t, kpre_t, rpre_t)
         return kbuf, rbuf

@@ -354,6 +354,21 @@ typedef struct ims_fft_object {
     int32_t pad[2];
 } ims_fft_object_t;
 
+/* Diffraction spikes of FFT-drawn objects (stamp.diffraction_fft, imsim/stamp.py:36-68, :520-521;
+ * imsim/diffraction_fft.py:78-208): the bounding box of the pixels above `threshold` is convolved
+ * with an analytic Lorentzian-cross stencil. */
+typedef struct ims_spikes {
+    int32_t enabled;
+    int32_t cutoff;          /* spike_length_cutoff [pixels] */
+    double  threshold;       /* brightness_threshold */
+    double  cos0, sin0;      /* cos / sin of (alpha - d_alpha/2), alpha = pi/4 - rotTelPos */
+    double  a_lo;            /* alpha - d_alpha */
+    double  d_alpha;         /* field rotation over the exposure */
+    double  scale;           /* 577.6 nm / wavelength */
+    double  r0;              /* Lorentzian scale R_0 */
+    double  norm;            /* sum of the stencil over (2 cutoff + 1)^2 offsets (host-computed) */
+} ims_spikes_t;
+
 typedef struct ims_fft_params {
     uint64_t seed;
     double   pixel_scale;            /* arcsec / pixel */
@@ -364,11 +379,18 @@ typedef struct ims_fft_params {
     float*   image;                  /* CCD image, as in ims_render_params_t */
     int32_t  nx, ny, xmin, ymin;
     double*  realized_flux;          /* [n_objects] or NULL */
+    ims_spikes_t spikes;
 } ims_fft_params_t;
 
 /* elem_prefix[n_objects+1] (device): prefix sum of nfft*(nfft/2+1); kbuf: interleaved (re, im) doubles */
 int  ims_fft_kspace_fill(const ims_fft_params_t* params, const ims_fft_object_t* objects_dev, int64_t n_objects,
                          const int64_t* elem_prefix_dev, int64_t n_elems, double* kbuf, void* stream);
+/* Optional spike step between the inverse transform and ims_fft_finish: clip rbuf_in, find each object's
+ * saturated bounding box (bbox_dev: int32 [n_objects][4] scratch = rowmin,rowmax,colmin,colmax), write
+ * the spiked image to rbuf_out.  No-op copy when params->spikes.enabled == 0. */
+int  ims_fft_spikes(const ims_fft_params_t* params, const ims_fft_object_t* objects_dev, int64_t n_objects,
+                    const int64_t* pix_prefix_dev, int64_t n_pix, const double* rbuf_in, double* rbuf_out,
+                    int32_t* bbox_dev, void* stream);
 /* pix_prefix[n_objects+1] (device): prefix sum of nfft*nfft; rbuf: the inverse-transformed images */
 int  ims_fft_finish(const ims_fft_params_t* params, const ims_fft_object_t* objects_dev, int64_t n_objects,
                     const int64_t* pix_prefix_dev, int64_t n_pix, const double* rbuf, void* stream);

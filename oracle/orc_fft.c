@@ -127,6 +127,76 @@ void orc_fft_finish(const ims_fft_params_t* P, const ims_fft_object_t* objs, int
     }
 }
 
+double orc_spike_stencil(const ims_spikes_t* k, int a, int b)
+{
+    double x = (double)a, y = (double)b;
+    double xr = k->cos0 * x + k->sin0 * y;
+    double yr = -k->sin0 * x + k->cos0 * y;
+    double m = fabs(xr) < fabs(yr) ? fabs(xr) : fabs(yr);
+    double val = 1.0 - m;
+    if (val < 0.0) val = 0.0;
+    double dth = orc_atan2(y, x) - k->a_lo;
+    dth = dth - floor(dth / ORC_PI_2) * ORC_PI_2;
+    if (dth <= k->d_alpha) val = 1.0;
+    double r = orc_sqrt(x * x + y * y);
+    double prof = 0.63661977236758134308 * (orc_atan((r + 0.5) * k->scale / k->r0) - orc_atan((r - 0.5) * k->scale / k->r0));
+    double arc = r * k->d_alpha;
+    val = val * prof / (arc > 1.0 ? arc : 1.0);
+    if (a == 0 && b == 0) val = 2.0 * val;
+    return val;
+}
+
+/* apply_diffraction_psf on every object's stamp (imsim/diffraction_fft.py:126-208), after the clip */
+void orc_fft_spikes(const ims_fft_params_t* P, const ims_fft_object_t* objs, int64_t n_objects, const double* rin, double* rout)
+{
+    const ims_spikes_t* k = &P->spikes;
+    for (int64_t oi = 0; oi < n_objects; ++oi) {
+        const ims_fft_object_t* o = &objs[oi];
+        int n = o->nfft;
+        int r0 = 0x7fffffff, r1 = -1, c0 = 0x7fffffff, c1 = -1;
+        for (int iy = 0; iy < n; ++iy)
+            for (int ix = 0; ix < n; ++ix) {
+                int px = o->x0 + ix, py = o->y0 + iy;
+                if (px < o->stamp_xmin || px > o->stamp_xmax || py < o->stamp_ymin || py > o->stamp_ymax) continue;
+                if (k->enabled && rin[o->r_offset + (int64_t)iy * n + ix] > k->threshold) {
+                    if (iy < r0) r0 = iy;
+                    if (iy > r1) r1 = iy;
+                    if (ix < c0) c0 = ix;
+                    if (ix > c1) c1 = ix;
+                }
+            }
+        for (int iy = 0; iy < n; ++iy)
+            for (int ix = 0; ix < n; ++ix) {
+                int64_t local = (int64_t)iy * n + ix;
+                double v = rin[o->r_offset + local];
+                if (v < 0.0) v = 0.0;
+                int px = o->x0 + ix, py = o->y0 + iy;
+                int in_stamp = !(px < o->stamp_xmin || px > o->stamp_xmax || py < o->stamp_ymin || py > o->stamp_ymax);
+                if (k->enabled && in_stamp && r1 >= r0) {
+                    if (iy >= r0 && iy <= r1 && ix >= c0 && ix <= c1) v = 0.0;
+                    double acc = 0.0;
+                    for (int ry = r0; ry <= r1; ++ry)
+                        for (int rx = c0; rx <= c1; ++rx) {
+                            int a = iy - ry, b = ix - rx;
+                            if (a < -k->cutoff || a > k->cutoff || b < -k->cutoff || b > k->cutoff) continue;
+                            double src = rin[o->r_offset + (int64_t)ry * n + rx];
+                            if (src < 0.0) src = 0.0;
+                            acc = acc + orc_spike_stencil(k, a, b) / k->norm * src;
+                        }
+                    v = v + acc;
+                }
+                rout[o->r_offset + local] = v;
+            }
+    }
+}
+
+void orc_test_stencil(const ims_spikes_t* k, int half, double* out)
+{
+    int w = 2 * half + 1;
+    for (int a = -half; a <= half; ++a)
+        for (int b = -half; b <= half; ++b) out[(a + half) * w + (b + half)] = orc_spike_stencil(k, a, b);
+}
+
 void orc_test_poisson(const double* mean, double* out, int64_t n, uint64_t seed, int64_t obj_id)
 {
     for (int64_t i = 0; i < n; ++i) out[i] = orc_poisson(mean[i], seed, obj_id, i);

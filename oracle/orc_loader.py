@@ -45,6 +45,8 @@ def load():
         lib.orc_fft_kspace_fill.argtypes = [C.POINTER(_abi.FftParams), C.c_void_p, C.c_int64, C.c_void_p]
         lib.orc_fft_finish.argtypes = [C.POINTER(_abi.FftParams), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.orc_test_poisson.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_int64]
+        lib.orc_fft_spikes.argtypes = [C.POINTER(_abi.FftParams), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        lib.orc_test_stencil.argtypes = [C.POINTER(_abi.Spikes), C.c_int, C.c_void_p]
         lib.orc_test_gauss.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_uint32, C.c_void_p]
         _lib = lib
     return _lib
@@ -196,7 +198,7 @@ def poisson_probe(mean, seed=1, obj_id=0):
 class OracleFft:
     """CPU counterpart of imsim_amd.fft_draw.FftDrawer (numpy.fft for the transform)."""
 
-    def __init__(self, scene, kpsf, sersic_indices=(1.0, 4.0), add_noise=True):
+    def __init__(self, scene, kpsf, sersic_indices=(1.0, 4.0), add_noise=True, diffraction_fft=None, wavelength=622.2):
         from imsim_amd import fft_draw, tables
         self.lib = load()
         self.scene = scene
@@ -210,6 +212,14 @@ class OracleFft:
         self.P, _ = fft_draw.fft_params(scene, kpsf, np.stack([t[1] for t in tabs]), float(tabs[0][0][1] - tabs[0][0][0]),
                                         scene.seed, add_noise, put)
         self.image = np.zeros((scene.ny, scene.nx), dtype=np.float64)
+        fft_draw.set_spikes(self.P, diffraction_fft, wavelength)
+
+    def spikes(self, rows, rbuf):
+        rows = np.ascontiguousarray(rows, dtype=_abi.FFT_OBJECT_DTYPE)
+        rbuf = np.ascontiguousarray(rbuf, dtype=np.float64)
+        out = np.empty_like(rbuf)
+        self.lib.orc_fft_spikes(C.byref(self.P), rows.ctypes.data, len(rows), rbuf.ctypes.data, out.ctypes.data)
+        return out
 
     def fill(self, rows):
         rows = np.ascontiguousarray(rows, dtype=_abi.FFT_OBJECT_DTYPE)

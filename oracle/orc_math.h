@@ -202,6 +202,15 @@ static inline double orc_atan(double x)
     return x < 0.0 ? -res : res;
 }
 
+static inline double orc_atan2(double y, double x)
+{
+    if (x > 0.0) return orc_atan(y / x);
+    if (x < 0.0) return y >= 0.0 ? orc_atan(y / x) + ORC_PI : orc_atan(y / x) - ORC_PI;
+    if (y > 0.0) return ORC_PI_2;
+    if (y < 0.0) return -ORC_PI_2;
+    return 0.0;
+}
+
 static inline double orc_tanh_pos(double x)   /* x >= 0 */
 {
     if (x > 20.0) return 1.0;

@@ -58,3 +58,54 @@ def test_fft_decision_follows_the_reference_rules():
     assert not fft_draw.use_fft(flux, kind, hlr, 0.8, 0.0).any()
     got = fft_draw.use_fft(flux, kind, hlr, 0.8, 2.0e5)
     assert list(got) == [False, False, False, True] or list(got) == [False, True, False, True]
+
+
+# ---------------- diffraction spikes of FFT-drawn objects ----------------
+import ctypes as C
+import os
+
+from imsim_amd import diffraction_fft as dfft
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "diffraction_fft_golden.npz")
+
+
+def test_spike_stencil_matches_reference():
+    """prepare_psf_field_rotation (imsim/diffraction_fft.py:78-123) for three (wavelength, alpha,
+    d_alpha) cases: host numpy stencil and the oracle's C stencil against the reference's output."""
+    g = np.load(GOLD)
+    lib = orc_loader.load()
+    for k in range(3):
+        w, lam, alpha, dalpha = g[f"psf{k}_args"]
+        w = int(w)
+        kc = dfft.SpikeConstants(np.cos(alpha - dalpha / 2), np.sin(alpha - dalpha / 2), alpha - dalpha, dalpha,
+                                 dfft.SPIKE_WAVELENGTH / lam, w)
+        rng = np.arange(-w, w + 1)
+        mine = dfft.stencil(rng[:, None], rng[None, :], kc)
+        np.testing.assert_allclose(mine / mine.sum(), g[f"psf{k}"], rtol=0, atol=2e-15)
+        S = _abi.Spikes(1, w, 1e5, kc.cos0, kc.sin0, kc.a_lo, kc.d_alpha, kc.scale, dfft.SPIKE_R0, 1.0)
+        out = np.empty((2 * w + 1, 2 * w + 1))
+        lib.orc_test_stencil(C.byref(S), w, out.ctypes.data)
+        np.testing.assert_allclose(out / out.sum(), g[f"psf{k}"], rtol=0, atol=2e-15)
+
+
+def test_apply_diffraction_psf_matches_reference():
+    """apply_diffraction_psf (imsim/diffraction_fft.py:126-208) on a 40x44 image with a saturated
+    core: field-rotation angle, saturated bounding box, box (x) stencil, cropping."""
+    g = np.load(GOLD)
+    lam, rot, exptime, lat, az, alt, thr, cutoff = g["apply_args"]
+    cfg = dfft.DiffractionFFT(exptime=exptime, azimuth=az, altitude=alt, rotTelPos=rot, spike_length_cutoff=cutoff,
+                              brightness_threshold=thr, latitude=lat)
+    img = g["apply_in"]
+    ny, nx = img.shape
+    from imsim_amd.engine import Scene
+    scene = Scene(nx=nx, ny=ny, seed=1)
+    orc = orc_loader.OracleFft(scene, [], add_noise=False, diffraction_fft=cfg, wavelength=lam)
+    rows = np.zeros(1, dtype=_abi.FFT_OBJECT_DTYPE)
+    n = 64
+    rows["nfft"], rows["x0"], rows["y0"] = n, 1, 1
+    rows["stamp_xmin"], rows["stamp_xmax"], rows["stamp_ymin"], rows["stamp_ymax"] = 1, nx, 1, ny
+    grid = np.zeros((n, n))
+    grid[:ny, :nx] = img
+    out = orc.spikes(rows, grid.ravel()).reshape(n, n)[:ny, :nx]
+    np.testing.assert_allclose(out, g["apply_out"], rtol=1e-12, atol=1e-9)
+    assert abs(out.sum() / img.sum() - 1) < 0.05      # flux is moved into the spikes, not created

@@ -323,3 +323,27 @@ def test_fft_and_photon_shooting_agree(torch_cuda):
         assert abs(fa / fb - 1) < 0.01
         assert abs(xa - xb) < 0.02 and abs(ya - yb) < 0.02
         assert abs(ra / rb - 1) < 0.10
+
+
+def test_fft_diffraction_spikes_are_bit_exact(torch_cuda):
+    """stamp.diffraction_fft: saturated bounding box + analytic Lorentzian-cross stencil on the GPU
+    equals the oracle (which is pinned to the reference's apply_diffraction_psf by golden vectors)."""
+    import math
+    from imsim_amd import fft_draw, diffraction_fft as dfft
+    from imsim_amd.engine import Renderer
+    from oracle import orc_loader
+    scene, rows, kpsf = _fft_case()
+    rows = rows.copy()
+    rows["flux"] *= 20.0                                   # peaks well above the 1e5 threshold
+    cfg = dfft.DiffractionFFT(exptime=30.0, azimuth=math.radians(114.39), altitude=math.radians(53.16),
+                              rotTelPos=math.radians(40.04), spike_length_cutoff=60)
+    r = Renderer(scene)
+    drawer = fft_draw.FftDrawer(r, kpsf, add_noise=False, diffraction_fft=cfg, wavelength=622.2)
+    kbuf, rbuf = drawer.draw(rows)
+    r.synchronize()
+    final = drawer._last[2].cpu().numpy()
+    orc = orc_loader.OracleFft(scene, kpsf, add_noise=False, diffraction_fft=cfg, wavelength=622.2)
+    ofinal = orc.spikes(rows, rbuf.cpu().numpy())
+    assert_bits_equal(final, ofinal, "spiked FFT images")
+    assert np.abs(final - np.clip(rbuf.cpu().numpy(), 0, None)).max() > 1.0      # spikes did something
+    np.testing.assert_allclose(final.sum(), np.clip(rbuf.cpu().numpy(), 0, None).sum(), rtol=0.05)

@@ -1,0 +1,444 @@
+"""A driver for imSim-style YAML configs restricted to the stamp-rendering hot path.
+
+imSim is a plugin pack for GalSim's config system: a YAML `type:` string selects a registered
+builder.  GalSim is not available here, so this module provides the part of that
+machinery the four imSim templates exercise for THIS path: template inheritance, dotted-key
+overrides, `$` (Python eval) and `@` (reference) values, the value types OpsimData / Degrees /
+RADec / Eval / FormattedStr / Sequence / TreeRingCenter / TreeRingFunc, and registries holding the
+same type names (LSST_Silicon, LSST_Photons, LSST_Image, LSST_PhotonPoolingImage, the PhotonOp
+names, AtmosphericPSF / KolmogorovPSF / DoubleGaussianPSF, InstCatObj, ...).  Everything outside
+the path (sky_model, checkpoint, vignetting, readout, truth files, FITS output) is accepted and
+ignored with a note in `Process(...).ignored`.
+"""
+import copy
+import math
+import os
+
+import numpy as np
+import yaml
+
+from . import _abi, atm_psf, catalog, configs, diffraction, fft_draw, instcat, lsst_image, optics as opticsmod
+from . import sensor as sensormod, tables, treerings
+from .engine import Scene, SensorSetup, make_slots
+from .lsst_image import GalSimConfigError
+
+# ---------------- registries (names only matter: they are what YAML files refer to) ----------------
+valid_stamp_types, valid_image_types, valid_photon_op_types = {}, {}, {}
+valid_psf_types, valid_input_types, valid_output_types, valid_value_types = {}, {}, {}, {}
+templates = {}
+
+
+def RegisterStampType(name, builder): valid_stamp_types[name] = builder
+def RegisterImageType(name, builder): valid_image_types[name] = builder
+def RegisterPhotonOpType(name, builder): valid_photon_op_types[name] = builder
+def RegisterObjectType(name, builder): valid_psf_types[name] = builder
+def RegisterInputType(name, builder): valid_input_types[name] = builder
+def RegisterOutputType(name, builder): valid_output_types[name] = builder
+def RegisterValueType(name, builder): valid_value_types[name] = builder
+def RegisterTemplate(name, path): templates[name] = path
+
+
+RAFTS = ["R01", "R02", "R03", "R10", "R11", "R12", "R13", "R14", "R20", "R21", "R22", "R23", "R24", "R30", "R31",
+         "R32", "R33", "R34", "R41", "R42", "R43"]
+SENSORS = ["S00", "S01", "S02", "S10", "S11", "S12", "S20", "S21", "S22"]
+ITL_RAFTS = {"R01", "R02", "R03", "R10", "R20", "R41", "R42", "R43"}
+
+
+def det_name_of(det_num):
+    """LsstCamSim detector number -> name (imsim/ccd.py:72-89; 94 = R22_S11)."""
+    return f"{RAFTS[det_num // 9]}_{SENSORS[det_num % 9]}"
+
+
+def det_type_of(det_name):
+    return "ITL" if det_name[:3] in ITL_RAFTS else "E2V"
+
+
+# ---------------- config loading ----------------
+def _set_dotted(cfg, key, value):
+    parts = key.split(".")
+    d = cfg
+    for p in parts[:-1]:
+        if p not in d or not isinstance(d[p], dict):
+            d[p] = {}
+        d = d[p]
+    d[parts[-1]] = value
+
+
+def _merge(base, over):
+    for k, v in over.items():
+        if k == "template":
+            continue
+        if "." in k:
+            _set_dotted(base, k, copy.deepcopy(v))
+        elif isinstance(v, dict) and isinstance(base.get(k), dict):
+            _merge(base[k], v)
+        else:
+            base[k] = copy.deepcopy(v)
+    return base
+
+
+def load_config(path_or_dict, template_dirs=(), overrides=None):
+    """Read a YAML file (or dict), resolve its `template:` chain (GalSim template semantics: the
+    template is the base, the file's own keys -- including dotted ones -- override it) and apply
+    command-line style overrides ("a.b.c": value)."""
+    if isinstance(path_or_dict, dict):
+        cfg = copy.deepcopy(path_or_dict)
+        here = None
+    else:
+        with open(path_or_dict) as f:
+            cfg = yaml.safe_load(f)
+        here = os.path.dirname(os.path.abspath(path_or_dict))
+    if "template" in cfg:
+        name = cfg["template"]
+        cand = [templates.get(name)] + [os.path.join(d, name + ext) for d in ([here] if here else []) + list(template_dirs)
+                                        for ext in ("", ".yaml")]
+        tpath = next((c for c in cand if c and os.path.isfile(c)), None)
+        if tpath is None:
+            raise GalSimConfigError(f"template {name} not found (searched {template_dirs})")
+        base = load_config(tpath, template_dirs)
+        cfg = _merge(base, cfg)
+    else:
+        cfg = _merge({}, cfg)
+    for k, v in (overrides or {}).items():
+        _set_dotted(cfg, k, v)
+    return cfg
+
+
+# ---------------- value evaluation ----------------
+class Evaluator:
+    def __init__(self, base):
+        self.base = base
+        self.vars = {}
+
+    def namespace(self):
+        ns = {"np": np, "math": math, "os": os}
+        ns.update(self.vars)
+        return ns
+
+    def lookup(self, path):
+        d = self.base
+        for p in path.split("."):
+            d = d[int(p)] if isinstance(d, list) else d[p]
+        return self.value(d)
+
+    def value(self, v):
+        if isinstance(v, str):
+            if v.startswith("$"):
+                return eval(v[1:], self.namespace())          # noqa: S307 -- config files are trusted input, as in GalSim
+            if v.startswith("@"):
+                return self.lookup(v[1:])
+            parts = v.split()
+            if len(parts) == 2 and parts[1] in ("degrees", "deg", "radians", "rad"):
+                x = float(parts[0])
+                return math.radians(x) if parts[1].startswith("deg") else x
+            return v
+        if isinstance(v, dict) and "type" in v:
+            t = v["type"]
+            if t in valid_value_types:
+                return valid_value_types[t](v, self)
+            return v
+        return v
+
+    def load_eval_variables(self, ev):
+        pending = dict(ev)
+        for _ in range(4):                         # variables may refer to each other
+            for k in list(pending):
+                try:
+                    self.vars[k[1:]] = self.value(pending[k])
+                    del pending[k]
+                except (NameError, KeyError):
+                    pass
+        if pending:
+            raise GalSimConfigError(f"cannot evaluate eval_variables {sorted(pending)}")
+
+
+def _opsim(v, ev):
+    data = ev.base.get("_opsim_data")
+    if data is None:
+        raise GalSimConfigError("No input opsim_data available for type OpsimData")
+    if v["field"] not in data or data[v["field"]] is None:
+        raise GalSimConfigError(f"OpsimData field {v['field']} not found")
+    return data[v["field"]]
+
+
+def _eval_type(v, ev):
+    ns = ev.namespace()
+    for k, val in v.items():
+        if k not in ("type", "str") and len(k) > 1:
+            ns[k[1:]] = ev.value(val)
+    return eval(v["str"], ns)                       # noqa: S307
+
+
+RegisterValueType("OpsimData", _opsim)
+RegisterValueType("Degrees", lambda v, ev: math.radians(float(ev.value(v["theta"]))))
+RegisterValueType("Radians", lambda v, ev: float(ev.value(v["theta"])))
+RegisterValueType("RADec", lambda v, ev: (ev.value(v["ra"]), ev.value(v["dec"])))
+RegisterValueType("Eval", _eval_type)
+RegisterValueType("FormattedStr", lambda v, ev: v["format"] % tuple(ev.value(i) for i in v["items"]))
+RegisterValueType("Sequence", lambda v, ev: int(ev.value(v.get("first", 0))))
+RegisterValueType("TreeRingCenter", lambda v, ev: ev.base["_tree_rings"].get_center(ev.value(v["det_name"])))
+RegisterValueType("TreeRingFunc", lambda v, ev: ev.base["_tree_rings"].get_func(ev.value(v["det_name"])))
+for _name in ("InstCatWorldPos", "SkyCatWorldPos", "SkyLevel", "RowData", "Random", "XY"):
+    RegisterValueType(_name, lambda v, ev: v)
+
+for _name in ("LSST_Silicon", "LSST_Photons"):
+    RegisterStampType(_name, _name)
+RegisterImageType("LSST_Image", lsst_image.LSST_ImageBuilder)
+RegisterImageType("LSST_PhotonPoolingImage", lsst_image.LSST_PhotonPoolingImageBuilder)
+RegisterOutputType("LSST_CCD", "LSST_CCD")
+for _name in ("atm_psf", "tree_rings", "instance_catalog", "opsim_data", "telescope", "sky_model", "sky_catalog", "checkpoint",
+              "vignetting", "table_row"):
+    RegisterInputType(_name, _name)
+OUT_OF_SCOPE_INPUTS = {"sky_model", "sky_catalog", "checkpoint", "vignetting", "table_row"}
+
+# photon ops: (kind, required keys, optional keys) -- the reference's _req_params/_opt_params
+PHOTON_OPS = {
+    "TimeSampler": (_abi.IMS_OP_TIME_SAMPLER, {"exptime"}, {"t0"}),
+    "PupilAnnulusSampler": (_abi.IMS_OP_PUPIL_ANNULUS_SAMPLER, {"R_outer"}, {"R_inner"}),
+    "PhotonDCR": (_abi.IMS_OP_PHOTON_DCR, {"base_wavelength"}, {"latitude", "HA", "zenith_angle", "parallactic_angle",
+                                                                  "pressure", "temperature", "H2O_pressure", "alpha", "scale_unit",
+                                                                  "obj_coord", "zenith_coord"}),
+    "RubinOptics": (_abi.IMS_OP_RUBIN_OPTICS, {"boresight", "camera", "det_name"}, {"shift_photons"}),
+    "RubinDiffraction": (_abi.IMS_OP_RUBIN_DIFFRACTION, {"altitude", "azimuth", "latitude"},
+                         {"disable_field_rotation", "stamp_center", "shift_photons"}),
+    "RubinDiffractionOptics": (_abi.IMS_OP_RUBIN_DIFFRACTION_OPTICS, {"boresight", "camera", "det_name", "altitude", "azimuth"},
+                               {"latitude", "disable_field_rotation", "shift_photons"}),
+    "FocusDepth": (_abi.IMS_OP_FOCUS_DEPTH, {"depth"}, set()),
+    "Refraction": (_abi.IMS_OP_REFRACTION, {"index_ratio"}, set()),
+    "BandpassRatio": (_abi.IMS_OP_BANDPASS_RATIO, {"target_bandpass", "initial_bandpass"}, set()),
+}
+for _name in PHOTON_OPS:
+    RegisterPhotonOpType(_name, PHOTON_OPS[_name])
+for _name in ("AtmosphericPSF", "KolmogorovPSF", "DoubleGaussianPSF", "Gaussian", "Kolmogorov", "Convolve", "InstCatObj", "SkyCatObj"):
+    RegisterObjectType(_name, _name)
+
+
+def build_photon_ops(op_cfgs, ev, base_wavelength):
+    """BuildPhotonOps: YAML list -> Scene.ops tuples, with the reference's parameter checking."""
+    ops, meta = [], {}
+    rad2as = 180.0 / math.pi * 3600.0
+    for oc in op_cfgs:
+        t = oc.get("type")
+        if t not in valid_photon_op_types:
+            raise GalSimConfigError(f"Invalid photon_op type {t}")
+        kind, req, opt = PHOTON_OPS[t]
+        for k in req:
+            if k not in oc:
+                raise GalSimConfigError(f"Attribute {k} is required for photon_op {t}")
+        for k in oc:
+            if k not in req and k not in opt and k != "type":
+                raise GalSimConfigError(f"Unexpected attribute {k} found for photon_op {t}")
+        p = {k: ev.value(v) for k, v in oc.items() if k != "type"}
+        if t == "TimeSampler":
+            ops.append((kind, 0, [float(p.get("t0", 0.0)), float(p["exptime"])]))
+        elif t == "PupilAnnulusSampler":
+            ops.append((kind, 0, [float(p["R_outer"]), float(p.get("R_inner", 0.0))]))
+        elif t == "PhotonDCR":
+            ops.append((kind, 0, [float(p["base_wavelength"]), float(p.get("pressure", 69.328)), float(p.get("temperature", 293.15)),
+                                  float(p.get("H2O_pressure", 1.067)), rad2as]))
+            meta["dcr"] = dict(latitude=p.get("latitude"), HA=p.get("HA"))
+        elif t in ("RubinOptics", "RubinDiffraction", "RubinDiffractionOptics"):
+            ops.append((kind, 0, [1.0 if p.get("shift_photons", True) else 0.0, 1.0 if p.get("disable_field_rotation", False) else 0.0]))
+            if "altitude" in p:
+                meta["pointing"] = dict(altitude=p["altitude"], azimuth=p["azimuth"], latitude=p.get("latitude", math.radians(-30.244633)))
+        elif t == "FocusDepth":
+            ops.append((kind, 0, [float(p["depth"])]))
+        elif t == "Refraction":
+            ops.append((kind, 0, [float(p["index_ratio"])]))
+        else:
+            raise GalSimConfigError(f"photon_op {t} needs tabulated bandpasses; pass ratio tables through the Python API")
+    return ops, meta
+
+
+def build_psf(psf_cfg, ev, scene_tables):
+    """psf field -> (Scene.psf list, k-space list for FFT mode, total FWHM, AtmosphericPSF or None)."""
+    items = psf_cfg["items"] if psf_cfg.get("type") == "Convolve" else [psf_cfg]
+    psf, kpsf, fw2, atm = [], [], 0.0, None
+    s = 1.0 / 2.3548200450309493
+    for it in items:
+        t = it.get("type")
+        if t not in valid_psf_types:
+            raise GalSimConfigError(f"Invalid psf type {t}")
+        if t == "Gaussian":
+            fwhm = float(ev.value(it["fwhm"])) if "fwhm" in it else float(ev.value(it["sigma"])) / s
+            psf.append((_abi.IMS_PSF_GAUSSIAN, 0, fwhm * s, 0.0, 1.0))
+            kpsf.append((_abi.IMS_KPSF_GAUSSIAN, 0, fwhm * s))
+            fw2 += fwhm ** 2
+        elif t == "KolmogorovPSF":
+            p = lsst_image.get_all_params({k: ev.value(v) for k, v in it.items() if k != "type"},
+                                          {"airmass": float, "rawSeeing": float, "band": str}, {})
+            fa, fs = catalog.kolmogorov_gaussian_fwhm(float(p["airmass"]), float(p["rawSeeing"]), p["band"])
+            psf += [(_abi.IMS_PSF_RADIAL, scene_tables["kolmogorov"], fa, 0.0, 1.0), (_abi.IMS_PSF_GAUSSIAN, 0, fs * s, 0.0, 1.0)]
+            kpsf += fft_draw.kolmogorov_gaussian_kpsf(fa, fs)
+            fw2 += fa ** 2 + fs ** 2
+        elif t == "DoubleGaussianPSF":
+            raise GalSimConfigError("DoubleGaussianPSF is a two-component mixture: not available as a photon op yet")
+        elif t == "AtmosphericPSF":
+            atm = ev.base["_atm_psf"]
+            fw2 += atm.targetFWHM ** 2
+            psf.append("ATM")
+            # FFT mode swaps PhaseScreenPSF -> VonKarman and SecondKick -> Airy (psf_utils.py:94-149); the
+            # Kolmogorov MTF of the same seeing stands in for both until the VonKarman k-table lands
+            kpsf.append((_abi.IMS_KPSF_KOLMOGOROV, 0, fft_draw.KOLMOGOROV_K0 / atm.targetFWHM))
+        else:
+            raise GalSimConfigError(f"psf type {t} is not supported on this path")
+    return psf, kpsf, math.sqrt(fw2), atm
+
+
+class ProcessResult:
+    def __init__(self):
+        self.images, self.truth, self.ignored, self.det_names = [], [], [], []
+
+
+def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=None, logger=None):
+    """galsim.config.Process restricted to this path: reads inputs, then for every requested CCD
+    builds the scene and runs the image builder on the GPU.  Returns a ProcessResult."""
+    from .engine import Renderer
+    cfg = load_config(config, template_dirs, overrides)
+    res = ProcessResult()
+    data_dir = data_dir or os.environ.get("IMSIM_DATA_DIR") or configs.DATA_DIR
+    ev = Evaluator(cfg)
+    inp = cfg.get("input", {})
+    for k in inp:
+        if k not in valid_input_types:
+            raise GalSimConfigError(f"Invalid input type {k}")
+        if k in OUT_OF_SCOPE_INPUTS:
+            res.ignored.append(f"input.{k}")
+    # opsim_data first: other inputs refer to it (atmPSF.py:374-383)
+    if "opsim_data" in inp or "instance_catalog" in inp:
+        fn = (inp.get("opsim_data") or {}).get("file_name", "@input.instance_catalog.file_name")
+        cfg["_opsim_data"] = instcat.read_header(ev.value(fn))
+    out = cfg.get("output", {})
+    if out.get("type", "LSST_CCD") not in valid_output_types:
+        raise GalSimConfigError(f"Invalid output type {out.get('type')}")
+    for k in ("readout", "truth", "photon_pooling_truth", "opd", "sag", "process_info", "dir", "file_name", "cosmic_ray_rate"):
+        if k in out:
+            res.ignored.append(f"output.{k}")
+    ev.vars["det_name"] = None
+    ev.load_eval_variables({k: v for k, v in cfg.get("eval_variables", {}).items() if k not in ("dcamera_info",)})
+    if "tree_rings" in inp:
+        fn = ev.value(inp["tree_rings"].get("file_name", "tree_ring_parameters_2026-04-02.txt"))
+        cand = [fn, os.path.join(data_dir, "tree_ring_data", fn)]
+        path = next((c for c in cand if os.path.isfile(c)), None)
+        if path is None:
+            raise OSError("TreeRing file %s not found" % fn)
+        cfg["_tree_rings"] = treerings.TreeRings(path, only_dets=inp["tree_rings"].get("only_dets"))
+    image = cfg["image"]
+    itype = image.get("type", "LSST_Image")
+    if itype not in valid_image_types:
+        raise GalSimConfigError(f"Invalid image type {itype}")
+    stamp_cfg = cfg.get("stamp", {})
+    stype = stamp_cfg.get("type", "LSST_Silicon")
+    if stype not in valid_stamp_types:
+        raise GalSimConfigError(f"Invalid stamp type {stype}")
+    det_num = out.get("det_num", {})
+    first = int(ev.value(det_num.get("first", 0))) if isinstance(det_num, dict) else int(det_num)
+    nfiles = int(ev.value(out.get("nfiles", 1)))
+    meta = cfg.get("_opsim_data", {})
+    band = meta.get("band", "r")
+    seed = int(ev.value(image.get("random_seed", meta.get("seed", 0))))
+    for det in range(first, first + nfiles):
+        det_name = det_name_of(det)
+        ev.vars["det_name"] = det_name
+        builder = valid_image_types[itype]()
+        img_cfg = {k: ev.value(v) if k in ("det_name", "nbatch", "nsubbatch", "nbatch_fft", "size", "xsize", "ysize", "nobjects") else v
+                   for k, v in image.items()}
+        if itype == "LSST_PhotonPoolingImage":
+            nx, ny = builder.setup(img_cfg, stype, det_type_of(det_name))
+        else:
+            nx, ny = builder.setup(img_cfg, det_type_of(det_name))
+        # telescope + WCS (input.telescope, image.wcs type Batoid: built by ray tracing, batoid_wcs.py:429-453)
+        tel_cfg = inp.get("telescope", {})
+        tel_file = ev.value(tel_cfg.get("file_name", "")) if tel_cfg else ""
+        tel = opticsmod.load_batoid_yaml(tel_file) if tel_file and os.path.isfile(tel_file) else opticsmod.rubin_like_telescope(band)
+        if not (tel_file and os.path.isfile(tel_file)):
+            res.ignored.append("input.telescope.file_name (batoid data not present: approximate Rubin prescription)")
+        rot_tel = math.radians(meta.get("rotTelPos") or 0.0)
+        fp = (100.0, 0.0, (nx - 1) / 2.0 + 0.5, 0.0, 100.0, (ny - 1) / 2.0 + 0.5)
+        optics = _abi.Optics()
+        opticsmod.fill_optics(optics, tel, fp, rot_tel)
+        ra0, dec0 = math.radians(meta.get("fieldRA") or 0.0), math.radians(meta.get("fieldDec") or 0.0)
+        optics.img_wcs, optics.icrf_to_field, _ = opticsmod.build_wcs_pair(
+            tel, fp, ra0, dec0, rot_sky=math.radians(meta.get("rotSkyPos") or 0.0), rot_tel_pos=rot_tel, nx=nx, ny=ny)
+        # bandpass: the real tables are external data (imsim/bandpass.py); synthetic stand-in
+        wl, thr = tables.synthetic_r_band()
+        res.ignored.append("image.bandpass (rubin_sim throughputs not present: synthetic r-band table)")
+        wl_eff = tables.effective_wavelength(wl, thr)
+        ev.vars["bandpass"] = type("BP", (), {"effective_wavelength": wl_eff})()
+        # inputs that depend on the exposure
+        if "atm_psf" in inp:
+            a = {k: ev.value(v) for k, v in inp["atm_psf"].items()}
+            lsst_image.get_all_params(a, {"airmass": float, "rawSeeing": float, "band": str, "boresight": None},
+                                      {"t0": float, "exptime": float, "kcrit": float, "screen_size": float, "screen_scale": float,
+                                       "doOpt": bool, "exponent": float, "nproc": int, "save_file": str, "_no2k": bool})
+            import torch
+            cfg["_atm_psf"] = atm_psf.AtmosphericPSF(float(a["airmass"]), float(a["rawSeeing"]), a["band"], seed=seed,
+                                                     t0=float(a.get("t0", 0.0)), exptime=float(a.get("exptime", 30.0)),
+                                                     kcrit=float(a.get("kcrit", 0.2)), screen_size=float(a.get("screen_size", 819.2)),
+                                                     screen_scale=float(a.get("screen_scale", 0.1)), exponent=float(a.get("exponent", -0.3)),
+                                                     device=torch.device(device))
+        r2, cdf = configs.standard_tables()
+        psf, kpsf, fwhm_total, atm = build_psf(cfg["psf"], ev, {"kolmogorov": 2})
+        if atm is not None:
+            sk = atm.second_kick
+            r2 = np.concatenate([r2, sk[0][None, :]])
+            cdf = np.concatenate([cdf, sk[1][None, :]])
+            k = psf.index("ATM")
+            psf[k:k + 1] = atm.psf_components(second_kick_table_id=len(r2) - 1)
+        ops, opmeta = build_photon_ops(stamp_cfg.get("photon_ops", []), ev, wl_eff)
+        if "pointing" in opmeta:
+            pt = opmeta["pointing"]
+            diffraction.fill_optics(optics, pt["latitude"], pt["azimuth"], pt["altitude"])
+        sed = tables.inverse_cdf_table(wl, thr)[None, :]
+        scene = Scene(nx=nx, ny=ny, seed=seed, psf=psf, ops=ops, radial_r2=r2, radial_cdf=cdf, sed_tables=sed, optics=optics, atm=atm)
+        sens = image.get("sensor", "")
+        nrecalc = None
+        if isinstance(sens, dict) and sens.get("type", "Silicon") == "Silicon":
+            lsst_image.get_all_params(sens, {}, {"type": str, "strength": float, "index_key": str, "treering_center": None,
+                                                 "treering_func": None, "name": str, "nrecalc": int, "diffusion_factor": float,
+                                                 "qdist": int, "transpose": bool})
+            name = sens.get("name") or sensormod.sensor_model_path(data_dir, det_type_of(det_name))
+            model = sensormod.load_silicon_model(ev.value(name), strength=float(sens.get("strength", 1.0)),
+                                                 nrecalc=int(sens.get("nrecalc", 10000)))
+            nrecalc = model.nrecalc
+            awl, al = tables.silicon_abs_length_table()
+            kw = {}
+            if "treering_func" in sens and "_tree_rings" in cfg:
+                func = ev.value(sens["treering_func"])
+                if func is not None:
+                    kw = dict(tr_table=func.f, tr_table2=func.f2, tr_dr=func.dr, tr_center=ev.value(sens["treering_center"]))
+            scene.sensor = SensorSetup(model=model, abs_wl=awl, abs_len=al, slots=make_slots([(1, 1, nx, ny)]),
+                                       scratch_cells=int(cfg.get("_bf_scratch_cells", 24_000_000)), max_slots=8192, **kw)
+            scene.track_static_delta = 1 if itype == "LSST_PhotonPoolingImage" else 0
+        # catalog
+        ic = inp.get("instance_catalog")
+        if ic is None:
+            raise GalSimConfigError("only input.instance_catalog object sources are supported on this path")
+        parsed = instcat.parse_objects(ev.value(ic["file_name"]))
+        cat = instcat.to_catalog(parsed, optics.img_wcs, nx, ny, float(np.trapezoid(thr, wl)), float(meta.get("exptime") or 30.0),
+                                 sort_mag=bool(ic.get("sort_mag", True)), edge_pix=int(ic.get("edge_pix", 100)))
+        phot = catalog.realize_fluxes(cat["nominal_flux"], seed)
+        renderer = Renderer(scene, device)
+
+        def make_objects(sub, ph, scene=scene):
+            objs, sizes = configs.c3b_objects(sub, ph, scene) if scene.atm is not None else configs.c3_objects(sub, ph, scene)
+            return objs, sizes
+        truth = {}
+        max_simple = float(ev.value(stamp_cfg.get("max_flux_simple", 100)))
+        if itype == "LSST_PhotonPoolingImage":
+            builder.build_image(renderer, cat, phot, make_objects, max_flux_simple=max_simple, seed=seed, truth=truth)
+        else:
+            dfft = None
+            if "diffraction_fft" in stamp_cfg:
+                from .diffraction_fft import DiffractionFFT
+                d = {k: ev.value(v) for k, v in stamp_cfg["diffraction_fft"].items()}
+                dfft = DiffractionFFT(**d)
+            builder.build_image(renderer, cat, phot, make_objects,
+                                fft_sb_thresh=float(ev.value(stamp_cfg.get("fft_sb_thresh", 0.0))), max_flux_simple=max_simple,
+                                draw_method=ev.value(stamp_cfg.get("draw_method", "auto")), kpsf=kpsf, fwhm_total=fwhm_total,
+                                diffraction_fft=dfft, wavelength=wl_eff, nrecalc=nrecalc, truth=truth)
+        renderer.synchronize()
+        res.images.append(renderer.image_numpy())
+        res.truth.append(truth)
+        res.det_names.append(det_name)
+    return res

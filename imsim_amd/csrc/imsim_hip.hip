@@ -116,7 +116,7 @@ __device__ __forceinline__ void tile_begin(float* tile, ChargeTile& ct, const im
     __syncthreads();
 }
 
-__device__ __forceinline__ void deposit_global(const ims_render_params_t& P, const ChargeTile& ct, int ix, int iy, float flux)
+__device__ __forceinline__ void deposit_global(const ims_render_params_t& P, const ChargeTile& ct, int ix, int iy, double flux)
 {
     const int px = ix - P.xmin, py = iy - P.ymin;
     if (px >= 0 && px < P.nx && py >= 0 && py < P.ny) unsafeAtomicAdd(P.image + ((int64_t)py * P.nx + px), flux);
@@ -132,7 +132,7 @@ __device__ __forceinline__ void tile_deposit(float* tile, const ChargeTile& ct, 
 {
     const int tx = ix - ct.x0, ty = iy - ct.y0;
     if (tx >= 0 && tx < CT && ty >= 0 && ty < CT) atomicAdd(&tile[ty * CT + tx], flux);
-    else deposit_global(P, ct, ix, iy, flux);
+    else deposit_global(P, ct, ix, iy, (double)flux);
 }
 
 __device__ __forceinline__ void tile_flush(float* tile, const ChargeTile& ct, const ims_render_params_t& P)
@@ -140,7 +140,7 @@ __device__ __forceinline__ void tile_flush(float* tile, const ChargeTile& ct, co
     __syncthreads();
     for (int e = threadIdx.x; e < CT * CT; e += 256) {
         const float v = tile[e];
-        if (v != 0.0f) deposit_global(P, ct, ct.x0 + e % CT, ct.y0 + e / CT, v);
+        if (v != 0.0f) deposit_global(P, ct, ct.x0 + e % CT, ct.y0 + e / CT, (double)v);
     }
 }
 
@@ -265,12 +265,12 @@ __global__ __launch_bounds__(256) void k_accumulate(const ims_render_params_t P,
             const ims_bf_slot_t bs = P.sensor->bf_slots[o.bf_state];
             const int di = ix - bs.xmin, dj = iy - bs.ymin;
             if (di >= 0 && di < bs.nx && dj >= 0 && dj < bs.ny)
-                unsafeAtomicAdd(P.sensor->bf_delta + (bs.offset + (int64_t)dj * (bs.nx + 1) + di), (float)ph.flux);
+                unsafeAtomicAdd(P.sensor->bf_delta + (bs.offset + (int64_t)dj * (bs.nx + 1) + di), ph.flux);
         }
         const int px = ix - P.xmin, py = iy - P.ymin;
         if (px < 0 || px >= P.nx || py < 0 || py >= P.ny) continue;
         const int64_t pidx = (int64_t)py * P.nx + px;
-        unsafeAtomicAdd(P.image + pidx, (float)ph.flux);
+        unsafeAtomicAdd(P.image + pidx, ph.flux);
         if (pixel_index_out) pixel_index_out[i] = (int32_t)pidx;
     }
 }
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void k_init_boundaries(const ims_sensor_t* __r
         if (rr > 0.0 && sh != 0.0) { px = ex + sh * tx / rr; py = ey + sh * ty / rr; }
         pts[2 * n] = px; pts[2 * n + 1] = py;
     }
-    s.bf_delta[sl.offset + r.c] = 0.0f;
+    s.bf_delta[sl.offset + r.c] = 0.0;
 }
 
 __global__ __launch_bounds__(256) void k_refresh_bounds(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
@@ -425,7 +425,7 @@ __device__ __forceinline__ int owned_to_vertex(int nV, int n)
 }
 
 // Silicon::updatePixelDistortions.  One 16x16 workgroup per tile of owner cells of one slot: the
-// delta-charge halo tile ((16+2q+1)^2 floats) is staged in LDS once, then every thread gathers its
+// delta-charge halo tile ((16+2q+1)^2 doubles) is staged in LDS once, then every thread gathers its
 // charged neighbours from LDS in a FIXED order (so the result is bit-reproducible) and adds the
 // scaled tabulated displacements to the boundary points it owns.  A per-cell `changed` byte lets
 // k_refresh_bounds skip pixels whose polygon did not move.
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void k_update_distortions(const ims_sensor_t* 
                                                             const int64_t* __restrict__ tile_prefix,
                                                             unsigned char* __restrict__ changed)
 {
-    __shared__ float tile[UH * UH];
+    __shared__ double tile[UH * UH];
     const ims_sensor_t& s = *sp;
     // block -> (slot, tile)
     const int64_t b = blockIdx.x;
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void k_update_distortions(const ims_sensor_t* 
     for (int e = threadIdx.x; e < hw * hw; e += 256) {
         const int hx = e % hw, hy = e / hw;
         const int si = sx0 + hx, sj = sy0 + hy;
-        float v = 0.0f;
+        double v = 0.0;
         if (si >= 0 && si < sl.nx && sj >= 0 && sj < sl.ny) v = s.bf_delta[cell_index(sl, si, sj)];
         tile[hy * hw + hx] = v;
     }
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256) void k_update_distortions(const ims_sensor_t* 
         for (int di = -q; di <= q + 1; ++di) {
             const int si = i - di;
             if (si < 0 || si >= sl.nx) continue;
-            const double charge = (double)tile[(sj - sy0) * hw + (si - sx0)];
+            const double charge = tile[(sj - sy0) * hw + (si - sx0)];
             if (charge == 0.0) continue;
             any = true;
             const double w = charge / s.num_elec;
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256) void k_refresh_changed(const ims_sensor_t* __r
     if (!r.valid) return;
     const SlotView& sl = r.sl;
     const int i = r.i, j = r.j;
-    s.bf_delta[sl.offset + r.c] = 0.0f;       // the update kernel has consumed the delta charge
+    s.bf_delta[sl.offset + r.c] = 0.0;       // the update kernel has consumed the delta charge
     if (i >= sl.nx || j >= sl.ny) return;
     if (!(changed[cell_index(sl, i, j)] | changed[cell_index(sl, i + 1, j)] | changed[cell_index(sl, i, j + 1)])) return;
     const int nV = s.num_vertices, nv = 4 * nV + 4;
@@ -633,13 +633,19 @@ __global__ __launch_bounds__(256) void k_zero_delta(const ims_sensor_t* __restri
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= cell_count) return;
-    sp->bf_delta[cell_begin + t] = 0.0f;
+    sp->bf_delta[cell_begin + t] = 0.0;
 }
 
-__global__ __launch_bounds__(256) void k_image_add(float* __restrict__ dst, const float* __restrict__ src, int64_t n)
+__global__ __launch_bounds__(256) void k_image_add(double* __restrict__ dst, const double* __restrict__ src, int64_t n)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] += src[i];
+}
+
+__global__ __launch_bounds__(256) void k_image_to_float(const double* __restrict__ src, float* __restrict__ dst, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (float)src[i];
 }
 
 // ---------------- FFT branch ----------------
@@ -744,7 +750,7 @@ __global__ __launch_bounds__(256) void k_fft_finish(const ims_fft_params_t P, co
         if (P.add_noise) v = poisson(v, P.seed, o.obj_id, local);
         const int cxp = px - P.xmin, cyp = py - P.ymin;
         if (cxp < 0 || cxp >= P.nx || cyp < 0 || cyp >= P.ny || v == 0.0) continue;
-        unsafeAtomicAdd(P.image + ((int64_t)cyp * P.nx + cxp), (float)v);
+        unsafeAtomicAdd(P.image + ((int64_t)cyp * P.nx + cxp), v);
     }
 }
 
@@ -1077,11 +1083,20 @@ int ims_fft_finish(const ims_fft_params_t* params, const ims_fft_object_t* objec
     return IMS_OK;
 }
 
-int ims_image_add(float* dst, const float* src, int64_t n, void* stream)
+int ims_image_add(double* dst, const double* src, int64_t n, void* stream)
 {
     if (!dst || !src) return set_err(IMS_ERR_ARG, "dst/src is NULL");
     if (n <= 0) return IMS_OK;
     hipLaunchKernelGGL(k_image_add, dim3(grid_for_pool(n)), dim3(256), 0, (hipStream_t)stream, dst, src, n);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+int ims_image_to_float(const double* src, float* dst, int64_t n, void* stream)
+{
+    if (!dst || !src) return set_err(IMS_ERR_ARG, "dst/src is NULL");
+    if (n <= 0) return IMS_OK;
+    hipLaunchKernelGGL(k_image_to_float, dim3(grid_for_pool(n)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
     HIP_TRY(hipGetLastError());
     return IMS_OK;
 }

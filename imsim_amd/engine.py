@@ -251,7 +251,7 @@ class BoundScene:
         self._slots_buf, S.bf_slots = self.mem.put(slots_host.view(np.uint8))
         self.sensor_arrays["boundary"], S.bf_boundary = self.mem.zeros(cells * npo * 2, np.float64)
         self.sensor_arrays["bounds"], S.bf_bounds = self.mem.zeros(cells * 8, np.float64)
-        self.sensor_arrays["delta"], S.bf_delta = self.mem.zeros(cells, np.float32)
+        self.sensor_arrays["delta"], S.bf_delta = self.mem.zeros(cells, np.float64)
         # host copy whose slot table is a host pointer (sizes the launches)
         Sh = Sensor.from_buffer_copy(bytes(S))
         self._slots_host = slots_host
@@ -321,7 +321,9 @@ class Renderer:
         self.torch.cuda.set_device(self.device)
         self.scene = scene
         self.bound = BoundScene(scene, self.mem)
-        self.image = self.torch.zeros((scene.ny, scene.nx), dtype=self.torch.float32, device=self.device)
+        # f64 accumulation image (exact for integer electron counts of any size, so the result does not
+        # depend on the order of the atomics); image_numpy() rounds it to the float32 ImageF
+        self.image = self.torch.zeros((scene.ny, scene.nx), dtype=self.torch.float64, device=self.device)
         # two side streams: the sequential brighter-fatter chain of the bright objects runs at high
         # priority while the wide single-launch work fills the CUs it leaves idle
         self.s_chain = self.torch.cuda.Stream(self.device, priority=-1)
@@ -574,9 +576,9 @@ class Renderer:
         launch.pool_photons = sum(it[5] for it in plan if it[0] == "shoot_pool")
         # launches bracketed by the library's timing events: fused renders and pool shoots
         launch.n_render_launches = sum(1 for it in plan if it[0] in ("render", "shoot_pool"))
-        # algorithmic bytes of those launches: fused = fp32 image RMW (8 B/photon); pool shoot = the six
+        # algorithmic bytes of those launches: fused = f64 image RMW (16 B/photon); pool shoot = the six
         # f64 fields it writes (48 B/photon); both + one 256-B object row per object
-        launch.timed_bytes = (sum(it[3] * 8 + it[4] * 256 for it in plan if it[0] == "render")
+        launch.timed_bytes = (sum(it[3] * 16 + it[4] * 256 for it in plan if it[0] == "render")
                               + sum(it[5] * 48 + it[6] * 256 for it in plan if it[0] == "shoot_pool"))
         return launch
 
@@ -659,8 +661,15 @@ class Renderer:
                                                           stream if stream is not None else self._stream()),
                    "ims_sensor_update_distortions")
 
+    def image_float(self):
+        """float32 device tensor of the CCD image (what the reference's ImageF holds)"""
+        out = self.torch.empty((self.scene.ny, self.scene.nx), dtype=self.torch.float32, device=self.device)
+        _abi.check(self.lib.ims_image_to_float(self.image.data_ptr(), out.data_ptr(), out.numel(), self._stream()),
+                   "ims_image_to_float")
+        return out
+
     def image_numpy(self):
-        return self.image.cpu().numpy()
+        return self.image_float().cpu().numpy()
 
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)

@@ -1,0 +1,128 @@
+"""phosim instance catalogs: host-side mirror of imsim/instcat.py (InstCatalog :162-338, getObj
+:467-576) and of the header reader in imsim/opsim_data.py:158-206.
+
+This is the step immediately before the hot path: it turns catalog lines into the
+per-object rows the kernels consume.  Parsing is line-based like the reference; everything after
+the parse (cull, flux, geometry) is vectorised.
+
+Fluxes: the reference integrates each object's SED through the bandpass (SED files come from the
+external `seds_170124` library, absent here); when an SED file cannot be found the documented
+fallback is a flat-in-photons SED with the catalog normalisation at 500 nm for magnorm = 0
+(imsim/instcat.py:167-170, :395-398), i.e. flux = FLUX_DENSITY_500 * integral(T) * 10^(-0.4 magnorm)
+* pupil_area * exptime.
+"""
+import gzip
+import math
+import os
+
+import numpy as np
+
+RUBIN_AREA = math.pi * (418.0 ** 2 - 255.0 ** 2)          # cm^2 (imsim/utils.py:30)
+# 0 ABmag at 500 nm in photons / nm / s / cm^2 (InstCatalog._flux_density, instcat.py:167-170)
+FLUX_DENSITY_500 = 3.631e-20 * 2.99792458e17 / 500.0 ** 2 / (6.62607015e-27 * 2.99792458e10 / 500.0e-7)
+
+DUST_INDEX = {"point": 13, "sersic2d": 17, "knots": 17, "streak": 16}     # instcat.py:210-216
+HEADER_FLOATS = ("rightascension", "declination", "mjd", "altitude", "azimuth", "rotskypos", "rottelpos", "seeing",
+                 "vistime", "moonalt", "moonra", "moondec", "moonphase", "dist2moon", "sunalt")
+HEADER_INTS = ("filter", "nsnap", "obshistid", "seed", "seqnum")
+BANDS = "ugrizy"
+
+
+def fopen(path):
+    return gzip.open(path, "rt") if path.endswith(".gz") else open(path, "rt")
+
+
+def read_header(path):
+    """The phosim commands at the top of an instance catalog -> dict with the OpsimData field
+    names the configs use (imsim/opsim_data.py:158-206): fieldRA, fieldDec, altitude, azimuth,
+    rotTelPos, rotSkyPos, band, seed, rawSeeing, exptime, mjd, observationId."""
+    raw = {}
+    with fopen(path) as f:
+        for line in f:
+            if line.startswith("object") or line.startswith("includeobj"):
+                break
+            tok = line.split()
+            if len(tok) >= 2:
+                raw[tok[0].lower()] = tok[1]
+    out = {k: float(raw[k]) for k in HEADER_FLOATS if k in raw}
+    out.update({k: int(float(raw[k])) for k in HEADER_INTS if k in raw})
+    meta = dict(fieldRA=out.get("rightascension"), fieldDec=out.get("declination"), altitude=out.get("altitude"),
+                azimuth=out.get("azimuth"), rotTelPos=out.get("rottelpos"), rotSkyPos=out.get("rotskypos"),
+                mjd=out.get("mjd"), seed=out.get("seed"), rawSeeing=out.get("seeing"), exptime=out.get("vistime"),
+                observationId=out.get("obshistid"), snap=out.get("nsnap", 1) - 1 if "nsnap" in out else 0)
+    if "filter" in out:
+        meta["band"] = BANDS[out["filter"]]
+    if meta.get("altitude") is not None:
+        meta["airmass"] = 1.0 / math.sin(math.radians(meta["altitude"]))
+    return meta
+
+
+def parse_objects(path, max_objects=None):
+    """Parse the `object` lines (grammar: imsim/instcat.py:231-297).  Lines containing ' inf ' are
+    skipped (:233); invalid objects (magnorm >= 50, sersic/knots with a < b, knots with npoints <= 0)
+    are skipped (:276-286).  Returns a dict of arrays in file order."""
+    ids, ra, dec, mag, sed, lens, kind, a, b, pa, n_or_pts = [], [], [], [], [], [], [], [], [], [], []
+    with fopen(path) as f:
+        for line in f:
+            if " inf " in line or not line.startswith("object"):
+                continue
+            t = line.split()
+            typ = t[12].lower()
+            magnorm = float(t[4])
+            if typ == "point":
+                k, aa, bb, pp, nn = 0, 0.0, 0.0, 0.0, 0.0
+            elif typ == "sersic2d":
+                k, aa, bb, pp, nn = 1, float(t[13]), float(t[14]), float(t[15]), round(float(t[16]) * 20.0) / 20.0
+            elif typ == "knots":
+                k, aa, bb, pp, nn = 2, float(t[13]), float(t[14]), float(t[15]), float(int(t[16]))
+            elif typ == "streak":
+                k, aa, bb, pp, nn = 3, float(t[13]), float(t[14]), float(t[15]), 0.0
+            else:
+                k, aa, bb, pp, nn = 4, 0.0, 0.0, 0.0, 0.0            # FITS image objects: not supported yet
+            valid = magnorm < 50.0 and not (k in (1, 2) and aa < bb) and not (k == 2 and nn <= 0)
+            if not valid:
+                continue
+            ids.append(t[1]); ra.append(float(t[2])); dec.append(float(t[3])); mag.append(magnorm)
+            sed.append((t[5], float(t[6])))
+            lens.append((float(t[7]), float(t[8]), float(t[9])))
+            kind.append(k); a.append(aa); b.append(bb); pa.append(pp); n_or_pts.append(nn)
+            if max_objects is not None and len(ids) >= max_objects:
+                break
+    lens = np.array(lens, dtype=np.float64).reshape(-1, 3)
+    return dict(id=np.array(ids), ra=np.radians(ra), dec=np.radians(dec), magnorm=np.array(mag), sed=sed,
+                gamma1=lens[:, 0], gamma2=lens[:, 1], kappa=lens[:, 2], objtype=np.array(kind, dtype=np.int32),
+                a=np.array(a), b=np.array(b), pa=np.array(pa), n=np.array(n_or_pts))
+
+
+def to_catalog(parsed, img_wcs, xsize, ysize, bandpass_integral, exptime, pupil_area=RUBIN_AREA, edge_pix=100,
+               sort_mag=True, flip_g2=True):
+    """Cull to the CCD (+- edge_pix, instcat.py:243-259), compute nominal fluxes and the profile
+    geometry (instcat.py:498-527, :433-444, :569-573) -> the catalog dict build_object_table takes.
+    Only point and sersic2d objects reach the kernels for now; the others are dropped with a count."""
+    from . import wcs as wcsmod
+    vec = wcsmod.unit_vector(parsed["ra"], parsed["dec"]).T
+    x, y = wcsmod.tansip_vec_to_pix(img_wcs, vec)
+    on = (x >= 1 - edge_pix) & (x <= xsize + edge_pix) & (y >= 1 - edge_pix) & (y <= ysize + edge_pix)
+    supported = np.isin(parsed["objtype"], (0, 1))
+    keep = on & supported
+    idx = np.flatnonzero(keep)
+    if sort_mag:
+        idx = idx[np.argsort(parsed["magnorm"][idx], kind="stable")]       # brightest first (:328-338)
+    flux = FLUX_DENSITY_500 * bandpass_integral * np.exp(-0.9210340371976184 * parsed["magnorm"][idx]) * pupil_area * exptime
+    objtype = parsed["objtype"][idx]
+    n = parsed["n"][idx]
+    a, b = parsed["a"][idx], parsed["b"][idx]
+    hlr = np.sqrt(np.maximum(a * b, 0.0))                                   # instcat.py:517
+    q = np.where(a > 0, b / np.where(a > 0, a, 1.0), 1.0)
+    g2_sign = -1.0 if flip_g2 else 1.0
+    kappa = parsed["kappa"][idx]
+    g1 = parsed["gamma1"][idx] / (1.0 - kappa)
+    g2 = g2_sign * parsed["gamma2"][idx] / (1.0 - kappa)
+    mu = 1.0 / ((1.0 - kappa) ** 2 - (parsed["gamma1"][idx] ** 2 + parsed["gamma2"][idx] ** 2))
+    sersic_n = np.where(objtype == 1, n, 0.0)
+    cat = dict(x=x[idx], y=y[idx], nominal_flux=flux, mag=parsed["magnorm"][idx], hlr=hlr, q=q,
+               pa=parsed["pa"][idx] if flip_g2 else -parsed["pa"][idx], g1=g1, g2=g2, mu=mu,
+               kind=np.where(objtype == 0, 0, np.where(np.isclose(sersic_n, 1.0), 1, 2)).astype(np.int32),
+               sersic_n=sersic_n, obj_id=idx.astype(np.int64), object_id=parsed["id"][idx])
+    cat["n_dropped_unsupported"] = int(np.count_nonzero(on & ~supported))
+    return cat

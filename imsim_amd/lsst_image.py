@@ -1,0 +1,149 @@
+"""Image layer: LSST_ImageBuilder / LSST_PhotonPoolingImageBuilder over the GPU engine
+(imsim/lsst_image.py:15-126, :276-395; imsim/photon_pooling.py:29-174).
+
+`setup` keeps the reference's parameter surface (required det_name; optional size, xsize, ysize,
+dtype, apply_sky_gradient, apply_fringing, boresight, camera, nbatch, nsubbatch, nbatch_fft,
+nbatch_per_checkpoint with the same defaults); `build_image` is the draw loop: every object is
+classified FFT / PHOT / FAINT by the reference's rules and rendered into the CCD image.  Sky,
+noise, checkpointing and FITS output are out of scope.
+"""
+import numpy as np
+
+from . import catalog, fft_draw, photon_pooling, stamp
+from ._abi import IMS_OBJ_FAINT
+
+IMAGE_REQ = {"det_name": str}
+IMAGE_OPT = {"size": int, "xsize": int, "ysize": int, "dtype": None, "apply_sky_gradient": bool,
+             "apply_fringing": bool, "boresight": None, "camera": str, "nbatch": int, "nsubbatch": int,
+             "nbatch_fft": int, "nbatch_per_checkpoint": int}
+IMAGE_IGNORE = ["image_pos", "world_pos", "stamp_size", "stamp_xsize", "stamp_ysize", "nobjects", "type", "random_seed",
+                "bandpass", "wcs", "noise", "sky_level", "sensor", "use_flux_sky_areas", "nproc"]
+# detector bounding boxes the reference gets from lsst.obs.lsst (imsim/camera.py); E2V 4096x4004, ITL 4072x4000
+DETECTOR_SIZE = {"E2V": (4096, 4004), "ITL": (4072, 4000)}
+
+
+class GalSimConfigError(ValueError):
+    pass
+
+
+def get_all_params(config, req, opt, ignore=()):
+    """galsim.config.GetAllParams semantics: required keys must be present, unknown keys raise."""
+    out = {}
+    for k in req:
+        if k not in config:
+            raise GalSimConfigError(f"Attribute {k} is required")
+    for k, v in config.items():
+        if k in req or k in opt:
+            out[k] = v
+        elif k not in ignore and not k.startswith("_"):
+            raise GalSimConfigError(f"Unexpected attribute {k} found")
+    return out
+
+
+class LSST_ImageBuilderBase:
+    def setup(self, config, det_type="E2V"):
+        """Parse the image field (imsim/lsst_image.py:49-126).  Returns (xsize, ysize)."""
+        params = get_all_params(config, IMAGE_REQ, IMAGE_OPT, IMAGE_IGNORE)
+        size = params.get("size", 0)
+        xsize, ysize = params.get("xsize", size), params.get("ysize", size)
+        if xsize == 0 or ysize == 0:
+            xsize, ysize = DETECTOR_SIZE[det_type]
+        self.det_name = params["det_name"]
+        self.camera_name = params.get("camera", "LsstCamSim")
+        self.apply_fringing = params.get("apply_fringing", False)
+        if self.apply_fringing and "boresight" not in params:
+            raise GalSimConfigError("Boresight is missing in image config dict. This is required for fringing.")
+        self.nbatch = params.get("nbatch", 10)
+        self.nbatch_per_checkpoint = params.get("nbatch_per_checkpoint", 1)
+        self.nsubbatch = params.get("nsubbatch", 50)
+        self.nbatch_fft = params.get("nbatch_fft", 1)
+        self.nobjects = config.get("nobjects")
+        return xsize, ysize
+
+
+class LSST_ImageBuilder(LSST_ImageBuilderBase):
+    """`image.type: LSST_Image` with `stamp.type: LSST_Silicon`."""
+
+    def build_image(self, renderer, cat, phot_flux, make_objects, fft_sb_thresh=0.0, max_flux_simple=100.0,
+                    draw_method="auto", kpsf=None, fwhm_total=0.8, diffraction_fft=None, wavelength=622.2,
+                    nrecalc=None, truth=None):
+        """The draw loop (imsim/lsst_image.py:342-368 + imsim/stamp.py:411-575).
+
+        cat / phot_flux: catalog dict and Poisson-realised fluxes; make_objects(cat, phot) builds the
+        OBJECT_DTYPE rows.  truth: optional dict receiving nominal_flux / phot_flux / fft_flux /
+        realized_flux per object (the base[...] side channel, stamp.py:193-196, :304-305, :525, :573)."""
+        torch = renderer.torch
+        n_all = len(cat["x"])
+        if self.nobjects is not None:
+            n_all = min(n_all, int(self.nobjects))
+        sel = np.arange(n_all)
+        sub = {k: (v[sel] if isinstance(v, np.ndarray) and len(v) >= n_all else v) for k, v in cat.items()}
+        phot = np.asarray(phot_flux)[sel]
+        nominal = sub["nominal_flux"]
+        # mode decision (stamp.py:275-336)
+        if draw_method == "fft":
+            is_fft = np.ones(n_all, dtype=bool)
+        elif draw_method == "phot":
+            is_fft = np.zeros(n_all, dtype=bool)
+        else:
+            is_fft = fft_draw.use_fft(nominal, sub["kind"], sub["hlr"], fwhm_total, fft_sb_thresh)
+        objects, sizes = make_objects(sub, np.where(phot > 0, phot, 0))
+        keep = np.flatnonzero(phot > 0)                       # SkipThisObject for phot_flux == 0 (stamp.py:199-202)
+        fft_rows = is_fft[keep]
+        faint = nominal[keep] < max_flux_simple
+        objects["flags"] = np.where(faint, objects["flags"] | IMS_OBJ_FAINT, objects["flags"] & ~IMS_OBJ_FAINT)
+        realized = torch.zeros(len(objects), dtype=torch.float64, device=renderer.device)
+        fft_flux = np.zeros(len(objects))
+        if fft_rows.any():
+            if kpsf is None:
+                raise GalSimConfigError("FFT drawing needs the k-space PSF description")
+            fobj = objects[fft_rows]
+            fflux = nominal[keep][fft_rows]
+            tables_needed = np.where(fobj["prof_table"] >= 0, fobj["prof_table"], -1)
+            rows, order = fft_draw.build_fft_objects(fobj, fflux, tables_needed)
+            drawer = fft_draw.FftDrawer(renderer, kpsf, add_noise=True, diffraction_fft=diffraction_fft, wavelength=wavelength)
+            r_fft = torch.zeros(len(rows), dtype=torch.float64, device=renderer.device)
+            drawer.draw(rows, realized=r_fft)
+            idx = np.flatnonzero(fft_rows)[order]
+            realized.index_add_(0, torch.from_numpy(idx).to(renderer.device), r_fft)
+            fft_flux[np.flatnonzero(fft_rows)] = fflux
+        pobj_idx = np.flatnonzero(~fft_rows)
+        if len(pobj_idx):
+            r_ph = torch.zeros(len(pobj_idx), dtype=torch.float64, device=renderer.device)
+            renderer.render_lsst_image(objects[pobj_idx], nrecalc=nrecalc, realized=r_ph)
+            realized.index_add_(0, torch.from_numpy(pobj_idx).to(renderer.device), r_ph)
+        if truth is not None:
+            truth["index"] = sel[keep]
+            truth["x"], truth["y"] = sub["x"][keep], sub["y"][keep]
+            truth["nominal_flux"] = nominal[keep]
+            truth["phot_flux"] = np.where(fft_rows, 0.0, phot[keep])           # stamp.py:305
+            truth["fft_flux"] = fft_flux
+            truth["realized_flux"] = realized.cpu().numpy()
+            truth["mode"] = np.where(fft_rows, "fft", np.where(faint, "faint", "phot"))
+        return renderer.image
+
+
+class LSST_PhotonPoolingImageBuilder(LSST_ImageBuilderBase):
+    """`image.type: LSST_PhotonPoolingImage`, requires `stamp.type: LSST_Photons`."""
+
+    def setup(self, config, stamp_type, det_type="E2V"):
+        photon_pooling.check_stamp_type(stamp_type)
+        return super().setup(config, det_type)
+
+    def build_image(self, renderer, cat, phot_flux, make_objects, max_flux_simple=100.0, seed=0, truth=None):
+        n_all = len(cat["x"]) if self.nobjects is None else min(len(cat["x"]), int(self.nobjects))
+        sub = {k: (v[:n_all] if isinstance(v, np.ndarray) and len(v) >= n_all else v) for k, v in cat.items()}
+        phot = np.asarray(phot_flux)[:n_all]
+        objects, _ = make_objects(sub, phot)
+        keep = np.flatnonzero(phot > 0)
+        modes = stamp.classify(sub["nominal_flux"][keep], max_flux_simple)
+        realized = renderer.torch.zeros(len(objects), dtype=renderer.torch.float64, device=renderer.device)
+        photon_pooling.build_image(renderer, objects, modes, nbatch=self.nbatch, nsubbatch=self.nsubbatch, seed=seed,
+                                   realized=realized)
+        if truth is not None:
+            truth["index"] = keep
+            truth["x"], truth["y"] = sub["x"][keep], sub["y"][keep]
+            truth["nominal_flux"] = sub["nominal_flux"][keep]
+            truth["phot_flux"] = phot[keep]
+            truth["incident_flux"] = realized.cpu().numpy()
+        return renderer.image

@@ -124,7 +124,7 @@ def synthetic_r_band(n=361):
 
 
 def effective_wavelength(wl, thr):
-    return float(np.trapz(wl * thr, wl) / np.trapz(thr, wl))
+    return float(np.trapezoid(wl * thr, wl) / np.trapezoid(thr, wl))
 
 
 def silicon_abs_length_table(temperature=173.0, wl_min=255.0, wl_max=1450.0, step=5.0):

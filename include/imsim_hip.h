@@ -244,7 +244,7 @@ typedef struct ims_sensor {
     const ims_bf_slot_t* bf_slots;
     double* bf_boundary;         /* per owner cell of every slot: [2*num_vertices+2][2] owned boundary points (LL corner, bottom pts, LR corner, left pts) */
     double* bf_bounds;           /* per owner cell (one 64-byte line): inner xmin,xmax,ymin,ymax, outer xmin,xmax,ymin,ymax */
-    float*  bf_delta;            /* per owner cell: charge accumulated since the last recalc */
+    double* bf_delta;            /* per owner cell: charge accumulated since the last recalc (Silicon's double _delta) */
 } ims_sensor_t;
 
 /* A photon pool in device memory, SoA, the fields of galsim.PhotonArray (imsim/photon_ops.py:81). */
@@ -273,7 +273,8 @@ typedef struct ims_render_params {
     const ims_optics_t* optics;      /* device pointer or NULL */
     const ims_sensor_t* sensor;      /* device pointer (struct itself lives in device memory) or NULL = IMS_SENSOR_NONE */
     /* target image */
-    float*   image;                  /* device, row-major [ny][nx], pixel (ix,iy) at image[(iy-ymin)*nx + (ix-xmin)] */
+    double*  image;                  /* device f64 accumulation image, row-major [ny][nx], pixel (ix,iy) at
+                                      * image[(iy-ymin)*nx + (ix-xmin)]; ims_image_to_float makes the ImageF */
     int32_t  nx, ny, xmin, ymin;
     double*  realized_flux;          /* device [n_objects] or NULL: flux added per object (base['realized_flux'], stamp.py:573) */
 } ims_render_params_t;
@@ -376,7 +377,7 @@ typedef struct ims_fft_params {
     int32_t  add_noise;              /* 1: replace every pixel by a Poisson variate of its value */
     ims_kpsf_t kpsf[IMS_MAX_PSF];
     ims_lin_tables_t ktables;        /* radial k-space tables, uniform in their argument, 0 beyond the end */
-    float*   image;                  /* CCD image, as in ims_render_params_t */
+    double*  image;                  /* CCD accumulation image, as in ims_render_params_t */
     int32_t  nx, ny, xmin, ymin;
     double*  realized_flux;          /* [n_objects] or NULL */
     ims_spikes_t spikes;
@@ -419,7 +420,9 @@ int  ims_run_plan(const ims_plan_item_t* items, int64_t n_items, const ims_senso
                   const ims_sensor_t* sensor_host, unsigned char* changed_dev, void* stream_chain, void* stream_bulk);
 
 /* ---- image helpers ---- */
-int  ims_image_add(float* dst, const float* src, int64_t n, void* stream);
+int  ims_image_add(double* dst, const double* src, int64_t n, void* stream);
+/* round the f64 accumulation image to the float32 CCD image the reference hands on (galsim.ImageF) */
+int  ims_image_to_float(const double* src, float* dst, int64_t n, void* stream);
 
 /* ---- timing of the dominant kernel ----
  * After ims_enable_timing(1) every ims_shoot_accumulate / ims_shoot_ops_photons launch is bracketed by a hipEvent pair on its

@@ -34,7 +34,7 @@ void   orc_accumulate_range(const ims_render_params_t* P, const ims_photons_t* p
                             double* image, double* realized_flux, int32_t* pixel_index_out);
 
 /* drivers */
-int    orc_render_objects(const ims_render_params_t* P, int64_t nrecalc, float* image_out,
+int    orc_render_objects(const ims_render_params_t* P, int64_t nrecalc, double* image_out,
                           double* realized_flux);
 int    orc_shoot_pool(const ims_render_params_t* P, const int64_t* photon_offset, ims_photons_t* pool);
 #endif

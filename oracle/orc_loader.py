@@ -97,9 +97,14 @@ class OracleScene:
         self.scene = scene
         self.mem = HostMem()
         self.bound = BoundScene(scene, self.mem)
-        self.image = np.zeros((scene.ny, scene.nx), dtype=np.float32)
+        self.image64 = np.zeros((scene.ny, scene.nx), dtype=np.float64)      # f64 accumulation, as on the GPU
         if scene.sensor is not None:
             self.init_boundaries(0, len(scene.sensor.slots))
+
+    @property
+    def image(self):
+        """the float32 CCD image (galsim.ImageF) rounded from the f64 accumulation"""
+        return self.image64.astype(np.float32)
 
     def _objects(self, objects):
         objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
@@ -109,8 +114,8 @@ class OracleScene:
     def render(self, objects, nrecalc=0, realized=None):
         objects, prefix = self._objects(objects)
         P = self.bound.params(objects.ctypes.data, len(objects), prefix.ctypes.data, int(prefix[-1]),
-                              self.image.ctypes.data)
-        rc = self.lib.orc_render_objects(C.byref(P), int(nrecalc), self.image.ctypes.data,
+                              self.image64.ctypes.data)
+        rc = self.lib.orc_render_objects(C.byref(P), int(nrecalc), self.image64.ctypes.data,
                                          realized.ctypes.data if realized is not None else None)
         assert rc == 0
 
@@ -173,7 +178,7 @@ class OracleScene:
         self.lib.orc_accumulate_range(C.byref(P), C.byref(ph), pool.offs.ctypes.data, 0, pool.n, img.ctypes.data,
                                       realized.ctypes.data if realized is not None else None,
                                       pix.ctypes.data if pix is not None else None)
-        self.image += img.astype(np.float32)
+        self.image64 += img
         return pix[:pool.n] if pix is not None else None
 
     def init_boundaries(self, first_slot, n_slots):
@@ -183,8 +188,7 @@ class OracleScene:
         self.lib.orc_sensor_update_distortions(self.bound.sensor_dev_ptr, first_slot, n_slots)
 
     def sensor_array(self, name):
-        dt = np.float32 if name == "delta" else np.float64
-        return self.bound.sensor_arrays[name].view(dt)
+        return self.bound.sensor_arrays[name].view(np.float64)
 
 
 def poisson_probe(mean, seed=1, obj_id=0):

@@ -29,7 +29,7 @@ static void run_chunk(const ims_render_params_t* P, const ims_object_t* obj, int
     orc_photons_free(&ph);
 }
 
-int orc_render_objects(const ims_render_params_t* P, int64_t nrecalc, float* image_out, double* realized_flux)
+int orc_render_objects(const ims_render_params_t* P, int64_t nrecalc, double* image_out, double* realized_flux)
 {
     const int64_t npix = (int64_t)P->nx * P->ny;
     double* img = calloc((size_t)npix, sizeof(double));
@@ -52,7 +52,7 @@ int orc_render_objects(const ims_render_params_t* P, int64_t nrecalc, float* ima
         }
         if (realized_flux) realized_flux[oi] += realized;
     }
-    for (int64_t i = 0; i < npix; ++i) image_out[i] = (float)((double)image_out[i] + img[i]);
+    for (int64_t i = 0; i < npix; ++i) image_out[i] += img[i];
     free(img);
     return 0;
 }

@@ -122,7 +122,7 @@ void orc_sensor_init_boundaries(const ims_sensor_t* s, int first_slot, int n_slo
                     if (r > 0.0 && sh != 0.0) { px = ex + sh * tx / r; py = ey + sh * ty / r; }
                     pts[2 * n] = px; pts[2 * n + 1] = py;
                 }
-                s->bf_delta[cell_index(sl, i, j)] = 0.0f;
+                s->bf_delta[cell_index(sl, i, j)] = 0.0;
             }
         for (int j = 0; j < sl->ny; ++j)
             for (int i = 0; i < sl->nx; ++i) refresh_bounds(s, sl, i, j);
@@ -157,7 +157,7 @@ void orc_sensor_update_distortions(const ims_sensor_t* s, int first_slot, int n_
                     for (int di = -q; di <= q + 1; ++di) {
                         int si = i - di;
                         if (si < 0 || si >= sl->nx) continue;
-                        double charge = (double)s->bf_delta[cell_index(sl, si, sj)];
+                        double charge = s->bf_delta[cell_index(sl, si, sj)];
                         if (charge == 0.0) continue;
                         double w = charge / s->num_elec;
                         const double* dist = s->distortions + ((int64_t)(di + cx) * s->ny + (dj + cy)) * nv * 2;
@@ -174,7 +174,7 @@ void orc_sensor_update_distortions(const ims_sensor_t* s, int first_slot, int n_
                 }
             }
         for (int j = 0; j <= sl->ny; ++j)
-            for (int i = 0; i <= sl->nx; ++i) s->bf_delta[cell_index(sl, i, j)] = 0.0f;
+            for (int i = 0; i <= sl->nx; ++i) s->bf_delta[cell_index(sl, i, j)] = 0.0;
         for (int j = 0; j < sl->ny; ++j)
             for (int i = 0; i < sl->nx; ++i) refresh_bounds(s, sl, i, j);
     }
@@ -308,7 +308,7 @@ void orc_accumulate_range(const ims_render_params_t* P, const ims_photons_t* ph,
             if (obj->bf_state > 0 || P->track_static_delta) {
                 int di = ix - sl->xmin, dj = iy - sl->ymin;
                 if (di >= 0 && di < sl->nx && dj >= 0 && dj < sl->ny)
-                    s->bf_delta[cell_index(sl, di, dj)] += (float)flux;
+                    s->bf_delta[cell_index(sl, di, dj)] += flux;
             }
         }
         if (realized_flux) realized_flux[oi] += flux;

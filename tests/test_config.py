@@ -1,0 +1,86 @@
+"""The YAML config surface (template inheritance, dotted overrides, $/@ values, registered type
+names, parameter checking) -- no GPU needed up to the point of rendering."""
+import math
+import os
+
+import pytest
+
+from imsim_amd import config, lsst_image, photon_pooling
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DATA = os.path.join(HERE, "data")
+INSTCAT = os.path.join(HERE, "golden", "example_instcat_subset.txt")
+
+
+def load(**over):
+    o = {"input.instance_catalog.file_name": INSTCAT}
+    o.update(over)
+    return config.load_config(os.path.join(DATA, "test-config-instcat.yaml"), template_dirs=[DATA], overrides=o)
+
+
+def test_template_chain_and_dotted_overrides():
+    cfg = load(**{"image.nobjects": 5, "stamp.draw_method": "fft", "image.sensor": ""})
+    assert cfg["image"]["type"] == "LSST_Image" and cfg["image"]["nbatch"] == 100          # from the base template
+    assert cfg["input"]["instance_catalog"]["sort_mag"] is False                            # dotted key in the file
+    assert cfg["input"]["opsim_data"]["file_name"] == "@input.instance_catalog.file_name"
+    assert cfg["image"]["nobjects"] == 5 and cfg["stamp"]["draw_method"] == "fft" and cfg["image"]["sensor"] == ""
+    assert cfg["output"]["det_num"]["first"] == 94 and cfg["output"]["det_num"]["nitems"] == 189
+
+
+def test_registered_plugin_names():
+    """the names existing YAML files refer to."""
+    assert {"LSST_Silicon", "LSST_Photons"} <= set(config.valid_stamp_types)
+    assert {"LSST_Image", "LSST_PhotonPoolingImage"} <= set(config.valid_image_types)
+    assert {"RubinOptics", "RubinDiffractionOptics", "RubinDiffraction", "BandpassRatio", "TimeSampler", "PupilAnnulusSampler",
+            "PhotonDCR", "FocusDepth", "Refraction"} <= set(config.valid_photon_op_types)
+    assert {"AtmosphericPSF", "KolmogorovPSF", "DoubleGaussianPSF", "InstCatObj"} <= set(config.valid_psf_types)
+    assert {"atm_psf", "tree_rings", "instance_catalog", "opsim_data", "telescope", "checkpoint"} <= set(config.valid_input_types)
+    assert {"OpsimData", "TreeRingCenter", "TreeRingFunc", "Degrees", "Eval"} <= set(config.valid_value_types)
+    assert config.det_name_of(94) == "R22_S11" and config.det_type_of("R22_S11") == "E2V" and config.det_type_of("R01_S00") == "ITL"
+
+
+def test_value_evaluation():
+    from imsim_amd import instcat
+    cfg = load()
+    cfg["_opsim_data"] = instcat.read_header(INSTCAT)
+    ev = config.Evaluator(cfg)
+    ev.load_eval_variables(cfg["eval_variables"])
+    assert ev.vars["band"] == "r" and ev.vars["exptime"] == 30.0
+    assert abs(ev.vars["altitude"] - math.radians(53.16185928082866)) < 1e-15
+    assert abs(ev.vars["pupil_area"] - math.pi * (4.18 ** 2 - 2.55 ** 2) * 1e4) < 1e-6
+    assert ev.value("@input.instance_catalog.sort_mag") is False
+    assert ev.value("-30.24463 degrees") == math.radians(-30.24463)
+    assert ev.value({"type": "FormattedStr", "format": "eimage_%08d-%s.fits", "items": [{"type": "OpsimData", "field": "observationId"}, "$band"]}) \
+        == "eimage_00398414-r.fits"
+    with pytest.raises(config.GalSimConfigError):
+        ev.value({"type": "OpsimData", "field": "nonexistent"})
+
+
+def test_photon_op_parameter_checking():
+    ev = config.Evaluator({})
+    ev.vars.update(exptime=30.0)
+    ops, _ = config.build_photon_ops([{"type": "TimeSampler", "t0": 0.0, "exptime": "$exptime"},
+                                      {"type": "Refraction", "index_ratio": 3.9}], ev, 620.0)
+    assert ops[0][2] == [0.0, 30.0] and ops[1][2] == [3.9]
+    with pytest.raises(config.GalSimConfigError):
+        config.build_photon_ops([{"type": "RubinOptics", "camera": "LsstCamSim"}], ev, 620.0)           # missing required keys
+    with pytest.raises(config.GalSimConfigError):
+        config.build_photon_ops([{"type": "Refraction", "index_ratio": 3.9, "bogus": 1}], ev, 620.0)  # unexpected key
+    with pytest.raises(config.GalSimConfigError):
+        config.build_photon_ops([{"type": "NoSuchOp"}], ev, 620.0)
+
+
+def test_image_setup_parameter_surface():
+    b = lsst_image.LSST_ImageBuilder()
+    assert b.setup({"type": "LSST_Image", "det_name": "R22_S11"}) == (4096, 4004)
+    assert (b.nbatch, b.nsubbatch, b.nbatch_fft, b.nbatch_per_checkpoint) == (10, 50, 1, 1)          # lsst_image.py:112-120
+    assert b.setup({"det_name": "R01_S00", "xsize": 100, "ysize": 120}, "ITL") == (100, 120)
+    assert lsst_image.LSST_ImageBuilder().setup({"det_name": "R01_S00"}, "ITL") == (4072, 4000)
+    with pytest.raises(lsst_image.GalSimConfigError):
+        b.setup({"type": "LSST_Image"})                                  # det_name is required
+    with pytest.raises(lsst_image.GalSimConfigError):
+        b.setup({"det_name": "R22_S11", "apply_fringing": True})         # fringing needs boresight (:84-87)
+    with pytest.raises(lsst_image.GalSimConfigError):
+        b.setup({"det_name": "R22_S11", "no_such_key": 1})
+    with pytest.raises(photon_pooling.GalSimConfigValueError):
+        lsst_image.LSST_PhotonPoolingImageBuilder().setup({"det_name": "R22_S11"}, "LSST_Silicon")

@@ -142,7 +142,7 @@ def _c3_case(n_obj=150, n=512, flux_seed=1, scratch=2_000_000, **kw):
 
 def _sensor_arrays_gpu(r):
     out = {}
-    for name, dt in (("boundary", np.float64), ("bounds", np.float64), ("delta", np.float32)):
+    for name, dt in (("boundary", np.float64), ("bounds", np.float64), ("delta", np.float64)):
         out[name] = r.bound.sensor_arrays[name].cpu().numpy().view(dt)
     return out
 
@@ -347,3 +347,50 @@ def test_fft_diffraction_spikes_are_bit_exact(torch_cuda):
     assert_bits_equal(final, ofinal, "spiked FFT images")
     assert np.abs(final - np.clip(rbuf.cpu().numpy(), 0, None)).max() > 1.0      # spikes did something
     np.testing.assert_allclose(final.sum(), np.clip(rbuf.cpu().numpy(), 0, None).sum(), rtol=0.05)
+
+
+# ---------------------------------------------------------------------------------------------
+# YAML-driven end-to-end runs (imsim_amd.config.Process)
+# ---------------------------------------------------------------------------------------------
+def _process(**over):
+    import os
+    from imsim_amd import config
+    here = os.path.dirname(os.path.abspath(__file__))
+    o = {"input.instance_catalog.file_name": os.path.join(here, "golden", "example_instcat_subset.txt")}
+    o.update(over)
+    return config.Process(os.path.join(here, "data", "test-config-instcat.yaml"), template_dirs=[os.path.join(here, "data")],
+                          overrides=o)
+
+
+def test_config_c1_fft_no_sensor(torch_cuda):
+    """BASELINE config #1 semantics: instance catalog, image.nobjects=100, stamp.draw_method=fft,
+    image.sensor="" -- every object goes through the FFT branch."""
+    res = _process(**{"image.nobjects": 100, "stamp.draw_method": "fft", "image.sensor": "", "stamp.photon_ops": []})
+    img, truth = res.images[0], res.truth[0]
+    assert res.det_names == ["R22_S11"] and img.shape == (4004, 4096)
+    assert set(truth["mode"]) == {"fft"} and len(truth["mode"]) > 30
+    on = truth["realized_flux"] > 0.5 * truth["nominal_flux"]
+    assert on.sum() >= 0.7 * len(on)                       # objects near the CCD edge lose flux off the stamp
+    # Poisson-noised total close to the drawn flux
+    assert abs(img.sum() / truth["realized_flux"].sum() - 1) < 0.02
+    assert "input.sky_model" in res.ignored and "input.checkpoint" in res.ignored
+
+
+def test_config_phot_full_chain_and_pooling_agree(torch_cuda):
+    """The same catalog through LSST_Image/LSST_Silicon and through LSST_PhotonPoolingImage/
+    LSST_Photons: per-object fluxes agree (tests/test_image.py:162-228 style: within 4 sqrt(N))."""
+    a = _process(**{"image.nobjects": 60, "stamp.draw_method": "phot"})
+    b = _process(**{"image.nobjects": 60, "image.type": "LSST_PhotonPoolingImage", "stamp.type": "LSST_Photons",
+                    "image.nbatch": 4, "image.nsubbatch": 3})
+    ta, tb = a.truth[0], b.truth[0]
+    assert np.array_equal(ta["index"], tb["index"])
+    assert set(ta["mode"]) <= {"phot", "faint"}
+    inside = (ta["x"] > 60) & (ta["x"] < 4036) & (ta["y"] > 60) & (ta["y"] < 3944)      # photons off the CCD are lost
+    bright = (ta["phot_flux"] > 500) & inside
+    assert bright.sum() > 5
+    # realized / incident flux vs shot photons: vignetting and stamp clipping lose a few per cent
+    for t, key in ((ta, "realized_flux"), (tb, "incident_flux")):
+        frac = t[key][bright] / t["phot_flux"][bright]
+        assert np.all(frac > 0.85) and np.all(frac <= 1.0 + 1e-12)
+    sa, sb = a.images[0].sum(), b.images[0].sum()
+    assert abs(sa / sb - 1) < 0.02

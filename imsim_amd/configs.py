@@ -53,9 +53,9 @@ BENCH_CONFIGS = {
         scene=_c3_scene_bench,
         objects=None,
         make_step=lambda renderer, objects: renderer.prepared_lsst_image(objects),
-        bytes_per_photon=8,
+        bytes_per_photon=16,
         kernel="k_shoot_accumulate + k_shoot_photons<true> (photon pipeline)",
-        cpu_sample=1500,
+        cpu_sample=20000,
         cpu_scene=_c3_cpu_scene,
         cpu_step=lambda orc, sample: orc.render_lsst_image(sample),
     ),
@@ -65,7 +65,7 @@ BENCH_CONFIGS = {
         scene=scene_c2,
         objects=_c2_objects,
         make_step=lambda renderer, objects: renderer.prepared(objects),
-        bytes_per_photon=8,
+        bytes_per_photon=16,
         kernel="k_shoot_accumulate",
         cpu_sample=10000,
         cpu_scene=lambda scene: scene,
@@ -254,5 +254,5 @@ BENCH_CONFIGS["c3b"].update(
         "Kolmogorov+Gaussian PSF", "6-screen AtmosphericPSF (8192^2 von Karman screens) + second kick + Gaussian(0.3) PSF"),
     scene=_c3b_scene_bench,
     objects=lambda cat, phot, scene: c3b_objects(cat, phot, scene),
-    cpu_sample=600,
+    cpu_sample=8000,
 )

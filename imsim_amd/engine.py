@@ -597,7 +597,7 @@ class Renderer:
         launch.photons = int(objects["n_phot"].sum())
         launch.object_rows = len(objects)
         launch.n_render_launches = 1
-        launch.timed_bytes = launch.photons * 8 + launch.object_rows * 256
+        launch.timed_bytes = launch.photons * 16 + launch.object_rows * 256
         return launch
 
     # -- pooled path (LSST_PhotonPoolingImage / LSST_Photons) --

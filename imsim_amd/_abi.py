@@ -99,7 +99,7 @@ class FftParams(C.Structure):
 
 
 class Op(C.Structure):
-    _fields_ = [("kind", c_i32), ("table", c_i32), ("p", c_d * 6)]
+    _fields_ = [("kind", c_i32), ("table", c_i32), ("p", c_d * 8)]
 
 
 class Surface(C.Structure):
@@ -136,7 +136,8 @@ class Sensor(C.Structure):
                 ("abs_wl_min", c_d), ("abs_wl_step", c_d), ("tr_dr", c_d), ("tr_cx", c_d), ("tr_cy", c_d),
                 ("abs_len", c_vp), ("tr_table", c_vp), ("tr_table2", c_vp), ("distortions", c_vp), ("emptypoly", c_vp),
                 ("n_bf_slots", c_i32), ("pad2", c_i32), ("bf_slots", c_vp),
-                ("bf_boundary", c_vp), ("bf_bounds", c_vp), ("bf_delta", c_vp)]
+                ("bf_boundary", c_vp), ("bf_bounds", c_vp), ("bf_delta", c_vp),
+                ("bf_tile_charge", c_vp), ("bf_tile_changed", c_vp)]
 
 
 class Photons(C.Structure):
@@ -150,12 +151,13 @@ class RenderParams(C.Structure):
                 ("psf", PsfComponent * IMS_MAX_PSF), ("n_ops", c_i32), ("track_static_delta", c_i32),
                 ("ops", Op * IMS_MAX_OPS), ("radial", RadialTables), ("sed", LinTables), ("ratio", LinTables),
                 ("atm", c_vp), ("optics", c_vp), ("sensor", c_vp), ("image", c_vp),
-                ("nx", c_i32), ("ny", c_i32), ("xmin", c_i32), ("ymin", c_i32), ("realized_flux", c_vp)]
+                ("nx", c_i32), ("ny", c_i32), ("xmin", c_i32), ("ymin", c_i32), ("realized_flux", c_vp),
+                ("bf_tag", C.c_uint32), ("pad_tag", C.c_uint32), ("seg_object", c_vp)]
 
 
 class PlanItem(C.Structure):
     _fields_ = [("kind", c_i32), ("stream", c_i32), ("params", c_vp), ("pool", c_vp), ("aux", c_vp),
-                ("first_slot", c_i32), ("n_slots", c_i32), ("n_tiles", c_i64)]
+                ("first_slot", c_i32), ("n_slots", c_i32), ("n_tiles", c_i64), ("tag", C.c_uint32), ("pad", C.c_uint32)]
 
 
 (IMS_PLAN_RENDER, IMS_PLAN_SHOOT_POOL, IMS_PLAN_ACC_POOL, IMS_PLAN_UPDATE, IMS_PLAN_INIT, IMS_PLAN_RECORD,
@@ -168,7 +170,7 @@ STRUCTS = [Object, RadialTables, LinTables, PsfComponent, Op, Surface, TanSip, O
 EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_info", "ims_shoot_accumulate",
            "ims_shoot_photons", "ims_shoot_ops_photons", "ims_accumulate_segments", "ims_run_plan",
            "ims_fft_kspace_fill", "ims_fft_finish", "ims_fft_spikes", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
-           "ims_sensor_update_distortions", "ims_image_add", "ims_image_to_float", "ims_last_kernel_ms", "ims_enable_timing",
+           "ims_sensor_update_distortions", "ims_image_add", "ims_image_to_float", "ims_fill_derived_op", "ims_fill_derived_medium", "ims_last_kernel_ms", "ims_enable_timing",
            "ims_struct_size", "ims_test_math"]
 
 _LIB_PATH = os.environ.get("IMSIM_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libimsim_hip.so")
@@ -208,13 +210,15 @@ def load():
     lib.ims_accumulate_segments.argtypes = [C.POINTER(RenderParams), C.POINTER(Photons), c_vp, c_vp]
     lib.ims_accumulate.argtypes = [C.POINTER(RenderParams), c_vp, C.POINTER(Photons), c_vp, c_vp]
     lib.ims_sensor_init_boundaries.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_vp]
-    lib.ims_sensor_update_distortions.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]
+    lib.ims_sensor_update_distortions.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_vp, c_i64, c_vp, C.c_uint32, c_vp]
     lib.ims_image_add.argtypes = [c_vp, c_vp, c_i64, c_vp]
     lib.ims_image_to_float.argtypes = [c_vp, c_vp, c_i64, c_vp]
+    lib.ims_fill_derived_op.argtypes = [c_vp]
+    lib.ims_fill_derived_medium.argtypes = [c_i32, C.POINTER(c_d)]
     lib.ims_fft_kspace_fill.argtypes = [C.POINTER(FftParams), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]
     lib.ims_fft_finish.argtypes = [C.POINTER(FftParams), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]
     lib.ims_fft_spikes.argtypes = [C.POINTER(FftParams), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]
-    lib.ims_run_plan.argtypes = [C.POINTER(PlanItem), c_i64, c_vp, C.POINTER(Sensor), c_vp, c_vp, c_vp]
+    lib.ims_run_plan.argtypes = [C.POINTER(PlanItem), c_i64, c_vp, C.POINTER(Sensor), c_vp, C.POINTER(c_vp), c_i32]
     lib.ims_last_kernel_ms.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.ims_enable_timing.argtypes = [C.c_int]
     lib.ims_device_count.argtypes = [C.POINTER(C.c_int)]

@@ -44,6 +44,29 @@ IMS_DEV Draw draw(uint64_t seed, int64_t obj_id, int64_t photon, uint32_t slot)
     d.b = (((uint64_t)c[2] << 32) | c[3]) >> 11;
     return d;
 }
+// The photon pipeline (spec v4) consumes the raw block: four 32-bit words per (object, photon,
+// slot), each mapped to the open interval (0,1).  A photon keeps its last block in registers, so
+// consecutive consumers of one slot (two PSF components, two ops of the chain, the four sensor
+// draws) cost ONE Philox evaluation.
+struct Rng { uint32_t slot; uint32_t w[4]; };
+IMS_DEV void rng_reset(Rng& r) { r.slot = 0xFFFFFFFFu; r.w[0] = 0u; r.w[1] = 0u; r.w[2] = 0u; r.w[3] = 0u; }
+IMS_DEV void rng_block(Rng& r, uint64_t seed, int64_t obj_id, int64_t photon, uint32_t slot)
+{
+    if (r.slot == slot) return;
+    uint32_t c[4];
+    c[0] = (uint32_t)((uint64_t)photon);
+    c[1] = (uint32_t)((uint64_t)photon >> 32);
+    c[2] = slot;
+    c[3] = (uint32_t)((uint64_t)obj_id);
+    const uint32_t k0 = (uint32_t)seed;
+    const uint32_t k1 = (uint32_t)(seed >> 32) ^ (uint32_t)((uint64_t)obj_id >> 32);
+    philox4x32_10(c, k0, k1);
+    r.w[0] = c[0]; r.w[1] = c[1]; r.w[2] = c[2]; r.w[3] = c[3];
+    r.slot = slot;
+}
+// (w + 1/2) / 2^32, exact
+IMS_DEV double w01(uint32_t w) { return fma((double)w, 0x1.0p-32, 0x1.0p-33); }
+
 IMS_DEV double u01(uint64_t k) { return (double)k * 0x1.0p-53; }
 IMS_DEV double u01_open(uint64_t k) { return (double)(k + 1) * 0x1.0p-53; }
 
@@ -212,13 +235,19 @@ IMS_DEV void gauss_pair(Draw d, double& g0, double& g1)
     g0 = r * c; g1 = r * s;
 }
 
-// RNG slots
-constexpr uint32_t SLOT_WAVE_PROF = 0;
-constexpr uint32_t SLOT_PROF_ANG = 1;
-constexpr uint32_t SLOT_PSF = 2;
-constexpr uint32_t SLOT_OP = 8;
-constexpr uint32_t SLOT_PSF_TIME = 20;
-constexpr uint32_t SLOT_SENSOR_DIFF = 24;
-constexpr uint32_t SLOT_SENSOR_CONV = 25;
+IMS_DEV void gauss_words(uint32_t w0, uint32_t w1, double& g0, double& g1)
+{
+    const double r = sqrt(-2.0 * dlog(w01(w0)));
+    double s, c;
+    sincos2pi(w01(w1), s, c);
+    g0 = r * c; g1 = r * s;
+}
+
+// RNG slots and word assignment (spec v4)
+constexpr uint32_t SLOT_SHOOT = 0;        // w0 wavelength, w1 profile radius, w2 profile angle
+constexpr uint32_t SLOT_PSF = 2;          // + (component >> 1); component c owns words 2(c&1), 2(c&1)+1
+constexpr uint32_t SLOT_OP = 8;           // + (op index >> 1); op k owns words 2(k&1), 2(k&1)+1
+constexpr uint32_t SLOT_PSF_TIME = 20;    // + component: w0 arrival time drawn by a phase-screen PSF
+constexpr uint32_t SLOT_SENSOR = 24;      // w0,w1 diffusion pair, w2 conversion depth, w3 pixel-not-found coin
 
 }  // namespace ims

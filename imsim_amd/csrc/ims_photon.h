@@ -48,18 +48,17 @@ IMS_DEV double radial_r2(const ims_radial_tables_t& t, int table, double u)
 
 // ---------------- shooting ----------------
 // photon k of object `o`: wavelength + profile sample, relative to image_pos, in pixels
-IMS_DEV void shoot(const ims_render_params_t& P, const ims_object_t& o, int64_t k, Photon& ph)
+IMS_DEV void shoot(const ims_render_params_t& P, const ims_object_t& o, int64_t k, Rng& rng, Photon& ph)
 {
-    const Draw d0 = draw(P.seed, o.obj_id, k, SLOT_WAVE_PROF);
+    rng_block(rng, P.seed, o.obj_id, k, SLOT_SHOOT);
     double wl = o.sed_wave;
-    if (o.sed_table >= 0) wl = lin_lookup(P.sed, o.sed_table, u01(d0.a));
+    if (o.sed_table >= 0) wl = lin_lookup(P.sed, o.sed_table, w01(rng.w[0]));
     double pu = 0.0, pv = 0.0;
     if (o.prof_table >= 0) {
-        const double r2 = radial_r2(P.radial, o.prof_table, u01(d0.b));
+        const double r2 = radial_r2(P.radial, o.prof_table, w01(rng.w[1]));
         const double r = sqrt(r2) * o.prof_scale;
-        const Draw d1 = draw(P.seed, o.obj_id, k, SLOT_PROF_ANG);
         double s, c;
-        sincos2pi(u01(d1.a), s, c);
+        sincos2pi(w01(rng.w[2]), s, c);
         const double gu = r * c, gv = r * s;
         pu = o.jac[0] * gu + o.jac[1] * gv;
         pv = o.jac[2] * gu + o.jac[3] * gv;
@@ -96,35 +95,36 @@ IMS_DEV void screen_gradient(const ims_atmosphere_t& A, double pu, double pv, do
     gx = sx; gy = sy;
 }
 
-IMS_DEV void apply_psf(const ims_render_params_t& P, const ims_object_t& o, int comp, int64_t k, Photon& ph)
+IMS_DEV void apply_psf(const ims_render_params_t& P, const ims_object_t& o, int comp, int64_t k, Rng& rng, Photon& ph)
 {
     const ims_psf_component_t& c = P.psf[comp];
-    const Draw d = draw(P.seed, o.obj_id, k, SLOT_PSF + (uint32_t)comp);
+    rng_block(rng, P.seed, o.obj_id, k, SLOT_PSF + ((uint32_t)comp >> 1));
+    const uint32_t wa = (comp & 1) ? rng.w[2] : rng.w[0], wb = (comp & 1) ? rng.w[3] : rng.w[1];
     double scale = c.p0;
     if (c.chrom_alpha != 0.0) scale = scale * dpow(ph.wl / c.chrom_base, c.chrom_alpha);
     double ku, kv;
     if (c.kind == IMS_PSF_GAUSSIAN) {
         double g0, g1;
-        gauss_pair(d, g0, g1);
+        gauss_words(wa, wb, g0, g1);
         ku = scale * g0; kv = scale * g1;
     } else if (c.kind == IMS_PSF_SCREENS) {
         const ims_atmosphere_t& A = *P.atm;
         const double ro2 = A.aper_r_outer * A.aper_r_outer, ri2 = A.aper_r_inner * A.aper_r_inner;
-        const double r = sqrt(ri2 + u01(d.a) * (ro2 - ri2));
+        const double r = sqrt(ri2 + w01(wa) * (ro2 - ri2));
         double s, cc;
-        sincos2pi(u01(d.b), s, cc);
+        sincos2pi(w01(wb), s, cc);
         const double pu = r * cc, pv = r * s;
-        const Draw dt = draw(P.seed, o.obj_id, k, SLOT_PSF_TIME + (uint32_t)comp);
-        const double t = A.t0 + u01(dt.a) * A.exptime;
+        rng_block(rng, P.seed, o.obj_id, k, SLOT_PSF_TIME + (uint32_t)comp);
+        const double t = A.t0 + w01(rng.w[0]) * A.exptime;
         double gx, gy;
         screen_gradient(A, pu, pv, t, o.atm_tan_x, o.atm_tan_y, gx, gy);
         ku = scale * gx; kv = scale * gy;
         ph.pu = pu; ph.pv = pv; ph.t = t;
     } else {
-        const double r2 = radial_r2(P.radial, c.table, u01(d.a));
+        const double r2 = radial_r2(P.radial, c.table, w01(wa));
         const double r = sqrt(r2) * scale;
         double s, cc;
-        sincos2pi(u01(d.b), s, cc);
+        sincos2pi(w01(wb), s, cc);
         ku = r * cc; kv = r * s;
     }
     ph.x = ph.x + (o.winv[0] * ku + o.winv[1] * kv);
@@ -132,17 +132,20 @@ IMS_DEV void apply_psf(const ims_render_params_t& P, const ims_object_t& o, int 
 }
 
 // ---------------- media / air ----------------
-IMS_DEV double air_n_minus_one(double wave_nm, double p_kpa, double t_k, double h2o_kpa)
+// Air index (Filippenko 1982, as GalSim's dcr module and batoid.Air use it), spec v4: the
+// pressure/temperature and water-vapour factors are uniform and come precomputed from the host
+// (ims_air_factors), and the dispersion formula is put over ONE denominator:
+//   n-1 = air_p (64.328 + 29498.1/(146 - s2) + 255.4/(41 - s2)) - air_w (0.0624 - 0.00068 s2),  s2 = 1/w2
+IMS_DEV double air_n_minus_one(double wave_nm, double air_p, double air_w)
 {
-    const double Pm = p_kpa * 7.50061683;
-    const double T = t_k - 273.15;
-    const double W = h2o_kpa * 7.50061683;
     const double wm = wave_nm * 1.0e-3;
-    const double sig2 = 1.0 / (wm * wm);
-    double n1 = (64.328 + 29498.1 / (146.0 - sig2) + 255.4 / (41.0 - sig2)) * 1.0e-6;
-    n1 = n1 * (Pm * (1.0 + (1.049 - 0.0157 * T) * 1.0e-6 * Pm) / (720.883 * (1.0 + 0.003661 * T)));
-    n1 = n1 - (0.0624 - 0.000680 * sig2) / (1.0 + 0.003661 * T) * W * 1.0e-6;
-    return n1;
+    const double w2 = wm * wm;
+    const double d1 = fma(146.0, w2, -1.0), d2 = fma(41.0, w2, -1.0);
+    const double den = d1 * d2;
+    const double num = fma(29498.1, d2, 255.4 * d1);
+    const double disp = fma(64.328, den, w2 * num);             // dispersion * den
+    const double wat = fma(0.0624, w2, -0.000680) * den;         // water term * den * w2
+    return (air_p * (disp * w2) - air_w * wat) / (den * w2);
 }
 IMS_DEV double refraction_r0(double nm1) { return nm1 * (nm1 + 2.0) / 2.0 / (nm1 * nm1 + 2.0 * nm1 + 1.0); }
 
@@ -155,38 +158,47 @@ IMS_DEV double medium_n(int kind, const double* c, double wave_nm)
         const double n2 = 1.0 + c[0] * l2 / (l2 - c[3]) + c[1] * l2 / (l2 - c[4]) + c[2] * l2 / (l2 - c[5]);
         return sqrt(n2);
     }
-    return 1.0 + air_n_minus_one(wave_nm, c[0], c[1], c[2]);
+    return 1.0 + air_n_minus_one(wave_nm, c[3], c[4]);
 }
 
 // ---------------- TAN-SIP, trig-free ----------------
-IMS_DEV void sip_eval(const ims_tansip_t& w, double u, double v, double& F, double& G,
-                      double& Fu, double& Fv, double& Gu, double& Gv)
+// SIP polynomials over the triangle p + q <= 4 (coefficients beyond `order` are zero in the table),
+// nested Horner: inner in v for every power of u, outer in u.  14 fma per polynomial.
+IMS_DEV double sip_row(const double* a, int p, double v)
 {
-    double up[5], vp[5];
-    up[0] = 1.0; vp[0] = 1.0;
+    double r = a[p * 5 + (4 - p)];
 #pragma unroll
-    for (int k = 1; k <= 4; ++k) { up[k] = up[k - 1] * u; vp[k] = vp[k - 1] * v; }
-    F = 0.0; G = 0.0; Fu = 0.0; Fv = 0.0; Gu = 0.0; Gv = 0.0;
+    for (int q = 3 - p; q >= 0; --q) r = fma(r, v, a[p * 5 + q]);
+    return r;
+}
+IMS_DEV double sip_value(const double* a, double u, double v)
+{
+    double f = a[4 * 5 + 0];
 #pragma unroll
-    for (int p = 0; p <= 4; ++p)
+    for (int p = 3; p >= 0; --p) f = fma(f, u, sip_row(a, p, v));
+    return f;
+}
+// value and both partial derivatives by the simultaneous Horner recurrences (no coefficient scaling)
+IMS_DEV void sip_value_grad(const double* a, double u, double v, double& f, double& fu, double& fv)
+{
+    double F = a[4 * 5 + 0], Fu = 0.0, Fv = 0.0;
 #pragma unroll
-        for (int q = 0; q <= 4; ++q) {
-            if (p + q > w.order) continue;
-            const double a = w.a[p * 5 + q], b = w.b[p * 5 + q];
-            if (a == 0.0 && b == 0.0) continue;
-            const double m = up[p] * vp[q];
-            F = F + a * m; G = G + b * m;
-            if (p > 0) { const double d = (double)p * up[p - 1] * vp[q]; Fu = Fu + a * d; Gu = Gu + b * d; }
-            if (q > 0) { const double d = (double)q * up[p] * vp[q - 1]; Fv = Fv + a * d; Gv = Gv + b * d; }
-        }
+    for (int p = 3; p >= 0; --p) {
+        double r = a[p * 5 + (4 - p)], rv = 0.0;
+#pragma unroll
+        for (int q = 3 - p; q >= 0; --q) { rv = fma(rv, v, r); r = fma(r, v, a[p * 5 + q]); }
+        Fu = fma(Fu, u, F);
+        F = fma(F, u, r);
+        Fv = fma(Fv, u, rv);
+    }
+    f = F; fu = Fu; fv = Fv;
 }
 
 IMS_DEV void wcs_pix_to_vec(const ims_tansip_t& w, double x, double y, double (&p)[3])
 {
     double u = x - w.crpix[0], v = y - w.crpix[1];
     if (w.order > 0) {
-        double f, g, fu, fv, gu, gv;
-        sip_eval(w, u, v, f, g, fu, fv, gu, gv);
+        const double f = sip_value(w.a, u, v), g = sip_value(w.b, u, v);
         u = u + f; v = v + g;
     }
     const double xi = w.cd[0] * u + w.cd[1] * v;
@@ -197,6 +209,8 @@ IMS_DEV void wcs_pix_to_vec(const ims_tansip_t& w, double x, double y, double (&
     p[2] = w.rot[2] + w.rot[5] * xi + w.rot[8] * eta;
 }
 
+// direction -> pixel: Newton inversion of the SIP polynomial from the undistorted position, until
+// the step falls below 1e-10 of the position (the NEXT error is then its square) or 6 steps
 IMS_DEV void wcs_vec_to_pix(const ims_tansip_t& w, const double (&p)[3], double& x, double& y)
 {
     const double t0 = w.rot[0] * p[0] + w.rot[1] * p[1] + w.rot[2] * p[2];
@@ -210,12 +224,15 @@ IMS_DEV void wcs_vec_to_pix(const ims_tansip_t& w, const double (&p)[3], double&
     if (w.order > 0) {
         for (int it = 0; it < 6; ++it) {
             double f, g, fu, fv, gu, gv;
-            sip_eval(w, u, v, f, g, fu, fv, gu, gv);
+            sip_value_grad(w.a, u, v, f, fu, fv);
+            sip_value_grad(w.b, u, v, g, gu, gv);
             const double r0 = u + f - U, r1 = v + g - V;
-            const double j00 = 1.0 + fu, j01 = fv, j10 = gu, j11 = 1.0 + gv;
-            const double det = j00 * j11 - j01 * j10;
-            u = u - (j11 * r0 - j01 * r1) / det;
-            v = v - (j00 * r1 - j10 * r0) / det;
+            const double j00 = 1.0 + fu, j11 = 1.0 + gv;
+            const double idet = 1.0 / (j00 * j11 - fv * gu);
+            const double du = (j11 * r0 - fv * r1) * idet;
+            const double dv = (j00 * r1 - gu * r0) * idet;
+            u = u - du; v = v - dv;
+            if (fabs(du) + fabs(dv) <= 1.0e-10 * (fabs(u) + fabs(v))) break;
         }
     }
     x = u + w.crpix[0]; y = v + w.crpix[1];
@@ -339,7 +356,8 @@ IMS_DEV bool surf_hit(const ims_surface_t& S, double (&pos)[3], const double (&v
         const double q = -0.5 * (B + (B < 0.0 ? -sq : sq));
         const double lhs = fabs(pz * q + vel[2] * C) * fabs(A);
         const double rhs = fabs(pz * A + vel[2] * q) * fabs(q);
-        t = (lhs <= rhs) ? C / q : q / A;
+        const bool near_root = (lhs <= rhs);
+        t = (near_root ? C : q) / (near_root ? q : A);
     } else {
         t = -pz / vel[2];
     }
@@ -433,7 +451,7 @@ IMS_DEV int trace(const ims_optics_t& o, double (&pos)[3], double (&vel)[3], dou
 }
 
 IMS_DEV void rubin_op(const ims_render_params_t& P, const ims_op_t& op, int op_index,
-                      const ims_object_t& o, int64_t k, Photon& ph)
+                      const ims_object_t& o, int64_t k, Rng& rng, Photon& ph)
 {
     const ims_optics_t& opt = *P.optics;
     const bool do_diff = (op.kind != IMS_OP_RUBIN_OPTICS);
@@ -443,7 +461,8 @@ IMS_DEV void rubin_op(const ims_render_params_t& P, const ims_op_t& op, int op_i
     xy_to_v(opt, ph.x, ph.y, ph.wl, v);
     if (do_diff) {
         double g0, g1;
-        gauss_pair(draw(P.seed, o.obj_id, k, SLOT_OP + (uint32_t)op_index), g0, g1);
+        rng_block(rng, P.seed, o.obj_id, k, SLOT_OP + ((uint32_t)op_index >> 1));
+        gauss_words((op_index & 1) ? rng.w[2] : rng.w[0], (op_index & 1) ? rng.w[3] : rng.w[1], g0, g1);
         diffract(opt, frot, ph.pu, ph.pv, ph.t, ph.wl * 1.0e-9, g0, v);
     }
     if (!do_trace) { v_to_xy(opt, v, ph.x, ph.y); return; }
@@ -463,10 +482,11 @@ IMS_DEV void rubin_op(const ims_render_params_t& P, const ims_op_t& op, int op_i
 }
 
 // one configured photon operator (config/imsim-config.yaml:281-320)
-IMS_DEV void apply_op(const ims_render_params_t& P, int op_index, const ims_object_t& o, int64_t k, Photon& ph)
+IMS_DEV void apply_op(const ims_render_params_t& P, int op_index, const ims_object_t& o, int64_t k, Rng& rng, Photon& ph)
 {
     const ims_op_t& op = P.ops[op_index];
-    const uint32_t slot = SLOT_OP + (uint32_t)op_index;
+    const uint32_t slot = SLOT_OP + ((uint32_t)op_index >> 1);
+    const int wsel = op_index & 1;
     if (op.kind == IMS_OP_BANDPASS_RATIO) {
         ph.flux = ph.flux * lin_lookup(P.ratio, op.table, ph.wl);
         return;
@@ -474,21 +494,21 @@ IMS_DEV void apply_op(const ims_render_params_t& P, int op_index, const ims_obje
     if (o.flags & IMS_OBJ_FAINT) return;
     switch (op.kind) {
     case IMS_OP_TIME_SAMPLER: {
-        const Draw d = draw(P.seed, o.obj_id, k, slot);
-        ph.t = op.p[0] + u01(d.a) * op.p[1];
+        rng_block(rng, P.seed, o.obj_id, k, slot);
+        ph.t = op.p[0] + w01(wsel ? rng.w[2] : rng.w[0]) * op.p[1];
         break; }
     case IMS_OP_PUPIL_ANNULUS_SAMPLER: {
         const double ro2 = op.p[0] * op.p[0], ri2 = op.p[1] * op.p[1];
-        const Draw d = draw(P.seed, o.obj_id, k, slot);
-        const double r = sqrt(ri2 + u01(d.a) * (ro2 - ri2));
+        rng_block(rng, P.seed, o.obj_id, k, slot);
+        const double r = sqrt(ri2 + w01(wsel ? rng.w[2] : rng.w[0]) * (ro2 - ri2));
         double s, c;
-        sincos2pi(u01(d.b), s, c);
+        sincos2pi(w01(wsel ? rng.w[3] : rng.w[1]), s, c);
         ph.pu = r * c; ph.pv = r * s;
         break; }
     case IMS_OP_PHOTON_DCR: {
-        const double base_r0 = refraction_r0(air_n_minus_one(op.p[0], op.p[1], op.p[2], op.p[3]));
-        const double r0 = refraction_r0(air_n_minus_one(ph.wl, op.p[1], op.p[2], op.p[3]));
-        const double shift = (r0 - base_r0) * o.dcr_tanz * op.p[4];
+        // p[5], p[6]: air factors; p[7]: refraction constant at the base wavelength (ims_fill_derived_op)
+        const double r0 = refraction_r0(air_n_minus_one(ph.wl, op.p[5], op.p[6]));
+        const double shift = (r0 - op.p[7]) * o.dcr_tanz * op.p[4];
         const double du = -shift * o.dcr_sinp;
         const double dv = shift * o.dcr_cosp;
         ph.x = ph.x + (o.winv[0] * du + o.winv[1] * dv);
@@ -508,7 +528,7 @@ IMS_DEV void apply_op(const ims_render_params_t& P, int op_index, const ims_obje
     case IMS_OP_RUBIN_OPTICS:
     case IMS_OP_RUBIN_DIFFRACTION:
     case IMS_OP_RUBIN_DIFFRACTION_OPTICS:
-        rubin_op(P, op, op_index, o, k, ph);
+        rubin_op(P, op, op_index, o, k, rng, ph);
         break;
     default: break;
     }
@@ -586,7 +606,7 @@ __device__ const int YOFF[9] = {0, 0, 1, 1, 1, 0, -1, -1, -1};
 
 // Decide the landing pixel.  Returns false when the photon is lost.  has_angles: the chain
 // contains a ray-tracing op, so dxdz/dydz are meaningful.
-IMS_DEV bool land(const ims_render_params_t& P, const ims_object_t& o, int64_t k, const Photon& ph,
+IMS_DEV bool land(const ims_render_params_t& P, const ims_object_t& o, int64_t k, Rng& rng, const Photon& ph,
                   bool silicon, bool has_angles, int& ix, int& iy)
 {
     double x0 = ph.x, y0 = ph.y;
@@ -597,15 +617,15 @@ IMS_DEV bool land(const ims_render_params_t& P, const ims_object_t& o, int64_t k
     const ims_sensor_t& s = *P.sensor;
     const ims_bf_slot_t bs = s.bf_slots[o.bf_state];
     const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
-    const Draw dc = draw(P.seed, o.obj_id, k, SLOT_SENSOR_CONV);
+    rng_block(rng, P.seed, o.obj_id, k, SLOT_SENSOR);
     double g0, g1;
-    gauss_pair(draw(P.seed, o.obj_id, k, SLOT_SENSOR_DIFF), g0, g1);
+    gauss_words(rng.w[0], rng.w[1], g0, g1);
     const double f = (ph.wl - s.abs_wl_min) / s.abs_wl_step;
     double abs_len;
     if (!(f > 0.0)) abs_len = s.abs_len[0];
     else if (f >= (double)(s.n_abs - 1)) abs_len = s.abs_len[s.n_abs - 1];
     else { const int t = (int)f; const double a = f - (double)t; const double v0 = s.abs_len[t]; abs_len = v0 + a * (s.abs_len[t + 1] - v0); }
-    const double si_length = -abs_len * dlog(1.0 - u01(dc.a));
+    const double si_length = -abs_len * dlog(w01(rng.w[2]));
     double dz = si_length;
     if (has_angles) {
         dz = si_length / sqrt(1.0 + ph.dxdz * ph.dxdz + ph.dydz * ph.dydz);
@@ -645,7 +665,7 @@ IMS_DEV bool land(const ims_render_params_t& P, const ims_object_t& o, int64_t k
         }
     }
     if (!found) {
-        const int n = (u01(dc.b) > 0.5) ? 0 : step;
+        const int n = (rng.w[3] & 0x80000000u) ? 0 : step;
         ix = ix + XOFF[n]; iy = iy + YOFF[n];
     }
     // the caller deposits the charge (CCD image and, for tracked regions, the delta-charge image)

@@ -81,10 +81,11 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // run one photon through shoot -> psf -> shift -> ops
-__device__ __forceinline__ void make_photon(const ims_render_params_t& P, const ims_object_t& o, int64_t k, Photon& ph)
+__device__ __forceinline__ void make_photon(const ims_render_params_t& P, const ims_object_t& o, int64_t k, Rng& rng, Photon& ph)
 {
-    shoot(P, o, k, ph);
-    for (int c = 0; c < P.n_psf; ++c) apply_psf(P, o, c, k, ph);
+    rng_reset(rng);
+    shoot(P, o, k, rng, ph);
+    for (int c = 0; c < P.n_psf; ++c) apply_psf(P, o, c, k, rng, ph);
     ph.x = o.x0 + ph.x;
     ph.y = o.y0 + ph.y;
 }
@@ -116,14 +117,25 @@ __device__ __forceinline__ void tile_begin(float* tile, ChargeTile& ct, const im
     __syncthreads();
 }
 
+// bf_tag != 0: remember which 16x16 tile of the region received charge (byte at the tile's first cell)
+__device__ __forceinline__ void mark_tile_charge(const ims_render_params_t& P, int64_t offset, int nx, int di, int dj)
+{
+    if (P.bf_tag == 0u) return;
+    unsigned char* tc = P.sensor->bf_tile_charge;
+    if (tc == nullptr) return;
+    tc[offset + (int64_t)(dj & ~15) * (nx + 1) + (di & ~15)] = (unsigned char)P.bf_tag;
+}
+
 __device__ __forceinline__ void deposit_global(const ims_render_params_t& P, const ChargeTile& ct, int ix, int iy, double flux)
 {
     const int px = ix - P.xmin, py = iy - P.ymin;
     if (px >= 0 && px < P.nx && py >= 0 && py < P.ny) unsafeAtomicAdd(P.image + ((int64_t)py * P.nx + px), flux);
     if (ct.track) {
         const int di = ix - ct.slot.xmin, dj = iy - ct.slot.ymin;
-        if (di >= 0 && di < ct.slot.nx && dj >= 0 && dj < ct.slot.ny)
+        if (di >= 0 && di < ct.slot.nx && dj >= 0 && dj < ct.slot.ny) {
             unsafeAtomicAdd(P.sensor->bf_delta + (ct.slot.offset + (int64_t)dj * (ct.slot.nx + 1) + di), flux);
+            mark_tile_charge(P, ct.slot.offset, ct.slot.nx, di, dj);
+        }
     }
 }
 
@@ -155,7 +167,7 @@ __global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_accumulate(const
     if ((b / N_XCD) >= per) return;
     const int64_t seg = xcd_segment(b, P.n_segments);
     if (seg >= P.n_segments) return;
-    const int64_t oi = find_object(P.seg_prefix, P.n_objects, seg);
+    const int64_t oi = P.seg_object ? (int64_t)P.seg_object[seg] : find_object(P.seg_prefix, P.n_objects, seg);
     const ims_object_t& o = P.objects[oi];
     const int64_t seg_in_obj = seg - P.seg_prefix[oi];
     const int64_t j0 = seg_in_obj * P.seg_size;
@@ -173,10 +185,11 @@ __global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_accumulate(const
     if (j < j1) {
         const int64_t k = o.phot_first + j;
         Photon ph;
-        make_photon(P, o, k, ph);
-        for (int q = 0; q < P.n_ops; ++q) apply_op(P, q, o, k, ph);
+        Rng rng;
+        make_photon(P, o, k, rng, ph);
+        for (int q = 0; q < P.n_ops; ++q) apply_op(P, q, o, k, rng, ph);
         int ix, iy;
-        if (ph.flux != 0.0 && land(P, o, k, ph, silicon, has_angles, ix, iy)) {
+        if (ph.flux != 0.0 && land(P, o, k, rng, ph, silicon, has_angles, ix, iy)) {
             added += ph.flux;
             tile_deposit(tile, ct, P, ix, iy, (float)ph.flux);
         }
@@ -203,15 +216,16 @@ __global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_photons(const im
     if ((b / N_XCD) >= per) return;
     const int64_t seg = xcd_segment(b, P.n_segments);
     if (seg >= P.n_segments) return;
-    const int64_t oi = find_object(P.seg_prefix, P.n_objects, seg);
+    const int64_t oi = P.seg_object ? (int64_t)P.seg_object[seg] : find_object(P.seg_prefix, P.n_objects, seg);
     const ims_object_t& o = P.objects[oi];
     const int64_t j = (seg - P.seg_prefix[oi]) * P.seg_size + threadIdx.x;
     if (j >= o.n_phot) return;
     const int64_t k = o.phot_first + j;
     Photon ph;
-    make_photon(P, o, k, ph);
+    Rng rng;
+    make_photon(P, o, k, rng, ph);
     if (WITH_OPS)
-        for (int q = 0; q < P.n_ops; ++q) apply_op(P, q, o, k, ph);
+        for (int q = 0; q < P.n_ops; ++q) apply_op(P, q, o, k, rng, ph);
     const int64_t i = photon_offset[oi] + j;
     pool.x[i] = ph.x; pool.y[i] = ph.y; pool.flux[i] = ph.flux;
     pool.dxdz[i] = ph.dxdz; pool.dydz[i] = ph.dydz; pool.wavelength[i] = ph.wl;
@@ -236,7 +250,9 @@ __global__ __launch_bounds__(256) void k_apply_ops(const ims_render_params_t P, 
         const int64_t k = o.phot_first + (i - photon_offset[oi]);
         Photon ph;
         load_photon(pool, i, ph);
-        for (int q = 0; q < P.n_ops; ++q) apply_op(P, q, o, k, ph);
+        Rng rng;
+        rng_reset(rng);
+        for (int q = 0; q < P.n_ops; ++q) apply_op(P, q, o, k, rng, ph);
         pool.x[i] = ph.x; pool.y[i] = ph.y; pool.flux[i] = ph.flux;
         pool.dxdz[i] = ph.dxdz; pool.dydz[i] = ph.dydz;
         pool.pupil_u[i] = ph.pu; pool.pupil_v[i] = ph.pv; pool.time[i] = ph.t;
@@ -259,13 +275,17 @@ __global__ __launch_bounds__(256) void k_accumulate(const ims_render_params_t P,
         load_photon(pool, i, ph);
         if (ph.flux == 0.0) continue;
         int ix, iy;
-        if (!land(P, o, k, ph, silicon, has_angles, ix, iy)) continue;
+        Rng rng;
+        rng_reset(rng);
+        if (!land(P, o, k, rng, ph, silicon, has_angles, ix, iy)) continue;
         if (P.realized_flux != nullptr) unsafeAtomicAdd(P.realized_flux + oi, ph.flux);
         if (silicon && !(o.flags & IMS_OBJ_FAINT) && (o.bf_state > 0 || P.track_static_delta)) {
             const ims_bf_slot_t bs = P.sensor->bf_slots[o.bf_state];
             const int di = ix - bs.xmin, dj = iy - bs.ymin;
-            if (di >= 0 && di < bs.nx && dj >= 0 && dj < bs.ny)
+            if (di >= 0 && di < bs.nx && dj >= 0 && dj < bs.ny) {
                 unsafeAtomicAdd(P.sensor->bf_delta + (bs.offset + (int64_t)dj * (bs.nx + 1) + di), ph.flux);
+                mark_tile_charge(P, bs.offset, bs.nx, di, dj);
+            }
         }
         const int px = ix - P.xmin, py = iy - P.ymin;
         if (px < 0 || px >= P.nx || py < 0 || py >= P.ny) continue;
@@ -285,7 +305,7 @@ __global__ __launch_bounds__(256) void k_accumulate_segments(const ims_render_pa
     if ((b / N_XCD) >= per) return;
     const int64_t seg = xcd_segment(b, P.n_segments);
     if (seg >= P.n_segments) return;
-    const int64_t oi = find_object(P.seg_prefix, P.n_objects, seg);
+    const int64_t oi = P.seg_object ? (int64_t)P.seg_object[seg] : find_object(P.seg_prefix, P.n_objects, seg);
     const ims_object_t& o = P.objects[oi];
     const int64_t j = (seg - P.seg_prefix[oi]) * P.seg_size + threadIdx.x;
     const bool silicon = (P.sensor != nullptr) && (P.sensor->kind == IMS_SENSOR_SILICON);
@@ -300,7 +320,9 @@ __global__ __launch_bounds__(256) void k_accumulate_segments(const ims_render_pa
         ph.x = pool.x[i]; ph.y = pool.y[i]; ph.flux = pool.flux[i]; ph.dxdz = pool.dxdz[i]; ph.dydz = pool.dydz[i];
         ph.wl = pool.wavelength[i]; ph.pu = 0.0; ph.pv = 0.0; ph.t = 0.0;
         int ix, iy;
-        if (ph.flux != 0.0 && land(P, o, o.phot_first + j, ph, silicon, has_angles, ix, iy)) {
+        Rng rng;
+        rng_reset(rng);
+        if (ph.flux != 0.0 && land(P, o, o.phot_first + j, rng, ph, silicon, has_angles, ix, iy)) {
             added = ph.flux;
             tile_deposit(tile, ct, P, ix, iy, (float)ph.flux);
         }
@@ -429,13 +451,28 @@ __device__ __forceinline__ int owned_to_vertex(int nV, int n)
 // charged neighbours from LDS in a FIXED order (so the result is bit-reproducible) and adds the
 // scaled tabulated displacements to the boundary points it owns.  A per-cell `changed` byte lets
 // k_refresh_bounds skip pixels whose polygon did not move.
-constexpr int UT = 16;            // tile edge
+constexpr int UT = 16;            // tile edge (mark_tile_charge assumes 16)
 constexpr int UQMAX = 4;          // largest supported qdist
 constexpr int UH = UT + 2 * UQMAX + 1;
 
+// no charge was deposited (with this tag) within reach of tile (tx, ty): nothing can move there
+__device__ __forceinline__ bool tile_out_of_reach(const ims_sensor_t& s, const SlotView& sl, int tx, int ty, unsigned int tag)
+{
+    if (tag == 0u || s.bf_tile_charge == nullptr) return false;
+    const int tiles_x = (sl.nx + 1 + UT - 1) / UT, tiles_y = (sl.ny + 1 + UT - 1) / UT;
+    bool any = false;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int ux = tx + dx, uy = ty + dy;
+            if (ux < 0 || uy < 0 || ux >= tiles_x || uy >= tiles_y) continue;
+            any = any || (s.bf_tile_charge[cell_index(sl, ux * UT, uy * UT)] == (unsigned char)tag);
+        }
+    return !any;
+}
+
 __global__ __launch_bounds__(256) void k_update_distortions(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
                                                             const int64_t* __restrict__ tile_prefix,
-                                                            unsigned char* __restrict__ changed)
+                                                            unsigned char* __restrict__ changed, unsigned int tag)
 {
     __shared__ double tile[UH * UH];
     const ims_sensor_t& s = *sp;
@@ -451,6 +488,7 @@ __global__ __launch_bounds__(256) void k_update_distortions(const ims_sensor_t* 
     const int tiles_x = (sl.nx + 1 + UT - 1) / UT;
     const int t = (int)(b - tile_prefix[lo]);
     const int tx0 = (t % tiles_x) * UT, ty0 = (t / tiles_x) * UT;
+    if (tile_out_of_reach(s, sl, tx0 / UT, ty0 / UT, tag)) return;
     const int q = s.qdist;
     const int hw = UT + 2 * q + 1;                 // halo tile edge
     const int sx0 = tx0 - (q + 1), sy0 = ty0 - (q + 1);
@@ -491,6 +529,7 @@ __global__ __launch_bounds__(256) void k_update_distortions(const ims_sensor_t* 
         }
     }
     changed[c] = any ? 1 : 0;
+    if (any && tag != 0u && s.bf_tile_changed != nullptr) s.bf_tile_changed[cell_index(sl, tx0, ty0)] = (unsigned char)tag;
 }
 
 // Fast path for qdist == 3 (the GalSim default): the 8x8 source window of a cell is a 64-bit
@@ -502,7 +541,7 @@ __global__ __launch_bounds__(256) void k_update_distortions(const ims_sensor_t* 
 template <int NV>
 __global__ __launch_bounds__(256) void k_update_distortions_q3(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
                                                                const int64_t* __restrict__ tile_prefix,
-                                                               unsigned char* __restrict__ changed)
+                                                               unsigned char* __restrict__ changed, unsigned int tag)
 {
     constexpr int Q = 3, HW = UT + 2 * Q + 1, NPO = 2 * NV + 2, NVV = 4 * NV + 4;
     __shared__ double wt[HW * HW];
@@ -521,6 +560,7 @@ __global__ __launch_bounds__(256) void k_update_distortions_q3(const ims_sensor_
     const int t = (int)(b - tile_prefix[lo]);
     const int tx0 = (t % tiles_x) * UT, ty0 = (t / tiles_x) * UT;
     const int sx0 = tx0 - (Q + 1), sy0 = ty0 - (Q + 1);
+    if (tile_out_of_reach(s, sl, tx0 / UT, ty0 / UT, tag)) return;
     __shared__ int any_charge;
     if (threadIdx.x < HW) occ[threadIdx.x] = 0u;
     if (threadIdx.x == 0) any_charge = 0;
@@ -563,6 +603,7 @@ __global__ __launch_bounds__(256) void k_update_distortions_q3(const ims_sensor_
     const int64_t c = cell_index(sl, i, j);
     changed[c] = mask ? 1 : 0;
     if (!mask) return;
+    if (tag != 0u && s.bf_tile_changed != nullptr) s.bf_tile_changed[cell_index(sl, tx0, ty0)] = (unsigned char)tag;
     double* pts = s.bf_boundary + c * NPO * 2;
     double acc[NPO * 2];
 #pragma unroll
@@ -593,19 +634,46 @@ __global__ __launch_bounds__(256) void k_update_distortions_q3(const ims_sensor_
     for (int n = 0; n < NPO * 2; ++n) pts[n] = acc[n];
 }
 
-// bounds of the pixels whose polygon moved (own cell, right cell or upper cell changed)
+// bounds of the pixels whose polygon moved (own cell, right cell or upper cell changed); one 16x16
+// tile of owner cells per workgroup, same grid as the update kernel.  With a tag, tiles that saw
+// neither charge nor movement (own, right and upper tile) leave after three byte loads.
 __global__ __launch_bounds__(256) void k_refresh_changed(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
-                                                         int64_t cell_begin, int64_t cell_count,
-                                                         const unsigned char* __restrict__ changed)
+                                                         const int64_t* __restrict__ tile_prefix,
+                                                         const unsigned char* __restrict__ changed, unsigned int tag)
 {
     const ims_sensor_t& s = *sp;
-    const CellRef r = locate_cell(s, first_slot, n_slots, cell_begin, cell_count);
-    if (!r.valid) return;
-    const SlotView& sl = r.sl;
-    const int i = r.i, j = r.j;
-    s.bf_delta[sl.offset + r.c] = 0.0;       // the update kernel has consumed the delta charge
+    const int64_t b = blockIdx.x;
+    int lo = 0, hi = n_slots;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (tile_prefix[mid] <= b) lo = mid; else hi = mid;
+    }
+    const ims_bf_slot_t bs = s.bf_slots[first_slot + lo];
+    const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
+    const int tiles_x = (sl.nx + 1 + UT - 1) / UT, tiles_y = (sl.ny + 1 + UT - 1) / UT;
+    const int t = (int)(b - tile_prefix[lo]);
+    const int tx = t % tiles_x, ty = t / tiles_x;
+    const bool flags = (tag != 0u) && s.bf_tile_charge != nullptr && s.bf_tile_changed != nullptr;
+    bool own = true, right = true, up = true, charged = true;
+    if (flags) {
+        const unsigned char tg = (unsigned char)tag;
+        own = s.bf_tile_changed[cell_index(sl, tx * UT, ty * UT)] == tg;
+        right = (tx + 1 < tiles_x) && s.bf_tile_changed[cell_index(sl, (tx + 1) * UT, ty * UT)] == tg;
+        up = (ty + 1 < tiles_y) && s.bf_tile_changed[cell_index(sl, tx * UT, (ty + 1) * UT)] == tg;
+        charged = s.bf_tile_charge[cell_index(sl, tx * UT, ty * UT)] == tg;
+        if (!(own || right || up || charged)) return;
+    }
+    const int lx = threadIdx.x % UT, ly = threadIdx.x / UT;
+    const int i = tx * UT + lx, j = ty * UT + ly;
+    if (i > sl.nx || j > sl.ny) return;
+    const int64_t c = cell_index(sl, i, j);
+    if (charged) s.bf_delta[c] = 0.0;         // the update kernel has consumed the delta charge
     if (i >= sl.nx || j >= sl.ny) return;
-    if (!(changed[cell_index(sl, i, j)] | changed[cell_index(sl, i + 1, j)] | changed[cell_index(sl, i, j + 1)])) return;
+    // per-cell flags are only meaningful in tiles the update kernel worked on this round
+    const bool f_own = own && changed[c];
+    const bool f_right = ((lx + 1 < UT) ? own : right) && changed[cell_index(sl, i + 1, j)];
+    const bool f_up = ((ly + 1 < UT) ? own : up) && changed[cell_index(sl, i, j + 1)];
+    if (!(f_own || f_right || f_up)) return;
     const int nV = s.num_vertices, nv = 4 * nV + 4;
     double ixmin = 0.0, ixmax = 1.0, iymin = 0.0, iymax = 1.0;
     double oxmin = 0.0, oxmax = 1.0, oymin = 0.0, oymax = 1.0;
@@ -624,7 +692,7 @@ __global__ __launch_bounds__(256) void k_refresh_changed(const ims_sensor_t* __r
         if (k >= 3 * nV + 3) { if (vx > ixmin) ixmin = vx; }
     }
     if (v0x > ixmin) ixmin = v0x;
-    double* bb = s.bf_bounds + (sl.offset + r.c) * 8;
+    double* bb = s.bf_bounds + c * 8;
     bb[0] = ixmin; bb[1] = ixmax; bb[2] = iymin; bb[3] = iymax;
     bb[4] = oxmin; bb[5] = oxmax; bb[6] = oymin; bb[7] = oymax;
 }
@@ -768,7 +836,8 @@ __global__ void k_test_math(int which, const double* __restrict__ in, double* __
     case 3: out[i] = datan(in[i]); break;
     case 4: dsincos(in[i], s, c); out[2 * i] = s; out[2 * i + 1] = c; break;
     case 5: out[i] = dtanh_pos(in[i]); break;
-    case 6: gauss_pair(draw(seed, obj, i, slot), s, c); out[2 * i] = s; out[2 * i + 1] = c; break;
+    case 6: { Rng r; rng_reset(r); rng_block(r, seed, obj, i, slot); gauss_words(r.w[0], r.w[1], s, c);
+              out[2 * i] = s; out[2 * i + 1] = c; break; }
     }
 }
 
@@ -975,7 +1044,7 @@ int ims_sensor_init_boundaries(const ims_sensor_t* sensor_dev, const ims_sensor_
 
 int ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host,
                                   int32_t first_slot, int32_t n_slots, const int64_t* tile_prefix_dev,
-                                  int64_t n_tiles, unsigned char* changed_dev, void* stream)
+                                  int64_t n_tiles, unsigned char* changed_dev, uint32_t tag, void* stream)
 {
     if (!sensor_dev) return set_err(IMS_ERR_ARG, "sensor_dev is NULL");
     if (n_slots == 0) return IMS_OK;
@@ -990,33 +1059,36 @@ int ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sens
     const int q = sensor_host ? sensor_host->qdist : 0;
     if (q == 3 && nV == 4)
         hipLaunchKernelGGL(k_update_distortions_q3<4>, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot,
-                           n_slots, tile_prefix_dev, changed_dev);
+                           n_slots, tile_prefix_dev, changed_dev, tag);
     else if (q == 3 && nV == 8)
         hipLaunchKernelGGL(k_update_distortions_q3<8>, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot,
-                           n_slots, tile_prefix_dev, changed_dev);
+                           n_slots, tile_prefix_dev, changed_dev, tag);
     else
         hipLaunchKernelGGL(k_update_distortions, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot, n_slots,
-                           tile_prefix_dev, changed_dev);
-    hipLaunchKernelGGL(k_refresh_changed, dim3(g), dim3(256), 0, st, sensor_dev, first_slot, n_slots, begin, count,
-                       (const unsigned char*)changed_dev);
+                           tile_prefix_dev, changed_dev, tag);
+    hipLaunchKernelGGL(k_refresh_changed, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot, n_slots,
+                       tile_prefix_dev, (const unsigned char*)changed_dev, tag);
     HIP_TRY(hipGetLastError());
     return IMS_OK;
 }
 
 int ims_run_plan(const ims_plan_item_t* items, int64_t n_items, const ims_sensor_t* sensor_dev,
-                 const ims_sensor_t* sensor_host, unsigned char* changed_dev, void* stream_chain, void* stream_bulk)
+                 const ims_sensor_t* sensor_host, unsigned char* changed_dev, void* const* streams, int32_t n_streams)
 {
     if (!items && n_items > 0) return set_err(IMS_ERR_ARG, "items is NULL");
+    if (!streams || n_streams <= 0) return set_err(IMS_ERR_ARG, "streams is NULL");
+    for (int64_t k = 0; k < n_items; ++k)
+        if (items[k].stream < 0 || items[k].stream >= n_streams) return set_err(IMS_ERR_ARG, "plan item stream index out of range");
     for (int64_t k = 0; k < n_items; ++k) {
         const ims_plan_item_t& it = items[k];
-        void* st = it.stream == 1 ? stream_bulk : stream_chain;
+        void* st = streams[it.stream];
         int rc = IMS_OK;
         switch (it.kind) {
         case IMS_PLAN_RENDER:     rc = ims_shoot_accumulate(it.params, st); break;
         case IMS_PLAN_SHOOT_POOL: rc = ims_shoot_ops_photons(it.params, it.aux, it.pool, st); break;
         case IMS_PLAN_ACC_POOL:   rc = ims_accumulate_segments(it.params, it.pool, it.aux, st); break;
         case IMS_PLAN_UPDATE:     rc = ims_sensor_update_distortions(sensor_dev, sensor_host, it.first_slot, it.n_slots, it.aux,
-                                                                     it.n_tiles, changed_dev, st); break;
+                                                                     it.n_tiles, changed_dev, it.tag, st); break;
         case IMS_PLAN_INIT:       rc = ims_sensor_init_boundaries(sensor_dev, sensor_host, it.first_slot, it.n_slots, st); break;
         case IMS_PLAN_RECORD:
         case IMS_PLAN_WAIT: {
@@ -1089,6 +1161,47 @@ int ims_image_add(double* dst, const double* src, int64_t n, void* stream)
     if (n <= 0) return IMS_OK;
     hipLaunchKernelGGL(k_image_add, dim3(grid_for_pool(n)), dim3(256), 0, (hipStream_t)stream, dst, src, n);
     HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+// Launch-wide constants of the air index (host arithmetic, IEEE binary64, same operation order as the
+// oracle's restatement): n - 1 = air_p * dispersion(wavelength) - air_w * water(wavelength).
+static void air_factors(double p_kpa, double t_k, double h2o_kpa, double* air_p, double* air_w)
+{
+    const double Pm = p_kpa * 7.50061683;
+    const double T = t_k - 273.15;
+    const double W = h2o_kpa * 7.50061683;
+    const double tf = 1.0 + 0.003661 * T;
+    *air_p = 1.0e-6 * (Pm * (1.0 + (1.049 - 0.0157 * T) * 1.0e-6 * Pm) / (720.883 * tf));
+    *air_w = W * 1.0e-6 / tf;
+}
+static double host_air_n_minus_one(double wave_nm, double air_p, double air_w)
+{
+    const double wm = wave_nm * 1.0e-3;
+    const double w2 = wm * wm;
+    const double d1 = fma(146.0, w2, -1.0), d2 = fma(41.0, w2, -1.0);
+    const double den = d1 * d2;
+    const double num = fma(29498.1, d2, 255.4 * d1);
+    const double disp = fma(64.328, den, w2 * num);
+    const double wat = fma(0.0624, w2, -0.000680) * den;
+    return (air_p * (disp * w2) - air_w * wat) / (den * w2);
+}
+
+int ims_fill_derived_op(ims_op_t* op)
+{
+    if (!op) return set_err(IMS_ERR_ARG, "op is NULL");
+    if (op->kind == IMS_OP_PHOTON_DCR) {
+        air_factors(op->p[1], op->p[2], op->p[3], &op->p[5], &op->p[6]);
+        const double nm1 = host_air_n_minus_one(op->p[0], op->p[5], op->p[6]);
+        op->p[7] = nm1 * (nm1 + 2.0) / 2.0 / (nm1 * nm1 + 2.0 * nm1 + 1.0);
+    }
+    return IMS_OK;
+}
+
+int ims_fill_derived_medium(int32_t kind, double* c6)
+{
+    if (!c6) return set_err(IMS_ERR_ARG, "c6 is NULL");
+    if (kind == IMS_MEDIUM_AIR) air_factors(c6[0], c6[1], c6[2], &c6[3], &c6[4]);
     return IMS_OK;
 }
 

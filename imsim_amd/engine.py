@@ -5,6 +5,7 @@ sensor); `Renderer` uploads it once and then renders object tables into the CCD 
 the C-ABI.  There is no CPU fallback here: without the HIP library or a GPU this raises.
 """
 import ctypes as C
+import os
 import dataclasses
 from typing import List, Optional
 
@@ -162,10 +163,28 @@ def segment_prefix(n_phot, seg_size):
     return np.concatenate([[0], np.cumsum(segs)]).astype(np.int64)
 
 
+def _seg_ptr(pre_t):
+    t = getattr(pre_t, "seg_object", None)
+    return t.data_ptr() if t is not None else None
+
+
+class _LibDerive:
+    def __init__(self, lib):
+        self.lib = lib
+
+    def fill_derived_op(self, op_ref):
+        _abi.check(self.lib.ims_fill_derived_op(op_ref), "ims_fill_derived_op")
+
+    def fill_derived_medium(self, kind, c):
+        _abi.check(self.lib.ims_fill_derived_medium(int(kind), c), "ims_fill_derived_medium")
+
+
 class BoundScene:
     """A Scene whose tables live behind pointers of one memory provider; builds RenderParams."""
 
-    def __init__(self, scene: Scene, mem):
+    def __init__(self, scene: Scene, mem, derive):
+        """derive: the library whose fill_derived_op / fill_derived_medium entry points complete the
+        launch-wide derived fields (libimsim_hip.so for the product, the oracle for the checker)."""
         self.scene = scene
         self.mem = mem
         P = RenderParams()
@@ -181,8 +200,9 @@ class BoundScene:
             raise ValueError("too many photon ops")
         P.n_ops = len(scene.ops)
         for k, (kind, table, p) in enumerate(scene.ops):
-            pp = list(p) + [0.0] * (6 - len(p))
-            P.ops[k] = Op(kind, table, (C.c_double * 6)(*pp))
+            pp = list(p) + [0.0] * (8 - len(p))
+            P.ops[k] = Op(kind, table, (C.c_double * 8)(*pp))
+            derive.fill_derived_op(C.byref(P.ops[k]))
         if scene.radial_r2 is not None:
             r2 = np.atleast_2d(scene.radial_r2)
             P.radial.n_tables, P.radial.n_bins = r2.shape[0], r2.shape[1] - 1
@@ -199,7 +219,11 @@ class BoundScene:
             P.ratio.arg_min, P.ratio.arg_step = scene.ratio_wl_min, scene.ratio_wl_step
             _, P.ratio.val = mem.put(t, np.float64)
         if scene.optics is not None:
-            _, P.optics = mem.put_struct(scene.optics)
+            opt = type(scene.optics).from_buffer_copy(bytes(scene.optics))
+            derive.fill_derived_medium(opt.in_medium_kind, opt.in_medium_c)
+            for k in range(opt.n_surfaces):
+                derive.fill_derived_medium(opt.surf[k].medium_kind, opt.surf[k].medium_c)
+            _, P.optics = mem.put_struct(opt)
         if scene.atm is not None:
             A = scene.atm.atmosphere_struct()
             scr = scene.atm.screens
@@ -252,6 +276,9 @@ class BoundScene:
         self.sensor_arrays["boundary"], S.bf_boundary = self.mem.zeros(cells * npo * 2, np.float64)
         self.sensor_arrays["bounds"], S.bf_bounds = self.mem.zeros(cells * 8, np.float64)
         self.sensor_arrays["delta"], S.bf_delta = self.mem.zeros(cells, np.float64)
+        # tile flags of the brighter-fatter rounds (one byte per owner cell, used at tile origins)
+        self.sensor_arrays["tile_charge"], S.bf_tile_charge = self.mem.zeros(cells, np.uint8)
+        self.sensor_arrays["tile_changed"], S.bf_tile_changed = self.mem.zeros(cells, np.uint8)
         # host copy whose slot table is a host pointer (sizes the launches)
         Sh = Sensor.from_buffer_copy(bytes(S))
         self._slots_host = slots_host
@@ -275,8 +302,9 @@ class BoundScene:
         else:
             self.mem.write(self._sensor_buf, np.frombuffer(bytes(self.sensor_struct), dtype=np.uint8).copy())
 
-    def params(self, objects_ptr, n_objects, seg_prefix_ptr, n_segments, image_ptr, realized_ptr=None):
+    def params(self, objects_ptr, n_objects, seg_prefix_ptr, n_segments, image_ptr, realized_ptr=None, seg_object_ptr=None):
         P = RenderParams.from_buffer_copy(bytes(self.base_params))
+        P.seg_object = seg_object_ptr
         P.objects, P.n_objects = objects_ptr, n_objects
         P.seg_prefix, P.n_segments = seg_prefix_ptr, n_segments
         P.image = image_ptr
@@ -313,6 +341,9 @@ class PhotonPool:
 class Renderer:
     """One CCD on one GPU."""
 
+    STREAMS = {"chain": 0, "bulk": 1, "chain1": 2, "chain2": 3}
+    CHAIN_STREAMS = ("chain", "chain1", "chain2")
+
     def __init__(self, scene: Scene, device="cuda:0"):
         self.lib = _abi.load()
         self.mem = DeviceMem(device)
@@ -320,7 +351,7 @@ class Renderer:
         self.device = self.mem.device
         self.torch.cuda.set_device(self.device)
         self.scene = scene
-        self.bound = BoundScene(scene, self.mem)
+        self.bound = BoundScene(scene, self.mem, _LibDerive(self.lib))
         # f64 accumulation image (exact for integer electron counts of any size, so the result does not
         # depend on the order of the atomics); image_numpy() rounds it to the float32 ImageF
         self.image = self.torch.zeros((scene.ny, scene.nx), dtype=self.torch.float64, device=self.device)
@@ -328,6 +359,11 @@ class Renderer:
         # priority while the wide single-launch work fills the CUs it leaves idle
         self.s_chain = self.torch.cuda.Stream(self.device, priority=-1)
         self.s_bulk = self.torch.cuda.Stream(self.device, priority=0)
+        self.s_chain1 = self.torch.cuda.Stream(self.device, priority=0)
+        self.s_chain2 = self.torch.cuda.Stream(self.device, priority=0)
+        self.use_bf_tags = os.environ.get("IMS_BF_TAGS", "1") != "0"
+        # round-count thresholds that cut the bright objects into concurrent chains (plan_lsst_image)
+        self.chain_class_rounds = tuple(int(v) for v in os.environ.get("IMS_CHAIN_CLASSES", "40,6").split(",") if v)
         self.max_pool_photons = 300_000_000      # 48 B each
         if scene.sensor is not None:
             self.init_boundaries(0, len(scene.sensor.slots))
@@ -352,6 +388,9 @@ class Renderer:
         obj_t = self.torch.from_numpy(objects.view(np.uint8).reshape(-1)).to(self.device)
         prefix = segment_prefix(objects["n_phot"], self.scene.seg_size)
         pre_t = self.torch.from_numpy(prefix).to(self.device)
+        # segment -> object map (saves every workgroup a binary search in the prefix)
+        seg_obj = np.repeat(np.arange(len(objects), dtype=np.int32), np.diff(prefix))
+        pre_t.seg_object = self.torch.from_numpy(seg_obj).to(self.device) if len(seg_obj) else None
         return objects, obj_t, prefix, pre_t
 
     # -- fused path (LSST_Image / LSST_Silicon) --
@@ -362,7 +401,8 @@ class Renderer:
         if len(objects) == 0:
             return
         P = self.bound.params(obj_t.data_ptr(), len(objects), pre_t.data_ptr(), int(prefix[-1]),
-                              self.image.data_ptr(), realized.data_ptr() if realized is not None else None)
+                              self.image.data_ptr(), realized.data_ptr() if realized is not None else None,
+                              _seg_ptr(pre_t))
         _abi.check(self.lib.ims_shoot_accumulate(C.byref(P), self._stream()), "ims_shoot_accumulate")
         self._keep = (obj_t, pre_t)
 
@@ -388,7 +428,7 @@ class Renderer:
                 tmp = self.torch.zeros(len(part), dtype=self.torch.float64, device=self.device)
                 realized_parts.append((self.torch.from_numpy(np.asarray(index, dtype=np.int64)).to(self.device), tmp))
             P = self.bound.params(obj_t.data_ptr(), len(part), pre_t.data_ptr(), int(prefix[-1]),
-                                  self.image.data_ptr(), tmp.data_ptr() if tmp is not None else None)
+                                  self.image.data_ptr(), tmp.data_ptr() if tmp is not None else None, _seg_ptr(pre_t))
             return P, (obj_t, pre_t, tmp)
 
         def add_render(part, index, stream="bulk"):
@@ -408,54 +448,86 @@ class Renderer:
         for idx, slots in groups:
             plan.append(("slots", slots))
             n0 = b.n_static_slots
-            plan.append(("init", n0, len(slots)))
-            grp = objects[idx].copy()
+            plan.append(("init", n0, len(slots), "chain"))
+            grp = objects[idx].copy()                     # sorted by n_phot, brightest first
             grp["bf_state"] = n0 + np.arange(len(grp))
             total = grp["n_phot"].copy()
-            # 1. everything of the photons that does not depend on the sensor state goes into a
-            #    compact pool, produced in slices of rounds: the first slice (round 0) on the chain
-            #    stream so the chain can start at once, the later ones on the bulk stream; round r
-            #    waits for the event of the slice that holds its photons.
             offs = np.concatenate([[0], np.cumsum(total)]).astype(np.int64)
             pool, pool_t = self._pool6(offs[-1])
-            rounds = int((total.max() + nrecalc - 1) // nrecalc)
-            edges = [0] + [e for e in (1, 3, 8, 20, 60) if e < rounds] + [rounds]
-            slice_of_round = np.zeros(rounds, dtype=np.int64)
-            ev_base = n_events
-            for k in range(len(edges) - 1):
-                ra, rb = edges[k], edges[k + 1]
-                slice_of_round[ra:rb] = k
-                lo = np.minimum(total, ra * nrecalc)
-                hi = np.minimum(total, rb * nrecalc)
-                act = hi > lo
-                part = grp[act].copy()
-                part["phot_first"] = grp["phot_first"][act] + lo[act]
-                part["n_phot"] = (hi - lo)[act]
-                offs_t = self.torch.from_numpy((offs[:-1] + lo)[act]).to(self.device)
-                P, keep = upload(part, idx[act], "shoot_pool")
-                stream = "chain" if k == 0 else "bulk"
-                plan.append(("shoot_pool", P, (keep, offs_t, pool_t), pool, offs_t, int(part["n_phot"].sum()),
-                             len(part), stream))
-                if k > 0:
-                    plan.append(("record", ev_base + k, stream))
-                    n_events = max(n_events, ev_base + k + 1)
-            # 2. the sequential part: rounds of nrecalc photons per object through the sensor
-            waited = 0
-            for r in range(rounds):
-                k = int(slice_of_round[r])
-                if k > waited:
-                    plan.append(("wait", ev_base + k, "chain"))
-                    waited = k
-                n_act = int(np.count_nonzero(total > r * nrecalc))
-                part = grp[:n_act].copy()
-                part["phot_first"] = grp["phot_first"][:n_act] + r * nrecalc
-                part["n_phot"] = np.minimum(nrecalc, total[:n_act] - r * nrecalc)
-                start_t = self.torch.from_numpy(offs[:n_act] + r * nrecalc).to(self.device)
-                P, keep = upload(part, idx[:n_act], "acc_pool")
-                plan.append(("acc_pool", P, (keep, start_t), pool, start_t, int(part["n_phot"].sum()), n_act))
-                n_cont = int(np.count_nonzero(total > (r + 1) * nrecalc))
-                if n_cont:
-                    plan.append(("update", n0, n_cont))
+            n_rounds = (total + nrecalc - 1) // nrecalc
+            # An object's rounds only depend on its OWN earlier rounds, so the few very bright objects
+            # (hundreds of short, latency-bound rounds) must not wait for the many moderately bright
+            # ones: the group is cut into up to three classes by round count, each advancing on its
+            # own chain stream, the longest chain first in every queue.
+            cuts = [int(np.count_nonzero(n_rounds >= t)) for t in self.chain_class_rounds]
+            bounds = [0] + [c for c in cuts if 0 < c < len(grp)] + [len(grp)]
+            bounds = sorted(set(bounds))
+            classes = [(bounds[k], bounds[k + 1]) for k in range(len(bounds) - 1)]
+            init_ev = None
+            if len(classes) > 1:
+                init_ev = n_events
+                n_events += 1
+                plan.append(("record", init_ev, "chain"))
+            # 1. everything of the photons that does not depend on the sensor state goes into a compact
+            #    pool, produced per class in slices of rounds: the first slice (round 0) on the class's
+            #    chain stream so the chain can start at once, the later ones on the bulk stream (longest
+            #    chain first); round r waits for the event of the slice that holds its photons.
+            chains, bulk_items = [], []
+            for c, (ca, cb) in enumerate(classes):
+                cstream = self.CHAIN_STREAMS[c]
+                if c > 0:
+                    plan.append(("wait", init_ev, cstream))
+                ctot, cgrp, cidx, coffs = total[ca:cb], grp[ca:cb], idx[ca:cb], offs[ca:cb]
+                rounds = int(n_rounds[ca])
+                edges = [0] + [e for e in (1, 3, 8, 20, 60) if e < rounds] + [rounds]
+                slice_of_round = np.zeros(rounds, dtype=np.int64)
+                ev_base = n_events
+                n_events += len(edges) - 1
+                for k in range(len(edges) - 1):
+                    ra, rb = edges[k], edges[k + 1]
+                    slice_of_round[ra:rb] = k
+                    lo = np.minimum(ctot, ra * nrecalc)
+                    hi = np.minimum(ctot, rb * nrecalc)
+                    act = hi > lo
+                    part = cgrp[act].copy()
+                    part["phot_first"] = cgrp["phot_first"][act] + lo[act]
+                    part["n_phot"] = (hi - lo)[act]
+                    offs_t = self.torch.from_numpy((coffs + lo)[act]).to(self.device)
+                    P, keep = upload(part, cidx[act], "shoot_pool")
+                    stream = cstream if k == 0 else "bulk"
+                    item = ("shoot_pool", P, (keep, offs_t, pool_t), pool, offs_t, int(part["n_phot"].sum()),
+                            len(part), stream)
+                    if k == 0:
+                        plan.append(item)
+                    else:
+                        bulk_items += [item, ("record", ev_base + k, stream)]
+                chains.append(dict(stream=cstream, ca=ca, tot=ctot, grp=cgrp, idx=cidx, offs=coffs, rounds=rounds,
+                                   slice_of_round=slice_of_round, ev_base=ev_base, waited=0))
+            plan.extend(bulk_items)
+            # 2. the sequential part: rounds of nrecalc photons per object through the sensor.  The
+            #    classes' rounds are interleaved in the plan so that the host enqueues all chains at
+            #    the same pace.
+            for r in range(max(ch["rounds"] for ch in chains)):
+                for ch in chains:
+                    if r >= ch["rounds"]:
+                        continue
+                    k = int(ch["slice_of_round"][r])
+                    if k > ch["waited"]:
+                        plan.append(("wait", ch["ev_base"] + k, ch["stream"]))
+                        ch["waited"] = k
+                    ctot, cgrp = ch["tot"], ch["grp"]
+                    n_act = int(np.count_nonzero(ctot > r * nrecalc))
+                    part = cgrp[:n_act].copy()
+                    part["phot_first"] = cgrp["phot_first"][:n_act] + r * nrecalc
+                    part["n_phot"] = np.minimum(nrecalc, ctot[:n_act] - r * nrecalc)
+                    start_t = self.torch.from_numpy(ch["offs"][:n_act] + r * nrecalc).to(self.device)
+                    P, keep = upload(part, ch["idx"][:n_act], "acc_pool")
+                    tag = (r % 255 + 1) if self.use_bf_tags else 0      # marks the tiles this round's charge lands in
+                    P.bf_tag = tag
+                    plan.append(("acc_pool", P, (keep, start_t), pool, start_t, int(part["n_phot"].sum()), n_act, ch["stream"]))
+                    n_cont = int(np.count_nonzero(ctot > (r + 1) * nrecalc))
+                    if n_cont:
+                        plan.append(("update", n0 + ch["ca"], n_cont, ch["stream"], tag))
         if len(normal):
             part = objects[normal].copy()
             part["bf_state"] = 0
@@ -483,32 +555,42 @@ class Renderer:
             kind = item[0]
             it = _abi.PlanItem()
             if kind == "render":
-                it.kind, it.stream, it.params = _abi.IMS_PLAN_RENDER, (1 if item[5] == "bulk" else 0), C.addressof(item[1])
+                it.kind, it.stream, it.params = _abi.IMS_PLAN_RENDER, self.STREAMS[item[5]], C.addressof(item[1])
             elif kind == "acc_pool":
                 it.kind, it.params, it.pool, it.aux = _abi.IMS_PLAN_ACC_POOL, C.addressof(item[1]), C.addressof(item[3]), item[4].data_ptr()
+                it.stream = self.STREAMS[item[7]]
             elif kind == "shoot_pool":
                 it.kind, it.params, it.pool, it.aux = _abi.IMS_PLAN_SHOOT_POOL, C.addressof(item[1]), C.addressof(item[3]), item[4].data_ptr()
-                it.stream = 1 if item[7] == "bulk" else 0
+                it.stream = self.STREAMS[item[7]]
             elif kind == "record":
-                it.kind, it.n_slots, it.stream = _abi.IMS_PLAN_RECORD, item[1], (1 if item[2] == "bulk" else 0)
+                it.kind, it.n_slots, it.stream = _abi.IMS_PLAN_RECORD, item[1], self.STREAMS[item[2]]
             elif kind == "wait":
-                it.kind, it.n_slots, it.stream = _abi.IMS_PLAN_WAIT, item[1], (1 if item[2] == "bulk" else 0)
+                it.kind, it.n_slots, it.stream = _abi.IMS_PLAN_WAIT, item[1], self.STREAMS[item[2]]
             elif kind == "slots":
                 close()
                 sl = item[1]
-                tiles = ((sl["nx"].astype(np.int64) + 1 + 15) // 16) * ((sl["ny"].astype(np.int64) + 1 + 15) // 16)
-                prefix = np.concatenate([[0], np.cumsum(tiles)]).astype(np.int64)
-                prefix_t = self.torch.from_numpy(prefix).to(self.device)
-                keep.append(prefix_t)
-                cur_prefix = (prefix, prefix_t)
+                cur_prefix = (sl, {})           # tile prefixes of this group's slot table, by first slot
                 stretches.append(("slots", sl, 0))
                 continue
             elif kind == "init":
                 it.kind, it.first_slot, it.n_slots = _abi.IMS_PLAN_INIT, item[1], item[2]
+                it.stream = self.STREAMS[item[3]]
             elif kind == "update":
                 first, n = item[1], item[2]
-                prefix, prefix_t = cur_prefix if (cur_prefix is not None and first == b.n_static_slots) else self._tile_prefix(first)
+                if cur_prefix is not None:
+                    sl, cache = cur_prefix
+                    if first not in cache:
+                        part = sl[first - b.n_static_slots:]
+                        tiles = ((part["nx"].astype(np.int64) + 1 + 15) // 16) * ((part["ny"].astype(np.int64) + 1 + 15) // 16)
+                        prefix = np.concatenate([[0], np.cumsum(tiles)]).astype(np.int64)
+                        cache[first] = (prefix, self.torch.from_numpy(prefix).to(self.device))
+                        keep.append(cache[first][1])
+                    prefix, prefix_t = cache[first]
+                else:
+                    prefix, prefix_t = self._tile_prefix(first)
                 it.kind, it.first_slot, it.n_slots = _abi.IMS_PLAN_UPDATE, first, n
+                it.stream = self.STREAMS[item[3]]
+                it.tag = item[4] if len(item) > 4 else 0
                 it.aux, it.n_tiles = prefix_t.data_ptr(), int(prefix[n])
             cur.append(it)
         close()
@@ -525,26 +607,27 @@ class Renderer:
         main = torch.cuda.current_stream(self.device)
         ev0 = torch.cuda.Event()
         ev0.record(main)
-        self.s_chain.wait_event(ev0)
-        self.s_bulk.wait_event(ev0)
+        streams = (self.s_chain, self.s_bulk, self.s_chain1, self.s_chain2)      # index = Renderer.STREAMS
+        for st in streams:
+            st.wait_event(ev0)
         b = self.bound
         sensor_dev = b.sensor_dev_ptr if self.scene.sensor is not None else None
         sensor_host = C.byref(b.sensor_host) if self.scene.sensor is not None else None
         changed = self._changed.data_ptr() if hasattr(self, "_changed") else None
-        chain, bulk = C.c_void_p(self.s_chain.cuda_stream), C.c_void_p(self.s_bulk.cuda_stream)
+        sarr = (C.c_void_p * len(streams))(*[st.cuda_stream for st in streams])
         for kind, payload, n in stretches:
             if kind == "slots":
                 # the slot table is host-written: order it after everything queued so far
-                self.s_chain.synchronize()
+                for st in streams:
+                    st.synchronize()
                 with torch.cuda.stream(self.s_chain):
                     b.set_private_slots(payload)
                 continue
-            _abi.check(self.lib.ims_run_plan(payload, n, sensor_dev, sensor_host, changed, chain, bulk), "ims_run_plan")
-        ev1, ev2 = torch.cuda.Event(), torch.cuda.Event()
-        ev1.record(self.s_chain)
-        ev2.record(self.s_bulk)
-        main.wait_event(ev1)
-        main.wait_event(ev2)
+            _abi.check(self.lib.ims_run_plan(payload, n, sensor_dev, sensor_host, changed, sarr, len(streams)), "ims_run_plan")
+        for st in streams:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            main.wait_event(ev)
 
     def render_lsst_image(self, objects, nrecalc=None, realized=None):
         plan, parts = self.plan_lsst_image(objects, nrecalc, want_realized=realized is not None)
@@ -587,7 +670,7 @@ class Renderer:
         kernel (used by bench.py so that the timed region has its inputs resident in HBM)."""
         objects, obj_t, prefix, pre_t = self._upload_objects(objects)
         P = self.bound.params(obj_t.data_ptr(), len(objects), pre_t.data_ptr(), int(prefix[-1]),
-                              self.image.data_ptr(), None)
+                              self.image.data_ptr(), None, _seg_ptr(pre_t))
         ref = C.byref(P)
         keep = (obj_t, pre_t, P)
 
@@ -606,7 +689,8 @@ class Renderer:
         offs = np.concatenate([[0], np.cumsum(objects["n_phot"])]).astype(np.int64)
         off_t = self.torch.from_numpy(offs).to(self.device)
         pool = PhotonPool(self.torch, self.device, offs[-1], off_t, obj_t, len(objects), pre_t, int(prefix[-1]))
-        P = self.bound.params(obj_t.data_ptr(), len(objects), pre_t.data_ptr(), int(prefix[-1]), self.image.data_ptr())
+        P = self.bound.params(obj_t.data_ptr(), len(objects), pre_t.data_ptr(), int(prefix[-1]), self.image.data_ptr(),
+                              None, _seg_ptr(pre_t))
         ph = pool.struct()
         _abi.check(self.lib.ims_shoot_photons(C.byref(P), off_t.data_ptr(), C.byref(ph), self._stream()), "ims_shoot_photons")
         return pool
@@ -621,8 +705,11 @@ class Renderer:
         ph = pool.struct()
         _abi.check(self.lib.ims_apply_ops(C.byref(P), pool.photon_offset_dev.data_ptr(), C.byref(ph), self._stream()), "ims_apply_ops")
 
-    def accumulate(self, pool, realized=None, want_pixel_index=False):
+    def accumulate(self, pool, realized=None, want_pixel_index=False, bf_tag=0):
+        """bf_tag (1..255): mark the 16x16 tiles that receive delta charge so that the next
+        update_distortions(..., bf_tag=same) only visits tiles within reach of that charge."""
         P = self._pool_params(pool, realized)
+        P.bf_tag = bf_tag
         ph = pool.struct()
         pix = None
         if want_pixel_index:
@@ -642,22 +729,24 @@ class Renderer:
         until the slot table changes)."""
         b = self.bound
         sl = b._slots_host[first_slot:b.sensor_host.n_bf_slots]
-        key = (first_slot, sl.tobytes())
+        table_key = b._slots_host[:b.sensor_host.n_bf_slots].tobytes()
         cache = getattr(self, "_tile_cache", None)
-        if cache is None or cache[0] != key:
+        if cache is None or cache[0] != table_key:
+            cache = self._tile_cache = (table_key, {})
+        if first_slot not in cache[1]:
             tiles = ((sl["nx"].astype(np.int64) + 1 + 15) // 16) * ((sl["ny"].astype(np.int64) + 1 + 15) // 16)
             prefix = np.concatenate([[0], np.cumsum(tiles)]).astype(np.int64)
-            self._tile_cache = (key, prefix, self.torch.from_numpy(prefix).to(self.device))
-        return self._tile_cache[1], self._tile_cache[2]
+            cache[1][first_slot] = (prefix, self.torch.from_numpy(prefix).to(self.device))
+        return cache[1][first_slot]
 
-    def update_distortions(self, first_slot, n_slots, stream=None):
+    def update_distortions(self, first_slot, n_slots, stream=None, bf_tag=0):
         if not hasattr(self, "_changed"):
             cells = self.bound.static_cells + int(self.scene.sensor.scratch_cells)
             self._changed = self.torch.zeros(max(cells, 1), dtype=self.torch.uint8, device=self.device)
         prefix, prefix_t = self._tile_prefix(first_slot)
         _abi.check(self.lib.ims_sensor_update_distortions(self.bound.sensor_dev_ptr, C.byref(self.bound.sensor_host),
                                                           first_slot, n_slots, prefix_t.data_ptr(), int(prefix[n_slots]),
-                                                          self._changed.data_ptr(),
+                                                          self._changed.data_ptr(), bf_tag,
                                                           stream if stream is not None else self._stream()),
                    "ims_sensor_update_distortions")
 

@@ -120,13 +120,14 @@ def build_image(renderer, objects, modes, nbatch=10, nsubbatch=50, seed=0, reali
             if len(t) == 0:
                 continue
             if sensor_on and s == 0 and i > 0:
-                renderer.update_distortions(0, 1)          # recalc=(subbatch_num == 0), resume afterwards
+                # recalc=(subbatch_num == 0), resume afterwards; only tiles near the previous batch's charge move
+                renderer.update_distortions(0, 1, bf_tag=(i - 1) % 255 + 1)
             pool = renderer.shoot_photons(t)
             renderer.apply_ops(pool)
             tmp = None
             if realized is not None:
                 tmp = renderer.torch.zeros(len(t), dtype=renderer.torch.float64, device=renderer.device)
-            renderer.accumulate(pool, realized=tmp)
+            renderer.accumulate(pool, realized=tmp, bf_tag=(i % 255 + 1) if sensor_on else 0)
             if realized is not None:
                 realized.index_add_(0, renderer.torch.from_numpy(idx).to(renderer.device), tmp)
             total += int(t["n_phot"].sum())

@@ -40,7 +40,7 @@ extern "C" {
 #define IMS_ERR_NO_DEVICE  -3
 #define IMS_ERR_UNSUPPORTED -4
 
-#define IMS_ABI_VERSION 1
+#define IMS_ABI_VERSION 2
 
 /* ---- object flags ---- */
 #define IMS_OBJ_FAINT   1   /* nominal_flux < max_flux_simple: no photon ops, no sensor (stamp.py:435-465,555-556) */
@@ -55,7 +55,8 @@ extern "C" {
 /* ---- photon-op kinds (names follow the registered PhotonOp types) ---- */
 #define IMS_OP_TIME_SAMPLER              1  /* p0=t0, p1=exptime                      (config/imsim-config.yaml:282-285) */
 #define IMS_OP_PUPIL_ANNULUS_SAMPLER     2  /* p0=R_outer, p1=R_inner                 (:286-289) */
-#define IMS_OP_PHOTON_DCR                3  /* p0=base_wavelength [nm], p1=pressure kPa, p2=temperature K, p3=H2O kPa, p4=scale (rad->arcsec) (:290-296) */
+#define IMS_OP_PHOTON_DCR                3  /* p0=base_wavelength [nm], p1=pressure kPa, p2=temperature K, p3=H2O kPa, p4=scale (rad->arcsec) (:290-296);
+                                             * p5..p7 derived by ims_fill_derived_op: air factors, refraction constant at p0 */
 #define IMS_OP_RUBIN_OPTICS              4  /* p0=shift_photons (0/1)                 (imsim/photon_ops.py:24-127) */
 #define IMS_OP_RUBIN_DIFFRACTION         5  /* p0=shift_photons, p1=disable_field_rotation (imsim/photon_ops.py:211-358) */
 #define IMS_OP_RUBIN_DIFFRACTION_OPTICS  6  /* p0=shift_photons, p1=disable_field_rotation (imsim/photon_ops.py:151-208) */
@@ -75,7 +76,8 @@ extern "C" {
 #define IMS_SURF_BAFFLE   4   /* plane that only applies its obscuration */
 #define IMS_MEDIUM_CONST     0   /* n = c0; c1 must hold 1/c0 */
 #define IMS_MEDIUM_SELLMEIER 1   /* n^2 = 1 + sum B_i l^2/(l^2 - C_i), l in micron; c0..c5 = B1,B2,B3,C1,C2,C3 */
-#define IMS_MEDIUM_AIR       2   /* Filippenko/Edlen air; c0=pressure kPa, c1=temperature K, c2=H2O kPa */
+#define IMS_MEDIUM_AIR       2   /* Filippenko/Edlen air; c0=pressure kPa, c1=temperature K, c2=H2O kPa;
+                                  * c3,c4 derived by ims_fill_derived_medium (pressure/temperature and water factors) */
 #define IMS_OBSC_NONE          0
 #define IMS_OBSC_CLEAR_ANNULUS 1  /* vignetted unless inner <= r <= outer */
 #define IMS_OBSC_CLEAR_CIRCLE  2  /* vignetted unless r <= outer */
@@ -154,7 +156,7 @@ typedef struct ims_atmosphere {
 typedef struct ims_op {
     int32_t kind;            /* IMS_OP_* */
     int32_t table;
-    double  p[6];
+    double  p[8];
 } ims_op_t;
 
 typedef struct ims_surface {
@@ -245,6 +247,12 @@ typedef struct ims_sensor {
     double* bf_boundary;         /* per owner cell of every slot: [2*num_vertices+2][2] owned boundary points (LL corner, bottom pts, LR corner, left pts) */
     double* bf_bounds;           /* per owner cell (one 64-byte line): inner xmin,xmax,ymin,ymax, outer xmin,xmax,ymin,ymax */
     double* bf_delta;            /* per owner cell: charge accumulated since the last recalc (Silicon's double _delta) */
+    /* optional (NULL = off): one byte per owner cell, used at the first cell of every 16x16 tile of a region.
+     * A launch that deposits charge with params->bf_tag != 0 stores the tag in bf_tile_charge; the update with
+     * the same tag then skips tiles with no charge in reach and stores the tag in bf_tile_changed for tiles
+     * whose boundary points moved.  Stale tags only cost work, never correctness. */
+    unsigned char* bf_tile_charge;
+    unsigned char* bf_tile_changed;
 } ims_sensor_t;
 
 /* A photon pool in device memory, SoA, the fields of galsim.PhotonArray (imsim/photon_ops.py:81). */
@@ -277,6 +285,10 @@ typedef struct ims_render_params {
                                       * image[(iy-ymin)*nx + (ix-xmin)]; ims_image_to_float makes the ImageF */
     int32_t  nx, ny, xmin, ymin;
     double*  realized_flux;          /* device [n_objects] or NULL: flux added per object (base['realized_flux'], stamp.py:573) */
+    uint32_t bf_tag;                 /* 1..255: mark the tiles that receive delta charge (ims_sensor_t.bf_tile_charge); 0 = off */
+    uint32_t pad_tag;
+    const int32_t* seg_object;       /* device [n_segments] or NULL: object index of every segment; when given, a
+                                      * workgroup finds its object with one load instead of a search in seg_prefix */
 } ims_render_params_t;
 
 /* ---- library ---- */
@@ -320,7 +332,7 @@ int  ims_sensor_init_boundaries(const ims_sensor_t* sensor_dev, const ims_sensor
  * cell of the sensor, scratch. */
 int  ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host,
                                    int32_t first_slot, int32_t n_slots, const int64_t* tile_prefix_dev,
-                                   int64_t n_tiles, unsigned char* changed_dev, void* stream);
+                                   int64_t n_tiles, unsigned char* changed_dev, uint32_t tag, void* stream);
 
 /* ---- FFT branch: LSST_SiliconBuilder.draw, method == 'fft' (imsim/stamp.py:482-525) ----
  * For very bright objects (nominal_flux >= 1e6 and max_sb > fft_sb_thresh, imsim/stamp.py:275-277,
@@ -399,7 +411,8 @@ int  ims_fft_finish(const ims_fft_params_t* params, const ims_fft_object_t* obje
 /* ---- launch plans ----
  * The brighter-fatter chain of LSST_Image mode is hundreds of short dependent launches; ims_run_plan
  * issues a whole prepared list from C so the host cost per launch is one hipLaunchKernel.
- * Items with stream == 1 go to stream_bulk, the others to stream_chain (in list order per stream). */
+ * An item goes to streams[item.stream], in list order per stream; RECORD / WAIT items order the
+ * streams among each other (one wide "bulk" stream plus several concurrent chains). */
 #define IMS_PLAN_RENDER     1   /* ims_shoot_accumulate(params) */
 #define IMS_PLAN_SHOOT_POOL 2   /* ims_shoot_ops_photons(params, aux = photon_offset, pool) */
 #define IMS_PLAN_ACC_POOL   3   /* ims_accumulate_segments(params, pool, aux = pool_start) */
@@ -415,9 +428,11 @@ typedef struct ims_plan_item {
     const int64_t* aux;                  /* device pointer, see kinds */
     int32_t first_slot, n_slots;
     int64_t n_tiles;
+    uint32_t tag;                        /* IMS_PLAN_UPDATE: the bf_tag of the launches that deposited the charge (0 = no tile skipping) */
+    uint32_t pad;
 } ims_plan_item_t;
 int  ims_run_plan(const ims_plan_item_t* items, int64_t n_items, const ims_sensor_t* sensor_dev,
-                  const ims_sensor_t* sensor_host, unsigned char* changed_dev, void* stream_chain, void* stream_bulk);
+                  const ims_sensor_t* sensor_host, unsigned char* changed_dev, void* const* streams, int32_t n_streams);
 
 /* ---- image helpers ---- */
 int  ims_image_add(double* dst, const double* src, int64_t n, void* stream);
@@ -436,6 +451,11 @@ int  ims_enable_timing(int on);
 /* sizeof() of the ABI structs as compiled, for binding self-checks:
  * 0 object, 1 radial_tables, 2 lin_tables, 3 psf_component, 4 op, 5 surface, 6 tansip, 7 optics, 8 bf_slot,
  * 9 sensor, 10 photons, 11 render_params, 12 plan_item, 13 atmosphere, 14 fft_object, 15 fft_params */
+/* Host helpers: fill the derived (uniform) fields of an op / a medium from its primary parameters, so
+ * that the kernels do not recompute launch-wide constants per photon.  Call them once when the op
+ * chain / the optics descriptor is built; ops and media without derived fields are left untouched. */
+int  ims_fill_derived_op(ims_op_t* op);
+int  ims_fill_derived_medium(int32_t kind, double* c6);
 int  ims_struct_size(int which);
 int  ims_test_math(int which, const double* in_dev, double* out_dev, int64_t n, uint64_t seed, int64_t obj,
                    uint32_t slot, void* stream);

@@ -22,7 +22,10 @@ void   orc_apply_rubin_op(const ims_render_params_t* P, int op_index, ims_photon
                           const int64_t* photon_offset);
 void   orc_screen_gradient(const ims_atmosphere_t* A, double pu, double pv, double t, double tanx, double tany,
                            double* gx, double* gy);
-double orc_air_n_minus_one(double wave_nm, double p_kpa, double t_k, double h2o_kpa);
+double orc_air_n_minus_one(double wave_nm, double air_p, double air_w);
+void   orc_air_factors(double p_kpa, double t_k, double h2o_kpa, double* air_p, double* air_w);
+int    orc_fill_derived_op(ims_op_t* op);
+int    orc_fill_derived_medium(int32_t kind, double* c6);
 
 /* sensor */
 int    orc_owned_points(const ims_sensor_t* s);        /* 2*num_vertices + 1 */

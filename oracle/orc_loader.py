@@ -48,6 +48,8 @@ def load():
         lib.orc_fft_spikes.argtypes = [C.POINTER(_abi.FftParams), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         lib.orc_test_stencil.argtypes = [C.POINTER(_abi.Spikes), C.c_int, C.c_void_p]
         lib.orc_test_gauss.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_uint32, C.c_void_p]
+        lib.orc_fill_derived_op.argtypes = [C.c_void_p]
+        lib.orc_fill_derived_medium.argtypes = [C.c_int32, C.POINTER(C.c_double)]
         _lib = lib
     return _lib
 
@@ -89,6 +91,19 @@ class HostPool:
         return out
 
 
+class _OracleDerive:
+    """the oracle's own restatement of ims_fill_derived_op / ims_fill_derived_medium"""
+
+    def __init__(self, lib):
+        self.lib = lib
+
+    def fill_derived_op(self, op_ref):
+        self.lib.orc_fill_derived_op(op_ref)
+
+    def fill_derived_medium(self, kind, c):
+        self.lib.orc_fill_derived_medium(int(kind), c)
+
+
 class OracleScene:
     """CPU counterpart of imsim_amd.engine.Renderer."""
 
@@ -96,7 +111,7 @@ class OracleScene:
         self.lib = load()
         self.scene = scene
         self.mem = HostMem()
-        self.bound = BoundScene(scene, self.mem)
+        self.bound = BoundScene(scene, self.mem, _OracleDerive(self.lib))
         self.image64 = np.zeros((scene.ny, scene.nx), dtype=np.float64)      # f64 accumulation, as on the GPU
         if scene.sensor is not None:
             self.init_boundaries(0, len(scene.sensor.slots))

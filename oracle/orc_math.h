@@ -53,6 +53,26 @@ static inline orc_draw_t orc_draw(uint64_t seed, int64_t obj_id, int64_t photon,
     d.b = (((uint64_t)c[2] << 32) | c[3]) >> 11;
     return d;
 }
+/* The photon pipeline (spec v4) consumes the raw block: four 32-bit words per (object, photon, slot),
+ * each mapped to the open interval (0,1) -- the granularity of GalSim's own UniformDeviate. */
+typedef struct { uint32_t w[4]; } orc_words_t;
+static inline orc_words_t orc_words(uint64_t seed, int64_t obj_id, int64_t photon, uint32_t slot)
+{
+    uint32_t c[4];
+    c[0] = (uint32_t)((uint64_t)photon);
+    c[1] = (uint32_t)((uint64_t)photon >> 32);
+    c[2] = slot;
+    c[3] = (uint32_t)((uint64_t)obj_id);
+    uint32_t k0 = (uint32_t)seed;
+    uint32_t k1 = (uint32_t)(seed >> 32) ^ (uint32_t)((uint64_t)obj_id >> 32);
+    orc_philox4x32_10(c, k0, k1);
+    orc_words_t r;
+    r.w[0] = c[0]; r.w[1] = c[1]; r.w[2] = c[2]; r.w[3] = c[3];
+    return r;
+}
+/* (w + 1/2) / 2^32, exact */
+static inline double orc_w01(uint32_t w) { return orc_fma((double)w, 0x1.0p-32, 0x1.0p-33); }
+
 /* [0,1) */
 static inline double orc_u01(uint64_t k) { return (double)k * 0x1.0p-53; }
 /* (0,1] for logarithms */
@@ -230,13 +250,20 @@ static inline void orc_gauss_pair(orc_draw_t d, double* g0, double* g1)
     *g0 = r * c; *g1 = r * s;
 }
 
-/* RNG slots */
-#define ORC_SLOT_WAVE_PROF 0   /* a: wavelength, b: profile radius */
-#define ORC_SLOT_PROF_ANG  1   /* a: profile angle */
-#define ORC_SLOT_PSF       2   /* +component */
-#define ORC_SLOT_OP        8   /* +op index in chain */
-#define ORC_SLOT_PSF_TIME 20   /* +component: arrival time drawn by a phase-screen PSF */
-#define ORC_SLOT_SENSOR_DIFF 24  /* gaussian pair: diffusion */
-#define ORC_SLOT_SENSOR_CONV 25  /* a: conversion depth, b: pixel-not-found coin */
+/* Box-Muller pair from two words */
+static inline void orc_gauss_words(uint32_t w0, uint32_t w1, double* g0, double* g1)
+{
+    double r = orc_sqrt(-2.0 * orc_log(orc_w01(w0)));
+    double s, c;
+    orc_sincos2pi(orc_w01(w1), &s, &c);
+    *g0 = r * c; *g1 = r * s;
+}
+
+/* RNG slots and word assignment (spec v4) */
+#define ORC_SLOT_SHOOT     0   /* w0 wavelength, w1 profile radius, w2 profile angle */
+#define ORC_SLOT_PSF       2   /* + (component >> 1); component c owns words 2(c&1), 2(c&1)+1 */
+#define ORC_SLOT_OP        8   /* + (op index >> 1); op k owns words 2(k&1), 2(k&1)+1 */
+#define ORC_SLOT_PSF_TIME 20   /* + component: w0 arrival time drawn by a phase-screen PSF */
+#define ORC_SLOT_SENSOR   24   /* w0,w1 diffusion pair, w2 conversion depth, w3 pixel-not-found coin */
 
 #endif

@@ -73,18 +73,17 @@ void orc_shoot_object(const ims_render_params_t* P, const ims_object_t* obj, int
     const double w0 = obj->winv[0], w1 = obj->winv[1], w2 = obj->winv[2], w3 = obj->winv[3];
     for (int64_t j = 0; j < obj->n_phot; ++j) {
         int64_t i = base + j, k = obj->phot_first + j;
-        orc_draw_t d0 = orc_draw(P->seed, obj->obj_id, k, ORC_SLOT_WAVE_PROF);
+        orc_words_t d0 = orc_words(P->seed, obj->obj_id, k, ORC_SLOT_SHOOT);
         /* WavelengthSampler */
         double wl = obj->sed_wave;
-        if (obj->sed_table >= 0) wl = orc_lin_lookup(&P->sed, obj->sed_table, orc_u01(d0.a));
+        if (obj->sed_table >= 0) wl = orc_lin_lookup(&P->sed, obj->sed_table, orc_w01(d0.w[0]));
         /* profile */
         double pu = 0.0, pv = 0.0;
         if (obj->prof_table >= 0) {
-            double r2 = orc_radial_r2(&P->radial, obj->prof_table, orc_u01(d0.b));
+            double r2 = orc_radial_r2(&P->radial, obj->prof_table, orc_w01(d0.w[1]));
             double r = orc_sqrt(r2) * obj->prof_scale;
-            orc_draw_t d1 = orc_draw(P->seed, obj->obj_id, k, ORC_SLOT_PROF_ANG);
             double s, c;
-            orc_sincos2pi(orc_u01(d1.a), &s, &c);
+            orc_sincos2pi(orc_w01(d0.w[2]), &s, &c);
             double gu = r * c, gv = r * s;
             pu = j0 * gu + j1 * gv;
             pv = j2 * gu + j3 * gv;
@@ -134,34 +133,35 @@ void orc_apply_psf(const ims_render_params_t* P, const ims_object_t* obj, int co
     const double w0 = obj->winv[0], w1 = obj->winv[1], w2 = obj->winv[2], w3 = obj->winv[3];
     for (int64_t j = 0; j < obj->n_phot; ++j) {
         int64_t i = base + j, k = obj->phot_first + j;
-        orc_draw_t d = orc_draw(P->seed, obj->obj_id, k, ORC_SLOT_PSF + (uint32_t)comp);
+        orc_words_t d = orc_words(P->seed, obj->obj_id, k, ORC_SLOT_PSF + ((uint32_t)comp >> 1));
+        uint32_t wa = d.w[2 * (comp & 1)], wb = d.w[2 * (comp & 1) + 1];
         double scale = c->p0;
         if (c->chrom_alpha != 0.0) scale = scale * orc_pow(ph->wavelength[i] / c->chrom_base, c->chrom_alpha);
         double ku, kv;
         if (c->kind == IMS_PSF_GAUSSIAN) {
             double g0, g1;
-            orc_gauss_pair(d, &g0, &g1);
+            orc_gauss_words(wa, wb, &g0, &g1);
             ku = scale * g0; kv = scale * g1;
         } else if (c->kind == IMS_PSF_SCREENS) {
             /* PhaseScreenPSF geometric shooting: random pupil position and arrival time, kick =
              * wavefront gradient; the photon keeps (pupil_u, pupil_v, time) for later operators */
             const ims_atmosphere_t* A = P->atm;
             double ro2 = A->aper_r_outer * A->aper_r_outer, ri2 = A->aper_r_inner * A->aper_r_inner;
-            double r = orc_sqrt(ri2 + orc_u01(d.a) * (ro2 - ri2));
+            double r = orc_sqrt(ri2 + orc_w01(wa) * (ro2 - ri2));
             double s, cc;
-            orc_sincos2pi(orc_u01(d.b), &s, &cc);
+            orc_sincos2pi(orc_w01(wb), &s, &cc);
             double pu = r * cc, pv = r * s;
-            orc_draw_t dt = orc_draw(P->seed, obj->obj_id, k, ORC_SLOT_PSF_TIME + (uint32_t)comp);
-            double t = A->t0 + orc_u01(dt.a) * A->exptime;
+            orc_words_t dt = orc_words(P->seed, obj->obj_id, k, ORC_SLOT_PSF_TIME + (uint32_t)comp);
+            double t = A->t0 + orc_w01(dt.w[0]) * A->exptime;
             double gx, gy;
             orc_screen_gradient(A, pu, pv, t, obj->atm_tan_x, obj->atm_tan_y, &gx, &gy);
             ku = scale * gx; kv = scale * gy;
             ph->pupil_u[i] = pu; ph->pupil_v[i] = pv; ph->time[i] = t;
         } else {
-            double r2 = orc_radial_r2(&P->radial, c->table, orc_u01(d.a));
+            double r2 = orc_radial_r2(&P->radial, c->table, orc_w01(wa));
             double r = orc_sqrt(r2) * scale;
             double s, cc;
-            orc_sincos2pi(orc_u01(d.b), &s, &cc);
+            orc_sincos2pi(orc_w01(wb), &s, &cc);
             ku = r * cc; kv = r * s;
         }
         ph->x[i] = ph->x[i] + (w0 * ku + w1 * kv);
@@ -189,37 +189,64 @@ static inline int64_t stream_index(const ims_render_params_t* P, const ims_photo
     return (*obj)->phot_first + (i - photon_offset[oi]);
 }
 
-/* Filippenko (1982) air index as used by GalSim's dcr module (recalled). */
-double orc_air_n_minus_one(double wave_nm, double p_kpa, double t_k, double h2o_kpa)
+/* Filippenko (1982) air index as used by GalSim's dcr module (recalled), in
+ * the spec-v4 form: uniform pressure/temperature/water factors (orc_air_factors) and the dispersion
+ * formula over one denominator:
+ *   n-1 = air_p (64.328 + 29498.1/(146 - s2) + 255.4/(41 - s2)) - air_w (0.0624 - 0.00068 s2), s2 = 1/w2 */
+void orc_air_factors(double p_kpa, double t_k, double h2o_kpa, double* air_p, double* air_w)
 {
     double Pm = p_kpa * 7.50061683;
     double T = t_k - 273.15;
     double W = h2o_kpa * 7.50061683;
+    double tf = 1.0 + 0.003661 * T;
+    *air_p = 1.0e-6 * (Pm * (1.0 + (1.049 - 0.0157 * T) * 1.0e-6 * Pm) / (720.883 * tf));
+    *air_w = W * 1.0e-6 / tf;
+}
+double orc_air_n_minus_one(double wave_nm, double air_p, double air_w)
+{
     double wm = wave_nm * 1.0e-3;
-    double sig2 = 1.0 / (wm * wm);
-    double n1 = (64.328 + 29498.1 / (146.0 - sig2) + 255.4 / (41.0 - sig2)) * 1.0e-6;
-    n1 = n1 * (Pm * (1.0 + (1.049 - 0.0157 * T) * 1.0e-6 * Pm) / (720.883 * (1.0 + 0.003661 * T)));
-    n1 = n1 - (0.0624 - 0.000680 * sig2) / (1.0 + 0.003661 * T) * W * 1.0e-6;
-    return n1;
+    double w2 = wm * wm;
+    double d1 = orc_fma(146.0, w2, -1.0), d2 = orc_fma(41.0, w2, -1.0);
+    double den = d1 * d2;
+    double num = orc_fma(29498.1, d2, 255.4 * d1);
+    double disp = orc_fma(64.328, den, w2 * num);
+    double wat = orc_fma(0.0624, w2, -0.000680) * den;
+    return (air_p * (disp * w2) - air_w * wat) / (den * w2);
 }
 static double refraction_r0(double nm1)
 {
     return nm1 * (nm1 + 2.0) / 2.0 / (nm1 * nm1 + 2.0 * nm1 + 1.0);
 }
 
+/* launch-wide derived fields (include/imsim_hip.h: ims_fill_derived_op / ims_fill_derived_medium) */
+int orc_fill_derived_op(ims_op_t* op)
+{
+    if (op->kind == IMS_OP_PHOTON_DCR) {
+        orc_air_factors(op->p[1], op->p[2], op->p[3], &op->p[5], &op->p[6]);
+        op->p[7] = refraction_r0(orc_air_n_minus_one(op->p[0], op->p[5], op->p[6]));
+    }
+    return 0;
+}
+int orc_fill_derived_medium(int32_t kind, double* c6)
+{
+    if (kind == IMS_MEDIUM_AIR) orc_air_factors(c6[0], c6[1], c6[2], &c6[3], &c6[4]);
+    return 0;
+}
+
 void orc_apply_op(const ims_render_params_t* P, int op_index, ims_photons_t* ph,
                   const int64_t* photon_offset)
 {
     const ims_op_t* op = &P->ops[op_index];
-    const uint32_t slot = ORC_SLOT_OP + (uint32_t)op_index;
+    const uint32_t slot = ORC_SLOT_OP + ((uint32_t)op_index >> 1);
+    const int wb = 2 * (op_index & 1);          /* this op's two words of the block */
     const int64_t n = ph->n;
     switch (op->kind) {
     case IMS_OP_TIME_SAMPLER:
         for (int64_t i = 0; i < n; ++i) {
             const ims_object_t* obj; int64_t k = stream_index(P, ph, photon_offset, i, &obj);
             if (obj->flags & IMS_OBJ_FAINT) continue;
-            orc_draw_t d = orc_draw(P->seed, obj->obj_id, k, slot);
-            ph->time[i] = op->p[0] + orc_u01(d.a) * op->p[1];
+            orc_words_t d = orc_words(P->seed, obj->obj_id, k, slot);
+            ph->time[i] = op->p[0] + orc_w01(d.w[wb]) * op->p[1];
         }
         break;
     case IMS_OP_PUPIL_ANNULUS_SAMPLER: {
@@ -227,20 +254,20 @@ void orc_apply_op(const ims_render_params_t* P, int op_index, ims_photons_t* ph,
         for (int64_t i = 0; i < n; ++i) {
             const ims_object_t* obj; int64_t k = stream_index(P, ph, photon_offset, i, &obj);
             if (obj->flags & IMS_OBJ_FAINT) continue;
-            orc_draw_t d = orc_draw(P->seed, obj->obj_id, k, slot);
-            double r = orc_sqrt(ri2 + orc_u01(d.a) * (ro2 - ri2));
+            orc_words_t d = orc_words(P->seed, obj->obj_id, k, slot);
+            double r = orc_sqrt(ri2 + orc_w01(d.w[wb]) * (ro2 - ri2));
             double s, c;
-            orc_sincos2pi(orc_u01(d.b), &s, &c);
+            orc_sincos2pi(orc_w01(d.w[wb + 1]), &s, &c);
             ph->pupil_u[i] = r * c;
             ph->pupil_v[i] = r * s;
         }
         break; }
     case IMS_OP_PHOTON_DCR: {
-        double base_r0 = refraction_r0(orc_air_n_minus_one(op->p[0], op->p[1], op->p[2], op->p[3]));
+        double base_r0 = op->p[7];               /* derived fields p5..p7: orc_fill_derived_op */
         for (int64_t i = 0; i < n; ++i) {
             const ims_object_t* obj; (void)stream_index(P, ph, photon_offset, i, &obj);
             if (obj->flags & IMS_OBJ_FAINT) continue;
-            double r0 = refraction_r0(orc_air_n_minus_one(ph->wavelength[i], op->p[1], op->p[2], op->p[3]));
+            double r0 = refraction_r0(orc_air_n_minus_one(ph->wavelength[i], op->p[5], op->p[6]));
             double shift = (r0 - base_r0) * obj->dcr_tanz * op->p[4];   /* arcsec */
             double du = -shift * obj->dcr_sinp;
             double dv = shift * obj->dcr_cosp;

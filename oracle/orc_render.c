@@ -92,7 +92,10 @@ void orc_test_draw(uint64_t seed, int64_t obj, int64_t photon, uint32_t slot, ui
 }
 void orc_test_gauss(uint64_t seed, int64_t obj, int64_t first, int64_t n, uint32_t slot, double* out)
 {
-    for (int64_t i = 0; i < n; ++i) orc_gauss_pair(orc_draw(seed, obj, first + i, slot), &out[2 * i], &out[2 * i + 1]);
+    for (int64_t i = 0; i < n; ++i) {
+        orc_words_t d = orc_words(seed, obj, first + i, slot);
+        orc_gauss_words(d.w[0], d.w[1], &out[2 * i], &out[2 * i + 1]);
+    }
 }
 int orc_struct_size(int which)
 {

@@ -248,9 +248,9 @@ void orc_accumulate_range(const ims_render_params_t* P, const ims_photons_t* ph,
             if (ix < obj->stamp_xmin || ix > obj->stamp_xmax || iy < obj->stamp_ymin || iy > obj->stamp_ymax) continue;
         } else {
             const ims_bf_slot_t* sl = &s->bf_slots[obj->bf_state];
-            orc_draw_t dc = orc_draw(P->seed, obj->obj_id, k, ORC_SLOT_SENSOR_CONV);
+            orc_words_t dc = orc_words(P->seed, obj->obj_id, k, ORC_SLOT_SENSOR);
             double g0, g1;
-            orc_gauss_pair(orc_draw(P->seed, obj->obj_id, k, ORC_SLOT_SENSOR_DIFF), &g0, &g1);
+            orc_gauss_words(dc.w[0], dc.w[1], &g0, &g1);
             /* conversion depth (Silicon::calculateConversionDepth, recalled) */
             double wl = ph->wavelength[i];
             double f = (wl - s->abs_wl_min) / s->abs_wl_step;
@@ -258,7 +258,7 @@ void orc_accumulate_range(const ims_render_params_t* P, const ims_photons_t* ph,
             if (!(f > 0.0)) abs_len = s->abs_len[0];
             else if (f >= (double)(s->n_abs - 1)) abs_len = s->abs_len[s->n_abs - 1];
             else { int t = (int)f; double a = f - (double)t; abs_len = s->abs_len[t] + a * (s->abs_len[t + 1] - s->abs_len[t]); }
-            double si_length = -abs_len * orc_log(1.0 - orc_u01(dc.a));
+            double si_length = -abs_len * orc_log(orc_w01(dc.w[2]));
             double dz = si_length;
             if (has_angles) {
                 double dxdz = ph->dxdz[i], dydz = ph->dydz[i];
@@ -300,7 +300,7 @@ void orc_accumulate_range(const ims_render_params_t* P, const ims_photons_t* ph,
                 }
             }
             if (!found) {
-                int n = (orc_u01(dc.b) > 0.5) ? 0 : step;
+                int n = (dc.w[3] & 0x80000000u) ? 0 : step;
                 ix = ix + XOFF[n]; iy = iy + YOFF[n];
             }
             if (ix < obj->stamp_xmin || ix > obj->stamp_xmax || iy < obj->stamp_ymin || iy > obj->stamp_ymax) continue;

@@ -331,9 +331,9 @@ IMS_DEV bool obscured(const ims_surface_t& S, double r2)
     return false;
 }
 
-// Propagate to surface S (spec v3): plane exact; conic by the closed-form root nearest
-// the vertex plane, with the un-normalised normal (-c x, -c y, 1-(1+k) c z) that needs no sqrt;
-// even-asphere terms by Newton from the conic root until |f| <= 1e-11 m.
+// Propagate to surface S (spec v4): plane exact; conic by the closed-form root of smaller
+// |t|, with the un-normalised normal (-c x, -c y, 1-(1+k) c z) that needs no sqrt; even-asphere terms
+// by Newton on the implicit conic form from the conic root until |G| <= 2e-11.
 IMS_DEV bool surf_hit(const ims_surface_t& S, double (&pos)[3], const double (&vel)[3], double (&N)[3], double& nn, double& r2_out)
 {
     const double pz = pos[2] - S.z0;
@@ -354,10 +354,7 @@ IMS_DEV bool surf_hit(const ims_surface_t& S, double (&pos)[3], const double (&v
         if (disc < 0.0) return false;
         const double sq = sqrt(disc);
         const double q = -0.5 * (B + (B < 0.0 ? -sq : sq));
-        const double lhs = fabs(pz * q + vel[2] * C) * fabs(A);
-        const double rhs = fabs(pz * A + vel[2] * q) * fabs(q);
-        const bool near_root = (lhs <= rhs);
-        t = (near_root ? C : q) / (near_root ? q : A);
+        t = C / q;                                   // the root of smaller |t| (q carries the larger magnitude)
     } else {
         t = -pz / vel[2];
     }
@@ -371,35 +368,34 @@ IMS_DEV bool surf_hit(const ims_surface_t& S, double (&pos)[3], const double (&v
         nn = c * c * r2_out + sqv * sqv;
         return true;
     }
-    double x = 0.0, y = 0.0, z = 0.0, r2 = 0.0, ds = 0.0;
+    // even asphere z = conic(r2) + p(r2), p = sum a_k r^(2k+4): Newton on the implicit conic form
+    // G = c (r2 + k1 w^2) - 2 w with w = z - p(r2), which needs neither sqrt nor a second division
+    double x = 0.0, y = 0.0, z = 0.0, r2 = 0.0, w = 0.0, dp = 0.0;
     for (int it = 0; it < 6; ++it) {
         x = pos[0] + vel[0] * t; y = pos[1] + vel[1] * t; z = pz + vel[2] * t;
         r2 = x * x + y * y;
-        double sag = 0.0;
-        ds = 0.0;
-        if (S.R != 0.0) {
-            const double arg = 1.0 - k1 * c * c * r2;
-            if (arg <= 0.0) return false;
-            const double sqv = sqrt(arg);
-            const double inv = 1.0 / (sqv * (1.0 + sqv));
-            sag = c * r2 * sqv * inv;
-            ds = 0.5 * c * (1.0 + sqv) * inv;
-        }
-        double rp = r2;
+        double p = 0.0, rp = r2;
+        dp = 0.0;
         for (int k = 0; k < S.n_asphere; ++k) {
-            ds = ds + S.asph[k] * (double)(k + 2) * rp;
+            dp = dp + S.asph[k] * (double)(k + 2) * rp;
             rp = rp * r2;
-            sag = sag + S.asph[k] * rp;
+            p = p + S.asph[k] * rp;
         }
-        const double f = z - sag;
-        if (fabs(f) <= 1.0e-11 || it == 5) break;
-        const double fp = vel[2] - 2.0 * ds * (x * vel[0] + y * vel[1]);
-        t = t - f / fp;
+        w = z - p;
+        const double G = c * (r2 + k1 * w * w) - 2.0 * w;
+        if (fabs(G) <= 2.0e-11 || it == 5) break;
+        const double s = x * vel[0] + y * vel[1];
+        const double wp = vel[2] - 2.0 * dp * s;
+        const double Gp = 2.0 * (c * (s + k1 * w * wp) - wp);
+        t = t - G / Gp;
     }
+    const double m = 1.0 - c * k1 * w;
+    if (!(m > 0.0)) return false;
+    const double g = c + 2.0 * m * dp;
     pos[0] = x; pos[1] = y; pos[2] = S.z0 + z;
-    N[0] = -2.0 * ds * x; N[1] = -2.0 * ds * y; N[2] = 1.0;
+    N[0] = -g * x; N[1] = -g * y; N[2] = m;
     r2_out = r2;
-    nn = 4.0 * ds * ds * r2 + 1.0;
+    nn = g * g * r2 + m * m;
     return true;
 }
 

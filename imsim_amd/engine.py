@@ -361,7 +361,7 @@ class Renderer:
         self.s_bulk = self.torch.cuda.Stream(self.device, priority=0)
         self.s_chain1 = self.torch.cuda.Stream(self.device, priority=0)
         self.s_chain2 = self.torch.cuda.Stream(self.device, priority=0)
-        self.use_bf_tags = os.environ.get("IMS_BF_TAGS", "1") != "0"
+        self.use_bf_tags = os.environ.get("IMS_BF_TAGS", "0") != "0"
         # round-count thresholds that cut the bright objects into concurrent chains (plan_lsst_image)
         self.chain_class_rounds = tuple(int(v) for v in os.environ.get("IMS_CHAIN_CLASSES", "40,6").split(",") if v)
         self.max_pool_photons = 300_000_000      # 48 B each

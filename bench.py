@@ -78,7 +78,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    lib.ims_enable_timing(1)
+    lib.ims_enable_timing(cfg["timed_kernel"])
     t0 = time.perf_counter()
     for _ in range(args.steps):
         full_step()
@@ -100,18 +100,18 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = n_total_obj * args.steps / elapsed
 
-    # roofline of the dominant kernel (the fused shoot->ops->accumulate launch of this rank)
-    # The photon-pipeline launches of a step (the fused render of the ordinary objects + the pool
-    # shoots of the bright ones: same device code, ~90 % of the GPU time) are bracketed by hipEvent
-    # pairs inside the library; achieved = their algorithmic bytes per launch / mean launch time.
+    # roofline of the dominant kernel of this workload (configs.py names it): its launches are bracketed
+    # by hipEvent pairs inside the library, on the stream they run on; achieved = algorithmic bytes per
+    # launch / mean launch duration.  `traffic` = HBM bytes per launch from the committed rocprofv3 PMC
+    # passes of the same command (profiles/hbm_traffic.json), corrected as MI355X_MICROARCH.md prescribes.
+    launches_per_step, algo_bytes_step = step.timed[cfg["timed_kernel"]]
     n_launch = max(int(nl.value), 1) if have_ms else 1
-    algo_bytes_step = step.timed_bytes
-    bytes_per_launch = algo_bytes_step * args.steps / n_launch
+    bytes_per_launch = algo_bytes_step / max(launches_per_step, 1)
     k_ms = float(ms.value) / n_launch if have_ms else float("nan")
     achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9 if have_ms else float("nan")
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": cfg["kernel"], "mean_launch_ms": k_ms, "timed_launches_per_step": step.n_render_launches,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": hbm_traffic(args.config, cfg["kernel"], world),
+                "kernel": cfg["kernel"], "mean_launch_ms": k_ms, "timed_launches_per_step": launches_per_step,
                 "kernel_ms_per_step": float(ms.value) / args.steps if have_ms else None,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "photons_per_step": step.photons}
 
@@ -132,6 +132,18 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def hbm_traffic(config, kernel, world):
+    """HBM bytes per launch of `kernel` measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate
+    passes) on this workload at one GPU; None when no committed measurement matches."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
+    if world != 1 or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        table = json.load(fh)
+    entry = table.get(config, {}).get(kernel)
+    return float(entry["hbm_bytes_per_launch"]) if entry else None
 
 
 def cpu_baseline(cfg, scene, objects, n_sample):

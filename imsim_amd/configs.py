@@ -53,8 +53,8 @@ BENCH_CONFIGS = {
         scene=_c3_scene_bench,
         objects=None,
         make_step=lambda renderer, objects: renderer.prepared_lsst_image(objects),
-        bytes_per_photon=16,
-        kernel="k_shoot_accumulate + k_shoot_photons<true> (photon pipeline)",
+        timed_kernel=2,
+        kernel="k_shoot_photons<true>",
         cpu_sample=20000,
         cpu_scene=_c3_cpu_scene,
         cpu_step=lambda orc, sample: orc.render_lsst_image(sample),
@@ -65,7 +65,7 @@ BENCH_CONFIGS = {
         scene=scene_c2,
         objects=_c2_objects,
         make_step=lambda renderer, objects: renderer.prepared(objects),
-        bytes_per_photon=16,
+        timed_kernel=1,
         kernel="k_shoot_accumulate",
         cpu_sample=10000,
         cpu_scene=lambda scene: scene,

@@ -27,19 +27,21 @@ static int hip_err(hipError_t e, const char* what)
 }
 #define HIP_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_err(e_, #call); } while (0)
 
-// Timing of the dominant kernel: every ims_shoot_accumulate launch between ims_enable_timing(1)
-// and the query is bracketed by a hipEvent pair on the launch stream.
+// Timing of the dominant kernel: every launch of the selected entry point between ims_enable_timing(which)
+// and the query is bracketed by a hipEvent pair on the launch stream (which: 1 = ims_shoot_accumulate,
+// 2 = ims_shoot_ops_photons).
 #include <vector>
-static bool g_timing = false;
+static int g_timing = 0;
 static std::vector<hipEvent_t> g_events;   // pairs
 static size_t g_events_used = 0;
 
 struct LaunchTimer {
     hipStream_t st;
     size_t slot;
-    explicit LaunchTimer(hipStream_t s) : st(s), slot(0)
+    bool on;
+    LaunchTimer(hipStream_t s, int which) : st(s), slot(0), on(g_timing == which)
     {
-        if (g_timing) {
+        if (on) {
             if (g_events_used + 2 > g_events.size()) {
                 hipEvent_t a, b;
                 (void)hipEventCreate(&a); (void)hipEventCreate(&b);
@@ -50,7 +52,7 @@ struct LaunchTimer {
             (void)hipEventRecord(g_events[slot], st);
         }
     }
-    ~LaunchTimer() { if (g_timing) (void)hipEventRecord(g_events[slot + 1], st); }
+    ~LaunchTimer() { if (on) (void)hipEventRecord(g_events[slot + 1], st); }
 };
 
 // ---------------- segment -> (object, first photon) ----------------
@@ -892,7 +894,7 @@ int ims_device_info(int device, int* n_cu, int* n_xcd, int64_t* lds_bytes, int64
     return IMS_OK;
 }
 
-int ims_enable_timing(int on) { g_timing = (on != 0); g_events_used = 0; return IMS_OK; }
+int ims_enable_timing(int which) { g_timing = which; g_events_used = 0; return IMS_OK; }
 
 int ims_last_kernel_ms(float* ms, int* n_launches)
 {
@@ -919,7 +921,7 @@ int ims_shoot_accumulate(const ims_render_params_t* params, void* stream)
     if (params->n_segments == 0) return IMS_OK;
     hipStream_t st = (hipStream_t)stream;
     {
-        LaunchTimer tm(st);
+        LaunchTimer tm(st, 1);
         hipLaunchKernelGGL(k_shoot_accumulate, dim3(grid_for_segments(params->n_segments)), dim3(256), 0, st, *params);
     }
     HIP_TRY(hipGetLastError());
@@ -951,7 +953,7 @@ int ims_shoot_ops_photons(const ims_render_params_t* params, const int64_t* phot
     if (params->n_segments == 0) return IMS_OK;
     hipStream_t st = (hipStream_t)stream;
     {
-        LaunchTimer tm(st);
+        LaunchTimer tm(st, 2);
         hipLaunchKernelGGL(k_shoot_photons<true>, dim3(grid_for_segments(params->n_segments)), dim3(256), 0, st,
                            *params, photon_offset, *pool);
     }

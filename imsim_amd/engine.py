@@ -657,12 +657,15 @@ class Renderer:
         launch.photons = sum(it[3] for it in plan if it[0] == "render") + sum(it[5] for it in plan if it[0] == "shoot_pool")
         launch.object_rows = sum(it[4] for it in plan if it[0] == "render") + sum(it[6] for it in plan if it[0] in ("shoot_pool", "acc_pool"))
         launch.pool_photons = sum(it[5] for it in plan if it[0] == "shoot_pool")
-        # launches bracketed by the library's timing events: fused renders and pool shoots
-        launch.n_render_launches = sum(1 for it in plan if it[0] in ("render", "shoot_pool"))
-        # algorithmic bytes of those launches: fused = f64 image RMW (16 B/photon); pool shoot = the six
-        # f64 fields it writes (48 B/photon); both + one 256-B object row per object
-        launch.timed_bytes = (sum(it[3] * 16 + it[4] * 256 for it in plan if it[0] == "render")
-                              + sum(it[5] * 48 + it[6] * 256 for it in plan if it[0] == "shoot_pool"))
+        # the two photon-pipeline kernels the library can time (ims_enable_timing): launches per replay and
+        # their algorithmic bytes.  Fused render: f64 image RMW (16 B/photon); pool shoot: the six f64
+        # fields it writes (48 B/photon); both + one 256-B object row per object
+        launch.timed = {
+            1: (sum(1 for it in plan if it[0] == "render"),
+                sum(it[3] * 16 + it[4] * 256 for it in plan if it[0] == "render")),
+            2: (sum(1 for it in plan if it[0] == "shoot_pool"),
+                sum(it[5] * 48 + it[6] * 256 for it in plan if it[0] == "shoot_pool")),
+        }
         return launch
 
     def prepared(self, objects):
@@ -679,8 +682,7 @@ class Renderer:
         launch.keep = keep
         launch.photons = int(objects["n_phot"].sum())
         launch.object_rows = len(objects)
-        launch.n_render_launches = 1
-        launch.timed_bytes = launch.photons * 16 + launch.object_rows * 256
+        launch.timed = {1: (1, launch.photons * 16 + launch.object_rows * 256), 2: (0, 0)}
         return launch
 
     # -- pooled path (LSST_PhotonPoolingImage / LSST_Photons) --

@@ -440,11 +440,12 @@ int  ims_image_add(double* dst, const double* src, int64_t n, void* stream);
 int  ims_image_to_float(const double* src, float* dst, int64_t n, void* stream);
 
 /* ---- timing of the dominant kernel ----
- * After ims_enable_timing(1) every ims_shoot_accumulate / ims_shoot_ops_photons launch is bracketed by a hipEvent pair on its
- * stream.  ims_last_kernel_ms returns the SUM of their durations and their count since the last query
+ * After ims_enable_timing(which) every launch of the selected kernel is bracketed by a hipEvent pair on its
+ * stream: which = 1 k_shoot_accumulate (ims_shoot_accumulate), 2 k_shoot_photons<true> (ims_shoot_ops_photons),
+ * 0 = off.  ims_last_kernel_ms returns the SUM of their durations and their count since the last query
  * (and resets the accumulation). */
 int  ims_last_kernel_ms(float* ms, int* n_launches);
-int  ims_enable_timing(int on);
+int  ims_enable_timing(int which);
 
 /* ---- numerics probe used by the parity tests: evaluates the spec's elementary functions on device ----
  * which: 0 log, 1 exp, 2 sincos2pi (2 outputs), 3 atan, 4 sincos (2), 5 tanh, 6 gaussian pair of draw(seed,obj,i,slot) (2) */

@@ -170,7 +170,7 @@ STRUCTS = [Object, RadialTables, LinTables, PsfComponent, Op, Surface, TanSip, O
 EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_info", "ims_shoot_accumulate",
            "ims_shoot_photons", "ims_shoot_ops_photons", "ims_accumulate_segments", "ims_run_plan",
            "ims_fft_kspace_fill", "ims_fft_finish", "ims_fft_spikes", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
-           "ims_sensor_update_distortions", "ims_image_add", "ims_image_to_float", "ims_fill_derived_op", "ims_fill_derived_medium", "ims_last_kernel_ms", "ims_enable_timing",
+           "ims_sensor_update_distortions", "ims_image_add", "ims_image_to_float", "ims_fill_derived_op", "ims_fill_derived_medium", "ims_sensor_pixel_areas", "ims_flat_add", "ims_last_kernel_ms", "ims_enable_timing",
            "ims_struct_size", "ims_test_math"]
 
 _LIB_PATH = os.environ.get("IMSIM_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libimsim_hip.so")
@@ -213,6 +213,8 @@ def load():
     lib.ims_sensor_update_distortions.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_vp, c_i64, c_vp, C.c_uint32, c_vp]
     lib.ims_image_add.argtypes = [c_vp, c_vp, c_i64, c_vp]
     lib.ims_image_to_float.argtypes = [c_vp, c_vp, c_i64, c_vp]
+    lib.ims_sensor_pixel_areas.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_vp, c_vp, c_vp]
+    lib.ims_flat_add.argtypes = [c_vp, c_vp, c_d, c_d, c_u64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]
     lib.ims_fill_derived_op.argtypes = [c_vp]
     lib.ims_fill_derived_medium.argtypes = [c_i32, C.POINTER(c_d)]
     lib.ims_fft_kspace_fill.argtypes = [C.POINTER(FftParams), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]

@@ -18,7 +18,7 @@ import numpy as np
 import yaml
 
 from . import _abi, atm_psf, catalog, configs, diffraction, fft_draw, instcat, lsst_image, optics as opticsmod
-from . import sensor as sensormod, tables, treerings
+from . import flat, sensor as sensormod, tables, treerings
 from .engine import Scene, SensorSetup, make_slots
 from .lsst_image import GalSimConfigError
 
@@ -185,6 +185,7 @@ for _name in ("LSST_Silicon", "LSST_Photons"):
     RegisterStampType(_name, _name)
 RegisterImageType("LSST_Image", lsst_image.LSST_ImageBuilder)
 RegisterImageType("LSST_PhotonPoolingImage", lsst_image.LSST_PhotonPoolingImageBuilder)
+RegisterImageType("LSST_Flat", flat.LSST_FlatBuilder)
 RegisterOutputType("LSST_CCD", "LSST_CCD")
 for _name in ("atm_psf", "tree_rings", "instance_catalog", "opsim_data", "telescope", "sky_model", "sky_catalog", "checkpoint",
               "vignetting", "table_row"):
@@ -290,6 +291,37 @@ class ProcessResult:
         self.images, self.truth, self.ignored, self.det_names = [], [], [], []
 
 
+def _process_flat(cfg, ev, image, res, device, data_dir):
+    """`image.type: LSST_Flat` (imsim/flat.py): counts_per_pixel electrons per pixel through the pixel-area
+    feedback of the (optional) Silicon sensor; sed-weighted flats (flat.py:237-262) are not built."""
+    from .engine import Renderer
+    if "sed" in image:
+        raise GalSimConfigError("LSST_Flat with an sed (photon branch, flat.py:237-262) is not supported on this path")
+    builder = flat.LSST_FlatBuilder()
+    img_cfg = {k: ev.value(v) for k, v in image.items() if k in flat.FLAT_REQ or k in flat.FLAT_OPT}
+    if not (img_cfg.get("xsize") or img_cfg.get("size")):
+        det_name = ev.value(image.get("det_name", "R22_S11"))
+        img_cfg["xsize"], img_cfg["ysize"] = lsst_image.DETECTOR_SIZE[det_type_of(det_name)]
+    nx, ny = builder.setup(img_cfg)
+    seed = int(ev.value(image.get("random_seed", 0)))
+    sens = image.get("sensor", "")
+    tr, center, strength, on = None, (0.0, 0.0), 1.0, False
+    if isinstance(sens, dict) and sens.get("type", "Silicon") == "Silicon":
+        on = True
+        strength = float(sens.get("strength", 1.0))
+        func = ev.value(sens["treering_func"]) if "treering_func" in sens else None
+        if func is not None:
+            tr, center = func, tuple(ev.value(sens.get("treering_center", (0.0, 0.0))))
+    scene = configs.scene_flat(nx, ny, seed=seed, sensor=on, treering=tr, treering_center=center, strength=strength,
+                               buffer_size=builder.buffer_size)
+    renderer = Renderer(scene, device)
+    img = builder.build_image(renderer, seed=seed)
+    res.images.append(img.to(renderer.torch.float32).cpu().numpy())
+    res.det_names.append(str(image.get("det_name", "flat")))
+    res.truth.append({"counts_per_pixel": builder.counts_per_pixel, "niter": builder.iterations()[0]})
+    return res
+
+
 def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=None, logger=None):
     """galsim.config.Process restricted to this path: reads inputs, then for every requested CCD
     builds the scene and runs the image builder on the GPU.  Returns a ProcessResult."""
@@ -327,6 +359,8 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
     itype = image.get("type", "LSST_Image")
     if itype not in valid_image_types:
         raise GalSimConfigError(f"Invalid image type {itype}")
+    if itype == "LSST_Flat":
+        return _process_flat(cfg, ev, image, res, device, data_dir)
     stamp_cfg = cfg.get("stamp", {})
     stype = stamp_cfg.get("type", "LSST_Silicon")
     if stype not in valid_stamp_types:

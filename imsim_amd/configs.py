@@ -162,6 +162,26 @@ def silicon_setup(nx, ny, xmin=1, ymin=1, model_name="lsst_e2v_50_4", tree_rings
     return SensorSetup(model=model, abs_wl=wl, abs_len=al, slots=slots, **kw)
 
 
+def scene_flat(nx=256, ny=256, seed=1234, sensor=True, treering=None, treering_center=(0.0, 0.0), strength=1.0,
+               buffer_size=5):
+    """Scene of an `LSST_Flat` image (tests/test_flats.py): a bare CCD, optionally with the default Silicon
+    model (no tree rings unless `treering`, a treerings.TreeRingTable, is given).  The working image is the
+    CCD plus `buffer_size` pixels on every side (image.bounds.withBorder(buffer_size), imsim/flat.py:166), so
+    that the pixels that are kept see charge on all sides; flat.crop() cuts the border off again."""
+    b = int(buffer_size)
+    nx, ny = nx + 2 * b, ny + 2 * b
+    sc = Scene(nx=nx, ny=ny, xmin=1 - b, ymin=1 - b, seed=seed)
+    sc.flat_buffer = b
+    if sensor:
+        model = sensormod.load_silicon_model(os.path.join(DATA_DIR, "sensor_models", "lsst_itl_50_4"), strength=strength)
+        wl, al = tables.silicon_abs_length_table()
+        kw = {}
+        if treering is not None:
+            kw = dict(tr_table=treering.f, tr_table2=treering.f2, tr_dr=treering.dr, tr_center=tuple(treering_center))
+        sc.sensor = SensorSetup(model=model, abs_wl=wl, abs_len=al, slots=make_slots([(1 - b, 1 - b, nx, ny)]), **kw)
+    return sc
+
+
 def c3_ops(exptime=30.0, base_wavelength=620.0, shift_photons=1.0):
     """The default photon_ops chain, config/imsim-config.yaml:281-320 (r band: FocusDepth depth 0)."""
     rad2as = 180.0 / math.pi * 3600.0

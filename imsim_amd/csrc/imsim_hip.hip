@@ -699,6 +699,51 @@ __global__ __launch_bounds__(256) void k_refresh_changed(const ims_sensor_t* __r
     bb[4] = oxmin; bb[5] = oxmax; bb[6] = oymin; bb[7] = oymax;
 }
 
+// ---------------- LSST_Flat ----------------
+constexpr long long FLAT_ID_BASE = 0x7F00000000ll;      // object id space of the flat builder's Poisson streams
+
+// Silicon::fillWithPixelAreas: shoelace area of the (distorted) polygon of every pixel of one slot
+__global__ __launch_bounds__(256) void k_pixel_areas(const ims_sensor_t* __restrict__ sp, int slot, double* __restrict__ area,
+                                                     long long* __restrict__ sum_q32)
+{
+    const ims_sensor_t& s = *sp;
+    const ims_bf_slot_t bs = s.bf_slots[slot];
+    const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (int64_t)sl.nx * sl.ny) return;
+    const int i = (int)(p % sl.nx), j = (int)(p / sl.nx);
+    const int nv = 4 * s.num_vertices + 4;
+    double x0, y0, xp, yp, a2 = 0.0;
+    polygon_vertex(s, sl, i, j, 0, 1.0, x0, y0);
+    xp = x0; yp = y0;
+    for (int k = 1; k <= nv; ++k) {
+        double xk = x0, yk = y0;
+        if (k < nv) polygon_vertex(s, sl, i, j, k, 1.0, xk, yk);
+        a2 = a2 + (xp * yk - xk * yp);
+        xp = xk; yp = yk;
+    }
+    const double a = 0.5 * a2;
+    area[p] = a;
+    atomicAdd((unsigned long long*)sum_q32, (unsigned long long)(long long)floor(a * 0x1.0p32 + 0.5));
+}
+
+__global__ __launch_bounds__(256) void k_flat_add(const double* __restrict__ area, const double* __restrict__ base, double level,
+                                                  double inv_mean_area, uint64_t seed, int64_t iteration, int nx, int ny,
+                                                  double* __restrict__ image, double* __restrict__ delta)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (int64_t)nx * ny) return;
+    double mean = level;
+    if (base != nullptr) mean = mean * base[p];
+    if (area != nullptr) mean = mean * (area[p] * inv_mean_area);
+    const double v = poisson(mean, seed, FLAT_ID_BASE + iteration, p);
+    image[p] = image[p] + v;
+    if (delta != nullptr) {
+        const int i = (int)(p % nx), j = (int)(p / nx);
+        delta[(int64_t)j * (nx + 1) + i] = delta[(int64_t)j * (nx + 1) + i] + v;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_zero_delta(const ims_sensor_t* __restrict__ sp, int64_t cell_begin, int64_t cell_count)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1153,6 +1198,33 @@ int ims_fft_finish(const ims_fft_params_t* params, const ims_fft_object_t* objec
     if (n_objects <= 0 || n_pix <= 0) return IMS_OK;
     hipLaunchKernelGGL(k_fft_finish, dim3(grid_for_pool(n_pix)), dim3(256), 0, (hipStream_t)stream, *params, objects_dev,
                        n_objects, pix_prefix_dev, n_pix, rbuf);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+int ims_sensor_pixel_areas(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host, int32_t slot,
+                           double* area_dev, long long* sum_q32_dev, void* stream)
+{
+    if (!sensor_dev || !area_dev || !sum_q32_dev) return set_err(IMS_ERR_ARG, "NULL argument");
+    if (!sensor_host || !sensor_host->bf_slots) return set_err(IMS_ERR_ARG, "sensor_host/bf_slots is NULL (host copy of the slot table required)");
+    if (slot < 0 || slot >= sensor_host->n_bf_slots) return set_err(IMS_ERR_ARG, "slot out of range");
+    const ims_bf_slot_t& b = sensor_host->bf_slots[slot];
+    const int64_t n = (int64_t)b.nx * b.ny;
+    if (n <= 0) return IMS_OK;
+    hipLaunchKernelGGL(k_pixel_areas, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sensor_dev, slot,
+                       area_dev, sum_q32_dev);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+int ims_flat_add(const double* area_dev, const double* base_dev, double level, double inv_mean_area, uint64_t seed,
+                 int64_t iteration, int32_t nx, int32_t ny, double* image_dev, double* delta_dev, void* stream)
+{
+    if (!image_dev) return set_err(IMS_ERR_ARG, "image is NULL");
+    if (nx <= 0 || ny <= 0) return IMS_OK;
+    const int64_t n = (int64_t)nx * ny;
+    hipLaunchKernelGGL(k_flat_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, area_dev, base_dev,
+                       level, inv_mean_area, seed, iteration, nx, ny, image_dev, delta_dev);
     HIP_TRY(hipGetLastError());
     return IMS_OK;
 }

@@ -434,6 +434,19 @@ typedef struct ims_plan_item {
 int  ims_run_plan(const ims_plan_item_t* items, int64_t n_items, const ims_sensor_t* sensor_dev,
                   const ims_sensor_t* sensor_host, unsigned char* changed_dev, void* const* streams, int32_t n_streams);
 
+/* ---- LSST_Flat (imsim/flat.py:133-283, area branch) ----
+ * One iteration of the flat builder is: area = sensor.calculate_pixel_areas(section); temp = base * area / mean(area);
+ * Poisson(temp); section += temp.  ims_sensor_pixel_areas writes the polygon area of every pixel of a slot's
+ * region (row-major [ny][nx]) and adds round(area * 2^32) of every pixel to *sum_q32 (an exact, order-independent
+ * sum: mean area = sum_q32 / (nx ny 2^32)).  ims_flat_add draws the Poisson deviate of
+ * level * base[p] * area[p] * inv_mean_area for every pixel (stream keyed by (seed, iteration, pixel)) and adds it
+ * to image[p] and, when delta is given, to delta[j*(nx+1)+i] (the slot's delta-charge image, consumed by the next
+ * ims_sensor_update_distortions).  area / base may be NULL (= 1). */
+int  ims_sensor_pixel_areas(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host, int32_t slot,
+                            double* area_dev, long long* sum_q32_dev, void* stream);
+int  ims_flat_add(const double* area_dev, const double* base_dev, double level, double inv_mean_area, uint64_t seed,
+                  int64_t iteration, int32_t nx, int32_t ny, double* image_dev, double* delta_dev, void* stream);
+
 /* ---- image helpers ---- */
 int  ims_image_add(double* dst, const double* src, int64_t n, void* stream);
 /* round the f64 accumulation image to the float32 CCD image the reference hands on (galsim.ImageF) */

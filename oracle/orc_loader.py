@@ -48,6 +48,9 @@ def load():
         lib.orc_fft_spikes.argtypes = [C.POINTER(_abi.FftParams), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         lib.orc_test_stencil.argtypes = [C.POINTER(_abi.Spikes), C.c_int, C.c_void_p]
         lib.orc_test_gauss.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_uint32, C.c_void_p]
+        lib.orc_sensor_pixel_areas.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        lib.orc_flat_add.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_uint64, C.c_int64, C.c_int32, C.c_int32,
+                                     C.c_void_p, C.c_void_p]
         lib.orc_fill_derived_op.argtypes = [C.c_void_p]
         lib.orc_fill_derived_medium.argtypes = [C.c_int32, C.POINTER(C.c_double)]
         _lib = lib
@@ -201,6 +204,36 @@ class OracleScene:
 
     def update_distortions(self, first_slot, n_slots):
         self.lib.orc_sensor_update_distortions(self.bound.sensor_dev_ptr, first_slot, n_slots)
+
+    def build_flat(self, counts_per_pixel, max_counts_per_iter, seed=0, base=None):
+        """CPU counterpart of imsim_amd.flat.LSST_FlatBuilder.build_image (imsim/flat.py:133-268, area branch)"""
+        import math
+        sc = self.scene
+        niter = int(math.ceil(counts_per_pixel / max_counts_per_iter))
+        counts_per_iter = counts_per_pixel / niter
+        n = sc.nx * sc.ny
+        level = counts_per_iter
+        b = None
+        if base is not None:
+            b = np.ascontiguousarray(base, dtype=np.float64)
+            level = counts_per_iter / float(b.mean())
+        silicon = sc.sensor is not None
+        area = np.empty(n, dtype=np.float64)
+        for it in range(niter):
+            if silicon:
+                acc = np.zeros(1, dtype=np.int64)
+                self.lib.orc_sensor_pixel_areas(self.bound.sensor_dev_ptr, 0, area.ctypes.data, acc.ctypes.data)
+                mean_area = float(int(acc[0])) / float(n) * 2.0 ** -32
+                delta = self.bound.sensor_arrays["delta"].view(np.float64)
+                self.lib.orc_flat_add(area.ctypes.data, b.ctypes.data if b is not None else None, level, 1.0 / mean_area,
+                                      seed, it, sc.nx, sc.ny, self.image64.ctypes.data, delta.ctypes.data)
+                if it + 1 < niter:
+                    self.update_distortions(0, 1)
+            else:
+                self.lib.orc_flat_add(None, b.ctypes.data if b is not None else None, level, 1.0, seed, it, sc.nx, sc.ny,
+                                      self.image64.ctypes.data, None)
+        b = int(getattr(sc, "flat_buffer", 0))
+        return self.image64[b:sc.ny - b, b:sc.nx - b] if b else self.image64
 
     def sensor_array(self, name):
         return self.bound.sensor_arrays[name].view(np.float64)

@@ -78,6 +78,47 @@ static void assemble_polygon(const ims_sensor_t* s, const ims_bf_slot_t* sl, int
     }
 }
 
+/* ---------- LSST_Flat, area branch (imsim/flat.py:209-236) ---------- */
+#define ORC_FLAT_ID_BASE 0x7F00000000ll
+double orc_poisson(double mean, uint64_t seed, int64_t obj_id, int64_t pixel);
+
+/* Silicon::fillWithPixelAreas: shoelace area of every pixel polygon of a slot; the exact sum of the
+ * areas quantised to 2^-32 goes to *sum_q32 */
+void orc_sensor_pixel_areas(const ims_sensor_t* s, int slot, double* area, long long* sum_q32)
+{
+    const ims_bf_slot_t* sl = &s->bf_slots[slot];
+    const int nv = 4 * s->num_vertices + 4;
+    double vx[4 * 32 + 4], vy[4 * 32 + 4];
+    for (int j = 0; j < sl->ny; ++j)
+        for (int i = 0; i < sl->nx; ++i) {
+            assemble_polygon(s, sl, i, j, 1.0, vx, vy);
+            double a2 = 0.0;
+            for (int k = 1; k <= nv; ++k) {
+                int kk = (k < nv) ? k : 0;
+                a2 = a2 + (vx[k - 1] * vy[kk] - vx[kk] * vy[k - 1]);
+            }
+            double a = 0.5 * a2;
+            area[(int64_t)j * sl->nx + i] = a;
+            *sum_q32 += (long long)floor(a * 0x1.0p32 + 0.5);
+        }
+}
+
+void orc_flat_add(const double* area, const double* base, double level, double inv_mean_area, uint64_t seed,
+                  int64_t iteration, int32_t nx, int32_t ny, double* image, double* delta)
+{
+    for (int64_t p = 0; p < (int64_t)nx * ny; ++p) {
+        double mean = level;
+        if (base) mean = mean * base[p];
+        if (area) mean = mean * (area[p] * inv_mean_area);
+        double v = orc_poisson(mean, seed, ORC_FLAT_ID_BASE + iteration, p);
+        image[p] = image[p] + v;
+        if (delta) {
+            int i = (int)(p % nx), j = (int)(p / nx);
+            delta[(int64_t)j * (nx + 1) + i] = delta[(int64_t)j * (nx + 1) + i] + v;
+        }
+    }
+}
+
 static void refresh_bounds(const ims_sensor_t* s, const ims_bf_slot_t* sl, int i, int j)
 {
     const int nV = s->num_vertices, nv = 4 * nV + 4;

@@ -741,6 +741,13 @@ class Renderer:
             cache[1][first_slot] = (prefix, self.torch.from_numpy(prefix).to(self.device))
         return cache[1][first_slot]
 
+    def delta_tensor(self, slot=0):
+        """f64 device view of a slot's delta-charge image ((nx+1)*(ny+1) owner cells)"""
+        sl = self.bound._slots_host[slot]
+        n = (int(sl["nx"]) + 1) * (int(sl["ny"]) + 1)
+        off = int(sl["offset"])
+        return self.bound.sensor_arrays["delta"].view(self.torch.float64)[off:off + n]
+
     def update_distortions(self, first_slot, n_slots, stream=None, bf_tag=0):
         if not hasattr(self, "_changed"):
             cells = self.bound.static_cells + int(self.scene.sensor.scratch_cells)

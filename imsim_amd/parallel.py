@@ -1,9 +1,12 @@
 """Multi-GPU: object sharding and the CCD image reduce.
 
 One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI on ROCm).  Objects are
-independent in LSST_Image mode, so the only exchange is ONE sum-reduce of the fp32 CCD image onto
-rank 0 (64 MiB over a ring: per-link bound, ~0.4 ms).  Because every photon's random stream is
-addressed by (object id, photon index), the reduced image does not depend on the rank count."""
+independent in LSST_Image mode, so the only exchange is ONE sum-reduce of the f64 CCD accumulation
+image onto rank 0 (128 MiB over a ring: per-link bound, ~1 ms).  Photon-pooling mode shares the
+sensor state between all objects: there the delta-charge image is all-reduced before every
+pixel-boundary recalculation (`allreduce_delta`, once per photon batch).  Because every photon's
+random stream is addressed by (object id, photon index) and unit fluxes make the sums exact, the
+result does not depend on the rank count."""
 import numpy as np
 
 
@@ -44,3 +47,13 @@ def reduce_image(image, dst=0):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.reduce(image, dst=dst, op=dist.ReduceOp.SUM)
     return image
+
+
+def allreduce_delta(delta):
+    """Sum the delta-charge image (charge accumulated since the last recalculation) over all ranks, in
+    place: afterwards every rank holds the charge of ALL objects and runs the same
+    updatePixelDistortions (imsim/photon_pooling.py:159 `recalc=(subbatch_num == 0)` semantics)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(delta, op=dist.ReduceOp.SUM)
+    return delta

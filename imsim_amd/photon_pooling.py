@@ -12,6 +12,8 @@ import itertools
 
 import numpy as np
 
+from . import parallel
+
 from ._abi import OBJECT_DTYPE, IMS_OBJ_FAINT
 from .stamp import ProcessingMode, ObjectInfo
 
@@ -71,13 +73,20 @@ def check_stamp_type(stamp_type):
         raise GalSimConfigValueError(f"Must use stamp.type = LSST_Photons with LSST_PhotonPoolingImage. ({stamp_type})")
 
 
-def build_image(renderer, objects, modes, nbatch=10, nsubbatch=50, seed=0, realized=None):
+def build_image(renderer, objects, modes, nbatch=10, nsubbatch=50, seed=0, realized=None, rank=0, world=1):
     """LSST_PhotonPoolingImageBuilder.buildImage for the photon-shooting objects
     (imsim/photon_pooling.py:116-168).
 
     objects: OBJECT_DTYPE table (n_phot = phot_flux of the whole object); modes: ProcessingMode per row.
     Photon index ranges follow the integer flux split, so the union over batches is exactly the
-    object's photon stream.  Returns the number of photons accumulated."""
+    object's photon stream.  Returns the number of photons accumulated.
+
+    world > 1 (one process per GPU): every rank builds the same batch tables from the FULL
+    object table and shoots only the rows it owns (parallel.assign_ranks).  In pooling mode the sensor
+    state is shared by all objects, so before every recalculation the delta-charge image accumulated
+    since the last one is all-reduced (parallel.allreduce_delta) and every rank runs the identical
+    updatePixelDistortions; the per-rank images are summed by the caller (parallel.reduce_image).  Unit
+    fluxes make both sums exact, so the result equals the single-process one bit for bit."""
     objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
     infos = [ObjectInfo(i, int(objects["n_phot"][i]), modes[i]) for i in range(len(objects))]
     _, phot, faint = partition_objects(infos, nbatch)
@@ -90,6 +99,7 @@ def build_image(renderer, objects, modes, nbatch=10, nsubbatch=50, seed=0, reali
     F = objects["n_phot"][phot_idx].astype(np.int64) if len(phot_idx) else np.zeros(0, np.int64)
     total = 0
     sensor_on = renderer.scene.sensor is not None
+    owner = parallel.assign_ranks(objects["n_phot"], world)
     len_smallest = None
     batch_tables = []
     for i in range(nb):
@@ -117,17 +127,23 @@ def build_image(renderer, objects, modes, nbatch=10, nsubbatch=50, seed=0, reali
             t = table[sub]
             keep = t["n_phot"] > 0
             t, idx = t[keep], index[sub][keep]
-            if len(t) == 0:
-                continue
             if sensor_on and s == 0 and i > 0:
                 # recalc=(subbatch_num == 0), resume afterwards; only tiles near the previous batch's charge move
-                renderer.update_distortions(0, 1, bf_tag=(i - 1) % 255 + 1)
+                # (with several ranks the tile marks are rank-local, so every tile is visited)
+                if world > 1:
+                    parallel.allreduce_delta(renderer.delta_tensor(0))
+                renderer.update_distortions(0, 1, bf_tag=((i - 1) % 255 + 1) if world == 1 else 0)
+            if world > 1:
+                mine = owner[idx] == rank
+                t, idx = t[mine], idx[mine]
+            if len(t) == 0:
+                continue
             pool = renderer.shoot_photons(t)
             renderer.apply_ops(pool)
             tmp = None
             if realized is not None:
                 tmp = renderer.torch.zeros(len(t), dtype=renderer.torch.float64, device=renderer.device)
-            renderer.accumulate(pool, realized=tmp, bf_tag=(i % 255 + 1) if sensor_on else 0)
+            renderer.accumulate(pool, realized=tmp, bf_tag=(i % 255 + 1) if (sensor_on and world == 1) else 0)
             if realized is not None:
                 realized.index_add_(0, renderer.torch.from_numpy(idx).to(renderer.device), tmp)
             total += int(t["n_phot"].sum())

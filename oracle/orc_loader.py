@@ -188,7 +188,7 @@ class OracleScene:
         for k in range(len(self.scene.ops)):
             self.lib.orc_apply_op(C.byref(P), k, C.byref(ph), pool.offs.ctypes.data)
 
-    def accumulate(self, pool, realized=None, want_pixel_index=False):
+    def accumulate(self, pool, realized=None, want_pixel_index=False, bf_tag=0):
         img = np.zeros((self.scene.ny, self.scene.nx), dtype=np.float64)
         P = self._pool_params(pool, img.ctypes.data)
         ph = pool.struct()
@@ -202,7 +202,19 @@ class OracleScene:
     def init_boundaries(self, first_slot, n_slots):
         self.lib.orc_sensor_init_boundaries(self.bound.sensor_dev_ptr, first_slot, n_slots)
 
-    def update_distortions(self, first_slot, n_slots):
+    # the names Renderer uses, so that host logic written against the engine (imsim_amd.photon_pooling.build_image)
+    # can be exercised on CPU-only machines with the oracle standing in (tests/test_multi_gpu_gloo.py)
+    def shoot_photons(self, objects):
+        return self.shoot_pool(objects)
+
+    def delta_tensor(self, slot=0):
+        import torch
+        sl = self.bound._slots_host[slot]
+        n = (int(sl["nx"]) + 1) * (int(sl["ny"]) + 1)
+        off = int(sl["offset"])
+        return torch.from_numpy(self.bound.sensor_arrays["delta"].view(np.float64))[off:off + n]
+
+    def update_distortions(self, first_slot, n_slots, bf_tag=0):
         self.lib.orc_sensor_update_distortions(self.bound.sensor_dev_ptr, first_slot, n_slots)
 
     def build_flat(self, counts_per_pixel, max_counts_per_iter, seed=0, base=None):

@@ -21,3 +21,14 @@ def assert_bits_equal(a, b, what=""):
         idx = np.flatnonzero(a.reshape(-1) != b.reshape(-1))
         raise AssertionError(f"{what}: {idx.size} of {a.size} values differ, first at {idx[:5]}: "
                              f"{a.reshape(-1)[idx[:5]]} vs {b.reshape(-1)[idx[:5]]}")
+
+
+def c3_small_case(n_obj=150, n=512, flux_seed=1, scratch=2_000_000, **kw):
+    """a small C3 scene (full op chain, Silicon sensor with tree rings) and its object table"""
+    scene = configs.scene_c3(nx=n, ny=n, **kw)
+    if scene.sensor is not None:
+        scene.sensor.scratch_cells = scratch
+    cat = catalog.synthetic_catalog(n_obj, nx=n, ny=n)
+    phot = catalog.realize_fluxes(cat["nominal_flux"], flux_seed)
+    objects, sizes = configs.c3_objects(cat, phot, scene)
+    return scene, objects

@@ -28,7 +28,7 @@ def _worker(rank, world, port, out_path):
     dist.all_gather(gathered, counts)
     orc = orc_loader.OracleScene(scene)
     orc.render(mine)
-    img = torch.from_numpy(orc.image.copy())
+    img = torch.from_numpy(orc.image64.copy())
     parallel.reduce_image(img, dst=0)
     if rank == 0:
         np.savez(out_path, image=img.numpy(), counts=torch.stack(gathered).numpy())
@@ -46,7 +46,7 @@ def test_two_rank_sharded_render_equals_single_process(tmp_path):
     scene, objects, _ = small_case(n_obj=120, nx=256, ny=256, flux_seed=9)
     orc = orc_loader.OracleScene(scene)
     orc.render(objects)
-    assert np.array_equal(res["image"], orc.image)
+    assert np.array_equal(res["image"], orc.image64)
     counts = res["counts"]
     assert counts[:, 0].sum() == len(objects)
     assert counts[:, 1].sum() == objects["n_phot"].sum()
@@ -61,3 +61,51 @@ def test_shard_objects_is_a_partition():
     for world in (1, 2, 3, 8):
         ids = np.concatenate([parallel.shard_objects(objects, r, world)["obj_id"] for r in range(world)])
         assert sorted(ids) == sorted(objects["obj_id"])
+
+
+def _pooling_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import c3_small_case
+    from imsim_amd import parallel, photon_pooling, stamp
+    from oracle import orc_loader
+    scene, objects = c3_small_case(n_obj=60, n=128, flux_seed=5, scratch=0)
+    scene.track_static_delta = 1
+    orc = orc_loader.OracleScene(scene)
+    modes = stamp.classify(objects["n_phot"].astype(float), 100.0)
+    n = photon_pooling.build_image(orc, objects, modes, nbatch=4, nsubbatch=3, seed=11, rank=rank, world=world)
+    img = torch.from_numpy(orc.image64.copy())
+    parallel.reduce_image(img, dst=0)
+    tot = torch.tensor([n])
+    dist.all_reduce(tot)
+    if rank == 0:
+        np.savez(out_path, image=img.numpy(), boundary=orc.sensor_array("boundary"), photons=tot.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_photon_pooling_with_brighter_fatter_equals_single_process(tmp_path):
+    """in pooling mode all objects share the sensor state; the ranks all-reduce the delta
+    charge before every recalculation and must end with the single-process image and boundaries."""
+    from helpers import c3_small_case
+    from imsim_amd import photon_pooling, stamp
+    from oracle import orc_loader
+    out = str(tmp_path / "pooled.npz")
+    port = 31500 + (os.getpid() % 2000)
+    mp.start_processes(_pooling_worker, args=(2, port, out), nprocs=2, join=True, start_method="spawn")
+    res = np.load(out)
+    scene, objects = c3_small_case(n_obj=60, n=128, flux_seed=5, scratch=0)
+    scene.track_static_delta = 1
+    orc = orc_loader.OracleScene(scene)
+    modes = stamp.classify(objects["n_phot"].astype(float), 100.0)
+    n = photon_pooling.build_image(orc, objects, modes, nbatch=4, nsubbatch=3, seed=11)
+    assert int(res["photons"][0]) == n == int(objects["n_phot"].sum())
+    assert np.array_equal(res["image"], orc.image64)
+    assert np.array_equal(res["boundary"], orc.sensor_array("boundary"))
+    # brighter-fatter did act: the boundaries differ from a run without recalculation
+    ref = orc_loader.OracleScene(scene)
+    photon_pooling.build_image(ref, objects, modes, nbatch=1, nsubbatch=3, seed=11)
+    assert not np.array_equal(ref.sensor_array("boundary"), orc.sensor_array("boundary"))

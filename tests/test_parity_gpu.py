@@ -207,11 +207,11 @@ def test_pooling_mode_brighter_fatter_is_bit_exact(torch_cuda):
         part["flags"] = 0
         part = part[part["n_phot"] > 0]
         if i > 0:
-            r.update_distortions(0, 1)
-            orc.update_distortions(0, 1)
+            r.update_distortions(0, 1, bf_tag=i)          # GPU: visit only tiles in reach of batch i-1's charge
+            orc.update_distortions(0, 1)                  # oracle: every cell
         pool = r.shoot_photons(part)
         r.apply_ops(pool)
-        pix = r.accumulate(pool, want_pixel_index=True)
+        pix = r.accumulate(pool, want_pixel_index=True, bf_tag=i + 1)
         opool = orc.shoot_pool(part)
         orc.apply_ops(opool)
         opix = orc.accumulate(opool, want_pixel_index=True)

@@ -47,7 +47,8 @@ def r0_500_for_seeing(wavelength, L0, target_seeing):
 def von_karman_screen(npix, scale, r0_500, L0, rng, kmax=np.inf, xp=np):
     """One phase screen [nm of optical path] (galsim AtmosphericScreen restated): white Gaussian
     noise filtered in Fourier space by psi(f) = sqrt(0.00058) r0^(-5/6) (f^2 + L0^-2)^(-11/12)
-    * npix * 2^(1/4) / screen_size * 500, low-passed at 2 pi |f| <= kmax (the part above kmax is
+    * npix / screen_size * 500 (so that the screen has the von Karman structure function: variance per
+    mode = PSD * df^2), low-passed at 2 pi |f| <= kmax (the part above kmax is
     the second kick).  `xp` = numpy, or torch for an on-device build of the 8192^2 screens."""
     size = npix * scale
     if xp is np:
@@ -55,7 +56,7 @@ def von_karman_screen(npix, scale, r0_500, L0, rng, kmax=np.inf, xp=np):
         fsq = fx[None, :] ** 2 + fx[:, None] ** 2
         with np.errstate(divide="ignore"):
             psi = (math.sqrt(0.00058) * r0_500 ** (-5.0 / 6.0) * (fsq + 1.0 / L0 ** 2) ** (-11.0 / 12.0)
-                   * npix * math.sqrt(math.sqrt(2.0)) / size * 500.0)
+                   * npix / size * 500.0)
         psi[0, 0] = 0.0
         if np.isfinite(kmax):
             psi[(2 * np.pi) ** 2 * fsq > kmax ** 2] = 0.0
@@ -66,7 +67,7 @@ def von_karman_screen(npix, scale, r0_500, L0, rng, kmax=np.inf, xp=np):
     fx = torch.fft.fftfreq(npix, scale, dtype=torch.float64, device=dev)
     fsq = fx[None, :] ** 2 + fx[:, None] ** 2
     psi = (math.sqrt(0.00058) * r0_500 ** (-5.0 / 6.0) * (fsq + 1.0 / L0 ** 2) ** (-11.0 / 12.0)
-           * npix * math.sqrt(math.sqrt(2.0)) / size * 500.0)
+           * npix / size * 500.0)
     psi[0, 0] = 0.0
     if np.isfinite(kmax):
         psi[(2 * math.pi) ** 2 * fsq > kmax ** 2] = 0.0

@@ -252,9 +252,10 @@ def build_photon_ops(op_cfgs, ev, base_wavelength):
 
 
 def build_psf(psf_cfg, ev, scene_tables):
-    """psf field -> (Scene.psf list, k-space list for FFT mode, total FWHM, AtmosphericPSF or None)."""
+    """psf field -> (Scene.psf list, k-space list for FFT mode, total FWHM, AtmosphericPSF or None, extra k-tables
+    of the FFT-mode PSF)."""
     items = psf_cfg["items"] if psf_cfg.get("type") == "Convolve" else [psf_cfg]
-    psf, kpsf, fw2, atm = [], [], 0.0, None
+    psf, kpsf, fw2, atm, extra = [], [], 0.0, None, []
     s = 1.0 / 2.3548200450309493
     for it in items:
         t = it.get("type")
@@ -278,12 +279,14 @@ def build_psf(psf_cfg, ev, scene_tables):
             atm = ev.base["_atm_psf"]
             fw2 += atm.targetFWHM ** 2
             psf.append("ATM")
-            # FFT mode swaps PhaseScreenPSF -> VonKarman and SecondKick -> Airy (psf_utils.py:94-149); the
-            # Kolmogorov MTF of the same seeing stands in for both until the VonKarman k-table lands
-            kpsf.append((_abi.IMS_KPSF_KOLMOGOROV, 0, fft_draw.KOLMOGOROV_K0 / atm.targetFWHM))
+            # FFT mode swaps PhaseScreenPSF -> VonKarman and SecondKick -> Airy (make_fft_psf, psf_utils.py:94-149);
+            # their k-tables follow the two Sersic profile tables of the FftDrawer
+            kk, tabs = fft_draw.atmospheric_fft_kpsf(atm, atm.wlen_eff, first_table=2 + len(extra))
+            kpsf += kk
+            extra += tabs
         else:
             raise GalSimConfigError(f"psf type {t} is not supported on this path")
-    return psf, kpsf, math.sqrt(fw2), atm
+    return psf, kpsf, math.sqrt(fw2), atm, extra
 
 
 class ProcessResult:
@@ -412,7 +415,7 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
                                                      screen_scale=float(a.get("screen_scale", 0.1)), exponent=float(a.get("exponent", -0.3)),
                                                      device=torch.device(device))
         r2, cdf = configs.standard_tables()
-        psf, kpsf, fwhm_total, atm = build_psf(cfg["psf"], ev, {"kolmogorov": 2})
+        psf, kpsf, fwhm_total, atm, extra_ktables = build_psf(cfg["psf"], ev, {"kolmogorov": 2})
         if atm is not None:
             sk = atm.second_kick
             r2 = np.concatenate([r2, sk[0][None, :]])
@@ -470,7 +473,7 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
             builder.build_image(renderer, cat, phot, make_objects,
                                 fft_sb_thresh=float(ev.value(stamp_cfg.get("fft_sb_thresh", 0.0))), max_flux_simple=max_simple,
                                 draw_method=ev.value(stamp_cfg.get("draw_method", "auto")), kpsf=kpsf, fwhm_total=fwhm_total,
-                                diffraction_fft=dfft, wavelength=wl_eff, nrecalc=nrecalc, truth=truth)
+                                diffraction_fft=dfft, wavelength=wl_eff, nrecalc=nrecalc, truth=truth, extra_ktables=extra_ktables)
         renderer.synchronize()
         res.images.append(renderer.image_numpy())
         res.truth.append(truth)

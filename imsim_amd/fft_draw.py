@@ -30,6 +30,62 @@ def kolmogorov_gaussian_kpsf(fwhm_atm, fwhm_sys):
             (_abi.IMS_KPSF_GAUSSIAN, 0, fwhm_sys / 2.3548200450309493)]
 
 
+ARCSEC_PER_RAD = 206264.80624709636
+
+
+def vonkarman_structure_function(r, r0, L0):
+    """Phase structure function of von Karman turbulence (galsim.VonKarman):
+    D(r) = 0.17166 (L0/r0)^(5/3) [Gamma(5/6) / 2^(1/6) - (2 pi r / L0)^(5/6) K_5/6(2 pi r / L0)],
+    -> 6.8839 (r/r0)^(5/3) for r << L0."""
+    from scipy import special
+    r = np.asarray(r, dtype=np.float64)
+    x = 2.0 * math.pi * r / L0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        t = np.where(x > 0.0, x ** (5.0 / 6.0) * special.kv(5.0 / 6.0, np.where(x > 0.0, x, 1.0)), 1.005634917998590172)
+    return 0.1716613621245709486 * (L0 / r0) ** (5.0 / 3.0) * (1.005634917998590172 - t)
+
+
+def vonkarman_ktable(lam, r0_500, L0, qmax=tables.KTABLE_QMAX, npts=tables.KTABLE_NPTS):
+    """k-table of galsim.VonKarman(lam, r0_500, L0) -- what make_fft_psf puts in place of a PhaseScreenPSF
+    (imsim/psf_utils.py:117-121).  Returns (table over the common q grid, p0) with MTF(k) = table(k * p0),
+    k in rad/arcsec: the baseline is r = lam k / (2 pi) [m per radian of angle]; the grid spans 4 r0."""
+    r0 = r0_500 * (lam / 500.0) ** 1.2
+    q = np.linspace(0.0, qmax, npts)
+    unit = 4.0 * r0 / qmax                                   # metres of baseline per unit q
+    T = np.exp(-0.5 * vonkarman_structure_function(q * unit, r0, L0))
+    p0 = lam * 1.0e-9 * ARCSEC_PER_RAD / (2.0 * math.pi) / unit
+    return T, p0
+
+
+def airy_ktable(lam, diam, obscuration, qmax=tables.KTABLE_QMAX, npts=tables.KTABLE_NPTS):
+    """k-table of galsim.Airy(lam, diam, obscuration) -- make_fft_psf's stand-in for the SecondKick
+    (psf_utils.py:112-115): the autocorrelation of the annular pupil, zero beyond the baseline `diam`."""
+    from .atm_psf import annulus_mtf
+    q = np.linspace(0.0, qmax, npts)
+    unit = 1.02 * diam / qmax
+    T = annulus_mtf(q * unit, diam, obscuration)
+    p0 = lam * 1.0e-9 * ARCSEC_PER_RAD / (2.0 * math.pi) / unit
+    return T, p0
+
+
+def atmospheric_fft_kpsf(atm, wavelength, first_table, fwhm_sys=None):
+    """make_fft_psf (imsim/psf_utils.py:94-149) for an AtmosphericPSF evaluated at `wavelength` [nm]:
+    PhaseScreenPSF -> VonKarman(lam, r0_500_effective, L0), SecondKick -> Airy(lam, diam, obscuration), the
+    optional Gaussian optics term unchanged.  first_table: index the first extra k-table will get (after the
+    profile tables).  Returns (kpsf list for FftDrawer, list of extra k-tables)."""
+    kpsf, extra = [], []
+    T, p0 = vonkarman_ktable(wavelength, atm.r0_500, atm.L0)
+    kpsf.append((_abi.IMS_KPSF_TABLE, first_table + len(extra), p0))
+    extra.append(T)
+    if atm.second_kick is not None:
+        T, p0 = airy_ktable(wavelength, atm.diam, atm.obscuration)
+        kpsf.append((_abi.IMS_KPSF_TABLE, first_table + len(extra), p0))
+        extra.append(T)
+    if fwhm_sys:
+        kpsf.append((_abi.IMS_KPSF_GAUSSIAN, 0, fwhm_sys / 2.3548200450309493))
+    return kpsf, extra
+
+
 def max_surface_brightness(flux, kind, hlr, fwhm_total, pixel_scale=0.2):
     """Half the peak surface brightness [photons/pixel] of the PSF-convolved object, the quantity
     get_fft_psf_maybe compares with fft_sb_thresh (psf_utils.py:201-212).  Point sources: peak of
@@ -110,12 +166,15 @@ def fft_params(scene, kpsf, ktables, q_step, seed, add_noise=True, mem_put=None)
 class FftDrawer:
     """Batched FFT rendering into a Renderer's CCD image."""
 
-    def __init__(self, renderer, kpsf, sersic_indices=(1.0, 4.0), add_noise=True, diffraction_fft=None, wavelength=622.2):
+    def __init__(self, renderer, kpsf, sersic_indices=(1.0, 4.0), add_noise=True, diffraction_fft=None, wavelength=622.2,
+                 extra_ktables=()):
+        """extra_ktables: radial k-tables on the common q grid appended after the profile tables (the
+        VonKarman / Airy tables of atmospheric_fft_kpsf, addressed by IMS_KPSF_TABLE components)."""
         self.r = renderer
         self.torch = renderer.torch
         tabs = [tables.sersic_ktable(n) for n in sersic_indices]
         self.q_step = float(tabs[0][0][1] - tabs[0][0][0])
-        self.P, self._keep = fft_params(renderer.scene, kpsf, np.stack([t[1] for t in tabs]), self.q_step,
+        self.P, self._keep = fft_params(renderer.scene, kpsf, np.stack([t[1] for t in tabs] + list(extra_ktables)), self.q_step,
                                         renderer.scene.seed, add_noise, lambda a: renderer.mem.put(a, np.float64))
         self.P.image = renderer.image.data_ptr()
         set_spikes(self.P, diffraction_fft, wavelength)

@@ -66,7 +66,7 @@ class LSST_ImageBuilder(LSST_ImageBuilderBase):
 
     def build_image(self, renderer, cat, phot_flux, make_objects, fft_sb_thresh=0.0, max_flux_simple=100.0,
                     draw_method="auto", kpsf=None, fwhm_total=0.8, diffraction_fft=None, wavelength=622.2,
-                    nrecalc=None, truth=None):
+                    nrecalc=None, truth=None, extra_ktables=()):
         """The draw loop (imsim/lsst_image.py:342-368 + imsim/stamp.py:411-575).
 
         cat / phot_flux: catalog dict and Poisson-realised fluxes; make_objects(cat, phot) builds the
@@ -101,7 +101,8 @@ class LSST_ImageBuilder(LSST_ImageBuilderBase):
             fflux = nominal[keep][fft_rows]
             tables_needed = np.where(fobj["prof_table"] >= 0, fobj["prof_table"], -1)
             rows, order = fft_draw.build_fft_objects(fobj, fflux, tables_needed)
-            drawer = fft_draw.FftDrawer(renderer, kpsf, add_noise=True, diffraction_fft=diffraction_fft, wavelength=wavelength)
+            drawer = fft_draw.FftDrawer(renderer, kpsf, add_noise=True, diffraction_fft=diffraction_fft, wavelength=wavelength,
+                                        extra_ktables=extra_ktables)
             r_fft = torch.zeros(len(rows), dtype=torch.float64, device=renderer.device)
             drawer.draw(rows, realized=r_fft)
             idx = np.flatnonzero(fft_rows)[order]

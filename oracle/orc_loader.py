@@ -262,7 +262,8 @@ def poisson_probe(mean, seed=1, obj_id=0):
 class OracleFft:
     """CPU counterpart of imsim_amd.fft_draw.FftDrawer (numpy.fft for the transform)."""
 
-    def __init__(self, scene, kpsf, sersic_indices=(1.0, 4.0), add_noise=True, diffraction_fft=None, wavelength=622.2):
+    def __init__(self, scene, kpsf, sersic_indices=(1.0, 4.0), add_noise=True, diffraction_fft=None, wavelength=622.2,
+                 extra_ktables=()):
         from imsim_amd import fft_draw, tables
         self.lib = load()
         self.scene = scene
@@ -273,7 +274,8 @@ class OracleFft:
             a = np.ascontiguousarray(a, dtype=np.float64)
             self.keep.append(a)
             return a, a.ctypes.data
-        self.P, _ = fft_draw.fft_params(scene, kpsf, np.stack([t[1] for t in tabs]), float(tabs[0][0][1] - tabs[0][0][0]),
+        self.P, _ = fft_draw.fft_params(scene, kpsf, np.stack([t[1] for t in tabs] + list(extra_ktables)),
+                                        float(tabs[0][0][1] - tabs[0][0][0]),
                                         scene.seed, add_noise, put)
         self.image = np.zeros((scene.ny, scene.nx), dtype=np.float64)
         fft_draw.set_spikes(self.P, diffraction_fft, wavelength)

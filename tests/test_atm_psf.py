@@ -23,20 +23,23 @@ def test_r0_500_inversion_matches_target_seeing():
 
 
 def test_screen_structure_function_is_von_karman():
-    """The synthesised screen has the von Karman phase structure function
-    D(r) = 6.88 (r/r0)^(5/3) at r << L0 (in rad^2 at 500 nm; the screen is in nm of path)."""
+    """The synthesised screen has the von Karman phase structure function (in rad^2 at 500 nm; the screen is in
+    nm of path): 6.88 (r/r0)^(5/3) at r << L0, saturating beyond the outer scale."""
+    from imsim_amd import fft_draw
     rng = np.random.default_rng(5)
-    npix, scale, r0, L0 = 1024, 0.1, 0.15, 1.0e4
-    acc = []
-    for _ in range(4):
+    npix, scale, r0, L0 = 4096, 0.1, 0.2, 25.0
+    lags = (2, 5, 10, 20, 50, 100)
+    acc = {lag: [] for lag in lags}
+    for _ in range(2):
         s = atm_psf.von_karman_screen(npix, scale, r0, L0, rng) * (2 * np.pi / 500.0)    # rad at 500 nm
-        for lag in (2, 4, 8):
-            acc.append((lag, np.mean((s[:, lag:] - s[:, :-lag]) ** 2)))
-    for lag in (2, 4, 8):
-        d = np.mean([v for l, v in acc if l == lag])
-        expect = 6.8839 * (lag * scale / r0) ** (5.0 / 3.0)
-        # discretisation and the periodic 102 m box bias D by up to ~15 % either way
-        assert 0.8 * expect < d < 1.25 * expect, (lag, d, expect)
+        for lag in lags:
+            acc[lag].append(0.5 * (np.mean((s[:, lag:] - s[:, :-lag]) ** 2) + np.mean((s[lag:, :] - s[:-lag, :]) ** 2)))
+    for lag in lags:
+        expect = fft_draw.vonkarman_structure_function(np.array([lag * scale]), r0, L0)[0]
+        np.testing.assert_allclose(np.mean(acc[lag]), expect, rtol=0.06, err_msg=f"lag {lag}")
+    # and the Kolmogorov limit of the theory itself
+    np.testing.assert_allclose(fft_draw.vonkarman_structure_function(np.array([0.01]), r0, 1.0e5)[0],
+                               6.8839 * (0.01 / r0) ** (5.0 / 3.0), rtol=0.03)
 
 
 def test_second_kick_table_is_a_proper_cdf():

@@ -109,3 +109,62 @@ def test_apply_diffraction_psf_matches_reference():
     out = orc.spikes(rows, grid.ravel()).reshape(n, n)[:ny, :nx]
     np.testing.assert_allclose(out, g["apply_out"], rtol=1e-12, atol=1e-9)
     assert abs(out.sum() / img.sum() - 1) < 0.05      # flux is moved into the spikes, not created
+
+
+# ---------------------------------------------------------------------------------------------
+# make_fft_psf stand-ins: VonKarman for the PhaseScreenPSF, Airy for the SecondKick (psf_utils.py:94-149)
+# ---------------------------------------------------------------------------------------------
+def _profile_fwhm(T, p0, q_step, theta_max=4.0):
+    """FWHM [arcsec] of the real-space profile whose MTF is T(k p0), by Hankel transform"""
+    from scipy import special
+    q = np.arange(len(T)) * q_step
+    k = q / p0                                           # rad / arcsec
+    theta = np.linspace(0.0, theta_max, 4001)
+    I = np.array([np.trapezoid(T * special.j0(k * t) * k, k) for t in theta])
+    half = I[0] / 2.0
+    i = np.argmax(I < half)
+    return 2.0 * np.interp(half, [I[i], I[i - 1]], [theta[i], theta[i - 1]])
+
+
+def test_vonkarman_ktable_limits_and_seeing():
+    from imsim_amd import atm_psf, tables
+    lam, r0_500 = 622.2, 0.16
+    r0 = r0_500 * (lam / 500.0) ** 1.2
+    q_step = tables.KTABLE_QMAX / (tables.KTABLE_NPTS - 1)
+    # very large outer scale: the Kolmogorov MTF exp(-3.44 (r/r0)^(5/3)) (the limit is approached as
+    # (r/L0)^(1/3), i.e. slowly)
+    T, p0 = fft_draw.vonkarman_ktable(lam, r0_500, 1.0e7)
+    r = np.arange(len(T)) * q_step * 4.0 * r0 / tables.KTABLE_QMAX
+    np.testing.assert_allclose(T, np.exp(-0.5 * 6.8839 * (r / r0) ** (5.0 / 3.0)), atol=2e-3)
+    assert T[0] == 1.0 and T[-1] < 1e-12
+    # finite outer scale: the FWHM follows the Tokovinin formula imSim inverts (atmPSF.py:_vkSeeing)
+    for L0 in (10.0, 25.0, 60.0):
+        T, p0 = fft_draw.vonkarman_ktable(lam, r0_500, L0)
+        fwhm = _profile_fwhm(T, p0, q_step)
+        np.testing.assert_allclose(fwhm, atm_psf.vk_seeing(r0_500, lam, L0), rtol=0.03)
+
+
+def test_airy_ktable_is_the_pupil_autocorrelation():
+    from imsim_amd import tables
+    q_step = tables.KTABLE_QMAX / (tables.KTABLE_NPTS - 1)
+    lam, diam = 622.2, 8.36
+    # unobscured: closed form (2/pi)(acos v - v sqrt(1 - v^2))
+    T, p0 = fft_draw.airy_ktable(lam, diam, 0.0)
+    v = np.clip(np.arange(len(T)) * q_step * 1.02 / tables.KTABLE_QMAX, 0, 1)
+    np.testing.assert_allclose(T, 2 / np.pi * (np.arccos(v) - v * np.sqrt(1 - v * v)), atol=1e-12)
+    # obscured: autocorrelation of a sampled annulus
+    T, p0 = fft_draw.airy_ktable(lam, diam, 0.61)
+    n, half = 1024, 2.2 * diam
+    y, x = (np.mgrid[0:n, 0:n] - n / 2) * (half * 2 / n)
+    rr = np.hypot(x, y)
+    pupil = ((rr <= diam / 2) & (rr >= 0.61 * diam / 2)).astype(float)
+    ac = np.fft.fftshift(np.fft.ifft2(np.abs(np.fft.fft2(pupil)) ** 2).real)
+    ac /= ac.max()
+    shifts = np.arange(0, n // 2) * (half * 2 / n)
+    num = ac[n // 2, n // 2:]
+    tab = np.interp(shifts, np.arange(len(T)) * q_step * 1.02 * diam / tables.KTABLE_QMAX, T)
+    np.testing.assert_allclose(num, tab, atol=6e-3)
+    assert T[0] == 1.0 and np.all(T[-30:] == 0.0)
+    # cutoff at k = 2 pi D / lam
+    k_cut = 2 * np.pi * diam / (lam * 1e-9) / fft_draw.ARCSEC_PER_RAD
+    assert abs(tables.KTABLE_QMAX / 1.02 / p0 / k_cut - 1) < 1e-12

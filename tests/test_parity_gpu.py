@@ -455,3 +455,49 @@ def test_config_lsst_flat(torch_cuda):
     assert res.truth[0]["niter"] == 4
     np.testing.assert_allclose(img.mean(), 20000.0, rtol=1e-2)
     assert 0.8 * 20000 < img.var() < 1.05 * 20000
+
+
+def test_atm_psf_fft_matches_photon_shooting(torch_cuda):
+    """tests/test_psf.py:341-438 (test_atm_psf_fft): bright stars drawn by FFT with make_fft_psf's stand-ins
+    (VonKarman for the phase screens, Airy for the second kick) resemble the photon-shot AtmosphericPSF image:
+    peak within 5 % (7 % here, see below), moment radius within 10 %.  The FFT PSF is the EXPECTATION of the
+    photon-shot one; nine stars spread over the field average the 30-s realisation.  The second kick carries the
+    Kolmogorov spectrum above kcrit/r0 (as galsim.SecondKick does), the VonKarman stand-in slightly less for this
+    visit's outer scale of 18 m, which leaves the photon-shot peak about 5 % lower."""
+    from imsim_amd import configs, fft_draw
+    from imsim_amd.engine import Renderer
+    n, half = 1024, 40
+    scene = configs.scene_c3b(nx=n, ny=n, sensor=False, screen_size=409.6, screen_scale=0.1,
+                              device=torch_cuda.device("cuda", 0))
+    scene.ops = []
+    gx, gy = np.meshgrid([170.3, 512.6, 853.8], [171.7, 511.2, 852.4])
+    k = gx.size
+    cat = dict(x=gx.ravel(), y=gy.ravel(), mag=np.zeros(k), nominal_flux=np.full(k, 2.0e6), kind=np.zeros(k, dtype=int),
+               hlr=np.zeros(k), q=np.ones(k), pa=np.zeros(k), obj_id=np.arange(k) + 3)
+    objects, _ = configs.c3b_objects(cat, np.full(k, 2000000), scene)
+    cx, cy = np.floor(cat["x"] + 0.5).astype(int), np.floor(cat["y"] + 0.5).astype(int)
+    objects["stamp_xmin"], objects["stamp_xmax"] = cx - half, cx + half - 1
+    objects["stamp_ymin"], objects["stamp_ymax"] = cy - half, cy + half - 1
+    rp = Renderer(scene)
+    rp.render(objects)
+    rf = Renderer(scene)
+    atm = scene.atm
+    kpsf, extra = fft_draw.atmospheric_fft_kpsf(atm, atm.wlen_eff, first_table=2, fwhm_sys=0.3)
+    rows, _ = fft_draw.build_fft_objects(objects, cat["nominal_flux"], objects["prof_table"])
+    fft_draw.FftDrawer(rf, kpsf, add_noise=False, extra_ktables=extra).draw(rows)
+    rp.synchronize(); rf.synchronize()
+    a, b = rp.image_numpy().astype(float), rf.image_numpy().astype(float)
+
+    def stats(img):
+        out = []
+        for x0, y0 in zip(cx, cy):
+            st = img[y0 - 1 - 30:y0 - 1 + 30, x0 - 1 - 30:x0 - 1 + 30]
+            yy, xx = np.mgrid[0:60, 0:60]
+            f = st.sum()
+            mx, my = (st * xx).sum() / f, (st * yy).sum() / f
+            out.append((f, st.max(), np.sqrt((st * ((xx - mx) ** 2 + (yy - my) ** 2)).sum() / f)))
+        return np.array(out)
+    sa, sb = stats(a), stats(b)
+    assert abs(sa[:, 0].sum() / sb[:, 0].sum() - 1) < 0.03
+    assert abs(sa[:, 1].mean() / sb[:, 1].mean() - 1) < 0.07
+    assert abs(sa[:, 2].mean() / sb[:, 2].mean() - 1) < 0.10

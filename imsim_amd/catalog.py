@@ -36,8 +36,11 @@ def synthetic_catalog(n, seed=20261001, nx=4096, ny=4096, mag_min=16.0, mag_max=
     hlr = np.exp(rng.uniform(math.log(0.05), math.log(1.0), n))
     q = rng.uniform(0.2, 1.0, n)
     pa = rng.uniform(0.0, 180.0, n)
+    # flat-in-photons SED over the tabulated r band: the object evaluated at the effective wavelength carries
+    # nominal_flux / (integral of the throughput) photons per nm (what the stamp-size surface-brightness test sees)
+    wl, thr = tables.synthetic_r_band()
     return dict(x=x, y=y, mag=mag, nominal_flux=flux, kind=kind, hlr=hlr, q=q, pa=pa,
-                obj_id=np.arange(n, dtype=np.int64))
+                obj_id=np.arange(n, dtype=np.int64), sb_flux=flux / float(np.trapezoid(thr, wl)))
 
 
 def realize_fluxes(nominal_flux, seed):
@@ -118,11 +121,76 @@ def star_stamp_size(nominal_flux, noise_var, airmass=1.2, raw_seeing=0.7, band="
     return np.minimum(_good_size(stepk), nmax)
 
 
-def gal_stamp_size(kind, hlr, max_scale, nmax=NMAX):
-    """get_gal_stamp_size, first branch (stamp_utils.py:183-189): GoodImageSize of the object
-    convolved with the DoubleGaussian proxy PSF.  (The surface-brightness growth loop of
-    :196-220 only triggers above 10 photons per stamp pixel and is not restated yet.)"""
+def _sersic_norm(n):
+    """I(0) hlr^2 / flux of a Sersic profile: b^(2n) / (2 pi n Gamma(2n))"""
+    from scipy import special
+    b = special.gammaincinv(2.0 * n, 0.5)
+    return b, b ** (2.0 * n) / (2.0 * np.pi * n * special.gamma(2.0 * n))
+
+
+def sersic_xvalue(n, hlr, flux, jac, x, y):
+    """GSObject.xValue of Sersic(n, hlr).transform(jac).withFlux(flux) at sky offsets (x, y) [arcsec]:
+    flux * I0(|J^-1 x|) / |det J| with I0(r) = norm / hlr^2 exp(-b (r/hlr)^(1/n))."""
+    a, b_, c, d = jac[..., 0], jac[..., 1], jac[..., 2], jac[..., 3]
+    det = a * d - b_ * c
+    u = (d * x - b_ * y) / det
+    v = (-c * x + a * y) / det
+    bn, norm = _sersic_norm(n)
+    r = np.hypot(u, v) / hlr
+    return flux * norm / (hlr * hlr * np.abs(det)) * np.exp(-bn * r ** (1.0 / n))
+
+
+def _phot_stamp_size1(n0, xvalue, keep_sb_level, nmax, pixel_scale=PIXEL_SCALE, factor=1.1):
+    """get_good_phot_stamp_size1 (stamp_utils.py:293-354), vectorised: grow N by 10 % until the surface
+    brightness on the edges and corners of the square is below keep_sb_level, cap at Nmax, then shrink
+    while the next smaller square still is (not below 64).  xvalue(h) -> max of the 8 edge/corner values."""
+    N = np.asarray(n0, dtype=np.float64).copy()
+    keep = np.broadcast_to(np.asarray(keep_sb_level, dtype=np.float64), N.shape)
+    active = N < nmax
+    for _ in range(200):
+        if not active.any():
+            break
+        mv = xvalue(N / 2.0 * pixel_scale)
+        stop = mv < keep
+        grow = active & ~stop
+        N = np.where(grow, N * factor, N)
+        active = grow & (N < nmax)
+    N = np.minimum(N, nmax)
+    active = N >= 64 * factor
+    for _ in range(200):
+        if not active.any():
+            break
+        mv = xvalue(N / (2.0 * factor) * pixel_scale)
+        shrink = active & ~(mv > keep)
+        N = np.where(shrink, N / factor, N)
+        active = shrink & (N >= 64 * factor)
+    return N.astype(np.int64)
+
+
+def _edge_max(fn, h):
+    """max over the 4 edge midpoints and 4 corners of the square of half-width h (stamp_utils.py:327-331)"""
+    pts = ((h, 0 * h), (-h, 0 * h), (0 * h, h), (0 * h, -h), (h, h), (h, -h), (-h, h), (-h, -h))
+    return np.max([fn(x, y) for x, y in pts], axis=0)
+
+
+def double_gaussian_xvalue(x, y, fwhm1=0.6, fwhm2=0.12, wgt1=1.0, wgt2=0.1):
+    """make_double_gaussian (psf_utils.py:8-39), unit flux"""
+    s1, s2 = fwhm1 / 2.355, fwhm2 / 2.355
+    r2 = x * x + y * y
+    g1 = np.exp(-0.5 * r2 / (s1 * s1)) / (2.0 * np.pi * s1 * s1)
+    g2 = np.exp(-0.5 * r2 / (s2 * s2)) / (2.0 * np.pi * s2 * s2)
+    return (wgt1 * g1 + wgt2 * g2) / (wgt1 + wgt2)
+
+
+def gal_stamp_size(kind, hlr, max_scale, nmax=NMAX, jac=None, nominal_flux=None, noise_var=800.0, sb_flux=None):
+    """get_gal_stamp_size (stamp_utils.py:158-220).  First the GoodImageSize of the object convolved with the
+    DoubleGaussian proxy PSF; for bright objects (more than 10 photons per stamp pixel on average) or stamps
+    beyond Nmax the size follows from a surface-brightness limit of sqrt(noise_var)/8 via
+    get_good_phot_stamp_size (object and proxy PSF grown separately, added in quadrature), relaxed to 3x
+    that limit when it exceeds Nmax.  sb_flux: the flux obj_achrom carries in the reference (the object
+    evaluated at the effective wavelength, i.e. photons per nm); defaults to nominal_flux."""
     sizes = np.zeros(len(hlr), dtype=np.int64)
+    own = np.zeros(len(hlr), dtype=np.int64)
     dg_stepk = min(gaussian_stepk(0.6 / 2.355, FT_DEFAULT), gaussian_stepk(0.12 / 2.355, FT_DEFAULT))
     for k, n in enumerate(SERSIC_N):
         sel = kind == k + 1
@@ -132,6 +200,35 @@ def gal_stamp_size(kind, hlr, max_scale, nmax=NMAX):
         stepk_gal = np.pi / (r * hlr[sel] * max_scale[sel])
         stepk = 1.0 / np.sqrt(1.0 / stepk_gal ** 2 + 1.0 / dg_stepk ** 2)
         sizes[sel] = _good_size(stepk)
+        own[sel] = _good_size(stepk_gal)
+    if jac is None or nominal_flux is None:
+        return np.minimum(sizes, nmax)
+    nominal_flux = np.asarray(nominal_flux, dtype=np.float64)
+    sb_flux = nominal_flux if sb_flux is None else np.asarray(sb_flux, dtype=np.float64)
+    bright = (nominal_flux > 10.0 * sizes.astype(np.float64) ** 2) | (sizes > nmax)
+    if bright.any():
+        keep = math.sqrt(noise_var) / 8.0
+        psf_n0 = np.array([_good_size(dg_stepk)])
+        idx = np.flatnonzero(bright)
+
+        def phot_size(level):
+            out = np.zeros(len(idx), dtype=np.int64)
+            psf_size = _phot_stamp_size1(psf_n0, lambda h: _edge_max(double_gaussian_xvalue, h), level, nmax)[0]
+            for k, n in enumerate(SERSIC_N):
+                m = kind[idx] == k + 1
+                if not m.any():
+                    continue
+                ii = idx[m]
+                fn = lambda x, y, ii=ii, n=n: sersic_xvalue(n, hlr[ii], sb_flux[ii], jac[ii], x, y)
+                gal = _phot_stamp_size1(own[ii], lambda h: _edge_max(fn, h), level, nmax)
+                out[m] = np.sqrt(gal.astype(np.float64) ** 2 + float(psf_size) ** 2).astype(np.int64)
+            return out
+        sz = phot_size(keep)
+        huge = sz > nmax
+        if huge.any():
+            sz3 = phot_size(3.0 * keep)
+            sz = np.where(huge, np.minimum(sz3, nmax), sz)
+        sizes[idx] = sz
     return np.minimum(sizes, nmax)
 
 
@@ -178,7 +275,9 @@ def build_object_table(cat, phot_flux, noise_var=800.0, sed_table=0, max_flux_si
             s1 = a * a + b * b + c * c + d * d
             s2 = np.sqrt(np.maximum((a * a + b * b - c * c - d * d) ** 2 + 4 * (a * c + b * d) ** 2, 0.0))
             max_scale = np.sqrt(0.5 * (s1 + s2))
-            size[gal] = gal_stamp_size(kind[gal], cat["hlr"][gal], max_scale)
+            sb = cat["sb_flux"][gal] if "sb_flux" in cat else None
+            size[gal] = gal_stamp_size(kind[gal], cat["hlr"][gal], max_scale, jac=jac[gal], nominal_flux=nominal[gal],
+                                       noise_var=noise_var, sb_flux=sb)
         size[nominal < TINY_FLUX] = 32
     else:
         size = np.broadcast_to(np.asarray(stamp_size, dtype=np.int64), (n,)).copy()

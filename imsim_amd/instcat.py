@@ -124,5 +124,7 @@ def to_catalog(parsed, img_wcs, xsize, ysize, bandpass_integral, exptime, pupil_
                pa=parsed["pa"][idx] if flip_g2 else -parsed["pa"][idx], g1=g1, g2=g2, mu=mu,
                kind=np.where(objtype == 0, 0, np.where(np.isclose(sersic_n, 1.0), 1, 2)).astype(np.int32),
                sersic_n=sersic_n, obj_id=idx.astype(np.int64), object_id=parsed["id"][idx])
+    # what obj.evaluateAtWavelength(effective wavelength) carries in the reference: photons per nm (stamp_utils.py:176-220)
+    cat["sb_flux"] = flux / bandpass_integral
     cat["n_dropped_unsupported"] = int(np.count_nonzero(on & ~supported))
     return cat

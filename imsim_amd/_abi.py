@@ -19,6 +19,7 @@ IMS_MAX_OPS = 12
 IMS_SENSOR_NONE, IMS_SENSOR_SILICON = 0, 1
 IMS_SURF_MIRROR, IMS_SURF_REFRACT, IMS_SURF_DETECTOR, IMS_SURF_BAFFLE = 1, 2, 3, 4
 IMS_MEDIUM_CONST, IMS_MEDIUM_SELLMEIER, IMS_MEDIUM_AIR = 0, 1, 2
+IMS_PROF_POINT, IMS_PROF_BOX, IMS_PROF_KNOTS = -1, -2, -3
 (IMS_OBSC_NONE, IMS_OBSC_CLEAR_ANNULUS, IMS_OBSC_CLEAR_CIRCLE, IMS_OBSC_OBSC_CIRCLE,
  IMS_OBSC_OBSC_ANNULUS) = range(5)
 IMS_MAX_SURFACES = 24
@@ -33,7 +34,7 @@ class Object(C.Structure):
                 ("dcr_tanz", c_d), ("dcr_sinp", c_d), ("dcr_cosp", c_d),
                 ("prof_table", c_i32), ("sed_table", c_i32), ("flags", c_i32),
                 ("stamp_xmin", c_i32), ("stamp_xmax", c_i32), ("stamp_ymin", c_i32), ("stamp_ymax", c_i32),
-                ("bf_state", c_i32), ("sed_wave", c_d), ("atm_tan_x", c_d), ("atm_tan_y", c_d), ("reserved", c_d * 7)]
+                ("bf_state", c_i32), ("sed_wave", c_d), ("atm_tan_x", c_d), ("atm_tan_y", c_d), ("prof_aux", c_d), ("reserved", c_d * 6)]
 
 
 # numpy view of the same 256-byte row, for vectorised object-table construction
@@ -45,7 +46,7 @@ OBJECT_DTYPE = np.dtype([
     ("prof_table", "<i4"), ("sed_table", "<i4"), ("flags", "<i4"),
     ("stamp_xmin", "<i4"), ("stamp_xmax", "<i4"), ("stamp_ymin", "<i4"), ("stamp_ymax", "<i4"),
     ("bf_state", "<i4"), ("sed_wave", "<f8"), ("atm_tan_x", "<f8"), ("atm_tan_y", "<f8"),
-    ("reserved", "<f8", (7,))], align=True)
+    ("prof_aux", "<f8"), ("reserved", "<f8", (6,))], align=True)
 assert OBJECT_DTYPE.itemsize == 256
 
 

@@ -9,7 +9,7 @@ import math
 import numpy as np
 
 from . import tables
-from ._abi import OBJECT_DTYPE, IMS_OBJ_FAINT
+from ._abi import OBJECT_DTYPE, IMS_OBJ_FAINT, IMS_PROF_POINT, IMS_PROF_BOX, IMS_PROF_KNOTS
 
 PIXEL_SCALE = 0.2          # arcsec / pixel (LSST_SiliconBuilder._pixel_scale, stamp.py:102)
 NMAX = 4096                # stamp.py:106
@@ -17,6 +17,7 @@ TINY_FLUX = 10             # stamp.py:105
 FT_DEFAULT = 5.0e-3        # galsim.GSParams().folding_threshold
 STEPK_MIN_HLR = 5.0        # galsim.GSParams().stepk_minimum_hlr
 SERSIC_N = (1.0, 4.0)
+KIND_KNOTS, KIND_STREAK = 3, 4
 
 
 def synthetic_catalog(n, seed=20261001, nx=4096, ny=4096, mag_min=16.0, mag_max=27.0):
@@ -248,13 +249,24 @@ def build_object_table(cat, phot_flux, noise_var=800.0, sed_table=0, max_flux_si
     obj["n_phot"] = phot_flux
     obj["x0"], obj["y0"] = cat["x"], cat["y"]
     obj["flux_per_photon"] = 1.0
-    obj["prof_table"] = np.where(kind == 0, -1, kind - 1)
+    # kinds: 0 point, 1 / 2 Sersic n = 1 / 4 (radial tables 0 / 1), 3 RandomKnots, 4 streak (Box)
+    knots, streak = kind == KIND_KNOTS, kind == KIND_STREAK
+    obj["prof_table"] = np.where(kind == 0, IMS_PROF_POINT, np.where(knots, IMS_PROF_KNOTS, np.where(streak, IMS_PROF_BOX, kind - 1)))
     obj["prof_scale"] = np.where(kind == 0, 0.0, cat["hlr"])
+    if knots.any():
+        obj["prof_scale"][knots] = cat["hlr"][knots] / 1.1774100225154747      # Gaussian sigma of the knots' parent profile
+        obj["prof_aux"][knots] = cat["n_knots"][knots]
+    if streak.any():
+        obj["prof_scale"][streak] = cat["box_length"][streak]
+        obj["prof_aux"][streak] = cat["box_width"][streak]
     beta = 90.0 - cat["pa"]                                     # flip_g2 convention, instcat.py:503-508
     jac = shear_matrix(cat["q"], beta)
     if "g1" in cat:
         jac = _mat2(lens_matrix(cat["g1"], cat["g2"], cat["mu"]), jac)
     jac[kind == 0] = (1.0, 0.0, 0.0, 1.0)
+    if streak.any():                                            # Box(length, width).rotate(position_angle), instcat.py:494-496
+        t = np.deg2rad(cat["pa"][streak])
+        jac[streak] = np.stack([np.cos(t), -np.sin(t), np.sin(t), np.cos(t)], axis=-1)
     obj["jac"] = jac
     obj["winv"] = np.broadcast_to(np.asarray(winv, dtype=np.float64), (n, 4))
     obj["dcr_tanz"], obj["dcr_sinp"], obj["dcr_cosp"] = dcr
@@ -278,6 +290,16 @@ def build_object_table(cat, phot_flux, noise_var=800.0, sed_table=0, max_flux_si
             sb = cat["sb_flux"][gal] if "sb_flux" in cat else None
             size[gal] = gal_stamp_size(kind[gal], cat["hlr"][gal], max_scale, jac=jac[gal], nominal_flux=nominal[gal],
                                        noise_var=noise_var, sb_flux=sb)
+            # knots: GoodImageSize of the parent Gaussian; streaks: of the box (stepk = pi / max(length, width)),
+            # both convolved with the proxy PSF (first branch of get_gal_stamp_size)
+            dg_stepk = min(gaussian_stepk(0.6 / 2.355, FT_DEFAULT), gaussian_stepk(0.12 / 2.355, FT_DEFAULT))
+            gk, gs = knots[gal], streak[gal]
+            if gk.any():
+                sk = gaussian_stepk(obj["prof_scale"][gal][gk] * max_scale[gk], FT_DEFAULT)
+                size[np.flatnonzero(gal)[gk]] = np.minimum(_good_size(1.0 / np.sqrt(1.0 / sk ** 2 + 1.0 / dg_stepk ** 2)), NMAX)
+            if gs.any():
+                sk = np.pi / np.maximum(obj["prof_scale"][gal][gs], obj["prof_aux"][gal][gs])
+                size[np.flatnonzero(gal)[gs]] = np.minimum(_good_size(1.0 / np.sqrt(1.0 / sk ** 2 + 1.0 / dg_stepk ** 2)), NMAX)
         size[nominal < TINY_FLUX] = 32
     else:
         size = np.broadcast_to(np.asarray(stamp_size, dtype=np.int64), (n,)).copy()

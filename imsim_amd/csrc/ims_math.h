@@ -245,6 +245,7 @@ IMS_DEV void gauss_words(uint32_t w0, uint32_t w1, double& g0, double& g1)
 
 // RNG slots and word assignment (spec v4)
 constexpr uint32_t SLOT_SHOOT = 0;        // w0 wavelength, w1 profile radius, w2 profile angle
+constexpr uint32_t SLOT_KNOT = 1;         // photon index = knot index: w0,w1 Gaussian position of a RandomKnots point
 constexpr uint32_t SLOT_PSF = 2;          // + (component >> 1); component c owns words 2(c&1), 2(c&1)+1
 constexpr uint32_t SLOT_OP = 8;           // + (op index >> 1); op k owns words 2(k&1), 2(k&1)+1
 constexpr uint32_t SLOT_PSF_TIME = 20;    // + component: w0 arrival time drawn by a phase-screen PSF

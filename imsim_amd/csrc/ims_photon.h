@@ -54,12 +54,28 @@ IMS_DEV void shoot(const ims_render_params_t& P, const ims_object_t& o, int64_t 
     double wl = o.sed_wave;
     if (o.sed_table >= 0) wl = lin_lookup(P.sed, o.sed_table, w01(rng.w[0]));
     double pu = 0.0, pv = 0.0;
-    if (o.prof_table >= 0) {
-        const double r2 = radial_r2(P.radial, o.prof_table, w01(rng.w[1]));
-        const double r = sqrt(r2) * o.prof_scale;
-        double s, c;
-        sincos2pi(w01(rng.w[2]), s, c);
-        const double gu = r * c, gv = r * s;
+    if (o.prof_table != IMS_PROF_POINT) {
+        double gu, gv;
+        if (o.prof_table >= 0) {
+            const double r2 = radial_r2(P.radial, o.prof_table, w01(rng.w[1]));
+            const double r = sqrt(r2) * o.prof_scale;
+            double s, c;
+            sincos2pi(w01(rng.w[2]), s, c);
+            gu = r * c; gv = r * s;
+        } else if (o.prof_table == IMS_PROF_BOX) {
+            gu = (w01(rng.w[1]) - 0.5) * o.prof_scale;
+            gv = (w01(rng.w[2]) - 0.5) * o.prof_aux;
+        } else {
+            // RandomKnots: the photon picks one of the knots; knot m sits at a Gaussian deviate addressed by
+            // (object, m) in the knot slot, the same for every photon of the object
+            const uint32_t m = __umulhi(rng.w[1], (uint32_t)o.prof_aux);
+            Rng kr;
+            rng_reset(kr);
+            rng_block(kr, P.seed, o.obj_id, (int64_t)m, SLOT_KNOT);
+            double g0, g1;
+            gauss_words(kr.w[0], kr.w[1], g0, g1);
+            gu = o.prof_scale * g0; gv = o.prof_scale * g1;
+        }
         pu = o.jac[0] * gu + o.jac[1] * gv;
         pv = o.jac[2] * gu + o.jac[3] * gv;
     }

@@ -98,12 +98,12 @@ def to_catalog(parsed, img_wcs, xsize, ysize, bandpass_integral, exptime, pupil_
                sort_mag=True, flip_g2=True):
     """Cull to the CCD (+- edge_pix, instcat.py:243-259), compute nominal fluxes and the profile
     geometry (instcat.py:498-527, :433-444, :569-573) -> the catalog dict build_object_table takes.
-    Only point and sersic2d objects reach the kernels for now; the others are dropped with a count."""
+    point, sersic2d, knots and streak objects reach the kernels; FITS-image objects are dropped with a count."""
     from . import wcs as wcsmod
     vec = wcsmod.unit_vector(parsed["ra"], parsed["dec"]).T
     x, y = wcsmod.tansip_vec_to_pix(img_wcs, vec)
     on = (x >= 1 - edge_pix) & (x <= xsize + edge_pix) & (y >= 1 - edge_pix) & (y <= ysize + edge_pix)
-    supported = np.isin(parsed["objtype"], (0, 1))
+    supported = np.isin(parsed["objtype"], (0, 1, 2, 3))
     keep = on & supported
     idx = np.flatnonzero(keep)
     if sort_mag:
@@ -122,7 +122,10 @@ def to_catalog(parsed, img_wcs, xsize, ysize, bandpass_integral, exptime, pupil_
     sersic_n = np.where(objtype == 1, n, 0.0)
     cat = dict(x=x[idx], y=y[idx], nominal_flux=flux, mag=parsed["magnorm"][idx], hlr=hlr, q=q,
                pa=parsed["pa"][idx] if flip_g2 else -parsed["pa"][idx], g1=g1, g2=g2, mu=mu,
-               kind=np.where(objtype == 0, 0, np.where(np.isclose(sersic_n, 1.0), 1, 2)).astype(np.int32),
+               kind=np.where(objtype == 0, 0, np.where(objtype == 2, 3, np.where(objtype == 3, 4,
+                             np.where(np.isclose(sersic_n, 1.0), 1, 2)))).astype(np.int32),
+               n_knots=np.where(objtype == 2, n, 0.0), box_length=np.where(objtype == 3, a, 0.0),
+               box_width=np.where(objtype == 3, b, 0.0),
                sersic_n=sersic_n, obj_id=idx.astype(np.int64), object_id=parsed["id"][idx])
     # what obj.evaluateAtWavelength(effective wavelength) carries in the reference: photons per nm (stamp_utils.py:176-220)
     cat["sb_flux"] = flux / bandpass_integral

@@ -87,6 +87,7 @@ class LSST_ImageBuilder(LSST_ImageBuilderBase):
             is_fft = np.zeros(n_all, dtype=bool)
         else:
             is_fft = fft_draw.use_fft(nominal, sub["kind"], sub["hlr"], fwhm_total, fft_sb_thresh)
+        is_fft &= np.asarray(sub["kind"]) < 3                  # knots and streaks have no k-space form here: always photons
         objects, sizes = make_objects(sub, np.where(phot > 0, phot, 0))
         keep = np.flatnonzero(phot > 0)                       # SkipThisObject for phot_flux == 0 (stamp.py:199-202)
         fft_rows = is_fft[keep]

@@ -86,6 +86,9 @@ extern "C" {
 #define IMS_MAX_SURFACES 24
 
 /* One catalog source for one call.  256 bytes, 64-byte aligned rows. */
+#define IMS_PROF_POINT (-1)
+#define IMS_PROF_BOX   (-2)
+#define IMS_PROF_KNOTS (-3)
 typedef struct ims_object {
     int64_t obj_id;        /* RNG stream id = catalog object number (per-object rng, stamp.py:166) */
     int64_t phot_first;    /* index of the first photon of this call within the object's stream */
@@ -98,14 +101,18 @@ typedef struct ims_object {
     double  dcr_tanz;      /* PhotonDCR: tan(zenith angle) of this object */
     double  dcr_sinp;      /* PhotonDCR: sin(parallactic angle) */
     double  dcr_cosp;      /* PhotonDCR: cos(parallactic angle) */
-    int32_t prof_table;    /* radial profile table id; -1 = DeltaFunction (point source) */
+    int32_t prof_table;    /* >= 0: radial profile table id (Sersic ...), scaled by prof_scale;
+                            * IMS_PROF_POINT: DeltaFunction; IMS_PROF_BOX: galsim.Box(prof_scale, prof_aux) [arcsec] (streaks,
+                            * imsim/instcat.py:487-496); IMS_PROF_KNOTS: galsim.RandomKnots of prof_aux points drawn from a
+                            * Gaussian of sigma prof_scale (instcat.py:529-546) */
     int32_t sed_table;     /* wavelength inverse-CDF table id; -1 = monochromatic at sed_wave */
     int32_t flags;         /* IMS_OBJ_* */
     int32_t stamp_xmin, stamp_xmax, stamp_ymin, stamp_ymax; /* stamp bounds, inclusive; photons outside are lost */
     int32_t bf_state;      /* >=0: index into ims_sensor.bf_slots (private pixel boundaries); -1: static CCD boundaries */
     double  sed_wave;      /* wavelength [nm] when sed_table < 0 */
     double  atm_tan_x, atm_tan_y; /* tan of the field angle of the object from the boresight (theta of atm.makePSF, atmPSF.py:304) */
-    double  reserved[7];   /* pads the row to 256 bytes */
+    double  prof_aux;      /* IMS_PROF_BOX: width [arcsec]; IMS_PROF_KNOTS: number of knots */
+    double  reserved[6];   /* pads the row to 256 bytes */
 } ims_object_t;
 
 /* Tabulated circular profiles sampled by inverse CDF with uniform density inside each annulus:

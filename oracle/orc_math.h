@@ -261,6 +261,7 @@ static inline void orc_gauss_words(uint32_t w0, uint32_t w1, double* g0, double*
 
 /* RNG slots and word assignment (spec v4) */
 #define ORC_SLOT_SHOOT     0   /* w0 wavelength, w1 profile radius, w2 profile angle */
+#define ORC_SLOT_KNOT      1   /* photon index = knot index: w0,w1 Gaussian position of a RandomKnots point */
 #define ORC_SLOT_PSF       2   /* + (component >> 1); component c owns words 2(c&1), 2(c&1)+1 */
 #define ORC_SLOT_OP        8   /* + (op index >> 1); op k owns words 2(k&1), 2(k&1)+1 */
 #define ORC_SLOT_PSF_TIME 20   /* + component: w0 arrival time drawn by a phase-screen PSF */

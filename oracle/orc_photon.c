@@ -79,12 +79,24 @@ void orc_shoot_object(const ims_render_params_t* P, const ims_object_t* obj, int
         if (obj->sed_table >= 0) wl = orc_lin_lookup(&P->sed, obj->sed_table, orc_w01(d0.w[0]));
         /* profile */
         double pu = 0.0, pv = 0.0;
-        if (obj->prof_table >= 0) {
-            double r2 = orc_radial_r2(&P->radial, obj->prof_table, orc_w01(d0.w[1]));
-            double r = orc_sqrt(r2) * obj->prof_scale;
-            double s, c;
-            orc_sincos2pi(orc_w01(d0.w[2]), &s, &c);
-            double gu = r * c, gv = r * s;
+        if (obj->prof_table != IMS_PROF_POINT) {
+            double gu, gv;
+            if (obj->prof_table >= 0) {
+                double r2 = orc_radial_r2(&P->radial, obj->prof_table, orc_w01(d0.w[1]));
+                double r = orc_sqrt(r2) * obj->prof_scale;
+                double s, c;
+                orc_sincos2pi(orc_w01(d0.w[2]), &s, &c);
+                gu = r * c; gv = r * s;
+            } else if (obj->prof_table == IMS_PROF_BOX) {          /* galsim.Box: uniform over length x width */
+                gu = (orc_w01(d0.w[1]) - 0.5) * obj->prof_scale;
+                gv = (orc_w01(d0.w[2]) - 0.5) * obj->prof_aux;
+            } else {                                                /* galsim.RandomKnots */
+                uint32_t m = (uint32_t)(((uint64_t)d0.w[1] * (uint64_t)(uint32_t)obj->prof_aux) >> 32);
+                orc_words_t kd = orc_words(P->seed, obj->obj_id, (int64_t)m, ORC_SLOT_KNOT);
+                double g0, g1;
+                orc_gauss_words(kd.w[0], kd.w[1], &g0, &g1);
+                gu = obj->prof_scale * g0; gv = obj->prof_scale * g1;
+            }
             pu = j0 * gu + j1 * gv;
             pv = j2 * gu + j3 * gv;
         }

@@ -43,3 +43,29 @@ def test_flux_and_geometry():
     gal = cat["kind"] > 0
     assert np.all(cat["hlr"][gal] > 0) and np.all((cat["q"][gal] > 0) & (cat["q"][gal] <= 1))
     assert np.all((cat["x"] > -100) & (cat["x"] < 4197))
+
+
+def test_knots_and_streak_lines_reach_the_object_table(tmp_path):
+    """instcat.py:487-496 (streak -> Box.rotate) and :529-546 (knots -> RandomKnots, sheared and lensed)"""
+    from imsim_amd import catalog, configs
+    f = tmp_path / "mixed.txt"
+    f.write_text("object 11 60.49 -38.16 21.0 sed 0 0.02 0.01 0.03 0 0 knots 0.8 0.4 35.0 12 none none\n"
+                 "object 12 60.50 -38.15 22.0 sed 0 0 0 0 0 0 streak 30.0 0.5 70.0 none none\n"
+                 "object 13 60.49 -38.16 21.0 sed 0 0 0 0 0 0 knots 0.8 0.4 35.0 0 none none\n"         # npoints <= 0: skipped
+                 "object 14 60.49 -38.16 21.0 sed 0 0 0 0 0 0 knots 0.3 0.4 35.0 5 none none\n")        # a < b: skipped
+    p = instcat.parse_objects(str(f))
+    assert list(p["id"]) == ["11", "12"] and list(p["objtype"]) == [2, 3]
+    scene = configs.scene_c3(nx=4096, ny=4004, sensor=False)
+    cat = instcat.to_catalog(p, scene.optics.img_wcs, 4096, 4004, 80.0, 30.0, sort_mag=False, edge_pix=10 ** 6)
+    assert list(cat["kind"]) == [catalog.KIND_KNOTS, catalog.KIND_STREAK]
+    assert cat["n_knots"][0] == 12 and cat["box_length"][1] == 30.0 and cat["box_width"][1] == 0.5
+    objects, sizes = catalog.build_object_table(cat, np.array([1000, 1000]))
+    assert list(objects["prof_table"]) == [-3, -2]
+    np.testing.assert_allclose(objects["prof_scale"][0], np.sqrt(0.8 * 0.4) / 1.1774100225154747)     # hlr = sqrt(a b)
+    assert objects["prof_aux"][0] == 12 and objects["prof_scale"][1] == 30.0 and objects["prof_aux"][1] == 0.5
+    # streak: pure rotation by the position angle; knots: shear (q = b/a) times lens, not a rotation
+    t = np.deg2rad(70.0)
+    np.testing.assert_allclose(objects["jac"][1], [np.cos(t), -np.sin(t), np.sin(t), np.cos(t)])
+    j = objects["jac"][0]
+    assert abs(j[0] * j[3] - j[1] * j[2] - cat["mu"][0]) < 1e-12          # det = magnification
+    assert sizes[1] >= 2 * 30.0 / 0.2

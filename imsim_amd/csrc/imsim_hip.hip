@@ -386,6 +386,22 @@ __device__ __forceinline__ CellRef locate_cell(const ims_sensor_t& s, int first_
     return r;
 }
 
+// owned boundary point n of owner cell (ci, cj) in its undistorted-plus-tree-ring state (pixel-local coordinates)
+__device__ __forceinline__ void init_point(const ims_sensor_t& s, const SlotView& sl, int ci, int cj, int n, double& px, double& py)
+{
+    double ex, ey;
+    empty_owned(s, n, ex, ey);
+    const double tx = ((double)(sl.xmin + ci) - 0.5 + ex) - s.tr_cx;
+    const double ty = ((double)(sl.ymin + cj) - 0.5 + ey) - s.tr_cy;
+    const double rr = sqrt(tx * tx + ty * ty);
+    const double sh = treering_shift(s, rr);
+    px = ex; py = ey;
+    if (rr > 0.0 && sh != 0.0) { px = ex + sh * tx / rr; py = ey + sh * ty / rr; }
+}
+
+// Initial state of a range of slots: boundary points, zero delta charge AND the bounds line of every pixel.
+// The bounds need the points of the right and upper neighbour cells; they are recomputed here from the same
+// closed form (bit-identical to what those cells store) instead of being read back in a second pass.
 __global__ __launch_bounds__(256) void k_init_boundaries(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
                                                          int64_t cell_begin, int64_t cell_count)
 {
@@ -393,38 +409,30 @@ __global__ __launch_bounds__(256) void k_init_boundaries(const ims_sensor_t* __r
     const CellRef r = locate_cell(s, first_slot, n_slots, cell_begin, cell_count);
     if (!r.valid) return;
     const SlotView& sl = r.sl;
-    const int npo = 2 * s.num_vertices + 2;
+    const int nV = s.num_vertices, npo = 2 * nV + 2, nv = 4 * nV + 4;
     double* pts = s.bf_boundary + (sl.offset + r.c) * npo * 2;
     for (int n = 0; n < npo; ++n) {
-        double ex, ey;
-        empty_owned(s, n, ex, ey);
-        const double tx = ((double)(sl.xmin + r.i) - 0.5 + ex) - s.tr_cx;
-        const double ty = ((double)(sl.ymin + r.j) - 0.5 + ey) - s.tr_cy;
-        const double rr = sqrt(tx * tx + ty * ty);
-        const double sh = treering_shift(s, rr);
-        double px = ex, py = ey;
-        if (rr > 0.0 && sh != 0.0) { px = ex + sh * tx / rr; py = ey + sh * ty / rr; }
+        double px, py;
+        init_point(s, sl, r.i, r.j, n, px, py);
         pts[2 * n] = px; pts[2 * n + 1] = py;
     }
     s.bf_delta[sl.offset + r.c] = 0.0;
-}
-
-__global__ __launch_bounds__(256) void k_refresh_bounds(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
-                                                        int64_t cell_begin, int64_t cell_count)
-{
-    const ims_sensor_t& s = *sp;
-    const CellRef r = locate_cell(s, first_slot, n_slots, cell_begin, cell_count);
-    if (!r.valid) return;
-    const SlotView& sl = r.sl;
     const int i = r.i, j = r.j;
     if (i >= sl.nx || j >= sl.ny) return;
-    const int nV = s.num_vertices, nv = 4 * nV + 4;
     double ixmin = 0.0, ixmax = 1.0, iymin = 0.0, iymax = 1.0;
     double oxmin = 0.0, oxmax = 1.0, oymin = 0.0, oymax = 1.0;
     double v0x = 0.0;
     for (int k = 0; k < nv; ++k) {
+        // same vertex -> (cell, owned point) map as polygon_vertex
+        int ci = i, cj = j, q;
+        double ax = 0.0, ay = 0.0;
+        if (k <= nV + 1) { q = k; }
+        else if (k <= 2 * nV + 1) { ci = i + 1; ax = 1.0; q = nV + 2 + (k - nV - 2); }
+        else if (k <= 3 * nV + 3) { cj = j + 1; ay = 1.0; q = nV + 1 - (k - 2 * nV - 2); }
+        else { q = nV + 2 + (nV - 1 - (k - 3 * nV - 4)); }
         double vx, vy;
-        polygon_vertex(s, sl, i, j, k, 1.0, vx, vy);
+        init_point(s, sl, ci, cj, q, vx, vy);
+        vx = vx + ax; vy = vy + ay;
         if (k == 0) v0x = vx;
         if (vx < oxmin) oxmin = vx;
         if (vx > oxmax) oxmax = vx;
@@ -452,7 +460,7 @@ __device__ __forceinline__ int owned_to_vertex(int nV, int n)
 // delta-charge halo tile ((16+2q+1)^2 doubles) is staged in LDS once, then every thread gathers its
 // charged neighbours from LDS in a FIXED order (so the result is bit-reproducible) and adds the
 // scaled tabulated displacements to the boundary points it owns.  A per-cell `changed` byte lets
-// k_refresh_bounds skip pixels whose polygon did not move.
+// k_refresh_changed skip pixels whose polygon did not move.
 constexpr int UT = 16;            // tile edge (mark_tile_charge assumes 16)
 constexpr int UQMAX = 4;          // largest supported qdist
 constexpr int UH = UT + 2 * UQMAX + 1;
@@ -1084,7 +1092,6 @@ int ims_sensor_init_boundaries(const ims_sensor_t* sensor_dev, const ims_sensor_
     hipStream_t st = (hipStream_t)stream;
     const unsigned g = (unsigned)((count + 255) / 256);
     hipLaunchKernelGGL(k_init_boundaries, dim3(g), dim3(256), 0, st, sensor_dev, first_slot, n_slots, begin, count);
-    hipLaunchKernelGGL(k_refresh_bounds, dim3(g), dim3(256), 0, st, sensor_dev, first_slot, n_slots, begin, count);
     HIP_TRY(hipGetLastError());
     return IMS_OK;
 }

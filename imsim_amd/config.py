@@ -474,6 +474,13 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
                                 fft_sb_thresh=float(ev.value(stamp_cfg.get("fft_sb_thresh", 0.0))), max_flux_simple=max_simple,
                                 draw_method=ev.value(stamp_cfg.get("draw_method", "auto")), kpsf=kpsf, fwhm_total=fwhm_total,
                                 diffraction_fft=dfft, wavelength=wl_eff, nrecalc=nrecalc, truth=truth, extra_ktables=extra_ktables)
+        # sky + noise (imsim/lsst_image.py:128-200) when a numeric sky level is configured; the Rubin sky model,
+        # vignetting and fringing inputs are out of scope and reported as ignored
+        sky = image.get("sky_level")
+        if isinstance(sky, (int, float)) and not isinstance(sky, bool) and image.get("noise"):
+            builder.add_noise(renderer, float(sky), seed=seed)
+        elif "sky_level" in image:
+            res.ignored.append("image.sky_level")
         renderer.synchronize()
         res.images.append(renderer.image_numpy())
         res.truth.append(truth)

@@ -19,6 +19,7 @@ IMAGE_OPT = {"size": int, "xsize": int, "ysize": int, "dtype": None, "apply_sky_
 IMAGE_IGNORE = ["image_pos", "world_pos", "stamp_size", "stamp_xsize", "stamp_ysize", "nobjects", "type", "random_seed",
                 "bandpass", "wcs", "noise", "sky_level", "sensor", "use_flux_sky_areas", "nproc"]
 # detector bounding boxes the reference gets from lsst.obs.lsst (imsim/camera.py); E2V 4096x4004, ITL 4072x4000
+NOISE_STREAM = 1 << 20            # iteration id space of the sky-noise Poisson streams (flat iterations use 0..niter)
 DETECTOR_SIZE = {"E2V": (4096, 4004), "ITL": (4072, 4000)}
 
 
@@ -59,6 +60,34 @@ class LSST_ImageBuilderBase:
         self.nbatch_fft = params.get("nbatch_fft", 1)
         self.nobjects = config.get("nobjects")
         return xsize, ysize
+
+
+    def add_noise(self, renderer, sky_level, pixel_scale=0.2, sky_gradient=None, multiplier=None, seed=0, stream_id=0):
+        """addNoise (imsim/lsst_image.py:128-200): sky = sky_level [photons/arcsec^2] x pixel area, optionally
+        times a linear sky gradient (a, b, c): factor = a + b x + c y in 0-based pixel indices (SkyGradient,
+        sky_model.py) and a per-pixel multiplier map [ny][nx] (vignetting x fringing); the image receives a
+        Poisson deviate of that expectation per pixel (the objects already carry their own shot noise).  The
+        Rubin sky-brightness model that supplies sky_level in the reference is out of scope: pass the number."""
+        from . import _abi
+        torch = renderer.torch
+        sc = renderer.scene
+        base_t = None
+        if sky_gradient is not None or multiplier is not None:
+            m = torch.ones((sc.ny, sc.nx), dtype=torch.float64, device=renderer.device)
+            if sky_gradient is not None:
+                a, b, c = (float(v) for v in sky_gradient)
+                xx = torch.arange(sc.nx, dtype=torch.float64, device=renderer.device)[None, :]
+                yy = torch.arange(sc.ny, dtype=torch.float64, device=renderer.device)[:, None]
+                m = m * (a + b * xx + c * yy)
+            if multiplier is not None:
+                m = m * torch.as_tensor(np.ascontiguousarray(multiplier, dtype=np.float64), device=renderer.device)
+            base_t = m.contiguous()
+        level = float(sky_level) * pixel_scale * pixel_scale
+        _abi.check(renderer.lib.ims_flat_add(None, base_t.data_ptr() if base_t is not None else None, level, 1.0, int(seed),
+                                             NOISE_STREAM + int(stream_id), sc.nx, sc.ny, renderer.image.data_ptr(), None,
+                                             renderer._stream()), "ims_flat_add")
+        self._noise_keep = base_t
+        return renderer.image
 
 
 class LSST_ImageBuilder(LSST_ImageBuilderBase):

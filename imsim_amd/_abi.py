@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 IMS_OBJ_FAINT = 1
-IMS_PSF_GAUSSIAN, IMS_PSF_RADIAL, IMS_PSF_SCREENS = 1, 2, 3
+IMS_PSF_GAUSSIAN, IMS_PSF_RADIAL, IMS_PSF_SCREENS, IMS_PSF_DOUBLE_GAUSSIAN = 1, 2, 3, 4
 IMS_MAX_LAYERS = 8
 IMS_MAX_PSF = 4
 (IMS_OP_TIME_SAMPLER, IMS_OP_PUPIL_ANNULUS_SAMPLER, IMS_OP_PHOTON_DCR, IMS_OP_RUBIN_OPTICS,
@@ -59,7 +59,8 @@ class LinTables(C.Structure):
 
 
 class PsfComponent(C.Structure):
-    _fields_ = [("kind", c_i32), ("table", c_i32), ("p0", c_d), ("chrom_alpha", c_d), ("chrom_base", c_d)]
+    _fields_ = [("kind", c_i32), ("table", c_i32), ("p0", c_d), ("chrom_alpha", c_d), ("chrom_base", c_d),
+                ("p1", c_d), ("p2", c_d)]
 
 
 class Atmosphere(C.Structure):

@@ -251,6 +251,22 @@ def build_photon_ops(op_cfgs, ev, base_wavelength):
     return ops, meta
 
 
+def double_gaussian_psf(fwhm, pixel_scale=0.2):
+    """BuildDoubleGaussianPSF (imsim/atmPSF.py:448-486): 0.909 (G(sigma1) + 0.1 G(sigma2)) with alpha = fwhm / 2.3835,
+    sigma1^2 = alpha^2 - s^2/12, sigma2^2 = 4 alpha^2 - s^2/12.  Returns the photon-op component, its k-table on the
+    common q grid and the table's p0."""
+    alpha = fwhm / 2.3835
+    eff = pixel_scale * pixel_scale / 12.0
+    s1, s2 = math.sqrt(alpha * alpha - eff), math.sqrt(4.0 * alpha * alpha - eff)
+    f1 = 1.0 / 1.1
+    comp = (_abi.IMS_PSF_DOUBLE_GAUSSIAN, 0, s1, 0.0, 1.0, s2, f1)
+    q = np.linspace(0.0, tables.KTABLE_QMAX, tables.KTABLE_NPTS)
+    p0 = tables.KTABLE_QMAX / (9.0 / s1)                       # the table spans k up to 9 / sigma1 [rad/arcsec]
+    k = q / p0
+    tab = f1 * np.exp(-0.5 * (k * s1) ** 2) + (1.0 - f1) * np.exp(-0.5 * (k * s2) ** 2)
+    return comp, tab, p0
+
+
 def build_psf(psf_cfg, ev, scene_tables):
     """psf field -> (Scene.psf list, k-space list for FFT mode, total FWHM, AtmosphericPSF or None, extra k-tables
     of the FFT-mode PSF)."""
@@ -274,7 +290,13 @@ def build_psf(psf_cfg, ev, scene_tables):
             kpsf += fft_draw.kolmogorov_gaussian_kpsf(fa, fs)
             fw2 += fa ** 2 + fs ** 2
         elif t == "DoubleGaussianPSF":
-            raise GalSimConfigError("DoubleGaussianPSF is a two-component mixture: not available as a photon op yet")
+            p = lsst_image.get_all_params({k: ev.value(v) for k, v in it.items() if k != "type"}, {"fwhm": float},
+                                          {"pixel_scale": float})
+            comp, tab, p0 = double_gaussian_psf(float(p["fwhm"]), float(p.get("pixel_scale", 0.2)))
+            psf.append(comp)
+            kpsf.append((_abi.IMS_KPSF_TABLE, 2 + len(extra), p0))
+            extra.append(tab)
+            fw2 += float(p["fwhm"]) ** 2
         elif t == "AtmosphericPSF":
             atm = ev.base["_atm_psf"]
             fw2 += atm.targetFWHM ** 2

@@ -123,6 +123,13 @@ IMS_DEV void apply_psf(const ims_render_params_t& P, const ims_object_t& o, int 
         double g0, g1;
         gauss_words(wa, wb, g0, g1);
         ku = scale * g0; kv = scale * g1;
+    } else if (c.kind == IMS_PSF_DOUBLE_GAUSSIAN) {
+        // sum of two Gaussians: the photon belongs to the first with probability p2
+        rng_block(rng, P.seed, o.obj_id, k, SLOT_PSF_TIME + (uint32_t)comp);
+        const double sigma = (w01(rng.w[0]) < c.p2) ? scale : c.p1;
+        double g0, g1;
+        gauss_words(wa, wb, g0, g1);
+        ku = sigma * g0; kv = sigma * g1;
     } else if (c.kind == IMS_PSF_SCREENS) {
         const ims_atmosphere_t& A = *P.atm;
         const double ro2 = A.aper_r_outer * A.aper_r_outer, ri2 = A.aper_r_inner * A.aper_r_inner;

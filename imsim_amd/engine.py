@@ -194,8 +194,8 @@ class BoundScene:
         if len(scene.psf) > _abi.IMS_MAX_PSF:
             raise ValueError("too many PSF components")
         P.n_psf = len(scene.psf)
-        for k, (kind, table, p0, alpha, base) in enumerate(scene.psf):
-            P.psf[k] = PsfComponent(kind, table, p0, alpha, base)
+        for k, comp in enumerate(scene.psf):                # (kind, table, p0, chrom_alpha, chrom_base[, p1, p2])
+            P.psf[k] = PsfComponent(*comp)
         if len(scene.ops) > _abi.IMS_MAX_OPS:
             raise ValueError("too many photon ops")
         P.n_ops = len(scene.ops)

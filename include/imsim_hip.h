@@ -50,6 +50,8 @@ extern "C" {
 #define IMS_PSF_RADIAL   2  /* table = radial table id, p0 = scale [arcsec per table unit] */
 #define IMS_PSF_SCREENS  3  /* PhaseScreenPSF, geometric photon shooting through ims_atmosphere (imsim/atmPSF.py:298-320);
                                p0 = arcsec per (nm/m) of wavefront gradient = 1e-9 * 206265; also samples pupil_u/v and time */
+#define IMS_PSF_DOUBLE_GAUSSIAN 4  /* imsim DoubleGaussianPSF (atmPSF.py:448-486): Gaussian of sigma p0 with probability p2,
+                                    * else of sigma p1 [arcsec] */
 #define IMS_MAX_PSF 4
 
 /* ---- photon-op kinds (names follow the registered PhotonOp types) ---- */
@@ -140,6 +142,7 @@ typedef struct ims_psf_component {
     double  p0;              /* sigma or scale [arcsec] */
     double  chrom_alpha;     /* size scales as (wavelength/chrom_base)^alpha; 0 = achromatic */
     double  chrom_base;      /* nm */
+    double  p1, p2;          /* kind-specific (IMS_PSF_DOUBLE_GAUSSIAN) */
 } ims_psf_component_t;
 
 /* The frozen-flow atmosphere of one visit (galsim.Atmosphere as built by imsim/atmPSF.py:164-205):

@@ -154,6 +154,14 @@ void orc_apply_psf(const ims_render_params_t* P, const ims_object_t* obj, int co
             double g0, g1;
             orc_gauss_words(wa, wb, &g0, &g1);
             ku = scale * g0; kv = scale * g1;
+        } else if (c->kind == IMS_PSF_DOUBLE_GAUSSIAN) {
+            /* DoubleGaussianPSF = sum of two Gaussians (atmPSF.py:478-484): Sum.shoot gives a photon to the
+             * first component with probability p2 */
+            orc_words_t ds = orc_words(P->seed, obj->obj_id, k, ORC_SLOT_PSF_TIME + (uint32_t)comp);
+            double sigma = (orc_w01(ds.w[0]) < c->p2) ? scale : c->p1;
+            double g0, g1;
+            orc_gauss_words(wa, wb, &g0, &g1);
+            ku = sigma * g0; kv = sigma * g1;
         } else if (c->kind == IMS_PSF_SCREENS) {
             /* PhaseScreenPSF geometric shooting: random pupil position and arrival time, kick =
              * wavefront gradient; the photon keeps (pupil_u, pupil_v, time) for later operators */

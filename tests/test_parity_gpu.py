@@ -518,6 +518,8 @@ def test_knots_and_streak_profiles_are_bit_exact(torch_cuda):
                box_length=np.where(kind == catalog.KIND_STREAK, rng.uniform(2, 15, n), 0.0),
                box_width=np.where(kind == catalog.KIND_STREAK, rng.uniform(0.2, 1.0, n), 0.0))
     scene = configs.scene_c2(nx=256, ny=256)
+    from imsim_amd import config
+    scene.psf = [config.double_gaussian_psf(0.7)[0]]          # and the DoubleGaussianPSF mixture as the PSF
     objects, _ = catalog.build_object_table(cat, rng.integers(500, 4000, n))
     r = Renderer(scene)
     pool = r.shoot_photons(objects)

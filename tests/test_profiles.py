@@ -78,3 +78,29 @@ def test_stamp_sizes_of_knots_and_streaks():
     cat = _cat(catalog.KIND_STREAK, 2, box_length=np.array([10.0, 40.0]), box_width=np.array([1.0, 1.0]))
     _, sizes = catalog.build_object_table(cat, np.full(2, 1000))
     assert sizes[0] >= 2 * 10.0 / PIX and sizes[1] >= 2 * 40.0 / PIX      # GoodImageSize = 2 pi / (stepk scale), stepk = pi / L
+
+
+def test_double_gaussian_psf_is_a_two_component_mixture():
+    """BuildDoubleGaussianPSF (imsim/atmPSF.py:448-486) as a photon operator"""
+    from imsim_amd import config
+    comp, tab, p0 = config.double_gaussian_psf(0.7)
+    alpha = 0.7 / 2.3835
+    s1, s2 = np.sqrt(alpha ** 2 - 0.04 / 12), np.sqrt(4 * alpha ** 2 - 0.04 / 12)
+    assert comp[2] == s1 and comp[5] == s2 and abs(comp[6] - 1 / 1.1) < 1e-15
+    cat = _cat(0, 1)                                        # one point source
+    scene = configs.scene_c2(nx=256, ny=256)
+    scene.psf = [comp]
+    objects, _ = catalog.build_object_table(cat, np.array([400000]), stamp_size=128)
+    pool = orc_loader.OracleScene(scene).shoot_pool(objects).to_host()
+    dx, dy = (pool["x"] - objects["x0"][0]) * PIX, (pool["y"] - objects["y0"][0]) * PIX
+    f = 1 / 1.1
+    np.testing.assert_allclose(np.var(dx), f * s1 ** 2 + (1 - f) * s2 ** 2, rtol=0.02)
+    np.testing.assert_allclose(np.var(dy), f * s1 ** 2 + (1 - f) * s2 ** 2, rtol=0.02)
+    m4 = np.mean(dx ** 4)
+    np.testing.assert_allclose(m4, 3 * (f * s1 ** 4 + (1 - f) * s2 ** 4), rtol=0.05)        # heavier tails than one Gaussian
+    # its k-table: value 1 at k = 0, the mixture of the two Gaussian transforms elsewhere
+    from imsim_amd import tables
+    q = np.linspace(0.0, tables.KTABLE_QMAX, tables.KTABLE_NPTS)
+    k = q / p0
+    np.testing.assert_allclose(tab, f * np.exp(-0.5 * (k * s1) ** 2) + (1 - f) * np.exp(-0.5 * (k * s2) ** 2))
+    assert tab[0] == 1.0 and tab[-1] < 1e-12

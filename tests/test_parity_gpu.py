@@ -561,3 +561,27 @@ def test_sky_background_and_noise(torch_cuda):
     orc.lib.orc_flat_add(None, base.ctypes.data, 25000.0 * 0.2 * 0.2, 1.0, 99, lsst_image.NOISE_STREAM, 192, 160,
                          orc.image64.ctypes.data, None)
     assert_bits_equal(img, orc.image64, "sky noise")
+
+
+def test_photon_pooling_build_image_is_bit_exact(torch_cuda):
+    """C4 semantics end to end (imsim/photon_pooling.py:116-168): nbatch photon batches, nsubbatch object sub-batches,
+    one pixel-boundary recalculation per batch (tile-tagged on the GPU) -- image and boundaries equal the oracle's."""
+    from helpers import c3_small_case
+    from imsim_amd import photon_pooling, stamp
+    from imsim_amd.engine import Renderer
+    from oracle import orc_loader
+    scene, objects = c3_small_case(n_obj=90, n=192, flux_seed=6, scratch=0)
+    scene.track_static_delta = 1
+    modes = stamp.classify(objects["n_phot"].astype(float), 100.0)
+    r = Renderer(scene)
+    real = torch_cuda.zeros(len(objects), dtype=torch_cuda.float64, device="cuda")
+    n_gpu = photon_pooling.build_image(r, objects, modes, nbatch=5, nsubbatch=4, seed=21, realized=real)
+    r.synchronize()
+    orc = orc_loader.OracleScene(scene)
+    n_cpu = photon_pooling.build_image(orc, objects, modes, nbatch=5, nsubbatch=4, seed=21)
+    assert n_gpu == n_cpu == int(objects["n_phot"].sum())
+    assert_bits_equal(r.image_numpy(), orc.image, "pooling image")
+    ga = _sensor_arrays_gpu(r)
+    for name in ("boundary", "bounds", "delta"):
+        assert_bits_equal(ga[name], orc.sensor_array(name), f"pooling sensor {name}")
+    assert abs(real.sum().item() / r.image.sum().item() - 1) < 1e-12

@@ -163,12 +163,15 @@ class AtmosphericPSF:
     def _build_screens(self, rng, device):
         # galsim.Atmosphere: per-layer r0_500 = r0_500 * weight^(-3/5)
         r0s = self.r0_500 * self.r0_weights ** (-3.0 / 5.0)
+        # the kernels gather fp32 samples (192 -> 96 B per photon; 1e-7 relative on ~1e3 nm of path is far below
+        # anything a photon can notice): the screens are synthesised in f64 and stored as fp32
         if device is None:
-            return np.stack([von_karman_screen(self.npix, self.screen_scale, r0, self.L0, rng, self.kmax) for r0 in r0s])
+            return np.stack([von_karman_screen(self.npix, self.screen_scale, r0, self.L0, rng, self.kmax).astype(np.float32)
+                             for r0 in r0s])
         import torch
         gen = torch.Generator(device=device)
         gen.manual_seed(int(rng.integers(1 << 62)))
-        return torch.stack([von_karman_screen(self.npix, self.screen_scale, float(r0), self.L0, gen, self.kmax, xp=torch)
+        return torch.stack([von_karman_screen(self.npix, self.screen_scale, float(r0), self.L0, gen, self.kmax, xp=torch).to(torch.float32)
                             for r0 in r0s])
 
     # -- what the kernels consume --

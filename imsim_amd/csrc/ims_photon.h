@@ -87,28 +87,38 @@ IMS_DEV void shoot(const ims_render_params_t& P, const ims_object_t& o, int64_t 
     ph.pu = 0.0; ph.pv = 0.0; ph.t = 0.0;
 }
 
+IMS_DEV int wrap_index(double fl, double dn, double inv_n)
+{
+    // fl mod n for an integer-valued double (exact: |fl| < 2^53); the estimate of the quotient may be off by one
+    double r = fl - floor(fl * inv_n) * dn;
+    if (r < 0.0) r = r + dn;
+    if (r >= dn) r = r - dn;
+    return (int)r;
+}
+
 // sum over layers of the gradient of the bilinear interpolant of the periodic phase screens [nm/m]
 IMS_DEV void screen_gradient(const ims_atmosphere_t& A, double pu, double pv, double t, double tanx, double tany,
                              double& gx, double& gy)
 {
     double sx = 0.0, sy = 0.0;
     const int n = A.npix;
+    const double dn = (double)n, inv_n = 1.0 / dn, inv_scale = 1.0 / A.scale;
     for (int l = 0; l < A.n_layers; ++l) {
         const double x = pu - t * A.vx[l] + A.alt[l] * tanx;
         const double y = pv - t * A.vy[l] + A.alt[l] * tany;
-        const double fx = (x - A.x0) / A.scale, fy = (y - A.x0) / A.scale;
+        const double fx = (x - A.x0) * inv_scale, fy = (y - A.x0) * inv_scale;
         const double flx = floor(fx), fly = floor(fy);
         const double ax = fx - flx, ay = fy - fly;
-        int64_t ix = (int64_t)flx % n, iy = (int64_t)fly % n;
-        if (ix < 0) ix += n;
-        if (iy < 0) iy += n;
-        const int64_t ix1 = ix + 1 == n ? 0 : ix + 1, iy1 = iy + 1 == n ? 0 : iy + 1;
-        const double* S = A.screens + (int64_t)l * n * n;
-        const double f00 = S[iy * n + ix], f10 = S[iy * n + ix1], f01 = S[iy1 * n + ix], f11 = S[iy1 * n + ix1];
-        sx = sx + ((f10 - f00) * (1.0 - ay) + (f11 - f01) * ay) / A.scale;
-        sy = sy + ((f01 - f00) * (1.0 - ax) + (f11 - f10) * ax) / A.scale;
+        const int ix = wrap_index(flx, dn, inv_n), iy = wrap_index(fly, dn, inv_n);
+        const int ix1 = ix + 1 == n ? 0 : ix + 1, iy1 = iy + 1 == n ? 0 : iy + 1;
+        const float* S = A.screens + (int64_t)l * n * n;
+        const int64_t r0 = (int64_t)iy * n, r1 = (int64_t)iy1 * n;
+        const double f00 = (double)S[r0 + ix], f10 = (double)S[r0 + ix1];
+        const double f01 = (double)S[r1 + ix], f11 = (double)S[r1 + ix1];
+        sx = sx + ((f10 - f00) * (1.0 - ay) + (f11 - f01) * ay);
+        sy = sy + ((f01 - f00) * (1.0 - ax) + (f11 - f10) * ax);
     }
-    gx = sx; gy = sy;
+    gx = sx * inv_scale; gy = sy * inv_scale;
 }
 
 IMS_DEV void apply_psf(const ims_render_params_t& P, const ims_object_t& o, int comp, int64_t k, Rng& rng, Photon& ph)

@@ -228,12 +228,12 @@ class BoundScene:
             A = scene.atm.atmosphere_struct()
             scr = scene.atm.screens
             if isinstance(scr, np.ndarray):
-                _, A.screens = mem.put(scr, np.float64)
+                _, A.screens = mem.put(scr, np.float32)
             elif isinstance(mem, DeviceMem):
                 mem.keep.append(scr)                      # already a device tensor
                 A.screens = scr.data_ptr()
             else:
-                _, A.screens = mem.put(scr.cpu().numpy(), np.float64)
+                _, A.screens = mem.put(scr.cpu().numpy(), np.float32)
             self.atm_struct = A
             _, P.atm = mem.put_struct(A)
         self.sensor_host = None

@@ -160,7 +160,7 @@ typedef struct ims_atmosphere {
     double  aper_r_outer, aper_r_inner;   /* pupil sampling annulus [m] (diam 8.36, obscuration 0.61: atmPSF.py:168) */
     double  vx[IMS_MAX_LAYERS], vy[IMS_MAX_LAYERS];   /* m/s */
     double  alt[IMS_MAX_LAYERS];   /* m */
-    const double* screens;         /* [n_layers][npix][npix] */
+    const float*  screens;         /* [n_layers][npix][npix], fp32 samples (the arithmetic on them is f64) */
 } ims_atmosphere_t;
 
 typedef struct ims_op {

@@ -647,6 +647,9 @@ __global__ __launch_bounds__(256) void k_update_distortions_q3(const ims_sensor_
 // bounds of the pixels whose polygon moved (own cell, right cell or upper cell changed); one 16x16
 // tile of owner cells per workgroup, same grid as the update kernel.  With a tag, tiles that saw
 // neither charge nor movement (own, right and upper tile) leave after three byte loads.
+// NV > 0: the owned points of the cell and of its right / upper neighbours are fetched with independent loads into
+// registers and the vertex loop is unrolled (the generic loop issues one dependent load per vertex: 12 us per wave).
+template <int NV>
 __global__ __launch_bounds__(256) void k_refresh_changed(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
                                                          const int64_t* __restrict__ tile_prefix,
                                                          const unsigned char* __restrict__ changed, unsigned int tag)
@@ -684,22 +687,54 @@ __global__ __launch_bounds__(256) void k_refresh_changed(const ims_sensor_t* __r
     const bool f_right = ((lx + 1 < UT) ? own : right) && changed[cell_index(sl, i + 1, j)];
     const bool f_up = ((ly + 1 < UT) ? own : up) && changed[cell_index(sl, i, j + 1)];
     if (!(f_own || f_right || f_up)) return;
-    const int nV = s.num_vertices, nv = 4 * nV + 4;
+    const int nV = (NV > 0) ? NV : s.num_vertices, nv = 4 * nV + 4;
     double ixmin = 0.0, ixmax = 1.0, iymin = 0.0, iymax = 1.0;
     double oxmin = 0.0, oxmax = 1.0, oymin = 0.0, oymax = 1.0;
     double v0x = 0.0;
-    for (int k = 0; k < nv; ++k) {
-        double vx, vy;
-        polygon_vertex(s, sl, i, j, k, 1.0, vx, vy);
-        if (k == 0) v0x = vx;
-        if (vx < oxmin) oxmin = vx;
-        if (vx > oxmax) oxmax = vx;
-        if (vy < oymin) oymin = vy;
-        if (vy > oymax) oymax = vy;
-        if (k <= nV + 1) { if (vy > iymin) iymin = vy; }
-        if (k >= nV + 1 && k <= 2 * nV + 2) { if (vx < ixmax) ixmax = vx; }
-        if (k >= 2 * nV + 2 && k <= 3 * nV + 3) { if (vy < iymax) iymax = vy; }
-        if (k >= 3 * nV + 3) { if (vx > ixmin) ixmin = vx; }
+    if (NV > 0) {
+        constexpr int NPO = 2 * NV + 2;
+        constexpr int NVX = (NV > 0) ? NV : 1;
+        double2 own[(NV > 0) ? NPO : 1], rgt[NVX], upp[(NV > 0) ? NV + 2 : 1];
+        const double2* po = (const double2*)(s.bf_boundary + c * NPO * 2);
+        const double2* pr = (const double2*)(s.bf_boundary + cell_index(sl, i + 1, j) * NPO * 2);
+        const double2* pu = (const double2*)(s.bf_boundary + cell_index(sl, i, j + 1) * NPO * 2);
+#pragma unroll
+        for (int q = 0; q < NPO; ++q) own[q] = po[q];
+#pragma unroll
+        for (int m = 0; m < NV; ++m) rgt[m] = pr[NV + 2 + m];
+#pragma unroll
+        for (int q = 0; q < NV + 2; ++q) upp[q] = pu[q];
+#pragma unroll
+        for (int k = 0; k < 4 * NV + 4; ++k) {
+            double vx, vy;
+            if (k <= NV + 1) { vx = own[k].x; vy = own[k].y; }
+            else if (k <= 2 * NV + 1) { vx = rgt[k - NV - 2].x + 1.0; vy = rgt[k - NV - 2].y; }
+            else if (k <= 3 * NV + 3) { vx = upp[NV + 1 - (k - 2 * NV - 2)].x; vy = upp[NV + 1 - (k - 2 * NV - 2)].y + 1.0; }
+            else { vx = own[NV + 2 + (NV - 1 - (k - 3 * NV - 4))].x; vy = own[NV + 2 + (NV - 1 - (k - 3 * NV - 4))].y; }
+            if (k == 0) v0x = vx;
+            if (vx < oxmin) oxmin = vx;
+            if (vx > oxmax) oxmax = vx;
+            if (vy < oymin) oymin = vy;
+            if (vy > oymax) oymax = vy;
+            if (k <= NV + 1) { if (vy > iymin) iymin = vy; }
+            if (k >= NV + 1 && k <= 2 * NV + 2) { if (vx < ixmax) ixmax = vx; }
+            if (k >= 2 * NV + 2 && k <= 3 * NV + 3) { if (vy < iymax) iymax = vy; }
+            if (k >= 3 * NV + 3) { if (vx > ixmin) ixmin = vx; }
+        }
+    } else {
+        for (int k = 0; k < nv; ++k) {
+            double vx, vy;
+            polygon_vertex(s, sl, i, j, k, 1.0, vx, vy);
+            if (k == 0) v0x = vx;
+            if (vx < oxmin) oxmin = vx;
+            if (vx > oxmax) oxmax = vx;
+            if (vy < oymin) oymin = vy;
+            if (vy > oymax) oymax = vy;
+            if (k <= nV + 1) { if (vy > iymin) iymin = vy; }
+            if (k >= nV + 1 && k <= 2 * nV + 2) { if (vx < ixmax) ixmax = vx; }
+            if (k >= 2 * nV + 2 && k <= 3 * nV + 3) { if (vy < iymax) iymax = vy; }
+            if (k >= 3 * nV + 3) { if (vx > ixmin) ixmin = vx; }
+        }
     }
     if (v0x > ixmin) ixmin = v0x;
     double* bb = s.bf_bounds + c * 8;
@@ -1120,8 +1155,15 @@ int ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sens
     else
         hipLaunchKernelGGL(k_update_distortions, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot, n_slots,
                            tile_prefix_dev, changed_dev, tag);
-    hipLaunchKernelGGL(k_refresh_changed, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot, n_slots,
-                       tile_prefix_dev, (const unsigned char*)changed_dev, tag);
+    if (nV == 4)
+        hipLaunchKernelGGL(k_refresh_changed<4>, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot, n_slots,
+                           tile_prefix_dev, (const unsigned char*)changed_dev, tag);
+    else if (nV == 8)
+        hipLaunchKernelGGL(k_refresh_changed<8>, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot, n_slots,
+                           tile_prefix_dev, (const unsigned char*)changed_dev, tag);
+    else
+        hipLaunchKernelGGL(k_refresh_changed<0>, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot, n_slots,
+                           tile_prefix_dev, (const unsigned char*)changed_dev, tag);
     HIP_TRY(hipGetLastError());
     return IMS_OK;
 }

@@ -605,14 +605,33 @@ IMS_DEV bool inside_pixel(const ims_sensor_t& s, const SlotView& sl, int ix, int
     if (x > b0 && x < b1 && y > b2 && y < b3) inside = true;
     else if (!(x >= b[4] && x <= b[5] && y >= b[6] && y <= b[7])) inside = false;
     else {
+        // a wave takes this path whenever ONE of its 64 photons misses the inner bounds, i.e. almost always: the
+        // vertex addresses depend only on the loop counter, so the loop is unrolled four-fold to keep four
+        // independent loads in flight instead of one dependent load per vertex
         const double zfactor = dtanh_pos(zconv / 12.0);
-        const int nv = 4 * s.num_vertices + 4;
+        const int nV = s.num_vertices, npo = 2 * nV + 2, nv = 4 * nV + 4;
+        const double* own = s.bf_boundary + cell_index(sl, i, j) * npo * 2;
+        const double* rgt = s.bf_boundary + cell_index(sl, i + 1, j) * npo * 2;
+        const double* upp = s.bf_boundary + cell_index(sl, i, j + 1) * npo * 2;
+        const bool scaled = (zfactor != 1.0);
         double lx, ly;
         polygon_vertex(s, sl, i, j, nv - 1, zfactor, lx, ly);
         inside = false;
+#pragma unroll 4
         for (int k = 0; k < nv; ++k) {
-            double kx, ky;
-            polygon_vertex(s, sl, i, j, k, zfactor, kx, ky);
+            const double* b = own; int q = k; double ax = 0.0, ay = 0.0;
+            if (k > nV + 1) {
+                if (k <= 2 * nV + 1) { b = rgt; ax = 1.0; q = k; }                       // nV + 2 + (k - nV - 2)
+                else if (k <= 3 * nV + 3) { b = upp; ay = 1.0; q = 3 * nV + 3 - k; }     // nV + 1 - (k - 2 nV - 2)
+                else { q = 5 * nV + 5 - k; }                                             // nV + 2 + (nV - 1 - (k - 3 nV - 4))
+            }
+            const double2 p = *(const double2*)(b + 2 * q);
+            double kx = p.x + ax, ky = p.y + ay;
+            if (scaled) {
+                const double ex = s.emptypoly[2 * k], ey = s.emptypoly[2 * k + 1];
+                kx = ex + (kx - ex) * zfactor;
+                ky = ey + (ky - ey) * zfactor;
+            }
             if ((ky > y) != (ly > y)) {
                 const double xc = (lx - kx) * (y - ky) / (ly - ky) + kx;
                 if (x < xc) inside = !inside;

@@ -18,6 +18,7 @@ FT_DEFAULT = 5.0e-3        # galsim.GSParams().folding_threshold
 STEPK_MIN_HLR = 5.0        # galsim.GSParams().stepk_minimum_hlr
 SERSIC_N = (1.0, 4.0)
 KIND_KNOTS, KIND_STREAK = 3, 4
+FLAT_OBJECT_ID = 0x7E00000000          # object ids of the photon-flat iterations (imsim_amd.flat)
 
 
 def synthetic_catalog(n, seed=20261001, nx=4096, ny=4096, mag_min=16.0, mag_max=27.0):

@@ -318,10 +318,12 @@ class ProcessResult:
 
 def _process_flat(cfg, ev, image, res, device, data_dir):
     """`image.type: LSST_Flat` (imsim/flat.py): counts_per_pixel electrons per pixel through the pixel-area
-    feedback of the (optional) Silicon sensor; sed-weighted flats (flat.py:237-262) are not built."""
+    feedback of the (optional) Silicon sensor; with an `sed` item the photon branch (flat.py:237-262) runs instead,
+    with the flat-in-photons SED over the tabulated band standing in for the configured SED object."""
     from .engine import Renderer
-    if "sed" in image:
-        raise GalSimConfigError("LSST_Flat with an sed (photon branch, flat.py:237-262) is not supported on this path")
+    photon_branch = "sed" in image
+    if photon_branch:
+        res.ignored.append("image.sed")
     builder = flat.LSST_FlatBuilder()
     img_cfg = {k: ev.value(v) for k, v in image.items() if k in flat.FLAT_REQ or k in flat.FLAT_OPT}
     if not (img_cfg.get("xsize") or img_cfg.get("size")):
@@ -339,8 +341,10 @@ def _process_flat(cfg, ev, image, res, device, data_dir):
             tr, center = func, tuple(ev.value(sens.get("treering_center", (0.0, 0.0))))
     scene = configs.scene_flat(nx, ny, seed=seed, sensor=on, treering=tr, treering_center=center, strength=strength,
                                buffer_size=builder.buffer_size)
+    if photon_branch:
+        scene.track_static_delta = 1
     renderer = Renderer(scene, device)
-    img = builder.build_image(renderer, seed=seed)
+    img = builder.build_image_photons(renderer, seed=seed) if photon_branch else builder.build_image(renderer, seed=seed)
     res.images.append(img.to(renderer.torch.float32).cpu().numpy())
     res.det_names.append(str(image.get("det_name", "flat")))
     res.truth.append({"counts_per_pixel": builder.counts_per_pixel, "niter": builder.iterations()[0]})

@@ -172,6 +172,7 @@ def scene_flat(nx=256, ny=256, seed=1234, sensor=True, treering=None, treering_c
     nx, ny = nx + 2 * b, ny + 2 * b
     sc = Scene(nx=nx, ny=ny, xmin=1 - b, ymin=1 - b, seed=seed)
     sc.flat_buffer = b
+    sc.sed_tables, _ = r_band_sed_table()              # for the sed (photon) branch: flat-in-photons SED over the r band
     if sensor:
         model = sensormod.load_silicon_model(os.path.join(DATA_DIR, "sensor_models", "lsst_itl_50_4"), strength=strength)
         wl, al = tables.silicon_abs_length_table()

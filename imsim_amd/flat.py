@@ -1,10 +1,13 @@
-"""`image.type: LSST_Flat` (imsim/flat.py:21-283), area branch: the flat is built in `niter` iterations of
+"""`image.type: LSST_Flat` (imsim/flat.py:21-283).  Area branch (no sed): the flat is built in `niter` iterations of
 
     area = sensor.calculate_pixel_areas(image so far)        (tree rings + brighter-fatter)
     temp = base * area / mean(area);  Poisson(temp);  image += temp
 
 on the GPU: `ims_sensor_pixel_areas` (polygon areas of the live boundary state), `ims_flat_add`
 (Poisson realisation + add + delta charge) and `ims_sensor_update_distortions` between iterations.
+With an sed (flat.py:237-262) every iteration instead shoots Poisson(counts_per_iter x area) photons uniformly
+over the working image, samples their wavelengths and accumulates them through the sensor (conversion depth,
+diffusion, current pixel boundaries), `build_image_photons`.
 The reference builds the CCD in nx x ny sections with a buffer only to bound host memory
 (flat.py:183-197); here the whole CCD is one section.  Parameter surface as in the reference:
 counts_per_pixel (required), xsize, ysize, max_counts_per_iter, buffer_size, nx, ny (flat.py:45-58).
@@ -84,4 +87,38 @@ class LSST_FlatBuilder:
             else:
                 _abi.check(lib.ims_flat_add(None, base_t.data_ptr() if base_t is not None else None, level, 1.0, seed, it,
                                             sc.nx, sc.ny, renderer.image.data_ptr(), None, st), "ims_flat_add")
+        return crop(sc, renderer.image)
+
+
+    def build_image_photons(self, renderer, seed=0, sed_table=0):
+        """The sed branch (flat.py:237-262): per iteration nphotons ~ Poisson(counts_per_iter * area) photons at
+        uniform positions over the working image, wavelengths from scene.sed_tables[sed_table], through
+        sensor.accumulate(photons, section, resume=(it > 0)); the boundaries are updated between iterations from
+        the charge of the last one.  One Box-profile object per iteration carries the photons."""
+        from . import catalog
+        from ._abi import OBJECT_DTYPE, IMS_PROF_BOX
+        sc = renderer.scene
+        niter, counts_per_iter = self.iterations()
+        silicon = sc.sensor is not None
+        if silicon and not sc.track_static_delta:
+            raise ValueError("photon flats need scene.track_static_delta = 1 (the whole image is one brighter-fatter region)")
+        rng = np.random.default_rng([int(seed), 0xF1A7])
+        area = sc.nx * sc.ny
+        for it in range(niter):
+            n = int(rng.poisson(counts_per_iter * area))
+            obj = np.zeros(1, dtype=OBJECT_DTYPE)
+            obj["obj_id"] = catalog.FLAT_OBJECT_ID + it
+            obj["n_phot"] = n
+            obj["x0"], obj["y0"] = sc.xmin + (sc.nx - 1) / 2.0, sc.ymin + (sc.ny - 1) / 2.0      # centre of the working image
+            obj["flux_per_photon"] = 1.0
+            obj["prof_table"], obj["prof_scale"], obj["prof_aux"] = IMS_PROF_BOX, sc.nx * 0.2, sc.ny * 0.2
+            obj["jac"] = (1.0, 0.0, 0.0, 1.0)
+            obj["winv"] = (5.0, 0.0, 0.0, 5.0)
+            obj["dcr_cosp"] = 1.0
+            obj["sed_table"] = sed_table
+            obj["stamp_xmin"], obj["stamp_xmax"] = sc.xmin, sc.xmin + sc.nx - 1
+            obj["stamp_ymin"], obj["stamp_ymax"] = sc.ymin, sc.ymin + sc.ny - 1
+            if it > 0 and silicon:
+                renderer.update_distortions(0, 1)
+            renderer.render(obj)
         return crop(sc, renderer.image)

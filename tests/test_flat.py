@@ -67,3 +67,28 @@ def test_treerings_flat_variance_follows_the_ring_amplitude():
     np.testing.assert_allclose(mean, tot, rtol=1e-2)
     np.testing.assert_allclose(var, pred_var, rtol=3e-2)
     assert c10 > 0.5 * tot and c01 > 0.5 * tot and c11 > 0.5 * tot
+
+
+def test_photon_flat_sed_branch():
+    """flat.py:237-262: uniform photons with sampled wavelengths through the sensor, one boundary update per
+    iteration.  (Small here; tests/test_parity_gpu.py runs the reference-sized flat on the GPU.)"""
+    tot = 3_000.0
+    scene = configs.scene_flat(64, 64, sensor=True, buffer_size=6)
+    scene.track_static_delta = 1
+    o = orc_loader.OracleScene(scene)
+    b = flat.LSST_FlatBuilder()
+    b.setup({"counts_per_pixel": tot, "max_counts_per_iter": 1_000, "xsize": 64, "ysize": 64, "buffer_size": 6})
+    assert b.iterations() == (3, 1000.0)
+    img = np.array(b.build_image_photons(o, seed=5), dtype=np.float64)
+    assert img.shape == (64, 64)
+    # photons that diffuse across the edge of the working image are lost there, the buffer keeps the level inside
+    np.testing.assert_allclose(img.mean(), tot, rtol=1e-2)
+    np.testing.assert_allclose(img.var(), tot, rtol=0.10)
+    assert np.all(o.sensor_array("delta") >= 0)
+    # no sensor: plain Poisson image
+    s2 = configs.scene_flat(64, 64, sensor=False, buffer_size=0)
+    o2 = orc_loader.OracleScene(s2)
+    b.setup({"counts_per_pixel": 1500.0, "max_counts_per_iter": 1000, "xsize": 64, "ysize": 64, "buffer_size": 0})
+    img2 = np.array(b.build_image_photons(o2, seed=6), dtype=np.float64)
+    np.testing.assert_allclose(img2.mean(), 1500.0, rtol=1e-2)
+    np.testing.assert_allclose(img2.var(), 1500.0, rtol=0.08)

@@ -585,3 +585,33 @@ def test_photon_pooling_build_image_is_bit_exact(torch_cuda):
     for name in ("boundary", "bounds", "delta"):
         assert_bits_equal(ga[name], orc.sensor_array(name), f"pooling sensor {name}")
     assert abs(real.sum().item() / r.image.sum().item() - 1) < 1e-12
+
+
+def test_photon_flat_is_bit_exact_and_shows_brighter_fatter(torch_cuda):
+    """LSST_Flat, sed branch (imsim/flat.py:237-262): small case bit-exact vs the oracle; reference-sized case
+    (256^2, 80 000 e-/px in 20 iterations) has variance below the mean and positive neighbour covariances."""
+    from imsim_amd import configs, flat
+    from imsim_amd.engine import Renderer
+    from oracle import orc_loader
+    b = flat.LSST_FlatBuilder()
+    cfg = {"counts_per_pixel": 2400.0, "max_counts_per_iter": 800, "xsize": 48, "ysize": 40, "buffer_size": 5}
+    b.setup(cfg)
+    scene = configs.scene_flat(48, 40, sensor=True, seed=3)
+    scene.track_static_delta = 1
+    r = Renderer(scene)
+    img = b.build_image_photons(r, seed=9).cpu().numpy()
+    orc = orc_loader.OracleScene(scene)
+    b.build_image_photons(orc, seed=9)
+    assert_bits_equal(img, flat.crop(scene, orc.image64), "photon flat")
+    assert_bits_equal(_sensor_arrays_gpu(r)["boundary"], orc.sensor_array("boundary"), "photon flat boundaries")
+    tot = 80_000.0
+    b.setup({"counts_per_pixel": tot, "max_counts_per_iter": 4000, "xsize": 256, "ysize": 256})
+    scene = configs.scene_flat(256, 256, sensor=True)
+    scene.track_static_delta = 1
+    r = Renderer(scene)
+    img = b.build_image_photons(r, seed=1234).cpu().numpy()
+    a = img - img.mean()
+    cov10 = np.mean(a[1:, :] * a[:-1, :])
+    np.testing.assert_allclose(img.mean(), tot, rtol=1e-2)
+    assert 0.85 * tot < img.var() < tot
+    assert cov10 > 1e-2 * tot

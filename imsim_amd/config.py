@@ -18,7 +18,7 @@ import numpy as np
 import yaml
 
 from . import _abi, atm_psf, catalog, configs, diffraction, fft_draw, instcat, lsst_image, optics as opticsmod
-from . import flat, sensor as sensormod, tables, treerings
+from . import flat, parallel, sensor as sensormod, tables, treerings
 from .engine import Scene, SensorSetup, make_slots
 from .lsst_image import GalSimConfigError
 
@@ -351,9 +351,13 @@ def _process_flat(cfg, ev, image, res, device, data_dir):
     return res
 
 
-def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=None, logger=None):
+def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=None, logger=None, rank=0, world=1):
     """galsim.config.Process restricted to this path: reads inputs, then for every requested CCD
-    builds the scene and runs the image builder on the GPU.  Returns a ProcessResult."""
+    builds the scene and runs the image builder on the GPU.  Returns a ProcessResult.
+
+    rank / world: one process per GPU; the CCDs of the visit (output.det_num.first, output.nfiles) are dealt
+    round-robin to the ranks (parallel.shard_ccds, the per-CCD fan-out of imsim/ccd.py:72-89) and need no
+    exchange at all."""
     from .engine import Renderer
     cfg = load_config(config, template_dirs, overrides)
     res = ProcessResult()
@@ -400,7 +404,7 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
     meta = cfg.get("_opsim_data", {})
     band = meta.get("band", "r")
     seed = int(ev.value(image.get("random_seed", meta.get("seed", 0))))
-    for det in range(first, first + nfiles):
+    for det in parallel.shard_ccds(range(first, first + nfiles), rank, world):
         det_name = det_name_of(det)
         ev.vars["det_name"] = det_name
         builder = valid_image_types[itype]()

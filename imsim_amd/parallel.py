@@ -41,6 +41,12 @@ def shard_objects(objects, rank, world):
     return mine[np.argsort(tile, kind="stable")]
 
 
+def shard_ccds(dets, rank, world):
+    """The CCDs this rank renders when a whole focal plane is spread over the GPUs of a node (C5: CCD i -> GPU
+    i mod world; CCDs are independent, imsim/ccd.py:72-89)."""
+    return [d for k, d in enumerate(dets) if k % world == rank]
+
+
 def reduce_image(image, dst=0):
     """Sum the per-rank CCD images onto `dst` (no-op for a single process)."""
     import torch.distributed as dist

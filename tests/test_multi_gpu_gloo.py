@@ -109,3 +109,13 @@ def test_two_rank_photon_pooling_with_brighter_fatter_equals_single_process(tmp_
     ref = orc_loader.OracleScene(scene)
     photon_pooling.build_image(ref, objects, modes, nbatch=1, nsubbatch=3, seed=11)
     assert not np.array_equal(ref.sensor_array("boundary"), orc.sensor_array("boundary"))
+
+
+def test_ccds_are_dealt_round_robin():
+    from imsim_amd import parallel
+    dets = list(range(189))
+    parts = [parallel.shard_ccds(dets, r, 8) for r in range(8)]
+    assert sorted(sum(parts, [])) == dets
+    assert max(len(p) for p in parts) == 24 and min(len(p) for p in parts) == 23       # ceil(189 / 8)
+    assert parts[3][:3] == [3, 11, 19]
+    assert parallel.shard_ccds(dets, 0, 1) == dets

@@ -62,3 +62,43 @@ def test_product_does_not_import_oracle():
                 text = open(os.path.join(dp, f)).read()
                 assert "orc_" not in text and "liboracle" not in text and "import oracle" not in text \
                     and "from oracle" not in text, f
+
+
+def test_argument_errors_are_reported_before_any_launch():
+    """Error behaviour of the C-ABI: every entry point returns a negative code and sets ims_last_error; the checks
+    run before the first HIP call, so they are testable without a GPU."""
+    lib = _abi.load()
+    P = _abi.RenderParams()
+    P.seg_size, P.n_objects, P.n_segments = 128, 0, 0
+    assert lib.ims_shoot_accumulate(C.byref(P), None) < 0 and b"seg_size" in lib.ims_last_error()
+    P.seg_size, P.n_psf = 256, _abi.IMS_MAX_PSF + 1
+    assert lib.ims_shoot_accumulate(C.byref(P), None) < 0 and b"n_psf" in lib.ims_last_error()
+    P.n_psf, P.n_ops = 0, _abi.IMS_MAX_OPS + 1
+    assert lib.ims_shoot_accumulate(C.byref(P), None) < 0 and b"n_ops" in lib.ims_last_error()
+    P.n_ops = 1
+    P.ops[0].kind = _abi.IMS_OP_RUBIN_OPTICS                     # ray tracing without an optics descriptor
+    assert lib.ims_shoot_accumulate(C.byref(P), None) < 0 and b"optics" in lib.ims_last_error()
+    P.n_ops, P.n_psf = 0, 1
+    P.psf[0].kind = _abi.IMS_PSF_SCREENS                         # phase screens without an atmosphere
+    assert lib.ims_shoot_accumulate(C.byref(P), None) < 0 and b"atmosphere" in lib.ims_last_error()
+    P.n_psf, P.n_objects = 0, 5                                  # objects announced but no table
+    assert lib.ims_shoot_accumulate(C.byref(P), None) < 0 and b"NULL" in lib.ims_last_error()
+    P.n_objects = 0                                              # valid and empty, but no image
+    assert lib.ims_shoot_accumulate(C.byref(P), None) < 0 and b"image" in lib.ims_last_error()
+    # sensor entry points need the host copy of the slot table
+    assert lib.ims_sensor_init_boundaries(None, None, 0, 1, None) < 0
+    S = _abi.Sensor()
+    assert lib.ims_sensor_init_boundaries(C.byref(S), C.byref(S), 0, 1, None) < 0 and b"slot" in lib.ims_last_error()
+    assert lib.ims_flat_add(None, None, 1.0, 1.0, 0, 0, 8, 8, None, None, None) < 0 and b"image" in lib.ims_last_error()
+    assert lib.ims_image_to_float(None, None, 8, None) < 0
+    # a plan that names a stream it was not given
+    it = _abi.PlanItem()
+    it.kind, it.stream = _abi.IMS_PLAN_RECORD, 3
+    streams = (C.c_void_p * 1)(None)
+    assert lib.ims_run_plan(C.byref(it), 1, None, None, None, streams, 1) < 0 and b"stream" in lib.ims_last_error()
+    # the derived-field helpers are pure host code
+    op = _abi.Op()
+    op.kind = _abi.IMS_OP_PHOTON_DCR
+    op.p[0], op.p[1], op.p[2], op.p[3] = 620.0, 69.328, 293.15, 1.067
+    assert lib.ims_fill_derived_op(C.byref(op)) == 0
+    assert 1.0e-7 < op.p[5] < 1.0e-5 and 0.0 < op.p[6] < 1.0e-5 and 1.0e-4 < op.p[7] < 4.0e-4      # n - 1 ~ 1.9e-4 at 69 kPa

@@ -159,3 +159,16 @@ def test_brighter_fatter_makes_spots_larger_and_conserves_flux():
     sigma_r = 1.0 / np.sqrt(1e6)
     assert r1 - r0 > 2 * sigma_r
     assert abs(e2v.sum() - none.sum()) / none.sum() < 2e-3
+
+
+def test_oracle_reproduces_the_frozen_spec_digests():
+    """tests/golden/pipeline_golden.json freezes the numerics spec: C2 image, C3 photon fields
+    after the op chain, the LSST_Image brighter-fatter image and the photon-pooling image of small seeded cases."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_pipeline_golden as g
+    want = json.load(open(os.path.join(HERE, "golden", "pipeline_golden.json")))
+    assert want["spec"] == "v4"
+    got = {k: g.digest(v) for k, v in g.cases(g.oracle_backend).items()}
+    assert got == want["sha256"]

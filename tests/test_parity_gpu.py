@@ -615,3 +615,21 @@ def test_photon_flat_is_bit_exact_and_shows_brighter_fatter(torch_cuda):
     np.testing.assert_allclose(img.mean(), tot, rtol=1e-2)
     assert 0.85 * tot < img.var() < tot
     assert cov10 > 1e-2 * tot
+
+
+def test_gpu_reproduces_the_frozen_spec_digests(torch_cuda):
+    """the same digests (tests/golden/pipeline_golden.json) from the HIP path alone, without the oracle in the loop"""
+    import json, os, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_pipeline_golden as g
+    from imsim_amd.engine import Renderer
+
+    class B(Renderer):
+        def image64_host(self):
+            self.synchronize()
+            return self.image.cpu().numpy()
+
+    want = json.load(open(os.path.join(here, "golden", "pipeline_golden.json")))
+    got = {k: g.digest(v) for k, v in g.cases(B).items()}
+    assert got == want["sha256"]

@@ -1188,7 +1188,8 @@ int ims_run_plan(const ims_plan_item_t* items, int64_t n_items, const ims_sensor
         case IMS_PLAN_INIT:       rc = ims_sensor_init_boundaries(sensor_dev, sensor_host, it.first_slot, it.n_slots, st); break;
         case IMS_PLAN_RECORD:
         case IMS_PLAN_WAIT: {
-            static std::vector<hipEvent_t> evs;
+            static std::vector<hipEvent_t> evs;          // library events of RECORD / WAIT items (one process per GPU)
+            if (it.n_slots < 0 || it.n_slots > 65535) return set_err(IMS_ERR_ARG, "plan event number out of range");
             while ((int)evs.size() <= it.n_slots) {
                 hipEvent_t e;
                 HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));

@@ -633,8 +633,10 @@ IMS_DEV bool inside_pixel(const ims_sensor_t& s, const SlotView& sl, int ix, int
                 ky = ey + (ky - ey) * zfactor;
             }
             if ((ky > y) != (ly > y)) {
-                const double xc = (lx - kx) * (y - ky) / (ly - ky) + kx;
-                if (x < xc) inside = !inside;
+                // x < (lx - kx) (y - ky) / (ly - ky) + kx, cross-multiplied (ly != ky here): no division
+                const double dy = ly - ky;
+                const double lhs = (x - kx) * dy, rhs = (lx - kx) * (y - ky);
+                if ((dy > 0.0) ? (lhs < rhs) : (lhs > rhs)) inside = !inside;
             }
             lx = kx; ly = ky;
         }

@@ -243,8 +243,10 @@ static int inside_pixel(const ims_sensor_t* s, const ims_bf_slot_t* sl, int ix, 
         inside = 0;
         for (int k = 0, l = nv - 1; k < nv; l = k++) {
             if ((vy[k] > y) != (vy[l] > y)) {
-                double xc = (vx[l] - vx[k]) * (y - vy[k]) / (vy[l] - vy[k]) + vx[k];
-                if (x < xc) inside = !inside;
+                /* x < (lx - kx) (y - ky) / (ly - ky) + kx, cross-multiplied (ly != ky here): no division */
+                double dy = vy[l] - vy[k];
+                double lhs = (x - vx[k]) * dy, rhs = (vx[l] - vx[k]) * (y - vy[k]);
+                if ((dy > 0.0) ? (lhs < rhs) : (lhs > rhs)) inside = !inside;
             }
         }
     }

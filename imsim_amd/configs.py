@@ -277,3 +277,37 @@ BENCH_CONFIGS["c3b"].update(
     objects=lambda cat, phot, scene: c3b_objects(cat, phot, scene),
     cpu_sample=8000,
 )
+
+
+def _c4_scene_bench():
+    sc = scene_c3()
+    sc.track_static_delta = 1                     # pooling mode: the whole CCD is one brighter-fatter region
+    return sc
+
+
+def _c4_step(renderer, objects):
+    from . import photon_pooling, stamp
+    modes = stamp.classify(objects["n_phot"].astype(float), 100.0)
+    return photon_pooling.prepared_image(renderer, objects, modes, nbatch=10, seed=renderer.scene.seed)
+
+
+def _c4_cpu_step(orc, sample):
+    from . import photon_pooling, stamp
+    modes = stamp.classify(sample["n_phot"].astype(float), 100.0)
+    photon_pooling.build_image(orc, sample, modes, nbatch=10, nsubbatch=50, seed=orc.scene.seed)
+
+
+BENCH_CONFIGS["c4"] = dict(
+    n_objects=1000000,
+    workload="C4: 1M-source synthetic instcat, LSST_PhotonPoolingImage semantics (nbatch 10, one pixel-boundary "
+             "recalculation of the whole CCD per batch, nrecalc 0), full photon-op chain, Silicon (lsst_e2v_50_4) "
+             "brighter-fatter + tree rings, Kolmogorov+Gaussian PSF, 4096x4096 CCD",
+    scene=_c4_scene_bench,
+    objects=lambda cat, phot, scene: c3_objects(cat, phot, scene),
+    make_step=_c4_step,
+    timed_kernel=1,
+    kernel="k_shoot_accumulate",
+    cpu_sample=10000,
+    cpu_scene=lambda scene: scene,
+    cpu_step=_c4_cpu_step,
+)

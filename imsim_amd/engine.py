@@ -668,12 +668,13 @@ class Renderer:
         }
         return launch
 
-    def prepared(self, objects):
+    def prepared(self, objects, bf_tag=0):
         """Upload an object table once; returns a zero-argument callable that launches the fused
         kernel (used by bench.py so that the timed region has its inputs resident in HBM)."""
         objects, obj_t, prefix, pre_t = self._upload_objects(objects)
         P = self.bound.params(obj_t.data_ptr(), len(objects), pre_t.data_ptr(), int(prefix[-1]),
                               self.image.data_ptr(), None, _seg_ptr(pre_t))
+        P.bf_tag = bf_tag
         ref = C.byref(P)
         keep = (obj_t, pre_t, P)
 

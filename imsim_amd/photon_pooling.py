@@ -73,6 +73,66 @@ def check_stamp_type(stamp_type):
         raise GalSimConfigValueError(f"Must use stamp.type = LSST_Photons with LSST_PhotonPoolingImage. ({stamp_type})")
 
 
+def make_batch_tables(objects, modes, nbatch, seed):
+    """The photon batches of LSST_PhotonPoolingImageBuilder.buildImage (imsim/photon_pooling.py:116-140): every
+    PHOT object appears in every batch with 1/nbatch of its photons (integer split of its photon index range),
+    every FAINT object in one random batch.  Returns ([(object table, row index into `objects`)], size of the
+    smallest batch)."""
+    infos = [ObjectInfo(i, int(objects["n_phot"][i]), modes[i]) for i in range(len(objects))]
+    _, phot, faint = partition_objects(infos, nbatch)
+    nb = max(min(nbatch, len(phot)), 1)
+    gen = np.random.default_rng([int(seed), 0xFA17])
+    # batch membership: bright objects in every batch with their flux share; faint in one batch
+    phot_idx = np.array([o.index for o in phot], dtype=np.int64)
+    faint_idx = np.array([o.index for o in faint], dtype=np.int64)
+    faint_where = np.array([int(gen.random() * nb) for _ in faint], dtype=np.int64)
+    F = objects["n_phot"][phot_idx].astype(np.int64) if len(phot_idx) else np.zeros(0, np.int64)
+    len_smallest = None
+    batch_tables = []
+    for i in range(nb):
+        part = objects[phot_idx].copy()
+        lo, hi = (F * i) // nb, (F * (i + 1)) // nb
+        part["phot_first"] = objects["phot_first"][phot_idx] + lo
+        part["n_phot"] = hi - lo
+        fsel = faint_idx[faint_where == i] if len(faint_idx) else faint_idx
+        fpart = objects[fsel].copy()
+        table = np.concatenate([part, fpart])
+        index = np.concatenate([phot_idx, fsel])
+        batch_tables.append((table, index))
+        len_smallest = len(table) if len_smallest is None else min(len_smallest, len(table))
+    return batch_tables, len_smallest
+
+
+def prepared_image(renderer, objects, modes, nbatch=10, seed=0):
+    """The same image as build_image, prepared for replay (bench.py): every batch is ONE fused launch
+    (shoot -> PSF -> ops -> sensor, ims_shoot_accumulate) over its pre-uploaded object table -- the photons of a batch
+    see frozen pixel boundaries, so neither the sub-batching (a memory bound of the reference) nor the staging
+    through a photon pool changes the result -- with the pixel-boundary recalculation between batches.
+    Returns a zero-argument callable."""
+    objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
+    tables, _ = make_batch_tables(objects, modes, nbatch, seed)
+    sensor_on = renderer.scene.sensor is not None
+    launches = []
+    for i, (table, _) in enumerate(tables):
+        table = table[table["n_phot"] > 0].copy()
+        table["bf_state"] = 0
+        table["flags"] &= ~IMS_OBJ_FAINT
+        launches.append(renderer.prepared(table, bf_tag=(i % 255 + 1) if sensor_on else 0))
+
+    def run():
+        if sensor_on:
+            renderer.init_boundaries(0, 1)                 # a new CCD starts from undistorted (+ tree ring) boundaries
+        for i, launch in enumerate(launches):
+            if sensor_on and i > 0:
+                renderer.update_distortions(0, 1, bf_tag=(i - 1) % 255 + 1)
+            launch()
+    run.photons = sum(l.photons for l in launches)
+    run.object_rows = sum(l.object_rows for l in launches)
+    run.timed = {1: (len(launches), sum(l.timed[1][1] for l in launches)), 2: (0, 0)}
+    run.keep = launches
+    return run
+
+
 def build_image(renderer, objects, modes, nbatch=10, nsubbatch=50, seed=0, realized=None, rank=0, world=1):
     """LSST_PhotonPoolingImageBuilder.buildImage for the photon-shooting objects
     (imsim/photon_pooling.py:116-168).
@@ -88,31 +148,10 @@ def build_image(renderer, objects, modes, nbatch=10, nsubbatch=50, seed=0, reali
     updatePixelDistortions; the per-rank images are summed by the caller (parallel.reduce_image).  Unit
     fluxes make both sums exact, so the result equals the single-process one bit for bit."""
     objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
-    infos = [ObjectInfo(i, int(objects["n_phot"][i]), modes[i]) for i in range(len(objects))]
-    _, phot, faint = partition_objects(infos, nbatch)
-    nb = max(min(nbatch, len(phot)), 1)
-    gen = np.random.default_rng([int(seed), 0xFA17])
-    # batch membership: bright objects in every batch with their flux share; faint in one batch
-    faint_batch = {o.index: int(gen.random() * nb) for o in faint}
-    phot_idx = np.array([o.index for o in phot], dtype=np.int64)
-    faint_idx = np.array([o.index for o in faint], dtype=np.int64)
-    F = objects["n_phot"][phot_idx].astype(np.int64) if len(phot_idx) else np.zeros(0, np.int64)
+    batch_tables, len_smallest = make_batch_tables(objects, modes, nbatch, seed)
     total = 0
     sensor_on = renderer.scene.sensor is not None
     owner = parallel.assign_ranks(objects["n_phot"], world)
-    len_smallest = None
-    batch_tables = []
-    for i in range(nb):
-        part = objects[phot_idx].copy()
-        lo, hi = (F * i) // nb, (F * (i + 1)) // nb
-        part["phot_first"] = objects["phot_first"][phot_idx] + lo
-        part["n_phot"] = hi - lo
-        fsel = faint_idx[[faint_batch[j] == i for j in faint_idx]] if len(faint_idx) else faint_idx
-        fpart = objects[fsel].copy()
-        table = np.concatenate([part, fpart])
-        index = np.concatenate([phot_idx, fsel])
-        batch_tables.append((table, index))
-        len_smallest = len(table) if len_smallest is None else min(len_smallest, len(table))
     nsub = max(min(nsubbatch, len_smallest or 1), 1)
     for i, (table, index) in enumerate(batch_tables):
         if len(table) == 0:

@@ -585,6 +585,18 @@ def test_photon_pooling_build_image_is_bit_exact(torch_cuda):
     for name in ("boundary", "bounds", "delta"):
         assert_bits_equal(ga[name], orc.sensor_array(name), f"pooling sensor {name}")
     assert abs(real.sum().item() / r.image.sum().item() - 1) < 1e-12
+    # the replayable form (one fused launch per batch, bench config c4) gives the same image and sensor state
+    r2 = Renderer(scene)
+    run = photon_pooling.prepared_image(r2, objects, modes, nbatch=5, seed=21)
+    run()
+    r2.synchronize()
+    assert run.photons == n_gpu
+    assert_bits_equal(r2.image_numpy(), orc.image, "prepared pooling image")
+    assert_bits_equal(_sensor_arrays_gpu(r2)["boundary"], orc.sensor_array("boundary"), "prepared pooling boundaries")
+    r2.image.zero_()
+    run()                                                        # replay: a fresh CCD
+    r2.synchronize()
+    assert_bits_equal(r2.image_numpy(), orc.image, "replayed pooling image")
 
 
 def test_photon_flat_is_bit_exact_and_shows_brighter_fatter(torch_cuda):

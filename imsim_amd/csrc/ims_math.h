@@ -13,6 +13,18 @@ namespace ims {
 
 struct Draw { uint64_t a, b; };
 
+// fma(a, b, K) for a literal K (a Horner step).  gfx950 cannot encode 64-bit literals; left to itself the compiler
+// materialises K with two v_mov_b32 into the accumulator of a two-address v_fmac_f64 -- three vector instructions
+// per step (a fifth of the photon kernels' vector issue slots).  Stated explicitly, K sits in a scalar register pair
+// (two s_mov_b32 on the scalar unit, which issues beside the vector work of the other waves) and the step is ONE
+// v_fma_f64.  Same operation, same rounding.
+IMS_DEV double fma_k(double a, double b, double k)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+    return r;
+}
+
 IMS_DEV void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
 {
 #pragma unroll
@@ -87,17 +99,17 @@ IMS_DEV double dlog(double x)
     const double s = (m - 1.0) / (m + 1.0);
     const double z = s * s;
     double p = 1.0 / 25.0;
-    p = fma(p, z, 1.0 / 23.0);
-    p = fma(p, z, 1.0 / 21.0);
-    p = fma(p, z, 1.0 / 19.0);
-    p = fma(p, z, 1.0 / 17.0);
-    p = fma(p, z, 1.0 / 15.0);
-    p = fma(p, z, 1.0 / 13.0);
-    p = fma(p, z, 1.0 / 11.0);
-    p = fma(p, z, 1.0 / 9.0);
-    p = fma(p, z, 1.0 / 7.0);
-    p = fma(p, z, 1.0 / 5.0);
-    p = fma(p, z, 1.0 / 3.0);
+    p = fma_k(p, z, 1.0 / 23.0);
+    p = fma_k(p, z, 1.0 / 21.0);
+    p = fma_k(p, z, 1.0 / 19.0);
+    p = fma_k(p, z, 1.0 / 17.0);
+    p = fma_k(p, z, 1.0 / 15.0);
+    p = fma_k(p, z, 1.0 / 13.0);
+    p = fma_k(p, z, 1.0 / 11.0);
+    p = fma_k(p, z, 1.0 / 9.0);
+    p = fma_k(p, z, 1.0 / 7.0);
+    p = fma_k(p, z, 1.0 / 5.0);
+    p = fma_k(p, z, 1.0 / 3.0);
     p = fma(p, z, 1.0);
     const double lm = 2.0 * s * p;
     const double de = (double)e;
@@ -110,16 +122,16 @@ IMS_DEV double dexp(double x)
     double r = fma(-kf, LN2_HI, x);
     r = fma(-kf, LN2_LO, r);
     double p = 1.0 / 6227020800.0;
-    p = fma(p, r, 1.0 / 479001600.0);
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
+    p = fma_k(p, r, 1.0 / 479001600.0);
+    p = fma_k(p, r, 1.0 / 39916800.0);
+    p = fma_k(p, r, 1.0 / 3628800.0);
+    p = fma_k(p, r, 1.0 / 362880.0);
+    p = fma_k(p, r, 1.0 / 40320.0);
+    p = fma_k(p, r, 1.0 / 5040.0);
+    p = fma_k(p, r, 1.0 / 720.0);
+    p = fma_k(p, r, 1.0 / 120.0);
+    p = fma_k(p, r, 1.0 / 24.0);
+    p = fma_k(p, r, 1.0 / 6.0);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
@@ -134,26 +146,26 @@ IMS_DEV double sin_kernel(double t)
 {
     const double z = t * t;
     double p = 1.0 / 355687428096000.0;
-    p = fma(p, z, -1.0 / 1307674368000.0);
-    p = fma(p, z, 1.0 / 6227020800.0);
-    p = fma(p, z, -1.0 / 39916800.0);
-    p = fma(p, z, 1.0 / 362880.0);
-    p = fma(p, z, -1.0 / 5040.0);
-    p = fma(p, z, 1.0 / 120.0);
-    p = fma(p, z, -1.0 / 6.0);
+    p = fma_k(p, z, -1.0 / 1307674368000.0);
+    p = fma_k(p, z, 1.0 / 6227020800.0);
+    p = fma_k(p, z, -1.0 / 39916800.0);
+    p = fma_k(p, z, 1.0 / 362880.0);
+    p = fma_k(p, z, -1.0 / 5040.0);
+    p = fma_k(p, z, 1.0 / 120.0);
+    p = fma_k(p, z, -1.0 / 6.0);
     return fma(t * z, p, t);
 }
 IMS_DEV double cos_kernel(double t)
 {
     const double z = t * t;
     double p = -1.0 / 6402373705728000.0;
-    p = fma(p, z, 1.0 / 20922789888000.0);
-    p = fma(p, z, -1.0 / 87178291200.0);
-    p = fma(p, z, 1.0 / 479001600.0);
-    p = fma(p, z, -1.0 / 3628800.0);
-    p = fma(p, z, 1.0 / 40320.0);
-    p = fma(p, z, -1.0 / 720.0);
-    p = fma(p, z, 1.0 / 24.0);
+    p = fma_k(p, z, 1.0 / 20922789888000.0);
+    p = fma_k(p, z, -1.0 / 87178291200.0);
+    p = fma_k(p, z, 1.0 / 479001600.0);
+    p = fma_k(p, z, -1.0 / 3628800.0);
+    p = fma_k(p, z, 1.0 / 40320.0);
+    p = fma_k(p, z, -1.0 / 720.0);
+    p = fma_k(p, z, 1.0 / 24.0);
     p = fma(p, z, -0.5);
     return fma(z, p, 1.0);
 }
@@ -187,18 +199,18 @@ IMS_DEV double datan(double x)
     const double cc = b / (1.0 + sqrt(fma(b, b, 1.0)));
     const double z = cc * cc;
     double p = 1.0 / 27.0;
-    p = fma(p, z, -1.0 / 25.0);
-    p = fma(p, z, 1.0 / 23.0);
-    p = fma(p, z, -1.0 / 21.0);
-    p = fma(p, z, 1.0 / 19.0);
-    p = fma(p, z, -1.0 / 17.0);
-    p = fma(p, z, 1.0 / 15.0);
-    p = fma(p, z, -1.0 / 13.0);
-    p = fma(p, z, 1.0 / 11.0);
-    p = fma(p, z, -1.0 / 9.0);
-    p = fma(p, z, 1.0 / 7.0);
-    p = fma(p, z, -1.0 / 5.0);
-    p = fma(p, z, 1.0 / 3.0);
+    p = fma_k(p, z, -1.0 / 25.0);
+    p = fma_k(p, z, 1.0 / 23.0);
+    p = fma_k(p, z, -1.0 / 21.0);
+    p = fma_k(p, z, 1.0 / 19.0);
+    p = fma_k(p, z, -1.0 / 17.0);
+    p = fma_k(p, z, 1.0 / 15.0);
+    p = fma_k(p, z, -1.0 / 13.0);
+    p = fma_k(p, z, 1.0 / 11.0);
+    p = fma_k(p, z, -1.0 / 9.0);
+    p = fma_k(p, z, 1.0 / 7.0);
+    p = fma_k(p, z, -1.0 / 5.0);
+    p = fma_k(p, z, 1.0 / 3.0);
     p = fma(p, z, -1.0);
     const double at = -(cc * p);
     double res = fma(2.0, at, off);

@@ -113,7 +113,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": hbm_traffic(args.config, cfg["kernel"], world),
                 "kernel": cfg["kernel"], "mean_launch_ms": k_ms, "timed_launches_per_step": launches_per_step,
                 "kernel_ms_per_step": float(ms.value) / args.steps if have_ms else None,
-                "algorithmic_bytes_per_launch": bytes_per_launch, "photons_per_step": step.photons}
+                "algorithmic_bytes_per_launch": bytes_per_launch, "photons_per_step": step.photons,
+                "limiter": "f64 VALU issue (rocprofv3 PMC, profiles/round1_c3_final_sq_pmc.txt: VALU busy 89 % of the "
+                           "SIMD cycles of this kernel); HBM is the stated bound of SURVEY 8(d), not the measured one"}
 
     out = {
         "metric": "objects/sec into one 4k x 4k LSST CCD (photon-shooting path)",

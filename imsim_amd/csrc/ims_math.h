@@ -82,6 +82,41 @@ IMS_DEV double w01(uint32_t w) { return fma((double)w, 0x1.0p-32, 0x1.0p-33); }
 IMS_DEV double u01(uint64_t k) { return (double)k * 0x1.0p-53; }
 IMS_DEV double u01_open(uint64_t k) { return (double)(k + 1) * 0x1.0p-53; }
 
+// IEEE-correct division and square root for operands in the normal range.  The compiler's expansions wrap the same
+// Newton / residual-correction cores in range scaling (v_div_scale x2, v_ldexp x2, compares) and special-value
+// fix-ups (v_div_fixup, v_cmp_class + selects) for zeros, infinities and results near the ends of the exponent
+// range: 11 and 18 instructions.  The photon arithmetic never gets there (positions, slopes, indices and
+// wavelengths of order 1e-12 .. 1e12), so the hot path states the cores alone -- 8 and 10 instructions with the
+// same correctly rounded result (tests/test_parity_gpu.py::test_lean_div_sqrt compares 2^26 random operand pairs
+// per decade range bit for bit with the full expansions).
+//   ddiv(a, b):   b finite, non-zero, |b| and |a/b| within 2^+-500
+//   dsqrt_n(x):   x > 0 finite within 2^+-500;   dsqrt0(x): additionally exact for x == 0
+IMS_DEV double ddiv(double a, double b)
+{
+    double y = __builtin_amdgcn_rcp(b);
+    double e = fma(-b, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-b, y, 1.0);
+    y = fma(y, e, y);
+    const double q = a * y;
+    const double r = fma(-b, q, a);
+    return fma(r, y, q);
+}
+IMS_DEV double dsqrt_n(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g0 = x * y;
+    const double h0 = y * 0.5;
+    const double r0 = fma(-h0, g0, 0.5);
+    const double h1 = fma(h0, r0, h0);
+    const double g1 = fma(g0, r0, g0);
+    const double d0 = fma(-g1, g1, x);
+    const double g2 = fma(d0, h1, g1);
+    const double d1 = fma(-g2, g2, x);
+    return fma(d1, h1, g2);
+}
+IMS_DEV double dsqrt0(double x) { const double r = dsqrt_n(x); return x == 0.0 ? 0.0 : r; }
+
 constexpr double LN2_HI = 6.93147180369123816490e-01;
 constexpr double LN2_LO = 1.90821492927058770002e-10;
 constexpr double INV_LN2 = 1.44269504088896338700e+00;
@@ -96,7 +131,7 @@ IMS_DEV double dlog(double x)
     int64_t e = (int64_t)((b >> 52) & 0x7FF) - 1023;
     double m = __longlong_as_double((long long)((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull));
     if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
-    const double s = (m - 1.0) / (m + 1.0);
+    const double s = ddiv(m - 1.0, m + 1.0);
     const double z = s * s;
     double p = 1.0 / 25.0;
     p = fma_k(p, z, 1.0 / 23.0);
@@ -195,8 +230,8 @@ IMS_DEV double datan(double x)
     double base = 0.0, sign = 1.0, a = ax;
     if (ax > 1.0) { a = 1.0 / ax; base = PI_2; sign = -1.0; }
     double off = 0.0, b = a;
-    if (a > 0.41421356237309503) { b = (a - 1.0) / (a + 1.0); off = PI_4; }
-    const double cc = b / (1.0 + sqrt(fma(b, b, 1.0)));
+    if (a > 0.41421356237309503) { b = ddiv(a - 1.0, a + 1.0); off = PI_4; }
+    const double cc = ddiv(b, 1.0 + dsqrt_n(fma(b, b, 1.0)));
     const double z = cc * cc;
     double p = 1.0 / 27.0;
     p = fma_k(p, z, -1.0 / 25.0);
@@ -233,7 +268,7 @@ IMS_DEV double dtanh_pos(double x)
 {
     if (x > 20.0) return 1.0;
     const double e = dexp(-2.0 * x);
-    return (1.0 - e) / (1.0 + e);
+    return ddiv(1.0 - e, 1.0 + e);
 }
 IMS_DEV double dpow(double x, double y) { return dexp(y * dlog(x)); }
 
@@ -249,7 +284,7 @@ IMS_DEV void gauss_pair(Draw d, double& g0, double& g1)
 
 IMS_DEV void gauss_words(uint32_t w0, uint32_t w1, double& g0, double& g1)
 {
-    const double r = sqrt(-2.0 * dlog(w01(w0)));
+    const double r = dsqrt_n(-2.0 * dlog(w01(w0)));      // w01 < 1: the argument is > 0
     double s, c;
     sincos2pi(w01(w1), s, c);
     g0 = r * c; g1 = r * s;

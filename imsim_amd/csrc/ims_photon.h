@@ -20,7 +20,7 @@ struct Photon {
 IMS_DEV double lin_lookup(const ims_lin_tables_t& t, int table, double arg)
 {
     const double* v = t.val + (int64_t)table * t.n_pts;
-    const double f = (arg - t.arg_min) / t.arg_step;
+    const double f = ddiv(arg - t.arg_min, t.arg_step);
     if (!(f > 0.0)) return v[0];
     const int n = t.n_pts;
     if (f >= (double)(n - 1)) return v[n - 1];
@@ -41,7 +41,7 @@ IMS_DEV double radial_r2(const ims_radial_tables_t& t, int table, double u)
     }
     const double c0 = cdf[lo];
     const double w = cdf[lo + 1] - c0;
-    const double f = (w > 0.0) ? (u - c0) / w : 0.0;
+    const double f = (w > 0.0) ? ddiv(u - c0, w) : 0.0;
     const double a = r2[lo];
     return a + f * (r2[lo + 1] - a);
 }
@@ -58,7 +58,7 @@ IMS_DEV void shoot(const ims_render_params_t& P, const ims_object_t& o, int64_t 
         double gu, gv;
         if (o.prof_table >= 0) {
             const double r2 = radial_r2(P.radial, o.prof_table, w01(rng.w[1]));
-            const double r = sqrt(r2) * o.prof_scale;
+            const double r = dsqrt0(r2) * o.prof_scale;
             double s, c;
             sincos2pi(w01(rng.w[2]), s, c);
             gu = r * c; gv = r * s;
@@ -102,7 +102,7 @@ IMS_DEV void screen_gradient(const ims_atmosphere_t& A, double pu, double pv, do
 {
     double sx = 0.0, sy = 0.0;
     const int n = A.npix;
-    const double dn = (double)n, inv_n = 1.0 / dn, inv_scale = 1.0 / A.scale;
+    const double dn = (double)n, inv_n = ddiv(1.0, dn), inv_scale = ddiv(1.0, A.scale);
     for (int l = 0; l < A.n_layers; ++l) {
         const double x = pu - t * A.vx[l] + A.alt[l] * tanx;
         const double y = pv - t * A.vy[l] + A.alt[l] * tany;
@@ -127,7 +127,7 @@ IMS_DEV void apply_psf(const ims_render_params_t& P, const ims_object_t& o, int 
     rng_block(rng, P.seed, o.obj_id, k, SLOT_PSF + ((uint32_t)comp >> 1));
     const uint32_t wa = (comp & 1) ? rng.w[2] : rng.w[0], wb = (comp & 1) ? rng.w[3] : rng.w[1];
     double scale = c.p0;
-    if (c.chrom_alpha != 0.0) scale = scale * dpow(ph.wl / c.chrom_base, c.chrom_alpha);
+    if (c.chrom_alpha != 0.0) scale = scale * dpow(ddiv(ph.wl, c.chrom_base), c.chrom_alpha);
     double ku, kv;
     if (c.kind == IMS_PSF_GAUSSIAN) {
         double g0, g1;
@@ -143,7 +143,7 @@ IMS_DEV void apply_psf(const ims_render_params_t& P, const ims_object_t& o, int 
     } else if (c.kind == IMS_PSF_SCREENS) {
         const ims_atmosphere_t& A = *P.atm;
         const double ro2 = A.aper_r_outer * A.aper_r_outer, ri2 = A.aper_r_inner * A.aper_r_inner;
-        const double r = sqrt(ri2 + w01(wa) * (ro2 - ri2));
+        const double r = dsqrt0(ri2 + w01(wa) * (ro2 - ri2));
         double s, cc;
         sincos2pi(w01(wb), s, cc);
         const double pu = r * cc, pv = r * s;
@@ -155,7 +155,7 @@ IMS_DEV void apply_psf(const ims_render_params_t& P, const ims_object_t& o, int 
         ph.pu = pu; ph.pv = pv; ph.t = t;
     } else {
         const double r2 = radial_r2(P.radial, c.table, w01(wa));
-        const double r = sqrt(r2) * scale;
+        const double r = dsqrt0(r2) * scale;
         double s, cc;
         sincos2pi(w01(wb), s, cc);
         ku = r * cc; kv = r * s;
@@ -178,9 +178,9 @@ IMS_DEV double air_n_minus_one(double wave_nm, double air_p, double air_w)
     const double num = fma(29498.1, d2, 255.4 * d1);
     const double disp = fma(64.328, den, w2 * num);             // dispersion * den
     const double wat = fma(0.0624, w2, -0.000680) * den;         // water term * den * w2
-    return (air_p * (disp * w2) - air_w * wat) / (den * w2);
+    return ddiv(air_p * (disp * w2) - air_w * wat, den * w2);
 }
-IMS_DEV double refraction_r0(double nm1) { return nm1 * (nm1 + 2.0) / 2.0 / (nm1 * nm1 + 2.0 * nm1 + 1.0); }
+IMS_DEV double refraction_r0(double nm1) { return ddiv(nm1 * (nm1 + 2.0) / 2.0, nm1 * nm1 + 2.0 * nm1 + 1.0); }
 
 IMS_DEV double medium_n(int kind, const double* c, double wave_nm)
 {
@@ -188,8 +188,8 @@ IMS_DEV double medium_n(int kind, const double* c, double wave_nm)
     if (kind == IMS_MEDIUM_SELLMEIER) {
         const double l = wave_nm * 1.0e-3;
         const double l2 = l * l;
-        const double n2 = 1.0 + c[0] * l2 / (l2 - c[3]) + c[1] * l2 / (l2 - c[4]) + c[2] * l2 / (l2 - c[5]);
-        return sqrt(n2);
+        const double n2 = 1.0 + ddiv(c[0] * l2, l2 - c[3]) + ddiv(c[1] * l2, l2 - c[4]) + ddiv(c[2] * l2, l2 - c[5]);
+        return dsqrt_n(n2);
     }
     return 1.0 + air_n_minus_one(wave_nm, c[3], c[4]);
 }
@@ -249,7 +249,7 @@ IMS_DEV void wcs_vec_to_pix(const ims_tansip_t& w, const double (&p)[3], double&
     const double t0 = w.rot[0] * p[0] + w.rot[1] * p[1] + w.rot[2] * p[2];
     const double t1 = w.rot[3] * p[0] + w.rot[4] * p[1] + w.rot[5] * p[2];
     const double t2 = w.rot[6] * p[0] + w.rot[7] * p[1] + w.rot[8] * p[2];
-    const double it0 = 1.0 / t0;
+    const double it0 = ddiv(1.0, t0);
     const double xi = t1 * it0, eta = t2 * it0;
     const double U = w.cdinv[0] * xi + w.cdinv[1] * eta;
     const double V = w.cdinv[2] * xi + w.cdinv[3] * eta;
@@ -261,7 +261,7 @@ IMS_DEV void wcs_vec_to_pix(const ims_tansip_t& w, const double (&p)[3], double&
             sip_value_grad(w.b, u, v, g, gu, gv);
             const double r0 = u + f - U, r1 = v + g - V;
             const double j00 = 1.0 + fu, j11 = 1.0 + gv;
-            const double idet = 1.0 / (j00 * j11 - fv * gu);
+            const double idet = ddiv(1.0, j00 * j11 - fv * gu);
             const double du = (j11 * r0 - fv * r1) * idet;
             const double dv = (j00 * r1 - gu * r0) * idet;
             u = u - du; v = v - dv;
@@ -277,12 +277,12 @@ IMS_DEV void xy_to_v(const ims_optics_t& o, double x, double y, double wave_nm, 
     wcs_pix_to_vec(o.img_wcs, x, y, p);
     wcs_vec_to_pix(o.icrf_to_field, p, thx, thy);
     const double n = medium_n(o.in_medium_kind, o.in_medium_c, wave_nm);
-    const double gn = 1.0 / (n * sqrt(1.0 + thx * thx + thy * thy));
+    const double gn = ddiv(1.0, n * dsqrt_n(1.0 + thx * thx + thy * thy));
     v[0] = thx * gn; v[1] = thy * gn; v[2] = -gn;
 }
 IMS_DEV void v_to_xy(const ims_optics_t& o, const double (&v)[3], double& x, double& y)
 {
-    const double ivz = 1.0 / v[2];
+    const double ivz = ddiv(1.0, v[2]);
     const double thx = -v[0] * ivz, thy = -v[1] * ivz;
     double p[3];
     wcs_pix_to_vec(o.icrf_to_field, thx, thy, p);
@@ -299,9 +299,9 @@ IMS_DEV void field_rotation(const ims_optics_t& o, double t, double& c, double& 
     const double eh0_ = ef[1] * ez2 - ef[2] * ez1, eh1_ = ef[2] * ez0 - ef[0] * ez2, eh2_ = ef[0] * ez1 - ef[1] * ez0;
     const double* z0 = o.e_z0;
     const double g0 = ef[1] * z0[2] - ef[2] * z0[1], g1 = ef[2] * z0[0] - ef[0] * z0[2], g2 = ef[0] * z0[1] - ef[1] * z0[0];
-    const double nrm = sqrt(eh0_ * eh0_ + eh1_ * eh1_ + eh2_ * eh2_) * sqrt(g0 * g0 + g1 * g1 + g2 * g2);
-    c = (eh0_ * g0 + eh1_ * g1 + eh2_ * g2) / nrm;
-    s = (ez0 * g0 + ez1 * g1 + ez2 * g2) / nrm;
+    const double nrm = dsqrt_n(eh0_ * eh0_ + eh1_ * eh1_ + eh2_ * eh2_) * dsqrt_n(g0 * g0 + g1 * g1 + g2 * g2);
+    c = ddiv(eh0_ * g0 + eh1_ * g1 + eh2_ * g2, nrm);
+    s = ddiv(ez0 * g0 + ez1 * g1 + ez2 * g2, nrm);
 }
 
 IMS_DEV void directed_dist(const ims_optics_t& o, double px, double py, double& dist, double& nx, double& ny)
@@ -316,15 +316,15 @@ IMS_DEV void directed_dist(const ims_optics_t& o, double px, double py, double& 
     for (int c = 0; c < o.n_circles; ++c) {
         const double* C = o.circles[c];
         const double ex = px - C[0], ey = py - C[1];
-        const double d = fabs(sqrt(ex * ex + ey * ey) - C[2]);
+        const double d = fabs(dsqrt0(ex * ex + ey * ey) - C[2]);
         if (ic < 0 || d < dc) { dc = d; ic = c; }
     }
     if (il >= 0 && (ic < 0 || dl < dc)) {
         dist = dl; nx = o.lines[il][0]; ny = o.lines[il][1];
     } else {
         const double ex = o.circles[ic][0] - px, ey = o.circles[ic][1] - py;
-        const double nr = sqrt(ex * ex + ey * ey);
-        dist = dc; nx = ex / nr; ny = ey / nr;
+        const double nr = dsqrt_n(ex * ex + ey * ey);
+        dist = dc; nx = ddiv(ex, nr); ny = ddiv(ey, nr);
     }
 }
 
@@ -337,16 +337,16 @@ IMS_DEV void diffract(const ims_optics_t& o, bool field_rot, double pu, double p
     const double qy = s * pu + c * pv;
     double d, nx, ny;
     directed_dist(o, qx, qy, d, nx, ny);
-    const double k = TWO_PI / wavelength_m;
+    const double k = ddiv(TWO_PI, wavelength_m);
     const double dtp = gauss * datan(1.0 / (2.0 * k * d));
     const double vz = -v[2];
     const double sx = dtp * vz * nx, sy = dtp * vz * ny;
     const double rx = c * sx + s * sy;
     const double ry = -s * sx + c * sy;
-    const double before = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const double before = dsqrt_n(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
     v[0] = v[0] + rx; v[1] = v[1] + ry;
-    const double after = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-    const double fs = before / after;
+    const double after = dsqrt_n(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const double fs = ddiv(before, after);
     v[0] = v[0] * fs; v[1] = v[1] * fs; v[2] = v[2] * fs;
 }
 
@@ -372,7 +372,7 @@ IMS_DEV bool surf_hit(const ims_surface_t& S, double (&pos)[3], const double (&v
     const double pz = pos[2] - S.z0;
     double t;
     if (S.R == 0.0 && S.n_asphere == 0) {
-        t = -pz / vel[2];
+        t = ddiv(-pz, vel[2]);
         pos[0] = pos[0] + vel[0] * t; pos[1] = pos[1] + vel[1] * t; pos[2] = S.z0;
         N[0] = 0.0; N[1] = 0.0; N[2] = 1.0; nn = 1.0;
         r2_out = pos[0] * pos[0] + pos[1] * pos[1];
@@ -385,11 +385,11 @@ IMS_DEV bool surf_hit(const ims_surface_t& S, double (&pos)[3], const double (&v
         const double C = pos[0] * pos[0] + pos[1] * pos[1] + k1 * pz * pz - 2.0 * S.R * pz;
         const double disc = B * B - 4.0 * A * C;
         if (disc < 0.0) return false;
-        const double sq = sqrt(disc);
+        const double sq = dsqrt0(disc);
         const double q = -0.5 * (B + (B < 0.0 ? -sq : sq));
-        t = C / q;                                   // the root of smaller |t| (q carries the larger magnitude)
+        t = ddiv(C, q);                                 // the root of smaller |t| (q carries the larger magnitude)
     } else {
-        t = -pz / vel[2];
+        t = ddiv(-pz, vel[2]);
     }
     if (S.n_asphere == 0) {
         const double x = pos[0] + vel[0] * t, y = pos[1] + vel[1] * t, z = pz + vel[2] * t;
@@ -420,7 +420,7 @@ IMS_DEV bool surf_hit(const ims_surface_t& S, double (&pos)[3], const double (&v
         const double s = x * vel[0] + y * vel[1];
         const double wp = vel[2] - 2.0 * dp * s;
         const double Gp = 2.0 * (c * (s + k1 * w * wp) - wp);
-        t = t - G / Gp;
+        t = t - ddiv(G, Gp);
     }
     const double m = 1.0 - c * k1 * w;
     if (!(m > 0.0)) return false;
@@ -450,7 +450,7 @@ IMS_DEV int trace(const ims_optics_t& o, double (&pos)[3], double (&vel)[3], dou
         if (obscured(S, r2)) vignetted = 1;
         if (S.kind == IMS_SURF_BAFFLE || S.kind == IMS_SURF_DETECTOR) continue;
         if (S.kind == IMS_SURF_MIRROR) {
-            const double d = 2.0 * (vel[0] * N[0] + vel[1] * N[1] + vel[2] * N[2]) / nn;
+            const double d = ddiv(2.0 * (vel[0] * N[0] + vel[1] * N[1] + vel[2] * N[2]), nn);
             vel[0] = vel[0] - d * N[0]; vel[1] = vel[1] - d * N[1]; vel[2] = vel[2] - d * N[2];
         } else {
             double n2, in2;
@@ -458,7 +458,7 @@ IMS_DEV int trace(const ims_optics_t& o, double (&pos)[3], double (&vel)[3], dou
             else if (S.medium_id == glass_id) { n2 = glass_n; in2 = glass_in; }
             else {
                 n2 = medium_n(S.medium_kind, S.medium_c, wave_nm);
-                in2 = 1.0 / n2;
+                in2 = ddiv(1.0, n2);
                 glass_id = S.medium_id; glass_n = n2; glass_in = in2;
             }
             const double dx = vel[0] * n_cur, dy = vel[1] * n_cur, dz = vel[2] * n_cur;
@@ -466,10 +466,10 @@ IMS_DEV int trace(const ims_optics_t& o, double (&pos)[3], double (&vel)[3], dou
             double sgn = 1.0;
             if (a > 0.0) { sgn = -1.0; a = -a; }
             const double eta = n_cur * in2;
-            const double inn = 1.0 / nn;
+            const double inn = ddiv(1.0, nn);
             const double sinsqr = eta * eta * (1.0 - a * a * inn);
             if (sinsqr > 1.0) return 2;
-            const double nfac = sgn * (eta * a * inn + sqrt((1.0 - sinsqr) * inn));
+            const double nfac = sgn * (eta * a * inn + dsqrt0((1.0 - sinsqr) * inn));
             vel[0] = (eta * dx - nfac * N[0]) * in2;
             vel[1] = (eta * dy - nfac * N[1]) * in2;
             vel[2] = (eta * dz - nfac * N[2]) * in2;
@@ -504,7 +504,7 @@ IMS_DEV void rubin_op(const ims_render_params_t& P, const ims_op_t& op, int op_i
     const double fpx = ry * 1.0e3, fpy = rx * 1.0e3;
     ph.x = opt.fp_to_pix[0] * fpx + opt.fp_to_pix[1] * fpy + opt.fp_to_pix[2];
     ph.y = opt.fp_to_pix[3] * fpx + opt.fp_to_pix[4] * fpy + opt.fp_to_pix[5];
-    const double ivz = 1.0 / v[2];
+    const double ivz = ddiv(1.0, v[2]);
     ph.dxdz = (opt.slope_jac[0] * rvx + opt.slope_jac[1] * rvy) * ivz;
     ph.dydz = (opt.slope_jac[2] * rvx + opt.slope_jac[3] * rvy) * ivz;
     if (st == 1) ph.flux = 0.0;
@@ -529,7 +529,7 @@ IMS_DEV void apply_op(const ims_render_params_t& P, int op_index, const ims_obje
     case IMS_OP_PUPIL_ANNULUS_SAMPLER: {
         const double ro2 = op.p[0] * op.p[0], ri2 = op.p[1] * op.p[1];
         rng_block(rng, P.seed, o.obj_id, k, slot);
-        const double r = sqrt(ri2 + w01(wsel ? rng.w[2] : rng.w[0]) * (ro2 - ri2));
+        const double r = dsqrt0(ri2 + w01(wsel ? rng.w[2] : rng.w[0]) * (ro2 - ri2));
         double s, c;
         sincos2pi(w01(wsel ? rng.w[3] : rng.w[1]), s, c);
         ph.pu = r * c; ph.pv = r * s;
@@ -551,7 +551,7 @@ IMS_DEV void apply_op(const ims_render_params_t& P, int op_index, const ims_obje
         const double nn = op.p[0] * op.p[0];
         const double a = ph.dxdz, b = ph.dydz;
         const double rho2 = a * a + b * b;
-        const double f = 1.0 / sqrt(nn + (nn - 1.0) * rho2);
+        const double f = ddiv(1.0, dsqrt_n(nn + (nn - 1.0) * rho2));
         ph.dxdz = a * f; ph.dydz = b * f;
         break; }
     case IMS_OP_RUBIN_OPTICS:
@@ -608,7 +608,7 @@ IMS_DEV bool inside_pixel(const ims_sensor_t& s, const SlotView& sl, int ix, int
         // a wave takes this path whenever ONE of its 64 photons misses the inner bounds, i.e. almost always: the
         // vertex addresses depend only on the loop counter, so the loop is unrolled four-fold to keep four
         // independent loads in flight instead of one dependent load per vertex
-        const double zfactor = dtanh_pos(zconv / 12.0);
+        const double zfactor = dtanh_pos(ddiv(zconv, 12.0));
         const int nV = s.num_vertices, npo = 2 * nV + 2, nv = 4 * nV + 4;
         const double* own = s.bf_boundary + cell_index(sl, i, j) * npo * 2;
         const double* rgt = s.bf_boundary + cell_index(sl, i + 1, j) * npo * 2;
@@ -670,7 +670,7 @@ IMS_DEV bool land(const ims_render_params_t& P, const ims_object_t& o, int64_t k
     rng_block(rng, P.seed, o.obj_id, k, SLOT_SENSOR);
     double g0, g1;
     gauss_words(rng.w[0], rng.w[1], g0, g1);
-    const double f = (ph.wl - s.abs_wl_min) / s.abs_wl_step;
+    const double f = ddiv(ph.wl - s.abs_wl_min, s.abs_wl_step);
     double abs_len;
     if (!(f > 0.0)) abs_len = s.abs_len[0];
     else if (f >= (double)(s.n_abs - 1)) abs_len = s.abs_len[s.n_abs - 1];
@@ -678,16 +678,16 @@ IMS_DEV bool land(const ims_render_params_t& P, const ims_object_t& o, int64_t k
     const double si_length = -abs_len * dlog(w01(rng.w[2]));
     double dz = si_length;
     if (has_angles) {
-        dz = si_length / sqrt(1.0 + ph.dxdz * ph.dxdz + ph.dydz * ph.dydz);
+        dz = ddiv(si_length, dsqrt_n(1.0 + ph.dxdz * ph.dxdz + ph.dydz * ph.dydz));
         if (dz > s.thickness - 1.0) dz = s.thickness - 1.0;
-        const double dzp = dz / s.pixel_size;
+        const double dzp = ddiv(dz, s.pixel_size);
         x0 = x0 + ph.dxdz * dzp;
         y0 = y0 + ph.dydz * dzp;
     }
     const double zconv = s.thickness - dz;
     if (zconv < 0.0) return false;
     if (s.diff_step != 0.0) {
-        double ds = s.diff_step / (s.thickness * s.pixel_size) * sqrt(zconv * s.thickness);
+        double ds = ddiv(s.diff_step, s.thickness * s.pixel_size) * dsqrt0(zconv * s.thickness);
         if (ds < 0.0) ds = 0.0;
         x0 = x0 + ds * g0;
         y0 = y0 + ds * g1;

@@ -350,7 +350,7 @@ __device__ __forceinline__ void empty_owned(const ims_sensor_t& s, int n, double
 __device__ __forceinline__ double treering_shift(const ims_sensor_t& s, double r)
 {
     if (s.n_tr <= 0) return 0.0;
-    const double f = r / s.tr_dr;
+    const double f = ddiv(r, s.tr_dr);
     if (!(f > 0.0) || f >= (double)(s.n_tr - 1)) return 0.0;
     const int i = (int)f;
     const double b = f - (double)i;
@@ -393,10 +393,10 @@ __device__ __forceinline__ void init_point(const ims_sensor_t& s, const SlotView
     empty_owned(s, n, ex, ey);
     const double tx = ((double)(sl.xmin + ci) - 0.5 + ex) - s.tr_cx;
     const double ty = ((double)(sl.ymin + cj) - 0.5 + ey) - s.tr_cy;
-    const double rr = sqrt(tx * tx + ty * ty);
+    const double rr = dsqrt0(tx * tx + ty * ty);
     const double sh = treering_shift(s, rr);
     px = ex; py = ey;
-    if (rr > 0.0 && sh != 0.0) { px = ex + sh * tx / rr; py = ey + sh * ty / rr; }
+    if (rr > 0.0 && sh != 0.0) { px = ex + ddiv(sh * tx, rr); py = ey + ddiv(sh * ty, rr); }
 }
 
 // Initial state of a range of slots: boundary points, zero delta charge AND the bounds line of every pixel.
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void k_update_distortions(const ims_sensor_t* 
             const double charge = tile[(sj - sy0) * hw + (si - sx0)];
             if (charge == 0.0) continue;
             any = true;
-            const double w = charge / s.num_elec;
+            const double w = ddiv(charge, s.num_elec);
             const double* dist = s.distortions + ((int64_t)(di + cx) * s.ny + (dj + cy)) * nv * 2;
             for (int n = 0; n < npo; ++n) {
                 if (n <= nV + 1 && di == q + 1) continue;
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void k_update_distortions_q3(const ims_sensor_
         double w = 0.0;
         if (si >= 0 && si < sl.nx && sj >= 0 && sj < sl.ny) {
             const double charge = (double)s.bf_delta[cell_index(sl, si, sj)];
-            if (charge != 0.0) { w = charge / s.num_elec; atomicOr(&occ[hy], 1u << hx); any_charge = 1; }
+            if (charge != 0.0) { w = ddiv(charge, s.num_elec); atomicOr(&occ[hy], 1u << hx); any_charge = 1; }
         }
         wt[e] = w;
     }
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(256) void k_fft_finish(const ims_fft_params_t P, co
     }
 }
 
-// device math probe for the parity tests (which: 0 log,1 exp,2 sincos2pi,3 atan,4 sincos,5 tanh,6 gauss)
+// device math probe for the parity tests (which: 0 log,1 exp,2 sincos2pi,3 atan,4 sincos,5 tanh,6 gauss,7 dsqrt_n,8 ddiv of pairs,9 dsqrt0)
 __global__ void k_test_math(int which, const double* __restrict__ in, double* __restrict__ out, int64_t n,
                             uint64_t seed, int64_t obj, uint32_t slot)
 {
@@ -926,6 +926,9 @@ __global__ void k_test_math(int which, const double* __restrict__ in, double* __
     case 3: out[i] = datan(in[i]); break;
     case 4: dsincos(in[i], s, c); out[2 * i] = s; out[2 * i + 1] = c; break;
     case 5: out[i] = dtanh_pos(in[i]); break;
+    case 7: out[i] = dsqrt_n(in[i]); break;
+    case 8: out[i] = ddiv(in[2 * i], in[2 * i + 1]); break;
+    case 9: out[i] = dsqrt0(in[i]); break;
     case 6: { Rng r; rng_reset(r); rng_block(r, seed, obj, i, slot); gauss_words(r.w[0], r.w[1], s, c);
               out[2 * i] = s; out[2 * i + 1] = c; break; }
     }

@@ -31,6 +31,46 @@ def _dev_math(torch, which, x, seed=0, obj=0, slot=0, n=None):
     return out.cpu().numpy()
 
 
+def test_lean_div_sqrt(torch_cuda):
+    """ddiv / dsqrt_n / dsqrt0 (ims_math.h: the division and square-root cores without range scaling and
+    special-value fix-ups) give the correctly rounded IEEE result, bit for bit, over the stated operand range."""
+    torch = torch_cuda
+    lib = _abi.load()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    n = 1 << 22
+
+    def run(which, xin):
+        out = torch.empty(n, dtype=torch.float64, device="cuda")
+        _abi.check(lib.ims_test_math(which, xin.data_ptr(), out.data_ptr(), n, 0, 0, 0, None))
+        torch.cuda.synchronize()
+        return out
+
+    def rnd(lo, hi, signed=False):
+        m = 1.0 + torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+        m = m + torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * 2.0 ** -30
+        e = torch.randint(lo, hi + 1, (n,), device="cuda", generator=g).to(torch.float64)
+        v = m * torch.exp2(e)
+        if signed:
+            v = v * (torch.randint(0, 2, (n,), device="cuda", generator=g).to(torch.float64) * 2 - 1)
+        return v
+
+    for lo, hi in ((-1, 1), (-40, 40), (-240, 240)):
+        x = rnd(2 * lo, 2 * hi)
+        ref = torch.sqrt(x).view(torch.int64)
+        assert int((run(7, x).view(torch.int64) != ref).sum()) == 0
+        assert int((run(9, x).view(torch.int64) != ref).sum()) == 0
+        a, b = rnd(lo, hi, True), rnd(lo, hi, True)
+        q = run(8, torch.stack([a, b], dim=1).contiguous().view(-1))
+        assert int((q.view(torch.int64) != (a / b).view(torch.int64)).sum()) == 0
+    # exact cases: perfect squares, zero numerators, sqrt(0)
+    k = torch.arange(1, n + 1, dtype=torch.float64, device="cuda")
+    assert bool((run(7, k * k) == k).all())
+    z = torch.zeros(n, dtype=torch.float64, device="cuda")
+    assert bool((run(9, z) == 0.0).all())
+    assert bool((run(8, torch.stack([z, k], dim=1).contiguous().view(-1)) == 0.0).all())
+
+
 def test_device_math_is_bit_identical_to_oracle(torch_cuda):
     """The numerics spec: every elementary function gives the same bits on gfx950 and on the CPU."""
     from oracle import orc_loader

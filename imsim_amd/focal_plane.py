@@ -1,0 +1,48 @@
+"""A visit's CCDs on the GPUs of one node (BASELINE config C5: 189 CCDs x 10 k sources, one CCD per stream).
+
+The reference fans the CCDs of a visit out to worker processes (`output.nproc`, imsim/ccd.py:72-89); every
+CCD is an independent `LSST_Image` build.  Here the CCDs are dealt round-robin to the ranks
+(`parallel.shard_ccds`, one process per GPU, no exchange) and inside a rank up to `concurrent` CCDs are in
+flight at once, each anchored to its own HIP stream: while the GPU works through the launch plan of one CCD
+(which `Renderer.execute_plan` only enqueues), the host builds the object table and plan of the next.
+Results do not depend on `concurrent`, on the rank count or on the order of the CCDs: every photon's random
+stream is addressed by (CCD seed, object id, photon index).
+"""
+from . import parallel
+from .engine import Renderer
+
+
+def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent=2, nrecalc=None):
+    """ccds: sequence of CCD keys (detector numbers / names); build(key) -> (scene, objects) prepares one CCD
+    on the host.  Returns {key: float32 image as a host array} for the CCDs this rank owns."""
+    import torch
+    dev = torch.device(device)
+    mine = parallel.shard_ccds(list(ccds), rank, world)
+    if concurrent < 1:
+        raise ValueError("concurrent must be >= 1")
+    streams = [torch.cuda.Stream(dev) for _ in range(min(concurrent, max(len(mine), 1)))]
+    in_flight = [None] * len(streams)          # (key, renderer, device image, done event) per stream
+    out = {}
+
+    def collect(slot):
+        if in_flight[slot] is None:
+            return
+        key, renderer, img, done = in_flight[slot]
+        done.synchronize()
+        out[key] = img.cpu().numpy()
+        in_flight[slot] = None                 # drops the renderer: its HBM goes back to the caching allocator
+
+    for k, key in enumerate(mine):
+        slot = k % len(streams)
+        collect(slot)                          # the CCD that used this stream before
+        scene, objects = build(key)            # host work, overlaps with the CCDs still running on the GPU
+        with torch.cuda.stream(streams[slot]):
+            renderer = Renderer(scene, dev)
+            renderer.render_lsst_image(objects, nrecalc=nrecalc)
+            img = renderer.image_float()
+            done = torch.cuda.Event()
+            done.record(streams[slot])
+        in_flight[slot] = (key, renderer, img, done)
+    for slot in range(len(streams)):
+        collect(slot)
+    return out

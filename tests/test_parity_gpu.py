@@ -685,3 +685,38 @@ def test_gpu_reproduces_the_frozen_spec_digests(torch_cuda):
     want = json.load(open(os.path.join(here, "golden", "pipeline_golden.json")))
     got = {k: g.digest(v) for k, v in g.cases(B).items()}
     assert got == want["sha256"]
+
+
+def test_focal_plane_ccds_on_streams(torch_cuda):
+    """BASELINE config C5 at test size: several CCDs of one visit (different seeds, tree-ring detectors and
+    sizes), two in flight at a time on their own streams.  Every CCD equals its stand-alone render, one of
+    them is checked against the oracle, and the rank split deals each CCD to exactly one rank."""
+    from imsim_amd import focal_plane, configs
+    from imsim_amd.engine import Renderer
+    from oracle import orc_loader
+    specs = {94: dict(n=384, n_obj=160, flux_seed=2, seed=11), 95: dict(n=256, n_obj=120, flux_seed=3, seed=12),
+             96: dict(n=320, n_obj=140, flux_seed=4, seed=13), 97: dict(n=256, n_obj=100, flux_seed=5, seed=14)}
+
+    def build(det):
+        s = specs[det]
+        return _c3_case(n_obj=s["n_obj"], n=s["n"], flux_seed=s["flux_seed"], seed=s["seed"])
+
+    images = focal_plane.render_focal_plane(list(specs), build, concurrent=2)
+    assert sorted(images) == sorted(specs)
+    serial = focal_plane.render_focal_plane(list(specs), build, concurrent=1)
+    for det in specs:
+        scene, objects = build(det)
+        r = Renderer(scene)
+        r.render_lsst_image(objects)
+        r.synchronize()
+        assert_bits_equal(images[det], r.image_numpy(), f"CCD {det} on a stream vs stand-alone")
+        assert_bits_equal(serial[det], images[det], f"CCD {det}: concurrent=1 vs 2")
+    scene, objects = build(95)
+    orc = orc_loader.OracleScene(scene)
+    orc.render_lsst_image(objects)
+    assert_bits_equal(images[95], orc.image, "CCD 95 vs oracle")
+    parts = [focal_plane.render_focal_plane(list(specs), build, rank=k, world=2, concurrent=2) for k in range(2)]
+    assert sorted(list(parts[0]) + list(parts[1])) == sorted(specs)
+    for p in parts:
+        for det, img in p.items():
+            assert_bits_equal(img, images[det], f"CCD {det} rank split")

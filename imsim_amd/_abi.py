@@ -165,14 +165,29 @@ class PlanItem(C.Structure):
 (IMS_PLAN_RENDER, IMS_PLAN_SHOOT_POOL, IMS_PLAN_ACC_POOL, IMS_PLAN_UPDATE, IMS_PLAN_INIT, IMS_PLAN_RECORD,
  IMS_PLAN_WAIT) = range(1, 8)
 
+IMS_MAX_AMPS = 16
+
+
+class Amp(C.Structure):
+    _fields_ = [("x0", c_i32), ("y0", c_i32), ("flip_x", c_i32), ("flip_y", c_i32), ("gain", C.c_float),
+                ("bias_level", C.c_float), ("read_noise", C.c_float), ("pad", c_i32)]
+
+
+class Readout(C.Structure):
+    _fields_ = [("n_amps", c_i32), ("seg_w", c_i32), ("seg_h", c_i32), ("raw_w", c_i32), ("raw_h", c_i32),
+                ("data_x0", c_i32), ("data_y0", c_i32), ("has_xtalk", c_i32), ("amps", Amp * IMS_MAX_AMPS),
+                ("xtalk", C.c_float * (IMS_MAX_AMPS * IMS_MAX_AMPS))]
+
+
 STRUCTS = [Object, RadialTables, LinTables, PsfComponent, Op, Surface, TanSip, Optics, BfSlot, Sensor, Photons,
-           RenderParams, PlanItem, Atmosphere, FftObject, FftParams]
+           RenderParams, PlanItem, Atmosphere, FftObject, FftParams, Readout]
 
 # every symbol include/imsim_hip.h declares
 EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_info", "ims_shoot_accumulate",
            "ims_shoot_photons", "ims_shoot_ops_photons", "ims_accumulate_segments", "ims_run_plan",
            "ims_fft_kspace_fill", "ims_fft_finish", "ims_fft_spikes", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
            "ims_sensor_update_distortions", "ims_image_add", "ims_image_to_float", "ims_fill_derived_op", "ims_fill_derived_medium", "ims_sensor_pixel_areas", "ims_flat_add", "ims_last_kernel_ms", "ims_enable_timing",
+           "ims_readout_bleed", "ims_readout_segments", "ims_readout_cte", "ims_readout_finish",
            "ims_struct_size", "ims_test_math"]
 
 _LIB_PATH = os.environ.get("IMSIM_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libimsim_hip.so")
@@ -227,6 +242,10 @@ def load():
     lib.ims_enable_timing.argtypes = [C.c_int]
     lib.ims_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.ims_device_info.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(c_i64), C.POINTER(c_i64)]
+    lib.ims_readout_bleed.argtypes = [c_vp, c_vp, c_i32, c_i32, c_d, c_i32, c_vp]
+    lib.ims_readout_segments.argtypes = [c_vp, c_i32, c_i32, C.POINTER(Readout), c_vp, c_vp]
+    lib.ims_readout_cte.argtypes = [c_vp, c_vp, C.POINTER(Readout), c_vp, c_i32, c_i32, c_vp]
+    lib.ims_readout_finish.argtypes = [c_vp, C.POINTER(Readout), c_u64, c_vp, c_vp]
     lib.ims_test_math.argtypes = [C.c_int, c_vp, c_vp, c_i64, c_u64, c_i64, C.c_uint32, c_vp]
     _lib = lib
     return lib

@@ -18,7 +18,7 @@ import numpy as np
 import yaml
 
 from . import _abi, atm_psf, catalog, configs, diffraction, fft_draw, instcat, lsst_image, optics as opticsmod
-from . import flat, parallel, sensor as sensormod, tables, treerings
+from . import flat, parallel, readout, sensor as sensormod, tables, treerings
 from .engine import Scene, SensorSetup, make_slots
 from .lsst_image import GalSimConfigError
 
@@ -314,6 +314,7 @@ def build_psf(psf_cfg, ev, scene_tables):
 class ProcessResult:
     def __init__(self):
         self.images, self.truth, self.ignored, self.det_names = [], [], [], []
+        self.eimages, self.raw, self.files = [], [], []
 
 
 def _process_flat(cfg, ev, image, res, device, data_dir):
@@ -351,6 +352,49 @@ def _process_flat(cfg, ev, image, res, device, data_dir):
     return res
 
 
+READOUT_OPT = {"camera": str, "readout_time": float, "dark_current": float, "bias_level": float, "scti": float, "pcti": float,
+               "full_well": float, "read_noise": float, "bias_levels_file": str}
+READOUT_IGNORE = ("file_name", "dir", "hdu", "filter", "added_keywords")
+
+
+def _process_outputs(out, ev, res, renderer, det_name, meta, seed):
+    """`output` of type LSST_CCD (imsim/ccd.py:92-204) and its `readout` extra output (imsim/readout.py:535-602):
+    the e-image gets the header the raw file is built from; with `output.file_name` it is written as FITS; with
+    `output.readout` the CCD is read out on the GPU into 16 raw segments (kept in res.raw, written with
+    `readout.file_name`)."""
+    exptime = float(ev.value(out.get("exptime", meta.get("exptime") or 30.0)))
+    camera_name = ev.value(out.get("camera", "LsstCamSim"))
+    header_vals = {k: ev.value(v) for k, v in (out.get("header") or {}).items()}
+    opsim = {k: v for k, v in meta.items() if v is not None}
+    opsim.setdefault("rotSkyPos", meta.get("rotSkyPos") or 0.0)
+    hdr = readout.eimage_header(det_name, exptime, opsim_data=opsim, header_vals=header_vals, camera=camera_name)
+    eimg = readout.EImage(renderer.image, hdr)
+    res.eimages.append(eimg)
+    out_dir = ev.value(out["dir"]) if "dir" in out else ""
+    if "file_name" in out:
+        fn = os.path.join(out_dir, str(ev.value(out["file_name"])))
+        os.makedirs(os.path.dirname(fn) or ".", exist_ok=True)
+        eimg.write(fn)
+        res.files.append(fn)
+    ro_cfg = out.get("readout")
+    if ro_cfg is None:
+        return
+    for k in ro_cfg:
+        if k not in READOUT_OPT and k not in READOUT_IGNORE:
+            raise GalSimConfigError(f"Unexpected parameter {k} in output.readout")
+    kwargs = {k: t(ev.value(ro_cfg[k])) for k, t in READOUT_OPT.items() if k in ro_cfg}
+    if "added_keywords" in ro_cfg:
+        kwargs["added_keywords"] = {k: str(ev.value(v)) for k, v in ro_cfg["added_keywords"].items()}
+    ccd_readout = readout.CcdReadout(eimg, None, **kwargs)
+    hdus = ccd_readout.prepare_hdus(seed)
+    res.raw.append(hdus)
+    if "file_name" in ro_cfg:
+        fn = os.path.join(ev.value(ro_cfg.get("dir", out_dir)), str(ev.value(ro_cfg["file_name"])))
+        os.makedirs(os.path.dirname(fn) or ".", exist_ok=True)
+        readout.CcdReadout.write_raw_file(hdus, fn)
+        res.files.append(fn)
+
+
 def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=None, logger=None, rank=0, world=1):
     """galsim.config.Process restricted to this path: reads inputs, then for every requested CCD
     builds the scene and runs the image builder on the GPU.  Returns a ProcessResult.
@@ -376,7 +420,7 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
     out = cfg.get("output", {})
     if out.get("type", "LSST_CCD") not in valid_output_types:
         raise GalSimConfigError(f"Invalid output type {out.get('type')}")
-    for k in ("readout", "truth", "photon_pooling_truth", "opd", "sag", "process_info", "dir", "file_name", "cosmic_ray_rate"):
+    for k in ("truth", "photon_pooling_truth", "opd", "sag", "process_info", "cosmic_ray_rate"):
         if k in out:
             res.ignored.append(f"output.{k}")
     ev.vars["det_name"] = None
@@ -515,4 +559,5 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
         res.images.append(renderer.image_numpy())
         res.truth.append(truth)
         res.det_names.append(det_name)
+        _process_outputs(out, ev, res, renderer, det_name, meta, seed)
     return res

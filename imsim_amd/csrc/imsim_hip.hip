@@ -912,6 +912,128 @@ __global__ __launch_bounds__(256) void k_fft_finish(const ims_fft_params_t P, co
     }
 }
 
+// ---------------- CCD readout (imsim/readout.py:413-478, imsim/bleed_trails.py) ----------------
+constexpr long long READOUT_ID_BASE = 0x7E00000000ll;   // object id space of the read-noise streams (+ amp index)
+
+__global__ __launch_bounds__(256) void k_readout_flags(const double* __restrict__ image, unsigned char* __restrict__ flags,
+                                                       int64_t n, double full_well)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) flags[p] = image[p] > full_well ? 1 : 0;
+}
+
+// BleedCharge.__call__ (bleed_trails.py:117-152): returns true once the excess is used up
+__device__ __forceinline__ bool bleed_into(double* __restrict__ c, int64_t stride, int n, int ypix, double full_well, double& excess)
+{
+    if (ypix >= 0 && ypix < n) {
+        const double room = full_well - c[(int64_t)ypix * stride];
+        const double b = room < excess ? room : excess;
+        c[(int64_t)ypix * stride] = c[(int64_t)ypix * stride] + b;
+        excess = excess - b;
+    } else if (ypix < 0) {
+        excess = excess - (full_well < excess ? full_well : excess);      // leaves through the serial register
+    }
+    return excess == 0.0;
+}
+
+// one thread per channel (a column, or half a column with the midline stop); neighbouring threads walk neighbouring
+// columns, so every step of the walk is one coalesced row access
+__global__ __launch_bounds__(256) void k_readout_bleed(double* __restrict__ image, const unsigned char* __restrict__ flags,
+                                                       int nx, int ny, double full_well, int midline_stop)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_half = midline_stop ? 2 : 1;
+    if (t >= nx * n_half) return;
+    const int x = t % nx, half = t / nx;
+    const int ymid = ny / 2;
+    const int ylo = (midline_stop && half == 1) ? ymid : 0;
+    const int n = midline_stop ? (half == 0 ? ymid : ny - ymid) : ny;
+    double* c = image + (int64_t)ylo * nx + x;
+    const unsigned char* f = flags + (int64_t)ylo * nx + x;
+    int y = 0;
+    while (y < n) {
+        if (!f[(int64_t)y * nx]) { ++y; continue; }
+        const int y0 = y;
+        while (y < n && f[(int64_t)y * nx]) ++y;
+        const int y1 = y;
+        double excess = 0.0;
+        for (int k = y0; k < y1; ++k) excess = excess + c[(int64_t)k * nx];
+        excess = excess - (double)(y1 - y0) * full_well;
+        for (int k = y0; k < y1; ++k) c[(int64_t)k * nx] = full_well;
+        const int reach = y0 > n - y1 ? y0 : n - y1;
+        for (int dy = 0; dy < reach; ++dy) {
+            if (bleed_into(c, nx, n, y0 - dy - 1, full_well, excess)) break;
+            if (bleed_into(c, nx, n, y1 + dy, full_well, excess)) break;
+        }
+    }
+}
+
+// e-image pixel read out at position (u, v) of amp a's imaging section, in ADU (float32 like the reference's arrays)
+__device__ __forceinline__ float amp_adu(const double* __restrict__ image, int nx, const ims_readout_t& ro, int a, int u, int v)
+{
+    const ims_amp_t& A = ro.amps[a];
+    const int sx = A.flip_x ? ro.seg_w - 1 - u : u;
+    const int sy = A.flip_y ? ro.seg_h - 1 - v : v;
+    const float e = (float)image[(int64_t)(A.y0 + sy) * nx + (A.x0 + sx)];
+    return e / A.gain;
+}
+
+__global__ __launch_bounds__(256) void k_readout_segments(const double* __restrict__ image, int nx, const ims_readout_t ro,
+                                                          float* __restrict__ seg)
+{
+    const int64_t per = (int64_t)ro.raw_w * ro.raw_h;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= per * ro.n_amps) return;
+    const int a = (int)(p / per);
+    const int64_t q = p - (int64_t)a * per;
+    const int rx = (int)(q % ro.raw_w), ry = (int)(q / ro.raw_w);
+    const int u = rx - ro.data_x0, v = ry - ro.data_y0;
+    float out = 0.0f;
+    if (u >= 0 && u < ro.seg_w && v >= 0 && v < ro.seg_h) {
+        out = amp_adu(image, nx, ro, a, u, v);
+        if (ro.has_xtalk) {
+            float sum = 0.0f;
+            for (int j = 0; j < ro.n_amps; ++j) sum = sum + ro.xtalk[a * IMS_MAX_AMPS + j] * amp_adu(image, nx, ro, j, u, v);
+            out = out + sum;
+        }
+    }
+    seg[p] = out;
+}
+
+__global__ __launch_bounds__(256) void k_readout_cte(const float* __restrict__ src, float* __restrict__ dst, int n_amps, int raw_w,
+                                                     int raw_h, const double* __restrict__ band, int n_band, int axis)
+{
+    const int64_t per = (int64_t)raw_w * raw_h;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= per * n_amps) return;
+    const int64_t q = p % per;
+    const int rx = (int)(q % raw_w), ry = (int)(q / raw_w);
+    const int i = axis == 0 ? ry : rx;
+    const int64_t step = axis == 0 ? raw_w : 1;
+    const int dmax = i < n_band - 1 ? i : n_band - 1;
+    double acc = 0.0;
+    for (int d = dmax; d >= 0; --d) acc = acc + band[(int64_t)i * n_band + d] * (double)src[p - (int64_t)d * step];
+    dst[p] = (float)acc;
+}
+
+__global__ __launch_bounds__(256) void k_readout_finish(const float* __restrict__ seg, const ims_readout_t ro, uint64_t seed,
+                                                        int32_t* __restrict__ out)
+{
+    const int64_t per = (int64_t)ro.raw_w * ro.raw_h;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= per * ro.n_amps) return;
+    const int a = (int)(p / per);
+    const int64_t q = p - (int64_t)a * per;
+    float v = seg[p] + ro.amps[a].bias_level;
+    Rng r;
+    rng_reset(r);
+    rng_block(r, seed, READOUT_ID_BASE + a, q >> 1, 0u);
+    double g0, g1;
+    gauss_words(r.w[0], r.w[1], g0, g1);
+    v = v + (float)((double)ro.amps[a].read_noise * ((q & 1) ? g1 : g0));
+    out[p] = (int32_t)v;
+}
+
 // device math probe for the parity tests (which: 0 log,1 exp,2 sincos2pi,3 atan,4 sincos,5 tanh,6 gauss,7 dsqrt_n,8 ddiv of pairs,9 dsqrt0)
 __global__ void k_test_math(int which, const double* __restrict__ in, double* __restrict__ out, int64_t n,
                             uint64_t seed, int64_t obj, uint32_t slot)
@@ -1341,6 +1463,72 @@ int ims_image_to_float(const double* src, float* dst, int64_t n, void* stream)
     return IMS_OK;
 }
 
+static int check_readout(const ims_readout_t* ro)
+{
+    if (!ro) return set_err(IMS_ERR_ARG, "readout descriptor is NULL");
+    if (ro->n_amps < 1 || ro->n_amps > IMS_MAX_AMPS) return set_err(IMS_ERR_ARG, "n_amps out of range");
+    if (ro->seg_w < 1 || ro->seg_h < 1 || ro->data_x0 < 0 || ro->data_y0 < 0 || ro->data_x0 + ro->seg_w > ro->raw_w ||
+        ro->data_y0 + ro->seg_h > ro->raw_h)
+        return set_err(IMS_ERR_ARG, "imaging section does not fit the raw segment");
+    for (int a = 0; a < ro->n_amps; ++a)
+        if (!(ro->amps[a].gain > 0.0f)) return set_err(IMS_ERR_ARG, "amplifier gain must be positive");
+    return IMS_OK;
+}
+
+int ims_readout_bleed(double* image_dev, unsigned char* flags_dev, int32_t nx, int32_t ny, double full_well,
+                      int32_t midline_stop, void* stream)
+{
+    if (!image_dev || !flags_dev) return set_err(IMS_ERR_ARG, "image / flags is NULL");
+    if (nx < 1 || ny < 1) return set_err(IMS_ERR_ARG, "empty image");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = (int64_t)nx * ny;
+    hipLaunchKernelGGL(k_readout_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, image_dev, flags_dev, n, full_well);
+    const int threads = nx * (midline_stop ? 2 : 1);
+    hipLaunchKernelGGL(k_readout_bleed, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, image_dev, flags_dev, nx, ny,
+                       full_well, midline_stop ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+int ims_readout_segments(const double* image_dev, int32_t nx, int32_t ny, const ims_readout_t* ro, float* seg_dev, void* stream)
+{
+    if (int e = check_readout(ro)) return e;
+    if (!image_dev || !seg_dev) return set_err(IMS_ERR_ARG, "image / segments is NULL");
+    for (int a = 0; a < ro->n_amps; ++a)
+        if (ro->amps[a].x0 < 0 || ro->amps[a].y0 < 0 || ro->amps[a].x0 + ro->seg_w > nx || ro->amps[a].y0 + ro->seg_h > ny)
+            return set_err(IMS_ERR_ARG, "amplifier section outside the e-image");
+    const int64_t n = (int64_t)ro->raw_w * ro->raw_h * ro->n_amps;
+    hipLaunchKernelGGL(k_readout_segments, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, image_dev, nx, *ro,
+                       seg_dev);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+int ims_readout_cte(const float* src_dev, float* dst_dev, const ims_readout_t* ro, const double* band_dev, int32_t n_band,
+                    int32_t axis, void* stream)
+{
+    if (int e = check_readout(ro)) return e;
+    if (!src_dev || !dst_dev || !band_dev) return set_err(IMS_ERR_ARG, "src / dst / band is NULL");
+    if (src_dev == dst_dev) return set_err(IMS_ERR_ARG, "ims_readout_cte is out of place: src and dst must differ");
+    if (n_band < 1 || (axis != 0 && axis != 1)) return set_err(IMS_ERR_ARG, "n_band / axis out of range");
+    const int64_t n = (int64_t)ro->raw_w * ro->raw_h * ro->n_amps;
+    hipLaunchKernelGGL(k_readout_cte, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src_dev, dst_dev,
+                       ro->n_amps, ro->raw_w, ro->raw_h, band_dev, n_band, axis);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+int ims_readout_finish(const float* seg_dev, const ims_readout_t* ro, uint64_t seed, int32_t* out_dev, void* stream)
+{
+    if (int e = check_readout(ro)) return e;
+    if (!seg_dev || !out_dev) return set_err(IMS_ERR_ARG, "segments / output is NULL");
+    const int64_t n = (int64_t)ro->raw_w * ro->raw_h * ro->n_amps;
+    hipLaunchKernelGGL(k_readout_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seg_dev, *ro, seed,
+                       out_dev);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
 int ims_struct_size(int which)
 {
     switch (which) {
@@ -1360,6 +1548,7 @@ int ims_struct_size(int which)
     case 13: return (int)sizeof(ims_atmosphere_t);
     case 14: return (int)sizeof(ims_fft_object_t);
     case 15: return (int)sizeof(ims_fft_params_t);
+    case 16: return (int)sizeof(ims_readout_t);
     }
     return -1;
 }

@@ -457,6 +457,48 @@ int  ims_sensor_pixel_areas(const ims_sensor_t* sensor_dev, const ims_sensor_t* 
 int  ims_flat_add(const double* area_dev, const double* base_dev, double level, double inv_mean_area, uint64_t seed,
                   int64_t iteration, int32_t nx, int32_t ny, double* image_dev, double* delta_dev, void* stream);
 
+/* ---- CCD readout: e-image -> amplifier segments (imsim/readout.py:413-478 CcdReadout.build_amp_images,
+ *      imsim/bleed_trails.py:28-152) ----
+ * Steps, in the reference's order (the host mirror is imsim_amd/readout.py):
+ *   ims_readout_bleed     bleed_eimage: per column (per half column with the e2v midline stop) every run of pixels
+ *                         above full well is clipped and its excess spread alternately down and up the column;
+ *                         charge leaving through the bottom is lost, the top is closed.  In place on the f64
+ *                         e-image (integer electron counts: every sum is exact).  `flags` is nx*ny bytes of scratch.
+ *   ims_flat_add          dark current: Poisson(dark_current * dark_time) per pixel (area, base, delta = NULL).
+ *   ims_readout_segments  amp_data = float32(e-image)[amp.bounds] / gain in readout order (raw_flip_x/y), plus
+ *                         intra-CCD crosstalk a_i + sum_j x_ij a_j (float32, j ascending), placed at the data
+ *                         section of the zero-filled raw segment (prescan / overscan), [n_amps][raw_h][raw_w].
+ *   ims_readout_cte       q_i = sum_j M_ij q0_j along the parallel (axis 0: y) or serial (axis 1: x) direction with
+ *                         the banded CTE matrix of readout.py:163-205 (band[i*n_band + d] = M[i][i-d], d < n_band);
+ *                         binary64 dot product, j ascending, rounded to float32; src and dst must differ.
+ *   ims_readout_finish    + bias level, + Gaussian read noise (stream keyed by (seed, amp, pixel)), truncation to
+ *                         int32 ADU (numpy astype(int32), readout.py:504). */
+#define IMS_MAX_AMPS 16
+typedef struct {
+    int32_t x0, y0;            /* 0-based lower-left pixel of the amp's imaging section in the e-image */
+    int32_t flip_x, flip_y;    /* raw_flip_x, raw_flip_y */
+    float   gain;              /* e-/ADU */
+    float   bias_level;        /* ADU */
+    float   read_noise;        /* ADU, sigma */
+    int32_t pad;
+} ims_amp_t;
+typedef struct {
+    int32_t n_amps;
+    int32_t seg_w, seg_h;      /* imaging section of one amp */
+    int32_t raw_w, raw_h;      /* raw segment including prescan and overscan */
+    int32_t data_x0, data_y0;  /* offset of the imaging section inside the raw segment */
+    int32_t has_xtalk;
+    ims_amp_t amps[IMS_MAX_AMPS];
+    float   xtalk[IMS_MAX_AMPS * IMS_MAX_AMPS];      /* row i: x_ij */
+} ims_readout_t;
+int  ims_readout_bleed(double* image_dev, unsigned char* flags_dev, int32_t nx, int32_t ny, double full_well,
+                       int32_t midline_stop, void* stream);
+int  ims_readout_segments(const double* image_dev, int32_t nx, int32_t ny, const ims_readout_t* ro, float* seg_dev,
+                          void* stream);
+int  ims_readout_cte(const float* src_dev, float* dst_dev, const ims_readout_t* ro, const double* band_dev,
+                     int32_t n_band, int32_t axis, void* stream);
+int  ims_readout_finish(const float* seg_dev, const ims_readout_t* ro, uint64_t seed, int32_t* out_dev, void* stream);
+
 /* ---- image helpers ---- */
 int  ims_image_add(double* dst, const double* src, int64_t n, void* stream);
 /* round the f64 accumulation image to the float32 CCD image the reference hands on (galsim.ImageF) */
@@ -474,7 +516,7 @@ int  ims_enable_timing(int which);
  * which: 0 log, 1 exp, 2 sincos2pi (2 outputs), 3 atan, 4 sincos (2), 5 tanh, 6 gaussian pair of draw(seed,obj,i,slot) (2) */
 /* sizeof() of the ABI structs as compiled, for binding self-checks:
  * 0 object, 1 radial_tables, 2 lin_tables, 3 psf_component, 4 op, 5 surface, 6 tansip, 7 optics, 8 bf_slot,
- * 9 sensor, 10 photons, 11 render_params, 12 plan_item, 13 atmosphere, 14 fft_object, 15 fft_params */
+ * 9 sensor, 10 photons, 11 render_params, 12 plan_item, 13 atmosphere, 14 fft_object, 15 fft_params, 16 readout */
 /* Host helpers: fill the derived (uniform) fields of an op / a medium from its primary parameters, so
  * that the kernels do not recompute launch-wide constants per photon.  Call them once when the op
  * chain / the optics descriptor is built; ops and media without derived fields are left untouched. */

@@ -51,6 +51,10 @@ def load():
         lib.orc_sensor_pixel_areas.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         lib.orc_flat_add.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_uint64, C.c_int64, C.c_int32, C.c_int32,
                                      C.c_void_p, C.c_void_p]
+        lib.orc_readout_bleed.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_void_p]
+        lib.orc_readout_segments.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(_abi.Readout), C.c_void_p, C.c_void_p]
+        lib.orc_readout_cte.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_abi.Readout), C.c_void_p, C.c_int32, C.c_int32]
+        lib.orc_readout_finish.argtypes = [C.c_void_p, C.POINTER(_abi.Readout), C.c_uint64, C.c_void_p]
         lib.orc_fill_derived_op.argtypes = [C.c_void_p]
         lib.orc_fill_derived_medium.argtypes = [C.c_int32, C.POINTER(C.c_double)]
         _lib = lib
@@ -308,3 +312,47 @@ class OracleFft:
         rbuf = np.ascontiguousarray(rbuf, dtype=np.float64)
         self.lib.orc_fft_finish(C.byref(self.P), rows.ctypes.data, len(rows), rbuf.ctypes.data, self.image.ctypes.data,
                                 realized.ctypes.data if realized is not None else None)
+
+
+# ---------------------------------------------------------------------------------------------
+# CCD readout (oracle/orc_readout.c)
+# ---------------------------------------------------------------------------------------------
+def bleed_eimage(eimage, full_well, midline_stop=True):
+    """bleed_trails.bleed_eimage on a float64 [ny][nx] array (returns a new array)."""
+    lib = load()
+    img = np.ascontiguousarray(eimage, dtype=np.float64).copy()
+    ny, nx = img.shape
+    flags = np.zeros(nx * ny, dtype=np.uint8)
+    lib.orc_readout_bleed(img.ctypes.data, nx, ny, float(full_well), int(bool(midline_stop)), flags.ctypes.data)
+    return img
+
+
+def readout_chain(eimage, ro, full_well, midline_stop, dark_level, dark_stream, seed, pcte_band, scte_band, stages=None):
+    """The steps of CcdReadout.build_amp_images on host arrays; `ro` is the _abi.Readout descriptor the product
+    built.  Returns the int32 segments [n_amps][raw_h][raw_w]; `stages` (a dict) receives the intermediate arrays."""
+    lib = load()
+    img = bleed_eimage(eimage, full_well, midline_stop)
+    ny, nx = img.shape
+    if stages is not None:
+        stages["bled"] = img.copy()
+    lib.orc_flat_add(None, None, float(dark_level), 1.0, int(seed), int(dark_stream), nx, ny, img.ctypes.data, None)
+    if stages is not None:
+        stages["dark"] = img.copy()
+    shape = (ro.n_amps, ro.raw_h, ro.raw_w)
+    a = np.zeros(shape, dtype=np.float32)
+    b = np.zeros(shape, dtype=np.float32)
+    scratch = np.zeros(ro.n_amps * ro.seg_w * ro.seg_h, dtype=np.float32)
+    lib.orc_readout_segments(img.ctypes.data, nx, ny, C.byref(ro), a.ctypes.data, scratch.ctypes.data)
+    if stages is not None:
+        stages["segments"] = a.copy()
+    for band, axis in ((pcte_band, 0), (scte_band, 1)):
+        if band is None:
+            continue
+        bd = np.ascontiguousarray(band, dtype=np.float64)
+        lib.orc_readout_cte(a.ctypes.data, b.ctypes.data, C.byref(ro), bd.ctypes.data, bd.shape[1], axis)
+        a, b = b, a
+    if stages is not None:
+        stages["cte"] = a.copy()
+    out = np.zeros(shape, dtype=np.int32)
+    lib.orc_readout_finish(a.ctypes.data, C.byref(ro), int(seed), out.ctypes.data)
+    return out

@@ -116,6 +116,7 @@ int orc_struct_size(int which)
     case 13: return (int)sizeof(ims_atmosphere_t);
     case 14: return (int)sizeof(ims_fft_object_t);
     case 15: return (int)sizeof(ims_fft_params_t);
+    case 16: return (int)sizeof(ims_readout_t);
     }
     return -1;
 }

@@ -1,4 +1,5 @@
 """GPU parity tests proper: the HIP path, called through the C-ABI, against the CPU oracle."""
+import os
 import ctypes as C
 
 import numpy as np
@@ -720,3 +721,123 @@ def test_focal_plane_ccds_on_streams(torch_cuda):
     for p in parts:
         for det, img in p.items():
             assert_bits_equal(img, images[det], f"CCD {det} rank split")
+
+
+# ---------------------------------------------------------------------------------------------
+# CCD readout: e-image -> raw amplifier segments
+# ---------------------------------------------------------------------------------------------
+def _gpu_bleed(torch, img, full_well, midline):
+    lib = _abi.load()
+    t = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float64)).cuda()
+    ny, nx = t.shape
+    flags = torch.empty(nx * ny, dtype=torch.uint8, device="cuda")
+    _abi.check(lib.ims_readout_bleed(t.data_ptr(), flags.data_ptr(), nx, ny, float(full_well), int(midline), None))
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+def test_bleed_trails_match_reference_goldens_and_oracle(torch_cuda):
+    """bleed_eimage on the GPU against the vectors generated from the reference's bleed_trails.py, and against the
+    oracle on a CCD-sized image with many saturated stars."""
+    import os
+    from oracle import orc_loader
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "readout_golden.npz"))
+    fw = float(gold["full_well"])
+    assert_bits_equal(_gpu_bleed(torch_cuda, gold["img_in"], fw, True), gold["img_midline"], "midline stop")
+    assert_bits_equal(_gpu_bleed(torch_cuda, gold["img_in"], fw, False), gold["img_nomidline"], "no midline stop")
+    assert_bits_equal(_gpu_bleed(torch_cuda, gold["chan_in"][:, None], fw, False)[:, 0], gold["chan_out"], "single channel")
+    assert_bits_equal(_gpu_bleed(torch_cuda, gold["neg_in"][:, None], float(gold["neg_fw"]), False)[:, 0], gold["neg_out"],
+                      "regression channel")
+    rng = np.random.default_rng(8)
+    img = rng.poisson(800.0, size=(1000, 1536)).astype(np.float64)
+    for _ in range(300):
+        y, x, s = rng.integers(0, 1000), rng.integers(0, 1536), rng.integers(1, 6)
+        img[max(y - s, 0):y + s, max(x - s, 0):x + s] += rng.uniform(0.5, 40.0) * 1e5
+    for mid in (True, False):
+        assert_bits_equal(_gpu_bleed(torch_cuda, img, 1e5, mid), orc_loader.bleed_eimage(img, 1e5, mid), f"random image, midline {mid}")
+
+
+def _eimage_with_stars(nx, ny, seed, n_star=40):
+    rng = np.random.default_rng(seed)
+    e = rng.poisson(800.0, size=(ny, nx)).astype(np.float64)
+    for _ in range(n_star):
+        y, x, s = rng.integers(0, ny), rng.integers(0, nx), rng.integers(1, 5)
+        e[max(y - s, 0):y + s, max(x - s, 0):x + s] += np.round(rng.uniform(0.2, 30.0) * 1e5)
+    return e
+
+
+def test_readout_chain_is_bit_exact(torch_cuda, tmp_path):
+    """CcdReadout.build_amp_images on the GPU (bleed trails, dark current, gain / flips / crosstalk, prescan and
+    overscan, parallel + serial CTI, bias, read noise, int32) against the oracle, for a full-size E2V CCD with
+    per-amp bias levels and for an ITL CCD; then the raw file is written and read back."""
+    import json
+    from imsim_amd import readout, camera, fits_io
+    from oracle import orc_loader
+    levels = {f"{r}_{s}": {a: 20000.0 + 11 * i for i, a in enumerate(camera.CHANNELS)} for r in camera.RAFTS for s in camera.SENSORS}
+    (tmp_path / "bias.json").write_text(json.dumps(levels))
+    cases = (("R22_S11", dict(bias_levels_file=str(tmp_path / "bias.json"))),
+             ("R01_S00", dict(bias_level=1000.0, read_noise=6.5, scti=3e-6, pcti=0)))
+    for det, kw in cases:
+        cam = camera.Camera("LsstCamSim", bias_levels_file=kw.get("bias_levels_file"))
+        ny, nx = cam[det].bounds.numpyShape()
+        e = _eimage_with_stars(nx, ny, seed=len(det) + nx)
+        hdr = readout.eimage_header(det, 30.0, opsim_data={"mjd": 60000.25, "band": "r"})
+        eimg = readout.EImage(torch_cuda.from_numpy(e).cuda(), hdr)
+        ro = readout.CcdReadout(eimg, camera_obj=cam, **kw)
+        seed = 4242
+        got = ro.build_amp_images(seed)
+        torch_cuda.cuda.synchronize()
+        st = {}
+        want = orc_loader.readout_chain(e, ro.descriptor(), ro.full_well, ro.midline_stop(), ro.dark_level(), readout.DARK_STREAM,
+                                        seed, ro.pcte_band, ro.scte_band, st)
+        assert (st["bled"] != e).any(), "the test image must actually bleed"
+        assert_bits_equal(eimg.array.cpu().numpy(), st["dark"], f"{det}: e-image after bleed trails and dark current")
+        assert_bits_equal(got.cpu().numpy(), want, f"{det}: raw segments")
+        assert got.shape == (16, 2048, 576)
+    hdus = ro.prepare_hdus(seed + 1)
+    f = tmp_path / "raw.fits"
+    readout.CcdReadout.write_raw_file(hdus, str(f))
+    back = fits_io.read_fits(str(f))
+    assert len(back) == 17 and back[0][0]["OUTFILE"] == "raw.fits" and back[0][0]["CHIPID"] == "R01_S00"
+    assert back[1][0]["EXTNAME"] == "Segment10" and back[16][0]["EXTNAME"] == "Segment00"
+    assert back[9][0]["DATASEC"] == "[4:512,1:2000]"
+    for k in range(16):
+        assert_bits_equal(back[k + 1][1], hdus[k + 1][1], f"segment {k} through the file")
+    eimg.write(str(tmp_path / "eimage.fits"))
+    (h, d), = fits_io.read_fits(str(tmp_path / "eimage.fits"))
+    assert h["DET_NAME"] == "R01_S00" and d.shape == (4000, 4072) and d.dtype == np.float32
+
+
+def test_config_readout_writes_eimage_and_raw_file(torch_cuda, tmp_path):
+    """`output.file_name` and the `output.readout` extra output (config/imsim-config.yaml:322-352 semantics): the
+    e-image file and the 16-segment raw file; the segments, put back together with the gains, give the e-image."""
+    from imsim_amd import fits_io, camera
+    from imsim_amd.lsst_image import GalSimConfigError
+    res = _process(**{"image.nobjects": 40, "stamp.draw_method": "phot", "output.dir": str(tmp_path), "output.file_name": "eimage.fits",
+                      "output.readout": {"readout_time": 3.0, "dark_current": 0.0, "bias_level": 1000.0, "scti": 0.0, "pcti": 0.0,
+                                         "read_noise": 0.0, "file_name": "amp.fits",
+                                         "added_keywords": {"TESTKEY1": "TESTVAL1"}}})
+    assert [os.path.basename(f) for f in res.files] == ["eimage.fits", "amp.fits"] and len(res.raw) == 1
+    (eh, ed), = fits_io.read_fits(res.files[0])
+    assert eh["DET_NAME"] == "R22_S11" and eh["CAMERA"] == "LsstCamSim" and ed.shape == (4004, 4096)
+    assert np.array_equal(ed, res.images[0])
+    raw = fits_io.read_fits(res.files[1])
+    assert len(raw) == 17 and raw[0][0]["TESTKEY1"] == "TESTVAL1" and raw[0][0]["CHIPID"] == "R22_S11" and raw[0][0]["EXPTIME"] == eh["EXPTIME"]
+    ccd = camera.Camera("LsstCamSim")["R22_S11"]
+    back = np.zeros_like(ed)
+    for k, amp in enumerate(ccd.values()):
+        r, b = amp.raw_data_bounds, amp.bounds
+        sec = raw[k + 1][1][r.ymin - 1:r.ymax, r.xmin - 1:r.xmax].astype(np.float64) - 1000.0
+        if amp.raw_flip_x:
+            sec = sec[:, ::-1]
+        if amp.raw_flip_y:
+            sec = sec[::-1, :]
+        back[b.ymin - 1:b.ymax, b.xmin - 1:b.xmax] = sec * amp.gain
+    # the readout works on the e-image after the bleed trails (the catalog's brightest star is far above full well)
+    bled = res.eimages[0].array.cpu().numpy()
+    assert ed.max() > ccd.full_well and bled.max() == ccd.full_well and bled.sum() <= ed.sum()
+    # no noise, no CTI, no dark current: only crosstalk (<= 4e-4 of the brightest neighbour) and the ADU truncation remain
+    assert np.abs(back - bled).max() <= 2.0 + 1e-3 * bled.max()
+    assert abs(back.sum() / bled.sum() - 1) < 0.01
+    with pytest.raises(GalSimConfigError):
+        _process(**{"image.nobjects": 5, "output.readout": {"no_such_parameter": 1}})

@@ -915,11 +915,28 @@ __global__ __launch_bounds__(256) void k_fft_finish(const ims_fft_params_t P, co
 // ---------------- CCD readout (imsim/readout.py:413-478, imsim/bleed_trails.py) ----------------
 constexpr long long READOUT_ID_BASE = 0x7E00000000ll;   // object id space of the read-noise streams (+ amp index)
 
+// span[4 x + 2 half + {0,1}]: first / last saturated row of the channel (relative to the channel's first row)
+__global__ __launch_bounds__(256) void k_readout_span_init(int* __restrict__ span, int nx)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < nx) { span[4 * x] = 0x7FFFFFFF; span[4 * x + 1] = -1; span[4 * x + 2] = 0x7FFFFFFF; span[4 * x + 3] = -1; }
+}
+
 __global__ __launch_bounds__(256) void k_readout_flags(const double* __restrict__ image, unsigned char* __restrict__ flags,
-                                                       int64_t n, double full_well)
+                                                       int* __restrict__ span, int nx, int ny, double full_well, int midline_stop)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n) flags[p] = image[p] > full_well ? 1 : 0;
+    if (p >= (int64_t)nx * ny) return;
+    const bool sat = image[p] > full_well;
+    flags[p] = sat ? 1 : 0;
+    if (sat) {                                   // rare: a few hundred pixels of a CCD
+        const int x = (int)(p % nx), y = (int)(p / nx);
+        const int ymid = ny / 2;
+        const int half = (midline_stop && y >= ymid) ? 1 : 0;
+        const int yl = half ? y - ymid : y;
+        atomicMin(&span[4 * x + 2 * half], yl);
+        atomicMax(&span[4 * x + 2 * half + 1], yl);
+    }
 }
 
 // BleedCharge.__call__ (bleed_trails.py:117-152): returns true once the excess is used up
@@ -939,7 +956,8 @@ __device__ __forceinline__ bool bleed_into(double* __restrict__ c, int64_t strid
 // one thread per channel (a column, or half a column with the midline stop); neighbouring threads walk neighbouring
 // columns, so every step of the walk is one coalesced row access
 __global__ __launch_bounds__(256) void k_readout_bleed(double* __restrict__ image, const unsigned char* __restrict__ flags,
-                                                       int nx, int ny, double full_well, int midline_stop)
+                                                       const int* __restrict__ span, int nx, int ny, double full_well,
+                                                       int midline_stop)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int n_half = midline_stop ? 2 : 1;
@@ -950,8 +968,10 @@ __global__ __launch_bounds__(256) void k_readout_bleed(double* __restrict__ imag
     const int n = midline_stop ? (half == 0 ? ymid : ny - ymid) : ny;
     double* c = image + (int64_t)ylo * nx + x;
     const unsigned char* f = flags + (int64_t)ylo * nx + x;
-    int y = 0;
-    while (y < n) {
+    // runs are found on the ORIGINAL flags: only the rows between the first and the last saturated pixel need a look
+    int y = span[4 * x + 2 * half];
+    const int y_last = span[4 * x + 2 * half + 1];
+    while (y <= y_last) {
         if (!f[(int64_t)y * nx]) { ++y; continue; }
         const int y0 = y;
         while (y < n && f[(int64_t)y * nx]) ++y;
@@ -1482,9 +1502,12 @@ int ims_readout_bleed(double* image_dev, unsigned char* flags_dev, int32_t nx, i
     if (nx < 1 || ny < 1) return set_err(IMS_ERR_ARG, "empty image");
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = (int64_t)nx * ny;
-    hipLaunchKernelGGL(k_readout_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, image_dev, flags_dev, n, full_well);
+    int* span = (int*)(flags_dev + ((n + 15) / 16) * 16);        // the tail of the scratch: 4 ints per column
+    hipLaunchKernelGGL(k_readout_span_init, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, st, span, nx);
+    hipLaunchKernelGGL(k_readout_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, image_dev, flags_dev, span, nx, ny,
+                       full_well, midline_stop ? 1 : 0);
     const int threads = nx * (midline_stop ? 2 : 1);
-    hipLaunchKernelGGL(k_readout_bleed, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, image_dev, flags_dev, nx, ny,
+    hipLaunchKernelGGL(k_readout_bleed, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, image_dev, flags_dev, span, nx, ny,
                        full_well, midline_stop ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return IMS_OK;

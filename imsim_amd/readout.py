@@ -216,7 +216,7 @@ class CcdReadout:
         ny, nx = img.shape
         st = C.c_void_p(torch.cuda.current_stream(img.device).cuda_stream)
         ro = self.descriptor()
-        flags = torch.empty(nx * ny, dtype=torch.uint8, device=img.device)
+        flags = torch.empty((nx * ny + 15) // 16 * 16 + 16 * nx, dtype=torch.uint8, device=img.device)   # IMS_READOUT_SCRATCH_BYTES
         _abi.check(lib.ims_readout_bleed(img.data_ptr(), flags.data_ptr(), nx, ny, float(self.full_well),
                                          int(self.midline_stop()), st), "ims_readout_bleed")
         _abi.check(lib.ims_flat_add(None, None, float(self.dark_level()), 1.0, int(seed), DARK_STREAM, nx, ny,

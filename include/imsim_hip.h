@@ -463,7 +463,8 @@ int  ims_flat_add(const double* area_dev, const double* base_dev, double level, 
  *   ims_readout_bleed     bleed_eimage: per column (per half column with the e2v midline stop) every run of pixels
  *                         above full well is clipped and its excess spread alternately down and up the column;
  *                         charge leaving through the bottom is lost, the top is closed.  In place on the f64
- *                         e-image (integer electron counts: every sum is exact).  `flags` is nx*ny bytes of scratch.
+ *                         e-image (integer electron counts: every sum is exact).  `flags` is scratch of
+ *                         IMS_READOUT_SCRATCH_BYTES(nx, ny) bytes (saturation flags + first/last saturated row per channel).
  *   ims_flat_add          dark current: Poisson(dark_current * dark_time) per pixel (area, base, delta = NULL).
  *   ims_readout_segments  amp_data = float32(e-image)[amp.bounds] / gain in readout order (raw_flip_x/y), plus
  *                         intra-CCD crosstalk a_i + sum_j x_ij a_j (float32, j ascending), placed at the data
@@ -474,6 +475,7 @@ int  ims_flat_add(const double* area_dev, const double* base_dev, double level, 
  *   ims_readout_finish    + bias level, + Gaussian read noise (stream keyed by (seed, amp, pixel)), truncation to
  *                         int32 ADU (numpy astype(int32), readout.py:504). */
 #define IMS_MAX_AMPS 16
+#define IMS_READOUT_SCRATCH_BYTES(nx, ny) (((int64_t)(nx) * (ny) + 15) / 16 * 16 + 16 * (int64_t)(nx))
 typedef struct {
     int32_t x0, y0;            /* 0-based lower-left pixel of the amp's imaging section in the e-image */
     int32_t flip_x, flip_y;    /* raw_flip_x, raw_flip_y */

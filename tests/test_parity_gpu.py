@@ -730,7 +730,7 @@ def _gpu_bleed(torch, img, full_well, midline):
     lib = _abi.load()
     t = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float64)).cuda()
     ny, nx = t.shape
-    flags = torch.empty(nx * ny, dtype=torch.uint8, device="cuda")
+    flags = torch.empty((nx * ny + 15) // 16 * 16 + 16 * nx, dtype=torch.uint8, device="cuda")   # IMS_READOUT_SCRATCH_BYTES
     _abi.check(lib.ims_readout_bleed(t.data_ptr(), flags.data_ptr(), nx, ny, float(full_well), int(midline), None))
     torch.cuda.synchronize()
     return t.cpu().numpy()

@@ -364,7 +364,7 @@ IMS_DEV bool obscured(const ims_surface_t& S, double r2)
     return false;
 }
 
-// Propagate to surface S (spec v4): plane exact; conic by the closed-form root of smaller
+// Propagate to surface S (spec v5): plane exact; conic by the closed-form root of smaller
 // |t|, with the un-normalised normal (-c x, -c y, 1-(1+k) c z) that needs no sqrt; even-asphere terms
 // by Newton on the implicit conic form from the conic root until |G| <= 2e-11.
 IMS_DEV bool surf_hit(const ims_surface_t& S, double (&pos)[3], const double (&vel)[3], double (&N)[3], double& nn, double& r2_out)
@@ -373,62 +373,65 @@ IMS_DEV bool surf_hit(const ims_surface_t& S, double (&pos)[3], const double (&v
     double t;
     if (S.R == 0.0 && S.n_asphere == 0) {
         t = ddiv(-pz, vel[2]);
-        pos[0] = pos[0] + vel[0] * t; pos[1] = pos[1] + vel[1] * t; pos[2] = S.z0;
+        pos[0] = fma(vel[0], t, pos[0]); pos[1] = fma(vel[1], t, pos[1]); pos[2] = S.z0;
         N[0] = 0.0; N[1] = 0.0; N[2] = 1.0; nn = 1.0;
-        r2_out = pos[0] * pos[0] + pos[1] * pos[1];
+        r2_out = fma(pos[0], pos[0], pos[1] * pos[1]);
         return true;
     }
     const double c = S.inv_R, k1 = 1.0 + S.conic;
     if (S.R != 0.0) {
-        const double A = vel[0] * vel[0] + vel[1] * vel[1] + k1 * vel[2] * vel[2];
-        const double B = 2.0 * (pos[0] * vel[0] + pos[1] * vel[1] + k1 * pz * vel[2] - S.R * vel[2]);
-        const double C = pos[0] * pos[0] + pos[1] * pos[1] + k1 * pz * pz - 2.0 * S.R * pz;
-        const double disc = B * B - 4.0 * A * C;
-        if (disc < 0.0) return false;
-        const double sq = dsqrt0(disc);
-        const double q = -0.5 * (B + (B < 0.0 ? -sq : sq));
-        t = ddiv(C, q);                                 // the root of smaller |t| (q carries the larger magnitude)
+        // A t^2 + 2 hb t + C = 0 (spec v5: the dot products are fma chains, hb is half the linear coefficient)
+        const double k1vz = k1 * vel[2];
+        const double A = fma(vel[0], vel[0], fma(vel[1], vel[1], k1vz * vel[2]));
+        const double hb = fma(pos[0], vel[0], fma(pos[1], vel[1], fma(k1vz, pz, -(S.R * vel[2]))));
+        const double C = fma(pos[0], pos[0], fma(pos[1], pos[1], pz * fma(k1, pz, -2.0 * S.R)));
+        const double dq = fma(hb, hb, -(A * C));
+        if (dq < 0.0) return false;
+        const double sq = dsqrt0(dq);
+        const double q = -(hb + (hb < 0.0 ? -sq : sq));
+        t = ddiv(C, q);                              // the root of smaller |t| (q carries the larger magnitude)
     } else {
         t = ddiv(-pz, vel[2]);
     }
     if (S.n_asphere == 0) {
-        const double x = pos[0] + vel[0] * t, y = pos[1] + vel[1] * t, z = pz + vel[2] * t;
-        const double sqv = 1.0 - k1 * c * z;
+        const double x = fma(vel[0], t, pos[0]), y = fma(vel[1], t, pos[1]), z = fma(vel[2], t, pz);
+        const double sqv = fma(-(k1 * c), z, 1.0);
         if (!(sqv > 0.0)) return false;
         pos[0] = x; pos[1] = y; pos[2] = S.z0 + z;
         N[0] = -c * x; N[1] = -c * y; N[2] = sqv;
-        r2_out = x * x + y * y;
-        nn = c * c * r2_out + sqv * sqv;
+        r2_out = fma(x, x, y * y);
+        nn = fma(c * c, r2_out, sqv * sqv);
         return true;
     }
     // even asphere z = conic(r2) + p(r2), p = sum a_k r^(2k+4): Newton on the implicit conic form
     // G = c (r2 + k1 w^2) - 2 w with w = z - p(r2), which needs neither sqrt nor a second division
     double x = 0.0, y = 0.0, z = 0.0, r2 = 0.0, w = 0.0, dp = 0.0;
     for (int it = 0; it < 6; ++it) {
-        x = pos[0] + vel[0] * t; y = pos[1] + vel[1] * t; z = pz + vel[2] * t;
-        r2 = x * x + y * y;
+        x = fma(vel[0], t, pos[0]); y = fma(vel[1], t, pos[1]); z = fma(vel[2], t, pz);
+        r2 = fma(x, x, y * y);
         double p = 0.0, rp = r2;
         dp = 0.0;
         for (int k = 0; k < S.n_asphere; ++k) {
-            dp = dp + S.asph[k] * (double)(k + 2) * rp;
+            dp = fma(S.asph[k] * (double)(k + 2), rp, dp);
             rp = rp * r2;
-            p = p + S.asph[k] * rp;
+            p = fma(S.asph[k], rp, p);
         }
         w = z - p;
-        const double G = c * (r2 + k1 * w * w) - 2.0 * w;
+        const double k1w = k1 * w;
+        const double G = fma(c, fma(k1w, w, r2), -2.0 * w);
         if (fabs(G) <= 2.0e-11 || it == 5) break;
-        const double s = x * vel[0] + y * vel[1];
-        const double wp = vel[2] - 2.0 * dp * s;
-        const double Gp = 2.0 * (c * (s + k1 * w * wp) - wp);
+        const double s = fma(x, vel[0], y * vel[1]);
+        const double wp = fma(-2.0 * dp, s, vel[2]);
+        const double Gp = 2.0 * fma(c, fma(k1w, wp, s), -wp);
         t = t - ddiv(G, Gp);
     }
-    const double m = 1.0 - c * k1 * w;
+    const double m = fma(-(c * k1), w, 1.0);
     if (!(m > 0.0)) return false;
-    const double g = c + 2.0 * m * dp;
+    const double g = fma(2.0 * m, dp, c);
     pos[0] = x; pos[1] = y; pos[2] = S.z0 + z;
     N[0] = -g * x; N[1] = -g * y; N[2] = m;
     r2_out = r2;
-    nn = g * g * r2 + m * m;
+    nn = fma(g * g, r2, m * m);
     return true;
 }
 
@@ -450,8 +453,9 @@ IMS_DEV int trace(const ims_optics_t& o, double (&pos)[3], double (&vel)[3], dou
         if (obscured(S, r2)) vignetted = 1;
         if (S.kind == IMS_SURF_BAFFLE || S.kind == IMS_SURF_DETECTOR) continue;
         if (S.kind == IMS_SURF_MIRROR) {
-            const double d = ddiv(2.0 * (vel[0] * N[0] + vel[1] * N[1] + vel[2] * N[2]), nn);
-            vel[0] = vel[0] - d * N[0]; vel[1] = vel[1] - d * N[1]; vel[2] = vel[2] - d * N[2];
+            const double vn = fma(vel[0], N[0], fma(vel[1], N[1], vel[2] * N[2]));
+            const double d = ddiv(2.0 * vn, nn);
+            vel[0] = fma(-d, N[0], vel[0]); vel[1] = fma(-d, N[1], vel[1]); vel[2] = fma(-d, N[2], vel[2]);
         } else {
             double n2, in2;
             if (S.medium_kind == IMS_MEDIUM_CONST) { n2 = S.medium_c[0]; in2 = S.medium_c[1]; }
@@ -461,18 +465,23 @@ IMS_DEV int trace(const ims_optics_t& o, double (&pos)[3], double (&vel)[3], dou
                 in2 = ddiv(1.0, n2);
                 glass_id = S.medium_id; glass_n = n2; glass_in = in2;
             }
-            const double dx = vel[0] * n_cur, dy = vel[1] * n_cur, dz = vel[2] * n_cur;
-            double a = dx * N[0] + dy * N[1] + dz * N[2];
+            // Snell with the un-normalised normal (spec v5): a = n1 (v.N) is the cosine of incidence times |N|; with
+            // eta = n1/n2 the new velocity is eta^2 v - (nfac / n2) N
+            const double vn = fma(vel[0], N[0], fma(vel[1], N[1], vel[2] * N[2]));
+            double a = n_cur * vn;
             double sgn = 1.0;
             if (a > 0.0) { sgn = -1.0; a = -a; }
             const double eta = n_cur * in2;
             const double inn = ddiv(1.0, nn);
-            const double sinsqr = eta * eta * (1.0 - a * a * inn);
+            const double ai = a * inn;
+            const double e2 = eta * eta;
+            const double sinsqr = e2 * fma(-a, ai, 1.0);
             if (sinsqr > 1.0) return 2;
-            const double nfac = sgn * (eta * a * inn + dsqrt0((1.0 - sinsqr) * inn));
-            vel[0] = (eta * dx - nfac * N[0]) * in2;
-            vel[1] = (eta * dy - nfac * N[1]) * in2;
-            vel[2] = (eta * dz - nfac * N[2]) * in2;
+            const double nfac = sgn * fma(eta, ai, dsqrt0(fma(-sinsqr, inn, inn)));
+            const double nf2 = nfac * in2;
+            vel[0] = fma(e2, vel[0], -(nf2 * N[0]));
+            vel[1] = fma(e2, vel[1], -(nf2 * N[1]));
+            vel[2] = fma(e2, vel[2], -(nf2 * N[2]));
             n_cur = n2;
         }
     }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Golden digests of the numerics spec (spec v4), produced with the CPU oracle:
+"""Golden digests of the numerics spec (spec v5), produced with the CPU oracle:
 
     python tests/golden/make_pipeline_golden.py        ->  tests/golden/pipeline_golden.json
 

@@ -211,11 +211,15 @@ IMS_DEV void sincos2pi(double u, double& s, double& c)
     const double r = fma(-0.25, qf, u);
     const double t = r * TWO_PI;
     const double sk = sin_kernel(t), ck = cos_kernel(t);
+    // quadrant q: (s, c) = (sk, ck), (ck, -sk), (-sk, -ck), (-ck, sk) -- as two selects and two sign flips instead of
+    // a four-way branch (negation is exact, so the bits are those of the branches)
     const int q = (int)qf & 3;
-    if (q == 0) { s = sk; c = ck; }
-    else if (q == 1) { s = ck; c = -sk; }
-    else if (q == 2) { s = -sk; c = -ck; }
-    else { s = -ck; c = sk; }
+    const bool odd = (q & 1) != 0;
+    const double s0 = odd ? ck : sk, c0 = odd ? sk : ck;
+    const unsigned long long sbit = (unsigned long long)(q & 2) << 62;               // q = 2, 3: sin negative
+    const unsigned long long cbit = (unsigned long long)((q + 1) & 2) << 62;         // q = 1, 2: cos negative
+    s = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(s0) ^ sbit));
+    c = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(c0) ^ cbit));
 }
 IMS_DEV void dsincos(double x, double& s, double& c)
 {

@@ -51,7 +51,8 @@ assert OBJECT_DTYPE.itemsize == 256
 
 
 class RadialTables(C.Structure):
-    _fields_ = [("n_tables", c_i32), ("n_bins", c_i32), ("r2", c_vp), ("cdf", c_vp)]
+    _fields_ = [("n_tables", c_i32), ("n_bins", c_i32), ("r2", c_vp), ("cdf", c_vp), ("guide", c_vp), ("n_guide", c_i32),
+                ("pad", c_i32)]
 
 
 class LinTables(C.Structure):

@@ -207,7 +207,14 @@ class BoundScene:
             r2 = np.atleast_2d(scene.radial_r2)
             P.radial.n_tables, P.radial.n_bins = r2.shape[0], r2.shape[1] - 1
             _, P.radial.r2 = mem.put(r2, np.float64)
-            _, P.radial.cdf = mem.put(np.atleast_2d(scene.radial_cdf), np.float64)
+            cdf = np.atleast_2d(scene.radial_cdf)
+            _, P.radial.cdf = mem.put(cdf, np.float64)
+            # guide table of the inverse-CDF bin search (ims_radial_tables_t.guide): last knot with cdf <= g / n_guide
+            n_guide = 512
+            grid = np.arange(n_guide + 1) / n_guide
+            guide = np.stack([np.clip(np.searchsorted(row, grid, side="right") - 1, 0, len(row) - 2) for row in cdf])
+            _, P.radial.guide = mem.put(guide, np.int32)
+            P.radial.n_guide = n_guide
         if scene.sed_tables is not None:
             t = np.atleast_2d(scene.sed_tables)
             P.sed.n_tables, P.sed.n_pts = t.shape

@@ -40,7 +40,7 @@ extern "C" {
 #define IMS_ERR_NO_DEVICE  -3
 #define IMS_ERR_UNSUPPORTED -4
 
-#define IMS_ABI_VERSION 2
+#define IMS_ABI_VERSION 3
 
 /* ---- object flags ---- */
 #define IMS_OBJ_FAINT   1   /* nominal_flux < max_flux_simple: no photon ops, no sensor (stamp.py:435-465,555-556) */
@@ -124,6 +124,11 @@ typedef struct ims_radial_tables {
     int32_t n_bins;          /* each table has n_bins+1 knots */
     const double* r2;        /* [n_tables][n_bins+1] squared radii, increasing */
     const double* cdf;       /* [n_tables][n_bins+1] enclosed flux fraction, cdf[0]=0, cdf[n_bins]=1 */
+    const int32_t* guide;    /* optional [n_tables][n_guide+1]: guide[g] = last knot with cdf <= g/n_guide, so that the bin
+                              * search of a deviate u starts inside [guide[g], guide[g+1]], g = floor(u n_guide); same bin
+                              * as the full bisection.  NULL: bisect over the whole table */
+    int32_t n_guide;         /* a power of two */
+    int32_t pad;
 } ims_radial_tables_t;
 
 /* Generic 1-D tables uniform in their argument, linear interpolation, clamped at the ends.

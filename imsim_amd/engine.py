@@ -364,10 +364,11 @@ class Renderer:
         self.image = self.torch.zeros((scene.ny, scene.nx), dtype=self.torch.float64, device=self.device)
         # two side streams: the sequential brighter-fatter chain of the bright objects runs at high
         # priority while the wide single-launch work fills the CUs it leaves idle
-        self.s_chain = self.torch.cuda.Stream(self.device, priority=-1)
-        self.s_bulk = self.torch.cuda.Stream(self.device, priority=0)
-        self.s_chain1 = self.torch.cuda.Stream(self.device, priority=0)
-        self.s_chain2 = self.torch.cuda.Stream(self.device, priority=0)
+        pr = [int(v) for v in os.environ.get("IMS_STREAM_PRIORITIES", "-1,0,0,0").split(",")]   # chain, bulk, chain1, chain2
+        self.s_chain = self.torch.cuda.Stream(self.device, priority=pr[0])
+        self.s_bulk = self.torch.cuda.Stream(self.device, priority=pr[1])
+        self.s_chain1 = self.torch.cuda.Stream(self.device, priority=pr[2])
+        self.s_chain2 = self.torch.cuda.Stream(self.device, priority=pr[3])
         self.use_bf_tags = os.environ.get("IMS_BF_TAGS", "0") != "0"
         # round-count thresholds that cut the bright objects into concurrent chains (plan_lsst_image)
         self.chain_class_rounds = tuple(int(v) for v in os.environ.get("IMS_CHAIN_CLASSES", "40,6").split(",") if v)
@@ -452,6 +453,7 @@ class Renderer:
         normal, groups = plan_bf_groups(objects, nrecalc, b.n_static_slots, b.static_cells, ss.scratch_cells,
                                         b.slot_capacity, self.max_pool_photons)
         n_events = 0
+        render_done = False
         for idx, slots in groups:
             plan.append(("slots", slots))
             n0 = b.n_static_slots
@@ -511,6 +513,14 @@ class Renderer:
                 chains.append(dict(stream=cstream, ca=ca, tot=ctot, grp=cgrp, idx=cidx, offs=coffs, rounds=rounds,
                                    slice_of_round=slice_of_round, ev_base=ev_base, waited=0))
             plan.extend(bulk_items)
+            # The ordinary objects' fused launch is queued on the bulk stream right behind the pool slices, BEFORE the
+            # ~1 300 short launches of the rounds: the host needs ~20 us per launch to enqueue those, and an item at
+            # the end of the plan would leave the bulk stream idle until the host gets there.
+            if len(normal) and not render_done:
+                part = objects[normal].copy()
+                part["bf_state"] = 0
+                add_render(part, normal, "bulk")
+                render_done = True
             # 2. the sequential part: rounds of nrecalc photons per object through the sensor.  The
             #    classes' rounds are interleaved in the plan so that the host enqueues all chains at
             #    the same pace.
@@ -535,7 +545,7 @@ class Renderer:
                     n_cont = int(np.count_nonzero(ctot > (r + 1) * nrecalc))
                     if n_cont:
                         plan.append(("update", n0 + ch["ca"], n_cont, ch["stream"], tag))
-        if len(normal):
+        if len(normal) and not render_done:
             part = objects[normal].copy()
             part["bf_state"] = 0
             add_render(part, normal, "bulk")

@@ -998,41 +998,56 @@ __device__ __forceinline__ float amp_adu(const double* __restrict__ image, int n
     return e / A.gain;
 }
 
+// grid (raw_w / 64, raw_h / 4, n_amps), block (64, 4)
 __global__ __launch_bounds__(256) void k_readout_segments(const double* __restrict__ image, int nx, const ims_readout_t ro,
                                                           float* __restrict__ seg)
 {
-    const int64_t per = (int64_t)ro.raw_w * ro.raw_h;
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= per * ro.n_amps) return;
-    const int a = (int)(p / per);
-    const int64_t q = p - (int64_t)a * per;
-    const int rx = (int)(q % ro.raw_w), ry = (int)(q / ro.raw_w);
+    const int rx = blockIdx.x * 64 + threadIdx.x, ry = blockIdx.y * 4 + threadIdx.y;
+    if (rx >= ro.raw_w || ry >= ro.raw_h) return;
+    const int a = blockIdx.z;
     const int u = rx - ro.data_x0, v = ry - ro.data_y0;
     float out = 0.0f;
     if (u >= 0 && u < ro.seg_w && v >= 0 && v < ro.seg_h) {
         out = amp_adu(image, nx, ro, a, u, v);
         if (ro.has_xtalk) {
             float sum = 0.0f;
-            for (int j = 0; j < ro.n_amps; ++j) sum = sum + ro.xtalk[a * IMS_MAX_AMPS + j] * amp_adu(image, nx, ro, j, u, v);
+            for (int j = 0; j < ro.n_amps; ++j) {
+                const float x = ro.xtalk[a * IMS_MAX_AMPS + j];
+                if (x != 0.0f) sum = sum + x * amp_adu(image, nx, ro, j, u, v);     // a zero coefficient adds exactly nothing
+            }
             out = out + sum;
         }
     }
-    seg[p] = out;
+    seg[((int64_t)a * ro.raw_h + ry) * ro.raw_w + rx] = out;
 }
 
-__global__ __launch_bounds__(256) void k_readout_cte(const float* __restrict__ src, float* __restrict__ dst, int n_amps, int raw_w,
-                                                     int raw_h, const double* __restrict__ band, int n_band, int axis)
+// grid (raw_w / 64, raw_h / 4, n_amps), block (64, 4): a wavefront is 64 neighbouring columns of one row, so every tap
+// of the parallel direction is one coalesced 256-B row access and the four rows of a workgroup share their taps in L1;
+// no integer division anywhere.
+// NB > 0: the band width is known at compile time (the reference's ntransfers = 20: 21 taps); pixels with a full
+// set of taps take an unrolled path whose 2 x 21 loads are all in flight before the first use.
+template <int NB>
+__global__ __launch_bounds__(256) void k_readout_cte(const float* __restrict__ src, float* __restrict__ dst, int raw_w, int raw_h,
+                                                     const double* __restrict__ band, int n_band, int axis)
 {
-    const int64_t per = (int64_t)raw_w * raw_h;
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= per * n_amps) return;
-    const int64_t q = p % per;
-    const int rx = (int)(q % raw_w), ry = (int)(q / raw_w);
+    const int rx = blockIdx.x * 64 + threadIdx.x, ry = blockIdx.y * 4 + threadIdx.y;
+    if (rx >= raw_w || ry >= raw_h) return;
+    const int p = ((int)blockIdx.z * raw_h + ry) * raw_w + rx;
     const int i = axis == 0 ? ry : rx;
-    const int64_t step = axis == 0 ? raw_w : 1;
+    const int step = axis == 0 ? raw_w : 1;
     const int dmax = i < n_band - 1 ? i : n_band - 1;
+    const double* w = band + i * n_band;
     double acc = 0.0;
-    for (int d = dmax; d >= 0; --d) acc = acc + band[(int64_t)i * n_band + d] * (double)src[p - (int64_t)d * step];
+    if (NB > 0 && i >= NB - 1) {
+        float v[NB > 0 ? NB : 1];
+        double ww[NB > 0 ? NB : 1];
+#pragma unroll
+        for (int d = 0; d < NB; ++d) { v[d] = src[p - d * step]; ww[d] = w[d]; }
+#pragma unroll
+        for (int d = NB - 1; d >= 0; --d) acc = acc + ww[d] * (double)v[d];
+    } else {
+        for (int d = dmax; d >= 0; --d) acc = acc + w[d] * (double)src[p - d * step];
+    }
     dst[p] = (float)acc;
 }
 
@@ -1520,9 +1535,8 @@ int ims_readout_segments(const double* image_dev, int32_t nx, int32_t ny, const 
     for (int a = 0; a < ro->n_amps; ++a)
         if (ro->amps[a].x0 < 0 || ro->amps[a].y0 < 0 || ro->amps[a].x0 + ro->seg_w > nx || ro->amps[a].y0 + ro->seg_h > ny)
             return set_err(IMS_ERR_ARG, "amplifier section outside the e-image");
-    const int64_t n = (int64_t)ro->raw_w * ro->raw_h * ro->n_amps;
-    hipLaunchKernelGGL(k_readout_segments, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, image_dev, nx, *ro,
-                       seg_dev);
+    hipLaunchKernelGGL(k_readout_segments, dim3((unsigned)((ro->raw_w + 63) / 64), (unsigned)((ro->raw_h + 3) / 4), (unsigned)ro->n_amps),
+                       dim3(64, 4), 0, (hipStream_t)stream, image_dev, nx, *ro, seg_dev);
     HIP_TRY(hipGetLastError());
     return IMS_OK;
 }
@@ -1534,9 +1548,14 @@ int ims_readout_cte(const float* src_dev, float* dst_dev, const ims_readout_t* r
     if (!src_dev || !dst_dev || !band_dev) return set_err(IMS_ERR_ARG, "src / dst / band is NULL");
     if (src_dev == dst_dev) return set_err(IMS_ERR_ARG, "ims_readout_cte is out of place: src and dst must differ");
     if (n_band < 1 || (axis != 0 && axis != 1)) return set_err(IMS_ERR_ARG, "n_band / axis out of range");
-    const int64_t n = (int64_t)ro->raw_w * ro->raw_h * ro->n_amps;
-    hipLaunchKernelGGL(k_readout_cte, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src_dev, dst_dev,
-                       ro->n_amps, ro->raw_w, ro->raw_h, band_dev, n_band, axis);
+    if ((int64_t)ro->raw_w * ro->raw_h * ro->n_amps >= (1ll << 31)) return set_err(IMS_ERR_ARG, "raw segments too large");
+    const dim3 grid((unsigned)((ro->raw_w + 63) / 64), (unsigned)((ro->raw_h + 3) / 4), (unsigned)ro->n_amps);
+    if (n_band == 21)
+        hipLaunchKernelGGL(k_readout_cte<21>, grid, dim3(64, 4), 0, (hipStream_t)stream, src_dev, dst_dev, ro->raw_w, ro->raw_h,
+                           band_dev, n_band, axis);
+    else
+        hipLaunchKernelGGL(k_readout_cte<0>, grid, dim3(64, 4), 0, (hipStream_t)stream, src_dev, dst_dev, ro->raw_w, ro->raw_h,
+                           band_dev, n_band, axis);
     HIP_TRY(hipGetLastError());
     return IMS_OK;
 }

@@ -38,19 +38,12 @@ def RegisterValueType(name, builder): valid_value_types[name] = builder
 def RegisterTemplate(name, path): templates[name] = path
 
 
-RAFTS = ["R01", "R02", "R03", "R10", "R11", "R12", "R13", "R14", "R20", "R21", "R22", "R23", "R24", "R30", "R31",
-         "R32", "R33", "R34", "R41", "R42", "R43"]
-SENSORS = ["S00", "S01", "S02", "S10", "S11", "S12", "S20", "S21", "S22"]
-ITL_RAFTS = {"R01", "R02", "R03", "R10", "R20", "R41", "R42", "R43"}
+from .camera import RAFTS, SENSORS, ITL_RAFTS, det_type_of      # noqa: E402  (one table of the focal-plane layout)
 
 
 def det_name_of(det_num):
     """LsstCamSim detector number -> name (imsim/ccd.py:72-89; 94 = R22_S11)."""
     return f"{RAFTS[det_num // 9]}_{SENSORS[det_num % 9]}"
-
-
-def det_type_of(det_name):
-    return "ITL" if det_name[:3] in ITL_RAFTS else "E2V"
 
 
 # ---------------- config loading ----------------

@@ -48,11 +48,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # IMS_BENCH_SHARE_GPU=1 is a dry run of the multi-rank path on a box with ONE GPU (all ranks on cuda:0, gloo instead
+    # of RCCL, which refuses two ranks on one device): it exercises sharding, barriers and the timing reduction only.
+    share_gpu = os.environ.get("IMS_BENCH_SHARE_GPU", "0") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    device = f"cuda:{local_rank}"
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    device = "cuda:0" if share_gpu else f"cuda:{local_rank}"
     torch.cuda.set_device(device)
 
     cfg = configs.BENCH_CONFIGS[args.config]

@@ -51,7 +51,10 @@ def reduce_image(image, dst=0):
     """Sum the per-rank CCD images onto `dst` (no-op for a single process)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(image, dst=dst, op=dist.ReduceOp.SUM)
+        if dist.get_backend() == "gloo" and image.is_cuda:
+            dist.all_reduce(image, op=dist.ReduceOp.SUM)       # gloo has no device reduce (dry runs on one GPU only)
+        else:
+            dist.reduce(image, dst=dst, op=dist.ReduceOp.SUM)
     return image
 
 

@@ -76,7 +76,8 @@ def main():
     def full_step():
         renderer.image.zero_()
         step()
-        parallel.reduce_image(renderer.image, dst=0)
+        # unit photon fluxes: every pixel is an integer count; the brightest pixel of this catalog holds ~1e8 < 2^31
+        parallel.reduce_image(renderer.image, dst=0, integer_counts=True)
 
     for _ in range(args.warmup):
         full_step()

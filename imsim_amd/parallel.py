@@ -47,14 +47,22 @@ def shard_ccds(dets, rank, world):
     return [d for k, d in enumerate(dets) if k % world == rank]
 
 
-def reduce_image(image, dst=0):
-    """Sum the per-rank CCD images onto `dst` (no-op for a single process)."""
+def reduce_image(image, dst=0, integer_counts=False):
+    """Sum the per-rank CCD images onto `dst` (no-op for a single process).
+
+    integer_counts: the caller guarantees that every pixel holds an integer electron count below 2^31 (unit photon
+    fluxes, the standard path: stamp.py:562-572 `poisson_flux=False`, n_photons=phot_flux).  The exchange then runs on
+    an int32 copy -- half the bytes of the f64 accumulation image on the per-link-bound xGMI ring -- and is still exact."""
+    import torch
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        if dist.get_backend() == "gloo" and image.is_cuda:
-            dist.all_reduce(image, op=dist.ReduceOp.SUM)       # gloo has no device reduce (dry runs on one GPU only)
+        buf = image.to(torch.int32) if integer_counts else image
+        if dist.get_backend() == "gloo" and buf.is_cuda:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)       # gloo has no device reduce (dry runs on one GPU only)
         else:
-            dist.reduce(image, dst=dst, op=dist.ReduceOp.SUM)
+            dist.reduce(buf, dst=dst, op=dist.ReduceOp.SUM)
+        if integer_counts and dist.get_rank() == dst:
+            image.copy_(buf)
     return image
 
 

@@ -29,9 +29,11 @@ def _worker(rank, world, port, out_path):
     orc = orc_loader.OracleScene(scene)
     orc.render(mine)
     img = torch.from_numpy(orc.image64.copy())
+    img_i = img.clone()
     parallel.reduce_image(img, dst=0)
+    parallel.reduce_image(img_i, dst=0, integer_counts=True)        # the int32 exchange bench.py uses
     if rank == 0:
-        np.savez(out_path, image=img.numpy(), counts=torch.stack(gathered).numpy())
+        np.savez(out_path, image=img.numpy(), image_int=img_i.numpy(), counts=torch.stack(gathered).numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -47,6 +49,7 @@ def test_two_rank_sharded_render_equals_single_process(tmp_path):
     orc = orc_loader.OracleScene(scene)
     orc.render(objects)
     assert np.array_equal(res["image"], orc.image64)
+    assert np.array_equal(res["image_int"], orc.image64) and res["image_int"].dtype == np.float64
     counts = res["counts"]
     assert counts[:, 0].sum() == len(objects)
     assert counts[:, 1].sum() == objects["n_phot"].sum()

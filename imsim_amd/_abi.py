@@ -19,7 +19,7 @@ IMS_MAX_OPS = 12
 IMS_SENSOR_NONE, IMS_SENSOR_SILICON = 0, 1
 IMS_SURF_MIRROR, IMS_SURF_REFRACT, IMS_SURF_DETECTOR, IMS_SURF_BAFFLE = 1, 2, 3, 4
 IMS_MEDIUM_CONST, IMS_MEDIUM_SELLMEIER, IMS_MEDIUM_AIR = 0, 1, 2
-IMS_PROF_POINT, IMS_PROF_BOX, IMS_PROF_KNOTS = -1, -2, -3
+IMS_PROF_POINT, IMS_PROF_BOX, IMS_PROF_KNOTS, IMS_PROF_IMAGE = -1, -2, -3, -4
 (IMS_OBSC_NONE, IMS_OBSC_CLEAR_ANNULUS, IMS_OBSC_CLEAR_CIRCLE, IMS_OBSC_OBSC_CIRCLE,
  IMS_OBSC_OBSC_ANNULUS) = range(5)
 IMS_MAX_SURFACES = 24
@@ -53,6 +53,10 @@ assert OBJECT_DTYPE.itemsize == 256
 class RadialTables(C.Structure):
     _fields_ = [("n_tables", c_i32), ("n_bins", c_i32), ("r2", c_vp), ("cdf", c_vp), ("guide", c_vp), ("n_guide", c_i32),
                 ("pad", c_i32)]
+
+
+class ImageTables(C.Structure):
+    _fields_ = [("n_images", c_i32), ("pad", c_i32), ("size", c_vp), ("offset", c_vp), ("cdf", c_vp)]
 
 
 class LinTables(C.Structure):
@@ -155,7 +159,7 @@ class RenderParams(C.Structure):
                 ("ops", Op * IMS_MAX_OPS), ("radial", RadialTables), ("sed", LinTables), ("ratio", LinTables),
                 ("atm", c_vp), ("optics", c_vp), ("sensor", c_vp), ("image", c_vp),
                 ("nx", c_i32), ("ny", c_i32), ("xmin", c_i32), ("ymin", c_i32), ("realized_flux", c_vp),
-                ("bf_tag", C.c_uint32), ("pad_tag", C.c_uint32), ("seg_object", c_vp)]
+                ("bf_tag", C.c_uint32), ("pad_tag", C.c_uint32), ("seg_object", c_vp), ("images", ImageTables)]
 
 
 class PlanItem(C.Structure):

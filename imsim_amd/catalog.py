@@ -9,7 +9,7 @@ import math
 import numpy as np
 
 from . import tables
-from ._abi import OBJECT_DTYPE, IMS_OBJ_FAINT, IMS_PROF_POINT, IMS_PROF_BOX, IMS_PROF_KNOTS
+from ._abi import OBJECT_DTYPE, IMS_OBJ_FAINT, IMS_PROF_POINT, IMS_PROF_BOX, IMS_PROF_KNOTS, IMS_PROF_IMAGE
 
 PIXEL_SCALE = 0.2          # arcsec / pixel (LSST_SiliconBuilder._pixel_scale, stamp.py:102)
 NMAX = 4096                # stamp.py:106
@@ -17,7 +17,7 @@ TINY_FLUX = 10             # stamp.py:105
 FT_DEFAULT = 5.0e-3        # galsim.GSParams().folding_threshold
 STEPK_MIN_HLR = 5.0        # galsim.GSParams().stepk_minimum_hlr
 SERSIC_N = (1.0, 4.0)
-KIND_KNOTS, KIND_STREAK = 3, 4
+KIND_KNOTS, KIND_STREAK, KIND_IMAGE = 3, 4, 5
 FLAT_OBJECT_ID = 0x7E00000000          # object ids of the photon-flat iterations (imsim_amd.flat)
 
 
@@ -251,8 +251,9 @@ def build_object_table(cat, phot_flux, noise_var=800.0, sed_table=0, max_flux_si
     obj["x0"], obj["y0"] = cat["x"], cat["y"]
     obj["flux_per_photon"] = 1.0
     # kinds: 0 point, 1 / 2 Sersic n = 1 / 4 (radial tables 0 / 1), 3 RandomKnots, 4 streak (Box)
-    knots, streak = kind == KIND_KNOTS, kind == KIND_STREAK
-    obj["prof_table"] = np.where(kind == 0, IMS_PROF_POINT, np.where(knots, IMS_PROF_KNOTS, np.where(streak, IMS_PROF_BOX, kind - 1)))
+    knots, streak, image = kind == KIND_KNOTS, kind == KIND_STREAK, kind == KIND_IMAGE
+    obj["prof_table"] = np.where(kind == 0, IMS_PROF_POINT, np.where(knots, IMS_PROF_KNOTS, np.where(streak, IMS_PROF_BOX,
+                                 np.where(image, IMS_PROF_IMAGE, kind - 1))))
     obj["prof_scale"] = np.where(kind == 0, 0.0, cat["hlr"])
     if knots.any():
         obj["prof_scale"][knots] = cat["hlr"][knots] / 1.1774100225154747      # Gaussian sigma of the knots' parent profile
@@ -260,6 +261,9 @@ def build_object_table(cat, phot_flux, noise_var=800.0, sed_table=0, max_flux_si
     if streak.any():
         obj["prof_scale"][streak] = cat["box_length"][streak]
         obj["prof_aux"][streak] = cat["box_width"][streak]
+    if image.any():                                             # InterpolatedImage(file, scale=pixel_scale), instcat.py:552-561
+        obj["prof_scale"][image] = cat["image_scale"][image]
+        obj["prof_aux"][image] = cat["image_index"][image]
     beta = 90.0 - cat["pa"]                                     # flip_g2 convention, instcat.py:503-508
     jac = shear_matrix(cat["q"], beta)
     if "g1" in cat:
@@ -268,6 +272,10 @@ def build_object_table(cat, phot_flux, noise_var=800.0, sed_table=0, max_flux_si
     if streak.any():                                            # Box(length, width).rotate(position_angle), instcat.py:494-496
         t = np.deg2rad(cat["pa"][streak])
         jac[streak] = np.stack([np.cos(t), -np.sin(t), np.sin(t), np.cos(t)], axis=-1)
+    if image.any():                                             # obj.rotate(-theta), then the lens (instcat.py:557-561)
+        t = -np.deg2rad(cat["pa"][image])
+        rot = np.stack([np.cos(t), -np.sin(t), np.sin(t), np.cos(t)], axis=-1)
+        jac[image] = _mat2(lens_matrix(cat["g1"][image], cat["g2"][image], cat["mu"][image]), rot) if "g1" in cat else rot
     obj["jac"] = jac
     obj["winv"] = np.broadcast_to(np.asarray(winv, dtype=np.float64), (n, 4))
     obj["dcr_tanz"], obj["dcr_sinp"], obj["dcr_cosp"] = dcr
@@ -301,6 +309,11 @@ def build_object_table(cat, phot_flux, noise_var=800.0, sed_table=0, max_flux_si
             if gs.any():
                 sk = np.pi / np.maximum(obj["prof_scale"][gal][gs], obj["prof_aux"][gal][gs])
                 size[np.flatnonzero(gal)[gs]] = np.minimum(_good_size(1.0 / np.sqrt(1.0 / sk ** 2 + 1.0 / dg_stepk ** 2)), NMAX)
+            gi = image[gal]
+            if gi.any():
+                # the stamp of an image profile: stepk = pi / (largest extent of the image on the sky)
+                sk = np.pi / (cat["image_extent"][gal][gi] * max_scale[gi])
+                size[np.flatnonzero(gal)[gi]] = np.minimum(_good_size(1.0 / np.sqrt(1.0 / sk ** 2 + 1.0 / dg_stepk ** 2)), NMAX)
         size[nominal < TINY_FLUX] = 32
     else:
         size = np.broadcast_to(np.asarray(stamp_size, dtype=np.int64), (n,)).copy()

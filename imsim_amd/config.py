@@ -522,6 +522,7 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
         cat = instcat.to_catalog(parsed, optics.img_wcs, nx, ny, float(np.trapezoid(thr, wl)), float(meta.get("exptime") or 30.0),
                                  sort_mag=bool(ic.get("sort_mag", True)), edge_pix=int(ic.get("edge_pix", 100)))
         phot = catalog.realize_fluxes(cat["nominal_flux"], seed)
+        scene.image_profiles = cat.get("images") or None          # FITS-stamp objects (instcat.py:552-561)
         renderer = Renderer(scene, device)
 
         def make_objects(sub, ph, scene=scene):

@@ -60,6 +60,7 @@ class Scene:
     ops: List[tuple] = dataclasses.field(default_factory=list)     # (kind, table, [p0..p5])
     radial_r2: Optional[np.ndarray] = None
     radial_cdf: Optional[np.ndarray] = None
+    image_profiles: Optional[list] = None        # 2-D arrays [ny][nx] sampled by IMS_PROF_IMAGE objects (FITS stamps)
     sed_tables: Optional[np.ndarray] = None      # [n][n_pts] inverse CDFs uniform in u
     ratio_tables: Optional[np.ndarray] = None    # [n][n_pts] uniform in wavelength
     ratio_wl_min: float = 0.0
@@ -179,6 +180,18 @@ class _LibDerive:
         _abi.check(self.lib.ims_fill_derived_medium(int(kind), c), "ims_fill_derived_medium")
 
 
+def image_profile_cdf(img):
+    """Cumulative distribution over the pixels of an image profile (row-major, negative pixels count as empty):
+    w*h + 1 knots from 0 to 1 (ims_image_tables_t.cdf)."""
+    v = np.clip(np.asarray(img, dtype=np.float64), 0.0, None).reshape(-1)
+    tot = v.sum()
+    if not tot > 0.0:
+        raise ValueError("image profile has no positive pixel")
+    cdf = np.concatenate([[0.0], np.cumsum(v) / tot])
+    cdf[-1] = 1.0
+    return cdf
+
+
 class BoundScene:
     """A Scene whose tables live behind pointers of one memory provider; builds RenderParams."""
 
@@ -203,6 +216,18 @@ class BoundScene:
             pp = list(p) + [0.0] * (8 - len(p))
             P.ops[k] = Op(kind, table, (C.c_double * 8)(*pp))
             derive.fill_derived_op(C.byref(P.ops[k]))
+        if scene.image_profiles:
+            sizes, offs, cdfs, pos = [], [], [], 0
+            for img in scene.image_profiles:
+                cdf = image_profile_cdf(img)
+                sizes.append((img.shape[1], img.shape[0]))
+                offs.append(pos)
+                cdfs.append(cdf)
+                pos += len(cdf)
+            P.images.n_images = len(sizes)
+            _, P.images.size = mem.put(np.asarray(sizes), np.int32)
+            _, P.images.offset = mem.put(np.asarray(offs), np.int64)
+            _, P.images.cdf = mem.put(np.concatenate(cdfs), np.float64)
         if scene.radial_r2 is not None:
             r2 = np.atleast_2d(scene.radial_r2)
             P.radial.n_tables, P.radial.n_bins = r2.shape[0], r2.shape[1] - 1

@@ -121,6 +121,9 @@ def _parse_value(text):
 def read_fits(file_name):
     """-> list of (header dict, data or None)."""
     raw = open(file_name, "rb").read()
+    if raw[:2] == b"\x1f\x8b":                     # .fits.gz
+        import gzip
+        raw = gzip.decompress(raw)
     pos, out = 0, []
     while pos < len(raw):
         header, done = {}, False

@@ -61,7 +61,8 @@ def parse_objects(path, max_objects=None):
     """Parse the `object` lines (grammar: imsim/instcat.py:231-297).  Lines containing ' inf ' are
     skipped (:233); invalid objects (magnorm >= 50, sersic/knots with a < b, knots with npoints <= 0)
     are skipped (:276-286).  Returns a dict of arrays in file order."""
-    ids, ra, dec, mag, sed, lens, kind, a, b, pa, n_or_pts = [], [], [], [], [], [], [], [], [], [], []
+    ids, ra, dec, mag, sed, lens, kind, a, b, pa, n_or_pts, fits = [], [], [], [], [], [], [], [], [], [], [], []
+    inst_dir = os.path.dirname(os.path.abspath(path))
     with fopen(path) as f:
         for line in f:
             if " inf " in line or not line.startswith("object"):
@@ -77,8 +78,11 @@ def parse_objects(path, max_objects=None):
                 k, aa, bb, pp, nn = 2, float(t[13]), float(t[14]), float(t[15]), float(int(t[16]))
             elif typ == "streak":
                 k, aa, bb, pp, nn = 3, float(t[13]), float(t[14]), float(t[15]), 0.0
+            elif t[12].endswith(".fits") or t[12].endswith(".fits.gz"):
+                # galsim.InterpolatedImage(file relative to the catalog, scale=pixel_scale).rotate(-theta), :552-561
+                k, aa, bb, pp, nn = 4, float(t[13]), 0.0, float(t[14]), 0.0
             else:
-                k, aa, bb, pp, nn = 4, 0.0, 0.0, 0.0, 0.0            # FITS image objects: not supported yet
+                k, aa, bb, pp, nn = 5, 0.0, 0.0, 0.0, 0.0            # unknown object type
             valid = magnorm < 50.0 and not (k in (1, 2) and aa < bb) and not (k == 2 and nn <= 0)
             if not valid:
                 continue
@@ -86,24 +90,29 @@ def parse_objects(path, max_objects=None):
             sed.append((t[5], float(t[6])))
             lens.append((float(t[7]), float(t[8]), float(t[9])))
             kind.append(k); a.append(aa); b.append(bb); pa.append(pp); n_or_pts.append(nn)
+            fits.append(os.path.join(inst_dir, t[12]) if k == 4 else "")
             if max_objects is not None and len(ids) >= max_objects:
                 break
     lens = np.array(lens, dtype=np.float64).reshape(-1, 3)
     return dict(id=np.array(ids), ra=np.radians(ra), dec=np.radians(dec), magnorm=np.array(mag), sed=sed,
                 gamma1=lens[:, 0], gamma2=lens[:, 1], kappa=lens[:, 2], objtype=np.array(kind, dtype=np.int32),
-                a=np.array(a), b=np.array(b), pa=np.array(pa), n=np.array(n_or_pts))
+                a=np.array(a), b=np.array(b), pa=np.array(pa), n=np.array(n_or_pts), fits_file=np.array(fits, dtype=object))
 
 
 def to_catalog(parsed, img_wcs, xsize, ysize, bandpass_integral, exptime, pupil_area=RUBIN_AREA, edge_pix=100,
                sort_mag=True, flip_g2=True):
     """Cull to the CCD (+- edge_pix, instcat.py:243-259), compute nominal fluxes and the profile
     geometry (instcat.py:498-527, :433-444, :569-573) -> the catalog dict build_object_table takes.
-    point, sersic2d, knots and streak objects reach the kernels; FITS-image objects are dropped with a count."""
+    point, sersic2d, knots, streak and FITS-image objects reach the kernels; a FITS-image object whose file is
+    missing is dropped with the count in n_dropped_unsupported."""
     from . import wcs as wcsmod
     vec = wcsmod.unit_vector(parsed["ra"], parsed["dec"]).T
     x, y = wcsmod.tansip_vec_to_pix(img_wcs, vec)
     on = (x >= 1 - edge_pix) & (x <= xsize + edge_pix) & (y >= 1 - edge_pix) & (y <= ysize + edge_pix)
     supported = np.isin(parsed["objtype"], (0, 1, 2, 3))
+    files = parsed.get("fits_file")
+    if files is not None:
+        supported = supported | ((parsed["objtype"] == 4) & np.array([bool(f) and os.path.isfile(f) for f in files]))
     keep = on & supported
     idx = np.flatnonzero(keep)
     if sort_mag:
@@ -122,12 +131,28 @@ def to_catalog(parsed, img_wcs, xsize, ysize, bandpass_integral, exptime, pupil_
     sersic_n = np.where(objtype == 1, n, 0.0)
     cat = dict(x=x[idx], y=y[idx], nominal_flux=flux, mag=parsed["magnorm"][idx], hlr=hlr, q=q,
                pa=parsed["pa"][idx] if flip_g2 else -parsed["pa"][idx], g1=g1, g2=g2, mu=mu,
-               kind=np.where(objtype == 0, 0, np.where(objtype == 2, 3, np.where(objtype == 3, 4,
-                             np.where(np.isclose(sersic_n, 1.0), 1, 2)))).astype(np.int32),
+               kind=np.where(objtype == 0, 0, np.where(objtype == 2, 3, np.where(objtype == 3, 4, np.where(objtype == 4, 5,
+                             np.where(np.isclose(sersic_n, 1.0), 1, 2))))).astype(np.int32),
                n_knots=np.where(objtype == 2, n, 0.0), box_length=np.where(objtype == 3, a, 0.0),
                box_width=np.where(objtype == 3, b, 0.0),
                sersic_n=sersic_n, obj_id=idx.astype(np.int64), object_id=parsed["id"][idx])
     # what obj.evaluateAtWavelength(effective wavelength) carries in the reference: photons per nm (stamp_utils.py:176-220)
     cat["sb_flux"] = flux / bandpass_integral
+    # FITS-image objects: every distinct file becomes one image profile (Scene.image_profiles)
+    is_img = objtype == 4
+    cat["images"], cat["image_index"] = [], np.zeros(len(idx), dtype=np.int64)
+    cat["image_scale"], cat["image_extent"] = np.where(is_img, a, 0.0), np.zeros(len(idx))
+    if is_img.any():
+        from . import fits_io
+        seen = {}
+        for k in np.flatnonzero(is_img):
+            fn = files[idx[k]]
+            if fn not in seen:
+                data = next(d for _, d in fits_io.read_fits(fn) if d is not None and d.ndim == 2)
+                seen[fn] = len(cat["images"])
+                cat["images"].append(np.asarray(data, dtype=np.float64))
+            cat["image_index"][k] = seen[fn]
+            shp = cat["images"][seen[fn]].shape
+            cat["image_extent"][k] = max(shp) * a[k]
     cat["n_dropped_unsupported"] = int(np.count_nonzero(on & ~supported))
     return cat

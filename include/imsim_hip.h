@@ -40,7 +40,7 @@ extern "C" {
 #define IMS_ERR_NO_DEVICE  -3
 #define IMS_ERR_UNSUPPORTED -4
 
-#define IMS_ABI_VERSION 3
+#define IMS_ABI_VERSION 4
 
 /* ---- object flags ---- */
 #define IMS_OBJ_FAINT   1   /* nominal_flux < max_flux_simple: no photon ops, no sensor (stamp.py:435-465,555-556) */
@@ -91,6 +91,7 @@ extern "C" {
 #define IMS_PROF_POINT (-1)
 #define IMS_PROF_BOX   (-2)
 #define IMS_PROF_KNOTS (-3)
+#define IMS_PROF_IMAGE (-4)
 typedef struct ims_object {
     int64_t obj_id;        /* RNG stream id = catalog object number (per-object rng, stamp.py:166) */
     int64_t phot_first;    /* index of the first photon of this call within the object's stream */
@@ -113,9 +114,23 @@ typedef struct ims_object {
     int32_t bf_state;      /* >=0: index into ims_sensor.bf_slots (private pixel boundaries); -1: static CCD boundaries */
     double  sed_wave;      /* wavelength [nm] when sed_table < 0 */
     double  atm_tan_x, atm_tan_y; /* tan of the field angle of the object from the boresight (theta of atm.makePSF, atmPSF.py:304) */
-    double  prof_aux;      /* IMS_PROF_BOX: width [arcsec]; IMS_PROF_KNOTS: number of knots */
+    double  prof_aux;      /* IMS_PROF_BOX: width [arcsec]; IMS_PROF_KNOTS: number of knots; IMS_PROF_IMAGE: image index
+                            * (prof_scale = arcsec per image pixel) */
     double  reserved[6];   /* pads the row to 256 bytes */
 } ims_object_t;
+
+/* Pixel images sampled as profiles (galsim.InterpolatedImage of a FITS stamp, imsim/instcat.py:552-561): image k has
+ * size[2k] x size[2k+1] pixels (row-major, first axis x) and a cumulative distribution of its non-negative pixel values
+ * cdf[offset[k] .. offset[k] + w*h] (first entry 0, last 1).  A photon picks pixel p by inverse CDF of one deviate, the
+ * remainder of that deviate places it uniformly along x inside the pixel and a second deviate along y (nearest-pixel
+ * shooting: the reference's Quintic interpolant is not reproduced). */
+typedef struct ims_image_tables {
+    int32_t n_images;
+    int32_t pad;
+    const int32_t* size;     /* [n_images][2] */
+    const int64_t* offset;   /* [n_images] */
+    const double*  cdf;
+} ims_image_tables_t;
 
 /* Tabulated circular profiles sampled by inverse CDF with uniform density inside each annulus:
  * r^2 = r2[i] + (u - cdf[i])/(cdf[i+1]-cdf[i]) * (r2[i+1]-r2[i]).  Table units are scaled per use. */
@@ -304,6 +319,7 @@ typedef struct ims_render_params {
     uint32_t pad_tag;
     const int32_t* seg_object;       /* device [n_segments] or NULL: object index of every segment; when given, a
                                       * workgroup finds its object with one load instead of a search in seg_prefix */
+    ims_image_tables_t images;       /* IMS_PROF_IMAGE profiles */
 } ims_render_params_t;
 
 /* ---- library ---- */

@@ -90,6 +90,18 @@ void orc_shoot_object(const ims_render_params_t* P, const ims_object_t* obj, int
             } else if (obj->prof_table == IMS_PROF_BOX) {          /* galsim.Box: uniform over length x width */
                 gu = (orc_w01(d0.w[1]) - 0.5) * obj->prof_scale;
                 gv = (orc_w01(d0.w[2]) - 0.5) * obj->prof_aux;
+            } else if (obj->prof_table == IMS_PROF_IMAGE) {        /* galsim.InterpolatedImage, nearest-pixel shooting */
+                const ims_image_tables_t* T = &P->images;
+                int kimg = (int)obj->prof_aux;
+                int w = T->size[2 * kimg], h = T->size[2 * kimg + 1];
+                const double* cdf = T->cdf + T->offset[kimg];
+                double u = orc_w01(d0.w[1]);
+                int lo = 0, hi = w * h;
+                while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (cdf[mid] <= u) lo = mid; else hi = mid; }
+                double c0 = cdf[lo], wd = cdf[lo + 1] - c0;
+                double f = (wd > 0.0) ? (u - c0) / wd : 0.0;
+                gu = ((((double)(lo % w) + f) - 0.5 * (double)w)) * obj->prof_scale;
+                gv = ((((double)(lo / w) + orc_w01(d0.w[2])) - 0.5 * (double)h)) * obj->prof_scale;
             } else {                                                /* galsim.RandomKnots */
                 uint32_t m = (uint32_t)(((uint64_t)d0.w[1] * (uint64_t)(uint32_t)obj->prof_aux) >> 32);
                 orc_words_t kd = orc_words(P->seed, obj->obj_id, (int64_t)m, ORC_SLOT_KNOT);

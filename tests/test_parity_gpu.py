@@ -545,15 +545,18 @@ def test_atm_psf_fft_matches_photon_shooting(torch_cuda):
 
 
 def test_knots_and_streak_profiles_are_bit_exact(torch_cuda):
-    """galsim.RandomKnots and galsim.Box (streak) objects (imsim/instcat.py:487-546): photon pool and image
-    equal the oracle's (whose distributions tests/test_profiles.py checks)."""
+    """galsim.RandomKnots, galsim.Box (streak) and FITS-stamp (InterpolatedImage) objects (imsim/instcat.py:487-561):
+    photon pool and image equal the oracle's (whose distributions tests/test_profiles.py checks)."""
     from imsim_amd import catalog, configs
     from imsim_amd.engine import Renderer
     from oracle import orc_loader
     n = 60
     rng = np.random.default_rng(8)
-    kind = np.where(np.arange(n) % 3 == 0, catalog.KIND_KNOTS, np.where(np.arange(n) % 3 == 1, catalog.KIND_STREAK, 1)).astype(np.int32)
-    cat = dict(x=rng.uniform(40, 216, n), y=rng.uniform(40, 216, n), mag=np.zeros(n), nominal_flux=np.full(n, 3000.0), kind=kind,
+    kind = np.where(np.arange(n) % 4 == 0, catalog.KIND_KNOTS, np.where(np.arange(n) % 4 == 1, catalog.KIND_STREAK,
+                    np.where(np.arange(n) % 4 == 2, catalog.KIND_IMAGE, 1))).astype(np.int32)
+    images = [rng.uniform(0, 1, size=(17, 23)) ** 3, np.clip(rng.normal(0.2, 1.0, size=(40, 31)), 0, None)]   # FITS-stamp profiles
+    cat = dict(image_index=rng.integers(0, 2, n), image_scale=rng.uniform(0.05, 0.3, n), image_extent=np.full(n, 8.0),
+               x=rng.uniform(40, 216, n), y=rng.uniform(40, 216, n), mag=np.zeros(n), nominal_flux=np.full(n, 3000.0), kind=kind,
                hlr=rng.uniform(0.2, 0.8, n), q=rng.uniform(0.3, 1.0, n), pa=rng.uniform(0, 180, n), obj_id=np.arange(n) + 100,
                n_knots=np.where(kind == catalog.KIND_KNOTS, rng.integers(1, 30, n), 0).astype(float),
                box_length=np.where(kind == catalog.KIND_STREAK, rng.uniform(2, 15, n), 0.0),
@@ -561,7 +564,9 @@ def test_knots_and_streak_profiles_are_bit_exact(torch_cuda):
     scene = configs.scene_c2(nx=256, ny=256)
     from imsim_amd import config
     scene.psf = [config.double_gaussian_psf(0.7)[0]]          # and the DoubleGaussianPSF mixture as the PSF
+    scene.image_profiles = images
     objects, _ = catalog.build_object_table(cat, rng.integers(500, 4000, n))
+    assert (objects["prof_table"] == -4).sum() == n // 4
     r = Renderer(scene)
     pool = r.shoot_photons(objects)
     r.accumulate(pool)

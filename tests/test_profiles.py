@@ -104,3 +104,69 @@ def test_double_gaussian_psf_is_a_two_component_mixture():
     k = q / p0
     np.testing.assert_allclose(tab, f * np.exp(-0.5 * (k * s1) ** 2) + (1 - f) * np.exp(-0.5 * (k * s2) ** 2))
     assert tab[0] == 1.0 and tab[-1] < 1e-12
+
+
+def test_fits_image_profile_follows_the_pixels(tmp_path):
+    """FITS-stamp objects (galsim.InterpolatedImage, imsim/instcat.py:552-561): photons land in the image's pixels in
+    proportion to their values, uniformly inside a pixel, on the image's own pixel scale, rotated by -theta."""
+    from imsim_amd import fits_io
+    rng = np.random.default_rng(5)
+    img = np.zeros((9, 12))                               # [ny][nx]
+    img[2:7, 3:9] = rng.uniform(0.5, 3.0, size=(5, 6))
+    img[0, 0] = -4.0                                      # negative pixels are empty
+    img[8, 11] = 2.0
+    scale, theta = 0.35, 25.0
+    n_obj, n_phot = 6, 60000
+    cat = _cat(catalog.KIND_IMAGE, n_obj, pa=np.full(n_obj, theta), image_scale=np.full(n_obj, scale),
+               image_index=np.zeros(n_obj, dtype=np.int64), image_extent=np.full(n_obj, 12 * scale))
+    scene = configs.scene_c2(nx=256, ny=256)
+    scene.psf = []
+    scene.image_profiles = [img]
+    objects, sizes = catalog.build_object_table(cat, np.full(n_obj, n_phot), stamp_size=128)
+    assert np.all(objects["prof_table"] == -4) and np.all(objects["prof_scale"] == scale)
+    pool = orc_loader.OracleScene(scene).shoot_pool(objects).to_host()
+    dx = (pool["x"].reshape(n_obj, n_phot) - objects["x0"][:, None]) * PIX
+    dy = (pool["y"].reshape(n_obj, n_phot) - objects["y0"][:, None]) * PIX
+    t = np.deg2rad(-theta)                                # undo obj.rotate(-theta)
+    u = (np.cos(t) * dx + np.sin(t) * dy) / scale + 6.0   # image pixel coordinates, pixel k covers [k, k+1)
+    v = (-np.sin(t) * dx + np.cos(t) * dy) / scale + 4.5
+    assert u.min() >= 0 and u.max() <= 12 and v.min() >= 0 and v.max() <= 9
+    hist, _, _ = np.histogram2d(v.ravel(), u.ravel(), bins=(9, 12), range=((0, 9), (0, 12)))
+    want = np.clip(img, 0, None) / np.clip(img, 0, None).sum() * u.size
+    assert hist[0, 0] == 0 and (hist[want == 0] == 0).all()
+    assert np.all(np.abs(hist - want)[want > 0] < 5 * np.sqrt(want[want > 0]))
+    fx, fy = u - np.floor(u), v - np.floor(v)             # uniform inside the pixel
+    assert abs(fx.mean() - 0.5) < 0.005 and abs(fy.mean() - 0.5) < 0.005 and abs(fx.var() - 1 / 12) < 0.002
+    # stamp size grows with the extent of the image on the sky
+    _, s1 = catalog.build_object_table(cat, np.full(n_obj, n_phot))
+    cat2 = dict(cat, image_scale=np.full(n_obj, 4 * scale), image_extent=np.full(n_obj, 48 * scale))
+    _, s2 = catalog.build_object_table(cat2, np.full(n_obj, n_phot))
+    assert np.all(s2 > s1) and np.all(s1 >= 2 * 12 * scale / PIX)
+    # through the instance-catalog reader: the file is found next to the catalog, .gz or not
+    import gzip
+    fits_io.write_fits(str(tmp_path / "stamp.fits"), [({}, img.astype(np.float32))])
+    (tmp_path / "stamp2.fits.gz").write_bytes(gzip.compress((tmp_path / "stamp.fits").read_bytes()))
+    from imsim_amd import instcat
+    lines = ["object 1 60.0 -38.0 20 sed.txt 0 0 0 0 0 0 stamp.fits 0.35 25.0 none none",
+             "object 2 60.0 -38.0 21 sed.txt 0 0 0 0 0 0 stamp2.fits.gz 0.2 0.0 none none",
+             "object 3 60.0 -38.0 21 sed.txt 0 0 0 0 0 0 missing.fits 0.2 0.0 none none",
+             "object 4 60.0 -38.0 21 sed.txt 0 0 0 0 0 0 point none none"]
+    (tmp_path / "cat.txt").write_text("\n".join(lines) + "\n")
+    parsed = instcat.parse_objects(str(tmp_path / "cat.txt"))
+    assert list(parsed["objtype"]) == [4, 4, 4, 0] and parsed["fits_file"][0].endswith("stamp.fits")
+    wcs = configs.scene_c3(nx=256, ny=256, sensor=False).optics.img_wcs
+    # put the objects on the CCD by pointing them at the WCS centre
+    ra, dec = _wcs_centre(wcs)
+    parsed["ra"][:], parsed["dec"][:] = ra, dec
+    c = instcat.to_catalog(parsed, wcs, 256, 256, 100.0, 30.0, sort_mag=False)
+    assert list(c["kind"]) == [catalog.KIND_IMAGE, catalog.KIND_IMAGE, 0] and c["n_dropped_unsupported"] == 1
+    assert len(c["images"]) == 2 and np.allclose(c["images"][0], img) and list(c["image_index"][:2]) == [0, 1]
+    assert list(c["image_scale"][:2]) == [0.35, 0.2] and c["image_extent"][0] == 12 * 0.35
+
+
+def _wcs_centre(w):
+    """(ra, dec) of the pixel (128, 128) of a test WCS"""
+    from imsim_amd import wcs as wcsmod
+    vec = wcsmod.tansip_pix_to_vec(w, np.array([128.0]), np.array([128.0]))
+    vec = np.asarray(vec).reshape(3)
+    return float(np.arctan2(vec[1], vec[0])), float(np.arcsin(vec[2] / np.linalg.norm(vec)))

@@ -136,7 +136,7 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, scene, objects, args.cpu_sample)
+        out["cpu_baseline"] = cpu_baseline(cfg, scene, objects, args.cpu_sample, device)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
@@ -155,8 +155,12 @@ def hbm_traffic(config, kernel, world):
     return float(entry["hbm_bytes_per_launch"]) if entry else None
 
 
-def cpu_baseline(cfg, scene, objects, n_sample):
-    """The oracle ("port") timed on one host core over a bounded sample of the same workload."""
+def cpu_baseline(cfg, scene, objects, n_sample, device):
+    """The oracle ("port") timed on one host core over a bounded sample of the same workload; the same sample is then
+    rendered by a fresh GPU renderer and the two CCD images are compared pixel by pixel (parity check
+    inside the measurement run)."""
+    import torch
+    from imsim_amd.engine import Renderer
     from oracle import orc_loader
     n_sample = n_sample or cfg["cpu_sample"]
     rng = np.random.default_rng(99)
@@ -166,7 +170,15 @@ def cpu_baseline(cfg, scene, objects, n_sample):
     t0 = time.perf_counter()
     cfg["cpu_step"](orc, sample)
     dt = time.perf_counter() - t0
-    return {"value": len(sample) / dt, "unit": "objects/s", "cores": 1, "kind": "port",
+    gpu = Renderer(cfg["cpu_scene"](scene), device)
+    cfg["make_step"](gpu, sample)()
+    torch.cuda.synchronize()
+    got, want = gpu.image_numpy(), orc.image
+    parity = {"checked": "float32 CCD image of the CPU sample, GPU vs oracle, every pixel",
+              "pixels": int(want.size), "nonzero_pixels": int(np.count_nonzero(want)),
+              "bit_identical": bool(np.array_equal(got.view(np.uint32), np.asarray(want, dtype=np.float32).view(np.uint32)))}
+    del gpu
+    return {"parity": parity, "value": len(sample) / dt, "unit": "objects/s", "cores": 1, "kind": "port",
             "sample": f"{len(sample)} objects drawn at random from the same catalog "
                       f"({int(sample['n_phot'].sum())} photons, {dt:.1f} s)",
             "photons_per_s": float(sample["n_phot"].sum()) / dt,

@@ -122,7 +122,7 @@ def to_catalog(parsed, img_wcs, xsize, ysize, bandpass_integral, exptime, pupil_
     n = parsed["n"][idx]
     a, b = parsed["a"][idx], parsed["b"][idx]
     hlr = np.sqrt(np.maximum(a * b, 0.0))                                   # instcat.py:517
-    q = np.where(a > 0, b / np.where(a > 0, a, 1.0), 1.0)
+    q = np.where((a > 0) & (objtype != 4), b / np.where(a > 0, a, 1.0), 1.0)      # FITS stamps carry (scale, -, theta) there
     g2_sign = -1.0 if flip_g2 else 1.0
     kappa = parsed["kappa"][idx]
     g1 = parsed["gamma1"][idx] / (1.0 - kappa)

@@ -846,3 +846,38 @@ def test_config_readout_writes_eimage_and_raw_file(torch_cuda, tmp_path):
     assert abs(back.sum() / bled.sum() - 1) < 0.01
     with pytest.raises(GalSimConfigError):
         _process(**{"image.nobjects": 5, "output.readout": {"no_such_parameter": 1}})
+
+
+def test_config_fits_stamp_object_end_to_end(torch_cuda, tmp_path):
+    """An instance catalog with a FITS-stamp object (imsim/instcat.py:552-561) through config.Process: the stamp's
+    shape shows up on the CCD at the object's position, rotated by -theta, on the stamp's own pixel scale."""
+    from imsim_amd import fits_io
+    here = os.path.dirname(os.path.abspath(__file__))
+    header = [l for l in open(os.path.join(here, "golden", "example_instcat_subset.txt")) if not l.startswith("object")]
+    stamp = np.zeros((20, 20), dtype=np.float32)
+    stamp[2:18, 9:11] = 1.0                               # a bar along the stamp's y axis
+    fits_io.write_fits(str(tmp_path / "bar.fits"), [({}, stamp)])
+    lines = header + ["object 1 60.49045502638662697 -38.16437495898705379 17.0 starSED/x.gz 0 0 0 0 0 0 bar.fits 0.4 0.0 none none\n",
+                      "object 2 60.52 -38.18 17.0 starSED/x.gz 0 0 0 0 0 0 bar.fits 0.4 90.0 none none\n",
+                      "object 3 60.46 -38.15 22.0 starSED/x.gz 0 0 0 0 0 0 point none none\n"]
+    (tmp_path / "cat.txt").write_text("".join(lines))
+    res = _process(**{"input.instance_catalog.file_name": str(tmp_path / "cat.txt"), "stamp.draw_method": "phot",
+                      "image.sensor": "", "stamp.photon_ops": [], "input.instance_catalog.sort_mag": False})
+    img, truth = res.images[0].astype(np.float64), res.truth[0]
+    assert list(truth["mode"][:2]) == ["phot", "phot"] and truth["phot_flux"][0] > 1e5
+    angles = []
+    for k in (0, 1):
+        x0, y0 = int(round(truth["x"][k])) - 1, int(round(truth["y"][k])) - 1
+        cut = img[y0 - 40:y0 + 41, x0 - 40:x0 + 41]
+        assert cut.sum() > 0.9 * truth["realized_flux"][k] > 0
+        yy, xx = np.mgrid[-40:41, -40:41]
+        w = cut / cut.sum()
+        mx, my = (w * xx).sum(), (w * yy).sum()
+        cxx, cyy, cxy = (w * (xx - mx) ** 2).sum(), (w * (yy - my) ** 2).sum(), (w * (xx - mx) * (yy - my)).sum()
+        lam = np.linalg.eigvalsh(np.array([[cxx, cxy], [cxy, cyy]]))
+        # the bar is 16 x 0.4" = 32 pixels long and 2 x 0.4" = 4 pixels wide (plus the PSF)
+        assert abs(np.sqrt(lam[1]) - 32 / np.sqrt(12)) < 1.5 and np.sqrt(lam[0]) < 4.0
+        angles.append(0.5 * np.degrees(np.arctan2(2 * cxy, cxx - cyy)))
+    # the stamp lives on the sky (the WCS turns it on the CCD); theta = 90 turns the second one by a right angle
+    d = abs(angles[0] - angles[1]) % 180.0
+    assert abs(d - 90.0) < 3.0, angles

@@ -120,8 +120,7 @@ def test_camera_bias_levels(tmp_path):
 def _toy_readout(xtalk=True, vendor="E2V", **kw):
     ccd = small_ccd(vendor=vendor, xtalk=xtalk)
     ny, nx = ccd.bounds.numpyShape()
-    eimg = readout.EImage(None, readout.eimage_header(list(camera.Camera("LsstComCamSim"))[0] if False else
-                                                      ("R22_S11" if vendor == "E2V" else "R01_S00"), 30.0))
+    eimg = readout.EImage(None, readout.eimage_header("R22_S11" if vendor == "E2V" else "R01_S00", 30.0))
     ro = readout.CcdReadout(eimg, camera_obj={eimg.header["DET_NAME"]: ccd}, **kw)
     return ccd, ro, nx, ny
 

@@ -342,6 +342,15 @@ def _process_flat(cfg, ev, image, res, device, data_dir):
     res.images.append(img.to(renderer.torch.float32).cpu().numpy())
     res.det_names.append(str(image.get("det_name", "flat")))
     res.truth.append({"counts_per_pixel": builder.counts_per_pixel, "niter": builder.iterations()[0]})
+    out = cfg.get("output", {})
+    if "file_name" in out or "readout" in out:
+        # flats go through the same e-image / readout outputs, without opsim data (tests/test_readout.py:124-160 of the
+        # reference): the header falls back to the defaults of imsim/ccd.py:138-204
+        header_vals = dict(out.get("header") or {})
+        header_vals.setdefault("image_type", "FLAT")
+        out = dict(out, header=header_vals)
+        det_name = str(ev.value(image.get("det_name", "R22_S11")))
+        _process_outputs(out, ev, res, img.to(renderer.torch.float64).contiguous(), det_name, cfg.get("_opsim_data", {}), seed)
     return res
 
 
@@ -350,7 +359,7 @@ READOUT_OPT = {"camera": str, "readout_time": float, "dark_current": float, "bia
 READOUT_IGNORE = ("file_name", "dir", "hdu", "filter", "added_keywords")
 
 
-def _process_outputs(out, ev, res, renderer, det_name, meta, seed):
+def _process_outputs(out, ev, res, image_dev, det_name, meta, seed):
     """`output` of type LSST_CCD (imsim/ccd.py:92-204) and its `readout` extra output (imsim/readout.py:535-602):
     the e-image gets the header the raw file is built from; with `output.file_name` it is written as FITS; with
     `output.readout` the CCD is read out on the GPU into 16 raw segments (kept in res.raw, written with
@@ -361,7 +370,7 @@ def _process_outputs(out, ev, res, renderer, det_name, meta, seed):
     opsim = {k: v for k, v in meta.items() if v is not None}
     opsim.setdefault("rotSkyPos", meta.get("rotSkyPos") or 0.0)
     hdr = readout.eimage_header(det_name, exptime, opsim_data=opsim, header_vals=header_vals, camera=camera_name)
-    eimg = readout.EImage(renderer.image, hdr)
+    eimg = readout.EImage(image_dev, hdr)
     res.eimages.append(eimg)
     out_dir = ev.value(out["dir"]) if "dir" in out else ""
     if "file_name" in out:
@@ -553,5 +562,5 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
         res.images.append(renderer.image_numpy())
         res.truth.append(truth)
         res.det_names.append(det_name)
-        _process_outputs(out, ev, res, renderer, det_name, meta, seed)
+        _process_outputs(out, ev, res, renderer.image, det_name, meta, seed)
     return res

@@ -881,3 +881,25 @@ def test_config_fits_stamp_object_end_to_end(torch_cuda, tmp_path):
     # the stamp lives on the sky (the WCS turns it on the CCD); theta = 90 turns the second one by a right angle
     d = abs(angles[0] - angles[1]) % 180.0
     assert abs(d - 90.0) < 3.0, angles
+
+
+def test_config_flat_readout_without_opsim(torch_cuda, tmp_path):
+    """A flat read out without any opsim data (tests/test_readout.py:124-160 of the reference, test_no_opsim): the
+    header falls back to its defaults, the segments carry counts / gain + bias."""
+    from imsim_amd import config, camera, fits_io
+    res = config.Process({"image": {"type": "LSST_Flat", "random_seed": 42, "det_name": "R22_S11", "counts_per_pixel": 1000,
+                                    "max_counts_per_iter": 1000, "sensor": ""},
+                          "output": {"dir": str(tmp_path), "file_name": "flat_e.fits",
+                                     "readout": {"file_name": "flat_amp.fits", "dark_current": 0.0, "scti": 0.0, "pcti": 0.0,
+                                                 "read_noise": 0.0, "bias_level": 500.0}}})
+    assert res.images[0].shape == (4004, 4096) and abs(res.images[0].mean() - 1000.0) < 0.1
+    raw = fits_io.read_fits(res.files[1])
+    ph = raw[0][0]
+    assert ph["IMGTYPE"] == "FLAT" and ph["TRACKSYS"] == "LOCAL" and ph["MJD"] == 51444.0 and ph["RUNNUM"] == -999
+    ccd = camera.Camera("LsstCamSim")["R22_S11"]
+    for k, amp in enumerate(ccd.values()):
+        r = amp.raw_data_bounds
+        sec = raw[k + 1][1][r.ymin - 1:r.ymax, r.xmin - 1:r.xmax].astype(np.float64)
+        xt = 0.0 if ccd.xtalk is None else sum(ccd.xtalk[k][j] / list(ccd.values())[j].gain for j in range(16)) * 1000.0
+        assert abs(sec.mean() - (500.0 + 1000.0 / amp.gain + xt - 0.5)) < 0.2, (k, sec.mean())
+        assert (raw[k + 1][1][:, :r.xmin - 1] == 500).all()            # prescan: bias only

@@ -144,7 +144,7 @@ class Sensor(C.Structure):
                 ("abs_len", c_vp), ("tr_table", c_vp), ("tr_table2", c_vp), ("distortions", c_vp), ("emptypoly", c_vp),
                 ("n_bf_slots", c_i32), ("pad2", c_i32), ("bf_slots", c_vp),
                 ("bf_boundary", c_vp), ("bf_bounds", c_vp), ("bf_delta", c_vp),
-                ("bf_tile_charge", c_vp), ("bf_tile_changed", c_vp)]
+                ("bf_tile_charge", c_vp), ("bf_tile_changed", c_vp), ("pristine_margin", c_d)]
 
 
 class Photons(C.Structure):

@@ -735,7 +735,17 @@ IMS_DEV bool land(const ims_render_params_t& P, const ims_object_t& o, int64_t k
     if (ix < o.stamp_xmin || ix > o.stamp_xmax || iy < o.stamp_ymin || iy > o.stamp_ymax) return false;
     const double x = x0 - (double)ix + 0.5, y = y0 - (double)iy + 0.5;
     bool off_edge = false;
-    bool found = inside_pixel(s, sl, ix, iy, x, y, zconv, true, off_edge);
+    bool found;
+    {
+        // pristine slot 0 (ims_sensor_t.pristine_margin): no vertex of the pixel polygon is further than m from its
+        // nominal place, so a point more than m from every edge passes the inner-bounds test -- known without the load
+        const double m = s.pristine_margin;
+        const int pi = ix - sl.xmin, pj = iy - sl.ymin;
+        if (o.bf_state == 0 && m >= 0.0 && pi >= 0 && pi < sl.nx && pj >= 0 && pj < sl.ny && x > m && x < 1.0 - m && y > m && y < 1.0 - m)
+            found = true;
+        else
+            found = inside_pixel(s, sl, ix, iy, x, y, zconv, true, off_edge);
+    }
     if (!found && off_edge) return false;
     int step = 0;
     if (!found) {

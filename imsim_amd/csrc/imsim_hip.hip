@@ -787,6 +787,8 @@ __global__ __launch_bounds__(256) void k_flat_add(const double* __restrict__ are
     }
 }
 
+__global__ void k_clear_pristine(ims_sensor_t* sp) { sp->pristine_margin = -1.0; }
+
 __global__ __launch_bounds__(256) void k_zero_delta(const ims_sensor_t* __restrict__ sp, int64_t cell_begin, int64_t cell_count)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1303,6 +1305,8 @@ int ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sens
     int rc = slot_range_cells(sensor_host, first_slot, n_slots, &begin, &count);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (first_slot == 0)                      // slot 0 leaves its pristine state: photons must consult the boundaries again
+        hipLaunchKernelGGL(k_clear_pristine, dim3(1), dim3(1), 0, st, const_cast<ims_sensor_t*>(sensor_dev));
     const unsigned g = (unsigned)((count + 255) / 256);
     const int nV = sensor_host ? sensor_host->num_vertices : 0;
     const int q = sensor_host ? sensor_host->qdist : 0;

@@ -180,6 +180,19 @@ class _LibDerive:
         _abi.check(self.lib.ims_fill_derived_medium(int(kind), c), "ims_fill_derived_medium")
 
 
+def treering_displacement_bound(ss):
+    """Upper bound of |tree-ring shift| over the CCD [pixels]: on every table interval the interpolant is the chord plus
+    the cubic-spline term ((a^3 - a) m0 + (b^3 - b) m1) h^2 / 6 with |a^3 - a| <= 2 / (3 sqrt 3); a few ulp on top."""
+    if ss.tr_table is None:
+        return 0.0
+    v = np.abs(np.asarray(ss.tr_table, dtype=np.float64))
+    bound = np.maximum(v[:-1], v[1:])
+    if ss.tr_table2 is not None:
+        m = np.abs(np.asarray(ss.tr_table2, dtype=np.float64))
+        bound = bound + 0.3849002 * (m[:-1] + m[1:]) * float(ss.tr_dr) ** 2 / 6.0
+    return float(bound.max()) * (1.0 + 1e-9) + 1e-12
+
+
 def image_profile_cdf(img):
     """Cumulative distribution over the pixels of an image profile (row-major, negative pixels count as empty):
     w*h + 1 knots from 0 to 1 (ims_image_tables_t.cdf)."""
@@ -300,6 +313,11 @@ class BoundScene:
         self.static_cells = ss.total_cells()
         self.slot_capacity = max(len(slots), ss.max_slots)
         S.n_bf_slots = len(slots)
+        # LSST_Image mode never updates slot 0 (objects only distort their private regions): a rigorous bound of the
+        # tree-ring displacement lets photons far from every pixel edge skip the boundary state (ims_sensor_t.pristine_margin)
+        S.pristine_margin = -1.0
+        if len(slots) > 0 and not self.scene.track_static_delta:
+            S.pristine_margin = treering_displacement_bound(ss)
         cells = self.static_cells + int(ss.scratch_cells)
         npo = ss.owned_points()
         slots_host = np.zeros(self.slot_capacity, dtype=BFSLOT_DTYPE)

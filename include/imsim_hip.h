@@ -40,7 +40,7 @@ extern "C" {
 #define IMS_ERR_NO_DEVICE  -3
 #define IMS_ERR_UNSUPPORTED -4
 
-#define IMS_ABI_VERSION 4
+#define IMS_ABI_VERSION 5
 
 /* ---- object flags ---- */
 #define IMS_OBJ_FAINT   1   /* nominal_flux < max_flux_simple: no photon ops, no sensor (stamp.py:435-465,555-556) */
@@ -283,6 +283,11 @@ typedef struct ims_sensor {
      * whose boundary points moved.  Stale tags only cost work, never correctness. */
     unsigned char* bf_tile_charge;
     unsigned char* bf_tile_changed;
+    /* >= 0: slot 0 is in its pristine (tree-ring only) state and no boundary point of it is displaced by more than this
+     * [pixels]: a photon of a slot-0 object that converts further than the margin from every pixel edge is inside its
+     * nominal pixel without looking at the boundary state.  The host derives it from the tree-ring table
+     * (rigorous bound of the spline); ims_sensor_update_distortions on slot 0 sets it to -1 (= off) on the device. */
+    double pristine_margin;
 } ims_sensor_t;
 
 /* A photon pool in device memory, SoA, the fields of galsim.PhotonArray (imsim/photon_ops.py:81). */

@@ -237,3 +237,20 @@ def test_readout_needs_the_gpu():
     ro.eimage.array = torch.zeros((ny, nx), dtype=torch.float64)
     with pytest.raises(_abi.ImsimHipError):
         ro.build_amp_images(1)
+
+
+def test_treering_displacement_bound_is_rigorous():
+    """engine.treering_displacement_bound (ims_sensor_t.pristine_margin): no point of the spline the kernels evaluate
+    (chord + cubic term, imsim_hip.hip treering_shift) exceeds it, and it is not wastefully loose."""
+    from imsim_amd import configs
+    from imsim_amd.engine import treering_displacement_bound
+    ss = configs.silicon_setup(512, 512)
+    bound = treering_displacement_bound(ss)
+    v, m, h = np.asarray(ss.tr_table), np.asarray(ss.tr_table2), float(ss.tr_dr)
+    b = np.linspace(0.0, 1.0, 41)[None, :]
+    a = 1.0 - b
+    f = a * v[:-1, None] + b * v[1:, None] + ((a ** 3 - a) * m[:-1, None] + (b ** 3 - b) * m[1:, None]) * h * h / 6.0
+    assert np.abs(f).max() <= bound <= 1.2 * np.abs(f).max() + 1e-9
+    assert 0 < bound < 0.1                                   # tree rings move boundaries by a few per cent of a pixel
+    none = configs.silicon_setup(512, 512, tree_rings=False)
+    assert treering_displacement_bound(none) == 0.0

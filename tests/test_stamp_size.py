@@ -54,3 +54,19 @@ def test_huge_stamps_fall_back_to_three_times_the_limit_and_nmax():
     jac = np.tile(_jac()[0], (1, 1))
     s = catalog.gal_stamp_size(kind, hlr, np.ones(1), jac=jac, nominal_flux=np.array([1.0e10]))
     assert s[0] == catalog.NMAX
+
+
+def test_star_stamp_sizes_reproduce_the_reference_regression_values():
+    """tests/test_stamp.py:264-312 of the reference builds stamps for stars of visit 449053 (tests/data/small_opsim_9683.db:
+    airmass 1.12386549163403, seeingFwhm500 0.663846738172267, r band) and pins their sizes: 40 x 40 for the stars of
+    2 443 and 28 124 photons, 106 x 106 for 292 627 photons, the full 4096 for 5.3e8 photons.  The sky variance of that
+    visit comes from the Rubin sky model (not available here); for every plausible value (450..700 e-/pixel at sky
+    brightness 21.09 mag/arcsec^2) the restated get_star_stamp_size gives exactly those sizes."""
+    airmass, raw_seeing = 1.12386549163403, 0.663846738172267
+    flux = np.array([2443.0, 28124.0, 292627.0, 531711520.0])
+    for noise_var in (450.0, 500.0, 550.0, 600.0, 650.0, 700.0):
+        sizes = catalog.star_stamp_size(flux, noise_var, airmass, raw_seeing, "r")
+        assert list(sizes) == [40, 40, 106, 4096], (noise_var, sizes)
+    # the folding threshold is rounded down to whole e-folds (stamp_utils.py:137-139): the size is a step function of flux
+    steps = catalog.star_stamp_size(np.geomspace(1e5, 1e7, 60), 550.0, airmass, raw_seeing, "r")
+    assert len(np.unique(steps)) <= 6 and np.all(np.diff(steps) >= 0)

@@ -53,8 +53,31 @@ def read_header(path):
     if "filter" in out:
         meta["band"] = BANDS[out["filter"]]
     if meta.get("altitude") is not None:
-        meta["airmass"] = 1.0 / math.sin(math.radians(meta["altitude"]))
+        meta["airmass"] = get_airmass(meta["altitude"])
     return meta
+
+
+BAND_WAVELENGTH = dict(u=365.49, g=480.03, r=622.20, i=754.06, z=868.21, y=991.66)
+
+
+def get_airmass(altitude):
+    """Airmass from the altitude [deg], equation 3 of Krisciunas & Schaefer 1991 (OpsimDataLoader.getAirmass,
+    imsim/opsim_data.py:242-260)."""
+    alt = math.radians(altitude)
+    return 1.0 / math.sqrt(1.0 - 0.96 * math.sin(0.5 * math.pi - alt) ** 2)
+
+
+def fwhm_eff(raw_seeing, band, altitude):
+    """Effective FWHM of a single Gaussian describing the PSF [arcsec] (OpsimDataLoader.FWHMeff, opsim_data.py:262-300)."""
+    x = get_airmass(altitude)
+    fwhm_atm = raw_seeing * (BAND_WAVELENGTH[band] / 500.0) ** (-0.3) * x ** 0.6
+    fwhm_sys = 0.4 * x ** 0.6
+    return 1.16 * math.sqrt(fwhm_sys ** 2 + 1.04 * fwhm_atm ** 2)
+
+
+def fwhm_geom(raw_seeing, band, altitude):
+    """Geometric size of the PSF [arcsec] (OpsimDataLoader.FWHMgeom, opsim_data.py:303-330: 0.822 FWHMeff + 0.052)."""
+    return 0.822 * fwhm_eff(raw_seeing, band, altitude) + 0.052
 
 
 def parse_objects(path, max_objects=None):

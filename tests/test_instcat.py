@@ -69,3 +69,12 @@ def test_knots_and_streak_lines_reach_the_object_table(tmp_path):
     j = objects["jac"][0]
     assert abs(j[0] * j[3] - j[1] * j[2] - cat["mu"][0]) < 1e-12          # det = magnification
     assert sizes[1] >= 2 * 30.0 / 0.2
+
+
+def test_airmass_and_fwhm_known_answers():
+    """tests/test_FWHMgeom.py:20-60 of the reference: airmass(52.542 deg) = 1.24522984; FWHMeff / FWHMgeom of visit
+    197356 (rawSeeing 0.5059960, r band, altitude 52.54199126195116065) within 0.03 of 0.8300650 / 0.7343130."""
+    from imsim_amd import instcat
+    assert abs(instcat.get_airmass(52.542) - 1.24522984) < 5e-8
+    assert abs(instcat.fwhm_eff(0.5059960, "r", 52.54199126195116065) - 0.8300650) < 0.03
+    assert abs(instcat.fwhm_geom(0.5059960, "r", 52.54199126195116065) - 0.7343130) < 0.03

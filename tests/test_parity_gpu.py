@@ -840,7 +840,8 @@ def test_config_readout_writes_eimage_and_raw_file(torch_cuda, tmp_path):
         back[b.ymin - 1:b.ymax, b.xmin - 1:b.xmax] = sec * amp.gain
     # the readout works on the e-image after the bleed trails (the catalog's brightest star is far above full well)
     bled = res.eimages[0].array.cpu().numpy()
-    assert ed.max() > ccd.full_well and bled.max() == ccd.full_well and bled.sum() <= ed.astype(np.float64).sum()
+    # (the e-image file is float32: its brightest pixels, > 2^24 e-, are rounded by a few electrons)
+    assert ed.max() > ccd.full_well and bled.max() == ccd.full_well and bled.sum() <= ed.astype(np.float64).sum() + 64
     # no noise, no CTI, no dark current: only crosstalk (<= 4e-4 of the brightest neighbour) and the ADU truncation remain
     assert np.abs(back - bled).max() <= 2.0 + 1e-3 * bled.max()
     assert abs(back.sum() / bled.sum() - 1) < 0.01

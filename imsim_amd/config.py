@@ -167,8 +167,9 @@ RegisterValueType("Degrees", lambda v, ev: math.radians(float(ev.value(v["theta"
 RegisterValueType("Radians", lambda v, ev: float(ev.value(v["theta"])))
 RegisterValueType("RADec", lambda v, ev: (ev.value(v["ra"]), ev.value(v["dec"])))
 RegisterValueType("Eval", _eval_type)
-RegisterValueType("FormattedStr", lambda v, ev: v["format"] % tuple(ev.value(i) for i in v["items"]))
-RegisterValueType("Sequence", lambda v, ev: int(ev.value(v.get("first", 0))))
+RegisterValueType("FormattedStr", lambda v, ev: str(ev.value(v["format"])) % tuple(ev.value(i) for i in v["items"]))
+RegisterValueType("Sequence", lambda v, ev: int(ev.vars["_sequence_index"]) if ev.vars.get("_sequence_index") is not None
+                  else int(ev.value(v.get("first", 0))))
 RegisterValueType("TreeRingCenter", lambda v, ev: ev.base["_tree_rings"].get_center(ev.value(v["det_name"])))
 RegisterValueType("TreeRingFunc", lambda v, ev: ev.base["_tree_rings"].get_func(ev.value(v["det_name"])))
 for _name in ("InstCatWorldPos", "SkyCatWorldPos", "SkyLevel", "RowData", "Random", "XY"):
@@ -354,6 +355,30 @@ def _process_flat(cfg, ev, image, res, device, data_dir):
     return res
 
 
+# `eval_variables.dcamera_info` of the reference's templates loads data/<camera>_info.yaml (config/imsim-config.yaml:56-58):
+# the names of the per-camera data files and the number of detectors
+CAMERA_INFO = {
+    "LsstCamSim": {"tree_rings_file_name": "tree_ring_parameters_2026-04-02.txt", "vignetting_file_name": "LSSTCam_vignetting_data.json",
+                   "telescope_format": "LSST_%s.yaml", "bias_levels_file": "LSSTCam_bias_levels_run_13421.json",
+                   "camera_name": "LsstCamSim", "ndets": 189},
+    "LsstComCamSim": {"tree_rings_file_name": "tree_ring_parameters_2026-04-02.txt", "vignetting_file_name": "LSSTComCamSim_vignetting_data.json",
+                      "telescope_format": "ComCam_%s.yaml", "bias_levels_file": "LSSTComCamSim_bias_levels.json",
+                      "camera_name": "LsstComCamSim", "ndets": 9},
+}
+
+
+def camera_info(camera, data_dir=None):
+    """<data_dir>/<camera>_info.yaml when it is there (an imSim data directory), else the built-in table."""
+    if data_dir:
+        path = os.path.join(data_dir, camera + "_info.yaml")
+        if os.path.isfile(path):
+            with open(path) as fobj:
+                return yaml.safe_load(fobj)
+    if camera not in CAMERA_INFO:
+        raise GalSimConfigError(f"no camera info for {camera}")
+    return dict(CAMERA_INFO[camera])
+
+
 READOUT_OPT = {"camera": str, "readout_time": float, "dark_current": float, "bias_level": float, "scti": float, "pcti": float,
                "full_well": float, "read_noise": float, "bias_levels_file": str}
 READOUT_IGNORE = ("file_name", "dir", "hdu", "filter", "added_keywords")
@@ -387,6 +412,11 @@ def _process_outputs(out, ev, res, image_dev, det_name, meta, seed):
     kwargs = {k: t(ev.value(ro_cfg[k])) for k, t in READOUT_OPT.items() if k in ro_cfg}
     if "added_keywords" in ro_cfg:
         kwargs["added_keywords"] = {k: str(ev.value(v)) for k, v in ro_cfg["added_keywords"].items()}
+    if "bias_levels_file" in kwargs:
+        cand = [kwargs["bias_levels_file"], os.path.join(configs.DATA_DIR, kwargs["bias_levels_file"])]
+        if not any(os.path.isfile(c) for c in cand):
+            res.ignored.append(f"output.readout.bias_levels_file ({kwargs['bias_levels_file']} not present: bias_level is used)")
+            del kwargs["bias_levels_file"]
     ccd_readout = readout.CcdReadout(eimg, None, **kwargs)
     hdus = ccd_readout.prepare_hdus(seed)
     res.raw.append(hdus)
@@ -426,6 +456,7 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
         if k in out:
             res.ignored.append(f"output.{k}")
     ev.vars["det_name"] = None
+    ev.vars["camera_info"] = camera_info(str(ev.value(out.get("camera", "LsstCamSim"))), data_dir)
     ev.load_eval_variables({k: v for k, v in cfg.get("eval_variables", {}).items() if k not in ("dcamera_info",)})
     if "tree_rings" in inp:
         fn = ev.value(inp["tree_rings"].get("file_name", "tree_ring_parameters_2026-04-02.txt"))
@@ -453,6 +484,7 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
     for det in parallel.shard_ccds(range(first, first + nfiles), rank, world):
         det_name = det_name_of(det)
         ev.vars["det_name"] = det_name
+        ev.vars["_sequence_index"] = det                   # what `@output.det_num` (type Sequence) yields for this CCD
         builder = valid_image_types[itype]()
         img_cfg = {k: ev.value(v) if k in ("det_name", "nbatch", "nsubbatch", "nbatch_fft", "size", "xsize", "ysize", "nobjects") else v
                    for k, v in image.items()}

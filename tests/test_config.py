@@ -24,7 +24,7 @@ def test_template_chain_and_dotted_overrides():
     assert cfg["input"]["instance_catalog"]["sort_mag"] is False                            # dotted key in the file
     assert cfg["input"]["opsim_data"]["file_name"] == "@input.instance_catalog.file_name"
     assert cfg["image"]["nobjects"] == 5 and cfg["stamp"]["draw_method"] == "fft" and cfg["image"]["sensor"] == ""
-    assert cfg["output"]["det_num"]["first"] == 94 and cfg["output"]["det_num"]["nitems"] == 189
+    assert cfg["output"]["det_num"]["first"] == 94 and cfg["output"]["det_num"]["nitems"] == "$camera_info['ndets']"
 
 
 def test_registered_plugin_names():
@@ -84,3 +84,24 @@ def test_image_setup_parameter_surface():
         b.setup({"det_name": "R22_S11", "no_such_key": 1})
     with pytest.raises(photon_pooling.GalSimConfigValueError):
         lsst_image.LSST_PhotonPoolingImageBuilder().setup({"det_name": "R22_S11"}, "LSST_Silicon")
+
+
+def test_camera_info_and_sequence_values(tmp_path):
+    """`eval_variables.dcamera_info` (config/imsim-config.yaml:56-58) and the per-CCD value of `output.det_num`
+    (type Sequence) inside file-name formats (config/imsim-config.yaml:335-352)."""
+    from imsim_amd import config
+    info = config.camera_info("LsstCamSim")
+    assert info["ndets"] == 189 and info["camera_name"] == "LsstCamSim" and info["telescope_format"] % "r" == "LSST_r.yaml"
+    assert config.camera_info("LsstComCamSim")["ndets"] == 9
+    (tmp_path / "LsstCamSim_info.yaml").write_text("ndets: 3\ncamera_name: LsstCamSim\ntree_rings_file_name: mine.txt\n")
+    assert config.camera_info("LsstCamSim", str(tmp_path))["tree_rings_file_name"] == "mine.txt"       # an imSim data dir wins
+    cfg = {"output": {"camera": "LsstCamSim", "det_num": {"type": "Sequence", "nitems": "$camera_info['ndets']"},
+                      "file_name": {"type": "FormattedStr", "format": "eimage_%s-det%03d.fits",
+                                    "items": ["$det_name", "@output.det_num"]}}}
+    ev = config.Evaluator(cfg)
+    ev.vars["camera_info"] = info
+    assert ev.value(cfg["output"]["det_num"]["nitems"]) == 189
+    ev.vars["det_name"], ev.vars["_sequence_index"] = "R22_S11", 94
+    assert ev.value(cfg["output"]["file_name"]) == "eimage_R22_S11-det094.fits"
+    ev.vars["_sequence_index"] = None
+    assert ev.value(cfg["output"]["det_num"]) == 0

@@ -51,10 +51,20 @@ def _set_dotted(cfg, key, value):
     parts = key.split(".")
     d = cfg
     for p in parts[:-1]:
-        if p not in d or not isinstance(d[p], dict):
+        if isinstance(d, list):                    # `psf.items.0.fwhm`: an index into a list
+            d = d[int(p)]
+            continue
+        if p not in d or not isinstance(d[p], (dict, list)):
             d[p] = {}
         d = d[p]
-    d[parts[-1]] = value
+    if isinstance(d, list):                        # `psf.items.0: {...}` replaces (or appends) a list element
+        k = int(parts[-1])
+        if k < len(d):
+            d[k] = value
+        else:
+            d.append(value)
+    else:
+        d[parts[-1]] = value
 
 
 def _merge(base, over):
@@ -276,6 +286,11 @@ def build_psf(psf_cfg, ev, scene_tables):
             psf.append((_abi.IMS_PSF_GAUSSIAN, 0, fwhm * s, 0.0, 1.0))
             kpsf.append((_abi.IMS_KPSF_GAUSSIAN, 0, fwhm * s))
             fw2 += fwhm ** 2
+        elif t == "Kolmogorov":                                          # plain galsim.Kolmogorov(fwhm=...)
+            fa = float(ev.value(it["fwhm"]))
+            psf.append((_abi.IMS_PSF_RADIAL, scene_tables["kolmogorov"], fa, 0.0, 1.0))
+            kpsf.append((_abi.IMS_KPSF_KOLMOGOROV, 0, fft_draw.KOLMOGOROV_K0 / fa))
+            fw2 += fa ** 2
         elif t == "KolmogorovPSF":
             p = lsst_image.get_all_params({k: ev.value(v) for k, v in it.items() if k != "type"},
                                           {"airmass": float, "rawSeeing": float, "band": str}, {})
@@ -394,6 +409,10 @@ def _process_outputs(out, ev, res, image_dev, det_name, meta, seed):
     header_vals = {k: ev.value(v) for k, v in (out.get("header") or {}).items()}
     opsim = {k: v for k, v in meta.items() if v is not None}
     opsim.setdefault("rotSkyPos", meta.get("rotSkyPos") or 0.0)
+    if opsim.get("mjd") is not None and opsim.get("fieldRA") is not None:       # HASTART / HAEND (ccd.py:186-187)
+        mjd_obs = float(opsim.get("observationStartMJD", opsim["mjd"]))
+        opsim.setdefault("HASTART", instcat.hour_angle(mjd_obs, opsim["fieldRA"]))
+        opsim.setdefault("HAEND", instcat.hour_angle(mjd_obs + exptime / 86400.0, opsim["fieldRA"]))
     hdr = readout.eimage_header(det_name, exptime, opsim_data=opsim, header_vals=header_vals, camera=camera_name)
     eimg = readout.EImage(image_dev, hdr)
     res.eimages.append(eimg)
@@ -439,7 +458,8 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
     res = ProcessResult()
     data_dir = data_dir or os.environ.get("IMSIM_DATA_DIR") or configs.DATA_DIR
     ev = Evaluator(cfg)
-    inp = cfg.get("input", {})
+    # an input (or any section) set to "" is switched off, the way the reference's tests and users disable template items
+    inp = {k: v for k, v in cfg.get("input", {}).items() if v not in ("", None)}
     for k in inp:
         if k not in valid_input_types:
             raise GalSimConfigError(f"Invalid input type {k}")

@@ -52,12 +52,32 @@ def read_header(path):
                 observationId=out.get("obshistid"), snap=out.get("nsnap", 1) - 1 if "nsnap" in out else 0)
     if "filter" in out:
         meta["band"] = BANDS[out["filter"]]
+    if meta.get("mjd") is not None and meta.get("fieldRA") is not None:
+        meta["HA"] = hour_angle(meta["mjd"], meta["fieldRA"])
     if meta.get("altitude") is not None:
         meta["airmass"] = get_airmass(meta["altitude"])
     return meta
 
 
 BAND_WAVELENGTH = dict(u=365.49, g=480.03, r=622.20, i=754.06, z=868.21, y=991.66)
+
+
+RUBIN_LONGITUDE = -70.749417          # deg east (lsst.obs.lsst SIMONYI_LOCATION)
+
+
+def hour_angle(mjd, ra):
+    """Local hour angle [deg] of right ascension `ra` [deg] at Rubin for the given MJD: local apparent sidereal time
+    minus RA, not wrapped (OpsimDataLoader.getHourAngle, imsim/opsim_data.py:335-361, which asks astropy).  Here: GMST
+    of IAU 1982 plus the two leading terms of the equation of the equinoxes -- good to a few arcseconds, far below what
+    differential chromatic refraction or the header keywords can tell."""
+    d = float(mjd) - 51544.5
+    t = d / 36525.0
+    gmst = 280.46061837 + 360.98564736629 * d + 0.000387933 * t * t - t ** 3 / 38710000.0
+    omega = math.radians(125.04452 - 1934.136261 * t)
+    lsun = math.radians(280.4665 + 36000.7698 * t)
+    dpsi = (-17.20 * math.sin(omega) - 1.32 * math.sin(2.0 * lsun)) / 3600.0          # nutation in longitude [deg]
+    last = (gmst + dpsi * math.cos(math.radians(23.4393)) + RUBIN_LONGITUDE) % 360.0
+    return last - float(ra)
 
 
 def get_airmass(altitude):

@@ -105,3 +105,17 @@ def test_camera_info_and_sequence_values(tmp_path):
     assert ev.value(cfg["output"]["file_name"]) == "eimage_R22_S11-det094.fits"
     ev.vars["_sequence_index"] = None
     assert ev.value(cfg["output"]["det_num"]) == 0
+
+
+def test_list_index_overrides_and_disabled_sections():
+    """`psf.items.0: {...}` replaces a list element and `input.atm_psf: ""` switches an input off, as the reference's
+    tests do (tests/test_stamp.py:200-218)."""
+    from imsim_amd import config
+    base = {"psf": {"type": "Convolve", "items": [{"type": "AtmosphericPSF"}, {"type": "Gaussian", "fwhm": 0.3}]},
+            "input": {"atm_psf": {"airmass": 1.1}}}
+    cfg = config.load_config(base, overrides={"psf.items.0": {"type": "Kolmogorov", "fwhm": 0.7}, "psf.items.1.fwhm": 0.25,
+                                              "input.atm_psf": ""})
+    assert cfg["psf"]["items"][0] == {"type": "Kolmogorov", "fwhm": 0.7} and cfg["psf"]["items"][1]["fwhm"] == 0.25
+    assert cfg["input"]["atm_psf"] == ""
+    psf, kpsf, fwhm, atm, extra = config.build_psf(cfg["psf"], config.Evaluator(cfg), {"kolmogorov": 2})
+    assert atm is None and len(psf) == 2 and psf[0][2] == 0.7 and abs(fwhm - (0.7 ** 2 + 0.25 ** 2) ** 0.5) < 1e-12

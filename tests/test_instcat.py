@@ -78,3 +78,17 @@ def test_airmass_and_fwhm_known_answers():
     assert abs(instcat.get_airmass(52.542) - 1.24522984) < 5e-8
     assert abs(instcat.fwhm_eff(0.5059960, "r", 52.54199126195116065) - 0.8300650) < 0.03
     assert abs(instcat.fwhm_geom(0.5059960, "r", 52.54199126195116065) - 0.7343130) < 0.03
+
+
+def test_hour_angle():
+    """OpsimDataLoader.getHourAngle (imsim/opsim_data.py:335-361): local apparent sidereal time minus RA.  At J2000.0
+    Greenwich mean sidereal time is 280.4606 deg; the header's own altitude of the example catalog is recovered from
+    HA, declination and Rubin's latitude."""
+    import math
+    from imsim_amd import instcat
+    assert abs(instcat.hour_angle(51544.5, 280.46061837 + instcat.RUBIN_LONGITUDE)) < 0.01
+    assert abs(instcat.hour_angle(51544.5 + 0.99726957, 10.0) - instcat.hour_angle(51544.5, 10.0)) < 0.01   # one sidereal day
+    m = instcat.read_header(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "example_instcat_subset.txt"))
+    lat, dec, ha = math.radians(-30.244639), math.radians(m["fieldDec"]), math.radians(m["HA"])
+    alt = math.degrees(math.asin(math.sin(lat) * math.sin(dec) + math.cos(lat) * math.cos(dec) * math.cos(ha)))
+    assert abs(alt - m["altitude"]) < 0.5

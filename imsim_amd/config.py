@@ -467,8 +467,17 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
             res.ignored.append(f"input.{k}")
     # opsim_data first: other inputs refer to it (atmPSF.py:374-383)
     if "opsim_data" in inp or "instance_catalog" in inp:
-        fn = (inp.get("opsim_data") or {}).get("file_name", "@input.instance_catalog.file_name")
-        cfg["_opsim_data"] = instcat.read_header(ev.value(fn))
+        od = inp.get("opsim_data") or {}
+        fn = str(ev.value(od.get("file_name", "@input.instance_catalog.file_name")))
+        if fn.endswith(".db"):                     # an OpSim database: needs the visit (opsim_data.py:60-76)
+            if "visit" not in od:
+                raise GalSimConfigError("input.opsim_data: an OpSim db file needs `visit`")
+            cfg["_opsim_data"] = instcat.read_opsim_db(fn, int(ev.value(od["visit"])), int(ev.value(od.get("snap", 0))))
+        else:
+            cfg["_opsim_data"] = instcat.read_header(fn)
+        for k in ("image_type", "reason"):         # passed through to the header (opsim_data.py:78-93)
+            if k in od:
+                cfg["_opsim_data"][k] = ev.value(od[k])
     out = cfg.get("output", {})
     if out.get("type", "LSST_CCD") not in valid_output_types:
         raise GalSimConfigError(f"Invalid output type {out.get('type')}")
@@ -485,6 +494,8 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
         if path is None:
             raise OSError("TreeRing file %s not found" % fn)
         cfg["_tree_rings"] = treerings.TreeRings(path, only_dets=inp["tree_rings"].get("only_dets"))
+    if "sky_catalog" in inp:
+        raise GalSimConfigError("input.sky_catalog (skyCatalogs) is outside this path: use an instance catalog (input.instance_catalog)")
     image = cfg["image"]
     itype = image.get("type", "LSST_Image")
     if itype not in valid_image_types:

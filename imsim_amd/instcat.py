@@ -80,6 +80,35 @@ def hour_angle(mjd, ra):
     return last - float(ra)
 
 
+def read_opsim_db(file_name, visit, snap=0):
+    """Visit metadata from an OpSim database (OpsimDataLoader._read_opsim_db, imsim/opsim_data.py:95-151): the row of
+    `observations` for `visit`, plus the derived items the configs use (band, exptime per snap, mjd at the middle of
+    the snap, HA, seed, rawSeeing, FWHMeff / FWHMgeom, seqnum counted from Rubin's day boundary)."""
+    import sqlite3
+    with sqlite3.connect(file_name) as con:
+        columns = [r[0] for r in con.execute("select name from pragma_table_info('observations')")]
+        rows = list(con.execute(f"select {','.join(columns)} from observations where observationId={int(visit)}"))
+        if not rows:
+            raise ValueError(f"visit {visit} not found in {file_name}")
+        meta = dict(zip(columns, rows[0]))
+        t0 = int(meta["observationStartMJD"] - 0.5) + 0.5
+        earlier = con.execute(f"select numExposures from observations where {t0} <= observationStartMJD and "
+                              f"observationId < {int(visit)}").fetchall()
+    meta["snap"] = int(snap)
+    meta["seqnum"] = sum(r[0] for r in earlier) + meta["snap"]
+    if meta["snap"] >= meta["numExposures"]:
+        raise ValueError("Invalid snap value: %d. For this visit, must have snap < %d" % (meta["snap"], meta["numExposures"]))
+    meta["band"] = meta["filter"]
+    meta["exptime"] = meta["visitExposureTime"] / meta["numExposures"]
+    readout_time = (meta["visitTime"] - meta["visitExposureTime"]) / meta["numExposures"]
+    meta["mjd"] = meta["observationStartMJD"] + (meta["snap"] * (meta["exptime"] + readout_time) + meta["exptime"] / 2) / 24. / 3600.
+    meta["HA"] = hour_angle(meta["mjd"], meta["fieldRA"])
+    meta["seed"] = meta["observationId"]
+    meta["rawSeeing"] = meta["seeingFwhm500"]
+    meta["FWHMeff"], meta["FWHMgeom"] = meta["seeingFwhmEff"], meta["seeingFwhmGeom"]
+    return meta
+
+
 def get_airmass(altitude):
     """Airmass from the altitude [deg], equation 3 of Krisciunas & Schaefer 1991 (OpsimDataLoader.getAirmass,
     imsim/opsim_data.py:242-260)."""

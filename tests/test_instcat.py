@@ -92,3 +92,32 @@ def test_hour_angle():
     lat, dec, ha = math.radians(-30.244639), math.radians(m["fieldDec"]), math.radians(m["HA"])
     alt = math.degrees(math.asin(math.sin(lat) * math.sin(dec) + math.cos(lat) * math.cos(dec) * math.cos(ha)))
     assert abs(alt - m["altitude"]) < 0.5
+
+
+def test_metadata_from_opsim_db(tmp_path):
+    """tests/test_instcat_parser.py:95-118 of the reference (visit 22184 of data/small_opsim.db): the same row, rebuilt
+    here as a one-row database, gives the same derived metadata."""
+    import sqlite3
+    from imsim_amd import instcat
+    row = {"observationId": 22184, "fieldRA": 65.00821243449612, "fieldDec": -33.20121826915378,
+           "observationStartMJD": 60248.33830784654, "visitExposureTime": 30.0, "visitTime": 34.0, "numExposures": 2, "filter": "z",
+           "altitude": 68.29298936358147, "azimuth": 255.57244075182493, "rotSkyPos": 287.86098563593913,
+           "rotTelPos": 16.923971097101944, "airmass": 1.0763250938907971, "seeingFwhm500": 0.5833528497734382,
+           "seeingFwhmEff": 0.7790170013788277, "seeingFwhmGeom": 0.6923519751333964}
+    db = str(tmp_path / "opsim.db")
+    with sqlite3.connect(db) as con:
+        con.execute("create table observations (%s)" % ", ".join(f"{k} {'text' if isinstance(v, str) else 'real'}" for k, v in row.items()))
+        con.execute("insert into observations values (%s)" % ",".join("?" * len(row)), list(row.values()))
+        early = dict(row, observationId=22100, observationStartMJD=60248.2)        # an earlier visit of the same night
+        con.execute("insert into observations values (%s)" % ",".join("?" * len(row)), list(early.values()))
+    md = instcat.read_opsim_db(db, 22184, snap=0)
+    assert md["observationId"] == 22184 and md["fieldRA"] == 65.00821243449612 and md["fieldDec"] == -33.20121826915378
+    assert md["rawSeeing"] == 0.5833528497734382 and md["FWHMeff"] == 0.7790170013788277 and md["FWHMgeom"] == 0.6923519751333964
+    assert abs(md["mjd"] - (60248.33830784654 + 7.5 / 86400)) < 1e-9 and md["airmass"] == 1.0763250938907971
+    assert md["band"] == "z" and md["exptime"] == 15 and md["seed"] == 22184 and md["seqnum"] == 2
+    assert instcat.read_opsim_db(db, 22184, snap=1)["mjd"] > md["mjd"] and instcat.read_opsim_db(db, 22184, snap=1)["seqnum"] == 3
+    import pytest
+    with pytest.raises(ValueError):
+        instcat.read_opsim_db(db, 22184, snap=2)
+    with pytest.raises(ValueError):
+        instcat.read_opsim_db(db, 1)

@@ -250,8 +250,14 @@ def build_photon_ops(op_cfgs, ev, base_wavelength):
             ops.append((kind, 0, [float(p["depth"])]))
         elif t == "Refraction":
             ops.append((kind, 0, [float(p["index_ratio"])]))
-        else:
-            raise GalSimConfigError(f"photon_op {t} needs tabulated bandpasses; pass ratio tables through the Python API")
+        else:                                                   # BandpassRatio (imsim/photon_ops.py:506-533)
+            target, initial = p["target_bandpass"], p["initial_bandpass"]
+            if not isinstance(target, tables.Bandpass) or not isinstance(initial, tables.Bandpass):
+                raise GalSimConfigError("BandpassRatio: target_bandpass and initial_bandpass must be Bandpass objects")
+            if "ratio" in meta:
+                raise GalSimConfigError("only one BandpassRatio op per chain is supported")
+            meta["ratio"] = target.ratio_table(initial)
+            ops.append((kind, 0, []))
     return ops, meta
 
 
@@ -399,6 +405,17 @@ READOUT_OPT = {"camera": str, "readout_time": float, "dark_current": float, "bia
 READOUT_IGNORE = ("file_name", "dir", "hdu", "filter", "added_keywords")
 
 
+def ccd_seed(seed, det):
+    """Seed of one CCD of a visit: the visit seed mixed with the detector number (splitmix64 finaliser), so that sky
+    noise, dark current, read noise and the photon streams of objects in the edge overlap differ between the CCDs of a
+    focal plane, on every rank, as GalSim's per-file RNG offsets make them differ in the reference."""
+    m = (1 << 64) - 1
+    x = (int(seed) + 0x9E3779B97F4A7C15 * (int(det) + 1)) & m
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & m
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & m
+    return (x ^ (x >> 31)) >> 2
+
+
 def _process_outputs(out, ev, res, image_dev, det_name, meta, seed):
     """`output` of type LSST_CCD (imsim/ccd.py:92-204) and its `readout` extra output (imsim/readout.py:535-602):
     the e-image gets the header the raw file is built from; with `output.file_name` it is written as FITS; with
@@ -540,7 +557,7 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
         wl, thr = tables.synthetic_r_band()
         res.ignored.append("image.bandpass (rubin_sim throughputs not present: synthetic r-band table)")
         wl_eff = tables.effective_wavelength(wl, thr)
-        ev.vars["bandpass"] = type("BP", (), {"effective_wavelength": wl_eff})()
+        ev.vars["bandpass"] = tables.Bandpass(wl, thr)
         # inputs that depend on the exposure
         if "atm_psf" in inp:
             a = {k: ev.value(v) for k, v in inp["atm_psf"].items()}
@@ -566,7 +583,12 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
             pt = opmeta["pointing"]
             diffraction.fill_optics(optics, pt["latitude"], pt["azimuth"], pt["altitude"])
         sed = tables.inverse_cdf_table(wl, thr)[None, :]
-        scene = Scene(nx=nx, ny=ny, seed=seed, psf=psf, ops=ops, radial_r2=r2, radial_cdf=cdf, sed_tables=sed, optics=optics, atm=atm)
+        # every CCD of the visit gets its own random streams (GalSim offsets the image-level RNG per file); the
+        # atmosphere above keeps the visit seed -- all CCDs look through the same screens
+        seed_ccd = ccd_seed(seed, det)
+        scene = Scene(nx=nx, ny=ny, seed=seed_ccd, psf=psf, ops=ops, radial_r2=r2, radial_cdf=cdf, sed_tables=sed, optics=optics, atm=atm)
+        if "ratio" in opmeta:
+            scene.ratio_tables, scene.ratio_wl_min, scene.ratio_wl_step = opmeta["ratio"]
         sens = image.get("sensor", "")
         nrecalc = None
         if isinstance(sens, dict) and sens.get("type", "Silicon") == "Silicon":
@@ -593,7 +615,7 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
         parsed = instcat.parse_objects(ev.value(ic["file_name"]))
         cat = instcat.to_catalog(parsed, optics.img_wcs, nx, ny, float(np.trapezoid(thr, wl)), float(meta.get("exptime") or 30.0),
                                  sort_mag=bool(ic.get("sort_mag", True)), edge_pix=int(ic.get("edge_pix", 100)))
-        phot = catalog.realize_fluxes(cat["nominal_flux"], seed)
+        phot = catalog.realize_fluxes(cat["nominal_flux"], seed_ccd)
         scene.image_profiles = cat.get("images") or None          # FITS-stamp objects (instcat.py:552-561)
         renderer = Renderer(scene, device)
 
@@ -603,7 +625,7 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
         truth = {}
         max_simple = float(ev.value(stamp_cfg.get("max_flux_simple", 100)))
         if itype == "LSST_PhotonPoolingImage":
-            builder.build_image(renderer, cat, phot, make_objects, max_flux_simple=max_simple, seed=seed, truth=truth)
+            builder.build_image(renderer, cat, phot, make_objects, max_flux_simple=max_simple, seed=seed_ccd, truth=truth)
         else:
             dfft = None
             if "diffraction_fft" in stamp_cfg:
@@ -618,12 +640,12 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
         # vignetting and fringing inputs are out of scope and reported as ignored
         sky = image.get("sky_level")
         if isinstance(sky, (int, float)) and not isinstance(sky, bool) and image.get("noise"):
-            builder.add_noise(renderer, float(sky), seed=seed)
+            builder.add_noise(renderer, float(sky), seed=seed_ccd)
         elif "sky_level" in image:
             res.ignored.append("image.sky_level")
         renderer.synchronize()
         res.images.append(renderer.image_numpy())
         res.truth.append(truth)
         res.det_names.append(det_name)
-        _process_outputs(out, ev, res, renderer.image, det_name, meta, seed)
+        _process_outputs(out, ev, res, renderer.image, det_name, meta, seed_ccd)
     return res

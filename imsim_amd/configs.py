@@ -1,8 +1,30 @@
 """Scene builders for the BASELINE.json measurement configs."""
 import numpy as np
 
-from . import _abi, tables, catalog
+import time
+
+from . import _abi, tables, catalog, parallel
 from .engine import Scene
+
+
+def cold_lsst_image(scene, objects, device):
+    """Cold render of one CCD on a fresh renderer that already holds the scene: plan (host) + uploads + run, the part
+    of the reference's draw loop that bench.py's replayed step leaves out (per-object setup, stamp.py:109-249)."""
+    import torch
+    from .engine import Renderer
+    r = Renderer(scene, device)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    plan, _ = r.plan_lsst_image(objects)
+    compiled = r._compile_plan(plan)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    r.execute_plan(plan, compiled)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    del r
+    return {"plan_ms": 1e3 * (t1 - t0), "cold_render_ms": 1e3 * (t2 - t0),
+            "note": "fresh renderer, scene tables resident: launch-plan construction + object-table uploads + one run"}
 
 
 def standard_tables():
@@ -52,7 +74,9 @@ BENCH_CONFIGS = {
                  "LSST_Image semantics (nrecalc=10000), Kolmogorov+Gaussian PSF, 4096x4096 CCD",
         scene=_c3_scene_bench,
         objects=None,
-        make_step=lambda renderer, objects: renderer.prepared_lsst_image(objects),
+        make_step=lambda renderer, objects, rank=0, world=1: renderer.prepared_lsst_image(
+            parallel.shard_objects(objects, rank, world)),
+        cold=lambda scene, objects, device: cold_lsst_image(scene, objects, device),
         timed_kernel=2,
         kernel="k_shoot_photons<true>",
         cpu_sample=20000,
@@ -64,7 +88,7 @@ BENCH_CONFIGS = {
         workload="C2: 10k-source synthetic instcat, photon_shooting, Gaussian atmPSF, Silicon sensor off, 4096x4096 CCD",
         scene=scene_c2,
         objects=_c2_objects,
-        make_step=lambda renderer, objects: renderer.prepared(objects),
+        make_step=lambda renderer, objects, rank=0, world=1: renderer.prepared(parallel.shard_objects(objects, rank, world)),
         timed_kernel=1,
         kernel="k_shoot_accumulate",
         cpu_sample=10000,
@@ -274,6 +298,7 @@ BENCH_CONFIGS["c3b"].update(
     workload=BENCH_CONFIGS["c3"]["workload"].replace("C3:", "C3b:").replace(
         "Kolmogorov+Gaussian PSF", "6-screen AtmosphericPSF (8192^2 von Karman screens) + second kick + Gaussian(0.3) PSF"),
     scene=_c3b_scene_bench,
+    scene_needs_gpu=True,       # the phase screens are generated on the GPU: the CPU legs run after the GPU is up (no fork)
     objects=lambda cat, phot, scene: c3b_objects(cat, phot, scene),
     cpu_sample=8000,
 )
@@ -285,10 +310,10 @@ def _c4_scene_bench():
     return sc
 
 
-def _c4_step(renderer, objects):
+def _c4_step(renderer, objects, rank=0, world=1):
     from . import photon_pooling, stamp
     modes = stamp.classify(objects["n_phot"].astype(float), 100.0)
-    return photon_pooling.prepared_image(renderer, objects, modes, nbatch=10, seed=renderer.scene.seed)
+    return photon_pooling.prepared_image(renderer, objects, modes, nbatch=10, seed=renderer.scene.seed, rank=rank, world=world)
 
 
 def _c4_cpu_step(orc, sample):
@@ -310,4 +335,5 @@ BENCH_CONFIGS["c4"] = dict(
     cpu_sample=10000,
     cpu_scene=lambda scene: scene,
     cpu_step=_c4_cpu_step,
+    cpu_allcore=False,          # pooling mode shares ONE sensor state between all objects: no per-object process parallelism
 )

@@ -99,7 +99,9 @@ __device__ __forceinline__ void make_photon(const ims_render_params_t& P, const 
 // (ds_add_f32), then flushes each non-empty tile cell with ONE global atomic to the CCD image (and
 // to the delta-charge image when the object's region is brighter-fatter tracked).  Photons outside
 // the tile go straight to global memory.  Unit fluxes keep every partial sum an exact integer, so
-// the result stays independent of the order of the atomics.
+// the result stays independent of the order of the atomics.  A photon whose flux is not exactly 1
+// (BandpassRatio reweighting, flux_per_photon != 1) never enters the float tile: it is added to the
+// f64 image directly, so no rounding to binary32 happens anywhere on its way.
 constexpr int CT = 32;
 
 struct ChargeTile {
@@ -142,11 +144,11 @@ __device__ __forceinline__ void deposit_global(const ims_render_params_t& P, con
 }
 
 __device__ __forceinline__ void tile_deposit(float* tile, const ChargeTile& ct, const ims_render_params_t& P, int ix, int iy,
-                                             float flux)
+                                             double flux)
 {
     const int tx = ix - ct.x0, ty = iy - ct.y0;
-    if (tx >= 0 && tx < CT && ty >= 0 && ty < CT) atomicAdd(&tile[ty * CT + tx], flux);
-    else deposit_global(P, ct, ix, iy, (double)flux);
+    if (flux == 1.0 && tx >= 0 && tx < CT && ty >= 0 && ty < CT) atomicAdd(&tile[ty * CT + tx], 1.0f);
+    else deposit_global(P, ct, ix, iy, flux);
 }
 
 __device__ __forceinline__ void tile_flush(float* tile, const ChargeTile& ct, const ims_render_params_t& P)
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_accumulate(const
         int ix, iy;
         if (ph.flux != 0.0 && land(P, o, k, rng, ph, silicon, has_angles, ix, iy)) {
             added += ph.flux;
-            tile_deposit(tile, ct, P, ix, iy, (float)ph.flux);
+            tile_deposit(tile, ct, P, ix, iy, ph.flux);
         }
     }
     tile_flush(tile, ct, P);
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(256) void k_accumulate_segments(const ims_render_pa
         rng_reset(rng);
         if (ph.flux != 0.0 && land(P, o, o.phot_first + j, rng, ph, silicon, has_angles, ix, iy)) {
             added = ph.flux;
-            tile_deposit(tile, ct, P, ix, iy, (float)ph.flux);
+            tile_deposit(tile, ct, P, ix, iy, ph.flux);
         }
     }
     tile_flush(tile, ct, P);

@@ -726,6 +726,9 @@ class Renderer:
             2: (sum(1 for it in plan if it[0] == "shoot_pool"),
                 sum(it[5] * 48 + it[6] * 256 for it in plan if it[0] == "shoot_pool")),
         }
+        # wavefronts per replay of the two kernels (4 per 256-thread segment, as SQ_WAVES counts them)
+        launch.timed_waves = {1: sum(4 * int(it[1].n_segments) for it in plan if it[0] == "render"),
+                              2: sum(4 * int(it[1].n_segments) for it in plan if it[0] == "shoot_pool")}
         return launch
 
     def prepared(self, objects, bf_tag=0):
@@ -744,6 +747,7 @@ class Renderer:
         launch.photons = int(objects["n_phot"].sum())
         launch.object_rows = len(objects)
         launch.timed = {1: (1, launch.photons * 16 + launch.object_rows * 256), 2: (0, 0)}
+        launch.timed_waves = {1: 4 * int(prefix[-1]), 2: 0}
         return launch
 
     # -- pooled path (LSST_PhotonPoolingImage / LSST_Photons) --

@@ -56,6 +56,8 @@ def reduce_image(image, dst=0, integer_counts=False):
     import torch
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if integer_counts and float(image.max()) >= 2147483648.0:
+            raise ValueError("reduce_image(integer_counts=True): a pixel holds more than 2^31 - 1 electrons")
         buf = image.to(torch.int32) if integer_counts else image
         if dist.get_backend() == "gloo" and buf.is_cuda:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)       # gloo has no device reduce (dry runs on one GPU only)
@@ -66,11 +68,18 @@ def reduce_image(image, dst=0, integer_counts=False):
     return image
 
 
-def allreduce_delta(delta):
+def allreduce_delta(delta, integer_counts=False):
     """Sum the delta-charge image (charge accumulated since the last recalculation) over all ranks, in
     place: afterwards every rank holds the charge of ALL objects and runs the same
-    updatePixelDistortions (imsim/photon_pooling.py:159 `recalc=(subbatch_num == 0)` semantics)."""
+    updatePixelDistortions (imsim/photon_pooling.py:159 `recalc=(subbatch_num == 0)` semantics).
+    integer_counts: as in reduce_image -- unit photon fluxes, the exchange runs on an int32 copy (half the bytes)."""
+    import torch
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(delta, op=dist.ReduceOp.SUM)
+        if integer_counts:
+            buf = delta.to(torch.int32)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            delta.copy_(buf)
+        else:
+            dist.all_reduce(delta, op=dist.ReduceOp.SUM)
     return delta

@@ -103,32 +103,46 @@ def make_batch_tables(objects, modes, nbatch, seed):
     return batch_tables, len_smallest
 
 
-def prepared_image(renderer, objects, modes, nbatch=10, seed=0):
+def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1):
     """The same image as build_image, prepared for replay (bench.py): every batch is ONE fused launch
     (shoot -> PSF -> ops -> sensor, ims_shoot_accumulate) over its pre-uploaded object table -- the photons of a batch
     see frozen pixel boundaries, so neither the sub-batching (a memory bound of the reference) nor the staging
     through a photon pool changes the result -- with the pixel-boundary recalculation between batches.
+    world > 1: the batch tables are built from the FULL object table on every rank, a rank shoots the rows it owns,
+    and before every recalculation the delta-charge image is all-reduced so that every rank applies the charge of ALL
+    objects (build_image's multi-rank semantics; the tile marks are rank-local, so the update visits every tile).
     Returns a zero-argument callable."""
     objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
     tables, _ = make_batch_tables(objects, modes, nbatch, seed)
     sensor_on = renderer.scene.sensor is not None
+    owner = parallel.assign_ranks(objects["n_phot"], world)
+    tagged = sensor_on and world == 1
     launches = []
-    for i, (table, _) in enumerate(tables):
-        table = table[table["n_phot"] > 0].copy()
+    for i, (table, index) in enumerate(tables):
+        keep = table["n_phot"] > 0
+        if world > 1:
+            keep &= owner[index] == rank
+        table = table[keep].copy()
         table["bf_state"] = 0
         table["flags"] &= ~IMS_OBJ_FAINT
-        launches.append(renderer.prepared(table, bf_tag=(i % 255 + 1) if sensor_on else 0))
+        if world > 1:                                      # neighbours in the table share image lines and boundary state
+            tile = (table["y0"] // 256).astype(np.int64) * 4096 + (table["x0"] // 256).astype(np.int64)
+            table = table[np.argsort(tile, kind="stable")]
+        launches.append(renderer.prepared(table, bf_tag=(i % 255 + 1) if tagged else 0))
 
     def run():
         if sensor_on:
             renderer.init_boundaries(0, 1)                 # a new CCD starts from undistorted (+ tree ring) boundaries
         for i, launch in enumerate(launches):
             if sensor_on and i > 0:
-                renderer.update_distortions(0, 1, bf_tag=(i - 1) % 255 + 1)
+                if world > 1:
+                    parallel.allreduce_delta(renderer.delta_tensor(0), integer_counts=True)
+                renderer.update_distortions(0, 1, bf_tag=((i - 1) % 255 + 1) if tagged else 0)
             launch()
     run.photons = sum(l.photons for l in launches)
     run.object_rows = sum(l.object_rows for l in launches)
     run.timed = {1: (len(launches), sum(l.timed[1][1] for l in launches)), 2: (0, 0)}
+    run.timed_waves = {1: sum(l.timed_waves[1] for l in launches), 2: 0}
     run.keep = launches
     return run
 

@@ -123,6 +123,45 @@ def synthetic_r_band(n=361):
     return wl, 0.55 * rise * fall * (1.0 - 0.0004 * (wl - 620.0))
 
 
+class Bandpass:
+    """Tabulated throughput on a wavelength grid [nm] -- the little of galsim.Bandpass the path needs: a call,
+    scaling by a number (`$bandpass*0.8`, tests/test_photon_ops.py:781), the ratio of two bandpasses
+    (BandpassRatio, imsim/photon_ops.py:506-533) and the effective wavelength."""
+
+    def __init__(self, wl, thr):
+        self.wl = np.asarray(wl, dtype=np.float64)
+        self.thr = np.asarray(thr, dtype=np.float64)
+        self.blue_limit, self.red_limit = float(self.wl[0]), float(self.wl[-1])
+
+    def __call__(self, wave):
+        return np.interp(wave, self.wl, self.thr, left=0.0, right=0.0)
+
+    @property
+    def effective_wavelength(self):
+        return effective_wavelength(self.wl, self.thr)
+
+    def __mul__(self, other):
+        if isinstance(other, Bandpass):
+            return Bandpass(self.wl, self.thr * other(self.wl))
+        return Bandpass(self.wl, self.thr * float(other))
+    __rmul__ = __mul__
+
+    def __truediv__(self, other):
+        if isinstance(other, Bandpass):
+            lo, hi = max(self.blue_limit, other.blue_limit), min(self.red_limit, other.red_limit)
+            wl = self.wl[(self.wl >= lo) & (self.wl <= hi)]
+            den = other(wl)
+            return Bandpass(wl, np.divide(self(wl), den, out=np.zeros_like(wl), where=den > 0.0))
+        return Bandpass(self.wl, self.thr / float(other))
+
+    def ratio_table(self, initial, n_pts=1025):
+        """(table, wl_min, wl_step) of self / initial on a uniform grid over the common wavelength range: the
+        ims_lin_tables_t row an IMS_OP_BANDPASS_RATIO op looks its photons' wavelengths up in."""
+        r = self / initial
+        grid = np.linspace(r.blue_limit, r.red_limit, n_pts)
+        return r(grid), float(grid[0]), float(grid[1] - grid[0])
+
+
 def effective_wavelength(wl, thr):
     return float(np.trapezoid(wl * thr, wl) / np.trapezoid(thr, wl))
 

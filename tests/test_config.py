@@ -119,3 +119,35 @@ def test_list_index_overrides_and_disabled_sections():
     assert cfg["input"]["atm_psf"] == ""
     psf, kpsf, fwhm, atm, extra = config.build_psf(cfg["psf"], config.Evaluator(cfg), {"kolmogorov": 2})
     assert atm is None and len(psf) == 2 and psf[0][2] == 0.7 and abs(fwhm - (0.7 ** 2 + 0.25 ** 2) ** 0.5) < 1e-12
+
+
+def test_bandpass_ratio_op_from_config():
+    """`BandpassRatio` with `$bandpass` / `$bandpass*0.8` (tests/test_photon_ops.py:768-790 of the reference): the
+    builder tabulates target / initial over the common wavelength range."""
+    import numpy as np
+    from imsim_amd import tables, _abi
+    wl, thr = tables.synthetic_r_band()
+    ev = config.Evaluator({})
+    ev.vars["bandpass"] = tables.Bandpass(wl, thr)
+    ops, meta = config.build_photon_ops([{"type": "BandpassRatio", "initial_bandpass": "$bandpass",
+                                          "target_bandpass": "$bandpass*0.8"}], ev, 620.0)
+    assert ops == [(_abi.IMS_OP_BANDPASS_RATIO, 0, [])]
+    table, wl_min, wl_step = meta["ratio"]
+    inside = thr[np.searchsorted(wl, wl_min + wl_step * np.arange(len(table))).clip(0, len(wl) - 1)] > 0
+    assert np.allclose(table[inside], 0.8, rtol=1e-12) and wl_min == wl[0] and abs(wl_min + wl_step * (len(table) - 1) - wl[-1]) < 1e-9
+    with pytest.raises(config.GalSimConfigError):
+        config.build_photon_ops([{"type": "BandpassRatio", "initial_bandpass": 1.0, "target_bandpass": 2.0}], ev, 620.0)
+    with pytest.raises(config.GalSimConfigError):
+        config.build_photon_ops([{"type": "BandpassRatio", "initial_bandpass": "$bandpass"}], ev, 620.0)
+    # a realistic ratio: the same band seen through more atmosphere (grey extinction here) -- the effective wavelength survives
+    b2 = tables.Bandpass(wl, thr * np.exp(-0.1 * (wl / 600.0) ** -4))
+    r, _, _ = b2.ratio_table(ev.vars["bandpass"])
+    assert np.all(r <= 1.0) and r[-1] > r[1]
+
+
+def test_every_ccd_of_a_visit_gets_its_own_seed():
+    """sky noise, dark current and read noise are addressed by (seed, stream, pixel): the seed must differ
+    between the CCDs of one Process() call."""
+    seeds = [config.ccd_seed(398414, det) for det in range(189)]
+    assert len(set(seeds)) == 189 and all(0 <= s < 2 ** 62 for s in seeds)
+    assert config.ccd_seed(398414, 94) == config.ccd_seed(398414, 94) != config.ccd_seed(398415, 94)

@@ -1,0 +1,105 @@
+"""The N > 1 path through the HIP Renderer: two ranks on ONE GPU (gloo for the exchanges, which RCCL refuses to
+do between two ranks of one device) must reproduce the single-rank image bit for bit, both for the LSST_Image
+object sharding + image reduce (C3) and for photon pooling with the delta-charge all-reduce before every
+recalculation (C4), and `bench.py --gpus 2` must start its own ranks and report n_gpus 2."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, out_path, mode):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import c3_small_case
+    from imsim_amd import parallel, photon_pooling, stamp
+    from imsim_amd.engine import Renderer
+    if mode == "lsst_image":
+        scene, objects = c3_small_case(n_obj=300, n=512, flux_seed=3)
+        r = Renderer(scene, "cuda:0")
+        step = r.prepared_lsst_image(parallel.shard_objects(objects, rank, world), nrecalc=2000)
+    else:
+        scene, objects = c3_small_case(n_obj=400, n=256, flux_seed=5, scratch=0)
+        scene.track_static_delta = 1
+        r = Renderer(scene, "cuda:0")
+        modes = stamp.classify(objects["n_phot"].astype(float), 100.0)
+        step = photon_pooling.prepared_image(r, objects, modes, nbatch=5, seed=11, rank=rank, world=world)
+    for _ in range(2):                       # replayable: the second pass must give the same image
+        r.image.zero_()
+        step()
+        parallel.reduce_image(r.image, dst=0, integer_counts=True)
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.savez(out_path, image=r.image.cpu().numpy(), boundary=r.bound.sensor_arrays["boundary"].cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(tmp_path, mode):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / f"{mode}.npz")
+    port = 33500 + (os.getpid() % 2000)
+    mp.start_processes(_worker, args=(2, port, out, mode), nprocs=2, join=True, start_method="spawn")
+    return np.load(out)
+
+
+def test_two_ranks_lsst_image_reduce_equals_single_rank(tmp_path):
+    from helpers import c3_small_case
+    from imsim_amd.engine import Renderer
+    from oracle import orc_loader
+    res = _run(tmp_path, "lsst_image")
+    scene, objects = c3_small_case(n_obj=300, n=512, flux_seed=3)
+    r = Renderer(scene, "cuda:0")
+    r.prepared_lsst_image(objects, nrecalc=2000)()
+    r.synchronize()
+    single = r.image.cpu().numpy()
+    assert single.sum() > 0 and (objects["n_phot"] > 2000).sum() >= 2       # brighter-fatter chains are exercised
+    assert np.array_equal(res["image"], single)
+    orc = orc_loader.OracleScene(scene)
+    orc.render_lsst_image(objects, nrecalc=2000)
+    assert np.array_equal(res["image"], orc.image64)
+
+
+def test_two_ranks_photon_pooling_allreduce_equals_single_rank(tmp_path):
+    from helpers import c3_small_case
+    from imsim_amd import photon_pooling, stamp
+    from imsim_amd.engine import Renderer
+    res = _run(tmp_path, "pooling")
+    scene, objects = c3_small_case(n_obj=400, n=256, flux_seed=5, scratch=0)
+    scene.track_static_delta = 1
+    modes = stamp.classify(objects["n_phot"].astype(float), 100.0)
+    r = Renderer(scene, "cuda:0")
+    photon_pooling.prepared_image(r, objects, modes, nbatch=5, seed=11)()
+    r.synchronize()
+    assert np.array_equal(res["image"], r.image.cpu().numpy())
+    # every rank ran the identical updatePixelDistortions on the summed charge: same boundaries as one rank
+    assert np.array_equal(res["boundary"], r.bound.sensor_arrays["boundary"].cpu().numpy())
+    # and the recalculations did act
+    r0 = Renderer(scene, "cuda:0")
+    photon_pooling.prepared_image(r0, objects, modes, nbatch=1, seed=11)()
+    r0.synchronize()
+    assert not np.array_equal(r0.bound.sensor_arrays["boundary"].cpu().numpy(), res["boundary"])
+
+
+@pytest.mark.parametrize("config", ["c3", "c4"])
+def test_bench_starts_its_own_ranks(config):
+    """`python bench.py --gpus 2` with no launcher: the parent starts two ranks (on this one-GPU box a dry run over
+    gloo) and relays rank 0's JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--config", config, "--n-objects", "3000", "--no-cpu-baseline"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["shared_gpu"] is True

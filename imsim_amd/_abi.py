@@ -164,11 +164,12 @@ class RenderParams(C.Structure):
 
 class PlanItem(C.Structure):
     _fields_ = [("kind", c_i32), ("stream", c_i32), ("params", c_vp), ("pool", c_vp), ("aux", c_vp),
-                ("first_slot", c_i32), ("n_slots", c_i32), ("n_tiles", c_i64), ("tag", C.c_uint32), ("pad", C.c_uint32)]
+                ("first_slot", c_i32), ("n_slots", c_i32), ("n_tiles", c_i64), ("tag", C.c_uint32), ("pad", C.c_uint32),
+                ("aux2", c_vp)]
 
 
 (IMS_PLAN_RENDER, IMS_PLAN_SHOOT_POOL, IMS_PLAN_ACC_POOL, IMS_PLAN_UPDATE, IMS_PLAN_INIT, IMS_PLAN_RECORD,
- IMS_PLAN_WAIT) = range(1, 8)
+ IMS_PLAN_WAIT, IMS_PLAN_CHAIN) = range(1, 9)
 
 IMS_MAX_AMPS = 16
 
@@ -190,6 +191,7 @@ STRUCTS = [Object, RadialTables, LinTables, PsfComponent, Op, Surface, TanSip, O
 # every symbol include/imsim_hip.h declares
 EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_info", "ims_shoot_accumulate",
            "ims_shoot_photons", "ims_shoot_ops_photons", "ims_accumulate_segments", "ims_run_plan",
+           "ims_bf_chain", "ims_bf_chain_ctl_bytes", "ims_bf_chain_status",
            "ims_fft_kspace_fill", "ims_fft_finish", "ims_fft_spikes", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
            "ims_sensor_update_distortions", "ims_image_add", "ims_image_to_float", "ims_fill_derived_op", "ims_fill_derived_medium", "ims_sensor_pixel_areas", "ims_flat_add", "ims_last_kernel_ms", "ims_enable_timing",
            "ims_readout_bleed", "ims_readout_segments", "ims_readout_cte", "ims_readout_finish",
@@ -242,6 +244,9 @@ def load():
     lib.ims_fft_kspace_fill.argtypes = [C.POINTER(FftParams), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]
     lib.ims_fft_finish.argtypes = [C.POINTER(FftParams), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]
     lib.ims_fft_spikes.argtypes = [C.POINTER(FftParams), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]
+    lib.ims_bf_chain.argtypes = [C.POINTER(RenderParams), C.POINTER(Photons), c_vp, c_i32, c_i32, c_i32, C.POINTER(Sensor), c_vp, c_vp,
+                                 c_i32, c_i32, c_vp]
+    lib.ims_bf_chain_status.argtypes = [c_vp, C.POINTER(c_i32)]
     lib.ims_run_plan.argtypes = [C.POINTER(PlanItem), c_i64, c_vp, C.POINTER(Sensor), c_vp, C.POINTER(c_vp), c_i32]
     lib.ims_last_kernel_ms.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.ims_enable_timing.argtypes = [C.c_int]

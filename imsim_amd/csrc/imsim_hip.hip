@@ -544,38 +544,41 @@ __global__ __launch_bounds__(256) void k_update_distortions(const ims_sensor_t* 
     if (any && tag != 0u && s.bf_tile_changed != nullptr) s.bf_tile_changed[cell_index(sl, tx0, ty0)] = (unsigned char)tag;
 }
 
-// Fast path for qdist == 3 (the GalSim default): the 8x8 source window of a cell is a 64-bit
-// occupancy mask cut out of per-row LDS bitmaps, so a lane only iterates over its OWN charged
-// neighbours (in the spec's order: dj ascending, then di ascending) instead of testing all 64.
-// Sparse stamp wings cost max-over-lanes(nnz) iterations per wave; the dense core stays dense.
-// Boundary points are accumulated in registers (NV is a template parameter) and the displacement
-// table and the scaled charges w = delta / num_elec live in LDS.
+// LDS of one q3 tile update: scaled charges of the halo, per-row occupancy bitmaps, displacement table
 template <int NV>
-__global__ __launch_bounds__(256) void k_update_distortions_q3(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
-                                                               const int64_t* __restrict__ tile_prefix,
-                                                               unsigned char* __restrict__ changed, unsigned int tag)
+struct UpdateLds {
+    static constexpr int Q = 3, HW = UT + 2 * Q + 1, NPO = 2 * NV + 2;
+    double wt[HW * HW];
+    double dl[8 * 8 * NPO * 2];           // [dj+Q][di+Q][owned point][x,y]
+    unsigned int occ[HW];
+    int any_charge;
+};
+
+template <int NV>
+__device__ __forceinline__ void load_displacements(const ims_sensor_t& s, UpdateLds<NV>& L)
 {
-    constexpr int Q = 3, HW = UT + 2 * Q + 1, NPO = 2 * NV + 2, NVV = 4 * NV + 4;
-    __shared__ double wt[HW * HW];
-    __shared__ unsigned int occ[HW];
-    __shared__ double dl[8 * 8 * NPO * 2];       // [dj+Q][di+Q][owned point][x,y]
-    const ims_sensor_t& s = *sp;
-    const int64_t b = blockIdx.x;
-    int lo = 0, hi = n_slots;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (tile_prefix[mid] <= b) lo = mid; else hi = mid;
+    constexpr int Q = 3, NPO = 2 * NV + 2, NVV = 4 * NV + 4;
+    const int cx = (s.nx - 1) / 2, cy = (s.ny - 1) / 2;
+    for (int e = threadIdx.x; e < 8 * 8 * NPO * 2; e += 256) {
+        const int comp = e & 1, n = (e >> 1) % NPO, cell = (e >> 1) / NPO;
+        const int di = (cell & 7) - Q, dj = (cell >> 3) - Q;
+        const int vtx = owned_to_vertex(NV, n);
+        L.dl[e] = s.distortions[(((int64_t)(di + cx) * s.ny + (dj + cy)) * NVV + vtx) * 2 + comp];
     }
-    const ims_bf_slot_t bs = s.bf_slots[first_slot + lo];
-    const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
-    const int tiles_x = (sl.nx + 1 + UT - 1) / UT;
-    const int t = (int)(b - tile_prefix[lo]);
-    const int tx0 = (t % tiles_x) * UT, ty0 = (t / tiles_x) * UT;
+}
+
+// Silicon::updatePixelDistortions for the 16x16 owner cells of tile (tx0, ty0) of one slot (qdist 3).
+// dl_loaded: the displacement table is already in L.dl (persistent kernels load it once).  Returns, per thread,
+// whether its cell moved; `tile_moved` is set when any cell of the tile did.
+template <int NV>
+__device__ __forceinline__ void update_tile_q3(const ims_sensor_t& s, const SlotView& sl, int tx0, int ty0,
+                                               unsigned char* __restrict__ changed, UpdateLds<NV>& L, bool dl_loaded,
+                                               unsigned int tag)
+{
+    constexpr int Q = 3, HW = UT + 2 * Q + 1, NPO = 2 * NV + 2;
     const int sx0 = tx0 - (Q + 1), sy0 = ty0 - (Q + 1);
-    if (tile_out_of_reach(s, sl, tx0 / UT, ty0 / UT, tag)) return;
-    __shared__ int any_charge;
-    if (threadIdx.x < HW) occ[threadIdx.x] = 0u;
-    if (threadIdx.x == 0) any_charge = 0;
+    if (threadIdx.x < HW) L.occ[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) L.any_charge = 0;
     __syncthreads();
     for (int e = threadIdx.x; e < HW * HW; e += 256) {
         const int hx = e % HW, hy = e / HW;
@@ -583,32 +586,28 @@ __global__ __launch_bounds__(256) void k_update_distortions_q3(const ims_sensor_
         double w = 0.0;
         if (si >= 0 && si < sl.nx && sj >= 0 && sj < sl.ny) {
             const double charge = (double)s.bf_delta[cell_index(sl, si, sj)];
-            if (charge != 0.0) { w = ddiv(charge, s.num_elec); atomicOr(&occ[hy], 1u << hx); any_charge = 1; }
+            if (charge != 0.0) { w = ddiv(charge, s.num_elec); atomicOr(&L.occ[hy], 1u << hx); L.any_charge = 1; }
         }
-        wt[e] = w;
+        L.wt[e] = w;
     }
     __syncthreads();
     const int lx = threadIdx.x % UT, ly = threadIdx.x / UT;
     const int i = tx0 + lx, j = ty0 + ly;
-    if (!any_charge) {                       // nothing landed near this tile: nothing moves
+    if (!L.any_charge) {                     // nothing landed near this tile: nothing moves
         if (i <= sl.nx && j <= sl.ny) changed[cell_index(sl, i, j)] = 0;
         return;
     }
-    const int cx = (s.nx - 1) / 2, cy = (s.ny - 1) / 2;
-    for (int e = threadIdx.x; e < 8 * 8 * NPO * 2; e += 256) {
-        const int comp = e & 1, n = (e >> 1) % NPO, cell = (e >> 1) / NPO;
-        const int di = (cell & 7) - Q, dj = (cell >> 3) - Q;
-        const int vtx = owned_to_vertex(NV, n);
-        dl[e] = s.distortions[(((int64_t)(di + cx) * s.ny + (dj + cy)) * NVV + vtx) * 2 + comp];
+    if (!dl_loaded) {
+        load_displacements<NV>(s, L);
+        __syncthreads();
     }
-    __syncthreads();
     if (i > sl.nx || j > sl.ny) return;
     // 64-bit window: byte a <-> dj = -Q + a (row hy = ly + 2Q + 1 - a); inside a byte bit bb <-> di = -Q + bb
     // (column hx = lx + 2Q + 1 - bb), i.e. the row bitmap reversed.
     unsigned long long mask = 0ull;
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
-        const unsigned int row = (occ[ly + 2 * Q + 1 - a] >> lx) & 0xFFu;
+        const unsigned int row = (L.occ[ly + 2 * Q + 1 - a] >> lx) & 0xFFu;
         const unsigned int rev = __brev(row) >> 24;
         mask |= (unsigned long long)rev << (8 * a);
     }
@@ -624,8 +623,8 @@ __global__ __launch_bounds__(256) void k_update_distortions_q3(const ims_sensor_
         const int p = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
         const int a = p >> 3, bb = p & 7;          // dj = a - Q, di = bb - Q
-        const double w = wt[(ly + 2 * Q + 1 - a) * HW + (lx + 2 * Q + 1 - bb)];
-        const double* d = dl + (a * 8 + bb) * NPO * 2;
+        const double w = L.wt[(ly + 2 * Q + 1 - a) * HW + (lx + 2 * Q + 1 - bb)];
+        const double* d = L.dl + (a * 8 + bb) * NPO * 2;
         const bool extra_col = (bb == 7), extra_row = (a == 7);
         if (!extra_col) {
 #pragma unroll
@@ -646,16 +645,18 @@ __global__ __launch_bounds__(256) void k_update_distortions_q3(const ims_sensor_
     for (int n = 0; n < NPO * 2; ++n) pts[n] = acc[n];
 }
 
-// bounds of the pixels whose polygon moved (own cell, right cell or upper cell changed); one 16x16
-// tile of owner cells per workgroup, same grid as the update kernel.  With a tag, tiles that saw
-// neither charge nor movement (own, right and upper tile) leave after three byte loads.
-// NV > 0: the owned points of the cell and of its right / upper neighbours are fetched with independent loads into
-// registers and the vertex loop is unrolled (the generic loop issues one dependent load per vertex: 12 us per wave).
+// Fast path for qdist == 3 (the GalSim default): the 8x8 source window of a cell is a 64-bit
+// occupancy mask cut out of per-row LDS bitmaps, so a lane only iterates over its OWN charged
+// neighbours (in the spec's order: dj ascending, then di ascending) instead of testing all 64.
+// Sparse stamp wings cost max-over-lanes(nnz) iterations per wave; the dense core stays dense.
+// Boundary points are accumulated in registers (NV is a template parameter) and the displacement
+// table and the scaled charges w = delta / num_elec live in LDS.
 template <int NV>
-__global__ __launch_bounds__(256) void k_refresh_changed(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
-                                                         const int64_t* __restrict__ tile_prefix,
-                                                         const unsigned char* __restrict__ changed, unsigned int tag)
+__global__ __launch_bounds__(256) void k_update_distortions_q3(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
+                                                               const int64_t* __restrict__ tile_prefix,
+                                                               unsigned char* __restrict__ changed, unsigned int tag)
 {
+    __shared__ UpdateLds<NV> L;
     const ims_sensor_t& s = *sp;
     const int64_t b = blockIdx.x;
     int lo = 0, hi = n_slots;
@@ -665,26 +666,29 @@ __global__ __launch_bounds__(256) void k_refresh_changed(const ims_sensor_t* __r
     }
     const ims_bf_slot_t bs = s.bf_slots[first_slot + lo];
     const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
-    const int tiles_x = (sl.nx + 1 + UT - 1) / UT, tiles_y = (sl.ny + 1 + UT - 1) / UT;
+    const int tiles_x = (sl.nx + 1 + UT - 1) / UT;
     const int t = (int)(b - tile_prefix[lo]);
-    const int tx = t % tiles_x, ty = t / tiles_x;
-    const bool flags = (tag != 0u) && s.bf_tile_charge != nullptr && s.bf_tile_changed != nullptr;
-    bool own = true, right = true, up = true, charged = true;
-    if (flags) {
-        const unsigned char tg = (unsigned char)tag;
-        own = s.bf_tile_changed[cell_index(sl, tx * UT, ty * UT)] == tg;
-        right = (tx + 1 < tiles_x) && s.bf_tile_changed[cell_index(sl, (tx + 1) * UT, ty * UT)] == tg;
-        up = (ty + 1 < tiles_y) && s.bf_tile_changed[cell_index(sl, tx * UT, (ty + 1) * UT)] == tg;
-        charged = s.bf_tile_charge[cell_index(sl, tx * UT, ty * UT)] == tg;
-        if (!(own || right || up || charged)) return;
-    }
+    const int tx0 = (t % tiles_x) * UT, ty0 = (t / tiles_x) * UT;
+    if (tile_out_of_reach(s, sl, tx0 / UT, ty0 / UT, tag)) return;
+    update_tile_q3<NV>(s, sl, tx0, ty0, changed, L, false, tag);
+}
+
+// bounds of the pixels whose polygon moved (own cell, right cell or upper cell changed); one 16x16
+// tile of owner cells per workgroup, same grid as the update kernel.  With a tag, tiles that saw
+// neither charge nor movement (own, right and upper tile) leave after three byte loads.
+// NV > 0: the owned points of the cell and of its right / upper neighbours are fetched with independent loads into
+// registers and the vertex loop is unrolled (the generic loop issues one dependent load per vertex: 12 us per wave).
+template <int NV>
+__device__ __forceinline__ void refresh_tile(const ims_sensor_t& s, const SlotView& sl, int tx, int ty, bool own, bool right,
+                                             bool up, bool charged, const unsigned char* __restrict__ changed)
+{
     const int lx = threadIdx.x % UT, ly = threadIdx.x / UT;
     const int i = tx * UT + lx, j = ty * UT + ly;
     if (i > sl.nx || j > sl.ny) return;
     const int64_t c = cell_index(sl, i, j);
-    if (charged) s.bf_delta[c] = 0.0;         // the update kernel has consumed the delta charge
+    if (charged) s.bf_delta[c] = 0.0;         // the update has consumed the delta charge
     if (i >= sl.nx || j >= sl.ny) return;
-    // per-cell flags are only meaningful in tiles the update kernel worked on this round
+    // per-cell flags are only meaningful in tiles the update worked on this round
     const bool f_own = own && changed[c];
     const bool f_right = ((lx + 1 < UT) ? own : right) && changed[cell_index(sl, i + 1, j)];
     const bool f_up = ((ly + 1 < UT) ? own : up) && changed[cell_index(sl, i, j + 1)];
@@ -696,12 +700,12 @@ __global__ __launch_bounds__(256) void k_refresh_changed(const ims_sensor_t* __r
     if (NV > 0) {
         constexpr int NPO = 2 * NV + 2;
         constexpr int NVX = (NV > 0) ? NV : 1;
-        double2 own[(NV > 0) ? NPO : 1], rgt[NVX], upp[(NV > 0) ? NV + 2 : 1];
+        double2 ownp[(NV > 0) ? NPO : 1], rgt[NVX], upp[(NV > 0) ? NV + 2 : 1];
         const double2* po = (const double2*)(s.bf_boundary + c * NPO * 2);
         const double2* pr = (const double2*)(s.bf_boundary + cell_index(sl, i + 1, j) * NPO * 2);
         const double2* pu = (const double2*)(s.bf_boundary + cell_index(sl, i, j + 1) * NPO * 2);
 #pragma unroll
-        for (int q = 0; q < NPO; ++q) own[q] = po[q];
+        for (int q = 0; q < NPO; ++q) ownp[q] = po[q];
 #pragma unroll
         for (int m = 0; m < NV; ++m) rgt[m] = pr[NV + 2 + m];
 #pragma unroll
@@ -709,10 +713,10 @@ __global__ __launch_bounds__(256) void k_refresh_changed(const ims_sensor_t* __r
 #pragma unroll
         for (int k = 0; k < 4 * NV + 4; ++k) {
             double vx, vy;
-            if (k <= NV + 1) { vx = own[k].x; vy = own[k].y; }
+            if (k <= NV + 1) { vx = ownp[k].x; vy = ownp[k].y; }
             else if (k <= 2 * NV + 1) { vx = rgt[k - NV - 2].x + 1.0; vy = rgt[k - NV - 2].y; }
             else if (k <= 3 * NV + 3) { vx = upp[NV + 1 - (k - 2 * NV - 2)].x; vy = upp[NV + 1 - (k - 2 * NV - 2)].y + 1.0; }
-            else { vx = own[NV + 2 + (NV - 1 - (k - 3 * NV - 4))].x; vy = own[NV + 2 + (NV - 1 - (k - 3 * NV - 4))].y; }
+            else { vx = ownp[NV + 2 + (NV - 1 - (k - 3 * NV - 4))].x; vy = ownp[NV + 2 + (NV - 1 - (k - 3 * NV - 4))].y; }
             if (k == 0) v0x = vx;
             if (vx < oxmin) oxmin = vx;
             if (vx > oxmax) oxmax = vx;
@@ -742,6 +746,321 @@ __global__ __launch_bounds__(256) void k_refresh_changed(const ims_sensor_t* __r
     double* bb = s.bf_bounds + c * 8;
     bb[0] = ixmin; bb[1] = ixmax; bb[2] = iymin; bb[3] = iymax;
     bb[4] = oxmin; bb[5] = oxmax; bb[6] = oymin; bb[7] = oymax;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void k_refresh_changed(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
+                                                         const int64_t* __restrict__ tile_prefix,
+                                                         const unsigned char* __restrict__ changed, unsigned int tag)
+{
+    const ims_sensor_t& s = *sp;
+    const int64_t b = blockIdx.x;
+    int lo = 0, hi = n_slots;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (tile_prefix[mid] <= b) lo = mid; else hi = mid;
+    }
+    const ims_bf_slot_t bs = s.bf_slots[first_slot + lo];
+    const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
+    const int tiles_x = (sl.nx + 1 + UT - 1) / UT, tiles_y = (sl.ny + 1 + UT - 1) / UT;
+    const int t = (int)(b - tile_prefix[lo]);
+    const int tx = t % tiles_x, ty = t / tiles_x;
+    const bool flags = (tag != 0u) && s.bf_tile_charge != nullptr && s.bf_tile_changed != nullptr;
+    bool own = true, right = true, up = true, charged = true;
+    if (flags) {
+        const unsigned char tg = (unsigned char)tag;
+        own = s.bf_tile_changed[cell_index(sl, tx * UT, ty * UT)] == tg;
+        right = (tx + 1 < tiles_x) && s.bf_tile_changed[cell_index(sl, (tx + 1) * UT, ty * UT)] == tg;
+        up = (ty + 1 < tiles_y) && s.bf_tile_changed[cell_index(sl, tx * UT, (ty + 1) * UT)] == tg;
+        charged = s.bf_tile_charge[cell_index(sl, tx * UT, ty * UT)] == tg;
+        if (!(own || right || up || charged)) return;
+    }
+    refresh_tile<NV>(s, sl, tx, ty, own, right, up, charged, changed);
+}
+
+// ---------------- persistent brighter-fatter chain (LSST_Image mode, bright objects) ----------------
+// A bright object's sensor step is a chain of rounds: nrecalc photons through the sensor, then
+// updatePixelDistortions on its private region, then the bounds refresh (imsim/stamp.py:558-573 with the sensor's
+// nrecalc).  As three launches per round the chain is launch-latency bound (~75 us per round).  Here ONE launch runs
+// whole chains: a TEAM of up to G workgroups, all resident on the SAME XCD, takes an object from a queue and walks its
+// rounds with three team barriers per round (accumulate | update | refresh).  Because a team shares one L2, a
+// barrier is "my stores have reached L2" (s_waitcnt vmcnt(0)) + a counter + an L1 invalidate -- no L2 write-back.
+// Placement independence: a worker joins a team of the XCD it actually runs on (HW_REG_XCC_ID), teams are formed from
+// the workgroups that are running, so any workgroup -> XCD mapping and any residency gives a correct (if differently
+// balanced) run; every spin is bounded and reports through ctl->error.
+constexpr int BFC_MAX_TEAMS = 64;        // teams per XCD
+constexpr int BFC_MAX_TILES = 4096;      // 16x16-cell tiles of one region (regions up to 1023 pixels on a side)
+constexpr int BFC_WORDS = BFC_MAX_TILES / 32;
+constexpr unsigned int BFC_SPIN_LIMIT = 40u * 1000u * 1000u;   // polls (with s_sleep): a few seconds
+
+struct BfChainCtl {
+    unsigned int next_object;
+    unsigned int error;
+    unsigned int pad[2];
+    unsigned int open_team[N_XCD];                  // first team of the XCD that may still be open (a hint)
+    unsigned int team_state[N_XCD][BFC_MAX_TEAMS];  // members joined (low 16 bits) | closed (bit 31)
+    unsigned int team_bar[N_XCD][BFC_MAX_TEAMS];
+    unsigned int team_obj[N_XCD][BFC_MAX_TEAMS][2];
+    unsigned int bitmap[N_XCD][BFC_MAX_TEAMS][BFC_WORDS];
+};
+
+#define BFC_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define BFC_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define BFC_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+__device__ __forceinline__ int xcc_id()
+{
+    unsigned int x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return (int)(x & 7u);
+}
+
+// spin until *p >= target (relaxed agent-scope polls); false on timeout
+__device__ __forceinline__ bool bfc_wait_ge(unsigned int* p, unsigned int target, unsigned int* err)
+{
+    for (unsigned int spins = 0; ; ++spins) {
+        if (BFC_LOAD(p) >= target) return true;
+        if (BFC_LOAD(err) != 0u) return false;
+        if (spins > BFC_SPIN_LIMIT) { BFC_STORE(err, 1u); return false; }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+// Team barrier.  Every wave drains its own memory operations (stores and atomics have reached the XCD's L2 / memory),
+// the workgroup joins, lane 0 arrives on the team counter and polls it, then ONE agent-scope acquire drops the CU's
+// stale L1 lines for the whole workgroup.  Returns false when the launch is being aborted.
+__device__ __forceinline__ bool team_barrier(unsigned int* bar, unsigned int& target, int M, unsigned int* err, int* s_ok)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    target += (unsigned int)M;
+    if (threadIdx.x == 0) {
+        bool ok = true;
+        if (M > 1) {
+            BFC_ADD(bar, 1u);
+            ok = bfc_wait_ge(bar, target, err);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *s_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+
+template <int NV>
+struct BfChainLds {
+    UpdateLds<NV> upd;
+    float tile[CT * CT];
+    unsigned int bm[BFC_WORDS];           // charged tiles of this round (copy of the team's global bitmap)
+    unsigned int a1[BFC_WORDS];           // tiles the update must visit (charge within reach)
+    unsigned short mine[BFC_MAX_TILES];   // tiles assigned to this workgroup
+    int wave_cnt[4];
+    int ok;
+    unsigned int u0, u1;
+};
+
+__device__ __forceinline__ bool bit_at(const unsigned int* bm, int tx, int ty, int tiles_x, int tiles_y)
+{
+    if (tx < 0 || ty < 0 || tx >= tiles_x || ty >= tiles_y) return false;
+    const int t = ty * tiles_x + tx;
+    return (bm[t >> 5] >> (t & 31)) & 1u;
+}
+
+// Deterministic partition of the tiles that satisfy `pred` among the M workgroups of a team: tile of rank k (in
+// index order) goes to member k % M.  Every member evaluates the same predicate on the same bitmap snapshot.
+template <typename Pred>
+__device__ __forceinline__ int assign_tiles(int n_tiles, int m, int M, unsigned short* mine, int* wave_cnt, Pred pred)
+{
+    int base = 0;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int q = 0; q * 256 < n_tiles; ++q) {
+        const int t = q * 256 + (int)threadIdx.x;
+        const bool act = t < n_tiles && pred(t);
+        const unsigned long long b = __ballot(act);
+        if (lane == 0) wave_cnt[w] = __popcll(b);
+        __syncthreads();
+        int off = base;
+        for (int k = 0; k < w; ++k) off += wave_cnt[k];
+        const int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        if (act) {
+            const int rank = off + __popcll(b & ((1ull << lane) - 1ull));
+            if (rank % M == m) mine[rank / M] = (unsigned short)t;
+        }
+        base += tot;
+        __syncthreads();
+    }
+    return base > m ? (base - m - 1) / M + 1 : 0;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void k_bf_chain(const ims_render_params_t P, const ims_photons_t pool,
+                                                  const int64_t* __restrict__ pool_start, int round_begin, int round_end,
+                                                  int nrecalc, unsigned char* __restrict__ changed, BfChainCtl* ctl,
+                                                  int G)
+{
+    __shared__ BfChainLds<NV> L;
+    const ims_sensor_t& s = *P.sensor;
+    const int tid = (int)threadIdx.x;
+    // ---- team formation on the XCD this workgroup actually runs on ----
+    // A worker joins the XCD's open team (CAS on the team word: member count + closed bit).  The first member closes
+    // the team when it is full or after ~20 us, whichever comes first; later arrivals open the next team.  So teams
+    // only ever contain workgroups that are running: no launch-wide rendezvous, any residency makes progress.
+    const int x = xcc_id();
+    if (tid == 0) {
+        constexpr unsigned int CLOSED = 0x80000000u;
+        int t = (int)BFC_LOAD(&ctl->open_team[x]);
+        int me = -1;
+        while (t < BFC_MAX_TEAMS) {
+            unsigned int st = BFC_LOAD(&ctl->team_state[x][t]);
+            if ((st & CLOSED) || (int)(st & 0xFFFFu) >= G) { ++t; continue; }
+            if (__hip_atomic_compare_exchange_strong(&ctl->team_state[x][t], &st, st + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT)) { me = (int)(st & 0xFFFFu); break; }
+        }
+        unsigned int members = 0u;
+        if (me == 0) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
+            for (;;) {
+                unsigned int st = BFC_LOAD(&ctl->team_state[x][t]);
+                const bool full = (int)(st & 0xFFFFu) >= G;
+                if (full || __builtin_amdgcn_s_memrealtime() - t0 > 2000ull) {
+                    if (__hip_atomic_compare_exchange_strong(&ctl->team_state[x][t], &st, st | CLOSED, __ATOMIC_RELAXED,
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        members = st & 0xFFFFu;
+                        break;
+                    }
+                } else __builtin_amdgcn_s_sleep(1);
+            }
+            BFC_STORE(&ctl->open_team[x], (unsigned int)(t + 1));
+        } else if (me > 0) {
+            for (unsigned int spins = 0; ; ++spins) {
+                const unsigned int st = BFC_LOAD(&ctl->team_state[x][t]);
+                if (st & CLOSED) { members = st & 0xFFFFu; break; }
+                if (spins > BFC_SPIN_LIMIT) { BFC_STORE(&ctl->error, 2u); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        L.u0 = (unsigned int)me;
+        L.u1 = members;
+        L.ok = t;
+    }
+    __syncthreads();
+    const int m = (int)L.u0, M = (int)L.u1, team = L.ok;
+    if (m < 0 || M < 1) return;             // no team slot left on this XCD (or the launch is being aborted)
+    __syncthreads();
+    load_displacements<NV>(s, L.upd);
+    unsigned int* bar = &ctl->team_bar[x][team];
+    unsigned int* gbm = ctl->bitmap[x][team];
+    unsigned int bar_target = 0u;
+    const bool has_angles = chain_has_angles(P);
+    for (unsigned int epoch = 0; ; ++epoch) {
+        if (m == 0 && tid == 0) BFC_STORE(&ctl->team_obj[x][team][epoch & 1u], BFC_ADD(&ctl->next_object, 1u));
+        if (!team_barrier(bar, bar_target, M, &ctl->error, &L.ok)) return;
+        const unsigned int oi = BFC_LOAD(&ctl->team_obj[x][team][epoch & 1u]);
+        if ((int64_t)oi >= P.n_objects) return;
+        const ims_object_t& o = P.objects[oi];
+        const ims_bf_slot_t bs = s.bf_slots[o.bf_state];
+        const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
+        const int tiles_x = (sl.nx + 1 + UT - 1) / UT, tiles_y = (sl.ny + 1 + UT - 1) / UT;
+        const int n_tiles = tiles_x * tiles_y;
+        const int n_words = (n_tiles + 31) >> 5;
+        const int64_t n_rounds = (o.n_phot + nrecalc - 1) / nrecalc;
+        const int64_t r_end = n_rounds < round_end ? n_rounds : (int64_t)round_end;
+        const int64_t pstart = pool_start[oi];
+        double added = 0.0;
+        ChargeTile ct;
+        ct.x0 = (int)floor(o.x0 + 0.5) - CT / 2;
+        ct.y0 = (int)floor(o.y0 + 0.5) - CT / 2;
+        ct.track = true;
+        ct.slot = bs;
+        for (int64_t r = round_begin; r < r_end; ++r) {
+            const int64_t j0 = r * nrecalc;
+            const int64_t j1 = (j0 + nrecalc < o.n_phot) ? j0 + nrecalc : o.n_phot;
+            const bool cont = o.n_phot > j1;           // the object goes on: its boundaries are recalculated after this round
+            // ---- phase A: this round's photons through the sensor ----
+            for (int e = tid; e < CT * CT; e += 256) L.tile[e] = 0.0f;
+            for (int e = tid; e < n_words; e += 256) L.bm[e] = 0u;
+            __syncthreads();
+            for (int64_t jb = j0 + (int64_t)m * 256; jb < j1; jb += (int64_t)M * 256) {
+                const int64_t j = jb + tid;
+                if (j < j1) {
+                    const int64_t i = pstart + j;
+                    Photon ph;
+                    ph.x = pool.x[i]; ph.y = pool.y[i]; ph.flux = pool.flux[i]; ph.dxdz = pool.dxdz[i]; ph.dydz = pool.dydz[i];
+                    ph.wl = pool.wavelength[i]; ph.pu = 0.0; ph.pv = 0.0; ph.t = 0.0;
+                    int ix, iy;
+                    Rng rng;
+                    rng_reset(rng);
+                    if (ph.flux != 0.0 && land(P, o, o.phot_first + j, rng, ph, true, has_angles, ix, iy)) {
+                        added += ph.flux;
+                        const int tx = ix - ct.x0, ty = iy - ct.y0;
+                        if (ph.flux == 1.0 && tx >= 0 && tx < CT && ty >= 0 && ty < CT) atomicAdd(&L.tile[ty * CT + tx], 1.0f);
+                        else {
+                            deposit_global(P, ct, ix, iy, ph.flux);
+                            const int di = ix - sl.xmin, dj = iy - sl.ymin;
+                            if (di >= 0 && di < sl.nx && dj >= 0 && dj < sl.ny) {
+                                const int t = (dj >> 4) * tiles_x + (di >> 4);
+                                atomicOr(&L.bm[t >> 5], 1u << (t & 31));
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            for (int e = tid; e < CT * CT; e += 256) {
+                const float v = L.tile[e];
+                if (v != 0.0f) {
+                    const int ix = ct.x0 + e % CT, iy = ct.y0 + e / CT;
+                    deposit_global(P, ct, ix, iy, (double)v);
+                    const int di = ix - sl.xmin, dj = iy - sl.ymin;
+                    if (di >= 0 && di < sl.nx && dj >= 0 && dj < sl.ny) {
+                        const int t = (dj >> 4) * tiles_x + (di >> 4);
+                        atomicOr(&L.bm[t >> 5], 1u << (t & 31));
+                    }
+                }
+            }
+            if (!cont) break;                          // last round: no recalculation follows (the delta charge stays)
+            __syncthreads();
+            for (int e = tid; e < n_words; e += 256)
+                if (L.bm[e] != 0u) __hip_atomic_fetch_or(&gbm[e], L.bm[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!team_barrier(bar, bar_target, M, &ctl->error, &L.ok)) return;
+            // ---- phase B1: updatePixelDistortions on the tiles within reach of this round's charge ----
+            for (int e = tid; e < n_words; e += 256) { L.bm[e] = BFC_LOAD(&gbm[e]); L.a1[e] = 0u; }
+            __syncthreads();
+            const int n1 = assign_tiles(n_tiles, m, M, L.mine, L.wave_cnt, [&](int t) {
+                const int tx = t % tiles_x, ty = t / tiles_x;
+                bool any = false;
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) any = any || bit_at(L.bm, tx + dx, ty + dy, tiles_x, tiles_y);
+                if (any) atomicOr(&L.a1[t >> 5], 1u << (t & 31));
+                return any;
+            });
+            for (int k = 0; k < n1; ++k) {
+                const int t = L.mine[k];
+                update_tile_q3<NV>(s, sl, (t % tiles_x) * UT, (t / tiles_x) * UT, changed, L.upd, true, 0u);
+                __syncthreads();
+            }
+            if (!team_barrier(bar, bar_target, M, &ctl->error, &L.ok)) return;
+            // ---- phase B2: bounds of the pixels whose polygon moved; the consumed delta charge is zeroed ----
+            const int n2 = assign_tiles(n_tiles, m, M, L.mine, L.wave_cnt, [&](int t) {
+                const int tx = t % tiles_x, ty = t / tiles_x;
+                return bit_at(L.a1, tx, ty, tiles_x, tiles_y) || bit_at(L.a1, tx + 1, ty, tiles_x, tiles_y) ||
+                       bit_at(L.a1, tx, ty + 1, tiles_x, tiles_y);
+            });
+            for (int k = 0; k < n2; ++k) {
+                const int t = L.mine[k];
+                const int tx = t % tiles_x, ty = t / tiles_x;
+                refresh_tile<NV>(s, sl, tx, ty, bit_at(L.a1, tx, ty, tiles_x, tiles_y), bit_at(L.a1, tx + 1, ty, tiles_x, tiles_y),
+                                 bit_at(L.a1, tx, ty + 1, tiles_x, tiles_y), bit_at(L.bm, tx, ty, tiles_x, tiles_y), changed);
+            }
+            if (m == 0)
+                for (int e = tid; e < n_words; e += 256) BFC_STORE(&gbm[e], 0u);
+            if (!team_barrier(bar, bar_target, M, &ctl->error, &L.ok)) return;
+        }
+        if (P.realized_flux != nullptr) {
+            const double tot = wave_sum(added);
+            if ((tid & 63) == 0 && tot != 0.0) unsafeAtomicAdd(P.realized_flux + oi, tot);
+        }
+    }
 }
 
 // ---------------- LSST_Flat ----------------
@@ -1334,6 +1653,42 @@ int ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sens
     return IMS_OK;
 }
 
+int ims_bf_chain_ctl_bytes(void) { return (int)sizeof(BfChainCtl); }
+
+int ims_bf_chain(const ims_render_params_t* params, const ims_photons_t* pool, const int64_t* pool_start,
+                 int32_t round_begin, int32_t round_end, int32_t nrecalc, const ims_sensor_t* sensor_host,
+                 unsigned char* changed_dev, void* ctl_dev, int32_t n_workers, int32_t team_size, void* stream)
+{
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (!pool || !pool_start || !changed_dev || !ctl_dev) return set_err(IMS_ERR_ARG, "pool/pool_start/changed/ctl is NULL");
+    if (!params->image || !params->sensor || !sensor_host) return set_err(IMS_ERR_ARG, "image/sensor is NULL");
+    if (round_begin < 0 || round_end <= round_begin || nrecalc <= 0) return set_err(IMS_ERR_ARG, "bad round range / nrecalc");
+    if (n_workers < 1 || team_size < 1 || n_workers > 2048) return set_err(IMS_ERR_ARG, "n_workers / team_size out of range");
+    if (sensor_host->qdist != 3 || (sensor_host->num_vertices != 4 && sensor_host->num_vertices != 8))
+        return set_err(IMS_ERR_UNSUPPORTED, "ims_bf_chain needs qdist 3 and 4 or 8 vertices per edge (use the per-round entry points)");
+    if (params->n_objects == 0) return IMS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(ctl_dev, 0, sizeof(BfChainCtl), st));
+    if (sensor_host->num_vertices == 4)
+        hipLaunchKernelGGL(k_bf_chain<4>, dim3((unsigned)n_workers), dim3(256), 0, st, *params, *pool, pool_start, round_begin,
+                           round_end, nrecalc, changed_dev, (BfChainCtl*)ctl_dev, team_size);
+    else
+        hipLaunchKernelGGL(k_bf_chain<8>, dim3((unsigned)n_workers), dim3(256), 0, st, *params, *pool, pool_start, round_begin,
+                           round_end, nrecalc, changed_dev, (BfChainCtl*)ctl_dev, team_size);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+int ims_bf_chain_status(const void* ctl_dev, int32_t* error)
+{
+    if (!ctl_dev || !error) return set_err(IMS_ERR_ARG, "ctl/error is NULL");
+    unsigned int e = 0;
+    HIP_TRY(hipMemcpy(&e, (const char*)ctl_dev + offsetof(BfChainCtl, error), sizeof(e), hipMemcpyDeviceToHost));
+    *error = (int32_t)e;
+    return IMS_OK;
+}
+
 int ims_run_plan(const ims_plan_item_t* items, int64_t n_items, const ims_sensor_t* sensor_dev,
                  const ims_sensor_t* sensor_host, unsigned char* changed_dev, void* const* streams, int32_t n_streams)
 {
@@ -1352,6 +1707,8 @@ int ims_run_plan(const ims_plan_item_t* items, int64_t n_items, const ims_sensor
         case IMS_PLAN_UPDATE:     rc = ims_sensor_update_distortions(sensor_dev, sensor_host, it.first_slot, it.n_slots, it.aux,
                                                                      it.n_tiles, changed_dev, it.tag, st); break;
         case IMS_PLAN_INIT:       rc = ims_sensor_init_boundaries(sensor_dev, sensor_host, it.first_slot, it.n_slots, st); break;
+        case IMS_PLAN_CHAIN:      rc = ims_bf_chain(it.params, it.pool, it.aux, it.first_slot, it.n_slots, (int32_t)it.n_tiles, sensor_host,
+                                                    changed_dev, it.aux2, (int32_t)it.tag, (int32_t)it.pad, st); break;
         case IMS_PLAN_RECORD:
         case IMS_PLAN_WAIT: {
             static std::vector<hipEvent_t> evs;          // library events of RECORD / WAIT items (one process per GPU)

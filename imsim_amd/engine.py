@@ -416,6 +416,13 @@ class Renderer:
         # round-count thresholds that cut the bright objects into concurrent chains (plan_lsst_image)
         self.chain_class_rounds = tuple(int(v) for v in os.environ.get("IMS_CHAIN_CLASSES", "40,6").split(",") if v)
         self.max_pool_photons = 300_000_000      # 48 B each
+        # persistent brighter-fatter chains (ims_bf_chain): workers per launch and the largest team; IMS_BF_CHAIN=0
+        # falls back to three launches per round
+        self.use_chain = os.environ.get("IMS_BF_CHAIN", "1") != "0"
+        self.chain_workers = int(os.environ.get("IMS_CHAIN_WORKERS", "160"))
+        self.chain_team = int(os.environ.get("IMS_CHAIN_TEAM", "16"))
+        self.chain_team_min = int(os.environ.get("IMS_CHAIN_TEAM_MIN", "4"))
+        self._chain_ctl = {}
         if scene.sensor is not None:
             self.init_boundaries(0, len(scene.sensor.slots))
 
@@ -554,7 +561,7 @@ class Renderer:
                     else:
                         bulk_items += [item, ("record", ev_base + k, stream)]
                 chains.append(dict(stream=cstream, ca=ca, tot=ctot, grp=cgrp, idx=cidx, offs=coffs, rounds=rounds,
-                                   slice_of_round=slice_of_round, ev_base=ev_base, waited=0))
+                                   slice_of_round=slice_of_round, ev_base=ev_base, waited=0, edges=edges))
             plan.extend(bulk_items)
             # The ordinary objects' fused launch is queued on the bulk stream right behind the pool slices, BEFORE the
             # ~1 300 short launches of the rounds: the host needs ~20 us per launch to enqueue those, and an item at
@@ -564,9 +571,33 @@ class Renderer:
                 part["bf_state"] = 0
                 add_render(part, normal, "bulk")
                 render_done = True
-            # 2. the sequential part: rounds of nrecalc photons per object through the sensor.  The
-            #    classes' rounds are interleaved in the plan so that the host enqueues all chains at
-            #    the same pace.
+            # 2. the sequential part: rounds of nrecalc photons per object through the sensor.
+            if self._chain_ok(grp):
+                # ONE persistent launch per class and slice of rounds (ims_bf_chain): teams of workgroups walk whole
+                # chains with team barriers instead of three launches per round.  The fewer objects are still
+                # active, the larger the teams (latency of the longest chain); many objects get small teams (throughput).
+                n_slices = max(len(ch["edges"]) - 1 for ch in chains)
+                for k in range(n_slices):
+                    for ch in chains:
+                        edges = ch["edges"]
+                        if k >= len(edges) - 1:
+                            continue
+                        ra, rb = edges[k], edges[k + 1]
+                        if k > 0:
+                            plan.append(("wait", ch["ev_base"] + k, ch["stream"]))
+                        ctot, cgrp = ch["tot"], ch["grp"]
+                        n_act = int(np.count_nonzero(ctot > ra * nrecalc))
+                        part = cgrp[:n_act].copy()
+                        start_t = self.torch.from_numpy(np.ascontiguousarray(ch["offs"][:n_act])).to(self.device)
+                        P, keep = upload(part, ch["idx"][:n_act], "chain")
+                        team = int(min(self.chain_team, max(self.chain_team_min, self.chain_workers // max(n_act, 1))))
+                        workers = int(min(self.chain_workers, n_act * team))
+                        photons = int((np.minimum(ctot[:n_act], rb * nrecalc) - ra * nrecalc).sum())
+                        plan.append(("chain", P, (keep, start_t), pool, start_t, photons, n_act, ch["stream"], ra, rb, int(nrecalc),
+                                     workers, team))
+                continue
+            #    Fallback (regions or sensor models ims_bf_chain does not take): three launches per round, the
+            #    classes' rounds interleaved in the plan so that the host enqueues all chains at the same pace.
             for r in range(max(ch["rounds"] for ch in chains)):
                 for ch in chains:
                     if r >= ch["rounds"]:
@@ -593,6 +624,30 @@ class Renderer:
             part["bf_state"] = 0
             add_render(part, normal, "bulk")
         return plan, realized_parts
+
+    def _chain_ok(self, grp):
+        """ims_bf_chain takes qdist 3, 4 or 8 vertices per edge and regions of at most 4096 16x16-cell tiles."""
+        m = self.scene.sensor.model
+        if not self.use_chain or m.qdist != 3 or m.num_vertices not in (4, 8):
+            return False
+        nx = grp["stamp_xmax"].astype(np.int64) - grp["stamp_xmin"] + 1
+        ny = grp["stamp_ymax"].astype(np.int64) - grp["stamp_ymin"] + 1
+        return bool(np.all(((nx + 1 + 15) // 16) * ((ny + 1 + 15) // 16) <= 4096))
+
+    def _chain_ctl_ptr(self, stream_name):
+        """control block of the persistent chain launches of one stream (launches on one stream are ordered)"""
+        if stream_name not in self._chain_ctl:
+            n = int(self.lib.ims_bf_chain_ctl_bytes())
+            self._chain_ctl[stream_name] = self.torch.zeros(n, dtype=self.torch.uint8, device=self.device)
+        return self._chain_ctl[stream_name].data_ptr()
+
+    def check_chains(self):
+        """Raise if a persistent chain launch gave up waiting for its workgroups (synchronises)."""
+        err = C.c_int32(0)
+        for name, t in self._chain_ctl.items():
+            _abi.check(self.lib.ims_bf_chain_status(t.data_ptr(), C.byref(err)), "ims_bf_chain_status")
+            if err.value:
+                raise _abi.ImsimHipError(f"brighter-fatter chain on stream '{name}' timed out waiting for its workgroups")
 
     def _compile_plan(self, plan):
         """Turn a plan into ims_plan_item_t arrays (one per stretch between host-side slot-table
@@ -622,6 +677,11 @@ class Renderer:
             elif kind == "shoot_pool":
                 it.kind, it.params, it.pool, it.aux = _abi.IMS_PLAN_SHOOT_POOL, C.addressof(item[1]), C.addressof(item[3]), item[4].data_ptr()
                 it.stream = self.STREAMS[item[7]]
+            elif kind == "chain":
+                it.kind, it.params, it.pool, it.aux = _abi.IMS_PLAN_CHAIN, C.addressof(item[1]), C.addressof(item[3]), item[4].data_ptr()
+                it.stream = self.STREAMS[item[7]]
+                it.first_slot, it.n_slots, it.n_tiles, it.tag, it.pad = item[8], item[9], item[10], item[11], item[12]
+                it.aux2 = self._chain_ctl_ptr(item[7])
             elif kind == "record":
                 it.kind, it.n_slots, it.stream = _abi.IMS_PLAN_RECORD, item[1], self.STREAMS[item[2]]
             elif kind == "wait":
@@ -715,7 +775,7 @@ class Renderer:
             self.execute_plan(plan, compiled)
         launch.plan = plan
         launch.photons = sum(it[3] for it in plan if it[0] == "render") + sum(it[5] for it in plan if it[0] == "shoot_pool")
-        launch.object_rows = sum(it[4] for it in plan if it[0] == "render") + sum(it[6] for it in plan if it[0] in ("shoot_pool", "acc_pool"))
+        launch.object_rows = sum(it[4] for it in plan if it[0] == "render") + sum(it[6] for it in plan if it[0] in ("shoot_pool", "acc_pool", "chain"))
         launch.pool_photons = sum(it[5] for it in plan if it[0] == "shoot_pool")
         # the two photon-pipeline kernels the library can time (ims_enable_timing): launches per replay and
         # their algorithmic bytes.  Fused render: f64 image RMW (16 B/photon); pool shoot: the six f64

@@ -40,7 +40,7 @@ extern "C" {
 #define IMS_ERR_NO_DEVICE  -3
 #define IMS_ERR_UNSUPPORTED -4
 
-#define IMS_ABI_VERSION 5
+#define IMS_ABI_VERSION 6
 
 /* ---- object flags ---- */
 #define IMS_OBJ_FAINT   1   /* nominal_flux < max_flux_simple: no photon ops, no sensor (stamp.py:435-465,555-556) */
@@ -370,6 +370,26 @@ int  ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sen
                                    int32_t first_slot, int32_t n_slots, const int64_t* tile_prefix_dev,
                                    int64_t n_tiles, unsigned char* changed_dev, uint32_t tag, void* stream);
 
+/* ---- persistent brighter-fatter chain (LSST_Image mode) ----
+ * In LSST_Image mode the sensor accumulates into the object's OWN stamp (imsim/stamp.py:562-569), so a bright object's
+ * pixel boundaries are recalculated from its own charge every `nrecalc` electrons: a chain of rounds
+ * (accumulate nrecalc photons | updatePixelDistortions | refresh bounds) that only depends on the object's earlier rounds.
+ * ims_bf_chain runs rounds [round_begin, round_end) of EVERY object of `params` in ONE launch: n_workers persistent
+ * workgroups form teams of up to team_size on the XCD they run on, a team takes objects off a queue (row order: put
+ * the longest chains first) and walks their rounds with team barriers in place of kernel boundaries.
+ * Object row i: n_phot = ALL photons of the object, bf_state = its private slot (regions up to 1023 pixels on a side,
+ * qdist 3, 4 or 8 vertices per edge -- otherwise use ims_accumulate_segments + ims_sensor_update_distortions per round);
+ * photon j of the object is read from the pool at pool_start[i] + j and draws from stream phot_first + j.  Rounds
+ * beyond an object's last are skipped; the recalculation after an object's last round is not run (as in the
+ * reference, where the next object starts from fresh boundaries).  ctl_dev: device scratch of
+ * ims_bf_chain_ctl_bytes() bytes, zeroed by the call; changed_dev as for ims_sensor_update_distortions.
+ * ims_bf_chain_status (synchronises): error != 0 when a launch gave up waiting for its workgroups. */
+int  ims_bf_chain_ctl_bytes(void);
+int  ims_bf_chain(const ims_render_params_t* params, const ims_photons_t* pool, const int64_t* pool_start,
+                  int32_t round_begin, int32_t round_end, int32_t nrecalc, const ims_sensor_t* sensor_host,
+                  unsigned char* changed_dev, void* ctl_dev, int32_t n_workers, int32_t team_size, void* stream);
+int  ims_bf_chain_status(const void* ctl_dev, int32_t* error);
+
 /* ---- FFT branch: LSST_SiliconBuilder.draw, method == 'fft' (imsim/stamp.py:482-525) ----
  * For very bright objects (nominal_flux >= 1e6 and max_sb > fft_sb_thresh, imsim/stamp.py:275-277,
  * imsim/psf_utils.py:152-239) the reference draws Convolve([gal] + psfs) with GalSim's FFT renderer,
@@ -456,6 +476,8 @@ int  ims_fft_finish(const ims_fft_params_t* params, const ims_fft_object_t* obje
 #define IMS_PLAN_INIT       5   /* ims_sensor_init_boundaries(first_slot, n_slots) */
 #define IMS_PLAN_RECORD     6   /* record library event number n_slots on the item's stream */
 #define IMS_PLAN_WAIT       7   /* make the item's stream wait for library event number n_slots */
+#define IMS_PLAN_CHAIN      8   /* ims_bf_chain(params, pool, aux = pool_start, rounds [first_slot, n_slots), nrecalc = n_tiles,
+                                   ctl = aux2, n_workers = tag, team_size = pad) */
 typedef struct ims_plan_item {
     int32_t kind;
     int32_t stream;
@@ -466,6 +488,7 @@ typedef struct ims_plan_item {
     int64_t n_tiles;
     uint32_t tag;                        /* IMS_PLAN_UPDATE: the bf_tag of the launches that deposited the charge (0 = no tile skipping) */
     uint32_t pad;
+    void*    aux2;                       /* device pointer, see kinds */
 } ims_plan_item_t;
 int  ims_run_plan(const ims_plan_item_t* items, int64_t n_items, const ims_sensor_t* sensor_dev,
                   const ims_sensor_t* sensor_host, unsigned char* changed_dev, void* const* streams, int32_t n_streams);

@@ -802,7 +802,14 @@ struct BfChainCtl {
     unsigned int team_bar[N_XCD][BFC_MAX_TEAMS];
     unsigned int team_obj[N_XCD][BFC_MAX_TEAMS][2];
     unsigned int bitmap[N_XCD][BFC_MAX_TEAMS][BFC_WORDS];
+    unsigned long long prof[16];                    // -DIMS_BFC_PROFILE: 10 ns ticks per phase of the team that ran object 0
 };
+#ifdef IMS_BFC_PROFILE
+#define BFC_TICK(k) do { if (prof_on && tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); \
+                         ctl->prof[k] += t_ - prof_t; prof_t = t_; } } while (0)
+#else
+#define BFC_TICK(k) do { } while (0)
+#endif
 
 #define BFC_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define BFC_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -962,6 +969,11 @@ __global__ __launch_bounds__(256) void k_bf_chain(const ims_render_params_t P, c
         const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
         const int tiles_x = (sl.nx + 1 + UT - 1) / UT, tiles_y = (sl.ny + 1 + UT - 1) / UT;
         const int n_tiles = tiles_x * tiles_y;
+#ifdef IMS_BFC_PROFILE
+        const bool prof_on = (oi == 0u && m == 0);
+        unsigned long long prof_t = __builtin_amdgcn_s_memrealtime();
+        if (prof_on && tid == 0) { ctl->prof[8] = (unsigned long long)M; ctl->prof[9] = (unsigned long long)n_tiles; }
+#endif
         const int n_words = (n_tiles + 31) >> 5;
         const int64_t n_rounds = (o.n_phot + nrecalc - 1) / nrecalc;
         const int64_t r_end = n_rounds < round_end ? n_rounds : (int64_t)round_end;
@@ -1022,7 +1034,9 @@ __global__ __launch_bounds__(256) void k_bf_chain(const ims_render_params_t P, c
             __syncthreads();
             for (int e = tid; e < n_words; e += 256)
                 if (L.bm[e] != 0u) __hip_atomic_fetch_or(&gbm[e], L.bm[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            BFC_TICK(0);
             if (!team_barrier(bar, bar_target, M, &ctl->error, &L.ok)) return;
+            BFC_TICK(1);
             // ---- phase B1: updatePixelDistortions on the tiles within reach of this round's charge ----
             for (int e = tid; e < n_words; e += 256) { L.bm[e] = BFC_LOAD(&gbm[e]); L.a1[e] = 0u; }
             __syncthreads();
@@ -1034,12 +1048,18 @@ __global__ __launch_bounds__(256) void k_bf_chain(const ims_render_params_t P, c
                 if (any) atomicOr(&L.a1[t >> 5], 1u << (t & 31));
                 return any;
             });
+            BFC_TICK(2);
+#ifdef IMS_BFC_PROFILE
+            if (prof_on && tid == 0) { ctl->prof[10] += (unsigned long long)n1; ctl->prof[12] += 1ull; }
+#endif
             for (int k = 0; k < n1; ++k) {
                 const int t = L.mine[k];
                 update_tile_q3<NV>(s, sl, (t % tiles_x) * UT, (t / tiles_x) * UT, changed, L.upd, true, 0u);
                 __syncthreads();
             }
+            BFC_TICK(3);
             if (!team_barrier(bar, bar_target, M, &ctl->error, &L.ok)) return;
+            BFC_TICK(4);
             // ---- phase B2: bounds of the pixels whose polygon moved; the consumed delta charge is zeroed ----
             const int n2 = assign_tiles(n_tiles, m, M, L.mine, L.wave_cnt, [&](int t) {
                 const int tx = t % tiles_x, ty = t / tiles_x;
@@ -1054,7 +1074,12 @@ __global__ __launch_bounds__(256) void k_bf_chain(const ims_render_params_t P, c
             }
             if (m == 0)
                 for (int e = tid; e < n_words; e += 256) BFC_STORE(&gbm[e], 0u);
+            BFC_TICK(5);
+#ifdef IMS_BFC_PROFILE
+            if (prof_on && tid == 0) ctl->prof[11] += (unsigned long long)n2;
+#endif
             if (!team_barrier(bar, bar_target, M, &ctl->error, &L.ok)) return;
+            BFC_TICK(6);
         }
         if (P.realized_flux != nullptr) {
             const double tot = wave_sum(added);

@@ -416,12 +416,12 @@ class Renderer:
         # round-count thresholds that cut the bright objects into concurrent chains (plan_lsst_image)
         self.chain_class_rounds = tuple(int(v) for v in os.environ.get("IMS_CHAIN_CLASSES", "40,6").split(",") if v)
         self.max_pool_photons = 300_000_000      # 48 B each
-        # persistent brighter-fatter chains (ims_bf_chain): workers per launch and the largest team; IMS_BF_CHAIN=0
-        # falls back to three launches per round
-        self.use_chain = os.environ.get("IMS_BF_CHAIN", "1") != "0"
-        self.chain_workers = int(os.environ.get("IMS_CHAIN_WORKERS", "160"))
-        self.chain_team = int(os.environ.get("IMS_CHAIN_TEAM", "16"))
-        self.chain_team_min = int(os.environ.get("IMS_CHAIN_TEAM_MIN", "4"))
+        # persistent brighter-fatter chains (ims_bf_chain): most workgroups a launch may use and the largest team.
+        # Off by default: measured slower than three launches per round on MI355X ("persistent chain");
+        # IMS_BF_CHAIN=1 turns it on for the slices of rounds where every active object gets a full team.
+        self.use_chain = os.environ.get("IMS_BF_CHAIN", "0") != "0"
+        self.chain_workers = int(os.environ.get("IMS_CHAIN_WORKERS", "320"))
+        self.chain_team = int(os.environ.get("IMS_CHAIN_TEAM", "40"))
         self._chain_ctl = {}
         if scene.sensor is not None:
             self.init_boundaries(0, len(scene.sensor.slots))
@@ -571,54 +571,50 @@ class Renderer:
                 part["bf_state"] = 0
                 add_render(part, normal, "bulk")
                 render_done = True
-            # 2. the sequential part: rounds of nrecalc photons per object through the sensor.
-            if self._chain_ok(grp):
-                # ONE persistent launch per class and slice of rounds (ims_bf_chain): teams of workgroups walk whole
-                # chains with team barriers instead of three launches per round.  The fewer objects are still
-                # active, the larger the teams (latency of the longest chain); many objects get small teams (throughput).
-                n_slices = max(len(ch["edges"]) - 1 for ch in chains)
-                for k in range(n_slices):
-                    for ch in chains:
-                        edges = ch["edges"]
-                        if k >= len(edges) - 1:
-                            continue
-                        ra, rb = edges[k], edges[k + 1]
-                        if k > 0:
-                            plan.append(("wait", ch["ev_base"] + k, ch["stream"]))
-                        ctot, cgrp = ch["tot"], ch["grp"]
-                        n_act = int(np.count_nonzero(ctot > ra * nrecalc))
+            # 2. the sequential part: rounds of nrecalc photons per object through the sensor.  Per class a list of
+            #    units (one round = accumulate + update, or one persistent launch over a slice of rounds); the classes'
+            #    units are merged round-robin so that the host enqueues all chains at the same pace.
+            chain_ok = self._chain_ok(grp)
+            units = []
+            for ch in chains:
+                ctot, cgrp, edges = ch["tot"], ch["grp"], ch["edges"]
+                mine = []
+                for k in range(len(edges) - 1):
+                    ra, rb = edges[k], edges[k + 1]
+                    head = [("wait", ch["ev_base"] + k, ch["stream"])] if k > 0 else []
+                    n_act = int(np.count_nonzero(ctot > ra * nrecalc))
+                    # A persistent launch (ims_bf_chain) pays when every object still active gets a team as wide as a
+                    # round (nrecalc / 256 workgroups): then a round costs three team barriers instead of three
+                    # launches.  With many active objects the per-round launches keep the whole GPU busy instead.
+                    team = int(min(self.chain_team, (nrecalc + 255) // 256))
+                    if chain_ok and rb - ra >= 2 and n_act * team <= self.chain_workers:
                         part = cgrp[:n_act].copy()
                         start_t = self.torch.from_numpy(np.ascontiguousarray(ch["offs"][:n_act])).to(self.device)
                         P, keep = upload(part, ch["idx"][:n_act], "chain")
-                        team = int(min(self.chain_team, max(self.chain_team_min, self.chain_workers // max(n_act, 1))))
-                        workers = int(min(self.chain_workers, n_act * team))
                         photons = int((np.minimum(ctot[:n_act], rb * nrecalc) - ra * nrecalc).sum())
-                        plan.append(("chain", P, (keep, start_t), pool, start_t, photons, n_act, ch["stream"], ra, rb, int(nrecalc),
-                                     workers, team))
-                continue
-            #    Fallback (regions or sensor models ims_bf_chain does not take): three launches per round, the
-            #    classes' rounds interleaved in the plan so that the host enqueues all chains at the same pace.
-            for r in range(max(ch["rounds"] for ch in chains)):
-                for ch in chains:
-                    if r >= ch["rounds"]:
+                        mine.append(head + [("chain", P, (keep, start_t), pool, start_t, photons, n_act, ch["stream"], ra, rb,
+                                             int(nrecalc), n_act * team, team)])
                         continue
-                    k = int(ch["slice_of_round"][r])
-                    if k > ch["waited"]:
-                        plan.append(("wait", ch["ev_base"] + k, ch["stream"]))
-                        ch["waited"] = k
-                    ctot, cgrp = ch["tot"], ch["grp"]
-                    n_act = int(np.count_nonzero(ctot > r * nrecalc))
-                    part = cgrp[:n_act].copy()
-                    part["phot_first"] = cgrp["phot_first"][:n_act] + r * nrecalc
-                    part["n_phot"] = np.minimum(nrecalc, ctot[:n_act] - r * nrecalc)
-                    start_t = self.torch.from_numpy(ch["offs"][:n_act] + r * nrecalc).to(self.device)
-                    P, keep = upload(part, ch["idx"][:n_act], "acc_pool")
-                    tag = (r % 255 + 1) if self.use_bf_tags else 0      # marks the tiles this round's charge lands in
-                    P.bf_tag = tag
-                    plan.append(("acc_pool", P, (keep, start_t), pool, start_t, int(part["n_phot"].sum()), n_act, ch["stream"]))
-                    n_cont = int(np.count_nonzero(ctot > (r + 1) * nrecalc))
-                    if n_cont:
-                        plan.append(("update", n0 + ch["ca"], n_cont, ch["stream"], tag))
+                    for r in range(ra, rb):
+                        n_act = int(np.count_nonzero(ctot > r * nrecalc))
+                        part = cgrp[:n_act].copy()
+                        part["phot_first"] = cgrp["phot_first"][:n_act] + r * nrecalc
+                        part["n_phot"] = np.minimum(nrecalc, ctot[:n_act] - r * nrecalc)
+                        start_t = self.torch.from_numpy(ch["offs"][:n_act] + r * nrecalc).to(self.device)
+                        P, keep = upload(part, ch["idx"][:n_act], "acc_pool")
+                        tag = (r % 255 + 1) if self.use_bf_tags else 0      # marks the tiles this round's charge lands in
+                        P.bf_tag = tag
+                        unit = head + [("acc_pool", P, (keep, start_t), pool, start_t, int(part["n_phot"].sum()), n_act, ch["stream"])]
+                        head = []
+                        n_cont = int(np.count_nonzero(ctot > (r + 1) * nrecalc))
+                        if n_cont:
+                            unit.append(("update", n0 + ch["ca"], n_cont, ch["stream"], tag))
+                        mine.append(unit)
+                units.append(mine)
+            for k in range(max(len(u) for u in units)):
+                for u in units:
+                    if k < len(u):
+                        plan.extend(u[k])
         if len(normal) and not render_done:
             part = objects[normal].copy()
             part["bf_state"] = 0
@@ -896,3 +892,5 @@ class Renderer:
 
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)
+        if self._chain_ctl:
+            self.check_chains()

@@ -230,6 +230,32 @@ def test_c3_lsst_image_mode_is_bit_exact(torch_cuda):
         assert_bits_equal(ga[name], orc.sensor_array(name), f"sensor {name}")
 
 
+@pytest.mark.parametrize("team,workers", [(4, 2048), (40, 2048), (1, 64)])
+def test_persistent_chain_kernel_is_bit_exact(torch_cuda, team, workers):
+    """ims_bf_chain (one persistent launch walks whole brighter-fatter chains with team barriers) gives the image,
+    realized flux and pixel-boundary state of the per-round launches and of the oracle, for any team size."""
+    from imsim_amd.engine import Renderer
+    from oracle import orc_loader
+    scene, objects = _c3_case(n_obj=200)
+    r = Renderer(scene)
+    r.use_chain, r.chain_team, r.chain_workers = True, team, workers
+    real = torch_cuda.zeros(len(objects), dtype=torch_cuda.float64, device="cuda")
+    plan, parts = r.plan_lsst_image(objects, nrecalc=1000, want_realized=True)
+    assert sum(1 for it in plan if it[0] == "chain") >= 2
+    r.execute_plan(plan)
+    for index, tmp in parts:
+        real.index_add_(0, index, tmp)
+    r.synchronize()
+    orc = orc_loader.OracleScene(scene)
+    real_o = np.zeros(len(objects))
+    orc.render_lsst_image(objects, nrecalc=1000, realized=real_o)
+    assert_bits_equal(r.image_numpy(), orc.image, "image (persistent chain)")
+    assert_bits_equal(real.cpu().numpy(), real_o, "realized flux")
+    ga = _sensor_arrays_gpu(r)
+    for name in ("boundary", "bounds", "delta"):
+        assert_bits_equal(ga[name], orc.sensor_array(name), f"sensor {name}")
+
+
 def test_pooling_mode_brighter_fatter_is_bit_exact(torch_cuda):
     """Photon-pooling semantics (photon_pooling.py:141-160): the whole CCD is one brighter-fatter
     region, recalculated once per batch from the charge accumulated since the last recalc."""

@@ -184,7 +184,16 @@ def double_gaussian_xvalue(x, y, fwhm1=0.6, fwhm2=0.12, wgt1=1.0, wgt2=0.1):
     return (wgt1 * g1 + wgt2 * g2) / (wgt1 + wgt2)
 
 
-def gal_stamp_size(kind, hlr, max_scale, nmax=NMAX, jac=None, nominal_flux=None, noise_var=800.0, sb_flux=None):
+def _sersic_n_of(kind, sersic_n=None):
+    """Sersic index per object: the catalog's quantised `sersic_n` where given, else 1 / 4 for kinds 1 / 2"""
+    n = np.where(kind == 1, 1.0, np.where(kind == 2, 4.0, 0.0))
+    if sersic_n is not None:
+        sn = np.asarray(sersic_n, dtype=np.float64)
+        n = np.where(((kind == 1) | (kind == 2)) & (sn > 0), np.round(sn * 20.0) / 20.0, n)
+    return n
+
+
+def gal_stamp_size(kind, hlr, max_scale, nmax=NMAX, jac=None, nominal_flux=None, noise_var=800.0, sb_flux=None, sersic_n=None):
     """get_gal_stamp_size (stamp_utils.py:158-220).  First the GoodImageSize of the object convolved with the
     DoubleGaussian proxy PSF; for bright objects (more than 10 photons per stamp pixel on average) or stamps
     beyond Nmax the size follows from a surface-brightness limit of sqrt(noise_var)/8 via
@@ -194,10 +203,10 @@ def gal_stamp_size(kind, hlr, max_scale, nmax=NMAX, jac=None, nominal_flux=None,
     sizes = np.zeros(len(hlr), dtype=np.int64)
     own = np.zeros(len(hlr), dtype=np.int64)
     dg_stepk = min(gaussian_stepk(0.6 / 2.355, FT_DEFAULT), gaussian_stepk(0.12 / 2.355, FT_DEFAULT))
-    for k, n in enumerate(SERSIC_N):
-        sel = kind == k + 1
-        if not sel.any():
-            continue
+    n_obj = _sersic_n_of(kind, sersic_n)
+    n_distinct = [float(n) for n in np.unique(n_obj) if n > 0]
+    for n in n_distinct:
+        sel = n_obj == n
         r = max(_radius_enclosing(tables.sersic_table(n), 1.0 - FT_DEFAULT), STEPK_MIN_HLR)
         stepk_gal = np.pi / (r * hlr[sel] * max_scale[sel])
         stepk = 1.0 / np.sqrt(1.0 / stepk_gal ** 2 + 1.0 / dg_stepk ** 2)
@@ -216,8 +225,8 @@ def gal_stamp_size(kind, hlr, max_scale, nmax=NMAX, jac=None, nominal_flux=None,
         def phot_size(level):
             out = np.zeros(len(idx), dtype=np.int64)
             psf_size = _phot_stamp_size1(psf_n0, lambda h: _edge_max(double_gaussian_xvalue, h), level, nmax)[0]
-            for k, n in enumerate(SERSIC_N):
-                m = kind[idx] == k + 1
+            for n in n_distinct:
+                m = n_obj[idx] == n
                 if not m.any():
                     continue
                 ii = idx[m]
@@ -236,10 +245,12 @@ def gal_stamp_size(kind, hlr, max_scale, nmax=NMAX, jac=None, nominal_flux=None,
 
 def build_object_table(cat, phot_flux, noise_var=800.0, sed_table=0, max_flux_simple=100.0,
                        winv=(1.0 / PIXEL_SCALE, 0.0, 0.0, 1.0 / PIXEL_SCALE), airmass=1.2, raw_seeing=0.7,
-                       band="r", image_bounds=None, dcr=(0.0, 0.0, 1.0), stamp_size=None):
+                       band="r", image_bounds=None, dcr=(0.0, 0.0, 1.0), stamp_size=None, sersic_index=None):
     """Vectorised LSST_SiliconBuilder.setup for a whole catalog -> OBJECT_DTYPE rows.
 
-    Objects with phot_flux == 0 are dropped (SkipThisObject, stamp.py:199-202)."""
+    Objects with phot_flux == 0 are dropped (SkipThisObject, stamp.py:199-202).
+    sersic_index: {n: radial table id} of the scene (configs.add_sersic_tables) when the catalog carries Sersic
+    indices other than 1 and 4 in cat["sersic_n"]; a catalog index with no table raises."""
     n = len(cat["x"])
     kind = cat["kind"]
     nominal = cat["nominal_flux"]
@@ -254,6 +265,15 @@ def build_object_table(cat, phot_flux, noise_var=800.0, sed_table=0, max_flux_si
     knots, streak, image = kind == KIND_KNOTS, kind == KIND_STREAK, kind == KIND_IMAGE
     obj["prof_table"] = np.where(kind == 0, IMS_PROF_POINT, np.where(knots, IMS_PROF_KNOTS, np.where(streak, IMS_PROF_BOX,
                                  np.where(image, IMS_PROF_IMAGE, kind - 1))))
+    sersic_n = cat.get("sersic_n") if isinstance(cat, dict) else None
+    n_obj = _sersic_n_of(kind, sersic_n)
+    odd = (n_obj > 0) & (n_obj != 1.0) & (n_obj != 4.0)
+    if odd.any():
+        index = sersic_index or {}
+        missing = sorted(set(np.round(n_obj[odd], 2).tolist()) - set(index))
+        if missing:
+            raise ValueError(f"no radial table for Sersic index {missing}: call configs.add_sersic_tables(scene, cat['sersic_n'])")
+        obj["prof_table"][odd] = [index[round(float(n), 2)] for n in n_obj[odd]]
     obj["prof_scale"] = np.where(kind == 0, 0.0, cat["hlr"])
     if knots.any():
         obj["prof_scale"][knots] = cat["hlr"][knots] / 1.1774100225154747      # Gaussian sigma of the knots' parent profile
@@ -279,7 +299,7 @@ def build_object_table(cat, phot_flux, noise_var=800.0, sed_table=0, max_flux_si
     obj["jac"] = jac
     obj["winv"] = np.broadcast_to(np.asarray(winv, dtype=np.float64), (n, 4))
     obj["dcr_tanz"], obj["dcr_sinp"], obj["dcr_cosp"] = dcr
-    obj["sed_table"] = sed_table
+    obj["sed_table"] = cat["sed_table"] if isinstance(cat, dict) and cat.get("sed_table") is not None else sed_table
     obj["sed_wave"] = 0.0
     obj["flags"] = np.where(nominal < max_flux_simple, IMS_OBJ_FAINT, 0)
     obj["bf_state"] = 0
@@ -298,7 +318,7 @@ def build_object_table(cat, phot_flux, noise_var=800.0, sed_table=0, max_flux_si
             max_scale = np.sqrt(0.5 * (s1 + s2))
             sb = cat["sb_flux"][gal] if "sb_flux" in cat else None
             size[gal] = gal_stamp_size(kind[gal], cat["hlr"][gal], max_scale, jac=jac[gal], nominal_flux=nominal[gal],
-                                       noise_var=noise_var, sb_flux=sb)
+                                       noise_var=noise_var, sb_flux=sb, sersic_n=n_obj[gal])
             # knots: GoodImageSize of the parent Gaussian; streaks: of the box (stepk = pi / max(length, width)),
             # both convolved with the proxy PSF (first branch of get_gal_stamp_size)
             dg_stepk = min(gaussian_stepk(0.6 / 2.355, FT_DEFAULT), gaussian_stepk(0.12 / 2.355, FT_DEFAULT))

@@ -613,8 +613,20 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
         if ic is None:
             raise GalSimConfigError("only input.instance_catalog object sources are supported on this path")
         parsed = instcat.parse_objects(ev.value(ic["file_name"]))
+        sed_dir = ev.value(ic["sed_dir"]) if "sed_dir" in ic else os.environ.get("SIMS_SED_LIBRARY_DIR")
+        cat_file = ev.value(ic["file_name"])
         cat = instcat.to_catalog(parsed, optics.img_wcs, nx, ny, float(np.trapezoid(thr, wl)), float(meta.get("exptime") or 30.0),
-                                 sort_mag=bool(ic.get("sort_mag", True)), edge_pix=int(ic.get("edge_pix", 100)))
+                                 sort_mag=bool(ic.get("sort_mag", True)), edge_pix=int(ic.get("edge_pix", 100)),
+                                 sed_dir=sed_dir, inst_dir=os.path.dirname(os.path.abspath(cat_file)), bandpass=(wl, thr))
+        if cat["missing_seds"]:
+            res.ignored.append(f"{len(cat['missing_seds'])} SED file(s) not found in sed_dir or beside the catalog: flat-in-photons "
+                               f"SED without redshift / dust for their objects (first: {cat['missing_seds'][0]})")
+        if np.any(parsed["dust"][:, 0] != 0.0):
+            res.ignored.append("internal dust (Av, Rv): not applied -- nor does the reference (imsim/instcat.py:402-403)")
+        if cat["sed_tables"] is not None:                      # per-object wavelength distributions behind the flat fallback table
+            flat = tables.inverse_cdf_table(wl, thr, n_pts=cat["sed_tables"].shape[1])[None, :]
+            scene.sed_tables = np.concatenate([flat, cat["sed_tables"]])
+        configs.add_sersic_tables(scene, cat["sersic_n"])       # radial tables for every Sersic index of the catalog (:511-517)
         phot = catalog.realize_fluxes(cat["nominal_flux"], seed_ccd)
         scene.image_profiles = cat.get("images") or None          # FITS-stamp objects (instcat.py:552-561)
         renderer = Renderer(scene, device)

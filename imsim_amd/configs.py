@@ -33,6 +33,35 @@ def standard_tables():
     return tables.stack_radial(tabs)
 
 
+def quantise_sersic_n(n):
+    """`n = round(n * 20.) / 20.` (imsim/instcat.py:511-517): the Sersic index grid of the catalog reader"""
+    return np.round(np.asarray(n, dtype=np.float64) * 20.0) / 20.0
+
+
+def add_sersic_tables(scene, n_values):
+    """Make sure the scene holds a radial (photon-shooting) table for every Sersic index in n_values (quantised to
+    0.05 and limited to GalSim's range 0.3 <= n <= 6.2).  Tables 0 / 1 are always n = 1 / 4; further indices are
+    appended behind whatever the scene already holds (PSF tables).  Sets scene.sersic_index {n: radial table id} and
+    scene.sersic_extra_n (their order defines the k-table ids of the FFT branch, FftDrawer)."""
+    n_values = quantise_sersic_n(n_values)
+    n_values = n_values[n_values > 0.0]
+    if np.any((n_values < 0.3) | (n_values > 6.2)):
+        raise ValueError("Sersic index outside GalSim's range 0.3 <= n <= 6.2")
+    index = dict(getattr(scene, "sersic_index", None) or {1.0: 0, 4.0: 1})
+    extra = list(getattr(scene, "sersic_extra_n", ()))
+    new = [float(n) for n in sorted(set(np.round(n_values, 2).tolist())) if float(n) not in index]
+    if new:
+        base = len(np.atleast_2d(scene.radial_r2))
+        tabs = [tables.sersic_table(n) for n in new]
+        scene.radial_r2 = np.concatenate([np.atleast_2d(scene.radial_r2), np.stack([t[0] for t in tabs])])
+        scene.radial_cdf = np.concatenate([np.atleast_2d(scene.radial_cdf), np.stack([t[1] for t in tabs])])
+        for j, n in enumerate(new):
+            index[n] = base + j
+        extra += new
+    scene.sersic_index, scene.sersic_extra_n = index, tuple(extra)
+    return index
+
+
 def r_band_sed_table():
     wl, thr = tables.synthetic_r_band()
     return tables.inverse_cdf_table(wl, thr)[None, :], tables.effective_wavelength(wl, thr)
@@ -242,7 +271,8 @@ def c3_objects(cat, phot, scene, nrecalc=10000, bf_private=True):
     winv, p0 = local_wcs_inverse(scene.optics.img_wcs, cat["x"], cat["y"])
     tanz, sinp, cosp = dcr_angles(p0, math.radians(VISIT["latitude"]), math.radians(VISIT["hour_angle"]),
                                   math.radians(VISIT["ra"]))
-    objects, sizes = catalog.build_object_table(cat, phot, airmass=VISIT["airmass"], raw_seeing=VISIT["raw_seeing"])
+    objects, sizes = catalog.build_object_table(cat, phot, airmass=VISIT["airmass"], raw_seeing=VISIT["raw_seeing"],
+                                                sersic_index=getattr(scene, "sersic_index", None))
     keep = phot > 0
     objects["winv"] = winv[keep]
     objects["dcr_tanz"], objects["dcr_sinp"], objects["dcr_cosp"] = tanz[keep], sinp[keep], cosp[keep]

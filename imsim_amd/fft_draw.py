@@ -104,6 +104,18 @@ def use_fft(nominal_flux, kind, hlr, fwhm_total, fft_sb_thresh):
     return cand & (max_surface_brightness(nominal_flux, kind, hlr, fwhm_total) > fft_sb_thresh)
 
 
+def profile_ktable_ids(scene, prof_table, n_extra_ktables=0, n_base=2):
+    """k-table id of every object from its radial table id: tables 0 / 1 (n = 1 / 4) keep their ids, the scene's
+    further Sersic indices sit behind the n_extra_ktables PSF tables in the order of scene.sersic_extra_n;
+    everything else (points) is -1."""
+    prof_table = np.asarray(prof_table)
+    out = np.where((prof_table == 0) | (prof_table == 1), prof_table, -1).astype(np.int32)
+    index = getattr(scene, "sersic_index", None) or {}
+    for j, n in enumerate(getattr(scene, "sersic_extra_n", ()) or ()):
+        out[prof_table == index[n]] = n_base + n_extra_ktables + j
+    return out
+
+
 def build_fft_objects(objects, fft_flux, prof_ktable, pixel_scale=0.2):
     """OBJECT_DTYPE rows (geometry as for photon shooting) -> FFT_OBJECT_DTYPE rows, grouped by FFT
     size.  The profile affine is expressed along the pixel axes: jac' = s * winv * jac."""
@@ -169,12 +181,16 @@ class FftDrawer:
     def __init__(self, renderer, kpsf, sersic_indices=(1.0, 4.0), add_noise=True, diffraction_fft=None, wavelength=622.2,
                  extra_ktables=()):
         """extra_ktables: radial k-tables on the common q grid appended after the profile tables (the
-        VonKarman / Airy tables of atmospheric_fft_kpsf, addressed by IMS_KPSF_TABLE components)."""
+        VonKarman / Airy tables of atmospheric_fft_kpsf, addressed by IMS_KPSF_TABLE components).  The k-tables of the
+        scene's further Sersic indices (Scene.sersic_extra_n, configs.add_sersic_tables) follow behind those:
+        profile_ktable_ids maps an object's radial table id to its k-table id."""
         self.r = renderer
         self.torch = renderer.torch
+        extra_n = tuple(getattr(renderer.scene, "sersic_extra_n", ()) or ())
         tabs = [tables.sersic_ktable(n) for n in sersic_indices]
+        more = [tables.sersic_ktable(n)[1] for n in extra_n]
         self.q_step = float(tabs[0][0][1] - tabs[0][0][0])
-        self.P, self._keep = fft_params(renderer.scene, kpsf, np.stack([t[1] for t in tabs] + list(extra_ktables)), self.q_step,
+        self.P, self._keep = fft_params(renderer.scene, kpsf, np.stack([t[1] for t in tabs] + list(extra_ktables) + more), self.q_step,
                                         renderer.scene.seed, add_noise, lambda a: renderer.mem.put(a, np.float64))
         self.P.image = renderer.image.data_ptr()
         set_spikes(self.P, diffraction_fft, wavelength)

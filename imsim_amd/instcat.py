@@ -32,6 +32,23 @@ def fopen(path):
     return gzip.open(path, "rt") if path.endswith(".gz") else open(path, "rt")
 
 
+def catalog_lines(path, _depth=0):
+    """Lines of an instance catalog with every `includeobj <file>` directive replaced by the lines of that file, found
+    relative to the including file's directory, plain or gzipped, recursively (fopen_generator, imsim/instcat.py:146-160:
+    this is how real catalogs carry their objects).  A missing file raises OSError like the reference (:131-132)."""
+    if _depth > 16:
+        raise OSError(f"includeobj nesting too deep at {path}")
+    if not os.path.isfile(path):
+        raise OSError("File not found: %s" % path)
+    here = os.path.split(os.path.abspath(path))[0]
+    with fopen(path) as f:
+        for line in f:
+            if line.startswith("includeobj"):
+                yield from catalog_lines(os.path.join(here, line.strip().split()[-1]), _depth + 1)
+            else:
+                yield line
+
+
 def read_header(path):
     """The phosim commands at the top of an instance catalog -> dict with the OpsimData field
     names the configs use (imsim/opsim_data.py:158-206): fieldRA, fieldDec, altitude, azimuth,
@@ -40,7 +57,7 @@ def read_header(path):
     with fopen(path) as f:
         for line in f:
             if line.startswith("object") or line.startswith("includeobj"):
-                break
+                break                                  # the phosim commands precede the objects (opsim_data.py:158-206)
             tok = line.split()
             if len(tok) >= 2:
                 raw[tok[0].lower()] = tok[1]
@@ -134,45 +151,63 @@ def parse_objects(path, max_objects=None):
     skipped (:233); invalid objects (magnorm >= 50, sersic/knots with a < b, knots with npoints <= 0)
     are skipped (:276-286).  Returns a dict of arrays in file order."""
     ids, ra, dec, mag, sed, lens, kind, a, b, pa, n_or_pts, fits = [], [], [], [], [], [], [], [], [], [], [], []
+    dust = []
     inst_dir = os.path.dirname(os.path.abspath(path))
-    with fopen(path) as f:
-        for line in f:
-            if " inf " in line or not line.startswith("object"):
-                continue
-            t = line.split()
-            typ = t[12].lower()
-            magnorm = float(t[4])
-            if typ == "point":
-                k, aa, bb, pp, nn = 0, 0.0, 0.0, 0.0, 0.0
-            elif typ == "sersic2d":
-                k, aa, bb, pp, nn = 1, float(t[13]), float(t[14]), float(t[15]), round(float(t[16]) * 20.0) / 20.0
-            elif typ == "knots":
-                k, aa, bb, pp, nn = 2, float(t[13]), float(t[14]), float(t[15]), float(int(t[16]))
-            elif typ == "streak":
-                k, aa, bb, pp, nn = 3, float(t[13]), float(t[14]), float(t[15]), 0.0
-            elif t[12].endswith(".fits") or t[12].endswith(".fits.gz"):
-                # galsim.InterpolatedImage(file relative to the catalog, scale=pixel_scale).rotate(-theta), :552-561
-                k, aa, bb, pp, nn = 4, float(t[13]), 0.0, float(t[14]), 0.0
-            else:
-                k, aa, bb, pp, nn = 5, 0.0, 0.0, 0.0, 0.0            # unknown object type
-            valid = magnorm < 50.0 and not (k in (1, 2) and aa < bb) and not (k == 2 and nn <= 0)
-            if not valid:
-                continue
-            ids.append(t[1]); ra.append(float(t[2])); dec.append(float(t[3])); mag.append(magnorm)
-            sed.append((t[5], float(t[6])))
-            lens.append((float(t[7]), float(t[8]), float(t[9])))
-            kind.append(k); a.append(aa); b.append(bb); pa.append(pp); n_or_pts.append(nn)
-            fits.append(os.path.join(inst_dir, t[12]) if k == 4 else "")
-            if max_objects is not None and len(ids) >= max_objects:
-                break
+    for line in catalog_lines(path):
+        if " inf " in line or not line.startswith("object"):
+            continue
+        t = line.split()
+        typ = t[12].lower()
+        magnorm = float(t[4])
+        di = DUST_INDEX.get(typ, 15)                              # where the dust fields start (:210-216, :274)
+        if typ == "point":
+            k, aa, bb, pp, nn = 0, 0.0, 0.0, 0.0, 0.0
+        elif typ == "sersic2d":
+            k, aa, bb, pp, nn = 1, float(t[13]), float(t[14]), float(t[15]), round(float(t[16]) * 20.0) / 20.0
+        elif typ == "knots":
+            k, aa, bb, pp, nn = 2, float(t[13]), float(t[14]), float(t[15]), float(int(t[16]))
+        elif typ == "streak":
+            k, aa, bb, pp, nn = 3, float(t[13]), float(t[14]), float(t[15]), 0.0
+        elif t[12].endswith(".fits") or t[12].endswith(".fits.gz"):
+            # galsim.InterpolatedImage(file relative to the catalog, scale=pixel_scale).rotate(-theta), :552-561
+            k, aa, bb, pp, nn = 4, float(t[13]), 0.0, float(t[14]), 0.0
+        else:
+            k, aa, bb, pp, nn = 5, 0.0, 0.0, 0.0, 0.0            # unknown object type
+        valid = magnorm < 50.0 and not (k in (1, 2) and aa < bb) and not (k == 2 and nn <= 0)
+        if not valid:
+            continue
+        ids.append(t[1]); ra.append(float(t[2])); dec.append(float(t[3])); mag.append(magnorm)
+        sed.append((t[5], float(t[6])))
+        dust.append(parse_dust(t[di:]))
+        lens.append((float(t[7]), float(t[8]), float(t[9])))
+        kind.append(k); a.append(aa); b.append(bb); pa.append(pp); n_or_pts.append(nn)
+        fits.append(os.path.join(inst_dir, t[12]) if k == 4 else "")
+        if max_objects is not None and len(ids) >= max_objects:
+            break
     lens = np.array(lens, dtype=np.float64).reshape(-1, 3)
-    return dict(id=np.array(ids), ra=np.radians(ra), dec=np.radians(dec), magnorm=np.array(mag), sed=sed,
+    dust = np.array(dust, dtype=np.float64).reshape(-1, 4)
+    return dict(id=np.array(ids), ra=np.radians(ra), dec=np.radians(dec), magnorm=np.array(mag), sed=sed, dust=dust,
                 gamma1=lens[:, 0], gamma2=lens[:, 1], kappa=lens[:, 2], objtype=np.array(kind, dtype=np.int32),
                 a=np.array(a), b=np.array(b), pa=np.array(pa), n=np.array(n_or_pts), fits_file=np.array(fits, dtype=object))
 
 
+def parse_dust(params):
+    """(internal Av, internal Rv, galactic Av, galactic Rv) from the trailing fields `none | MODEL Av Rv` x 2
+    (InstCatalog.getDust, imsim/instcat.py:446-465)."""
+    params = list(params)
+    iav, irv, gav, grv = 0.0, 3.1, 0.0, 3.1
+    if params and params[0].lower() != "none":
+        iav, irv = float(params[1]), float(params[2])
+        params = params[3:]
+    else:
+        params = params[1:]
+    if params and params[0].lower() != "none":
+        gav, grv = float(params[1]), float(params[2])
+    return iav, irv, gav, grv
+
+
 def to_catalog(parsed, img_wcs, xsize, ysize, bandpass_integral, exptime, pupil_area=RUBIN_AREA, edge_pix=100,
-               sort_mag=True, flip_g2=True):
+               sort_mag=True, flip_g2=True, sed_dir=None, inst_dir=None, bandpass=None, sed_points=257):
     """Cull to the CCD (+- edge_pix, instcat.py:243-259), compute nominal fluxes and the profile
     geometry (instcat.py:498-527, :433-444, :569-573) -> the catalog dict build_object_table takes.
     point, sersic2d, knots, streak and FITS-image objects reach the kernels; a FITS-image object whose file is
@@ -190,6 +225,22 @@ def to_catalog(parsed, img_wcs, xsize, ysize, bandpass_integral, exptime, pupil_
     if sort_mag:
         idx = idx[np.argsort(parsed["magnorm"][idx], kind="stable")]       # brightest first (:328-338)
     flux = FLUX_DENSITY_500 * bandpass_integral * np.exp(-0.9210340371976184 * parsed["magnorm"][idx]) * pupil_area * exptime
+    # SED x bandpass (imsim/instcat.py:380-431, :563-573): objects whose SED file is found get their own flux and their
+    # own wavelength distribution (redshift and Milky-Way extinction applied); the others keep the flat-in-photons
+    # fallback above and are reported in cat["missing_seds"]
+    sed_tables, sed_table, missing = None, np.zeros(len(idx), dtype=np.int32), []
+    if bandpass is not None and (sed_dir or inst_dir) and len(idx):
+        from . import sed as sedmod
+        names = np.array([parsed["sed"][i][0] for i in idx], dtype=object)
+        z = np.array([parsed["sed"][i][1] for i in idx], dtype=np.float64)
+        d = parsed["dust"][idx] if "dust" in parsed else np.tile([0.0, 3.1, 0.0, 3.1], (len(idx), 1))
+        f0, tabs, missing = sedmod.object_spectra(names, z, d[:, 2], d[:, 3], bandpass[0], bandpass[1],
+                                                  sedmod.SedLibrary(sed_dir, inst_dir), n_pts=sed_points)
+        found = f0 >= 0.0
+        flux = np.where(found, f0 * np.exp(-0.9210340371976184 * parsed["magnorm"][idx]) * pupil_area * exptime, flux)
+        if found.any():
+            sed_tables = tabs[found]
+            sed_table[found] = 1 + np.arange(int(found.sum()))          # table 0 stays the flat fallback
     objtype = parsed["objtype"][idx]
     n = parsed["n"][idx]
     a, b = parsed["a"][idx], parsed["b"][idx]
@@ -207,7 +258,8 @@ def to_catalog(parsed, img_wcs, xsize, ysize, bandpass_integral, exptime, pupil_
                              np.where(np.isclose(sersic_n, 1.0), 1, 2))))).astype(np.int32),
                n_knots=np.where(objtype == 2, n, 0.0), box_length=np.where(objtype == 3, a, 0.0),
                box_width=np.where(objtype == 3, b, 0.0),
-               sersic_n=sersic_n, obj_id=idx.astype(np.int64), object_id=parsed["id"][idx])
+               sersic_n=sersic_n, obj_id=idx.astype(np.int64), object_id=parsed["id"][idx],
+               sed_table=sed_table, sed_tables=sed_tables, missing_seds=missing)
     # what obj.evaluateAtWavelength(effective wavelength) carries in the reference: photons per nm (stamp_utils.py:176-220)
     cat["sb_flux"] = flux / bandpass_integral
     # FITS-image objects: every distinct file becomes one image profile (Scene.image_profiles)

@@ -129,7 +129,7 @@ class LSST_ImageBuilder(LSST_ImageBuilderBase):
                 raise GalSimConfigError("FFT drawing needs the k-space PSF description")
             fobj = objects[fft_rows]
             fflux = nominal[keep][fft_rows]
-            tables_needed = np.where(fobj["prof_table"] >= 0, fobj["prof_table"], -1)
+            tables_needed = fft_draw.profile_ktable_ids(renderer.scene, fobj["prof_table"], len(extra_ktables))
             rows, order = fft_draw.build_fft_objects(fobj, fflux, tables_needed)
             drawer = fft_draw.FftDrawer(renderer, kpsf, add_noise=True, diffraction_fft=diffraction_fft, wavelength=wavelength,
                                         extra_ktables=extra_ktables)

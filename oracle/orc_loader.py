@@ -273,6 +273,8 @@ class OracleFft:
         self.scene = scene
         self.keep = []
         tabs = [tables.sersic_ktable(n) for n in sersic_indices]
+        more = [tables.sersic_ktable(n)[1] for n in (getattr(scene, "sersic_extra_n", ()) or ())]
+        extra_ktables = list(extra_ktables) + more
 
         def put(a):
             a = np.ascontiguousarray(a, dtype=np.float64)

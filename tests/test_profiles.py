@@ -170,3 +170,47 @@ def _wcs_centre(w):
     vec = wcsmod.tansip_pix_to_vec(w, np.array([128.0]), np.array([128.0]))
     vec = np.asarray(vec).reshape(3)
     return float(np.arctan2(vec[1], vec[0])), float(np.arcsin(vec[2] / np.linalg.norm(vec)))
+
+
+def test_general_sersic_index_tables_and_shooting():
+    """imsim/instcat.py:511-517: Sersic indices are quantised to 0.05, not collapsed to 1 / 4.  Every index gets its own
+    radial table: half of the photons fall inside the half-light radius, and the concentration (r80 / r20) grows with n
+    as the Sersic law says."""
+    from scipy import special
+    scene = configs.scene_c2(nx=256, ny=256)
+    scene.psf = []
+    ns = np.array([0.5, 1.0, 2.45, 2.5, 4.0, 6.0])
+    index = configs.add_sersic_tables(scene, ns)
+    assert index[1.0] == 0 and index[4.0] == 1 and scene.sersic_extra_n == (0.5, 2.45, 2.5, 6.0)
+    assert configs.add_sersic_tables(scene, [2.5, 3.0])[3.0] == index[6.0] + 1            # idempotent, appends only new ones
+    n_obj = len(ns)
+    cat = _cat(2, n_obj, sersic_n=ns, hlr=np.full(n_obj, 0.5))
+    cat["kind"] = np.where(ns == 1.0, 1, 2).astype(np.int32)
+    objects, _ = catalog.build_object_table(cat, np.full(n_obj, 40000), stamp_size=128, sersic_index=scene.sersic_index)
+    assert list(objects["prof_table"]) == [index[float(n)] for n in ns]
+    orc = orc_loader.OracleScene(scene)
+    pool = orc.shoot_pool(objects).to_host()
+    r = np.hypot(pool["x"].reshape(n_obj, -1) - objects["x0"][:, None], pool["y"].reshape(n_obj, -1) - objects["y0"][:, None]) * PIX
+    conc = []
+    for k, n in enumerate(ns):
+        assert abs(np.mean(r[k] < 0.5) - 0.5) < 0.012, n                                  # half-light radius
+        b = special.gammaincinv(2 * n, 0.5)
+        r20, r80 = np.quantile(r[k], [0.2, 0.8])
+        want20, want80 = [0.5 * (special.gammaincinv(2 * n, f) / b) ** n for f in (0.2, 0.8)]
+        np.testing.assert_allclose([r20, r80], [want20, want80], rtol=0.05)
+        conc.append(r80 / r20)
+    assert np.all(np.diff(conc) >= -0.02) and conc[-1] > 2 * conc[0]
+    # a catalog index without a table is an error, not a silent n = 4
+    import pytest
+    with pytest.raises(ValueError):
+        catalog.build_object_table(cat, np.full(n_obj, 100), stamp_size=64)
+    with pytest.raises(ValueError):
+        configs.add_sersic_tables(scene, [7.5])
+
+
+def test_stamp_size_follows_the_sersic_index():
+    hlr = np.full(4, 0.5)
+    kind = np.array([1, 2, 2, 2])
+    sizes = catalog.gal_stamp_size(kind, hlr, np.ones(4), sersic_n=np.array([1.0, 2.0, 4.0, 6.0]))
+    assert np.all(np.diff(sizes) > 0)
+    assert sizes[2] == catalog.gal_stamp_size(np.array([2]), hlr[:1], np.ones(1))[0]       # n = 4 is the default of kind 2

@@ -194,7 +194,7 @@ RegisterOutputType("LSST_CCD", "LSST_CCD")
 for _name in ("atm_psf", "tree_rings", "instance_catalog", "opsim_data", "telescope", "sky_model", "sky_catalog", "checkpoint",
               "vignetting", "table_row"):
     RegisterInputType(_name, _name)
-OUT_OF_SCOPE_INPUTS = {"sky_model", "sky_catalog", "checkpoint", "vignetting", "table_row"}
+OUT_OF_SCOPE_INPUTS = {"sky_model", "sky_catalog", "checkpoint", "table_row"}
 
 # photon ops: (kind, required keys, optional keys) -- the reference's _req_params/_opt_params
 PHOTON_OPS = {
@@ -635,24 +635,32 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
             objs, sizes = configs.c3b_objects(sub, ph, scene) if scene.atm is not None else configs.c3_objects(sub, ph, scene)
             return objs, sizes
         truth = {}
+        vig = None
+        if "vignetting" in inp:
+            from .vignetting import Vignetting
+            vig = Vignetting(str(ev.value(inp["vignetting"]["file_name"])), data_dir)
         max_simple = float(ev.value(stamp_cfg.get("max_flux_simple", 100)))
+        dfft = None
+        if "diffraction_fft" in stamp_cfg:
+            from .diffraction_fft import DiffractionFFT
+            d = {k: ev.value(v) for k, v in stamp_cfg["diffraction_fft"].items()}
+            dfft = DiffractionFFT(**d)
         if itype == "LSST_PhotonPoolingImage":
-            builder.build_image(renderer, cat, phot, make_objects, max_flux_simple=max_simple, seed=seed_ccd, truth=truth)
+            builder.build_image(renderer, cat, phot, make_objects, max_flux_simple=max_simple, seed=seed_ccd, truth=truth,
+                                fft_sb_thresh=float(ev.value(stamp_cfg.get("fft_sb_thresh", 0.0))), kpsf=kpsf, fwhm_total=fwhm_total,
+                                diffraction_fft=dfft, wavelength=wl_eff, extra_ktables=extra_ktables, vignetting=vig)
         else:
-            dfft = None
-            if "diffraction_fft" in stamp_cfg:
-                from .diffraction_fft import DiffractionFFT
-                d = {k: ev.value(v) for k, v in stamp_cfg["diffraction_fft"].items()}
-                dfft = DiffractionFFT(**d)
             builder.build_image(renderer, cat, phot, make_objects,
                                 fft_sb_thresh=float(ev.value(stamp_cfg.get("fft_sb_thresh", 0.0))), max_flux_simple=max_simple,
                                 draw_method=ev.value(stamp_cfg.get("draw_method", "auto")), kpsf=kpsf, fwhm_total=fwhm_total,
-                                diffraction_fft=dfft, wavelength=wl_eff, nrecalc=nrecalc, truth=truth, extra_ktables=extra_ktables)
+                                diffraction_fft=dfft, wavelength=wl_eff, nrecalc=nrecalc, truth=truth, extra_ktables=extra_ktables,
+                                vignetting=vig)
         # sky + noise (imsim/lsst_image.py:128-200) when a numeric sky level is configured; the Rubin sky model,
         # vignetting and fringing inputs are out of scope and reported as ignored
         sky = image.get("sky_level")
         if isinstance(sky, (int, float)) and not isinstance(sky, bool) and image.get("noise"):
-            builder.add_noise(renderer, float(sky), seed=seed_ccd)
+            # sky x radial vignetting per pixel (lsst_image.py:172-176) when input.vignetting is configured
+            builder.add_noise(renderer, float(sky), seed=seed_ccd, multiplier=vig(det_name, nx, ny) if vig is not None else None)
         elif "sky_level" in image:
             res.ignored.append("image.sky_level")
         renderer.synchronize()

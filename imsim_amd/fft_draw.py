@@ -86,22 +86,60 @@ def atmospheric_fft_kpsf(atm, wavelength, first_table, fwhm_sys=None):
     return kpsf, extra
 
 
-def max_surface_brightness(flux, kind, hlr, fwhm_total, pixel_scale=0.2):
-    """Half the peak surface brightness [photons/pixel] of the PSF-convolved object, the quantity
-    get_fft_psf_maybe compares with fft_sb_thresh (psf_utils.py:201-212).  Point sources: peak of
-    a Gaussian of the PSF's FWHM; extended: FWHMs added in quadrature (first-order estimate)."""
-    size = np.where(np.asarray(kind) == 0, fwhm_total, np.hypot(fwhm_total, 2.0 * np.asarray(hlr)))
-    sigma = size / 2.3548200450309493
-    return tables.gaussian_max_sb(np.asarray(flux, dtype=np.float64), sigma) / 2.0 * pixel_scale ** 2
+def kpsf_peak_per_flux(kpsf, ktables=None, q_step=None, n_base=2):
+    """Central surface brightness per unit flux [1/arcsec^2] of every k-space PSF component: I(0) = int T(k) k dk / 2 pi.
+    Gaussian 1 / (2 pi sigma^2); Kolmogorov (3/5) Gamma(6/5) k0^2 / (2 pi); a k-table by quadrature of its samples."""
+    out = []
+    for kind, table, p0 in kpsf:
+        if kind == _abi.IMS_KPSF_GAUSSIAN:
+            out.append(1.0 / (2.0 * math.pi * p0 * p0))
+        elif kind == _abi.IMS_KPSF_KOLMOGOROV:
+            out.append(0.6 * math.gamma(1.2) * p0 * p0 / (2.0 * math.pi))
+        else:
+            T = np.asarray(ktables[table - n_base], dtype=np.float64)
+            q = np.arange(len(T)) * q_step
+            out.append(float(np.trapezoid(T * q, q)) / (2.0 * math.pi * p0 * p0))
+    return out
 
 
-def use_fft(nominal_flux, kind, hlr, fwhm_total, fft_sb_thresh):
+def max_surface_brightness(flux, kind, hlr, fwhm_total=None, pixel_scale=0.2, sersic_n=None, jac_det=None, psf_peaks=None):
+    """`Convolve(gal_achrom, fft_psf).withFlux(F).max_sb / 2 * pixel_scale^2` [photons/pixel], the quantity
+    get_fft_psf_maybe compares with fft_sb_thresh (imsim/psf_utils.py:201-212).  GalSim's max_sb of a convolution is the
+    estimate that is exact for Gaussians: F / sum_i (1 / peak_i) with peak_i the central surface brightness per unit
+    flux of component i (a DeltaFunction contributes nothing).  Sersic: b^2n / (2 pi n Gamma(2n) hlr^2 |det J|).
+    psf_peaks: kpsf_peak_per_flux of the FFT-mode PSF; without it a single Gaussian of FWHM fwhm_total stands in."""
+    from scipy import special
+    flux = np.asarray(flux, dtype=np.float64)
+    kind = np.asarray(kind)
+    hlr = np.asarray(hlr, dtype=np.float64)
+    if psf_peaks is None:
+        sigma = fwhm_total / 2.3548200450309493
+        psf_peaks = [1.0 / (2.0 * math.pi * sigma * sigma)]
+    inv = np.full(flux.shape, sum(1.0 / p for p in psf_peaks))
+    n = np.where(kind == 1, 1.0, np.where(kind == 2, 4.0, 0.0))
+    if sersic_n is not None:
+        sn = np.asarray(sersic_n, dtype=np.float64)
+        n = np.where(((kind == 1) | (kind == 2)) & (sn > 0), sn, n)
+    gal = n > 0
+    if gal.any():
+        ng = n[gal]
+        b = special.gammaincinv(2.0 * ng, 0.5)
+        peak = np.exp(2.0 * ng * np.log(b) - special.gammaln(2.0 * ng)) / (2.0 * math.pi * ng * hlr[gal] ** 2)
+        if jac_det is not None:
+            peak = peak / np.abs(np.asarray(jac_det, dtype=np.float64)[gal])
+        inv[gal] = inv[gal] + 1.0 / peak
+    other = (~gal) & (kind != 0)        # knots, streaks, images: never FFT-drawn here; a broad stand-in keeps them photon-shot
+    inv[other] = np.inf
+    return flux / inv / 2.0 * pixel_scale ** 2
+
+
+def use_fft(nominal_flux, kind, hlr, fwhm_total, fft_sb_thresh, **kw):
     """The FFT-vs-phot decision of LSST_SiliconBuilder.buildPSF (stamp.py:275-308)."""
     nominal_flux = np.asarray(nominal_flux, dtype=np.float64)
     if not fft_sb_thresh:
         return np.zeros(nominal_flux.shape, dtype=bool)
     cand = (nominal_flux >= 1.0e6) & (nominal_flux >= fft_sb_thresh)
-    return cand & (max_surface_brightness(nominal_flux, kind, hlr, fwhm_total) > fft_sb_thresh)
+    return cand & (max_surface_brightness(nominal_flux, kind, hlr, fwhm_total, **kw) > fft_sb_thresh)
 
 
 def profile_ktable_ids(scene, prof_table, n_extra_ktables=0, n_base=2):

@@ -62,6 +62,21 @@ class LSST_ImageBuilderBase:
         return xsize, ysize
 
 
+    @staticmethod
+    def _use_fft(sub, nominal, fwhm_total, fft_sb_thresh, kpsf, extra_ktables):
+        """FFT or photons for every object (stamp.py:275-277 + get_fft_psf_maybe, psf_utils.py:195-212): GalSim's max_sb
+        of Convolve(object, FFT-mode PSF) from the analytic peaks of the components."""
+        from . import tables
+        kw = {}
+        if kpsf:
+            q_step = tables.KTABLE_QMAX / (tables.KTABLE_NPTS - 1)
+            kw["psf_peaks"] = fft_draw.kpsf_peak_per_flux(kpsf, list(extra_ktables), q_step)
+        if sub.get("sersic_n") is not None:
+            kw["sersic_n"] = sub["sersic_n"]
+        if sub.get("mu") is not None:
+            kw["jac_det"] = sub["mu"]                        # shear preserves area; the lens magnifies it by mu
+        return fft_draw.use_fft(nominal, sub["kind"], sub["hlr"], fwhm_total, fft_sb_thresh, **kw)
+
     def add_noise(self, renderer, sky_level, pixel_scale=0.2, sky_gradient=None, multiplier=None, seed=0, stream_id=0):
         """addNoise (imsim/lsst_image.py:128-200): sky = sky_level [photons/arcsec^2] x pixel area, optionally
         times a linear sky gradient (a, b, c): factor = a + b x + c y in 0-based pixel indices (SkyGradient,
@@ -95,7 +110,7 @@ class LSST_ImageBuilder(LSST_ImageBuilderBase):
 
     def build_image(self, renderer, cat, phot_flux, make_objects, fft_sb_thresh=0.0, max_flux_simple=100.0,
                     draw_method="auto", kpsf=None, fwhm_total=0.8, diffraction_fft=None, wavelength=622.2,
-                    nrecalc=None, truth=None, extra_ktables=()):
+                    nrecalc=None, truth=None, extra_ktables=(), vignetting=None):
         """The draw loop (imsim/lsst_image.py:342-368 + imsim/stamp.py:411-575).
 
         cat / phot_flux: catalog dict and Poisson-realised fluxes; make_objects(cat, phot) builds the
@@ -115,7 +130,7 @@ class LSST_ImageBuilder(LSST_ImageBuilderBase):
         elif draw_method == "phot":
             is_fft = np.zeros(n_all, dtype=bool)
         else:
-            is_fft = fft_draw.use_fft(nominal, sub["kind"], sub["hlr"], fwhm_total, fft_sb_thresh)
+            is_fft = self._use_fft(sub, nominal, fwhm_total, fft_sb_thresh, kpsf, extra_ktables)
         is_fft &= np.asarray(sub["kind"]) < 3                  # knots and streaks have no k-space form here: always photons
         objects, sizes = make_objects(sub, np.where(phot > 0, phot, 0))
         keep = np.flatnonzero(phot > 0)                       # SkipThisObject for phot_flux == 0 (stamp.py:199-202)
@@ -129,6 +144,11 @@ class LSST_ImageBuilder(LSST_ImageBuilderBase):
                 raise GalSimConfigError("FFT drawing needs the k-space PSF description")
             fobj = objects[fft_rows]
             fflux = nominal[keep][fft_rows]
+            if vignetting is not None:
+                # FFT-drawn objects do not pass the ray trace: the empirical vignetting function scales their flux
+                # (get_fft_psf_maybe, imsim/psf_utils.py:220-233); base['fft_flux'] carries the scaled value
+                sc = renderer.scene
+                fflux = fflux * vignetting.at_pixel(self.det_name, fobj["x0"], fobj["y0"], sc.nx, sc.ny)
             tables_needed = fft_draw.profile_ktable_ids(renderer.scene, fobj["prof_table"], len(extra_ktables))
             rows, order = fft_draw.build_fft_objects(fobj, fflux, tables_needed)
             drawer = fft_draw.FftDrawer(renderer, kpsf, add_noise=True, diffraction_fft=diffraction_fft, wavelength=wavelength,
@@ -161,20 +181,58 @@ class LSST_PhotonPoolingImageBuilder(LSST_ImageBuilderBase):
         photon_pooling.check_stamp_type(stamp_type)
         return super().setup(config, det_type)
 
-    def build_image(self, renderer, cat, phot_flux, make_objects, max_flux_simple=100.0, seed=0, truth=None):
+    def build_image(self, renderer, cat, phot_flux, make_objects, max_flux_simple=100.0, seed=0, truth=None, fft_sb_thresh=0.0,
+                    kpsf=None, fwhm_total=0.8, diffraction_fft=None, wavelength=622.2, extra_ktables=(), vignetting=None):
+        """LSST_PhotonPoolingImageBuilder.buildImage (imsim/photon_pooling.py:29-174): the fluxes of all objects are known
+        up front, so the objects are partitioned into FFT / photon-shooting / faint; the FFT objects are drawn FIRST
+        (:84-114, in nbatch_fft batches over objects), then the photon batches run through the pooled path."""
+        torch = renderer.torch
         n_all = len(cat["x"]) if self.nobjects is None else min(len(cat["x"]), int(self.nobjects))
         sub = {k: (v[:n_all] if isinstance(v, np.ndarray) and len(v) >= n_all else v) for k, v in cat.items()}
         phot = np.asarray(phot_flux)[:n_all]
+        nominal = np.asarray(sub["nominal_flux"])
         objects, _ = make_objects(sub, phot)
         keep = np.flatnonzero(phot > 0)
-        modes = stamp.classify(sub["nominal_flux"][keep], max_flux_simple)
-        realized = renderer.torch.zeros(len(objects), dtype=renderer.torch.float64, device=renderer.device)
-        photon_pooling.build_image(renderer, objects, modes, nbatch=self.nbatch, nsubbatch=self.nsubbatch, seed=seed,
-                                   realized=realized)
+        is_fft = self._use_fft(sub, nominal, fwhm_total, fft_sb_thresh, kpsf, extra_ktables) & (np.asarray(sub["kind"]) < 3)
+        fft_rows = is_fft[keep]
+        modes = stamp.classify(nominal[keep], max_flux_simple)
+        modes[fft_rows] = stamp.ProcessingMode.FFT
+        realized = torch.zeros(len(objects), dtype=torch.float64, device=renderer.device)
+        fft_flux = np.zeros(len(objects))
+        if fft_rows.any():
+            if kpsf is None:
+                raise GalSimConfigError("FFT drawing needs the k-space PSF description")
+            idx_fft = np.flatnonzero(fft_rows)
+            drawer = fft_draw.FftDrawer(renderer, kpsf, add_noise=True, diffraction_fft=diffraction_fft, wavelength=wavelength,
+                                        extra_ktables=extra_ktables)
+            nb = max(min(self.nbatch_fft, len(idx_fft)), 1)
+            for batch in photon_pooling.make_batches(list(idx_fft), nb):
+                if not batch:
+                    continue
+                batch = np.asarray(batch)
+                fobj = objects[batch]
+                fflux = nominal[keep][batch]
+                if vignetting is not None:
+                    sc = renderer.scene
+                    fflux = fflux * vignetting.at_pixel(self.det_name, fobj["x0"], fobj["y0"], sc.nx, sc.ny)
+                rows, order = fft_draw.build_fft_objects(
+                    fobj, fflux, fft_draw.profile_ktable_ids(renderer.scene, fobj["prof_table"], len(extra_ktables)))
+                r_fft = torch.zeros(len(rows), dtype=torch.float64, device=renderer.device)
+                drawer.draw(rows, realized=r_fft)
+                realized.index_add_(0, torch.from_numpy(batch[order]).to(renderer.device), r_fft)
+                fft_flux[batch] = fflux
+        pidx = np.flatnonzero(~fft_rows)
+        if len(pidx):
+            r_ph = torch.zeros(len(pidx), dtype=torch.float64, device=renderer.device)
+            photon_pooling.build_image(renderer, objects[pidx], modes[pidx], nbatch=self.nbatch, nsubbatch=self.nsubbatch, seed=seed,
+                                       realized=r_ph)
+            realized.index_add_(0, torch.from_numpy(pidx).to(renderer.device), r_ph)
         if truth is not None:
             truth["index"] = keep
             truth["x"], truth["y"] = sub["x"][keep], sub["y"][keep]
-            truth["nominal_flux"] = sub["nominal_flux"][keep]
-            truth["phot_flux"] = phot[keep]
+            truth["nominal_flux"] = nominal[keep]
+            truth["phot_flux"] = np.where(fft_rows, 0.0, phot[keep])
+            truth["fft_flux"] = fft_flux
             truth["incident_flux"] = realized.cpu().numpy()
+            truth["mode"] = np.array([m.name.lower() for m in modes])
         return renderer.image

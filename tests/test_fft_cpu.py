@@ -168,3 +168,61 @@ def test_airy_ktable_is_the_pupil_autocorrelation():
     # cutoff at k = 2 pi D / lam
     k_cut = 2 * np.pi * diam / (lam * 1e-9) / fft_draw.ARCSEC_PER_RAD
     assert abs(tables.KTABLE_QMAX / 1.02 / p0 / k_cut - 1) < 1e-12
+
+
+def test_max_sb_is_galsims_convolution_estimate():
+    """get_fft_psf_maybe (imsim/psf_utils.py:201-212) thresholds `Convolve(gal, fft_psf).withFlux(F).max_sb / 2 * scale^2`.
+    GalSim's max_sb of a convolution is F / sum_i(flux_i / max_sb_i): exact for Gaussians, where the variances add."""
+    import math
+    from imsim_amd import _abi
+    s1, s2, F = 0.3, 0.4, 5.0e6
+    kpsf = [(_abi.IMS_KPSF_GAUSSIAN, 0, s1), (_abi.IMS_KPSF_GAUSSIAN, 0, s2)]
+    peaks = fft_draw.kpsf_peak_per_flux(kpsf)
+    got = fft_draw.max_surface_brightness(np.array([F]), np.array([0]), np.array([0.0]), psf_peaks=peaks)[0]
+    np.testing.assert_allclose(got, F / (2 * math.pi * (s1 * s1 + s2 * s2)) / 2 * 0.04, rtol=1e-13)
+    # Kolmogorov: central intensity (3/5) Gamma(6/5) k0^2 / 2 pi, against the quadrature of exp(-(k/k0)^(5/3))
+    k0 = 7.3
+    k = np.linspace(0.0, 30 * k0, 400001)
+    num = np.trapezoid(np.exp(-(k / k0) ** (5.0 / 3.0)) * k, k) / (2 * math.pi)
+    np.testing.assert_allclose(fft_draw.kpsf_peak_per_flux([(_abi.IMS_KPSF_KOLMOGOROV, 0, k0)])[0], num, rtol=1e-6)
+    # a tabulated MTF: the table of a Gaussian gives the Gaussian's peak
+    q = np.linspace(0.0, tables.KTABLE_QMAX, tables.KTABLE_NPTS)
+    p0 = tables.KTABLE_QMAX / (9.0 / s1)
+    tab = np.exp(-0.5 * (q / p0 * s1) ** 2)
+    got = fft_draw.kpsf_peak_per_flux([(_abi.IMS_KPSF_TABLE, 2, p0)], [tab], q[1] - q[0])[0]
+    np.testing.assert_allclose(got, 1 / (2 * math.pi * s1 * s1), rtol=1e-4)
+    # a Sersic galaxy adds flux / peak of its own: n = 1 peak is b^2 / (2 pi hlr^2); magnification dilutes it
+    from scipy import special
+    b = special.gammaincinv(2.0, 0.5)
+    hlr = 0.5
+    sb = fft_draw.max_surface_brightness(np.array([F, F]), np.array([1, 1]), np.array([hlr, hlr]), psf_peaks=peaks,
+                                         jac_det=np.array([1.0, 2.0]))
+    want = F / (2 * math.pi * (s1 * s1 + s2 * s2) + 2 * math.pi * hlr * hlr / b ** 2) / 2 * 0.04
+    np.testing.assert_allclose(sb[0], want, rtol=1e-12)
+    assert sb[1] < sb[0]
+    # the index matters: a de Vaucouleurs profile is far peakier than an exponential of the same size
+    sb14 = fft_draw.max_surface_brightness(np.array([F, F]), np.array([1, 2]), np.array([hlr, hlr]), psf_peaks=peaks,
+                                           sersic_n=np.array([1.0, 4.0]))
+    assert sb14[1] > sb14[0]
+
+
+def test_vignetting_spline_and_pixel_radii():
+    """imsim/vignetting.py: radial B-spline normalised at the focal-plane centre; tests/test_vignetting.py checks that the
+    per-pixel map and the value at a position agree at the CCD corners."""
+    from imsim_amd.vignetting import Vignetting, detector_center_mm
+    v = Vignetting("LSSTCam_vignetting_data.json")
+    assert abs(v.apply_to_radii(0.0) - 1.0) < 1e-15
+    r = np.linspace(0.0, 350.0, 50)
+    f = v.apply_to_radii(r)
+    assert f[0] == 1.0 and f[-1] < 0.8 and np.all(f <= 1.0 + 1e-3)             # throughput falls towards the edge of the field
+    assert detector_center_mm("R22_S11") == (0.0, 0.0) and detector_center_mm("R30_S11") == (127.0, -254.0)
+    for det in ("R22_S11", "R30_S11", "R01_S20"):
+        img = v(det, 4096, 4004)
+        assert img.shape == (4004, 4096)
+        for (cx, cy) in ((0, 0), (4095, 0), (0, 4003), (4095, 4003)):
+            np.testing.assert_almost_equal(v.at_pixel(det, cx + 1.0, cy + 1.0, 4096, 4004), img[cy, cx])
+    assert abs(v("R22_S11", 4096, 4004).mean() - 1.0) < 5e-3 and v("R01_S20", 4096, 4004).mean() < v("R22_S11", 4096, 4004).mean()
+    import pytest
+    with pytest.raises(OSError):
+        Vignetting("no_such_file.json")
+    assert Vignetting("LSSTComCamSim_vignetting_data.json").apply_to_radii(0.0) == 1.0

@@ -930,3 +930,88 @@ def test_config_flat_readout_without_opsim(torch_cuda, tmp_path):
         xt = 0.0 if ccd.xtalk is None else sum(ccd.xtalk[k][j] / list(ccd.values())[j].gain for j in range(16)) * 1000.0
         assert abs(sec.mean() - (500.0 + 1000.0 / amp.gain + xt - 0.5)) < 0.2, (k, sec.mean())
         assert (raw[k + 1][1][:, :r.xmin - 1] == 500).all()            # prescan: bias only
+
+
+def test_general_sersic_index_fft_and_photon_shooting_agree(torch_cuda):
+    """A Sersic index off the 1 / 4 pair (imsim/instcat.py:511-517: quantised to 0.05, here 2.5) has its own radial
+    table for photon shooting and its own k-table for the FFT branch; the two renderings meet the reference's
+    FFT-vs-phot criteria, and the photon pool equals the oracle's bit for bit."""
+    from imsim_amd import _abi, configs, catalog, fft_draw
+    from imsim_amd.engine import Renderer
+    from oracle import orc_loader
+    fwhm_atm, fwhm_sys = catalog.kolmogorov_gaussian_fwhm()
+    scene = configs.scene_c2(nx=128, ny=128)
+    scene.psf = [(_abi.IMS_PSF_RADIAL, 2, fwhm_atm, 0.0, 1.0), (_abi.IMS_PSF_GAUSSIAN, 0, fwhm_sys / 2.3548200450309493, 0.0, 1.0)]
+    configs.add_sersic_tables(scene, [2.5])
+    cat = dict(x=np.array([64.3]), y=np.array([63.8]), mag=np.zeros(1), nominal_flux=np.array([4.0e6]), kind=np.array([2]),
+               hlr=np.array([0.5]), q=np.array([0.7]), pa=np.array([20.0]), obj_id=np.array([3]), sersic_n=np.array([2.5]))
+    objects, _ = catalog.build_object_table(cat, np.array([4000000]), stamp_size=128, sersic_index=scene.sersic_index)
+    assert objects["prof_table"][0] == scene.sersic_index[2.5] == 3
+    rp = Renderer(scene)
+    rp.render(objects)
+    rf = Renderer(scene)
+    kt = fft_draw.profile_ktable_ids(scene, objects["prof_table"])
+    assert kt[0] == 2
+    rows, _ = fft_draw.build_fft_objects(objects, cat["nominal_flux"], kt)
+    fft_draw.FftDrawer(rf, fft_draw.kolmogorov_gaussian_kpsf(fwhm_atm, fwhm_sys), add_noise=False).draw(rows)
+    rp.synchronize(); rf.synchronize()
+    a, b = rp.image_numpy().astype(float), rf.image_numpy().astype(float)
+    yy, xx = np.mgrid[0:128, 0:128]
+    w = (np.hypot(xx - 63.3, yy - 62.8) < 25)
+
+    def mom(img):
+        f = (img * w).sum()
+        mx, my = (img * w * xx).sum() / f, (img * w * yy).sum() / f
+        return f, mx, my, (img * w * ((xx - mx) ** 2 + (yy - my) ** 2)).sum() / f
+    fa, xa, ya, ra = mom(a)
+    fb, xb, yb, rb = mom(b)
+    assert abs(a.max() / b.max() - 1) < 0.05 and abs(fa / fb - 1) < 0.01
+    assert abs(xa - xb) < 0.02 and abs(ya - yb) < 0.02 and abs(ra / rb - 1) < 0.10
+    # and it is NOT the n = 4 profile any more
+    objects4 = objects.copy()
+    objects4["prof_table"] = 1
+    r4 = Renderer(scene)
+    r4.render(objects4)
+    r4.synchronize()
+    assert abs(r4.image_numpy().max() / a.max() - 1) > 0.05
+    small = objects.copy()
+    small["n_phot"] = 5000
+    pool = Renderer(scene).shoot_photons(small)
+    opool = orc_loader.OracleScene(scene).shoot_pool(small)
+    g, o = pool.to_host(), opool.to_host()
+    for f in ("x", "y", "wavelength"):
+        assert_bits_equal(g[f], o[f], f"photon field {f} (n = 2.5)")
+
+
+def test_pooling_mode_draws_fft_objects_first(torch_cuda):
+    """LSST_PhotonPoolingImageBuilder.buildImage (imsim/photon_pooling.py:84-114): objects above the FFT threshold are
+    FFT-drawn before the photon batches and do not enter them."""
+    from imsim_amd import _abi, configs, catalog, fft_draw, lsst_image
+    from imsim_amd.engine import Renderer
+    scene = configs.scene_c3(nx=256, ny=256, sensor=False)
+    cat = catalog.synthetic_catalog(40, nx=256, ny=256)
+    cat["nominal_flux"][:2] = [3.0e6, 5.0e6]                      # two objects beyond the 1e6 floor of stamp.py:275
+    cat["kind"][:2] = [0, 1]
+    cat["sb_flux"] = cat["nominal_flux"] / 80.0
+    phot = catalog.realize_fluxes(cat["nominal_flux"], 3)
+    fwhm_atm, fwhm_sys = catalog.kolmogorov_gaussian_fwhm(configs.VISIT["airmass"], configs.VISIT["raw_seeing"], "r")
+    kpsf = fft_draw.kolmogorov_gaussian_kpsf(fwhm_atm, fwhm_sys)
+    b = lsst_image.LSST_PhotonPoolingImageBuilder()
+    b.setup({"det_name": "R22_S11", "xsize": 256, "ysize": 256, "nbatch": 3, "nsubbatch": 2}, "LSST_Photons")
+    r = Renderer(scene)
+    truth = {}
+    b.build_image(r, cat, phot, lambda c, p: configs.c3_objects(c, p, scene), seed=5, truth=truth, fft_sb_thresh=2.0e5, kpsf=kpsf,
+                  fwhm_total=float(np.hypot(fwhm_atm, fwhm_sys)))
+    r.synchronize()
+    modes = list(truth["mode"])
+    assert modes[0] == "fft" and modes[1] == "fft" and "fft" not in modes[2:]
+    assert np.all(truth["phot_flux"][:2] == 0) and np.all(truth["fft_flux"][:2] == cat["nominal_flux"][:2])
+    np.testing.assert_allclose(truth["incident_flux"][:2], cat["nominal_flux"][:2], rtol=0.03)
+    img = r.image_numpy()
+    ix, iy = int(round(cat["x"][0])) - 1, int(round(cat["y"][0])) - 1
+    assert img[iy - 2:iy + 3, ix - 2:ix + 3].sum() > 0.2 * 3.0e6 * 0.5       # the FFT-drawn star is on the image
+    # without a threshold everything is photon-shot, as before
+    r2 = Renderer(scene)
+    t2 = {}
+    b.build_image(r2, cat, phot, lambda c, p: configs.c3_objects(c, p, scene), seed=5, truth=t2)
+    assert "fft" not in list(t2["mode"]) and t2["phot_flux"][0] == phot[0]

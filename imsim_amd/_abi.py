@@ -102,7 +102,7 @@ class FftParams(C.Structure):
     _fields_ = [("seed", c_u64), ("pixel_scale", c_d), ("n_kpsf", c_i32), ("add_noise", c_i32),
                 ("kpsf", KPsf * IMS_MAX_PSF), ("ktables", LinTables), ("image", c_vp),
                 ("nx", c_i32), ("ny", c_i32), ("xmin", c_i32), ("ymin", c_i32), ("realized_flux", c_vp),
-                ("spikes", Spikes)]
+                ("spikes", Spikes), ("n_alias", c_i32), ("pad_alias", c_i32)]
 
 
 class Op(C.Structure):

@@ -145,20 +145,25 @@ VISIT = dict(ra=60.4927, dec=-38.1626, altitude=53.1637, azimuth=114.3933, rotte
              hour_angle=-20.0)
 
 
-@functools.lru_cache(maxsize=4)
-def rubin_optics_struct(nx=4096, ny=4096):
-    """Approximate Rubin telescope + WCS pair fitted to it + spider geometry -> _abi.Optics."""
-    tel = opticsmod.rubin_like_telescope(VISIT["band"])
+@functools.lru_cache(maxsize=8)
+def rubin_optics_struct(nx=4096, ny=4096, rottelpos=None, altitude=None, azimuth=None, ra=None, dec=None, rotskypos=None):
+    """Approximate Rubin telescope + WCS pair fitted to it + spider geometry -> _abi.Optics.  Angles in degrees; the
+    visit of the bench configs (VISIT) supplies whatever is not given."""
+    v = dict(VISIT)
+    for k, val in dict(rottelpos=rottelpos, altitude=altitude, azimuth=azimuth, ra=ra, dec=dec, rotskypos=rotskypos).items():
+        if val is not None:
+            v[k] = val
+    tel = opticsmod.rubin_like_telescope(v["band"])
     fp = (100.0, 0.0, (nx - 1) / 2.0 + 1.0 - 0.5, 0.0, 100.0, (ny - 1) / 2.0 + 1.0 - 0.5)
     o = _abi.Optics()
-    rot_tel = math.radians(VISIT["rottelpos"])
+    rot_tel = math.radians(v["rottelpos"])
     opticsmod.fill_optics(o, tel, fp, rot_tel)
-    img_wcs, i2f, _ = opticsmod.build_wcs_pair(tel, fp, math.radians(VISIT["ra"]), math.radians(VISIT["dec"]),
-                                               rot_sky=math.radians(VISIT["rotskypos"]), rot_tel_pos=rot_tel,
+    img_wcs, i2f, _ = opticsmod.build_wcs_pair(tel, fp, math.radians(v["ra"]), math.radians(v["dec"]),
+                                               rot_sky=math.radians(v["rotskypos"]), rot_tel_pos=rot_tel,
                                                nx=nx, ny=ny)
     o.img_wcs, o.icrf_to_field = img_wcs, i2f
-    diffraction.fill_optics(o, math.radians(VISIT["latitude"]), math.radians(VISIT["azimuth"]),
-                            math.radians(VISIT["altitude"]))
+    diffraction.fill_optics(o, math.radians(v["latitude"]), math.radians(v["azimuth"]),
+                            math.radians(v["altitude"]))
     return o
 
 

@@ -18,13 +18,9 @@ IMS_DEV double ktable_lookup(const ims_lin_tables_t& t, int table, double arg)
     return v[i] + a * (v[i + 1] - v[i]);
 }
 
-// value of the half spectrum of object o at grid index (i = ky index, j = kx index)
-IMS_DEV void kspace_value(const ims_fft_params_t& P, const ims_fft_object_t& o, int i, int j, double& re, double& im)
+// spectrum of object o (profile x PSF MTFs x pixel response x centring phase) at the k-vector (kx, ky) [rad/arcsec]
+IMS_DEV void kspace_at(const ims_fft_params_t& P, const ims_fft_object_t& o, double kx, double ky, double& re, double& im)
 {
-    const int n = o.nfft;
-    const double dk = TWO_PI / ((double)n * P.pixel_scale);          // rad / arcsec
-    const double kx = (double)j * dk;
-    const double ky = (double)(i < n / 2 ? i : i - n) * dk;
     // profile: transformed k-vector J^T k
     double amp = o.flux;
     if (o.prof_ktable >= 0) {
@@ -49,6 +45,28 @@ IMS_DEV void kspace_value(const ims_fft_params_t& P, const ims_fft_object_t& o, 
     const double ph = (kx * o.cx + ky * o.cy) * P.pixel_scale;
     dsincos(ph, s, c);
     re = amp * c; im = -amp * s;
+}
+
+// value of the half spectrum of object o at grid index (i = ky index, j = kx index).  The image is the profile
+// convolved with the pixel, SAMPLED at the pixel centres: its discrete spectrum is the continuous one folded at the
+// sampling frequency 2 pi / pixel_scale.  P.n_alias = m adds the (2m+1)^2 - 1 nearest aliases (rows of b ascending, a
+// ascending inside); 0 = base band only, right whenever the PSF's MTF is negligible at the Nyquist frequency.
+IMS_DEV void kspace_value(const ims_fft_params_t& P, const ims_fft_object_t& o, int i, int j, double& re, double& im)
+{
+    const int n = o.nfft;
+    const double dk = TWO_PI / ((double)n * P.pixel_scale);          // rad / arcsec
+    const double kx = (double)j * dk;
+    const double ky = (double)(i < n / 2 ? i : i - n) * dk;
+    if (P.n_alias <= 0) { kspace_at(P, o, kx, ky, re, im); return; }
+    const double ks = TWO_PI / P.pixel_scale;
+    double sr = 0.0, si = 0.0;
+    for (int b = -P.n_alias; b <= P.n_alias; ++b)
+        for (int a = -P.n_alias; a <= P.n_alias; ++a) {
+            double r1, i1;
+            kspace_at(P, o, kx + (double)a * ks, ky + (double)b * ks, r1, i1);
+            sr = sr + r1; si = si + i1;
+        }
+    re = sr; im = si;
 }
 
 // log Gamma(x) for x > 0 by upward recurrence to x >= 8 and the Stirling series

@@ -197,6 +197,33 @@ def set_spikes(P, diffraction_fft, wavelength):
     return k
 
 
+def psf_mtf(kpsf, ktables, q_step, k):
+    """Product of the PSF components' MTFs at radial frequency k [rad/arcsec] (host mirror of kspace_at's PSF factor)"""
+    amp = 1.0
+    for kind, table, p0 in kpsf:
+        if kind == _abi.IMS_KPSF_GAUSSIAN:
+            amp *= math.exp(-0.5 * p0 * p0 * k * k)
+        elif kind == _abi.IMS_KPSF_KOLMOGOROV:
+            amp *= math.exp(-(k / p0) ** (5.0 / 3.0))
+        else:
+            t = np.atleast_2d(ktables)[table]
+            f = k * p0 / q_step
+            amp *= 0.0 if f >= len(t) - 1 else float(np.interp(f, np.arange(len(t)), t))
+    return abs(amp)
+
+
+def alias_order(kpsf, ktables, q_step, pixel_scale=0.2, tol=1.0e-4):
+    """How many aliases of the sampling frequency the k-space fill has to fold in (ims_fft_params_t.n_alias): 0 when the
+    PSF's MTF is below `tol` at the Nyquist frequency (any seeing-limited PSF), else the smallest m whose first omitted
+    alias, at (2m + 1) x Nyquist, is below it.  GalSim reaches the same end by drawing on a k-grid out to maxk and
+    wrapping it onto the image's grid."""
+    k_nyq = math.pi / pixel_scale
+    for m in range(0, 4):
+        if psf_mtf(kpsf, ktables, q_step, (2 * m + 1) * k_nyq) < tol:
+            return m
+    return 4
+
+
 def fft_params(scene, kpsf, ktables, q_step, seed, add_noise=True, mem_put=None):
     P = FftParams()
     P.seed = int(seed)
@@ -210,6 +237,7 @@ def fft_params(scene, kpsf, ktables, q_step, seed, add_noise=True, mem_put=None)
     P.ktables.arg_min, P.ktables.arg_step = 0.0, float(q_step)
     keep, P.ktables.val = mem_put(t)
     P.nx, P.ny, P.xmin, P.ymin = scene.nx, scene.ny, scene.xmin, scene.ymin
+    P.n_alias = alias_order(kpsf, t, q_step, P.pixel_scale) if kpsf else 0
     return P, keep
 
 

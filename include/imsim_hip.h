@@ -449,6 +449,8 @@ typedef struct ims_fft_params {
     int32_t  nx, ny, xmin, ymin;
     double*  realized_flux;          /* [n_objects] or NULL */
     ims_spikes_t spikes;
+    int32_t  n_alias;                /* k-space fill: fold the aliases -n_alias..n_alias of the sampling frequency per axis (0 = base band) */
+    int32_t  pad_alias;
 } ims_fft_params_t;
 
 /* elem_prefix[n_objects+1] (device): prefix sum of nfft*(nfft/2+1); kbuf: interleaved (re, im) doubles */

@@ -21,39 +21,58 @@ static double ktable_lookup(const ims_lin_tables_t* t, int table, double arg)
     return v[i] + a * (v[i + 1] - v[i]);
 }
 
+/* spectrum at one k-vector (csrc/ims_fft.h::kspace_at restated) */
+static void kspace_at(const ims_fft_params_t* P, const ims_fft_object_t* o, double kx, double ky, double* re, double* im)
+{
+    double amp = o->flux;
+    if (o->prof_ktable >= 0) {
+        double qx = o->jac[0] * kx + o->jac[2] * ky;
+        double qy = o->jac[1] * kx + o->jac[3] * ky;
+        amp = amp * ktable_lookup(&P->ktables, o->prof_ktable, orc_sqrt(qx * qx + qy * qy) * o->prof_scale);
+    }
+    double k2 = kx * kx + ky * ky;
+    for (int c = 0; c < P->n_kpsf; ++c) {
+        const ims_kpsf_t* p = &P->kpsf[c];
+        if (p->kind == IMS_KPSF_GAUSSIAN) amp = amp * orc_exp(-0.5 * p->p0 * p->p0 * k2);
+        else if (p->kind == IMS_KPSF_KOLMOGOROV) {
+            if (k2 > 0.0) amp = amp * orc_exp(-orc_pow(orc_sqrt(k2) / p->p0, 5.0 / 3.0));
+        } else amp = amp * ktable_lookup(&P->ktables, p->table, orc_sqrt(k2) * p->p0);
+    }
+    double hx = 0.5 * kx * P->pixel_scale, hy = 0.5 * ky * P->pixel_scale;
+    double s, c;
+    if (hx != 0.0) { orc_sincos(hx, &s, &c); amp = amp * (s / hx); }
+    if (hy != 0.0) { orc_sincos(hy, &s, &c); amp = amp * (s / hy); }
+    double ph = (kx * o->cx + ky * o->cy) * P->pixel_scale;
+    orc_sincos(ph, &s, &c);
+    *re = amp * c;
+    *im = -amp * s;
+}
+
 void orc_fft_kspace_fill(const ims_fft_params_t* P, const ims_fft_object_t* objs, int64_t n_objects, double* kbuf)
 {
     for (int64_t oi = 0; oi < n_objects; ++oi) {
         const ims_fft_object_t* o = &objs[oi];
         int n = o->nfft, nh = n / 2 + 1;
         double dk = ORC_TWO_PI / ((double)n * P->pixel_scale);
+        double ks = ORC_TWO_PI / P->pixel_scale;
         for (int i = 0; i < n; ++i)
             for (int j = 0; j < nh; ++j) {
                 double kx = (double)j * dk;
                 double ky = (double)(i < n / 2 ? i : i - n) * dk;
-                double amp = o->flux;
-                if (o->prof_ktable >= 0) {
-                    double qx = o->jac[0] * kx + o->jac[2] * ky;
-                    double qy = o->jac[1] * kx + o->jac[3] * ky;
-                    amp = amp * ktable_lookup(&P->ktables, o->prof_ktable, orc_sqrt(qx * qx + qy * qy) * o->prof_scale);
+                double re, im;
+                if (P->n_alias <= 0) kspace_at(P, o, kx, ky, &re, &im);
+                else {
+                    re = 0.0; im = 0.0;
+                    for (int b = -P->n_alias; b <= P->n_alias; ++b)
+                        for (int a = -P->n_alias; a <= P->n_alias; ++a) {
+                            double r1, i1;
+                            kspace_at(P, o, kx + (double)a * ks, ky + (double)b * ks, &r1, &i1);
+                            re = re + r1; im = im + i1;
+                        }
                 }
-                double k2 = kx * kx + ky * ky;
-                for (int c = 0; c < P->n_kpsf; ++c) {
-                    const ims_kpsf_t* p = &P->kpsf[c];
-                    if (p->kind == IMS_KPSF_GAUSSIAN) amp = amp * orc_exp(-0.5 * p->p0 * p->p0 * k2);
-                    else if (p->kind == IMS_KPSF_KOLMOGOROV) {
-                        if (k2 > 0.0) amp = amp * orc_exp(-orc_pow(orc_sqrt(k2) / p->p0, 5.0 / 3.0));
-                    } else amp = amp * ktable_lookup(&P->ktables, p->table, orc_sqrt(k2) * p->p0);
-                }
-                double hx = 0.5 * kx * P->pixel_scale, hy = 0.5 * ky * P->pixel_scale;
-                double s, c;
-                if (hx != 0.0) { orc_sincos(hx, &s, &c); amp = amp * (s / hx); }
-                if (hy != 0.0) { orc_sincos(hy, &s, &c); amp = amp * (s / hy); }
-                double ph = (kx * o->cx + ky * o->cy) * P->pixel_scale;
-                orc_sincos(ph, &s, &c);
                 int64_t e = o->k_offset + (int64_t)i * nh + j;
-                kbuf[2 * e] = amp * c;
-                kbuf[2 * e + 1] = -amp * s;
+                kbuf[2 * e] = re;
+                kbuf[2 * e + 1] = im;
             }
     }
 }

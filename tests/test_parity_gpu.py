@@ -448,7 +448,7 @@ def test_config_phot_full_chain_and_pooling_agree(torch_cuda):
     LSST_Photons: per-object fluxes agree (tests/test_image.py:162-228 style: within 4 sqrt(N))."""
     a = _process(**{"image.nobjects": 60, "stamp.draw_method": "phot"})
     b = _process(**{"image.nobjects": 60, "image.type": "LSST_PhotonPoolingImage", "stamp.type": "LSST_Photons",
-                    "image.nbatch": 4, "image.nsubbatch": 3})
+                    "image.nbatch": 4, "image.nsubbatch": 3, "stamp.fft_sb_thresh": 0})      # no threshold: nothing is FFT-drawn
     ta, tb = a.truth[0], b.truth[0]
     assert np.array_equal(ta["index"], tb["index"])
     assert set(ta["mode"]) <= {"phot", "faint"}
@@ -967,13 +967,15 @@ def test_general_sersic_index_fft_and_photon_shooting_agree(torch_cuda):
     fb, xb, yb, rb = mom(b)
     assert abs(a.max() / b.max() - 1) < 0.05 and abs(fa / fb - 1) < 0.01
     assert abs(xa - xb) < 0.02 and abs(ya - yb) < 0.02 and abs(ra / rb - 1) < 0.10
-    # and it is NOT the n = 4 profile any more
+    # and it is NOT the n = 4 profile any more: a de Vaucouleurs profile of the same half-light radius puts more light far out
     objects4 = objects.copy()
     objects4["prof_table"] = 1
     r4 = Renderer(scene)
     r4.render(objects4)
     r4.synchronize()
-    assert abs(r4.image_numpy().max() / a.max() - 1) > 0.05
+    ring = (np.hypot(xx - 63.3, yy - 62.8) > 12) & w
+    a4 = r4.image_numpy().astype(float)
+    assert a4[ring].sum() > 1.15 * a[ring].sum()
     small = objects.copy()
     small["n_phot"] = 5000
     pool = Renderer(scene).shoot_photons(small)
@@ -1000,7 +1002,7 @@ def test_pooling_mode_draws_fft_objects_first(torch_cuda):
     b.setup({"det_name": "R22_S11", "xsize": 256, "ysize": 256, "nbatch": 3, "nsubbatch": 2}, "LSST_Photons")
     r = Renderer(scene)
     truth = {}
-    b.build_image(r, cat, phot, lambda c, p: configs.c3_objects(c, p, scene), seed=5, truth=truth, fft_sb_thresh=2.0e5, kpsf=kpsf,
+    b.build_image(r, cat, phot, lambda c, p: configs.c3_objects(c, p, scene), seed=5, truth=truth, fft_sb_thresh=2.0e4, kpsf=kpsf,
                   fwhm_total=float(np.hypot(fwhm_atm, fwhm_sys)))
     r.synchronize()
     modes = list(truth["mode"])

@@ -1,0 +1,144 @@
+"""Pins against numbers the REFERENCE produced: tests/data/fft-diffraction/raytrace_diffraction_values_{0,300}_exptime.npz
+hold the spike statistics of imSim's own ray-traced (batoid + GalSim) rendering of one bright star through
+RubinDiffractionOptics (generate_reference_data_from_raytracing, tests/test_diffraction_fft.py:275-291): centre,
+folded spike angle and its spread, log-log slope and intercept of the radial brightness.  The same star is rendered
+here by the HIP photon path and by the FFT spike path, the statistics are computed with the reference's estimators
+(restated below from tests/test_diffraction_fft.py:515-607) and compared with the stored values under the reference's
+own tolerances (:363-420)."""
+import math
+import os
+
+import numpy as np
+import pytest
+from scipy import stats
+
+from imsim_amd import _abi, configs, catalog
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fft-diffraction")
+XSIZE = YSIZE = 3500          # tests/test_diffraction_fft.py:294-295
+STAMP = 1000
+ROTTELPOS, ALT, AZ = 20.0, 88.0, 73.7707957
+R_MIN = 5.0
+
+
+def center_of_brightness(image):
+    return np.array([np.sum(image * np.arange(image.shape[0])[:, None]), np.sum(image * np.arange(image.shape[1]))]) / np.sum(image)
+
+
+def folded_spike_angle(image, x_center, y_center, r_min):
+    x, y = np.mgrid[0:image.shape[0], 0:image.shape[1]]
+    r = np.hypot(y - y_center, x - x_center)
+    m = r > r_min
+    alpha = np.arctan2(y[m] - y_center, x[m] - x_center) % (np.pi / 2.0)
+    w = image[m] / np.sum(image[m])
+    xm, ym = np.sum(np.cos(4 * alpha) * w), np.sum(np.sin(4 * alpha) * w)
+    R = math.hypot(xm, ym)
+    return math.atan2(ym, xm) / 4, math.sqrt(-2 * math.log(R)) / 4
+
+
+def radial_brightness_asymptotics(image, x_center, y_center, r_min=R_MIN, num_bins=25):
+    x, y = np.mgrid[0:image.shape[0], 0:image.shape[1]]
+    r = np.hypot(y - y_center, x - x_center)
+    r_max = np.max(r[image > 0.0])
+    b, r = image[r <= r_max], r[r <= r_max]
+    bins = np.geomspace(r_min, np.max(r), num=num_bins)
+    dist, _ = np.histogram(r, bins=bins, weights=b)
+    dist = dist / (np.diff(bins) * np.sum(b))
+    reg = stats.linregress(np.log((bins[1:] + bins[:-1]) / 2.0), np.log(dist))
+    return reg.slope, reg.intercept, reg.stderr, reg.intercept_stderr
+
+
+def _scene(exptime, r_outer=4.18, r_inner=2.55):
+    optics = configs.rubin_optics_struct(XSIZE, YSIZE, rottelpos=ROTTELPOS, altitude=ALT, azimuth=AZ)
+    sc = configs.scene_c2(nx=XSIZE, ny=YSIZE)
+    sc.optics = optics
+    sc.psf = [(_abi.IMS_PSF_GAUSSIAN, 0, 0.3 / 2.3548200450309493, 0.0, 1.0)]
+    sc.ops = [(_abi.IMS_OP_TIME_SAMPLER, 0, [0.0, exptime]), (_abi.IMS_OP_PUPIL_ANNULUS_SAMPLER, 0, [r_outer, r_inner]),
+              (_abi.IMS_OP_RUBIN_DIFFRACTION_OPTICS, 0, [1.0, 1.0 if exptime == 0.0 else 0.0])]
+    return sc
+
+
+def _star(scene, ref_c, n_phot):
+    """the star at the stored centre: c = (row, column) array indices -> 1-based image coordinates"""
+    cat = catalog.synthetic_catalog(1, nx=XSIZE, ny=YSIZE)
+    cat["x"][:], cat["y"][:] = ref_c[1] + 1.0, ref_c[0] + 1.0
+    cat["kind"][:] = 0
+    cat["nominal_flux"][:] = float(n_phot)
+    objects, _ = configs.c3_objects(cat, np.array([n_phot]), scene)
+    icx, icy = int(math.floor(cat["x"][0] + 0.5)), int(math.floor(cat["y"][0] + 0.5))
+    objects["stamp_xmin"], objects["stamp_xmax"] = icx - STAMP // 2, icx - STAMP // 2 + STAMP - 1
+    objects["stamp_ymin"], objects["stamp_ymax"] = icy - STAMP // 2, icy - STAMP // 2 + STAMP - 1
+    return objects
+
+
+def _stats(scene, ref):
+    from imsim_amd.engine import Renderer
+    r = Renderer(scene)
+    r.render(_star(scene, ref["c"], 6_000_000))
+    r.synchronize()
+    img = r.image.cpu().numpy()
+    assert img.sum() > 4.0e6
+    c = center_of_brightness(img)
+    angle, angle_std = folded_spike_angle(img, c[0], c[1], r_min=10.0)
+    return c, angle, angle_std, radial_brightness_asymptotics(img, c[0], c[1])
+
+
+@pytest.mark.parametrize("exptime", [0.0, 300.0])
+def test_ray_traced_spikes_match_the_references_stored_statistics(exptime):
+    """Centre, spike angle (at exptime 300 s it carries the field rotation) and the 1 / r^2 law hold for the nominal pupil
+    (PupilAnnulusSampler 2.55 .. 4.18 as in the reference's config).  The spread of the folded angle and the
+    intercept are reproduced once the two rim zones of the pupil do not reach the detector: in the reference's batoid
+    model the surfaces behind M1 clip them, so the isotropic light diffracted at the inner and outer pupil edges
+    (62 % of the light beyond 10 pixels for the bare annulus) is absent from its image and the struts dominate; the
+    approximate prescription shipped here (optics.rubin_like_telescope; the real LSST_r.yaml is external data) clips
+    nothing behind M1.  Sampling the pupil 2 cm inside both rims emulates that clipping and then ALL five stored
+    statistics are met under the reference's own tolerances -- which pins the strut geometry, the kick law
+    phi* = atan(lambda / 4 pi delta) through the ray trace, the plate scale and the field-rotation rate."""
+    ref = np.load(os.path.join(GOLD, f"raytrace_diffraction_values_{int(exptime)}_exptime.npz"))
+    c, angle, angle_std, (slope, intercept, slope_err, intercept_err) = _stats(_scene(exptime), ref)
+    np.testing.assert_allclose(c, ref["c"], atol=2.0, rtol=0.0)                         # :383-386 (2 pixel tolerance)
+    if exptime == 0.0:
+        np.testing.assert_allclose(np.rad2deg(angle), 45.0 - ROTTELPOS, atol=1.0)       # :388-396
+    np.testing.assert_allclose(np.rad2deg(angle), np.rad2deg(ref["angle"]), atol=1.0)
+    np.testing.assert_allclose(slope, -2.0, atol=0.2)                                   # :314 brightness ~ 1 / r^2
+    assert slope_err < 0.2 and intercept_err < 0.8
+    c, angle, angle_std, (slope, intercept, slope_err, intercept_err) = _stats(_scene(exptime, 4.16, 2.58), ref)
+    np.testing.assert_allclose(c, ref["c"], atol=2.0, rtol=0.0)
+    np.testing.assert_allclose(np.rad2deg(angle), np.rad2deg(ref["angle"]), atol=1.0)
+    np.testing.assert_allclose(np.rad2deg(angle_std), np.rad2deg(ref["angle_stddev"]), atol=2.0)     # :400-405
+    np.testing.assert_allclose(slope, ref["slope"], atol=0.1)
+    np.testing.assert_allclose(intercept, ref["intercept"], atol=0.5)                   # :417-418
+    assert slope_err < 0.2 and intercept_err < 0.8
+
+
+def test_fft_spikes_match_the_references_ray_tracing(tmp_path):
+    """tests/test_diffraction_fft.py:353-420: the FFT spike stencil against the stored ray-tracing statistics."""
+    from imsim_amd import fft_draw
+    from imsim_amd.diffraction_fft import DiffractionFFT
+    from imsim_amd.engine import Renderer
+    ref = np.load(os.path.join(GOLD, "raytrace_diffraction_values_0_exptime.npz"))
+    scene = _scene(0.0)
+    scene.ops = []
+    objects = _star(scene, ref["c"], 6_000_000)
+    r = Renderer(scene)
+    rows, _ = fft_draw.build_fft_objects(objects, np.array([6.0e6]), np.array([-1]))
+    wl_eff = 622.2
+    d = DiffractionFFT(exptime=0.0, azimuth=math.radians(AZ), altitude=math.radians(ALT), rotTelPos=math.radians(ROTTELPOS),
+                       brightness_threshold=1.0e5)
+    fft_draw.FftDrawer(r, [(_abi.IMS_KPSF_GAUSSIAN, 0, 0.3 / 2.3548200450309493)], add_noise=False, diffraction_fft=d,
+                       wavelength=wl_eff).draw(rows)
+    r.synchronize()
+    img = r.image.cpu().numpy()
+    # the estimators take "image > 0" as "light": numerical residue of the transform (here below 1e-9 electrons per
+    # pixel, far under what GalSim's float32 stamps resolve next to a 2e6-electron peak) is not light
+    img = np.where(img > 1.0e-6, img, 0.0)
+    c = center_of_brightness(img)
+    np.testing.assert_allclose(c, ref["c"], atol=2.0, rtol=0.0)
+    angle, angle_std = folded_spike_angle(img, c[0], c[1], r_min=10.0)
+    np.testing.assert_allclose(np.rad2deg(angle), 45.0 - ROTTELPOS, atol=1.0)
+    np.testing.assert_allclose(np.rad2deg(angle_std), np.rad2deg(ref["angle_stddev"]), atol=2.0)
+    slope, intercept, slope_err, intercept_err = radial_brightness_asymptotics(img, c[0], c[1])
+    np.testing.assert_allclose(slope, -2.0, atol=0.6)                                   # :408
+    s = 577.6 / wl_eff                                                                   # diffraction_fft.WAVELENGTH / effective wavelength
+    np.testing.assert_allclose(intercept, ref["intercept"] - math.log(s), atol=0.5)     # :411-418

@@ -100,7 +100,7 @@ def main():
     def build_inputs():
         n_obj = args.n_objects or cfg["n_objects"]
         scene = cfg["scene"]()
-        cat = catalog.synthetic_catalog(n_obj, nx=scene.nx, ny=scene.ny)
+        cat = cfg["catalog"](n_obj, scene) if "catalog" in cfg else catalog.synthetic_catalog(n_obj, nx=scene.nx, ny=scene.ny)
         phot = catalog.realize_fluxes(cat["nominal_flux"], scene.seed)
         objects, _ = cfg["objects"](cat, phot, scene)
         return scene, objects
@@ -190,9 +190,14 @@ def main():
                                               "with the concurrent brighter-fatter chains, so frac is of the whole chip"}
     roofline["limiter"] = ("f64 VALU issue (rocprofv3 SQ PMC in profiles/); HBM is the stated bound of SURVEY 8(d), "
                            "not the measured one")
+    if getattr(step, "branch_bytes", None):
+        # FFT branch: SURVEY 8(d)'s 24 N^2 B per object over the whole step (fill + transform + finish)
+        roofline["branch"] = {"algorithmic_bytes_per_step": step.branch_bytes,
+                              "achieved": step.branch_bytes / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
+                              "frac": step.branch_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     out = {
-        "metric": "objects/sec into one 4k x 4k LSST CCD (photon-shooting path)",
+        "metric": cfg.get("metric", "objects/sec into one 4k x 4k LSST CCD (photon-shooting path)"),
         "value": value, "unit": "objects/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
@@ -301,6 +306,16 @@ def cpu_parity(cfg, scene, cpu, device):
     cpu["parity"] = {"checked": "float32 CCD image of the CPU sample, GPU vs oracle, every pixel",
                      "pixels": int(want.size), "nonzero_pixels": int(np.count_nonzero(want)),
                      "bit_identical": bool(np.array_equal(got.view(np.uint32), np.asarray(want, dtype=np.float32).view(np.uint32)))}
+    if cfg.get("parity_mode") == "close":
+        # FFT branch: the k-space values are bit-identical, the library transforms (rocFFT vs numpy) agree to ~1e-11 of the
+        # peak, so a Poisson deviate can differ where its mean sits within that of a decision boundary
+        w = np.asarray(want, dtype=np.float64)
+        diff = np.abs(got.astype(np.float64) - w)
+        cpu["parity"].update(differing_pixels=int(np.count_nonzero(diff)), max_abs_diff=float(diff.max()),
+                             flux_ratio=float(got.sum() / max(w.sum(), 1e-300)),
+                             tolerance="pixels that differ < 1e-4 of the non-zero ones; total flux within 1e-6",
+                             within_tolerance=bool(np.count_nonzero(diff) <= 1e-4 * max(np.count_nonzero(w), 1) + 2
+                                                   and abs(got.sum() / max(w.sum(), 1e-300) - 1) < 1e-6))
     del gpu
     return cpu
 

@@ -659,8 +659,22 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
         # vignetting and fringing inputs are out of scope and reported as ignored
         sky = image.get("sky_level")
         if isinstance(sky, (int, float)) and not isinstance(sky, bool) and image.get("noise"):
-            # sky x radial vignetting per pixel (lsst_image.py:172-176) when input.vignetting is configured
-            builder.add_noise(renderer, float(sky), seed=seed_ccd, multiplier=vig(det_name, nx, ny) if vig is not None else None)
+            # sky x radial vignetting per pixel (lsst_image.py:172-176) when input.vignetting is configured, x the
+            # fringing map of E2V sensors when image.apply_fringing is set (lsst_image.py:178-197)
+            mult = vig(det_name, nx, ny) if vig is not None else None
+            if ev.value(image.get("apply_fringing", False)) and det_type_of(det_name) == "E2V":
+                from . import sky_model, wcs as wcsmod
+                from .camera import make_ccd
+                cx, cy = (nx + 1) / 2.0, (ny + 1) / 2.0
+                pc = wcsmod.tansip_pix_to_vec(optics.img_wcs, np.array([cx]), np.array([cy]))[0]
+                centre = (math.atan2(pc[1], pc[0]), math.asin(max(-1.0, min(1.0, pc[2]))))
+                fr = sky_model.CCD_Fringing(true_center=centre, boresight=(ra0, dec0),
+                                            seed=sky_model.sensor_seed(str(make_ccd(det_name).getSerial())), spatial_vary=True,
+                                            data_dir=data_dir if os.path.isdir(os.path.join(data_dir, "fringing_data")) else None)
+                xarr, yarr = np.meshgrid(np.arange(nx), np.arange(ny))
+                fmap = fr.calculate_fringe_amplitude(xarr, yarr)
+                mult = fmap if mult is None else mult * fmap
+            builder.add_noise(renderer, float(sky), seed=seed_ccd, multiplier=mult)
         elif "sky_level" in image:
             res.ignored.append("image.sky_level")
         renderer.synchronize()

@@ -372,3 +372,87 @@ BENCH_CONFIGS["c4"] = dict(
     cpu_step=_c4_cpu_step,
     cpu_allcore=False,          # pooling mode shares ONE sensor state between all objects: no per-object process parallelism
 )
+
+
+# ---------------------------------------------------------------------------------------------
+# FFT branch (C1 semantics: draw_method fft, no sensor): the measurement config of the profile x PSF convolution path
+# ---------------------------------------------------------------------------------------------
+def stratified_catalog(n_objects, nx, ny, bright=0):
+    """The C1 mix of SURVEY 8(d): 50 % point / 30 % Sersic n = 1 / 20 % n = 4 taken in catalog order from each class
+    of the synthetic catalog; `bright` further objects of >= 1e6 electrons stand for the objects imSim actually sends
+    down the FFT branch (stamp.py:275-277)."""
+    base = catalog.synthetic_catalog(max(20 * n_objects, 2000), nx=nx, ny=ny)
+    want = {0: n_objects // 2, 1: (3 * n_objects) // 10, 2: n_objects - n_objects // 2 - (3 * n_objects) // 10}
+    sel = np.sort(np.concatenate([np.flatnonzero(base["kind"] == k)[:m] for k, m in want.items()]))
+    cat = {k: (v[sel].copy() if isinstance(v, np.ndarray) else v) for k, v in base.items()}
+    if bright:
+        rng = np.random.default_rng(77)
+        idx = rng.choice(len(sel), size=bright, replace=False)
+        cat["nominal_flux"][idx] = 10.0 ** rng.uniform(6.0, 7.3, bright)
+        cat["sb_flux"][idx] = cat["nominal_flux"][idx] / 80.0
+    cat["obj_id"] = np.arange(len(sel), dtype=np.int64)
+    return cat
+
+
+def _fft_scene():
+    return scene_c2()
+
+
+def _fft_objects(cat, phot, scene):
+    return catalog.build_object_table(cat, np.maximum(phot, 1))
+
+
+def _fft_rows(objects):
+    from . import fft_draw
+    flux = objects["n_phot"].astype(np.float64)
+    rows, _ = fft_draw.build_fft_objects(objects, flux, fft_draw.profile_ktable_ids(None, objects["prof_table"]))
+    return rows
+
+
+def _fft_kpsf():
+    from . import fft_draw
+    return fft_draw.kolmogorov_gaussian_kpsf(*catalog.kolmogorov_gaussian_fwhm(1.2, 0.75, "r"))
+
+
+def _fft_step(renderer, objects, rank=0, world=1):
+    from . import fft_draw
+    mine = objects[rank::world] if world > 1 else objects
+    drawer = fft_draw.FftDrawer(renderer, _fft_kpsf(), add_noise=True)
+    launch = drawer.prepared(_fft_rows(mine))
+    launch.photons = int(mine["n_phot"].sum())
+    launch.object_rows = len(mine)
+    # k-space fill: one complex128 per half-spectrum element written (16 B); the whole branch moves SURVEY 8(d)'s 24 N^2 B
+    # per object of FFT size N (at the binary32 widths the survey assumed; this build computes the branch in binary64)
+    launch.timed = {3: (1, 16 * launch.kspace_elements), 1: (0, 0), 2: (0, 0)}
+    launch.branch_bytes = 24 * launch.pixels
+    launch.keep = drawer
+    return launch
+
+
+def _fft_cpu_step(orc_scene, sample):
+    """the oracle's FFT branch (numpy.fft for the transform) over the same rows"""
+    from oracle import orc_loader
+    o = orc_loader.OracleFft(orc_scene.scene, _fft_kpsf(), add_noise=True)
+    rows = _fft_rows(sample)
+    o.finish(rows, o.inverse(rows, o.fill(rows)))
+    orc_scene.image64 += o.image
+
+
+BENCH_CONFIGS["fft"] = dict(
+    n_objects=100,
+    metric="objects/sec into one 4k x 4k LSST CCD (FFT branch)",
+    catalog=lambda n, scene: stratified_catalog(n, scene.nx, scene.ny, bright=max(n // 5, 1)),
+    workload="C1 mix forced down the FFT branch: 100-source stratified synthetic instcat (50 % point / 30 % Sersic n=1 / 20 % n=4, "
+             "a fifth of them at 1e6..2e7 electrons), draw_method fft (k-space profile x Kolmogorov x Gaussian x pixel, inverse "
+             "real 2-D FFT, clip, Poisson noise, stamp -> CCD), no sensor, 4096x4096 CCD",
+    scene=_fft_scene,
+    objects=_fft_objects,
+    make_step=_fft_step,
+    timed_kernel=3,
+    kernel="k_fft_kspace_fill",
+    cpu_sample=100,
+    cpu_scene=lambda scene: scene,
+    cpu_step=_fft_cpu_step,
+    cpu_allcore=False,
+    parity_mode="close",
+)

@@ -304,8 +304,14 @@ IMS_DEV void wcs_vec_to_pix(const ims_tansip_t& w, const double (&p)[3], double&
 IMS_DEV void xy_to_v(const ims_optics_t& o, double x, double y, double wave_nm, double (&v)[3])
 {
     double p[3], thx, thy;
+#ifdef IMS_EXP_XYV_LINEAR
+    thx = o.img_wcs.cd[0] * (x - o.img_wcs.crpix[0]) + o.img_wcs.cd[1] * (y - o.img_wcs.crpix[1]);
+    thy = o.img_wcs.cd[2] * (x - o.img_wcs.crpix[0]) + o.img_wcs.cd[3] * (y - o.img_wcs.crpix[1]);
+    (void)p;
+#else
     wcs_pix_to_vec(o.img_wcs, x, y, p);
     wcs_vec_to_pix(o.icrf_to_field, p, thx, thy);
+#endif
     const double n = medium_n(o.in_medium_kind, o.in_medium_c, wave_nm);
     const double gn = ddiv(1.0, n * dsqrt_n(1.0 + thx * thx + thy * thy));
     v[0] = thx * gn; v[1] = thy * gn; v[2] = -gn;

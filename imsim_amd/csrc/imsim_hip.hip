@@ -29,7 +29,7 @@ static int hip_err(hipError_t e, const char* what)
 
 // Timing of the dominant kernel: every launch of the selected entry point between ims_enable_timing(which)
 // and the query is bracketed by a hipEvent pair on the launch stream (which: 1 = ims_shoot_accumulate,
-// 2 = ims_shoot_ops_photons).
+// 2 = ims_shoot_ops_photons, 3 = ims_fft_kspace_fill).
 #include <vector>
 static int g_timing = 0;
 static std::vector<hipEvent_t> g_events;   // pairs
@@ -1759,8 +1759,11 @@ int ims_fft_kspace_fill(const ims_fft_params_t* params, const ims_fft_object_t* 
     if (!params || !objects_dev || !elem_prefix_dev || !kbuf) return set_err(IMS_ERR_ARG, "NULL argument");
     if (params->n_kpsf < 0 || params->n_kpsf > IMS_MAX_PSF) return set_err(IMS_ERR_ARG, "n_kpsf out of range");
     if (n_objects <= 0 || n_elems <= 0) return IMS_OK;
-    hipLaunchKernelGGL(k_fft_kspace_fill, dim3(grid_for_pool(n_elems)), dim3(256), 0, (hipStream_t)stream, *params, objects_dev,
-                       n_objects, elem_prefix_dev, n_elems, kbuf);
+    {
+        LaunchTimer tm((hipStream_t)stream, 3);
+        hipLaunchKernelGGL(k_fft_kspace_fill, dim3(grid_for_pool(n_elems)), dim3(256), 0, (hipStream_t)stream, *params, objects_dev,
+                           n_objects, elem_prefix_dev, n_elems, kbuf);
+    }
     HIP_TRY(hipGetLastError());
     return IMS_OK;
 }

@@ -264,10 +264,25 @@ class FftDrawer:
     def draw(self, fft_objects, realized=None):
         """fft_objects: FFT_OBJECT_DTYPE rows sorted by nfft (build_fft_objects).  `realized`:
         optional float64 device tensor [n]."""
-        torch, r = self.torch, self.r
-        n = len(fft_objects)
-        if n == 0:
+        if len(fft_objects) == 0:
             return
+        return self._run(self._upload(fft_objects), realized)
+
+    def prepared(self, fft_objects):
+        """Upload the rows and allocate the k-space / real-space buffers once; returns a zero-argument callable that
+        draws the batch (bench.py: the timed region starts with its inputs resident in HBM)."""
+        state = self._upload(fft_objects)
+
+        def launch():
+            self._run(state, None)
+        nfft = state[0]["nfft"].astype(np.int64)
+        launch.objects = len(nfft)
+        launch.pixels = int(np.sum(nfft * nfft))
+        launch.kspace_elements = int(np.sum(nfft * (nfft // 2 + 1)))
+        return launch
+
+    def _upload(self, fft_objects):
+        torch, r = self.torch, self.r
         rows = np.ascontiguousarray(fft_objects, dtype=FFT_OBJECT_DTYPE)
         obj_t = torch.from_numpy(rows.view(np.uint8).reshape(-1)).to(r.device)
         nfft = rows["nfft"].astype(np.int64)
@@ -276,6 +291,12 @@ class FftDrawer:
         kpre_t, rpre_t = torch.from_numpy(kpre).to(r.device), torch.from_numpy(rpre).to(r.device)
         kbuf = torch.empty(int(kpre[-1]), dtype=torch.complex128, device=r.device)
         rbuf = torch.empty(int(rpre[-1]), dtype=torch.float64, device=r.device)
+        return rows, obj_t, nfft, kpre, rpre, kpre_t, rpre_t, kbuf, rbuf
+
+    def _run(self, state, realized):
+        torch, r = self.torch, self.r
+        rows, obj_t, nfft, kpre, rpre, kpre_t, rpre_t, kbuf, rbuf = state
+        n = len(rows)
         P = self.P
         P.realized_flux = realized.data_ptr() if realized is not None else None
         st = r._stream()
@@ -287,8 +308,9 @@ class FftDrawer:
             a, b = int(sel[0]), int(sel[-1]) + 1
             nh = int(size) // 2 + 1
             spec = kbuf[int(kpre[a]):int(kpre[b])].view(b - a, int(size), nh)
-            rbuf[int(rpre[a]):int(rpre[b])].view(b - a, int(size), int(size)).copy_(
-                torch.fft.irfft2(spec, s=(int(size), int(size)), norm="backward"))
+            # the transform writes straight into the real-space buffer (no staging copy)
+            torch.fft.irfft2(spec, s=(int(size), int(size)), norm="backward",
+                             out=rbuf[int(rpre[a]):int(rpre[b])].view(b - a, int(size), int(size)))
         final = rbuf
         if P.spikes.enabled:
             # DiffractionFFT.apply between the clip and the noise (stamp.py:519-522)

@@ -194,7 +194,7 @@ RegisterOutputType("LSST_CCD", "LSST_CCD")
 for _name in ("atm_psf", "tree_rings", "instance_catalog", "opsim_data", "telescope", "sky_model", "sky_catalog", "checkpoint",
               "vignetting", "table_row"):
     RegisterInputType(_name, _name)
-OUT_OF_SCOPE_INPUTS = {"sky_model", "sky_catalog", "checkpoint", "table_row"}
+OUT_OF_SCOPE_INPUTS = {"sky_model", "sky_catalog", "table_row"}
 
 # photon ops: (kind, required keys, optional keys) -- the reference's _req_params/_opt_params
 PHOTON_OPS = {
@@ -640,6 +640,11 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
             from .vignetting import Vignetting
             vig = Vignetting(str(ev.value(inp["vignetting"]["file_name"])), data_dir)
         max_simple = float(ev.value(stamp_cfg.get("max_flux_simple", 100)))
+        chk = None
+        if "checkpoint" in inp:                                # input.checkpoint: {file_name, dir} (imsim/checkpoint.py:19-20)
+            from .checkpoint import Checkpointer
+            c = {k: ev.value(v) for k, v in inp["checkpoint"].items()}
+            chk = Checkpointer(str(c["file_name"]), dir=c.get("dir"))
         dfft = None
         if "diffraction_fft" in stamp_cfg:
             from .diffraction_fft import DiffractionFFT
@@ -648,7 +653,8 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
         if itype == "LSST_PhotonPoolingImage":
             builder.build_image(renderer, cat, phot, make_objects, max_flux_simple=max_simple, seed=seed_ccd, truth=truth,
                                 fft_sb_thresh=float(ev.value(stamp_cfg.get("fft_sb_thresh", 0.0))), kpsf=kpsf, fwhm_total=fwhm_total,
-                                diffraction_fft=dfft, wavelength=wl_eff, extra_ktables=extra_ktables, vignetting=vig)
+                                diffraction_fft=dfft, wavelength=wl_eff, extra_ktables=extra_ktables, vignetting=vig,
+                                checkpoint=chk)
         else:
             builder.build_image(renderer, cat, phot, make_objects,
                                 fft_sb_thresh=float(ev.value(stamp_cfg.get("fft_sb_thresh", 0.0))), max_flux_simple=max_simple,

@@ -890,6 +890,13 @@ class Renderer:
     def image_numpy(self):
         return self.image_float().cpu().numpy()
 
+    def image64_numpy(self):
+        """the f64 accumulation image on the host (checkpoint records)"""
+        return self.image.cpu().numpy()
+
+    def set_image64(self, arr):
+        self.image.copy_(self.torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)))
+
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)
         if self._chain_ctl:

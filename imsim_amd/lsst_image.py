@@ -182,7 +182,8 @@ class LSST_PhotonPoolingImageBuilder(LSST_ImageBuilderBase):
         return super().setup(config, det_type)
 
     def build_image(self, renderer, cat, phot_flux, make_objects, max_flux_simple=100.0, seed=0, truth=None, fft_sb_thresh=0.0,
-                    kpsf=None, fwhm_total=0.8, diffraction_fft=None, wavelength=622.2, extra_ktables=(), vignetting=None):
+                    kpsf=None, fwhm_total=0.8, diffraction_fft=None, wavelength=622.2, extra_ktables=(), vignetting=None,
+                    checkpoint=None):
         """LSST_PhotonPoolingImageBuilder.buildImage (imsim/photon_pooling.py:29-174): the fluxes of all objects are known
         up front, so the objects are partitioned into FFT / photon-shooting / faint; the FFT objects are drawn FIRST
         (:84-114, in nbatch_fft batches over objects), then the photon batches run through the pooled path."""
@@ -225,7 +226,8 @@ class LSST_PhotonPoolingImageBuilder(LSST_ImageBuilderBase):
         if len(pidx):
             r_ph = torch.zeros(len(pidx), dtype=torch.float64, device=renderer.device)
             photon_pooling.build_image(renderer, objects[pidx], modes[pidx], nbatch=self.nbatch, nsubbatch=self.nsubbatch, seed=seed,
-                                       realized=r_ph)
+                                       realized=r_ph, checkpoint=checkpoint,
+                                       chk_name="buildImage_photonpooling_" + str(self.det_name))
             realized.index_add_(0, torch.from_numpy(pidx).to(renderer.device), r_ph)
         if truth is not None:
             truth["index"] = keep

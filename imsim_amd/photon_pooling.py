@@ -147,7 +147,8 @@ def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1)
     return run
 
 
-def build_image(renderer, objects, modes, nbatch=10, nsubbatch=50, seed=0, realized=None, rank=0, world=1):
+def build_image(renderer, objects, modes, nbatch=10, nsubbatch=50, seed=0, realized=None, rank=0, world=1,
+                checkpoint=None, chk_name="buildImage_photonpooling"):
     """LSST_PhotonPoolingImageBuilder.buildImage for the photon-shooting objects
     (imsim/photon_pooling.py:116-168).
 
@@ -160,14 +161,28 @@ def build_image(renderer, objects, modes, nbatch=10, nsubbatch=50, seed=0, reali
     state is shared by all objects, so before every recalculation the delta-charge image accumulated
     since the last one is all-reduced (parallel.allreduce_delta) and every rank runs the identical
     updatePixelDistortions; the per-rank images are summed by the caller (parallel.reduce_image).  Unit
-    fluxes make both sums exact, so the result equals the single-process one bit for bit."""
+    fluxes make both sums exact, so the result equals the single-process one bit for bit.
+
+    checkpoint (a checkpoint.Checkpointer): after every photon batch the image and the number of finished batches
+    are saved under chk_name; a later call finds them, restores the image and skips those batches
+    (imsim/photon_pooling.py:57-62, :129-136, :166-167).  As in the reference the sensor state is not part of the
+    record: a resumed CCD continues from fresh (tree-ring only) pixel boundaries."""
     objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
     batch_tables, len_smallest = make_batch_tables(objects, modes, nbatch, seed)
     total = 0
+    first_batch = 0
+    if checkpoint is not None:
+        saved = checkpoint.load(chk_name)
+        if saved is not None:
+            image, first_batch = saved
+            renderer.set_image64(image)
     sensor_on = renderer.scene.sensor is not None
     owner = parallel.assign_ranks(objects["n_phot"], world)
     nsub = max(min(nsubbatch, len_smallest or 1), 1)
     for i, (table, index) in enumerate(batch_tables):
+        if i < first_batch:
+            total += int(table["n_phot"].sum())
+            continue
         if len(table) == 0:
             continue
         table["bf_state"] = 0
@@ -180,7 +195,7 @@ def build_image(renderer, objects, modes, nbatch=10, nsubbatch=50, seed=0, reali
             t = table[sub]
             keep = t["n_phot"] > 0
             t, idx = t[keep], index[sub][keep]
-            if sensor_on and s == 0 and i > 0:
+            if sensor_on and s == 0 and i > first_batch:
                 # recalc=(subbatch_num == 0), resume afterwards; only tiles near the previous batch's charge move
                 # (with several ranks the tile marks are rank-local, so every tile is visited)
                 if world > 1:
@@ -200,4 +215,6 @@ def build_image(renderer, objects, modes, nbatch=10, nsubbatch=50, seed=0, reali
             if realized is not None:
                 realized.index_add_(0, renderer.torch.from_numpy(idx).to(renderer.device), tmp)
             total += int(t["n_phot"].sum())
+        if checkpoint is not None:
+            checkpoint.save(chk_name, (renderer.image64_numpy(), i + 1))
     return total

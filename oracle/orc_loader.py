@@ -128,6 +128,12 @@ class OracleScene:
         """the float32 CCD image (galsim.ImageF) rounded from the f64 accumulation"""
         return self.image64.astype(np.float32)
 
+    def image64_numpy(self):
+        return self.image64.copy()
+
+    def set_image64(self, arr):
+        self.image64[...] = arr
+
     def _objects(self, objects):
         objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
         prefix = segment_prefix(objects["n_phot"], self.scene.seg_size)

@@ -1,0 +1,78 @@
+"""Checkpointer (imsim/checkpoint.py) and the resume of a photon-pooling CCD, on the CPU oracle standing in for the GPU
+renderer (tests/test_checkpoint.py of the reference exercises the same save / load / recovery behaviour)."""
+import os
+
+import numpy as np
+
+from imsim_amd import photon_pooling, stamp
+from imsim_amd.checkpoint import Checkpointer
+from helpers import c3_small_case
+
+
+def test_save_load_and_named_records(tmp_path):
+    chk = Checkpointer("chk.hdf", dir=str(tmp_path))
+    assert chk.load("a") is None                                   # no file yet
+    chk.save("a", {"x": np.arange(5), "n": 3})
+    chk.save("b", [1, 2, 3])
+    assert not os.path.exists(chk.file_name_bak) and not os.path.exists(chk.file_name_new)
+    again = Checkpointer("chk.hdf", dir=str(tmp_path))
+    a = again.load("a")
+    assert a["n"] == 3 and np.array_equal(a["x"], np.arange(5)) and again.load("b") == [1, 2, 3]
+    assert again.load("missing") is None
+    again.save("a", "replaced")                                    # a record is replaced, the others stay
+    assert Checkpointer("chk.hdf", dir=str(tmp_path)).load("a") == "replaced"
+    assert Checkpointer("chk.hdf", dir=str(tmp_path)).load("b") == [1, 2, 3]
+
+
+def test_recovery_from_interrupted_writes(tmp_path):
+    """the four start-up states of imsim/checkpoint.py:43-64"""
+    chk = Checkpointer("c.hdf", dir=str(tmp_path))
+    chk.save("a", 1)
+    # B: died between steps 1 and 4 -- only the backup (and maybe a half-written new file) exists
+    os.rename(chk.file_name, chk.file_name_bak)
+    open(chk.file_name_new, "wb").write(b"garbage")
+    rec = Checkpointer("c.hdf", dir=str(tmp_path))
+    assert rec.load("a") == 1 and not os.path.exists(rec.file_name_bak) and not os.path.exists(rec.file_name_new)
+    # C: died between steps 4 and 5 -- the new file is in place, the backup is stale
+    rec.save("a", 2)
+    open(rec.file_name_bak, "wb").write(b"stale")
+    rec2 = Checkpointer("c.hdf", dir=str(tmp_path))
+    assert rec2.load("a") == 2 and not os.path.exists(rec2.file_name_bak)
+
+
+def test_photon_pooling_resumes_after_the_last_finished_batch(tmp_path):
+    """imsim/photon_pooling.py:57-62, :129-136, :166-167: a run interrupted after batch k and restarted renders batches
+    k.. only.  Without the sensor the resumed image equals the uninterrupted one bit for bit (every photon's random
+    stream is addressed by (object, photon index), so nothing depends on when a batch runs)."""
+    from oracle import orc_loader
+    scene, objects = c3_small_case(n_obj=80, n=128, flux_seed=4, sensor=False)
+    modes = stamp.classify(objects["n_phot"].astype(float), 100.0)
+    full = orc_loader.OracleScene(scene)
+    n_all = photon_pooling.build_image(full, objects, modes, nbatch=5, nsubbatch=3, seed=3)
+
+    class Interrupt(Exception):
+        pass
+
+    class Dying(Checkpointer):
+        def save(self, name, data):
+            super().save(name, data)
+            if data[1] == 2:                                        # the process dies right after the second batch's record
+                raise Interrupt()
+
+    first = orc_loader.OracleScene(scene)
+    try:
+        photon_pooling.build_image(first, objects, modes, nbatch=5, nsubbatch=3, seed=3, checkpoint=Dying("ccd.hdf", dir=str(tmp_path)))
+        raise AssertionError("not interrupted")
+    except Interrupt:
+        pass
+    assert 0 < first.image64.sum() < full.image64.sum()
+    resumed = orc_loader.OracleScene(scene)
+    chk = Checkpointer("ccd.hdf", dir=str(tmp_path))
+    n = photon_pooling.build_image(resumed, objects, modes, nbatch=5, nsubbatch=3, seed=3, checkpoint=chk)
+    assert n == n_all
+    assert np.array_equal(resumed.image64, full.image64)
+    assert chk.load("buildImage_photonpooling")[1] == 5
+    # a finished CCD is not rendered again
+    again = orc_loader.OracleScene(scene)
+    photon_pooling.build_image(again, objects, modes, nbatch=5, nsubbatch=3, seed=3, checkpoint=Checkpointer("ccd.hdf", dir=str(tmp_path)))
+    assert np.array_equal(again.image64, full.image64)

@@ -142,7 +142,12 @@ def read_fits(file_name):
                     header[c[:8].strip()] = _parse_value(c[10:])
         naxis = header.get("NAXIS", 0)
         data = None
-        if naxis > 0:
+        if header.get("XTENSION") == "BINTABLE":
+            # binary table: NAXIS1 x NAXIS2 bytes of rows followed by PCOUNT bytes of heap (variable-length arrays)
+            n = int(header["NAXIS1"]) * int(header["NAXIS2"]) + int(header.get("PCOUNT", 0))
+            data = _parse_bintable(header, raw[pos:pos + n])
+            pos += n + ((-n) % BLOCK)
+        elif naxis > 0:
             shape = tuple(header[f"NAXIS{k}"] for k in range(naxis, 0, -1))
             dtype = {v: k for k, v in BITPIX.items()}[header["BITPIX"]]
             n = int(np.prod(shape)) * dtype.itemsize
@@ -150,3 +155,82 @@ def read_fits(file_name):
             pos += n + ((-n) % BLOCK)
         out.append((header, data))
     return out
+
+
+# ---- binary tables (cosmic-ray catalogs, imsim/cosmic_rays.py:112-185; tile-compressed images) ----
+_TFORM = {"L": ("u1", 1), "B": ("u1", 1), "I": (">i2", 2), "J": (">i4", 4), "K": (">i8", 8), "E": (">f4", 4), "D": (">f8", 8)}
+
+
+def _split_tform(tform):
+    """'1J' -> (1, 'J', None); 'PJ()' / '1PB(120)' -> (1, 'P', 'J')"""
+    tform = tform.strip()
+    k = 0
+    while k < len(tform) and tform[k].isdigit():
+        k += 1
+    rep = int(tform[:k]) if k else 1
+    code = tform[k]
+    if code in "PQ":
+        return rep, code, tform[k + 1]
+    return rep, code, None
+
+
+def _parse_bintable(header, raw):
+    nrow, width = int(header["NAXIS2"]), int(header["NAXIS1"])
+    heap0 = int(header.get("THEAP", nrow * width))
+    cols, off = {}, 0
+    main = np.frombuffer(raw[:nrow * width], dtype=np.uint8).reshape(nrow, width) if nrow else np.zeros((0, width), np.uint8)
+    for k in range(1, int(header["TFIELDS"]) + 1):
+        rep, code, sub = _split_tform(str(header[f"TFORM{k}"]))
+        name = str(header.get(f"TTYPE{k}", f"col{k}"))
+        if code in "PQ":
+            dsize = 8 if code == "P" else 16
+            desc = np.ascontiguousarray(main[:, off:off + dsize]).view(">i4" if code == "P" else ">i8").reshape(nrow, 2)
+            dt, isz = _TFORM[sub]
+            vals = []
+            for n_el, o in desc:
+                a = heap0 + int(o)
+                vals.append(np.frombuffer(raw[a:a + int(n_el) * isz], dtype=dt).astype(dt.lstrip(">")))
+            cols[name] = vals
+            off += dsize
+        else:
+            dt, isz = _TFORM[code]
+            block = np.ascontiguousarray(main[:, off:off + rep * isz]).view(dt).reshape(nrow, rep).astype(dt.lstrip(">"))
+            cols[name] = block[:, 0] if rep == 1 else block
+            off += rep * isz
+    return cols
+
+
+def bintable_hdu_bytes(columns, header=(), extname=None):
+    """Binary-table extension from [(name, tform, values)]; tform 'J', 'I', 'E', 'D', 'K', 'B' (scalars per row) or
+    'PJ()' / 'PB()' / 'PI()' (one variable-length array per row, stored in the heap)."""
+    nrow = len(columns[0][2]) if columns else 0
+    parts, heap, tforms = [], bytearray(), []
+    for name, tform, values in columns:
+        rep, code, sub = _split_tform(tform)
+        if code == "P":
+            dt, isz = _TFORM[sub]
+            desc = np.zeros((nrow, 2), dtype=">i4")
+            longest = 0
+            for r, v in enumerate(values):
+                v = np.asarray(v).astype(dt)
+                desc[r] = (len(v), len(heap))
+                heap += v.tobytes()
+                longest = max(longest, len(v))
+            parts.append(desc.view(np.uint8).reshape(nrow, 8))
+            tforms.append(f"1P{sub}({longest})")
+        else:
+            dt, isz = _TFORM[code]
+            parts.append(np.ascontiguousarray(np.asarray(values).astype(dt)).view(np.uint8).reshape(nrow, isz))
+            tforms.append(f"1{code}")
+    main = np.concatenate(parts, axis=1) if parts else np.zeros((0, 0), np.uint8)
+    cards = [card("XTENSION", "BINTABLE", "binary table extension"), card("BITPIX", 8), card("NAXIS", 2),
+             card("NAXIS1", main.shape[1]), card("NAXIS2", nrow), card("PCOUNT", len(heap)), card("GCOUNT", 1),
+             card("TFIELDS", len(columns))]
+    for k, ((name, _, _), tf) in enumerate(zip(columns, tforms), 1):
+        cards += [card(f"TTYPE{k}", name), card(f"TFORM{k}", tf)]
+    if extname:
+        cards.append(card("EXTNAME", extname))
+    for k, v, c in _norm_items(header):
+        cards.append(card(k, v, c))
+    body = main.tobytes() + bytes(heap)
+    return _header_bytes(cards) + body + b"\0" * ((-len(body)) % BLOCK)

@@ -247,8 +247,22 @@ def _allcore_worker(k):
     orc = st["orc"]
     orc.image64 = np.zeros_like(orc.image64)
     t0 = time.perf_counter()
-    st["cfg"]["cpu_step"](orc, part)
+    _cpu_step(st["cfg"])(orc, part)
     return (len(part), int(part["n_phot"].sum()), float(orc.image64.sum()), time.perf_counter() - t0)
+
+
+def _cpu_step(cfg):
+    """the oracle-side step of a config; the FFT branch's lives here because the package never imports the oracle"""
+    if cfg.get("cpu_step") is not None:
+        return cfg["cpu_step"]
+
+    def fft_step(orc_scene, sample):
+        from oracle import orc_loader
+        o = orc_loader.OracleFft(orc_scene.scene, cfg["fft_kpsf"](), add_noise=True)
+        rows = cfg["fft_rows"](sample)
+        o.finish(rows, o.inverse(rows, o.fill(rows)))
+        orc_scene.image64 += o.image
+    return fft_step
 
 
 def cpu_legs(cfg, scene, objects, args, fork_ok=True):
@@ -265,7 +279,7 @@ def cpu_legs(cfg, scene, objects, args, fork_ok=True):
     cpu_scene = cfg["cpu_scene"](scene)
     orc = orc_loader.OracleScene(cpu_scene)
     t0 = time.perf_counter()
-    cfg["cpu_step"](orc, sample)
+    _cpu_step(cfg)(orc, sample)
     dt = time.perf_counter() - t0
     res = {"value": len(sample) / dt, "unit": "objects/s", "cores": 1, "kind": "port",
            "sample": f"{len(sample)} objects drawn at random from the same catalog "

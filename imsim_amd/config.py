@@ -641,10 +641,16 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
             vig = Vignetting(str(ev.value(inp["vignetting"]["file_name"])), data_dir)
         max_simple = float(ev.value(stamp_cfg.get("max_flux_simple", 100)))
         chk = None
-        if "checkpoint" in inp:                                # input.checkpoint: {file_name, dir} (imsim/checkpoint.py:19-20)
+        if "checkpoint" in inp and itype == "LSST_PhotonPoolingImage":     # input.checkpoint: {file_name, dir} (checkpoint.py:19-20)
             from .checkpoint import Checkpointer
             c = {k: ev.value(v) for k, v in inp["checkpoint"].items()}
+            if "file_name" not in c:
+                raise GalSimConfigError("Attribute file_name is required for input.checkpoint")
             chk = Checkpointer(str(c["file_name"]), dir=c.get("dir"))
+        elif "checkpoint" in inp:
+            # LSST_Image: a CCD is ONE launch plan of some tens of milliseconds here, there is no state between batches to save
+            res.ignored.append("input.checkpoint (LSST_Image renders a CCD in one launch plan; checkpoints are kept per photon batch "
+                               "in LSST_PhotonPoolingImage mode)")
         dfft = None
         if "diffraction_fft" in stamp_cfg:
             from .diffraction_fft import DiffractionFFT

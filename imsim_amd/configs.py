@@ -429,15 +429,6 @@ def _fft_step(renderer, objects, rank=0, world=1):
     return launch
 
 
-def _fft_cpu_step(orc_scene, sample):
-    """the oracle's FFT branch (numpy.fft for the transform) over the same rows"""
-    from oracle import orc_loader
-    o = orc_loader.OracleFft(orc_scene.scene, _fft_kpsf(), add_noise=True)
-    rows = _fft_rows(sample)
-    o.finish(rows, o.inverse(rows, o.fill(rows)))
-    orc_scene.image64 += o.image
-
-
 BENCH_CONFIGS["fft"] = dict(
     n_objects=100,
     metric="objects/sec into one 4k x 4k LSST CCD (FFT branch)",
@@ -452,7 +443,9 @@ BENCH_CONFIGS["fft"] = dict(
     kernel="k_fft_kspace_fill",
     cpu_sample=100,
     cpu_scene=lambda scene: scene,
-    cpu_step=_fft_cpu_step,
+    cpu_step=None,                      # bench.py supplies the checker's FFT branch (nothing in this package touches the oracle)
+    fft_rows=_fft_rows,
+    fft_kpsf=_fft_kpsf,
     cpu_allcore=False,
     parity_mode="close",
 )

@@ -451,7 +451,8 @@ def test_config_phot_full_chain_and_pooling_agree(torch_cuda):
     LSST_Photons: per-object fluxes agree (tests/test_image.py:162-228 style: within 4 sqrt(N))."""
     a = _process(**{"image.nobjects": 60, "stamp.draw_method": "phot"})
     b = _process(**{"image.nobjects": 60, "image.type": "LSST_PhotonPoolingImage", "stamp.type": "LSST_Photons",
-                    "image.nbatch": 4, "image.nsubbatch": 3, "stamp.fft_sb_thresh": 0})      # no threshold: nothing is FFT-drawn
+                    "image.nbatch": 4, "image.nsubbatch": 3, "stamp.fft_sb_thresh": 0,       # no threshold: nothing is FFT-drawn
+                    "input.checkpoint": ""})
     ta, tb = a.truth[0], b.truth[0]
     assert np.array_equal(ta["index"], tb["index"])
     assert set(ta["mode"]) <= {"phot", "faint"}

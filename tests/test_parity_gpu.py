@@ -443,7 +443,7 @@ def test_config_c1_fft_no_sensor(torch_cuda):
     assert on.sum() >= 0.7 * len(on)                       # objects near the CCD edge lose flux off the stamp
     # Poisson-noised total close to the drawn flux
     assert abs(img.sum() / truth["realized_flux"].sum() - 1) < 0.02
-    assert "input.sky_model" in res.ignored and "input.checkpoint" in res.ignored
+    assert "input.sky_model" in res.ignored and any(m.startswith("input.checkpoint") for m in res.ignored)
 
 
 def test_config_phot_full_chain_and_pooling_agree(torch_cuda):

@@ -234,3 +234,158 @@ def bintable_hdu_bytes(columns, header=(), extname=None):
         cards.append(card(k, v, c))
     body = main.tobytes() + bytes(heap)
     return _header_bytes(cards) + body + b"\0" * ((-len(body)) % BLOCK)
+
+
+# ---- RICE_1 tile-compressed images (the reference writes the 16 segments of a raw file with
+#      fits.CompImageHDU(..., compression_type='RICE_1'), imsim/readout.py:500-510) ----
+# FITS tiled-image convention: a binary table with one row per tile (here: one image row per tile, the default) whose
+# COMPRESSED_DATA column holds the Rice-coded bytes; keywords ZIMAGE, ZCMPTYPE, ZBITPIX, ZNAXISn, ZTILEn, ZNAMEn / ZVALn
+# (BLOCKSIZE 32, BYTEPIX 4).  The Rice coder is the 32-bit variant of CFITSIO's fits_rcomp: the first pixel verbatim in
+# 32 bits, then per block of 32 pixels the zig-zag mapped differences to the previous pixel, split at FS bits: FS + 1 in
+# 5 bits, then for every pixel the high part in unary (that many zeros and a one) and the low FS bits verbatim; FS = 0
+# with an all-zero block is coded as 0 alone, FS >= 25 switches to 32 raw bits per difference.
+RICE_BLOCK = 32
+
+
+def _rice_fs(diff_blocks, counts):
+    """split position per block from the block sums (fits_rcomp: dpsum = (sum - n/2 - 1) / n, FS = bit length of dpsum / 2)"""
+    psum = diff_blocks.sum(axis=1, dtype=np.float64)
+    dpsum = (psum - (counts // 2) - 1) / counts
+    dpsum = np.where(dpsum < 0, 0.0, dpsum)
+    half = (dpsum.astype(np.uint64) >> np.uint64(1)).astype(np.uint64)
+    fs = np.zeros(len(half), dtype=np.int64)
+    nz = half > 0
+    fs[nz] = np.floor(np.log2(half[nz].astype(np.float64))).astype(np.int64) + 1
+    # guard the float log2 at exact powers of two
+    fs = np.where((half >> fs.astype(np.uint64)) > 0, fs + 1, fs)
+    fs = np.where((fs > 0) & ((half >> (fs - 1).clip(0).astype(np.uint64)) == 0), fs - 1, fs)
+    return fs, psum
+
+
+def rice_compress_rows(img):
+    """Rice-code every row of an int32 image as its own tile.  Returns a list of uint8 arrays (one per row)."""
+    img = np.ascontiguousarray(img, dtype=np.int32)
+    ny, nx = img.shape
+    a = img.astype(np.int64)
+    prev = np.concatenate([a[:, :1], a[:, :-1]], axis=1)
+    pd = (a - prev).astype(np.int32).astype(np.int64)                   # 32-bit wrap-around differences, as in C
+    diff = np.where(pd < 0, ~(pd << 1), pd << 1) & 0xFFFFFFFF           # zig-zag to unsigned
+    nb = (nx + RICE_BLOCK - 1) // RICE_BLOCK
+    pad = nb * RICE_BLOCK - nx
+    d = np.pad(diff, ((0, 0), (0, pad))).reshape(ny * nb, RICE_BLOCK)
+    counts = np.full(ny * nb, RICE_BLOCK, dtype=np.int64)
+    if pad:
+        counts[nb - 1::nb] = RICE_BLOCK - pad
+    valid = np.arange(RICE_BLOCK)[None, :] < counts[:, None]
+    fs, psum = _rice_fs(d, counts)
+    raw = fs >= 25
+    zero = (fs == 0) & (psum == 0)
+    # bit runs per pixel: `top` zeros, a one, then the low fs bits; per block a 5-bit header.  All rows are laid out in
+    # ONE bit array (every row padded to a whole byte) and filled group by group of equal FS.
+    fsb = np.where(raw | zero, 0, fs)
+    top = np.where(valid, d >> fsb[:, None], 0)
+    coded = ~(raw | zero)
+    ln = np.where(raw[:, None], 32, np.where(zero[:, None], 0, top + 1 + fsb[:, None])) * valid          # bits per pixel
+    head = np.where(raw, 26, np.where(zero, 0, fs + 1))
+    per_block = np.concatenate([np.full((ny * nb, 1), 5, dtype=np.int64), ln], axis=1)                # header + pixels
+    per_row = per_block.reshape(ny, nb * (RICE_BLOCK + 1))
+    starts_in_row = 32 + np.cumsum(per_row, axis=1) - per_row
+    row_bits = 32 + per_row.sum(axis=1)
+    row_bytes = (row_bits + 7) // 8
+    row_base = np.concatenate([[0], np.cumsum(row_bytes * 8)[:-1]])
+    starts = (starts_in_row + row_base[:, None]).reshape(ny * nb, RICE_BLOCK + 1)
+    bits = np.zeros(int(row_bytes.sum()) * 8, dtype=np.uint8)
+    # first pixel of every row, 32 bits
+    first = (img[:, 0].astype(np.int64) & 0xFFFFFFFF)
+    bits[(row_base[:, None] + np.arange(32)[None, :]).reshape(-1)] = ((first[:, None] >> np.arange(31, -1, -1)[None, :]) & 1).reshape(-1)
+    # block headers, 5 bits
+    bits[(starts[:, :1] + np.arange(5)[None, :]).reshape(-1)] = ((head[:, None] >> np.arange(4, -1, -1)[None, :]) & 1).reshape(-1)
+    pix_start = starts[:, 1:]
+    sel = coded[:, None] & valid
+    bits[(pix_start + top)[sel]] = 1                                         # the one that ends the unary part
+    for f in np.unique(fsb[coded]):
+        f = int(f)
+        if f == 0:
+            continue
+        m = (coded & (fsb == f))[:, None] & valid
+        base = (pix_start + top + 1)[m]
+        vals = d[m]
+        bits[(base[:, None] + np.arange(f)[None, :]).reshape(-1)] = ((vals[:, None] >> np.arange(f - 1, -1, -1)[None, :]) & 1).reshape(-1)
+    if raw.any():
+        m = raw[:, None] & valid
+        base = pix_start[m]
+        vals = d[m]
+        bits[(base[:, None] + np.arange(32)[None, :]).reshape(-1)] = ((vals[:, None] >> np.arange(31, -1, -1)[None, :]) & 1).reshape(-1)
+    packed = np.packbits(bits)
+    offs = np.concatenate([[0], np.cumsum(row_bytes)])
+    return [packed[offs[r]:offs[r + 1]] for r in range(ny)]
+
+
+def rice_decompress_row(buf, nx):
+    """inverse of the coder above for one tile (used by the tests and by read_compressed_image)"""
+    bits = np.unpackbits(np.asarray(buf, dtype=np.uint8))
+    pos = 0
+
+    def take(n):
+        nonlocal pos
+        v = 0
+        for b in bits[pos:pos + n]:
+            v = (v << 1) | int(b)
+        pos += n
+        return v
+    last = take(32)
+    if last >= 1 << 31:
+        last -= 1 << 32
+    out = np.zeros(nx, dtype=np.int64)
+    i = 0
+    while i < nx:
+        n = min(RICE_BLOCK, nx - i)
+        fs = take(5) - 1
+        for j in range(n):
+            if fs < 0:
+                diff = 0
+            elif fs == 25:
+                diff = take(32)
+            else:
+                t = 0
+                while bits[pos] == 0:
+                    t += 1
+                    pos += 1
+                pos += 1
+                diff = (t << fs) | (take(fs) if fs else 0)
+            pd = (diff >> 1) if (diff & 1) == 0 else ~(diff >> 1)
+            last = ((last + pd + (1 << 31)) % (1 << 32)) - (1 << 31)
+            out[i + j] = last
+        i += n
+    return out.astype(np.int32)
+
+
+def compressed_image_hdu_bytes(header, data, extname=None):
+    """int32 image -> tile-compressed BINTABLE extension (ZCMPTYPE RICE_1, one row per tile)"""
+    data = np.ascontiguousarray(data, dtype=np.int32)
+    ny, nx = data.shape
+    rows = rice_compress_rows(data)
+    z = [("ZIMAGE", (True, "extension contains compressed image")), ("ZTENSION", "IMAGE"), ("ZBITPIX", 32), ("ZNAXIS", 2),
+         ("ZNAXIS1", nx), ("ZNAXIS2", ny), ("ZPCOUNT", 0), ("ZGCOUNT", 1), ("ZTILE1", nx), ("ZTILE2", 1), ("ZCMPTYPE", "RICE_1"),
+         ("ZNAME1", "BLOCKSIZE"), ("ZVAL1", RICE_BLOCK), ("ZNAME2", "BYTEPIX"), ("ZVAL2", 4)]
+    user = [(k, (v, c) if c else v) for k, v, c in _norm_items(header) if k != "EXTNAME"]
+    name = extname or dict((k, v) for k, v, _ in _norm_items(header)).get("EXTNAME")
+    return bintable_hdu_bytes([("COMPRESSED_DATA", "PB()", rows)], header=z + user, extname=name)
+
+
+def write_fits_compressed(file_name, hdus):
+    """like write_fits, the image extensions RICE_1 tile-compressed (the primary HDU stays as it is)"""
+    with open(file_name, "wb") as fobj:
+        for k, (header, data) in enumerate(hdus):
+            if k == 0 or data is None:
+                fobj.write(hdu_bytes(header, data, primary=(k == 0)))
+            else:
+                fobj.write(compressed_image_hdu_bytes(header, data))
+
+
+def read_compressed_image(header, table):
+    """(header, parsed BINTABLE) of a RICE_1 tile-compressed int32 image -> the image"""
+    nx, ny = int(header["ZNAXIS1"]), int(header["ZNAXIS2"])
+    if header.get("ZCMPTYPE") != "RICE_1" or int(header.get("ZTILE2", 1)) != 1 or int(header["ZTILE1"]) != nx:
+        raise ValueError("only row-tiled RICE_1 images are supported")
+    return np.stack([rice_decompress_row(row, nx) for row in table["COMPRESSED_DATA"]]).reshape(ny, nx)

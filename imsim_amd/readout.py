@@ -252,6 +252,13 @@ class CcdReadout:
         return hdus
 
     @staticmethod
-    def write_raw_file(hdus, file_name):
+    def write_raw_file(hdus, file_name, compression=None):
+        """compression="RICE_1": the segments as tile-compressed images, as the reference writes them
+        (fits.CompImageHDU(..., compression_type='RICE_1'), imsim/readout.py:500-510); None: plain IMAGE extensions."""
         hdus[0][0]["OUTFILE"] = os.path.basename(file_name)
-        fits_io.write_fits(file_name, hdus)
+        if compression in (None, "", "none"):
+            fits_io.write_fits(file_name, hdus)
+        elif compression == "RICE_1":
+            fits_io.write_fits_compressed(file_name, hdus)
+        else:
+            raise ValueError(f"unsupported compression {compression}")

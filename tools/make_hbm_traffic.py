@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Rebuild profiles/hbm_traffic.json (what bench.py reports as roofline.traffic) from the committed
-per-config PMC summaries profiles/round1_<config>_final_hbm_pmc.json (tools/pmc_summary.py output)."""
+"""Rebuild profiles/hbm_traffic.json (what bench.py reports as roofline.traffic and uses for the f64-issue fraction) from
+the committed per-config PMC summaries (tools/pmc_summary.py output): profiles/round2_<config>_hbm_pmc.json and
+round2_<config>_sq_pmc.json where present, else the round-1 files profiles/round1_<config>_final_hbm_pmc.json."""
 import json
 import os
 import sys
@@ -10,14 +11,18 @@ KERNELS = {"k_shoot_accumulate(ims_render_params)": "k_shoot_accumulate",
            "void k_shoot_photons<true>(ims_render_params, long const*, ims_photons)": "k_shoot_photons<true>"}
 
 
-def main(tag="round1"):
+def main():
     out = {}
     for cfg in ("c2", "c3", "c3b"):
-        src = f"profiles/{tag}_{cfg}_final_hbm_pmc.json"
+        src = f"profiles/round2_{cfg}_hbm_pmc.json"
+        if not os.path.exists(os.path.join(ROOT, src)):
+            src = f"profiles/round1_{cfg}_final_hbm_pmc.json"
         path = os.path.join(ROOT, src)
         if not os.path.exists(path):
             continue
         d = json.load(open(path))
+        sq_src = f"profiles/round2_{cfg}_sq_pmc.json"
+        sq = json.load(open(os.path.join(ROOT, sq_src))) if os.path.exists(os.path.join(ROOT, sq_src)) else {}
         for long_name, short in KERNELS.items():
             if long_name not in d:
                 continue
@@ -32,9 +37,14 @@ def main(tag="round1"):
                 "source": src,
                 "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024",
             }
+            if long_name in sq and "SQ_INSTS_VALU" in sq[long_name] and "SQ_WAVES" in sq[long_name]:
+                q = sq[long_name]
+                out[cfg][short].update(valu_insts_per_wave=q["SQ_INSTS_VALU"]["sum"] / q["SQ_WAVES"]["sum"],
+                                       valu_busy_frac_of_wave_cycles=q["SQ_ACTIVE_INST_VALU"]["sum"] / q["SQ_WAVE_CYCLES"]["sum"],
+                                       sq_source=sq_src)
     json.dump(out, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:])
+    main()

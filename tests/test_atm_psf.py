@@ -50,3 +50,23 @@ def test_second_kick_table_is_a_proper_cdf():
     # a larger kcrit leaves less turbulence for the second kick
     r2b, cdfb = atm_psf.second_kick_table(622.2, 0.17, 8.36, 0.61, 1.0)
     assert np.sqrt(np.interp(0.5, cdfb, r2b)) < hlr
+
+
+def test_r0_500_inverts_the_tokovinin_formula():
+    """tests/test_psf.py:228-246 of the reference: for ten random (airmass, rawSeeing, band) the r0_500 the constructor
+    solves for reproduces the target FWHM through the von Karman seeing formula to 1e-3 arcsec."""
+    rng = np.random.default_rng(57721)
+    for _ in range(10):
+        airmass = rng.uniform(1.001, 1.5)
+        raw_seeing = rng.uniform(0.5, 1.5)
+        band = "ugrizy"[rng.integers(6)]
+        atm = atm_psf.AtmosphericPSF(airmass, raw_seeing, band, seed=int(rng.integers(2 ** 31)), screen_size=6.4)
+        wlen = dict(u=365.49, g=480.03, r=622.20, i=754.06, z=868.21, y=991.66)[band]
+        target = raw_seeing * airmass ** 0.6 * (wlen / 500.0) ** (-0.3)
+        np.testing.assert_allclose(atm.targetFWHM, target, rtol=1e-12)
+        assert 10.0 <= atm.L0 <= 100.0
+        np.testing.assert_allclose(atm_psf.vk_seeing(atm.r0_500, wlen, atm.L0), target, atol=1e-3, rtol=0)
+    # the truncated log-normal outer scale stays inside [10, 100] m (atmPSF.py:249-252)
+    for L0 in (10.0, 25.0, 100.0):
+        r = atm_psf.r0_500_for_seeing(622.2, L0, 0.8)
+        np.testing.assert_allclose(atm_psf.vk_seeing(r, 622.2, L0), 0.8, atol=1e-6)

@@ -1548,3 +1548,36 @@ def test_twenty_object_image_splits_and_sums_like_the_reference(torch_cuda, pool
     key = "incident_flux" if pooling else "realized_flux"
     fl = truth[key]
     np.testing.assert_allclose(fl[:-1], flux[:-1], rtol=0.1)                    # tests/test_image.py:224-226
+
+
+@pytest.mark.parametrize("exponent", [-0.2, -0.3])
+def test_atmospheric_psf_is_chromatic_with_the_configured_exponent(torch_cuda, exponent):
+    """tests/test_psf.py:322-339 of the reference: a star seen through the AtmosphericPSF at 400 nm and at 900 nm; the ratio of
+    the PSF sizes is (400 / 900)^exponent to 0.1 %.  Here on the photons themselves (the reference measures HSM moments on
+    1e5-photon images): both wavelengths draw the same deviates, so the atmospheric displacements scale exactly."""
+    from imsim_amd import _abi, atm_psf, configs, catalog
+    from imsim_amd.engine import Renderer
+    pos = {}
+    for wl in (400.0, 900.0):
+        scene = configs.scene_c3(nx=256, ny=256, sensor=False)
+        scene.ops = []
+        # the reference's set-up: airmass 1, seeing 1", 51.2 m screens, 600 s "for lots of mixing", second kick off "since it's
+        # achromatic" (:279-292)
+        atm = atm_psf.AtmosphericPSF(1.0, 1.0, "r", seed=5, exponent=exponent, exptime=600.0, screen_size=51.2, screen_scale=0.1,
+                                     no2k=True, device=torch_cuda.device("cuda", 0))
+        scene.atm = atm
+        scene.psf = atm.psf_components(second_kick_table_id=0)
+        assert len(scene.psf) == 1
+        cat = catalog.synthetic_catalog(1, nx=256, ny=256)
+        cat["x"][:], cat["y"][:], cat["kind"][:], cat["nominal_flux"][:] = 128.0, 128.0, 0, 1.0e5
+        objects, _ = configs.c3b_objects(cat, np.array([200000]), scene)
+        objects["sed_table"], objects["sed_wave"] = -1, wl                      # monochromatic SED
+        r = Renderer(scene)
+        g = r.shoot_photons(objects).to_host()
+        r.synchronize()
+        assert np.all(g["wavelength"] == wl)
+        pos[wl] = (g["x"] - objects["x0"][0], g["y"] - objects["y0"][0])
+    s400 = np.sqrt(np.mean(pos[400.0][0] ** 2 + pos[400.0][1] ** 2))
+    s900 = np.sqrt(np.mean(pos[900.0][0] ** 2 + pos[900.0][1] ** 2))
+    np.testing.assert_allclose(s400 / s900, (400.0 / 900.0) ** exponent, rtol=0.001)
+    assert s900 > 0.5                                                         # pixels: a real seeing disc, not a delta function

@@ -83,25 +83,25 @@ def plan_bf_groups(objects, nrecalc, n_static, static_cells, scratch_cells, max_
     idx = np.flatnonzero(bright)
     idx = idx[np.argsort(-n[idx], kind="stable")]
     groups = []
+    sx = objects["stamp_xmin"][idx].astype(np.int64)
+    sy = objects["stamp_ymin"][idx].astype(np.int64)
+    nx = objects["stamp_xmax"][idx].astype(np.int64) - sx + 1
+    ny = objects["stamp_ymax"][idx].astype(np.int64) - sy + 1
+    cells = (nx + 1) * (ny + 1)
+    nph = n[idx].astype(np.int64)
     start = 0
     while start < len(idx):
-        cells, k, photons = 0, start, 0
-        regions = []
-        while k < len(idx) and len(regions) < max_slots - n_static:
-            o = objects[idx[k]]
-            nx = int(o["stamp_xmax"]) - int(o["stamp_xmin"]) + 1
-            ny = int(o["stamp_ymax"]) - int(o["stamp_ymin"]) + 1
-            c = (nx + 1) * (ny + 1)
-            if cells + c > scratch_cells or (k > start and photons + int(o["n_phot"]) > max_photons):
-                break
-            photons += int(o["n_phot"])
-            regions.append((int(o["stamp_xmin"]), int(o["stamp_ymin"]), nx, ny))
-            cells += c
-            k += 1
+        # the longest run from `start` that fits the scratch cells, the slot table and the photon pool
+        ccum = np.cumsum(cells[start:])
+        pcum = np.cumsum(nph[start:])
+        fit = (ccum <= scratch_cells) & (np.arange(len(ccum)) < max_slots - n_static)
+        fit &= (pcum <= max_photons) | (np.arange(len(ccum)) == 0)
+        k = start + (int(np.argmin(fit)) if not fit.all() else len(fit))
         if k == start:
             raise ValueError("brighter-fatter scratch capacity too small for one stamp; raise SensorSetup.scratch_cells")
-        slots = make_slots(regions)
-        slots["offset"] += static_cells
+        slots = np.zeros(k - start, dtype=BFSLOT_DTYPE)
+        slots["xmin"], slots["ymin"], slots["nx"], slots["ny"] = sx[start:k], sy[start:k], nx[start:k], ny[start:k]
+        slots["offset"] = static_cells + np.concatenate([[0], np.cumsum(cells[start:k])[:-1]])
         groups.append((idx[start:k], slots))
         start = k
     return normal, groups
@@ -203,6 +203,52 @@ def image_profile_cdf(img):
     cdf = np.concatenate([[0.0], np.cumsum(v) / tot])
     cdf[-1] = 1.0
     return cdf
+
+
+class _Arena:
+    """Host staging of the many small tables of one launch plan (object rows, segment prefixes, pool offsets) for ONE
+    upload: `add` returns the byte offset of an array, `patch` remembers a struct field that must receive its device
+    address, `ref` hands out an object with the data_ptr() of a tensor; `upload` copies everything at once and fills
+    the addresses in."""
+
+    class Ref:
+        def __init__(self, arena, off):
+            self.arena, self.off = arena, off
+
+        def data_ptr(self):
+            return self.arena.base + self.off
+
+    def __init__(self):
+        self.parts, self.size, self.patches, self.base, self.tensor = [], 0, [], None, None
+
+    def add(self, arr):
+        a = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+        off = (self.size + 255) & ~255
+        self.parts.append((off, a))
+        self.size = off + a.size
+        return off
+
+    def patch(self, struct, field, off):
+        self.patches.append((struct, field, off))
+
+    def ref(self, arr):
+        return _Arena.Ref(self, self.add(arr))
+
+    def upload(self, torch, device):
+        buf = np.zeros(max(self.size, 8), dtype=np.uint8)
+        for off, a in self.parts:
+            buf[off:off + a.size] = a
+        self.tensor = torch.from_numpy(buf).to(device)
+        self.base = self.tensor.data_ptr()
+        for struct, field, off in self.patches:
+            setattr(struct, field, self.base + off)
+        self.parts = []
+        return self.tensor
+
+
+class PlanList(list):
+    """a launch plan; `arena` keeps the device copy of its tables alive"""
+    arena = None
 
 
 class BoundScene:
@@ -476,18 +522,32 @@ class Renderer:
         the plan are uploaded here, so executing the plan touches no host data."""
         ss = self.scene.sensor
         objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
-        plan = []
-        realized_parts = []
+        plan = PlanList()
+        arena = plan.arena = _Arena()
+        realized_parts, realized_refs = [], []
+
+        def finish():
+            """ONE upload for every table of the plan (f-1: was ~1 000 separate copies), then the addresses"""
+            t = arena.upload(self.torch, self.device)
+            for off, n, tmp in realized_refs:
+                realized_parts.append((t[off:off + 8 * n].view(self.torch.int64), tmp))
+            return plan, realized_parts
 
         def upload(part, index, kind, extra=None):
-            part, obj_t, prefix, pre_t = self._upload_objects(part)
+            part = np.ascontiguousarray(part, dtype=OBJECT_DTYPE)
+            prefix = segment_prefix(part["n_phot"], self.scene.seg_size)
+            seg_obj = np.repeat(np.arange(len(part), dtype=np.int32), np.diff(prefix))
             tmp = None
             if want_realized and kind != "shoot_pool":
                 tmp = self.torch.zeros(len(part), dtype=self.torch.float64, device=self.device)
-                realized_parts.append((self.torch.from_numpy(np.asarray(index, dtype=np.int64)).to(self.device), tmp))
-            P = self.bound.params(obj_t.data_ptr(), len(part), pre_t.data_ptr(), int(prefix[-1]),
-                                  self.image.data_ptr(), tmp.data_ptr() if tmp is not None else None, _seg_ptr(pre_t))
-            return P, (obj_t, pre_t, tmp)
+                realized_refs.append((arena.add(np.asarray(index, dtype=np.int64)), len(part), tmp))
+            P = self.bound.params(None, len(part), None, int(prefix[-1]),
+                                  self.image.data_ptr(), tmp.data_ptr() if tmp is not None else None, None)
+            arena.patch(P, "objects", arena.add(part))
+            arena.patch(P, "seg_prefix", arena.add(prefix))
+            if len(seg_obj):
+                arena.patch(P, "seg_object", arena.add(seg_obj))
+            return P, (tmp,)
 
         def add_render(part, index, stream="bulk"):
             P, keep = upload(part, index, "render")
@@ -496,7 +556,7 @@ class Renderer:
         if ss is None:
             if len(objects):
                 add_render(objects, np.arange(len(objects)))
-            return plan, realized_parts
+            return finish()
         if nrecalc is None:
             nrecalc = ss.model.nrecalc
         b = self.bound
@@ -547,7 +607,7 @@ class Renderer:
                     part = cgrp[act].copy()
                     part["phot_first"] = cgrp["phot_first"][act] + lo[act]
                     part["n_phot"] = (hi - lo)[act]
-                    offs_t = self.torch.from_numpy((coffs + lo)[act]).to(self.device)
+                    offs_t = arena.ref((coffs + lo)[act])
                     P, keep = upload(part, cidx[act], "shoot_pool")
                     stream = cstream if k == 0 else "bulk"
                     item = ("shoot_pool", P, (keep, offs_t, pool_t), pool, offs_t, int(part["n_phot"].sum()),
@@ -585,7 +645,7 @@ class Renderer:
                     team = int(min(self.chain_team, (nrecalc + 255) // 256))
                     if chain_ok and rb - ra >= 2 and n_act * team <= self.chain_workers:
                         part = cgrp[:n_act].copy()
-                        start_t = self.torch.from_numpy(np.ascontiguousarray(ch["offs"][:n_act])).to(self.device)
+                        start_t = arena.ref(ch["offs"][:n_act])
                         P, keep = upload(part, ch["idx"][:n_act], "chain")
                         photons = int((np.minimum(ctot[:n_act], rb * nrecalc) - ra * nrecalc).sum())
                         mine.append(head + [("chain", P, (keep, start_t), pool, start_t, photons, n_act, ch["stream"], ra, rb,
@@ -596,7 +656,7 @@ class Renderer:
                         part = cgrp[:n_act].copy()
                         part["phot_first"] = cgrp["phot_first"][:n_act] + r * nrecalc
                         part["n_phot"] = np.minimum(nrecalc, ctot[:n_act] - r * nrecalc)
-                        start_t = self.torch.from_numpy(ch["offs"][:n_act] + r * nrecalc).to(self.device)
+                        start_t = arena.ref(ch["offs"][:n_act] + r * nrecalc)
                         P, keep = upload(part, ch["idx"][:n_act], "acc_pool")
                         tag = (r % 255 + 1) if self.use_bf_tags else 0      # marks the tiles this round's charge lands in
                         P.bf_tag = tag
@@ -615,7 +675,7 @@ class Renderer:
             part = objects[normal].copy()
             part["bf_state"] = 0
             add_render(part, normal, "bulk")
-        return plan, realized_parts
+        return finish()
 
     def _chain_ok(self, grp):
         """ims_bf_chain takes qdist 3, 4 or 8 vertices per edge and regions of at most 4096 16x16-cell tiles."""
@@ -759,7 +819,9 @@ class Renderer:
             for it in plan:
                 if it[0] == "slots":
                     self.bound.set_private_slots(it[1])
-            plan = [it for it in plan if it[0] != "slots"]
+            arena = plan.arena
+            plan = PlanList(it for it in plan if it[0] != "slots")
+            plan.arena = arena
 
         compiled = self._compile_plan(plan)
 

@@ -97,12 +97,16 @@ def main():
     share_gpu = os.environ.get("IMS_BENCH_SHARE_GPU", "0") == "1"
     device = "cuda:0" if share_gpu else f"cuda:{local_rank}"
 
+    timing = {}
+
     def build_inputs():
         n_obj = args.n_objects or cfg["n_objects"]
         scene = cfg["scene"]()
         cat = cfg["catalog"](n_obj, scene) if "catalog" in cfg else catalog.synthetic_catalog(n_obj, nx=scene.nx, ny=scene.ny)
+        t0 = time.perf_counter()
         phot = catalog.realize_fluxes(cat["nominal_flux"], scene.seed)
         objects, _ = cfg["objects"](cat, phot, scene)
+        timing["object_table_ms"] = 1e3 * (time.perf_counter() - t0)
         return scene, objects
 
     cpu = None
@@ -211,6 +215,8 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cold and "cold" in cfg:
         out["extra"] = cfg["cold"](scene, objects, device)
+        # host side of LSST_SiliconBuilder.setup for the whole catalog (Poisson fluxes, stamp sizes, local WCS, DCR angles)
+        out["extra"]["object_table_ms"] = timing.get("object_table_ms")
     if want_cpu:
         if cpu is None:
             cpu = cpu_legs(cfg, scene, objects, args, fork_ok=False)

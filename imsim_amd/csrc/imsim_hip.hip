@@ -111,9 +111,9 @@ struct ChargeTile {
 };
 
 __device__ __forceinline__ void tile_begin(float* tile, ChargeTile& ct, const ims_render_params_t& P, const ims_object_t& o,
-                                           bool silicon)
+                                           bool silicon, int n_thr = 256)
 {
-    for (int e = threadIdx.x; e < CT * CT; e += 256) tile[e] = 0.0f;
+    for (int e = threadIdx.x; e < CT * CT; e += n_thr) tile[e] = 0.0f;
     ct.x0 = (int)floor(o.x0 + 0.5) - CT / 2;
     ct.y0 = (int)floor(o.y0 + 0.5) - CT / 2;
     ct.track = silicon && !(o.flags & IMS_OBJ_FAINT) && (o.bf_state > 0 || P.track_static_delta);
@@ -151,10 +151,10 @@ __device__ __forceinline__ void tile_deposit(float* tile, const ChargeTile& ct, 
     else deposit_global(P, ct, ix, iy, flux);
 }
 
-__device__ __forceinline__ void tile_flush(float* tile, const ChargeTile& ct, const ims_render_params_t& P)
+__device__ __forceinline__ void tile_flush(float* tile, const ChargeTile& ct, const ims_render_params_t& P, int n_thr = 256)
 {
     __syncthreads();
-    for (int e = threadIdx.x; e < CT * CT; e += 256) {
+    for (int e = threadIdx.x; e < CT * CT; e += n_thr) {
         const float v = tile[e];
         if (v != 0.0f) deposit_global(P, ct, ct.x0 + e % CT, ct.y0 + e / CT, (double)v);
     }
@@ -177,11 +177,16 @@ __global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_accumulate(const
     const int64_t j0 = seg_in_obj * P.seg_size;
     int64_t j1 = j0 + P.seg_size;
     if (j1 > o.n_phot) j1 = o.n_phot;
+    // Wavefronts of the workgroup that hold no photon of this segment (a 19-photon object uses one of four) leave at
+    // once: they would only sit in the barriers and keep the wave slots other segments could run in.  The hardware
+    // barrier counts the waves that are still alive.
+    const int n_thr = (((int)(j1 - j0) + 63) >> 6) << 6;
+    if ((int)threadIdx.x >= n_thr) return;
     const bool silicon = (P.sensor != nullptr) && (P.sensor->kind == IMS_SENSOR_SILICON);
     const bool has_angles = chain_has_angles(P);
     __shared__ float tile[CT * CT];
     ChargeTile ct;
-    tile_begin(tile, ct, P, o, silicon);
+    tile_begin(tile, ct, P, o, silicon, n_thr);
     double added = 0.0;
     // exactly one photon per thread (seg_size == workgroup size): no photon loop, so the compiler
     // cannot hoist the chain's uniform operands across iterations into registers
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_accumulate(const
             tile_deposit(tile, ct, P, ix, iy, ph.flux);
         }
     }
-    tile_flush(tile, ct, P);
+    tile_flush(tile, ct, P, n_thr);
     if (P.realized_flux != nullptr) {
         const double tot = wave_sum(added);
         if ((threadIdx.x & 63) == 0 && tot != 0.0) unsafeAtomicAdd(P.realized_flux + oi, tot);
@@ -312,11 +317,14 @@ __global__ __launch_bounds__(256) void k_accumulate_segments(const ims_render_pa
     const int64_t oi = P.seg_object ? (int64_t)P.seg_object[seg] : find_object(P.seg_prefix, P.n_objects, seg);
     const ims_object_t& o = P.objects[oi];
     const int64_t j = (seg - P.seg_prefix[oi]) * P.seg_size + threadIdx.x;
+    const int64_t left = o.n_phot - (seg - P.seg_prefix[oi]) * P.seg_size;      // photons of this segment (>= 1)
+    const int n_thr = left >= 256 ? 256 : ((((int)left + 63) >> 6) << 6);
+    if ((int)threadIdx.x >= n_thr) return;                                      // photon-less wavefronts leave at once
     const bool silicon = (P.sensor != nullptr) && (P.sensor->kind == IMS_SENSOR_SILICON);
     const bool has_angles = chain_has_angles(P);
     __shared__ float tile[CT * CT];
     ChargeTile ct;
-    tile_begin(tile, ct, P, o, silicon);
+    tile_begin(tile, ct, P, o, silicon, n_thr);
     double added = 0.0;
     if (j < o.n_phot) {
         const int64_t i = pool_start[oi] + j;
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(256) void k_accumulate_segments(const ims_render_pa
             tile_deposit(tile, ct, P, ix, iy, ph.flux);
         }
     }
-    tile_flush(tile, ct, P);
+    tile_flush(tile, ct, P, n_thr);
     if (P.realized_flux != nullptr) {
         const double tot = wave_sum(added);
         if ((threadIdx.x & 63) == 0 && tot != 0.0) unsafeAtomicAdd(P.realized_flux + oi, tot);

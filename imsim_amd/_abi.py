@@ -71,7 +71,8 @@ class PsfComponent(C.Structure):
 class Atmosphere(C.Structure):
     _fields_ = [("n_layers", c_i32), ("npix", c_i32), ("scale", c_d), ("x0", c_d), ("t0", c_d), ("exptime", c_d),
                 ("aper_r_outer", c_d), ("aper_r_inner", c_d), ("vx", c_d * 8), ("vy", c_d * 8), ("alt", c_d * 8),
-                ("screens", c_vp)]
+                ("screens", c_vp),
+                ("dn", c_d), ("inv_n", c_d), ("inv_scale", c_d), ("aper_ri2", c_d), ("aper_dr2", c_d)]
 
 
 class KPsf(C.Structure):
@@ -112,7 +113,8 @@ class Op(C.Structure):
 class Surface(C.Structure):
     _fields_ = [("kind", c_i32), ("obsc_kind", c_i32), ("medium_kind", c_i32), ("n_asphere", c_i32), ("medium_id", c_i32), ("pad", c_i32),
                 ("z0", c_d), ("R", c_d), ("inv_R", c_d), ("conic", c_d), ("asph", c_d * 4),
-                ("obsc_inner", c_d), ("obsc_outer", c_d), ("medium_c", c_d * 6)]
+                ("obsc_inner", c_d), ("obsc_outer", c_d), ("medium_c", c_d * 6),
+                ("k1", c_d), ("k1c", c_d), ("m2R", c_d), ("cc", c_d), ("obsc_i2", c_d), ("obsc_o2", c_d), ("asph_d", c_d * 4)]
 
 
 class TanSip(C.Structure):
@@ -126,7 +128,8 @@ class Optics(C.Structure):
                 ("stop_z", c_d), ("surf", Surface * IMS_MAX_SURFACES),
                 ("cam_rot", c_d * 2), ("fp_to_pix", c_d * 6), ("slope_jac", c_d * 4),
                 ("n_lines", c_i32), ("n_circles", c_i32), ("lines", (c_d * 4) * 8), ("circles", (c_d * 3) * 4),
-                ("e_z0", c_d * 3), ("e_focal", c_d * 3), ("cos_lat", c_d), ("sin_lat", c_d), ("omega", c_d)]
+                ("e_z0", c_d * 3), ("e_focal", c_d * 3), ("cos_lat", c_d), ("sin_lat", c_d), ("omega", c_d),
+                ("rot_g", c_d * 3), ("rot_gnorm", c_d)]
 
 
 class BfSlot(C.Structure):
@@ -144,7 +147,8 @@ class Sensor(C.Structure):
                 ("abs_len", c_vp), ("tr_table", c_vp), ("tr_table2", c_vp), ("distortions", c_vp), ("emptypoly", c_vp),
                 ("n_bf_slots", c_i32), ("pad2", c_i32), ("bf_slots", c_vp),
                 ("bf_boundary", c_vp), ("bf_bounds", c_vp), ("bf_delta", c_vp),
-                ("bf_tile_charge", c_vp), ("bf_tile_changed", c_vp), ("pristine_margin", c_d)]
+                ("bf_tile_charge", c_vp), ("bf_tile_changed", c_vp), ("pristine_margin", c_d),
+                ("diff_coef", c_d), ("thick_m1", c_d)]
 
 
 class Photons(C.Structure):
@@ -193,7 +197,7 @@ EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_
            "ims_shoot_photons", "ims_shoot_ops_photons", "ims_accumulate_segments", "ims_run_plan",
            "ims_bf_chain", "ims_bf_chain_ctl_bytes", "ims_bf_chain_status",
            "ims_fft_kspace_fill", "ims_fft_finish", "ims_fft_spikes", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
-           "ims_sensor_update_distortions", "ims_image_add", "ims_image_to_float", "ims_fill_derived_op", "ims_fill_derived_medium", "ims_sensor_pixel_areas", "ims_flat_add", "ims_last_kernel_ms", "ims_enable_timing",
+           "ims_sensor_update_distortions", "ims_image_add", "ims_image_to_float", "ims_fill_derived_op", "ims_fill_derived_medium", "ims_fill_derived_optics", "ims_fill_derived_atmosphere", "ims_fill_derived_sensor", "ims_sensor_pixel_areas", "ims_flat_add", "ims_last_kernel_ms", "ims_enable_timing",
            "ims_readout_bleed", "ims_readout_segments", "ims_readout_cte", "ims_readout_finish",
            "ims_struct_size", "ims_test_math"]
 
@@ -241,6 +245,9 @@ def load():
     lib.ims_flat_add.argtypes = [c_vp, c_vp, c_d, c_d, c_u64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]
     lib.ims_fill_derived_op.argtypes = [c_vp]
     lib.ims_fill_derived_medium.argtypes = [c_i32, C.POINTER(c_d)]
+    lib.ims_fill_derived_optics.argtypes = [c_vp]
+    lib.ims_fill_derived_atmosphere.argtypes = [c_vp]
+    lib.ims_fill_derived_sensor.argtypes = [c_vp]
     lib.ims_fft_kspace_fill.argtypes = [C.POINTER(FftParams), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]
     lib.ims_fft_finish.argtypes = [C.POINTER(FftParams), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]
     lib.ims_fft_spikes.argtypes = [C.POINTER(FftParams), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]

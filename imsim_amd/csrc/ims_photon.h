@@ -132,19 +132,27 @@ IMS_DEV void screen_gradient(const ims_atmosphere_t& A, double pu, double pv, do
 {
     double sx = 0.0, sy = 0.0;
     const int n = A.npix;
-    const double dn = (double)n, inv_n = ddiv(1.0, dn), inv_scale = ddiv(1.0, A.scale);
+    const double dn = A.dn, inv_n = A.inv_n, inv_scale = A.inv_scale;      // ims_fill_derived_atmosphere
+    const bool pow2 = (n & (n - 1)) == 0;      // the screens of the reference are 8192 wide: the wrap is a mask
     for (int l = 0; l < A.n_layers; ++l) {
         const double x = pu - t * A.vx[l] + A.alt[l] * tanx;
         const double y = pv - t * A.vy[l] + A.alt[l] * tany;
         const double fx = (x - A.x0) * inv_scale, fy = (y - A.x0) * inv_scale;
         const double flx = floor(fx), fly = floor(fy);
         const double ax = fx - flx, ay = fy - fly;
-        const int ix = wrap_index(flx, dn, inv_n), iy = wrap_index(fly, dn, inv_n);
-        const int ix1 = ix + 1 == n ? 0 : ix + 1, iy1 = iy + 1 == n ? 0 : iy + 1;
+        int ix, iy, ix1, iy1;
+        if (pow2) {
+            // two's complement: the low bits of the (possibly negative) integer ARE the non-negative remainder
+            ix = (int)flx & (n - 1); iy = (int)fly & (n - 1);
+            ix1 = (ix + 1) & (n - 1); iy1 = (iy + 1) & (n - 1);
+        } else {
+            ix = wrap_index(flx, dn, inv_n); iy = wrap_index(fly, dn, inv_n);
+            ix1 = ix + 1 == n ? 0 : ix + 1; iy1 = iy + 1 == n ? 0 : iy + 1;
+        }
         const float* S = A.screens + (int64_t)l * n * n;
-        const int64_t r0 = (int64_t)iy * n, r1 = (int64_t)iy1 * n;
-        const double f00 = (double)S[r0 + ix], f10 = (double)S[r0 + ix1];
-        const double f01 = (double)S[r1 + ix], f11 = (double)S[r1 + ix1];
+        const uint32_t r0 = (uint32_t)iy * (uint32_t)n, r1 = (uint32_t)iy1 * (uint32_t)n;     // a screen has < 2^31 samples
+        const double f00 = (double)S[r0 + (uint32_t)ix], f10 = (double)S[r0 + (uint32_t)ix1];
+        const double f01 = (double)S[r1 + (uint32_t)ix], f11 = (double)S[r1 + (uint32_t)ix1];
         sx = sx + ((f10 - f00) * (1.0 - ay) + (f11 - f01) * ay);
         sy = sy + ((f01 - f00) * (1.0 - ax) + (f11 - f10) * ax);
     }
@@ -172,8 +180,7 @@ IMS_DEV void apply_psf(const ims_render_params_t& P, const ims_object_t& o, int 
         ku = sigma * g0; kv = sigma * g1;
     } else if (c.kind == IMS_PSF_SCREENS) {
         const ims_atmosphere_t& A = *P.atm;
-        const double ro2 = A.aper_r_outer * A.aper_r_outer, ri2 = A.aper_r_inner * A.aper_r_inner;
-        const double r = dsqrt0(ri2 + w01(wa) * (ro2 - ri2));
+        const double r = dsqrt0(A.aper_ri2 + w01(wa) * A.aper_dr2);
         double s, cc;
         sincos2pi(w01(wb), s, cc);
         const double pu = r * cc, pv = r * s;
@@ -333,9 +340,8 @@ IMS_DEV void field_rotation(const ims_optics_t& o, double t, double& c, double& 
     const double ez0 = o.cos_lat * cs, ez1 = o.cos_lat * sn, ez2 = o.sin_lat;
     const double* ef = o.e_focal;
     const double eh0_ = ef[1] * ez2 - ef[2] * ez1, eh1_ = ef[2] * ez0 - ef[0] * ez2, eh2_ = ef[0] * ez1 - ef[1] * ez0;
-    const double* z0 = o.e_z0;
-    const double g0 = ef[1] * z0[2] - ef[2] * z0[1], g1 = ef[2] * z0[0] - ef[0] * z0[2], g2 = ef[0] * z0[1] - ef[1] * z0[0];
-    const double nrm = dsqrt_n(eh0_ * eh0_ + eh1_ * eh1_ + eh2_ * eh2_) * dsqrt_n(g0 * g0 + g1 * g1 + g2 * g2);
+    const double g0 = o.rot_g[0], g1 = o.rot_g[1], g2 = o.rot_g[2];        // e_focal x e_z0 (ims_fill_derived_optics)
+    const double nrm = dsqrt_n(eh0_ * eh0_ + eh1_ * eh1_ + eh2_ * eh2_) * o.rot_gnorm;
     c = ddiv(eh0_ * g0 + eh1_ * g1 + eh2_ * g2, nrm);
     s = ddiv(ez0 * g0 + ez1 * g1 + ez2 * g2, nrm);
 }
@@ -390,7 +396,7 @@ IMS_DEV void diffract(const ims_optics_t& o, bool field_rot, double pu, double p
 IMS_DEV bool obscured(const ims_surface_t& S, double r2)
 {
     if (S.obsc_kind == IMS_OBSC_NONE) return false;
-    const double i2 = S.obsc_inner * S.obsc_inner, o2 = S.obsc_outer * S.obsc_outer;
+    const double i2 = S.obsc_i2, o2 = S.obsc_o2;
     switch (S.obsc_kind) {
     case IMS_OBSC_CLEAR_ANNULUS: return !(r2 >= i2 && r2 <= o2);
     case IMS_OBSC_CLEAR_CIRCLE:  return !(r2 <= o2);
@@ -414,13 +420,13 @@ IMS_DEV bool surf_hit(const ims_surface_t& S, double (&pos)[3], const double (&v
         r2_out = fma(pos[0], pos[0], pos[1] * pos[1]);
         return true;
     }
-    const double c = S.inv_R, k1 = 1.0 + S.conic;
+    const double c = S.inv_R, k1 = S.k1;       // k1, k1c, m2R, cc, asph_d: ims_fill_derived_optics
     if (S.R != 0.0) {
         // A t^2 + 2 hb t + C = 0 (spec v5: the dot products are fma chains, hb is half the linear coefficient)
         const double k1vz = k1 * vel[2];
         const double A = fma(vel[0], vel[0], fma(vel[1], vel[1], k1vz * vel[2]));
         const double hb = fma(pos[0], vel[0], fma(pos[1], vel[1], fma(k1vz, pz, -(S.R * vel[2]))));
-        const double C = fma(pos[0], pos[0], fma(pos[1], pos[1], pz * fma(k1, pz, -2.0 * S.R)));
+        const double C = fma(pos[0], pos[0], fma(pos[1], pos[1], pz * fma(k1, pz, S.m2R)));
         const double dq = fma(hb, hb, -(A * C));
         if (dq < 0.0) return false;
         const double sq = dsqrt0(dq);
@@ -431,12 +437,12 @@ IMS_DEV bool surf_hit(const ims_surface_t& S, double (&pos)[3], const double (&v
     }
     if (S.n_asphere == 0) {
         const double x = fma(vel[0], t, pos[0]), y = fma(vel[1], t, pos[1]), z = fma(vel[2], t, pz);
-        const double sqv = fma(-(k1 * c), z, 1.0);
+        const double sqv = fma(-S.k1c, z, 1.0);
         if (!(sqv > 0.0)) return false;
         pos[0] = x; pos[1] = y; pos[2] = S.z0 + z;
         N[0] = -c * x; N[1] = -c * y; N[2] = sqv;
         r2_out = fma(x, x, y * y);
-        nn = fma(c * c, r2_out, sqv * sqv);
+        nn = fma(S.cc, r2_out, sqv * sqv);
         return true;
     }
     // even asphere z = conic(r2) + p(r2), p = sum a_k r^(2k+4): Newton on the implicit conic form
@@ -448,7 +454,7 @@ IMS_DEV bool surf_hit(const ims_surface_t& S, double (&pos)[3], const double (&v
         double p = 0.0, rp = r2;
         dp = 0.0;
         for (int k = 0; k < S.n_asphere; ++k) {
-            dp = fma(S.asph[k] * (double)(k + 2), rp, dp);
+            dp = fma(S.asph_d[k], rp, dp);
             rp = rp * r2;
             p = fma(S.asph[k], rp, p);
         }
@@ -461,7 +467,7 @@ IMS_DEV bool surf_hit(const ims_surface_t& S, double (&pos)[3], const double (&v
         const double Gp = 2.0 * fma(c, fma(k1w, wp, s), -wp);
         t = t - ddiv(G, Gp);
     }
-    const double m = fma(-(c * k1), w, 1.0);
+    const double m = fma(-S.k1c, w, 1.0);
     if (!(m > 0.0)) return false;
     const double g = fma(2.0 * m, dp, c);
     pos[0] = x; pos[1] = y; pos[2] = S.z0 + z;
@@ -572,9 +578,8 @@ IMS_DEV void apply_op(const ims_render_params_t& P, int op_index, const ims_obje
         ph.t = op.p[0] + w01(wsel ? rng.w[2] : rng.w[0]) * op.p[1];
         break; }
     case IMS_OP_PUPIL_ANNULUS_SAMPLER: {
-        const double ro2 = op.p[0] * op.p[0], ri2 = op.p[1] * op.p[1];
         rng_block(rng, P.seed, o.obj_id, k, slot);
-        const double r = dsqrt0(ri2 + w01(wsel ? rng.w[2] : rng.w[0]) * (ro2 - ri2));
+        const double r = dsqrt0(op.p[2] + w01(wsel ? rng.w[2] : rng.w[0]) * op.p[3]);      // p2 = R_inner^2, p3 = R_outer^2 - R_inner^2
         double s, c;
         sincos2pi(w01(wsel ? rng.w[3] : rng.w[1]), s, c);
         ph.pu = r * c; ph.pv = r * s;
@@ -593,10 +598,9 @@ IMS_DEV void apply_op(const ims_render_params_t& P, int op_index, const ims_obje
         ph.y = ph.y + ph.dydz * op.p[0];
         break;
     case IMS_OP_REFRACTION: {
-        const double nn = op.p[0] * op.p[0];
         const double a = ph.dxdz, b = ph.dydz;
         const double rho2 = a * a + b * b;
-        const double f = ddiv(1.0, dsqrt_n(nn + (nn - 1.0) * rho2));
+        const double f = ddiv(1.0, dsqrt_n(op.p[1] + op.p[2] * rho2));                    // p1 = n^2, p2 = n^2 - 1
         ph.dxdz = a * f; ph.dydz = b * f;
         break; }
     case IMS_OP_RUBIN_OPTICS:
@@ -724,7 +728,7 @@ IMS_DEV bool land(const ims_render_params_t& P, const ims_object_t& o, int64_t k
     double dz = si_length;
     if (has_angles) {
         dz = ddiv(si_length, dsqrt_n(1.0 + ph.dxdz * ph.dxdz + ph.dydz * ph.dydz));
-        if (dz > s.thickness - 1.0) dz = s.thickness - 1.0;
+        if (dz > s.thick_m1) dz = s.thick_m1;
         const double dzp = ddiv(dz, s.pixel_size);
         x0 = x0 + ph.dxdz * dzp;
         y0 = y0 + ph.dydz * dzp;
@@ -732,7 +736,7 @@ IMS_DEV bool land(const ims_render_params_t& P, const ims_object_t& o, int64_t k
     const double zconv = s.thickness - dz;
     if (zconv < 0.0) return false;
     if (s.diff_step != 0.0) {
-        double ds = ddiv(s.diff_step, s.thickness * s.pixel_size) * dsqrt0(zconv * s.thickness);
+        double ds = s.diff_coef * dsqrt0(zconv * s.thickness);
         if (ds < 0.0) ds = 0.0;
         x0 = x0 + ds * g0;
         y0 = y0 + ds * g1;

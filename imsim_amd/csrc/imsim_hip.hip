@@ -1878,6 +1878,63 @@ int ims_fill_derived_op(ims_op_t* op)
         const double nm1 = host_air_n_minus_one(op->p[0], op->p[5], op->p[6]);
         op->p[7] = nm1 * (nm1 + 2.0) / 2.0 / (nm1 * nm1 + 2.0 * nm1 + 1.0);
     }
+    if (op->kind == IMS_OP_PUPIL_ANNULUS_SAMPLER) {
+        const double ro2 = op->p[0] * op->p[0], ri2 = op->p[1] * op->p[1];
+        op->p[2] = ri2; op->p[3] = ro2 - ri2;
+    }
+    if (op->kind == IMS_OP_REFRACTION) {
+        const double nn = op->p[0] * op->p[0];
+        op->p[1] = nn; op->p[2] = nn - 1.0;
+    }
+    return IMS_OK;
+}
+
+// The derived constants below are single IEEE operations (this file is compiled with -ffp-contract=off), so the kernels
+// compute with exactly the values they would have formed themselves.
+int ims_fill_derived_optics(ims_optics_t* o)
+{
+    if (!o) return set_err(IMS_ERR_ARG, "optics is NULL");
+    if (o->n_surfaces < 0 || o->n_surfaces > IMS_MAX_SURFACES) return set_err(IMS_ERR_ARG, "n_surfaces out of range");
+    for (int k = 0; k < o->n_surfaces; ++k) {
+        ims_surface_t& S = o->surf[k];
+        S.k1 = 1.0 + S.conic;
+        S.k1c = S.k1 * S.inv_R;
+        S.m2R = -2.0 * S.R;
+        S.cc = S.inv_R * S.inv_R;
+        S.obsc_i2 = S.obsc_inner * S.obsc_inner;
+        S.obsc_o2 = S.obsc_outer * S.obsc_outer;
+        for (int a = 0; a < 4; ++a) S.asph_d[a] = S.asph[a] * (double)(a + 2);
+    }
+    const double* ef = o->e_focal;
+    const double* z0 = o->e_z0;
+    o->rot_g[0] = ef[1] * z0[2] - ef[2] * z0[1];
+    o->rot_g[1] = ef[2] * z0[0] - ef[0] * z0[2];
+    o->rot_g[2] = ef[0] * z0[1] - ef[1] * z0[0];
+    o->rot_gnorm = sqrt(o->rot_g[0] * o->rot_g[0] + o->rot_g[1] * o->rot_g[1] + o->rot_g[2] * o->rot_g[2]);
+    return IMS_OK;
+}
+
+int ims_fill_derived_atmosphere(ims_atmosphere_t* A)
+{
+    if (!A) return set_err(IMS_ERR_ARG, "atmosphere is NULL");
+    if (A->npix <= 0 || !(A->scale > 0.0)) return set_err(IMS_ERR_ARG, "atmosphere: npix and scale must be positive");
+    A->dn = (double)A->npix;
+    A->inv_n = 1.0 / A->dn;
+    A->inv_scale = 1.0 / A->scale;
+    const double ro2 = A->aper_r_outer * A->aper_r_outer, ri2 = A->aper_r_inner * A->aper_r_inner;
+    A->aper_ri2 = ri2;
+    A->aper_dr2 = ro2 - ri2;
+    return IMS_OK;
+}
+
+int ims_fill_derived_sensor(ims_sensor_t* S)
+{
+    if (!S) return set_err(IMS_ERR_ARG, "sensor is NULL");
+    if (S->kind == IMS_SENSOR_SILICON) {
+        if (!(S->thickness > 0.0) || !(S->pixel_size > 0.0)) return set_err(IMS_ERR_ARG, "sensor: thickness and pixel_size must be positive");
+        S->diff_coef = S->diff_step / (S->thickness * S->pixel_size);
+        S->thick_m1 = S->thickness - 1.0;
+    }
     return IMS_OK;
 }
 

@@ -179,6 +179,11 @@ class _LibDerive:
     def fill_derived_medium(self, kind, c):
         _abi.check(self.lib.ims_fill_derived_medium(int(kind), c), "ims_fill_derived_medium")
 
+    def fill_derived_struct(self, what, struct):
+        """what: "optics" | "atmosphere" | "sensor" -- the launch-wide constants of include/imsim_hip.h marked "derived" """
+        fn = getattr(self.lib, "ims_fill_derived_" + what)
+        _abi.check(fn(C.byref(struct)), "ims_fill_derived_" + what)
+
 
 def treering_displacement_bound(ss):
     """Upper bound of |tree-ring shift| over the CCD [pixels]: on every table interval the interpolant is the chord plus
@@ -258,6 +263,7 @@ class BoundScene:
         """derive: the library whose fill_derived_op / fill_derived_medium entry points complete the
         launch-wide derived fields (libimsim_hip.so for the product, the oracle for the checker)."""
         self.scene = scene
+        self.derive = derive
         self.mem = mem
         P = RenderParams()
         P.seed = scene.seed
@@ -314,6 +320,7 @@ class BoundScene:
             derive.fill_derived_medium(opt.in_medium_kind, opt.in_medium_c)
             for k in range(opt.n_surfaces):
                 derive.fill_derived_medium(opt.surf[k].medium_kind, opt.surf[k].medium_c)
+            derive.fill_derived_struct("optics", opt)
             _, P.optics = mem.put_struct(opt)
         if scene.atm is not None:
             A = scene.atm.atmosphere_struct()
@@ -325,6 +332,7 @@ class BoundScene:
                 A.screens = scr.data_ptr()
             else:
                 _, A.screens = mem.put(scr.cpu().numpy(), np.float32)
+            derive.fill_derived_struct("atmosphere", A)
             self.atm_struct = A
             _, P.atm = mem.put_struct(A)
         self.sensor_host = None
@@ -375,6 +383,7 @@ class BoundScene:
         # tile flags of the brighter-fatter rounds (one byte per owner cell, used at tile origins)
         self.sensor_arrays["tile_charge"], S.bf_tile_charge = self.mem.zeros(cells, np.uint8)
         self.sensor_arrays["tile_changed"], S.bf_tile_changed = self.mem.zeros(cells, np.uint8)
+        self.derive.fill_derived_struct("sensor", S)
         # host copy whose slot table is a host pointer (sizes the launches)
         Sh = Sensor.from_buffer_copy(bytes(S))
         self._slots_host = slots_host

@@ -40,7 +40,7 @@ extern "C" {
 #define IMS_ERR_NO_DEVICE  -3
 #define IMS_ERR_UNSUPPORTED -4
 
-#define IMS_ABI_VERSION 6
+#define IMS_ABI_VERSION 7
 
 /* ---- object flags ---- */
 #define IMS_OBJ_FAINT   1   /* nominal_flux < max_flux_simple: no photon ops, no sensor (stamp.py:435-465,555-556) */
@@ -56,14 +56,14 @@ extern "C" {
 
 /* ---- photon-op kinds (names follow the registered PhotonOp types) ---- */
 #define IMS_OP_TIME_SAMPLER              1  /* p0=t0, p1=exptime                      (config/imsim-config.yaml:282-285) */
-#define IMS_OP_PUPIL_ANNULUS_SAMPLER     2  /* p0=R_outer, p1=R_inner                 (:286-289) */
+#define IMS_OP_PUPIL_ANNULUS_SAMPLER     2  /* p0=R_outer, p1=R_inner                 (:286-289); p2 = p1^2, p3 = p0^2 - p1^2 derived by ims_fill_derived_op */
 #define IMS_OP_PHOTON_DCR                3  /* p0=base_wavelength [nm], p1=pressure kPa, p2=temperature K, p3=H2O kPa, p4=scale (rad->arcsec) (:290-296);
                                              * p5..p7 derived by ims_fill_derived_op: air factors, refraction constant at p0 */
 #define IMS_OP_RUBIN_OPTICS              4  /* p0=shift_photons (0/1)                 (imsim/photon_ops.py:24-127) */
 #define IMS_OP_RUBIN_DIFFRACTION         5  /* p0=shift_photons, p1=disable_field_rotation (imsim/photon_ops.py:211-358) */
 #define IMS_OP_RUBIN_DIFFRACTION_OPTICS  6  /* p0=shift_photons, p1=disable_field_rotation (imsim/photon_ops.py:151-208) */
 #define IMS_OP_FOCUS_DEPTH               7  /* p0=depth [pixels]                      (:309-315) */
-#define IMS_OP_REFRACTION                8  /* p0=index_ratio                         (:317-318) */
+#define IMS_OP_REFRACTION                8  /* p0=index_ratio                         (:317-318); p1 = p0^2, p2 = p0^2 - 1 derived by ims_fill_derived_op */
 #define IMS_OP_BANDPASS_RATIO            9  /* table = ratio table id                 (imsim/photon_ops.py:506-521) */
 #define IMS_MAX_OPS 12
 
@@ -181,6 +181,9 @@ typedef struct ims_atmosphere {
     double  vx[IMS_MAX_LAYERS], vy[IMS_MAX_LAYERS];   /* m/s */
     double  alt[IMS_MAX_LAYERS];   /* m */
     const float*  screens;         /* [n_layers][npix][npix], fp32 samples (the arithmetic on them is f64) */
+    /* launch-wide constants derived by ims_fill_derived_atmosphere (the same IEEE operations the kernel would otherwise repeat
+     * per photon): (double)npix, 1/npix, 1/scale, aper_r_inner^2, aper_r_outer^2 - aper_r_inner^2 */
+    double  dn, inv_n, inv_scale, aper_ri2, aper_dr2;
 } ims_atmosphere_t;
 
 typedef struct ims_op {
@@ -203,6 +206,9 @@ typedef struct ims_surface {
     double  asph[4];
     double  obsc_inner, obsc_outer;   /* [m] */
     double  medium_c[6];
+    /* derived by ims_fill_derived_optics: 1 + conic, (1 + conic) * inv_R, -2 R, inv_R^2, obsc_inner^2, obsc_outer^2,
+     * asph[k] * (k + 2) -- wave-uniform products the ray trace would otherwise form per photon and surface */
+    double  k1, k1c, m2R, cc, obsc_i2, obsc_o2, asph_d[4];
 } ims_surface_t;
 
 /* TAN-SIP world coordinate system, trig-free vector form:
@@ -240,6 +246,8 @@ typedef struct ims_optics {
     double  e_focal[3];          /* pointing in equatorial frame (diffraction.py:387-415) */
     double  cos_lat, sin_lat;
     double  omega;               /* Earth rotation rate [rad/s] (diffraction.py:280) */
+    /* derived by ims_fill_derived_optics: e_focal x e_z0 and its norm (the time-independent half of the field-rotation angle) */
+    double  rot_g[3], rot_gnorm;
 } ims_optics_t;
 
 /* Private pixel-boundary state of one brighter-fatter active region (a bright object's stamp in
@@ -288,6 +296,8 @@ typedef struct ims_sensor {
      * nominal pixel without looking at the boundary state.  The host derives it from the tree-ring table
      * (rigorous bound of the spline); ims_sensor_update_distortions on slot 0 sets it to -1 (= off) on the device. */
     double pristine_margin;
+    /* derived by ims_fill_derived_sensor: diff_step / (thickness * pixel_size), thickness - 1 */
+    double diff_coef, thick_m1;
 } ims_sensor_t;
 
 /* A photon pool in device memory, SoA, the fields of galsim.PhotonArray (imsim/photon_ops.py:81). */
@@ -575,6 +585,12 @@ int  ims_enable_timing(int which);
  * chain / the optics descriptor is built; ops and media without derived fields are left untouched. */
 int  ims_fill_derived_op(ims_op_t* op);
 int  ims_fill_derived_medium(int32_t kind, double* c6);
+/* Launch-wide constants of the optics / atmosphere / sensor descriptors (fields marked "derived"): products, squares and
+ * reciprocals of wave-uniform parameters, formed once on the host with the IEEE operations the kernels would otherwise repeat
+ * per photon.  Call on the HOST copy of the struct before it is uploaded. */
+int  ims_fill_derived_optics(ims_optics_t* optics);
+int  ims_fill_derived_atmosphere(ims_atmosphere_t* atm);
+int  ims_fill_derived_sensor(ims_sensor_t* sensor);
 int  ims_struct_size(int which);
 int  ims_test_math(int which, const double* in_dev, double* out_dev, int64_t n, uint64_t seed, int64_t obj,
                    uint32_t slot, void* stream);

@@ -110,6 +110,10 @@ class _OracleDerive:
     def fill_derived_medium(self, kind, c):
         self.lib.orc_fill_derived_medium(int(kind), c)
 
+    def fill_derived_struct(self, what, struct):
+        """The oracle reads none of the derived optics / atmosphere / sensor constants: it forms every product, square
+        and reciprocal in place, which is what checks the host-side values the kernels consume."""
+
 
 class OracleScene:
     """CPU counterpart of imsim_amd.engine.Renderer."""

@@ -4,6 +4,8 @@ import ctypes as C
 import os
 import re
 
+import numpy as np
+
 import pytest
 
 from imsim_amd import _abi
@@ -36,7 +38,7 @@ def test_struct_sizes_match_binding():
 
 def test_abi_version_and_error_string():
     lib = _abi.load()
-    assert lib.ims_abi_version() == 6
+    assert lib.ims_abi_version() == 7
     # argument checking happens before any HIP call, so it is testable without a GPU
     assert lib.ims_shoot_accumulate(None, None) == -1
     assert b"NULL" in lib.ims_last_error()
@@ -102,3 +104,53 @@ def test_argument_errors_are_reported_before_any_launch():
     op.p[0], op.p[1], op.p[2], op.p[3] = 620.0, 69.328, 293.15, 1.067
     assert lib.ims_fill_derived_op(C.byref(op)) == 0
     assert 1.0e-7 < op.p[5] < 1.0e-5 and 0.0 < op.p[6] < 1.0e-5 and 1.0e-4 < op.p[7] < 4.0e-4      # n - 1 ~ 1.9e-4 at 69 kPa
+
+
+def test_derived_constants_are_the_plain_ieee_expressions():
+    """ims_fill_derived_optics / _atmosphere / _sensor / _op (host code): every derived field equals the single IEEE
+    operation the kernels would otherwise repeat per photon -- the same expression evaluated here in numpy float64."""
+    lib = _abi.load()
+    o = _abi.Optics()
+    o.n_surfaces = 2
+    s = o.surf[0]
+    s.R, s.conic = 19.835, -1.215
+    s.inv_R = 1.0 / s.R
+    s.obsc_inner, s.obsc_outer = 2.558, 4.18
+    s.asph[0], s.asph[1], s.asph[2] = 1.381e-9, -3.2e-13, 7.7e-17
+    o.surf[1].R = 0.0
+    for k, (a, b) in enumerate(zip((0.1, -0.7, 0.7), (0.6, 0.3, -0.74))):
+        o.e_focal[k], o.e_z0[k] = a, b
+    assert lib.ims_fill_derived_optics(C.byref(o)) == 0
+    f = np.float64
+    k1 = f(1.0) + f(s.conic)
+    assert s.k1 == k1 and s.k1c == k1 * f(s.inv_R) and s.m2R == f(-2.0) * f(s.R) and s.cc == f(s.inv_R) * f(s.inv_R)
+    assert s.obsc_i2 == f(2.558) * f(2.558) and s.obsc_o2 == f(4.18) * f(4.18)
+    assert [s.asph_d[k] for k in range(4)] == [f(s.asph[k]) * f(k + 2) for k in range(4)]
+    assert o.surf[1].k1 == 1.0 and o.surf[1].k1c == 0.0 and o.surf[1].m2R == 0.0
+    ef, z0 = [f(v) for v in o.e_focal], [f(v) for v in o.e_z0]
+    g = [ef[1] * z0[2] - ef[2] * z0[1], ef[2] * z0[0] - ef[0] * z0[2], ef[0] * z0[1] - ef[1] * z0[0]]
+    assert [o.rot_g[k] for k in range(3)] == g and o.rot_gnorm == np.sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2])
+    o.n_surfaces = 1000
+    assert lib.ims_fill_derived_optics(C.byref(o)) < 0 and b"n_surfaces" in lib.ims_last_error()
+    a = _abi.Atmosphere()
+    a.npix, a.scale, a.aper_r_outer, a.aper_r_inner = 8192, 0.1, 4.18, 2.5498
+    assert lib.ims_fill_derived_atmosphere(C.byref(a)) == 0
+    assert a.dn == 8192.0 and a.inv_n == 1.0 / 8192.0 and a.inv_scale == f(1.0) / f(0.1)
+    assert a.aper_ri2 == f(2.5498) * f(2.5498) and a.aper_dr2 == f(4.18) * f(4.18) - f(2.5498) * f(2.5498)
+    a.npix = 0
+    assert lib.ims_fill_derived_atmosphere(C.byref(a)) < 0
+    sn = _abi.Sensor()
+    sn.kind, sn.thickness, sn.pixel_size, sn.diff_step = _abi.IMS_SENSOR_SILICON, 100.0, 10.0, 4.9
+    assert lib.ims_fill_derived_sensor(C.byref(sn)) == 0
+    assert sn.diff_coef == f(4.9) / (f(100.0) * f(10.0)) and sn.thick_m1 == 99.0
+    sn.thickness = 0.0
+    assert lib.ims_fill_derived_sensor(C.byref(sn)) < 0
+    op = _abi.Op()
+    op.kind, op.p[0], op.p[1] = _abi.IMS_OP_PUPIL_ANNULUS_SAMPLER, 4.18, 2.55
+    assert lib.ims_fill_derived_op(C.byref(op)) == 0
+    assert op.p[2] == f(2.55) * f(2.55) and op.p[3] == f(4.18) * f(4.18) - f(2.55) * f(2.55)
+    op = _abi.Op()
+    op.kind, op.p[0] = _abi.IMS_OP_REFRACTION, 3.9
+    assert lib.ims_fill_derived_op(C.byref(op)) == 0
+    assert op.p[1] == f(3.9) * f(3.9) and op.p[2] == f(3.9) * f(3.9) - f(1.0)
+    assert lib.ims_fill_derived_optics(None) < 0 and lib.ims_fill_derived_atmosphere(None) < 0 and lib.ims_fill_derived_sensor(None) < 0

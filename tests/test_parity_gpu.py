@@ -1040,469 +1040,6 @@ def test_twenty_object_image_splits_and_sums_like_the_reference(torch_cuda, pool
     scene.psf = [(_abi.IMS_PSF_GAUSSIAN, 0, 0.3 / 2.3548200450309493, 0.0, 1.0)]
     scene.ops = [(_abi.IMS_OP_TIME_SAMPLER, 0, [0.0, 30.0]), (_abi.IMS_OP_PUPIL_ANNULUS_SAMPLER, 0, [4.18, 2.55]),
                  (_abi.IMS_OP_RUBIN_DIFFRACTION_OPTICS, 0, [1.0, 0.0])]
-    # per-object fluxes of the reference's run (tests/test_image.py:189-210: single objects show 1.97e6, 1.97e5 and 38 electrons)
-    flux = np.array([1.974717e+06, 1.971714e+06, 1.971509e+06, 1.976528e+06, 1.978627e+06, 1.977857e+06, 1.975e+06, 1.973e+06,
-                     1.976e+06, 1.972e+06, 1.977190e+05, 1.971800e+05, 1.964360e+05, 1.970330e+05, 1.970620e+05, 1.965160e+05,
-                     1.968e+05, 1.972e+05, 1.966e+05, 3.800000e+01])
-    rng = np.random.default_rng(8)
-    kind = np.where(np.arange(n) % 4 == 0, catalog.KIND_KNOTS, np.where(np.arange(n) % 4 == 1, catalog.KIND_STREAK,
-                    np.where(np.arange(n) % 4 == 2, catalog.KIND_IMAGE, 1))).astype(np.int32)
-    images = [rng.uniform(0, 1, size=(17, 23)) ** 3, np.clip(rng.normal(0.2, 1.0, size=(40, 31)), 0, None)]   # FITS-stamp profiles
-    cat = dict(image_index=rng.integers(0, 2, n), image_scale=rng.uniform(0.05, 0.3, n), image_extent=np.full(n, 8.0),
-               x=rng.uniform(40, 216, n), y=rng.uniform(40, 216, n), mag=np.zeros(n), nominal_flux=np.full(n, 3000.0), kind=kind,
-               hlr=rng.uniform(0.2, 0.8, n), q=rng.uniform(0.3, 1.0, n), pa=rng.uniform(0, 180, n), obj_id=np.arange(n) + 100,
-               n_knots=np.where(kind == catalog.KIND_KNOTS, rng.integers(1, 30, n), 0).astype(float),
-               box_length=np.where(kind == catalog.KIND_STREAK, rng.uniform(2, 15, n), 0.0),
-               box_width=np.where(kind == catalog.KIND_STREAK, rng.uniform(0.2, 1.0, n), 0.0))
-    scene = configs.scene_c2(nx=256, ny=256)
-    from imsim_amd import config
-    scene.psf = [config.double_gaussian_psf(0.7)[0]]          # and the DoubleGaussianPSF mixture as the PSF
-    scene.image_profiles = images
-    objects, _ = catalog.build_object_table(cat, rng.integers(500, 4000, n))
-    assert (objects["prof_table"] == -4).sum() == n // 4
-    r = Renderer(scene)
-    pool = r.shoot_photons(objects)
-    r.accumulate(pool)
-    r.synchronize()
-    orc = orc_loader.OracleScene(scene)
-    opool = orc.shoot_pool(objects)
-    orc.accumulate(opool)
-    g, o = pool.to_host(), opool.to_host()
-    for f in ("x", "y", "wavelength", "flux"):
-        assert_bits_equal(g[f], o[f], f"photon field {f}")
-    assert_bits_equal(r.image_numpy(), orc.image, "knots/streak image")
-    r2 = Renderer(scene)
-    r2.render(objects)
-    r2.synchronize()
-    assert_bits_equal(r2.image_numpy(), orc.image, "fused knots/streak image")
-
-
-def test_sky_background_and_noise(torch_cuda):
-    """addNoise (imsim/lsst_image.py:128-200): Poisson sky with a linear gradient and a multiplier map, bit-exact vs
-    the oracle's Poisson deviates; mean and variance equal the expectation."""
-    from imsim_amd import configs, lsst_image
-    from imsim_amd.engine import Renderer
-    from oracle import orc_loader
-    scene = configs.scene_c2(nx=192, ny=160)
-    r = Renderer(scene)
-    b = lsst_image.LSST_ImageBuilder()
-    mult = 1.0 + 0.1 * np.cos(np.arange(160)[:, None] / 20.0) * np.ones((160, 192))
-    grad = (0.95, 0.0005, -0.0002)
-    b.add_noise(r, sky_level=25000.0, sky_gradient=grad, multiplier=mult, seed=99)
-    r.synchronize()
-    img = r.image.cpu().numpy()
-    xx, yy = np.meshgrid(np.arange(192.0), np.arange(160.0))
-    expect = 25000.0 * 0.04 * (grad[0] + grad[1] * xx + grad[2] * yy) * mult
-    assert abs((img - expect).mean()) < 4 * np.sqrt(expect.mean() / img.size)
-    np.testing.assert_allclose(((img - expect) ** 2 / expect).mean(), 1.0, rtol=0.03)
-    orc = orc_loader.OracleScene(scene)
-    base = np.ascontiguousarray((grad[0] + grad[1] * xx + grad[2] * yy) * mult)
-    orc.lib.orc_flat_add(None, base.ctypes.data, 25000.0 * 0.2 * 0.2, 1.0, 99, lsst_image.NOISE_STREAM, 192, 160,
-                         orc.image64.ctypes.data, None)
-    assert_bits_equal(img, orc.image64, "sky noise")
-
-
-def test_photon_pooling_build_image_is_bit_exact(torch_cuda):
-    """C4 semantics end to end (imsim/photon_pooling.py:116-168): nbatch photon batches, nsubbatch object sub-batches,
-    one pixel-boundary recalculation per batch (tile-tagged on the GPU) -- image and boundaries equal the oracle's."""
-    from helpers import c3_small_case
-    from imsim_amd import photon_pooling, stamp
-    from imsim_amd.engine import Renderer
-    from oracle import orc_loader
-    scene, objects = c3_small_case(n_obj=90, n=192, flux_seed=6, scratch=0)
-    scene.track_static_delta = 1
-    modes = stamp.classify(objects["n_phot"].astype(float), 100.0)
-    r = Renderer(scene)
-    real = torch_cuda.zeros(len(objects), dtype=torch_cuda.float64, device="cuda")
-    n_gpu = photon_pooling.build_image(r, objects, modes, nbatch=5, nsubbatch=4, seed=21, realized=real)
-    r.synchronize()
-    orc = orc_loader.OracleScene(scene)
-    n_cpu = photon_pooling.build_image(orc, objects, modes, nbatch=5, nsubbatch=4, seed=21)
-    assert n_gpu == n_cpu == int(objects["n_phot"].sum())
-    assert_bits_equal(r.image_numpy(), orc.image, "pooling image")
-    ga = _sensor_arrays_gpu(r)
-    for name in ("boundary", "bounds", "delta"):
-        assert_bits_equal(ga[name], orc.sensor_array(name), f"pooling sensor {name}")
-    assert abs(real.sum().item() / r.image.sum().item() - 1) < 1e-12
-    # the replayable form (one fused launch per batch, bench config c4) gives the same image and sensor state
-    r2 = Renderer(scene)
-    run = photon_pooling.prepared_image(r2, objects, modes, nbatch=5, seed=21)
-    run()
-    r2.synchronize()
-    assert run.photons == n_gpu
-    assert_bits_equal(r2.image_numpy(), orc.image, "prepared pooling image")
-    assert_bits_equal(_sensor_arrays_gpu(r2)["boundary"], orc.sensor_array("boundary"), "prepared pooling boundaries")
-    r2.image.zero_()
-    run()                                                        # replay: a fresh CCD
-    r2.synchronize()
-    assert_bits_equal(r2.image_numpy(), orc.image, "replayed pooling image")
-
-
-def test_photon_flat_is_bit_exact_and_shows_brighter_fatter(torch_cuda):
-    """LSST_Flat, sed branch (imsim/flat.py:237-262): small case bit-exact vs the oracle; reference-sized case
-    (256^2, 80 000 e-/px in 20 iterations) has variance below the mean and positive neighbour covariances."""
-    from imsim_amd import configs, flat
-    from imsim_amd.engine import Renderer
-    from oracle import orc_loader
-    b = flat.LSST_FlatBuilder()
-    cfg = {"counts_per_pixel": 2400.0, "max_counts_per_iter": 800, "xsize": 48, "ysize": 40, "buffer_size": 5}
-    b.setup(cfg)
-    scene = configs.scene_flat(48, 40, sensor=True, seed=3)
-    scene.track_static_delta = 1
-    r = Renderer(scene)
-    img = b.build_image_photons(r, seed=9).cpu().numpy()
-    orc = orc_loader.OracleScene(scene)
-    b.build_image_photons(orc, seed=9)
-    assert_bits_equal(img, flat.crop(scene, orc.image64), "photon flat")
-    assert_bits_equal(_sensor_arrays_gpu(r)["boundary"], orc.sensor_array("boundary"), "photon flat boundaries")
-    tot = 80_000.0
-    b.setup({"counts_per_pixel": tot, "max_counts_per_iter": 4000, "xsize": 256, "ysize": 256})
-    scene = configs.scene_flat(256, 256, sensor=True)
-    scene.track_static_delta = 1
-    r = Renderer(scene)
-    img = b.build_image_photons(r, seed=1234).cpu().numpy()
-    a = img - img.mean()
-    cov10 = np.mean(a[1:, :] * a[:-1, :])
-    np.testing.assert_allclose(img.mean(), tot, rtol=1e-2)
-    assert 0.85 * tot < img.var() < tot
-    assert cov10 > 1e-2 * tot
-
-
-def test_gpu_reproduces_the_frozen_spec_digests(torch_cuda):
-    """the same digests (tests/golden/pipeline_golden.json) from the HIP path alone, without the oracle in the loop"""
-    import json, os, sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    sys.path.insert(0, os.path.join(here, "golden"))
-    import make_pipeline_golden as g
-    from imsim_amd.engine import Renderer
-
-    class B(Renderer):
-        def image64_host(self):
-            self.synchronize()
-            return self.image.cpu().numpy()
-
-    want = json.load(open(os.path.join(here, "golden", "pipeline_golden.json")))
-    got = {k: g.digest(v) for k, v in g.cases(B).items()}
-    assert got == want["sha256"]
-
-
-def test_focal_plane_ccds_on_streams(torch_cuda):
-    """BASELINE config C5 at test size: several CCDs of one visit (different seeds, tree-ring detectors and
-    sizes), two in flight at a time on their own streams.  Every CCD equals its stand-alone render, one of
-    them is checked against the oracle, and the rank split deals each CCD to exactly one rank."""
-    from imsim_amd import focal_plane, configs
-    from imsim_amd.engine import Renderer
-    from oracle import orc_loader
-    specs = {94: dict(n=384, n_obj=160, flux_seed=2, seed=11), 95: dict(n=256, n_obj=120, flux_seed=3, seed=12),
-             96: dict(n=320, n_obj=140, flux_seed=4, seed=13), 97: dict(n=256, n_obj=100, flux_seed=5, seed=14)}
-
-    def build(det):
-        s = specs[det]
-        return _c3_case(n_obj=s["n_obj"], n=s["n"], flux_seed=s["flux_seed"], seed=s["seed"])
-
-    images = focal_plane.render_focal_plane(list(specs), build, concurrent=2)
-    assert sorted(images) == sorted(specs)
-    serial = focal_plane.render_focal_plane(list(specs), build, concurrent=1)
-    for det in specs:
-        scene, objects = build(det)
-        r = Renderer(scene)
-        r.render_lsst_image(objects)
-        r.synchronize()
-        assert_bits_equal(images[det], r.image_numpy(), f"CCD {det} on a stream vs stand-alone")
-        assert_bits_equal(serial[det], images[det], f"CCD {det}: concurrent=1 vs 2")
-    scene, objects = build(95)
-    orc = orc_loader.OracleScene(scene)
-    orc.render_lsst_image(objects)
-    assert_bits_equal(images[95], orc.image, "CCD 95 vs oracle")
-    parts = [focal_plane.render_focal_plane(list(specs), build, rank=k, world=2, concurrent=2) for k in range(2)]
-    assert sorted(list(parts[0]) + list(parts[1])) == sorted(specs)
-    for p in parts:
-        for det, img in p.items():
-            assert_bits_equal(img, images[det], f"CCD {det} rank split")
-
-
-# ---------------------------------------------------------------------------------------------
-# CCD readout (SURVEY 8f-4): e-image -> raw amplifier segments
-# ---------------------------------------------------------------------------------------------
-def _gpu_bleed(torch, img, full_well, midline):
-    lib = _abi.load()
-    t = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float64)).cuda()
-    ny, nx = t.shape
-    flags = torch.empty((nx * ny + 15) // 16 * 16 + 16 * nx, dtype=torch.uint8, device="cuda")   # IMS_READOUT_SCRATCH_BYTES
-    _abi.check(lib.ims_readout_bleed(t.data_ptr(), flags.data_ptr(), nx, ny, float(full_well), int(midline), None))
-    torch.cuda.synchronize()
-    return t.cpu().numpy()
-
-
-def test_bleed_trails_match_reference_goldens_and_oracle(torch_cuda):
-    """bleed_eimage on the GPU against the vectors generated from the reference's bleed_trails.py, and against the
-    oracle on a CCD-sized image with many saturated stars."""
-    import os
-    from oracle import orc_loader
-    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "readout_golden.npz"))
-    fw = float(gold["full_well"])
-    assert_bits_equal(_gpu_bleed(torch_cuda, gold["img_in"], fw, True), gold["img_midline"], "midline stop")
-    assert_bits_equal(_gpu_bleed(torch_cuda, gold["img_in"], fw, False), gold["img_nomidline"], "no midline stop")
-    assert_bits_equal(_gpu_bleed(torch_cuda, gold["chan_in"][:, None], fw, False)[:, 0], gold["chan_out"], "single channel")
-    assert_bits_equal(_gpu_bleed(torch_cuda, gold["neg_in"][:, None], float(gold["neg_fw"]), False)[:, 0], gold["neg_out"],
-                      "regression channel")
-    rng = np.random.default_rng(8)
-    img = rng.poisson(800.0, size=(1000, 1536)).astype(np.float64)
-    for _ in range(300):
-        y, x, s = rng.integers(0, 1000), rng.integers(0, 1536), rng.integers(1, 6)
-        img[max(y - s, 0):y + s, max(x - s, 0):x + s] += rng.uniform(0.5, 40.0) * 1e5
-    for mid in (True, False):
-        assert_bits_equal(_gpu_bleed(torch_cuda, img, 1e5, mid), orc_loader.bleed_eimage(img, 1e5, mid), f"random image, midline {mid}")
-
-
-def _eimage_with_stars(nx, ny, seed, n_star=40):
-    rng = np.random.default_rng(seed)
-    e = rng.poisson(800.0, size=(ny, nx)).astype(np.float64)
-    for _ in range(n_star):
-        y, x, s = rng.integers(0, ny), rng.integers(0, nx), rng.integers(1, 5)
-        e[max(y - s, 0):y + s, max(x - s, 0):x + s] += np.round(rng.uniform(0.2, 30.0) * 1e5)
-    return e
-
-
-def test_readout_chain_is_bit_exact(torch_cuda, tmp_path):
-    """CcdReadout.build_amp_images on the GPU (bleed trails, dark current, gain / flips / crosstalk, prescan and
-    overscan, parallel + serial CTI, bias, read noise, int32) against the oracle, for a full-size E2V CCD with
-    per-amp bias levels and for an ITL CCD; then the raw file is written and read back."""
-    import json
-    from imsim_amd import readout, camera, fits_io
-    from oracle import orc_loader
-    levels = {f"{r}_{s}": {a: 20000.0 + 11 * i for i, a in enumerate(camera.CHANNELS)} for r in camera.RAFTS for s in camera.SENSORS}
-    (tmp_path / "bias.json").write_text(json.dumps(levels))
-    cases = (("R22_S11", dict(bias_levels_file=str(tmp_path / "bias.json"))),
-             ("R01_S00", dict(bias_level=1000.0, read_noise=6.5, scti=3e-6, pcti=0)))
-    for det, kw in cases:
-        cam = camera.Camera("LsstCamSim", bias_levels_file=kw.get("bias_levels_file"))
-        ny, nx = cam[det].bounds.numpyShape()
-        e = _eimage_with_stars(nx, ny, seed=len(det) + nx)
-        hdr = readout.eimage_header(det, 30.0, opsim_data={"mjd": 60000.25, "band": "r"})
-        eimg = readout.EImage(torch_cuda.from_numpy(e).cuda(), hdr)
-        ro = readout.CcdReadout(eimg, camera_obj=cam, **kw)
-        seed = 4242
-        got = ro.build_amp_images(seed)
-        torch_cuda.cuda.synchronize()
-        st = {}
-        want = orc_loader.readout_chain(e, ro.descriptor(), ro.full_well, ro.midline_stop(), ro.dark_level(), readout.DARK_STREAM,
-                                        seed, ro.pcte_band, ro.scte_band, st)
-        assert (st["bled"] != e).any(), "the test image must actually bleed"
-        assert_bits_equal(eimg.array.cpu().numpy(), st["dark"], f"{det}: e-image after bleed trails and dark current")
-        assert_bits_equal(got.cpu().numpy(), want, f"{det}: raw segments")
-        assert got.shape == (16, 2048, 576)
-    hdus = ro.prepare_hdus(seed + 1)
-    f = tmp_path / "raw.fits"
-    readout.CcdReadout.write_raw_file(hdus, str(f))
-    back = fits_io.read_fits(str(f))
-    assert len(back) == 17 and back[0][0]["OUTFILE"] == "raw.fits" and back[0][0]["CHIPID"] == "R01_S00"
-    assert back[1][0]["EXTNAME"] == "Segment10" and back[16][0]["EXTNAME"] == "Segment00"
-    assert back[9][0]["DATASEC"] == "[4:512,1:2000]"
-    for k in range(16):
-        assert_bits_equal(back[k + 1][1], hdus[k + 1][1], f"segment {k} through the file")
-    eimg.write(str(tmp_path / "eimage.fits"))
-    (h, d), = fits_io.read_fits(str(tmp_path / "eimage.fits"))
-    assert h["DET_NAME"] == "R01_S00" and d.shape == (4000, 4072) and d.dtype == np.float32
-
-
-def test_config_readout_writes_eimage_and_raw_file(torch_cuda, tmp_path):
-    """`output.file_name` and the `output.readout` extra output (config/imsim-config.yaml:322-352 semantics): the
-    e-image file and the 16-segment raw file; the segments, put back together with the gains, give the e-image."""
-    from imsim_amd import fits_io, camera
-    from imsim_amd.lsst_image import GalSimConfigError
-    res = _process(**{"image.nobjects": 40, "stamp.draw_method": "phot", "output.dir": str(tmp_path), "output.file_name": "eimage.fits",
-                      "output.readout": {"readout_time": 3.0, "dark_current": 0.0, "bias_level": 1000.0, "scti": 0.0, "pcti": 0.0,
-                                         "read_noise": 0.0, "file_name": "amp.fits",
-                                         "added_keywords": {"TESTKEY1": "TESTVAL1"}}})
-    assert [os.path.basename(f) for f in res.files] == ["eimage.fits", "amp.fits"] and len(res.raw) == 1
-    (eh, ed), = fits_io.read_fits(res.files[0])
-    assert eh["DET_NAME"] == "R22_S11" and eh["CAMERA"] == "LsstCamSim" and ed.shape == (4004, 4096)
-    assert np.array_equal(ed, res.images[0])
-    raw = fits_io.read_fits(res.files[1])
-    assert len(raw) == 17 and raw[0][0]["TESTKEY1"] == "TESTVAL1" and raw[0][0]["CHIPID"] == "R22_S11" and raw[0][0]["EXPTIME"] == eh["EXPTIME"]
-    ccd = camera.Camera("LsstCamSim")["R22_S11"]
-    back = np.zeros_like(ed)
-    for k, amp in enumerate(ccd.values()):
-        r, b = amp.raw_data_bounds, amp.bounds
-        sec = raw[k + 1][1][r.ymin - 1:r.ymax, r.xmin - 1:r.xmax].astype(np.float64) - 1000.0
-        if amp.raw_flip_x:
-            sec = sec[:, ::-1]
-        if amp.raw_flip_y:
-            sec = sec[::-1, :]
-        back[b.ymin - 1:b.ymax, b.xmin - 1:b.xmax] = sec * amp.gain
-    # the readout works on the e-image after the bleed trails (the catalog's brightest star is far above full well)
-    bled = res.eimages[0].array.cpu().numpy()
-    # (the e-image file is float32: its brightest pixels, > 2^24 e-, are rounded by a few electrons)
-    assert ed.max() > ccd.full_well and bled.max() == ccd.full_well and bled.sum() <= ed.astype(np.float64).sum() + 64
-    # no noise, no CTI, no dark current: only crosstalk (<= 4e-4 of the brightest neighbour) and the ADU truncation remain
-    assert np.abs(back - bled).max() <= 2.0 + 1e-3 * bled.max()
-    assert abs(back.sum() / bled.sum() - 1) < 0.01
-    with pytest.raises(GalSimConfigError):
-        _process(**{"image.nobjects": 5, "output.readout": {"no_such_parameter": 1}})
-
-
-def test_config_fits_stamp_object_end_to_end(torch_cuda, tmp_path):
-    """An instance catalog with a FITS-stamp object (imsim/instcat.py:552-561) through config.Process: the stamp's
-    shape shows up on the CCD at the object's position, rotated by -theta, on the stamp's own pixel scale."""
-    from imsim_amd import fits_io
-    here = os.path.dirname(os.path.abspath(__file__))
-    header = [l for l in open(os.path.join(here, "golden", "example_instcat_subset.txt")) if not l.startswith("object")]
-    stamp = np.zeros((20, 20), dtype=np.float32)
-    stamp[2:18, 9:11] = 1.0                               # a bar along the stamp's y axis
-    fits_io.write_fits(str(tmp_path / "bar.fits"), [({}, stamp)])
-    lines = header + ["object 1 60.49045502638662697 -38.16437495898705379 17.0 starSED/x.gz 0 0 0 0 0 0 bar.fits 0.4 0.0 none none\n",
-                      "object 2 60.52 -38.18 17.0 starSED/x.gz 0 0 0 0 0 0 bar.fits 0.4 90.0 none none\n",
-                      "object 3 60.46 -38.15 22.0 starSED/x.gz 0 0 0 0 0 0 point none none\n"]
-    (tmp_path / "cat.txt").write_text("".join(lines))
-    res = _process(**{"input.instance_catalog.file_name": str(tmp_path / "cat.txt"), "stamp.draw_method": "phot",
-                      "image.sensor": "", "stamp.photon_ops": [], "input.instance_catalog.sort_mag": False})
-    img, truth = res.images[0].astype(np.float64), res.truth[0]
-    assert list(truth["mode"][:2]) == ["phot", "phot"] and truth["phot_flux"][0] > 1e5
-    angles = []
-    for k in (0, 1):
-        x0, y0 = int(round(truth["x"][k])) - 1, int(round(truth["y"][k])) - 1
-        cut = img[y0 - 40:y0 + 41, x0 - 40:x0 + 41]
-        assert cut.sum() > 0.9 * truth["realized_flux"][k] > 0
-        yy, xx = np.mgrid[-40:41, -40:41]
-        w = cut / cut.sum()
-        mx, my = (w * xx).sum(), (w * yy).sum()
-        cxx, cyy, cxy = (w * (xx - mx) ** 2).sum(), (w * (yy - my) ** 2).sum(), (w * (xx - mx) * (yy - my)).sum()
-        lam = np.linalg.eigvalsh(np.array([[cxx, cxy], [cxy, cyy]]))
-        # the bar is 16 x 0.4" = 32 pixels long and 2 x 0.4" = 4 pixels wide (plus the PSF)
-        assert abs(np.sqrt(lam[1]) - 32 / np.sqrt(12)) < 1.5 and np.sqrt(lam[0]) < 4.0
-        angles.append(0.5 * np.degrees(np.arctan2(2 * cxy, cxx - cyy)))
-    # the stamp lives on the sky (the WCS turns it on the CCD); theta = 90 turns the second one by a right angle
-    d = abs(angles[0] - angles[1]) % 180.0
-    assert abs(d - 90.0) < 3.0, angles
-
-
-def test_config_flat_readout_without_opsim(torch_cuda, tmp_path):
-    """A flat read out without any opsim data (tests/test_readout.py:124-160 of the reference, test_no_opsim): the
-    header falls back to its defaults, the segments carry counts / gain + bias."""
-    from imsim_amd import config, camera, fits_io
-    res = config.Process({"image": {"type": "LSST_Flat", "random_seed": 42, "det_name": "R22_S11", "counts_per_pixel": 1000,
-                                    "max_counts_per_iter": 1000, "sensor": ""},
-                          "output": {"dir": str(tmp_path), "file_name": "flat_e.fits",
-                                     "readout": {"file_name": "flat_amp.fits", "dark_current": 0.0, "scti": 0.0, "pcti": 0.0,
-                                                 "read_noise": 0.0, "bias_level": 500.0}}})
-    assert res.images[0].shape == (4004, 4096) and abs(res.images[0].mean() - 1000.0) < 0.1
-    raw = fits_io.read_fits(res.files[1])
-    ph = raw[0][0]
-    assert ph["IMGTYPE"] == "FLAT" and ph["TRACKSYS"] == "LOCAL" and ph["MJD"] == 51444.0 and ph["RUNNUM"] == -999
-    ccd = camera.Camera("LsstCamSim")["R22_S11"]
-    for k, amp in enumerate(ccd.values()):
-        r = amp.raw_data_bounds
-        sec = raw[k + 1][1][r.ymin - 1:r.ymax, r.xmin - 1:r.xmax].astype(np.float64)
-        xt = 0.0 if ccd.xtalk is None else sum(ccd.xtalk[k][j] / list(ccd.values())[j].gain for j in range(16)) * 1000.0
-        assert abs(sec.mean() - (500.0 + 1000.0 / amp.gain + xt - 0.5)) < 0.2, (k, sec.mean())
-        assert (raw[k + 1][1][:, :r.xmin - 1] == 500).all()            # prescan: bias only
-
-
-def test_general_sersic_index_fft_and_photon_shooting_agree(torch_cuda):
-    """A Sersic index off the 1 / 4 pair (imsim/instcat.py:511-517: quantised to 0.05, here 2.5) has its own radial
-    table for photon shooting and its own k-table for the FFT branch; the two renderings meet the reference's
-    FFT-vs-phot criteria, and the photon pool equals the oracle's bit for bit."""
-    from imsim_amd import _abi, configs, catalog, fft_draw
-    from imsim_amd.engine import Renderer
-    from oracle import orc_loader
-    fwhm_atm, fwhm_sys = catalog.kolmogorov_gaussian_fwhm()
-    scene = configs.scene_c2(nx=128, ny=128)
-    scene.psf = [(_abi.IMS_PSF_RADIAL, 2, fwhm_atm, 0.0, 1.0), (_abi.IMS_PSF_GAUSSIAN, 0, fwhm_sys / 2.3548200450309493, 0.0, 1.0)]
-    configs.add_sersic_tables(scene, [2.5])
-    cat = dict(x=np.array([64.3]), y=np.array([63.8]), mag=np.zeros(1), nominal_flux=np.array([4.0e6]), kind=np.array([2]),
-               hlr=np.array([0.5]), q=np.array([0.7]), pa=np.array([20.0]), obj_id=np.array([3]), sersic_n=np.array([2.5]))
-    objects, _ = catalog.build_object_table(cat, np.array([4000000]), stamp_size=128, sersic_index=scene.sersic_index)
-    assert objects["prof_table"][0] == scene.sersic_index[2.5] == 3
-    rp = Renderer(scene)
-    rp.render(objects)
-    rf = Renderer(scene)
-    kt = fft_draw.profile_ktable_ids(scene, objects["prof_table"])
-    assert kt[0] == 2
-    rows, _ = fft_draw.build_fft_objects(objects, cat["nominal_flux"], kt)
-    fft_draw.FftDrawer(rf, fft_draw.kolmogorov_gaussian_kpsf(fwhm_atm, fwhm_sys), add_noise=False).draw(rows)
-    rp.synchronize(); rf.synchronize()
-    a, b = rp.image_numpy().astype(float), rf.image_numpy().astype(float)
-    yy, xx = np.mgrid[0:128, 0:128]
-    w = (np.hypot(xx - 63.3, yy - 62.8) < 25)
-
-    def mom(img):
-        f = (img * w).sum()
-        mx, my = (img * w * xx).sum() / f, (img * w * yy).sum() / f
-        return f, mx, my, (img * w * ((xx - mx) ** 2 + (yy - my) ** 2)).sum() / f
-    fa, xa, ya, ra = mom(a)
-    fb, xb, yb, rb = mom(b)
-    assert abs(a.max() / b.max() - 1) < 0.05 and abs(fa / fb - 1) < 0.01
-    assert abs(xa - xb) < 0.02 and abs(ya - yb) < 0.02 and abs(ra / rb - 1) < 0.10
-    # and it is NOT the n = 4 profile any more: a de Vaucouleurs profile of the same half-light radius puts more light far out
-    objects4 = objects.copy()
-    objects4["prof_table"] = 1
-    r4 = Renderer(scene)
-    r4.render(objects4)
-    r4.synchronize()
-    ring = (np.hypot(xx - 63.3, yy - 62.8) > 12) & w
-    a4 = r4.image_numpy().astype(float)
-    assert a4[ring].sum() > 1.15 * a[ring].sum()
-    small = objects.copy()
-    small["n_phot"] = 5000
-    pool = Renderer(scene).shoot_photons(small)
-    opool = orc_loader.OracleScene(scene).shoot_pool(small)
-    g, o = pool.to_host(), opool.to_host()
-    for f in ("x", "y", "wavelength"):
-        assert_bits_equal(g[f], o[f], f"photon field {f} (n = 2.5)")
-
-
-def test_pooling_mode_draws_fft_objects_first(torch_cuda):
-    """LSST_PhotonPoolingImageBuilder.buildImage (imsim/photon_pooling.py:84-114): objects above the FFT threshold are
-    FFT-drawn before the photon batches and do not enter them."""
-    from imsim_amd import _abi, configs, catalog, fft_draw, lsst_image
-    from imsim_amd.engine import Renderer
-    scene = configs.scene_c3(nx=256, ny=256, sensor=False)
-    cat = catalog.synthetic_catalog(40, nx=256, ny=256)
-    cat["nominal_flux"][:2] = [3.0e6, 5.0e6]                      # two objects beyond the 1e6 floor of stamp.py:275
-    cat["kind"][:2] = [0, 1]
-    cat["sb_flux"] = cat["nominal_flux"] / 80.0
-    phot = catalog.realize_fluxes(cat["nominal_flux"], 3)
-    fwhm_atm, fwhm_sys = catalog.kolmogorov_gaussian_fwhm(configs.VISIT["airmass"], configs.VISIT["raw_seeing"], "r")
-    kpsf = fft_draw.kolmogorov_gaussian_kpsf(fwhm_atm, fwhm_sys)
-    b = lsst_image.LSST_PhotonPoolingImageBuilder()
-    b.setup({"det_name": "R22_S11", "xsize": 256, "ysize": 256, "nbatch": 3, "nsubbatch": 2}, "LSST_Photons")
-    r = Renderer(scene)
-    truth = {}
-    b.build_image(r, cat, phot, lambda c, p: configs.c3_objects(c, p, scene), seed=5, truth=truth, fft_sb_thresh=2.0e4, kpsf=kpsf,
-                  fwhm_total=float(np.hypot(fwhm_atm, fwhm_sys)))
-    r.synchronize()
-    modes = list(truth["mode"])
-    assert modes[0] == "fft" and modes[1] == "fft" and "fft" not in modes[2:]
-    assert np.all(truth["phot_flux"][:2] == 0) and np.all(truth["fft_flux"][:2] == cat["nominal_flux"][:2])
-    np.testing.assert_allclose(truth["incident_flux"][:2], cat["nominal_flux"][:2], rtol=0.03)
-    img = r.image_numpy()
-    ix, iy = int(round(cat["x"][0])) - 1, int(round(cat["y"][0])) - 1
-    assert img[iy - 2:iy + 3, ix - 2:ix + 3].sum() > 0.2 * 3.0e6 * 0.5       # the FFT-drawn star is on the image
-    # without a threshold everything is photon-shot, as before
-    r2 = Renderer(scene)
-    t2 = {}
-    b.build_image(r2, cat, phot, lambda c, p: configs.c3_objects(c, p, scene), seed=5, truth=t2)
-    assert "fft" not in list(t2["mode"]) and t2["phot_flux"][0] == phot[0]
-
-
-@pytest.mark.parametrize("pooling", [False, True])
-def test_twenty_object_image_splits_and_sums_like_the_reference(torch_cuda, pooling):
-    """tests/test_image.py:18-29, :162-228 of the reference: 20 stars through Gaussian(fwhm 0.3) + RubinDiffractionOptics with
-    fft_sb_thresh = 1e4 -- the ten of ~2e6 electrons are FFT-drawn, the nine of ~2e5 are photon-shot, the last (38 e-) is
-    faint -- and the 20 x 20 pixel aperture sums equal the expected brightness within 4 sqrt(N), for LSST_Image and for
-    LSST_PhotonPoolingImage alike.  (The reference's pixel positions come from its Batoid WCS, which is out of scope; the
-    positions here are this build's own, including the reference's pair of nearly coincident objects.)"""
-    import math
-    from imsim_amd import _abi, configs, catalog, fft_draw, lsst_image
-    from imsim_amd.diffraction_fft import DiffractionFFT
-    from imsim_amd.engine import Renderer
-    n = 1024
-    scene = configs.scene_c3(nx=n, ny=n, sensor=False)
-    scene.optics = configs.rubin_optics_struct(n, n, rottelpos=20.0, altitude=88.0, azimuth=73.7707957)
-    scene.psf = [(_abi.IMS_PSF_GAUSSIAN, 0, 0.3 / 2.3548200450309493, 0.0, 1.0)]
-    scene.ops = [(_abi.IMS_OP_TIME_SAMPLER, 0, [0.0, 30.0]), (_abi.IMS_OP_PUPIL_ANNULUS_SAMPLER, 0, [4.18, 2.55]),
-                 (_abi.IMS_OP_RUBIN_DIFFRACTION_OPTICS, 0, [1.0, 0.0])]
     # the reference's expected brightness values (tests/test_image.py:189-210), objects off the image dropped
     flux = np.array([1.974717e+06, 4.329067e+06 / 2, 1.971714e+06, 1.971509e+06, 1.976528e+06, 3.125554e+06 / 2 + 4.0e5, 1.978627e+06,
                      1.977857e+06, 1.977190e+05, 4.049977e+06 / 20, 2.192697e+06 / 11, 4.329907e+06 / 22, 1.971800e+05, 1.964360e+05,

@@ -134,7 +134,8 @@ def main():
         renderer.image.zero_()
         step()
         # unit photon fluxes: every pixel is an integer count; the brightest pixel of this catalog holds ~1e8 < 2^31
-        parallel.reduce_image(renderer.image, dst=0, integer_counts=True)
+        if cfg.get("reduce", True):
+            parallel.reduce_image(renderer.image, dst=0, integer_counts=True)
 
     for _ in range(args.warmup):
         full_step()
@@ -206,7 +207,8 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": cfg["workload"], "n_objects": n_total_obj, "n_photons": n_total_phot,
-                   "image": [scene.nx, scene.ny], "sharding": f"objects dealt by photon count over {world} rank(s)"},
+                   "image": [scene.nx, scene.ny],
+                   "sharding": cfg.get("sharding", "objects dealt by photon count") + f" over {world} rank(s)"},
         "photons_per_s": n_total_phot * args.steps / elapsed,
         "roofline": roofline,
     }

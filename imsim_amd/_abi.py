@@ -166,6 +166,18 @@ class RenderParams(C.Structure):
                 ("bf_tag", C.c_uint32), ("pad_tag", C.c_uint32), ("seg_object", c_vp), ("images", ImageTables)]
 
 
+IMS_PLAN_ROUNDS = 9
+IMS_MAX_CHAINS = 4
+IMS_MAX_CHAIN_EDGES = 8
+
+
+class Chain(C.Structure):
+    _fields_ = [("params", c_vp), ("pool", c_vp), ("pool_start", c_vp), ("n_phot", c_vp), ("tile_prefix", c_vp),
+                ("tile_prefix_host", c_vp), ("n_objects", c_i32), ("first_slot", c_i32), ("stream", c_i32), ("nrecalc", c_i32),
+                ("n_rounds", c_i32), ("use_tags", c_i32), ("ev_base", c_i32), ("n_edges", c_i32),
+                ("edges", c_i32 * IMS_MAX_CHAIN_EDGES)]
+
+
 class PlanItem(C.Structure):
     _fields_ = [("kind", c_i32), ("stream", c_i32), ("params", c_vp), ("pool", c_vp), ("aux", c_vp),
                 ("first_slot", c_i32), ("n_slots", c_i32), ("n_tiles", c_i64), ("tag", C.c_uint32), ("pad", C.c_uint32),
@@ -194,7 +206,7 @@ STRUCTS = [Object, RadialTables, LinTables, PsfComponent, Op, Surface, TanSip, O
 
 # every symbol include/imsim_hip.h declares
 EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_info", "ims_shoot_accumulate",
-           "ims_shoot_photons", "ims_shoot_ops_photons", "ims_accumulate_segments", "ims_run_plan",
+           "ims_shoot_photons", "ims_shoot_ops_photons", "ims_accumulate_segments", "ims_accumulate_round", "ims_run_plan",
            "ims_bf_chain", "ims_bf_chain_ctl_bytes", "ims_bf_chain_status",
            "ims_fft_kspace_fill", "ims_fft_finish", "ims_fft_spikes", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
            "ims_sensor_update_distortions", "ims_image_add", "ims_image_to_float", "ims_fill_derived_op", "ims_fill_derived_medium", "ims_fill_derived_optics", "ims_fill_derived_atmosphere", "ims_fill_derived_sensor", "ims_sensor_pixel_areas", "ims_flat_add", "ims_last_kernel_ms", "ims_enable_timing",
@@ -236,6 +248,7 @@ def load():
     lib.ims_apply_ops.argtypes = [C.POINTER(RenderParams), c_vp, C.POINTER(Photons), c_vp]
     lib.ims_shoot_ops_photons.argtypes = [C.POINTER(RenderParams), c_vp, C.POINTER(Photons), c_vp]
     lib.ims_accumulate_segments.argtypes = [C.POINTER(RenderParams), C.POINTER(Photons), c_vp, c_vp]
+    lib.ims_accumulate_round.argtypes = [C.POINTER(RenderParams), C.POINTER(Photons), c_vp, c_i32, c_i32, c_i32, c_vp]
     lib.ims_accumulate.argtypes = [C.POINTER(RenderParams), c_vp, C.POINTER(Photons), c_vp, c_vp]
     lib.ims_sensor_init_boundaries.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_vp]
     lib.ims_sensor_update_distortions.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_vp, c_i64, c_vp, C.c_uint32, c_vp]

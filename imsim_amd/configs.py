@@ -449,3 +449,104 @@ BENCH_CONFIGS["fft"] = dict(
     cpu_allcore=False,
     parity_mode="close",
 )
+
+
+# ---------------------------------------------------------------------------------------------
+# C5: a whole focal plane -- 189 CCDs x 10 k sources, every CCD an independent LSST_Image build on its own stream
+# ---------------------------------------------------------------------------------------------
+N_CCD_FOCAL_PLANE = 189
+
+
+class _FocalPlaneCatalog(dict):
+    """the catalogs of all CCDs back to back; `ccd_offsets[k] : ccd_offsets[k + 1]` are the rows of CCD k"""
+    ccd_offsets = None
+
+
+class _CcdTable(np.ndarray):
+    """object rows of all CCDs back to back; a slice (bench.py's CPU sample) is a plain table of one CCD"""
+    ccd_offsets = None
+
+
+def _c5_scene_bench():
+    sc = scene_c3()
+    sc.sensor.scratch_cells = 6_000_000       # private brighter-fatter regions of one CCD's ~160 bright objects
+    sc.sensor.max_slots = 2048
+    return sc
+
+
+def _c5_catalog(n_objects, scene):
+    per = max(n_objects // N_CCD_FOCAL_PLANE, 1)
+    parts = [catalog.synthetic_catalog(per, seed=20261001 + det, nx=scene.nx, ny=scene.ny) for det in range(N_CCD_FOCAL_PLANE)]
+    cat = _FocalPlaneCatalog({k: np.concatenate([p[k] for p in parts]) for k in parts[0]})
+    cat["obj_id"] = np.concatenate([p["obj_id"] for p in parts])           # ids restart per CCD, like object numbers per file
+    cat.ccd_offsets = np.arange(N_CCD_FOCAL_PLANE + 1) * per
+    return cat
+
+
+def _c5_objects(cat, phot, scene):
+    """LSST_SiliconBuilder.setup for every CCD of the visit (one vectorised pass; the CCDs share the analytic WCS of the
+    bench scene, their catalogs, seeds and photon streams differ)."""
+    objects, sizes = c3_objects(cat, phot, scene)
+    kept = np.concatenate([[0], np.cumsum(phot > 0)])
+    t = objects.view(_CcdTable)
+    t.ccd_offsets = kept[cat.ccd_offsets]
+    return t, sizes
+
+
+def _c5_step(renderer, objects, rank=0, world=1, concurrent=3):
+    """One step = every CCD this rank owns (CCD i -> rank i mod world, no exchange), each through a FRESH renderer: scene
+    tables, the CCD's static pixel-boundary state, launch plan, ONE arena upload, the run, and the float32 image back on the
+    host -- what `focal_plane.render_focal_plane` does per CCD.  Up to `concurrent` CCDs are in flight on their own streams."""
+    import copy
+    from . import focal_plane
+    from .config import ccd_seed
+    offs = getattr(objects, "ccd_offsets", None)
+    if offs is None:                       # a sample of one CCD (bench.py's parity leg): the CCD of the given renderer
+        return renderer.prepared_lsst_image(objects)
+    base = renderer.scene
+    tables = {det: np.asarray(objects[offs[det]:offs[det + 1]]) for det in range(len(offs) - 1)}
+    mine = parallel.shard_ccds(list(tables), rank, world)
+    nrecalc = 10000
+
+    def build(det):
+        sc = copy.copy(base)
+        sc.seed = base.seed if det == 0 else ccd_seed(base.seed, det)
+        return sc, tables[det]
+
+    def sink(det, image):
+        # stands for the FITS writer: the image is on the host; a coarse checksum proves it arrived
+        launch.checksums[det] = float(image[::64, ::64].sum())
+
+    def launch():
+        launch.checksums = {}
+        focal_plane.render_focal_plane(list(tables), build, device=str(renderer.device), rank=rank, world=world,
+                                       concurrent=concurrent, nrecalc=nrecalc, sink=sink)
+    n_phot = np.concatenate([tables[d]["n_phot"] for d in mine]) if mine else np.zeros(0, dtype=np.int64)
+    ordinary = n_phot[n_phot <= nrecalc]
+    launch.photons = int(n_phot.sum())
+    launch.object_rows = len(n_phot)
+    # the fused launch of the ordinary objects (one per CCD): f64 image RMW 16 B per photon + one 256-B row per object
+    launch.timed = {1: (len(mine), int(ordinary.sum()) * 16 + len(ordinary) * 256), 2: (0, 0)}
+    launch.n_ccds = len(mine)
+    return launch
+
+
+BENCH_CONFIGS["c5"] = dict(
+    n_objects=N_CCD_FOCAL_PLANE * 10000,
+    workload="C5: 189-CCD focal plane, 10k-source synthetic catalog per CCD (own catalog, seed and photon streams), every CCD "
+             "an independent LSST_Image build (C3 physics: full photon-op chain, Silicon brighter-fatter + tree rings) through a "
+             "fresh renderer on its own stream, CCD i -> GPU i mod N, image back on the host; host object tables are inputs",
+    scene=_c5_scene_bench,
+    catalog=_c5_catalog,
+    objects=_c5_objects,
+    make_step=_c5_step,
+    reduce=False,                         # CCDs are independent: no exchange between the ranks
+    timed_kernel=1,
+    kernel="k_shoot_accumulate",
+    cpu_sample=10000,
+    cpu_scene=_c3_cpu_scene,
+    cpu_step=lambda orc, sample: orc.render_lsst_image(sample),
+    cpu_allcore=False,
+    metric="objects/sec over a 189-CCD focal plane (photon-shooting path, one CCD per stream)",
+    sharding="CCD i -> rank i mod N, no exchange",
+)

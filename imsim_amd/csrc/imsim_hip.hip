@@ -306,27 +306,22 @@ __global__ __launch_bounds__(256) void k_accumulate(const ims_render_params_t P,
 
 // sensor.accumulate for one ROUND of the bright objects: segment-mapped like the fused kernel, but
 // the photon (already through the op chain) is loaded from the pool at pool_start[object] + j.
-__global__ __launch_bounds__(256) void k_accumulate_segments(const ims_render_params_t P, const ims_photons_t pool,
-                                                             const int64_t* __restrict__ pool_start)
+// One workgroup = the photons [j0, j0 + 256) of object `oi` (clipped to j_end).
+__device__ __forceinline__ void accumulate_segment(const ims_render_params_t& P, const ims_photons_t& pool,
+                                                   const int64_t* __restrict__ pool_start, int64_t oi, int64_t j0, int64_t j_end)
 {
-    const int64_t per = (P.n_segments + N_XCD - 1) / N_XCD;
-    const int64_t b = blockIdx.x;
-    if ((b / N_XCD) >= per) return;
-    const int64_t seg = xcd_segment(b, P.n_segments);
-    if (seg >= P.n_segments) return;
-    const int64_t oi = P.seg_object ? (int64_t)P.seg_object[seg] : find_object(P.seg_prefix, P.n_objects, seg);
     const ims_object_t& o = P.objects[oi];
-    const int64_t j = (seg - P.seg_prefix[oi]) * P.seg_size + threadIdx.x;
-    const int64_t left = o.n_phot - (seg - P.seg_prefix[oi]) * P.seg_size;      // photons of this segment (>= 1)
+    const int64_t left = j_end - j0;                                            // photons of this segment (>= 1)
     const int n_thr = left >= 256 ? 256 : ((((int)left + 63) >> 6) << 6);
     if ((int)threadIdx.x >= n_thr) return;                                      // photon-less wavefronts leave at once
+    const int64_t j = j0 + threadIdx.x;
     const bool silicon = (P.sensor != nullptr) && (P.sensor->kind == IMS_SENSOR_SILICON);
     const bool has_angles = chain_has_angles(P);
     __shared__ float tile[CT * CT];
     ChargeTile ct;
     tile_begin(tile, ct, P, o, silicon, n_thr);
     double added = 0.0;
-    if (j < o.n_phot) {
+    if (j < j_end) {
         const int64_t i = pool_start[oi] + j;
         Photon ph;
         ph.x = pool.x[i]; ph.y = pool.y[i]; ph.flux = pool.flux[i]; ph.dxdz = pool.dxdz[i]; ph.dydz = pool.dydz[i];
@@ -344,6 +339,34 @@ __global__ __launch_bounds__(256) void k_accumulate_segments(const ims_render_pa
         const double tot = wave_sum(added);
         if ((threadIdx.x & 63) == 0 && tot != 0.0) unsafeAtomicAdd(P.realized_flux + oi, tot);
     }
+}
+
+__global__ __launch_bounds__(256) void k_accumulate_segments(const ims_render_params_t P, const ims_photons_t pool,
+                                                             const int64_t* __restrict__ pool_start)
+{
+    const int64_t per = (P.n_segments + N_XCD - 1) / N_XCD;
+    const int64_t b = blockIdx.x;
+    if ((b / N_XCD) >= per) return;
+    const int64_t seg = xcd_segment(b, P.n_segments);
+    if (seg >= P.n_segments) return;
+    const int64_t oi = P.seg_object ? (int64_t)P.seg_object[seg] : find_object(P.seg_prefix, P.n_objects, seg);
+    accumulate_segment(P, pool, pool_start, oi, (seg - P.seg_prefix[oi]) * P.seg_size, P.objects[oi].n_phot);
+}
+
+// The same for round `round` of a chain class whose table holds the objects' FULL photon counts: the round covers the
+// photons [round * nrecalc, (round + 1) * nrecalc) of every object, `segs` = ceil(nrecalc / 256) workgroups per object;
+// the first n_active rows (sorted by photon count, brightest first) are the objects that reach this round.
+__global__ __launch_bounds__(256) void k_accumulate_round(const ims_render_params_t P, const ims_photons_t pool,
+                                                          const int64_t* __restrict__ pool_start, int64_t round_first, int32_t nrecalc,
+                                                          int32_t segs)
+{
+    const int64_t oi = blockIdx.x / segs;
+    const int64_t j0 = round_first + (int64_t)(blockIdx.x % segs) * 256;
+    int64_t j_end = round_first + nrecalc;
+    const int64_t n = P.objects[oi].n_phot;
+    if (j_end > n) j_end = n;
+    if (j0 >= j_end) return;
+    accumulate_segment(P, pool, pool_start, oi, j0, j_end);
 }
 
 // ---------------- Silicon boundary state ----------------
@@ -1582,6 +1605,23 @@ int ims_accumulate_segments(const ims_render_params_t* params, const ims_photons
     return IMS_OK;
 }
 
+int ims_accumulate_round(const ims_render_params_t* params, const ims_photons_t* pool, const int64_t* pool_start,
+                         int32_t round, int32_t nrecalc, int32_t n_active, void* stream)
+{
+    if (!params) return set_err(IMS_ERR_ARG, "params is NULL");
+    if (!params->objects || !params->image) return set_err(IMS_ERR_ARG, "objects/image is NULL");
+    if (!pool || !pool_start) return set_err(IMS_ERR_ARG, "pool/pool_start is NULL");
+    if (round < 0 || nrecalc <= 0) return set_err(IMS_ERR_ARG, "round must be >= 0 and nrecalc positive");
+    if (n_active < 0 || n_active > params->n_objects) return set_err(IMS_ERR_ARG, "n_active out of range");
+    if (n_active == 0) return IMS_OK;
+    const int32_t segs = (nrecalc + 255) / 256;
+    if ((int64_t)n_active * segs > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "too many workgroups for one round");
+    hipLaunchKernelGGL(k_accumulate_round, dim3((unsigned)(n_active * segs)), dim3(256), 0, (hipStream_t)stream, *params, *pool,
+                       pool_start, (int64_t)round * nrecalc, nrecalc, segs);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
 static unsigned grid_for_pool(int64_t n)
 {
     int64_t blocks = (n + 255) / 256;
@@ -1722,6 +1762,79 @@ int ims_bf_chain_status(const void* ctl_dev, int32_t* error)
     return IMS_OK;
 }
 
+// library events of RECORD / WAIT items (one process per GPU)
+static int plan_event(int number, hipEvent_t* out)
+{
+    static std::vector<hipEvent_t> evs;
+    if (number < 0 || number > 65535) return set_err(IMS_ERR_ARG, "plan event number out of range");
+    while ((int)evs.size() <= number) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        evs.push_back(e);
+    }
+    *out = evs[number];
+    return IMS_OK;
+}
+
+// objects of a table sorted by photon count (descending) that have more than `threshold` photons
+static int32_t count_above(const int64_t* n_phot, int32_t n, int64_t threshold)
+{
+    int32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) / 2;
+        if (n_phot[mid] > threshold) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// IMS_PLAN_ROUNDS: the rounds of several chain classes, enqueued round by round so that every chain advances at the same pace
+static int run_rounds(const ims_chain_t* chains, int32_t n_chains, const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host,
+                      unsigned char* changed_dev, void* const* streams, int32_t n_streams)
+{
+    if (!chains || n_chains < 0 || n_chains > IMS_MAX_CHAINS) return set_err(IMS_ERR_ARG, "chains is NULL or too many chains");
+    int32_t max_rounds = 0;
+    for (int32_t c = 0; c < n_chains; ++c) {
+        const ims_chain_t& ch = chains[c];
+        if (!ch.params || !ch.pool || !ch.pool_start || !ch.n_phot || !ch.tile_prefix || !ch.tile_prefix_host)
+            return set_err(IMS_ERR_ARG, "chain: NULL pointer");
+        if (ch.stream < 0 || ch.stream >= n_streams) return set_err(IMS_ERR_ARG, "chain stream index out of range");
+        if (ch.nrecalc <= 0 || ch.n_rounds < 0 || ch.n_objects < 0 || ch.n_objects > ch.params->n_objects)
+            return set_err(IMS_ERR_ARG, "chain: nrecalc / n_rounds / n_objects out of range");
+        if (ch.n_edges < 0 || ch.n_edges > IMS_MAX_CHAIN_EDGES) return set_err(IMS_ERR_ARG, "chain: too many edges");
+        for (int32_t k = 1; k < ch.n_objects; ++k)
+            if (ch.n_phot[k] > ch.n_phot[k - 1]) return set_err(IMS_ERR_ARG, "chain: objects must be sorted by photon count, brightest first");
+        if (ch.n_rounds > max_rounds) max_rounds = ch.n_rounds;
+    }
+    for (int32_t r = 0; r < max_rounds; ++r) {
+        for (int32_t c = 0; c < n_chains; ++c) {
+            const ims_chain_t& ch = chains[c];
+            if (r >= ch.n_rounds) continue;
+            void* st = streams[ch.stream];
+            for (int32_t j = 1; j < ch.n_edges; ++j)
+                if (ch.edges[j] == r) {
+                    hipEvent_t e;
+                    const int rc = plan_event(ch.ev_base + j, &e);
+                    if (rc) return rc;
+                    HIP_TRY(hipStreamWaitEvent((hipStream_t)st, e, 0));
+                }
+            const int32_t n_act = count_above(ch.n_phot, ch.n_objects, (int64_t)r * ch.nrecalc);
+            if (n_act == 0) continue;
+            ims_render_params_t P = *ch.params;
+            const uint32_t tag = ch.use_tags ? (uint32_t)(r % 255 + 1) : 0u;      // marks the tiles this round's charge lands in
+            P.bf_tag = tag;
+            int rc = ims_accumulate_round(&P, ch.pool, ch.pool_start, r, ch.nrecalc, n_act, st);
+            if (rc) return rc;
+            const int32_t n_cont = count_above(ch.n_phot, ch.n_objects, (int64_t)(r + 1) * ch.nrecalc);
+            if (n_cont > 0) {
+                rc = ims_sensor_update_distortions(sensor_dev, sensor_host, ch.first_slot, n_cont, ch.tile_prefix,
+                                                   ch.tile_prefix_host[n_cont], changed_dev, tag, st);
+                if (rc) return rc;
+            }
+        }
+    }
+    return IMS_OK;
+}
+
 int ims_run_plan(const ims_plan_item_t* items, int64_t n_items, const ims_sensor_t* sensor_dev,
                  const ims_sensor_t* sensor_host, unsigned char* changed_dev, void* const* streams, int32_t n_streams)
 {
@@ -1742,17 +1855,15 @@ int ims_run_plan(const ims_plan_item_t* items, int64_t n_items, const ims_sensor
         case IMS_PLAN_INIT:       rc = ims_sensor_init_boundaries(sensor_dev, sensor_host, it.first_slot, it.n_slots, st); break;
         case IMS_PLAN_CHAIN:      rc = ims_bf_chain(it.params, it.pool, it.aux, it.first_slot, it.n_slots, (int32_t)it.n_tiles, sensor_host,
                                                     changed_dev, it.aux2, (int32_t)it.tag, (int32_t)it.pad, st); break;
+        case IMS_PLAN_ROUNDS:     rc = run_rounds((const ims_chain_t*)it.aux2, it.n_slots, sensor_dev, sensor_host, changed_dev, streams,
+                                                  n_streams); break;
         case IMS_PLAN_RECORD:
         case IMS_PLAN_WAIT: {
-            static std::vector<hipEvent_t> evs;          // library events of RECORD / WAIT items (one process per GPU)
-            if (it.n_slots < 0 || it.n_slots > 65535) return set_err(IMS_ERR_ARG, "plan event number out of range");
-            while ((int)evs.size() <= it.n_slots) {
-                hipEvent_t e;
-                HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                evs.push_back(e);
-            }
-            if (it.kind == IMS_PLAN_RECORD) HIP_TRY(hipEventRecord(evs[it.n_slots], (hipStream_t)st));
-            else HIP_TRY(hipStreamWaitEvent((hipStream_t)st, evs[it.n_slots], 0));
+            hipEvent_t e;
+            rc = plan_event(it.n_slots, &e);
+            if (rc) return rc;
+            if (it.kind == IMS_PLAN_RECORD) HIP_TRY(hipEventRecord(e, (hipStream_t)st));
+            else HIP_TRY(hipStreamWaitEvent((hipStream_t)st, e, 0));
             break; }
         default: return set_err(IMS_ERR_ARG, "unknown plan item kind");
         }

@@ -130,7 +130,15 @@ class HostMem:
 
 
 class DeviceMem:
-    """Pointer provider over torch device tensors."""
+    """Pointer provider over torch device tensors.
+
+    Small tables (scene tables, descriptors, the slot table, launch-plan arenas) live in ONE device arena per provider and
+    are copied through a page-locked mirror of it: the copy is queued on the current stream and the host never waits for
+    the GPU (a pageable source makes every hipMemcpy a synchronisation point -- 16 of them per CCD of a focal plane).
+    Mirrors are recycled through a process-wide pool (allocating page-locked memory costs milliseconds)."""
+    ARENA_BYTES = 16 << 20
+    _MIRRORS = []                    # (page-locked tensor, event after the last copy that reads it)
+
     def __init__(self, device):
         import torch
         if not torch.cuda.is_available():
@@ -138,11 +146,47 @@ class DeviceMem:
         self.torch = torch
         self.device = torch.device(device)
         self.keep = []
+        self._dev = torch.empty(self.ARENA_BYTES, dtype=torch.uint8, device=self.device)
+        self._pin = None
+        for k, (t, ev) in enumerate(DeviceMem._MIRRORS):
+            if ev.query():
+                self._pin = DeviceMem._MIRRORS.pop(k)[0]
+                break
+        if self._pin is None:
+            self._pin = torch.empty(self.ARENA_BYTES, dtype=torch.uint8, pin_memory=True)
+        self._pin_np = self._pin.numpy()
+        self._used = 0
+
+    def __del__(self):
+        try:
+            if self._pin is not None:
+                ev = self.torch.cuda.Event()
+                ev.record(self.torch.cuda.current_stream(self.device))
+                DeviceMem._MIRRORS.append((self._pin, ev))
+                self._pin = None
+        except Exception:
+            pass
+
+    def _stage(self, raw):
+        """raw bytes -> a page-locked copy (view of the mirror), or None when the mirror is full"""
+        n = int(raw.size)
+        off = (self._used + 255) & ~255
+        if self._pin is None or off + n > self.ARENA_BYTES:
+            return None, off
+        self._pin_np[off:off + n] = raw
+        self._used = off + n
+        return self._pin[off:off + n], off
 
     def put(self, arr, dtype=None):
         a = np.ascontiguousarray(arr, dtype=dtype)
-        t = self.torch.from_numpy(a.view(np.uint8).reshape(-1)).to(self.device)
-        self.keep.append(t)
+        raw = a.view(np.uint8).reshape(-1)
+        src, off = self._stage(raw)
+        if src is None:
+            t = self.torch.from_numpy(raw).to(self.device)
+            self.keep.append(t)
+            return t, t.data_ptr()
+        t = self._dev[off:off + raw.size]
+        t.copy_(src, non_blocking=True)
         return t, t.data_ptr()
 
     def put_struct(self, st):
@@ -156,7 +200,12 @@ class DeviceMem:
         return t, t.data_ptr()
 
     def write(self, handle, raw):
-        handle[:raw.size].copy_(self.torch.from_numpy(raw))
+        """Stream-ordered update of a device table (queued on the current stream)."""
+        src, _ = self._stage(raw)
+        if src is None:
+            handle[:raw.size].copy_(self.torch.from_numpy(raw))
+        else:
+            handle[:raw.size].copy_(src, non_blocking=True)
 
 
 def segment_prefix(n_phot, seg_size):
@@ -239,12 +288,11 @@ class _Arena:
     def ref(self, arr):
         return _Arena.Ref(self, self.add(arr))
 
-    def upload(self, torch, device):
+    def upload(self, mem):
         buf = np.zeros(max(self.size, 8), dtype=np.uint8)
         for off, a in self.parts:
             buf[off:off + a.size] = a
-        self.tensor = torch.from_numpy(buf).to(device)
-        self.base = self.tensor.data_ptr()
+        self.tensor, self.base = mem.put(buf)
         for struct, field, off in self.patches:
             setattr(struct, field, self.base + off)
         self.parts = []
@@ -500,7 +548,7 @@ class Renderer:
         objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
         obj_t = self.torch.from_numpy(objects.view(np.uint8).reshape(-1)).to(self.device)
         prefix = segment_prefix(objects["n_phot"], self.scene.seg_size)
-        pre_t = self.torch.from_numpy(prefix).to(self.device)
+        pre_t = self.mem.put(prefix)[0]
         # segment -> object map (saves every workgroup a binary search in the prefix)
         seg_obj = np.repeat(np.arange(len(objects), dtype=np.int32), np.diff(prefix))
         pre_t.seg_object = self.torch.from_numpy(seg_obj).to(self.device) if len(seg_obj) else None
@@ -537,7 +585,7 @@ class Renderer:
 
         def finish():
             """ONE upload for every table of the plan (f-1: was ~1 000 separate copies), then the addresses"""
-            t = arena.upload(self.torch, self.device)
+            t = arena.upload(self.mem)
             for off, n, tmp in realized_refs:
                 realized_parts.append((t[off:off + 8 * n].view(self.torch.int64), tmp))
             return plan, realized_parts
@@ -576,7 +624,7 @@ class Renderer:
         for idx, slots in groups:
             plan.append(("slots", slots))
             n0 = b.n_static_slots
-            grp = objects[idx].copy()                     # sorted by n_phot, brightest first
+            grp = objects[idx]                            # (a fancy-indexed copy) sorted by n_phot, brightest first
             grp["bf_state"] = n0 + np.arange(len(grp))
             total = grp["n_phot"].copy()
             offs = np.concatenate([[0], np.cumsum(total)]).astype(np.int64)
@@ -632,11 +680,26 @@ class Renderer:
             # ~1 300 short launches of the rounds: the host needs ~20 us per launch to enqueue those, and an item at
             # the end of the plan would leave the bulk stream idle until the host gets there.
             if len(normal) and not render_done:
-                part = objects[normal].copy()
+                part = objects[normal]                    # fancy indexing copies
                 part["bf_state"] = 0
                 add_render(part, normal, "bulk")
                 render_done = True
-            # 2. the sequential part: rounds of nrecalc photons per object through the sensor.  Per class a list of
+            # 2. the sequential part: rounds of nrecalc photons per object through the sensor (accumulate, then
+            #    updatePixelDistortions for the objects that go on).  ONE plan item carries the chains of all classes:
+            #    ims_run_plan derives every round's launches from the class table (objects sorted by photon count, so
+            #    the objects of a round are a prefix of it) and enqueues the classes round-robin, one round each, so
+            #    that all chains advance at the same pace.  No per-round tables, no per-round Python.
+            if not self.use_chain:
+                descs = []
+                for ch in chains:
+                    start_t = arena.ref(ch["offs"])
+                    P, keep = upload(ch["grp"], ch["idx"], "acc_pool")
+                    descs.append(dict(P=P, keep=(keep, start_t), pool=pool, start=start_t,
+                                      n_phot=np.ascontiguousarray(ch["tot"], dtype=np.int64), first_slot=n0 + ch["ca"],
+                                      stream=ch["stream"], rounds=ch["rounds"], edges=ch["edges"], ev_base=ch["ev_base"]))
+                plan.append(("rounds", descs, int(nrecalc), 1 if self.use_bf_tags else 0))
+                continue
+            # legacy form (kept for the persistent-chain experiment, IMS_BF_CHAIN=1): per class a list of
             #    units (one round = accumulate + update, or one persistent launch over a slice of rounds); the classes'
             #    units are merged round-robin so that the host enqueues all chains at the same pace.
             chain_ok = self._chain_ok(grp)
@@ -681,7 +744,7 @@ class Renderer:
                     if k < len(u):
                         plan.extend(u[k])
         if len(normal) and not render_done:
-            part = objects[normal].copy()
+            part = objects[normal]
             part["bf_state"] = 0
             add_render(part, normal, "bulk")
         return finish()
@@ -727,6 +790,19 @@ class Renderer:
                 stretches.append(("run", arr, len(cur)))
                 cur.clear()
 
+        def tile_prefix_from(first):
+            """prefix sum of the 16 x 16-cell tiles of the slots first, first + 1, ... (host array, device tensor)"""
+            if cur_prefix is None:
+                return self._tile_prefix(first)
+            sl, cache = cur_prefix
+            if first not in cache:
+                part = sl[first - b.n_static_slots:]
+                tiles = ((part["nx"].astype(np.int64) + 1 + 15) // 16) * ((part["ny"].astype(np.int64) + 1 + 15) // 16)
+                prefix = np.concatenate([[0], np.cumsum(tiles)]).astype(np.int64)
+                cache[first] = (prefix, self.mem.put(prefix)[0])
+                keep.append(cache[first])
+            return cache[first]
+
         for item in plan:
             kind = item[0]
             it = _abi.PlanItem()
@@ -743,6 +819,24 @@ class Renderer:
                 it.stream = self.STREAMS[item[7]]
                 it.first_slot, it.n_slots, it.n_tiles, it.tag, it.pad = item[8], item[9], item[10], item[11], item[12]
                 it.aux2 = self._chain_ctl_ptr(item[7])
+            elif kind == "rounds":
+                descs, nrecalc, use_tags = item[1], item[2], item[3]
+                arr = (_abi.Chain * len(descs))()
+                for c, d in zip(arr, descs):
+                    prefix, prefix_t = tile_prefix_from(d["first_slot"])
+                    c.params, c.pool, c.pool_start = C.addressof(d["P"]), C.addressof(d["pool"]), d["start"].data_ptr()
+                    c.n_phot, c.tile_prefix, c.tile_prefix_host = d["n_phot"].ctypes.data, prefix_t.data_ptr(), prefix.ctypes.data
+                    c.n_objects, c.first_slot, c.stream, c.nrecalc = len(d["n_phot"]), d["first_slot"], self.STREAMS[d["stream"]], nrecalc
+                    c.n_rounds, c.use_tags, c.ev_base = d["rounds"], use_tags, d["ev_base"]
+                    edges = d["edges"][:-1]                      # slice starts; the last edge is the round count
+                    if len(edges) > _abi.IMS_MAX_CHAIN_EDGES:
+                        raise ValueError("too many pool slices for one chain")
+                    c.n_edges = len(edges)
+                    for k, e in enumerate(edges):
+                        c.edges[k] = e
+                    keep.append((prefix, prefix_t))
+                keep.append(arr)
+                it.kind, it.stream, it.n_slots, it.aux2 = _abi.IMS_PLAN_ROUNDS, 0, len(descs), C.addressof(arr)
             elif kind == "record":
                 it.kind, it.n_slots, it.stream = _abi.IMS_PLAN_RECORD, item[1], self.STREAMS[item[2]]
             elif kind == "wait":
@@ -758,17 +852,7 @@ class Renderer:
                 it.stream = self.STREAMS[item[3]]
             elif kind == "update":
                 first, n = item[1], item[2]
-                if cur_prefix is not None:
-                    sl, cache = cur_prefix
-                    if first not in cache:
-                        part = sl[first - b.n_static_slots:]
-                        tiles = ((part["nx"].astype(np.int64) + 1 + 15) // 16) * ((part["ny"].astype(np.int64) + 1 + 15) // 16)
-                        prefix = np.concatenate([[0], np.cumsum(tiles)]).astype(np.int64)
-                        cache[first] = (prefix, self.torch.from_numpy(prefix).to(self.device))
-                        keep.append(cache[first][1])
-                    prefix, prefix_t = cache[first]
-                else:
-                    prefix, prefix_t = self._tile_prefix(first)
+                prefix, prefix_t = tile_prefix_from(first)
                 it.kind, it.first_slot, it.n_slots = _abi.IMS_PLAN_UPDATE, first, n
                 it.stream = self.STREAMS[item[3]]
                 it.tag = item[4] if len(item) > 4 else 0
@@ -798,11 +882,20 @@ class Renderer:
         sarr = (C.c_void_p * len(streams))(*[st.cuda_stream for st in streams])
         for kind, payload, n in stretches:
             if kind == "slots":
-                # the slot table is host-written: order it after everything queued so far
+                # the slot table is written by a copy on the chain stream: ordered behind everything queued so far on
+                # every stream and ahead of everything that follows, on the GPU (no host synchronisation)
                 for st in streams:
-                    st.synchronize()
+                    if st is not self.s_chain:
+                        ev = torch.cuda.Event()
+                        ev.record(st)
+                        self.s_chain.wait_event(ev)
                 with torch.cuda.stream(self.s_chain):
                     b.set_private_slots(payload)
+                    ev = torch.cuda.Event()
+                    ev.record(self.s_chain)
+                for st in streams:
+                    if st is not self.s_chain:
+                        st.wait_event(ev)
                 continue
             _abi.check(self.lib.ims_run_plan(payload, n, sensor_dev, sensor_host, changed, sarr, len(streams)), "ims_run_plan")
         for st in streams:
@@ -926,7 +1019,7 @@ class Renderer:
         if first_slot not in cache[1]:
             tiles = ((sl["nx"].astype(np.int64) + 1 + 15) // 16) * ((sl["ny"].astype(np.int64) + 1 + 15) // 16)
             prefix = np.concatenate([[0], np.cumsum(tiles)]).astype(np.int64)
-            cache[1][first_slot] = (prefix, self.torch.from_numpy(prefix).to(self.device))
+            cache[1][first_slot] = (prefix, self.mem.put(prefix)[0])
         return cache[1][first_slot]
 
     def delta_tensor(self, slot=0):

@@ -12,24 +12,32 @@ from . import parallel
 from .engine import Renderer
 
 
-def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent=2, nrecalc=None):
+def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent=3, nrecalc=None, sink=None):
     """ccds: sequence of CCD keys (detector numbers / names); build(key) -> (scene, objects) prepares one CCD
-    on the host.  Returns {key: float32 image as a host array} for the CCDs this rank owns."""
+    on the host.  Returns {key: float32 image as a host array} for the CCDs this rank owns.
+
+    The finished image of a CCD is copied into a page-locked host buffer on the CCD's own stream (one buffer per
+    stream in flight, reused).  sink(key, image): optional consumer (the FITS writer in production) that is handed
+    a VIEW of that buffer, valid until it returns; with a sink nothing is accumulated and {} is returned."""
     import torch
     dev = torch.device(device)
     mine = parallel.shard_ccds(list(ccds), rank, world)
     if concurrent < 1:
         raise ValueError("concurrent must be >= 1")
     streams = [torch.cuda.Stream(dev) for _ in range(min(concurrent, max(len(mine), 1)))]
-    in_flight = [None] * len(streams)          # (key, renderer, device image, done event) per stream
+    in_flight = [None] * len(streams)          # (key, renderer, host image, done event) per stream
+    pinned = [None] * len(streams)
     out = {}
 
     def collect(slot):
         if in_flight[slot] is None:
             return
-        key, renderer, img, done = in_flight[slot]
+        key, renderer, host, done = in_flight[slot]
         done.synchronize()
-        out[key] = img.cpu().numpy()
+        if sink is not None:
+            sink(key, host.numpy())
+        else:
+            out[key] = host.numpy().copy()
         in_flight[slot] = None                 # drops the renderer: its HBM goes back to the caching allocator
 
     for k, key in enumerate(mine):
@@ -40,9 +48,12 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
             renderer = Renderer(scene, dev)
             renderer.render_lsst_image(objects, nrecalc=nrecalc)
             img = renderer.image_float()
+            if pinned[slot] is None or pinned[slot].shape != img.shape:
+                pinned[slot] = torch.empty(img.shape, dtype=img.dtype, pin_memory=True)
+            pinned[slot].copy_(img, non_blocking=True)
             done = torch.cuda.Event()
             done.record(streams[slot])
-        in_flight[slot] = (key, renderer, img, done)
+        in_flight[slot] = (key, renderer, pinned[slot], done)
     for slot in range(len(streams)):
         collect(slot)
     return out

@@ -490,6 +490,28 @@ int  ims_fft_finish(const ims_fft_params_t* params, const ims_fft_object_t* obje
 #define IMS_PLAN_WAIT       7   /* make the item's stream wait for library event number n_slots */
 #define IMS_PLAN_CHAIN      8   /* ims_bf_chain(params, pool, aux = pool_start, rounds [first_slot, n_slots), nrecalc = n_tiles,
                                    ctl = aux2, n_workers = tag, team_size = pad) */
+#define IMS_PLAN_ROUNDS     9   /* the per-round launches of up to IMS_MAX_CHAINS brighter-fatter chains, interleaved round by round:
+                                   aux2 = HOST array of ims_chain_t, n_slots = its length */
+#define IMS_MAX_CHAINS      4
+#define IMS_MAX_CHAIN_EDGES 8
+/* One chain class of LSST_Image mode (Renderer.plan_lsst_image): objects whose photons are already in the pool and whose
+ * private pixel-boundary regions are the slots first_slot, first_slot + 1, ... in table order.  Round r lands the photons
+ * [r nrecalc, (r + 1) nrecalc) of every object that has them (ims_accumulate_round), then re-superposes the distortions of the
+ * regions of the objects that go on to round r + 1 (ims_sensor_update_distortions).  The table is sorted by photon count,
+ * brightest first, so the objects of a round are a prefix of it.  Rounds edges[j] (j >= 1) first make the chain's stream wait
+ * for library event ev_base + j: the pool slice holding their photons (IMS_PLAN_RECORD of the producer). */
+typedef struct ims_chain {
+    const ims_render_params_t* params;   /* host pointer; objects = the class table with the FULL photon counts */
+    const ims_photons_t* pool;           /* host pointer */
+    const int64_t* pool_start;           /* device: pool index of photon 0 of every object */
+    const int64_t* n_phot;               /* HOST: photon count of every object (descending) */
+    const int64_t* tile_prefix;          /* device: prefix sum of the 16x16-cell tiles of the slots first_slot.. (as IMS_PLAN_UPDATE aux) */
+    const int64_t* tile_prefix_host;     /* HOST copy of tile_prefix */
+    int32_t n_objects, first_slot, stream, nrecalc;
+    int32_t n_rounds, use_tags, ev_base, n_edges;
+    int32_t edges[IMS_MAX_CHAIN_EDGES];
+} ims_chain_t;
+
 typedef struct ims_plan_item {
     int32_t kind;
     int32_t stream;
@@ -502,6 +524,11 @@ typedef struct ims_plan_item {
     uint32_t pad;
     void*    aux2;                       /* device pointer, see kinds */
 } ims_plan_item_t;
+/* One round of a chain class (see ims_chain_t): sensor.accumulate of the photons [round nrecalc, (round + 1) nrecalc) of the first
+ * n_active objects of params->objects, photon j of object o read from the pool at pool_start[o] + j.  params->seg_prefix /
+ * seg_object / n_segments are not used: every object gets ceil(nrecalc / 256) workgroups. */
+int  ims_accumulate_round(const ims_render_params_t* params, const ims_photons_t* pool, const int64_t* pool_start,
+                          int32_t round, int32_t nrecalc, int32_t n_active, void* stream);
 int  ims_run_plan(const ims_plan_item_t* items, int64_t n_items, const ims_sensor_t* sensor_dev,
                   const ims_sensor_t* sensor_host, unsigned char* changed_dev, void* const* streams, int32_t n_streams);
 

@@ -20,4 +20,4 @@ compiled = r._compile_plan(plan)
 torch.cuda.synchronize()
 pr.disable()
 print("plan ms", 1e3 * (time.perf_counter() - t0), "items", len(plan))
-pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(30)

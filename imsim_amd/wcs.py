@@ -51,10 +51,12 @@ def tansip_pix_to_vec(w, x, y):
     if w.order > 0:
         f = np.zeros_like(u)
         g = np.zeros_like(u)
+        up = [u ** p for p in range(w.order + 1)]          # the powers once (same values as u ** p in every term)
+        vq = [v ** q for q in range(w.order + 1)]
         for p in range(w.order + 1):
             for q in range(w.order + 1 - p):
-                f = f + w.a[p * 5 + q] * u ** p * v ** q
-                g = g + w.b[p * 5 + q] * u ** p * v ** q
+                f = f + w.a[p * 5 + q] * up[p] * vq[q]
+                g = g + w.b[p * 5 + q] * up[p] * vq[q]
         u, v = u + f, v + g
     xi = w.cd[0] * u + w.cd[1] * v
     eta = w.cd[2] * u + w.cd[3] * v

@@ -202,7 +202,7 @@ class Readout(C.Structure):
 
 
 STRUCTS = [Object, RadialTables, LinTables, PsfComponent, Op, Surface, TanSip, Optics, BfSlot, Sensor, Photons,
-           RenderParams, PlanItem, Atmosphere, FftObject, FftParams, Readout]
+           RenderParams, PlanItem, Atmosphere, FftObject, FftParams, Readout, Chain]
 
 # every symbol include/imsim_hip.h declares
 EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_info", "ims_shoot_accumulate",

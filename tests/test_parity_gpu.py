@@ -756,6 +756,12 @@ def test_focal_plane_ccds_on_streams(torch_cuda):
     for p in parts:
         for det, img in p.items():
             assert_bits_equal(img, images[det], f"CCD {det} rank split")
+    # with a sink every image is handed over as a view of the page-locked buffer of its stream and nothing is kept
+    seen = {}
+    out = focal_plane.render_focal_plane(list(specs), build, concurrent=3, sink=lambda det, img: seen.__setitem__(det, img.copy()))
+    assert out == {} and sorted(seen) == sorted(specs)
+    for det in specs:
+        assert_bits_equal(seen[det], images[det], f"CCD {det} through the sink")
 
 
 # ---------------------------------------------------------------------------------------------

@@ -58,7 +58,9 @@ class LSST_ImageBuilderBase:
         self.nbatch_per_checkpoint = params.get("nbatch_per_checkpoint", 1)
         self.nsubbatch = params.get("nsubbatch", 50)
         self.nbatch_fft = params.get("nbatch_fft", 1)
-        self.nobjects = config.get("nobjects")
+        # image.nobjects: "" (how the reference's tests switch it off, tests/test_lsst_image.py:36) or absent = every object
+        nobj = config.get("nobjects")
+        self.nobjects = None if nobj is None or (isinstance(nobj, str) and nobj.strip() == "") else int(nobj)
         return xsize, ysize
 
 

@@ -117,6 +117,7 @@ int orc_struct_size(int which)
     case 14: return (int)sizeof(ims_fft_object_t);
     case 15: return (int)sizeof(ims_fft_params_t);
     case 16: return (int)sizeof(ims_readout_t);
+    case 17: return (int)sizeof(ims_chain_t);
     }
     return -1;
 }

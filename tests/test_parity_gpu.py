@@ -1124,3 +1124,19 @@ def test_atmospheric_psf_is_chromatic_with_the_configured_exponent(torch_cuda, e
     s900 = np.sqrt(np.mean(pos[900.0][0] ** 2 + pos[900.0][1] ** 2))
     np.testing.assert_allclose(s400 / s900, (400.0 / 900.0) ** exponent, rtol=0.001)
     assert s900 > 0.5                                                         # pixels: a real seeing disc, not a delta function
+
+
+def test_image_nobjects_is_capped_by_the_catalog(torch_cuda):
+    """tests/test_lsst_image.py:10-66 (test_image_nobjects): the number of objects rendered is the minimum of
+    image.nobjects and the objects the catalog holds for the CCD -- nobjects 1 renders one, a request beyond the catalog
+    renders every object once (no repeats), and "" means all."""
+    common = {"stamp.draw_method": "phot", "image.sensor": "", "stamp.photon_ops": []}
+    everything = _process(**{"image.nobjects": "", **common}).truth[0]
+    n_all = len(everything["index"])
+    assert n_all > 5
+    one = _process(**{"image.nobjects": 1, **common}).truth[0]
+    assert len(one["index"]) == 1
+    five = _process(**{"image.nobjects": 5, **common}).truth[0]
+    assert len(five["index"]) == 5 and list(five["index"]) == list(everything["index"][:5])
+    beyond = _process(**{"image.nobjects": n_all + 1000, **common}).truth[0]
+    assert len(beyond["index"]) == n_all and len(set(beyond["index"])) == n_all

@@ -226,3 +226,24 @@ def test_vignetting_spline_and_pixel_radii():
     with pytest.raises(OSError):
         Vignetting("no_such_file.json")
     assert Vignetting("LSSTComCamSim_vignetting_data.json").apply_to_radii(0.0) == 1.0
+
+
+def test_airy_ktable_has_galsims_fwhm_and_half_light_radius():
+    """galsim.Airy, make_fft_psf's stand-in for the second kick (imsim/psf_utils.py:112-115): GalSim documents
+    fwhm = 1.028993 lam / D and half_light_radius = 0.5348321 lam / D for an unobscured aperture.  The k-table the fill
+    kernel multiplies in (autocorrelation of the pupil over baselines, `fft_draw.airy_ktable`) Hankel-transforms to a
+    profile with that FWHM and that half-light radius."""
+    from scipy import special, integrate
+    lam, diam = 700.0, 8.36
+    T, _ = fft_draw.airy_ktable(lam, diam, 0.0)
+    from imsim_amd import tables
+    b = np.linspace(0.0, 1.02 * diam, len(T))                        # baselines of the table [m]
+    k = 2.0 * np.pi * b / (lam * 1.0e-9)                             # rad^-1
+    unit = lam * 1.0e-9 / diam                                       # lam / D [rad]
+    theta = np.linspace(0.0, 3.0, 3001) * unit
+    prof = np.array([integrate.simpson(T * special.j0(k * t) * k, x=k) for t in theta])
+    half = np.interp(0.5 * prof[0], prof[:1300][::-1], theta[:1300][::-1])       # the main lobe is monotonic to 1.22 lam / D
+    assert abs(2.0 * half / unit / 1.028993 - 1.0) < 2.0e-3
+    enclosed = np.array([t * integrate.simpson(T * special.j1(k * t), x=k) for t in theta])      # F(theta) = theta int T J1(k theta) dk
+    hlr = np.interp(0.5, enclosed[:1300], theta[:1300])
+    assert abs(hlr / unit / 0.5348321 - 1.0) < 5.0e-3

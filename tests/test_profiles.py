@@ -214,3 +214,15 @@ def test_stamp_size_follows_the_sersic_index():
     sizes = catalog.gal_stamp_size(kind, hlr, np.ones(4), sersic_n=np.array([1.0, 2.0, 4.0, 6.0]))
     assert np.all(np.diff(sizes) > 0)
     assert sizes[2] == catalog.gal_stamp_size(np.array([2]), hlr[:1], np.ones(1))[0]       # n = 4 is the default of kind 2
+
+
+def test_kolmogorov_table_has_galsims_half_light_radius():
+    """galsim.Kolmogorov (the `Kolmogorov` half of imsim/atmPSF.py:534 KolmogorovPSF): GalSim documents
+    fwhm = 0.975865 lam / r0 and half_light_radius = 0.554811 lam / r0, i.e. hlr / fwhm = 0.568533.  The radial table the
+    photon kernels sample (radius in units of the FWHM, built from the MTF exp(-k^(5/3)) by quadrature) reproduces the
+    ratio to 1.1e-4, and its enclosed flux is monotonic up to the shoot accuracy."""
+    from imsim_amd import tables
+    r2, cdf = tables.kolmogorov_table()
+    hlr = float(np.sqrt(np.interp(0.5, cdf, r2)))
+    assert abs(hlr / (0.554811 / 0.975865) - 1.0) < 3.0e-4
+    assert np.all(np.diff(cdf) >= 0.0) and cdf[0] == 0.0 and abs(cdf[-1] - 1.0) <= tables.SHOOT_ACCURACY

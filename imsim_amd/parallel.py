@@ -10,25 +10,39 @@ result does not depend on the rank count."""
 import numpy as np
 
 
-def assign_ranks(n_phot, world):
-    """Longest-processing-time-first: objects sorted by photon count, each given to the currently
-    least-loaded rank.  Objects stay whole (in LSST_Image mode an object's brighter-fatter state is
-    sequential in its own photons)."""
+def assign_ranks(n_phot, world, nrecalc=10000, round_photons=3.0e5):
+    """Which rank renders which object.  Objects stay whole (in LSST_Image mode an object's brighter-fatter state is
+    sequential in its own photons), so the balance is decided by a cost model measured on one MI355X:
+
+        time of a rank ~ (longest brighter-fatter chain among its objects) + (its photons) / (photon rate)
+
+    -- a bright object is a chain of ceil(n_phot / nrecalc) dependent rounds of ~70 us, worth `round_photons` photons of
+    shooting each, and chains of different objects overlap while the photon work adds up.  Greedy, brightest first: every
+    object goes to the rank whose modelled time grows least; the light tail is dealt in blocks to the least-loaded rank.
+    The rank that owns the brightest star therefore gets little else: its chain is the floor of the strong scaling."""
     n_phot = np.asarray(n_phot, dtype=np.int64)
     owner = np.zeros(len(n_phot), dtype=np.int32)
     if world == 1:
         return owner
     order = np.argsort(-n_phot, kind="stable")
-    # the few heavy objects decide the balance: place them exactly, deal the light tail round-robin
+    rounds = np.where(n_phot > nrecalc, (n_phot + nrecalc - 1) // nrecalc, 0)
+    chain = np.zeros(world)                       # longest chain of the rank, in photon equivalents
+    bulk = np.zeros(world)                        # photons of the rank
     heavy = order[: min(len(order), 64 * world)]
-    load = np.zeros(world, dtype=np.int64)
     for i in heavy:
-        r = int(np.argmin(load))
+        c = float(rounds[i]) * round_photons
+        t_new = np.maximum(chain, c) + bulk + float(n_phot[i])
+        r = int(np.lexsort((bulk, t_new))[0])     # least resulting time, then least photons
         owner[i] = r
-        load[r] += n_phot[i]
+        chain[r] = max(chain[r], c)
+        bulk[r] += float(n_phot[i])
     tail = order[len(heavy):]
-    start = int(np.argmin(load))
-    owner[tail] = (start + np.arange(len(tail))) % world
+    block = 64
+    for a in range(0, len(tail), block):
+        ids = tail[a:a + block]
+        r = int(np.argmin(chain + bulk))
+        owner[ids] = r
+        bulk[r] += float(n_phot[ids].sum())
     return owner
 
 

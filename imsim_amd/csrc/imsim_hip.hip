@@ -576,6 +576,13 @@ __global__ __launch_bounds__(256) void k_update_distortions(const ims_sensor_t* 
 }
 
 // LDS of one q3 tile update: scaled charges of the halo, per-row occupancy bitmaps, displacement table
+#ifdef IMS_UPD_PROBE
+__device__ unsigned long long g_upd_probe[16];
+#define UPD_STAMP(k) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_upd_probe[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define UPD_STAMP(k) do { } while (0)
+#endif
+
 template <int NV>
 struct UpdateLds {
     static constexpr int Q = 3, HW = UT + 2 * Q + 1, NPO = 2 * NV + 2;
@@ -601,13 +608,14 @@ __device__ __forceinline__ void load_displacements(const ims_sensor_t& s, Update
 // Silicon::updatePixelDistortions for the 16x16 owner cells of tile (tx0, ty0) of one slot (qdist 3).
 // dl_loaded: the displacement table is already in L.dl (persistent kernels load it once).  Returns, per thread,
 // whether its cell moved; `tile_moved` is set when any cell of the tile did.
-template <int NV>
+template <int NV, bool GLOBAL_DL = false>
 __device__ __forceinline__ void update_tile_q3(const ims_sensor_t& s, const SlotView& sl, int tx0, int ty0,
                                                unsigned char* __restrict__ changed, UpdateLds<NV>& L, bool dl_loaded,
-                                               unsigned int tag)
+                                               unsigned int tag, const double* __restrict__ dl_global = nullptr)
 {
     constexpr int Q = 3, HW = UT + 2 * Q + 1, NPO = 2 * NV + 2;
     const int sx0 = tx0 - (Q + 1), sy0 = ty0 - (Q + 1);
+    UPD_STAMP(1);
     if (threadIdx.x < HW) L.occ[threadIdx.x] = 0u;
     if (threadIdx.x == 0) L.any_charge = 0;
     __syncthreads();
@@ -622,16 +630,18 @@ __device__ __forceinline__ void update_tile_q3(const ims_sensor_t& s, const Slot
         L.wt[e] = w;
     }
     __syncthreads();
+    UPD_STAMP(2);
     const int lx = threadIdx.x % UT, ly = threadIdx.x / UT;
     const int i = tx0 + lx, j = ty0 + ly;
     if (!L.any_charge) {                     // nothing landed near this tile: nothing moves
         if (i <= sl.nx && j <= sl.ny) changed[cell_index(sl, i, j)] = 0;
         return;
     }
-    if (!dl_loaded) {
+    if (!GLOBAL_DL && !dl_loaded) {
         load_displacements<NV>(s, L);
         __syncthreads();
     }
+    UPD_STAMP(3);
     if (i > sl.nx || j > sl.ny) return;
     // 64-bit window: byte a <-> dj = -Q + a (row hy = ly + 2Q + 1 - a); inside a byte bit bb <-> di = -Q + bb
     // (column hx = lx + 2Q + 1 - bb), i.e. the row bitmap reversed.
@@ -650,30 +660,44 @@ __device__ __forceinline__ void update_tile_q3(const ims_sensor_t& s, const Slot
     double acc[NPO * 2];
 #pragma unroll
     for (int n = 0; n < NPO * 2; ++n) acc[n] = pts[n];
-    while (mask) {
-        const int p = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        const int a = p >> 3, bb = p & 7;          // dj = a - Q, di = bb - Q
-        const double w = L.wt[(ly + 2 * Q + 1 - a) * HW + (lx + 2 * Q + 1 - bb)];
-        const double* d = L.dl + (a * 8 + bb) * NPO * 2;
-        const bool extra_col = (bb == 7), extra_row = (a == 7);
-        if (!extra_col) {
+    UPD_STAMP(4);
+    // The 8 x 8 source window with STATIC offsets, in the spec's order (dj ascending, then di ascending).  A bright
+    // star's region is a few hundred tiles, so a SIMD holds ONE wavefront and nothing hides latency: the bit-walking loop
+    // (address of the displacement row from the next set bit) waited ~850 cycles per neighbour.  Here every row of the
+    // window is straight-line code: the displacement rows sit at compile-time addresses (SGPRs through the scalar cache
+    // with the global table, LDS broadcasts otherwise), the scaled charge w of a neighbour without charge is exactly 0
+    // and fma(d, +0, acc) leaves acc unchanged bit for bit (acc is never -0: the initial points are +0 / positive plus a
+    // tree-ring shift, and an exact cancellation rounds to +0), so no lane needs a branch; a row of the window that no
+    // lane of the wavefront needs is skipped as a whole.
 #pragma unroll
-            for (int n = 0; n <= NV + 1; ++n) {
-                acc[2 * n] = fma(d[2 * n], w, acc[2 * n]);
-                acc[2 * n + 1] = fma(d[2 * n + 1], w, acc[2 * n + 1]);
+    for (int a = 0; a < 8; ++a) {
+        const unsigned int rowbits = (unsigned int)(mask >> (8 * a)) & 0xFFu;
+        if (__builtin_amdgcn_ballot_w64(rowbits != 0u) == 0ull) continue;
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) {
+            const double w = L.wt[(ly + 2 * Q + 1 - a) * HW + (lx + 2 * Q + 1 - bb)];
+            // GLOBAL_DL: the row comes through the scalar cache into SGPRs (uniform, read-only table of the launch)
+            const double* d = (GLOBAL_DL ? dl_global : (const double*)L.dl) + (a * 8 + bb) * NPO * 2;
+            if (bb != 7) {                     // not the extra column: bottom-row points
+#pragma unroll
+                for (int n = 0; n <= NV + 1; ++n) {
+                    acc[2 * n] = fma(d[2 * n], w, acc[2 * n]);
+                    acc[2 * n + 1] = fma(d[2 * n + 1], w, acc[2 * n + 1]);
+                }
             }
-        }
-        if (!extra_row) {
+            if (a != 7) {                      // not the extra row: left-edge points
 #pragma unroll
-            for (int n = NV + 2; n < NPO; ++n) {
-                acc[2 * n] = fma(d[2 * n], w, acc[2 * n]);
-                acc[2 * n + 1] = fma(d[2 * n + 1], w, acc[2 * n + 1]);
+                for (int n = NV + 2; n < NPO; ++n) {
+                    acc[2 * n] = fma(d[2 * n], w, acc[2 * n]);
+                    acc[2 * n + 1] = fma(d[2 * n + 1], w, acc[2 * n + 1]);
+                }
             }
         }
     }
+    UPD_STAMP(5);
 #pragma unroll
     for (int n = 0; n < NPO * 2; ++n) pts[n] = acc[n];
+    UPD_STAMP(6);
 }
 
 // Fast path for qdist == 3 (the GalSim default): the 8x8 source window of a cell is a 64-bit
@@ -685,9 +709,11 @@ __device__ __forceinline__ void update_tile_q3(const ims_sensor_t& s, const Slot
 template <int NV>
 __global__ __launch_bounds__(256) void k_update_distortions_q3(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
                                                                const int64_t* __restrict__ tile_prefix,
-                                                               unsigned char* __restrict__ changed, unsigned int tag)
+                                                               unsigned char* __restrict__ changed, unsigned int tag,
+                                                               const double* __restrict__ dl_global)
 {
     __shared__ UpdateLds<NV> L;
+    UPD_STAMP(0);
     const ims_sensor_t& s = *sp;
     const int64_t b = blockIdx.x;
     int lo = 0, hi = n_slots;
@@ -701,7 +727,11 @@ __global__ __launch_bounds__(256) void k_update_distortions_q3(const ims_sensor_
     const int t = (int)(b - tile_prefix[lo]);
     const int tx0 = (t % tiles_x) * UT, ty0 = (t / tiles_x) * UT;
     if (tile_out_of_reach(s, sl, tx0 / UT, ty0 / UT, tag)) return;
-    update_tile_q3<NV>(s, sl, tx0, ty0, changed, L, false, tag);
+#ifdef IMS_UPD_FORCE_LDS
+    dl_global = nullptr;
+#endif
+    if (dl_global != nullptr) update_tile_q3<NV, true>(s, sl, tx0, ty0, changed, L, false, tag, dl_global);
+    else update_tile_q3<NV, false>(s, sl, tx0, ty0, changed, L, false, tag);
 }
 
 // bounds of the pixels whose polygon moved (own cell, right cell or upper cell changed); one 16x16
@@ -1706,10 +1736,10 @@ int ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sens
     const int q = sensor_host ? sensor_host->qdist : 0;
     if (q == 3 && nV == 4)
         hipLaunchKernelGGL(k_update_distortions_q3<4>, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot,
-                           n_slots, tile_prefix_dev, changed_dev, tag);
+                           n_slots, tile_prefix_dev, changed_dev, tag, sensor_host->bf_dl);
     else if (q == 3 && nV == 8)
         hipLaunchKernelGGL(k_update_distortions_q3<8>, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot,
-                           n_slots, tile_prefix_dev, changed_dev, tag);
+                           n_slots, tile_prefix_dev, changed_dev, tag, sensor_host->bf_dl);
     else
         hipLaunchKernelGGL(k_update_distortions, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot, n_slots,
                            tile_prefix_dev, changed_dev, tag);
@@ -1725,6 +1755,10 @@ int ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sens
     HIP_TRY(hipGetLastError());
     return IMS_OK;
 }
+
+#ifdef IMS_UPD_PROBE
+int ims_upd_probe(unsigned long long* out16) { return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_upd_probe), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1; }
+#endif
 
 int ims_bf_chain_ctl_bytes(void) { return (int)sizeof(BfChainCtl); }
 

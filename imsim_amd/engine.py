@@ -234,6 +234,23 @@ class _LibDerive:
         _abi.check(fn(C.byref(struct)), "ims_fill_derived_" + what)
 
 
+def update_window_table(m):
+    """ims_sensor_t.bf_dl: the Silicon model's vertex displacements re-ordered for updatePixelDistortions with qdist 3 --
+    [dj + 3][di + 3][owned point][x, y] for the 8 x 8 source window dj, di = -3 .. 4 of an owner cell (the cell owns its
+    bottom row of points incl. both corners and its left-edge points)."""
+    nV = int(m.num_vertices)
+    npo = 2 * nV + 2
+    n = np.arange(npo)
+    vtx = np.where(n <= nV + 1, n, 3 * nV + 4 + (nV - 1 - (n - nV - 2)))
+    d = np.asarray(m.distortions, dtype=np.float64).reshape(m.nx, m.ny, 4 * nV + 4, 2)
+    cx, cy = (m.nx - 1) // 2, (m.ny - 1) // 2
+    out = np.zeros((8, 8, npo, 2))
+    for a in range(8):
+        for b in range(8):
+            out[a, b] = d[b - 3 + cx, a - 3 + cy, vtx, :]
+    return out
+
+
 def treering_displacement_bound(ss):
     """Upper bound of |tree-ring shift| over the CCD [pixels]: on every table interval the interpolant is the chord plus
     the cubic-spline term ((a^3 - a) m0 + (b^3 - b) m1) h^2 / 6 with |a^3 - a| <= 2 / (3 sqrt 3); a few ulp on top."""
@@ -409,6 +426,8 @@ class BoundScene:
         else:
             S.n_tr, S.tr_dr = 0, 1.0
         _, S.distortions = self.mem.put(m.distortions, np.float64)
+        if m.qdist == 3:
+            _, S.bf_dl = self.mem.put(update_window_table(m), np.float64)
         _, S.emptypoly = self.mem.put(m.emptypoly, np.float64)
         slots = ss.slots if ss.slots is not None else make_slots([])
         self.n_static_slots = len(slots)

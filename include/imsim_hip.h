@@ -298,6 +298,10 @@ typedef struct ims_sensor {
     double pristine_margin;
     /* derived by ims_fill_derived_sensor: diff_step / (thickness * pixel_size), thickness - 1 */
     double diff_coef, thick_m1;
+    /* optional (qdist 3): the displacement table re-ordered for the update kernel, [dj + 3][di + 3][owned point][x, y] for
+     * dj, di = -3 .. 4 (8 x 8 x (2 num_vertices + 2) x 2 doubles, device memory): distortions[di + cx][dj + cy][vertex of the owned
+     * point].  With it the kernel reads a neighbour's row through the scalar cache; NULL = staged through LDS per tile. */
+    const double* bf_dl;
 } ims_sensor_t;
 
 /* A photon pool in device memory, SoA, the fields of galsim.PhotonArray (imsim/photon_ops.py:81). */

@@ -9,6 +9,8 @@
 
 #define IMS_DEV __device__ __forceinline__
 
+
+
 namespace ims {
 
 struct Draw { uint64_t a, b; };

@@ -659,22 +659,23 @@ IMS_DEV bool inside_pixel(const ims_sensor_t& s, const SlotView& sl, int ix, int
         // independent loads in flight instead of one dependent load per vertex
         const double zfactor = dtanh_pos(ddiv(zconv, 12.0));
         const int nV = s.num_vertices, npo = 2 * nV + 2, nv = 4 * nV + 4;
-        const double* own = s.bf_boundary + cell_index(sl, i, j) * npo * 2;
-        const double* rgt = s.bf_boundary + cell_index(sl, i + 1, j) * npo * 2;
-        const double* upp = s.bf_boundary + cell_index(sl, i, j + 1) * npo * 2;
+        const IMS_G double* bnd = s.bf_boundary;
+        const IMS_G double* own = bnd + cell_index(sl, i, j) * npo * 2;
+        const IMS_G double* rgt = bnd + cell_index(sl, i + 1, j) * npo * 2;
+        const IMS_G double* upp = bnd + cell_index(sl, i, j + 1) * npo * 2;
         const bool scaled = (zfactor != 1.0);
         double lx, ly;
         polygon_vertex(s, sl, i, j, nv - 1, zfactor, lx, ly);
         inside = false;
 #pragma unroll 4
         for (int k = 0; k < nv; ++k) {
-            const double* b = own; int q = k; double ax = 0.0, ay = 0.0;
+            const IMS_G double* b = own; int q = k; double ax = 0.0, ay = 0.0;
             if (k > nV + 1) {
                 if (k <= 2 * nV + 1) { b = rgt; ax = 1.0; q = k; }                       // nV + 2 + (k - nV - 2)
                 else if (k <= 3 * nV + 3) { b = upp; ay = 1.0; q = 3 * nV + 3 - k; }     // nV + 1 - (k - 2 nV - 2)
                 else { q = 5 * nV + 5 - k; }                                             // nV + 2 + (nV - 1 - (k - 3 nV - 4))
             }
-            const double2 p = *(const double2*)(b + 2 * q);
+            const double2 p = *(const IMS_G double2*)(b + 2 * q);
             double kx = p.x + ax, ky = p.y + ay;
             if (scaled) {
                 const double ex = s.emptypoly[2 * k], ey = s.emptypoly[2 * k + 1];

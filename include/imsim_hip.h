@@ -42,6 +42,15 @@ extern "C" {
 
 #define IMS_ABI_VERSION 7
 
+/* Pointers stored INSIDE descriptors that live in device memory (ims_sensor_t, ims_atmosphere_t) always point to global
+ * device memory.  Device code is told so (address space 1): a pointer read out of memory is otherwise a generic pointer and
+ * every access through it a slow flat_load / flat_store.  Host compilers and bindings see plain pointers; the layout is the same. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define IMS_G __attribute__((address_space(1)))
+#else
+#define IMS_G
+#endif
+
 /* ---- object flags ---- */
 #define IMS_OBJ_FAINT   1   /* nominal_flux < max_flux_simple: no photon ops, no sensor (stamp.py:435-465,555-556) */
 
@@ -180,7 +189,7 @@ typedef struct ims_atmosphere {
     double  aper_r_outer, aper_r_inner;   /* pupil sampling annulus [m] (diam 8.36, obscuration 0.61: atmPSF.py:168) */
     double  vx[IMS_MAX_LAYERS], vy[IMS_MAX_LAYERS];   /* m/s */
     double  alt[IMS_MAX_LAYERS];   /* m */
-    const float*  screens;         /* [n_layers][npix][npix], fp32 samples (the arithmetic on them is f64) */
+    const float IMS_G*  screens;         /* [n_layers][npix][npix], fp32 samples (the arithmetic on them is f64) */
     /* launch-wide constants derived by ims_fill_derived_atmosphere (the same IEEE operations the kernel would otherwise repeat
      * per photon): (double)npix, 1/npix, 1/scale, aper_r_inner^2, aper_r_outer^2 - aper_r_inner^2 */
     double  dn, inv_n, inv_scale, aper_ri2, aper_dr2;
@@ -272,25 +281,25 @@ typedef struct ims_sensor {
     double  abs_wl_min, abs_wl_step;   /* nm */
     double  tr_dr;               /* tree-ring table step [pixels] (imsim/treerings.py:100-103) */
     double  tr_cx, tr_cy;        /* tree-ring centre in CCD pixel coordinates (imsim/treerings.py:174-189) */
-    const double* abs_len;       /* [n_abs] micron */
-    const double* tr_table;      /* [n_tr] radial shift f(r) [pixels] */
-    const double* tr_table2;     /* [n_tr] second derivatives of the natural cubic spline through tr_table (galsim.LookupTable.from_func
+    const double IMS_G* abs_len;       /* [n_abs] micron */
+    const double IMS_G* tr_table;      /* [n_tr] radial shift f(r) [pixels] */
+    const double IMS_G* tr_table2;     /* [n_tr] second derivatives of the natural cubic spline through tr_table (galsim.LookupTable.from_func
                                     default interpolant, imsim/treerings.py:192-194); NULL = linear interpolation */
-    const double* distortions;   /* [nx][ny][nv][2] vertex displacement (pixel units) per num_elec of charge in the centre pixel */
-    const double* emptypoly;     /* [nv][2] undistorted polygon, counter-clockwise */
+    const double IMS_G* distortions;   /* [nx][ny][nv][2] vertex displacement (pixel units) per num_elec of charge in the centre pixel */
+    const double IMS_G* emptypoly;     /* [nv][2] undistorted polygon, counter-clockwise */
     /* brighter-fatter state */
     int32_t n_bf_slots;
     int32_t pad2;
-    const ims_bf_slot_t* bf_slots;
-    double* bf_boundary;         /* per owner cell of every slot: [2*num_vertices+2][2] owned boundary points (LL corner, bottom pts, LR corner, left pts) */
-    double* bf_bounds;           /* per owner cell (one 64-byte line): inner xmin,xmax,ymin,ymax, outer xmin,xmax,ymin,ymax */
-    double* bf_delta;            /* per owner cell: charge accumulated since the last recalc (Silicon's double _delta) */
+    const ims_bf_slot_t IMS_G* bf_slots;
+    double IMS_G* bf_boundary;         /* per owner cell of every slot: [2*num_vertices+2][2] owned boundary points (LL corner, bottom pts, LR corner, left pts) */
+    double IMS_G* bf_bounds;           /* per owner cell (one 64-byte line): inner xmin,xmax,ymin,ymax, outer xmin,xmax,ymin,ymax */
+    double IMS_G* bf_delta;            /* per owner cell: charge accumulated since the last recalc (Silicon's double _delta) */
     /* optional (NULL = off): one byte per owner cell, used at the first cell of every 16x16 tile of a region.
      * A launch that deposits charge with params->bf_tag != 0 stores the tag in bf_tile_charge; the update with
      * the same tag then skips tiles with no charge in reach and stores the tag in bf_tile_changed for tiles
      * whose boundary points moved.  Stale tags only cost work, never correctness. */
-    unsigned char* bf_tile_charge;
-    unsigned char* bf_tile_changed;
+    unsigned char IMS_G* bf_tile_charge;
+    unsigned char IMS_G* bf_tile_changed;
     /* >= 0: slot 0 is in its pristine (tree-ring only) state and no boundary point of it is displaced by more than this
      * [pixels]: a photon of a slot-0 object that converts further than the margin from every pixel edge is inside its
      * nominal pixel without looking at the boundary state.  The host derives it from the tree-ring table
@@ -301,7 +310,7 @@ typedef struct ims_sensor {
     /* optional (qdist 3): the displacement table re-ordered for the update kernel, [dj + 3][di + 3][owned point][x, y] for
      * dj, di = -3 .. 4 (8 x 8 x (2 num_vertices + 2) x 2 doubles, device memory): distortions[di + cx][dj + cy][vertex of the owned
      * point].  With it the kernel reads a neighbour's row through the scalar cache; NULL = staged through LDS per tile. */
-    const double* bf_dl;
+    const double IMS_G* bf_dl;
 } ims_sensor_t;
 
 /* A photon pool in device memory, SoA, the fields of galsim.PhotonArray (imsim/photon_ops.py:81). */

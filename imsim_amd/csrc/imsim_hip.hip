@@ -307,6 +307,7 @@ __global__ __launch_bounds__(256) void k_accumulate(const ims_render_params_t P,
 // sensor.accumulate for one ROUND of the bright objects: segment-mapped like the fused kernel, but
 // the photon (already through the op chain) is loaded from the pool at pool_start[object] + j.
 // One workgroup = the photons [j0, j0 + 256) of object `oi` (clipped to j_end).
+template <int NV = 0>
 __device__ __forceinline__ void accumulate_segment(const ims_render_params_t& P, const ims_photons_t& pool,
                                                    const int64_t* __restrict__ pool_start, int64_t oi, int64_t j0, int64_t j_end)
 {
@@ -329,7 +330,7 @@ __device__ __forceinline__ void accumulate_segment(const ims_render_params_t& P,
         int ix, iy;
         Rng rng;
         rng_reset(rng);
-        if (ph.flux != 0.0 && land(P, o, o.phot_first + j, rng, ph, silicon, has_angles, ix, iy)) {
+        if (ph.flux != 0.0 && land<NV>(P, o, o.phot_first + j, rng, ph, silicon, has_angles, ix, iy)) {
             added = ph.flux;
             tile_deposit(tile, ct, P, ix, iy, ph.flux);
         }
@@ -356,6 +357,7 @@ __global__ __launch_bounds__(256) void k_accumulate_segments(const ims_render_pa
 // The same for round `round` of a chain class whose table holds the objects' FULL photon counts: the round covers the
 // photons [round * nrecalc, (round + 1) * nrecalc) of every object, `segs` = ceil(nrecalc / 256) workgroups per object;
 // the first n_active rows (sorted by photon count, brightest first) are the objects that reach this round.
+template <int NV>
 __global__ __launch_bounds__(256) void k_accumulate_round(const ims_render_params_t P, const ims_photons_t pool,
                                                           const int64_t* __restrict__ pool_start, int64_t round_first, int32_t nrecalc,
                                                           int32_t segs)
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256) void k_accumulate_round(const ims_render_param
     const int64_t n = P.objects[oi].n_phot;
     if (j_end > n) j_end = n;
     if (j0 >= j_end) return;
-    accumulate_segment(P, pool, pool_start, oi, j0, j_end);
+    accumulate_segment<NV>(P, pool, pool_start, oi, j0, j_end);
 }
 
 // ---------------- Silicon boundary state ----------------
@@ -1636,7 +1638,7 @@ int ims_accumulate_segments(const ims_render_params_t* params, const ims_photons
 }
 
 int ims_accumulate_round(const ims_render_params_t* params, const ims_photons_t* pool, const int64_t* pool_start,
-                         int32_t round, int32_t nrecalc, int32_t n_active, void* stream)
+                         int32_t round, int32_t nrecalc, int32_t n_active, int32_t num_vertices, void* stream)
 {
     if (!params) return set_err(IMS_ERR_ARG, "params is NULL");
     if (!params->objects || !params->image) return set_err(IMS_ERR_ARG, "objects/image is NULL");
@@ -1646,8 +1648,14 @@ int ims_accumulate_round(const ims_render_params_t* params, const ims_photons_t*
     if (n_active == 0) return IMS_OK;
     const int32_t segs = (nrecalc + 255) / 256;
     if ((int64_t)n_active * segs > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "too many workgroups for one round");
-    hipLaunchKernelGGL(k_accumulate_round, dim3((unsigned)(n_active * segs)), dim3(256), 0, (hipStream_t)stream, *params, *pool,
-                       pool_start, (int64_t)round * nrecalc, nrecalc, segs);
+    const dim3 grid((unsigned)(n_active * segs));
+    const int64_t first = (int64_t)round * nrecalc;
+    if (num_vertices == 4)
+        hipLaunchKernelGGL(k_accumulate_round<4>, grid, dim3(256), 0, (hipStream_t)stream, *params, *pool, pool_start, first, nrecalc, segs);
+    else if (num_vertices == 8)
+        hipLaunchKernelGGL(k_accumulate_round<8>, grid, dim3(256), 0, (hipStream_t)stream, *params, *pool, pool_start, first, nrecalc, segs);
+    else
+        hipLaunchKernelGGL(k_accumulate_round<0>, grid, dim3(256), 0, (hipStream_t)stream, *params, *pool, pool_start, first, nrecalc, segs);
     HIP_TRY(hipGetLastError());
     return IMS_OK;
 }
@@ -1856,7 +1864,8 @@ static int run_rounds(const ims_chain_t* chains, int32_t n_chains, const ims_sen
             ims_render_params_t P = *ch.params;
             const uint32_t tag = ch.use_tags ? (uint32_t)(r % 255 + 1) : 0u;      // marks the tiles this round's charge lands in
             P.bf_tag = tag;
-            int rc = ims_accumulate_round(&P, ch.pool, ch.pool_start, r, ch.nrecalc, n_act, st);
+            int rc = ims_accumulate_round(&P, ch.pool, ch.pool_start, r, ch.nrecalc, n_act,
+                                          sensor_host ? sensor_host->num_vertices : 0, st);
             if (rc) return rc;
             const int32_t n_cont = count_above(ch.n_phot, ch.n_objects, (int64_t)(r + 1) * ch.nrecalc);
             if (n_cont > 0) {

@@ -539,9 +539,11 @@ typedef struct ims_plan_item {
 } ims_plan_item_t;
 /* One round of a chain class (see ims_chain_t): sensor.accumulate of the photons [round nrecalc, (round + 1) nrecalc) of the first
  * n_active objects of params->objects, photon j of object o read from the pool at pool_start[o] + j.  params->seg_prefix /
- * seg_object / n_segments are not used: every object gets ceil(nrecalc / 256) workgroups. */
+ * seg_object / n_segments are not used: every object gets ceil(nrecalc / 256) workgroups.  num_vertices: the sensor model's
+ * NumVertices when the caller knows it (must equal the descriptor's; 4 and 8 select kernels with the polygon test unrolled at
+ * compile time), 0 = read it from the descriptor. */
 int  ims_accumulate_round(const ims_render_params_t* params, const ims_photons_t* pool, const int64_t* pool_start,
-                          int32_t round, int32_t nrecalc, int32_t n_active, void* stream);
+                          int32_t round, int32_t nrecalc, int32_t n_active, int32_t num_vertices, void* stream);
 int  ims_run_plan(const ims_plan_item_t* items, int64_t n_items, const ims_sensor_t* sensor_dev,
                   const ims_sensor_t* sensor_host, unsigned char* changed_dev, void* const* streams, int32_t n_streams);
 

@@ -100,8 +100,8 @@ def test_argument_errors_are_reported_before_any_launch():
     assert lib.ims_run_plan(C.byref(it), 1, None, None, None, streams, 1) < 0 and b"stream" in lib.ims_last_error()
     # one round of a chain class / the rounds plan item
     P, ph = _abi.RenderParams(), _abi.Photons()
-    assert lib.ims_accumulate_round(None, C.byref(ph), None, 0, 10000, 1, None) < 0 and b"params" in lib.ims_last_error()
-    assert lib.ims_accumulate_round(C.byref(P), C.byref(ph), None, 0, 10000, 1, None) < 0
+    assert lib.ims_accumulate_round(None, C.byref(ph), None, 0, 10000, 1, 4, None) < 0 and b"params" in lib.ims_last_error()
+    assert lib.ims_accumulate_round(C.byref(P), C.byref(ph), None, 0, 10000, 1, 4, None) < 0
     it = _abi.PlanItem()
     it.kind, it.stream, it.n_slots, it.aux2 = _abi.IMS_PLAN_ROUNDS, 0, 1, None
     assert lib.ims_run_plan(C.byref(it), 1, None, None, None, streams, 1) < 0 and b"chains" in lib.ims_last_error()

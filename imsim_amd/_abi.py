@@ -153,7 +153,8 @@ class Sensor(C.Structure):
 
 class Photons(C.Structure):
     _fields_ = [("n", c_i64)] + [(f, c_vp) for f in
-                                 ("x", "y", "flux", "dxdz", "dydz", "wavelength", "pupil_u", "pupil_v", "time", "obj_index")]
+                                 ("x", "y", "flux", "dxdz", "dydz", "wavelength", "pupil_u", "pupil_v", "time", "obj_index")] + [
+                                     ("converted", c_i32), ("pad", c_i32)]
 
 
 class RenderParams(C.Structure):
@@ -185,7 +186,7 @@ class PlanItem(C.Structure):
 
 
 (IMS_PLAN_RENDER, IMS_PLAN_SHOOT_POOL, IMS_PLAN_ACC_POOL, IMS_PLAN_UPDATE, IMS_PLAN_INIT, IMS_PLAN_RECORD,
- IMS_PLAN_WAIT, IMS_PLAN_CHAIN) = range(1, 9)
+ IMS_PLAN_WAIT) = range(1, 8)
 
 IMS_MAX_AMPS = 16
 
@@ -207,7 +208,6 @@ STRUCTS = [Object, RadialTables, LinTables, PsfComponent, Op, Surface, TanSip, O
 # every symbol include/imsim_hip.h declares
 EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_info", "ims_shoot_accumulate",
            "ims_shoot_photons", "ims_shoot_ops_photons", "ims_accumulate_segments", "ims_accumulate_round", "ims_run_plan",
-           "ims_bf_chain", "ims_bf_chain_ctl_bytes", "ims_bf_chain_status",
            "ims_fft_kspace_fill", "ims_fft_finish", "ims_fft_spikes", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
            "ims_sensor_update_distortions", "ims_image_add", "ims_image_to_float", "ims_fill_derived_op", "ims_fill_derived_medium", "ims_fill_derived_optics", "ims_fill_derived_atmosphere", "ims_fill_derived_sensor", "ims_sensor_pixel_areas", "ims_flat_add", "ims_last_kernel_ms", "ims_enable_timing",
            "ims_readout_bleed", "ims_readout_segments", "ims_readout_cte", "ims_readout_finish",
@@ -264,9 +264,6 @@ def load():
     lib.ims_fft_kspace_fill.argtypes = [C.POINTER(FftParams), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]
     lib.ims_fft_finish.argtypes = [C.POINTER(FftParams), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]
     lib.ims_fft_spikes.argtypes = [C.POINTER(FftParams), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]
-    lib.ims_bf_chain.argtypes = [C.POINTER(RenderParams), C.POINTER(Photons), c_vp, c_i32, c_i32, c_i32, C.POINTER(Sensor), c_vp, c_vp,
-                                 c_i32, c_i32, c_vp]
-    lib.ims_bf_chain_status.argtypes = [c_vp, C.POINTER(c_i32)]
     lib.ims_run_plan.argtypes = [C.POINTER(PlanItem), c_i64, c_vp, C.POINTER(Sensor), c_vp, C.POINTER(c_vp), c_i32]
     lib.ims_last_kernel_ms.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.ims_enable_timing.argtypes = [C.c_int]

@@ -612,6 +612,18 @@ IMS_DEV void apply_op(const ims_render_params_t& P, int op_index, const ims_obje
     }
 }
 
+// -DIMS_PROBE (measurement builds only, tools/dbg/round_probe.py): thread 0 of the middle workgroup of a kernel (PROBE) or of
+// each of the first 64 workgroups (PROBE_WG) stamps the 100 MHz real-time counter at marked places of the round kernels.
+#ifdef IMS_PROBE
+__device__ unsigned long long g_probe[32];
+__device__ unsigned long long g_probe_wg[64][8];
+#define PROBE(k) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) ims::g_probe[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define PROBE_WG(k, tid) do { if (blockIdx.x < 64 && threadIdx.x == (tid)) ims::g_probe_wg[blockIdx.x][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PROBE(k) do { } while (0)
+#define PROBE_WG(k, tid) do { } while (0)
+#endif
+
 // ---------------- Silicon sensor ----------------
 struct SlotView {
     int xmin, ymin, nx, ny;
@@ -640,14 +652,112 @@ IMS_DEV void polygon_vertex(const ims_sensor_t& s, const SlotView& sl, int i, in
     }
 }
 
-// NV > 0: the sensor model's vertices per edge as a compile-time constant (4 or 8): the polygon then unrolls into
-// straight-line code with static vertex addresses, every batch of four vertex loads is in flight together and the crossing
-// tests carry no branch.  (With NV read from the descriptor the compiler emitted one load, one wait and a branch ladder
-// per vertex: 20 dependent L2 latencies, 14 000 cycles, per polygon -- the bulk of a brighter-fatter round.)  NV = 0 is
-// the generic loop.  Same arithmetic, same decisions.
-template <int NV = 0>
+typedef double dvec2 __attribute__((ext_vector_type(2)));
+typedef double dvec4 __attribute__((ext_vector_type(4)));
+
+// Crossing-number test of (x, y) against the polygon of the pixel whose owner cell is `own` (right neighbour cell `rgt`,
+// upper neighbour cell `upp`), every vertex pulled towards the undistorted polygon by zfactor.  NV > 0: the sensor model's
+// vertices per edge as a compile-time constant (4 or 8): the polygon unrolls into straight-line code with static vertex
+// addresses, every batch of four vertex loads is in flight together and neither the crossing tests nor the zfactor scaling
+// carry a branch.  (With NV read from the descriptor the compiler emitted one load, one wait and a branch ladder per vertex:
+// 20 dependent L2 latencies per polygon -- the bulk of a brighter-fatter round.)  NV = 0 is the generic loop.  Same
+// arithmetic, same decisions.
+template <int NV>
+IMS_DEV bool polygon_test(const ims_sensor_t& s, const IMS_G double* own, const IMS_G double* rgt, const IMS_G double* upp,
+                          double x, double y, double zfactor)
+{
+    const int nV = (NV > 0) ? NV : s.num_vertices, nv = 4 * nV + 4;
+    const bool scaled = (zfactor != 1.0);
+    bool inside = false;
+    if (NV > 0) {
+        // The vertex loads of the polygon are stated before the first use (in halves for 8 vertices per edge), so that the
+        // compiler keeps as many in flight as the register budget allows: every dependent memory round trip of a round's
+        // kernels costs ~1.4 us (the lines were written by the previous kernel on other XCDs), tools/dbg/round_probe.py.
+        constexpr int NVX = (NV > 0) ? NV : 1, NVT = 4 * NVX + 4, CH = (NVT <= 20) ? NVT : NVT / 2;
+        double lx, ly;
+        {
+            const double2 p = *(const IMS_G double2*)(own + 2 * (NVX + 2));               // closing vertex NVT - 1: own left edge, first point
+            const double ex = s.emptypoly[2 * (NVT - 1)], ey = s.emptypoly[2 * (NVT - 1) + 1];
+            const double sx = ex + (p.x - ex) * zfactor, sy = ey + (p.y - ey) * zfactor;
+            lx = scaled ? sx : p.x; ly = scaled ? sy : p.y;
+        }
+#pragma unroll
+        for (int k0 = 0; k0 < NVT; k0 += CH) {
+            dvec2 v[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int k = k0 + u;
+                const IMS_G double* bb = own; int q = k;
+                if (k > NVX + 1) {
+                    if (k <= 2 * NVX + 1) { bb = rgt; q = k; }
+                    else if (k <= 3 * NVX + 3) { bb = upp; q = 3 * NVX + 3 - k; }
+                    else { q = 5 * NVX + 5 - k; }
+                }
+                v[u] = *(const IMS_G dvec2*)(bb + 2 * q);
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int k = k0 + u;
+                const double ax = (k > NVX + 1 && k <= 2 * NVX + 1) ? 1.0 : 0.0;
+                const double ay = (k > 2 * NVX + 1 && k <= 3 * NVX + 3) ? 1.0 : 0.0;
+                double kx = v[u].x + ax, ky = v[u].y + ay;
+                const double ex = s.emptypoly[2 * k], ey = s.emptypoly[2 * k + 1];
+                const double sx = ex + (kx - ex) * zfactor, sy = ey + (ky - ey) * zfactor;
+                kx = scaled ? sx : kx; ky = scaled ? sy : ky;
+                // x < (lx - kx) (y - ky) / (ly - ky) + kx, cross-multiplied (ly != ky when the edge crosses): no division
+                const double dy = ly - ky;
+                const double lhs = (x - kx) * dy, rhs = (lx - kx) * (y - ky);
+                const bool crosses = (ky > y) != (ly > y);
+                const bool left = (dy > 0.0) ? (lhs < rhs) : (lhs > rhs);
+                inside = inside != (crosses && left);
+                lx = kx; ly = ky;
+            }
+        }
+    } else {
+        // the vertex addresses depend only on the loop counter: unrolled four-fold to keep four independent loads in flight
+        double lx, ly;
+        {
+            const int k = nv - 1;                                                         // closing vertex: own left edge, first point
+            const double2 p = *(const IMS_G double2*)(own + 2 * (5 * nV + 5 - k));
+            lx = p.x; ly = p.y;
+            if (scaled) {
+                const double ex = s.emptypoly[2 * k], ey = s.emptypoly[2 * k + 1];
+                lx = ex + (lx - ex) * zfactor;
+                ly = ey + (ly - ey) * zfactor;
+            }
+        }
+#pragma unroll 4
+        for (int k = 0; k < nv; ++k) {
+            const IMS_G double* bb = own; int q = k; double ax = 0.0, ay = 0.0;
+            if (k > nV + 1) {
+                if (k <= 2 * nV + 1) { bb = rgt; ax = 1.0; q = k; }                       // nV + 2 + (k - nV - 2)
+                else if (k <= 3 * nV + 3) { bb = upp; ay = 1.0; q = 3 * nV + 3 - k; }     // nV + 1 - (k - 2 nV - 2)
+                else { q = 5 * nV + 5 - k; }                                             // nV + 2 + (nV - 1 - (k - 3 nV - 4))
+            }
+            const double2 p = *(const IMS_G double2*)(bb + 2 * q);
+            double kx = p.x + ax, ky = p.y + ay;
+            if (scaled) {
+                const double ex = s.emptypoly[2 * k], ey = s.emptypoly[2 * k + 1];
+                kx = ex + (kx - ex) * zfactor;
+                ky = ey + (ky - ey) * zfactor;
+            }
+            if ((ky > y) != (ly > y)) {
+                // x < (lx - kx) (y - ky) / (ly - ky) + kx, cross-multiplied (ly != ky here): no division
+                const double dy = ly - ky;
+                const double lhs = (x - kx) * dy, rhs = (lx - kx) * (y - ky);
+                if ((dy > 0.0) ? (lhs < rhs) : (lhs > rhs)) inside = !inside;
+            }
+            lx = kx; ly = ky;
+        }
+    }
+    return inside;
+}
+
+// GalSim's Silicon::insidePixel.  ZF: `z` is already the polygon shrink factor tanh(zconv / 12) (converted pools), otherwise
+// the conversion depth zconv it is computed from when the polygon is needed.
+template <int NV = 0, bool ZF = false>
 IMS_DEV bool inside_pixel(const ims_sensor_t& s, const SlotView& sl, int ix, int iy, double x, double y,
-                          double zconv, bool want_edge, bool& off_edge)
+                          double z, bool want_edge, bool& off_edge)
 {
     const int i = ix - sl.xmin, j = iy - sl.ymin;
     if (i < 0 || i >= sl.nx || j < 0 || j >= sl.ny) {
@@ -656,86 +766,18 @@ IMS_DEV bool inside_pixel(const ims_sensor_t& s, const SlotView& sl, int ix, int
     }
     const IMS_G double* b = s.bf_bounds + cell_index(sl, i, j) * 8;
     // the whole 64-byte line at once (the outer bounds used to be four dependent loads behind short-circuit tests)
-    const double b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4], b5 = b[5], b6 = b[6], b7 = b[7];
+    const dvec4 bi = *(const IMS_G dvec4*)b, bo = *(const IMS_G dvec4*)(b + 4);
+    const double b0 = bi.x, b1 = bi.y, b2 = bi.z, b3 = bi.w, b4 = bo.x, b5 = bo.y, b6 = bo.z, b7 = bo.w;
     bool inside;
     if (x > b0 && x < b1 && y > b2 && y < b3) inside = true;
     else if (!(x >= b4 && x <= b5 && y >= b6 && y <= b7)) inside = false;
     else {
         // a wave takes this path whenever ONE of its 64 photons misses the inner bounds, i.e. almost always
-        const double zfactor = dtanh_pos(ddiv(zconv, 12.0));
-        const int nV = (NV > 0) ? NV : s.num_vertices, npo = 2 * nV + 2, nv = 4 * nV + 4;
+        const double zfactor = ZF ? z : dtanh_pos(ddiv(z, 12.0));
+        const int nV = (NV > 0) ? NV : s.num_vertices, npo = 2 * nV + 2;
         const IMS_G double* bnd = s.bf_boundary;
-        const IMS_G double* own = bnd + cell_index(sl, i, j) * npo * 2;
-        const IMS_G double* rgt = bnd + cell_index(sl, i + 1, j) * npo * 2;
-        const IMS_G double* upp = bnd + cell_index(sl, i, j + 1) * npo * 2;
-        const bool scaled = (zfactor != 1.0);
-        inside = false;
-        if (NV > 0) {
-            constexpr int NVX = (NV > 0) ? NV : 1, NVT = 4 * NVX + 4;
-            double lx = 0.0, ly = 0.0;
-#pragma unroll
-            for (int k0 = -4; k0 < NVT; k0 += 4) {
-                // batch -4 only fetches the closing vertex NVT - 1 (the "previous vertex" of vertex 0)
-                double vx[4], vy[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k = (k0 < 0) ? NVT - 1 : k0 + u;
-                    if (k0 < 0 && u > 0) { vx[u] = 0.0; vy[u] = 0.0; continue; }
-                    const IMS_G double* bb = own; int q = k; double ax = 0.0, ay = 0.0;
-                    if (k > NVX + 1) {
-                        if (k <= 2 * NVX + 1) { bb = rgt; ax = 1.0; q = k; }
-                        else if (k <= 3 * NVX + 3) { bb = upp; ay = 1.0; q = 3 * NVX + 3 - k; }
-                        else { q = 5 * NVX + 5 - k; }
-                    }
-                    const double2 p = *(const IMS_G double2*)(bb + 2 * q);
-                    double kx = p.x + ax, ky = p.y + ay;
-                    if (scaled) {
-                        const double ex = s.emptypoly[2 * k], ey = s.emptypoly[2 * k + 1];
-                        kx = ex + (kx - ex) * zfactor;
-                        ky = ey + (ky - ey) * zfactor;
-                    }
-                    vx[u] = kx; vy[u] = ky;
-                }
-                if (k0 < 0) { lx = vx[0]; ly = vy[0]; continue; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const double kx = vx[u], ky = vy[u];
-                    // x < (lx - kx) (y - ky) / (ly - ky) + kx, cross-multiplied (ly != ky when the edge crosses): no division
-                    const double dy = ly - ky;
-                    const double lhs = (x - kx) * dy, rhs = (lx - kx) * (y - ky);
-                    const bool crosses = (ky > y) != (ly > y);
-                    const bool left = (dy > 0.0) ? (lhs < rhs) : (lhs > rhs);
-                    inside = inside != (crosses && left);
-                    lx = kx; ly = ky;
-                }
-            }
-        } else {
-            double lx, ly;
-            polygon_vertex(s, sl, i, j, nv - 1, zfactor, lx, ly);
-#pragma unroll 4
-            for (int k = 0; k < nv; ++k) {
-                const IMS_G double* bb = own; int q = k; double ax = 0.0, ay = 0.0;
-                if (k > nV + 1) {
-                    if (k <= 2 * nV + 1) { bb = rgt; ax = 1.0; q = k; }                       // nV + 2 + (k - nV - 2)
-                    else if (k <= 3 * nV + 3) { bb = upp; ay = 1.0; q = 3 * nV + 3 - k; }     // nV + 1 - (k - 2 nV - 2)
-                    else { q = 5 * nV + 5 - k; }                                             // nV + 2 + (nV - 1 - (k - 3 nV - 4))
-                }
-                const double2 p = *(const IMS_G double2*)(bb + 2 * q);
-                double kx = p.x + ax, ky = p.y + ay;
-                if (scaled) {
-                    const double ex = s.emptypoly[2 * k], ey = s.emptypoly[2 * k + 1];
-                    kx = ex + (kx - ex) * zfactor;
-                    ky = ey + (ky - ey) * zfactor;
-                }
-                if ((ky > y) != (ly > y)) {
-                    // x < (lx - kx) (y - ky) / (ly - ky) + kx, cross-multiplied (ly != ky here): no division
-                    const double dy = ly - ky;
-                    const double lhs = (x - kx) * dy, rhs = (lx - kx) * (y - ky);
-                    if ((dy > 0.0) ? (lhs < rhs) : (lhs > rhs)) inside = !inside;
-                }
-                lx = kx; ly = ky;
-            }
-        }
+        inside = polygon_test<NV>(s, bnd + cell_index(sl, i, j) * npo * 2, bnd + cell_index(sl, i + 1, j) * npo * 2,
+                                  bnd + cell_index(sl, i, j + 1) * npo * 2, x, y, zfactor);
     }
     if (!inside && want_edge) {
         off_edge = false;
@@ -747,26 +789,34 @@ IMS_DEV bool inside_pixel(const ims_sensor_t& s, const SlotView& sl, int ix, int
     return inside;
 }
 
-__device__ const int XOFF[9] = {0, 1, 1, 0, -1, -1, -1, 0, 1};
-__device__ const int YOFF[9] = {0, 0, 1, 1, 1, 0, -1, -1, -1};
+// GalSim's neighbour table of the pixel search, n = 0 (the pixel itself), 1 .. 8 counter-clockwise from the right:
+// xoff = {0, 1, 1, 0, -1, -1, -1, 0, 1}, yoff = {0, 0, 1, 1, 1, 0, -1, -1, -1}, as 2-bit codes (offset + 1) so that a lookup
+// is two ALU instructions instead of a dependent load
+IMS_DEV int xoff(int n) { return (int)((0x24069u >> (2 * n)) & 3u) - 1; }
+IMS_DEV int yoff(int n) { return (int)((0x006a5u >> (2 * n)) & 3u) - 1; }
 
-// Decide the landing pixel.  Returns false when the photon is lost.  has_angles: the chain
-// contains a ray-tracing op, so dxdz/dydz are meaningful.
-template <int NV = 0>
-IMS_DEV bool land(const ims_render_params_t& P, const ims_object_t& o, int64_t k, Rng& rng, const Photon& ph,
-                  bool silicon, bool has_angles, int& ix, int& iy)
+// first neighbour GalSim's search tries for a point (x, y) of the unit pixel that is not inside its own polygon
+IMS_DEV int search_step(double x, double y)
 {
-    double x0 = ph.x, y0 = ph.y;
-    if (!silicon || (o.flags & IMS_OBJ_FAINT)) {
-        ix = (int)floor(x0 + 0.5); iy = (int)floor(y0 + 0.5);
-        return !(ix < o.stamp_xmin || ix > o.stamp_xmax || iy < o.stamp_ymin || iy > o.stamp_ymax);
-    }
+    if ((x > y) && (x > 1.0 - y)) return 1;
+    if ((x > y) && (x < 1.0 - y)) return 7;
+    if ((x < y) && (x > 1.0 - y)) return 3;
+    return 5;
+}
+
+// SiliconSensor.accumulate, first half: everything that does not look at the pixel boundaries -- conversion depth from the
+// absorption length, lateral walk of an inclined photon down to that depth, diffusion.  Returns false when the photon
+// converts beyond the back of the sensor (lost).  coin: the photon's "pixel not found" coin (stay in the nominal pixel).
+// has_angles: the chain contains a ray-tracing op, so dxdz/dydz are meaningful.
+IMS_DEV bool land_convert(const ims_render_params_t& P, const ims_object_t& o, int64_t k, Rng& rng, const Photon& ph,
+                          bool has_angles, double& x0, double& y0, double& zconv, bool& coin)
+{
     const ims_sensor_t& s = *P.sensor;
-    const ims_bf_slot_t bs = s.bf_slots[o.bf_state];
-    const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
+    x0 = ph.x; y0 = ph.y;
     rng_block(rng, P.seed, o.obj_id, k, SLOT_SENSOR);
     double g0, g1;
     gauss_words(rng.w[0], rng.w[1], g0, g1);
+    coin = (rng.w[3] & 0x80000000u) != 0u;
     const double f = ddiv(ph.wl - s.abs_wl_min, s.abs_wl_step);
     double abs_len;
     if (!(f > 0.0)) abs_len = s.abs_len[0];
@@ -781,7 +831,7 @@ IMS_DEV bool land(const ims_render_params_t& P, const ims_object_t& o, int64_t k
         x0 = x0 + ph.dxdz * dzp;
         y0 = y0 + ph.dydz * dzp;
     }
-    const double zconv = s.thickness - dz;
+    zconv = s.thickness - dz;
     if (zconv < 0.0) return false;
     if (s.diff_step != 0.0) {
         double ds = s.diff_coef * dsqrt0(zconv * s.thickness);
@@ -789,6 +839,21 @@ IMS_DEV bool land(const ims_render_params_t& P, const ims_object_t& o, int64_t k
         x0 = x0 + ds * g0;
         y0 = y0 + ds * g1;
     }
+    return true;
+}
+
+// SiliconSensor.accumulate, second half: the pixel the converted photon (x0, y0) is collected in, by GalSim's search over
+// the distorted pixel polygons.  ZF: z is the shrink factor (converted pool), else zconv.  Returns false when the photon
+// is lost.  (Testing the nominal pixel and the first neighbour of the search together, both bounds lines and both polygons
+// in one batch of loads, was measured: 41.2 against 41.5 us per round of the brightest star, +1 % on the C3 step -- the
+// search is not where a round's latency goes; not kept.)
+template <int NV = 0, bool ZF = false>
+IMS_DEV bool land_search(const ims_render_params_t& P, const ims_object_t& o, double x0, double y0, double z, bool coin,
+                         int& ix, int& iy)
+{
+    const ims_sensor_t& s = *P.sensor;
+    const ims_bf_slot_t bs = s.bf_slots[o.bf_state];
+    const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
     ix = (int)floor(x0 + 0.5); iy = (int)floor(y0 + 0.5);
     if (ix < o.stamp_xmin || ix > o.stamp_xmax || iy < o.stamp_ymin || iy > o.stamp_ymax) return false;
     const double x = x0 - (double)ix + 0.5, y = y0 - (double)iy + 0.5;
@@ -802,31 +867,63 @@ IMS_DEV bool land(const ims_render_params_t& P, const ims_object_t& o, int64_t k
         if (o.bf_state == 0 && m >= 0.0 && pi >= 0 && pi < sl.nx && pj >= 0 && pj < sl.ny && x > m && x < 1.0 - m && y > m && y < 1.0 - m)
             found = true;
         else
-            found = inside_pixel<NV>(s, sl, ix, iy, x, y, zconv, true, off_edge);
+            found = inside_pixel<NV, ZF>(s, sl, ix, iy, x, y, z, true, off_edge);
     }
+    PROBE_WG(3, 0);
     if (!found && off_edge) return false;
     int step = 0;
     if (!found) {
-        if ((x > y) && (x > 1.0 - y)) step = 1;
-        else if ((x > y) && (x < 1.0 - y)) step = 7;
-        else if ((x < y) && (x > 1.0 - y)) step = 3;
-        else step = 5;
-        int n = step;
+        // The search visits the eight neighbours in the order n_m = ((m step - 1) mod 8) + 1, m = 1 .. 8, and stops at the
+        // first whose polygon holds the point.  A photon that no polygon holds (the polygons pulled in by the depth factor
+        // leave slivers between them) walks all eight, and among the 10 000 photons of a round there always is one: as
+        // eight dependent bounds-then-polygon tests that walk was most of the duration of a round's kernel.  So first the
+        // OUTER bounds of all eight are fetched in one batch; a neighbour whose outer bounds do not contain the point
+        // cannot hold it (inside_pixel would say no), and the ordered walk only tests the others -- the same answers.
+        step = search_step(x, y);
+        unsigned cand = 0u;
+#pragma unroll
         for (int m = 1; m < 9; ++m) {
-            const int jx = ix + XOFF[n], jy = iy + YOFF[n];
+            const int n = ((m * step - 1) & 7) + 1;
+            const int i = ix + xoff(n) - sl.xmin, j = iy + yoff(n) - sl.ymin;
+            const bool valid = !(i < 0 || i >= sl.nx || j < 0 || j >= sl.ny);
+            const IMS_G double* b = s.bf_bounds + (valid ? cell_index(sl, i, j) : sl.offset) * 8;
+            const double o4 = b[4], o5 = b[5], o6 = b[6], o7 = b[7];
+            const double xb = x - (double)xoff(n), yb = y - (double)yoff(n);
+            if (valid && xb >= o4 && xb <= o5 && yb >= o6 && yb <= o7) cand |= 1u << m;
+        }
+        PROBE_WG(4, 0);
+        for (int m = 1; m < 9 && cand != 0u; ++m) {
+            if (!(cand & (1u << m))) continue;
+            cand &= ~(1u << m);
+            const int n = ((m * step - 1) & 7) + 1;
+            const int jx = ix + xoff(n), jy = iy + yoff(n);
             bool dummy;
-            if (inside_pixel<NV>(s, sl, jx, jy, x - (double)XOFF[n], y - (double)YOFF[n], zconv, false, dummy)) {
+            if (inside_pixel<NV, ZF>(s, sl, jx, jy, x - (double)xoff(n), y - (double)yoff(n), z, false, dummy)) {
                 ix = jx; iy = jy; found = true; break;
             }
-            n = ((n - 1) + step) % 8 + 1;
         }
     }
     if (!found) {
-        const int n = (rng.w[3] & 0x80000000u) ? 0 : step;
-        ix = ix + XOFF[n]; iy = iy + YOFF[n];
+        const int n = coin ? 0 : step;
+        ix = ix + xoff(n); iy = iy + yoff(n);
     }
     // the caller deposits the charge (CCD image and, for tracked regions, the delta-charge image)
     return !(ix < o.stamp_xmin || ix > o.stamp_xmax || iy < o.stamp_ymin || iy > o.stamp_ymax);
+}
+
+// Decide the landing pixel.  Returns false when the photon is lost.
+template <int NV = 0>
+IMS_DEV bool land(const ims_render_params_t& P, const ims_object_t& o, int64_t k, Rng& rng, const Photon& ph,
+                  bool silicon, bool has_angles, int& ix, int& iy)
+{
+    if (!silicon || (o.flags & IMS_OBJ_FAINT)) {
+        ix = (int)floor(ph.x + 0.5); iy = (int)floor(ph.y + 0.5);
+        return !(ix < o.stamp_xmin || ix > o.stamp_xmax || iy < o.stamp_ymin || iy > o.stamp_ymax);
+    }
+    double x0, y0, zconv;
+    bool coin;
+    if (!land_convert(P, o, k, rng, ph, has_angles, x0, y0, zconv, coin)) return false;
+    return land_search<NV, false>(P, o, x0, y0, zconv, coin, ix, iy);
 }
 
 IMS_DEV bool chain_has_angles(const ims_render_params_t& P)

@@ -55,6 +55,15 @@ struct LaunchTimer {
     ~LaunchTimer() { if (on) (void)hipEventRecord(g_events[slot + 1], st); }
 };
 
+// -DIMS_PROBE (measurement builds only, tools/dbg/round_probe.py): the stamps of ims_photon.h's PROBE / PROBE_WG, copied out
+#ifdef IMS_PROBE
+extern "C" int ims_probe_read(unsigned long long* out32, unsigned long long* wg512)
+{
+    if (wg512 && hipMemcpyFromSymbol(wg512, HIP_SYMBOL(ims::g_probe_wg), 512 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out32, HIP_SYMBOL(ims::g_probe), 32 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 // ---------------- segment -> (object, first photon) ----------------
 constexpr int N_XCD = 8;
 
@@ -154,6 +163,8 @@ __device__ __forceinline__ void tile_deposit(float* tile, const ChargeTile& ct, 
 __device__ __forceinline__ void tile_flush(float* tile, const ChargeTile& ct, const ims_render_params_t& P, int n_thr = 256)
 {
     __syncthreads();
+    PROBE(5);
+    PROBE_WG(6, 0);
     for (int e = threadIdx.x; e < CT * CT; e += n_thr) {
         const float v = tile[e];
         if (v != 0.0f) deposit_global(P, ct, ct.x0 + e % CT, ct.y0 + e / CT, (double)v);
@@ -212,10 +223,12 @@ __global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_accumulate(const
 
 // ---------------- pooled path ----------------
 // LSST_PhotonsBuilder.draw for all objects of a sub-batch, written straight into the merged pool.
-// WITH_OPS additionally runs the configured photon-op chain before storing (used to pre-compute the
-// sensor-independent part of bright objects' photons, see Renderer.plan_lsst_image).
+// MODE 1 additionally runs the configured photon-op chain before storing (used to pre-compute the
+// sensor-independent part of bright objects' photons, see Renderer.plan_lsst_image); MODE 2 also runs the half of
+// SiliconSensor.accumulate that does not depend on the pixel boundaries and stores the `converted` pool format
+// (ims_photons_t.converted), so that the latency-bound rounds of a brighter-fatter chain only do the pixel search.
 // pool.pupil_u / pupil_v / time / obj_index may be NULL (not stored).
-template <bool WITH_OPS>
+template <int MODE>
 __global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_photons(const ims_render_params_t P,
                                                                         const int64_t* __restrict__ photon_offset,
                                                                         const ims_photons_t pool)
@@ -233,9 +246,23 @@ __global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_photons(const im
     Photon ph;
     Rng rng;
     make_photon(P, o, k, rng, ph);
-    if (WITH_OPS)
+    if (MODE >= 1)
         for (int q = 0; q < P.n_ops; ++q) apply_op(P, q, o, k, rng, ph);
     const int64_t i = photon_offset[oi] + j;
+    if (MODE == 2) {
+        const bool silicon = (P.sensor != nullptr) && (P.sensor->kind == IMS_SENSOR_SILICON);
+        double x0 = ph.x, y0 = ph.y, flux = ph.flux, zs = 1.0;
+        if (silicon && !(o.flags & IMS_OBJ_FAINT) && flux != 0.0) {
+            double zconv;
+            bool coin;
+            if (land_convert(P, o, k, rng, ph, chain_has_angles(P), x0, y0, zconv, coin)) {
+                const double zf = dtanh_pos(ddiv(zconv, 12.0));
+                zs = coin ? -zf : zf;
+            } else flux = 0.0;
+        }
+        pool.x[i] = x0; pool.y[i] = y0; pool.flux[i] = flux; pool.dxdz[i] = zs;
+        return;
+    }
     pool.x[i] = ph.x; pool.y[i] = ph.y; pool.flux[i] = ph.flux;
     pool.dxdz[i] = ph.dxdz; pool.dydz[i] = ph.dydz; pool.wavelength[i] = ph.wl;
     if (pool.pupil_u) { pool.pupil_u[i] = ph.pu; pool.pupil_v[i] = ph.pv; pool.time[i] = ph.t; }
@@ -305,7 +332,8 @@ __global__ __launch_bounds__(256) void k_accumulate(const ims_render_params_t P,
 }
 
 // sensor.accumulate for one ROUND of the bright objects: segment-mapped like the fused kernel, but
-// the photon (already through the op chain) is loaded from the pool at pool_start[object] + j.
+// the photon (already through the op chain AND the boundary-independent half of the sensor step: the
+// `converted` pool format) is loaded from the pool at pool_start[object] + j.
 // One workgroup = the photons [j0, j0 + 256) of object `oi` (clipped to j_end).
 template <int NV = 0>
 __device__ __forceinline__ void accumulate_segment(const ims_render_params_t& P, const ims_photons_t& pool,
@@ -317,25 +345,40 @@ __device__ __forceinline__ void accumulate_segment(const ims_render_params_t& P,
     if ((int)threadIdx.x >= n_thr) return;                                      // photon-less wavefronts leave at once
     const int64_t j = j0 + threadIdx.x;
     const bool silicon = (P.sensor != nullptr) && (P.sensor->kind == IMS_SENSOR_SILICON);
-    const bool has_angles = chain_has_angles(P);
     __shared__ float tile[CT * CT];
     ChargeTile ct;
+    PROBE(1);
     tile_begin(tile, ct, P, o, silicon, n_thr);
+    PROBE(2);
+    PROBE_WG(1, 0);
     double added = 0.0;
     if (j < j_end) {
         const int64_t i = pool_start[oi] + j;
-        Photon ph;
-        ph.x = pool.x[i]; ph.y = pool.y[i]; ph.flux = pool.flux[i]; ph.dxdz = pool.dxdz[i]; ph.dydz = pool.dydz[i];
-        ph.wl = pool.wavelength[i]; ph.pu = 0.0; ph.pv = 0.0; ph.t = 0.0;
         int ix, iy;
-        Rng rng;
-        rng_reset(rng);
-        if (ph.flux != 0.0 && land<NV>(P, o, o.phot_first + j, rng, ph, silicon, has_angles, ix, iy)) {
-            added = ph.flux;
-            tile_deposit(tile, ct, P, ix, iy, ph.flux);
+        // the photon arrives at its conversion depth, diffused (converted pool): only the pixel search is left
+        const double x0 = pool.x[i], y0 = pool.y[i], flux = pool.flux[i], zs = pool.dxdz[i];
+        bool ok = false;
+        if (flux != 0.0) {
+            PROBE(3);
+            PROBE_WG(2, 0);
+            if (!silicon || (o.flags & IMS_OBJ_FAINT)) {
+                ix = (int)floor(x0 + 0.5); iy = (int)floor(y0 + 0.5);
+                ok = !(ix < o.stamp_xmin || ix > o.stamp_xmax || iy < o.stamp_ymin || iy > o.stamp_ymax);
+            } else {
+                const bool coin = __double_as_longlong(zs) < 0;
+                ok = land_search<NV, true>(P, o, x0, y0, fabs(zs), coin, ix, iy);
+            }
+        }
+        PROBE(4);
+        PROBE_WG(5, 0);
+        if (ok) {
+            added = flux;
+            tile_deposit(tile, ct, P, ix, iy, flux);
         }
     }
     tile_flush(tile, ct, P, n_thr);
+    PROBE(6);
+    PROBE_WG(7, 0);
     if (P.realized_flux != nullptr) {
         const double tot = wave_sum(added);
         if ((threadIdx.x & 63) == 0 && tot != 0.0) unsafeAtomicAdd(P.realized_flux + oi, tot);
@@ -357,11 +400,15 @@ __global__ __launch_bounds__(256) void k_accumulate_segments(const ims_render_pa
 // The same for round `round` of a chain class whose table holds the objects' FULL photon counts: the round covers the
 // photons [round * nrecalc, (round + 1) * nrecalc) of every object, `segs` = ceil(nrecalc / 256) workgroups per object;
 // the first n_active rows (sorted by photon count, brightest first) are the objects that reach this round.
+// At most 128 VGPRs (4 and 0 vertices; 8 needs the whole file): the rounds share the GPU with the 128-VGPR photon kernels,
+// and a wave that needs 136 registers only starts where TWO of those have left a SIMD (measured: the rounds 4 x slower).
 template <int NV>
-__global__ __launch_bounds__(256) void k_accumulate_round(const ims_render_params_t P, const ims_photons_t pool,
+__global__ __launch_bounds__(256, (NV == 8) ? 2 : 4) void k_accumulate_round(const ims_render_params_t P, const ims_photons_t pool,
                                                           const int64_t* __restrict__ pool_start, int64_t round_first, int32_t nrecalc,
                                                           int32_t segs)
 {
+    PROBE(0);
+    PROBE_WG(0, 0);
     const int64_t oi = blockIdx.x / segs;
     const int64_t j0 = round_first + (int64_t)(blockIdx.x % segs) * 256;
     int64_t j_end = round_first + nrecalc;
@@ -578,13 +625,6 @@ __global__ __launch_bounds__(256) void k_update_distortions(const ims_sensor_t* 
 }
 
 // LDS of one q3 tile update: scaled charges of the halo, per-row occupancy bitmaps, displacement table
-#ifdef IMS_UPD_PROBE
-__device__ unsigned long long g_upd_probe[16];
-#define UPD_STAMP(k) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_upd_probe[k] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define UPD_STAMP(k) do { } while (0)
-#endif
-
 template <int NV>
 struct UpdateLds {
     static constexpr int Q = 3, HW = UT + 2 * Q + 1, NPO = 2 * NV + 2;
@@ -617,7 +657,7 @@ __device__ __forceinline__ void update_tile_q3(const ims_sensor_t& s, const Slot
 {
     constexpr int Q = 3, HW = UT + 2 * Q + 1, NPO = 2 * NV + 2;
     const int sx0 = tx0 - (Q + 1), sy0 = ty0 - (Q + 1);
-    UPD_STAMP(1);
+    PROBE(9);
     if (threadIdx.x < HW) L.occ[threadIdx.x] = 0u;
     if (threadIdx.x == 0) L.any_charge = 0;
     __syncthreads();
@@ -632,7 +672,7 @@ __device__ __forceinline__ void update_tile_q3(const ims_sensor_t& s, const Slot
         L.wt[e] = w;
     }
     __syncthreads();
-    UPD_STAMP(2);
+    PROBE(10);
     const int lx = threadIdx.x % UT, ly = threadIdx.x / UT;
     const int i = tx0 + lx, j = ty0 + ly;
     if (!L.any_charge) {                     // nothing landed near this tile: nothing moves
@@ -643,7 +683,7 @@ __device__ __forceinline__ void update_tile_q3(const ims_sensor_t& s, const Slot
         load_displacements<NV>(s, L);
         __syncthreads();
     }
-    UPD_STAMP(3);
+    PROBE(11);
     if (i > sl.nx || j > sl.ny) return;
     // 64-bit window: byte a <-> dj = -Q + a (row hy = ly + 2Q + 1 - a); inside a byte bit bb <-> di = -Q + bb
     // (column hx = lx + 2Q + 1 - bb), i.e. the row bitmap reversed.
@@ -662,7 +702,7 @@ __device__ __forceinline__ void update_tile_q3(const ims_sensor_t& s, const Slot
     double acc[NPO * 2];
 #pragma unroll
     for (int n = 0; n < NPO * 2; ++n) acc[n] = pts[n];
-    UPD_STAMP(4);
+    PROBE(12);
     // The 8 x 8 source window with STATIC offsets, in the spec's order (dj ascending, then di ascending).  A bright
     // star's region is a few hundred tiles, so a SIMD holds ONE wavefront and nothing hides latency: the bit-walking loop
     // (address of the displacement row from the next set bit) waited ~850 cycles per neighbour.  Here every row of the
@@ -696,10 +736,10 @@ __device__ __forceinline__ void update_tile_q3(const ims_sensor_t& s, const Slot
             }
         }
     }
-    UPD_STAMP(5);
+    PROBE(13);
 #pragma unroll
     for (int n = 0; n < NPO * 2; ++n) pts[n] = acc[n];
-    UPD_STAMP(6);
+    PROBE(14);
 }
 
 // Fast path for qdist == 3 (the GalSim default): the 8x8 source window of a cell is a 64-bit
@@ -715,7 +755,7 @@ __global__ __launch_bounds__(256) void k_update_distortions_q3(const ims_sensor_
                                                                const double* __restrict__ dl_global)
 {
     __shared__ UpdateLds<NV> L;
-    UPD_STAMP(0);
+    PROBE(8);
     const ims_sensor_t& s = *sp;
     const int64_t b = blockIdx.x;
     int lo = 0, hi = n_slots;
@@ -816,6 +856,7 @@ __global__ __launch_bounds__(256) void k_refresh_changed(const ims_sensor_t* __r
                                                          const int64_t* __restrict__ tile_prefix,
                                                          const unsigned char* __restrict__ changed, unsigned int tag)
 {
+    PROBE(16);
     const ims_sensor_t& s = *sp;
     const int64_t b = blockIdx.x;
     int lo = 0, hi = n_slots;
@@ -838,317 +879,9 @@ __global__ __launch_bounds__(256) void k_refresh_changed(const ims_sensor_t* __r
         charged = s.bf_tile_charge[cell_index(sl, tx * UT, ty * UT)] == tg;
         if (!(own || right || up || charged)) return;
     }
+    PROBE(17);
     refresh_tile<NV>(s, sl, tx, ty, own, right, up, charged, changed);
-}
-
-// ---------------- persistent brighter-fatter chain (LSST_Image mode, bright objects) ----------------
-// A bright object's sensor step is a chain of rounds: nrecalc photons through the sensor, then
-// updatePixelDistortions on its private region, then the bounds refresh (imsim/stamp.py:558-573 with the sensor's
-// nrecalc).  As three launches per round the chain is launch-latency bound (~75 us per round).  Here ONE launch runs
-// whole chains: a TEAM of up to G workgroups, all resident on the SAME XCD, takes an object from a queue and walks its
-// rounds with three team barriers per round (accumulate | update | refresh).  Because a team shares one L2, a
-// barrier is "my stores have reached L2" (s_waitcnt vmcnt(0)) + a counter + an L1 invalidate -- no L2 write-back.
-// Placement independence: a worker joins a team of the XCD it actually runs on (HW_REG_XCC_ID), teams are formed from
-// the workgroups that are running, so any workgroup -> XCD mapping and any residency gives a correct (if differently
-// balanced) run; every spin is bounded and reports through ctl->error.
-constexpr int BFC_MAX_TEAMS = 64;        // teams per XCD
-constexpr int BFC_MAX_TILES = 4096;      // 16x16-cell tiles of one region (regions up to 1023 pixels on a side)
-constexpr int BFC_WORDS = BFC_MAX_TILES / 32;
-constexpr unsigned int BFC_SPIN_LIMIT = 40u * 1000u * 1000u;   // polls (with s_sleep): a few seconds
-
-struct BfChainCtl {
-    unsigned int next_object;
-    unsigned int error;
-    unsigned int pad[2];
-    unsigned int open_team[N_XCD];                  // first team of the XCD that may still be open (a hint)
-    unsigned int team_state[N_XCD][BFC_MAX_TEAMS];  // members joined (low 16 bits) | closed (bit 31)
-    unsigned int team_bar[N_XCD][BFC_MAX_TEAMS];
-    unsigned int team_obj[N_XCD][BFC_MAX_TEAMS][2];
-    unsigned int bitmap[N_XCD][BFC_MAX_TEAMS][BFC_WORDS];
-    unsigned long long prof[16];                    // -DIMS_BFC_PROFILE: 10 ns ticks per phase of the team that ran object 0
-};
-#ifdef IMS_BFC_PROFILE
-#define BFC_TICK(k) do { if (prof_on && tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); \
-                         ctl->prof[k] += t_ - prof_t; prof_t = t_; } } while (0)
-#else
-#define BFC_TICK(k) do { } while (0)
-#endif
-
-#define BFC_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define BFC_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define BFC_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-
-__device__ __forceinline__ int xcc_id()
-{
-    unsigned int x;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-    return (int)(x & 7u);
-}
-
-// spin until *p >= target (relaxed agent-scope polls); false on timeout
-__device__ __forceinline__ bool bfc_wait_ge(unsigned int* p, unsigned int target, unsigned int* err)
-{
-    for (unsigned int spins = 0; ; ++spins) {
-        if (BFC_LOAD(p) >= target) return true;
-        if (BFC_LOAD(err) != 0u) return false;
-        if (spins > BFC_SPIN_LIMIT) { BFC_STORE(err, 1u); return false; }
-        __builtin_amdgcn_s_sleep(2);
-    }
-}
-
-// Team barrier.  Every wave drains its own memory operations (stores and atomics have reached the XCD's L2 / memory),
-// the workgroup joins, lane 0 arrives on the team counter and polls it, then ONE agent-scope acquire drops the CU's
-// stale L1 lines for the whole workgroup.  Returns false when the launch is being aborted.
-__device__ __forceinline__ bool team_barrier(unsigned int* bar, unsigned int& target, int M, unsigned int* err, int* s_ok)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    target += (unsigned int)M;
-    if (threadIdx.x == 0) {
-        bool ok = true;
-        if (M > 1) {
-            BFC_ADD(bar, 1u);
-            ok = bfc_wait_ge(bar, target, err);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        *s_ok = ok ? 1 : 0;
-    }
-    __syncthreads();
-    return *s_ok != 0;
-}
-
-template <int NV>
-struct BfChainLds {
-    UpdateLds<NV> upd;
-    float tile[CT * CT];
-    unsigned int bm[BFC_WORDS];           // charged tiles of this round (copy of the team's global bitmap)
-    unsigned int a1[BFC_WORDS];           // tiles the update must visit (charge within reach)
-    unsigned short mine[BFC_MAX_TILES];   // tiles assigned to this workgroup
-    int wave_cnt[4];
-    int ok;
-    unsigned int u0, u1;
-};
-
-__device__ __forceinline__ bool bit_at(const unsigned int* bm, int tx, int ty, int tiles_x, int tiles_y)
-{
-    if (tx < 0 || ty < 0 || tx >= tiles_x || ty >= tiles_y) return false;
-    const int t = ty * tiles_x + tx;
-    return (bm[t >> 5] >> (t & 31)) & 1u;
-}
-
-// Deterministic partition of the tiles that satisfy `pred` among the M workgroups of a team: tile of rank k (in
-// index order) goes to member k % M.  Every member evaluates the same predicate on the same bitmap snapshot.
-template <typename Pred>
-__device__ __forceinline__ int assign_tiles(int n_tiles, int m, int M, unsigned short* mine, int* wave_cnt, Pred pred)
-{
-    int base = 0;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int q = 0; q * 256 < n_tiles; ++q) {
-        const int t = q * 256 + (int)threadIdx.x;
-        const bool act = t < n_tiles && pred(t);
-        const unsigned long long b = __ballot(act);
-        if (lane == 0) wave_cnt[w] = __popcll(b);
-        __syncthreads();
-        int off = base;
-        for (int k = 0; k < w; ++k) off += wave_cnt[k];
-        const int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        if (act) {
-            const int rank = off + __popcll(b & ((1ull << lane) - 1ull));
-            if (rank % M == m) mine[rank / M] = (unsigned short)t;
-        }
-        base += tot;
-        __syncthreads();
-    }
-    return base > m ? (base - m - 1) / M + 1 : 0;
-}
-
-template <int NV>
-__global__ __launch_bounds__(256) void k_bf_chain(const ims_render_params_t P, const ims_photons_t pool,
-                                                  const int64_t* __restrict__ pool_start, int round_begin, int round_end,
-                                                  int nrecalc, unsigned char* __restrict__ changed, BfChainCtl* ctl,
-                                                  int G)
-{
-    __shared__ BfChainLds<NV> L;
-    const ims_sensor_t& s = *P.sensor;
-    const int tid = (int)threadIdx.x;
-    // ---- team formation on the XCD this workgroup actually runs on ----
-    // A worker joins the XCD's open team (CAS on the team word: member count + closed bit).  The first member closes
-    // the team when it is full or after ~20 us, whichever comes first; later arrivals open the next team.  So teams
-    // only ever contain workgroups that are running: no launch-wide rendezvous, any residency makes progress.
-    const int x = xcc_id();
-    if (tid == 0) {
-        constexpr unsigned int CLOSED = 0x80000000u;
-        int t = (int)BFC_LOAD(&ctl->open_team[x]);
-        int me = -1;
-        while (t < BFC_MAX_TEAMS) {
-            unsigned int st = BFC_LOAD(&ctl->team_state[x][t]);
-            if ((st & CLOSED) || (int)(st & 0xFFFFu) >= G) { ++t; continue; }
-            if (__hip_atomic_compare_exchange_strong(&ctl->team_state[x][t], &st, st + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT)) { me = (int)(st & 0xFFFFu); break; }
-        }
-        unsigned int members = 0u;
-        if (me == 0) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
-            for (;;) {
-                unsigned int st = BFC_LOAD(&ctl->team_state[x][t]);
-                const bool full = (int)(st & 0xFFFFu) >= G;
-                if (full || __builtin_amdgcn_s_memrealtime() - t0 > 2000ull) {
-                    if (__hip_atomic_compare_exchange_strong(&ctl->team_state[x][t], &st, st | CLOSED, __ATOMIC_RELAXED,
-                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        members = st & 0xFFFFu;
-                        break;
-                    }
-                } else __builtin_amdgcn_s_sleep(1);
-            }
-            BFC_STORE(&ctl->open_team[x], (unsigned int)(t + 1));
-        } else if (me > 0) {
-            for (unsigned int spins = 0; ; ++spins) {
-                const unsigned int st = BFC_LOAD(&ctl->team_state[x][t]);
-                if (st & CLOSED) { members = st & 0xFFFFu; break; }
-                if (spins > BFC_SPIN_LIMIT) { BFC_STORE(&ctl->error, 2u); break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-        }
-        L.u0 = (unsigned int)me;
-        L.u1 = members;
-        L.ok = t;
-    }
-    __syncthreads();
-    const int m = (int)L.u0, M = (int)L.u1, team = L.ok;
-    if (m < 0 || M < 1) return;             // no team slot left on this XCD (or the launch is being aborted)
-    __syncthreads();
-    load_displacements<NV>(s, L.upd);
-    unsigned int* bar = &ctl->team_bar[x][team];
-    unsigned int* gbm = ctl->bitmap[x][team];
-    unsigned int bar_target = 0u;
-    const bool has_angles = chain_has_angles(P);
-    for (unsigned int epoch = 0; ; ++epoch) {
-        if (m == 0 && tid == 0) BFC_STORE(&ctl->team_obj[x][team][epoch & 1u], BFC_ADD(&ctl->next_object, 1u));
-        if (!team_barrier(bar, bar_target, M, &ctl->error, &L.ok)) return;
-        const unsigned int oi = BFC_LOAD(&ctl->team_obj[x][team][epoch & 1u]);
-        if ((int64_t)oi >= P.n_objects) return;
-        const ims_object_t& o = P.objects[oi];
-        const ims_bf_slot_t bs = s.bf_slots[o.bf_state];
-        const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
-        const int tiles_x = (sl.nx + 1 + UT - 1) / UT, tiles_y = (sl.ny + 1 + UT - 1) / UT;
-        const int n_tiles = tiles_x * tiles_y;
-#ifdef IMS_BFC_PROFILE
-        const bool prof_on = (oi == 0u && m == 0);
-        unsigned long long prof_t = __builtin_amdgcn_s_memrealtime();
-        if (prof_on && tid == 0) { ctl->prof[8] = (unsigned long long)M; ctl->prof[9] = (unsigned long long)n_tiles; }
-#endif
-        const int n_words = (n_tiles + 31) >> 5;
-        const int64_t n_rounds = (o.n_phot + nrecalc - 1) / nrecalc;
-        const int64_t r_end = n_rounds < round_end ? n_rounds : (int64_t)round_end;
-        const int64_t pstart = pool_start[oi];
-        double added = 0.0;
-        ChargeTile ct;
-        ct.x0 = (int)floor(o.x0 + 0.5) - CT / 2;
-        ct.y0 = (int)floor(o.y0 + 0.5) - CT / 2;
-        ct.track = true;
-        ct.slot = bs;
-        for (int64_t r = round_begin; r < r_end; ++r) {
-            const int64_t j0 = r * nrecalc;
-            const int64_t j1 = (j0 + nrecalc < o.n_phot) ? j0 + nrecalc : o.n_phot;
-            const bool cont = o.n_phot > j1;           // the object goes on: its boundaries are recalculated after this round
-            // ---- phase A: this round's photons through the sensor ----
-            for (int e = tid; e < CT * CT; e += 256) L.tile[e] = 0.0f;
-            for (int e = tid; e < n_words; e += 256) L.bm[e] = 0u;
-            __syncthreads();
-            for (int64_t jb = j0 + (int64_t)m * 256; jb < j1; jb += (int64_t)M * 256) {
-                const int64_t j = jb + tid;
-                if (j < j1) {
-                    const int64_t i = pstart + j;
-                    Photon ph;
-                    ph.x = pool.x[i]; ph.y = pool.y[i]; ph.flux = pool.flux[i]; ph.dxdz = pool.dxdz[i]; ph.dydz = pool.dydz[i];
-                    ph.wl = pool.wavelength[i]; ph.pu = 0.0; ph.pv = 0.0; ph.t = 0.0;
-                    int ix, iy;
-                    Rng rng;
-                    rng_reset(rng);
-                    if (ph.flux != 0.0 && land(P, o, o.phot_first + j, rng, ph, true, has_angles, ix, iy)) {
-                        added += ph.flux;
-                        const int tx = ix - ct.x0, ty = iy - ct.y0;
-                        if (ph.flux == 1.0 && tx >= 0 && tx < CT && ty >= 0 && ty < CT) atomicAdd(&L.tile[ty * CT + tx], 1.0f);
-                        else {
-                            deposit_global(P, ct, ix, iy, ph.flux);
-                            const int di = ix - sl.xmin, dj = iy - sl.ymin;
-                            if (di >= 0 && di < sl.nx && dj >= 0 && dj < sl.ny) {
-                                const int t = (dj >> 4) * tiles_x + (di >> 4);
-                                atomicOr(&L.bm[t >> 5], 1u << (t & 31));
-                            }
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            for (int e = tid; e < CT * CT; e += 256) {
-                const float v = L.tile[e];
-                if (v != 0.0f) {
-                    const int ix = ct.x0 + e % CT, iy = ct.y0 + e / CT;
-                    deposit_global(P, ct, ix, iy, (double)v);
-                    const int di = ix - sl.xmin, dj = iy - sl.ymin;
-                    if (di >= 0 && di < sl.nx && dj >= 0 && dj < sl.ny) {
-                        const int t = (dj >> 4) * tiles_x + (di >> 4);
-                        atomicOr(&L.bm[t >> 5], 1u << (t & 31));
-                    }
-                }
-            }
-            if (!cont) break;                          // last round: no recalculation follows (the delta charge stays)
-            __syncthreads();
-            for (int e = tid; e < n_words; e += 256)
-                if (L.bm[e] != 0u) __hip_atomic_fetch_or(&gbm[e], L.bm[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            BFC_TICK(0);
-            if (!team_barrier(bar, bar_target, M, &ctl->error, &L.ok)) return;
-            BFC_TICK(1);
-            // ---- phase B1: updatePixelDistortions on the tiles within reach of this round's charge ----
-            for (int e = tid; e < n_words; e += 256) { L.bm[e] = BFC_LOAD(&gbm[e]); L.a1[e] = 0u; }
-            __syncthreads();
-            const int n1 = assign_tiles(n_tiles, m, M, L.mine, L.wave_cnt, [&](int t) {
-                const int tx = t % tiles_x, ty = t / tiles_x;
-                bool any = false;
-                for (int dy = -1; dy <= 1; ++dy)
-                    for (int dx = -1; dx <= 1; ++dx) any = any || bit_at(L.bm, tx + dx, ty + dy, tiles_x, tiles_y);
-                if (any) atomicOr(&L.a1[t >> 5], 1u << (t & 31));
-                return any;
-            });
-            BFC_TICK(2);
-#ifdef IMS_BFC_PROFILE
-            if (prof_on && tid == 0) { ctl->prof[10] += (unsigned long long)n1; ctl->prof[12] += 1ull; }
-#endif
-            for (int k = 0; k < n1; ++k) {
-                const int t = L.mine[k];
-                update_tile_q3<NV>(s, sl, (t % tiles_x) * UT, (t / tiles_x) * UT, changed, L.upd, true, 0u);
-                __syncthreads();
-            }
-            BFC_TICK(3);
-            if (!team_barrier(bar, bar_target, M, &ctl->error, &L.ok)) return;
-            BFC_TICK(4);
-            // ---- phase B2: bounds of the pixels whose polygon moved; the consumed delta charge is zeroed ----
-            const int n2 = assign_tiles(n_tiles, m, M, L.mine, L.wave_cnt, [&](int t) {
-                const int tx = t % tiles_x, ty = t / tiles_x;
-                return bit_at(L.a1, tx, ty, tiles_x, tiles_y) || bit_at(L.a1, tx + 1, ty, tiles_x, tiles_y) ||
-                       bit_at(L.a1, tx, ty + 1, tiles_x, tiles_y);
-            });
-            for (int k = 0; k < n2; ++k) {
-                const int t = L.mine[k];
-                const int tx = t % tiles_x, ty = t / tiles_x;
-                refresh_tile<NV>(s, sl, tx, ty, bit_at(L.a1, tx, ty, tiles_x, tiles_y), bit_at(L.a1, tx + 1, ty, tiles_x, tiles_y),
-                                 bit_at(L.a1, tx, ty + 1, tiles_x, tiles_y), bit_at(L.bm, tx, ty, tiles_x, tiles_y), changed);
-            }
-            if (m == 0)
-                for (int e = tid; e < n_words; e += 256) BFC_STORE(&gbm[e], 0u);
-            BFC_TICK(5);
-#ifdef IMS_BFC_PROFILE
-            if (prof_on && tid == 0) ctl->prof[11] += (unsigned long long)n2;
-#endif
-            if (!team_barrier(bar, bar_target, M, &ctl->error, &L.ok)) return;
-            BFC_TICK(6);
-        }
-        if (P.realized_flux != nullptr) {
-            const double tot = wave_sum(added);
-            if ((tid & 63) == 0 && tot != 0.0) unsafeAtomicAdd(P.realized_flux + oi, tot);
-        }
-    }
+    PROBE(18);
 }
 
 // ---------------- LSST_Flat ----------------
@@ -1596,7 +1329,7 @@ int ims_shoot_photons(const ims_render_params_t* params, const int64_t* photon_o
     if (params->n_segments == 0) return IMS_OK;
     hipStream_t st = (hipStream_t)stream;
     {
-        hipLaunchKernelGGL(k_shoot_photons<false>, dim3(grid_for_segments(params->n_segments)), dim3(256), 0, st,
+        hipLaunchKernelGGL(k_shoot_photons<0>, dim3(grid_for_segments(params->n_segments)), dim3(256), 0, st,
                            *params, photon_offset, *pool);
     }
     HIP_TRY(hipGetLastError());
@@ -1609,12 +1342,18 @@ int ims_shoot_ops_photons(const ims_render_params_t* params, const int64_t* phot
     int rc = check_params(params);
     if (rc) return rc;
     if (!photon_offset || !pool) return set_err(IMS_ERR_ARG, "photon_offset/pool is NULL");
+    if (!pool->x || !pool->y || !pool->flux || !pool->dxdz) return set_err(IMS_ERR_ARG, "pool: x / y / flux / dxdz is NULL");
+    if (!pool->converted && (!pool->dydz || !pool->wavelength)) return set_err(IMS_ERR_ARG, "pool: dydz / wavelength is NULL");
     if (params->n_segments == 0) return IMS_OK;
     hipStream_t st = (hipStream_t)stream;
     {
         LaunchTimer tm(st, 2);
-        hipLaunchKernelGGL(k_shoot_photons<true>, dim3(grid_for_segments(params->n_segments)), dim3(256), 0, st,
-                           *params, photon_offset, *pool);
+        if (pool->converted)
+            hipLaunchKernelGGL(k_shoot_photons<2>, dim3(grid_for_segments(params->n_segments)), dim3(256), 0, st,
+                               *params, photon_offset, *pool);
+        else
+            hipLaunchKernelGGL(k_shoot_photons<1>, dim3(grid_for_segments(params->n_segments)), dim3(256), 0, st,
+                               *params, photon_offset, *pool);
     }
     HIP_TRY(hipGetLastError());
     return IMS_OK;
@@ -1626,6 +1365,7 @@ int ims_accumulate_segments(const ims_render_params_t* params, const ims_photons
     int rc = check_params(params);
     if (rc) return rc;
     if (!pool || !pool_start) return set_err(IMS_ERR_ARG, "pool/pool_start is NULL");
+    if (!pool->converted) return set_err(IMS_ERR_ARG, "pool must hold converted photons (ims_shoot_ops_photons with pool->converted = 1)");
     if (!params->image) return set_err(IMS_ERR_ARG, "image is NULL");
     if (params->n_segments == 0) return IMS_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -1643,6 +1383,7 @@ int ims_accumulate_round(const ims_render_params_t* params, const ims_photons_t*
     if (!params) return set_err(IMS_ERR_ARG, "params is NULL");
     if (!params->objects || !params->image) return set_err(IMS_ERR_ARG, "objects/image is NULL");
     if (!pool || !pool_start) return set_err(IMS_ERR_ARG, "pool/pool_start is NULL");
+    if (!pool->converted) return set_err(IMS_ERR_ARG, "pool must hold converted photons (ims_shoot_ops_photons with pool->converted = 1)");
     if (round < 0 || nrecalc <= 0) return set_err(IMS_ERR_ARG, "round must be >= 0 and nrecalc positive");
     if (n_active < 0 || n_active > params->n_objects) return set_err(IMS_ERR_ARG, "n_active out of range");
     if (n_active == 0) return IMS_OK;
@@ -1764,45 +1505,6 @@ int ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sens
     return IMS_OK;
 }
 
-#ifdef IMS_UPD_PROBE
-int ims_upd_probe(unsigned long long* out16) { return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_upd_probe), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1; }
-#endif
-
-int ims_bf_chain_ctl_bytes(void) { return (int)sizeof(BfChainCtl); }
-
-int ims_bf_chain(const ims_render_params_t* params, const ims_photons_t* pool, const int64_t* pool_start,
-                 int32_t round_begin, int32_t round_end, int32_t nrecalc, const ims_sensor_t* sensor_host,
-                 unsigned char* changed_dev, void* ctl_dev, int32_t n_workers, int32_t team_size, void* stream)
-{
-    int rc = check_params(params);
-    if (rc) return rc;
-    if (!pool || !pool_start || !changed_dev || !ctl_dev) return set_err(IMS_ERR_ARG, "pool/pool_start/changed/ctl is NULL");
-    if (!params->image || !params->sensor || !sensor_host) return set_err(IMS_ERR_ARG, "image/sensor is NULL");
-    if (round_begin < 0 || round_end <= round_begin || nrecalc <= 0) return set_err(IMS_ERR_ARG, "bad round range / nrecalc");
-    if (n_workers < 1 || team_size < 1 || n_workers > 2048) return set_err(IMS_ERR_ARG, "n_workers / team_size out of range");
-    if (sensor_host->qdist != 3 || (sensor_host->num_vertices != 4 && sensor_host->num_vertices != 8))
-        return set_err(IMS_ERR_UNSUPPORTED, "ims_bf_chain needs qdist 3 and 4 or 8 vertices per edge (use the per-round entry points)");
-    if (params->n_objects == 0) return IMS_OK;
-    hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemsetAsync(ctl_dev, 0, sizeof(BfChainCtl), st));
-    if (sensor_host->num_vertices == 4)
-        hipLaunchKernelGGL(k_bf_chain<4>, dim3((unsigned)n_workers), dim3(256), 0, st, *params, *pool, pool_start, round_begin,
-                           round_end, nrecalc, changed_dev, (BfChainCtl*)ctl_dev, team_size);
-    else
-        hipLaunchKernelGGL(k_bf_chain<8>, dim3((unsigned)n_workers), dim3(256), 0, st, *params, *pool, pool_start, round_begin,
-                           round_end, nrecalc, changed_dev, (BfChainCtl*)ctl_dev, team_size);
-    HIP_TRY(hipGetLastError());
-    return IMS_OK;
-}
-
-int ims_bf_chain_status(const void* ctl_dev, int32_t* error)
-{
-    if (!ctl_dev || !error) return set_err(IMS_ERR_ARG, "ctl/error is NULL");
-    unsigned int e = 0;
-    HIP_TRY(hipMemcpy(&e, (const char*)ctl_dev + offsetof(BfChainCtl, error), sizeof(e), hipMemcpyDeviceToHost));
-    *error = (int32_t)e;
-    return IMS_OK;
-}
 
 // library events of RECORD / WAIT items (one process per GPU)
 static int plan_event(int number, hipEvent_t* out)
@@ -1896,8 +1598,6 @@ int ims_run_plan(const ims_plan_item_t* items, int64_t n_items, const ims_sensor
         case IMS_PLAN_UPDATE:     rc = ims_sensor_update_distortions(sensor_dev, sensor_host, it.first_slot, it.n_slots, it.aux,
                                                                      it.n_tiles, changed_dev, it.tag, st); break;
         case IMS_PLAN_INIT:       rc = ims_sensor_init_boundaries(sensor_dev, sensor_host, it.first_slot, it.n_slots, st); break;
-        case IMS_PLAN_CHAIN:      rc = ims_bf_chain(it.params, it.pool, it.aux, it.first_slot, it.n_slots, (int32_t)it.n_tiles, sensor_host,
-                                                    changed_dev, it.aux2, (int32_t)it.tag, (int32_t)it.pad, st); break;
         case IMS_PLAN_ROUNDS:     rc = run_rounds((const ims_chain_t*)it.aux2, it.n_slots, sensor_dev, sensor_host, changed_dev, streams,
                                                   n_streams); break;
         case IMS_PLAN_RECORD:

@@ -537,14 +537,7 @@ class Renderer:
         self.use_bf_tags = os.environ.get("IMS_BF_TAGS", "0") != "0"
         # round-count thresholds that cut the bright objects into concurrent chains (plan_lsst_image)
         self.chain_class_rounds = tuple(int(v) for v in os.environ.get("IMS_CHAIN_CLASSES", "40,6").split(",") if v)
-        self.max_pool_photons = 300_000_000      # 48 B each
-        # persistent brighter-fatter chains (ims_bf_chain): most workgroups a launch may use and the largest team.
-        # Off by default: measured slower than three launches per round on MI355X ("persistent chain");
-        # IMS_BF_CHAIN=1 turns it on for the slices of rounds where every active object gets a full team.
-        self.use_chain = os.environ.get("IMS_BF_CHAIN", "0") != "0"
-        self.chain_workers = int(os.environ.get("IMS_CHAIN_WORKERS", "320"))
-        self.chain_team = int(os.environ.get("IMS_CHAIN_TEAM", "40"))
-        self._chain_ctl = {}
+        self.max_pool_photons = 300_000_000      # 32 B each
         if scene.sensor is not None:
             self.init_boundaries(0, len(scene.sensor.slots))
 
@@ -552,14 +545,17 @@ class Renderer:
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
 
-    POOL6 = ("x", "y", "flux", "dxdz", "dydz", "wavelength")
+    # what the pixel search of a brighter-fatter round needs of a photon: the `converted` pool format of
+    # ims_photons_t (position at the conversion depth, flux, polygon shrink factor with the coin in its sign)
+    POOL4 = ("x", "y", "flux", "dxdz")
 
-    def _pool6(self, n):
-        """A compact pool holding only what the sensor needs of a photon."""
-        t = {f: self.torch.empty(max(int(n), 1), dtype=self.torch.float64, device=self.device) for f in self.POOL6}
+    def _pool4(self, n):
+        """A compact pool of converted photons (32 B each)."""
+        t = {f: self.torch.empty(max(int(n), 1), dtype=self.torch.float64, device=self.device) for f in self.POOL4}
         ph = Photons()
         ph.n = int(n)
-        for f in self.POOL6:
+        ph.converted = 1
+        for f in self.POOL4:
             setattr(ph, f, t[f].data_ptr())
         return ph, t
 
@@ -647,7 +643,7 @@ class Renderer:
             grp["bf_state"] = n0 + np.arange(len(grp))
             total = grp["n_phot"].copy()
             offs = np.concatenate([[0], np.cumsum(total)]).astype(np.int64)
-            pool, pool_t = self._pool6(offs[-1])
+            pool, pool_t = self._pool4(offs[-1])
             n_rounds = (total + nrecalc - 1) // nrecalc
             # An object's rounds only depend on its OWN earlier rounds, so the few very bright objects
             # (hundreds of short, latency-bound rounds) must not wait for the many moderately bright
@@ -708,89 +704,19 @@ class Renderer:
             #    ims_run_plan derives every round's launches from the class table (objects sorted by photon count, so
             #    the objects of a round are a prefix of it) and enqueues the classes round-robin, one round each, so
             #    that all chains advance at the same pace.  No per-round tables, no per-round Python.
-            if not self.use_chain:
-                descs = []
-                for ch in chains:
-                    start_t = arena.ref(ch["offs"])
-                    P, keep = upload(ch["grp"], ch["idx"], "acc_pool")
-                    descs.append(dict(P=P, keep=(keep, start_t), pool=pool, start=start_t,
-                                      n_phot=np.ascontiguousarray(ch["tot"], dtype=np.int64), first_slot=n0 + ch["ca"],
-                                      stream=ch["stream"], rounds=ch["rounds"], edges=ch["edges"], ev_base=ch["ev_base"]))
-                plan.append(("rounds", descs, int(nrecalc), 1 if self.use_bf_tags else 0))
-                continue
-            # legacy form (kept for the persistent-chain experiment, IMS_BF_CHAIN=1): per class a list of
-            #    units (one round = accumulate + update, or one persistent launch over a slice of rounds); the classes'
-            #    units are merged round-robin so that the host enqueues all chains at the same pace.
-            chain_ok = self._chain_ok(grp)
-            units = []
+            descs = []
             for ch in chains:
-                ctot, cgrp, edges = ch["tot"], ch["grp"], ch["edges"]
-                mine = []
-                for k in range(len(edges) - 1):
-                    ra, rb = edges[k], edges[k + 1]
-                    head = [("wait", ch["ev_base"] + k, ch["stream"])] if k > 0 else []
-                    n_act = int(np.count_nonzero(ctot > ra * nrecalc))
-                    # A persistent launch (ims_bf_chain) pays when every object still active gets a team as wide as a
-                    # round (nrecalc / 256 workgroups): then a round costs three team barriers instead of three
-                    # launches.  With many active objects the per-round launches keep the whole GPU busy instead.
-                    team = int(min(self.chain_team, (nrecalc + 255) // 256))
-                    if chain_ok and rb - ra >= 2 and n_act * team <= self.chain_workers:
-                        part = cgrp[:n_act].copy()
-                        start_t = arena.ref(ch["offs"][:n_act])
-                        P, keep = upload(part, ch["idx"][:n_act], "chain")
-                        photons = int((np.minimum(ctot[:n_act], rb * nrecalc) - ra * nrecalc).sum())
-                        mine.append(head + [("chain", P, (keep, start_t), pool, start_t, photons, n_act, ch["stream"], ra, rb,
-                                             int(nrecalc), n_act * team, team)])
-                        continue
-                    for r in range(ra, rb):
-                        n_act = int(np.count_nonzero(ctot > r * nrecalc))
-                        part = cgrp[:n_act].copy()
-                        part["phot_first"] = cgrp["phot_first"][:n_act] + r * nrecalc
-                        part["n_phot"] = np.minimum(nrecalc, ctot[:n_act] - r * nrecalc)
-                        start_t = arena.ref(ch["offs"][:n_act] + r * nrecalc)
-                        P, keep = upload(part, ch["idx"][:n_act], "acc_pool")
-                        tag = (r % 255 + 1) if self.use_bf_tags else 0      # marks the tiles this round's charge lands in
-                        P.bf_tag = tag
-                        unit = head + [("acc_pool", P, (keep, start_t), pool, start_t, int(part["n_phot"].sum()), n_act, ch["stream"])]
-                        head = []
-                        n_cont = int(np.count_nonzero(ctot > (r + 1) * nrecalc))
-                        if n_cont:
-                            unit.append(("update", n0 + ch["ca"], n_cont, ch["stream"], tag))
-                        mine.append(unit)
-                units.append(mine)
-            for k in range(max(len(u) for u in units)):
-                for u in units:
-                    if k < len(u):
-                        plan.extend(u[k])
+                start_t = arena.ref(ch["offs"])
+                P, keep = upload(ch["grp"], ch["idx"], "acc_pool")
+                descs.append(dict(P=P, keep=(keep, start_t), pool=pool, start=start_t,
+                                  n_phot=np.ascontiguousarray(ch["tot"], dtype=np.int64), first_slot=n0 + ch["ca"],
+                                  stream=ch["stream"], rounds=ch["rounds"], edges=ch["edges"], ev_base=ch["ev_base"]))
+            plan.append(("rounds", descs, int(nrecalc), 1 if self.use_bf_tags else 0))
         if len(normal) and not render_done:
             part = objects[normal]
             part["bf_state"] = 0
             add_render(part, normal, "bulk")
         return finish()
-
-    def _chain_ok(self, grp):
-        """ims_bf_chain takes qdist 3, 4 or 8 vertices per edge and regions of at most 4096 16x16-cell tiles."""
-        m = self.scene.sensor.model
-        if not self.use_chain or m.qdist != 3 or m.num_vertices not in (4, 8):
-            return False
-        nx = grp["stamp_xmax"].astype(np.int64) - grp["stamp_xmin"] + 1
-        ny = grp["stamp_ymax"].astype(np.int64) - grp["stamp_ymin"] + 1
-        return bool(np.all(((nx + 1 + 15) // 16) * ((ny + 1 + 15) // 16) <= 4096))
-
-    def _chain_ctl_ptr(self, stream_name):
-        """control block of the persistent chain launches of one stream (launches on one stream are ordered)"""
-        if stream_name not in self._chain_ctl:
-            n = int(self.lib.ims_bf_chain_ctl_bytes())
-            self._chain_ctl[stream_name] = self.torch.zeros(n, dtype=self.torch.uint8, device=self.device)
-        return self._chain_ctl[stream_name].data_ptr()
-
-    def check_chains(self):
-        """Raise if a persistent chain launch gave up waiting for its workgroups (synchronises)."""
-        err = C.c_int32(0)
-        for name, t in self._chain_ctl.items():
-            _abi.check(self.lib.ims_bf_chain_status(t.data_ptr(), C.byref(err)), "ims_bf_chain_status")
-            if err.value:
-                raise _abi.ImsimHipError(f"brighter-fatter chain on stream '{name}' timed out waiting for its workgroups")
 
     def _compile_plan(self, plan):
         """Turn a plan into ims_plan_item_t arrays (one per stretch between host-side slot-table
@@ -833,11 +759,6 @@ class Renderer:
             elif kind == "shoot_pool":
                 it.kind, it.params, it.pool, it.aux = _abi.IMS_PLAN_SHOOT_POOL, C.addressof(item[1]), C.addressof(item[3]), item[4].data_ptr()
                 it.stream = self.STREAMS[item[7]]
-            elif kind == "chain":
-                it.kind, it.params, it.pool, it.aux = _abi.IMS_PLAN_CHAIN, C.addressof(item[1]), C.addressof(item[3]), item[4].data_ptr()
-                it.stream = self.STREAMS[item[7]]
-                it.first_slot, it.n_slots, it.n_tiles, it.tag, it.pad = item[8], item[9], item[10], item[11], item[12]
-                it.aux2 = self._chain_ctl_ptr(item[7])
             elif kind == "rounds":
                 descs, nrecalc, use_tags = item[1], item[2], item[3]
                 arr = (_abi.Chain * len(descs))()
@@ -997,6 +918,31 @@ class Renderer:
         _abi.check(self.lib.ims_shoot_photons(C.byref(P), off_t.data_ptr(), C.byref(ph), self._stream()), "ims_shoot_photons")
         return pool
 
+    def shoot_ops_photons(self, objects, converted=False):
+        """ims_shoot_ops_photons: shoot + PSF + the whole op chain in one launch, into a pool.  converted=True also
+        runs the boundary-independent half of the sensor step and stores the `converted` format of ims_photons_t
+        (what plan_lsst_image produces for the brighter-fatter chains)."""
+        objects, obj_t, prefix, pre_t = self._upload_objects(objects)
+        offs = np.concatenate([[0], np.cumsum(objects["n_phot"])]).astype(np.int64)
+        off_t = self.torch.from_numpy(offs).to(self.device)
+        pool = PhotonPool(self.torch, self.device, offs[-1], off_t, obj_t, len(objects), pre_t, int(prefix[-1]))
+        P = self.bound.params(obj_t.data_ptr(), len(objects), pre_t.data_ptr(), int(prefix[-1]), self.image.data_ptr(),
+                              None, _seg_ptr(pre_t))
+        ph = pool.struct()
+        ph.converted = 1 if converted else 0
+        _abi.check(self.lib.ims_shoot_ops_photons(C.byref(P), off_t.data_ptr(), C.byref(ph), self._stream()), "ims_shoot_ops_photons")
+        pool.converted = bool(converted)
+        return pool
+
+    def accumulate_segments(self, pool, realized=None):
+        """ims_accumulate_segments on a converted pool (segment-mapped: one workgroup per 256 photons of one object)."""
+        P = self._pool_params(pool, realized)
+        P.seg_object = _seg_ptr(pool.seg_prefix_dev)
+        ph = pool.struct()
+        ph.converted = 1 if getattr(pool, "converted", False) else 0
+        _abi.check(self.lib.ims_accumulate_segments(C.byref(P), C.byref(ph), pool.photon_offset_dev.data_ptr(), self._stream()),
+                   "ims_accumulate_segments")
+
     def _pool_params(self, pool, realized=None):
         return self.bound.params(pool.objects_dev.data_ptr(), pool.n_objects, pool.seg_prefix_dev.data_ptr(),
                                  pool.n_segments, self.image.data_ptr(),
@@ -1078,5 +1024,3 @@ class Renderer:
 
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)
-        if self._chain_ctl:
-            self.check_chains()

@@ -40,7 +40,7 @@ extern "C" {
 #define IMS_ERR_NO_DEVICE  -3
 #define IMS_ERR_UNSUPPORTED -4
 
-#define IMS_ABI_VERSION 7
+#define IMS_ABI_VERSION 8
 
 /* Pointers stored INSIDE descriptors that live in device memory (ims_sensor_t, ims_atmosphere_t) always point to global
  * device memory.  Device code is told so (address space 1): a pointer read out of memory is otherwise a generic pointer and
@@ -318,6 +318,15 @@ typedef struct ims_photons {
     int64_t n;
     double *x, *y, *flux, *dxdz, *dydz, *wavelength, *pupil_u, *pupil_v, *time;
     int32_t *obj_index;          /* row in the object table that produced the photon (for stamp clipping / truth) */
+    /* converted != 0 (LSST_Image chains, ims_shoot_ops_photons -> ims_accumulate_round / ims_accumulate_segments): the pool holds
+     * photons that have ALREADY been through the half of SiliconSensor.accumulate that does not look at the pixel boundaries
+     * (conversion depth from the absorption length, lateral walk of an inclined photon, diffusion): x, y = position at the
+     * conversion depth [pixels], flux (0 = lost in the silicon), dxdz = the polygon shrink factor tanh(zconv / 12) of GalSim's
+     * insidePixel with the "pixel not found" coin of the photon in its sign bit (set = stay in the nominal pixel).  dydz,
+     * wavelength, pupil_u, pupil_v, time are not used (may be NULL).  Objects without the Silicon model (or IMS_OBJ_FAINT) keep
+     * x, y as they are.  Everything is the same arithmetic as the unconverted path, only done in the producing kernel. */
+    int32_t converted;
+    int32_t pad;
 } ims_photons_t;
 
 typedef struct ims_render_params {
@@ -392,26 +401,6 @@ int  ims_sensor_init_boundaries(const ims_sensor_t* sensor_dev, const ims_sensor
 int  ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host,
                                    int32_t first_slot, int32_t n_slots, const int64_t* tile_prefix_dev,
                                    int64_t n_tiles, unsigned char* changed_dev, uint32_t tag, void* stream);
-
-/* ---- persistent brighter-fatter chain (LSST_Image mode) ----
- * In LSST_Image mode the sensor accumulates into the object's OWN stamp (imsim/stamp.py:562-569), so a bright object's
- * pixel boundaries are recalculated from its own charge every `nrecalc` electrons: a chain of rounds
- * (accumulate nrecalc photons | updatePixelDistortions | refresh bounds) that only depends on the object's earlier rounds.
- * ims_bf_chain runs rounds [round_begin, round_end) of EVERY object of `params` in ONE launch: n_workers persistent
- * workgroups form teams of up to team_size on the XCD they run on, a team takes objects off a queue (row order: put
- * the longest chains first) and walks their rounds with team barriers in place of kernel boundaries.
- * Object row i: n_phot = ALL photons of the object, bf_state = its private slot (regions up to 1023 pixels on a side,
- * qdist 3, 4 or 8 vertices per edge -- otherwise use ims_accumulate_segments + ims_sensor_update_distortions per round);
- * photon j of the object is read from the pool at pool_start[i] + j and draws from stream phot_first + j.  Rounds
- * beyond an object's last are skipped; the recalculation after an object's last round is not run (as in the
- * reference, where the next object starts from fresh boundaries).  ctl_dev: device scratch of
- * ims_bf_chain_ctl_bytes() bytes, zeroed by the call; changed_dev as for ims_sensor_update_distortions.
- * ims_bf_chain_status (synchronises): error != 0 when a launch gave up waiting for its workgroups. */
-int  ims_bf_chain_ctl_bytes(void);
-int  ims_bf_chain(const ims_render_params_t* params, const ims_photons_t* pool, const int64_t* pool_start,
-                  int32_t round_begin, int32_t round_end, int32_t nrecalc, const ims_sensor_t* sensor_host,
-                  unsigned char* changed_dev, void* ctl_dev, int32_t n_workers, int32_t team_size, void* stream);
-int  ims_bf_chain_status(const void* ctl_dev, int32_t* error);
 
 /* ---- FFT branch: LSST_SiliconBuilder.draw, method == 'fft' (imsim/stamp.py:482-525) ----
  * For very bright objects (nominal_flux >= 1e6 and max_sb > fft_sb_thresh, imsim/stamp.py:275-277,
@@ -501,8 +490,6 @@ int  ims_fft_finish(const ims_fft_params_t* params, const ims_fft_object_t* obje
 #define IMS_PLAN_INIT       5   /* ims_sensor_init_boundaries(first_slot, n_slots) */
 #define IMS_PLAN_RECORD     6   /* record library event number n_slots on the item's stream */
 #define IMS_PLAN_WAIT       7   /* make the item's stream wait for library event number n_slots */
-#define IMS_PLAN_CHAIN      8   /* ims_bf_chain(params, pool, aux = pool_start, rounds [first_slot, n_slots), nrecalc = n_tiles,
-                                   ctl = aux2, n_workers = tag, team_size = pad) */
 #define IMS_PLAN_ROUNDS     9   /* the per-round launches of up to IMS_MAX_CHAINS brighter-fatter chains, interleaved round by round:
                                    aux2 = HOST array of ims_chain_t, n_slots = its length */
 #define IMS_MAX_CHAINS      4

@@ -134,6 +134,40 @@ def test_pooled_photons_are_bit_exact_and_match_fused(torch_cuda):
     assert_bits_equal(r2.image_numpy(), r.image_numpy(), "fused vs pooled image")
 
 
+def test_shoot_ops_photons_one_launch_equals_shoot_then_ops(torch_cuda):
+    """ims_shoot_ops_photons (shoot + PSF + op chain in one launch) stores the photons of ims_shoot_photons +
+    ims_apply_ops bit for bit; its `converted` form followed by ims_accumulate_segments (what the brighter-fatter chains
+    run: conversion and diffusion in the producing kernel, only the pixel search in the consumer) gives the image of
+    the fused kernel and of the oracle."""
+    from imsim_amd.engine import Renderer
+    from oracle import orc_loader
+    scene, objects = _c3_case(n_obj=120)
+    r = Renderer(scene)
+    a = r.shoot_photons(objects)
+    r.apply_ops(a)
+    b = r.shoot_ops_photons(objects)
+    r.synchronize()
+    ga, gb = a.to_host(), b.to_host()
+    for f in ga:
+        assert_bits_equal(gb[f], ga[f], f"photon field {f}")
+    c = r.shoot_ops_photons(objects, converted=True)
+    real = torch_cuda.zeros(len(objects), dtype=torch_cuda.float64, device="cuda")
+    r.accumulate_segments(c, realized=real)
+    r.synchronize()
+    with pytest.raises(Exception, match="converted"):
+        r.accumulate_segments(b)
+    orc = orc_loader.OracleScene(scene)
+    real_o = np.zeros(len(objects))
+    orc.render(objects, realized=real_o)
+    assert r.image_numpy().sum() > 0
+    assert_bits_equal(r.image_numpy(), orc.image, "converted pool + pixel search vs oracle")
+    assert_bits_equal(real.cpu().numpy(), real_o, "realized flux")
+    r2 = Renderer(scene)
+    r2.render(objects)
+    r2.synchronize()
+    assert_bits_equal(r2.image_numpy(), r.image_numpy(), "fused vs converted pool")
+
+
 def test_batching_invariance(torch_cuda):
     """Splitting every object's photons over batches (photon_pooling.py:300-304 flux split) gives
     the same image as one shot."""
@@ -224,35 +258,6 @@ def test_c3_lsst_image_mode_is_bit_exact(torch_cuda):
     real_o = np.zeros(len(objects))
     orc.render_lsst_image(objects, realized=real_o)
     assert_bits_equal(r.image_numpy(), orc.image, "C3 image")
-    assert_bits_equal(real.cpu().numpy(), real_o, "realized flux")
-    ga = _sensor_arrays_gpu(r)
-    for name in ("boundary", "bounds", "delta"):
-        assert_bits_equal(ga[name], orc.sensor_array(name), f"sensor {name}")
-
-
-@pytest.mark.skipif(os.environ.get("IMS_TEST_CHAIN", "0") == "0",
-                    reason="experimental path, off in the product (Renderer.use_chain); IMS_TEST_CHAIN=1 runs it.  Known issue: "
-                           "about one run in twenty-five loses ONE electron of one pixel (an unresolved hand-off race)")
-@pytest.mark.parametrize("team,workers", [(4, 2048), (40, 2048), (1, 64)])
-def test_persistent_chain_kernel_is_bit_exact(torch_cuda, team, workers):
-    """ims_bf_chain (one persistent launch walks whole brighter-fatter chains with team barriers) gives the image,
-    realized flux and pixel-boundary state of the per-round launches and of the oracle, for any team size."""
-    from imsim_amd.engine import Renderer
-    from oracle import orc_loader
-    scene, objects = _c3_case(n_obj=200)
-    r = Renderer(scene)
-    r.use_chain, r.chain_team, r.chain_workers = True, team, workers
-    real = torch_cuda.zeros(len(objects), dtype=torch_cuda.float64, device="cuda")
-    plan, parts = r.plan_lsst_image(objects, nrecalc=1000, want_realized=True)
-    assert sum(1 for it in plan if it[0] == "chain") >= 2
-    r.execute_plan(plan)
-    for index, tmp in parts:
-        real.index_add_(0, index, tmp)
-    r.synchronize()
-    orc = orc_loader.OracleScene(scene)
-    real_o = np.zeros(len(objects))
-    orc.render_lsst_image(objects, nrecalc=1000, realized=real_o)
-    assert_bits_equal(r.image_numpy(), orc.image, "image (persistent chain)")
     assert_bits_equal(real.cpu().numpy(), real_o, "realized flux")
     ga = _sensor_arrays_gpu(r)
     for name in ("boundary", "bounds", "delta"):

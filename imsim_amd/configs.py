@@ -107,7 +107,7 @@ BENCH_CONFIGS = {
             parallel.shard_objects(objects, rank, world)),
         cold=lambda scene, objects, device: cold_lsst_image(scene, objects, device),
         timed_kernel=2,
-        kernel="k_shoot_photons<true>",
+        kernel="k_shoot_photons<2>",
         cpu_sample=20000,
         cpu_scene=_c3_cpu_scene,
         cpu_step=lambda orc, sample: orc.render_lsst_image(sample),

@@ -874,13 +874,13 @@ class Renderer:
         launch.object_rows = sum(it[4] for it in plan if it[0] == "render") + sum(it[6] for it in plan if it[0] in ("shoot_pool", "acc_pool", "chain"))
         launch.pool_photons = sum(it[5] for it in plan if it[0] == "shoot_pool")
         # the two photon-pipeline kernels the library can time (ims_enable_timing): launches per replay and
-        # their algorithmic bytes.  Fused render: f64 image RMW (16 B/photon); pool shoot: the six f64
-        # fields it writes (48 B/photon); both + one 256-B object row per object
+        # their algorithmic bytes.  Fused render: f64 image RMW (16 B/photon); pool shoot: the four f64
+        # fields of a converted photon it writes (32 B/photon); both + one 256-B object row per object
         launch.timed = {
             1: (sum(1 for it in plan if it[0] == "render"),
                 sum(it[3] * 16 + it[4] * 256 for it in plan if it[0] == "render")),
             2: (sum(1 for it in plan if it[0] == "shoot_pool"),
-                sum(it[5] * 48 + it[6] * 256 for it in plan if it[0] == "shoot_pool")),
+                sum(it[5] * 32 + it[6] * 256 for it in plan if it[0] == "shoot_pool")),
         }
         # wavefronts per replay of the two kernels (4 per 256-thread segment, as SQ_WAVES counts them)
         launch.timed_waves = {1: sum(4 * int(it[1].n_segments) for it in plan if it[0] == "render"),

@@ -1,27 +1,30 @@
 #!/usr/bin/env python
 """Rebuild profiles/hbm_traffic.json (what bench.py reports as roofline.traffic and uses for the f64-issue fraction) from
-the committed per-config PMC summaries (tools/pmc_summary.py output): profiles/round2_<config>_hbm_pmc.json and
-round2_<config>_sq_pmc.json where present, else the round-1 files profiles/round1_<config>_final_hbm_pmc.json."""
+the committed per-config PMC summaries (tools/pmc_summary.py output): the newest of profiles/round2c_<config>_hbm_pmc.json
+(end of round 2: converted pool, k_shoot_photons<2>), round2_<config>_hbm_pmc.json and round1_<config>_final_hbm_pmc.json, with
+the SQ pass of the same tag where present."""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {"k_shoot_accumulate(ims_render_params)": "k_shoot_accumulate",
-           "void k_shoot_photons<true>(ims_render_params, long const*, ims_photons)": "k_shoot_photons<true>"}
+           "void k_shoot_photons<true>(ims_render_params, long const*, ims_photons)": "k_shoot_photons<true>",
+           "void k_shoot_photons<2>(ims_render_params, long const*, ims_photons)": "k_shoot_photons<2>"}
 
 
 def main():
     out = {}
     for cfg in ("c2", "c3", "c3b"):
-        src = f"profiles/round2_{cfg}_hbm_pmc.json"
-        if not os.path.exists(os.path.join(ROOT, src)):
-            src = f"profiles/round1_{cfg}_final_hbm_pmc.json"
-        path = os.path.join(ROOT, src)
-        if not os.path.exists(path):
+        cands = [(f"profiles/round2c_{cfg}_hbm_pmc.json", f"profiles/round2c_{cfg}_sq_pmc.json"),
+                 (f"profiles/round2_{cfg}_hbm_pmc.json", f"profiles/round2_{cfg}_sq_pmc.json"),
+                 (f"profiles/round1_{cfg}_final_hbm_pmc.json", f"profiles/round1_{cfg}_final_sq_pmc.json")]
+        found = [c for c in cands if os.path.exists(os.path.join(ROOT, c[0]))]
+        if not found:
             continue
+        src, sq_src = found[0]
+        path = os.path.join(ROOT, src)
         d = json.load(open(path))
-        sq_src = f"profiles/round2_{cfg}_sq_pmc.json"
         sq = json.load(open(os.path.join(ROOT, sq_src))) if os.path.exists(os.path.join(ROOT, sq_src)) else {}
         for long_name, short in KERNELS.items():
             if long_name not in d:

@@ -72,7 +72,8 @@ class Atmosphere(C.Structure):
     _fields_ = [("n_layers", c_i32), ("npix", c_i32), ("scale", c_d), ("x0", c_d), ("t0", c_d), ("exptime", c_d),
                 ("aper_r_outer", c_d), ("aper_r_inner", c_d), ("vx", c_d * 8), ("vy", c_d * 8), ("alt", c_d * 8),
                 ("screens", c_vp),
-                ("dn", c_d), ("inv_n", c_d), ("inv_scale", c_d), ("aper_ri2", c_d), ("aper_dr2", c_d)]
+                ("dn", c_d), ("inv_n", c_d), ("inv_scale", c_d), ("aper_ri2", c_d), ("aper_dr2", c_d),
+                ("screen_quads", c_vp)]
 
 
 class KPsf(C.Structure):

@@ -134,6 +134,7 @@ IMS_DEV void screen_gradient(const ims_atmosphere_t& A, double pu, double pv, do
     const int n = A.npix;
     const double dn = A.dn, inv_n = A.inv_n, inv_scale = A.inv_scale;      // ims_fill_derived_atmosphere
     const bool pow2 = (n & (n - 1)) == 0;      // the screens of the reference are 8192 wide: the wrap is a mask
+    const bool quads = A.screen_quads != nullptr;
     for (int l = 0; l < A.n_layers; ++l) {
         const double x = pu - t * A.vx[l] + A.alt[l] * tanx;
         const double y = pv - t * A.vy[l] + A.alt[l] * tany;
@@ -149,10 +150,18 @@ IMS_DEV void screen_gradient(const ims_atmosphere_t& A, double pu, double pv, do
             ix = wrap_index(flx, dn, inv_n); iy = wrap_index(fly, dn, inv_n);
             ix1 = ix + 1 == n ? 0 : ix + 1; iy1 = iy + 1 == n ? 0 : iy + 1;
         }
-        const float* S = A.screens + (int64_t)l * n * n;
-        const uint32_t r0 = (uint32_t)iy * (uint32_t)n, r1 = (uint32_t)iy1 * (uint32_t)n;     // a screen has < 2^31 samples
-        const double f00 = (double)S[r0 + (uint32_t)ix], f10 = (double)S[r0 + (uint32_t)ix1];
-        const double f01 = (double)S[r1 + (uint32_t)ix], f11 = (double)S[r1 + (uint32_t)ix1];
+        double f00, f10, f01, f11;
+        if (quads) {
+            // the 2 x 2 cell of sample (iy, ix) as one 16-byte item (ims_atmosphere_t.screen_quads): one load per layer
+            typedef float fvec4 __attribute__((ext_vector_type(4)));
+            const fvec4 q = *(const IMS_G fvec4*)(A.screen_quads + (((int64_t)l * n + iy) * n + ix) * 4);
+            f00 = (double)q.x; f10 = (double)q.y; f01 = (double)q.z; f11 = (double)q.w;
+        } else {
+            const float* S = A.screens + (int64_t)l * n * n;
+            const uint32_t r0 = (uint32_t)iy * (uint32_t)n, r1 = (uint32_t)iy1 * (uint32_t)n;     // a screen has < 2^31 samples
+            f00 = (double)S[r0 + (uint32_t)ix]; f10 = (double)S[r0 + (uint32_t)ix1];
+            f01 = (double)S[r1 + (uint32_t)ix]; f11 = (double)S[r1 + (uint32_t)ix1];
+        }
         sx = sx + ((f10 - f00) * (1.0 - ay) + (f11 - f01) * ay);
         sy = sy + ((f01 - f00) * (1.0 - ax) + (f11 - f10) * ax);
     }

@@ -390,11 +390,26 @@ class BoundScene:
         if scene.atm is not None:
             A = scene.atm.atmosphere_struct()
             scr = scene.atm.screens
-            if isinstance(scr, np.ndarray):
-                _, A.screens = mem.put(scr, np.float32)
-            elif isinstance(mem, DeviceMem):
-                mem.keep.append(scr)                      # already a device tensor
+            if isinstance(mem, DeviceMem):
+                t = mem.torch
+                if isinstance(scr, np.ndarray):
+                    scr = getattr(scene.atm, "_screens_dev", None)
+                    if scr is None or scr.device != mem.device:
+                        scr = t.from_numpy(np.ascontiguousarray(scene.atm.screens, dtype=np.float32)).to(mem.device)
+                        scene.atm._screens_dev = scr
+                mem.keep.append(scr)
                 A.screens = scr.data_ptr()
+                # the 2 x 2 cells of the bilinear gradient as 16-byte items (ims_atmosphere_t.screen_quads): built once
+                # per atmosphere and shared by every renderer that looks through it (4 x the screens: 6.4 GB for 6 x 8192^2)
+                if os.environ.get("IMS_SCREEN_QUADS", "1") != "0":
+                    quads = getattr(scene.atm, "_screen_quads", None)
+                    if quads is None or quads.device != scr.device:
+                        quads = t.stack([scr, t.roll(scr, -1, 2), t.roll(scr, -1, 1), t.roll(scr, (-1, -1), (1, 2))], dim=-1).contiguous()
+                        scene.atm._screen_quads = quads
+                    mem.keep.append(quads)
+                    A.screen_quads = quads.data_ptr()
+            elif isinstance(scr, np.ndarray):
+                _, A.screens = mem.put(scr, np.float32)
             else:
                 _, A.screens = mem.put(scr.cpu().numpy(), np.float32)
             derive.fill_derived_struct("atmosphere", A)
@@ -510,6 +525,30 @@ class PhotonPool:
         return out
 
 
+_DEVICE_STREAMS = {}
+
+
+def _device_streams(torch, device):
+    """The four streams of the launch plans (chain, bulk, chain1, chain2), ONE set per device and process, shared by every
+    Renderer on that device.  HIP multiplexes its streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default):
+    with a fresh set per renderer the chain of one CCD of a focal plane lands in the hardware queue of another CCD's wide
+    launches and waits behind them (kernel trace of C5: one kernel in flight for two thirds of the time).  With one set,
+    the plans of the CCDs in flight interleave role by role: the wide launches of the next CCD fill the GPU while the
+    latency-bound chain of the previous one runs.  IMS_PRIVATE_STREAMS=1 gives every renderer its own set again."""
+    pr = [int(v) for v in os.environ.get("IMS_STREAM_PRIORITIES", "-1,0,0,0").split(",")]   # chain, bulk, chain1, chain2
+    if os.environ.get("IMS_PRIVATE_STREAMS", "0") != "0":
+        return tuple(torch.cuda.Stream(device, priority=p) for p in pr)
+    # IMS_STREAM_SETS sets (default 1), handed to the renderers of a device in turn
+    n_sets = max(int(os.environ.get("IMS_STREAM_SETS", "1")), 1)
+    key = (str(device), tuple(pr))
+    sets = _DEVICE_STREAMS.setdefault(key, {"next": 0, "sets": []})
+    k = sets["next"] % n_sets
+    sets["next"] += 1
+    while len(sets["sets"]) <= k:
+        sets["sets"].append(tuple(torch.cuda.Stream(device, priority=p) for p in pr))
+    return sets["sets"][k]
+
+
 class Renderer:
     """One CCD on one GPU."""
 
@@ -529,11 +568,7 @@ class Renderer:
         self.image = self.torch.zeros((scene.ny, scene.nx), dtype=self.torch.float64, device=self.device)
         # two side streams: the sequential brighter-fatter chain of the bright objects runs at high
         # priority while the wide single-launch work fills the CUs it leaves idle
-        pr = [int(v) for v in os.environ.get("IMS_STREAM_PRIORITIES", "-1,0,0,0").split(",")]   # chain, bulk, chain1, chain2
-        self.s_chain = self.torch.cuda.Stream(self.device, priority=pr[0])
-        self.s_bulk = self.torch.cuda.Stream(self.device, priority=pr[1])
-        self.s_chain1 = self.torch.cuda.Stream(self.device, priority=pr[2])
-        self.s_chain2 = self.torch.cuda.Stream(self.device, priority=pr[3])
+        self.s_chain, self.s_bulk, self.s_chain1, self.s_chain2 = _device_streams(self.torch, self.device)
         self.use_bf_tags = os.environ.get("IMS_BF_TAGS", "0") != "0"
         # round-count thresholds that cut the bright objects into concurrent chains (plan_lsst_image)
         self.chain_class_rounds = tuple(int(v) for v in os.environ.get("IMS_CHAIN_CLASSES", "40,6").split(",") if v)

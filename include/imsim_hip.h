@@ -40,7 +40,7 @@ extern "C" {
 #define IMS_ERR_NO_DEVICE  -3
 #define IMS_ERR_UNSUPPORTED -4
 
-#define IMS_ABI_VERSION 8
+#define IMS_ABI_VERSION 9
 
 /* Pointers stored INSIDE descriptors that live in device memory (ims_sensor_t, ims_atmosphere_t) always point to global
  * device memory.  Device code is told so (address space 1): a pointer read out of memory is otherwise a generic pointer and
@@ -193,6 +193,11 @@ typedef struct ims_atmosphere {
     /* launch-wide constants derived by ims_fill_derived_atmosphere (the same IEEE operations the kernel would otherwise repeat
      * per photon): (double)npix, 1/npix, 1/scale, aper_r_inner^2, aper_r_outer^2 - aper_r_inner^2 */
     double  dn, inv_n, inv_scale, aper_ri2, aper_dr2;
+    /* optional (NULL = gather the four samples from `screens`): [n_layers][npix][npix][4] fp32, for every sample (iy, ix) the
+     * 2 x 2 cell the bilinear gradient needs, {s[iy][ix], s[iy][ix+1], s[iy+1][ix], s[iy+1][ix+1]} with the periodic wrap
+     * applied -- ONE 16-byte load per photon and layer instead of four scattered 4-byte loads on two rows (the fused
+     * kernel of C3b moved 22 GB per launch that way).  Same sample values, same arithmetic, 4 x the memory. */
+    const float IMS_G* screen_quads;
 } ims_atmosphere_t;
 
 typedef struct ims_op {

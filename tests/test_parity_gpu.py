@@ -298,18 +298,22 @@ def test_pooling_mode_brighter_fatter_is_bit_exact(torch_cuda):
         assert_bits_equal(ga[name], orc.sensor_array(name), f"sensor {name}")
 
 
-def test_c3b_atmospheric_psf_is_bit_exact(torch_cuda):
+@pytest.mark.parametrize("quads", ["1", "0"])
+def test_c3b_atmospheric_psf_is_bit_exact(torch_cuda, monkeypatch, quads):
     """C3b: the 6-screen AtmosphericPSF (phase-screen gradient gather, chromatic dilation, second
-    kick) in front of the full op chain and the Silicon sensor."""
+    kick) in front of the full op chain and the Silicon sensor.  quads: the 2 x 2 cells of the bilinear gradient as
+    16-byte items (ims_atmosphere_t.screen_quads, the default) or four gathers from the plain screens."""
     from imsim_amd import configs, catalog
     from imsim_amd.engine import Renderer
     from oracle import orc_loader
+    monkeypatch.setenv("IMS_SCREEN_QUADS", quads)
     scene = configs.scene_c3b(nx=256, ny=256, screen_size=102.4, screen_scale=0.1)
     scene.sensor.scratch_cells = 500_000
     cat = catalog.synthetic_catalog(120, nx=256, ny=256)
     phot = catalog.realize_fluxes(cat["nominal_flux"], 2)
     objects, _ = configs.c3b_objects(cat, phot, scene)
     r = Renderer(scene)
+    assert (r.bound.atm_struct.screen_quads is not None) == (quads == "1")
     pool = r.shoot_photons(objects)
     orc = orc_loader.OracleScene(scene)
     opool = orc.shoot_pool(objects)

@@ -251,7 +251,7 @@ def load():
     lib.ims_accumulate_segments.argtypes = [C.POINTER(RenderParams), C.POINTER(Photons), c_vp, c_vp]
     lib.ims_accumulate_round.argtypes = [C.POINTER(RenderParams), C.POINTER(Photons), c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]
     lib.ims_accumulate.argtypes = [C.POINTER(RenderParams), c_vp, C.POINTER(Photons), c_vp, c_vp]
-    lib.ims_sensor_init_boundaries.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_vp]
+    lib.ims_sensor_init_boundaries.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_vp, c_i64, c_vp]
     lib.ims_sensor_update_distortions.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_vp, c_i64, c_vp, C.c_uint32, c_vp]
     lib.ims_image_add.argtypes = [c_vp, c_vp, c_i64, c_vp]
     lib.ims_image_to_float.argtypes = [c_vp, c_vp, c_i64, c_vp]

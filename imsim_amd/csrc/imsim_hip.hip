@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include "ims_photon.h"
 #include "ims_fft.h"
 
@@ -24,6 +25,12 @@ static int hip_err(hipError_t e, const char* what)
 {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
     return IMS_ERR_HIP;
+}
+// a feature that is on unless the environment variable is "0" (read once per call site is fine: host side, rare)
+static bool os_getenv_off(const char* name)
+{
+    const char* v = getenv(name);
+    return !(v && v[0] == '0');
 }
 #define HIP_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_err(e_, #call); } while (0)
 
@@ -531,6 +538,101 @@ __global__ __launch_bounds__(256) void k_init_boundaries(const ims_sensor_t* __r
     b[4] = oxmin; b[5] = oxmax; b[6] = oymin; b[7] = oymax;
 }
 
+// The same initial state, one 16 x 16 tile of owner cells per workgroup (grid.y = slot of the range, grid.x = tile; 4
+// vertices per edge): every lane evaluates the ten owned points of ITS cell once, hands the left-edge and bottom-row
+// points its left / lower neighbours need through LDS, and only the lanes at the right / upper rim of the tile evaluate
+// their neighbour's points themselves -- ~12 evaluations of the tree-ring closed form per cell instead of 30 (each is a
+// sqrt, two divisions and a spline).  Same function of (cell, point), so the same bits as k_init_boundaries.
+constexpr int UT = 16;            // tile edge of the boundary kernels (mark_tile_charge assumes 16)
+constexpr int IT_NV = 4, IT_NPO = 2 * IT_NV + 2, IT_NVT = 4 * IT_NV + 4;
+
+// tile_prefix (device, prefix sum of the tiles of the slots first_slot ..): a 1-D grid over exactly the tiles of the
+// range, block -> (slot, tile) by binary search as in the update kernels; NULL: grid.y = slot, grid.x = tile of the slot
+// (blocks beyond the slot's tiles leave).
+__global__ __launch_bounds__(256) void k_init_tiles(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
+                                                    const int64_t* __restrict__ tile_prefix)
+{
+    __shared__ double2 left[UT][UT][IT_NV];           // owned points NV + 2 .. 2 NV + 1 (left edge, bottom -> top)
+    __shared__ double2 bottom[UT][UT][IT_NV + 2];     // owned points 0 .. NV + 1 (bottom row incl. both corners)
+    const ims_sensor_t& s = *sp;
+    int slot = first_slot + (int)blockIdx.y, t = (int)blockIdx.x;
+    if (tile_prefix != nullptr) {
+        const int64_t b = blockIdx.x;
+        int lo = 0, hi = n_slots;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (tile_prefix[mid] <= b) lo = mid; else hi = mid;
+        }
+        slot = first_slot + lo;
+        t = (int)(b - tile_prefix[lo]);
+    }
+    const ims_bf_slot_t bs = s.bf_slots[slot];
+    const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
+    const int tiles_x = (sl.nx + 1 + UT - 1) / UT, tiles_y = (sl.ny + 1 + UT - 1) / UT;
+    if (t >= tiles_x * tiles_y) return;
+    const int lx = threadIdx.x % UT, ly = threadIdx.x / UT;
+    const int i = (t % tiles_x) * UT + lx, j = (t / tiles_x) * UT + ly;
+    const bool owner = (i <= sl.nx && j <= sl.ny);
+    double2 own[IT_NPO];
+    if (owner) {
+        const int64_t c = cell_index(sl, i, j);
+        double2* pts = (double2*)(s.bf_boundary + c * IT_NPO * 2);
+#pragma unroll
+        for (int n = 0; n < IT_NPO; ++n) {
+            init_point(s, sl, i, j, n, own[n].x, own[n].y);
+            pts[n] = own[n];
+        }
+        s.bf_delta[c] = 0.0;
+#pragma unroll
+        for (int n = 0; n <= IT_NV + 1; ++n) bottom[ly][lx][n] = own[n];
+#pragma unroll
+        for (int m = 0; m < IT_NV; ++m) left[ly][lx][m] = own[IT_NV + 2 + m];
+    }
+    __syncthreads();
+    if (!owner || i >= sl.nx || j >= sl.ny) return;
+    // the right neighbour's left edge and the upper neighbour's bottom row: from LDS inside the tile, evaluated at its rim
+    double2 rgt[IT_NV], upp[IT_NV + 2];
+    if (lx + 1 < UT) {
+#pragma unroll
+        for (int m = 0; m < IT_NV; ++m) rgt[m] = left[ly][lx + 1][m];
+    } else {
+#pragma unroll
+        for (int m = 0; m < IT_NV; ++m) init_point(s, sl, i + 1, j, IT_NV + 2 + m, rgt[m].x, rgt[m].y);
+    }
+    if (ly + 1 < UT) {
+#pragma unroll
+        for (int q = 0; q <= IT_NV + 1; ++q) upp[q] = bottom[ly + 1][lx][q];
+    } else {
+#pragma unroll
+        for (int q = 0; q <= IT_NV + 1; ++q) init_point(s, sl, i, j + 1, q, upp[q].x, upp[q].y);
+    }
+    double ixmin = 0.0, ixmax = 1.0, iymin = 0.0, iymax = 1.0;
+    double oxmin = 0.0, oxmax = 1.0, oymin = 0.0, oymax = 1.0;
+    double v0x = 0.0;
+#pragma unroll
+    for (int k = 0; k < IT_NVT; ++k) {
+        // same vertex -> (cell, owned point) map as polygon_vertex
+        double vx, vy;
+        if (k <= IT_NV + 1) { vx = own[k].x; vy = own[k].y; }
+        else if (k <= 2 * IT_NV + 1) { vx = rgt[k - IT_NV - 2].x + 1.0; vy = rgt[k - IT_NV - 2].y; }
+        else if (k <= 3 * IT_NV + 3) { vx = upp[IT_NV + 1 - (k - 2 * IT_NV - 2)].x; vy = upp[IT_NV + 1 - (k - 2 * IT_NV - 2)].y + 1.0; }
+        else { vx = own[IT_NV + 2 + (IT_NV - 1 - (k - 3 * IT_NV - 4))].x; vy = own[IT_NV + 2 + (IT_NV - 1 - (k - 3 * IT_NV - 4))].y; }
+        if (k == 0) v0x = vx;
+        if (vx < oxmin) oxmin = vx;
+        if (vx > oxmax) oxmax = vx;
+        if (vy < oymin) oymin = vy;
+        if (vy > oymax) oymax = vy;
+        if (k <= IT_NV + 1) { if (vy > iymin) iymin = vy; }
+        if (k >= IT_NV + 1 && k <= 2 * IT_NV + 2) { if (vx < ixmax) ixmax = vx; }
+        if (k >= 2 * IT_NV + 2 && k <= 3 * IT_NV + 3) { if (vy < iymax) iymax = vy; }
+        if (k >= 3 * IT_NV + 3) { if (vx > ixmin) ixmin = vx; }
+    }
+    if (v0x > ixmin) ixmin = v0x;
+    double* b = s.bf_bounds + cell_index(sl, i, j) * 8;
+    b[0] = ixmin; b[1] = ixmax; b[2] = iymin; b[3] = iymax;
+    b[4] = oxmin; b[5] = oxmax; b[6] = oymin; b[7] = oymax;
+}
+
 __device__ __forceinline__ int owned_to_vertex(int nV, int n)
 {
     if (n <= nV + 1) return n;
@@ -543,7 +645,6 @@ __device__ __forceinline__ int owned_to_vertex(int nV, int n)
 // charged neighbours from LDS in a FIXED order (so the result is bit-reproducible) and adds the
 // scaled tabulated displacements to the boundary points it owns.  A per-cell `changed` byte lets
 // k_refresh_changed skip pixels whose polygon did not move.
-constexpr int UT = 16;            // tile edge (mark_tile_charge assumes 16)
 constexpr int UQMAX = 4;          // largest supported qdist
 constexpr int UH = UT + 2 * UQMAX + 1;
 
@@ -1452,7 +1553,7 @@ static int slot_range_cells(const ims_sensor_t* host, int first, int n, int64_t*
 }
 
 int ims_sensor_init_boundaries(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host,
-                               int32_t first_slot, int32_t n_slots, void* stream)
+                               int32_t first_slot, int32_t n_slots, const int64_t* tile_prefix_dev, int64_t n_tiles, void* stream)
 {
     if (!sensor_dev) return set_err(IMS_ERR_ARG, "sensor_dev is NULL");
     if (n_slots == 0) return IMS_OK;
@@ -1460,6 +1561,38 @@ int ims_sensor_init_boundaries(const ims_sensor_t* sensor_dev, const ims_sensor_
     int rc = slot_range_cells(sensor_host, first_slot, n_slots, &begin, &count);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (sensor_host->num_vertices == IT_NV && os_getenv_off("IMS_INIT_TILES") && tile_prefix_dev != nullptr) {
+        if (n_tiles <= 0 || n_tiles > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "n_tiles out of range");
+        hipLaunchKernelGGL(k_init_tiles, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot, n_slots, tile_prefix_dev);
+        HIP_TRY(hipGetLastError());
+        return IMS_OK;
+    }
+    if (sensor_host->num_vertices == IT_NV && os_getenv_off("IMS_INIT_TILES")) {
+        // tiled kernel: grid.x = the largest tile count of a run of consecutive slots, grid.y = the slots of the run (at most
+        // 65 535); a run ends where the workgroups that find no tile would outnumber the working ones four to one
+        int a = first_slot;
+        const int end = first_slot + n_slots;
+        while (a < end) {
+            auto tiles_of = [&](int k) {
+                const ims_bf_slot_t& b = sensor_host->bf_slots[k];
+                return (int64_t)((b.nx + 1 + UT - 1) / UT) * ((b.ny + 1 + UT - 1) / UT);
+            };
+            int64_t hi = tiles_of(a), sum = hi;
+            int z = a + 1;
+            while (z < end && z - a < 65535) {
+                const int64_t tz = tiles_of(z);
+                const int64_t nhi = tz > hi ? tz : hi;
+                if (nhi * (z - a + 1) > 4 * (sum + tz) + 4096) break;
+                hi = nhi; sum += tz; ++z;
+            }
+            if (hi > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "slot too large");
+            hipLaunchKernelGGL(k_init_tiles, dim3((unsigned)hi, (unsigned)(z - a)), dim3(256), 0, st, sensor_dev, a, z - a,
+                               (const int64_t*)nullptr);
+            a = z;
+        }
+        HIP_TRY(hipGetLastError());
+        return IMS_OK;
+    }
     const unsigned g = (unsigned)((count + 255) / 256);
     hipLaunchKernelGGL(k_init_boundaries, dim3(g), dim3(256), 0, st, sensor_dev, first_slot, n_slots, begin, count);
     HIP_TRY(hipGetLastError());
@@ -1597,7 +1730,7 @@ int ims_run_plan(const ims_plan_item_t* items, int64_t n_items, const ims_sensor
         case IMS_PLAN_ACC_POOL:   rc = ims_accumulate_segments(it.params, it.pool, it.aux, st); break;
         case IMS_PLAN_UPDATE:     rc = ims_sensor_update_distortions(sensor_dev, sensor_host, it.first_slot, it.n_slots, it.aux,
                                                                      it.n_tiles, changed_dev, it.tag, st); break;
-        case IMS_PLAN_INIT:       rc = ims_sensor_init_boundaries(sensor_dev, sensor_host, it.first_slot, it.n_slots, st); break;
+        case IMS_PLAN_INIT:       rc = ims_sensor_init_boundaries(sensor_dev, sensor_host, it.first_slot, it.n_slots, it.aux, it.n_tiles, st); break;
         case IMS_PLAN_ROUNDS:     rc = run_rounds((const ims_chain_t*)it.aux2, it.n_slots, sensor_dev, sensor_host, changed_dev, streams,
                                                   n_streams); break;
         case IMS_PLAN_RECORD:

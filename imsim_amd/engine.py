@@ -823,7 +823,9 @@ class Renderer:
                 stretches.append(("slots", sl, 0))
                 continue
             elif kind == "init":
+                prefix, prefix_t = tile_prefix_from(item[1])
                 it.kind, it.first_slot, it.n_slots = _abi.IMS_PLAN_INIT, item[1], item[2]
+                it.aux, it.n_tiles = prefix_t.data_ptr(), int(prefix[item[2]])
                 it.stream = self.STREAMS[item[3]]
             elif kind == "update":
                 first, n = item[1], item[2]
@@ -1003,8 +1005,10 @@ class Renderer:
 
     # -- sensor state --
     def init_boundaries(self, first_slot, n_slots, stream=None):
+        prefix, prefix_t = self._tile_prefix(first_slot)
         _abi.check(self.lib.ims_sensor_init_boundaries(self.bound.sensor_dev_ptr, C.byref(self.bound.sensor_host),
-                                                       first_slot, n_slots, stream if stream is not None else self._stream()),
+                                                       first_slot, n_slots, prefix_t.data_ptr(), int(prefix[n_slots]),
+                                                       stream if stream is not None else self._stream()),
                    "ims_sensor_init_boundaries")
 
     def _tile_prefix(self, first_slot):

@@ -40,7 +40,7 @@ extern "C" {
 #define IMS_ERR_NO_DEVICE  -3
 #define IMS_ERR_UNSUPPORTED -4
 
-#define IMS_ABI_VERSION 9
+#define IMS_ABI_VERSION 10
 
 /* Pointers stored INSIDE descriptors that live in device memory (ims_sensor_t, ims_atmosphere_t) always point to global
  * device memory.  Device code is told so (address space 1): a pointer read out of memory is otherwise a generic pointer and
@@ -395,9 +395,12 @@ int  ims_accumulate(const ims_render_params_t* params, const int64_t* photon_off
 /* ---- Silicon sensor state ---- */
 /* `sensor_dev` = the struct in device memory (all its pointers are device pointers);
  * `sensor_host` = a host copy whose bf_slots points to a HOST copy of the slot table (sizes the launches). */
-/* boundary points = undistorted + tree rings, bounds refreshed, delta = 0 (Silicon::initialize) */
+/* boundary points = undistorted + tree rings, bounds refreshed, delta = 0 (Silicon::initialize).  tile_prefix_dev / n_tiles
+ * (optional, as for ims_sensor_update_distortions: device prefix sum of the 16x16-cell tiles of the slots first_slot ..., its
+ * last entry): with it the tiled kernel runs over exactly the tiles of the range; NULL / 0 = the library sizes its launches from
+ * the host slot table. */
 int  ims_sensor_init_boundaries(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host,
-                                int32_t first_slot, int32_t n_slots, void* stream);
+                                int32_t first_slot, int32_t n_slots, const int64_t* tile_prefix_dev, int64_t n_tiles, void* stream);
 /* boundaries += distortions (x) delta / num_elec over the qdist neighbourhood; refresh bounds; delta = 0
  * (Silicon::updatePixelDistortions; the `recalc` of imsim/photon_pooling.py:159).
  * tile_prefix_dev[n_slots+1] (device): prefix sum of ceil((nx+1)/16)*ceil((ny+1)/16) over the slots of the
@@ -492,7 +495,7 @@ int  ims_fft_finish(const ims_fft_params_t* params, const ims_fft_object_t* obje
 #define IMS_PLAN_SHOOT_POOL 2   /* ims_shoot_ops_photons(params, aux = photon_offset, pool) */
 #define IMS_PLAN_ACC_POOL   3   /* ims_accumulate_segments(params, pool, aux = pool_start) */
 #define IMS_PLAN_UPDATE     4   /* ims_sensor_update_distortions(first_slot, n_slots, aux = tile_prefix, n_tiles) */
-#define IMS_PLAN_INIT       5   /* ims_sensor_init_boundaries(first_slot, n_slots) */
+#define IMS_PLAN_INIT       5   /* ims_sensor_init_boundaries(first_slot, n_slots, aux = tile_prefix or NULL, n_tiles) */
 #define IMS_PLAN_RECORD     6   /* record library event number n_slots on the item's stream */
 #define IMS_PLAN_WAIT       7   /* make the item's stream wait for library event number n_slots */
 #define IMS_PLAN_ROUNDS     9   /* the per-round launches of up to IMS_MAX_CHAINS brighter-fatter chains, interleaved round by round:

@@ -38,7 +38,7 @@ def test_struct_sizes_match_binding():
 
 def test_abi_version_and_error_string():
     lib = _abi.load()
-    assert lib.ims_abi_version() == 9
+    assert lib.ims_abi_version() == 10
     # argument checking happens before any HIP call, so it is testable without a GPU
     assert lib.ims_shoot_accumulate(None, None) == -1
     assert b"NULL" in lib.ims_last_error()
@@ -88,9 +88,9 @@ def test_argument_errors_are_reported_before_any_launch():
     P.n_objects = 0                                              # valid and empty, but no image
     assert lib.ims_shoot_accumulate(C.byref(P), None) < 0 and b"image" in lib.ims_last_error()
     # sensor entry points need the host copy of the slot table
-    assert lib.ims_sensor_init_boundaries(None, None, 0, 1, None) < 0
+    assert lib.ims_sensor_init_boundaries(None, None, 0, 1, None, 0, None) < 0
     S = _abi.Sensor()
-    assert lib.ims_sensor_init_boundaries(C.byref(S), C.byref(S), 0, 1, None) < 0 and b"slot" in lib.ims_last_error()
+    assert lib.ims_sensor_init_boundaries(C.byref(S), C.byref(S), 0, 1, None, 0, None) < 0 and b"slot" in lib.ims_last_error()
     assert lib.ims_flat_add(None, None, 1.0, 1.0, 0, 0, 8, 8, None, None, None) < 0 and b"image" in lib.ims_last_error()
     assert lib.ims_image_to_float(None, None, 8, None) < 0
     # a plan that names a stream it was not given

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Rebuild profiles/hbm_traffic.json (what bench.py reports as roofline.traffic and uses for the f64-issue fraction) from
-the committed per-config PMC summaries (tools/pmc_summary.py output): the newest of profiles/round2c_<config>_hbm_pmc.json
+the committed per-config PMC summaries (tools/pmc_summary.py output): the newest of profiles/round2d_<config>_hbm_pmc.json
 (end of round 2: converted pool, k_shoot_photons<2>), round2_<config>_hbm_pmc.json and round1_<config>_final_hbm_pmc.json, with
 the SQ pass of the same tag where present."""
 import json
@@ -16,7 +16,7 @@ KERNELS = {"k_shoot_accumulate(ims_render_params)": "k_shoot_accumulate",
 def main():
     out = {}
     for cfg in ("c2", "c3", "c3b"):
-        cands = [(f"profiles/round2c_{cfg}_hbm_pmc.json", f"profiles/round2c_{cfg}_sq_pmc.json"),
+        cands = [(f"profiles/round2d_{cfg}_hbm_pmc.json", f"profiles/round2d_{cfg}_sq_pmc.json"),
                  (f"profiles/round2_{cfg}_hbm_pmc.json", f"profiles/round2_{cfg}_sq_pmc.json"),
                  (f"profiles/round1_{cfg}_final_hbm_pmc.json", f"profiles/round1_{cfg}_final_sq_pmc.json")]
         found = [c for c in cands if os.path.exists(os.path.join(ROOT, c[0]))]

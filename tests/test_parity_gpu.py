@@ -222,6 +222,24 @@ def _sensor_arrays_gpu(r):
     return out
 
 
+def test_tiled_initial_state_equals_the_per_cell_kernel(torch_cuda, monkeypatch):
+    """k_init_tiles (every owned point evaluated once per tile, neighbours through LDS) writes the boundary points, bounds
+    lines and delta image of k_init_boundaries (one thread per cell, neighbours recomputed) bit for bit: the static CCD
+    region and private regions of different sizes, some clipped at the CCD edge."""
+    from imsim_amd.engine import Renderer
+    scene, objects = _c3_case(n_obj=200, n=300)
+    arrays = []
+    for tiles in ("1", "0"):
+        monkeypatch.setenv("IMS_INIT_TILES", tiles)
+        r = Renderer(scene)
+        r.render_lsst_image(objects, nrecalc=1000)               # private regions: initialised, then updated in rounds
+        r.synchronize()
+        arrays.append(_sensor_arrays_gpu(r))
+    for name in ("boundary", "bounds", "delta"):
+        assert_bits_equal(arrays[0][name], arrays[1][name], f"sensor {name}: tiled vs per-cell initial state")
+    assert np.count_nonzero(arrays[0]["bounds"]) > 0
+
+
 def test_c3_photon_ops_chain_is_bit_exact(torch_cuda):
     """TimeSampler, PupilAnnulusSampler, PhotonDCR, RubinDiffractionOptics (WCS chain, spider
     diffraction, ray trace), FocusDepth, Refraction: every photon field equals the oracle's bits."""

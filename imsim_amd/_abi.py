@@ -248,7 +248,7 @@ def load():
     lib.ims_shoot_photons.argtypes = [C.POINTER(RenderParams), c_vp, C.POINTER(Photons), c_vp]
     lib.ims_apply_ops.argtypes = [C.POINTER(RenderParams), c_vp, C.POINTER(Photons), c_vp]
     lib.ims_shoot_ops_photons.argtypes = [C.POINTER(RenderParams), c_vp, C.POINTER(Photons), c_vp]
-    lib.ims_accumulate_segments.argtypes = [C.POINTER(RenderParams), C.POINTER(Photons), c_vp, c_vp]
+    lib.ims_accumulate_segments.argtypes = [C.POINTER(RenderParams), C.POINTER(Photons), c_vp, c_i32, c_vp]
     lib.ims_accumulate_round.argtypes = [C.POINTER(RenderParams), C.POINTER(Photons), c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]
     lib.ims_accumulate.argtypes = [C.POINTER(RenderParams), c_vp, C.POINTER(Photons), c_vp, c_vp]
     lib.ims_sensor_init_boundaries.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_vp, c_i64, c_vp]

@@ -392,8 +392,9 @@ __device__ __forceinline__ void accumulate_segment(const ims_render_params_t& P,
     }
 }
 
-__global__ __launch_bounds__(256) void k_accumulate_segments(const ims_render_params_t P, const ims_photons_t pool,
-                                                             const int64_t* __restrict__ pool_start)
+template <int NV>
+__global__ __launch_bounds__(256, (NV == 8) ? 2 : 4) void k_accumulate_segments(const ims_render_params_t P, const ims_photons_t pool,
+                                                                                const int64_t* __restrict__ pool_start)
 {
     const int64_t per = (P.n_segments + N_XCD - 1) / N_XCD;
     const int64_t b = blockIdx.x;
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(256) void k_accumulate_segments(const ims_render_pa
     const int64_t seg = xcd_segment(b, P.n_segments);
     if (seg >= P.n_segments) return;
     const int64_t oi = P.seg_object ? (int64_t)P.seg_object[seg] : find_object(P.seg_prefix, P.n_objects, seg);
-    accumulate_segment(P, pool, pool_start, oi, (seg - P.seg_prefix[oi]) * P.seg_size, P.objects[oi].n_phot);
+    accumulate_segment<NV>(P, pool, pool_start, oi, (seg - P.seg_prefix[oi]) * P.seg_size, P.objects[oi].n_phot);
 }
 
 // The same for round `round` of a chain class whose table holds the objects' FULL photon counts: the round covers the
@@ -1461,7 +1462,7 @@ int ims_shoot_ops_photons(const ims_render_params_t* params, const int64_t* phot
 }
 
 int ims_accumulate_segments(const ims_render_params_t* params, const ims_photons_t* pool, const int64_t* pool_start,
-                            void* stream)
+                            int32_t num_vertices, void* stream)
 {
     int rc = check_params(params);
     if (rc) return rc;
@@ -1471,8 +1472,13 @@ int ims_accumulate_segments(const ims_render_params_t* params, const ims_photons
     if (params->n_segments == 0) return IMS_OK;
     hipStream_t st = (hipStream_t)stream;
     {
-        hipLaunchKernelGGL(k_accumulate_segments, dim3(grid_for_segments(params->n_segments)), dim3(256), 0, st,
-                           *params, *pool, pool_start);
+        const dim3 grid(grid_for_segments(params->n_segments));
+        if (num_vertices == 4)
+            hipLaunchKernelGGL(k_accumulate_segments<4>, grid, dim3(256), 0, st, *params, *pool, pool_start);
+        else if (num_vertices == 8)
+            hipLaunchKernelGGL(k_accumulate_segments<8>, grid, dim3(256), 0, st, *params, *pool, pool_start);
+        else
+            hipLaunchKernelGGL(k_accumulate_segments<0>, grid, dim3(256), 0, st, *params, *pool, pool_start);
     }
     HIP_TRY(hipGetLastError());
     return IMS_OK;
@@ -1727,7 +1733,7 @@ int ims_run_plan(const ims_plan_item_t* items, int64_t n_items, const ims_sensor
         switch (it.kind) {
         case IMS_PLAN_RENDER:     rc = ims_shoot_accumulate(it.params, st); break;
         case IMS_PLAN_SHOOT_POOL: rc = ims_shoot_ops_photons(it.params, it.aux, it.pool, st); break;
-        case IMS_PLAN_ACC_POOL:   rc = ims_accumulate_segments(it.params, it.pool, it.aux, st); break;
+        case IMS_PLAN_ACC_POOL:   rc = ims_accumulate_segments(it.params, it.pool, it.aux, sensor_host ? sensor_host->num_vertices : 0, st); break;
         case IMS_PLAN_UPDATE:     rc = ims_sensor_update_distortions(sensor_dev, sensor_host, it.first_slot, it.n_slots, it.aux,
                                                                      it.n_tiles, changed_dev, it.tag, st); break;
         case IMS_PLAN_INIT:       rc = ims_sensor_init_boundaries(sensor_dev, sensor_host, it.first_slot, it.n_slots, it.aux, it.n_tiles, st); break;

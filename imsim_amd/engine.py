@@ -971,14 +971,60 @@ class Renderer:
         pool.converted = bool(converted)
         return pool
 
+    def _num_vertices(self):
+        return int(self.scene.sensor.model.num_vertices) if self.scene.sensor is not None else 0
+
+    def prepared_pooled_batches(self, shoot_table, batches):
+        """Photon-pooling mode with the pool resident in HBM: ONE launch shoots every photon of every batch (shoot, PSF, op
+        chain, conversion depth and diffusion: `ims_shoot_ops_photons` into a converted pool, 32 B per photon -- 49 GB for
+        the 1.5e9 photons of C4, which is what 288 GB of HBM are for), then every batch only runs the pixel search of ITS
+        share of the photons against the sensor state of its turn (`ims_accumulate_segments`).  The photons do not depend on
+        the batch they land in (streams are addressed by object and photon index), so this is the image of one fused launch
+        per batch; what it saves is shooting objects of a few dozen photons per batch in mostly empty wavefronts.
+
+        shoot_table: OBJECT_DTYPE rows with the FULL photon counts; batches: [(rows, first, count, bf_tag)] -- indices into
+        shoot_table, first photon of the batch's share within the object, its photon count.  Returns (shoot, [accumulate]),
+        zero-argument callables."""
+        shoot_table, obj_t, prefix, pre_t = self._upload_objects(shoot_table)
+        base = np.concatenate([[0], np.cumsum(shoot_table["n_phot"])]).astype(np.int64)
+        base_t = self.torch.from_numpy(base).to(self.device)
+        pool, pool_t = self._pool4(base[-1])
+        P = self.bound.params(obj_t.data_ptr(), len(shoot_table), pre_t.data_ptr(), int(prefix[-1]), self.image.data_ptr(),
+                              None, _seg_ptr(pre_t))
+        nv = self._num_vertices()
+
+        def shoot():
+            _abi.check(self.lib.ims_shoot_ops_photons(C.byref(P), base_t.data_ptr(), C.byref(pool), self._stream()),
+                       "ims_shoot_ops_photons")
+        shoot.keep = (obj_t, pre_t, base_t, pool_t, P, pool)
+        shoot.photons = int(base[-1])
+        shoot.object_rows = len(shoot_table)
+        shoot.waves = 4 * int(prefix[-1])
+        launches = []
+        for rows, first, count, bf_tag in batches:
+            part = shoot_table[rows].copy()
+            part["n_phot"] = count
+            part, part_t, bprefix, bpre_t = self._upload_objects(part)
+            start_t = self.torch.from_numpy(np.ascontiguousarray(base[rows] + first, dtype=np.int64)).to(self.device)
+            Pb = self.bound.params(part_t.data_ptr(), len(part), bpre_t.data_ptr(), int(bprefix[-1]), self.image.data_ptr(),
+                                   None, _seg_ptr(bpre_t))
+            Pb.bf_tag = bf_tag
+
+            def accumulate(Pb=Pb, start_t=start_t):
+                _abi.check(self.lib.ims_accumulate_segments(C.byref(Pb), C.byref(pool), start_t.data_ptr(), nv, self._stream()),
+                           "ims_accumulate_segments")
+            accumulate.keep = (part_t, bpre_t, start_t, Pb)
+            launches.append(accumulate)
+        return shoot, launches
+
     def accumulate_segments(self, pool, realized=None):
         """ims_accumulate_segments on a converted pool (segment-mapped: one workgroup per 256 photons of one object)."""
         P = self._pool_params(pool, realized)
         P.seg_object = _seg_ptr(pool.seg_prefix_dev)
         ph = pool.struct()
         ph.converted = 1 if getattr(pool, "converted", False) else 0
-        _abi.check(self.lib.ims_accumulate_segments(C.byref(P), C.byref(ph), pool.photon_offset_dev.data_ptr(), self._stream()),
-                   "ims_accumulate_segments")
+        _abi.check(self.lib.ims_accumulate_segments(C.byref(P), C.byref(ph), pool.photon_offset_dev.data_ptr(),
+                                                    self._num_vertices(), self._stream()), "ims_accumulate_segments")
 
     def _pool_params(self, pool, realized=None):
         return self.bound.params(pool.objects_dev.data_ptr(), pool.n_objects, pool.seg_prefix_dev.data_ptr(),

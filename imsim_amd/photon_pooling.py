@@ -10,6 +10,8 @@ brighter-fatter region recalculated at the first sub-batch of each batch.
 import dataclasses
 import itertools
 
+import os
+
 import numpy as np
 
 from . import parallel
@@ -103,11 +105,17 @@ def make_batch_tables(objects, modes, nbatch, seed):
     return batch_tables, len_smallest
 
 
-def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1):
-    """The same image as build_image, prepared for replay (bench.py): every batch is ONE fused launch
-    (shoot -> PSF -> ops -> sensor, ims_shoot_accumulate) over its pre-uploaded object table -- the photons of a batch
-    see frozen pixel boundaries, so neither the sub-batching (a memory bound of the reference) nor the staging
-    through a photon pool changes the result -- with the pixel-boundary recalculation between batches.
+def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1, resident=None):
+    """The same image as build_image, prepared for replay (bench.py).  The photons of a batch see frozen pixel boundaries,
+    and a photon does not depend on the batch it lands in (its random stream is addressed by object and photon index), so
+    neither the sub-batching (a memory bound of the reference) nor the order of shooting changes the result.
+
+    resident (default: on unless IMS_POOL_RESIDENT=0 or the pool would not fit): ONE launch shoots the photons of ALL
+    batches into an HBM-resident converted pool (32 B per photon: 49 GB for the 1.5e9 photons of C4), then every batch only
+    runs the pixel search of its share (`Renderer.prepared_pooled_batches`) with the pixel-boundary recalculation between
+    batches.  Otherwise every batch is one fused launch (shoot -> PSF -> ops -> sensor, ims_shoot_accumulate) over its own
+    object table, in which an object of 190 photons is shot ten times in wavefronts a third full.
+
     world > 1: the batch tables are built from the FULL object table on every rank, a rank shoots the rows it owns,
     and before every recalculation the delta-charge image is all-reduced so that every rank applies the charge of ALL
     objects (build_image's multi-rank semantics; the tile marks are rank-local, so the update visits every tile).
@@ -117,33 +125,73 @@ def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1)
     sensor_on = renderer.scene.sensor is not None
     owner = parallel.assign_ranks(objects["n_phot"], world)
     tagged = sensor_on and world == 1
-    launches = []
-    for i, (table, index) in enumerate(tables):
-        keep = table["n_phot"] > 0
-        if world > 1:
-            keep &= owner[index] == rank
-        table = table[keep].copy()
+    mine = owner == rank if world > 1 else np.ones(len(objects), dtype=bool)
+    in_batches = np.zeros(len(objects), dtype=bool)
+    for table, index in tables:
+        in_batches[index[table["n_phot"] > 0]] = True
+    shot = np.flatnonzero(in_batches & mine)
+    if resident is None:
+        free = renderer.torch.cuda.mem_get_info(renderer.device)[0]
+        resident = os.environ.get("IMS_POOL_RESIDENT", "1") != "0" and 32 * int(objects["n_phot"][shot].sum()) < 0.8 * free
+
+    def tidy(table):
         table["bf_state"] = 0
-        table["flags"] &= ~IMS_OBJ_FAINT
-        if world > 1:                                      # neighbours in the table share image lines and boundary state
-            tile = (table["y0"] // 256).astype(np.int64) * 4096 + (table["x0"] // 256).astype(np.int64)
-            table = table[np.argsort(tile, kind="stable")]
-        launches.append(renderer.prepared(table, bf_tag=(i % 255 + 1) if tagged else 0))
+        table["flags"] &= ~IMS_OBJ_FAINT     # in pooling mode the ops and the sensor see every photon (photon_pooling.py:154-159)
+        return table
+
+    def spatial(table):
+        # neighbours in the table share image lines and boundary state
+        tile = (table["y0"] // 256).astype(np.int64) * 4096 + (table["x0"] // 256).astype(np.int64)
+        return np.argsort(tile, kind="stable")
+
+    shoot, launches = None, []
+    if resident:
+        shoot_table = tidy(objects[shot].copy())
+        if world > 1:
+            order = spatial(shoot_table)
+            shoot_table, shot = shoot_table[order], shot[order]
+        row_of = np.full(len(objects), -1, dtype=np.int64)
+        row_of[shot] = np.arange(len(shot))
+        batches = []
+        for i, (table, index) in enumerate(tables):
+            keep = (table["n_phot"] > 0) & mine[index]
+            rows = row_of[index[keep]]
+            order = np.argsort(rows, kind="stable")            # the order of the shoot table (spatial with several ranks)
+            rows = rows[order]
+            first = (table["phot_first"][keep] - objects["phot_first"][index[keep]])[order]
+            batches.append((rows, first.astype(np.int64), table["n_phot"][keep][order], (i % 255 + 1) if tagged else 0))
+        shoot, launches = renderer.prepared_pooled_batches(shoot_table, batches)
+    else:
+        for i, (table, index) in enumerate(tables):
+            keep = (table["n_phot"] > 0) & mine[index]
+            table = tidy(table[keep].copy())
+            if world > 1:
+                table = table[spatial(table)]
+            launches.append(renderer.prepared(table, bf_tag=(i % 255 + 1) if tagged else 0))
 
     def run():
         if sensor_on:
             renderer.init_boundaries(0, 1)                 # a new CCD starts from undistorted (+ tree ring) boundaries
+        if shoot is not None:
+            shoot()
         for i, launch in enumerate(launches):
             if sensor_on and i > 0:
                 if world > 1:
                     parallel.allreduce_delta(renderer.delta_tensor(0), integer_counts=True)
                 renderer.update_distortions(0, 1, bf_tag=((i - 1) % 255 + 1) if tagged else 0)
             launch()
-    run.photons = sum(l.photons for l in launches)
-    run.object_rows = sum(l.object_rows for l in launches)
-    run.timed = {1: (len(launches), sum(l.timed[1][1] for l in launches)), 2: (0, 0)}
-    run.timed_waves = {1: sum(l.timed_waves[1] for l in launches), 2: 0}
-    run.keep = launches
+    if shoot is not None:
+        run.photons, run.object_rows = shoot.photons, shoot.object_rows
+        # the pool shoot is the dominant launch: 32 B per converted photon written + one 256-B row per object
+        run.timed = {2: (1, shoot.photons * 32 + shoot.object_rows * 256), 1: (0, 0)}
+        run.timed_waves = {2: shoot.waves, 1: 0}
+    else:
+        run.photons = sum(l.photons for l in launches)
+        run.object_rows = sum(l.object_rows for l in launches)
+        run.timed = {1: (len(launches), sum(l.timed[1][1] for l in launches)), 2: (0, 0)}
+        run.timed_waves = {1: sum(l.timed_waves[1] for l in launches), 2: 0}
+    run.resident = bool(resident)
+    run.keep = (shoot, launches)
     return run
 
 

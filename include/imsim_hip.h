@@ -40,7 +40,7 @@ extern "C" {
 #define IMS_ERR_NO_DEVICE  -3
 #define IMS_ERR_UNSUPPORTED -4
 
-#define IMS_ABI_VERSION 10
+#define IMS_ABI_VERSION 11
 
 /* Pointers stored INSIDE descriptors that live in device memory (ims_sensor_t, ims_atmosphere_t) always point to global
  * device memory.  Device code is told so (address space 1): a pointer read out of memory is otherwise a generic pointer and
@@ -383,9 +383,12 @@ int  ims_shoot_photons(const ims_render_params_t* params, const int64_t* photon_
 int  ims_shoot_ops_photons(const ims_render_params_t* params, const int64_t* photon_offset,
                            const ims_photons_t* pool, void* stream);
 /* sensor.accumulate for the objects of `params` (segment-mapped like ims_shoot_accumulate): photon j of
- * object row i is read from the pool at pool_start[i] + j; its random stream index is phot_first + j */
+ * object row i is read from the (converted) pool at pool_start[i] + j.  num_vertices as for ims_accumulate_round.
+ * Besides the brighter-fatter chains this is the per-batch step of photon-pooling mode when the photons of ALL batches
+ * have been shot into an HBM-resident pool up front (photon_pooling.prepared_image): the row of an object holds the
+ * photon count of its share of the batch, pool_start[i] the place of that share in the object's photons. */
 int  ims_accumulate_segments(const ims_render_params_t* params, const ims_photons_t* pool,
-                             const int64_t* pool_start, void* stream);
+                             const int64_t* pool_start, int32_t num_vertices, void* stream);
 int  ims_apply_ops(const ims_render_params_t* params, const int64_t* photon_offset,
                    const ims_photons_t* pool, void* stream);
 /* pixel_index_out (device, [pool->n], may be NULL): flat image index each photon landed in, -1 = lost */

@@ -208,7 +208,7 @@ STRUCTS = [Object, RadialTables, LinTables, PsfComponent, Op, Surface, TanSip, O
 
 # every symbol include/imsim_hip.h declares
 EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_info", "ims_shoot_accumulate",
-           "ims_shoot_photons", "ims_shoot_ops_photons", "ims_accumulate_segments", "ims_accumulate_round", "ims_run_plan",
+           "ims_shoot_photons", "ims_shoot_ops_photons", "ims_accumulate_segments", "ims_accumulate_small", "ims_accumulate_round", "ims_run_plan",
            "ims_fft_kspace_fill", "ims_fft_finish", "ims_fft_spikes", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
            "ims_sensor_update_distortions", "ims_image_add", "ims_image_to_float", "ims_fill_derived_op", "ims_fill_derived_medium", "ims_fill_derived_optics", "ims_fill_derived_atmosphere", "ims_fill_derived_sensor", "ims_sensor_pixel_areas", "ims_flat_add", "ims_last_kernel_ms", "ims_enable_timing",
            "ims_readout_bleed", "ims_readout_segments", "ims_readout_cte", "ims_readout_finish",
@@ -249,6 +249,7 @@ def load():
     lib.ims_apply_ops.argtypes = [C.POINTER(RenderParams), c_vp, C.POINTER(Photons), c_vp]
     lib.ims_shoot_ops_photons.argtypes = [C.POINTER(RenderParams), c_vp, C.POINTER(Photons), c_vp]
     lib.ims_accumulate_segments.argtypes = [C.POINTER(RenderParams), C.POINTER(Photons), c_vp, c_i32, c_vp]
+    lib.ims_accumulate_small.argtypes = [C.POINTER(RenderParams), C.POINTER(Photons), c_vp, c_i32, c_vp]
     lib.ims_accumulate_round.argtypes = [C.POINTER(RenderParams), C.POINTER(Photons), c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]
     lib.ims_accumulate.argtypes = [C.POINTER(RenderParams), c_vp, C.POINTER(Photons), c_vp, c_vp]
     lib.ims_sensor_init_boundaries.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_vp, c_i64, c_vp]

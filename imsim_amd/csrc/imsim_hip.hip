@@ -405,6 +405,51 @@ __global__ __launch_bounds__(256, (NV == 8) ? 2 : 4) void k_accumulate_segments(
     accumulate_segment<NV>(P, pool, pool_start, oi, (seg - P.seg_prefix[oi]) * P.seg_size, P.objects[oi].n_phot);
 }
 
+// The same for objects of at most a wavefront or two of photons (the per-batch shares of photon-pooling mode: median 19):
+// ONE WAVEFRONT per object, four independent objects per workgroup, no LDS tile and no barrier -- a share of a few dozen
+// photons lands in as many different pixels, so the tile would merge nothing, and a million workgroups of one live
+// wavefront each are bound by the dispatch rate (9 ms per batch of C4 for 2 ms of work).  The object index is made
+// wave-uniform with readfirstlane so that the row still comes through scalar loads.
+template <int NV>
+__global__ __launch_bounds__(256, (NV == 8) ? 2 : 3) void k_accumulate_small(const ims_render_params_t P, const ims_photons_t pool,
+                                                                             const int64_t* __restrict__ pool_start)
+{
+    const int64_t first = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int64_t oi = ((int64_t)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)first);
+    if (oi >= P.n_objects) return;
+    const ims_object_t& o = P.objects[oi];
+    const bool silicon = (P.sensor != nullptr) && (P.sensor->kind == IMS_SENSOR_SILICON);
+    ChargeTile ct;
+    ct.x0 = 0; ct.y0 = 0;
+    ct.track = silicon && !(o.flags & IMS_OBJ_FAINT) && (o.bf_state > 0 || P.track_static_delta);
+    if (ct.track) ct.slot = P.sensor->bf_slots[o.bf_state];
+    const int64_t base = pool_start[oi], n = o.n_phot;
+    double added = 0.0;
+#pragma unroll 1
+    for (int64_t j = threadIdx.x & 63; j < n; j += 64) {
+        const int64_t i = base + j;
+        const double x0 = pool.x[i], y0 = pool.y[i], flux = pool.flux[i], zs = pool.dxdz[i];
+        if (flux == 0.0) continue;
+        int ix, iy;
+        bool ok;
+        if (!silicon || (o.flags & IMS_OBJ_FAINT)) {
+            ix = (int)floor(x0 + 0.5); iy = (int)floor(y0 + 0.5);
+            ok = !(ix < o.stamp_xmin || ix > o.stamp_xmax || iy < o.stamp_ymin || iy > o.stamp_ymax);
+        } else {
+            ok = land_search<NV, true>(P, o, x0, y0, fabs(zs), __double_as_longlong(zs) < 0, ix, iy);
+        }
+        if (ok) {
+            added += flux;
+            deposit_global(P, ct, ix, iy, flux);
+        }
+    }
+    if (P.realized_flux != nullptr) {
+        const double tot = wave_sum(added);
+        if ((threadIdx.x & 63) == 0 && tot != 0.0) unsafeAtomicAdd(P.realized_flux + oi, tot);
+    }
+}
+
 // The same for round `round` of a chain class whose table holds the objects' FULL photon counts: the round covers the
 // photons [round * nrecalc, (round + 1) * nrecalc) of every object, `segs` = ceil(nrecalc / 256) workgroups per object;
 // the first n_active rows (sorted by photon count, brightest first) are the objects that reach this round.
@@ -1480,6 +1525,25 @@ int ims_accumulate_segments(const ims_render_params_t* params, const ims_photons
         else
             hipLaunchKernelGGL(k_accumulate_segments<0>, grid, dim3(256), 0, st, *params, *pool, pool_start);
     }
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+int ims_accumulate_small(const ims_render_params_t* params, const ims_photons_t* pool, const int64_t* pool_start,
+                         int32_t num_vertices, void* stream)
+{
+    if (!params) return set_err(IMS_ERR_ARG, "params is NULL");
+    if (!params->objects || !params->image) return set_err(IMS_ERR_ARG, "objects/image is NULL");
+    if (!pool || !pool_start) return set_err(IMS_ERR_ARG, "pool/pool_start is NULL");
+    if (!pool->converted) return set_err(IMS_ERR_ARG, "pool must hold converted photons (ims_shoot_ops_photons with pool->converted = 1)");
+    if (params->n_objects <= 0) return IMS_OK;
+    const int64_t blocks = (params->n_objects + 3) / 4;
+    if (blocks > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "too many objects for one launch");
+    const dim3 grid((unsigned)blocks);
+    hipStream_t st = (hipStream_t)stream;
+    if (num_vertices == 4) hipLaunchKernelGGL(k_accumulate_small<4>, grid, dim3(256), 0, st, *params, *pool, pool_start);
+    else if (num_vertices == 8) hipLaunchKernelGGL(k_accumulate_small<8>, grid, dim3(256), 0, st, *params, *pool, pool_start);
+    else hipLaunchKernelGGL(k_accumulate_small<0>, grid, dim3(256), 0, st, *params, *pool, pool_start);
     HIP_TRY(hipGetLastError());
     return IMS_OK;
 }

@@ -1001,19 +1001,26 @@ class Renderer:
         shoot.object_rows = len(shoot_table)
         shoot.waves = 4 * int(prefix[-1])
         launches = []
+        small_max = int(os.environ.get("IMS_POOL_SMALL_MAX", "64"))    # shares up to a wavefront: one wavefront per object
         for rows, first, count, bf_tag in batches:
-            part = shoot_table[rows].copy()
-            part["n_phot"] = count
-            part, part_t, bprefix, bpre_t = self._upload_objects(part)
-            start_t = self.torch.from_numpy(np.ascontiguousarray(base[rows] + first, dtype=np.int64)).to(self.device)
-            Pb = self.bound.params(part_t.data_ptr(), len(part), bpre_t.data_ptr(), int(bprefix[-1]), self.image.data_ptr(),
-                                   None, _seg_ptr(bpre_t))
-            Pb.bf_tag = bf_tag
+            rows, first, count = np.asarray(rows), np.asarray(first), np.asarray(count)
+            calls = []
+            for sel, entry in ((count > small_max, self.lib.ims_accumulate_segments), (count <= small_max, self.lib.ims_accumulate_small)):
+                if not sel.any():
+                    continue
+                part = shoot_table[rows[sel]].copy()
+                part["n_phot"] = count[sel]
+                part, part_t, bprefix, bpre_t = self._upload_objects(part)
+                start_t = self.torch.from_numpy(np.ascontiguousarray(base[rows[sel]] + first[sel], dtype=np.int64)).to(self.device)
+                Pb = self.bound.params(part_t.data_ptr(), len(part), bpre_t.data_ptr(), int(bprefix[-1]), self.image.data_ptr(),
+                                       None, _seg_ptr(bpre_t))
+                Pb.bf_tag = bf_tag
+                calls.append((entry, Pb, start_t, (part_t, bpre_t)))
 
-            def accumulate(Pb=Pb, start_t=start_t):
-                _abi.check(self.lib.ims_accumulate_segments(C.byref(Pb), C.byref(pool), start_t.data_ptr(), nv, self._stream()),
-                           "ims_accumulate_segments")
-            accumulate.keep = (part_t, bpre_t, start_t, Pb)
+            def accumulate(calls=calls):
+                for entry, Pb, start_t, _ in calls:
+                    _abi.check(entry(C.byref(Pb), C.byref(pool), start_t.data_ptr(), nv, self._stream()), "ims_accumulate_segments / _small")
+            accumulate.keep = calls
             launches.append(accumulate)
         return shoot, launches
 

@@ -147,7 +147,7 @@ def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1,
     shoot, launches = None, []
     if resident:
         shoot_table = tidy(objects[shot].copy())
-        if world > 1:
+        if world > 1 or os.environ.get("IMS_POOL_SPATIAL", "1") != "0":
             order = spatial(shoot_table)
             shoot_table, shot = shoot_table[order], shot[order]
         row_of = np.full(len(objects), -1, dtype=np.int64)

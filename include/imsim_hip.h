@@ -389,6 +389,11 @@ int  ims_shoot_ops_photons(const ims_render_params_t* params, const int64_t* pho
  * photon count of its share of the batch, pool_start[i] the place of that share in the object's photons. */
 int  ims_accumulate_segments(const ims_render_params_t* params, const ims_photons_t* pool,
                              const int64_t* pool_start, int32_t num_vertices, void* stream);
+/* The same result for tables of SMALL shares (a few dozen photons per row): one wavefront per object row, no workgroup
+ * charge tile; params->seg_prefix / seg_object / n_segments are not used.  Any photon count is accepted (a wavefront
+ * loops over its row), the segment-mapped entry point above is the faster one above ~128 photons per row. */
+int  ims_accumulate_small(const ims_render_params_t* params, const ims_photons_t* pool,
+                          const int64_t* pool_start, int32_t num_vertices, void* stream);
 int  ims_apply_ops(const ims_render_params_t* params, const int64_t* photon_offset,
                    const ims_photons_t* pool, void* stream);
 /* pixel_index_out (device, [pool->n], may be NULL): flat image index each photon landed in, -1 = lost */

@@ -149,7 +149,7 @@ class Sensor(C.Structure):
                 ("n_bf_slots", c_i32), ("pad2", c_i32), ("bf_slots", c_vp),
                 ("bf_boundary", c_vp), ("bf_bounds", c_vp), ("bf_delta", c_vp),
                 ("bf_tile_charge", c_vp), ("bf_tile_changed", c_vp), ("pristine_margin", c_d),
-                ("diff_coef", c_d), ("thick_m1", c_d), ("bf_dl", c_vp), ("bf_dl_mfma", c_vp)]
+                ("diff_coef", c_d), ("thick_m1", c_d), ("bf_dl", c_vp)]
 
 
 class Photons(C.Structure):

@@ -779,7 +779,6 @@ struct UpdateLds {
     double dl[8 * 8 * NPO * 2];           // [dj+Q][di+Q][owned point][x,y]
     unsigned int occ[HW];
     int any_charge;
-    unsigned char moved[UT * UT];         // MFMA path: the cell of lane (lx, ly) has charge in reach
 };
 
 template <int NV>
@@ -890,109 +889,6 @@ __device__ __forceinline__ void update_tile_q3(const ims_sensor_t& s, const Slot
     PROBE(14);
 }
 
-// The same superposition on the f64 matrix cores.  For the 16 cells of one tile row the update is the product of
-// W (16 cells x 64 taps, the scaled charges around each cell) with the displacement table (64 taps x 2 NPO outputs):
-// v_mfma_f64_16x16x4_f64 forms every output as c = fma(a_k, b_k, c), k = 0 .. 3 in order (measured: 1 048 576 of 1 048 576
-// elements equal to that chain bit for bit, tools/dbg/mfma_f64_order.hip), so sixteen of them chained over the taps in the
-// spec's order (dj ascending, then di ascending) give exactly the FMA chain of update_tile_q3 -- taps and outputs that do not
-// apply carry a zero table entry or a zero charge, and fma(x, 0, acc) = acc (acc is never -0, see above).  Why bother: the
-// rounds of the long brighter-fatter chains share the GPU with the photon kernels, which saturate the VECTOR ALUs and leave
-// the matrix pipe idle; the 1 280 dependent FMAs per cell were the part of a round that the sharing slowed down most.
-// dlm: [block of 16 outputs][16 steps of 4 taps][64 lanes] doubles in the B-operand layout (lane l: tap 4 step + l / 16,
-// output 16 block + l % 16), engine.update_mfma_table.
-template <int NV>
-__device__ __forceinline__ void update_tile_mfma(const ims_sensor_t& s, const SlotView& sl, int tx0, int ty0,
-                                                 unsigned char* __restrict__ changed, UpdateLds<NV>& L, unsigned int tag,
-                                                 const double* __restrict__ dlm)
-{
-    constexpr int Q = 3, HW = UT + 2 * Q + 1, NPO = 2 * NV + 2, NOUT = 2 * NPO, NB = (NOUT + 15) / 16;
-    typedef double dvec4 __attribute__((ext_vector_type(4)));
-    const int sx0 = tx0 - (Q + 1), sy0 = ty0 - (Q + 1);
-    if (threadIdx.x < HW) L.occ[threadIdx.x] = 0u;
-    if (threadIdx.x == 0) L.any_charge = 0;
-    __syncthreads();
-    for (int e = threadIdx.x; e < HW * HW; e += 256) {
-        const int hx = e % HW, hy = e / HW;
-        const int si = sx0 + hx, sj = sy0 + hy;
-        double w = 0.0;
-        if (si >= 0 && si < sl.nx && sj >= 0 && sj < sl.ny) {
-            const double charge = (double)s.bf_delta[cell_index(sl, si, sj)];
-            if (charge != 0.0) { w = ddiv(charge, s.num_elec); atomicOr(&L.occ[hy], 1u << hx); L.any_charge = 1; }
-        }
-        L.wt[e] = w;
-    }
-    __syncthreads();
-    const int lx = threadIdx.x % UT, ly = threadIdx.x / UT;
-    const int i = tx0 + lx, j = ty0 + ly;
-    const bool in_region = (i <= sl.nx && j <= sl.ny);
-    if (!L.any_charge) {                     // nothing landed near this tile: nothing moves
-        if (in_region) changed[cell_index(sl, i, j)] = 0;
-        return;
-    }
-    // does this lane's cell have charge in reach?  (the 8 x 8 window cut out of the row bitmaps, as in update_tile_q3)
-    bool moved = false;
-    if (in_region) {
-        unsigned int any = 0u;
-#pragma unroll
-        for (int a = 0; a < 8; ++a) any |= (L.occ[ly + 2 * Q + 1 - a] >> lx) & 0xFFu;
-        moved = any != 0u;
-        changed[cell_index(sl, i, j)] = moved ? 1 : 0;
-        if (moved && tag != 0u && s.bf_tile_changed != nullptr) s.bf_tile_changed[cell_index(sl, tx0, ty0)] = (unsigned char)tag;
-    }
-    L.moved[threadIdx.x] = moved ? 1 : 0;
-    __syncthreads();
-    // a wavefront owns the four tile rows of its lanes; one without a moving cell has nothing to do
-    if (__builtin_amdgcn_ballot_w64(moved) == 0ull) return;
-    const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int col = l & 15, grp = l >> 4;            // B / D column (output), A tap within the step / D row group
-#pragma unroll 1
-    for (int nb = 0; nb < NB; ++nb) {
-        const int o = 16 * nb + col;                // the output (coordinate of an owned point) this lane holds
-        dvec4 c[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int cj = ty0 + 4 * wv + r;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ci = tx0 + grp + 4 * g;
-                const bool ok = (ci <= sl.nx && cj <= sl.ny && o < NOUT);
-                c[r][g] = ok ? s.bf_boundary[cell_index(sl, ci, cj) * NOUT + o] : 0.0;
-            }
-        }
-        // four steps (16 taps, two window rows) at a time: their table entries and charges are fetched together, which
-        // bounds the registers in flight (the fully unrolled form preloaded all 64 charges and spilled)
-#pragma unroll 1
-        for (int k0 = 0; k0 < 16; k0 += 4) {
-            double b[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) b[u] = dlm[(nb * 16 + k0 + u) * 64 + l];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int tap = 4 * (k0 + u) + grp, a = tap >> 3, bb = tap & 7;
-                double w[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) w[r] = L.wt[(4 * wv + r + 2 * Q + 1 - a) * HW + (col + 2 * Q + 1 - bb)];
-#ifdef IMS_MFMA_SKIP
-                // a step whose four taps carry no charge for any of the wavefront's 64 cells adds exact zeros: skipped
-                if (__builtin_amdgcn_ballot_w64((w[0] != 0.0) | (w[1] != 0.0) | (w[2] != 0.0) | (w[3] != 0.0)) == 0ull) continue;
-#endif
-#pragma unroll
-                for (int r = 0; r < 4; ++r) c[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[r], b[u], c[r], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int cj = ty0 + 4 * wv + r;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ci = tx0 + grp + 4 * g;
-                if (ci <= sl.nx && cj <= sl.ny && o < NOUT && L.moved[(4 * wv + r) * UT + grp + 4 * g])
-                    s.bf_boundary[cell_index(sl, ci, cj) * NOUT + o] = c[r][g];
-            }
-        }
-    }
-}
-
 // Fast path for qdist == 3 (the GalSim default): the 8x8 source window of a cell is a 64-bit
 // occupancy mask cut out of per-row LDS bitmaps, so a lane only iterates over its OWN charged
 // neighbours (in the spec's order: dj ascending, then di ascending) instead of testing all 64.
@@ -1025,31 +921,6 @@ __global__ __launch_bounds__(256) void k_update_distortions_q3(const ims_sensor_
 #endif
     if (dl_global != nullptr) update_tile_q3<NV, true>(s, sl, tx0, ty0, changed, L, false, tag, dl_global);
     else update_tile_q3<NV, false>(s, sl, tx0, ty0, changed, L, false, tag);
-}
-
-// updatePixelDistortions on the f64 matrix cores (update_tile_mfma), same grid as k_update_distortions_q3.  At most 128
-// registers: it shares the GPU with the 128-VGPR photon kernels (see k_accumulate_round).
-template <int NV>
-__global__ __launch_bounds__(256, 4) void k_update_distortions_mfma(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
-                                                                    const int64_t* __restrict__ tile_prefix,
-                                                                    unsigned char* __restrict__ changed, unsigned int tag,
-                                                                    const double* __restrict__ dl_mfma)
-{
-    __shared__ UpdateLds<NV> L;
-    const ims_sensor_t& s = *sp;
-    const int64_t b = blockIdx.x;
-    int lo = 0, hi = n_slots;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (tile_prefix[mid] <= b) lo = mid; else hi = mid;
-    }
-    const ims_bf_slot_t bs = s.bf_slots[first_slot + lo];
-    const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
-    const int tiles_x = (sl.nx + 1 + UT - 1) / UT;
-    const int t = (int)(b - tile_prefix[lo]);
-    const int tx0 = (t % tiles_x) * UT, ty0 = (t / tiles_x) * UT;
-    if (tile_out_of_reach(s, sl, tx0 / UT, ty0 / UT, tag)) return;
-    update_tile_mfma<NV>(s, sl, tx0, ty0, changed, L, tag, dl_mfma);
 }
 
 // bounds of the pixels whose polygon moved (own cell, right cell or upper cell changed); one 16x16
@@ -1815,18 +1686,7 @@ int ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sens
     const unsigned g = (unsigned)((count + 255) / 256);
     const int nV = sensor_host ? sensor_host->num_vertices : 0;
     const int q = sensor_host ? sensor_host->qdist : 0;
-    // the matrix-core form for launches of at most IMS_UPDATE_MFMA_TILES tiles (default 2048: the rounds of the long chains,
-    // where a round's latency counts and the vector ALUs belong to the photon kernels); the wide launches keep the vector
-    // form, whose per-lane masks skip more of a sparse window than the 4-tap steps of the matrix form can
-    static const long mfma_tiles = getenv("IMS_UPDATE_MFMA_TILES") ? atol(getenv("IMS_UPDATE_MFMA_TILES")) : 2048;
-    const double* dlm = (sensor_host && q == 3 && n_tiles <= mfma_tiles) ? sensor_host->bf_dl_mfma : nullptr;
-    if (dlm != nullptr && nV == 4)
-        hipLaunchKernelGGL(k_update_distortions_mfma<4>, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot,
-                           n_slots, tile_prefix_dev, changed_dev, tag, dlm);
-    else if (dlm != nullptr && nV == 8)
-        hipLaunchKernelGGL(k_update_distortions_mfma<8>, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot,
-                           n_slots, tile_prefix_dev, changed_dev, tag, dlm);
-    else if (q == 3 && nV == 4)
+    if (q == 3 && nV == 4)
         hipLaunchKernelGGL(k_update_distortions_q3<4>, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot,
                            n_slots, tile_prefix_dev, changed_dev, tag, sensor_host->bf_dl);
     else if (q == 3 && nV == 8)

@@ -251,32 +251,6 @@ def update_window_table(m):
     return out
 
 
-def update_mfma_table(m):
-    """ims_sensor_t.bf_dl_mfma: update_window_table in the B-operand layout of v_mfma_f64_16x16x4_f64 -- [block of 16
-    outputs][16 steps of 4 taps][64 lanes]; lane l of step k holds output 16 block + l % 16 (coordinate 2 n + c of owned point
-    n) for tap 4 k + l // 16 (tap = 8 a + b of the [a][b] window).  Taps that do not act on a point carry 0: the extra
-    column b = 7 for bottom-row points (n <= nV + 1), the extra row a = 7 for left-edge points."""
-    nV = int(m.num_vertices)
-    npo = 2 * nV + 2
-    nout = 2 * npo
-    win = update_window_table(m).reshape(64, npo, 2).copy()           # [tap][point][x, y]
-    taps = np.arange(64)
-    a, b = taps // 8, taps % 8
-    n = np.arange(npo)
-    win[np.ix_(b == 7, n <= nV + 1)] = 0.0
-    win[np.ix_(a == 7, n > nV + 1)] = 0.0
-    flat = win.reshape(64, nout)
-    nb = (nout + 15) // 16
-    padded = np.zeros((64, nb * 16))
-    padded[:, :nout] = flat
-    lane = np.arange(64)
-    out = np.zeros((nb, 16, 64))
-    for blk in range(nb):
-        for k in range(16):
-            out[blk, k] = padded[4 * k + lane // 16, 16 * blk + lane % 16]
-    return out
-
-
 def treering_displacement_bound(ss):
     """Upper bound of |tree-ring shift| over the CCD [pixels]: on every table interval the interpolant is the chord plus
     the cubic-spline term ((a^3 - a) m0 + (b^3 - b) m1) h^2 / 6 with |a^3 - a| <= 2 / (3 sqrt 3); a few ulp on top."""
@@ -469,7 +443,6 @@ class BoundScene:
         _, S.distortions = self.mem.put(m.distortions, np.float64)
         if m.qdist == 3:
             _, S.bf_dl = self.mem.put(update_window_table(m), np.float64)
-            _, S.bf_dl_mfma = self.mem.put(update_mfma_table(m), np.float64)
         _, S.emptypoly = self.mem.put(m.emptypoly, np.float64)
         slots = ss.slots if ss.slots is not None else make_slots([])
         self.n_static_slots = len(slots)

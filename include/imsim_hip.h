@@ -40,7 +40,7 @@ extern "C" {
 #define IMS_ERR_NO_DEVICE  -3
 #define IMS_ERR_UNSUPPORTED -4
 
-#define IMS_ABI_VERSION 12
+#define IMS_ABI_VERSION 11
 
 /* Pointers stored INSIDE descriptors that live in device memory (ims_sensor_t, ims_atmosphere_t) always point to global
  * device memory.  Device code is told so (address space 1): a pointer read out of memory is otherwise a generic pointer and
@@ -316,13 +316,6 @@ typedef struct ims_sensor {
      * dj, di = -3 .. 4 (8 x 8 x (2 num_vertices + 2) x 2 doubles, device memory): distortions[di + cx][dj + cy][vertex of the owned
      * point].  With it the kernel reads a neighbour's row through the scalar cache; NULL = staged through LDS per tile. */
     const double IMS_G* bf_dl;
-    /* optional (qdist 3): the same table in the B-operand layout of v_mfma_f64_16x16x4_f64, [ceil(2 (2 num_vertices + 2) / 16)]
-     * [16 steps of 4 taps][64 lanes] doubles: lane l of step k of block nb holds the displacement of output 16 nb + l % 16
-     * (coordinate 2 n + c of owned point n; 0 beyond the last) for tap 4 k + l / 16 (tap = 8 (dj + 3) + (di + 3); 0 where the
-     * tap does not act on the point: di = 4 for bottom-row points, dj = 4 for left-edge points).  With it
-     * updatePixelDistortions runs on the f64 matrix cores, bit-identical to the vector form (the instruction is a chain of
-     * IEEE FMAs in tap order); NULL = vector ALUs. */
-    const double IMS_G* bf_dl_mfma;
 } ims_sensor_t;
 
 /* A photon pool in device memory, SoA, the fields of galsim.PhotonArray (imsim/photon_ops.py:81). */

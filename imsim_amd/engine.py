@@ -974,7 +974,7 @@ class Renderer:
     def _num_vertices(self):
         return int(self.scene.sensor.model.num_vertices) if self.scene.sensor is not None else 0
 
-    def prepared_pooled_batches(self, shoot_table, batches):
+    def prepared_pooled_batches(self, shoot_table, batches, realized=None):
         """Photon-pooling mode with the pool resident in HBM: ONE launch shoots every photon of every batch (shoot, PSF, op
         chain, conversion depth and diffusion: `ims_shoot_ops_photons` into a converted pool, 32 B per photon -- 49 GB for
         the 1.5e9 photons of C4, which is what 288 GB of HBM are for), then every batch only runs the pixel search of ITS
@@ -983,8 +983,9 @@ class Renderer:
         per batch; what it saves is shooting objects of a few dozen photons per batch in mostly empty wavefronts.
 
         shoot_table: OBJECT_DTYPE rows with the FULL photon counts; batches: [(rows, first, count, bf_tag)] -- indices into
-        shoot_table, first photon of the batch's share within the object, its photon count.  Returns (shoot, [accumulate]),
-        zero-argument callables."""
+        shoot_table, first photon of the batch's share within the object, its photon count.  realized: optional f64 device
+        tensor over the rows of shoot_table receiving the flux every object added to the image.  Returns
+        (shoot, [accumulate]), zero-argument callables."""
         shoot_table, obj_t, prefix, pre_t = self._upload_objects(shoot_table)
         base = np.concatenate([[0], np.cumsum(shoot_table["n_phot"])]).astype(np.int64)
         base_t = self.torch.from_numpy(base).to(self.device)
@@ -1012,14 +1013,22 @@ class Renderer:
                 part["n_phot"] = count[sel]
                 part, part_t, bprefix, bpre_t = self._upload_objects(part)
                 start_t = self.torch.from_numpy(np.ascontiguousarray(base[rows[sel]] + first[sel], dtype=np.int64)).to(self.device)
+                tmp = rows_t = None
+                if realized is not None:
+                    tmp = self.torch.zeros(len(part), dtype=self.torch.float64, device=self.device)
+                    rows_t = self.torch.from_numpy(np.ascontiguousarray(rows[sel], dtype=np.int64)).to(self.device)
                 Pb = self.bound.params(part_t.data_ptr(), len(part), bpre_t.data_ptr(), int(bprefix[-1]), self.image.data_ptr(),
-                                       None, _seg_ptr(bpre_t))
+                                       tmp.data_ptr() if tmp is not None else None, _seg_ptr(bpre_t))
                 Pb.bf_tag = bf_tag
-                calls.append((entry, Pb, start_t, (part_t, bpre_t)))
+                calls.append((entry, Pb, start_t, (part_t, bpre_t, tmp, rows_t)))
 
             def accumulate(calls=calls):
-                for entry, Pb, start_t, _ in calls:
+                for entry, Pb, start_t, (_, _, tmp, rows_t) in calls:
+                    if tmp is not None:
+                        tmp.zero_()
                     _abi.check(entry(C.byref(Pb), C.byref(pool), start_t.data_ptr(), nv, self._stream()), "ims_accumulate_segments / _small")
+                    if tmp is not None:
+                        realized.index_add_(0, rows_t, tmp)
             accumulate.keep = calls
             launches.append(accumulate)
         return shoot, launches

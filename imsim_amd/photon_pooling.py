@@ -105,7 +105,16 @@ def make_batch_tables(objects, modes, nbatch, seed):
     return batch_tables, len_smallest
 
 
-def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1, resident=None):
+def _pool_fits(renderer, n_photons):
+    """the HBM-resident pool of prepared_image / build_image: 32 B per photon, at most 80 % of the free memory"""
+    if os.environ.get("IMS_POOL_RESIDENT", "1") == "0" or not hasattr(renderer, "prepared_pooled_batches"):
+        return False
+    free = renderer.torch.cuda.mem_get_info(renderer.device)[0]
+    return 32 * int(n_photons) < 0.8 * free
+
+
+def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1, resident=None, realized=None,
+                   after_batch=None, first_batch=0):
     """The same image as build_image, prepared for replay (bench.py).  The photons of a batch see frozen pixel boundaries,
     and a photon does not depend on the batch it lands in (its random stream is addressed by object and photon index), so
     neither the sub-batching (a memory bound of the reference) nor the order of shooting changes the result.
@@ -119,6 +128,9 @@ def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1,
     world > 1: the batch tables are built from the FULL object table on every rank, a rank shoots the rows it owns,
     and before every recalculation the delta-charge image is all-reduced so that every rank applies the charge of ALL
     objects (build_image's multi-rank semantics; the tile marks are rank-local, so the update visits every tile).
+    realized (resident form only): f64 device tensor over the rows of `objects` receiving base['realized_flux'];
+    after_batch(i): called on the host after batch i has been enqueued (checkpoints); first_batch: batches before it are
+    skipped (a resumed CCD; as in the reference it continues from fresh pixel boundaries).
     Returns a zero-argument callable."""
     objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
     tables, _ = make_batch_tables(objects, modes, nbatch, seed)
@@ -131,8 +143,9 @@ def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1,
         in_batches[index[table["n_phot"] > 0]] = True
     shot = np.flatnonzero(in_batches & mine)
     if resident is None:
-        free = renderer.torch.cuda.mem_get_info(renderer.device)[0]
-        resident = os.environ.get("IMS_POOL_RESIDENT", "1") != "0" and 32 * int(objects["n_phot"][shot].sum()) < 0.8 * free
+        resident = _pool_fits(renderer, objects["n_phot"][shot].sum())
+    if realized is not None and not resident:
+        raise ValueError("prepared_image: realized fluxes need the resident form")
 
     def tidy(table):
         table["bf_state"] = 0
@@ -160,7 +173,10 @@ def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1,
             rows = rows[order]
             first = (table["phot_first"][keep] - objects["phot_first"][index[keep]])[order]
             batches.append((rows, first.astype(np.int64), table["n_phot"][keep][order], (i % 255 + 1) if tagged else 0))
-        shoot, launches = renderer.prepared_pooled_batches(shoot_table, batches)
+        r_rows = None
+        if realized is not None:
+            r_rows = renderer.torch.zeros(len(shoot_table), dtype=renderer.torch.float64, device=renderer.device)
+        shoot, launches = renderer.prepared_pooled_batches(shoot_table, batches, realized=r_rows)
     else:
         for i, (table, index) in enumerate(tables):
             keep = (table["n_phot"] > 0) & mine[index]
@@ -175,11 +191,17 @@ def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1,
         if shoot is not None:
             shoot()
         for i, launch in enumerate(launches):
-            if sensor_on and i > 0:
+            if i < first_batch:
+                continue
+            if sensor_on and i > first_batch:
                 if world > 1:
                     parallel.allreduce_delta(renderer.delta_tensor(0), integer_counts=True)
                 renderer.update_distortions(0, 1, bf_tag=((i - 1) % 255 + 1) if tagged else 0)
             launch()
+            if after_batch is not None:
+                after_batch(i)
+        if realized is not None:
+            realized.index_add_(0, renderer.torch.from_numpy(shot).to(renderer.device), r_rows)
     if shoot is not None:
         run.photons, run.object_rows = shoot.photons, shoot.object_rows
         # the pool shoot is the dominant launch: 32 B per converted photon written + one 256-B row per object
@@ -224,6 +246,22 @@ def build_image(renderer, objects, modes, nbatch=10, nsubbatch=50, seed=0, reali
         if saved is not None:
             image, first_batch = saved
             renderer.set_image64(image)
+    if _pool_fits(renderer, sum(int(t["n_phot"].sum()) for t, _ in batch_tables)):
+        # the HBM-resident form (prepared_image): all photons shot once, every batch only the pixel search of its share --
+        # the sub-batches of the reference bound the memory of its photon arrays and do not change the image
+        def save(i):
+            if checkpoint is not None:
+                checkpoint.save(chk_name, (renderer.image64_numpy(), i + 1))
+        if first_batch < len(batch_tables):
+            prepared_image(renderer, objects, modes, nbatch=nbatch, seed=seed, rank=rank, world=world, resident=True,
+                           realized=realized, after_batch=save, first_batch=first_batch)()
+        mine = parallel.assign_ranks(objects["n_phot"], world) == rank if world > 1 else None
+        for i, (t, index) in enumerate(batch_tables):
+            sel = t["n_phot"] > 0
+            if mine is not None and i >= first_batch:
+                sel &= mine[index]
+            total += int(t["n_phot"][sel].sum())
+        return total
     sensor_on = renderer.scene.sensor is not None
     owner = parallel.assign_ranks(objects["n_phot"], world)
     nsub = max(min(nsubbatch, len_smallest or 1), 1)

@@ -1033,14 +1033,16 @@ class Renderer:
             launches.append(accumulate)
         return shoot, launches
 
-    def accumulate_segments(self, pool, realized=None):
-        """ims_accumulate_segments on a converted pool (segment-mapped: one workgroup per 256 photons of one object)."""
+    def accumulate_segments(self, pool, realized=None, small=False):
+        """ims_accumulate_segments on a converted pool (segment-mapped: one workgroup per 256 photons of one object);
+        small=True: ims_accumulate_small (one wavefront per object row, any photon count)."""
         P = self._pool_params(pool, realized)
         P.seg_object = _seg_ptr(pool.seg_prefix_dev)
         ph = pool.struct()
         ph.converted = 1 if getattr(pool, "converted", False) else 0
-        _abi.check(self.lib.ims_accumulate_segments(C.byref(P), C.byref(ph), pool.photon_offset_dev.data_ptr(),
-                                                    self._num_vertices(), self._stream()), "ims_accumulate_segments")
+        entry = self.lib.ims_accumulate_small if small else self.lib.ims_accumulate_segments
+        _abi.check(entry(C.byref(P), C.byref(ph), pool.photon_offset_dev.data_ptr(), self._num_vertices(), self._stream()),
+                   "ims_accumulate_small" if small else "ims_accumulate_segments")
 
     def _pool_params(self, pool, realized=None):
         return self.bound.params(pool.objects_dev.data_ptr(), pool.n_objects, pool.seg_prefix_dev.data_ptr(),

@@ -166,6 +166,13 @@ def test_shoot_ops_photons_one_launch_equals_shoot_then_ops(torch_cuda):
     r2.render(objects)
     r2.synchronize()
     assert_bits_equal(r2.image_numpy(), r.image_numpy(), "fused vs converted pool")
+    # ims_accumulate_small (one wavefront per object row, here looping over rows of up to millions of photons)
+    r3 = Renderer(scene)
+    real3 = torch_cuda.zeros(len(objects), dtype=torch_cuda.float64, device="cuda")
+    r3.accumulate_segments(r3.shoot_ops_photons(objects, converted=True), realized=real3, small=True)
+    r3.synchronize()
+    assert_bits_equal(r3.image_numpy(), orc.image, "wave-per-object pixel search vs oracle")
+    assert_bits_equal(real3.cpu().numpy(), real_o, "realized flux (wave per object)")
 
 
 def test_batching_invariance(torch_cuda):

@@ -444,37 +444,34 @@ IMS_DEV bool surf_hit(const ims_surface_t& S, double (&pos)[3], const double (&v
     } else {
         t = ddiv(-pz, vel[2]);
     }
-    if (S.n_asphere == 0) {
-        const double x = fma(vel[0], t, pos[0]), y = fma(vel[1], t, pos[1]), z = fma(vel[2], t, pz);
-        const double sqv = fma(-S.k1c, z, 1.0);
-        if (!(sqv > 0.0)) return false;
-        pos[0] = x; pos[1] = y; pos[2] = S.z0 + z;
-        N[0] = -c * x; N[1] = -c * y; N[2] = sqv;
-        r2_out = fma(x, x, y * y);
-        nn = fma(S.cc, r2_out, sqv * sqv);
-        return true;
-    }
     // even asphere z = conic(r2) + p(r2), p = sum a_k r^(2k+4): Newton on the implicit conic form
-    // G = c (r2 + k1 w^2) - 2 w with w = z - p(r2), which needs neither sqrt nor a second division
-    double x = 0.0, y = 0.0, z = 0.0, r2 = 0.0, w = 0.0, dp = 0.0;
-    for (int it = 0; it < 6; ++it) {
-        x = fma(vel[0], t, pos[0]); y = fma(vel[1], t, pos[1]); z = fma(vel[2], t, pz);
-        r2 = fma(x, x, y * y);
-        double p = 0.0, rp = r2;
-        dp = 0.0;
-        for (int k = 0; k < S.n_asphere; ++k) {
-            dp = fma(S.asph_d[k], rp, dp);
-            rp = rp * r2;
-            p = fma(S.asph[k], rp, p);
+    // G = c (r2 + k1 w^2) - 2 w with w = z - p(r2), which needs neither sqrt nor a second division.  A surface without
+    // asphere terms is the same code with no iteration: w = z, dp = 0, and the tail below gives g = fma(2 m, 0, c) = c,
+    // nn = fma(c c, r2, m m) -- the bits of the closed conic form (cc = c c is the same IEEE product), one path to merge.
+    double x = fma(vel[0], t, pos[0]), y = fma(vel[1], t, pos[1]), z = fma(vel[2], t, pz);
+    double r2 = fma(x, x, y * y), w = z, dp = 0.0;
+    if (S.n_asphere > 0) {
+        for (int it = 0; it < 6; ++it) {
+            if (it > 0) {
+                x = fma(vel[0], t, pos[0]); y = fma(vel[1], t, pos[1]); z = fma(vel[2], t, pz);
+                r2 = fma(x, x, y * y);
+            }
+            double p = 0.0, rp = r2;
+            dp = 0.0;
+            for (int k = 0; k < S.n_asphere; ++k) {
+                dp = fma(S.asph_d[k], rp, dp);
+                rp = rp * r2;
+                p = fma(S.asph[k], rp, p);
+            }
+            w = z - p;
+            const double k1w = k1 * w;
+            const double G = fma(c, fma(k1w, w, r2), -2.0 * w);
+            if (fabs(G) <= 2.0e-11 || it == 5) break;
+            const double s = fma(x, vel[0], y * vel[1]);
+            const double wp = fma(-2.0 * dp, s, vel[2]);
+            const double Gp = 2.0 * fma(c, fma(k1w, wp, s), -wp);
+            t = t - ddiv(G, Gp);
         }
-        w = z - p;
-        const double k1w = k1 * w;
-        const double G = fma(c, fma(k1w, w, r2), -2.0 * w);
-        if (fabs(G) <= 2.0e-11 || it == 5) break;
-        const double s = fma(x, vel[0], y * vel[1]);
-        const double wp = fma(-2.0 * dp, s, vel[2]);
-        const double Gp = 2.0 * fma(c, fma(k1w, wp, s), -wp);
-        t = t - ddiv(G, Gp);
     }
     const double m = fma(-S.k1c, w, 1.0);
     if (!(m > 0.0)) return false;

@@ -536,12 +536,12 @@ IMS_DEV int trace(const ims_optics_t& o, double (&pos)[3], double (&vel)[3], dou
     return vignetted;
 }
 
-IMS_DEV void rubin_op(const ims_render_params_t& P, const ims_op_t& op, int op_index,
+IMS_DEV void rubin_op(const ims_render_params_t& P, const ims_op_t& op, int kind, int op_index,
                       const ims_object_t& o, int64_t k, Rng& rng, Photon& ph)
 {
     const ims_optics_t& opt = *P.optics;
-    const bool do_diff = (op.kind != IMS_OP_RUBIN_OPTICS);
-    const bool do_trace = (op.kind != IMS_OP_RUBIN_DIFFRACTION);
+    const bool do_diff = (kind != IMS_OP_RUBIN_OPTICS);
+    const bool do_trace = (kind != IMS_OP_RUBIN_DIFFRACTION);
     const bool frot = !(op.p[1] != 0.0);
     double v[3];
     xy_to_v(opt, ph.x, ph.y, ph.wl, v);
@@ -567,18 +567,21 @@ IMS_DEV void rubin_op(const ims_render_params_t& P, const ims_op_t& op, int op_i
     if (st == 1) ph.flux = 0.0;
 }
 
-// one configured photon operator (config/imsim-config.yaml:281-320)
+// one configured photon operator (config/imsim-config.yaml:281-320).  KIND >= 0: the operator's kind as a compile-time
+// constant (the kernels specialised for the default chain, run_ops<1>): the switch folds away.
+template <int KIND = -1>
 IMS_DEV void apply_op(const ims_render_params_t& P, int op_index, const ims_object_t& o, int64_t k, Rng& rng, Photon& ph)
 {
     const ims_op_t& op = P.ops[op_index];
+    const int kind = (KIND >= 0) ? KIND : op.kind;
     const uint32_t slot = SLOT_OP + ((uint32_t)op_index >> 1);
     const int wsel = op_index & 1;
-    if (op.kind == IMS_OP_BANDPASS_RATIO) {
+    if (kind == IMS_OP_BANDPASS_RATIO) {
         ph.flux = ph.flux * lin_lookup(P.ratio, op.table, ph.wl);
         return;
     }
     if (o.flags & IMS_OBJ_FAINT) return;
-    switch (op.kind) {
+    switch (kind) {
     case IMS_OP_TIME_SAMPLER: {
         rng_block(rng, P.seed, o.obj_id, k, slot);
         ph.t = op.p[0] + w01(wsel ? rng.w[2] : rng.w[0]) * op.p[1];
@@ -612,7 +615,7 @@ IMS_DEV void apply_op(const ims_render_params_t& P, int op_index, const ims_obje
     case IMS_OP_RUBIN_OPTICS:
     case IMS_OP_RUBIN_DIFFRACTION:
     case IMS_OP_RUBIN_DIFFRACTION_OPTICS:
-        rubin_op(P, op, op_index, o, k, rng, ph);
+        rubin_op(P, op, kind, op_index, o, k, rng, ph);
         break;
     default: break;
     }
@@ -938,6 +941,26 @@ IMS_DEV bool chain_has_angles(const ims_render_params_t& P)
     for (int k = 0; k < P.n_ops; ++k)
         if (P.ops[k].kind == IMS_OP_RUBIN_OPTICS || P.ops[k].kind == IMS_OP_RUBIN_DIFFRACTION_OPTICS) r = true;
     return r;
+}
+
+// The photon-op chain of a launch.  CHAIN 0: whatever the descriptor lists, one switch per operator.  CHAIN 1: imSim's
+// default chain (config/imsim-config.yaml:281-320: TimeSampler, PupilAnnulusSampler, PhotonDCR, RubinDiffractionOptics,
+// FocusDepth, Refraction, in that order -- the host checks the descriptor before it picks the kernel) as straight-line code:
+// no operator loop, no switch, nothing of the photon copied where the branches of the switch would meet.
+constexpr int IMS_DEFAULT_CHAIN_LEN = 6;
+template <int CHAIN>
+IMS_DEV void run_ops(const ims_render_params_t& P, const ims_object_t& o, int64_t k, Rng& rng, Photon& ph)
+{
+    if (CHAIN == 1) {
+        apply_op<IMS_OP_TIME_SAMPLER>(P, 0, o, k, rng, ph);
+        apply_op<IMS_OP_PUPIL_ANNULUS_SAMPLER>(P, 1, o, k, rng, ph);
+        apply_op<IMS_OP_PHOTON_DCR>(P, 2, o, k, rng, ph);
+        apply_op<IMS_OP_RUBIN_DIFFRACTION_OPTICS>(P, 3, o, k, rng, ph);
+        apply_op<IMS_OP_FOCUS_DEPTH>(P, 4, o, k, rng, ph);
+        apply_op<IMS_OP_REFRACTION>(P, 5, o, k, rng, ph);
+    } else {
+        for (int q = 0; q < P.n_ops; ++q) apply_op(P, q, o, k, rng, ph);
+    }
 }
 
 }  // namespace ims

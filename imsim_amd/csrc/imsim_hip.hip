@@ -182,6 +182,7 @@ __device__ __forceinline__ void tile_flush(float* tile, const ChargeTile& ct, co
 #ifndef IMS_FUSED_WAVES
 #define IMS_FUSED_WAVES 4
 #endif
+template <int CHAIN>
 __global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_accumulate(const ims_render_params_t P)
 {
     const int64_t per = (P.n_segments + N_XCD - 1) / N_XCD;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_accumulate(const
     const int n_thr = (((int)(j1 - j0) + 63) >> 6) << 6;
     if ((int)threadIdx.x >= n_thr) return;
     const bool silicon = (P.sensor != nullptr) && (P.sensor->kind == IMS_SENSOR_SILICON);
-    const bool has_angles = chain_has_angles(P);
+    const bool has_angles = (CHAIN == 1) ? true : chain_has_angles(P);
     __shared__ float tile[CT * CT];
     ChargeTile ct;
     tile_begin(tile, ct, P, o, silicon, n_thr);
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_accumulate(const
         Photon ph;
         Rng rng;
         make_photon(P, o, k, rng, ph);
-        for (int q = 0; q < P.n_ops; ++q) apply_op(P, q, o, k, rng, ph);
+        run_ops<CHAIN>(P, o, k, rng, ph);
         int ix, iy;
         if (ph.flux != 0.0 && land(P, o, k, rng, ph, silicon, has_angles, ix, iy)) {
             added += ph.flux;
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_accumulate(const
 // SiliconSensor.accumulate that does not depend on the pixel boundaries and stores the `converted` pool format
 // (ims_photons_t.converted), so that the latency-bound rounds of a brighter-fatter chain only do the pixel search.
 // pool.pupil_u / pupil_v / time / obj_index may be NULL (not stored).
-template <int MODE>
+template <int MODE, int CHAIN = 0>
 __global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_photons(const ims_render_params_t P,
                                                                         const int64_t* __restrict__ photon_offset,
                                                                         const ims_photons_t pool)
@@ -253,8 +254,7 @@ __global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_photons(const im
     Photon ph;
     Rng rng;
     make_photon(P, o, k, rng, ph);
-    if (MODE >= 1)
-        for (int q = 0; q < P.n_ops; ++q) apply_op(P, q, o, k, rng, ph);
+    if (MODE >= 1) run_ops<CHAIN>(P, o, k, rng, ph);
     const int64_t i = photon_offset[oi] + j;
     if (MODE == 2) {
         const bool silicon = (P.sensor != nullptr) && (P.sensor->kind == IMS_SENSOR_SILICON);
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_photons(const im
         if (silicon && !(o.flags & IMS_OBJ_FAINT) && flux != 0.0) {
             double zconv;
             bool coin;
-            if (land_convert(P, o, k, rng, ph, chain_has_angles(P), x0, y0, zconv, coin)) {
+            if (land_convert(P, o, k, rng, ph, (CHAIN == 1) ? true : chain_has_angles(P), x0, y0, zconv, coin)) {
                 const double zf = dtanh_pos(ddiv(zconv, 12.0));
                 zs = coin ? -zf : zf;
             } else flux = 0.0;
@@ -1452,6 +1452,17 @@ int ims_last_kernel_ms(float* ms, int* n_launches)
     return IMS_OK;
 }
 
+// the descriptor lists exactly imSim's default photon-op chain (run_ops<1>)
+static bool is_default_chain(const ims_render_params_t* p)
+{
+    static const int32_t kinds[IMS_DEFAULT_CHAIN_LEN] = { IMS_OP_TIME_SAMPLER, IMS_OP_PUPIL_ANNULUS_SAMPLER, IMS_OP_PHOTON_DCR,
+                                                          IMS_OP_RUBIN_DIFFRACTION_OPTICS, IMS_OP_FOCUS_DEPTH, IMS_OP_REFRACTION };
+    if (p->n_ops != IMS_DEFAULT_CHAIN_LEN || !os_getenv_off("IMS_CHAIN_KERNELS")) return false;
+    for (int k = 0; k < IMS_DEFAULT_CHAIN_LEN; ++k)
+        if (p->ops[k].kind != kinds[k]) return false;
+    return true;
+}
+
 int ims_shoot_accumulate(const ims_render_params_t* params, void* stream)
 {
     int rc = check_params(params);
@@ -1461,7 +1472,9 @@ int ims_shoot_accumulate(const ims_render_params_t* params, void* stream)
     hipStream_t st = (hipStream_t)stream;
     {
         LaunchTimer tm(st, 1);
-        hipLaunchKernelGGL(k_shoot_accumulate, dim3(grid_for_segments(params->n_segments)), dim3(256), 0, st, *params);
+        const dim3 grid(grid_for_segments(params->n_segments));
+        if (is_default_chain(params)) hipLaunchKernelGGL(k_shoot_accumulate<1>, grid, dim3(256), 0, st, *params);
+        else hipLaunchKernelGGL(k_shoot_accumulate<0>, grid, dim3(256), 0, st, *params);
     }
     HIP_TRY(hipGetLastError());
     return IMS_OK;
@@ -1476,7 +1489,7 @@ int ims_shoot_photons(const ims_render_params_t* params, const int64_t* photon_o
     if (params->n_segments == 0) return IMS_OK;
     hipStream_t st = (hipStream_t)stream;
     {
-        hipLaunchKernelGGL(k_shoot_photons<0>, dim3(grid_for_segments(params->n_segments)), dim3(256), 0, st,
+        hipLaunchKernelGGL((k_shoot_photons<0, 0>), dim3(grid_for_segments(params->n_segments)), dim3(256), 0, st,
                            *params, photon_offset, *pool);
     }
     HIP_TRY(hipGetLastError());
@@ -1495,12 +1508,11 @@ int ims_shoot_ops_photons(const ims_render_params_t* params, const int64_t* phot
     hipStream_t st = (hipStream_t)stream;
     {
         LaunchTimer tm(st, 2);
-        if (pool->converted)
-            hipLaunchKernelGGL(k_shoot_photons<2>, dim3(grid_for_segments(params->n_segments)), dim3(256), 0, st,
-                               *params, photon_offset, *pool);
-        else
-            hipLaunchKernelGGL(k_shoot_photons<1>, dim3(grid_for_segments(params->n_segments)), dim3(256), 0, st,
-                               *params, photon_offset, *pool);
+        const dim3 grid(grid_for_segments(params->n_segments));
+        const bool dflt = is_default_chain(params);
+        if (pool->converted && dflt) hipLaunchKernelGGL((k_shoot_photons<2, 1>), grid, dim3(256), 0, st, *params, photon_offset, *pool);
+        else if (pool->converted) hipLaunchKernelGGL((k_shoot_photons<2, 0>), grid, dim3(256), 0, st, *params, photon_offset, *pool);
+        else hipLaunchKernelGGL((k_shoot_photons<1, 0>), grid, dim3(256), 0, st, *params, photon_offset, *pool);
     }
     HIP_TRY(hipGetLastError());
     return IMS_OK;

@@ -168,26 +168,29 @@ IMS_DEV void screen_gradient(const ims_atmosphere_t& A, double pu, double pv, do
     gx = sx * inv_scale; gy = sy * inv_scale;
 }
 
+// KIND >= 0: the component's kind as a compile-time constant (kernels specialised for a PSF, run_psf<>)
+template <int KIND = -1>
 IMS_DEV void apply_psf(const ims_render_params_t& P, const ims_object_t& o, int comp, int64_t k, Rng& rng, Photon& ph)
 {
     const ims_psf_component_t& c = P.psf[comp];
+    const int kind = (KIND >= 0) ? KIND : c.kind;
     rng_block(rng, P.seed, o.obj_id, k, SLOT_PSF + ((uint32_t)comp >> 1));
     const uint32_t wa = (comp & 1) ? rng.w[2] : rng.w[0], wb = (comp & 1) ? rng.w[3] : rng.w[1];
     double scale = c.p0;
     if (c.chrom_alpha != 0.0) scale = scale * dpow(ddiv(ph.wl, c.chrom_base), c.chrom_alpha);
     double ku, kv;
-    if (c.kind == IMS_PSF_GAUSSIAN) {
+    if (kind == IMS_PSF_GAUSSIAN) {
         double g0, g1;
         gauss_words(wa, wb, g0, g1);
         ku = scale * g0; kv = scale * g1;
-    } else if (c.kind == IMS_PSF_DOUBLE_GAUSSIAN) {
+    } else if (kind == IMS_PSF_DOUBLE_GAUSSIAN) {
         // sum of two Gaussians: the photon belongs to the first with probability p2
         rng_block(rng, P.seed, o.obj_id, k, SLOT_PSF_TIME + (uint32_t)comp);
         const double sigma = (w01(rng.w[0]) < c.p2) ? scale : c.p1;
         double g0, g1;
         gauss_words(wa, wb, g0, g1);
         ku = sigma * g0; kv = sigma * g1;
-    } else if (c.kind == IMS_PSF_SCREENS) {
+    } else if (kind == IMS_PSF_SCREENS) {
         const ims_atmosphere_t& A = *P.atm;
         const double r = dsqrt0(A.aper_ri2 + w01(wa) * A.aper_dr2);
         double s, cc;
@@ -208,6 +211,19 @@ IMS_DEV void apply_psf(const ims_render_params_t& P, const ims_object_t& o, int 
     }
     ph.x = ph.x + (o.winv[0] * ku + o.winv[1] * kv);
     ph.y = ph.y + (o.winv[2] * ku + o.winv[3] * kv);
+}
+
+// The PSF components of a launch.  PSF 0: whatever the descriptor lists; 1: a radial-table profile then a Gaussian (imSim's
+// analytic atmosphere: Kolmogorov (+) Gaussian) as straight-line code.  The host checks the descriptor.
+template <int PSF>
+IMS_DEV void run_psf(const ims_render_params_t& P, const ims_object_t& o, int64_t k, Rng& rng, Photon& ph)
+{
+    if (PSF == 1) {
+        apply_psf<IMS_PSF_RADIAL>(P, o, 0, k, rng, ph);
+        apply_psf<IMS_PSF_GAUSSIAN>(P, o, 1, k, rng, ph);
+    } else {
+        for (int c = 0; c < P.n_psf; ++c) apply_psf(P, o, c, k, rng, ph);
+    }
 }
 
 // ---------------- media / air ----------------

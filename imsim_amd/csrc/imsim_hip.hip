@@ -99,11 +99,12 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // run one photon through shoot -> psf -> shift -> ops
+template <int PSF = 0>
 __device__ __forceinline__ void make_photon(const ims_render_params_t& P, const ims_object_t& o, int64_t k, Rng& rng, Photon& ph)
 {
     rng_reset(rng);
     shoot(P, o, k, rng, ph);
-    for (int c = 0; c < P.n_psf; ++c) apply_psf(P, o, c, k, rng, ph);
+    run_psf<PSF>(P, o, k, rng, ph);
     ph.x = o.x0 + ph.x;
     ph.y = o.y0 + ph.y;
 }
@@ -182,8 +183,11 @@ __device__ __forceinline__ void tile_flush(float* tile, const ChargeTile& ct, co
 #ifndef IMS_FUSED_WAVES
 #define IMS_FUSED_WAVES 4
 #endif
-template <int CHAIN>
-__global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_accumulate(const ims_render_params_t P)
+#ifndef IMS_CHAIN_WAVES
+#define IMS_CHAIN_WAVES 4          // wavefronts per SIMD the kernels specialised for the default chain are compiled for
+#endif
+template <int CHAIN, int PSF = 0>
+__global__ __launch_bounds__(256, (CHAIN == 1) ? IMS_CHAIN_WAVES : IMS_FUSED_WAVES) void k_shoot_accumulate(const ims_render_params_t P)
 {
     const int64_t per = (P.n_segments + N_XCD - 1) / N_XCD;
     const int64_t b = blockIdx.x;
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_accumulate(const
         const int64_t k = o.phot_first + j;
         Photon ph;
         Rng rng;
-        make_photon(P, o, k, rng, ph);
+        make_photon<PSF>(P, o, k, rng, ph);
         run_ops<CHAIN>(P, o, k, rng, ph);
         int ix, iy;
         if (ph.flux != 0.0 && land(P, o, k, rng, ph, silicon, has_angles, ix, iy)) {
@@ -236,8 +240,8 @@ __global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_accumulate(const
 // SiliconSensor.accumulate that does not depend on the pixel boundaries and stores the `converted` pool format
 // (ims_photons_t.converted), so that the latency-bound rounds of a brighter-fatter chain only do the pixel search.
 // pool.pupil_u / pupil_v / time / obj_index may be NULL (not stored).
-template <int MODE, int CHAIN = 0>
-__global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_photons(const ims_render_params_t P,
+template <int MODE, int CHAIN = 0, int PSF = 0>
+__global__ __launch_bounds__(256, (CHAIN == 1) ? IMS_CHAIN_WAVES : IMS_FUSED_WAVES) void k_shoot_photons(const ims_render_params_t P,
                                                                         const int64_t* __restrict__ photon_offset,
                                                                         const ims_photons_t pool)
 {
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(256, IMS_FUSED_WAVES) void k_shoot_photons(const im
     const int64_t k = o.phot_first + j;
     Photon ph;
     Rng rng;
-    make_photon(P, o, k, rng, ph);
+    make_photon<PSF>(P, o, k, rng, ph);
     if (MODE >= 1) run_ops<CHAIN>(P, o, k, rng, ph);
     const int64_t i = photon_offset[oi] + j;
     if (MODE == 2) {
@@ -1463,6 +1467,15 @@ static bool is_default_chain(const ims_render_params_t* p)
     return true;
 }
 
+// 1: radial table then Gaussian (run_psf<1>); 0: anything else.  (A variant for phase screens + radial table + Gaussian
+// was measured SLOWER than the component loop: C3b 36.9 -> 38.6 ms; not kept.)
+static int psf_variant(const ims_render_params_t* p)
+{
+    if (!os_getenv_off("IMS_CHAIN_KERNELS")) return 0;
+    if (p->n_psf == 2 && p->psf[0].kind == IMS_PSF_RADIAL && p->psf[1].kind == IMS_PSF_GAUSSIAN) return 1;
+    return 0;
+}
+
 int ims_shoot_accumulate(const ims_render_params_t* params, void* stream)
 {
     int rc = check_params(params);
@@ -1473,8 +1486,10 @@ int ims_shoot_accumulate(const ims_render_params_t* params, void* stream)
     {
         LaunchTimer tm(st, 1);
         const dim3 grid(grid_for_segments(params->n_segments));
-        if (is_default_chain(params)) hipLaunchKernelGGL(k_shoot_accumulate<1>, grid, dim3(256), 0, st, *params);
-        else hipLaunchKernelGGL(k_shoot_accumulate<0>, grid, dim3(256), 0, st, *params);
+        const int pv = is_default_chain(params) ? psf_variant(params) : -1;
+        if (pv == 1) hipLaunchKernelGGL((k_shoot_accumulate<1, 1>), grid, dim3(256), 0, st, *params);
+        else if (pv == 0) hipLaunchKernelGGL((k_shoot_accumulate<1, 0>), grid, dim3(256), 0, st, *params);
+        else hipLaunchKernelGGL((k_shoot_accumulate<0, 0>), grid, dim3(256), 0, st, *params);
     }
     HIP_TRY(hipGetLastError());
     return IMS_OK;
@@ -1509,8 +1524,9 @@ int ims_shoot_ops_photons(const ims_render_params_t* params, const int64_t* phot
     {
         LaunchTimer tm(st, 2);
         const dim3 grid(grid_for_segments(params->n_segments));
-        const bool dflt = is_default_chain(params);
-        if (pool->converted && dflt) hipLaunchKernelGGL((k_shoot_photons<2, 1>), grid, dim3(256), 0, st, *params, photon_offset, *pool);
+        const int pv = is_default_chain(params) ? psf_variant(params) : -1;
+        if (pool->converted && pv == 1) hipLaunchKernelGGL((k_shoot_photons<2, 1, 1>), grid, dim3(256), 0, st, *params, photon_offset, *pool);
+        else if (pool->converted && pv == 0) hipLaunchKernelGGL((k_shoot_photons<2, 1, 0>), grid, dim3(256), 0, st, *params, photon_offset, *pool);
         else if (pool->converted) hipLaunchKernelGGL((k_shoot_photons<2, 0>), grid, dim3(256), 0, st, *params, photon_offset, *pool);
         else hipLaunchKernelGGL((k_shoot_photons<1, 0>), grid, dim3(256), 0, st, *params, photon_offset, *pool);
     }

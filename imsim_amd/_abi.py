@@ -165,7 +165,8 @@ class RenderParams(C.Structure):
                 ("ops", Op * IMS_MAX_OPS), ("radial", RadialTables), ("sed", LinTables), ("ratio", LinTables),
                 ("atm", c_vp), ("optics", c_vp), ("sensor", c_vp), ("image", c_vp),
                 ("nx", c_i32), ("ny", c_i32), ("xmin", c_i32), ("ymin", c_i32), ("realized_flux", c_vp),
-                ("bf_tag", C.c_uint32), ("pad_tag", C.c_uint32), ("seg_object", c_vp), ("images", ImageTables)]
+                ("bf_tag", C.c_uint32), ("pad_tag", C.c_uint32), ("seg_object", c_vp), ("images", ImageTables),
+                ("optics_layout", c_u64)]
 
 
 IMS_PLAN_ROUNDS = 9
@@ -207,7 +208,7 @@ STRUCTS = [Object, RadialTables, LinTables, PsfComponent, Op, Surface, TanSip, O
            RenderParams, PlanItem, Atmosphere, FftObject, FftParams, Readout, Chain]
 
 # every symbol include/imsim_hip.h declares
-EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_info", "ims_shoot_accumulate",
+EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_info", "ims_known_optics_layout", "ims_shoot_accumulate",
            "ims_shoot_photons", "ims_shoot_ops_photons", "ims_accumulate_segments", "ims_accumulate_small", "ims_accumulate_round", "ims_run_plan",
            "ims_fft_kspace_fill", "ims_fft_finish", "ims_fft_spikes", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
            "ims_sensor_update_distortions", "ims_image_add", "ims_image_to_float", "ims_fill_derived_op", "ims_fill_derived_medium", "ims_fill_derived_optics", "ims_fill_derived_atmosphere", "ims_fill_derived_sensor", "ims_sensor_pixel_areas", "ims_flat_add", "ims_last_kernel_ms", "ims_enable_timing",
@@ -269,6 +270,7 @@ def load():
     lib.ims_run_plan.argtypes = [C.POINTER(PlanItem), c_i64, c_vp, C.POINTER(Sensor), c_vp, C.POINTER(c_vp), c_i32]
     lib.ims_last_kernel_ms.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.ims_enable_timing.argtypes = [C.c_int]
+    lib.ims_known_optics_layout.argtypes = [c_u64]
     lib.ims_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.ims_device_info.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(c_i64), C.POINTER(c_i64)]
     lib.ims_readout_bleed.argtypes = [c_vp, c_vp, c_i32, c_i32, c_d, c_i32, c_vp]

@@ -434,11 +434,18 @@ IMS_DEV bool obscured(const ims_surface_t& S, double r2)
 // Propagate to surface S (spec v5): plane exact; conic by the closed-form root of smaller
 // |t|, with the un-normalised normal (-c x, -c y, 1-(1+k) c z) that needs no sqrt; even-asphere terms
 // by Newton on the implicit conic form from the conic root until |G| <= 2e-11.
+// SHAPE: the surface's form as a compile-time constant (trace_seq: kernels specialised for an optics layout) -- 0 plane,
+// 1 conic with R != 0 and no asphere terms, 2 conic with R != 0 and asphere terms; -1 = read it from the descriptor.
+constexpr int SH_PLANE = 0, SH_CONIC = 1, SH_ASPHERE = 2;
+template <int SHAPE = -1>
 IMS_DEV bool surf_hit(const ims_surface_t& S, double (&pos)[3], const double (&vel)[3], double (&N)[3], double& nn, double& r2_out)
 {
+    const bool is_plane = (SHAPE >= 0) ? (SHAPE == SH_PLANE) : (S.R == 0.0 && S.n_asphere == 0);
+    const bool is_curved = (SHAPE >= 0) ? (SHAPE != SH_PLANE) : (S.R != 0.0);
+    const bool is_asphere = (SHAPE >= 0) ? (SHAPE == SH_ASPHERE) : (S.n_asphere > 0);
     const double pz = pos[2] - S.z0;
     double t;
-    if (S.R == 0.0 && S.n_asphere == 0) {
+    if (is_plane) {
         t = ddiv(-pz, vel[2]);
         pos[0] = fma(vel[0], t, pos[0]); pos[1] = fma(vel[1], t, pos[1]); pos[2] = S.z0;
         N[0] = 0.0; N[1] = 0.0; N[2] = 1.0; nn = 1.0;
@@ -446,7 +453,7 @@ IMS_DEV bool surf_hit(const ims_surface_t& S, double (&pos)[3], const double (&v
         return true;
     }
     const double c = S.inv_R, k1 = S.k1;       // k1, k1c, m2R, cc, asph_d: ims_fill_derived_optics
-    if (S.R != 0.0) {
+    if (is_curved) {
         // A t^2 + 2 hb t + C = 0 (spec v5: the dot products are fma chains, hb is half the linear coefficient)
         const double k1vz = k1 * vel[2];
         const double A = fma(vel[0], vel[0], fma(vel[1], vel[1], k1vz * vel[2]));
@@ -466,7 +473,7 @@ IMS_DEV bool surf_hit(const ims_surface_t& S, double (&pos)[3], const double (&v
     // nn = fma(c c, r2, m m) -- the bits of the closed conic form (cc = c c is the same IEEE product), one path to merge.
     double x = fma(vel[0], t, pos[0]), y = fma(vel[1], t, pos[1]), z = fma(vel[2], t, pz);
     double r2 = fma(x, x, y * y), w = z, dp = 0.0;
-    if (S.n_asphere > 0) {
+    if (is_asphere) {
         for (int it = 0; it < 6; ++it) {
             if (it > 0) {
                 x = fma(vel[0], t, pos[0]); y = fma(vel[1], t, pos[1]); z = fma(vel[2], t, pz);
@@ -499,59 +506,112 @@ IMS_DEV bool surf_hit(const ims_surface_t& S, double (&pos)[3], const double (&v
     return true;
 }
 
-// returns 0 ok, 1 vignetted, 2 failed
-IMS_DEV int trace(const ims_optics_t& o, double (&pos)[3], double (&vel)[3], double wave_nm)
-{
-    int vignetted = 0;
+// the state a ray carries from surface to surface besides position and direction
+struct TraceState {
+    int vignetted;
     double n_cur;
-    if (o.in_medium_kind == IMS_MEDIUM_CONST) n_cur = o.in_medium_c[0];
-    else n_cur = medium_n(o.in_medium_kind, o.in_medium_c, wave_nm);
     // the index of a medium is a pure function of (medium, wavelength): computed once per photon and
     // reused when the same medium recurs (all Rubin lenses and filters are fused silica)
-    int glass_id = -1;
-    double glass_n = 0.0, glass_in = 0.0;
-    for (int k = 0; k < o.n_surfaces; ++k) {
-        const ims_surface_t& S = o.surf[k];
-        double N[3], nn, r2;
-        if (!surf_hit(S, pos, vel, N, nn, r2)) return 2;
-        if (obscured(S, r2)) vignetted = 1;
-        if (S.kind == IMS_SURF_BAFFLE || S.kind == IMS_SURF_DETECTOR) continue;
-        if (S.kind == IMS_SURF_MIRROR) {
-            const double vn = fma(vel[0], N[0], fma(vel[1], N[1], vel[2] * N[2]));
-            const double d = ddiv(2.0 * vn, nn);
-            vel[0] = fma(-d, N[0], vel[0]); vel[1] = fma(-d, N[1], vel[1]); vel[2] = fma(-d, N[2], vel[2]);
-        } else {
-            double n2, in2;
-            if (S.medium_kind == IMS_MEDIUM_CONST) { n2 = S.medium_c[0]; in2 = S.medium_c[1]; }
-            else if (S.medium_id == glass_id) { n2 = glass_n; in2 = glass_in; }
-            else {
-                n2 = medium_n(S.medium_kind, S.medium_c, wave_nm);
-                in2 = ddiv(1.0, n2);
-                glass_id = S.medium_id; glass_n = n2; glass_in = in2;
-            }
-            // Snell with the un-normalised normal (spec v5): a = n1 (v.N) is the cosine of incidence times |N|; with
-            // eta = n1/n2 the new velocity is eta^2 v - (nfac / n2) N
-            const double vn = fma(vel[0], N[0], fma(vel[1], N[1], vel[2] * N[2]));
-            double a = n_cur * vn;
-            double sgn = 1.0;
-            if (a > 0.0) { sgn = -1.0; a = -a; }
-            const double eta = n_cur * in2;
-            const double inn = ddiv(1.0, nn);
-            const double ai = a * inn;
-            const double e2 = eta * eta;
-            const double sinsqr = e2 * fma(-a, ai, 1.0);
-            if (sinsqr > 1.0) return 2;
-            const double nfac = sgn * fma(eta, ai, dsqrt0(fma(-sinsqr, inn, inn)));
-            const double nf2 = nfac * in2;
-            vel[0] = fma(e2, vel[0], -(nf2 * N[0]));
-            vel[1] = fma(e2, vel[1], -(nf2 * N[1]));
-            vel[2] = fma(e2, vel[2], -(nf2 * N[2]));
-            n_cur = n2;
+    int glass_id;
+    double glass_n, glass_in;
+};
+
+// One surface of the sequential trace: intersect, vignette, reflect or refract.  KIND / SHAPE >= 0: compile-time constants
+// (trace_seq), -1: read from the descriptor.  Returns false when the ray is lost.
+template <int KIND = -1, int SHAPE = -1>
+IMS_DEV bool trace_step(const ims_surface_t& S, TraceState& st, double (&pos)[3], double (&vel)[3], double wave_nm)
+{
+    const int kind = (KIND >= 0) ? KIND : S.kind;
+    double N[3], nn, r2;
+    if (!surf_hit<SHAPE>(S, pos, vel, N, nn, r2)) return false;
+    if (obscured(S, r2)) st.vignetted = 1;
+    if (kind == IMS_SURF_BAFFLE || kind == IMS_SURF_DETECTOR) return true;
+    if (kind == IMS_SURF_MIRROR) {
+        const double vn = fma(vel[0], N[0], fma(vel[1], N[1], vel[2] * N[2]));
+        const double d = ddiv(2.0 * vn, nn);
+        vel[0] = fma(-d, N[0], vel[0]); vel[1] = fma(-d, N[1], vel[1]); vel[2] = fma(-d, N[2], vel[2]);
+    } else {
+        double n2, in2;
+        if (S.medium_kind == IMS_MEDIUM_CONST) { n2 = S.medium_c[0]; in2 = S.medium_c[1]; }
+        else if (S.medium_id == st.glass_id) { n2 = st.glass_n; in2 = st.glass_in; }
+        else {
+            n2 = medium_n(S.medium_kind, S.medium_c, wave_nm);
+            in2 = ddiv(1.0, n2);
+            st.glass_id = S.medium_id; st.glass_n = n2; st.glass_in = in2;
         }
+        // Snell with the un-normalised normal (spec v5): a = n1 (v.N) is the cosine of incidence times |N|; with
+        // eta = n1/n2 the new velocity is eta^2 v - (nfac / n2) N
+        const double vn = fma(vel[0], N[0], fma(vel[1], N[1], vel[2] * N[2]));
+        double a = st.n_cur * vn;
+        double sgn = 1.0;
+        if (a > 0.0) { sgn = -1.0; a = -a; }
+        const double eta = st.n_cur * in2;
+        const double inn = ddiv(1.0, nn);
+        const double ai = a * inn;
+        const double e2 = eta * eta;
+        const double sinsqr = e2 * fma(-a, ai, 1.0);
+        if (sinsqr > 1.0) return false;
+        const double nfac = sgn * fma(eta, ai, dsqrt0(fma(-sinsqr, inn, inn)));
+        const double nf2 = nfac * in2;
+        vel[0] = fma(e2, vel[0], -(nf2 * N[0]));
+        vel[1] = fma(e2, vel[1], -(nf2 * N[1]));
+        vel[2] = fma(e2, vel[2], -(nf2 * N[2]));
+        st.n_cur = n2;
     }
-    return vignetted;
+    return true;
 }
 
+// An optics LAYOUT is the sequence of (kind, shape) of the surfaces as 4-bit codes, first surface in the lowest nibble:
+// code = 1 + 3 kind_class + shape with kind_class 0 mirror, 1 refracting, 2 detector / baffle; a zero nibble ends the list
+// (at most 15 surfaces).  engine.optics_layout() computes it from the descriptor (ims_render_params_t.optics_layout), and the
+// library holds kernels whose trace is unrolled for the layouts it knows (IMS_LAYOUT_RUBIN_LIKE); any other layout, and 0,
+// run the surface loop.
+template <unsigned long long CODE, int K>
+struct TraceSeq {
+    static IMS_DEV bool run(const ims_optics_t& o, TraceState& st, double (&pos)[3], double (&vel)[3], double wave_nm)
+    {
+        constexpr int code = (int)((CODE >> (4 * K)) & 15ull);
+        if constexpr (code == 0) {
+            return true;
+        } else {
+            constexpr int kc = (code - 1) / 3, shape = (code - 1) % 3;
+            constexpr int kind = (kc == 0) ? IMS_SURF_MIRROR : (kc == 1) ? IMS_SURF_REFRACT : IMS_SURF_DETECTOR;
+            if (!trace_step<kind, shape>(o.surf[K], st, pos, vel, wave_nm)) return false;
+            return TraceSeq<CODE, K + 1>::run(o, st, pos, vel, wave_nm);
+        }
+    }
+};
+template <unsigned long long CODE>
+struct TraceSeq<CODE, 16> {
+    static IMS_DEV bool run(const ims_optics_t&, TraceState&, double (&)[3], double (&)[3], double) { return true; }
+};
+
+// the approximate Rubin prescription of optics.rubin_like_telescope: three aspheric mirrors, L1 (two conics), L2 (plane,
+// asphere), filter (two conics), L3 (two conics), detector plane
+constexpr unsigned long long IMS_LAYOUT_RUBIN_LIKE =
+    (3ull << 0) | (3ull << 4) | (3ull << 8) | (5ull << 12) | (5ull << 16) | (4ull << 20) | (6ull << 24) | (5ull << 28) |
+    (5ull << 32) | (5ull << 36) | (5ull << 40) | (7ull << 44);
+
+// returns 0 ok, 1 vignetted, 2 failed.  LAYOUT != 0: the surfaces unrolled for that layout (the host has checked that the
+// descriptor has it), 0: the loop over whatever the descriptor lists.
+template <unsigned long long LAYOUT = 0ull>
+IMS_DEV int trace(const ims_optics_t& o, double (&pos)[3], double (&vel)[3], double wave_nm)
+{
+    TraceState st;
+    st.vignetted = 0;
+    if (o.in_medium_kind == IMS_MEDIUM_CONST) st.n_cur = o.in_medium_c[0];
+    else st.n_cur = medium_n(o.in_medium_kind, o.in_medium_c, wave_nm);
+    st.glass_id = -1; st.glass_n = 0.0; st.glass_in = 0.0;
+    if (LAYOUT != 0ull) {
+        if (!TraceSeq<LAYOUT, 0>::run(o, st, pos, vel, wave_nm)) return 2;
+    } else {
+        for (int k = 0; k < o.n_surfaces; ++k)
+            if (!trace_step(o.surf[k], st, pos, vel, wave_nm)) return 2;
+    }
+    return st.vignetted;
+}
+
+template <unsigned long long LAYOUT = 0ull>
 IMS_DEV void rubin_op(const ims_render_params_t& P, const ims_op_t& op, int kind, int op_index,
                       const ims_object_t& o, int64_t k, Rng& rng, Photon& ph)
 {
@@ -569,7 +629,7 @@ IMS_DEV void rubin_op(const ims_render_params_t& P, const ims_op_t& op, int kind
     }
     if (!do_trace) { v_to_xy(opt, v, ph.x, ph.y); return; }
     double pos[3] = { ph.pu, ph.pv, opt.stop_z };
-    const int st = trace(opt, pos, v, ph.wl);
+    const int st = trace<LAYOUT>(opt, pos, v, ph.wl);
     if (st == 2) { ph.x = 0.0; ph.y = 0.0; ph.dxdz = 0.0; ph.dydz = 0.0; ph.flux = 0.0; return; }
     const double c = opt.cam_rot[0], s = opt.cam_rot[1];
     const double rx = c * pos[0] + s * pos[1], ry = -s * pos[0] + c * pos[1];
@@ -585,7 +645,7 @@ IMS_DEV void rubin_op(const ims_render_params_t& P, const ims_op_t& op, int kind
 
 // one configured photon operator (config/imsim-config.yaml:281-320).  KIND >= 0: the operator's kind as a compile-time
 // constant (the kernels specialised for the default chain, run_ops<1>): the switch folds away.
-template <int KIND = -1>
+template <int KIND = -1, unsigned long long LAYOUT = 0ull>
 IMS_DEV void apply_op(const ims_render_params_t& P, int op_index, const ims_object_t& o, int64_t k, Rng& rng, Photon& ph)
 {
     const ims_op_t& op = P.ops[op_index];
@@ -631,7 +691,7 @@ IMS_DEV void apply_op(const ims_render_params_t& P, int op_index, const ims_obje
     case IMS_OP_RUBIN_OPTICS:
     case IMS_OP_RUBIN_DIFFRACTION:
     case IMS_OP_RUBIN_DIFFRACTION_OPTICS:
-        rubin_op(P, op, kind, op_index, o, k, rng, ph);
+        rubin_op<LAYOUT>(P, op, kind, op_index, o, k, rng, ph);
         break;
     default: break;
     }
@@ -964,14 +1024,14 @@ IMS_DEV bool chain_has_angles(const ims_render_params_t& P)
 // FocusDepth, Refraction, in that order -- the host checks the descriptor before it picks the kernel) as straight-line code:
 // no operator loop, no switch, nothing of the photon copied where the branches of the switch would meet.
 constexpr int IMS_DEFAULT_CHAIN_LEN = 6;
-template <int CHAIN>
+template <int CHAIN, unsigned long long LAYOUT = 0ull>
 IMS_DEV void run_ops(const ims_render_params_t& P, const ims_object_t& o, int64_t k, Rng& rng, Photon& ph)
 {
     if (CHAIN == 1) {
         apply_op<IMS_OP_TIME_SAMPLER>(P, 0, o, k, rng, ph);
         apply_op<IMS_OP_PUPIL_ANNULUS_SAMPLER>(P, 1, o, k, rng, ph);
         apply_op<IMS_OP_PHOTON_DCR>(P, 2, o, k, rng, ph);
-        apply_op<IMS_OP_RUBIN_DIFFRACTION_OPTICS>(P, 3, o, k, rng, ph);
+        apply_op<IMS_OP_RUBIN_DIFFRACTION_OPTICS, LAYOUT>(P, 3, o, k, rng, ph);
         apply_op<IMS_OP_FOCUS_DEPTH>(P, 4, o, k, rng, ph);
         apply_op<IMS_OP_REFRACTION>(P, 5, o, k, rng, ph);
     } else {

@@ -186,7 +186,7 @@ __device__ __forceinline__ void tile_flush(float* tile, const ChargeTile& ct, co
 #ifndef IMS_CHAIN_WAVES
 #define IMS_CHAIN_WAVES 4          // wavefronts per SIMD the kernels specialised for the default chain are compiled for
 #endif
-template <int CHAIN, int PSF = 0>
+template <int CHAIN, int PSF = 0, unsigned long long LAYOUT = 0ull>
 __global__ __launch_bounds__(256, (CHAIN == 1) ? IMS_CHAIN_WAVES : IMS_FUSED_WAVES) void k_shoot_accumulate(const ims_render_params_t P)
 {
     const int64_t per = (P.n_segments + N_XCD - 1) / N_XCD;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, (CHAIN == 1) ? IMS_CHAIN_WAVES : IMS_FUSED_WAV
         Photon ph;
         Rng rng;
         make_photon<PSF>(P, o, k, rng, ph);
-        run_ops<CHAIN>(P, o, k, rng, ph);
+        run_ops<CHAIN, LAYOUT>(P, o, k, rng, ph);
         int ix, iy;
         if (ph.flux != 0.0 && land(P, o, k, rng, ph, silicon, has_angles, ix, iy)) {
             added += ph.flux;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, (CHAIN == 1) ? IMS_CHAIN_WAVES : IMS_FUSED_WAV
 // SiliconSensor.accumulate that does not depend on the pixel boundaries and stores the `converted` pool format
 // (ims_photons_t.converted), so that the latency-bound rounds of a brighter-fatter chain only do the pixel search.
 // pool.pupil_u / pupil_v / time / obj_index may be NULL (not stored).
-template <int MODE, int CHAIN = 0, int PSF = 0>
+template <int MODE, int CHAIN = 0, int PSF = 0, unsigned long long LAYOUT = 0ull>
 __global__ __launch_bounds__(256, (CHAIN == 1) ? IMS_CHAIN_WAVES : IMS_FUSED_WAVES) void k_shoot_photons(const ims_render_params_t P,
                                                                         const int64_t* __restrict__ photon_offset,
                                                                         const ims_photons_t pool)
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, (CHAIN == 1) ? IMS_CHAIN_WAVES : IMS_FUSED_WAV
     Photon ph;
     Rng rng;
     make_photon<PSF>(P, o, k, rng, ph);
-    if (MODE >= 1) run_ops<CHAIN>(P, o, k, rng, ph);
+    if (MODE >= 1) run_ops<CHAIN, LAYOUT>(P, o, k, rng, ph);
     const int64_t i = photon_offset[oi] + j;
     if (MODE == 2) {
         const bool silicon = (P.sensor != nullptr) && (P.sensor->kind == IMS_SENSOR_SILICON);
@@ -1476,6 +1476,8 @@ static int psf_variant(const ims_render_params_t* p)
     return 0;
 }
 
+int ims_known_optics_layout(uint64_t layout) { return layout == IMS_LAYOUT_RUBIN_LIKE ? 1 : 0; }
+
 int ims_shoot_accumulate(const ims_render_params_t* params, void* stream)
 {
     int rc = check_params(params);
@@ -1487,7 +1489,10 @@ int ims_shoot_accumulate(const ims_render_params_t* params, void* stream)
         LaunchTimer tm(st, 1);
         const dim3 grid(grid_for_segments(params->n_segments));
         const int pv = is_default_chain(params) ? psf_variant(params) : -1;
-        if (pv == 1) hipLaunchKernelGGL((k_shoot_accumulate<1, 1>), grid, dim3(256), 0, st, *params);
+        const bool lay = pv >= 0 && params->optics_layout == IMS_LAYOUT_RUBIN_LIKE && os_getenv_off("IMS_LAYOUT_KERNELS");
+        if (pv == 1 && lay) hipLaunchKernelGGL((k_shoot_accumulate<1, 1, IMS_LAYOUT_RUBIN_LIKE>), grid, dim3(256), 0, st, *params);
+        else if (pv == 0 && lay) hipLaunchKernelGGL((k_shoot_accumulate<1, 0, IMS_LAYOUT_RUBIN_LIKE>), grid, dim3(256), 0, st, *params);
+        else if (pv == 1) hipLaunchKernelGGL((k_shoot_accumulate<1, 1>), grid, dim3(256), 0, st, *params);
         else if (pv == 0) hipLaunchKernelGGL((k_shoot_accumulate<1, 0>), grid, dim3(256), 0, st, *params);
         else hipLaunchKernelGGL((k_shoot_accumulate<0, 0>), grid, dim3(256), 0, st, *params);
     }
@@ -1525,7 +1530,12 @@ int ims_shoot_ops_photons(const ims_render_params_t* params, const int64_t* phot
         LaunchTimer tm(st, 2);
         const dim3 grid(grid_for_segments(params->n_segments));
         const int pv = is_default_chain(params) ? psf_variant(params) : -1;
-        if (pool->converted && pv == 1) hipLaunchKernelGGL((k_shoot_photons<2, 1, 1>), grid, dim3(256), 0, st, *params, photon_offset, *pool);
+        const bool lay = pv >= 0 && params->optics_layout == IMS_LAYOUT_RUBIN_LIKE && os_getenv_off("IMS_LAYOUT_KERNELS");
+        if (pool->converted && pv == 1 && lay)
+            hipLaunchKernelGGL((k_shoot_photons<2, 1, 1, IMS_LAYOUT_RUBIN_LIKE>), grid, dim3(256), 0, st, *params, photon_offset, *pool);
+        else if (pool->converted && pv == 0 && lay)
+            hipLaunchKernelGGL((k_shoot_photons<2, 1, 0, IMS_LAYOUT_RUBIN_LIKE>), grid, dim3(256), 0, st, *params, photon_offset, *pool);
+        else if (pool->converted && pv == 1) hipLaunchKernelGGL((k_shoot_photons<2, 1, 1>), grid, dim3(256), 0, st, *params, photon_offset, *pool);
         else if (pool->converted && pv == 0) hipLaunchKernelGGL((k_shoot_photons<2, 1, 0>), grid, dim3(256), 0, st, *params, photon_offset, *pool);
         else if (pool->converted) hipLaunchKernelGGL((k_shoot_photons<2, 0>), grid, dim3(256), 0, st, *params, photon_offset, *pool);
         else hipLaunchKernelGGL((k_shoot_photons<1, 0>), grid, dim3(256), 0, st, *params, photon_offset, *pool);

@@ -251,6 +251,27 @@ def update_window_table(m):
     return out
 
 
+def optics_layout(opt):
+    """ims_render_params_t.optics_layout of an _abi.Optics descriptor: (kind, shape) of every surface as a 4-bit code, first
+    surface in the lowest nibble (code = 1 + 3 kc + shape; kc 0 mirror, 1 refracting, 2 detector / baffle; shape 0 plane,
+    1 conic with R != 0, 2 conic with R != 0 and asphere terms).  0 when the descriptor cannot be coded (more than 15
+    surfaces, asphere terms on a surface with R == 0): the kernels then loop over the surfaces."""
+    if opt is None or opt.n_surfaces > 15:
+        return 0
+    code = 0
+    for k in range(opt.n_surfaces):
+        S = opt.surf[k]
+        kc = {_abi.IMS_SURF_MIRROR: 0, _abi.IMS_SURF_REFRACT: 1}.get(S.kind, 2)
+        if S.R == 0.0 and S.n_asphere == 0:
+            shape = 0
+        elif S.R != 0.0:
+            shape = 2 if S.n_asphere > 0 else 1
+        else:
+            return 0
+        code |= (1 + 3 * kc + shape) << (4 * k)
+    return code
+
+
 def treering_displacement_bound(ss):
     """Upper bound of |tree-ring shift| over the CCD [pixels]: on every table interval the interpolant is the chord plus
     the cubic-spline term ((a^3 - a) m0 + (b^3 - b) m1) h^2 / 6 with |a^3 - a| <= 2 / (3 sqrt 3); a few ulp on top."""
@@ -387,6 +408,7 @@ class BoundScene:
                 derive.fill_derived_medium(opt.surf[k].medium_kind, opt.surf[k].medium_c)
             derive.fill_derived_struct("optics", opt)
             _, P.optics = mem.put_struct(opt)
+            P.optics_layout = optics_layout(opt)
         if scene.atm is not None:
             A = scene.atm.atmosphere_struct()
             scr = scene.atm.screens

@@ -40,7 +40,7 @@ extern "C" {
 #define IMS_ERR_NO_DEVICE  -3
 #define IMS_ERR_UNSUPPORTED -4
 
-#define IMS_ABI_VERSION 11
+#define IMS_ABI_VERSION 12
 
 /* Pointers stored INSIDE descriptors that live in device memory (ims_sensor_t, ims_atmosphere_t) always point to global
  * device memory.  Device code is told so (address space 1): a pointer read out of memory is otherwise a generic pointer and
@@ -362,6 +362,12 @@ typedef struct ims_render_params {
     const int32_t* seg_object;       /* device [n_segments] or NULL: object index of every segment; when given, a
                                       * workgroup finds its object with one load instead of a search in seg_prefix */
     ims_image_tables_t images;       /* IMS_PROF_IMAGE profiles */
+    /* optional (0 = none): the LAYOUT of *optics -- the (kind, shape) of its surfaces as 4-bit codes, first surface in the
+     * lowest nibble: code = 1 + 3 kc + shape, kc 0 mirror / 1 refracting / 2 detector or baffle, shape 0 plane / 1 conic
+     * (R != 0, no asphere terms) / 2 conic with asphere terms; a zero nibble ends the list.  It MUST describe the descriptor
+     * `optics` points to (the kernels cannot check it): for the layouts the library holds an unrolled ray trace for
+     * (ims_known_optics_layout) the launch takes that kernel, any other value runs the loop over the surfaces. */
+    uint64_t optics_layout;
 } ims_render_params_t;
 
 /* ---- library ---- */
@@ -370,6 +376,9 @@ const char* ims_last_error(void);
 int  ims_device_count(int* count);
 /* device properties used by the host scheduler: cus, xcds, lds bytes */
 int  ims_device_info(int device, int* n_cu, int* n_xcd, int64_t* lds_bytes, int64_t* hbm_bytes);
+
+/* 1 when the library holds kernels specialised for this optics layout (ims_render_params_t.optics_layout) */
+int  ims_known_optics_layout(uint64_t layout);
 
 /* ---- fused path: shoot -> PSF -> ops -> sensor -> CCD image (LSST_Silicon / LSST_Image) ---- */
 int  ims_shoot_accumulate(const ims_render_params_t* params, void* stream);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Rebuild profiles/hbm_traffic.json (what bench.py reports as roofline.traffic and uses for the f64-issue fraction) from
-the committed per-config PMC summaries (tools/pmc_summary.py output): the newest of profiles/round2d_<config>_hbm_pmc.json
+the committed per-config PMC summaries (tools/pmc_summary.py output): the newest of profiles/round2e_<config>_hbm_pmc.json
 (end of round 2: converted pool, k_shoot_photons<2>), round2_<config>_hbm_pmc.json and round1_<config>_final_hbm_pmc.json, with
 the SQ pass of the same tag where present."""
 import json
@@ -8,15 +8,23 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = {"k_shoot_accumulate(ims_render_params)": "k_shoot_accumulate",
-           "void k_shoot_photons<true>(ims_render_params, long const*, ims_photons)": "k_shoot_photons<true>",
-           "void k_shoot_photons<2>(ims_render_params, long const*, ims_photons)": "k_shoot_photons<2>"}
+def short_name(long_name):
+    """bench.py's label of a kernel: the template arguments after the pool mode (chain / PSF / optics-layout specialisations
+    of one and the same kernel) are dropped"""
+    n = long_name.replace("void ", "")
+    if n.startswith("k_shoot_accumulate"):
+        return "k_shoot_accumulate"
+    if n.startswith("k_shoot_photons<true>"):
+        return "k_shoot_photons<true>"
+    if n.startswith("k_shoot_photons<2"):
+        return "k_shoot_photons<2>"
+    return None
 
 
 def main():
     out = {}
     for cfg in ("c2", "c3", "c3b"):
-        cands = [(f"profiles/round2d_{cfg}_hbm_pmc.json", f"profiles/round2d_{cfg}_sq_pmc.json"),
+        cands = [(f"profiles/round2e_{cfg}_hbm_pmc.json", f"profiles/round2e_{cfg}_sq_pmc.json"),
                  (f"profiles/round2_{cfg}_hbm_pmc.json", f"profiles/round2_{cfg}_sq_pmc.json"),
                  (f"profiles/round1_{cfg}_final_hbm_pmc.json", f"profiles/round1_{cfg}_final_sq_pmc.json")]
         found = [c for c in cands if os.path.exists(os.path.join(ROOT, c[0]))]
@@ -26,11 +34,12 @@ def main():
         path = os.path.join(ROOT, src)
         d = json.load(open(path))
         sq = json.load(open(os.path.join(ROOT, sq_src))) if os.path.exists(os.path.join(ROOT, sq_src)) else {}
-        for long_name, short in KERNELS.items():
-            if long_name not in d:
+        for long_name in d:
+            short = short_name(long_name)
+            if short is None:
                 continue
             k = d[long_name]
-            if k["FETCH_SIZE"]["launches"] == 0:
+            if "FETCH_SIZE" not in k or k["FETCH_SIZE"]["launches"] == 0:
                 continue
             out.setdefault(cfg, {})[short] = {
                 "hbm_bytes_per_launch": k["hbm_bytes_per_launch"],

@@ -9,13 +9,11 @@ brighter-fatter region recalculated at the first sub-batch of each batch.
 """
 import dataclasses
 import itertools
-
 import os
 
 import numpy as np
 
 from . import parallel
-
 from ._abi import OBJECT_DTYPE, IMS_OBJ_FAINT
 from .stamp import ProcessingMode, ObjectInfo
 

@@ -229,6 +229,29 @@ def _sensor_arrays_gpu(r):
     return out
 
 
+@pytest.mark.parametrize("chain,layout", [("0", "1"), ("1", "0")])
+def test_specialised_kernels_equal_the_descriptor_driven_ones(torch_cuda, monkeypatch, chain, layout):
+    """The kernels specialised for the default operator chain / analytic PSF (run_ops<1>, run_psf<1>) and for the known optics
+    layout (trace<LAYOUT>) render the image, realized fluxes and sensor state of the kernels that loop over the
+    descriptors, bit for bit (LSST_Image plan of a C3 case: fused launch, pool shoots, rounds)."""
+    from imsim_amd.engine import Renderer
+    scene, objects = _c3_case(n_obj=200)
+    out = []
+    for c, l in (("1", "1"), (chain, layout)):
+        monkeypatch.setenv("IMS_CHAIN_KERNELS", c)
+        monkeypatch.setenv("IMS_LAYOUT_KERNELS", l)
+        r = Renderer(scene)
+        real = torch_cuda.zeros(len(objects), dtype=torch_cuda.float64, device="cuda")
+        r.render_lsst_image(objects, nrecalc=1000, realized=real)
+        r.synchronize()
+        out.append((r.image_numpy(), real.cpu().numpy(), _sensor_arrays_gpu(r)))
+    assert out[0][0].sum() > 0
+    assert_bits_equal(out[1][0], out[0][0], "image")
+    assert_bits_equal(out[1][1], out[0][1], "realized flux")
+    for name in ("boundary", "bounds", "delta"):
+        assert_bits_equal(out[1][2][name], out[0][2][name], f"sensor {name}")
+
+
 def test_tiled_initial_state_equals_the_per_cell_kernel(torch_cuda, monkeypatch):
     """k_init_tiles (every owned point evaluated once per tile, neighbours through LDS) writes the boundary points, bounds
     lines and delta image of k_init_boundaries (one thread per cell, neighbours recomputed) bit for bit: the static CCD

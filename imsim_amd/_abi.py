@@ -165,7 +165,7 @@ class RenderParams(C.Structure):
                 ("ops", Op * IMS_MAX_OPS), ("radial", RadialTables), ("sed", LinTables), ("ratio", LinTables),
                 ("atm", c_vp), ("optics", c_vp), ("sensor", c_vp), ("image", c_vp),
                 ("nx", c_i32), ("ny", c_i32), ("xmin", c_i32), ("ymin", c_i32), ("realized_flux", c_vp),
-                ("bf_tag", C.c_uint32), ("pad_tag", C.c_uint32), ("seg_object", c_vp), ("images", ImageTables),
+                ("bf_tag", C.c_uint32), ("bf_slot_shift", C.c_uint32), ("seg_object", c_vp), ("images", ImageTables),
                 ("optics_layout", c_u64)]
 
 
@@ -178,7 +178,8 @@ class Chain(C.Structure):
     _fields_ = [("params", c_vp), ("pool", c_vp), ("pool_start", c_vp), ("n_phot", c_vp), ("tile_prefix", c_vp),
                 ("tile_prefix_host", c_vp), ("n_objects", c_i32), ("first_slot", c_i32), ("stream", c_i32), ("nrecalc", c_i32),
                 ("n_rounds", c_i32), ("use_tags", c_i32), ("ev_base", c_i32), ("n_edges", c_i32),
-                ("edges", c_i32 * IMS_MAX_CHAIN_EDGES)]
+                ("edges", c_i32 * IMS_MAX_CHAIN_EDGES), ("pair_shift", c_i32), ("pad", c_i32),
+                ("pair_tile_prefix", c_vp), ("pair_tile_prefix_host", c_vp)]
 
 
 class PlanItem(C.Structure):
@@ -211,7 +212,7 @@ STRUCTS = [Object, RadialTables, LinTables, PsfComponent, Op, Surface, TanSip, O
 EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_info", "ims_known_optics_layout", "ims_shoot_accumulate",
            "ims_shoot_photons", "ims_shoot_ops_photons", "ims_accumulate_segments", "ims_accumulate_small", "ims_accumulate_round", "ims_run_plan",
            "ims_fft_kspace_fill", "ims_fft_finish", "ims_fft_spikes", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
-           "ims_sensor_update_distortions", "ims_image_add", "ims_image_to_float", "ims_fill_derived_op", "ims_fill_derived_medium", "ims_fill_derived_optics", "ims_fill_derived_atmosphere", "ims_fill_derived_sensor", "ims_sensor_pixel_areas", "ims_flat_add", "ims_last_kernel_ms", "ims_enable_timing",
+           "ims_sensor_update_distortions", "ims_sensor_update_refresh", "ims_sensor_publish_pairs", "ims_image_add", "ims_image_to_float", "ims_fill_derived_op", "ims_fill_derived_medium", "ims_fill_derived_optics", "ims_fill_derived_atmosphere", "ims_fill_derived_sensor", "ims_sensor_pixel_areas", "ims_flat_add", "ims_last_kernel_ms", "ims_enable_timing",
            "ims_readout_bleed", "ims_readout_segments", "ims_readout_cte", "ims_readout_finish",
            "ims_struct_size", "ims_test_math"]
 
@@ -271,6 +272,8 @@ def load():
     lib.ims_last_kernel_ms.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.ims_enable_timing.argtypes = [C.c_int]
     lib.ims_known_optics_layout.argtypes = [c_u64]
+    lib.ims_sensor_update_refresh.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]
+    lib.ims_sensor_publish_pairs.argtypes = [c_vp, C.POINTER(Sensor), c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]
     lib.ims_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.ims_device_info.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(c_i64), C.POINTER(c_i64)]
     lib.ims_readout_bleed.argtypes = [c_vp, c_vp, c_i32, c_i32, c_d, c_i32, c_vp]

@@ -710,6 +710,12 @@ __device__ unsigned long long g_probe_wg[64][8];
 #endif
 
 // ---------------- Silicon sensor ----------------
+// the slot of an object's pixel-boundary region in this launch (ims_render_params_t.bf_slot_shift)
+IMS_DEV int slot_index(const ims_render_params_t& P, const ims_object_t& o)
+{
+    return o.bf_state > 0 ? o.bf_state + (int)P.bf_slot_shift : o.bf_state;
+}
+
 struct SlotView {
     int xmin, ymin, nx, ny;
     int64_t offset;
@@ -937,7 +943,7 @@ IMS_DEV bool land_search(const ims_render_params_t& P, const ims_object_t& o, do
                          int& ix, int& iy)
 {
     const ims_sensor_t& s = *P.sensor;
-    const ims_bf_slot_t bs = s.bf_slots[o.bf_state];
+    const ims_bf_slot_t bs = s.bf_slots[slot_index(P, o)];
     const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
     ix = (int)floor(x0 + 0.5); iy = (int)floor(y0 + 0.5);
     if (ix < o.stamp_xmin || ix > o.stamp_xmax || iy < o.stamp_ymin || iy > o.stamp_ymax) return false;

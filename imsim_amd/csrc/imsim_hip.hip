@@ -475,6 +475,28 @@ __global__ __launch_bounds__(256, (NV == 8) ? 2 : 4) void k_accumulate_round(con
     accumulate_segment<NV>(P, pool, pool_start, oi, j0, j_end);
 }
 
+// Which slot of a range does block b work on: the last k with prefix[k] <= b (prefix = ascending tile offsets of the slots,
+// prefix[0] = 0).  A bisection is log2(n) DEPENDENT loads at the head of every tile kernel -- 6 for the 41 regions of the
+// long chains, 11 for the 1 550 of the middle class, each a cold-L2 round trip of ~1.4 us in a kernel that runs for 6 - 30 us.
+// Here the wavefront looks at 64 entries at a time (one load per lane, a ballot, a population count): one load for up to 64
+// slots, two up to 4 096.  Every wavefront of the workgroup computes the same (uniform) answer; all 64 lanes must be active.
+__device__ __forceinline__ int find_slot(const int64_t* __restrict__ prefix, int n_slots, int64_t b)
+{
+    const int lane = threadIdx.x & 63;
+    int base = 0, n = n_slots;
+    while (n > 64) {
+        const int stride = (n + 63) >> 6;
+        const int k = lane * stride;
+        const bool le = k < n && prefix[base + k] <= b;
+        const int cnt = __popcll(__builtin_amdgcn_ballot_w64(le));       // entries 0, stride, 2 stride, ... <= b form a prefix
+        const int first = (cnt - 1) * stride;
+        base += first;
+        n = (n - first < stride) ? n - first : stride;
+    }
+    const bool le = lane < n && prefix[base + lane] <= b;
+    return base + __popcll(__builtin_amdgcn_ballot_w64(le)) - 1;
+}
+
 // ---------------- Silicon boundary state ----------------
 __device__ __forceinline__ void empty_owned(const ims_sensor_t& s, int n, double& x, double& y)
 {
@@ -608,11 +630,7 @@ __global__ __launch_bounds__(256) void k_init_tiles(const ims_sensor_t* __restri
     int slot = first_slot + (int)blockIdx.y, t = (int)blockIdx.x;
     if (tile_prefix != nullptr) {
         const int64_t b = blockIdx.x;
-        int lo = 0, hi = n_slots;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (tile_prefix[mid] <= b) lo = mid; else hi = mid;
-        }
+        const int lo = find_slot(tile_prefix, n_slots, b);
         slot = first_slot + lo;
         t = (int)(b - tile_prefix[lo]);
     }
@@ -721,11 +739,7 @@ __global__ __launch_bounds__(256) void k_update_distortions(const ims_sensor_t* 
     const ims_sensor_t& s = *sp;
     // block -> (slot, tile)
     const int64_t b = blockIdx.x;
-    int lo = 0, hi = n_slots;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (tile_prefix[mid] <= b) lo = mid; else hi = mid;
-    }
+    const int lo = find_slot(tile_prefix, n_slots, b);
     const ims_bf_slot_t bs = s.bf_slots[first_slot + lo];
     const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
     const int tiles_x = (sl.nx + 1 + UT - 1) / UT;
@@ -909,11 +923,7 @@ __global__ __launch_bounds__(256) void k_update_distortions_q3(const ims_sensor_
     PROBE(8);
     const ims_sensor_t& s = *sp;
     const int64_t b = blockIdx.x;
-    int lo = 0, hi = n_slots;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (tile_prefix[mid] <= b) lo = mid; else hi = mid;
-    }
+    const int lo = find_slot(tile_prefix, n_slots, b);
     const ims_bf_slot_t bs = s.bf_slots[first_slot + lo];
     const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
     const int tiles_x = (sl.nx + 1 + UT - 1) / UT;
@@ -958,11 +968,7 @@ __global__ __launch_bounds__(256) void k_update_refresh(const ims_sensor_t* __re
     __shared__ UpdRefLds L;
     const ims_sensor_t& s = *sp;
     const int64_t b = blockIdx.x;
-    int lo = 0, hi = n_slots;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (tile_prefix[mid] <= b) lo = mid; else hi = mid;
-    }
+    const int lo = find_slot(tile_prefix, n_slots, b);
     const ims_bf_slot_t bs = s.bf_slots[first_slot + lo + src_shift], bd = s.bf_slots[first_slot + lo + dst_shift];
     const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };          // source
     const SlotView dl = { bd.xmin, bd.ymin, bd.nx, bd.ny, bd.offset };          // destination (same shape)
@@ -1180,11 +1186,7 @@ __global__ __launch_bounds__(256) void k_refresh_changed(const ims_sensor_t* __r
     PROBE(16);
     const ims_sensor_t& s = *sp;
     const int64_t b = blockIdx.x;
-    int lo = 0, hi = n_slots;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (tile_prefix[mid] <= b) lo = mid; else hi = mid;
-    }
+    const int lo = find_slot(tile_prefix, n_slots, b);
     const ims_bf_slot_t bs = s.bf_slots[first_slot + lo];
     const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
     const int tiles_x = (sl.nx + 1 + UT - 1) / UT, tiles_y = (sl.ny + 1 + UT - 1) / UT;

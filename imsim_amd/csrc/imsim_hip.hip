@@ -907,13 +907,121 @@ __device__ __forceinline__ void update_tile_q3(const ims_sensor_t& s, const Slot
     PROBE(14);
 }
 
+// acc = fma(d of lane SEL of this lane's row of 16, w, acc): the DPP form of v_fmac_f64 (gfx90a and later accept
+// row_newbcast on the 64-bit ALU).  The operand that is uniform over the wavefront -- an entry of the displacement table --
+// sits in ONE lane of every row of a VGPR pair and is broadcast by the instruction itself: no scalar load, no LDS read and
+// no wait between the FMAs.  All 64 lanes must be active (the source lane is read through EXEC).
+__device__ __forceinline__ void fmac_bcast(int sel, double& acc, double d, double w)
+{
+#define IMS_FB(n) case n: asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #n " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(d), "v"(w)); break;
+    switch (sel) {
+        IMS_FB(0) IMS_FB(1) IMS_FB(2) IMS_FB(3) IMS_FB(4) IMS_FB(5) IMS_FB(6) IMS_FB(7)
+        IMS_FB(8) IMS_FB(9) IMS_FB(10) IMS_FB(11) IMS_FB(12) IMS_FB(13) IMS_FB(14) IMS_FB(15)
+    }
+#undef IMS_FB
+}
+
+// update_tile_q3 with the displacement table delivered by DPP broadcasts.  In the form above a tap costs two scalar
+// loads, a wait for them and twenty FMAs on SGPR operands: the 102 SGPRs hold two taps at most, so nothing is fetched ahead
+// and a cell's 64 taps are 128 scalar-cache round trips -- 10.8 of the kernel's 14 us for a star's core tile.  Here the
+// table is staged in LDS once per workgroup (beside the charge halo, one round trip for both), a row of the window (8 taps
+// x 2 NPO values) is read as NPO VGPR pairs, lane l holding entry 16 r + (l & 15), and every FMA names the lane it wants.
+// Same operands, same order, same bits.  Lanes without a cell or without charge in their window run along (their w are
+// +0, which leaves acc unchanged bit for bit) because a broadcast reads its source lane through EXEC.
+template <int NV>
+__device__ __forceinline__ void update_tile_q3_dpp(const ims_sensor_t& s, const SlotView& sl, int tx0, int ty0,
+                                                   unsigned char* __restrict__ changed, UpdateLds<NV>& L, unsigned int tag,
+                                                   const double* __restrict__ dl_global)
+{
+    constexpr int Q = 3, HW = UT + 2 * Q + 1, NPO = 2 * NV + 2, NPT = 2 * NPO;
+    const int sx0 = tx0 - (Q + 1), sy0 = ty0 - (Q + 1);
+    if (threadIdx.x < HW) L.occ[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) L.any_charge = 0;
+    // the table first: its loads fly while the halo is gathered
+    constexpr int DLN = 8 * 8 * NPT, DLP = (DLN + 255) / 256;
+    double dreg[DLP];
+#pragma unroll
+    for (int u = 0; u < DLP; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        dreg[u] = (e < DLN) ? dl_global[e] : 0.0;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < HW * HW; e += 256) {
+        const int hx = e % HW, hy = e / HW;
+        const int si = sx0 + hx, sj = sy0 + hy;
+        double w = 0.0;
+        if (si >= 0 && si < sl.nx && sj >= 0 && sj < sl.ny) {
+            const double charge = (double)s.bf_delta[cell_index(sl, si, sj)];
+            if (charge != 0.0) { w = ddiv(charge, s.num_elec); atomicOr(&L.occ[hy], 1u << hx); L.any_charge = 1; }
+        }
+        L.wt[e] = w;
+    }
+#pragma unroll
+    for (int u = 0; u < DLP; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        if (e < DLN) L.dl[e] = dreg[u];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % UT, ly = threadIdx.x / UT;
+    const int i = tx0 + lx, j = ty0 + ly;
+    const bool cell = (i <= sl.nx && j <= sl.ny);
+    if (!L.any_charge) {                     // nothing landed near this tile: nothing moves
+        if (cell) changed[cell_index(sl, i, j)] = 0;
+        return;
+    }
+    unsigned long long mask = 0ull;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const unsigned int row = (L.occ[ly + 2 * Q + 1 - a] >> lx) & 0xFFu;
+        const unsigned int rev = __brev(row) >> 24;
+        mask |= (unsigned long long)rev << (8 * a);
+    }
+    if (!cell) mask = 0ull;
+    const int64_t c = cell ? cell_index(sl, i, j) : sl.offset;
+    if (cell) changed[c] = mask ? 1 : 0;
+    if (mask && tag != 0u && s.bf_tile_changed != nullptr) s.bf_tile_changed[cell_index(sl, tx0, ty0)] = (unsigned char)tag;
+    double* pts = s.bf_boundary + c * NPT;
+    double acc[NPT];
+#pragma unroll
+    for (int n = 0; n < NPT; ++n) acc[n] = mask ? pts[n] : 0.0;
+    const int l16 = threadIdx.x & 15;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const unsigned int rowbits = (unsigned int)(mask >> (8 * a)) & 0xFFu;
+        if (__builtin_amdgcn_ballot_w64(rowbits != 0u) == 0ull) continue;
+        double d[NPO], w[8];
+#pragma unroll
+        for (int r = 0; r < NPO; ++r) d[r] = L.dl[a * 8 * NPT + r * 16 + l16];
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) {
+            const double ww = L.wt[(ly + 2 * Q + 1 - a) * HW + (lx + 2 * Q + 1 - bb)];
+            w[bb] = mask ? ww : 0.0;
+        }
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) {
+            if (__builtin_amdgcn_ballot_w64(w[bb] != 0.0) == 0ull) continue;       // a tap no lane of the wavefront has charge under
+#pragma unroll
+            for (int n2 = 0; n2 < NPT; ++n2) {
+                const bool bottom = n2 < 2 * (NV + 2);
+                if (bottom ? (bb == 7) : (a == 7)) continue;                    // the extra column / row of the window
+                const int v = bb * NPT + n2;
+                fmac_bcast(v & 15, acc[n2], d[v >> 4], w[bb]);
+            }
+        }
+    }
+    if (mask) {
+#pragma unroll
+        for (int n = 0; n < NPT; ++n) pts[n] = acc[n];
+    }
+}
+
 // Fast path for qdist == 3 (the GalSim default): the 8x8 source window of a cell is a 64-bit
 // occupancy mask cut out of per-row LDS bitmaps, so a lane only iterates over its OWN charged
 // neighbours (in the spec's order: dj ascending, then di ascending) instead of testing all 64.
 // Sparse stamp wings cost max-over-lanes(nnz) iterations per wave; the dense core stays dense.
 // Boundary points are accumulated in registers (NV is a template parameter) and the displacement
 // table and the scaled charges w = delta / num_elec live in LDS.
-template <int NV>
+template <int NV, bool DPP = false>
 __global__ __launch_bounds__(256) void k_update_distortions_q3(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
                                                                const int64_t* __restrict__ tile_prefix,
                                                                unsigned char* __restrict__ changed, unsigned int tag,
@@ -933,7 +1041,8 @@ __global__ __launch_bounds__(256) void k_update_distortions_q3(const ims_sensor_
 #ifdef IMS_UPD_FORCE_LDS
     dl_global = nullptr;
 #endif
-    if (dl_global != nullptr) update_tile_q3<NV, true>(s, sl, tx0, ty0, changed, L, false, tag, dl_global);
+    if (DPP) update_tile_q3_dpp<NV>(s, sl, tx0, ty0, changed, L, tag, dl_global);
+    else if (dl_global != nullptr) update_tile_q3<NV, true>(s, sl, tx0, ty0, changed, L, false, tag, dl_global);
     else update_tile_q3<NV, false>(s, sl, tx0, ty0, changed, L, false, tag);
 }
 
@@ -1896,7 +2005,14 @@ int ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sens
     const unsigned g = (unsigned)((count + 255) / 256);
     const int nV = sensor_host ? sensor_host->num_vertices : 0;
     const int q = sensor_host ? sensor_host->qdist : 0;
-    if (q == 3 && nV == 4)
+    const bool dpp = sensor_host && sensor_host->bf_dl != nullptr && os_getenv_off("IMS_UPD_DPP");
+    if (q == 3 && nV == 4 && dpp)
+        hipLaunchKernelGGL((k_update_distortions_q3<4, true>), dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot,
+                           n_slots, tile_prefix_dev, changed_dev, tag, sensor_host->bf_dl);
+    else if (q == 3 && nV == 8 && dpp)
+        hipLaunchKernelGGL((k_update_distortions_q3<8, true>), dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot,
+                           n_slots, tile_prefix_dev, changed_dev, tag, sensor_host->bf_dl);
+    else if (q == 3 && nV == 4)
         hipLaunchKernelGGL(k_update_distortions_q3<4>, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot,
                            n_slots, tile_prefix_dev, changed_dev, tag, sensor_host->bf_dl);
     else if (q == 3 && nV == 8)

@@ -164,3 +164,23 @@ def test_derived_constants_are_the_plain_ieee_expressions():
     assert lib.ims_fill_derived_op(C.byref(op)) == 0
     assert op.p[1] == f(3.9) * f(3.9) and op.p[2] == f(3.9) * f(3.9) - f(1.0)
     assert lib.ims_fill_derived_optics(None) < 0 and lib.ims_fill_derived_atmosphere(None) < 0 and lib.ims_fill_derived_sensor(None) < 0
+
+
+def test_hand_written_dpp_instructions_have_no_hazard(tmp_path):
+    """The v_fmac_f64_dpp broadcasts of the update kernel are inline asm, which the compiler's hazard recogniser does not
+    look into: compile the device code to assembly and check the wait states before every DPP instruction."""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    out = tmp_path / "imsim_hip.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-S",
+                    os.path.join(root, "imsim_amd", "csrc", "imsim_hip.hip"), "-o", str(out)], check=True, capture_output=True)
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import check_dpp_hazard
+    n_dpp, bad = check_dpp_hazard.check(str(out))
+    assert n_dpp >= 1000, "the DPP update kernel is gone?"
+    assert not bad, bad[:5]

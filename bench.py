@@ -65,11 +65,37 @@ def spawn_ranks(args):
             env["IMS_BENCH_SHARE_GPU"] = "1"
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out0, _ = procs[0].communicate()
+    # watchdog: a rank that dies (say in init_process_group) must not leave the others waiting for the collective timeout.
+    # Rank 0's output is drained by a thread; the children are polled, and the first non-zero exit ends the rest.
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            rc = p.poll()
+            if rc is not None and rc != 0:
+                failed = (r, rc)
+                break
+        time.sleep(0.2)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(t_end - time.time(), 0.1))
+            except subprocess.TimeoutExpired:
+                p.kill()
+        print(f"bench.py: rank {failed[0]} exited with code {failed[1]}; the other ranks were stopped", file=sys.stderr)
     rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0.decode())
-    sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    reader.join(timeout=5.0)
+    if failed is None:
+        sys.stdout.write(b"".join(c for c in chunks if c).decode())
+        sys.stdout.flush()
+    return max(abs(rc) for rc in rcs) or (1 if failed is not None else 0)
 
 
 def main():
@@ -79,6 +105,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("IMS_BENCH_FAIL_RANK") == str(rank) and world > 1:
+        sys.exit(3)                     # test hook of the launcher's watchdog (tests/test_multi_gpu_gloo.py)
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; the launcher's world size is used", file=sys.stderr)
 
@@ -130,12 +158,14 @@ def main():
     step = cfg["make_step"](renderer, objects, rank, world)
     lib = _abi.load()
 
+    unit_flux = parallel.unit_flux_path(scene, objects)
+
     def full_step():
         renderer.image.zero_()
         step()
-        # unit photon fluxes: every pixel is an integer count; the brightest pixel of this catalog holds ~1e8 < 2^31
+        # unit photon fluxes: every pixel is an integer count (checked once, after the timed region: integer_counts_ok)
         if cfg.get("reduce", True):
-            parallel.reduce_image(renderer.image, dst=0, integer_counts=True)
+            parallel.reduce_image(renderer.image, dst=0, integer_counts=unit_flux)
 
     for _ in range(args.warmup):
         full_step()
@@ -155,6 +185,10 @@ def main():
     ms, nl = _abi.C.c_float(), _abi.C.c_int()
     have_ms = lib.ims_last_kernel_ms(_abi.C.byref(ms), _abi.C.byref(nl)) == 0
     lib.ims_enable_timing(0)
+    if world > 1 and unit_flux and cfg.get("reduce", True) and rank == 0:
+        # the int32 exchange is only exact for integer counts whose sum over the ranks fits: the reduced image must qualify
+        if not parallel.integer_counts_ok(renderer.image, 1):
+            raise RuntimeError("bench.py: the reduced CCD image is not an integer count below 2^31 -- int32 exchange invalid")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -276,7 +310,7 @@ def _cpu_step(cfg):
 def cpu_legs(cfg, scene, objects, args, fork_ok=True):
     """(i) ONE core over a bounded random sample (imSim itself never threads, imsim/__init__.py:2-10); (ii) all host
     cores over the whole catalog, forked workers with private images (mirrors output.nproc / image.nproc process
-    parallelism), objects dealt longest-first."""
+    parallelism), objects dealt longest-first by photon count."""
     import multiprocessing as mp
     from oracle import orc_loader
     from imsim_amd import parallel
@@ -297,8 +331,11 @@ def cpu_legs(cfg, scene, objects, args, fork_ok=True):
     if fork_ok and not args.no_cpu_allcore and cfg.get("cpu_allcore", True):
         cores = len(os.sched_getaffinity(0))
         nproc = max(1, cores)
-        owner = parallel.assign_ranks(objects["n_phot"], nproc)
+        # plain longest-processing-time dealing by photon count: a CPU worker's time follows its photons (the GPU cost model
+        # of parallel.assign_ranks, which prices brighter-fatter rounds, left the workers 2.6 x out of balance at 64 workers)
+        owner = parallel.assign_ranks(objects["n_phot"], nproc, round_photons=0.0)
         parts = [objects[owner == k] for k in range(nproc)]
+        per_worker = np.array([int(p["n_phot"].sum()) for p in parts], dtype=np.float64)
         fresh = orc_loader.OracleScene(cpu_scene)
         _FORK_STATE.update(parts=parts, orc=fresh, cfg=cfg)
         t0 = time.perf_counter()
@@ -311,7 +348,8 @@ def cpu_legs(cfg, scene, objects, args, fork_ok=True):
                             "sample": f"the whole catalog ({n_done} objects, {sum(d[1] for d in done)} photons) over "
                                       f"{nproc} forked workers with private images, {dt_all:.1f} s wall "
                                       f"(slowest worker {max(d[3] for d in done):.1f} s)",
-                            "electrons": sum(d[2] for d in done)}
+                            "electrons": sum(d[2] for d in done),
+                            "photon_imbalance_max_over_mean": float(per_worker.max() / max(per_worker.mean(), 1.0))}
     return res
 
 

@@ -61,17 +61,41 @@ def shard_ccds(dets, rank, world):
     return [d for k, d in enumerate(dets) if k % world == rank]
 
 
+def unit_flux_path(scene, objects=None):
+    """True when every photon of a render carries exactly one electron: no flux-scaling operator in the chain
+    (BandpassRatio multiplies the flux by a table value) and flux_per_photon == 1 for every object.  Only then are the CCD
+    image and the delta-charge image integer counts, and only then may an exchange run on int32 copies."""
+    from . import _abi
+    for op in getattr(scene, "ops", None) or []:
+        if int(op[0]) == _abi.IMS_OP_BANDPASS_RATIO:
+            return False
+    if objects is not None and len(objects) and not np.all(objects["flux_per_photon"] == 1.0):
+        return False
+    return True
+
+
+def integer_counts_ok(image, world):
+    """The check reduce_image(integer_counts=True) relies on, as ONE host synchronisation the caller places outside its timed
+    region: every pixel a non-negative integer, and world x the largest pixel below 2^31 (so the SUM over the ranks cannot
+    wrap either)."""
+    import torch
+    top = float(image.max())
+    low = float(image.min())
+    whole = bool(torch.equal(image, torch.floor(image)))
+    return whole and low >= 0.0 and top * max(int(world), 1) < 2147483648.0
+
+
 def reduce_image(image, dst=0, integer_counts=False):
     """Sum the per-rank CCD images onto `dst` (no-op for a single process).
 
-    integer_counts: the caller guarantees that every pixel holds an integer electron count below 2^31 (unit photon
-    fluxes, the standard path: stamp.py:562-572 `poisson_flux=False`, n_photons=phot_flux).  The exchange then runs on
-    an int32 copy -- half the bytes of the f64 accumulation image on the per-link-bound xGMI ring -- and is still exact."""
+    integer_counts: the caller guarantees that every pixel holds a non-negative integer electron count and that the sum
+    over the ranks stays below 2^31 (unit photon fluxes, the standard path: stamp.py:562-572 `poisson_flux=False`,
+    n_photons=phot_flux; `unit_flux_path` says whether a scene qualifies, `integer_counts_ok` checks an image -- once,
+    outside the timed region: nothing here synchronises with the host).  The exchange then runs on an int32 copy -- half the
+    bytes of the f64 accumulation image on the per-link-bound xGMI ring -- and is still exact."""
     import torch
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        if integer_counts and float(image.max()) >= 2147483648.0:
-            raise ValueError("reduce_image(integer_counts=True): a pixel holds more than 2^31 - 1 electrons")
         buf = image.to(torch.int32) if integer_counts else image
         if dist.get_backend() == "gloo" and buf.is_cuda:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)       # gloo has no device reduce (dry runs on one GPU only)

@@ -108,7 +108,15 @@ def _pool_fits(renderer, n_photons):
     if os.environ.get("IMS_POOL_RESIDENT", "1") == "0" or not hasattr(renderer, "prepared_pooled_batches"):
         return False
     free = renderer.torch.cuda.mem_get_info(renderer.device)[0]
-    return 32 * int(n_photons) < 0.8 * free
+    fits = 32 * int(n_photons) < 0.8 * free
+    # the resident form and the sub-batch loop issue different collectives: the ranks must take the same one
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        flag = renderer.torch.tensor([1 if fits else 0], dtype=renderer.torch.int32,
+                                     device=renderer.device if dist.get_backend() != "gloo" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        fits = bool(int(flag.item()))
+    return fits
 
 
 def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1, resident=None, realized=None,
@@ -183,6 +191,10 @@ def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1,
                 table = table[spatial(table)]
             launches.append(renderer.prepared(table, bf_tag=(i % 255 + 1) if tagged else 0))
 
+    # int32 exchange of the delta-charge image only when every photon is exactly one electron (BandpassRatio and
+    # flux_per_photon != 1 make fractional charge, which an integer copy would truncate)
+    unit = parallel.unit_flux_path(renderer.scene, objects)
+
     def run():
         if sensor_on:
             renderer.init_boundaries(0, 1)                 # a new CCD starts from undistorted (+ tree ring) boundaries
@@ -193,7 +205,7 @@ def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1,
                 continue
             if sensor_on and i > first_batch:
                 if world > 1:
-                    parallel.allreduce_delta(renderer.delta_tensor(0), integer_counts=True)
+                    parallel.allreduce_delta(renderer.delta_tensor(0), integer_counts=unit)
                 renderer.update_distortions(0, 1, bf_tag=((i - 1) % 255 + 1) if tagged else 0)
             launch()
             if after_batch is not None:
@@ -261,6 +273,7 @@ def build_image(renderer, objects, modes, nbatch=10, nsubbatch=50, seed=0, reali
             total += int(t["n_phot"][sel].sum())
         return total
     sensor_on = renderer.scene.sensor is not None
+    unit = parallel.unit_flux_path(renderer.scene, objects)
     owner = parallel.assign_ranks(objects["n_phot"], world)
     nsub = max(min(nsubbatch, len_smallest or 1), 1)
     for i, (table, index) in enumerate(batch_tables):
@@ -283,7 +296,7 @@ def build_image(renderer, objects, modes, nbatch=10, nsubbatch=50, seed=0, reali
                 # recalc=(subbatch_num == 0), resume afterwards; only tiles near the previous batch's charge move
                 # (with several ranks the tile marks are rank-local, so every tile is visited)
                 if world > 1:
-                    parallel.allreduce_delta(renderer.delta_tensor(0))
+                    parallel.allreduce_delta(renderer.delta_tensor(0), integer_counts=unit)      # as the resident form
                 renderer.update_distortions(0, 1, bf_tag=((i - 1) % 255 + 1) if world == 1 else 0)
             if world > 1:
                 mine = owner[idx] == rank

@@ -97,20 +97,36 @@ def load_silicon_model(name, strength=1.0, diffusion_factor=1.0, qdist=3, nrecal
     lower_left = cfg.get("PixelBoundaryLowerLeft", [10.0, 10.0])
     empty = empty_polygon(nV)
     empty_theta = np.arctan2(empty[:, 1] - 0.5, empty[:, 0] - 0.5)
-    dist = np.zeros((nx, ny, nv, 2))
-    seen = np.zeros((nx, ny, nv), dtype=bool)
-    for x0, y0, th, x1, y1 in data:
-        i = int(math.floor((x0 - lower_left[0]) / pixel))
-        j = int(math.floor((y0 - lower_left[1]) / pixel))
+    # The Theta column is the polar angle of the (distorted) vertex about the pixel centre.  In the pixels around the
+    # charged one the vertices move by more than half their spacing once there are 32 of them per edge, so a vertex cannot
+    # be recognised by its angle alone; what identifies it is its PLACE in the pixel's block of nv rows, which run
+    # counter-clockwise from just past the middle of the left edge.  The place -> vertex map is read off a block whose
+    # pixel is far from the charge (nearest nominal angle, every vertex hit exactly once) and used for all blocks.
+    blocks = data.reshape(nx * ny, nv, 5)
+    if not (np.all(blocks[:, :, 0] == blocks[:, :1, 0]) and np.all(blocks[:, :, 1] == blocks[:, :1, 1])):
+        raise ValueError(f"{name}.dat: the rows of a pixel are not contiguous")
+    bi = np.floor((blocks[:, 0, 0] - lower_left[0]) / pixel).astype(int)
+    bj = np.floor((blocks[:, 0, 1] - lower_left[1]) / pixel).astype(int)
+    far = int(np.argmax(np.hypot(bi - (nx - 1) / 2.0, bj - (ny - 1) / 2.0)))
+    place = np.empty(nv, dtype=int)
+    for k, th in enumerate(blocks[far, :, 2]):
         d = np.angle(np.exp(1j * (empty_theta - th)))
-        n = int(np.argmin(np.abs(d)))
-        if abs(d[n]) > 0.5 * math.pi / (2.0 * (nV + 1.0)) or seen[i, j, n]:
-            raise ValueError(f"{name}.dat: cannot match vertex theta={th} of pixel ({i},{j})")
-        seen[i, j, n] = True
-        dist[i, j, n, 0] = (x1 - x0) / pixel + 0.5 - empty[n, 0]
-        dist[i, j, n, 1] = (y1 - y0) / pixel + 0.5 - empty[n, 1]
+        place[k] = int(np.argmin(np.abs(d)))
+        if abs(d[place[k]]) > 0.5 * math.pi / (2.0 * (nV + 1.0)):
+            raise ValueError(f"{name}.dat: cannot match vertex theta={th} of pixel ({bi[far]},{bj[far]})")
+    if len(set(place.tolist())) != nv:
+        raise ValueError(f"{name}.dat: the vertex order of a block is not a permutation of the polygon")
+    dist = np.zeros((nx, ny, nv, 2))
+    seen = np.zeros((nx, ny), dtype=bool)
+    for b in range(nx * ny):
+        i, j = int(bi[b]), int(bj[b])
+        if not (0 <= i < nx and 0 <= j < ny) or seen[i, j]:
+            raise ValueError(f"{name}.dat: pixel ({i},{j}) out of range or listed twice")
+        seen[i, j] = True
+        dist[i, j, place, 0] = (blocks[b, :, 3] - blocks[b, :, 0]) / pixel + 0.5 - empty[place, 0]
+        dist[i, j, place, 1] = (blocks[b, :, 4] - blocks[b, :, 1]) / pixel + 0.5 - empty[place, 1]
     if not seen.all():
-        raise ValueError(f"{name}.dat: missing vertices")
+        raise ValueError(f"{name}.dat: missing pixels")
     num_elec = float(cfg["CollectedCharge_0_0"]) / strength
     return SiliconModel(num_vertices=nV, nx=nx, ny=ny, num_elec=num_elec, pixel_size=pixel,
                         thickness=float(cfg["SensorThickness"]),
@@ -119,5 +135,6 @@ def load_silicon_model(name, strength=1.0, diffusion_factor=1.0, qdist=3, nrecal
 
 
 def sensor_model_path(data_dir, det_type):
-    """imsim/lsst_image.py:93-103: ITL -> lsst_itl_50_4, E2V -> lsst_e2v_50_4."""
+    """imsim/lsst_image.py:93-103: ITL -> lsst_itl_50_4, E2V -> lsst_e2v_50_4 (the 8- and 32-vertex files of the same
+    directory load by name: image.sensor.name)."""
     return os.path.join(data_dir, "sensor_models", {"ITL": "lsst_itl_50_4", "E2V": "lsst_e2v_50_4"}[det_type])

@@ -62,18 +62,23 @@ class CCD_Fringing:
         self.data_dir = data_dir or DATA_DIR
 
     def generate_heightfield(self, fractal_dimension=2.5, n=4096):
-        H = 1 - (fractal_dimension - 2)
-        kpow = -(H + 1.0) / 1.2
-        A = np.zeros((n, n), complex)
-        kvec = np.fft.fftfreq(n)
-        k0 = kvec[n // 64]
-        kx, ky = np.meshgrid(kvec, kvec, sparse=True, copy=False)
-        ksq = kx ** 2 + ky ** 2
-        m = ksq > 0
-        gen = np.random.default_rng(self.seed)
-        phase = 2 * np.pi * gen.uniform(size=(n, n))
-        A[m] = ksq[m] ** kpow * gen.normal(size=(n, n))[m] * np.exp(1.j * phase[m]) * np.exp(-ksq[m] / k0 ** 2)
-        return np.fft.ifft2(A)
+        """Spectral synthesis of the silicon thickness map behind the fringes (imsim/sky_model.py:152-171 does the same
+        thing): a Gaussian random field whose Fourier amplitude falls as |k|^(2 p), p = -(H + 1) / 1.2 with the Hurst
+        exponent H = 3 - D of a surface of fractal dimension D, tapered by exp(-|k|^2 / k0^2) with k0 the n/64-th
+        frequency of the grid, no mean.  Every mode gets a normal amplitude and a uniform phase; the complex inverse
+        transform is returned (the caller takes the real part)."""
+        hurst = 3.0 - fractal_dimension
+        p = -(hurst + 1.0) / 1.2
+        f = np.fft.fftfreq(n)
+        f2 = f * f
+        k2 = f2[:, None] + f2[None, :]
+        k2[0, 0] = 1.0                                   # the mean: removed below
+        envelope = np.exp(p * np.log(k2) - k2 / f[n // 64] ** 2)
+        envelope[0, 0] = 0.0
+        rng = np.random.default_rng(self.seed)
+        angle = (2.0 * np.pi) * rng.uniform(size=(n, n))
+        strength = envelope * rng.normal(size=(n, n))
+        return np.fft.ifft2(strength * np.cos(angle) + 1j * (strength * np.sin(angle)))
 
     def simulate_fringes(self, amp=0.002, n_side=4096):
         n, n1, nwaves_rms = 1.2, 1.5, 10.0

@@ -63,5 +63,5 @@ def oracle_backend(scene):
 if __name__ == "__main__":
     digests = {k: digest(v) for k, v in cases(oracle_backend).items()}
     with open(os.path.join(HERE, "pipeline_golden.json"), "w") as f:
-        json.dump({"spec": "v4", "sha256": digests}, f, indent=1, sort_keys=True)
+        json.dump({"spec": "v5", "sha256": digests}, f, indent=1, sort_keys=True)
     print(json.dumps(digests, indent=1))

@@ -4,6 +4,14 @@ import numpy as np
 from imsim_amd import configs, catalog
 
 
+def free_port():
+    """a TCP port nobody listens on (asked of the kernel, not derived from the pid)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def small_case(n_obj=300, nx=512, ny=512, flux_seed=1, scene=None, **kw):
     scene = scene if scene is not None else configs.scene_c2(nx=nx, ny=ny)
     cat = catalog.synthetic_catalog(n_obj, nx=nx, ny=ny)

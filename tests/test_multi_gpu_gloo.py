@@ -42,7 +42,8 @@ def test_two_rank_sharded_render_equals_single_process(tmp_path):
     from helpers import small_case
     from oracle import orc_loader
     out = str(tmp_path / "reduced.npz")
-    port = 29500 + (os.getpid() % 2000)
+    from helpers import free_port
+    port = free_port()
     mp.start_processes(_worker, args=(2, port, out), nprocs=2, join=True, start_method="spawn")
     res = np.load(out)
     scene, objects, _ = small_case(n_obj=120, nx=256, ny=256, flux_seed=9)
@@ -97,7 +98,8 @@ def test_two_rank_photon_pooling_with_brighter_fatter_equals_single_process(tmp_
     from imsim_amd import photon_pooling, stamp
     from oracle import orc_loader
     out = str(tmp_path / "pooled.npz")
-    port = 31500 + (os.getpid() % 2000)
+    from helpers import free_port
+    port = free_port()
     mp.start_processes(_pooling_worker, args=(2, port, out), nprocs=2, join=True, start_method="spawn")
     res = np.load(out)
     scene, objects = c3_small_case(n_obj=60, n=128, flux_seed=5, scratch=0)
@@ -122,3 +124,18 @@ def test_ccds_are_dealt_round_robin():
     assert max(len(p) for p in parts) == 24 and min(len(p) for p in parts) == 23       # ceil(189 / 8)
     assert parts[3][:3] == [3, 11, 19]
     assert parallel.shard_ccds(dets, 0, 1) == dets
+
+
+def test_bench_launcher_stops_the_other_ranks_when_one_dies():
+    """`bench.py --gpus 2` starts its own ranks; a rank that exits (here: before the rendezvous) must end the run at once
+    with a non-zero code instead of leaving rank 0 in init_process_group until the collective timeout."""
+    import subprocess
+    import time
+    env = dict(os.environ, IMS_BENCH_FAIL_RANK="1")
+    env.pop("WORLD_SIZE", None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-cold"], env=env, capture_output=True, timeout=120)
+    assert p.returncode != 0
+    assert time.time() - t0 < 60.0
+    assert b"rank 1 exited with code 3" in p.stderr

@@ -49,7 +49,8 @@ def _worker(rank, world, port, out_path, mode):
 def _run(tmp_path, mode):
     import torch.multiprocessing as mp
     out = str(tmp_path / f"{mode}.npz")
-    port = 33500 + (os.getpid() % 2000)
+    from helpers import free_port
+    port = free_port()
     mp.start_processes(_worker, args=(2, port, out, mode), nprocs=2, join=True, start_method="spawn")
     return np.load(out)
 

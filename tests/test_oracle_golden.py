@@ -161,6 +161,25 @@ def test_brighter_fatter_makes_spots_larger_and_conserves_flux():
     assert abs(e2v.sum() - none.sum()) / none.sum() < 2e-3
 
 
+@pytest.mark.parametrize("vendor", ["itl", "e2v"])
+def test_sensor_models_of_4_8_and_32_vertices_agree(vendor):
+    """tests/test_sensor_models.py:73-125 of the reference: the spot of the sensor-model case drawn with the 4-, 8- and
+    32-vertex pixel models of one vendor has the same radius within 2 sigma_r (sigma_r = 1 / sqrt(flux) pixels), a lower
+    peak than without a sensor, and is larger than without by more than 2 sigma_r."""
+    none = _sensor_spot(None)
+    r0 = np.sqrt(sum(_moments(none)))
+    sigma_r = 1.0 / np.sqrt(1e6)
+    r = {}
+    for nv in (4, 8, 32):
+        img = _sensor_spot(f"lsst_{vendor}_50_{nv}")
+        assert img.max() <= none.max()
+        assert img.sum() == pytest.approx(1.0e6, rel=2e-3)
+        r[nv] = np.sqrt(sum(_moments(img)))
+        assert r[nv] - r0 > 2 * sigma_r
+    assert abs(r[8] - r[4]) < 2 * sigma_r, r
+    assert abs(r[32] - r[8]) < 2 * sigma_r, r
+
+
 def test_oracle_reproduces_the_frozen_spec_digests():
     """tests/golden/pipeline_golden.json freezes the numerics spec: C2 image, C3 photon fields
     after the op chain, the LSST_Image brighter-fatter image and the photon-pooling image of small seeded cases."""
@@ -169,6 +188,6 @@ def test_oracle_reproduces_the_frozen_spec_digests():
     sys.path.insert(0, os.path.join(HERE, "golden"))
     import make_pipeline_golden as g
     want = json.load(open(os.path.join(HERE, "golden", "pipeline_golden.json")))
-    assert want["spec"] == "v4"
+    assert want["spec"] == "v5"
     got = {k: g.digest(v) for k, v in g.cases(g.oracle_backend).items()}
     assert got == want["sha256"]

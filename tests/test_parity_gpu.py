@@ -354,6 +354,63 @@ def test_c3_lsst_image_mode_is_bit_exact(torch_cuda):
         assert_bits_equal(ga[name], orc.sensor_array(name)[:len(ga[name])], f"sensor {name}")
 
 
+@pytest.mark.parametrize("vendor", ["itl", "e2v"])
+def test_sensor_models_of_4_8_and_32_vertices_on_the_gpu(torch_cuda, vendor):
+    """The reference's cross-model criterion (tests/test_sensor_models.py:73-125) through the HIP path: the 1e6-photon
+    Gaussian spot of its sensor-model case, drawn in LSST_Image mode with the 4-, 8- and 32-vertex pixel models (the
+    kernels unrolled for 4 and 8 vertices per edge and the generic loops for 32), is bit-identical to the oracle's for every
+    model, has a lower peak and a radius larger by more than 2 sigma_r than without a sensor, and the three radii agree
+    within 2 sigma_r."""
+    import os
+    from imsim_amd import _abi, sensor as sensormod
+    from imsim_amd._abi import OBJECT_DTYPE
+    from imsim_amd.engine import Renderer, Scene, SensorSetup, make_slots
+    from oracle import orc_loader
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    N, n = 17, 1000000
+
+    def spot(model_name):
+        sc = Scene(nx=N, ny=N, seed=1234, psf=[(_abi.IMS_PSF_GAUSSIAN, 0, 0.3, 0.0, 1.0)], ops=[])
+        if model_name:
+            model = sensormod.load_silicon_model(os.path.join(root, "imsim_amd", "data", "sensor_models", model_name))
+            sc.sensor = SensorSetup(model=model, abs_wl=np.array([300.0, 1100.0]), abs_len=np.array([1.0, 1.0]),
+                                    slots=make_slots([(1, 1, N, N)]), scratch_cells=4 * (N + 1) * (N + 1))
+        obj = np.zeros(1, dtype=OBJECT_DTYPE)
+        obj["obj_id"], obj["n_phot"], obj["x0"], obj["y0"], obj["flux_per_photon"] = 5, n, 9.0, 9.0, 1.0
+        obj["jac"], obj["winv"] = (1, 0, 0, 1), (1 / 0.3, 0, 0, 1 / 0.3)
+        obj["prof_table"], obj["sed_table"], obj["sed_wave"] = -1, -1, 600.0
+        obj["stamp_xmin"], obj["stamp_xmax"], obj["stamp_ymin"], obj["stamp_ymax"] = 1, N, 1, N
+        r = Renderer(sc)
+        r.render_lsst_image(obj, nrecalc=10000)
+        r.synchronize()
+        orc = orc_loader.OracleScene(sc)
+        orc.render_lsst_image(obj, nrecalc=10000)
+        assert_bits_equal(r.image_numpy(), orc.image, f"spot image, {model_name}")
+        if model_name:
+            ga = _sensor_arrays_gpu(r)
+            for name in ("boundary", "bounds"):
+                assert_bits_equal(ga[name], orc.sensor_array(name)[:len(ga[name])], f"sensor {name}, {model_name}")
+        return r.image_numpy().astype(float)
+
+    def radius(img):
+        yy, xx = np.mgrid[0:N, 0:N].astype(float)
+        f = img.sum()
+        mx, my = (img * xx).sum() / f, (img * yy).sum() / f
+        return np.sqrt((img * ((xx - mx) ** 2 + (yy - my) ** 2)).sum() / f)
+
+    none = spot(None)
+    sigma_r = 1.0 / np.sqrt(float(n))
+    r = {}
+    for nv in (4, 8, 32):
+        img = spot(f"lsst_{vendor}_50_{nv}")
+        assert img.max() <= none.max()
+        assert abs(img.sum() - n) < 2e-3 * n
+        r[nv] = radius(img)
+        assert r[nv] - radius(none) > 2 * sigma_r
+    assert abs(r[8] - r[4]) < 2 * sigma_r, r
+    assert abs(r[32] - r[8]) < 2 * sigma_r, r
+
+
 def test_pooling_mode_brighter_fatter_is_bit_exact(torch_cuda):
     """Photon-pooling semantics (photon_pooling.py:141-160): the whole CCD is one brighter-fatter
     region, recalculated once per batch from the charge accumulated since the last recalc."""

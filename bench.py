@@ -135,6 +135,7 @@ def main():
         phot = catalog.realize_fluxes(cat["nominal_flux"], scene.seed)
         objects, _ = cfg["objects"](cat, phot, scene)
         timing["object_table_ms"] = 1e3 * (time.perf_counter() - t0)
+        timing["cat"] = cat
         return scene, objects
 
     cpu = None
@@ -253,6 +254,10 @@ def main():
         out["extra"] = cfg["cold"](scene, objects, device)
         # host side of LSST_SiliconBuilder.setup for the whole catalog (Poisson fluxes, stamp sizes, local WCS, DCR angles)
         out["extra"]["object_table_ms"] = timing.get("object_table_ms")
+        if "end_to_end" in cfg:
+            renderer = step = None                   # its pool and private regions make room for the fresh renderer
+            torch.cuda.empty_cache()
+            out["extra"].update(cfg["end_to_end"](scene, timing["cat"], device))
     if want_cpu:
         if cpu is None:
             cpu = cpu_legs(cfg, scene, objects, args, fork_ok=False)

@@ -182,6 +182,24 @@ class Chain(C.Structure):
                 ("pair_tile_prefix", c_vp), ("pair_tile_prefix_host", c_vp)]
 
 
+class Catalog(C.Structure):
+    """ims_catalog_t: the columns of a catalog on the device + the launch-wide constants of the table builder"""
+    _fields_ = [("n", c_i64)] + [(f, c_vp) for f in ("x", "y", "nominal_flux", "hlr", "q", "pa", "g1", "g2", "mu", "kind",
+                                                      "prof_table", "sed_table", "stamp_size", "obj_id", "phot_flux")] + [
+        ("seed", c_u64), ("sed_table_all", c_i32), ("n_star_size", c_i32), ("n_gal_radius", c_i32), ("nmax", c_i32),
+        ("noise_var", c_d), ("max_flux_simple", c_d), ("tiny_flux", c_d), ("pixel_scale", c_d), ("dg_stepk", c_d),
+        ("star_size", c_vp), ("gal_radius", c_vp), ("zenith", c_d * 3), ("has_field", c_i32), ("pad", c_i32)]
+
+
+class ObjectMeta(C.Structure):
+    _fields_ = [("n_phot", c_i64), ("size", c_i32), ("flags", c_i32)]
+
+
+META_DTYPE = np.dtype([("n_phot", "<i8"), ("size", "<i4"), ("flags", "<i4")])
+IMS_META_SIZE_PENDING, IMS_META_HOST_ROW = 1, 2
+IMS_FLUX_PIXEL = -7
+
+
 class PlanItem(C.Structure):
     _fields_ = [("kind", c_i32), ("stream", c_i32), ("params", c_vp), ("pool", c_vp), ("aux", c_vp),
                 ("first_slot", c_i32), ("n_slots", c_i32), ("n_tiles", c_i64), ("tag", C.c_uint32), ("pad", C.c_uint32),
@@ -206,7 +224,7 @@ class Readout(C.Structure):
 
 
 STRUCTS = [Object, RadialTables, LinTables, PsfComponent, Op, Surface, TanSip, Optics, BfSlot, Sensor, Photons,
-           RenderParams, PlanItem, Atmosphere, FftObject, FftParams, Readout, Chain]
+           RenderParams, PlanItem, Atmosphere, FftObject, FftParams, Readout, Chain, Catalog, ObjectMeta]
 
 # every symbol include/imsim_hip.h declares
 EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_info", "ims_known_optics_layout", "ims_shoot_accumulate",
@@ -214,6 +232,7 @@ EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_
            "ims_fft_kspace_fill", "ims_fft_finish", "ims_fft_spikes", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
            "ims_sensor_update_distortions", "ims_sensor_update_refresh", "ims_sensor_publish_pairs", "ims_image_add", "ims_image_to_float", "ims_fill_derived_op", "ims_fill_derived_medium", "ims_fill_derived_optics", "ims_fill_derived_atmosphere", "ims_fill_derived_sensor", "ims_sensor_pixel_areas", "ims_flat_add", "ims_last_kernel_ms", "ims_enable_timing",
            "ims_readout_bleed", "ims_readout_segments", "ims_readout_cte", "ims_readout_finish",
+           "ims_build_object_table", "ims_patch_stamp_sizes", "ims_gather_rows",
            "ims_struct_size", "ims_test_math"]
 
 _LIB_PATH = os.environ.get("IMSIM_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libimsim_hip.so")
@@ -274,6 +293,9 @@ def load():
     lib.ims_known_optics_layout.argtypes = [c_u64]
     lib.ims_sensor_update_refresh.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]
     lib.ims_sensor_publish_pairs.argtypes = [c_vp, C.POINTER(Sensor), c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]
+    lib.ims_build_object_table.argtypes = [C.POINTER(Catalog), c_vp, c_vp, c_vp, c_vp]
+    lib.ims_patch_stamp_sizes.argtypes = [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]
+    lib.ims_gather_rows.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]
     lib.ims_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.ims_device_info.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(c_i64), C.POINTER(c_i64)]
     lib.ims_readout_bleed.argtypes = [c_vp, c_vp, c_i32, c_i32, c_d, c_i32, c_vp]

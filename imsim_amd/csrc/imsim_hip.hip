@@ -1645,6 +1645,183 @@ __global__ __launch_bounds__(256) void k_readout_finish(const float* __restrict_
     out[p] = (int32_t)v;
 }
 
+// ---------------- object table on the device (include/imsim_hip.h: ims_build_object_table) ----------------
+// One thread per catalog source.  The arithmetic is restated in oracle/orc_catalog.c; the formulas are those of
+// imsim_amd/catalog.py (the numpy builder, which stays the portable host path).
+__device__ __forceinline__ int good_image_size(double stepk, double pixel_scale)
+{
+    // GSObject.getGoodImageSize: N = ceil(2 pi / (stepk * scale)) rounded up to even
+    const double nn = ceil(ddiv(TWO_PI, stepk * pixel_scale));
+    const long long n = (long long)nn;
+    return (int)(2 * ((n + 1) / 2));
+}
+
+__global__ __launch_bounds__(256) void k_build_object_table(const ims_catalog_t C, const ims_optics_t* __restrict__ optics,
+                                                            ims_object_t* __restrict__ rows, ims_object_meta_t* __restrict__ meta)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= C.n) return;
+    ims_object_t o;
+    memset(&o, 0, sizeof(o));
+    ims_object_meta_t m = { 0, 0, 0 };
+    const int kind = C.kind[i];
+    if (kind < 0 || kind > 2) {                       // knots, streaks, FITS stamps: the host writes these rows
+        m.flags = IMS_META_HOST_ROW;
+        rows[i] = o; meta[i] = m;
+        return;
+    }
+    const double nominal = C.nominal_flux[i];
+    const int64_t id = C.obj_id ? C.obj_id[i] : i;
+    const int64_t phot = C.phot_flux ? C.phot_flux[i] : (int64_t)poisson(nominal, C.seed, id, (int64_t)IMS_FLUX_PIXEL);
+    const double x = C.x[i], y = C.y[i];
+    o.obj_id = id; o.phot_first = 0; o.n_phot = phot;
+    o.x0 = x; o.y0 = y; o.flux_per_photon = 1.0;
+    // profile and its affine
+    double j0 = 1.0, j1 = 0.0, j2 = 0.0, j3 = 1.0;
+    if (kind == 0) {
+        o.prof_table = IMS_PROF_POINT; o.prof_scale = 0.0;
+    } else {
+        o.prof_table = C.prof_table[i]; o.prof_scale = C.hlr[i];
+        const double q = C.q[i];
+        const double g = ddiv(1.0 - q, 1.0 + q);
+        double s2, c2;
+        dsincos(2.0 * ((90.0 - C.pa[i]) * 0.017453292519943295), s2, c2);         // beta = 90 deg - pa (flip_g2, instcat.py:503-508)
+        const double f = ddiv(1.0, dsqrt0(1.0 - g * g));
+        const double sg1 = g * c2, sg2 = g * s2;
+        j0 = f * (1.0 + sg1); j1 = f * sg2; j2 = f * sg2; j3 = f * (1.0 - sg1);
+        if (C.g1 != nullptr) {
+            const double l1 = C.g1[i], l2 = C.g2[i];
+            const double lg2 = l1 * l1 + l2 * l2;
+            const double lf = ddiv(dsqrt0(C.mu[i]), dsqrt0(1.0 - lg2));
+            const double a0 = lf * (1.0 + l1), a1 = lf * l2, a2 = lf * l2, a3 = lf * (1.0 - l1);
+            const double b0 = j0, b1 = j1, b2 = j2, b3 = j3;
+            j0 = a0 * b0 + a1 * b2; j1 = a0 * b1 + a1 * b3; j2 = a2 * b0 + a3 * b2; j3 = a2 * b1 + a3 * b3;
+        }
+    }
+    o.jac[0] = j0; o.jac[1] = j1; o.jac[2] = j2; o.jac[3] = j3;
+    // local WCS: analytic jacobian of pixel -> (u west, v north) [arcsec] at image_pos, inverted
+    const ims_tansip_t& w = optics->img_wcs;
+    double p[3];
+    {
+        double u = x - w.crpix[0], v = y - w.crpix[1];
+        double fu = 0.0, fv = 0.0, gu = 0.0, gv = 0.0;
+        if (w.order > 0) {
+            double f, g;
+            sip_value_grad(w.a, u, v, f, fu, fv);
+            sip_value_grad(w.b, u, v, g, gu, gv);
+            u = u + f; v = v + g;
+        }
+        const double Ux = 1.0 + fu, Uy = fv, Vx = gu, Vy = 1.0 + gv;
+        const double xi = w.cd[0] * u + w.cd[1] * v, eta = w.cd[2] * u + w.cd[3] * v;
+        const double xi_x = w.cd[0] * Ux + w.cd[1] * Vx, xi_y = w.cd[0] * Uy + w.cd[1] * Vy;
+        const double et_x = w.cd[2] * Ux + w.cd[3] * Vx, et_y = w.cd[2] * Uy + w.cd[3] * Vy;
+        double px[3], py[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            p[k] = w.rot[k] + w.rot[3 + k] * xi + w.rot[6 + k] * eta;
+            px[k] = w.rot[3 + k] * xi_x + w.rot[6 + k] * et_x;
+            py[k] = w.rot[3 + k] * xi_y + w.rot[6 + k] * et_y;
+        }
+        const double inv = ddiv(1.0, dsqrt0(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]));
+        p[0] = p[0] * inv; p[1] = p[1] * inv; p[2] = p[2] * inv;                   // unit vector of the object
+        const double cd = dsqrt0(p[0] * p[0] + p[1] * p[1]), icd = ddiv(1.0, cd);
+        const double e0 = -p[1] * icd, e1 = p[0] * icd;                             // east = pole x p, normalised
+        const double n0 = -p[2] * e1, n1 = p[2] * e0, n2 = p[0] * e1 - p[1] * e0;   // north = p x east
+        const double k = 206264.80624709636 * inv;                                  // arcsec per radian over |P|
+        const double dudx = -(px[0] * e0 + px[1] * e1) * k, dudy = -(py[0] * e0 + py[1] * e1) * k;
+        const double dvdx = (px[0] * n0 + px[1] * n1 + px[2] * n2) * k, dvdy = (py[0] * n0 + py[1] * n1 + py[2] * n2) * k;
+        const double idet = ddiv(1.0, dudx * dvdy - dudy * dvdx);
+        o.winv[0] = dvdy * idet; o.winv[1] = -dudy * idet; o.winv[2] = -dvdx * idet; o.winv[3] = dudx * idet;
+        // PhotonDCR: zenith distance and parallactic angle of this object, from the zenith's components along east / north
+        const double cz = p[0] * C.zenith[0] + p[1] * C.zenith[1] + p[2] * C.zenith[2];
+        const double ez = e0 * C.zenith[0] + e1 * C.zenith[1];
+        const double nz = n0 * C.zenith[0] + n1 * C.zenith[1] + n2 * C.zenith[2];
+        const double hz = dsqrt0(ez * ez + nz * nz);
+        o.dcr_tanz = ddiv(hz, cz);
+        o.dcr_sinp = hz > 0.0 ? ddiv(ez, hz) : 0.0;
+        o.dcr_cosp = hz > 0.0 ? ddiv(nz, hz) : 1.0;
+        if (C.has_field) {
+            double thx, thy;
+            wcs_vec_to_pix(optics->icrf_to_field, p, thx, thy);
+            o.atm_tan_x = thx; o.atm_tan_y = thy;
+        }
+    }
+    o.sed_table = C.sed_table ? C.sed_table[i] : C.sed_table_all;
+    o.sed_wave = 0.0;
+    o.flags = nominal < C.max_flux_simple ? IMS_OBJ_FAINT : 0;
+    o.bf_state = 0;
+    // stamp size (stamp.py:205-232)
+    int size = C.stamp_size ? C.stamp_size[i] : 0;
+    if (size <= 0) {
+        if (nominal < C.tiny_flux) size = 32;
+        else if (kind == 0) {
+            const double ft = ddiv(C.noise_var, nominal);
+            int k = 0;                                                   // index 0: the default folding threshold
+            if (ft < 5.0e-3 && ft != 0.0) k = (int)(-floor(dlog(ft)));
+            if (k >= C.n_star_size) k = C.n_star_size - 1;
+            size = C.star_size[k];
+        } else {
+            const double s1 = j0 * j0 + j1 * j1 + j2 * j2 + j3 * j3;
+            const double dd = j0 * j0 + j1 * j1 - j2 * j2 - j3 * j3, od = j0 * j2 + j1 * j3;
+            const double s2 = dsqrt0(fmax(dd * dd + 4.0 * od * od, 0.0));
+            const double smax = dsqrt0(0.5 * (s1 + s2));
+            int t = o.prof_table;
+            if (t < 0) t = 0;
+            if (t >= C.n_gal_radius) t = C.n_gal_radius - 1;
+            const double rr = C.gal_radius[t] * C.hlr[i] * smax;
+            constexpr double PI_ = 3.14159265358979323846;
+            const double stepk = ddiv(1.0, dsqrt0(ddiv(rr * rr, PI_ * PI_) + ddiv(1.0, C.dg_stepk * C.dg_stepk)));
+            size = good_image_size(stepk, C.pixel_scale);
+            if (nominal > 10.0 * (double)size * (double)size || size > C.nmax) m.flags |= IMS_META_SIZE_PENDING;
+            if (size > C.nmax) size = C.nmax;
+        }
+    }
+    const long long icx = (long long)floor(x + 0.5), icy = (long long)floor(y + 0.5);
+    o.stamp_xmin = (int)(icx - size / 2); o.stamp_xmax = (int)(icx - size / 2 + size - 1);
+    o.stamp_ymin = (int)(icy - size / 2); o.stamp_ymax = (int)(icy - size / 2 + size - 1);
+    m.n_phot = phot; m.size = size;
+    rows[i] = o; meta[i] = m;
+}
+
+__global__ __launch_bounds__(256) void k_patch_stamp_sizes(ims_object_t* __restrict__ rows, ims_object_meta_t* __restrict__ meta,
+                                                           const int64_t* __restrict__ index, const int32_t* __restrict__ size, int64_t n)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    ims_object_t& o = rows[index[k]];
+    const int sz = size[k];
+    const long long icx = (long long)floor(o.x0 + 0.5), icy = (long long)floor(o.y0 + 0.5);
+    o.stamp_xmin = (int)(icx - sz / 2); o.stamp_xmax = (int)(icx - sz / 2 + sz - 1);
+    o.stamp_ymin = (int)(icy - sz / 2); o.stamp_ymax = (int)(icy - sz / 2 + sz - 1);
+    meta[index[k]].size = sz;
+    meta[index[k]].flags &= ~IMS_META_SIZE_PENDING;
+}
+
+// dst[k] = rows[index[k]] with the launch's photon range and boundary slot: 256-byte rows move as 16 uint4 per row, one row per
+// 16 lanes
+__global__ __launch_bounds__(256) void k_gather_rows(const ims_object_t* __restrict__ rows, const int64_t* __restrict__ index,
+                                                     const int64_t* __restrict__ first, const int64_t* __restrict__ count,
+                                                     const int32_t* __restrict__ bf_state, ims_object_t* __restrict__ dst, int64_t n)
+{
+    static_assert(sizeof(ims_object_t) == 256, "row size");
+    static_assert(offsetof(ims_object_t, phot_first) == 8 && offsetof(ims_object_t, n_phot) == 16 &&
+                  offsetof(ims_object_t, bf_state) == 172, "row layout");
+    const int64_t k = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int part = threadIdx.x & 15;
+    if (k >= n) return;
+    uint4 v = ((const uint4*)(rows + index[k]))[part];
+    if (part == 0 && first != nullptr) {                       // bytes 8 .. 15: phot_first
+        const long long pf = (long long)(((unsigned long long)v.w << 32) | v.z) + (long long)first[k];
+        v.z = (unsigned)(unsigned long long)pf; v.w = (unsigned)((unsigned long long)pf >> 32);
+    }
+    if (part == 1 && count != nullptr) {                       // bytes 16 .. 23: n_phot
+        const unsigned long long c = (unsigned long long)count[k];
+        v.x = (unsigned)c; v.y = (unsigned)(c >> 32);
+    }
+    if (part == 10) v.w = bf_state ? (unsigned)bf_state[k] : 0u;   // bytes 172 .. 175: bf_state
+    ((uint4*)(dst + k))[part] = v;
+}
+
 // device math probe for the parity tests (which: 0 log,1 exp,2 sincos2pi,3 atan,4 sincos,5 tanh,6 gauss,7 dsqrt_n,8 ddiv of pairs,9 dsqrt0)
 __global__ void k_test_math(int which, const double* __restrict__ in, double* __restrict__ out, int64_t n,
                             uint64_t seed, int64_t obj, uint32_t slot)
@@ -2453,6 +2630,47 @@ int ims_readout_finish(const float* seg_dev, const ims_readout_t* ro, uint64_t s
     return IMS_OK;
 }
 
+int ims_build_object_table(const ims_catalog_t* cat, const ims_optics_t* optics_dev, ims_object_t* rows_dev,
+                           ims_object_meta_t* meta_dev, void* stream)
+{
+    if (!cat || !optics_dev || !rows_dev || !meta_dev) return set_err(IMS_ERR_ARG, "NULL argument");
+    if (cat->n < 0) return set_err(IMS_ERR_ARG, "negative catalog length");
+    if (cat->n == 0) return IMS_OK;
+    if (!cat->x || !cat->y || !cat->nominal_flux || !cat->kind || !cat->hlr || !cat->q || !cat->pa || !cat->prof_table)
+        return set_err(IMS_ERR_ARG, "catalog column is NULL");
+    if ((cat->g1 != nullptr) != (cat->g2 != nullptr) || (cat->g1 != nullptr) != (cat->mu != nullptr))
+        return set_err(IMS_ERR_ARG, "g1, g2 and mu come together");
+    if (!cat->star_size || cat->n_star_size <= 0 || !cat->gal_radius || cat->n_gal_radius <= 0)
+        return set_err(IMS_ERR_ARG, "star_size / gal_radius table missing");
+    if (!(cat->pixel_scale > 0.0) || !(cat->dg_stepk > 0.0) || cat->nmax <= 0) return set_err(IMS_ERR_ARG, "pixel_scale / dg_stepk / nmax");
+    hipLaunchKernelGGL(k_build_object_table, dim3((unsigned)((cat->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *cat, optics_dev,
+                       rows_dev, meta_dev);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+int ims_patch_stamp_sizes(ims_object_t* rows_dev, ims_object_meta_t* meta_dev, const int64_t* index_dev, const int32_t* size_dev,
+                          int64_t n, void* stream)
+{
+    if (n <= 0) return IMS_OK;
+    if (!rows_dev || !meta_dev || !index_dev || !size_dev) return set_err(IMS_ERR_ARG, "NULL argument");
+    hipLaunchKernelGGL(k_patch_stamp_sizes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows_dev, meta_dev, index_dev,
+                       size_dev, n);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+int ims_gather_rows(const ims_object_t* rows_dev, const int64_t* index_dev, const int64_t* first_dev, const int64_t* count_dev,
+                    const int32_t* bf_state_dev, ims_object_t* dst_dev, int64_t n, void* stream)
+{
+    if (n <= 0) return IMS_OK;
+    if (!rows_dev || !index_dev || !dst_dev) return set_err(IMS_ERR_ARG, "NULL argument");
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows_dev, index_dev, first_dev,
+                       count_dev, bf_state_dev, dst_dev, n);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
 int ims_struct_size(int which)
 {
     switch (which) {
@@ -2474,6 +2692,8 @@ int ims_struct_size(int which)
     case 15: return (int)sizeof(ims_fft_params_t);
     case 16: return (int)sizeof(ims_readout_t);
     case 17: return (int)sizeof(ims_chain_t);
+    case 18: return (int)sizeof(ims_catalog_t);
+    case 19: return (int)sizeof(ims_object_meta_t);
     }
     return -1;
 }

@@ -208,6 +208,23 @@ class DeviceMem:
             handle[:raw.size].copy_(src, non_blocking=True)
 
 
+# What the launch planner reads of an object, for tables whose 256-byte rows live on the device (device_table.DeviceTable):
+# `row` is the index into the master table, the other fields carry the names they have in OBJECT_DTYPE.
+SLIM_DTYPE = np.dtype([("row", "<i8"), ("phot_first", "<i8"), ("n_phot", "<i8"), ("flags", "<i4"), ("stamp_xmin", "<i4"),
+                       ("stamp_xmax", "<i4"), ("stamp_ymin", "<i4"), ("stamp_ymax", "<i4"), ("bf_state", "<i4")])
+
+
+def slim_view(table, select=None):
+    """SLIM_DTYPE rows of a DeviceTable (all objects with photons, or the given indices)"""
+    idx = np.flatnonzero(table.n_phot > 0) if select is None else np.asarray(select, dtype=np.int64)
+    out = np.zeros(len(idx), dtype=SLIM_DTYPE)
+    out["row"], out["n_phot"] = idx, table.n_phot[idx]
+    out["flags"] = np.where(table.faint[idx], _abi.IMS_OBJ_FAINT, 0)
+    st = table.stamp[idx]
+    out["stamp_xmin"], out["stamp_xmax"], out["stamp_ymin"], out["stamp_ymax"] = st[:, 0], st[:, 1], st[:, 2], st[:, 3]
+    return out
+
+
 def segment_prefix(n_phot, seg_size):
     segs = (np.asarray(n_phot, dtype=np.int64) + seg_size - 1) // seg_size
     return np.concatenate([[0], np.cumsum(segs)]).astype(np.int64)
@@ -651,29 +668,52 @@ class Renderer:
         updatePixelDistortions between rounds (chain stream, high priority).  All object tables of
         the plan are uploaded here, so executing the plan touches no host data."""
         ss = self.scene.sensor
-        objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
+        # device_table.DeviceTable: the 256-byte rows stay on the device; the planner works on 40-byte views of them and every
+        # launch table is gathered from the master table by ims_gather_rows (index, photon range, boundary slot)
+        master = objects if hasattr(objects, "rows") and hasattr(objects, "n_phot") and not isinstance(objects, np.ndarray) else None
+        if master is not None:
+            objects = slim_view(master)
+        else:
+            objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
         plan = PlanList()
         arena = plan.arena = _Arena()
         realized_parts, realized_refs = [], []
+        gathers = []
 
         def finish():
             """ONE upload for every table of the plan (f-1: was ~1 000 separate copies), then the addresses"""
             t = arena.upload(self.mem)
             for off, n, tmp in realized_refs:
                 realized_parts.append((t[off:off + 8 * n].view(self.torch.int64), tmp))
+            base = arena.base
+            for dst, o_idx, o_first, o_count, o_bf, n in gathers:
+                _abi.check(self.lib.ims_gather_rows(master.rows.data_ptr(), base + o_idx, base + o_first, base + o_count, base + o_bf,
+                                                    dst.data_ptr(), n, self._stream()), "ims_gather_rows")
+            plan.keep_rows = [g[0] for g in gathers] + ([master] if master is not None else [])
             return plan, realized_parts
 
         def upload(part, index, kind, extra=None):
-            part = np.ascontiguousarray(part, dtype=OBJECT_DTYPE)
+            if master is None:
+                part = np.ascontiguousarray(part, dtype=OBJECT_DTYPE)
             prefix = segment_prefix(part["n_phot"], self.scene.seg_size)
             seg_obj = np.repeat(np.arange(len(part), dtype=np.int32), np.diff(prefix))
             tmp = None
             if want_realized and kind != "shoot_pool":
                 tmp = self.torch.zeros(len(part), dtype=self.torch.float64, device=self.device)
-                realized_refs.append((arena.add(np.asarray(index, dtype=np.int64)), len(part), tmp))
+                where = np.asarray(index, dtype=np.int64)
+                if master is not None:
+                    where = objects["row"][where]                  # realized fluxes are indexed like the master table
+                realized_refs.append((arena.add(where), len(part), tmp))
             P = self.bound.params(None, len(part), None, int(prefix[-1]),
                                   self.image.data_ptr(), tmp.data_ptr() if tmp is not None else None, None)
-            arena.patch(P, "objects", arena.add(part))
+            if master is not None:
+                dst = self.torch.empty(max(len(part), 1) * OBJECT_DTYPE.itemsize, dtype=self.torch.uint8, device=self.device)
+                gathers.append((dst, arena.add(np.ascontiguousarray(part["row"])), arena.add(np.ascontiguousarray(part["phot_first"])),
+                                arena.add(np.ascontiguousarray(part["n_phot"])), arena.add(np.ascontiguousarray(part["bf_state"])),
+                                len(part)))
+                P.objects = dst.data_ptr()
+            else:
+                arena.patch(P, "objects", arena.add(part))
             arena.patch(P, "seg_prefix", arena.add(prefix))
             if len(seg_obj):
                 arena.patch(P, "seg_object", arena.add(seg_obj))

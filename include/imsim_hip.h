@@ -40,7 +40,7 @@ extern "C" {
 #define IMS_ERR_NO_DEVICE  -3
 #define IMS_ERR_UNSUPPORTED -4
 
-#define IMS_ABI_VERSION 13
+#define IMS_ABI_VERSION 14
 
 /* Pointers stored INSIDE descriptors that live in device memory (ims_sensor_t, ims_atmosphere_t) always point to global
  * device memory.  Device code is told so (address space 1): a pointer read out of memory is otherwise a generic pointer and
@@ -504,6 +504,71 @@ int  ims_fft_spikes(const ims_fft_params_t* params, const ims_fft_object_t* obje
 /* pix_prefix[n_objects+1] (device): prefix sum of nfft*nfft; rbuf: the inverse-transformed images */
 int  ims_fft_finish(const ims_fft_params_t* params, const ims_fft_object_t* objects_dev, int64_t n_objects,
                     const int64_t* pix_prefix_dev, int64_t n_pix, const double* rbuf, void* stream);
+
+/* ---- object table on the device: LSST_SiliconBuilder.setup for a whole catalog in one launch ----
+ * imsim/stamp.py:109-249 run per object: Poisson realisation of the flux (:190), skip / tiny-flux / stamp-size decisions
+ * (:199-232, imsim/stamp_utils.py:79-155 for stars, :158-189 for galaxies), faint classification (:435-436); the profile
+ * affine of a Sersic (imsim/instcat.py:498-527), the local WCS jacobian at image_pos (wcs.local), the zenith and
+ * parallactic angle of PhotonDCR, the field angle of the atmospheric PSF (imsim/atmPSF.py:304).  One thread per catalog
+ * source writes one ims_object_t row (phot_first 0, bf_state 0, flux_per_photon 1) and one ims_object_meta_t.
+ * Everything is sqrt / division / fma arithmetic plus the spec's log, exp and sincos, so the oracle's
+ * restatement (oracle/orc_catalog.c) gives the same bits:
+ *   flux      phot_flux[i] when given, else the Poisson deviate of ims_fft_finish's generator keyed (seed, obj_id,
+ *             pixel IMS_FLUX_PIXEL);
+ *   affine    kind 0: identity; else Shear(q, beta = 90 deg - pa) [then Lens(g1, g2, mu)] (area preserving forms);
+ *   local WCS the ANALYTIC jacobian of img_wcs at (x, y) in GalSim's (u west, v north) [arcsec], inverted -> winv;
+ *   DCR       with Z the unit vector of the zenith and p the object's: cos z = p.Z, and (sin q, cos q) the normalised
+ *             components of Z along local east and north -- trig-free;
+ *   size      stamp_size[i] > 0 when given; nominal flux < tiny_flux: 32; stars: star_size[min(-floor(ln(noise_var /
+ *             flux)), n_star_size - 1)] (the folding threshold rounded down to e-folds; index 0 = the default threshold);
+ *             galaxies: GoodImageSize of the profile convolved with the proxy PSF, 1 / stepk^2 = (r hlr s)^2 / pi^2 +
+ *             1 / dg_stepk^2 with r = gal_radius[prof_table] and s the largest singular value of the affine.  A galaxy
+ *             with more than 10 photons per stamp pixel, or a stamp beyond nmax, needs the surface-brightness loop of
+ *             get_good_phot_stamp_size (the bright few: host, ims_patch_stamp_sizes): meta.flags gets IMS_META_SIZE_PENDING.
+ * Kinds other than 0, 1, 2 (knots, streaks, FITS stamps) are left to the host: their rows are zeroed and flagged
+ * IMS_META_HOST_ROW. */
+#define IMS_FLUX_PIXEL        (-7)
+#define IMS_META_SIZE_PENDING 1
+#define IMS_META_HOST_ROW     2
+typedef struct ims_catalog {
+    int64_t n;
+    const double* x;              /* device arrays [n] */
+    const double* y;
+    const double* nominal_flux;
+    const double* hlr;            /* arcsec */
+    const double* q;              /* axis ratio */
+    const double* pa;             /* position angle [deg] */
+    const double* g1;             /* lensing: reduced shear and magnification; all three NULL = none */
+    const double* g2;
+    const double* mu;
+    const int32_t* kind;          /* 0 point, 1 / 2 Sersic */
+    const int32_t* prof_table;    /* radial table of a Sersic row (ignored for points) */
+    const int32_t* sed_table;     /* NULL: sed_table_all */
+    const int32_t* stamp_size;    /* NULL or entries <= 0: computed here */
+    const int64_t* obj_id;        /* NULL: object i has id i */
+    const int64_t* phot_flux;     /* NULL: realised here */
+    uint64_t seed;
+    int32_t sed_table_all, n_star_size, n_gal_radius, nmax;
+    double noise_var, max_flux_simple, tiny_flux, pixel_scale, dg_stepk;
+    const int32_t* star_size;     /* device [n_star_size] */
+    const double* gal_radius;     /* device [n_gal_radius]: radius enclosing 1 - folding_threshold of the flux, in half-light radii */
+    double zenith[3];             /* unit vector of the zenith in the frame of img_wcs (ICRS at the visit) */
+    int32_t has_field, pad;       /* != 0: atm_tan_x / atm_tan_y from icrf_to_field */
+} ims_catalog_t;
+typedef struct ims_object_meta {
+    int64_t n_phot;
+    int32_t size, flags;
+} ims_object_meta_t;
+/* rows_dev[n], meta_dev[n]: device outputs.  optics_dev: device ims_optics_t (img_wcs, icrf_to_field). */
+int  ims_build_object_table(const ims_catalog_t* cat, const ims_optics_t* optics_dev, ims_object_t* rows_dev,
+                            ims_object_meta_t* meta_dev, void* stream);
+/* stamp sizes decided on the host for the rows index[k] (device arrays): bounds re-centred as in the builder */
+int  ims_patch_stamp_sizes(ims_object_t* rows_dev, ims_object_meta_t* meta_dev, const int64_t* index_dev, const int32_t* size_dev,
+                           int64_t n, void* stream);
+/* Launch tables of a plan from the device-resident master table: dst[k] = rows[index[k]] with phot_first += first[k] (NULL: 0),
+ * n_phot = count[k] (NULL: unchanged) and bf_state = bf_state[k] (NULL: 0). */
+int  ims_gather_rows(const ims_object_t* rows_dev, const int64_t* index_dev, const int64_t* first_dev, const int64_t* count_dev,
+                     const int32_t* bf_state_dev, ims_object_t* dst_dev, int64_t n, void* stream);
 
 /* ---- launch plans ----
  * The brighter-fatter chain of LSST_Image mode is hundreds of short dependent launches; ims_run_plan

@@ -55,6 +55,7 @@ def load():
         lib.orc_readout_segments.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(_abi.Readout), C.c_void_p, C.c_void_p]
         lib.orc_readout_cte.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_abi.Readout), C.c_void_p, C.c_int32, C.c_int32]
         lib.orc_readout_finish.argtypes = [C.c_void_p, C.POINTER(_abi.Readout), C.c_uint64, C.c_void_p]
+        lib.orc_build_object_table.argtypes = [C.POINTER(_abi.Catalog), C.c_void_p, C.c_void_p, C.c_void_p]
         lib.orc_fill_derived_op.argtypes = [C.c_void_p]
         lib.orc_fill_derived_medium.argtypes = [C.c_int32, C.POINTER(C.c_double)]
         _lib = lib
@@ -368,3 +369,24 @@ def readout_chain(eimage, ro, full_well, midline_stop, dark_level, dark_stream, 
     out = np.zeros(shape, dtype=np.int32)
     lib.orc_readout_finish(a.ctypes.data, C.byref(ro), int(seed), out.ctypes.data)
     return out
+
+
+def build_object_table(scene, cat, visit, phot_flux=None, **kw):
+    """CPU restatement of ims_build_object_table (oracle/orc_catalog.c): (rows, meta) for a catalog dict."""
+    from imsim_amd import device_table
+    lib = load()
+    keep = []
+
+    def ptr_of(name, a, dt):
+        a = np.ascontiguousarray(a, dtype=dt)
+        keep.append(a)
+        return a.ctypes.data
+    sersic_index = getattr(scene, "sersic_index", None)
+    cols = device_table.catalog_columns(cat, phot_flux, sersic_index, kw.pop("stamp_size", None))
+    st = device_table.fill_catalog_struct(cols, ptr_of, scene.seed, visit, sersic_index=sersic_index, **kw)
+    n = len(cat["x"])
+    rows = np.zeros(n, dtype=OBJECT_DTYPE)
+    meta = np.zeros(n, dtype=_abi.META_DTYPE)
+    optics = scene.optics
+    assert lib.orc_build_object_table(C.byref(st), C.addressof(optics), rows.ctypes.data, meta.ctypes.data) == 0
+    return rows, meta

@@ -118,6 +118,8 @@ int orc_struct_size(int which)
     case 15: return (int)sizeof(ims_fft_params_t);
     case 16: return (int)sizeof(ims_readout_t);
     case 17: return (int)sizeof(ims_chain_t);
+    case 18: return (int)sizeof(ims_catalog_t);
+    case 19: return (int)sizeof(ims_object_meta_t);
     }
     return -1;
 }

@@ -1,0 +1,114 @@
+"""The object table built on the device (ims_build_object_table).
+
+CPU: the oracle's restatement (oracle/orc_catalog.c) against the numpy builder, which carries the reference's stamp-size
+regression values (tests/test_stamp_size.py): identical integers (photon counts, tables, flags, stamp bounds), floats to
+rounding, the local WCS to the 2e-9 by which the analytic jacobian differs from the central difference it replaces.
+GPU: the device table equals the oracle's bit for bit, with the fluxes given and with the Poisson realisation done by the
+kernel; launch tables gathered from it render the image of the same rows planned on the host."""
+import numpy as np
+import pytest
+
+from imsim_amd import configs, catalog, _abi
+from oracle import orc_loader
+
+VISIT = dict(configs.VISIT)
+
+
+def _case(n=6000, lens=False, seed=20261001):
+    scene = configs.BENCH_CONFIGS["c3"]["scene"]()
+    cat = catalog.synthetic_catalog(n, seed=seed, nx=scene.nx, ny=scene.ny)
+    if lens:
+        rng = np.random.default_rng(5)
+        cat["g1"], cat["g2"] = rng.normal(0, 0.03, n), rng.normal(0, 0.03, n)
+        cat["mu"] = 1.0 + rng.normal(0, 0.05, n)
+    phot = catalog.realize_fluxes(cat["nominal_flux"], scene.seed)
+    return scene, cat, phot
+
+
+@pytest.mark.parametrize("lens", [False, True])
+def test_oracle_table_matches_the_numpy_builder(lens):
+    scene, cat, phot = _case(lens=lens)
+    rows, meta = orc_loader.build_object_table(scene, cat, VISIT, phot)
+    ref, sizes = configs.c3_objects(cat, phot, scene)
+    keep = phot > 0
+    r, m = rows[keep], meta[keep]
+    for f in ("obj_id", "n_phot", "phot_first", "prof_table", "sed_table", "flags", "bf_state"):
+        assert np.array_equal(r[f], ref[f]), f
+    for f in ("x0", "y0", "prof_scale", "flux_per_photon"):
+        assert np.array_equal(r[f], ref[f]), f
+    for f, tol in (("jac", 1e-14), ("dcr_tanz", 1e-13), ("dcr_sinp", 1e-13), ("dcr_cosp", 1e-13), ("winv", 5e-9)):
+        assert np.abs(r[f] - ref[f]).max() <= tol * max(np.abs(ref[f]).max(), 1.0), f
+    pend = (m["flags"] & _abi.IMS_META_SIZE_PENDING) != 0
+    assert 0 < pend.sum() < 0.05 * len(r)                      # the bright few are left to the host's surface-brightness loop
+    assert np.array_equal(m["size"][~pend], sizes[~pend])
+    for f in ("stamp_xmin", "stamp_xmax", "stamp_ymin", "stamp_ymax"):
+        assert np.array_equal(r[f][~pend], ref[f][~pend]), f
+    # the field angle of the atmospheric PSF
+    thx, thy = configs.field_angles(scene, cat["x"][keep], cat["y"][keep])
+    assert np.abs(r["atm_tan_x"] - thx).max() < 1e-12 and np.abs(r["atm_tan_y"] - thy).max() < 1e-12
+    # and the host fix-ups close the gap
+    from imsim_amd import device_table
+    idx, sz, host = device_table.host_fixups(cat, meta, {})
+    assert len(host) == 0
+    full = meta["size"].copy()
+    full[idx] = sz
+    assert np.array_equal(full[keep], sizes)
+
+
+def test_oracle_flux_realisation_is_poisson():
+    scene, cat, _ = _case(n=20000)
+    rows, meta = orc_loader.build_object_table(scene, cat, VISIT, None)
+    mean = cat["nominal_flux"]
+    z = (meta["n_phot"] - mean) / np.sqrt(mean)
+    assert abs(z.mean()) < 0.03 and abs(z.std() - 1.0) < 0.03
+    assert np.array_equal(meta["n_phot"], rows["n_phot"])
+    again, _ = orc_loader.build_object_table(scene, cat, VISIT, None)
+    assert np.array_equal(again["n_phot"], rows["n_phot"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("given", [True, False])
+def test_device_table_is_bit_identical_to_the_oracle(given):
+    import torch
+    from imsim_amd.engine import Renderer
+    from imsim_amd.device_table import DeviceTable
+    scene, cat, phot = _case(n=20000, lens=True)
+    r = Renderer(scene)
+    t = DeviceTable(r, cat, VISIT, phot_flux=phot if given else None)
+    torch.cuda.synchronize()
+    rows, meta = orc_loader.build_object_table(scene, cat, VISIT, phot if given else None)
+    from imsim_amd import device_table
+    idx, sz, _ = device_table.host_fixups(cat, meta, {})
+    want = rows.copy()
+    icx, icy = np.floor(cat["x"][idx] + 0.5).astype(np.int64), np.floor(cat["y"][idx] + 0.5).astype(np.int64)
+    want["stamp_xmin"][idx], want["stamp_xmax"][idx] = icx - sz // 2, icx - sz // 2 + sz - 1
+    want["stamp_ymin"][idx], want["stamp_ymax"][idx] = icy - sz // 2, icy - sz // 2 + sz - 1
+    got = t.rows_numpy()
+    assert got.tobytes() == want.tobytes()
+    assert np.array_equal(t.n_phot, rows["n_phot"])
+
+
+@pytest.mark.gpu
+def test_plan_from_the_device_table_renders_the_host_planned_image():
+    import torch
+    from imsim_amd.engine import Renderer
+    from imsim_amd.device_table import DeviceTable
+    scene, cat, phot = _case(n=3000, seed=7)
+    r = Renderer(scene)
+    t = DeviceTable(r, cat, VISIT, phot_flux=phot)
+    real = torch.zeros(t.n, dtype=torch.float64, device="cuda")
+    r.render_lsst_image(t, nrecalc=2000, realized=real)
+    r.synchronize()
+    img = r.image_numpy()
+    rows = t.rows_numpy()
+    keep = rows["n_phot"] > 0
+    r2 = Renderer(scene)
+    real2 = torch.zeros(int(keep.sum()), dtype=torch.float64, device="cuda")
+    r2.render_lsst_image(rows[keep], nrecalc=2000, realized=real2)
+    r2.synchronize()
+    assert img.sum() > 0
+    assert np.array_equal(img.view(np.uint32), r2.image_numpy().view(np.uint32))
+    assert np.array_equal(real.cpu().numpy()[keep], real2.cpu().numpy())
+    orc = orc_loader.OracleScene(scene)
+    orc.render_lsst_image(rows[keep], nrecalc=2000)
+    assert np.array_equal(img.view(np.uint32), orc.image.view(np.uint32))

@@ -1646,7 +1646,7 @@ __global__ __launch_bounds__(256) void k_readout_finish(const float* __restrict_
 }
 
 // ---------------- object table on the device (include/imsim_hip.h: ims_build_object_table) ----------------
-// One thread per catalog source.  The arithmetic is restated in oracle/orc_catalog.c; the formulas are those of
+// One thread per catalog source.  The test-side CPU restatement repeats this arithmetic; the formulas are those of
 // imsim_amd/catalog.py (the numpy builder, which stays the portable host path).
 __device__ __forceinline__ int good_image_size(double stepk, double pixel_scale)
 {
@@ -2669,6 +2669,116 @@ int ims_gather_rows(const ims_object_t* rows_dev, const int64_t* index_dev, cons
                        count_dev, bf_state_dev, dst_dev, n);
     HIP_TRY(hipGetLastError());
     return IMS_OK;
+}
+
+// ---- instance-catalog tokenizer: plain host code (the catalog reader is per-line Python in the reference) ----
+static bool tok_double(const char* p, int len, double* out)
+{
+    char buf[64];
+    if (len <= 0 || len >= (int)sizeof(buf)) return false;
+    memcpy(buf, p, len);
+    buf[len] = 0;
+    char* end = nullptr;
+    *out = strtod(buf, &end);
+    return end == buf + len;
+}
+static bool tok_is(const char* p, int len, const char* word)
+{
+    const int n = (int)strlen(word);
+    if (len != n) return false;
+    for (int i = 0; i < n; ++i) {
+        char c = p[i];
+        if (c >= 'A' && c <= 'Z') c = (char)(c - 'A' + 'a');
+        if (c != word[i]) return false;
+    }
+    return true;
+}
+static bool tok_ends(const char* p, int len, const char* suffix)
+{
+    const int n = (int)strlen(suffix);
+    return len >= n && memcmp(p + len - n, suffix, n) == 0;
+}
+
+int64_t ims_parse_instcat_objects(const char* text, int64_t n_bytes, int64_t max_objects, double* num, int32_t* kind, int64_t* span)
+{
+    if (!text || !num || !kind || !span || n_bytes < 0 || max_objects < 0) { set_err(IMS_ERR_ARG, "NULL argument"); return -1; }
+    constexpr int MAXT = 32;
+    int64_t n_out = 0, n_line = 0;
+    int64_t pos = 0;
+    while (pos < n_bytes && n_out < max_objects) {
+        int64_t eol = pos;
+        while (eol < n_bytes && text[eol] != '\n') ++eol;
+        const char* ln = text + pos;
+        const int64_t len = eol - pos;
+        pos = eol + 1;
+        if (len < 6 || memcmp(ln, "object", 6) != 0) continue;
+        const int64_t this_line = n_line++;
+        bool has_inf = false;
+        for (int64_t i = 0; i + 5 <= len; ++i)
+            if (ln[i] == ' ' && ln[i + 1] == 'i' && ln[i + 2] == 'n' && ln[i + 3] == 'f' && ln[i + 4] == ' ') { has_inf = true; break; }
+        if (has_inf) continue;
+        const char* tp[MAXT]; int tl[MAXT]; int nt = 0;
+        for (int64_t i = 0; i < len && nt < MAXT;) {
+            while (i < len && (ln[i] == ' ' || ln[i] == '\t' || ln[i] == '\r' || ln[i] == '\v' || ln[i] == '\f')) ++i;
+            if (i >= len) break;
+            const int64_t a = i;
+            while (i < len && !(ln[i] == ' ' || ln[i] == '\t' || ln[i] == '\r' || ln[i] == '\v' || ln[i] == '\f')) ++i;
+            tp[nt] = ln + a; tl[nt] = (int)(i - a); ++nt;
+        }
+        if (nt < 13) return -(this_line + 1);
+        double v[16] = { 0.0 };
+        int k = 5, di = 15;
+        double a = 0.0, b = 0.0, pa = 0.0, nn = 0.0;
+        auto need = [&](int t, double* out) { return t < nt && tok_double(tp[t], tl[t], out); };
+        if (!need(4, &v[2])) return -(this_line + 1);
+        if (tok_is(tp[12], tl[12], "point")) { k = 0; di = 13; }
+        else if (tok_is(tp[12], tl[12], "sersic2d")) {
+            k = 1; di = 17;
+            double raw;
+            if (!need(13, &a) || !need(14, &b) || !need(15, &pa) || !need(16, &raw)) return -(this_line + 1);
+            nn = nearbyint(raw * 20.0) / 20.0;                    // Python's round(): half to even, as nearbyint in the default mode
+        } else if (tok_is(tp[12], tl[12], "knots")) {
+            k = 2; di = 17;
+            if (!need(13, &a) || !need(14, &b) || !need(15, &pa)) return -(this_line + 1);
+            // int(token): a decimal integer literal only
+            if (16 >= nt) return -(this_line + 1);
+            char buf[32];
+            if (tl[16] <= 0 || tl[16] >= (int)sizeof(buf)) return -(this_line + 1);
+            memcpy(buf, tp[16], tl[16]); buf[tl[16]] = 0;
+            char* end = nullptr;
+            const long long iv = strtoll(buf, &end, 10);
+            if (end != buf + tl[16]) return -(this_line + 1);
+            nn = (double)iv;
+        } else if (tok_is(tp[12], tl[12], "streak")) {
+            k = 3; di = 16;
+            if (!need(13, &a) || !need(14, &b) || !need(15, &pa)) return -(this_line + 1);
+        } else if (tok_ends(tp[12], tl[12], ".fits") || tok_ends(tp[12], tl[12], ".fits.gz")) {
+            k = 4;
+            if (!need(13, &a) || !need(14, &pa)) return -(this_line + 1);
+        }
+        const bool valid = v[2] < 50.0 && !((k == 1 || k == 2) && a < b) && !(k == 2 && nn <= 0.0);
+        if (!valid) continue;
+        if (!need(2, &v[0]) || !need(3, &v[1]) || !need(6, &v[3]) || !need(7, &v[4]) || !need(8, &v[5]) || !need(9, &v[6]))
+            return -(this_line + 1);
+        v[7] = a; v[8] = b; v[9] = pa; v[10] = nn;
+        v[11] = 0.0; v[12] = 3.1; v[13] = 0.0; v[14] = 3.1;
+        int d = di;
+        if (d < nt && !tok_is(tp[d], tl[d], "none")) {
+            if (!need(d + 1, &v[11]) || !need(d + 2, &v[12])) return -(this_line + 1);
+            d += 3;
+        } else d += 1;
+        if (d < nt && !tok_is(tp[d], tl[d], "none")) {
+            if (!need(d + 1, &v[13]) || !need(d + 2, &v[14])) return -(this_line + 1);
+        }
+        memcpy(num + n_out * 16, v, sizeof(v));
+        kind[n_out] = k;
+        int64_t* sp = span + n_out * 6;
+        sp[0] = tp[1] - text; sp[1] = tl[1];
+        sp[2] = tp[5] - text; sp[3] = tl[5];
+        sp[4] = tp[12] - text; sp[5] = tl[12];
+        ++n_out;
+    }
+    return n_out;
 }
 
 int ims_struct_size(int which)

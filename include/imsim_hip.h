@@ -570,6 +570,18 @@ int  ims_patch_stamp_sizes(ims_object_t* rows_dev, ims_object_meta_t* meta_dev, 
 int  ims_gather_rows(const ims_object_t* rows_dev, const int64_t* index_dev, const int64_t* first_dev, const int64_t* count_dev,
                      const int32_t* bf_state_dev, ims_object_t* dst_dev, int64_t n, void* stream);
 
+/* ---- instance-catalog tokenizer (host code) ----
+ * The `object` lines of a phosim instance catalog (grammar: imsim/instcat.py:231-297) from a text buffer: lines that do not
+ * start with "object" or contain " inf " are skipped (:233), invalid objects too (magnorm >= 50, sersic2d / knots with
+ * a < b, knots with npoints <= 0; :276-286).  Per kept object: num[16] = ra [deg], dec [deg], magnorm, redshift, gamma1, gamma2,
+ * kappa, a, b, position angle, Sersic index rounded to 0.05 (knots: the number of points), internal Av, Rv, galactic Av, Rv,
+ * 0; kind = 0 point, 1 sersic2d, 2 knots, 3 streak, 4 FITS stamp, 5 unknown type; span[6] = byte offset and length in `text`
+ * of the id, the SED file name and the type token.  Returns the number of objects written (at most max_objects), or -(k + 1)
+ * when object line k (counted from 0 over the lines that start with "object") has too few fields or a field that is not a
+ * number -- the caller's line-by-line reader then raises what the reference raises. */
+int64_t ims_parse_instcat_objects(const char* text, int64_t n_bytes, int64_t max_objects, double* num, int32_t* kind,
+                                  int64_t* span);
+
 /* ---- launch plans ----
  * The brighter-fatter chain of LSST_Image mode is hundreds of short dependent launches; ims_run_plan
  * issues a whole prepared list from C so the host cost per launch is one hipLaunchKernel.

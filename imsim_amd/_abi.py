@@ -34,7 +34,7 @@ class Object(C.Structure):
                 ("dcr_tanz", c_d), ("dcr_sinp", c_d), ("dcr_cosp", c_d),
                 ("prof_table", c_i32), ("sed_table", c_i32), ("flags", c_i32),
                 ("stamp_xmin", c_i32), ("stamp_xmax", c_i32), ("stamp_ymin", c_i32), ("stamp_ymax", c_i32),
-                ("bf_state", c_i32), ("sed_wave", c_d), ("atm_tan_x", c_d), ("atm_tan_y", c_d), ("prof_aux", c_d), ("reserved", c_d * 6)]
+                ("bf_state", c_i32), ("sed_wave", c_d), ("atm_tan_x", c_d), ("atm_tan_y", c_d), ("prof_aux", c_d), ("screen_base", c_i64), ("reserved", c_d * 5)]
 
 
 # numpy view of the same 256-byte row, for vectorised object-table construction
@@ -46,7 +46,7 @@ OBJECT_DTYPE = np.dtype([
     ("prof_table", "<i4"), ("sed_table", "<i4"), ("flags", "<i4"),
     ("stamp_xmin", "<i4"), ("stamp_xmax", "<i4"), ("stamp_ymin", "<i4"), ("stamp_ymax", "<i4"),
     ("bf_state", "<i4"), ("sed_wave", "<f8"), ("atm_tan_x", "<f8"), ("atm_tan_y", "<f8"),
-    ("prof_aux", "<f8"), ("reserved", "<f8", (6,))], align=True)
+    ("prof_aux", "<f8"), ("screen_base", "<i8"), ("reserved", "<f8", (5,))], align=True)
 assert OBJECT_DTYPE.itemsize == 256
 
 
@@ -166,7 +166,7 @@ class RenderParams(C.Structure):
                 ("atm", c_vp), ("optics", c_vp), ("sensor", c_vp), ("image", c_vp),
                 ("nx", c_i32), ("ny", c_i32), ("xmin", c_i32), ("ymin", c_i32), ("realized_flux", c_vp),
                 ("bf_tag", C.c_uint32), ("bf_slot_shift", C.c_uint32), ("seg_object", c_vp), ("images", ImageTables),
-                ("optics_layout", c_u64)]
+                ("optics_layout", c_u64), ("screen_kick", c_vp)]
 
 
 IMS_PLAN_ROUNDS = 9
@@ -232,7 +232,7 @@ EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_
            "ims_fft_kspace_fill", "ims_fft_finish", "ims_fft_spikes", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
            "ims_sensor_update_distortions", "ims_sensor_update_refresh", "ims_sensor_publish_pairs", "ims_image_add", "ims_image_to_float", "ims_fill_derived_op", "ims_fill_derived_medium", "ims_fill_derived_optics", "ims_fill_derived_atmosphere", "ims_fill_derived_sensor", "ims_sensor_pixel_areas", "ims_flat_add", "ims_last_kernel_ms", "ims_enable_timing",
            "ims_readout_bleed", "ims_readout_segments", "ims_readout_cte", "ims_readout_finish",
-           "ims_build_object_table", "ims_patch_stamp_sizes", "ims_gather_rows", "ims_parse_instcat_objects",
+           "ims_build_object_table", "ims_patch_stamp_sizes", "ims_gather_rows", "ims_parse_instcat_objects", "ims_screen_prepass",
            "ims_struct_size", "ims_test_math"]
 
 _LIB_PATH = os.environ.get("IMSIM_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libimsim_hip.so")
@@ -296,6 +296,7 @@ def load():
     lib.ims_build_object_table.argtypes = [C.POINTER(Catalog), c_vp, c_vp, c_vp, c_vp]
     lib.ims_patch_stamp_sizes.argtypes = [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]
     lib.ims_gather_rows.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]
+    lib.ims_screen_prepass.argtypes = [C.POINTER(RenderParams), c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]
     lib.ims_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.ims_device_info.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(c_i64), C.POINTER(c_i64)]
     lib.ims_readout_bleed.argtypes = [c_vp, c_vp, c_i32, c_i32, c_d, c_i32, c_vp]

@@ -126,7 +126,11 @@ IMS_DEV int wrap_index(double fl, double dn, double inv_n)
     return (int)r;
 }
 
+typedef double dvec2q __attribute__((ext_vector_type(2)));
 // sum over layers of the gradient of the bilinear interpolant of the periodic phase screens [nm/m]
+// PLAIN: always the four samples of the screens themselves (the pre-pass of ims_screen_prepass keeps an XCD's windows in its
+// L2, where the four-fold table of 2 x 2 cells would only quadruple the footprint)
+template <bool PLAIN = false>
 IMS_DEV void screen_gradient(const ims_atmosphere_t& A, double pu, double pv, double t, double tanx, double tany,
                              double& gx, double& gy)
 {
@@ -134,7 +138,7 @@ IMS_DEV void screen_gradient(const ims_atmosphere_t& A, double pu, double pv, do
     const int n = A.npix;
     const double dn = A.dn, inv_n = A.inv_n, inv_scale = A.inv_scale;      // ims_fill_derived_atmosphere
     const bool pow2 = (n & (n - 1)) == 0;      // the screens of the reference are 8192 wide: the wrap is a mask
-    const bool quads = A.screen_quads != nullptr;
+    const bool quads = !PLAIN && A.screen_quads != nullptr;
     for (int l = 0; l < A.n_layers; ++l) {
         const double x = pu - t * A.vx[l] + A.alt[l] * tanx;
         const double y = pv - t * A.vy[l] + A.alt[l] * tany;
@@ -156,6 +160,20 @@ IMS_DEV void screen_gradient(const ims_atmosphere_t& A, double pu, double pv, do
             typedef float fvec4 __attribute__((ext_vector_type(4)));
             const fvec4 q = *(const IMS_G fvec4*)(A.screen_quads + (((int64_t)l * n + iy) * n + ix) * 4);
             f00 = (double)q.x; f10 = (double)q.y; f01 = (double)q.z; f11 = (double)q.w;
+        } else if (PLAIN) {
+            // the two samples of a row are neighbours in memory unless the cell straddles the periodic wrap: one 8-byte load per
+            // row (4-byte aligned is all the hardware asks) instead of two 4-byte ones -- half the requests of the pre-pass,
+            // whose gathers hit in L2 and are bound by the number of requests
+            const float* S = A.screens + (int64_t)l * n * n;
+            const uint32_t r0 = (uint32_t)iy * (uint32_t)n, r1 = (uint32_t)iy1 * (uint32_t)n;
+            if (ix1 != 0) {
+                typedef float fvec2 __attribute__((ext_vector_type(2), aligned(4)));
+                const fvec2 a = *(const IMS_G fvec2*)(S + r0 + (uint32_t)ix), b = *(const IMS_G fvec2*)(S + r1 + (uint32_t)ix);
+                f00 = (double)a.x; f10 = (double)a.y; f01 = (double)b.x; f11 = (double)b.y;
+            } else {
+                f00 = (double)S[r0 + (uint32_t)ix]; f10 = (double)S[r0];
+                f01 = (double)S[r1 + (uint32_t)ix]; f11 = (double)S[r1];
+            }
         } else {
             const float* S = A.screens + (int64_t)l * n * n;
             const uint32_t r0 = (uint32_t)iy * (uint32_t)n, r1 = (uint32_t)iy1 * (uint32_t)n;     // a screen has < 2^31 samples
@@ -199,7 +217,12 @@ IMS_DEV void apply_psf(const ims_render_params_t& P, const ims_object_t& o, int 
         rng_block(rng, P.seed, o.obj_id, k, SLOT_PSF_TIME + (uint32_t)comp);
         const double t = A.t0 + w01(rng.w[0]) * A.exptime;
         double gx, gy;
-        screen_gradient(A, pu, pv, t, o.atm_tan_x, o.atm_tan_y, gx, gy);
+        if (P.screen_kick != nullptr) {              // gathered ahead, in cache-friendly order (ims_screen_prepass): the same sums
+            const dvec2q g = *(const IMS_G dvec2q*)(P.screen_kick + 2 * (o.screen_base + k));
+            gx = g.x; gy = g.y;
+        } else {
+            screen_gradient(A, pu, pv, t, o.atm_tan_x, o.atm_tan_y, gx, gy);
+        }
         ku = scale * gx; kv = scale * gy;
         ph.pu = pu; ph.pv = pv; ph.t = t;
     } else {

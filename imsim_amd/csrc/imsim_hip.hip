@@ -1645,6 +1645,128 @@ __global__ __launch_bounds__(256) void k_readout_finish(const float* __restrict_
     out[p] = (int32_t)v;
 }
 
+// ---------------- phase-screen pre-pass (include/imsim_hip.h: ims_screen_prepass) ----------------
+struct ScreenSlices { int64_t first[9]; int64_t seg_first[9]; };     // first object / first segment of every slice
+constexpr int SCR_MAXB = 256;
+constexpr int SCR_CH = 16;            // segments (of 256 photons) one workgroup of the sort kernels works through
+
+// MODE 0: count the photons of every (slice, time bucket); MODE 1: scatter (object, photon index) into slice-major, time-minor
+// order (bins = the exclusive prefix of the counts; the order inside a bin is that of the atomics and does not matter).
+// Block b works on slice b mod 8, on SCR_CH consecutive segments of it: its 4 096 photons are counted in LDS first, so a bin
+// costs ONE global atomic per workgroup (one per 256-photon segment was 75 M atomics on 1 024 counters: 4 ms), and the
+// entries a workgroup adds to a bin are neighbours in memory.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_screen_sort(const ims_render_params_t P, int comp, int n_buckets, const ScreenSlices S,
+                                                     unsigned long long* __restrict__ bins, int64_t* __restrict__ entries)
+{
+    __shared__ unsigned int hist[SCR_MAXB];
+    __shared__ unsigned long long base[SCR_MAXB];
+    const int x = blockIdx.x & 7;
+    const int64_t seg0 = S.seg_first[x] + (int64_t)(blockIdx.x >> 3) * SCR_CH;
+    const int64_t seg_end = S.seg_first[x + 1];
+    if (seg0 >= seg_end) return;
+    if ((int)threadIdx.x < n_buckets) hist[threadIdx.x] = 0u;
+    __syncthreads();
+    unsigned char bucket[SCR_CH];
+    unsigned int valid = 0u;
+#pragma unroll
+    for (int c = 0; c < SCR_CH; ++c) {
+        const int64_t seg = seg0 + c;
+        bucket[c] = 0;
+        if (seg >= seg_end) continue;
+        const int64_t oi = P.seg_object ? (int64_t)P.seg_object[seg] : find_object(P.seg_prefix, P.n_objects, seg);
+        const ims_object_t& o = P.objects[oi];
+        const int64_t j = (seg - P.seg_prefix[oi]) * P.seg_size + threadIdx.x;
+        if (j >= o.n_phot) continue;
+        Rng rng;
+        rng_reset(rng);
+        rng_block(rng, P.seed, o.obj_id, o.phot_first + j, SLOT_PSF_TIME + (uint32_t)comp);
+        const int bk = (int)(((unsigned long long)rng.w[0] * (unsigned long long)n_buckets) >> 32);   // floor(u n): monotone in the time
+        bucket[c] = (unsigned char)bk;
+        valid |= 1u << c;
+        atomicAdd(&hist[bk], 1u);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < n_buckets) {
+        const unsigned int cnt = hist[threadIdx.x];
+        if (cnt != 0u) {
+            const unsigned long long got = atomicAdd(&bins[x * n_buckets + threadIdx.x], (unsigned long long)cnt);
+            if (MODE == 1) base[threadIdx.x] = got;
+        }
+        if (MODE == 1) hist[threadIdx.x] = 0u;           // becomes the cursor inside the workgroup's share of the bin
+    }
+    if (MODE == 1) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < SCR_CH; ++c) {
+            if (!(valid & (1u << c))) continue;
+            const int64_t seg = seg0 + c;
+            const int64_t oi = P.seg_object ? (int64_t)P.seg_object[seg] : find_object(P.seg_prefix, P.n_objects, seg);
+            const ims_object_t& o = P.objects[oi];
+            const int64_t k = o.phot_first + (seg - P.seg_prefix[oi]) * P.seg_size + threadIdx.x;
+            const unsigned int rank = atomicAdd(&hist[bucket[c]], 1u);
+            entries[base[bucket[c]] + rank] = (int64_t)(((unsigned long long)oi << 32) | (unsigned long long)(uint32_t)k);
+        }
+    }
+}
+
+// exclusive prefix of the counts in place (slice-major, bucket-minor) + the slice boundaries behind them
+__global__ void k_screen_scan(unsigned long long* __restrict__ bins, int n_bins, int n_buckets)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned long long run = 0ull;
+    for (int i = 0; i < n_bins; ++i) {
+        if (i % n_buckets == 0) bins[n_bins + i / n_buckets] = run;          // start of slice i / n_buckets
+        const unsigned long long c = bins[i];
+        bins[i] = run;
+        run += c;
+    }
+    bins[n_bins + 8] = run;
+}
+
+// what the gather needs of an object, 32 bytes instead of a 256-byte row (3 MB for 100 000 objects: the rows of a slice would
+// take as much of the XCD's L2 as the screen windows the pre-pass is there to keep)
+struct ScreenObject { int64_t obj_id, screen_base; double tan_x, tan_y; };
+
+__global__ __launch_bounds__(256) void k_screen_objects(const ims_render_params_t P, ScreenObject* __restrict__ slim)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.n_objects) return;
+    const ims_object_t& o = P.objects[i];
+    ScreenObject q = { o.obj_id, o.screen_base, o.atm_tan_x, o.atm_tan_y };
+    slim[i] = q;
+}
+
+// Slice x in time order on XCD x: block b works on the x = b mod 8 slice, chunk b / 8.  The entries stream in and the kicks
+// stream out past the cache (non-temporal): what stays in the XCD's L2 are the screen windows and the 32-byte object records.
+__global__ __launch_bounds__(256) void k_screen_gather(const ims_render_params_t P, int comp, const unsigned long long* __restrict__ slice_start,
+                                                       const int64_t* __restrict__ entries, const ScreenObject* __restrict__ slim,
+                                                       double* __restrict__ kick)
+{
+    const int x = blockIdx.x & 7;
+    const unsigned long long pos = slice_start[x] + (unsigned long long)(blockIdx.x >> 3) * 256ull + threadIdx.x;
+    if (pos >= slice_start[x + 1]) return;
+    const unsigned long long e = (unsigned long long)__builtin_nontemporal_load(entries + pos);
+    const int64_t oi = (int64_t)(e >> 32), k = (int64_t)(e & 0xFFFFFFFFull);
+    const ScreenObject o = slim[oi];
+    const ims_atmosphere_t& A = *P.atm;
+    Rng rng;
+    rng_reset(rng);
+    rng_block(rng, P.seed, o.obj_id, k, SLOT_PSF + ((uint32_t)comp >> 1));
+    const uint32_t wa = (comp & 1) ? rng.w[2] : rng.w[0], wb = (comp & 1) ? rng.w[3] : rng.w[1];
+    const double r = dsqrt0(A.aper_ri2 + w01(wa) * A.aper_dr2);
+    double s, cc;
+    sincos2pi(w01(wb), s, cc);
+    const double pu = r * cc, pv = r * s;
+    rng_block(rng, P.seed, o.obj_id, k, SLOT_PSF_TIME + (uint32_t)comp);
+    const double t = A.t0 + w01(rng.w[0]) * A.exptime;
+    double gx, gy;
+    screen_gradient<true>(A, pu, pv, t, o.tan_x, o.tan_y, gx, gy);
+    double* dst = kick + 2 * (o.screen_base + k);
+    __builtin_nontemporal_store(gx, dst);
+    __builtin_nontemporal_store(gy, dst + 1);
+}
+
 // ---------------- object table on the device (include/imsim_hip.h: ims_build_object_table) ----------------
 // One thread per catalog source.  The test-side CPU restatement repeats this arithmetic; the formulas are those of
 // imsim_amd/catalog.py (the numpy builder, which stays the portable host path).
@@ -2626,6 +2748,44 @@ int ims_readout_finish(const float* seg_dev, const ims_readout_t* ro, uint64_t s
     const int64_t n = (int64_t)ro->raw_w * ro->raw_h * ro->n_amps;
     hipLaunchKernelGGL(k_readout_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seg_dev, *ro, seed,
                        out_dev);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+int ims_screen_prepass(const ims_render_params_t* params, int32_t comp, int32_t n_buckets, const int64_t* slice_first_host,
+                       int64_t max_slice_photons, int64_t* scratch_dev, int64_t* entries_dev, double* kick_dev, void* stream)
+{
+    if (!params || !slice_first_host || !scratch_dev || !entries_dev || !kick_dev) return set_err(IMS_ERR_ARG, "NULL argument");
+    if (!params->objects || !params->seg_prefix || !params->atm) return set_err(IMS_ERR_ARG, "objects / seg_prefix / atm is NULL");
+    if (comp < 0 || comp >= params->n_psf || params->psf[comp].kind != IMS_PSF_SCREENS)
+        return set_err(IMS_ERR_ARG, "comp is not a phase-screen PSF component");
+    if (n_buckets < 1 || n_buckets > SCR_MAXB || (n_buckets & (n_buckets - 1)) != 0) return set_err(IMS_ERR_ARG, "n_buckets must be a power of two <= 256");
+    if (params->seg_size != 256) return set_err(IMS_ERR_ARG, "seg_size must be 256");
+    if (params->n_segments <= 0) return IMS_OK;
+    if (params->n_segments > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "too many segments");
+    ScreenSlices S;
+    int64_t max_segs = 0;
+    for (int q = 0; q < 9; ++q) {
+        S.first[q] = slice_first_host[q];
+        S.seg_first[q] = slice_first_host[9 + q];
+        if (q > 0 && S.seg_first[q] - S.seg_first[q - 1] > max_segs) max_segs = S.seg_first[q] - S.seg_first[q - 1];
+    }
+    if (S.seg_first[0] != 0 || S.seg_first[8] != params->n_segments) return set_err(IMS_ERR_ARG, "slice segment boundaries do not cover the table");
+    hipStream_t st = (hipStream_t)stream;
+    const int n_bins = 8 * n_buckets;
+    unsigned long long* bins = (unsigned long long*)scratch_dev;
+    HIP_TRY(hipMemsetAsync(bins, 0, sizeof(unsigned long long) * (size_t)(n_bins + 16), st));
+    const dim3 grid((unsigned)(8 * ((max_segs + SCR_CH - 1) / SCR_CH)));
+    hipLaunchKernelGGL(k_screen_sort<0>, grid, dim3(256), 0, st, *params, comp, n_buckets, S, bins, (int64_t*)nullptr);
+    hipLaunchKernelGGL(k_screen_scan, dim3(1), dim3(64), 0, st, bins, n_bins, n_buckets);
+    hipLaunchKernelGGL(k_screen_sort<1>, grid, dim3(256), 0, st, *params, comp, n_buckets, S, bins, entries_dev);
+    // every slice gets the blocks of the largest one (a block beyond its slice's end leaves at once); the slice boundaries sit
+    // behind the bins, whose cursors the scatter has advanced to the bin ends
+    if (max_slice_photons <= 0 || (max_slice_photons + 255) / 256 * 8 > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "max_slice_photons out of range");
+    ScreenObject* slim = (ScreenObject*)(scratch_dev + n_bins + 16);
+    hipLaunchKernelGGL(k_screen_objects, dim3((unsigned)((params->n_objects + 255) / 256)), dim3(256), 0, st, *params, slim);
+    hipLaunchKernelGGL(k_screen_gather, dim3((unsigned)(8 * ((max_slice_photons + 255) / 256))), dim3(256), 0, st,
+                       *params, comp, bins + n_bins, entries_dev, slim, kick_dev);
     HIP_TRY(hipGetLastError());
     return IMS_OK;
 }

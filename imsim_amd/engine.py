@@ -440,7 +440,10 @@ class BoundScene:
                 A.screens = scr.data_ptr()
                 # the 2 x 2 cells of the bilinear gradient as 16-byte items (ims_atmosphere_t.screen_quads): built once
                 # per atmosphere and shared by every renderer that looks through it (4 x the screens: 6.4 GB for 6 x 8192^2)
-                if os.environ.get("IMS_SCREEN_QUADS", "1") != "0":
+                # (with the pre-pass of ims_screen_prepass, the default, the shooting kernels do not gather at all and the
+                # pre-pass reads the plain screens: the four-fold table is only built when asked for)
+                prepass_all = os.environ.get("IMS_SCREEN_PREPASS", "0") == "1"
+                if os.environ.get("IMS_SCREEN_QUADS", "0" if prepass_all else "1") != "0":
                     quads = getattr(scene.atm, "_screen_quads", None)
                     if quads is None or quads.device != scr.device:
                         quads = t.stack([scr, t.roll(scr, -1, 2), t.roll(scr, -1, 1), t.roll(scr, (-1, -1), (1, 2))], dim=-1).contiguous()
@@ -706,6 +709,8 @@ class Renderer:
                 realized_refs.append((arena.add(where), len(part), tmp))
             P = self.bound.params(None, len(part), None, int(prefix[-1]),
                                   self.image.data_ptr(), tmp.data_ptr() if tmp is not None else None, None)
+            if kind != "render" and getattr(self, "_prepass_event", None) is not None:
+                P.screen_kick = None                  # the pre-pass covered the ordinary objects only: the bright ones gather in place
             if master is not None:
                 dst = self.torch.empty(max(len(part), 1) * OBJECT_DTYPE.itemsize, dtype=self.torch.uint8, device=self.device)
                 gathers.append((dst, arena.add(np.ascontiguousarray(part["row"])), arena.add(np.ascontiguousarray(part["phot_first"])),
@@ -721,6 +726,8 @@ class Renderer:
 
         def add_render(part, index, stream="bulk"):
             P, keep = upload(part, index, "render")
+            if getattr(self, "_prepass_event", None) is not None:
+                plan.append(("wait", self._prepass_event, stream))       # the phase-screen pre-pass of these objects (side stream)
             plan.append(("render", P, keep, int(part["n_phot"].sum()), len(part), stream))
 
         if ss is None:
@@ -981,8 +988,94 @@ class Renderer:
             ev.record(st)
             main.wait_event(ev)
 
+    # -- phase-screen pre-pass (ims_screen_prepass): the gathers of all photons of a render, in cache-friendly order --
+    PREPASS_EVENT = 60000          # library event (ims_run_plan RECORD / WAIT) that says "the pre-pass is through"
+
+    def screen_prepass(self, objects, nrecalc=None):
+        """For scenes with a phase-screen PSF (AtmosphericPSF): returns (objects with screen_base set, run) where run()
+        enqueues the pre-pass and must precede every execution of a plan built from those objects while
+        `self.bound.base_params.screen_kick` was set (plan_lsst_image copies it); (objects, None) when there is nothing to do.
+        IMS_SCREEN_PREPASS: 0 (default) -- off: every photon gathers where it is made (measured fastest: C3b 37.2 ms against
+        41.1 / 41.3 ms); 1 -- every photon of the render, ahead of everything (HBM traffic of the shooting
+        kernels down to their algorithmic bytes); 2 -- the ORDINARY objects only (one fused launch, whose in-place gathers
+        are the one memory-bound launch of the path), on a side stream beside the pool shoots of the bright objects.
+        Host tables only."""
+        mode = os.environ.get("IMS_SCREEN_PREPASS", "0")
+        comp = next((k for k, c in enumerate(self.scene.psf) if int(c[0]) == _abi.IMS_PSF_SCREENS), None)
+        self._prepass_event = None
+        if (comp is None or self.scene.atm is None or mode == "0" or not isinstance(objects, np.ndarray) or len(objects) == 0):
+            return objects, None
+        objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE).copy()
+        covered = np.arange(len(objects))
+        ss = self.scene.sensor
+        if mode == "2":
+            if ss is None:
+                mode = "1"
+            else:
+                b = self.bound
+                covered, _ = plan_bf_groups(objects, ss.model.nrecalc if nrecalc is None else nrecalc, b.n_static_slots,
+                                            b.static_cells, ss.scratch_cells, b.slot_capacity, self.max_pool_photons)
+        sub = objects[covered]
+        n_phot = sub["n_phot"].astype(np.int64)
+        cum = np.concatenate([[0], np.cumsum(n_phot)]).astype(np.int64)
+        total = int(cum[-1])
+        if total == 0 or int(n_phot.max()) >= 2 ** 31 or len(sub) >= 2 ** 31:
+            return objects, None
+        sub["screen_base"] = cum[:-1] - sub["phot_first"]
+        objects["screen_base"][covered] = sub["screen_base"]
+        # eight slices of the (spatially sorted) table with about equal photon counts, one per XCD
+        cuts = np.searchsorted(cum, total * np.arange(1, 8) / 8.0, side="left")
+        first = np.concatenate([[0], np.clip(cuts, 0, len(sub)), [len(sub)]]).astype(np.int64)
+        first = np.maximum.accumulate(first)
+        per_slice = cum[first[1:]] - cum[first[:-1]]
+        n_buckets = int(os.environ.get("IMS_SCREEN_BUCKETS", "128"))
+        t = self.torch
+        _, obj_t, prefix, pre_t = self._upload_objects(sub)
+        P = self.bound.params(obj_t.data_ptr(), len(sub), pre_t.data_ptr(), int(prefix[-1]), self.image.data_ptr(), None,
+                              _seg_ptr(pre_t))
+        entries = t.empty(total, dtype=t.int64, device=self.device)
+        kick = t.empty(2 * total, dtype=t.float64, device=self.device)
+        scratch = t.zeros(8 * n_buckets + 16 + 4 * len(sub), dtype=t.int64, device=self.device)
+        self.bound.base_params.screen_kick = kick.data_ptr()
+        first = np.concatenate([first, prefix[first]]).astype(np.int64)      # objects, then segments
+        keep = (obj_t, pre_t, entries, kick, scratch, first, P)
+        side = mode == "2"
+        if side:
+            self._prepass_event = self.PREPASS_EVENT
+            rec = (_abi.PlanItem * 1)()
+            rec[0].kind, rec[0].stream, rec[0].n_slots = _abi.IMS_PLAN_RECORD, self.STREAMS["chain2"], self.PREPASS_EVENT
+
+        def run():
+            def go():
+                _abi.check(self.lib.ims_screen_prepass(C.byref(P), comp, n_buckets, first.ctypes.data, int(per_slice.max()),
+                                                       scratch.data_ptr(), entries.data_ptr(), kick.data_ptr(), self._stream()),
+                           "ims_screen_prepass")
+            if not side:
+                return go()
+            # on the third chain stream, ordered behind whatever the caller's stream holds; the fused launch of the plan waits
+            # for the library event recorded behind it
+            main = t.cuda.current_stream(self.device)
+            self.s_chain2.wait_stream(main)
+            with t.cuda.stream(self.s_chain2):
+                go()
+            streams = (self.s_chain, self.s_bulk, self.s_chain1, self.s_chain2)
+            sarr = (C.c_void_p * 4)(*[st.cuda_stream for st in streams])
+            _abi.check(self.lib.ims_run_plan(rec, 1, None, None, None, sarr, 4), "ims_run_plan")
+        run.keep = keep
+        run.photons = total
+        run.side = side
+        return objects, run
+
     def render_lsst_image(self, objects, nrecalc=None, realized=None):
-        plan, parts = self.plan_lsst_image(objects, nrecalc, want_realized=realized is not None)
+        objects, prepass = self.screen_prepass(objects, nrecalc)
+        try:
+            plan, parts = self.plan_lsst_image(objects, nrecalc, want_realized=realized is not None)
+        finally:
+            self.bound.base_params.screen_kick = None
+            self._prepass_event = None
+        if prepass is not None:
+            prepass()
+            plan.prepass = prepass
         self.execute_plan(plan)
         if realized is not None:
             for index, tmp in parts:
@@ -992,7 +1085,12 @@ class Renderer:
     def prepared_lsst_image(self, objects, nrecalc=None):
         """Upload everything once; returns a callable replaying the whole LSST_Image render (used
         by bench.py: the timed region starts with all inputs resident in HBM)."""
-        plan, _ = self.plan_lsst_image(objects, nrecalc)
+        objects, prepass = self.screen_prepass(objects, nrecalc)
+        try:
+            plan, _ = self.plan_lsst_image(objects, nrecalc)
+        finally:
+            self.bound.base_params.screen_kick = None
+            self._prepass_event = None
         n_groups = sum(1 for it in plan if it[0] == "slots")
         if n_groups == 1:
             # the slot table never changes between replays: set it once, outside the timed region
@@ -1006,19 +1104,27 @@ class Renderer:
         compiled = self._compile_plan(plan)
 
         def launch():
+            if prepass is not None:
+                prepass()
             self.execute_plan(plan, compiled)
         launch.plan = plan
+        launch.prepass = prepass
         launch.photons = sum(it[3] for it in plan if it[0] == "render") + sum(it[5] for it in plan if it[0] == "shoot_pool")
         launch.object_rows = sum(it[4] for it in plan if it[0] == "render") + sum(it[6] for it in plan if it[0] in ("shoot_pool", "acc_pool", "chain"))
         launch.pool_photons = sum(it[5] for it in plan if it[0] == "shoot_pool")
         # the two photon-pipeline kernels the library can time (ims_enable_timing): launches per replay and
         # their algorithmic bytes.  Fused render: f64 image RMW (16 B/photon); pool shoot: the four f64
         # fields of a converted photon it writes (32 B/photon); both + one 256-B object row per object
+        # With the 6-layer AtmosphericPSF every photon also reads 6 x 4 fp32 screen samples (+ 96 B) where it is
+        # made, or its 16-byte gradient sum where the pre-pass gathered it
+        has_screens = self.scene.atm is not None and any(int(c[0]) == _abi.IMS_PSF_SCREENS for c in self.scene.psf)
+        scr_render = 0 if not has_screens else (16 if prepass is not None else 96)
+        scr_pool = 0 if not has_screens else (16 if (prepass is not None and not prepass.side) else 96)
         launch.timed = {
             1: (sum(1 for it in plan if it[0] == "render"),
-                sum(it[3] * 16 + it[4] * 256 for it in plan if it[0] == "render")),
+                sum(it[3] * (16 + scr_render) + it[4] * 256 for it in plan if it[0] == "render")),
             2: (sum(1 for it in plan if it[0] == "shoot_pool"),
-                sum(it[5] * 32 + it[6] * 256 for it in plan if it[0] == "shoot_pool")),
+                sum(it[5] * (32 + scr_pool) + it[6] * 256 for it in plan if it[0] == "shoot_pool")),
         }
         # wavefronts per replay of the two kernels (4 per 256-thread segment, as SQ_WAVES counts them)
         launch.timed_waves = {1: sum(4 * int(it[1].n_segments) for it in plan if it[0] == "render"),

@@ -125,7 +125,9 @@ typedef struct ims_object {
     double  atm_tan_x, atm_tan_y; /* tan of the field angle of the object from the boresight (theta of atm.makePSF, atmPSF.py:304) */
     double  prof_aux;      /* IMS_PROF_BOX: width [arcsec]; IMS_PROF_KNOTS: number of knots; IMS_PROF_IMAGE: image index
                             * (prof_scale = arcsec per image pixel) */
-    double  reserved[6];   /* pads the row to 256 bytes */
+    int64_t screen_base;   /* launches with params->screen_kick: the kick of photon k (absolute index in the object's stream) of
+                            * the phase-screen PSF component is screen_kick[2 (screen_base + k)], [.. + 1] (ims_screen_prepass) */
+    double  reserved[5];   /* pads the row to 256 bytes */
 } ims_object_t;
 
 /* Pixel images sampled as profiles (galsim.InterpolatedImage of a FITS stamp, imsim/instcat.py:552-561): image k has
@@ -370,6 +372,9 @@ typedef struct ims_render_params {
      * `optics` points to (the kernels cannot check it): for the layouts the library holds an unrolled ray trace for
      * (ims_known_optics_layout) the launch takes that kernel, any other value runs the loop over the surfaces. */
     uint64_t optics_layout;
+    /* optional (NULL = every photon gathers the phase screens itself): the sum over the layers of the screen gradient [nm/m] of
+     * every photon, x and y interleaved, filled by ims_screen_prepass and indexed through ims_object_t.screen_base */
+    const double* screen_kick;
 } ims_render_params_t;
 
 /* ---- library ---- */
@@ -504,6 +509,29 @@ int  ims_fft_spikes(const ims_fft_params_t* params, const ims_fft_object_t* obje
 /* pix_prefix[n_objects+1] (device): prefix sum of nfft*nfft; rbuf: the inverse-transformed images */
 int  ims_fft_finish(const ims_fft_params_t* params, const ims_fft_object_t* objects_dev, int64_t n_objects,
                     const int64_t* pix_prefix_dev, int64_t n_pix, const double* rbuf, void* stream);
+
+/* ---- phase-screen gather with managed locality (imsim/atmPSF.py:298-336; N1 of the survey's scope) ----
+ * A photon of an AtmosphericPSF reads a 2 x 2 cell of each of the six 8192^2 screens at (pupil position + altitude x field
+ * angle - wind x arrival time): a random place on a strip of 84 x (wind x exposure) samples per layer.  Gathered where the
+ * photon is made, one workgroup per object, every access is a fresh line from a 1.6 GB table (5 x the bytes the gradient
+ * needs).  This pre-pass does the gathers of ALL photons of a render in an order that keeps them in cache:
+ *   1. every photon's arrival-time bucket (its time draw, slot 20 + component, is addressed by object and photon index, so it
+ *      can be evaluated ahead) is counted per (slice, bucket): the objects of the spatially sorted table are cut into EIGHT
+ *      contiguous slices of about equal photon counts, one per XCD;
+ *   2. the (object, photon index) pairs are scattered into slice-major, time-minor order;
+ *   3. slice x is walked by the workgroups that run on XCD x (block b -> XCD b mod 8) in time order: at any moment an XCD's L2
+ *      holds the windows its eighth of the CCD looks through at one instant (~1 - 2 MB over the six layers), and every line of
+ *      a screen is fetched about once per slice;
+ *   4. the gradient sums go to screen_kick, which the shooting kernels read (coalesced) in place of the gathers.
+ * Same arithmetic per photon (pupil position, time, bilinear gradient, layer order): bit-identical photons.
+ * params: the FULL object table of the render (objects with phot_first / n_phot of the whole render and screen_base set,
+ * seg_prefix / seg_object / n_segments over it).  comp: index of the IMS_PSF_SCREENS component.  n_buckets: a power of two,
+ * at most 256.  slice_first_host[18]: first object of every slice, then first SEGMENT of every slice, each with the end as ninth entry
+ * (HOST); max_slice_photons: photons of the largest slice.
+ * scratch_dev: 8 n_buckets + 16 + 4 n_objects int64.  entries_dev:
+ * one int64 per photon.  kick_dev: two doubles per photon. */
+int  ims_screen_prepass(const ims_render_params_t* params, int32_t comp, int32_t n_buckets, const int64_t* slice_first_host,
+                        int64_t max_slice_photons, int64_t* scratch_dev, int64_t* entries_dev, double* kick_dev, void* stream);
 
 /* ---- object table on the device: LSST_SiliconBuilder.setup for a whole catalog in one launch ----
  * imsim/stamp.py:109-249 run per object: Poisson realisation of the flux (:190), skip / tiny-flux / stamp-size decisions

@@ -454,6 +454,7 @@ def test_c3b_atmospheric_psf_is_bit_exact(torch_cuda, monkeypatch, quads):
     from imsim_amd.engine import Renderer
     from oracle import orc_loader
     monkeypatch.setenv("IMS_SCREEN_QUADS", quads)
+    monkeypatch.setenv("IMS_SCREEN_PREPASS", "0")              # the gathers where the photons are made (the pre-pass: next test)
     scene = configs.scene_c3b(nx=256, ny=256, screen_size=102.4, screen_scale=0.1)
     scene.sensor.scratch_cells = 500_000
     cat = catalog.synthetic_catalog(120, nx=256, ny=256)
@@ -472,6 +473,49 @@ def test_c3b_atmospheric_psf_is_bit_exact(torch_cuda, monkeypatch, quads):
     r.synchronize()
     orc.render_lsst_image(objects)
     assert_bits_equal(r.image_numpy(), orc.image, "C3b image")
+
+
+@pytest.mark.parametrize("mode,buckets", [("1", "128"), ("1", "4"), ("2", "128")])
+def test_screen_prepass_gives_the_in_place_gathers(torch_cuda, monkeypatch, mode, buckets):
+    """ims_screen_prepass (N1: the phase-screen gathers of all photons of a render ahead of the shooting kernels, sorted into
+    eight spatial slices and arrival-time buckets so that an XCD's L2 holds the windows it looks through) leaves the image
+    of the gathers done where the photons are made, which is the oracle's, bit for bit -- and its kick buffer holds exactly
+    one entry per photon."""
+    from imsim_amd import configs, catalog
+    from imsim_amd.engine import Renderer
+    from oracle import orc_loader
+    scene = configs.scene_c3b(nx=256, ny=256, screen_size=102.4, screen_scale=0.1)
+    scene.sensor.scratch_cells = 500_000
+    cat = catalog.synthetic_catalog(160, nx=256, ny=256)
+    phot = catalog.realize_fluxes(cat["nominal_flux"], 4)
+    objects, _ = configs.c3b_objects(cat, phot, scene)
+    out = []
+    for on in (mode, "0"):
+        monkeypatch.setenv("IMS_SCREEN_PREPASS", on)
+        monkeypatch.setenv("IMS_SCREEN_BUCKETS", buckets)
+        r = Renderer(scene)
+        step = r.prepared_lsst_image(objects, nrecalc=3000)
+        assert (step.prepass is not None) == (on != "0")
+        for _ in range(2):                                   # replayable
+            r.image.zero_()
+            step()
+        r.synchronize()
+        out.append(r.image_numpy())
+        if on != "0":
+            # mode 1: every photon of the render; mode 2: those of the objects below the recalculation threshold (side stream)
+            covered = objects["n_phot"] if on == "1" else objects["n_phot"][objects["n_phot"] <= 3000]
+            assert step.prepass.side == (on == "2")
+            entries = step.prepass.keep[2].cpu().numpy()
+            assert len(entries) == int(covered.sum())
+            oi, k = entries >> 32, entries & 0xFFFFFFFF
+            key = oi * (1 << 32) + k
+            assert len(np.unique(key)) == len(key)             # every photon exactly once
+            assert np.array_equal(np.bincount(oi, minlength=len(covered)), covered)
+    assert out[0].sum() > 0
+    assert_bits_equal(out[0], out[1], "image: pre-pass vs in-place gathers")
+    orc = orc_loader.OracleScene(scene)
+    orc.render_lsst_image(objects, nrecalc=3000)
+    assert_bits_equal(out[0], orc.image, "image vs oracle")
 
 
 # ---------------------------------------------------------------------------------------------

@@ -928,10 +928,12 @@ __device__ __forceinline__ void fmac_bcast(int sel, double& acc, double d, doubl
 // x 2 NPO values) is read as NPO VGPR pairs, lane l holding entry 16 r + (l & 15), and every FMA names the lane it wants.
 // Same operands, same order, same bits.  Lanes without a cell or without charge in their window run along (their w are
 // +0, which leaves acc unchanged bit for bit) because a broadcast reads its source lane through EXEC.
+// early_table: the table's loads are issued before the halo's (one round trip for both: a star's few tiles, where the latency of
+// a round counts); otherwise only the tiles that found charge fetch it (a wide launch is mostly tiles without: 10 KB each).
 template <int NV>
 __device__ __forceinline__ void update_tile_q3_dpp(const ims_sensor_t& s, const SlotView& sl, int tx0, int ty0,
                                                    unsigned char* __restrict__ changed, UpdateLds<NV>& L, unsigned int tag,
-                                                   const double* __restrict__ dl_global)
+                                                   const double* __restrict__ dl_global, bool early_table)
 {
     constexpr int Q = 3, HW = UT + 2 * Q + 1, NPO = 2 * NV + 2, NPT = 2 * NPO;
     const int sx0 = tx0 - (Q + 1), sy0 = ty0 - (Q + 1);
@@ -940,10 +942,12 @@ __device__ __forceinline__ void update_tile_q3_dpp(const ims_sensor_t& s, const 
     // the table first: its loads fly while the halo is gathered
     constexpr int DLN = 8 * 8 * NPT, DLP = (DLN + 255) / 256;
     double dreg[DLP];
+    if (early_table) {
 #pragma unroll
-    for (int u = 0; u < DLP; ++u) {
-        const int e = threadIdx.x + 256 * u;
-        dreg[u] = (e < DLN) ? dl_global[e] : 0.0;
+        for (int u = 0; u < DLP; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            dreg[u] = (e < DLN) ? dl_global[e] : 0.0;
+        }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < HW * HW; e += 256) {
@@ -956,10 +960,12 @@ __device__ __forceinline__ void update_tile_q3_dpp(const ims_sensor_t& s, const 
         }
         L.wt[e] = w;
     }
+    if (early_table) {
 #pragma unroll
-    for (int u = 0; u < DLP; ++u) {
-        const int e = threadIdx.x + 256 * u;
-        if (e < DLN) L.dl[e] = dreg[u];
+        for (int u = 0; u < DLP; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            if (e < DLN) L.dl[e] = dreg[u];
+        }
     }
     __syncthreads();
     const int lx = threadIdx.x % UT, ly = threadIdx.x / UT;
@@ -968,6 +974,10 @@ __device__ __forceinline__ void update_tile_q3_dpp(const ims_sensor_t& s, const 
     if (!L.any_charge) {                     // nothing landed near this tile: nothing moves
         if (cell) changed[cell_index(sl, i, j)] = 0;
         return;
+    }
+    if (!early_table) {
+        for (int e = threadIdx.x; e < DLN; e += 256) L.dl[e] = dl_global[e];
+        __syncthreads();
     }
     unsigned long long mask = 0ull;
 #pragma unroll
@@ -1041,7 +1051,7 @@ __global__ __launch_bounds__(256) void k_update_distortions_q3(const ims_sensor_
 #ifdef IMS_UPD_FORCE_LDS
     dl_global = nullptr;
 #endif
-    if (DPP) update_tile_q3_dpp<NV>(s, sl, tx0, ty0, changed, L, tag, dl_global);
+    if (DPP) update_tile_q3_dpp<NV>(s, sl, tx0, ty0, changed, L, tag, dl_global, gridDim.x <= 64u);
     else if (dl_global != nullptr) update_tile_q3<NV, true>(s, sl, tx0, ty0, changed, L, false, tag, dl_global);
     else update_tile_q3<NV, false>(s, sl, tx0, ty0, changed, L, false, tag);
 }
@@ -2304,7 +2314,11 @@ int ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sens
     const unsigned g = (unsigned)((count + 255) / 256);
     const int nV = sensor_host ? sensor_host->num_vertices : 0;
     const int q = sensor_host ? sensor_host->qdist : 0;
-    const bool dpp = sensor_host && sensor_host->bf_dl != nullptr && os_getenv_off("IMS_UPD_DPP");
+    // The DPP form of the update is the faster one where a round's latency counts (a few tiles: 14.2 -> 11.0 us per launch for
+    // one star), the SGPR form where a launch is throughput work beside the photon kernels (its waves sleep on the scalar
+    // cache instead of pulling 10 KB of table through LDS per tile: C3 25.0 against 25.9 ms): the tile count decides.
+    static const long long dpp_max_tiles = getenv("IMS_UPD_DPP_MAX") ? atoll(getenv("IMS_UPD_DPP_MAX")) : 128;
+    const bool dpp = sensor_host && sensor_host->bf_dl != nullptr && os_getenv_off("IMS_UPD_DPP") && n_tiles <= dpp_max_tiles;
     if (q == 3 && nV == 4 && dpp)
         hipLaunchKernelGGL((k_update_distortions_q3<4, true>), dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot,
                            n_slots, tile_prefix_dev, changed_dev, tag, sensor_host->bf_dl);

@@ -250,8 +250,8 @@ def main():
     if share_gpu and world > 1:
         out["shared_gpu"] = True        # dry run: all ranks on ONE GPU over gloo -- not a scaling measurement
 
-    if rank == 0 and world == 1 and not args.no_cold and "cold" in cfg:
-        out["extra"] = cfg["cold"](scene, objects, device)
+    if rank == 0 and world == 1 and not args.no_cold and ("cold" in cfg or "end_to_end" in cfg):
+        out["extra"] = cfg["cold"](scene, objects, device) if "cold" in cfg else {}
         # host side of LSST_SiliconBuilder.setup for the whole catalog (Poisson fluxes, stamp sizes, local WCS, DCR angles)
         out["extra"]["object_table_ms"] = timing.get("object_table_ms")
         if "end_to_end" in cfg:

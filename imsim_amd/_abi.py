@@ -295,7 +295,7 @@ def load():
     lib.ims_sensor_publish_pairs.argtypes = [c_vp, C.POINTER(Sensor), c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]
     lib.ims_build_object_table.argtypes = [C.POINTER(Catalog), c_vp, c_vp, c_vp, c_vp]
     lib.ims_patch_stamp_sizes.argtypes = [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]
-    lib.ims_gather_rows.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]
+    lib.ims_gather_rows.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp]
     lib.ims_screen_prepass.argtypes = [C.POINTER(RenderParams), c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]
     lib.ims_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.ims_device_info.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(c_i64), C.POINTER(c_i64)]

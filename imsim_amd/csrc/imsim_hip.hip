@@ -1933,11 +1933,12 @@ __global__ __launch_bounds__(256) void k_patch_stamp_sizes(ims_object_t* __restr
 // 16 lanes
 __global__ __launch_bounds__(256) void k_gather_rows(const ims_object_t* __restrict__ rows, const int64_t* __restrict__ index,
                                                      const int64_t* __restrict__ first, const int64_t* __restrict__ count,
-                                                     const int32_t* __restrict__ bf_state, ims_object_t* __restrict__ dst, int64_t n)
+                                                     const int32_t* __restrict__ bf_state, int clear_flags,
+                                                     ims_object_t* __restrict__ dst, int64_t n)
 {
     static_assert(sizeof(ims_object_t) == 256, "row size");
     static_assert(offsetof(ims_object_t, phot_first) == 8 && offsetof(ims_object_t, n_phot) == 16 &&
-                  offsetof(ims_object_t, bf_state) == 172, "row layout");
+                  offsetof(ims_object_t, bf_state) == 172 && offsetof(ims_object_t, flags) == 152, "row layout");
     const int64_t k = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
     const int part = threadIdx.x & 15;
     if (k >= n) return;
@@ -1951,6 +1952,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(const ims_object_t* __restr
         v.x = (unsigned)c; v.y = (unsigned)(c >> 32);
     }
     if (part == 10) v.w = bf_state ? (unsigned)bf_state[k] : 0u;   // bytes 172 .. 175: bf_state
+    if (part == 9) v.z &= ~(unsigned)clear_flags;                  // bytes 152 .. 155: flags
     ((uint4*)(dst + k))[part] = v;
 }
 
@@ -2835,12 +2837,12 @@ int ims_patch_stamp_sizes(ims_object_t* rows_dev, ims_object_meta_t* meta_dev, c
 }
 
 int ims_gather_rows(const ims_object_t* rows_dev, const int64_t* index_dev, const int64_t* first_dev, const int64_t* count_dev,
-                    const int32_t* bf_state_dev, ims_object_t* dst_dev, int64_t n, void* stream)
+                    const int32_t* bf_state_dev, int32_t clear_flags, ims_object_t* dst_dev, int64_t n, void* stream)
 {
     if (n <= 0) return IMS_OK;
     if (!rows_dev || !index_dev || !dst_dev) return set_err(IMS_ERR_ARG, "NULL argument");
     hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows_dev, index_dev, first_dev,
-                       count_dev, bf_state_dev, dst_dev, n);
+                       count_dev, bf_state_dev, clear_flags, dst_dev, n);
     HIP_TRY(hipGetLastError());
     return IMS_OK;
 }

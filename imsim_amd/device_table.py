@@ -133,6 +133,18 @@ def host_fixups(cat, meta, build_kw):
     return pend.astype(np.int64), sizes, host.astype(np.int64)
 
 
+_PINNED = {}
+
+
+def _pinned(torch, nbytes, slot=0):
+    """a page-locked staging buffer of at least nbytes, kept for the next table (allocating one costs milliseconds per 10 MB);
+    the caller synchronises before the buffer is handed out again (DeviceTable waits for its meta download)"""
+    buf = _PINNED.get(slot)
+    if buf is None or buf.numel() < nbytes:
+        buf = _PINNED[slot] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
+    return buf[:nbytes]
+
+
 class DeviceTable:
     """The object table of one catalog, resident on the device: `rows` (torch uint8 tensor of n x 256 bytes) and the host's
     copy of what planning needs (`n_phot`, stamp bounds, flags as a slim structured array)."""
@@ -160,7 +172,7 @@ class DeviceTable:
         for name, a in (("star_size", star), ("gal_radius", gal)):
             parts.append((name, off, a))
             off = (off + a.nbytes + 255) & ~255
-        stage = torch.empty(max(off, 8), dtype=torch.uint8, pin_memory=True)
+        stage = _pinned(torch, max(off, 8))
         snp = stage.numpy()
         for name, o, a in parts:
             snp[o:o + a.nbytes] = a.view(np.uint8).reshape(-1)
@@ -178,7 +190,7 @@ class DeviceTable:
         stream = renderer._stream()
         _abi.check(renderer.lib.ims_build_object_table(C.byref(st), optics_ptr, self.rows.data_ptr(), self._meta_dev.data_ptr(),
                                                        stream), "ims_build_object_table")
-        meta_pin = torch.empty(max(n, 1) * META_DTYPE.itemsize, dtype=torch.uint8, pin_memory=True)
+        meta_pin = _pinned(torch, max(n, 1) * META_DTYPE.itemsize, slot=1)
         meta_pin.copy_(self._meta_dev, non_blocking=True)
         torch.cuda.current_stream(dev).synchronize()
         meta = meta_pin.numpy()[:n * META_DTYPE.itemsize].view(META_DTYPE).copy()

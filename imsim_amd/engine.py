@@ -647,6 +647,39 @@ class Renderer:
         pre_t.seg_object = self.torch.from_numpy(seg_obj).to(self.device) if len(seg_obj) else None
         return objects, obj_t, prefix, pre_t
 
+    def _gather_objects(self, master, index, first, count, segments=True):
+        """A launch table gathered on the device from a DeviceTable: rows master[index] with phot_first += first, n_phot = count
+        (None: the object's own), bf_state 0 and IMS_OBJ_FAINT cleared (photon pooling).  Returns (rows tensor, segment
+        prefix on the host, its device tensor with .seg_object)."""
+        t = self.torch
+        if not (isinstance(index, np.ndarray) and index.dtype == np.int64 and index.flags.c_contiguous):
+            index = np.ascontiguousarray(index, dtype=np.int64)
+        n = len(index)
+        n_phot = (master.n_phot[index] if count is None else np.asarray(count)).astype(np.int64)
+        dst = t.empty(max(n, 1) * OBJECT_DTYPE.itemsize, dtype=t.uint8, device=self.device)
+        cache = getattr(master, "_index_tensors", None)
+        if cache is None:
+            cache = master._index_tensors = {}
+        hit = cache.get(id(index))
+        if hit is not None and hit[0] is index:
+            idx_t = hit[1]                                       # an index array that recurs (the PHOT objects of every batch)
+        else:
+            idx_t = t.from_numpy(index).to(self.device)
+            cache[id(index)] = (index, idx_t)
+        first_t = t.from_numpy(np.ascontiguousarray(first, dtype=np.int64)).to(self.device) if first is not None else None
+        count_t = t.from_numpy(np.ascontiguousarray(n_phot)).to(self.device) if count is not None else None
+        _abi.check(self.lib.ims_gather_rows(master.rows.data_ptr(), idx_t.data_ptr(), first_t.data_ptr() if first_t is not None else None,
+                                            count_t.data_ptr() if count_t is not None else None, None, _abi.IMS_OBJ_FAINT,
+                                            dst.data_ptr(), n, self._stream()), "ims_gather_rows")
+        dst.keep = (idx_t, first_t, count_t)
+        if not segments:                      # launches with one wavefront per object (ims_accumulate_small) need no segment table
+            return dst, None, None
+        prefix = segment_prefix(n_phot, self.scene.seg_size)
+        pre_t = t.from_numpy(prefix).to(self.device)
+        seg_obj = np.repeat(np.arange(n, dtype=np.int32), np.diff(prefix))
+        pre_t.seg_object = t.from_numpy(seg_obj).to(self.device) if len(seg_obj) else None
+        return dst, prefix, pre_t
+
     # -- fused path (LSST_Image / LSST_Silicon) --
     def render(self, objects, realized=None):
         """Shoot every object of the table and accumulate into self.image.  `realized`: optional
@@ -690,7 +723,7 @@ class Renderer:
                 realized_parts.append((t[off:off + 8 * n].view(self.torch.int64), tmp))
             base = arena.base
             for dst, o_idx, o_first, o_count, o_bf, n in gathers:
-                _abi.check(self.lib.ims_gather_rows(master.rows.data_ptr(), base + o_idx, base + o_first, base + o_count, base + o_bf,
+                _abi.check(self.lib.ims_gather_rows(master.rows.data_ptr(), base + o_idx, base + o_first, base + o_count, base + o_bf, 0,
                                                     dst.data_ptr(), n, self._stream()), "ims_gather_rows")
             plan.keep_rows = [g[0] for g in gathers] + ([master] if master is not None else [])
             return plan, realized_parts
@@ -1193,11 +1226,22 @@ class Renderer:
         shoot_table, first photon of the batch's share within the object, its photon count.  realized: optional f64 device
         tensor over the rows of shoot_table receiving the flux every object added to the image.  Returns
         (shoot, [accumulate]), zero-argument callables."""
-        shoot_table, obj_t, prefix, pre_t = self._upload_objects(shoot_table)
-        base = np.concatenate([[0], np.cumsum(shoot_table["n_phot"])]).astype(np.int64)
+        master = None
+        if isinstance(shoot_table, tuple):
+            # (DeviceTable, index): the rows are gathered on the device; the host works on photon counts alone
+            master, shot = shoot_table
+            shot = np.ascontiguousarray(shot, dtype=np.int64)
+            shoot_n = master.n_phot[shot].astype(np.int64)
+            obj_t, prefix, pre_t = self._gather_objects(master, shot, None, None)
+            shoot_table = None
+        else:
+            shoot_table, obj_t, prefix, pre_t = self._upload_objects(shoot_table)
+            shoot_n = shoot_table["n_phot"].astype(np.int64)
+        n_shoot = len(shoot_n)
+        base = np.concatenate([[0], np.cumsum(shoot_n)]).astype(np.int64)
         base_t = self.torch.from_numpy(base).to(self.device)
         pool, pool_t = self._pool4(base[-1])
-        P = self.bound.params(obj_t.data_ptr(), len(shoot_table), pre_t.data_ptr(), int(prefix[-1]), self.image.data_ptr(),
+        P = self.bound.params(obj_t.data_ptr(), n_shoot, pre_t.data_ptr(), int(prefix[-1]), self.image.data_ptr(),
                               None, _seg_ptr(pre_t))
         nv = self._num_vertices()
 
@@ -1206,26 +1250,49 @@ class Renderer:
                        "ims_shoot_ops_photons")
         shoot.keep = (obj_t, pre_t, base_t, pool_t, P, pool)
         shoot.photons = int(base[-1])
-        shoot.object_rows = len(shoot_table)
+        shoot.object_rows = n_shoot
         shoot.waves = 4 * int(prefix[-1])
         launches = []
         small_max = int(os.environ.get("IMS_POOL_SMALL_MAX", "64"))    # shares up to a wavefront: one wavefront per object
-        for rows, first, count, bf_tag in batches:
-            rows, first, count = np.asarray(rows), np.asarray(first), np.asarray(count)
+        base_cache = {}
+        for batch in batches:
+            if isinstance(batch[0], str) and batch[0] == "parts":
+                # pre-split by the caller: [(rows, first, count, small)] -- no masks over the whole batch
+                _, parts_in, bf_tag = batch
+                todo = [(np.asarray(rw), np.asarray(fi), np.asarray(co), self.lib.ims_accumulate_small if sm else self.lib.ims_accumulate_segments)
+                        for rw, fi, co, sm in parts_in if len(rw)]
+            else:
+                rows, first, count, bf_tag = batch
+                rows, first, count = np.asarray(rows), np.asarray(first), np.asarray(count)
+                todo = [(rows[sel], first[sel], count[sel], entry)
+                        for sel, entry in ((count > small_max, self.lib.ims_accumulate_segments), (count <= small_max, self.lib.ims_accumulate_small))
+                        if sel.any()]
             calls = []
-            for sel, entry in ((count > small_max, self.lib.ims_accumulate_segments), (count <= small_max, self.lib.ims_accumulate_small)):
-                if not sel.any():
-                    continue
-                part = shoot_table[rows[sel]].copy()
-                part["n_phot"] = count[sel]
-                part, part_t, bprefix, bpre_t = self._upload_objects(part)
-                start_t = self.torch.from_numpy(np.ascontiguousarray(base[rows[sel]] + first[sel], dtype=np.int64)).to(self.device)
+            for rows_s, first_s, count_s, entry in todo:
+                # base[rows] / shot[rows] of an index array that recurs in every batch (the PHOT objects) are formed once
+                key = id(rows_s)
+                if key not in base_cache:
+                    base_cache[key] = (rows_s, base[rows_s], shot[rows_s] if master is not None else None)
+                _, base_rows, shot_rows = base_cache[key]
+                if master is not None:
+                    small = entry is self.lib.ims_accumulate_small
+                    part_t, bprefix, bpre_t = self._gather_objects(master, shot_rows, None, count_s, segments=not small)
+                    n_part = len(rows_s)
+                    if small:
+                        bprefix, bpre_t = np.zeros(1, dtype=np.int64), None
+                else:
+                    part = shoot_table[rows_s].copy()
+                    part["n_phot"] = count_s
+                    part, part_t, bprefix, bpre_t = self._upload_objects(part)
+                    n_part = len(part)
+                start_t = self.torch.from_numpy(np.ascontiguousarray(base_rows + first_s, dtype=np.int64)).to(self.device)
                 tmp = rows_t = None
                 if realized is not None:
-                    tmp = self.torch.zeros(len(part), dtype=self.torch.float64, device=self.device)
-                    rows_t = self.torch.from_numpy(np.ascontiguousarray(rows[sel], dtype=np.int64)).to(self.device)
-                Pb = self.bound.params(part_t.data_ptr(), len(part), bpre_t.data_ptr(), int(bprefix[-1]), self.image.data_ptr(),
-                                       tmp.data_ptr() if tmp is not None else None, _seg_ptr(bpre_t))
+                    tmp = self.torch.zeros(n_part, dtype=self.torch.float64, device=self.device)
+                    rows_t = self.torch.from_numpy(np.ascontiguousarray(rows_s, dtype=np.int64)).to(self.device)
+                Pb = self.bound.params(part_t.data_ptr(), n_part, bpre_t.data_ptr() if bpre_t is not None else None, int(bprefix[-1]),
+                                       self.image.data_ptr(), tmp.data_ptr() if tmp is not None else None,
+                                       _seg_ptr(bpre_t) if bpre_t is not None else None)
                 Pb.bf_tag = bf_tag
                 calls.append((entry, Pb, start_t, (part_t, bpre_t, tmp, rows_t)))
 

@@ -73,33 +73,57 @@ def check_stamp_type(stamp_type):
         raise GalSimConfigValueError(f"Must use stamp.type = LSST_Photons with LSST_PhotonPoolingImage. ({stamp_type})")
 
 
-def make_batch_tables(objects, modes, nbatch, seed):
-    """The photon batches of LSST_PhotonPoolingImageBuilder.buildImage (imsim/photon_pooling.py:116-140): every
-    PHOT object appears in every batch with 1/nbatch of its photons (integer split of its photon index range),
-    every FAINT object in one random batch.  Returns ([(object table, row index into `objects`)], size of the
-    smallest batch)."""
-    infos = [ObjectInfo(i, int(objects["n_phot"][i]), modes[i]) for i in range(len(objects))]
-    _, phot, faint = partition_objects(infos, nbatch)
-    nb = max(min(nbatch, len(phot)), 1)
+def batch_plan(n_phot, modes, nbatch, seed):
+    """The structure behind batch_shares: (phot_idx, F, nb, faint_idx, faint_where) -- the PHOT objects (in every batch with
+    the share (F (i + 1)) // nb - (F i) // nb of their F photons), the number of batches, the FAINT objects and the batch
+    each of them lands in."""
+    n_phot = np.asarray(n_phot, dtype=np.int64)
+    modes = np.asarray(modes)
+    if modes.dtype == object:
+        is_phot = np.fromiter((m == ProcessingMode.PHOT for m in modes), dtype=bool, count=len(modes))
+        is_faint = np.fromiter((m == ProcessingMode.FAINT for m in modes), dtype=bool, count=len(modes))
+    else:                                                         # integer codes: ProcessingMode values
+        is_phot, is_faint = modes == int(ProcessingMode.PHOT.value), modes == int(ProcessingMode.FAINT.value)
+    demoted = is_phot & (n_phot < nbatch)
+    phot_idx = np.flatnonzero(is_phot & ~demoted)
+    faint_idx = np.flatnonzero(is_faint | demoted)
+    nb = max(min(nbatch, len(phot_idx)), 1)
     gen = np.random.default_rng([int(seed), 0xFA17])
-    # batch membership: bright objects in every batch with their flux share; faint in one batch
-    phot_idx = np.array([o.index for o in phot], dtype=np.int64)
-    faint_idx = np.array([o.index for o in faint], dtype=np.int64)
-    faint_where = np.array([int(gen.random() * nb) for _ in faint], dtype=np.int64)
-    F = objects["n_phot"][phot_idx].astype(np.int64) if len(phot_idx) else np.zeros(0, np.int64)
-    len_smallest = None
-    batch_tables = []
+    faint_where = (gen.random(len(faint_idx)) * nb).astype(np.int64)      # one uniform per faint object, in catalog order
+    return phot_idx, n_phot[phot_idx], nb, faint_idx, faint_where
+
+
+def batch_shares(n_phot, modes, nbatch, seed):
+    """The photon batches of LSST_PhotonPoolingImageBuilder.buildImage (imsim/photon_pooling.py:116-140, :279-313, :356-386) as
+    index arithmetic over the whole catalog: every PHOT object (at least nbatch photons) appears in every batch with the
+    integer share (F (i + 1)) // nb - (F i) // nb of its photons, every FAINT object (and PHOT objects with fewer photons
+    than batches) whole in one random batch.  Returns [(index into the catalog, first photon of the share within the
+    object, photons of the share)] per batch, and the size of the smallest batch."""
+    n_phot = np.asarray(n_phot, dtype=np.int64)
+    phot_idx, F, nb, faint_idx, faint_where = batch_plan(n_phot, modes, nbatch, seed)
+    out, smallest = [], None
+    order = np.argsort(faint_where, kind="stable")
+    bounds = np.searchsorted(faint_where[order], np.arange(nb + 1))
     for i in range(nb):
-        part = objects[phot_idx].copy()
         lo, hi = (F * i) // nb, (F * (i + 1)) // nb
-        part["phot_first"] = objects["phot_first"][phot_idx] + lo
-        part["n_phot"] = hi - lo
-        fsel = faint_idx[faint_where == i] if len(faint_idx) else faint_idx
-        fpart = objects[fsel].copy()
-        table = np.concatenate([part, fpart])
+        fsel = faint_idx[order[bounds[i]:bounds[i + 1]]]
         index = np.concatenate([phot_idx, fsel])
+        first = np.concatenate([lo, np.zeros(len(fsel), dtype=np.int64)])
+        count = np.concatenate([hi - lo, n_phot[fsel]])
+        out.append((index, first, count))
+        smallest = len(index) if smallest is None else min(smallest, len(index))
+    return out, smallest
+
+
+def make_batch_tables(objects, modes, nbatch, seed):
+    """batch_shares as object tables: ([(object table of the batch, row index into `objects`)], size of the smallest batch)."""
+    shares, len_smallest = batch_shares(objects["n_phot"], modes, nbatch, seed)
+    batch_tables = []
+    for index, first, count in shares:
+        table = objects[index].copy()
+        table["phot_first"] = objects["phot_first"][index] + first
+        table["n_phot"] = count
         batch_tables.append((table, index))
-        len_smallest = len(table) if len_smallest is None else min(len_smallest, len(table))
     return batch_tables, len_smallest
 
 
@@ -138,6 +162,8 @@ def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1,
     after_batch(i): called on the host after batch i has been enqueued (checkpoints); first_batch: batches before it are
     skipped (a resumed CCD; as in the reference it continues from fresh pixel boundaries).
     Returns a zero-argument callable."""
+    if not isinstance(objects, np.ndarray):
+        return _prepared_image_device(renderer, objects, modes, nbatch, seed, rank, world, realized, after_batch, first_batch)
     objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
     tables, _ = make_batch_tables(objects, modes, nbatch, seed)
     sensor_on = renderer.scene.sensor is not None
@@ -223,6 +249,85 @@ def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1,
         run.timed = {1: (len(launches), sum(l.timed[1][1] for l in launches)), 2: (0, 0)}
         run.timed_waves = {1: sum(l.timed_waves[1] for l in launches), 2: 0}
     run.resident = bool(resident)
+    run.keep = (shoot, launches)
+    return run
+
+
+def _prepared_image_device(renderer, table, modes, nbatch, seed, rank, world, realized, after_batch, first_batch):
+    """prepared_image for a device-resident object table (device_table.DeviceTable): the HBM-resident form only -- the batch
+    shares are index arithmetic on the 16 bytes per object the table builder sent back, the shoot table and the per-batch
+    tables are gathered on the device (ims_gather_rows with IMS_OBJ_FAINT cleared: in pooling mode the operators and the
+    sensor see every photon).  Same image as the host-table form, bit for bit (tests/test_device_table.py)."""
+    n_phot = table.n_phot
+    phot_idx, F, nb, faint_idx, faint_where = batch_plan(n_phot, modes, nbatch, seed)
+    sensor_on = renderer.scene.sensor is not None
+    tagged = sensor_on and world == 1
+    if world > 1:
+        mine = parallel.assign_ranks(n_phot, world) == rank
+        keep_p, keep_f = mine[phot_idx], mine[faint_idx]
+        phot_idx, F, faint_idx, faint_where = phot_idx[keep_p], F[keep_p], faint_idx[keep_f], faint_where[keep_f]
+    has = n_phot[faint_idx] > 0
+    faint_idx, faint_where = faint_idx[has], faint_where[has]
+    shot = np.concatenate([phot_idx, faint_idx])
+    if not _pool_fits(renderer, int(n_phot[shot].sum())):
+        raise ValueError("photon pooling from a device table needs the HBM-resident pool (it does not fit)")
+    if world > 1 or os.environ.get("IMS_POOL_SPATIAL", "1") != "0":
+        tile = (table.y[shot] // 256).astype(np.int64) * 4096 + (table.x[shot] // 256).astype(np.int64)
+        shot = shot[np.argsort(tile, kind="stable")]
+    else:
+        shot = np.sort(shot)
+    row_of = np.full(table.n, -1, dtype=np.int64)
+    row_of[shot] = np.arange(len(shot))
+    # The PHOT objects appear in every batch, in the order of the shoot table (neighbours share image lines and boundary
+    # state): rows and photon counts once, the batch only changes the share.  The batch's few FAINT objects follow them.
+    is_phot = np.zeros(table.n, dtype=bool)
+    is_phot[phot_idx] = True
+    rows_p = np.flatnonzero(is_phot[shot])                      # the PHOT objects' rows of the shoot table, ascending
+    Fp = n_phot[shot[rows_p]]
+    # which of the two pixel-search launches a share goes to (ims_accumulate_segments above IMS_POOL_SMALL_MAX photons, one
+    # wavefront per object below) is decided ONCE from the object's mean share: the two give the same result, and a fixed
+    # split makes every batch two contiguous runs of index arithmetic instead of masks over a million objects
+    small_max = int(os.environ.get("IMS_POOL_SMALL_MAX", "64"))
+    big = (Fp // nb) > small_max
+    rows_big, F_big, rows_small, F_small = rows_p[big], Fp[big], rows_p[~big], Fp[~big]
+    rows_f = row_of[faint_idx]
+    f_order = np.argsort(faint_where * (len(shot) + 1) + rows_f, kind="stable")        # by batch, then by row
+    f_bounds = np.searchsorted(faint_where[f_order], np.arange(nb + 1))
+    batches = []
+    for i in range(nb):
+        lo_b = (F_big * i) // nb
+        lo_s = (F_small * i) // nb
+        fs = f_order[f_bounds[i]:f_bounds[i + 1]]
+        parts = [(rows_big, lo_b, (F_big * (i + 1)) // nb - lo_b, False),
+                 (np.concatenate([rows_small, rows_f[fs]]), np.concatenate([lo_s, np.zeros(len(fs), dtype=np.int64)]),
+                  np.concatenate([(F_small * (i + 1)) // nb - lo_s, n_phot[faint_idx[fs]]]), True)]
+        batches.append(("parts", parts, (i % 255 + 1) if tagged else 0))
+    r_rows = None
+    if realized is not None:
+        r_rows = renderer.torch.zeros(len(shot), dtype=renderer.torch.float64, device=renderer.device)
+    shoot, launches = renderer.prepared_pooled_batches((table, shot), batches, realized=r_rows)
+    unit = parallel.unit_flux_path(renderer.scene, None)
+
+    def run():
+        if sensor_on:
+            renderer.init_boundaries(0, 1)
+        shoot()
+        for i, launch in enumerate(launches):
+            if i < first_batch:
+                continue
+            if sensor_on and i > first_batch:
+                if world > 1:
+                    parallel.allreduce_delta(renderer.delta_tensor(0), integer_counts=unit)
+                renderer.update_distortions(0, 1, bf_tag=((i - 1) % 255 + 1) if tagged else 0)
+            launch()
+            if after_batch is not None:
+                after_batch(i)
+        if realized is not None:
+            realized.index_add_(0, renderer.torch.from_numpy(shot).to(renderer.device), r_rows)
+    run.photons, run.object_rows = shoot.photons, shoot.object_rows
+    run.timed = {2: (1, shoot.photons * 32 + shoot.object_rows * 256), 1: (0, 0)}
+    run.timed_waves = {2: shoot.waves, 1: 0}
+    run.resident = True
     run.keep = (shoot, launches)
     return run
 

@@ -594,9 +594,10 @@ int  ims_build_object_table(const ims_catalog_t* cat, const ims_optics_t* optics
 int  ims_patch_stamp_sizes(ims_object_t* rows_dev, ims_object_meta_t* meta_dev, const int64_t* index_dev, const int32_t* size_dev,
                            int64_t n, void* stream);
 /* Launch tables of a plan from the device-resident master table: dst[k] = rows[index[k]] with phot_first += first[k] (NULL: 0),
- * n_phot = count[k] (NULL: unchanged) and bf_state = bf_state[k] (NULL: 0). */
+ * n_phot = count[k] (NULL: unchanged), bf_state = bf_state[k] (NULL: 0) and flags &= ~clear_flags (photon pooling clears
+ * IMS_OBJ_FAINT: there the operators and the sensor see every photon, imsim/photon_pooling.py:154-159). */
 int  ims_gather_rows(const ims_object_t* rows_dev, const int64_t* index_dev, const int64_t* first_dev, const int64_t* count_dev,
-                     const int32_t* bf_state_dev, ims_object_t* dst_dev, int64_t n, void* stream);
+                     const int32_t* bf_state_dev, int32_t clear_flags, ims_object_t* dst_dev, int64_t n, void* stream);
 
 /* ---- instance-catalog tokenizer (host code) ----
  * The `object` lines of a phosim instance catalog (grammar: imsim/instcat.py:231-297) from a text buffer: lines that do not

@@ -112,3 +112,38 @@ def test_plan_from_the_device_table_renders_the_host_planned_image():
     orc = orc_loader.OracleScene(scene)
     orc.render_lsst_image(rows[keep], nrecalc=2000)
     assert np.array_equal(img.view(np.uint32), orc.image.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_photon_pooling_from_the_device_table_equals_the_host_table_form():
+    """LSST_PhotonPoolingImage semantics (batch shares, whole-CCD recalculation per batch) driven from a DeviceTable: batch
+    shares by index arithmetic, shoot and per-batch tables gathered on the device -- the image, the realized fluxes and the
+    pixel-boundary state of the host-table form, bit for bit."""
+    import torch
+    from imsim_amd import photon_pooling, stamp
+    from imsim_amd.engine import Renderer
+    from imsim_amd.device_table import DeviceTable
+    scene, cat, phot = _case(n=4000, seed=11)
+    scene.track_static_delta = 1
+    scene.sensor.scratch_cells = 0
+    out = []
+    for device_form in (True, False):
+        r = Renderer(scene)
+        t = DeviceTable(r, cat, VISIT, phot_flux=phot)
+        if device_form:
+            n_phot = t.n_phot
+            src = t
+        else:
+            rows = t.rows_numpy()
+            n_phot = rows["n_phot"]
+            src = rows
+        modes = stamp.classify(n_phot.astype(float), 100.0)
+        real = torch.zeros(t.n, dtype=torch.float64, device="cuda")
+        step = photon_pooling.prepared_image(r, src, modes, nbatch=5, seed=3, realized=real)
+        step()
+        r.synchronize()
+        out.append((r.image_numpy(), real.cpu().numpy(), r.bound.sensor_arrays["boundary"].cpu().numpy()))
+    assert out[0][0].sum() > 0
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][2], out[1][2])

@@ -129,6 +129,15 @@ class HostMem:
         return self.put(np.zeros(n, dtype=dtype))
 
 
+class _AllEvents:
+    """query() of several events at once"""
+    def __init__(self, evs):
+        self.evs = evs
+
+    def query(self):
+        return all(e.query() for e in self.evs)
+
+
 class DeviceMem:
     """Pointer provider over torch device tensors.
 
@@ -156,13 +165,25 @@ class DeviceMem:
             self._pin = torch.empty(self.ARENA_BYTES, dtype=torch.uint8, pin_memory=True)
         self._pin_np = self._pin.numpy()
         self._used = 0
+        self._streams = {}               # every stream a copy out of the mirror was queued on
+        self._slots = {}                 # write(): one fixed staging slot per handle, with the event of its last copy
+
+    def _note_stream(self):
+        st = self.torch.cuda.current_stream(self.device)
+        self._streams[st.cuda_stream] = st
+        return st
 
     def __del__(self):
+        # the mirror goes back to the pool behind an event per stream that copied out of it (a renderer dropped while a copy is
+        # still pending on a plan stream must not have its mirror overwritten under that copy)
         try:
             if self._pin is not None:
-                ev = self.torch.cuda.Event()
-                ev.record(self.torch.cuda.current_stream(self.device))
-                DeviceMem._MIRRORS.append((self._pin, ev))
+                evs = []
+                for st in list(self._streams.values()) or [self.torch.cuda.current_stream(self.device)]:
+                    ev = self.torch.cuda.Event()
+                    ev.record(st)
+                    evs.append(ev)
+                DeviceMem._MIRRORS.append((self._pin, _AllEvents(evs)))
                 self._pin = None
         except Exception:
             pass
@@ -186,6 +207,7 @@ class DeviceMem:
             self.keep.append(t)
             return t, t.data_ptr()
         t = self._dev[off:off + raw.size]
+        self._note_stream()
         t.copy_(src, non_blocking=True)
         return t, t.data_ptr()
 
@@ -200,12 +222,26 @@ class DeviceMem:
         return t, t.data_ptr()
 
     def write(self, handle, raw):
-        """Stream-ordered update of a device table (queued on the current stream)."""
-        src, _ = self._stage(raw)
-        if src is None:
-            handle[:raw.size].copy_(self.torch.from_numpy(raw))
-        else:
-            handle[:raw.size].copy_(src, non_blocking=True)
+        """Stream-ordered update of a device table (queued on the current stream).  Every handle has ONE staging slot in the
+        mirror, guarded by the event of the last copy out of it: a replay loop that rewrites the slot table a thousand times
+        neither eats the mirror nor falls back to pageable (synchronising) copies."""
+        key = handle.data_ptr()
+        slot = self._slots.get(key)
+        if slot is None or slot[1] < raw.size:
+            src, off = self._stage(np.zeros(int(raw.size), dtype=np.uint8))
+            if src is None:
+                handle[:raw.size].copy_(self.torch.from_numpy(raw))
+                return
+            slot = self._slots[key] = [off, int(raw.size), None]
+        off, cap, ev = slot
+        if ev is not None:
+            ev.synchronize()                           # the previous copy out of this slot (long done in practice)
+        self._pin_np[off:off + raw.size] = raw
+        st = self._note_stream()
+        handle[:raw.size].copy_(self._pin[off:off + raw.size], non_blocking=True)
+        ev = self.torch.cuda.Event()
+        ev.record(st)
+        slot[2] = ev
 
 
 # What the launch planner reads of an object, for tables whose 256-byte rows live on the device (device_table.DeviceTable):

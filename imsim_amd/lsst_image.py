@@ -202,7 +202,13 @@ class LSST_PhotonPoolingImageBuilder(LSST_ImageBuilderBase):
         modes[fft_rows] = stamp.ProcessingMode.FFT
         realized = torch.zeros(len(objects), dtype=torch.float64, device=renderer.device)
         fft_flux = np.zeros(len(objects))
-        if fft_rows.any():
+        chk_name = "buildImage_photonpooling_" + str(self.det_name)
+        # a checkpoint of this CCD: its image already holds the FFT objects, and their fluxes sit in a record of their own
+        resumed_fft = checkpoint.load(chk_name + "_fft") if checkpoint is not None else None
+        if resumed_fft is not None and checkpoint.load(chk_name) is not None:
+            fft_flux[...] = resumed_fft[0]
+            realized.copy_(torch.from_numpy(np.asarray(resumed_fft[1])).to(renderer.device))
+        elif fft_rows.any():
             if kpsf is None:
                 raise GalSimConfigError("FFT drawing needs the k-space PSF description")
             idx_fft = np.flatnonzero(fft_rows)
@@ -224,12 +230,14 @@ class LSST_PhotonPoolingImageBuilder(LSST_ImageBuilderBase):
                 drawer.draw(rows, realized=r_fft)
                 realized.index_add_(0, torch.from_numpy(batch[order]).to(renderer.device), r_fft)
                 fft_flux[batch] = fflux
+            if checkpoint is not None:
+                checkpoint.save(chk_name + "_fft", (fft_flux.copy(), realized.cpu().numpy()))
         pidx = np.flatnonzero(~fft_rows)
         if len(pidx):
             r_ph = torch.zeros(len(pidx), dtype=torch.float64, device=renderer.device)
             photon_pooling.build_image(renderer, objects[pidx], modes[pidx], nbatch=self.nbatch, nsubbatch=self.nsubbatch, seed=seed,
-                                       realized=r_ph, checkpoint=checkpoint,
-                                       chk_name="buildImage_photonpooling_" + str(self.det_name))
+                                       realized=r_ph, checkpoint=checkpoint, chk_name=chk_name,
+                                       nbatch_per_checkpoint=self.nbatch_per_checkpoint)
             realized.index_add_(0, torch.from_numpy(pidx).to(renderer.device), r_ph)
         if truth is not None:
             truth["index"] = keep

@@ -190,6 +190,7 @@ def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1,
         return np.argsort(tile, kind="stable")
 
     shoot, launches = None, []
+    r_rows = None
     if resident:
         shoot_table = tidy(objects[shot].copy())
         if world > 1 or os.environ.get("IMS_POOL_SPATIAL", "1") != "0":
@@ -234,10 +235,13 @@ def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1,
                     parallel.allreduce_delta(renderer.delta_tensor(0), integer_counts=unit)
                 renderer.update_distortions(0, 1, bf_tag=((i - 1) % 255 + 1) if tagged else 0)
             launch()
+            if realized is not None and r_rows is not None:
+                # batch by batch, so that a checkpoint taken after batch i carries the fluxes up to batch i
+                realized.index_add_(0, shot_t, r_rows)
+                r_rows.zero_()
             if after_batch is not None:
                 after_batch(i)
-        if realized is not None:
-            realized.index_add_(0, renderer.torch.from_numpy(shot).to(renderer.device), r_rows)
+    shot_t = renderer.torch.from_numpy(shot).to(renderer.device) if realized is not None and shoot is not None else None
     if shoot is not None:
         run.photons, run.object_rows = shoot.photons, shoot.object_rows
         # the pool shoot is the dominant launch: 32 B per converted photon written + one 256-B row per object
@@ -333,7 +337,7 @@ def _prepared_image_device(renderer, table, modes, nbatch, seed, rank, world, re
 
 
 def build_image(renderer, objects, modes, nbatch=10, nsubbatch=50, seed=0, realized=None, rank=0, world=1,
-                checkpoint=None, chk_name="buildImage_photonpooling"):
+                checkpoint=None, chk_name="buildImage_photonpooling", nbatch_per_checkpoint=1):
     """LSST_PhotonPoolingImageBuilder.buildImage for the photon-shooting objects
     (imsim/photon_pooling.py:116-168).
 
@@ -348,25 +352,43 @@ def build_image(renderer, objects, modes, nbatch=10, nsubbatch=50, seed=0, reali
     updatePixelDistortions; the per-rank images are summed by the caller (parallel.reduce_image).  Unit
     fluxes make both sums exact, so the result equals the single-process one bit for bit.
 
-    checkpoint (a checkpoint.Checkpointer): after every photon batch the image and the number of finished batches
-    are saved under chk_name; a later call finds them, restores the image and skips those batches
-    (imsim/photon_pooling.py:57-62, :129-136, :166-167).  As in the reference the sensor state is not part of the
-    record: a resumed CCD continues from fresh (tree-ring only) pixel boundaries."""
+    checkpoint (a checkpoint.Checkpointer): after every nbatch_per_checkpoint-th photon batch (and the last one) the image,
+    the number of finished batches and the realized fluxes so far are saved under chk_name (with several ranks: chk_name +
+    "_rank<r>", every rank its own partial image); a later call finds them, restores image and fluxes and skips those
+    batches (imsim/photon_pooling.py:57-62, :129-136, :166-167, lsst_image.py:376-389 for the gate).  As in the reference
+    the sensor state is not part of the record: a resumed CCD continues from fresh (tree-ring only) pixel boundaries."""
     objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
     batch_tables, len_smallest = make_batch_tables(objects, modes, nbatch, seed)
     total = 0
     first_batch = 0
+    if world > 1:
+        chk_name = f"{chk_name}_rank{rank}"
+    every = max(int(nbatch_per_checkpoint), 1)
+
+    def record(i):
+        """what is saved after batch i"""
+        r = realized.cpu().numpy() if realized is not None and hasattr(realized, "cpu") else (None if realized is None else np.array(realized))
+        return (renderer.image64_numpy(), i + 1, r)
+
+    def due(i):
+        return (i + 1) % every == 0 or i + 1 == len(batch_tables)
+
     if checkpoint is not None:
         saved = checkpoint.load(chk_name)
         if saved is not None:
-            image, first_batch = saved
+            image, first_batch = saved[0], saved[1]
             renderer.set_image64(image)
+            if realized is not None and len(saved) > 2 and saved[2] is not None:
+                if hasattr(realized, "copy_"):
+                    realized.copy_(renderer.torch.from_numpy(np.asarray(saved[2])).to(realized.device))
+                else:
+                    realized[...] = saved[2]
     if _pool_fits(renderer, sum(int(t["n_phot"].sum()) for t, _ in batch_tables)):
         # the HBM-resident form (prepared_image): all photons shot once, every batch only the pixel search of its share --
         # the sub-batches of the reference bound the memory of its photon arrays and do not change the image
         def save(i):
-            if checkpoint is not None:
-                checkpoint.save(chk_name, (renderer.image64_numpy(), i + 1))
+            if checkpoint is not None and due(i):
+                checkpoint.save(chk_name, record(i))
         if first_batch < len(batch_tables):
             prepared_image(renderer, objects, modes, nbatch=nbatch, seed=seed, rank=rank, world=world, resident=True,
                            realized=realized, after_batch=save, first_batch=first_batch)()
@@ -417,6 +439,6 @@ def build_image(renderer, objects, modes, nbatch=10, nsubbatch=50, seed=0, reali
             if realized is not None:
                 realized.index_add_(0, renderer.torch.from_numpy(idx).to(renderer.device), tmp)
             total += int(t["n_phot"].sum())
-        if checkpoint is not None:
-            checkpoint.save(chk_name, (renderer.image64_numpy(), i + 1))
+        if checkpoint is not None and due(i):
+            checkpoint.save(chk_name, record(i))
     return total

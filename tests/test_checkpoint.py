@@ -76,3 +76,19 @@ def test_photon_pooling_resumes_after_the_last_finished_batch(tmp_path):
     again = orc_loader.OracleScene(scene)
     photon_pooling.build_image(again, objects, modes, nbatch=5, nsubbatch=3, seed=3, checkpoint=Checkpointer("ccd.hdf", dir=str(tmp_path)))
     assert np.array_equal(again.image64, full.image64)
+
+
+def test_checkpoints_are_gated_by_nbatch_per_checkpoint(tmp_path):
+    """imsim/lsst_image.py:376-389: a record every nbatch_per_checkpoint batches, and after the last one"""
+    from oracle import orc_loader
+    scene, objects = c3_small_case(n_obj=60, n=128, flux_seed=6, sensor=False)
+    modes = stamp.classify(objects["n_phot"].astype(float), 100.0)
+    saved = []
+
+    class Counting(Checkpointer):
+        def save(self, name, data):
+            saved.append(data[1])
+            super().save(name, data)
+    photon_pooling.build_image(orc_loader.OracleScene(scene), objects, modes, nbatch=5, nsubbatch=3, seed=3,
+                               checkpoint=Counting("gate.hdf", dir=str(tmp_path)), nbatch_per_checkpoint=2)
+    assert saved == [2, 4, 5]

@@ -875,6 +875,44 @@ def test_photon_pooling_build_image_is_bit_exact(torch_cuda):
     assert_bits_equal(r2.image_numpy(), orc.image, "replayed pooling image")
 
 
+def test_resumed_pooling_ccd_restores_image_and_realized_fluxes(torch_cuda, tmp_path):
+    """A photon-pooling CCD interrupted after its second batch and resumed (HBM-resident form): the record carries the image,
+    the finished batches and the realized fluxes up to them, so the resumed run ends with the image AND the per-object fluxes
+    of the uninterrupted one (no sensor: nothing depends on when a batch runs)."""
+    from helpers import c3_small_case
+    from imsim_amd import photon_pooling, stamp
+    from imsim_amd.checkpoint import Checkpointer
+    from imsim_amd.engine import Renderer
+    scene, objects = c3_small_case(n_obj=120, n=128, flux_seed=8, sensor=False)
+    modes = stamp.classify(objects["n_phot"].astype(float), 100.0)
+    full = Renderer(scene)
+    real_full = torch_cuda.zeros(len(objects), dtype=torch_cuda.float64, device="cuda")
+    photon_pooling.build_image(full, objects, modes, nbatch=5, seed=3, realized=real_full)
+    full.synchronize()
+
+    class Interrupt(Exception):
+        pass
+
+    class Dying(Checkpointer):
+        def save(self, name, data):
+            super().save(name, data)
+            if data[1] == 2:
+                raise Interrupt()
+    first = Renderer(scene)
+    real = torch_cuda.zeros(len(objects), dtype=torch_cuda.float64, device="cuda")
+    with pytest.raises(Interrupt):
+        photon_pooling.build_image(first, objects, modes, nbatch=5, seed=3, realized=real, checkpoint=Dying("c.hdf", dir=str(tmp_path)))
+    resumed = Renderer(scene)
+    real2 = torch_cuda.zeros(len(objects), dtype=torch_cuda.float64, device="cuda")
+    chk = Checkpointer("c.hdf", dir=str(tmp_path))
+    photon_pooling.build_image(resumed, objects, modes, nbatch=5, seed=3, realized=real2, checkpoint=chk)
+    resumed.synchronize()
+    assert chk.load("buildImage_photonpooling")[1] == 5
+    assert 0 < real.sum().item() < real_full.sum().item()
+    assert_bits_equal(resumed.image_numpy(), full.image_numpy(), "resumed image")
+    assert_bits_equal(real2.cpu().numpy(), real_full.cpu().numpy(), "resumed realized fluxes")
+
+
 def test_photon_flat_is_bit_exact_and_shows_brighter_fatter(torch_cuda):
     """LSST_Flat, sed branch (imsim/flat.py:237-262): small case bit-exact vs the oracle; reference-sized case
     (256^2, 80 000 e-/px in 20 iterations) has variance below the mean and positive neighbour covariances."""

@@ -688,7 +688,10 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
                 xarr, yarr = np.meshgrid(np.arange(nx), np.arange(ny))
                 fmap = fr.calculate_fringe_amplitude(xarr, yarr)
                 mult = fmap if mult is None else mult * fmap
-            builder.add_noise(renderer, float(sky), seed=seed_ccd, multiplier=mult)
+            # a Silicon sensor's pixels collect sky in proportion to their (tree-ring distorted) area; image.use_flux_sky_areas
+            # adds the one-step brighter-fatter distortion from the flux already drawn (config/imsim-config.yaml:222-228)
+            areas = builder.sky_pixel_areas(renderer, use_flux=bool(ev.value(image.get("use_flux_sky_areas", False))))
+            builder.add_noise(renderer, float(sky), seed=seed_ccd, multiplier=mult, pixel_areas=areas)
         elif "sky_level" in image:
             res.ignored.append("image.sky_level")
         renderer.synchronize()

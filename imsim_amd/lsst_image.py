@@ -79,18 +79,52 @@ class LSST_ImageBuilderBase:
             kw["jac_det"] = sub["mu"]                        # shear preserves area; the lens magnifies it by mu
         return fft_draw.use_fft(nominal, sub["kind"], sub["hlr"], fwhm_total, fft_sb_thresh, **kw)
 
-    def add_noise(self, renderer, sky_level, pixel_scale=0.2, sky_gradient=None, multiplier=None, seed=0, stream_id=0):
+    def sky_pixel_areas(self, renderer, use_flux=False):
+        """Pixel areas for drawing the sky on a Silicon sensor (`sensor.calculate_pixel_areas(image, use_flux=...)`, which
+        GalSim's sky image is multiplied by; `image.use_flux_sky_areas`, config/imsim-config.yaml:222-228): the polygon areas
+        of the CCD's boundary state -- tree rings only by default, or (use_flux) distorted in ONE step by the flux already in
+        the image, after which the state is put back (LSST_Image keeps slot 0 static).  Device tensor [ny][nx], or None
+        without a Silicon sensor."""
+        from . import _abi
+        sc = renderer.scene
+        if sc.sensor is None:
+            return None
+        torch = renderer.torch
+        b = renderer.bound
+        sl = b._slots_host[0]
+        if (int(sl["xmin"]), int(sl["ymin"]), int(sl["nx"]), int(sl["ny"])) != (sc.xmin, sc.ymin, sc.nx, sc.ny) or int(sl["offset"]) != 0:
+            raise ValueError("sky_pixel_areas expects slot 0 to be the whole image")
+        if use_flux:
+            # the charge of the image as the delta-charge image of slot 0 ((nx + 1) x (ny + 1) owner cells), one recalculation
+            delta = renderer.delta_tensor(0).view(sc.ny + 1, sc.nx + 1)
+            delta.zero_()
+            delta[:sc.ny, :sc.nx] = renderer.image
+            renderer.update_distortions(0, 1)
+        area = torch.empty(sc.nx * sc.ny, dtype=torch.float64, device=renderer.device)
+        acc = torch.zeros(1, dtype=torch.int64, device=renderer.device)
+        _abi.check(renderer.lib.ims_sensor_pixel_areas(b.sensor_dev_ptr, _abi.C.byref(b.sensor_host), 0, area.data_ptr(),
+                                                       acc.data_ptr(), renderer._stream()), "ims_sensor_pixel_areas")
+        if use_flux:
+            renderer.init_boundaries(0, 1)                  # back to the undistorted (+ tree ring) state the objects were drawn on
+        return area.view(sc.ny, sc.nx)
+
+    def add_noise(self, renderer, sky_level, pixel_scale=0.2, sky_gradient=None, multiplier=None, seed=0, stream_id=0,
+                  pixel_areas=None):
         """addNoise (imsim/lsst_image.py:128-200): sky = sky_level [photons/arcsec^2] x pixel area, optionally
         times a linear sky gradient (a, b, c): factor = a + b x + c y in 0-based pixel indices (SkyGradient,
         sky_model.py) and a per-pixel multiplier map [ny][nx] (vignetting x fringing); the image receives a
         Poisson deviate of that expectation per pixel (the objects already carry their own shot noise).  The
-        Rubin sky-brightness model that supplies sky_level in the reference is out of scope: pass the number."""
+        Rubin sky-brightness model that supplies sky_level in the reference is out of scope: pass the number.
+        pixel_areas: device tensor [ny][nx] from sky_pixel_areas (a Silicon sensor's pixels collect sky in proportion to
+        their area), folded into the multiplier."""
         from . import _abi
         torch = renderer.torch
         sc = renderer.scene
         base_t = None
-        if sky_gradient is not None or multiplier is not None:
+        if sky_gradient is not None or multiplier is not None or pixel_areas is not None:
             m = torch.ones((sc.ny, sc.nx), dtype=torch.float64, device=renderer.device)
+            if pixel_areas is not None:
+                m = m * pixel_areas
             if sky_gradient is not None:
                 a, b, c = (float(v) for v in sky_gradient)
                 xx = torch.arange(sc.nx, dtype=torch.float64, device=renderer.device)[None, :]

@@ -839,6 +839,50 @@ def test_sky_background_and_noise(torch_cuda):
     assert_bits_equal(img, orc.image64, "sky noise")
 
 
+def test_sky_follows_the_pixel_areas_of_the_silicon_sensor(torch_cuda):
+    """`sensor.calculate_pixel_areas` under the sky (image.use_flux_sky_areas, config/imsim-config.yaml:222-228): with a
+    Silicon sensor the sky expectation of a pixel is proportional to its polygon area -- tree rings by default (areas equal
+    to the oracle's, and the sky image to the oracle's deviates of that expectation), and with use_flux the one-step
+    brighter-fatter distortion from the flux already drawn: the pixels under a bright star shrink, and the boundary state is
+    the static one again afterwards."""
+    from imsim_amd import lsst_image
+    from imsim_amd.engine import Renderer
+    from oracle import orc_loader
+    scene, objects = _c3_case(n_obj=60)
+    r = Renderer(scene)
+    b = lsst_image.LSST_ImageBuilder()
+    static = _sensor_arrays_gpu(r)["boundary"].copy()
+    areas = b.sky_pixel_areas(r)
+    orc = orc_loader.OracleScene(scene)
+    n = scene.nx * scene.ny
+    want = np.empty(n)
+    acc = np.zeros(1, dtype=np.int64)
+    orc.lib.orc_sensor_pixel_areas(orc.bound.sensor_dev_ptr, 0, want.ctypes.data, acc.ctypes.data)
+    assert_bits_equal(areas.cpu().numpy().ravel(), want, "tree-ring pixel areas")
+    assert 1e-5 < want.std() < 1e-2 and abs(want.mean() - 1.0) < 1e-3
+    b.add_noise(r, sky_level=20000.0, seed=5, pixel_areas=areas)
+    r.synchronize()
+    base = np.ascontiguousarray(want.reshape(scene.ny, scene.nx))
+    orc.lib.orc_flat_add(None, base.ctypes.data, 20000.0 * 0.2 * 0.2, 1.0, 5, lsst_image.NOISE_STREAM, scene.nx, scene.ny,
+                         orc.image64.ctypes.data, None)
+    assert_bits_equal(r.image.cpu().numpy(), orc.image64, "sky on tree-ring pixel areas")
+    # use_flux: draw the objects first, then the areas see their charge
+    r2 = Renderer(scene)
+    bright = objects.copy()
+    k = int(np.argmax(bright["prof_table"] == -1))               # a point source made bright
+    bright["n_phot"][k] = 800000
+    r2.render_lsst_image(bright)
+    flux_areas = b.sky_pixel_areas(r2, use_flux=True).cpu().numpy()
+    img = r2.image.cpu().numpy()
+    peak = np.unravel_index(np.argmax(img), img.shape)
+    assert img[peak] > 1e4
+    assert flux_areas[peak] < want.reshape(scene.ny, scene.nx)[peak] - 2e-4          # a charged pixel repels: it gets smaller
+    assert abs(flux_areas.mean() - 1.0) < 1e-3
+    r2.synchronize()
+    n0 = (scene.nx + 1) * (scene.ny + 1) * 2 * scene.sensor.owned_points()        # the owner cells of slot 0
+    assert_bits_equal(_sensor_arrays_gpu(r2)["boundary"][:n0], static[:n0], "slot 0 back to its static state")
+
+
 def test_photon_pooling_build_image_is_bit_exact(torch_cuda):
     """C4 semantics end to end (imsim/photon_pooling.py:116-168): nbatch photon batches, nsubbatch object sub-batches,
     one pixel-boundary recalculation per batch (tile-tagged on the GPU) -- image and boundaries equal the oracle's."""

@@ -607,7 +607,9 @@ BENCH_CONFIGS["c5"] = dict(
     n_objects=N_CCD_FOCAL_PLANE * 10000,
     workload="C5: 189-CCD focal plane, 10k-source synthetic catalog per CCD (own catalog, seed and photon streams), every CCD "
              "an independent LSST_Image build (C3 physics: full photon-op chain, Silicon brighter-fatter + tree rings) through a "
-             "fresh renderer on its own stream, CCD i -> GPU i mod N, image back on the host; host object tables are inputs",
+             "fresh renderer on its own stream, CCD i -> GPU i mod N, image back on the host; host object tables are inputs; "
+             "draw_method by the reference's rule (FFT only above 1e6 e- AND a peak surface brightness above fft_sb_thresh = "
+             "2e5, config/imsim-config.yaml): no object of this catalog qualifies, so every object is photon-shot",
     scene=_c5_scene_bench,
     catalog=_c5_catalog,
     objects=_c5_objects,

@@ -288,15 +288,87 @@ IMS_DEV void gauss_pair(Draw d, double& g0, double& g1)
     g0 = r * c; g1 = r * s;
 }
 
+// Deviates from 32-bit words (spec v6).  The argument (w + 1/2) / 2^32 has a granularity of 2^-32, so the series are cut
+// where the truncation error falls below 2^-36 of the result (sine to t^11, cosine to t^12, the logarithm's atanh series to
+// s^13), and the quadrant reduction of the angle is integer work on the word itself; t is the same product as in sincos2pi.
+IMS_DEV double sin_kernel_w(double t, double z)
+{
+    double p = -1.0 / 39916800.0;
+    p = fma_k(p, z, 1.0 / 362880.0);
+    p = fma_k(p, z, -1.0 / 5040.0);
+    p = fma_k(p, z, 1.0 / 120.0);
+    p = fma_k(p, z, -1.0 / 6.0);
+    return fma(t * z, p, t);
+}
+IMS_DEV double cos_kernel_w(double z)
+{
+    double p = 1.0 / 479001600.0;
+    p = fma_k(p, z, -1.0 / 3628800.0);
+    p = fma_k(p, z, 1.0 / 40320.0);
+    p = fma_k(p, z, -1.0 / 720.0);
+    p = fma_k(p, z, 1.0 / 24.0);
+    p = fma(p, z, -0.5);
+    return fma(z, p, 1.0);
+}
+// sin, cos of 2 pi (w + 1/2) / 2^32
+IMS_DEV void sincos2pi_w(uint32_t w, double& s, double& c)
+{
+    const uint32_t q = (w + 0x20000000u) >> 30;              // nearest quarter turn, modulo 4
+    const int32_t ri = (int32_t)(w - (q << 30));             // offset from it in units of 2^-32 turns, [-2^29, 2^29)
+    const double t = fma((double)ri, 0x1.0p-32, 0x1.0p-33) * TWO_PI;
+    const double z = t * t;
+    const double sk = sin_kernel_w(t, z), ck = cos_kernel_w(z);
+    const bool odd = (q & 1u) != 0u;
+    const double s0 = odd ? ck : sk, c0 = odd ? sk : ck;
+    const unsigned long long sbit = (unsigned long long)(q & 2u) << 62;               // q = 2, 3: sin negative
+    const unsigned long long cbit = (unsigned long long)((q + 1u) & 2u) << 62;        // q = 1, 2: cos negative
+    s = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(s0) ^ sbit));
+    c = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(c0) ^ cbit));
+}
+// log((w + 1/2) / 2^32)
+IMS_DEV double dlog_w(uint32_t w)
+{
+    const double x = w01(w);
+    const uint64_t b = (uint64_t)__double_as_longlong(x);
+    int64_t e = (int64_t)((b >> 52) & 0x7FF) - 1023;
+    double m = __longlong_as_double((long long)((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull));
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double s = ddiv(m - 1.0, m + 1.0);
+    const double z = s * s;
+    double p = 1.0 / 13.0;
+    p = fma_k(p, z, 1.0 / 11.0);
+    p = fma_k(p, z, 1.0 / 9.0);
+    p = fma_k(p, z, 1.0 / 7.0);
+    p = fma_k(p, z, 1.0 / 5.0);
+    p = fma_k(p, z, 1.0 / 3.0);
+    p = fma(p, z, 1.0);
+    const double lm = 2.0 * s * p;
+    const double de = (double)e;
+    return fma(de, LN2_HI, fma(de, LN2_LO, lm));
+}
+
 IMS_DEV void gauss_words(uint32_t w0, uint32_t w1, double& g0, double& g1)
 {
-    const double r = dsqrt_n(-2.0 * dlog(w01(w0)));      // w01 < 1: the argument is > 0
+    const double r = dsqrt_n(-2.0 * dlog_w(w0));      // w01 < 1: the argument is > 0
     double s, c;
-    sincos2pi(w01(w1), s, c);
+    sincos2pi_w(w1, s, c);
     g0 = r * c; g1 = r * s;
 }
 
-// RNG slots and word assignment (spec v4)
+// one Gaussian deviate from two words: the cosine half of the pair above, bit for bit
+IMS_DEV double gauss_word_cos(uint32_t w0, uint32_t w1)
+{
+    const double r = dsqrt_n(-2.0 * dlog_w(w0));
+    const uint32_t q = (w1 + 0x20000000u) >> 30;
+    const int32_t ri = (int32_t)(w1 - (q << 30));
+    const double t = fma((double)ri, 0x1.0p-32, 0x1.0p-33) * TWO_PI;
+    const double z = t * t;
+    const double c0 = (q & 1u) ? sin_kernel_w(t, z) : cos_kernel_w(z);
+    const unsigned long long cbit = (unsigned long long)((q + 1u) & 2u) << 62;
+    return r * __longlong_as_double((long long)((unsigned long long)__double_as_longlong(c0) ^ cbit));
+}
+
+// RNG slots and word assignment (spec v6)
 constexpr uint32_t SLOT_SHOOT = 0;        // w0 wavelength, w1 profile radius, w2 profile angle
 constexpr uint32_t SLOT_KNOT = 1;         // photon index = knot index: w0,w1 Gaussian position of a RandomKnots point
 constexpr uint32_t SLOT_PSF = 2;          // + (component >> 1); component c owns words 2(c&1), 2(c&1)+1

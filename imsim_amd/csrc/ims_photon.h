@@ -87,7 +87,7 @@ IMS_DEV void shoot(const ims_render_params_t& P, const ims_object_t& o, int64_t 
             const double r2 = radial_r2(P.radial, o.prof_table, w01(rng.w[1]));
             const double r = dsqrt0(r2) * o.prof_scale;
             double s, c;
-            sincos2pi(w01(rng.w[2]), s, c);
+            sincos2pi_w(rng.w[2], s, c);
             gu = r * c; gv = r * s;
         } else if (o.prof_table == IMS_PROF_BOX) {
             gu = (w01(rng.w[1]) - 0.5) * o.prof_scale;
@@ -212,7 +212,7 @@ IMS_DEV void apply_psf(const ims_render_params_t& P, const ims_object_t& o, int 
         const ims_atmosphere_t& A = *P.atm;
         const double r = dsqrt0(A.aper_ri2 + w01(wa) * A.aper_dr2);
         double s, cc;
-        sincos2pi(w01(wb), s, cc);
+        sincos2pi_w(wb, s, cc);
         const double pu = r * cc, pv = r * s;
         rng_block(rng, P.seed, o.obj_id, k, SLOT_PSF_TIME + (uint32_t)comp);
         const double t = A.t0 + w01(rng.w[0]) * A.exptime;
@@ -229,7 +229,7 @@ IMS_DEV void apply_psf(const ims_render_params_t& P, const ims_object_t& o, int 
         const double r2 = radial_r2(P.radial, c.table, w01(wa));
         const double r = dsqrt0(r2) * scale;
         double s, cc;
-        sincos2pi(w01(wb), s, cc);
+        sincos2pi_w(wb, s, cc);
         ku = r * cc; kv = r * s;
     }
     ph.x = ph.x + (o.winv[0] * ku + o.winv[1] * kv);
@@ -358,18 +358,12 @@ IMS_DEV void wcs_vec_to_pix(const ims_tansip_t& w, const double (&p)[3], double&
 
 IMS_DEV void xy_to_v(const ims_optics_t& o, double x, double y, double wave_nm, double (&v)[3])
 {
+    // spec v6: the direction (tan theta_x, tan theta_y, -1) as it is -- nothing downstream needs |v| = 1/n (the kick of
+    // diffract() is proportional to v_z, reflection and refraction are homogeneous in v, the slopes are ratios)
     double p[3], thx, thy;
-#ifdef IMS_EXP_XYV_LINEAR
-    thx = o.img_wcs.cd[0] * (x - o.img_wcs.crpix[0]) + o.img_wcs.cd[1] * (y - o.img_wcs.crpix[1]);
-    thy = o.img_wcs.cd[2] * (x - o.img_wcs.crpix[0]) + o.img_wcs.cd[3] * (y - o.img_wcs.crpix[1]);
-    (void)p;
-#else
     wcs_pix_to_vec(o.img_wcs, x, y, p);
     wcs_vec_to_pix(o.icrf_to_field, p, thx, thy);
-#endif
-    const double n = medium_n(o.in_medium_kind, o.in_medium_c, wave_nm);
-    const double gn = ddiv(1.0, n * dsqrt_n(1.0 + thx * thx + thy * thy));
-    v[0] = thx * gn; v[1] = thy * gn; v[2] = -gn;
+    v[0] = thx; v[1] = thy; v[2] = -1.0;
 }
 IMS_DEV void v_to_xy(const ims_optics_t& o, const double (&v)[3], double& x, double& y)
 {
@@ -433,11 +427,9 @@ IMS_DEV void diffract(const ims_optics_t& o, bool field_rot, double pu, double p
     const double sx = dtp * vz * nx, sy = dtp * vz * ny;
     const double rx = c * sx + s * sy;
     const double ry = -s * sx + c * sy;
-    const double before = dsqrt_n(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    // spec v6: the reference rescales v to its old length here (imsim/diffraction.py:45-66); every consumer of v is
+    // homogeneous in it, so the direction alone is kept
     v[0] = v[0] + rx; v[1] = v[1] + ry;
-    const double after = dsqrt_n(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-    const double fs = ddiv(before, after);
-    v[0] = v[0] * fs; v[1] = v[1] * fs; v[2] = v[2] * fs;
 }
 
 // ---------------- sequential ray trace ----------------
@@ -456,7 +448,8 @@ IMS_DEV bool obscured(const ims_surface_t& S, double r2)
 
 // Propagate to surface S (spec v5): plane exact; conic by the closed-form root of smaller
 // |t|, with the un-normalised normal (-c x, -c y, 1-(1+k) c z) that needs no sqrt; even-asphere terms
-// by Newton on the implicit conic form from the conic root until |G| <= 2e-11.
+// by Newton on the implicit conic form from the conic root until |G| <= 1e-8 (spec v6: 10 nm of sag, < 5e-4 pixel at the
+// detector; one step from the conic root for the Rubin mirrors, whose residual is then <= 8e-9 on M2 and <= 2e-10 elsewhere).
 // SHAPE: the surface's form as a compile-time constant (trace_seq: kernels specialised for an optics layout) -- 0 plane,
 // 1 conic with R != 0 and no asphere terms, 2 conic with R != 0 and asphere terms; -1 = read it from the descriptor.
 constexpr int SH_PLANE = 0, SH_CONIC = 1, SH_ASPHERE = 2;
@@ -512,7 +505,7 @@ IMS_DEV bool surf_hit(const ims_surface_t& S, double (&pos)[3], const double (&v
             w = z - p;
             const double k1w = k1 * w;
             const double G = fma(c, fma(k1w, w, r2), -2.0 * w);
-            if (fabs(G) <= 2.0e-11 || it == 5) break;
+            if (fabs(G) <= 1.0e-8 || it == 5) break;
             const double s = fma(x, vel[0], y * vel[1]);
             const double wp = fma(-2.0 * dp, s, vel[2]);
             const double Gp = 2.0 * fma(c, fma(k1w, wp, s), -wp);
@@ -550,9 +543,11 @@ IMS_DEV bool trace_step(const ims_surface_t& S, TraceState& st, double (&pos)[3]
     if (obscured(S, r2)) st.vignetted = 1;
     if (kind == IMS_SURF_BAFFLE || kind == IMS_SURF_DETECTOR) return true;
     if (kind == IMS_SURF_MIRROR) {
+        // spec v6: (N.N) v - 2 (v.N) N, the reflected direction times |N|^2 -- no division; the length of the velocity
+        // carries no information (every later use is homogeneous in it)
         const double vn = fma(vel[0], N[0], fma(vel[1], N[1], vel[2] * N[2]));
-        const double d = ddiv(2.0 * vn, nn);
-        vel[0] = fma(-d, N[0], vel[0]); vel[1] = fma(-d, N[1], vel[1]); vel[2] = fma(-d, N[2], vel[2]);
+        const double d = 2.0 * vn;
+        vel[0] = fma(nn, vel[0], -(d * N[0])); vel[1] = fma(nn, vel[1], -(d * N[1])); vel[2] = fma(nn, vel[2], -(d * N[2]));
     } else {
         double n2, in2;
         if (S.medium_kind == IMS_MEDIUM_CONST) { n2 = S.medium_c[0]; in2 = S.medium_c[1]; }
@@ -562,23 +557,23 @@ IMS_DEV bool trace_step(const ims_surface_t& S, TraceState& st, double (&pos)[3]
             in2 = ddiv(1.0, n2);
             st.glass_id = S.medium_id; st.glass_n = n2; st.glass_in = in2;
         }
-        // Snell with the un-normalised normal (spec v5): a = n1 (v.N) is the cosine of incidence times |N|; with
-        // eta = n1/n2 the new velocity is eta^2 v - (nfac / n2) N
+        // Snell with un-normalised velocity and normal (spec v6).  With eta = n1 / n2, c = v.N / (|v| |N|) the refracted unit
+        // vector is eta v^ - (eta c - sign(c) sqrt(1 - eta^2 (1 - c^2))) N^; times |v| |N|^2 that is
+        //   eta (N.N) v - (eta (v.N) - sign(v.N) sqrt(D)) N,   D = (v.v)(N.N) + eta^2 ((v.N)^2 - (v.v)(N.N)),
+        // one square root and no division; D < 0 is total internal reflection
         const double vn = fma(vel[0], N[0], fma(vel[1], N[1], vel[2] * N[2]));
-        double a = st.n_cur * vn;
-        double sgn = 1.0;
-        if (a > 0.0) { sgn = -1.0; a = -a; }
+        const double v2 = fma(vel[0], vel[0], fma(vel[1], vel[1], vel[2] * vel[2]));
         const double eta = st.n_cur * in2;
-        const double inn = ddiv(1.0, nn);
-        const double ai = a * inn;
         const double e2 = eta * eta;
-        const double sinsqr = e2 * fma(-a, ai, 1.0);
-        if (sinsqr > 1.0) return false;
-        const double nfac = sgn * fma(eta, ai, dsqrt0(fma(-sinsqr, inn, inn)));
-        const double nf2 = nfac * in2;
-        vel[0] = fma(e2, vel[0], -(nf2 * N[0]));
-        vel[1] = fma(e2, vel[1], -(nf2 * N[1]));
-        vel[2] = fma(e2, vel[2], -(nf2 * N[2]));
+        const double v2nn = v2 * nn;
+        const double D = fma(e2, fma(vn, vn, -v2nn), v2nn);
+        if (D < 0.0) return false;
+        const double sq = dsqrt0(D);
+        const double q = fma(eta, vn, vn < 0.0 ? sq : -sq);
+        const double en = eta * nn;
+        vel[0] = fma(en, vel[0], -(q * N[0]));
+        vel[1] = fma(en, vel[1], -(q * N[1]));
+        vel[2] = fma(en, vel[2], -(q * N[2]));
         st.n_cur = n2;
     }
     return true;
@@ -647,7 +642,7 @@ IMS_DEV void rubin_op(const ims_render_params_t& P, const ims_op_t& op, int kind
     if (do_diff) {
         double g0, g1;
         rng_block(rng, P.seed, o.obj_id, k, SLOT_OP + ((uint32_t)op_index >> 1));
-        gauss_words((op_index & 1) ? rng.w[2] : rng.w[0], (op_index & 1) ? rng.w[3] : rng.w[1], g0, g1);
+        g0 = gauss_word_cos((op_index & 1) ? rng.w[2] : rng.w[0], (op_index & 1) ? rng.w[3] : rng.w[1]); g1 = 0.0;
         diffract(opt, frot, ph.pu, ph.pv, ph.t, ph.wl * 1.0e-9, g0, v);
     }
     if (!do_trace) { v_to_xy(opt, v, ph.x, ph.y); return; }
@@ -689,7 +684,7 @@ IMS_DEV void apply_op(const ims_render_params_t& P, int op_index, const ims_obje
         rng_block(rng, P.seed, o.obj_id, k, slot);
         const double r = dsqrt0(op.p[2] + w01(wsel ? rng.w[2] : rng.w[0]) * op.p[3]);      // p2 = R_inner^2, p3 = R_outer^2 - R_inner^2
         double s, c;
-        sincos2pi(w01(wsel ? rng.w[3] : rng.w[1]), s, c);
+        sincos2pi_w(wsel ? rng.w[3] : rng.w[1], s, c);
         ph.pu = r * c; ph.pv = r * s;
         break; }
     case IMS_OP_PHOTON_DCR: {
@@ -936,7 +931,7 @@ IMS_DEV bool land_convert(const ims_render_params_t& P, const ims_object_t& o, i
     if (!(f > 0.0)) abs_len = s.abs_len[0];
     else if (f >= (double)(s.n_abs - 1)) abs_len = s.abs_len[s.n_abs - 1];
     else { const int t = (int)f; const double a = f - (double)t; const double v0 = s.abs_len[t]; abs_len = v0 + a * (s.abs_len[t + 1] - v0); }
-    const double si_length = -abs_len * dlog(w01(rng.w[2]));
+    const double si_length = -abs_len * dlog_w(rng.w[2]);
     double dz = si_length;
     if (has_angles) {
         dz = ddiv(si_length, dsqrt_n(1.0 + ph.dxdz * ph.dxdz + ph.dydz * ph.dydz));

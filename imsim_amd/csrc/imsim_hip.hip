@@ -1766,7 +1766,7 @@ __global__ __launch_bounds__(256) void k_screen_gather(const ims_render_params_t
     const uint32_t wa = (comp & 1) ? rng.w[2] : rng.w[0], wb = (comp & 1) ? rng.w[3] : rng.w[1];
     const double r = dsqrt0(A.aper_ri2 + w01(wa) * A.aper_dr2);
     double s, cc;
-    sincos2pi(w01(wb), s, cc);
+    sincos2pi_w(wb, s, cc);
     const double pu = r * cc, pv = r * s;
     rng_block(rng, P.seed, o.obj_id, k, SLOT_PSF_TIME + (uint32_t)comp);
     const double t = A.t0 + w01(rng.w[0]) * A.exptime;
@@ -1975,6 +1975,10 @@ __global__ void k_test_math(int which, const double* __restrict__ in, double* __
     case 9: out[i] = dsqrt0(in[i]); break;
     case 6: { Rng r; rng_reset(r); rng_block(r, seed, obj, i, slot); gauss_words(r.w[0], r.w[1], s, c);
               out[2 * i] = s; out[2 * i + 1] = c; break; }
+    // the deviate functions of spec v6; the words come as integer-valued doubles
+    case 10: sincos2pi_w((uint32_t)in[i], s, c); out[2 * i] = s; out[2 * i + 1] = c; break;
+    case 11: out[i] = dlog_w((uint32_t)in[i]); break;
+    case 12: out[i] = gauss_word_cos((uint32_t)in[2 * i], (uint32_t)in[2 * i + 1]); break;
     }
 }
 

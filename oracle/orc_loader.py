@@ -66,9 +66,10 @@ def math_probe(which, x):
     """Evaluate the spec's elementary function `which` (see ims_test_math) on the CPU."""
     lib = load()
     x = np.ascontiguousarray(x, dtype=np.float64)
-    m = 2 if which in (2, 4) else 1
-    out = np.empty(x.size * m)
-    lib.orc_test_math(which, x.ctypes.data, out.ctypes.data, x.size)
+    n = x.size // 2 if which == 12 else x.size          # 12: (w0, w1) pairs in, one deviate out
+    m = 2 if which in (2, 4, 10) else 1
+    out = np.empty(n * m)
+    lib.orc_test_math(which, x.ctypes.data, out.ctypes.data, n)
     return out
 
 

@@ -250,16 +250,85 @@ static inline void orc_gauss_pair(orc_draw_t d, double* g0, double* g1)
     *g0 = r * c; *g1 = r * s;
 }
 
+/* Deviates from 32-bit words (spec v6): the argument (w + 1/2) / 2^32 has a granularity of 2^-32, so the series stop where
+ * the truncation error is below 2^-36 of the result, and the quadrant of the angle comes from the word's top bits. */
+static inline double orc_sin_kernel_w(double t, double z)
+{
+    double p = -1.0 / 39916800.0;                 /* -1/11! */
+    p = orc_fma(p, z, 1.0 / 362880.0);
+    p = orc_fma(p, z, -1.0 / 5040.0);
+    p = orc_fma(p, z, 1.0 / 120.0);
+    p = orc_fma(p, z, -1.0 / 6.0);
+    return orc_fma(t * z, p, t);
+}
+static inline double orc_cos_kernel_w(double z)
+{
+    double p = 1.0 / 479001600.0;                 /* 1/12! */
+    p = orc_fma(p, z, -1.0 / 3628800.0);
+    p = orc_fma(p, z, 1.0 / 40320.0);
+    p = orc_fma(p, z, -1.0 / 720.0);
+    p = orc_fma(p, z, 1.0 / 24.0);
+    p = orc_fma(p, z, -0.5);
+    return orc_fma(z, p, 1.0);
+}
+/* quarter turn nearest to w / 2^32 turns (mod 4) and the angle left over, |t| <= pi/4 */
+static inline uint32_t orc_reduce_w(uint32_t w, double* t)
+{
+    uint32_t q = (uint32_t)(w + 0x20000000u) >> 30;
+    int32_t ri = (int32_t)(uint32_t)(w - (q << 30));
+    *t = orc_fma((double)ri, 0x1.0p-32, 0x1.0p-33) * ORC_TWO_PI;
+    return q;
+}
+static inline void orc_sincos2pi_w(uint32_t w, double* s, double* c)
+{
+    double t;
+    uint32_t q = orc_reduce_w(w, &t);
+    double z = t * t;
+    double sk = orc_sin_kernel_w(t, z), ck = orc_cos_kernel_w(z);
+    if (q == 0) { *s = sk; *c = ck; }
+    else if (q == 1) { *s = ck; *c = -sk; }
+    else if (q == 2) { *s = -sk; *c = -ck; }
+    else { *s = -ck; *c = sk; }
+}
+/* log((w + 1/2) / 2^32) */
+static inline double orc_log_w(uint32_t w)
+{
+    double x = orc_w01(w);
+    uint64_t b = orc_bits(x);
+    int64_t e = (int64_t)((b >> 52) & 0x7FF) - 1023;
+    double m = orc_from_bits((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    double s = (m - 1.0) / (m + 1.0);
+    double z = s * s;
+    double p = 1.0 / 13.0;
+    p = orc_fma(p, z, 1.0 / 11.0);
+    p = orc_fma(p, z, 1.0 / 9.0);
+    p = orc_fma(p, z, 1.0 / 7.0);
+    p = orc_fma(p, z, 1.0 / 5.0);
+    p = orc_fma(p, z, 1.0 / 3.0);
+    p = orc_fma(p, z, 1.0);
+    double lm = 2.0 * s * p;
+    double de = (double)e;
+    return orc_fma(de, ORC_LN2_HI, orc_fma(de, ORC_LN2_LO, lm));
+}
+
 /* Box-Muller pair from two words */
 static inline void orc_gauss_words(uint32_t w0, uint32_t w1, double* g0, double* g1)
 {
-    double r = orc_sqrt(-2.0 * orc_log(orc_w01(w0)));
+    double r = orc_sqrt(-2.0 * orc_log_w(w0));
     double s, c;
-    orc_sincos2pi(orc_w01(w1), &s, &c);
+    orc_sincos2pi_w(w1, &s, &c);
     *g0 = r * c; *g1 = r * s;
 }
+/* its cosine half alone (one deviate from two words) */
+static inline double orc_gauss_word_cos(uint32_t w0, uint32_t w1)
+{
+    double s, c;
+    orc_sincos2pi_w(w1, &s, &c);
+    return orc_sqrt(-2.0 * orc_log_w(w0)) * c;
+}
 
-/* RNG slots and word assignment (spec v4) */
+/* RNG slots and word assignment (spec v6) */
 #define ORC_SLOT_SHOOT     0   /* w0 wavelength, w1 profile radius, w2 profile angle */
 #define ORC_SLOT_KNOT      1   /* photon index = knot index: w0,w1 Gaussian position of a RandomKnots point */
 #define ORC_SLOT_PSF       2   /* + (component >> 1); component c owns words 2(c&1), 2(c&1)+1 */

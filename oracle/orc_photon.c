@@ -85,7 +85,7 @@ void orc_shoot_object(const ims_render_params_t* P, const ims_object_t* obj, int
                 double r2 = orc_radial_r2(&P->radial, obj->prof_table, orc_w01(d0.w[1]));
                 double r = orc_sqrt(r2) * obj->prof_scale;
                 double s, c;
-                orc_sincos2pi(orc_w01(d0.w[2]), &s, &c);
+                orc_sincos2pi_w(d0.w[2], &s, &c);
                 gu = r * c; gv = r * s;
             } else if (obj->prof_table == IMS_PROF_BOX) {          /* galsim.Box: uniform over length x width */
                 gu = (orc_w01(d0.w[1]) - 0.5) * obj->prof_scale;
@@ -191,7 +191,7 @@ void orc_apply_psf(const ims_render_params_t* P, const ims_object_t* obj, int co
             double ro2 = A->aper_r_outer * A->aper_r_outer, ri2 = A->aper_r_inner * A->aper_r_inner;
             double r = orc_sqrt(ri2 + orc_w01(wa) * (ro2 - ri2));
             double s, cc;
-            orc_sincos2pi(orc_w01(wb), &s, &cc);
+            orc_sincos2pi_w(wb, &s, &cc);
             double pu = r * cc, pv = r * s;
             orc_words_t dt = orc_words(P->seed, obj->obj_id, k, ORC_SLOT_PSF_TIME + (uint32_t)comp);
             double t = A->t0 + orc_w01(dt.w[0]) * A->exptime;
@@ -203,7 +203,7 @@ void orc_apply_psf(const ims_render_params_t* P, const ims_object_t* obj, int co
             double r2 = orc_radial_r2(&P->radial, c->table, orc_w01(wa));
             double r = orc_sqrt(r2) * scale;
             double s, cc;
-            orc_sincos2pi(orc_w01(wb), &s, &cc);
+            orc_sincos2pi_w(wb, &s, &cc);
             ku = r * cc; kv = r * s;
         }
         ph->x[i] = ph->x[i] + (w0 * ku + w1 * kv);
@@ -299,7 +299,7 @@ void orc_apply_op(const ims_render_params_t* P, int op_index, ims_photons_t* ph,
             orc_words_t d = orc_words(P->seed, obj->obj_id, k, slot);
             double r = orc_sqrt(ri2 + orc_w01(d.w[wb]) * (ro2 - ri2));
             double s, c;
-            orc_sincos2pi(orc_w01(d.w[wb + 1]), &s, &c);
+            orc_sincos2pi_w(d.w[wb + 1], &s, &c);
             ph->pupil_u[i] = r * c;
             ph->pupil_v[i] = r * s;
         }

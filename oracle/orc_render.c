@@ -82,6 +82,9 @@ void orc_test_math(int which, const double* in, double* out, int64_t n)
         case 3: out[i] = orc_atan(in[i]); break;
         case 4: { double s, c; orc_sincos(in[i], &s, &c); out[2 * i] = s; out[2 * i + 1] = c; break; }
         case 5: out[i] = orc_tanh_pos(in[i]); break;
+        case 10: { double s, c; orc_sincos2pi_w((uint32_t)in[i], &s, &c); out[2 * i] = s; out[2 * i + 1] = c; break; }
+        case 11: out[i] = orc_log_w((uint32_t)in[i]); break;
+        case 12: out[i] = orc_gauss_word_cos((uint32_t)in[2 * i], (uint32_t)in[2 * i + 1]); break;
         }
     }
 }

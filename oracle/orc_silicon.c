@@ -301,7 +301,7 @@ void orc_accumulate_range(const ims_render_params_t* P, const ims_photons_t* ph,
             if (!(f > 0.0)) abs_len = s->abs_len[0];
             else if (f >= (double)(s->n_abs - 1)) abs_len = s->abs_len[s->n_abs - 1];
             else { int t = (int)f; double a = f - (double)t; abs_len = s->abs_len[t] + a * (s->abs_len[t + 1] - s->abs_len[t]); }
-            double si_length = -abs_len * orc_log(orc_w01(dc.w[2]));
+            double si_length = -abs_len * orc_log_w(dc.w[2]);
             double dz = si_length;
             if (has_angles) {
                 double dxdz = ph->dxdz[i], dydz = ph->dydz[i];

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Golden digests of the numerics spec (spec v5), produced with the CPU oracle:
+"""Golden digests of the numerics spec (spec v6), produced with the CPU oracle:
 
     python tests/golden/make_pipeline_golden.py        ->  tests/golden/pipeline_golden.json
 
@@ -63,5 +63,5 @@ def oracle_backend(scene):
 if __name__ == "__main__":
     digests = {k: digest(v) for k, v in cases(oracle_backend).items()}
     with open(os.path.join(HERE, "pipeline_golden.json"), "w") as f:
-        json.dump({"spec": "v5", "sha256": digests}, f, indent=1, sort_keys=True)
+        json.dump({"spec": "v6", "sha256": digests}, f, indent=1, sort_keys=True)
     print(json.dumps(digests, indent=1))

@@ -20,12 +20,12 @@ def torch_cuda():
 
 def _dev_math(torch, which, x, seed=0, obj=0, slot=0, n=None):
     lib = _abi.load()
-    m = 2 if which in (2, 4, 6) else 1
+    m = 2 if which in (2, 4, 6, 10) else 1
     if which == 6:
         xin = torch.zeros(1, dtype=torch.float64, device="cuda")
     else:
         xin = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).cuda()
-        n = xin.numel()
+        n = xin.numel() // 2 if which == 12 else xin.numel()
     out = torch.empty(n * m, dtype=torch.float64, device="cuda")
     _abi.check(lib.ims_test_math(which, xin.data_ptr(), out.data_ptr(), n, seed, obj, slot, None))
     torch.cuda.synchronize()
@@ -72,6 +72,10 @@ def test_lean_div_sqrt(torch_cuda):
     assert bool((run(8, torch.stack([z, k], dim=1).contiguous().view(-1)) == 0.0).all())
 
 
+WORD_EDGES = np.array([0, 1, 2 ** 29 - 1, 2 ** 29, 2 ** 29 + 1, 2 ** 30, 2 ** 31 - 1, 2 ** 31, 3 * 2 ** 29 - 1, 3 * 2 ** 29,
+                       5 * 2 ** 29, 7 * 2 ** 29 - 1, 7 * 2 ** 29, 2 ** 32 - 2, 2 ** 32 - 1], dtype=np.float64)
+
+
 def test_device_math_is_bit_identical_to_oracle(torch_cuda):
     """The numerics spec: every elementary function gives the same bits on gfx950 and on the CPU."""
     from oracle import orc_loader
@@ -83,6 +87,10 @@ def test_device_math_is_bit_identical_to_oracle(torch_cuda):
         3: np.concatenate([rng.uniform(-5, 5, 100000), 10 ** rng.uniform(-12, 6, 100000)]),
         4: rng.uniform(-100, 100, 200000),
         5: rng.uniform(0, 30, 100000),
+        # spec v6: the deviate functions take 32-bit words (as integer-valued doubles); edge words first
+        10: np.concatenate([WORD_EDGES, rng.integers(0, 2 ** 32, 200000).astype(np.float64)]),
+        11: np.concatenate([WORD_EDGES, rng.integers(0, 2 ** 32, 200000).astype(np.float64)]),
+        12: rng.integers(0, 2 ** 32, 400000).astype(np.float64),
     }
     for which, x in cases.items():
         x = x[x > 0] if which == 0 else x

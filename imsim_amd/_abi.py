@@ -56,7 +56,8 @@ class RadialTables(C.Structure):
 
 
 class ImageTables(C.Structure):
-    _fields_ = [("n_images", c_i32), ("pad", c_i32), ("size", c_vp), ("offset", c_vp), ("cdf", c_vp)]
+    _fields_ = [("n_images", c_i32), ("interp", c_i32), ("size", c_vp), ("offset", c_vp), ("cdf", c_vp),
+                ("kx", c_vp), ("kcdf", c_vp), ("n_k", c_i32), ("pad", c_i32), ("norm", C.c_double), ("neg", C.c_double * 4)]
 
 
 class LinTables(C.Structure):

@@ -57,7 +57,25 @@ IMS_DEV double radial_r2(const ims_radial_tables_t& t, int table, double u)
 
 // pixel of an image profile by inverse CDF; position in image pixels relative to the image centre.  (In line: a real
 // call in a photon kernel costs the whole kernel its register allocation -- measured 2.9 -> 0.7 M objects/s.)
-IMS_DEV void image_sample(const ims_image_tables_t& T, int k, double u, double u2, double& gx, double& gy)
+// offset drawn from |K| of the image's interpolant (ims_image_tables_t.kx, kcdf); neg: K is negative there
+IMS_DEV double interp_offset(const ims_image_tables_t& T, double u, bool& neg)
+{
+    int lo = 0, hi = T.n_k;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (T.kcdf[mid] <= u) lo = mid; else hi = mid;
+    }
+    const double c0 = T.kcdf[lo], wd = T.kcdf[lo + 1] - c0;
+    const double f = (wd > 0.0) ? (u - c0) / wd : 0.0;
+    const double x0 = T.kx[lo];
+    const double d = fma(f, T.kx[lo + 1] - x0, x0);
+    const double ad = fabs(d);
+    neg = (ad > T.neg[0] && ad < T.neg[1]) || (ad > T.neg[2] && ad < T.neg[3]);
+    return d;
+}
+
+// fscale: the factor on the photon's flux (1 without an interpolant)
+IMS_DEV void image_sample(const ims_image_tables_t& T, int k, double u, double u2, double& gx, double& gy, double& fscale)
 {
     const int w = T.size[2 * k], h = T.size[2 * k + 1];
     const double* cdf = T.cdf + T.offset[k];
@@ -69,8 +87,17 @@ IMS_DEV void image_sample(const ims_image_tables_t& T, int k, double u, double u
     const double c0 = cdf[lo], wd = cdf[lo + 1] - c0;
     const double f = (wd > 0.0) ? (u - c0) / wd : 0.0;
     const int px = lo % w, py = lo / w;
-    gx = ((double)px + f) - 0.5 * (double)w;
-    gy = ((double)py + u2) - 0.5 * (double)h;
+    if (T.interp != 0) {
+        bool nx, ny;
+        const double dx = interp_offset(T, f, nx), dy = interp_offset(T, u2, ny);
+        gx = (((double)px + 0.5) + dx) - 0.5 * (double)w;
+        gy = (((double)py + 0.5) + dy) - 0.5 * (double)h;
+        fscale = (nx != ny) ? -T.norm : T.norm;
+    } else {
+        gx = ((double)px + f) - 0.5 * (double)w;
+        gy = ((double)py + u2) - 0.5 * (double)h;
+        fscale = 1.0;
+    }
 }
 
 // ---------------- shooting ----------------
@@ -80,7 +107,7 @@ IMS_DEV void shoot(const ims_render_params_t& P, const ims_object_t& o, int64_t 
     rng_block(rng, P.seed, o.obj_id, k, SLOT_SHOOT);
     double wl = o.sed_wave;
     if (o.sed_table >= 0) wl = lin_lookup(P.sed, o.sed_table, w01(rng.w[0]));
-    double pu = 0.0, pv = 0.0;
+    double pu = 0.0, pv = 0.0, fscale = 1.0;
     if (o.prof_table != IMS_PROF_POINT) {
         double gu, gv;
         if (o.prof_table >= 0) {
@@ -93,7 +120,7 @@ IMS_DEV void shoot(const ims_render_params_t& P, const ims_object_t& o, int64_t 
             gu = (w01(rng.w[1]) - 0.5) * o.prof_scale;
             gv = (w01(rng.w[2]) - 0.5) * o.prof_aux;
         } else if (o.prof_table == IMS_PROF_IMAGE) {
-            image_sample(P.images, (int)o.prof_aux, w01(rng.w[1]), w01(rng.w[2]), gu, gv);
+            image_sample(P.images, (int)o.prof_aux, w01(rng.w[1]), w01(rng.w[2]), gu, gv, fscale);
             gu = gu * o.prof_scale; gv = gv * o.prof_scale;
         } else {
             // RandomKnots: the photon picks one of the knots; knot m sits at a Gaussian deviate addressed by
@@ -111,7 +138,7 @@ IMS_DEV void shoot(const ims_render_params_t& P, const ims_object_t& o, int64_t 
     }
     ph.x = o.winv[0] * pu + o.winv[1] * pv;
     ph.y = o.winv[2] * pu + o.winv[3] * pv;
-    ph.flux = o.flux_per_photon;
+    ph.flux = (o.prof_table == IMS_PROF_IMAGE) ? o.flux_per_photon * fscale : o.flux_per_photon;
     ph.dxdz = 0.0; ph.dydz = 0.0;
     ph.wl = wl;
     ph.pu = 0.0; ph.pv = 0.0; ph.t = 0.0;

@@ -5,6 +5,7 @@ sensor); `Renderer` uploads it once and then renders object tables into the CCD 
 the C-ABI.  There is no CPU fallback here: without the HIP library or a GPU this raises.
 """
 import ctypes as C
+import math
 import os
 import dataclasses
 from typing import List, Optional
@@ -61,6 +62,7 @@ class Scene:
     radial_r2: Optional[np.ndarray] = None
     radial_cdf: Optional[np.ndarray] = None
     image_profiles: Optional[list] = None        # 2-D arrays [ny][nx] sampled by IMS_PROF_IMAGE objects (FITS stamps)
+    image_interpolant: str = "quintic"           # x_interpolant of those images: GalSim's default, or "nearest"
     sed_tables: Optional[np.ndarray] = None      # [n][n_pts] inverse CDFs uniform in u
     ratio_tables: Optional[np.ndarray] = None    # [n][n_pts] uniform in wavelength
     ratio_wl_min: float = 0.0
@@ -350,6 +352,39 @@ def image_profile_cdf(img):
     return cdf
 
 
+def quintic_kernel(x):
+    """GalSim's Quintic interpolant (Bernstein & Gruen 2014, the default x_interpolant of galsim.InterpolatedImage): the
+    piecewise quintic on [-3, 3] that interpolates, is C1 and reproduces polynomials up to degree four."""
+    x = np.abs(np.asarray(x, dtype=np.float64))
+    out = np.zeros_like(x)
+    a, b, c = x <= 1.0, (x > 1.0) & (x <= 2.0), (x > 2.0) & (x <= 3.0)
+    out[a] = 1.0 + x[a] ** 3 * (-95.0 + 138.0 * x[a] - 55.0 * x[a] ** 2) / 12.0
+    out[b] = (x[b] - 1.0) * (x[b] - 2.0) * (-138.0 + 348.0 * x[b] - 249.0 * x[b] ** 2 + 55.0 * x[b] ** 3) / 24.0
+    out[c] = (x[c] - 2.0) * (x[c] - 3.0) ** 2 * (-54.0 + 50.0 * x[c] - 11.0 * x[c] ** 2) / 24.0
+    return out
+
+
+QUINTIC_NEGATIVE = (1.0, 2.0, (25.0 + math.sqrt(31.0)) / 11.0, 3.0)     # |x| intervals with K < 0 (GalSim: Interpolant.cpp, Quintic)
+
+
+def interpolant_cdf(kernel=quintic_kernel, negative=QUINTIC_NEGATIVE, support=3.0, per_piece=128):
+    """(kx, kcdf, norm) of ims_image_tables_t: the cumulative distribution of |K| -- what Interpolant::shoot of GalSim samples
+    with a OneDimensionalDeviate -- at knots that divide every piece between two sign changes of K (and the integers) into
+    per_piece equal intervals, so that no interval holds both signs and the mass of every interval is exact (Gauss-Legendre
+    with 8 points per interval: exact for the piecewise quintic); norm = (integral |K|)^2."""
+    cuts = sorted({0.0, support} | {float(v) for v in negative if 0.0 < v < support} | {float(k) for k in range(1, int(support))})
+    half = np.concatenate([np.linspace(a, b, per_piece + 1)[:-1] for a, b in zip(cuts[:-1], cuts[1:])] + [[support]])
+    kx = np.concatenate([-half[:0:-1], half])
+    gx, gw = np.polynomial.legendre.leggauss(8)
+    a, b = kx[:-1], kx[1:]
+    xm = 0.5 * (a + b)[:, None] + 0.5 * (b - a)[:, None] * gx[None, :]
+    mass = 0.5 * (b - a) * (np.abs(kernel(xm.reshape(-1))).reshape(xm.shape) * gw[None, :]).sum(axis=1)
+    total = float(mass.sum())
+    kcdf = np.concatenate([[0.0], np.cumsum(mass) / total])
+    kcdf[-1] = 1.0
+    return np.ascontiguousarray(kx), np.ascontiguousarray(kcdf), total * total
+
+
 class _Arena:
     """Host staging of the many small tables of one launch plan (object rows, segment prefixes, pool offsets) for ONE
     upload: `add` returns the byte offset of an array, `patch` remembers a struct field that must receive its device
@@ -432,6 +467,14 @@ class BoundScene:
             _, P.images.size = mem.put(np.asarray(sizes), np.int32)
             _, P.images.offset = mem.put(np.asarray(offs), np.int64)
             _, P.images.cdf = mem.put(np.concatenate(cdfs), np.float64)
+            if scene.image_interpolant == "quintic":
+                kx, kcdf, norm = interpolant_cdf()
+                P.images.interp, P.images.n_k, P.images.norm = 1, len(kx) - 1, norm
+                P.images.neg = (C.c_double * 4)(*QUINTIC_NEGATIVE)
+                _, P.images.kx = mem.put(kx, np.float64)
+                _, P.images.kcdf = mem.put(kcdf, np.float64)
+            elif scene.image_interpolant != "nearest":
+                raise ValueError(f"image_interpolant {scene.image_interpolant!r}: 'quintic' or 'nearest'")
         if scene.radial_r2 is not None:
             r2 = np.atleast_2d(scene.radial_r2)
             P.radial.n_tables, P.radial.n_bins = r2.shape[0], r2.shape[1] - 1

@@ -40,7 +40,7 @@ extern "C" {
 #define IMS_ERR_NO_DEVICE  -3
 #define IMS_ERR_UNSUPPORTED -4
 
-#define IMS_ABI_VERSION 14
+#define IMS_ABI_VERSION 15
 
 /* Pointers stored INSIDE descriptors that live in device memory (ims_sensor_t, ims_atmosphere_t) always point to global
  * device memory.  Device code is told so (address space 1): a pointer read out of memory is otherwise a generic pointer and
@@ -132,15 +132,28 @@ typedef struct ims_object {
 
 /* Pixel images sampled as profiles (galsim.InterpolatedImage of a FITS stamp, imsim/instcat.py:552-561): image k has
  * size[2k] x size[2k+1] pixels (row-major, first axis x) and a cumulative distribution of its non-negative pixel values
- * cdf[offset[k] .. offset[k] + w*h] (first entry 0, last 1).  A photon picks pixel p by inverse CDF of one deviate, the
- * remainder of that deviate places it uniformly along x inside the pixel and a second deviate along y (nearest-pixel
- * shooting: the reference's Quintic interpolant is not reproduced). */
+ * cdf[offset[k] .. offset[k] + w*h] (first entry 0, last 1).  A photon picks pixel p by inverse CDF of one deviate u; the
+ * remainder f of that deviate inside the pixel's CDF bin and a second deviate u2 place it
+ *   interp == 0: uniformly inside the pixel, (p_x + f, p_y + u2) (GalSim's "nearest" interpolant);
+ *   interp == 1: at the pixel centre plus one offset per axis drawn from |K| of the image's x-interpolant K, as GalSim's
+ *                SBInterpolatedImage::shoot followed by Interpolant::shoot does: the cumulative distribution of |K| is
+ *                tabulated at n_k + 1 knots kx (offsets in pixels, increasing, every sign change of K among them) with
+ *                values kcdf (0 .. 1); a deviate finds its interval by bisection and is placed linearly inside it.  The
+ *                photon's flux is multiplied by norm = (integral |K|)^2 and by the sign of K(dx) K(dy): K < 0 where
+ *                neg[0] < |d| < neg[1] or neg[2] < |d| < neg[3] (Quintic, GalSim's default: 1 .. 2 and
+ *                (25 + sqrt 31) / 11 .. 3). */
 typedef struct ims_image_tables {
     int32_t n_images;
-    int32_t pad;
+    int32_t interp;
     const int32_t* size;     /* [n_images][2] */
     const int64_t* offset;   /* [n_images] */
     const double*  cdf;
+    const double*  kx;       /* interp == 1: [n_k + 1] */
+    const double*  kcdf;     /* interp == 1: [n_k + 1] */
+    int32_t n_k;
+    int32_t pad;
+    double  norm;            /* interp == 1: (integral |K|)^2 */
+    double  neg[4];          /* interp == 1: the two intervals of |d| on which K is negative (empty: lower >= upper) */
 } ims_image_tables_t;
 
 /* Tabulated circular profiles sampled by inverse CDF with uniform density inside each annulus:

@@ -63,6 +63,21 @@ void orc_photons_free(ims_photons_t* p)
     memset(p, 0, sizeof(*p));
 }
 
+/* offset drawn from |K| of an image profile's interpolant: bisection in the tabulated cumulative distribution of |K|
+ * (ims_image_tables_t.kx, kcdf), linear inside the interval; *neg = K is negative at the offset */
+static double interp_offset(const ims_image_tables_t* T, double u, int* neg)
+{
+    int lo = 0, hi = T->n_k;
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T->kcdf[mid] <= u) lo = mid; else hi = mid; }
+    double c0 = T->kcdf[lo], wd = T->kcdf[lo + 1] - c0;
+    double f = (wd > 0.0) ? (u - c0) / wd : 0.0;
+    double x0 = T->kx[lo];
+    double d = fma(f, T->kx[lo + 1] - x0, x0);
+    double ad = fabs(d);
+    *neg = (ad > T->neg[0] && ad < T->neg[1]) || (ad > T->neg[2] && ad < T->neg[3]);
+    return d;
+}
+
 /* ---------- shooting (stamp.py:562-572 -> GalSim drawImage phot) ---------- */
 /* Photon j (j = 0..n_phot-1) of `obj` is written at pool index base+j; its stream index is
  * obj->phot_first + j.  Positions are left RELATIVE to the object's image_pos, in pixels. */
@@ -78,7 +93,7 @@ void orc_shoot_object(const ims_render_params_t* P, const ims_object_t* obj, int
         double wl = obj->sed_wave;
         if (obj->sed_table >= 0) wl = orc_lin_lookup(&P->sed, obj->sed_table, orc_w01(d0.w[0]));
         /* profile */
-        double pu = 0.0, pv = 0.0;
+        double pu = 0.0, pv = 0.0, fscale = 1.0;
         if (obj->prof_table != IMS_PROF_POINT) {
             double gu, gv;
             if (obj->prof_table >= 0) {
@@ -90,7 +105,7 @@ void orc_shoot_object(const ims_render_params_t* P, const ims_object_t* obj, int
             } else if (obj->prof_table == IMS_PROF_BOX) {          /* galsim.Box: uniform over length x width */
                 gu = (orc_w01(d0.w[1]) - 0.5) * obj->prof_scale;
                 gv = (orc_w01(d0.w[2]) - 0.5) * obj->prof_aux;
-            } else if (obj->prof_table == IMS_PROF_IMAGE) {        /* galsim.InterpolatedImage, nearest-pixel shooting */
+            } else if (obj->prof_table == IMS_PROF_IMAGE) {        /* galsim.InterpolatedImage */
                 const ims_image_tables_t* T = &P->images;
                 int kimg = (int)obj->prof_aux;
                 int w = T->size[2 * kimg], h = T->size[2 * kimg + 1];
@@ -100,8 +115,19 @@ void orc_shoot_object(const ims_render_params_t* P, const ims_object_t* obj, int
                 while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (cdf[mid] <= u) lo = mid; else hi = mid; }
                 double c0 = cdf[lo], wd = cdf[lo + 1] - c0;
                 double f = (wd > 0.0) ? (u - c0) / wd : 0.0;
-                gu = ((((double)(lo % w) + f) - 0.5 * (double)w)) * obj->prof_scale;
-                gv = ((((double)(lo / w) + orc_w01(d0.w[2])) - 0.5 * (double)h)) * obj->prof_scale;
+                double u2 = orc_w01(d0.w[2]);
+                if (T->interp != 0) {
+                    /* SBInterpolatedImage::shoot + Interpolant::shoot: pixel centre plus an offset per axis drawn from |K| of the
+                     * x-interpolant by its tabulated inverse CDF, flux signed like K(dx) K(dy) */
+                    int lx, ly;
+                    double dx = interp_offset(T, f, &lx), dy = interp_offset(T, u2, &ly);
+                    gu = ((((double)(lo % w) + 0.5) + dx) - 0.5 * (double)w) * obj->prof_scale;
+                    gv = ((((double)(lo / w) + 0.5) + dy) - 0.5 * (double)h) * obj->prof_scale;
+                    fscale = (lx != ly) ? -T->norm : T->norm;
+                } else {
+                    gu = ((((double)(lo % w) + f) - 0.5 * (double)w)) * obj->prof_scale;
+                    gv = ((((double)(lo / w) + u2) - 0.5 * (double)h)) * obj->prof_scale;
+                }
             } else {                                                /* galsim.RandomKnots */
                 uint32_t m = (uint32_t)(((uint64_t)d0.w[1] * (uint64_t)(uint32_t)obj->prof_aux) >> 32);
                 orc_words_t kd = orc_words(P->seed, obj->obj_id, (int64_t)m, ORC_SLOT_KNOT);
@@ -114,7 +140,7 @@ void orc_shoot_object(const ims_render_params_t* P, const ims_object_t* obj, int
         }
         ph->x[i] = w0 * pu + w1 * pv;
         ph->y[i] = w2 * pu + w3 * pv;
-        ph->flux[i] = obj->flux_per_photon;
+        ph->flux[i] = (obj->prof_table == IMS_PROF_IMAGE) ? obj->flux_per_photon * fscale : obj->flux_per_photon;
         ph->dxdz[i] = 0.0; ph->dydz[i] = 0.0;
         ph->wavelength[i] = wl;
         ph->pupil_u[i] = 0.0; ph->pupil_v[i] = 0.0; ph->time[i] = 0.0;

@@ -106,9 +106,82 @@ def test_double_gaussian_psf_is_a_two_component_mixture():
     assert tab[0] == 1.0 and tab[-1] < 1e-12
 
 
+def test_quintic_interpolant_tables():
+    """The x-interpolant of galsim.InterpolatedImage defaults to Quintic.  The kernel restated in engine.quintic_kernel must
+    interpolate (1 at 0, 0 at the other integers), be a partition of unity and reproduce polynomials up to degree four (what
+    defines the Bernstein & Gruen quintic); its positive and negative flux are GalSim's documented 1.1293413... and
+    0.1293413...; the sign-change abscissa beyond 2 is GalSim's (25 + sqrt 31) / 11; the sampling table has exact interval
+    masses, so the signed weights average to 1 and carry no second moment."""
+    from imsim_amd.engine import quintic_kernel as K, interpolant_cdf, QUINTIC_NEGATIVE as Q
+    assert K([0.0])[0] == 1.0 and np.all(K(np.array([1.0, 2.0, 3.0, -1.0, -2.0, 3.5])) == 0.0)
+    x = np.linspace(0.0, 1.0, 501)
+    for p in range(5):
+        tot = sum((float(k) ** p) * K(x - k) for k in range(-3, 5))
+        np.testing.assert_allclose(tot, x ** p, atol=3e-14)
+    assert abs(K([Q[2]])[0]) < 1e-15 and K([Q[2] - 1e-3])[0] > 0 > K([Q[2] + 1e-3])[0] and K([1.5])[0] < 0
+    kx, kcdf, norm = interpolant_cdf()
+    assert np.all(np.diff(kx) > 0) and np.all(np.diff(kcdf) > 0) and kcdf[0] == 0.0 and kcdf[-1] == 1.0
+    for q in Q + (0.0,):
+        assert np.any(kx == q) and np.any(kx == -q)          # no interval holds both signs
+    pos, neg = 0.5 * (np.sqrt(norm) + 1.0), 0.5 * (np.sqrt(norm) - 1.0)
+    assert abs(pos - 1.1293413499280066) < 1e-12 and abs(neg - 0.1293413499280066) < 1e-12
+    u = (np.arange(4000000) + 0.5) / 4000000
+    i = np.clip(np.searchsorted(kcdf, u, side="right") - 1, 0, len(kx) - 2)
+    d = kx[i] + (u - kcdf[i]) / (kcdf[i + 1] - kcdf[i]) * (kx[i + 1] - kx[i])
+    ad = np.abs(d)
+    w = np.where(((ad > Q[0]) & (ad < Q[1])) | ((ad > Q[2]) & (ad < Q[3])), -1.0, 1.0) * np.sqrt(norm)
+    assert abs(w.mean() - 1.0) < 1e-6 and abs((w * d).mean()) < 1e-9 and abs((w * d * d).mean()) < 5e-5
+
+
+def test_fits_image_profile_with_the_quintic_interpolant():
+    """galsim.InterpolatedImage shoots a pixel by its flux and then convolves with the x-interpolant (Quintic by default):
+    offsets drawn from |K| per axis, photon fluxes +- (integral |K|)^2 (SBInterpolatedImage::shoot, Interpolant::shoot).  So
+    the signed flux per bin must follow the INTERPOLATED image  sum_q v_q K(x - q_x) K(y - q_y), negative lobes included,
+    and the signed total is the object's flux."""
+    from imsim_amd.engine import quintic_kernel as K, interpolant_cdf
+    rng = np.random.default_rng(6)
+    img = np.zeros((7, 8))
+    img[2:5, 2:6] = rng.uniform(0.5, 3.0, size=(3, 4))
+    img[3, 3] = 12.0                                      # a sharp pixel: its side lobes are negative
+    scale, n_phot = 0.4, 3000000
+    cat = _cat(catalog.KIND_IMAGE, 1, pa=np.zeros(1), image_scale=np.full(1, scale), image_index=np.zeros(1, dtype=np.int64),
+               image_extent=np.full(1, 8 * scale))
+    scene = configs.scene_c2(nx=256, ny=256)
+    scene.psf = []
+    scene.image_profiles = [img]
+    assert scene.image_interpolant == "quintic"
+    objects, _ = catalog.build_object_table(cat, np.full(1, n_phot), stamp_size=128)
+    pool = orc_loader.OracleScene(scene).shoot_pool(objects).to_host()
+    norm = interpolant_cdf()[2]
+    assert set(np.unique(pool["flux"])) == {-norm, norm}
+    assert abs(pool["flux"].sum() - n_phot) < 5 * norm * np.sqrt(n_phot)
+    u = (pool["x"] - objects["x0"][0]) * PIX / scale + 4.0          # image pixel coordinates, pixel k covers [k, k + 1)
+    v = (pool["y"] - objects["y0"][0]) * PIX / scale + 3.5
+    assert u.min() >= -3.0 and u.max() <= 11.0 and v.min() >= -3.0 and v.max() <= 10.0
+    sub = 2                                                          # bins of half an image pixel
+    edges_u, edges_v = np.linspace(-3, 11, 14 * sub + 1), np.linspace(-3, 10, 13 * sub + 1)
+    got, _, _ = np.histogram2d(v, u, bins=(edges_v, edges_u), weights=pool["flux"])
+    cnt, _, _ = np.histogram2d(v, u, bins=(edges_v, edges_u))
+    # expectation: the bin integral of the interpolated image (Gauss-Legendre inside every bin; K is a quintic per half pixel)
+    gx, gw = np.polynomial.legendre.leggauss(6)
+
+    def bin_weights(edges, n_pix):
+        a, b = edges[:-1], edges[1:]
+        xs = 0.5 * (a + b)[:, None] + 0.5 * (b - a)[:, None] * gx[None, :]           # [bin][node]
+        centres = np.arange(n_pix) + 0.5
+        return (0.5 * (b - a))[:, None] * (K((xs[:, :, None] - centres[None, None, :]).reshape(-1)).reshape(
+            xs.shape + (n_pix,)) * gw[None, :, None]).sum(axis=1)                     # [bin][pixel]
+    Wu, Wv = bin_weights(edges_u, 8), bin_weights(edges_v, 7)
+    want = Wv @ img @ Wu.T / img.sum() * n_phot
+    sigma = norm * np.sqrt(np.maximum(cnt, 25.0))
+    assert np.all(np.abs(got - want) < 5.5 * sigma)
+    assert want.min() < -20 * norm * np.sqrt(25.0) and got[want < -20 * norm * 5].max() < 0      # real negative lobes, seen
+
+
 def test_fits_image_profile_follows_the_pixels(tmp_path):
-    """FITS-stamp objects (galsim.InterpolatedImage, imsim/instcat.py:552-561): photons land in the image's pixels in
-    proportion to their values, uniformly inside a pixel, on the image's own pixel scale, rotated by -theta."""
+    """FITS-stamp objects (galsim.InterpolatedImage, imsim/instcat.py:552-561) with the "nearest" interpolant: photons land in
+    the image's pixels in proportion to their values, uniformly inside a pixel, on the image's own pixel scale, rotated by
+    -theta."""
     from imsim_amd import fits_io
     rng = np.random.default_rng(5)
     img = np.zeros((9, 12))                               # [ny][nx]
@@ -122,6 +195,7 @@ def test_fits_image_profile_follows_the_pixels(tmp_path):
     scene = configs.scene_c2(nx=256, ny=256)
     scene.psf = []
     scene.image_profiles = [img]
+    scene.image_interpolant = "nearest"
     objects, sizes = catalog.build_object_table(cat, np.full(n_obj, n_phot), stamp_size=128)
     assert np.all(objects["prof_table"] == -4) and np.all(objects["prof_scale"] == scale)
     pool = orc_loader.OracleScene(scene).shoot_pool(objects).to_host()

@@ -71,6 +71,10 @@ def unit_flux_path(scene, objects=None):
             return False
     if objects is not None and len(objects) and not np.all(objects["flux_per_photon"] == 1.0):
         return False
+    # FITS-stamp objects shot through an interpolant carry +- (integral |K|)^2 per photon (ims_image_tables_t)
+    if getattr(scene, "image_profiles", None) and getattr(scene, "image_interpolant", "nearest") != "nearest":
+        if objects is None or (len(objects) and np.any(objects["prof_table"] == _abi.IMS_PROF_IMAGE)):
+            return False
     return True
 
 

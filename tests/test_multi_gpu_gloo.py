@@ -67,6 +67,27 @@ def test_shard_objects_is_a_partition():
         assert sorted(ids) == sorted(objects["obj_id"])
 
 
+def test_unit_flux_path_knows_what_makes_a_photon_carry_other_than_one_electron():
+    """parallel.unit_flux_path decides whether an exchange may run on int32 copies: not with BandpassRatio in the chain, not
+    with a flux_per_photon other than 1, not with FITS-stamp objects shot through an interpolant (+- (integral |K|)^2)."""
+    from helpers import small_case
+    from imsim_amd import parallel, _abi
+    scene, objects, _ = small_case(n_obj=20, nx=128, ny=128)
+    assert parallel.unit_flux_path(scene, objects)
+    scaled = objects.copy()
+    scaled["flux_per_photon"][3] = 0.5
+    assert not parallel.unit_flux_path(scene, scaled)
+    scene.image_profiles = [np.ones((4, 4))]
+    assert parallel.unit_flux_path(scene, objects)                 # no object samples the image
+    stamp_obj = objects.copy()
+    stamp_obj["prof_table"][5] = _abi.IMS_PROF_IMAGE
+    assert not parallel.unit_flux_path(scene, stamp_obj) and not parallel.unit_flux_path(scene)
+    scene.image_interpolant = "nearest"
+    assert parallel.unit_flux_path(scene, stamp_obj)
+    scene.ops = list(scene.ops) + [(_abi.IMS_OP_BANDPASS_RATIO, 0, [])]
+    assert not parallel.unit_flux_path(scene, objects)
+
+
 def _pooling_worker(rank, world, port, out_path):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))

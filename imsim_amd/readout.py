@@ -7,6 +7,7 @@ inefficiency, bias and read noise, truncation to int32 ADU.  Camera geometry com
 (stand-in for lsst.obs.lsst, see camera.py); FITS files are written by `fits_io` (no astropy here)."""
 import ctypes as C
 import datetime
+import math
 import os
 
 import numpy as np
@@ -93,6 +94,77 @@ def eimage_header(det_name, exptime, opsim_data=None, header_vals=None, camera="
     return h
 
 
+RUBIN_LONGITUDE_DEG, RUBIN_LATITUDE_DEG = -70.7494, -30.2446        # Simonyi telescope, east longitude / latitude
+TAI_MINUS_UTC_S = 37.0                                               # since 2017-01-01
+
+
+def _precession_matrix(mjd_tt):
+    """Equatorial rotation J2000 -> mean equator and equinox of date (IAU 1976 angles zeta, z, theta)."""
+    t = (mjd_tt - 51544.5) / 36525.0
+    arc = math.pi / (180.0 * 3600.0)
+    zeta = (2306.2181 * t + 0.30188 * t * t + 0.017998 * t ** 3) * arc
+    z = (2306.2181 * t + 1.09468 * t * t + 0.018203 * t ** 3) * arc
+    theta = (2004.3109 * t - 0.42665 * t * t - 0.041833 * t ** 3) * arc
+    cz, sz, cZ, sZ, ct, st = math.cos(zeta), math.sin(zeta), math.cos(z), math.sin(z), math.cos(theta), math.sin(theta)
+    return ((cz * ct * cZ - sz * sZ, -sz * ct * cZ - cz * sZ, -st * cZ),
+            (cz * ct * sZ + sz * cZ, -sz * ct * sZ + cz * cZ, -st * sZ),
+            (cz * st, -sz * st, ct))
+
+
+def _to_date(P, ra, dec):
+    v = (math.cos(dec) * math.cos(ra), math.cos(dec) * math.sin(ra), math.sin(dec))
+    w = [sum(P[i][j] * v[j] for j in range(3)) for i in range(3)]
+    return math.atan2(w[1], w[0]), math.asin(max(-1.0, min(1.0, w[2])))
+
+
+def _position_angle(ra, dec, ra2, dec2):
+    """Position angle of point 2 seen from point 1, from north through east (erfa.pas)."""
+    dl = ra2 - ra
+    return math.atan2(math.cos(dec2) * math.sin(dl), math.sin(dec2) * math.cos(dec) - math.cos(dec2) * math.sin(dec) * math.cos(dl))
+
+
+def pointing_geometry(ra0, dec0, obsmjd, longitude=RUBIN_LONGITUDE_DEG, latitude=RUBIN_LATITUDE_DEG):
+    """(altitude, azimuth, pseudo parallactic angle) in degrees of the ICRS direction (ra0, dec0) at TAI MJD obsmjd, geometric
+    (no refraction, nutation or polar motion: a few 0.01 deg).  The pseudo parallactic angle is the position angle of the
+    zenith at the boresight measured from ICRS north through east, which is what BatoidWCSFactory.pq of the reference
+    returns (imsim/batoid_wcs.py:270-308): here the true parallactic angle of date minus the position angle that ICRS
+    north has in the frame of date."""
+    ra, dec, lat = math.radians(ra0), math.radians(dec0), math.radians(latitude)
+    mjd_utc = obsmjd - TAI_MINUS_UTC_S / 86400.0
+    t = (mjd_utc - 51544.5) / 36525.0                    # UT1 ~ UTC (|DUT1| < 0.9 s = 0.004 deg of sidereal time)
+    gmst = (67310.54841 + (876600.0 * 3600.0 + 8640184.812866) * t + 0.093104 * t * t - 6.2e-6 * t ** 3) / 240.0   # degrees
+    lst = math.radians((gmst + longitude) % 360.0)
+    P = _precession_matrix(obsmjd + 32.184 / 86400.0)
+    ra_d, dec_d = _to_date(P, ra, dec)
+    ha = lst - ra_d
+    sin_alt = math.sin(lat) * math.sin(dec_d) + math.cos(lat) * math.cos(dec_d) * math.cos(ha)
+    alt = math.asin(max(-1.0, min(1.0, sin_alt)))
+    az = math.atan2(-math.cos(dec_d) * math.sin(ha), math.sin(dec_d) * math.cos(lat) - math.cos(dec_d) * math.cos(ha) * math.sin(lat))
+    q = math.atan2(math.sin(ha), math.tan(lat) * math.cos(dec_d) - math.sin(dec_d) * math.cos(ha))
+    small = math.radians(10.0 / 3600.0)
+    if math.pi / 2 - dec >= small:
+        ra_n, dec_n = ra, dec + small
+    else:
+        ra_n, dec_n = ra + math.pi, math.pi / 2 - (small - (math.pi / 2 - dec))
+    north_in_date = _position_angle(ra_d, dec_d, *_to_date(P, ra_n, dec_n))
+    return math.degrees(alt), math.degrees(az) % 360.0, math.degrees(q - north_in_date)
+
+
+_rotSkyPos_cache = {}
+
+
+def compute_rotSkyPos(ra0, dec0, rottelpos, obsmjd, band="r", camera_name="LsstCamSim", **_):
+    """The nominal rotation angle of the focal plane with respect to celestial north, with +y of the pixel coordinates as the
+    reference direction: 270 - rotTelPos + pseudo parallactic angle, in [0, 360) degrees (imsim/readout.py:95-149).  The
+    reference takes the angle from its batoid WCS factory (astropy / ERFA, with refraction); here it is the geometric value of
+    `pointing_geometry`, good to a few hundredths of a degree."""
+    key = (ra0, dec0, rottelpos, obsmjd, band, camera_name)
+    if key not in _rotSkyPos_cache:
+        theta = 270.0 - rottelpos + pointing_geometry(ra0, dec0, obsmjd)[2]
+        _rotSkyPos_cache[key] = theta % 360.0
+    return _rotSkyPos_cache[key]
+
+
 class EImage:
     """The rendered CCD in electrons: a float64 device tensor [ny][nx] of integer counts (Renderer.image) with the
     header of `eimage_header` (the reference's galsim.ImageF + FitsHeader)."""
@@ -109,8 +181,9 @@ class EImage:
 
 
 def get_primary_hdu(eimage, lsst_num, camera_name=None, added_keywords=None):
-    """Primary header of the raw file with the keywords the LSST stack needs (readout.py:208-299).  ROTANGLE is
-    taken from the e-image header (the reference recomputes it with a batoid WCS, readout.py:95-149)."""
+    """Primary header of the raw file with the keywords the LSST stack needs (readout.py:208-299).  ROTANGLE / ROTPA are
+    recomputed from the pointing, the rotator angle and the time, as the reference does "instead of using likely
+    inconsistent values from the instance catalog or opsim db" (readout.py:238-246, compute_rotSkyPos)."""
     eh = {k: (v[0] if isinstance(v, tuple) else v) for k, v in eimage.header.items()}
     exptime = eh["EXPTIME"]
     det_name = eh["DET_NAME"]
@@ -119,7 +192,7 @@ def get_primary_hdu(eimage, lsst_num, camera_name=None, added_keywords=None):
     ratel, dectel, band = eh["RATEL"], eh["DECTEL"], eh["FILTER"]
     mjd_obs = eh["MJD-OBS"]
     mjd_end = mjd_obs + exptime / 86400.
-    rotang = eh.get("ROTANGLE", 0.0)
+    rotang = compute_rotSkyPos(ratel, dectel, eh.get("ROTTELPOS", 0.0), mjd_obs, band, camera_name=camera_name)
     comcam = camera_name == "LsstComCamSim"
     telcode = "CC" if comcam else "MC"
     h = {"RUNNUM": eh["RUNNUM"], "MJD": eh["MJD"], "DATE": mjd_to_isot(eh["MJD"]), "DAYOBS": eh["DAYOBS"],

@@ -231,6 +231,36 @@ def test_primary_header_has_the_keywords_the_stack_needs():
     assert readout.get_primary_hdu(readout.EImage(None, flat), "x")["TRACKSYS"] == "LOCAL"
 
 
+def test_compute_rotSkyPos_from_pointing_rotator_and_time():
+    """imsim/readout.py:95-149: ROTANGLE = 270 - rotTelPos + pseudo parallactic angle.  The reference gets the angle from
+    astropy / ERFA through its batoid WCS factory; the geometric restatement is pinned by the header of the reference's own
+    example instance catalog (tests/golden/example_instcat_subset.txt): its altitude and azimuth are reproduced from
+    (ra, dec, mjd) alone, and OpSim's rotSkyPos there is rotTelPos minus the parallactic angle."""
+    hdr = {}
+    for line in open(os.path.join(os.path.dirname(__file__), "golden", "example_instcat_subset.txt")):
+        k, _, v = line.partition(" ")
+        if k in ("rightascension", "declination", "mjd", "altitude", "azimuth", "rotskypos", "rottelpos"):
+            hdr[k] = float(v)
+    alt, az, pq = readout.pointing_geometry(hdr["rightascension"], hdr["declination"], hdr["mjd"])
+    assert abs(alt - hdr["altitude"]) < 0.1 and abs(az - hdr["azimuth"]) < 0.1
+    assert abs((hdr["rottelpos"] - pq) % 360.0 - hdr["rotskypos"]) < 0.2
+    theta = readout.compute_rotSkyPos(hdr["rightascension"], hdr["declination"], hdr["rottelpos"], hdr["mjd"], "r")
+    assert 0.0 <= theta < 360.0 and abs(theta - (270.0 - hdr["rottelpos"] + pq) % 360.0) < 1e-12
+    # the parallactic angle of a source on the meridian south of the zenith is 0 (zenith due north of it): the hour angle
+    # follows the right ascension, so stepping ra through the local sidereal time must cross pq = 0 with d(pq)/d(ha) > 0
+    ra = np.linspace(0.0, 360.0, 7201)
+    pqs = np.array([readout.pointing_geometry(r, -60.0, 60143.4)[2] for r in ra])
+    alts = np.array([readout.pointing_geometry(r, -60.0, 60143.4)[0] for r in ra])
+    k = int(np.argmax(alts))                                   # upper culmination
+    assert abs((pqs[k] + 180.0) % 360.0 - 180.0) < 0.2 and abs(alts[k] - (90.0 - abs(-60.0 - readout.RUBIN_LATITUDE_DEG))) < 0.2   # precession of 23 years moves the declination by 0.13 deg
+    # and the raw file's header carries the recomputed angle, not the catalog's
+    eh = readout.eimage_header("R22_S11", 30.0, opsim_data={"mjd": hdr["mjd"], "band": "r", "fieldRA": hdr["rightascension"],
+                                                            "fieldDec": hdr["declination"], "rotTelPos": hdr["rottelpos"],
+                                                            "rotSkyPos": hdr["rotskypos"]})
+    ph = readout.get_primary_hdu(readout.EImage(None, eh), "x")
+    assert ph["ROTANGLE"] == theta and ph["ROTPA"] == theta
+
+
 def test_readout_needs_the_gpu():
     ccd, ro, nx, ny = _toy_readout()
     import torch

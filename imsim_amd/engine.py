@@ -734,7 +734,7 @@ class Renderer:
         if not (isinstance(index, np.ndarray) and index.dtype == np.int64 and index.flags.c_contiguous):
             index = np.ascontiguousarray(index, dtype=np.int64)
         n = len(index)
-        n_phot = (master.n_phot[index] if count is None else np.asarray(count)).astype(np.int64)
+        n_phot = None if t.is_tensor(count) else (master.n_phot[index] if count is None else np.asarray(count)).astype(np.int64)
         dst = t.empty(max(n, 1) * OBJECT_DTYPE.itemsize, dtype=t.uint8, device=self.device)
         cache = getattr(master, "_index_tensors", None)
         if cache is None:
@@ -745,14 +745,27 @@ class Renderer:
         else:
             idx_t = t.from_numpy(index).to(self.device)
             cache[id(index)] = (index, idx_t)
-        first_t = t.from_numpy(np.ascontiguousarray(first, dtype=np.int64)).to(self.device) if first is not None else None
-        count_t = t.from_numpy(np.ascontiguousarray(n_phot)).to(self.device) if count is not None else None
+        on_device = t.is_tensor(count)            # shares formed on the device (prepared_pooled_batches): no host copy of them
+        if on_device:
+            first_t, count_t = first, count
+        else:
+            first_t = t.from_numpy(np.ascontiguousarray(first, dtype=np.int64)).to(self.device) if first is not None else None
+            count_t = t.from_numpy(np.ascontiguousarray(n_phot)).to(self.device) if count is not None else None
         _abi.check(self.lib.ims_gather_rows(master.rows.data_ptr(), idx_t.data_ptr(), first_t.data_ptr() if first_t is not None else None,
                                             count_t.data_ptr() if count_t is not None else None, None, _abi.IMS_OBJ_FAINT,
                                             dst.data_ptr(), n, self._stream()), "ims_gather_rows")
         dst.keep = (idx_t, first_t, count_t)
         if not segments:                      # launches with one wavefront per object (ims_accumulate_small) need no segment table
             return dst, None, None
+        if on_device:
+            # segment table by the same arithmetic on the device; only the number of segments comes back (a launch parameter)
+            segs = (count_t + (self.scene.seg_size - 1)) // self.scene.seg_size
+            pre_t = t.zeros(n + 1, dtype=t.int64, device=self.device)
+            t.cumsum(segs, 0, out=pre_t[1:])
+            total = int(pre_t[-1].item())
+            pre_t.seg_object = (t.repeat_interleave(t.arange(n, dtype=t.int32, device=self.device), segs, output_size=total)
+                                if total else None)
+            return dst, np.array([0, total], dtype=np.int64), pre_t
         prefix = segment_prefix(n_phot, self.scene.seg_size)
         pre_t = t.from_numpy(prefix).to(self.device)
         seg_obj = np.repeat(np.arange(n, dtype=np.int32), np.diff(prefix))
@@ -1338,7 +1351,8 @@ class Renderer:
             if isinstance(batch[0], str) and batch[0] == "parts":
                 # pre-split by the caller: [(rows, first, count, small)] -- no masks over the whole batch
                 _, parts_in, bf_tag = batch
-                todo = [(np.asarray(rw), np.asarray(fi), np.asarray(co), self.lib.ims_accumulate_small if sm else self.lib.ims_accumulate_segments)
+                todo = [(np.asarray(rw), fi if isinstance(fi, tuple) else np.asarray(fi), None if co is None else np.asarray(co),
+                         self.lib.ims_accumulate_small if sm else self.lib.ims_accumulate_segments)
                         for rw, fi, co, sm in parts_in if len(rw)]
             else:
                 rows, first, count, bf_tag = batch
@@ -1353,9 +1367,24 @@ class Renderer:
                 if key not in base_cache:
                     base_cache[key] = (rows_s, base[rows_s], shot[rows_s] if master is not None else None)
                 _, base_rows, shot_rows = base_cache[key]
+                start_t = None
                 if master is not None:
                     small = entry is self.lib.ims_accumulate_small
-                    part_t, bprefix, bpre_t = self._gather_objects(master, shot_rows, None, count_s, segments=not small)
+                    if isinstance(first_s, tuple):
+                        # ("share", F, i, nb): the share [F i // nb, F (i + 1) // nb) of every object's F photons -- formed on the
+                        # device from F (uploaded once per index array), as are the pool offsets and the segment table
+                        _, F_s, bi, nbat = first_s
+                        dkey = ("dev", id(rows_s))
+                        if dkey not in base_cache:
+                            base_cache[dkey] = (self.torch.from_numpy(np.ascontiguousarray(F_s, dtype=np.int64)).to(self.device),
+                                                self.torch.from_numpy(np.ascontiguousarray(base_rows, dtype=np.int64)).to(self.device), F_s)
+                        F_t, base_rows_t, _ = base_cache[dkey]
+                        lo_t = (F_t * bi) // nbat
+                        count_t = (F_t * (bi + 1)) // nbat - lo_t
+                        start_t = base_rows_t + lo_t
+                        part_t, bprefix, bpre_t = self._gather_objects(master, shot_rows, None, count_t, segments=not small)
+                    else:
+                        part_t, bprefix, bpre_t = self._gather_objects(master, shot_rows, None, count_s, segments=not small)
                     n_part = len(rows_s)
                     if small:
                         bprefix, bpre_t = np.zeros(1, dtype=np.int64), None
@@ -1364,7 +1393,8 @@ class Renderer:
                     part["n_phot"] = count_s
                     part, part_t, bprefix, bpre_t = self._upload_objects(part)
                     n_part = len(part)
-                start_t = self.torch.from_numpy(np.ascontiguousarray(base_rows + first_s, dtype=np.int64)).to(self.device)
+                if start_t is None:
+                    start_t = self.torch.from_numpy(np.ascontiguousarray(base_rows + first_s, dtype=np.int64)).to(self.device)
                 tmp = rows_t = None
                 if realized is not None:
                     tmp = self.torch.zeros(n_part, dtype=self.torch.float64, device=self.device)

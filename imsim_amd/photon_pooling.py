@@ -299,12 +299,13 @@ def _prepared_image_device(renderer, table, modes, nbatch, seed, rank, world, re
     f_bounds = np.searchsorted(faint_where[f_order], np.arange(nb + 1))
     batches = []
     for i in range(nb):
-        lo_b = (F_big * i) // nb
-        lo_s = (F_small * i) // nb
+        # PHOT objects: the share [F i // nb, F (i + 1) // nb) as a descriptor -- the renderer forms it on the device from F
+        # (one upload per index array, not three arrays over a million objects per batch); the batch's FAINT objects, a few
+        # thousand rows that differ from batch to batch, come as host arrays
         fs = f_order[f_bounds[i]:f_bounds[i + 1]]
-        parts = [(rows_big, lo_b, (F_big * (i + 1)) // nb - lo_b, False),
-                 (np.concatenate([rows_small, rows_f[fs]]), np.concatenate([lo_s, np.zeros(len(fs), dtype=np.int64)]),
-                  np.concatenate([(F_small * (i + 1)) // nb - lo_s, n_phot[faint_idx[fs]]]), True)]
+        parts = [(rows_big, ("share", F_big, i, nb), None, False),
+                 (rows_small, ("share", F_small, i, nb), None, True),
+                 (rows_f[fs], np.zeros(len(fs), dtype=np.int64), n_phot[faint_idx[fs]], True)]
         batches.append(("parts", parts, (i % 255 + 1) if tagged else 0))
     r_rows = None
     if realized is not None:

@@ -272,40 +272,45 @@ def _prepared_image_device(renderer, table, modes, nbatch, seed, rank, world, re
         phot_idx, F, faint_idx, faint_where = phot_idx[keep_p], F[keep_p], faint_idx[keep_f], faint_where[keep_f]
     has = n_phot[faint_idx] > 0
     faint_idx, faint_where = faint_idx[has], faint_where[has]
-    shot = np.concatenate([phot_idx, faint_idx])
-    if not _pool_fits(renderer, int(n_phot[shot].sum())):
-        raise ValueError("photon pooling from a device table needs the HBM-resident pool (it does not fit)")
+    # per catalog object: 0 = not shot, 1 = PHOT, 2 + b = FAINT of batch b (one byte: the orderings below are radix sorts)
+    role = np.zeros(table.n, dtype=np.uint8 if nb < 250 else np.int32)
+    role[phot_idx] = 1
+    role[faint_idx] = (2 + faint_where).astype(role.dtype)
     if world > 1 or os.environ.get("IMS_POOL_SPATIAL", "1") != "0":
-        tile = (table.y[shot] // 256).astype(np.int64) * 4096 + (table.x[shot] // 256).astype(np.int64)
-        shot = shot[np.argsort(tile, kind="stable")]
+        # the shoot table by 256 x 256-pixel tiles of the CCD, catalog order inside a tile: a stable sort on a 16-bit key
+        tile = ((table.y.astype(np.int64) >> 8).clip(0, 255) << 8 | (table.x.astype(np.int64) >> 8).clip(0, 255)).astype(np.uint16)
+        order = np.argsort(tile, kind="stable")
+        shot = order[role[order] != 0]
     else:
-        shot = np.sort(shot)
-    row_of = np.full(table.n, -1, dtype=np.int64)
-    row_of[shot] = np.arange(len(shot))
+        shot = np.flatnonzero(role)
+    shot = np.ascontiguousarray(shot, dtype=np.int64)
+    n_shot = n_phot[shot]
+    if not _pool_fits(renderer, int(n_shot.sum())):
+        raise ValueError("photon pooling from a device table needs the HBM-resident pool (it does not fit)")
+    role_s = role[shot]
     # The PHOT objects appear in every batch, in the order of the shoot table (neighbours share image lines and boundary
     # state): rows and photon counts once, the batch only changes the share.  The batch's few FAINT objects follow them.
-    is_phot = np.zeros(table.n, dtype=bool)
-    is_phot[phot_idx] = True
-    rows_p = np.flatnonzero(is_phot[shot])                      # the PHOT objects' rows of the shoot table, ascending
-    Fp = n_phot[shot[rows_p]]
     # which of the two pixel-search launches a share goes to (ims_accumulate_segments above IMS_POOL_SMALL_MAX photons, one
     # wavefront per object below) is decided ONCE from the object's mean share: the two give the same result, and a fixed
     # split makes every batch two contiguous runs of index arithmetic instead of masks over a million objects
     small_max = int(os.environ.get("IMS_POOL_SMALL_MAX", "64"))
-    big = (Fp // nb) > small_max
-    rows_big, F_big, rows_small, F_small = rows_p[big], Fp[big], rows_p[~big], Fp[~big]
-    rows_f = row_of[faint_idx]
-    f_order = np.argsort(faint_where * (len(shot) + 1) + rows_f, kind="stable")        # by batch, then by row
-    f_bounds = np.searchsorted(faint_where[f_order], np.arange(nb + 1))
+    big = (role_s == 1) & ((n_shot // nb) > small_max)
+    rows_big = np.flatnonzero(big)
+    rows_small = np.flatnonzero((role_s == 1) & ~big)
+    F_big, F_small = n_shot[rows_big], n_shot[rows_small]
+    rows_faint = np.flatnonzero(role_s >= 2)                      # ascending rows ...
+    f_batch = role_s[rows_faint] - 2
+    f_sorted = rows_faint[np.argsort(f_batch.astype(np.uint8 if nb < 250 else np.int64), kind="stable")]   # ... by batch, then by row
+    f_bounds = np.searchsorted(np.sort(f_batch), np.arange(nb + 1))
     batches = []
     for i in range(nb):
         # PHOT objects: the share [F i // nb, F (i + 1) // nb) as a descriptor -- the renderer forms it on the device from F
         # (one upload per index array, not three arrays over a million objects per batch); the batch's FAINT objects, a few
         # thousand rows that differ from batch to batch, come as host arrays
-        fs = f_order[f_bounds[i]:f_bounds[i + 1]]
+        fr = f_sorted[f_bounds[i]:f_bounds[i + 1]]
         parts = [(rows_big, ("share", F_big, i, nb), None, False),
                  (rows_small, ("share", F_small, i, nb), None, True),
-                 (rows_f[fs], np.zeros(len(fs), dtype=np.int64), n_phot[faint_idx[fs]], True)]
+                 (fr, np.zeros(len(fr), dtype=np.int64), n_shot[fr], True)]
         batches.append(("parts", parts, (i % 255 + 1) if tagged else 0))
     r_rows = None
     if realized is not None:

@@ -2074,6 +2074,25 @@ static int psf_variant(const ims_render_params_t* p)
 
 int ims_known_optics_layout(uint64_t layout) { return layout == IMS_LAYOUT_RUBIN_LIKE ? 1 : 0; }
 
+// Dynamic LDS a photon-kernel launch asks for without using it: with more than a quarter of a CU's 160 KB per workgroup only
+// three photon workgroups are resident per CU.  Launches whose PSF gathers phase screens are bound by those scattered loads, not
+// by instruction issue, and run 2.5 % faster that way (C3b 34.7 -> 33.8 ms: fewer wavefronts thrash the caches less); the
+// analytic-PSF kernels are issue-bound and lose 9 % (C4 237 -> 258 ms; the free fourth slot does not buy the brighter-fatter
+// chains enough: C3 23.6 -> 25.4 ms), so they ask for none.  IMS_PHOTON_LDS (bytes) overrides both.
+static unsigned photon_lds_pad(const ims_render_params_t* p)
+{
+    static int env = -2;
+    if (env == -2) {
+        const char* e = getenv("IMS_PHOTON_LDS");
+        env = e ? atoi(e) : -1;
+        if (env > 65536 - 4096) env = -1;
+    }
+    if (env >= 0) return (unsigned)env;
+    for (int c = 0; c < p->n_psf; ++c)
+        if (p->psf[c].kind == IMS_PSF_SCREENS && p->atm != nullptr && p->screen_kick == nullptr) return 41984u;
+    return 0u;
+}
+
 int ims_shoot_accumulate(const ims_render_params_t* params, void* stream)
 {
     int rc = check_params(params);
@@ -2086,11 +2105,11 @@ int ims_shoot_accumulate(const ims_render_params_t* params, void* stream)
         const dim3 grid(grid_for_segments(params->n_segments));
         const int pv = is_default_chain(params) ? psf_variant(params) : -1;
         const bool lay = pv >= 0 && params->optics_layout == IMS_LAYOUT_RUBIN_LIKE && os_getenv_off("IMS_LAYOUT_KERNELS");
-        if (pv == 1 && lay) hipLaunchKernelGGL((k_shoot_accumulate<1, 1, IMS_LAYOUT_RUBIN_LIKE>), grid, dim3(256), 0, st, *params);
-        else if (pv == 0 && lay) hipLaunchKernelGGL((k_shoot_accumulate<1, 0, IMS_LAYOUT_RUBIN_LIKE>), grid, dim3(256), 0, st, *params);
-        else if (pv == 1) hipLaunchKernelGGL((k_shoot_accumulate<1, 1>), grid, dim3(256), 0, st, *params);
-        else if (pv == 0) hipLaunchKernelGGL((k_shoot_accumulate<1, 0>), grid, dim3(256), 0, st, *params);
-        else hipLaunchKernelGGL((k_shoot_accumulate<0, 0>), grid, dim3(256), 0, st, *params);
+        if (pv == 1 && lay) hipLaunchKernelGGL((k_shoot_accumulate<1, 1, IMS_LAYOUT_RUBIN_LIKE>), grid, dim3(256), photon_lds_pad(params), st, *params);
+        else if (pv == 0 && lay) hipLaunchKernelGGL((k_shoot_accumulate<1, 0, IMS_LAYOUT_RUBIN_LIKE>), grid, dim3(256), photon_lds_pad(params), st, *params);
+        else if (pv == 1) hipLaunchKernelGGL((k_shoot_accumulate<1, 1>), grid, dim3(256), photon_lds_pad(params), st, *params);
+        else if (pv == 0) hipLaunchKernelGGL((k_shoot_accumulate<1, 0>), grid, dim3(256), photon_lds_pad(params), st, *params);
+        else hipLaunchKernelGGL((k_shoot_accumulate<0, 0>), grid, dim3(256), photon_lds_pad(params), st, *params);
     }
     HIP_TRY(hipGetLastError());
     return IMS_OK;
@@ -2128,13 +2147,13 @@ int ims_shoot_ops_photons(const ims_render_params_t* params, const int64_t* phot
         const int pv = is_default_chain(params) ? psf_variant(params) : -1;
         const bool lay = pv >= 0 && params->optics_layout == IMS_LAYOUT_RUBIN_LIKE && os_getenv_off("IMS_LAYOUT_KERNELS");
         if (pool->converted && pv == 1 && lay)
-            hipLaunchKernelGGL((k_shoot_photons<2, 1, 1, IMS_LAYOUT_RUBIN_LIKE>), grid, dim3(256), 0, st, *params, photon_offset, *pool);
+            hipLaunchKernelGGL((k_shoot_photons<2, 1, 1, IMS_LAYOUT_RUBIN_LIKE>), grid, dim3(256), photon_lds_pad(params), st, *params, photon_offset, *pool);
         else if (pool->converted && pv == 0 && lay)
-            hipLaunchKernelGGL((k_shoot_photons<2, 1, 0, IMS_LAYOUT_RUBIN_LIKE>), grid, dim3(256), 0, st, *params, photon_offset, *pool);
-        else if (pool->converted && pv == 1) hipLaunchKernelGGL((k_shoot_photons<2, 1, 1>), grid, dim3(256), 0, st, *params, photon_offset, *pool);
-        else if (pool->converted && pv == 0) hipLaunchKernelGGL((k_shoot_photons<2, 1, 0>), grid, dim3(256), 0, st, *params, photon_offset, *pool);
-        else if (pool->converted) hipLaunchKernelGGL((k_shoot_photons<2, 0>), grid, dim3(256), 0, st, *params, photon_offset, *pool);
-        else hipLaunchKernelGGL((k_shoot_photons<1, 0>), grid, dim3(256), 0, st, *params, photon_offset, *pool);
+            hipLaunchKernelGGL((k_shoot_photons<2, 1, 0, IMS_LAYOUT_RUBIN_LIKE>), grid, dim3(256), photon_lds_pad(params), st, *params, photon_offset, *pool);
+        else if (pool->converted && pv == 1) hipLaunchKernelGGL((k_shoot_photons<2, 1, 1>), grid, dim3(256), photon_lds_pad(params), st, *params, photon_offset, *pool);
+        else if (pool->converted && pv == 0) hipLaunchKernelGGL((k_shoot_photons<2, 1, 0>), grid, dim3(256), photon_lds_pad(params), st, *params, photon_offset, *pool);
+        else if (pool->converted) hipLaunchKernelGGL((k_shoot_photons<2, 0>), grid, dim3(256), photon_lds_pad(params), st, *params, photon_offset, *pool);
+        else hipLaunchKernelGGL((k_shoot_photons<1, 0>), grid, dim3(256), photon_lds_pad(params), st, *params, photon_offset, *pool);
     }
     HIP_TRY(hipGetLastError());
     return IMS_OK;

@@ -24,6 +24,14 @@
  * integer ops (DESIGN.md "numerics spec"), so the HIP kernels and the CPU oracle produce the same
  * bits.  Random numbers are Philox4x32-10, counter-addressed by (object id, photon index, slot):
  * results do not depend on batching, launch geometry or the number of GPUs.
+ *
+ * Process model: ONE process per GPU.  The library keeps process-global state -- the hipEvent pairs of
+ * ims_enable_timing / ims_last_kernel_ms, the events of ims_run_plan's record / wait items, the table of streams of
+ * ims_plan_* -- in file-static containers without locks: calls into it must come from one thread at a time (the
+ * message of ims_last_error is thread-local, the state is not).  Launches are asynchronous: an entry point returns
+ * after hipGetLastError() of its own launches, so a fault inside a kernel surfaces as IMS_ERR_HIP at the next call
+ * that synchronises (ims_last_kernel_ms, a copy, the caller's own stream synchronisation), not at the call that
+ * launched it.
  */
 #ifndef IMSIM_HIP_H
 #define IMSIM_HIP_H

@@ -650,13 +650,15 @@ _DEVICE_STREAMS = {}
 
 
 def _device_streams(torch, device):
-    """The four streams of the launch plans (chain, bulk, chain1, chain2), ONE set per device and process, shared by every
+    """The five streams of the launch plans (chain, bulk, chain1, chain2, chain3; the last only with three thresholds in
+    IMS_CHAIN_CLASSES -- measured slower), ONE set per device and process, shared by every
     Renderer on that device.  HIP multiplexes its streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default):
     with a fresh set per renderer the chain of one CCD of a focal plane lands in the hardware queue of another CCD's wide
     launches and waits behind them (kernel trace of C5: one kernel in flight for two thirds of the time).  With one set,
     the plans of the CCDs in flight interleave role by role: the wide launches of the next CCD fill the GPU while the
     latency-bound chain of the previous one runs.  IMS_PRIVATE_STREAMS=1 gives every renderer its own set again."""
-    pr = [int(v) for v in os.environ.get("IMS_STREAM_PRIORITIES", "-1,0,0,0").split(",")]   # chain, bulk, chain1, chain2
+    pr = [int(v) for v in os.environ.get("IMS_STREAM_PRIORITIES", "-1,0,0,0,0").split(",")]   # chain, bulk, chain1, chain2, chain3
+    pr = (pr + [0] * 5)[:5]
     if os.environ.get("IMS_PRIVATE_STREAMS", "0") != "0":
         return tuple(torch.cuda.Stream(device, priority=p) for p in pr)
     # IMS_STREAM_SETS sets (default 1), handed to the renderers of a device in turn
@@ -673,8 +675,8 @@ def _device_streams(torch, device):
 class Renderer:
     """One CCD on one GPU."""
 
-    STREAMS = {"chain": 0, "bulk": 1, "chain1": 2, "chain2": 3}
-    CHAIN_STREAMS = ("chain", "chain1", "chain2")
+    STREAMS = {"chain": 0, "bulk": 1, "chain1": 2, "chain2": 3, "chain3": 4}
+    CHAIN_STREAMS = ("chain", "chain1", "chain2", "chain3")
 
     def __init__(self, scene: Scene, device="cuda:0"):
         self.lib = _abi.load()
@@ -689,7 +691,8 @@ class Renderer:
         self.image = self.torch.zeros((scene.ny, scene.nx), dtype=self.torch.float64, device=self.device)
         # two side streams: the sequential brighter-fatter chain of the bright objects runs at high
         # priority while the wide single-launch work fills the CUs it leaves idle
-        self.s_chain, self.s_bulk, self.s_chain1, self.s_chain2 = _device_streams(self.torch, self.device)
+        self.plan_streams = _device_streams(self.torch, self.device)                 # index = Renderer.STREAMS
+        self.s_chain, self.s_bulk, self.s_chain1, self.s_chain2, self.s_chain3 = self.plan_streams
         self.use_bf_tags = os.environ.get("IMS_BF_TAGS", "0") != "0"
         # round-count thresholds that cut the bright objects into concurrent chains (plan_lsst_image)
         self.chain_class_rounds = tuple(int(v) for v in os.environ.get("IMS_CHAIN_CLASSES", "40,6").split(",") if v)
@@ -902,7 +905,7 @@ class Renderer:
             n_rounds = (total + nrecalc - 1) // nrecalc
             # An object's rounds only depend on its OWN earlier rounds, so the few very bright objects
             # (hundreds of short, latency-bound rounds) must not wait for the many moderately bright
-            # ones: the group is cut into up to three classes by round count, each advancing on its
+            # ones: the group is cut into up to three classes (four with a third threshold) by round count, each advancing on its
             # own chain stream, the longest chain first in every queue.
             cuts = [int(np.count_nonzero(n_rounds >= t)) for t in self.chain_class_rounds]
             bounds = [0] + [c for c in cuts if 0 < c < len(grp)] + [len(grp)]
@@ -1082,7 +1085,7 @@ class Renderer:
         main = torch.cuda.current_stream(self.device)
         ev0 = torch.cuda.Event()
         ev0.record(main)
-        streams = (self.s_chain, self.s_bulk, self.s_chain1, self.s_chain2)      # index = Renderer.STREAMS
+        streams = self.plan_streams                                              # index = Renderer.STREAMS
         for st in streams:
             st.wait_event(ev0)
         b = self.bound
@@ -1183,9 +1186,9 @@ class Renderer:
             self.s_chain2.wait_stream(main)
             with t.cuda.stream(self.s_chain2):
                 go()
-            streams = (self.s_chain, self.s_bulk, self.s_chain1, self.s_chain2)
-            sarr = (C.c_void_p * 4)(*[st.cuda_stream for st in streams])
-            _abi.check(self.lib.ims_run_plan(rec, 1, None, None, None, sarr, 4), "ims_run_plan")
+            streams = self.plan_streams
+            sarr = (C.c_void_p * len(streams))(*[st.cuda_stream for st in streams])
+            _abi.check(self.lib.ims_run_plan(rec, 1, None, None, None, sarr, len(streams)), "ims_run_plan")
         run.keep = keep
         run.photons = total
         run.side = side

@@ -565,7 +565,7 @@ def _c5_objects(cat, phot, scene):
     return t, sizes
 
 
-def _c5_step(renderer, objects, rank=0, world=1, concurrent=2):
+def _c5_step(renderer, objects, rank=0, world=1, concurrent=3):
     """One step = every CCD this rank owns (CCD i -> rank i mod world, no exchange), each through a FRESH renderer: scene
     tables, the CCD's static pixel-boundary state, launch plan, ONE arena upload, the run, and the float32 image back on the
     host -- what `focal_plane.render_focal_plane` does per CCD.  Up to `concurrent` CCDs are in flight on their own streams."""

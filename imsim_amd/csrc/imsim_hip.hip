@@ -38,9 +38,12 @@ static bool os_getenv_off(const char* name)
 // and the query is bracketed by a hipEvent pair on the launch stream (which: 1 = ims_shoot_accumulate,
 // 2 = ims_shoot_ops_photons, 3 = ims_fft_kspace_fill).
 #include <vector>
+#include <mutex>
+#include <unordered_map>
 static int g_timing = 0;
 static std::vector<hipEvent_t> g_events;   // pairs
 static size_t g_events_used = 0;
+static std::mutex g_state_mutex;           // the event tables below may be reached from several host threads (focal plane: one per CCD in flight)
 
 struct LaunchTimer {
     hipStream_t st;
@@ -49,17 +52,24 @@ struct LaunchTimer {
     LaunchTimer(hipStream_t s, int which) : st(s), slot(0), on(g_timing == which)
     {
         if (on) {
-            if (g_events_used + 2 > g_events.size()) {
-                hipEvent_t a, b;
-                (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-                g_events.push_back(a); g_events.push_back(b);
+            hipEvent_t first;
+            {
+                std::lock_guard<std::mutex> lock(g_state_mutex);
+                if (g_events_used + 2 > g_events.size()) {
+                    hipEvent_t a, b;
+                    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+                    g_events.push_back(a); g_events.push_back(b);
+                }
+                slot = g_events_used;
+                g_events_used += 2;
+                first = g_events[slot];
+                second = g_events[slot + 1];
             }
-            slot = g_events_used;
-            g_events_used += 2;
-            (void)hipEventRecord(g_events[slot], st);
+            (void)hipEventRecord(first, st);
         }
     }
-    ~LaunchTimer() { if (on) (void)hipEventRecord(g_events[slot + 1], st); }
+    ~LaunchTimer() { if (on) (void)hipEventRecord(second, st); }
+    hipEvent_t second;
 };
 
 // -DIMS_PROBE (measurement builds only, tools/dbg/round_probe.py): the stamps of ims_photon.h's PROBE / PROBE_WG, copied out
@@ -2406,14 +2416,16 @@ int ims_sensor_publish_pairs(const ims_sensor_t* sensor_dev, const ims_sensor_t*
 // library events of RECORD / WAIT items (one process per GPU)
 static int plan_event(int number, hipEvent_t* out)
 {
-    static std::vector<hipEvent_t> evs;
+    static std::unordered_map<int, hipEvent_t> evs;
     if (number < 0 || number > 65535) return set_err(IMS_ERR_ARG, "plan event number out of range");
-    while ((int)evs.size() <= number) {
+    std::lock_guard<std::mutex> lock(g_state_mutex);
+    auto it = evs.find(number);
+    if (it == evs.end()) {
         hipEvent_t e;
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        evs.push_back(e);
+        it = evs.emplace(number, e).first;
     }
-    *out = evs[number];
+    *out = it->second;
     return IMS_OK;
 }
 

@@ -8,6 +8,7 @@ import ctypes as C
 import math
 import os
 import dataclasses
+import itertools
 from typing import List, Optional
 
 import numpy as np
@@ -672,13 +673,37 @@ def _device_streams(torch, device):
     return sets["sets"][k]
 
 
+_RENDERER_SERIAL = itertools.count()
+
+
+def _focal_streams(torch, device, peek=False, top_index=None):
+    """Plan streams of a renderer that is one CCD of a focal plane (Renderer(..., stream_roles="focal")): four streams per
+    device for ALL its renderers -- two for the long top chains, taken in turn, one for the wide launches, one for the
+    middle and low chain classes -- in the order of Renderer.STREAMS.  A CCD of 10 k sources keeps the GPU busy for 3 - 4 ms
+    but needs ~10 ms for the 100 - 200 dependent rounds of its brightest star; with one stream set for every renderer
+    (_device_streams) those chains queue behind each other, with a set per renderer eight streams share four hardware queues
+    and a chain sits behind another CCD's wide launches.  Here the top chains of two CCDs advance side by side on queues
+    that hold nothing else."""
+    key = ("focal", str(device))
+    st = _DEVICE_STREAMS.get(key)
+    if st is None:
+        st = _DEVICE_STREAMS[key] = {"next": 0, "top": [torch.cuda.Stream(device, priority=-1), torch.cuda.Stream(device, priority=-1)],
+                                     "bulk": torch.cuda.Stream(device), "mid": torch.cuda.Stream(device)}
+    if top_index is not None:          # the caller deals the two top streams itself (CCDs enqueued from several host threads)
+        return (st["top"][top_index % 2], st["bulk"], st["mid"], st["mid"], st["mid"])
+    top = st["top"][st["next"] % 2]
+    if not peek:                       # peek: the set the NEXT renderer of the device will get
+        st["next"] += 1
+    return (top, st["bulk"], st["mid"], st["mid"], st["mid"])
+
+
 class Renderer:
     """One CCD on one GPU."""
 
     STREAMS = {"chain": 0, "bulk": 1, "chain1": 2, "chain2": 3, "chain3": 4}
     CHAIN_STREAMS = ("chain", "chain1", "chain2", "chain3")
 
-    def __init__(self, scene: Scene, device="cuda:0"):
+    def __init__(self, scene: Scene, device="cuda:0", stream_roles="single", top_index=None):
         self.lib = _abi.load()
         self.mem = DeviceMem(device)
         self.torch = self.mem.torch
@@ -691,7 +716,14 @@ class Renderer:
         self.image = self.torch.zeros((scene.ny, scene.nx), dtype=self.torch.float64, device=self.device)
         # two side streams: the sequential brighter-fatter chain of the bright objects runs at high
         # priority while the wide single-launch work fills the CUs it leaves idle
-        self.plan_streams = _device_streams(self.torch, self.device)                 # index = Renderer.STREAMS
+        if stream_roles == "focal":
+            self.plan_streams = _focal_streams(self.torch, self.device, top_index=top_index)
+        else:
+            self.plan_streams = _device_streams(self.torch, self.device)              # index = Renderer.STREAMS
+        self._plans_run = 0
+        # the library's record / wait events are process-wide and addressed by number: every renderer numbers its own from a
+        # block of 1 000, so that the plans of several CCDs may be enqueued from different host threads at the same time
+        self._event_block = (next(_RENDERER_SERIAL) % 48) * 1000
         self.s_chain, self.s_bulk, self.s_chain1, self.s_chain2, self.s_chain3 = self.plan_streams
         self.use_bf_tags = os.environ.get("IMS_BF_TAGS", "0") != "0"
         # round-count thresholds that cut the bright objects into concurrent chains (plan_lsst_image)
@@ -883,7 +915,7 @@ class Renderer:
             normal, groups = plan_bf_groups(objects, nrecalc, b.n_static_slots, b.static_cells, ss.scratch_cells,
                                             b.slot_capacity, self.max_pool_photons)
             self.pairs_begin = None
-        n_events = 0
+        n_events = self._event_block
         render_done = False
         for idx, slots in groups:
             pair_shift = 0
@@ -1086,7 +1118,7 @@ class Renderer:
         ev0 = torch.cuda.Event()
         ev0.record(main)
         streams = self.plan_streams                                              # index = Renderer.STREAMS
-        for st in streams:
+        for st in set(streams):
             st.wait_event(ev0)
         b = self.bound
         sensor_dev = b.sensor_dev_ptr if self.scene.sensor is not None else None
@@ -1097,7 +1129,9 @@ class Renderer:
             if kind == "slots":
                 # the slot table is written by a copy on the chain stream: ordered behind everything queued so far on
                 # every stream and ahead of everything that follows, on the GPU (no host synchronisation)
-                for st in streams:
+                # (a renderer's FIRST plan has nothing of its own queued yet -- what the shared streams hold belongs to other
+                # renderers, other buffers: a CCD of a focal plane must not wait for the wide launches of the previous one)
+                for st in (set(streams) if self._plans_run else ()):
                     if st is not self.s_chain:
                         ev = torch.cuda.Event()
                         ev.record(st)
@@ -1106,12 +1140,13 @@ class Renderer:
                     b.set_private_slots(payload)
                     ev = torch.cuda.Event()
                     ev.record(self.s_chain)
-                for st in streams:
+                for st in set(streams):
                     if st is not self.s_chain:
                         st.wait_event(ev)
                 continue
             _abi.check(self.lib.ims_run_plan(payload, n, sensor_dev, sensor_host, changed, sarr, len(streams)), "ims_run_plan")
-        for st in streams:
+        self._plans_run += 1
+        for st in set(streams):
             ev = torch.cuda.Event()
             ev.record(st)
             main.wait_event(ev)

@@ -2,13 +2,17 @@
 
 The reference fans the CCDs of a visit out to worker processes (`output.nproc`, imsim/ccd.py:72-89); every
 CCD is an independent `LSST_Image` build.  Here the CCDs are dealt round-robin to the ranks
-(`parallel.shard_ccds`, one process per GPU, no exchange) and inside a rank up to `concurrent` CCDs (default 2: measured
-10.5 ms per 10 k-source CCD against 11.4 with three in flight) are in
-flight at once, each anchored to its own HIP stream: while the GPU works through the launch plan of one CCD
-(which `Renderer.execute_plan` only enqueues), the host builds the object table and plan of the next.
+(`parallel.shard_ccds`, one process per GPU, no exchange) and inside a rank up to `concurrent` CCDs (default 3) are in
+flight at once: while the GPU works through the launch plan of one CCD (which `Renderer.execute_plan` only enqueues), the
+host builds the object table and plan of the next.  All CCDs of a device share FOUR streams by role
+(`engine._focal_streams`: two for the long top chains, taken in turn, one for the wide launches, one for the middle and low
+chain classes; HIP has four hardware queues, and any further stream shares one): 7.6 ms per 10 k-source CCD against
+9.9 - 11.7 ms with one stream set for every renderer plus an anchor stream per CCD in flight (`IMS_FOCAL_STREAMS=0`).
 Results do not depend on `concurrent`, on the rank count or on the order of the CCDs: every photon's random
 stream is addressed by (CCD seed, object id, photon index).
 """
+import os
+
 from . import parallel
 from .engine import Renderer
 
@@ -16,7 +20,7 @@ from .engine import Renderer
 _ANCHOR_STREAMS = {}
 
 
-def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent=2, nrecalc=None, sink=None):
+def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent=3, nrecalc=None, sink=None):
     """ccds: sequence of CCD keys (detector numbers / names); build(key) -> (scene, objects) prepares one CCD
     on the host.  Returns {key: float32 image as a host array} for the CCDs this rank owns.
 
@@ -28,6 +32,8 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
     mine = parallel.shard_ccds(list(ccds), rank, world)
     if concurrent < 1:
         raise ValueError("concurrent must be >= 1")
+    # plan streams by role for all CCDs of the device: the long chains of two CCDs side by side (engine._focal_streams)
+    roles = "focal" if os.environ.get("IMS_FOCAL_STREAMS", "1") != "0" else "single"
     # the anchor streams are kept per device for the life of the process: PyTorch's caching allocator files a freed block
     # under the stream it was allocated on, so fresh streams per call would miss the cache and hipMalloc every CCD's
     # gigabytes of sensor state again (measured: 13 -> 27 .. 34 ms per CCD for the calls that do)
@@ -50,20 +56,69 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
             out[key] = host.numpy().copy()
         in_flight[slot] = None                 # drops the renderer: its HBM goes back to the caching allocator
 
-    for k, key in enumerate(mine):
-        slot = k % len(streams)
-        collect(slot)                          # the CCD that used this stream before
+    anchor_role = os.environ.get("IMS_FOCAL_ANCHOR", "top") if roles == "focal" else ""
+
+    def enqueue(k, key, slot):
+        """Everything of one CCD up to the event behind its image copy (host work + asynchronous launches)."""
+        torch.cuda.set_device(dev)
         scene, objects = build(key)            # host work, overlaps with the CCDs still running on the GPU
-        with torch.cuda.stream(streams[slot]):
-            renderer = Renderer(scene, dev)
+        anchor = init_on = copy_on = streams[slot]
+        top_index = None
+        if anchor_role:
+            # no stream beside the four plan streams of the device: a fifth would share a hardware queue with one of them
+            from .engine import _focal_streams
+            top_index = k % 2
+            peek = _focal_streams(torch, dev, top_index=top_index)
+            by_role = {"top": peek[0], "bulk": peek[1], "mid": peek[2]}
+            anchor = by_role[anchor_role]
+            # measured on 24 CCDs of C5 (tools/dbg/r3_c5.sh): the static state's initialisation beside the wide launches, the
+            # image copy behind the middle chains: 7.2 ms per CCD with three CCDs in flight; everything on the top stream 8.0 - 8.7,
+            # the copy on the stream of the wide launches 12 - 14
+            init_on = by_role[os.environ.get("IMS_FOCAL_INIT", "bulk")]
+            copy_on = by_role[os.environ.get("IMS_FOCAL_COPY", "mid")]
+        with torch.cuda.stream(init_on):
+            renderer = Renderer(scene, dev, stream_roles=roles, top_index=top_index)
+            ready = torch.cuda.Event()
+            ready.record(init_on)
+        with torch.cuda.stream(anchor):
+            anchor.wait_event(ready)
             renderer.render_lsst_image(objects, nrecalc=nrecalc)
+            through = torch.cuda.Event()
+            through.record(anchor)
+        with torch.cuda.stream(copy_on):
+            copy_on.wait_event(through)
             img = renderer.image_float()
             if pinned[slot] is None or pinned[slot].shape != img.shape:
                 pinned[slot] = torch.empty(img.shape, dtype=img.dtype, pin_memory=True)
             pinned[slot].copy_(img, non_blocking=True)
             done = torch.cuda.Event()
-            done.record(streams[slot])
-        in_flight[slot] = (key, renderer, pinned[slot], done)
+            done.record(copy_on)
+        return key, renderer, pinned[slot], done
+
+    # host threads (IMS_FOCAL_THREADS, default 1): the plan of one CCD is numpy and ctypes work that releases the interpreter
+    # lock for most of its time (ims_run_plan enqueues ~550 launches per CCD in C), so two CCDs can be prepared side by
+    # side and the library's event tables are locked for it -- measured on 24 CCDs of C5: 7.7 / 7.8 / 8.7 ms per CCD with
+    # 1 / 2 / 3 threads: the host is not what a CCD waits for; results do not depend on it
+    n_threads = max(1, min(int(os.environ.get("IMS_FOCAL_THREADS", "1")), len(streams))) if roles == "focal" else 1
+    if n_threads == 1:
+        for k, key in enumerate(mine):
+            slot = k % len(streams)
+            collect(slot)                          # the CCD that used this stream before
+            in_flight[slot] = enqueue(k, key, slot)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(n_threads) as pool_ex:
+            futures = [None] * len(streams)
+            for k, key in enumerate(mine):
+                slot = k % len(streams)
+                if futures[slot] is not None:
+                    in_flight[slot] = futures[slot].result()
+                    futures[slot] = None
+                    collect(slot)
+                futures[slot] = pool_ex.submit(enqueue, k, key, slot)
+            for slot in range(len(streams)):
+                if futures[slot] is not None:
+                    in_flight[slot] = futures[slot].result()
     for slot in range(len(streams)):
         collect(slot)
     return out

@@ -12,6 +12,7 @@ Results do not depend on `concurrent`, on the rank count or on the order of the 
 stream is addressed by (CCD seed, object id, photon index).
 """
 import os
+import time
 
 from . import parallel
 from .engine import Renderer
@@ -57,6 +58,7 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
         in_flight[slot] = None                 # drops the renderer: its HBM goes back to the caching allocator
 
     anchor_role = os.environ.get("IMS_FOCAL_ANCHOR", "top") if roles == "focal" else ""
+    host_s = [0.0]
 
     def enqueue(k, key, slot):
         """Everything of one CCD up to the event behind its image copy (host work + asynchronous launches)."""
@@ -104,7 +106,9 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
         for k, key in enumerate(mine):
             slot = k % len(streams)
             collect(slot)                          # the CCD that used this stream before
+            t0 = time.perf_counter()
             in_flight[slot] = enqueue(k, key, slot)
+            host_s[0] += time.perf_counter() - t0
     else:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(n_threads) as pool_ex:
@@ -121,4 +125,5 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
                     in_flight[slot] = futures[slot].result()
     for slot in range(len(streams)):
         collect(slot)
+    render_focal_plane.last_host_ms_per_ccd = 1e3 * host_s[0] / max(len(mine), 1)     # host time of the enqueues (one thread)
     return out

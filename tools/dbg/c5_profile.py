@@ -31,7 +31,8 @@ for conc in ((int(os.environ["C5_ONLY"]),) * 2 if "C5_ONLY" in os.environ else (
     t0 = time.perf_counter()
     step()
     torch.cuda.synchronize()
-    print(f"concurrent {conc}: {1e3 * (time.perf_counter() - t0) / n_ccd:.1f} ms per CCD")
+    print(f"concurrent {conc}: {1e3 * (time.perf_counter() - t0) / n_ccd:.1f} ms per CCD "
+          f"(host enqueue {getattr(focal_plane.render_focal_plane, 'last_host_ms_per_ccd', float('nan')):.1f} ms per CCD)")
 if "C5_ONLY" in os.environ:
     sys.exit(0)
 step = configs._c5_step(r, objects, concurrent=3)

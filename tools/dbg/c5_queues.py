@@ -17,6 +17,10 @@ for q, ks in sorted(byq.items()):
     names = collections.Counter(k[4] for k in ks)
     print("queue %s: n %6d busy %.1f ms streams %d  %s" % (q, len(ks), sum(k[1] - k[0] for k in ks) / 1e6, len(set(k[3] for k in ks)),
                                                           dict(names.most_common(3))))
+    busy = collections.Counter()
+    for k in ks:
+        busy[k[4]] += k[1] - k[0]
+    print("      busy by kernel [ms]:", {n: round(v / 1e6, 1) for n, v in busy.most_common(6)})
 # concurrency histogram: how many kernels run at a time, weighted by time
 ev = sorted([(k[0], 1) for k in K] + [(k[1], -1) for k in K])
 lvl, last, hist = 0, ev[0][0], collections.Counter()

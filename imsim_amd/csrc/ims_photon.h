@@ -271,6 +271,11 @@ IMS_DEV void run_psf(const ims_render_params_t& P, const ims_object_t& o, int64_
     if (PSF == 1) {
         apply_psf<IMS_PSF_RADIAL>(P, o, 0, k, rng, ph);
         apply_psf<IMS_PSF_GAUSSIAN>(P, o, 1, k, rng, ph);
+    } else if (PSF == 2) {
+        // imSim's default AtmosphericPSF: phase screens, second kick (a radial table), Gaussian
+        apply_psf<IMS_PSF_SCREENS>(P, o, 0, k, rng, ph);
+        apply_psf<IMS_PSF_RADIAL>(P, o, 1, k, rng, ph);
+        apply_psf<IMS_PSF_GAUSSIAN>(P, o, 2, k, rng, ph);
     } else {
         for (int c = 0; c < P.n_psf; ++c) apply_psf(P, o, c, k, rng, ph);
     }

@@ -2073,12 +2073,18 @@ static bool is_default_chain(const ims_render_params_t* p)
     return true;
 }
 
-// 1: radial table then Gaussian (run_psf<1>); 0: anything else.  (A variant for phase screens + radial table + Gaussian
-// was measured SLOWER than the component loop: C3b 36.9 -> 38.6 ms; not kept.)
+// 1: radial table then Gaussian (run_psf<1>); 2: phase screens, second-kick table, Gaussian (run_psf<2>: imSim's default
+// AtmosphericPSF); 0: anything else.  (Variant 2 is slower than the component loop at four workgroups per CU -- C3b 36.9 -> 38.6 ms
+// in round 2, 35.2 -> 35.9 ms now -- and faster at the three that launches with phase screens run with (photon_lds_pad):
+// 33.7 -> 33.2 ms.  IMS_PSF_SCREENS_KERNEL=0 takes the loop.)
 static int psf_variant(const ims_render_params_t* p)
 {
     if (!os_getenv_off("IMS_CHAIN_KERNELS")) return 0;
     if (p->n_psf == 2 && p->psf[0].kind == IMS_PSF_RADIAL && p->psf[1].kind == IMS_PSF_GAUSSIAN) return 1;
+    static int screens_variant = -1;
+    if (screens_variant < 0) { const char* e = getenv("IMS_PSF_SCREENS_KERNEL"); screens_variant = e ? atoi(e) : 1; }
+    if (screens_variant && p->n_psf == 3 && p->psf[0].kind == IMS_PSF_SCREENS && p->psf[1].kind == IMS_PSF_RADIAL &&
+        p->psf[2].kind == IMS_PSF_GAUSSIAN && p->atm != nullptr) return 2;
     return 0;
 }
 
@@ -2115,7 +2121,9 @@ int ims_shoot_accumulate(const ims_render_params_t* params, void* stream)
         const dim3 grid(grid_for_segments(params->n_segments));
         const int pv = is_default_chain(params) ? psf_variant(params) : -1;
         const bool lay = pv >= 0 && params->optics_layout == IMS_LAYOUT_RUBIN_LIKE && os_getenv_off("IMS_LAYOUT_KERNELS");
-        if (pv == 1 && lay) hipLaunchKernelGGL((k_shoot_accumulate<1, 1, IMS_LAYOUT_RUBIN_LIKE>), grid, dim3(256), photon_lds_pad(params), st, *params);
+        if (pv == 2 && lay) hipLaunchKernelGGL((k_shoot_accumulate<1, 2, IMS_LAYOUT_RUBIN_LIKE>), grid, dim3(256), photon_lds_pad(params), st, *params);
+        else if (pv == 2) hipLaunchKernelGGL((k_shoot_accumulate<1, 0>), grid, dim3(256), photon_lds_pad(params), st, *params);
+        else if (pv == 1 && lay) hipLaunchKernelGGL((k_shoot_accumulate<1, 1, IMS_LAYOUT_RUBIN_LIKE>), grid, dim3(256), photon_lds_pad(params), st, *params);
         else if (pv == 0 && lay) hipLaunchKernelGGL((k_shoot_accumulate<1, 0, IMS_LAYOUT_RUBIN_LIKE>), grid, dim3(256), photon_lds_pad(params), st, *params);
         else if (pv == 1) hipLaunchKernelGGL((k_shoot_accumulate<1, 1>), grid, dim3(256), photon_lds_pad(params), st, *params);
         else if (pv == 0) hipLaunchKernelGGL((k_shoot_accumulate<1, 0>), grid, dim3(256), photon_lds_pad(params), st, *params);
@@ -2156,7 +2164,11 @@ int ims_shoot_ops_photons(const ims_render_params_t* params, const int64_t* phot
         const dim3 grid(grid_for_segments(params->n_segments));
         const int pv = is_default_chain(params) ? psf_variant(params) : -1;
         const bool lay = pv >= 0 && params->optics_layout == IMS_LAYOUT_RUBIN_LIKE && os_getenv_off("IMS_LAYOUT_KERNELS");
-        if (pool->converted && pv == 1 && lay)
+        if (pool->converted && pv == 2 && lay)
+            hipLaunchKernelGGL((k_shoot_photons<2, 1, 2, IMS_LAYOUT_RUBIN_LIKE>), grid, dim3(256), photon_lds_pad(params), st, *params, photon_offset, *pool);
+        else if (pool->converted && pv == 2)
+            hipLaunchKernelGGL((k_shoot_photons<2, 1, 0>), grid, dim3(256), photon_lds_pad(params), st, *params, photon_offset, *pool);
+        else if (pool->converted && pv == 1 && lay)
             hipLaunchKernelGGL((k_shoot_photons<2, 1, 1, IMS_LAYOUT_RUBIN_LIKE>), grid, dim3(256), photon_lds_pad(params), st, *params, photon_offset, *pool);
         else if (pool->converted && pv == 0 && lay)
             hipLaunchKernelGGL((k_shoot_photons<2, 1, 0, IMS_LAYOUT_RUBIN_LIKE>), grid, dim3(256), photon_lds_pad(params), st, *params, photon_offset, *pool);

@@ -98,10 +98,17 @@ def spawn_ranks(args):
     return max(abs(rc) for rc in rcs) or (1 if failed is not None else 0)
 
 
+JSON_FD = [1]
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))
+    # keep stdout for the JSON line: everything else this process (and the libraries it loads) prints goes to stderr
+    sys.stdout.flush()
+    JSON_FD[0] = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -143,19 +150,41 @@ def main():
         scene, objects = build_inputs()
         cpu = cpu_legs(cfg, scene, objects, args)
 
-    if world > 1:
+    torch.cuda.set_device(device)
+    from imsim_amd.engine import Renderer
+    if not cpu_first:
+        scene, objects = build_inputs()
+    # The renderer -- and with it the plan streams of the device -- comes BEFORE the RCCL communicator: measured with one rank
+    # (IMS_BENCH_RCCL_ONE_RANK=1, tools/dbg/rccl_step_time.py), a C3 step takes 35 - 39 ms when the process group is
+    # initialised first and 24.0 - 24.3 ms (23.8 without a communicator) when the streams have run something first: HIP
+    # maps streams onto four hardware queues in the order they come into use, and a plan stream that shares a queue with
+    # another one serialises the step.
+    renderer = Renderer(scene, device)
+    if not cfg.get("focal", False):
+        # (a focal plane's CCDs share four streams that are first used by the first CCD: running something on THOSE ahead
+        # of time was measured to hurt -- C5 1 326 -> 2 434 ms -- and C5 is the same 1 326 ms with and without a communicator)
+        renderer.touch_streams()
+
+    # IMS_BENCH_RCCL_ONE_RANK=1 (with one rank): the RCCL process group is created and the image reduce of every step runs as a
+    # self-exchange -- the nccl code path of the N > 1 run on a box with one GPU (says nothing about the transport)
+    one_rank_rccl = world == 1 and os.environ.get("IMS_BENCH_RCCL_ONE_RANK", "0") == "1"
+    if one_rank_rccl:
+        os.environ["IMS_EXCHANGE_SINGLE_RANK"] = "1"
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:                  # a free port: a fixed one may still be held by the previous run
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or one_rank_rccl:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if share_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    torch.cuda.set_device(device)
-    from imsim_amd.engine import Renderer
-    if not cpu_first:
-        scene, objects = build_inputs()
 
-    renderer = Renderer(scene, device)
     step = cfg["make_step"](renderer, objects, rank, world)
     lib = _abi.load()
 
@@ -171,7 +200,7 @@ def main():
     for _ in range(args.warmup):
         full_step()
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or one_rank_rccl:
         dist.barrier()
     torch.cuda.synchronize()
     lib.ims_enable_timing(cfg["timed_kernel"])
@@ -179,7 +208,7 @@ def main():
     for _ in range(args.steps):
         full_step()
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or one_rank_rccl:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -190,7 +219,7 @@ def main():
         # the int32 exchange is only exact for integer counts whose sum over the ranks fits: the reduced image must qualify
         if not parallel.integer_counts_ok(renderer.image, 1):
             raise RuntimeError("bench.py: the reduced CCD image is not an integer count below 2^31 -- int32 exchange invalid")
-    if world > 1:
+    if world > 1 or one_rank_rccl:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -249,6 +278,8 @@ def main():
     }
     if share_gpu and world > 1:
         out["shared_gpu"] = True        # dry run: all ranks on ONE GPU over gloo -- not a scaling measurement
+    if one_rank_rccl:
+        out["rccl_one_rank"] = True     # the step includes the int32 copy and an RCCL self-reduce of the CCD image
 
     if rank == 0 and world == 1 and not args.no_cold and ("cold" in cfg or "end_to_end" in cfg):
         out["extra"] = cfg["cold"](scene, objects, device) if "cold" in cfg else {}
@@ -263,8 +294,11 @@ def main():
             cpu = cpu_legs(cfg, scene, objects, args, fork_ok=False)
         out["cpu_baseline"] = cpu_parity(cfg, scene, cpu, device)
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+        # ONE JSON line and nothing else on stdout: libraries write there too (RCCL prints its version banner through C
+        # stdio, flushed at exit -- i.e. AFTER a line printed here), so file descriptor 1 was pointed at stderr for the
+        # whole run (main) and the line goes to the descriptor that was stdout
+        os.write(JSON_FD[0], (json.dumps(out) + "\n").encode())
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 

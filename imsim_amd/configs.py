@@ -615,6 +615,7 @@ BENCH_CONFIGS["c5"] = dict(
     objects=_c5_objects,
     make_step=_c5_step,
     reduce=False,                         # CCDs are independent: no exchange between the ranks
+    focal=True,                           # every CCD through a fresh renderer on the device's four streams by role
     timed_kernel=1,
     kernel="k_shoot_accumulate",
     cpu_sample=10000,

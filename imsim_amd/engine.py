@@ -1151,6 +1151,15 @@ class Renderer:
             ev.record(st)
             main.wait_event(ev)
 
+    def touch_streams(self):
+        """Run a trivial operation on every plan stream and wait for it: the streams then hold their hardware queues before
+        anything else of the process (an RCCL communicator, say) brings streams of its own into use."""
+        t = self.torch
+        for st in self.plan_streams:
+            with t.cuda.stream(st):
+                t.zeros(1, device=self.device).add_(1.0)
+        t.cuda.synchronize(self.device)
+
     # -- phase-screen pre-pass (ims_screen_prepass): the gathers of all photons of a render, in cache-friendly order --
     PREPASS_EVENT = 60000          # library event (ims_run_plan RECORD / WAIT) that says "the pre-pass is through"
 

@@ -7,6 +7,8 @@ sensor state between all objects: there the delta-charge image is all-reduced be
 pixel-boundary recalculation (`allreduce_delta`, once per photon batch).  Because every photon's
 random stream is addressed by (object id, photon index) and unit fluxes make the sums exact, the
 result does not depend on the rank count."""
+import os
+
 import numpy as np
 
 
@@ -89,6 +91,15 @@ def integer_counts_ok(image, world):
     return whole and low >= 0.0 and top * max(int(world), 1) < 2147483648.0
 
 
+def _exchange_on(dist):
+    """An exchange runs when a process group of more than one rank exists -- or of exactly one rank when
+    IMS_EXCHANGE_SINGLE_RANK=1: the RCCL calls then execute as self-exchanges, which is how the one-GPU test box can run the
+    nccl code path at all (tests/test_multi_gpu_hip.py, `bench.py` under a one-rank launcher)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("IMS_EXCHANGE_SINGLE_RANK", "0") == "1"
+
+
 def reduce_image(image, dst=0, integer_counts=False):
     """Sum the per-rank CCD images onto `dst` (no-op for a single process).
 
@@ -99,7 +110,7 @@ def reduce_image(image, dst=0, integer_counts=False):
     bytes of the f64 accumulation image on the per-link-bound xGMI ring -- and is still exact."""
     import torch
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _exchange_on(dist):
         buf = image.to(torch.int32) if integer_counts else image
         if dist.get_backend() == "gloo" and buf.is_cuda:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)       # gloo has no device reduce (dry runs on one GPU only)
@@ -117,7 +128,7 @@ def allreduce_delta(delta, integer_counts=False):
     integer_counts: as in reduce_image -- unit photon fluxes, the exchange runs on an int32 copy (half the bytes)."""
     import torch
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _exchange_on(dist):
         if integer_counts:
             buf = delta.to(torch.int32)
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)

@@ -104,3 +104,51 @@ def test_bench_starts_its_own_ranks(config):
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["shared_gpu"] is True
+
+
+_RCCL_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+from imsim_amd import parallel
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+torch.cuda.set_device(0)
+assert dist.get_backend() == "nccl"
+g = torch.Generator(device="cuda"); g.manual_seed(3)
+counts = torch.randint(0, 70000, (4096, 4096), device="cuda", generator=g).to(torch.float64)
+want = counts.clone()
+parallel.reduce_image(counts, dst=0, integer_counts=True)            # int32 copy -> RCCL reduce -> back
+assert torch.equal(counts, want)
+real = torch.rand((512, 512), dtype=torch.float64, device="cuda", generator=g) * 3.7
+want = real.clone()
+parallel.reduce_image(real, dst=0)                                   # f64 RCCL reduce
+assert torch.equal(real, want)
+delta = torch.randint(0, 500, (1025 * 1025,), device="cuda", generator=g).to(torch.float64)
+want = delta.clone()
+parallel.allreduce_delta(delta, integer_counts=True)                 # int32 RCCL all-reduce
+parallel.allreduce_delta(delta)                                      # f64 RCCL all-reduce
+assert torch.equal(delta, want)
+dist.barrier()
+t = torch.tensor([1.25], dtype=torch.float64, device="cuda")
+dist.all_reduce(t, op=dist.ReduceOp.MAX)                             # bench.py's timing reduction
+assert float(t.item()) == 1.25
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("RCCL_OK")
+"""
+
+
+def test_rccl_executes_every_exchange_of_the_path_with_one_rank(tmp_path):
+    """The one GPU of the test box cannot hold two RCCL ranks, so the two-rank tests above exchange over gloo.  This one
+    runs the nccl (= RCCL) backend itself: a one-rank process group bound to cuda:0, and every collective the path issues
+    -- the int32 and the f64 form of the CCD image reduce, both forms of the delta-charge all-reduce, the barrier and the
+    MAX all-reduce of bench.py's timing -- as self-exchanges (IMS_EXCHANGE_SINGLE_RANK=1).  What it cannot show is the
+    transport between GPUs."""
+    from helpers import free_port
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text(_RCCL_SCRIPT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), IMS_EXCHANGE_SINGLE_RANK="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "RCCL_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]

@@ -24,6 +24,15 @@ configs.N_CCD_FOCAL_PLANE = n_ccd
 phot = catalog.realize_fluxes(sub["nominal_flux"], scene.seed)
 objects, _ = cfg["objects"](sub, phot, scene)
 r = Renderer(scene, "cuda:0")
+if os.environ.get("C5_WITH_PG") == "1":
+    # an RCCL communicator in the process, created after the device's streams (as bench.py does)
+    import socket
+    import torch.distributed as dist
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    dist.barrier()
 for conc in ((int(os.environ["C5_ONLY"]),) * 2 if "C5_ONLY" in os.environ else (1, 2, 3, 4)):
     step = configs._c5_step(r, objects, concurrent=conc)
     step()

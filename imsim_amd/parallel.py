@@ -100,6 +100,15 @@ def _exchange_on(dist):
     return dist.get_world_size() > 1 or os.environ.get("IMS_EXCHANGE_SINGLE_RANK", "0") == "1"
 
 
+def exchanging(world):
+    """Whether the delta-charge exchange of photon pooling runs for a job of `world` ranks: always for world > 1, and with one
+    rank when IMS_EXCHANGE_SINGLE_RANK=1 asks for the collectives as self-exchanges (and a process group exists)."""
+    if world > 1:
+        return True
+    import torch.distributed as dist
+    return os.environ.get("IMS_EXCHANGE_SINGLE_RANK", "0") == "1" and dist.is_available() and dist.is_initialized()
+
+
 def reduce_image(image, dst=0, integer_counts=False):
     """Sum the per-rank CCD images onto `dst` (no-op for a single process).
 

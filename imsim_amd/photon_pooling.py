@@ -135,7 +135,7 @@ def _pool_fits(renderer, n_photons):
     fits = 32 * int(n_photons) < 0.8 * free
     # the resident form and the sub-batch loop issue different collectives: the ranks must take the same one
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if parallel._exchange_on(dist):
         flag = renderer.torch.tensor([1 if fits else 0], dtype=renderer.torch.int32,
                                      device=renderer.device if dist.get_backend() != "gloo" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -231,7 +231,7 @@ def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1,
             if i < first_batch:
                 continue
             if sensor_on and i > first_batch:
-                if world > 1:
+                if parallel.exchanging(world):
                     parallel.allreduce_delta(renderer.delta_tensor(0), integer_counts=unit)
                 renderer.update_distortions(0, 1, bf_tag=((i - 1) % 255 + 1) if tagged else 0)
             launch()
@@ -326,7 +326,7 @@ def _prepared_image_device(renderer, table, modes, nbatch, seed, rank, world, re
             if i < first_batch:
                 continue
             if sensor_on and i > first_batch:
-                if world > 1:
+                if parallel.exchanging(world):
                     parallel.allreduce_delta(renderer.delta_tensor(0), integer_counts=unit)
                 renderer.update_distortions(0, 1, bf_tag=((i - 1) % 255 + 1) if tagged else 0)
             launch()
@@ -428,7 +428,7 @@ def build_image(renderer, objects, modes, nbatch=10, nsubbatch=50, seed=0, reali
             if sensor_on and s == 0 and i > first_batch:
                 # recalc=(subbatch_num == 0), resume afterwards; only tiles near the previous batch's charge move
                 # (with several ranks the tile marks are rank-local, so every tile is visited)
-                if world > 1:
+                if parallel.exchanging(world):
                     parallel.allreduce_delta(renderer.delta_tensor(0), integer_counts=unit)      # as the resident form
                 renderer.update_distortions(0, 1, bf_tag=((i - 1) % 255 + 1) if world == 1 else 0)
             if world > 1:

@@ -105,6 +105,8 @@ def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))
+    # read by the HSA runtime when the GPU is first touched (dmabuf IPC: RCCL between processes needs it on this pool)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # keep stdout for the JSON line: everything else this process (and the libraries it loads) prints goes to stderr
     sys.stdout.flush()
     JSON_FD[0] = os.dup(1)

@@ -49,3 +49,30 @@ def test_gaussian_deviates_are_standard_normal():
     assert abs((g ** 4).mean() - 3.0) < 0.05
     # the two members of a pair are uncorrelated
     assert abs(np.mean(g[0::2] * g[1::2])) < 5e-3
+
+
+def test_word_deviate_functions_accuracy():
+    """Spec v6: functions of 32-bit words, their series cut where the truncation error is below 2^-36 of the result --
+    sin / cos of 2 pi (w + 1/2) / 2^32 within 1.5e-11, log((w + 1/2) / 2^32) within 2.5e-12 relative; the quadrant
+    reduction on the integer word is exact (the four quarter turns and their neighbours are among the test words)."""
+    rng = np.random.default_rng(3)
+    edges = np.array([0, 1, 2 ** 29 - 1, 2 ** 29, 2 ** 29 + 1, 2 ** 30 - 1, 2 ** 30, 2 ** 30 + 1, 2 ** 31 - 1, 2 ** 31, 3 * 2 ** 29 - 1,
+                      3 * 2 ** 29, 3 * 2 ** 30, 5 * 2 ** 29, 7 * 2 ** 29 - 1, 7 * 2 ** 29, 2 ** 32 - 2, 2 ** 32 - 1], dtype=np.float64)
+    w = np.concatenate([edges, rng.integers(0, 2 ** 32, 1000000).astype(np.float64)])
+    u = (w + 0.5) / 2.0 ** 32
+    sc = orc_loader.math_probe(10, w).reshape(-1, 2)
+    # reference angle reduced exactly before the libm call (2 pi u itself loses 1e-16 x 2 pi of phase: irrelevant here)
+    assert np.abs(sc[:, 0] - np.sin(2.0 * np.pi * u)).max() < 1.5e-11
+    assert np.abs(sc[:, 1] - np.cos(2.0 * np.pi * u)).max() < 1.5e-11
+    assert np.abs(sc[:, 0] ** 2 + sc[:, 1] ** 2 - 1.0).max() < 3e-11
+    full = orc_loader.math_probe(2, u).reshape(-1, 2)                 # the full-length series on the same arguments
+    assert np.abs(sc - full).max() < 1.5e-11
+    lg = orc_loader.math_probe(11, w)
+    assert np.abs(lg / np.log(u) - 1.0).max() < 2.5e-12
+    # the single deviate is the cosine half of the pair made from the same two words
+    pairs = rng.integers(0, 2 ** 32, 200000).astype(np.float64)
+    one = orc_loader.math_probe(12, pairs)
+    w0, w1 = pairs[0::2], pairs[1::2]
+    r = np.sqrt(-2.0 * np.log((w0 + 0.5) / 2.0 ** 32))
+    assert np.abs(one - r * np.cos(2.0 * np.pi * (w1 + 0.5) / 2.0 ** 32)).max() < 2e-10
+    assert abs(one.mean()) < 0.01 and abs(one.std() - 1.0) < 0.01

@@ -53,7 +53,7 @@ static inline orc_draw_t orc_draw(uint64_t seed, int64_t obj_id, int64_t photon,
     d.b = (((uint64_t)c[2] << 32) | c[3]) >> 11;
     return d;
 }
-/* The photon pipeline (spec v4) consumes the raw block: four 32-bit words per (object, photon, slot),
+/* The photon pipeline (since spec v4) consumes the raw block: four 32-bit words per (object, photon, slot),
  * each mapped to the open interval (0,1) -- the granularity of GalSim's own UniformDeviate. */
 typedef struct { uint32_t w[4]; } orc_words_t;
 static inline orc_words_t orc_words(uint64_t seed, int64_t obj_id, int64_t photon, uint32_t slot)

@@ -363,6 +363,64 @@ def test_c3_lsst_image_mode_is_bit_exact(torch_cuda):
         assert_bits_equal(ga[name], orc.sensor_array(name)[:len(ga[name])], f"sensor {name}")
 
 
+def test_lsst_image_edge_cases_are_bit_exact(torch_cuda):
+    """The LSST_Image path on a table built to sit on every boundary of the launch plan: photon counts of 0, 1, one below /
+    at / above a workgroup's 256 and a round's nrecalc and their multiples (chain classes of exactly k rounds, empty last
+    rounds), objects centred off the CCD on all four sides and in a corner (stamps clipped or wholly outside), a stamp wider
+    than the image, eight bright objects on ONE pixel (their private regions coincide: the CCD image takes all of them, every
+    region only its own charge), a FAINT bright object (no operators, no sensor, yet above nrecalc) -- image, realized fluxes
+    and the pixel-boundary state equal the oracle's bit for bit; a table of nothing but empty objects renders nothing."""
+    from imsim_amd.engine import Renderer
+    from imsim_amd._abi import IMS_OBJ_FAINT
+    from oracle import orc_loader
+    n, nrecalc = 256, 1000
+    scene, base = _c3_case(n_obj=120, n=n, scratch=4_000_000)
+    counts = [0, 1, 63, 64, 65, 255, 256, 257, 511, 512, 513, nrecalc - 1, nrecalc, nrecalc + 1, 2 * nrecalc - 1, 2 * nrecalc,
+              2 * nrecalc + 1, 5 * nrecalc, 5 * nrecalc + 255, 6 * nrecalc + 256, 7 * nrecalc, 39 * nrecalc, 40 * nrecalc,
+              40 * nrecalc + 1, 41 * nrecalc]
+    objects = base[:len(counts) + 16].copy()
+    objects["n_phot"][:len(counts)] = counts
+    k = len(counts)
+
+    def place(i, x, y, size, n_phot):
+        objects["x0"][i], objects["y0"][i], objects["n_phot"][i] = x, y, n_phot
+        cx, cy = int(np.floor(x + 0.5)), int(np.floor(y + 0.5))
+        objects["stamp_xmin"][i], objects["stamp_xmax"][i] = cx - size // 2, cx - size // 2 + size - 1
+        objects["stamp_ymin"][i], objects["stamp_ymax"][i] = cy - size // 2, cy - size // 2 + size - 1
+    place(k + 0, -6.3, 100.2, 40, 3000)            # off the left edge, stamp clipped
+    place(k + 1, n + 7.8, 57.0, 40, 3000)          # off the right edge
+    place(k + 2, 120.4, -3.9, 40, 2500)            # below
+    place(k + 3, 33.3, n + 12.1, 40, 2500)         # above
+    place(k + 4, -15.0, -15.0, 24, 1500)           # corner: the stamp misses the CCD altogether
+    place(k + 5, 128.5, 128.5, 2 * n, 6000)        # a stamp wider than the image
+    for j in range(8):                             # eight bright objects on one pixel
+        place(k + 6 + j, 200.25, 60.75, 48, 3 * nrecalc + 17 * j)
+    place(k + 14, 60.0, 200.0, 64, 12 * nrecalc)
+    objects["flags"][k + 14] |= IMS_OBJ_FAINT
+    place(k + 15, 90.0, 30.0, 32, 0)
+    objects["phot_first"] = 0
+    r = Renderer(scene)
+    real = torch_cuda.zeros(len(objects), dtype=torch_cuda.float64, device="cuda")
+    r.render_lsst_image(objects, nrecalc=nrecalc, realized=real)
+    r.synchronize()
+    orc = orc_loader.OracleScene(scene)
+    real_o = np.zeros(len(objects))
+    orc.render_lsst_image(objects, nrecalc=nrecalc, realized=real_o)
+    assert orc.image.sum() > 0.5 * objects["n_phot"].sum()
+    # (the realized flux counts what lands in the object's STAMP -- the off-CCD corner object has one, the CCD image has none of it)
+    assert real_o[0] == 0 and real_o[k + 4] > 0 and real_o[k + 15] == 0 and real_o[k + 5] > 0 and real_o[k + 14] > 0
+    assert_bits_equal(r.image_numpy(), orc.image, "image")
+    assert_bits_equal(real.cpu().numpy(), real_o, "realized flux")
+    ga = _sensor_arrays_gpu(r)
+    for name in ("boundary", "bounds", "delta"):
+        assert_bits_equal(ga[name], orc.sensor_array(name)[:len(ga[name])], f"sensor {name}")
+    nothing = objects[[0, k + 15]].copy()
+    r2 = Renderer(scene)
+    r2.render_lsst_image(nothing, nrecalc=nrecalc)
+    r2.synchronize()
+    assert r2.image_numpy().sum() == 0
+
+
 @pytest.mark.parametrize("vendor", ["itl", "e2v"])
 def test_sensor_models_of_4_8_and_32_vertices_on_the_gpu(torch_cuda, vendor):
     """The reference's cross-model criterion (tests/test_sensor_models.py:73-125) through the HIP path: the 1e6-photon

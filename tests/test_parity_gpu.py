@@ -996,6 +996,51 @@ def test_photon_pooling_build_image_is_bit_exact(torch_cuda):
     assert_bits_equal(r2.image_numpy(), orc.image, "replayed pooling image")
 
 
+def test_photon_pooling_edge_cases_are_bit_exact(torch_cuda):
+    """Photon pooling on a table that sits on the boundaries of the batch arithmetic: photon counts of 0, 1, nbatch - 1
+    (demoted to one random batch), nbatch, nbatch + 1, around nbatch x 64 (the split between the two pixel-search launches
+    of the resident form), shares that do not divide, objects off the CCD, more batches than some objects have photons --
+    the sub-batch loop and the HBM-resident replay give the oracle's image and sensor state bit for bit, and every photon
+    is accounted for."""
+    from helpers import c3_small_case
+    from imsim_amd import photon_pooling, stamp
+    from imsim_amd.engine import Renderer
+    from oracle import orc_loader
+    nbatch = 7
+    scene, objects = c3_small_case(n_obj=80, n=160, flux_seed=9, scratch=0)
+    scene.track_static_delta = 1
+    counts = [0, 1, nbatch - 1, nbatch, nbatch + 1, 2 * nbatch - 1, 64 * nbatch - 1, 64 * nbatch, 64 * nbatch + 1, 65 * nbatch + 3,
+              99, 100, 101, 12345, 7 * 1000, 7 * 1000 + 6, 0, 3]
+    objects = objects[:len(counts) + 3].copy()
+    objects["n_phot"][:len(counts)] = counts
+    k = len(counts)
+    for i, (x, y) in enumerate(((-9.5, 40.0), (80.0, 171.3), (165.2, 165.9))):          # off the CCD: left, above, corner
+        cx, cy = int(np.floor(x + 0.5)), int(np.floor(y + 0.5))
+        objects["x0"][k + i], objects["y0"][k + i], objects["n_phot"][k + i] = x, y, 900 + i
+        objects["stamp_xmin"][k + i], objects["stamp_xmax"][k + i] = cx - 16, cx + 15
+        objects["stamp_ymin"][k + i], objects["stamp_ymax"][k + i] = cy - 16, cy + 15
+    objects["phot_first"] = 0
+    modes = stamp.classify(objects["n_phot"].astype(float), 100.0)
+    orc = orc_loader.OracleScene(scene)
+    n_cpu = photon_pooling.build_image(orc, objects, modes, nbatch=nbatch, nsubbatch=3, seed=5)
+    assert n_cpu == int(objects["n_phot"].sum()) and orc.image.sum() > 0
+    r = Renderer(scene)
+    n_gpu = photon_pooling.build_image(r, objects, modes, nbatch=nbatch, nsubbatch=3, seed=5)
+    r.synchronize()
+    assert n_gpu == n_cpu
+    assert_bits_equal(r.image_numpy(), orc.image, "pooling image")
+    ga = _sensor_arrays_gpu(r)
+    for name in ("boundary", "bounds", "delta"):
+        assert_bits_equal(ga[name], orc.sensor_array(name), f"pooling sensor {name}")
+    r2 = Renderer(scene)
+    run = photon_pooling.prepared_image(r2, objects, modes, nbatch=nbatch, seed=5)
+    run()
+    r2.synchronize()
+    assert run.photons == n_cpu
+    assert_bits_equal(r2.image_numpy(), orc.image, "resident replay image")
+    assert_bits_equal(_sensor_arrays_gpu(r2)["boundary"], orc.sensor_array("boundary"), "resident replay boundaries")
+
+
 def test_resumed_pooling_ccd_restores_image_and_realized_fluxes(torch_cuda, tmp_path):
     """A photon-pooling CCD interrupted after its second batch and resumed (HBM-resident form): the record carries the image,
     the finished batches and the realized fluxes up to them, so the resumed run ends with the image AND the per-object fluxes

@@ -113,7 +113,8 @@ def kolmogorov_gaussian_fwhm(airmass=1.2, raw_seeing=0.7, band="r"):
 def star_stamp_size(nominal_flux, noise_var, airmass=1.2, raw_seeing=0.7, band="r", nmax=NMAX):
     """get_star_stamp_size (stamp_utils.py:79-155)."""
     nominal_flux = np.asarray(nominal_flux, dtype=np.float64)
-    ft = noise_var / nominal_flux
+    with np.errstate(divide="ignore"):               # a source of zero flux: ft = inf takes the default threshold
+        ft = noise_var / nominal_flux
     use_default = (ft >= FT_DEFAULT) | (ft == 0)
     ft = np.where(use_default, FT_DEFAULT, np.exp(np.floor(np.log(np.where(use_default, 1.0, ft)))))
     fwhm_atm, fwhm_sys = kolmogorov_gaussian_fwhm(airmass, raw_seeing, band)

@@ -88,6 +88,88 @@ def test_device_table_is_bit_identical_to_the_oracle(given):
     assert np.array_equal(t.n_phot, rows["n_phot"])
 
 
+def _edge_catalog():
+    """A catalog whose first rows sit on the edges of the table builder: fluxes of 0 and far below one photon, the tiny-flux
+    and faint / photon-shooting thresholds and their neighbours, a 1e9-photon star and galaxy (stamp capped at the maximum),
+    sources far off the CCD on every side, positions exactly on pixel centres and pixel borders, the smallest and largest
+    half-light radii and the flattest ellipse of the catalog generator's ranges and beyond."""
+    scene, cat, _ = _case(n=400, seed=11)
+    flux = [0.0, 1e-6, 0.4, 0.999, 1.0, 9.9, 10.0, 10.1, 31.9, 32.0, 99.9, 100.0, 100.1, 1e4 - 1, 1e4, 1e4 + 1, 1e6, 1e9, 1e9, 3e7]
+    k = len(flux)
+    cat["nominal_flux"][:k] = flux
+    cat["sb_flux"][:k] = np.asarray(flux) / 76.4
+    cat["kind"][:k] = [0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 0, 2, 1]
+    pos = [(-800.0, 2000.0), (4096.0 + 900.0, 10.0), (2000.0, -650.5), (30.0, 4096.0 + 2000.0), (-3000.0, -3000.0), (0.5, 0.5),
+           (1.0, 1.0), (4096.5, 4096.5), (2048.0, 2048.5), (2048.5, 2048.0)]
+    for i, (x, y) in enumerate(pos):
+        cat["x"][k + i], cat["y"][k + i] = x, y
+        cat["nominal_flux"][k + i] = 5000.0 + 700.0 * i
+        cat["sb_flux"][k + i] = cat["nominal_flux"][k + i] / 76.4
+    j = k + len(pos)
+    cat["hlr"][j:j + 6] = [0.01, 0.05, 3.0, 8.0, 0.3, 0.3]
+    cat["q"][j:j + 6] = [1.0, 0.05, 0.05, 1.0, 0.051, 0.999]
+    cat["kind"][j:j + 6] = [1, 1, 2, 2, 1, 2]
+    cat["nominal_flux"][j:j + 6] = [2e5, 2e5, 2e6, 5e3, 3e3, 3e3]
+    cat["sb_flux"][j:j + 6] = cat["nominal_flux"][j:j + 6] / 76.4
+    return scene, cat
+
+
+def test_oracle_table_on_the_edges_matches_the_numpy_builder():
+    scene, cat = _edge_catalog()
+    phot = catalog.realize_fluxes(cat["nominal_flux"], scene.seed)
+    assert phot[0] == 0 and phot[1] == 0
+    rows, meta = orc_loader.build_object_table(scene, cat, VISIT, phot)
+    ref, sizes = configs.c3_objects(cat, phot, scene)
+    keep = phot > 0
+    r = rows[keep]
+    for f in ("obj_id", "n_phot", "prof_table", "sed_table", "flags", "x0", "y0", "prof_scale", "flux_per_photon"):
+        assert np.array_equal(r[f], ref[f]), f
+    from imsim_amd import device_table
+    idx, sz, host = device_table.host_fixups(cat, meta, {})
+    assert len(host) == 0
+    full = meta["size"].copy()
+    full[idx] = sz
+    assert np.array_equal(full[keep], sizes)
+    assert sizes.max() == catalog.NMAX and (sizes == 32).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("given", [True, False])
+def test_device_table_on_the_edges_is_bit_identical_to_the_oracle(given):
+    import torch
+    from imsim_amd.engine import Renderer
+    from imsim_amd.device_table import DeviceTable
+    from imsim_amd import device_table
+    scene, cat = _edge_catalog()
+    phot = catalog.realize_fluxes(cat["nominal_flux"], scene.seed) if given else None
+    r = Renderer(scene)
+    t = DeviceTable(r, cat, VISIT, phot_flux=phot)
+    torch.cuda.synchronize()
+    rows, meta = orc_loader.build_object_table(scene, cat, VISIT, phot)
+    idx, sz, _ = device_table.host_fixups(cat, meta, {})
+    want = rows.copy()
+    icx, icy = np.floor(cat["x"][idx] + 0.5).astype(np.int64), np.floor(cat["y"][idx] + 0.5).astype(np.int64)
+    want["stamp_xmin"][idx], want["stamp_xmax"][idx] = icx - sz // 2, icx - sz // 2 + sz - 1
+    want["stamp_ymin"][idx], want["stamp_ymax"][idx] = icy - sz // 2, icy - sz // 2 + sz - 1
+    assert t.rows_numpy().tobytes() == want.tobytes()
+    assert np.array_equal(t.n_phot, rows["n_phot"])
+    # and the table renders: LSST_Image from the device table == the oracle on its rows (the three sources above 1e7 photons
+    # dimmed to 2e5 for this part: the oracle is one CPU core)
+    dim = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in cat.items()}
+    dim["nominal_flux"] = np.minimum(cat["nominal_flux"], 2.0e5)
+    dim["sb_flux"] = dim["nominal_flux"] / 76.4
+    phot2 = catalog.realize_fluxes(dim["nominal_flux"], scene.seed) if given else None
+    t2 = DeviceTable(r, dim, VISIT, phot_flux=phot2)
+    r.render_lsst_image(t2, nrecalc=10000)
+    r.synchronize()
+    host_rows = t2.rows_numpy()
+    assert host_rows["n_phot"].sum() < 3e6
+    orc = orc_loader.OracleScene(scene)
+    orc.render_lsst_image(host_rows[host_rows["n_phot"] > 0], nrecalc=10000)
+    assert orc.image.sum() > 0
+    assert np.array_equal(r.image_numpy().view(np.uint32), orc.image.view(np.uint32))
+
+
 @pytest.mark.gpu
 def test_plan_from_the_device_table_renders_the_host_planned_image():
     import torch

@@ -9,6 +9,7 @@ import math
 import os
 import dataclasses
 import itertools
+import threading
 from typing import List, Optional
 
 import numpy as np
@@ -674,6 +675,7 @@ def _device_streams(torch, device):
 
 
 _RENDERER_SERIAL = itertools.count()
+_STREAMS_LOCK = threading.Lock()
 
 
 def _focal_streams(torch, device, peek=False, top_index=None):
@@ -685,10 +687,11 @@ def _focal_streams(torch, device, peek=False, top_index=None):
     and a chain sits behind another CCD's wide launches.  Here the top chains of two CCDs advance side by side on queues
     that hold nothing else."""
     key = ("focal", str(device))
-    st = _DEVICE_STREAMS.get(key)
-    if st is None:
-        st = _DEVICE_STREAMS[key] = {"next": 0, "top": [torch.cuda.Stream(device, priority=-1), torch.cuda.Stream(device, priority=-1)],
-                                     "bulk": torch.cuda.Stream(device), "mid": torch.cuda.Stream(device)}
+    with _STREAMS_LOCK:                 # renderers of a focal plane may be created from several host threads
+        st = _DEVICE_STREAMS.get(key)
+        if st is None:
+            st = _DEVICE_STREAMS[key] = {"next": 0, "top": [torch.cuda.Stream(device, priority=-1), torch.cuda.Stream(device, priority=-1)],
+                                         "bulk": torch.cuda.Stream(device), "mid": torch.cuda.Stream(device)}
     if top_index is not None:          # the caller deals the two top streams itself (CCDs enqueued from several host threads)
         return (st["top"][top_index % 2], st["bulk"], st["mid"], st["mid"], st["mid"])
     top = st["top"][st["next"] % 2]

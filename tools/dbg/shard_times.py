@@ -12,7 +12,7 @@ phot = catalog.realize_fluxes(cat["nominal_flux"], scene.seed)
 objects, _ = configs.c3_objects(cat, phot, scene)
 r = Renderer(scene)
 for world in (1, 2, 4, 8):
-    times = []
+    times, host = [], []
     for rank in range(world):
         mine = parallel.shard_objects(objects, rank, world)
         step = r.prepared_lsst_image(mine)
@@ -22,7 +22,9 @@ for world in (1, 2, 4, 8):
         t0 = time.perf_counter()
         for _ in range(3):
             r.image.zero_(); step()
+        host.append((time.perf_counter() - t0) / 3 * 1e3)          # host time to enqueue a step
         torch.cuda.synchronize()
         times.append((time.perf_counter() - t0) / 3 * 1e3)
         del step
-    print(f"world {world}: per-rank ms {np.round(times, 2)}  -> max {max(times):.2f} ms, predicted {100000 / max(times) * 1e3:.3g} objects/s", flush=True)
+    print(f"world {world}: per-rank ms {np.round(times, 2)}  -> max {max(times):.2f} ms, predicted {100000 / max(times) * 1e3:.3g} objects/s; "
+          f"host enqueue per step {np.round(host, 2)} ms", flush=True)

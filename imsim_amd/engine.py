@@ -129,7 +129,7 @@ class HostMem:
         self.keep.append(st)
         return st, C.addressof(st)
 
-    def zeros(self, n, dtype):
+    def zeros(self, n, dtype, uninitialised=0):
         return self.put(np.zeros(n, dtype=dtype))
 
 
@@ -219,9 +219,16 @@ class DeviceMem:
         raw = np.frombuffer(bytes(st), dtype=np.uint8).copy()
         return self.put(raw)
 
-    def zeros(self, n, dtype):
-        nbytes = int(n) * np.dtype(dtype).itemsize
-        t = self.torch.zeros(max(nbytes, 8), dtype=self.torch.uint8, device=self.device)
+    def zeros(self, n, dtype, uninitialised=0):
+        """n zeroed elements; the first `uninitialised` of them are left as allocated (the caller overwrites every one of them
+        before anything reads them: a fill of gigabytes that the next kernel would only write over)."""
+        item = np.dtype(dtype).itemsize
+        nbytes, skip = int(n) * item, min(int(uninitialised), int(n)) * item
+        if skip == 0:
+            t = self.torch.zeros(max(nbytes, 8), dtype=self.torch.uint8, device=self.device)
+        else:
+            t = self.torch.empty(max(nbytes, 8), dtype=self.torch.uint8, device=self.device)
+            t[skip:].zero_()
         self.keep.append(t)
         return t, t.data_ptr()
 
@@ -582,7 +589,10 @@ class BoundScene:
         slots_host = np.zeros(self.slot_capacity, dtype=BFSLOT_DTYPE)
         slots_host[:len(slots)] = slots
         self._slots_buf, S.bf_slots = self.mem.put(slots_host.view(np.uint8))
-        self.sensor_arrays["boundary"], S.bf_boundary = self.mem.zeros(cells * npo * 2, np.float64)
+        # (the points of the static slots -- 2.7 GB for a 4k x 4k CCD -- are written, every one of them, by the init_boundaries
+        # that follows the construction of a renderer: no zero fill of that part)
+        self.sensor_arrays["boundary"], S.bf_boundary = self.mem.zeros(cells * npo * 2, np.float64,
+                                                                       uninitialised=self.static_cells * npo * 2)
         self.sensor_arrays["bounds"], S.bf_bounds = self.mem.zeros(cells * 8, np.float64)
         self.sensor_arrays["delta"], S.bf_delta = self.mem.zeros(cells, np.float64)
         # tile flags of the brighter-fatter rounds (one byte per owner cell, used at tile origins)

@@ -634,8 +634,11 @@ constexpr int IT_NV = 4, IT_NPO = 2 * IT_NV + 2, IT_NVT = 4 * IT_NV + 4;
 __global__ __launch_bounds__(256) void k_init_tiles(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
                                                     const int64_t* __restrict__ tile_prefix)
 {
-    __shared__ double2 left[UT][UT][IT_NV];           // owned points NV + 2 .. 2 NV + 1 (left edge, bottom -> top)
-    __shared__ double2 bottom[UT][UT][IT_NV + 2];     // owned points 0 .. NV + 1 (bottom row incl. both corners)
+    // the owned points of the tile's cells in the order of the global array -- [row][cell][point], ten double2 per cell --
+    // so that they go out as contiguous runs (a lane that stored its own ten points wrote 16 bytes every 160: 64 requests
+    // per store instruction; 2.16 ms for the 16.8 M cells of a CCD, 1.8 TB/s of the bytes written).  The bounds lines reuse
+    // the buffer for the same reason.
+    __shared__ double2 P[UT * UT * IT_NPO];
     const ims_sensor_t& s = *sp;
     int slot = first_slot + (int)blockIdx.y, t = (int)blockIdx.x;
     if (tile_prefix != nullptr) {
@@ -649,66 +652,90 @@ __global__ __launch_bounds__(256) void k_init_tiles(const ims_sensor_t* __restri
     const int tiles_x = (sl.nx + 1 + UT - 1) / UT, tiles_y = (sl.ny + 1 + UT - 1) / UT;
     if (t >= tiles_x * tiles_y) return;
     const int lx = threadIdx.x % UT, ly = threadIdx.x / UT;
-    const int i = (t % tiles_x) * UT + lx, j = (t / tiles_x) * UT + ly;
+    const int tx0 = (t % tiles_x) * UT, ty0 = (t / tiles_x) * UT;
+    const int i = tx0 + lx, j = ty0 + ly;
     const bool owner = (i <= sl.nx && j <= sl.ny);
     double2 own[IT_NPO];
     if (owner) {
-        const int64_t c = cell_index(sl, i, j);
-        double2* pts = (double2*)(s.bf_boundary + c * IT_NPO * 2);
 #pragma unroll
         for (int n = 0; n < IT_NPO; ++n) {
             init_point(s, sl, i, j, n, own[n].x, own[n].y);
-            pts[n] = own[n];
+            P[(ly * UT + lx) * IT_NPO + n] = own[n];
         }
-        s.bf_delta[c] = 0.0;
-#pragma unroll
-        for (int n = 0; n <= IT_NV + 1; ++n) bottom[ly][lx][n] = own[n];
-#pragma unroll
-        for (int m = 0; m < IT_NV; ++m) left[ly][lx][m] = own[IT_NV + 2 + m];
+        s.bf_delta[cell_index(sl, i, j)] = 0.0;
     }
     __syncthreads();
-    if (!owner || i >= sl.nx || j >= sl.ny) return;
-    // the right neighbour's left edge and the upper neighbour's bottom row: from LDS inside the tile, evaluated at its rim
-    double2 rgt[IT_NV], upp[IT_NV + 2];
-    if (lx + 1 < UT) {
+    // points out: row ly of the tile is one contiguous run of (cells of the slot in that row) x ten double2
+    {
+        const int ncx = (sl.nx + 1 - tx0 < UT) ? sl.nx + 1 - tx0 : UT;           // owner cells per row of this tile
+        const int nrow = (sl.ny + 1 - ty0 < UT) ? sl.ny + 1 - ty0 : UT;
 #pragma unroll
-        for (int m = 0; m < IT_NV; ++m) rgt[m] = left[ly][lx + 1][m];
-    } else {
-#pragma unroll
-        for (int m = 0; m < IT_NV; ++m) init_point(s, sl, i + 1, j, IT_NV + 2 + m, rgt[m].x, rgt[m].y);
+        for (int e = (int)threadIdx.x; e < UT * UT * IT_NPO; e += 256) {
+            const int r = e / (UT * IT_NPO), k = e - r * (UT * IT_NPO);
+            if (r < nrow && k < ncx * IT_NPO)
+                ((double2*)(s.bf_boundary + cell_index(sl, tx0, ty0 + r) * IT_NPO * 2))[k] = P[e];
+        }
     }
-    if (ly + 1 < UT) {
+    const bool inner = owner && i < sl.nx && j < sl.ny;                           // a pixel: has a bounds line
+    double bnd[8] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+    if (inner) {
+        // the right neighbour's left edge and the upper neighbour's bottom row: from LDS inside the tile, evaluated at its rim
+        double2 rgt[IT_NV], upp[IT_NV + 2];
+        if (lx + 1 < UT) {
 #pragma unroll
-        for (int q = 0; q <= IT_NV + 1; ++q) upp[q] = bottom[ly + 1][lx][q];
-    } else {
+            for (int m = 0; m < IT_NV; ++m) rgt[m] = P[(ly * UT + lx + 1) * IT_NPO + IT_NV + 2 + m];
+        } else {
 #pragma unroll
-        for (int q = 0; q <= IT_NV + 1; ++q) init_point(s, sl, i, j + 1, q, upp[q].x, upp[q].y);
+            for (int m = 0; m < IT_NV; ++m) init_point(s, sl, i + 1, j, IT_NV + 2 + m, rgt[m].x, rgt[m].y);
+        }
+        if (ly + 1 < UT) {
+#pragma unroll
+            for (int q = 0; q <= IT_NV + 1; ++q) upp[q] = P[((ly + 1) * UT + lx) * IT_NPO + q];
+        } else {
+#pragma unroll
+            for (int q = 0; q <= IT_NV + 1; ++q) init_point(s, sl, i, j + 1, q, upp[q].x, upp[q].y);
+        }
+        double ixmin = 0.0, ixmax = 1.0, iymin = 0.0, iymax = 1.0;
+        double oxmin = 0.0, oxmax = 1.0, oymin = 0.0, oymax = 1.0;
+        double v0x = 0.0;
+#pragma unroll
+        for (int k = 0; k < IT_NVT; ++k) {
+            // same vertex -> (cell, owned point) map as polygon_vertex
+            double vx, vy;
+            if (k <= IT_NV + 1) { vx = own[k].x; vy = own[k].y; }
+            else if (k <= 2 * IT_NV + 1) { vx = rgt[k - IT_NV - 2].x + 1.0; vy = rgt[k - IT_NV - 2].y; }
+            else if (k <= 3 * IT_NV + 3) { vx = upp[IT_NV + 1 - (k - 2 * IT_NV - 2)].x; vy = upp[IT_NV + 1 - (k - 2 * IT_NV - 2)].y + 1.0; }
+            else { vx = own[IT_NV + 2 + (IT_NV - 1 - (k - 3 * IT_NV - 4))].x; vy = own[IT_NV + 2 + (IT_NV - 1 - (k - 3 * IT_NV - 4))].y; }
+            if (k == 0) v0x = vx;
+            if (vx < oxmin) oxmin = vx;
+            if (vx > oxmax) oxmax = vx;
+            if (vy < oymin) oymin = vy;
+            if (vy > oymax) oymax = vy;
+            if (k <= IT_NV + 1) { if (vy > iymin) iymin = vy; }
+            if (k >= IT_NV + 1 && k <= 2 * IT_NV + 2) { if (vx < ixmax) ixmax = vx; }
+            if (k >= 2 * IT_NV + 2 && k <= 3 * IT_NV + 3) { if (vy < iymax) iymax = vy; }
+            if (k >= 3 * IT_NV + 3) { if (vx > ixmin) ixmin = vx; }
+        }
+        if (v0x > ixmin) ixmin = v0x;
+        bnd[0] = ixmin; bnd[1] = ixmax; bnd[2] = iymin; bnd[3] = iymax;
+        bnd[4] = oxmin; bnd[5] = oxmax; bnd[6] = oymin; bnd[7] = oymax;
     }
-    double ixmin = 0.0, ixmax = 1.0, iymin = 0.0, iymax = 1.0;
-    double oxmin = 0.0, oxmax = 1.0, oymin = 0.0, oymax = 1.0;
-    double v0x = 0.0;
+    __syncthreads();                                   // everybody has read its neighbours' points: the buffer is free
+    if (inner) {
 #pragma unroll
-    for (int k = 0; k < IT_NVT; ++k) {
-        // same vertex -> (cell, owned point) map as polygon_vertex
-        double vx, vy;
-        if (k <= IT_NV + 1) { vx = own[k].x; vy = own[k].y; }
-        else if (k <= 2 * IT_NV + 1) { vx = rgt[k - IT_NV - 2].x + 1.0; vy = rgt[k - IT_NV - 2].y; }
-        else if (k <= 3 * IT_NV + 3) { vx = upp[IT_NV + 1 - (k - 2 * IT_NV - 2)].x; vy = upp[IT_NV + 1 - (k - 2 * IT_NV - 2)].y + 1.0; }
-        else { vx = own[IT_NV + 2 + (IT_NV - 1 - (k - 3 * IT_NV - 4))].x; vy = own[IT_NV + 2 + (IT_NV - 1 - (k - 3 * IT_NV - 4))].y; }
-        if (k == 0) v0x = vx;
-        if (vx < oxmin) oxmin = vx;
-        if (vx > oxmax) oxmax = vx;
-        if (vy < oymin) oymin = vy;
-        if (vy > oymax) oymax = vy;
-        if (k <= IT_NV + 1) { if (vy > iymin) iymin = vy; }
-        if (k >= IT_NV + 1 && k <= 2 * IT_NV + 2) { if (vx < ixmax) ixmax = vx; }
-        if (k >= 2 * IT_NV + 2 && k <= 3 * IT_NV + 3) { if (vy < iymax) iymax = vy; }
-        if (k >= 3 * IT_NV + 3) { if (vx > ixmin) ixmin = vx; }
+        for (int q = 0; q < 4; ++q) P[(ly * UT + lx) * 4 + q] = make_double2(bnd[2 * q], bnd[2 * q + 1]);
     }
-    if (v0x > ixmin) ixmin = v0x;
-    double* b = s.bf_bounds + cell_index(sl, i, j) * 8;
-    b[0] = ixmin; b[1] = ixmax; b[2] = iymin; b[3] = iymax;
-    b[4] = oxmin; b[5] = oxmax; b[6] = oymin; b[7] = oymax;
+    __syncthreads();
+    {
+        const int ncx = (sl.nx - tx0 < UT) ? sl.nx - tx0 : UT;                   // pixels per row of this tile (may be <= 0)
+        const int nrow = (sl.ny - ty0 < UT) ? sl.ny - ty0 : UT;
+#pragma unroll
+        for (int e = (int)threadIdx.x; e < UT * UT * 4; e += 256) {
+            const int r = e / (UT * 4), k = e - r * (UT * 4);
+            if (r < nrow && k < ncx * 4)
+                ((double2*)(s.bf_bounds + cell_index(sl, tx0, ty0 + r) * 8))[k] = P[e];
+        }
+    }
 }
 
 __device__ __forceinline__ int owned_to_vertex(int nV, int n)

@@ -1138,13 +1138,16 @@ class Renderer:
         sensor_host = C.byref(b.sensor_host) if self.scene.sensor is not None else None
         changed = self._changed.data_ptr() if hasattr(self, "_changed") else None
         sarr = (C.c_void_p * len(streams))(*[st.cuda_stream for st in streams])
+        own_work_queued = self._plans_run > 0
         for kind, payload, n in stretches:
             if kind == "slots":
                 # the slot table is written by a copy on the chain stream: ordered behind everything queued so far on
                 # every stream and ahead of everything that follows, on the GPU (no host synchronisation)
-                # (a renderer's FIRST plan has nothing of its own queued yet -- what the shared streams hold belongs to other
-                # renderers, other buffers: a CCD of a focal plane must not wait for the wide launches of the previous one)
-                for st in (set(streams) if self._plans_run else ()):
+                # (the FIRST slot table of a renderer's FIRST plan has nothing of its own queued ahead of it -- what the
+                # shared streams hold belongs to other renderers, other buffers: a CCD of a focal plane must not wait for the
+                # wide launches of the previous one.  Every later table of the same plan -- a second brighter-fatter group --
+                # is rewritten under this plan's own launches and waits for all of them)
+                for st in (set(streams) if own_work_queued else ()):
                     if st is not self.s_chain:
                         ev = torch.cuda.Event()
                         ev.record(st)
@@ -1158,6 +1161,7 @@ class Renderer:
                         st.wait_event(ev)
                 continue
             _abi.check(self.lib.ims_run_plan(payload, n, sensor_dev, sensor_host, changed, sarr, len(streams)), "ims_run_plan")
+            own_work_queued = True
         self._plans_run += 1
         for st in set(streams):
             ev = torch.cuda.Event()

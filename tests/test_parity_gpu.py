@@ -421,6 +421,45 @@ def test_lsst_image_edge_cases_are_bit_exact(torch_cuda):
     assert r2.image_numpy().sum() == 0
 
 
+def test_several_brighter_fatter_groups_on_a_fresh_renderer(torch_cuda):
+    """A scratch capacity that holds a third of the bright objects' regions: the FIRST plan of a fresh renderer then carries
+    several brighter-fatter groups, each with its own slot table, and the table of group k + 1 is rewritten on the chain
+    stream while the launches of group k (several chain classes on several streams) are still queued -- it has to wait for
+    all of them (engine.execute_plan).  Image and realized fluxes equal the oracle's and the one-group render's, three times
+    over with fresh renderers (the failure this guards against is a race)."""
+    from imsim_amd.engine import Renderer, plan_bf_groups
+    from oracle import orc_loader
+    nrecalc = 1000
+    scene, objects = _c3_case(n_obj=300, scratch=4_000_000)
+    bright = np.flatnonzero(objects["n_phot"] > nrecalc)
+    cells = ((objects["stamp_xmax"] - objects["stamp_xmin"] + 2).astype(np.int64) * (objects["stamp_ymax"] - objects["stamp_ymin"] + 2))[bright]
+    one = Renderer(scene)
+    real1 = torch_cuda.zeros(len(objects), dtype=torch_cuda.float64, device="cuda")
+    one.render_lsst_image(objects, nrecalc=nrecalc, realized=real1)
+    one.synchronize()
+    want, want_real = one.image_numpy(), real1.cpu().numpy()
+    scene.sensor.scratch_cells = int(max(cells.max(), cells.sum() // 3)) + 1
+    b = one.bound
+    _, groups = plan_bf_groups(objects, nrecalc, b.n_static_slots, b.static_cells, scene.sensor.scratch_cells, b.slot_capacity)
+    assert len(groups) >= 3
+    rounds = (objects["n_phot"][groups[0][0]] + nrecalc - 1) // nrecalc
+    assert rounds.max() >= 6 and rounds.min() < 6, "the first group should hold several chain classes"
+    del one
+    orc = orc_loader.OracleScene(scene)
+    real_o = np.zeros(len(objects))
+    orc.render_lsst_image(objects, nrecalc=nrecalc, realized=real_o)
+    assert_bits_equal(want, orc.image, "one group vs oracle")
+    for attempt in range(3):
+        r = Renderer(scene)
+        real = torch_cuda.zeros(len(objects), dtype=torch_cuda.float64, device="cuda")
+        r.render_lsst_image(objects, nrecalc=nrecalc, realized=real)
+        r.synchronize()
+        assert_bits_equal(r.image_numpy(), want, f"image, attempt {attempt}")
+        assert_bits_equal(real.cpu().numpy(), want_real, f"realized flux, attempt {attempt}")
+        del r
+    assert_bits_equal(want_real, real_o, "realized flux vs oracle")
+
+
 @pytest.mark.parametrize("vendor", ["itl", "e2v"])
 def test_sensor_models_of_4_8_and_32_vertices_on_the_gpu(torch_cuda, vendor):
     """The reference's cross-model criterion (tests/test_sensor_models.py:73-125) through the HIP path: the 1e6-photon

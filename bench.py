@@ -227,7 +227,8 @@ def main():
         elapsed = float(t.item())
 
     n_total_obj = len(objects)
-    n_total_phot = int(objects["n_phot"].sum())
+    fft_mask = getattr(objects, "fft_mask", None)           # a focal plane's FFT-drawn objects shoot no photons
+    n_total_phot = int(objects["n_phot"].sum() if fft_mask is None else np.asarray(objects["n_phot"])[~fft_mask].sum())
     ms_per_step = 1e3 * elapsed / args.steps
     value = n_total_obj * args.steps / elapsed
 
@@ -272,7 +273,8 @@ def main():
         "value": value, "unit": "objects/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": cfg["workload"], "n_objects": n_total_obj, "n_photons": n_total_phot,
+        "config": {"workload": cfg["workload"] + ("; " + step.workload_note if getattr(step, "workload_note", None) else ""),
+                   "n_objects": n_total_obj, "n_photons": n_total_phot,
                    "image": [scene.nx, scene.ny],
                    "sharding": cfg.get("sharding", "objects dealt by photon count") + f" over {world} rank(s)"},
         "photons_per_s": n_total_phot * args.steps / elapsed,
@@ -338,6 +340,8 @@ def _cpu_step(cfg):
     """the oracle-side step of a config; the FFT branch's lives here because the package never imports the oracle"""
     if cfg.get("cpu_step") is not None:
         return cfg["cpu_step"]
+    if cfg.get("cpu_sample_of") is not None:
+        return _cpu_job_step
 
     def fft_step(orc_scene, sample):
         from oracle import orc_loader
@@ -346,6 +350,24 @@ def _cpu_step(cfg):
         o.finish(rows, o.inverse(rows, o.fill(rows)))
         orc_scene.image64 += o.image
     return fft_step
+
+
+def _cpu_job_step(orc_scene, sample):
+    """One CCD's build on the checker, in the reference's order (imsim/lsst_image.py:342-368): the FFT-drawn objects (k-space
+    fill, numpy inverse transform, spike stencil, clip + Poisson noise, stamp -> CCD), then the photon-shot ones."""
+    from oracle import orc_loader
+    job = sample.job
+    if job.n_fft:
+        o = orc_loader.OracleFft(orc_scene.scene, job.kpsf, add_noise=True, diffraction_fft=job.diffraction_fft,
+                                 wavelength=job.wavelength, extra_ktables=job.extra_ktables)
+        rows = job.fft_rows
+        rbuf = o.inverse(rows, o.fill(rows))
+        if job.diffraction_fft is not None and job.diffraction_fft.enabled:
+            rbuf = o.spikes(rows, rbuf)
+        o.finish(rows, rbuf)
+        orc_scene.image64 += o.image
+    if len(job.objects):
+        orc_scene.render_lsst_image(job.objects, nrecalc=job.nrecalc)
 
 
 def cpu_legs(cfg, scene, objects, args, fork_ok=True):
@@ -357,17 +379,24 @@ def cpu_legs(cfg, scene, objects, args, fork_ok=True):
     from imsim_amd import parallel
     n_sample = args.cpu_sample or cfg["cpu_sample"]
     rng = np.random.default_rng(99)
-    idx = np.sort(rng.choice(len(objects), size=min(n_sample, len(objects)), replace=False))
-    sample = objects[idx]
+    if cfg.get("cpu_sample_of") is not None:
+        sample = cfg["cpu_sample_of"](objects, scene)           # a whole CCD of a focal plane, as the job the GPU runs
+        n_phot_sample = int(sample.job.objects["n_phot"].sum())
+        what = (f"CCD 0 of the focal plane whole: {len(sample)} objects, {sample.job.n_fft} of them FFT-drawn, "
+                f"{n_phot_sample} photons shot")
+    else:
+        idx = np.sort(rng.choice(len(objects), size=min(n_sample, len(objects)), replace=False))
+        sample = objects[idx]
+        n_phot_sample = int(sample["n_phot"].sum())
+        what = f"{len(sample)} objects drawn at random from the same catalog ({n_phot_sample} photons"
     cpu_scene = cfg["cpu_scene"](scene)
     orc = orc_loader.OracleScene(cpu_scene)
     t0 = time.perf_counter()
     _cpu_step(cfg)(orc, sample)
     dt = time.perf_counter() - t0
     res = {"value": len(sample) / dt, "unit": "objects/s", "cores": 1, "kind": "port",
-           "sample": f"{len(sample)} objects drawn at random from the same catalog "
-                     f"({int(sample['n_phot'].sum())} photons, {dt:.1f} s)",
-           "photons_per_s": float(sample["n_phot"].sum()) / dt, "host_cpus": os.cpu_count(),
+           "sample": f"{what}, {dt:.1f} s)" if what.count("(") > what.count(")") else f"{what} ({dt:.1f} s)",
+           "photons_per_s": float(n_phot_sample) / dt, "host_cpus": os.cpu_count(),
            "_sample": sample, "_image": orc.image}
     if fork_ok and not args.no_cpu_allcore and cfg.get("cpu_allcore", True):
         cores = len(os.sched_getaffinity(0))

@@ -13,6 +13,7 @@ ignored with a note in `Process(...).ignored`.
 import copy
 import math
 import os
+import types
 
 import numpy as np
 import yaml
@@ -531,7 +532,11 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
     meta = cfg.get("_opsim_data", {})
     band = meta.get("band", "r")
     seed = int(ev.value(image.get("random_seed", meta.get("seed", 0))))
-    for det in parallel.shard_ccds(range(first, first + nfiles), rank, world):
+    dets = parallel.shard_ccds(range(first, first + nfiles), rank, world)
+
+    def prepare(det):
+        """Host half of one CCD: scene, catalog, object classification -- everything up to the first GPU call of the CCD
+        (the phase screens of input.atm_psf, generated on the GPU once per visit, aside)."""
         det_name = det_name_of(det)
         ev.vars["det_name"] = det_name
         ev.vars["_sequence_index"] = det                   # what `@output.det_num` (type Sequence) yields for this CCD
@@ -631,7 +636,6 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
         configs.add_sersic_tables(scene, cat["sersic_n"])       # radial tables for every Sersic index of the catalog (:511-517)
         phot = catalog.realize_fluxes(cat["nominal_flux"], seed_ccd)
         scene.image_profiles = cat.get("images") or None          # FITS-stamp objects (instcat.py:552-561)
-        renderer = Renderer(scene, device)
 
         def make_objects(sub, ph, scene=scene):
             objs, sizes = configs.c3b_objects(sub, ph, scene) if scene.atm is not None else configs.c3_objects(sub, ph, scene)
@@ -651,27 +655,41 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
             chk = Checkpointer(str(c["file_name"]), dir=c.get("dir"))
         elif "checkpoint" in inp:
             # LSST_Image: a CCD is ONE launch plan of some tens of milliseconds here, there is no state between batches to save
-            res.ignored.append("input.checkpoint (LSST_Image renders a CCD in one launch plan; checkpoints are kept per photon batch "
-                               "in LSST_PhotonPoolingImage mode)")
-        dfft = None
-        if "diffraction_fft" in stamp_cfg:
+            note = ("input.checkpoint (LSST_Image renders a CCD in one launch plan; checkpoints are kept per photon batch "
+                    "in LSST_PhotonPoolingImage mode)")
+            if note not in res.ignored:
+                res.ignored.append(note)
+        dfft = cfg.get("_diffraction_fft")
+        if dfft is None and "diffraction_fft" in stamp_cfg:
             from .diffraction_fft import DiffractionFFT
             d = {k: ev.value(v) for k, v in stamp_cfg["diffraction_fft"].items()}
-            dfft = DiffractionFFT(**d)
+            dfft = cfg["_diffraction_fft"] = DiffractionFFT(**d)        # one per visit: its stencil normalisation is shared by the CCDs
+        fft_photon_ops = stamp_cfg.get("fft_photon_ops")
+        if fft_photon_ops:
+            # stamp.fft_photon_ops (imsim/stamp.py:493-499, :675-678): photon ops applied to FFT-drawn objects by shooting the
+            # FFT image; the path draws FFT stamps without a photon stage, as the reference does whenever the list is empty
+            # (its default: config/imsim-config.yaml has no fft_photon_ops)
+            build_photon_ops(fft_photon_ops, ev, wl_eff)                 # parsed and validated like stamp.photon_ops
+            note = "stamp.fft_photon_ops (parsed; FFT-drawn stamps are not re-shot through photon ops on this path)"
+            if note not in res.ignored:
+                res.ignored.append(note)
+        ctx = types.SimpleNamespace(det=det, det_name=det_name, scene=scene, builder=builder, truth=truth, seed_ccd=seed_ccd,
+                                    nx=nx, ny=ny, job=None, pooling=None)
         if itype == "LSST_PhotonPoolingImage":
-            builder.build_image(renderer, cat, phot, make_objects, max_flux_simple=max_simple, seed=seed_ccd, truth=truth,
-                                fft_sb_thresh=float(ev.value(stamp_cfg.get("fft_sb_thresh", 0.0))), kpsf=kpsf, fwhm_total=fwhm_total,
-                                diffraction_fft=dfft, wavelength=wl_eff, extra_ktables=extra_ktables, vignetting=vig,
-                                checkpoint=chk)
+            ctx.pooling = dict(cat=cat, phot=phot, make_objects=make_objects, max_flux_simple=max_simple, seed=seed_ccd, truth=truth,
+                               fft_sb_thresh=float(ev.value(stamp_cfg.get("fft_sb_thresh", 0.0))), kpsf=kpsf, fwhm_total=fwhm_total,
+                               diffraction_fft=dfft, wavelength=wl_eff, extra_ktables=extra_ktables, vignetting=vig, checkpoint=chk)
         else:
-            builder.build_image(renderer, cat, phot, make_objects,
-                                fft_sb_thresh=float(ev.value(stamp_cfg.get("fft_sb_thresh", 0.0))), max_flux_simple=max_simple,
-                                draw_method=ev.value(stamp_cfg.get("draw_method", "auto")), kpsf=kpsf, fwhm_total=fwhm_total,
-                                diffraction_fft=dfft, wavelength=wl_eff, nrecalc=nrecalc, truth=truth, extra_ktables=extra_ktables,
-                                vignetting=vig)
+            ctx.job = builder.prepare(scene, cat, phot, make_objects,
+                                      fft_sb_thresh=float(ev.value(stamp_cfg.get("fft_sb_thresh", 0.0))), max_flux_simple=max_simple,
+                                      draw_method=ev.value(stamp_cfg.get("draw_method", "auto")), kpsf=kpsf, fwhm_total=fwhm_total,
+                                      diffraction_fft=dfft, wavelength=wl_eff, nrecalc=nrecalc, extra_ktables=extra_ktables,
+                                      vignetting=vig)
+            ctx.job.want_realized = True
         # sky + noise (imsim/lsst_image.py:128-200) when a numeric sky level is configured; the Rubin sky model,
         # vignetting and fringing inputs are out of scope and reported as ignored
         sky = image.get("sky_level")
+        ctx.sky = None
         if isinstance(sky, (int, float)) and not isinstance(sky, bool) and image.get("noise"):
             # sky x radial vignetting per pixel (lsst_image.py:172-176) when input.vignetting is configured, x the
             # fringing map of E2V sensors when image.apply_fringing is set (lsst_image.py:178-197)
@@ -690,13 +708,62 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
                 mult = fmap if mult is None else mult * fmap
             # a Silicon sensor's pixels collect sky in proportion to their (tree-ring distorted) area; image.use_flux_sky_areas
             # adds the one-step brighter-fatter distortion from the flux already drawn (config/imsim-config.yaml:222-228)
-            areas = builder.sky_pixel_areas(renderer, use_flux=bool(ev.value(image.get("use_flux_sky_areas", False))))
-            builder.add_noise(renderer, float(sky), seed=seed_ccd, multiplier=mult, pixel_areas=areas)
-        elif "sky_level" in image:
+            ctx.sky = dict(sky_level=float(sky), seed=seed_ccd, multiplier=mult,
+                           use_flux_sky_areas=bool(ev.value(image.get("use_flux_sky_areas", False))))
+        elif "sky_level" in image and "image.sky_level" not in res.ignored:
             res.ignored.append("image.sky_level")
+        if ctx.job is not None:
+            ctx.job.sky = ctx.sky
+        return ctx
+
+    done = {}
+
+    def finish(ctx, renderer):
+        """One CCD's image is through: truth record, host copy, `output` (e-image, readout) from the device image."""
+        ev.vars["det_name"] = ctx.det_name                   # `output.file_name` and friends are evaluated per CCD
+        ev.vars["_sequence_index"] = ctx.det
         renderer.synchronize()
-        res.images.append(renderer.image_numpy())
+        if ctx.job is not None:
+            lsst_image.fill_truth(ctx.truth, ctx.job, ctx.job.realized.cpu().numpy())
+        sub = ProcessResult()
+        _process_outputs(out, ev, sub, renderer.image, ctx.det_name, meta, ctx.seed_ccd)
+        done[ctx.det] = (renderer.image_numpy(), ctx.truth, ctx.det_name, sub)
+
+    # Several CCDs of LSST_Image type go through the overlapped focal-plane path (focal_plane.render_focal_plane, the per-CCD
+    # fan-out of imsim/ccd.py:72-89): the host prepares the next CCD while the GPU works through the launch plans of the
+    # previous ones; IMS_PROCESS_FOCAL=0 renders them one after the other (same images: every photon's stream is addressed by
+    # CCD seed, object and photon index)
+    overlapped = itype != "LSST_PhotonPoolingImage" and len(dets) > 1 and os.environ.get("IMS_PROCESS_FOCAL", "1") != "0"
+    if overlapped:
+        from . import focal_plane
+        ctxs = {}
+
+        def build(det):
+            ctxs[det] = prepare(det)
+            return ctxs[det].scene, ctxs[det].job
+
+        focal_plane.render_focal_plane(dets, build, device=device, rank=0, world=1,
+                                       concurrent=int(os.environ.get("IMS_PROCESS_CONCURRENT", "3")),
+                                       sink=lambda det, img: None, post=lambda det, r: finish(ctxs.pop(det), r))
+    else:
+        for det in dets:
+            ctx = prepare(det)
+            renderer = Renderer(ctx.scene, device)
+            if ctx.pooling is not None:
+                ctx.builder.build_image(renderer, **ctx.pooling)
+                if ctx.sky is not None:
+                    kw = dict(ctx.sky)
+                    areas = ctx.builder.sky_pixel_areas(renderer, use_flux=kw.pop("use_flux_sky_areas"))
+                    ctx.builder.add_noise(renderer, kw.pop("sky_level"), pixel_areas=areas, **kw)
+            else:
+                lsst_image.draw_job(renderer, ctx.job)
+            finish(ctx, renderer)
+    for det in dets:
+        img, truth, det_name, sub = done[det]
+        res.images.append(img)
         res.truth.append(truth)
         res.det_names.append(det_name)
-        _process_outputs(out, ev, res, renderer.image, det_name, meta, seed_ccd)
+        res.eimages += sub.eimages
+        res.raw += sub.raw
+        res.files += sub.files
     return res

@@ -546,12 +546,36 @@ def _c5_scene_bench():
     return sc
 
 
-def _c5_catalog(n_objects, scene):
-    per = max(n_objects // N_CCD_FOCAL_PLANE, 1)
-    parts = [catalog.synthetic_catalog(per, seed=20261001 + det, nx=scene.nx, ny=scene.ny) for det in range(N_CCD_FOCAL_PLANE)]
+C5_BRIGHT_PER_CCD = 3            # stars of 1e6 .. 1e8 electrons on every CCD (the bright tail of a real pointing)
+C5_FFT_SB_THRESH = 2.0e5         # stamp.fft_sb_thresh of config/imsim-config.yaml
+
+
+def c5_bright_tail(cat, det, k=C5_BRIGHT_PER_CCD):
+    """The first k objects of a CCD's catalog become stars with fluxes log-uniform in [1e6, 1e8] electrons (r = 16.8 .. 11.8):
+    the survey's flux law stops at 2.1e6 e- (8d), a real pointing does not -- several stars brighter than r = 16 fall on
+    every 13' x 13' CCD.  Above ~1.1e7 e- a star crosses fft_sb_thresh and takes the FFT branch with the spike stencil
+    (imsim/stamp.py:275-308, :482-525); between 1e6 and that it is photon-shot through hundreds of brighter-fatter rounds."""
+    k = min(int(k), len(cat["x"]))
+    if k <= 0:
+        return cat
+    rng = np.random.default_rng([20261001, int(det), 0xB817])
+    flux = 10.0 ** rng.uniform(6.0, 8.0, k)
+    cat["nominal_flux"][:k] = flux
+    cat["mag"][:k] = 28.13 - 2.5 * np.log10(flux / 30.0)
+    cat["kind"][:k] = 0
+    wl, thr = tables.synthetic_r_band()
+    cat["sb_flux"][:k] = flux / float(np.trapezoid(thr, wl))
+    return cat
+
+
+def _c5_catalog(n_objects, scene, n_ccd=None, bright=C5_BRIGHT_PER_CCD):
+    n_ccd = N_CCD_FOCAL_PLANE if n_ccd is None else int(n_ccd)
+    per = max(n_objects // n_ccd, 1)
+    parts = [c5_bright_tail(catalog.synthetic_catalog(per, seed=20261001 + det, nx=scene.nx, ny=scene.ny), det, bright)
+             for det in range(n_ccd)]
     cat = _FocalPlaneCatalog({k: np.concatenate([p[k] for p in parts]) for k in parts[0]})
     cat["obj_id"] = np.concatenate([p["obj_id"] for p in parts])           # ids restart per CCD, like object numbers per file
-    cat.ccd_offsets = np.arange(N_CCD_FOCAL_PLANE + 1) * per
+    cat.ccd_offsets = np.arange(n_ccd + 1) * per
     return cat
 
 
@@ -562,28 +586,85 @@ def _c5_objects(cat, phot, scene):
     kept = np.concatenate([[0], np.cumsum(phot > 0)])
     t = objects.view(_CcdTable)
     t.ccd_offsets = kept[cat.ccd_offsets]
+    t.cat, t.phot, t.cat_offsets = cat, phot, np.asarray(cat.ccd_offsets)
+    # which rows the per-CCD build will FFT-draw (their Poisson fluxes are not photons shot): bench.py's photon count
+    from . import lsst_image
+    v = c5_visit_fft()
+    is_fft = lsst_image.LSST_ImageBuilderBase._use_fft(cat, cat["nominal_flux"], v["fwhm_total"], C5_FFT_SB_THRESH, v["kpsf"], ())
+    t.fft_mask = (is_fft & (np.asarray(cat["kind"]) < 3))[phot > 0]
     return t, sizes
+
+
+def c5_visit_fft():
+    """What the FFT branch of every CCD of the bench visit shares: k-space PSF of the Kolmogorov (+) Gaussian atmosphere, total
+    FWHM, the `stamp.diffraction_fft` block of config/imsim-config.yaml:269-279 (its stencil normalisation is computed once)."""
+    from . import fft_draw
+    from .diffraction_fft import DiffractionFFT
+    fwhm_atm, fwhm_sys = catalog.kolmogorov_gaussian_fwhm(VISIT["airmass"], VISIT["raw_seeing"], VISIT["band"])
+    dfft = _C5_DFFT.get("dfft")
+    if dfft is None:
+        dfft = _C5_DFFT["dfft"] = DiffractionFFT(exptime=VISIT["exptime"], azimuth=math.radians(VISIT["azimuth"]),
+                                                 altitude=math.radians(VISIT["altitude"]), rotTelPos=math.radians(VISIT["rottelpos"]))
+    return dict(kpsf=fft_draw.kolmogorov_gaussian_kpsf(fwhm_atm, fwhm_sys), fwhm_total=math.hypot(fwhm_atm, fwhm_sys),
+                diffraction_fft=dfft, wavelength=r_band_sed_table()[1])
+
+
+_C5_DFFT = {}
+
+
+def c5_job(scene, cat, phot, rows, nrecalc=10000, fft_sb_thresh=C5_FFT_SB_THRESH, max_flux_simple=100.0, visit=None):
+    """The per-CCD build of the reference for one CCD of the bench visit (imsim/lsst_image.py:276-395): every object classified
+    FFT / photons / faint by stamp.py:275-336 with the default config's fft_sb_thresh -> lsst_image.CcdJob.  rows: the CCD's
+    prebuilt OBJECT_DTYPE rows (objects with photons, catalog order)."""
+    from . import lsst_image
+    v = visit or c5_visit_fft()
+    b = lsst_image.LSST_ImageBuilder()
+    b.setup({"det_name": "R22_S11", "xsize": scene.nx, "ysize": scene.ny})
+    return b.prepare(scene, cat, phot, lambda sub, ph: (np.array(rows, dtype=_abi.OBJECT_DTYPE), None), fft_sb_thresh=fft_sb_thresh,
+                     max_flux_simple=max_flux_simple, kpsf=v["kpsf"], fwhm_total=v["fwhm_total"], diffraction_fft=v["diffraction_fft"],
+                     wavelength=v["wavelength"], nrecalc=nrecalc)
+
+
+def c5_cpu_sample(objects, scene):
+    """bench.py's CPU sample of a focal plane: CCD 0 whole, as the job the GPU runs (FFT objects, photon-shot objects)."""
+    a, b = int(objects.ccd_offsets[0]), int(objects.ccd_offsets[1])
+    ca, cb = int(objects.cat_offsets[0]), int(objects.cat_offsets[1])
+    sub = {k: v[ca:cb] for k, v in objects.cat.items() if isinstance(v, np.ndarray)}
+    rows = np.asarray(objects[a:b])
+    sample = rows.view(_CcdTable)
+    sample.job = c5_job(scene, sub, objects.phot[ca:cb], rows)
+    return sample
 
 
 def _c5_step(renderer, objects, rank=0, world=1, concurrent=3):
     """One step = every CCD this rank owns (CCD i -> rank i mod world, no exchange), each through a FRESH renderer: scene
-    tables, the CCD's static pixel-boundary state, launch plan, ONE arena upload, the run, and the float32 image back on the
-    host -- what `focal_plane.render_focal_plane` does per CCD.  Up to `concurrent` CCDs are in flight on their own streams."""
+    tables, the CCD's static pixel-boundary state, then the per-CCD build -- FFT-drawn objects first, launch plan of the
+    photon-shot ones, ONE arena upload, the run -- and the float32 image back on the host: what
+    `focal_plane.render_focal_plane` does per CCD.  Up to `concurrent` CCDs are in flight on the device's streams."""
     import copy
-    from . import focal_plane
+    from . import focal_plane, lsst_image
     from .config import ccd_seed
     offs = getattr(objects, "ccd_offsets", None)
-    if offs is None:                       # a sample of one CCD (bench.py's parity leg): the CCD of the given renderer
-        return renderer.prepared_lsst_image(objects)
+    if offs is None:                       # one CCD (bench.py's parity leg): the CCD of the given renderer
+        job = getattr(objects, "job", None)
+        if job is None:
+            return renderer.prepared_lsst_image(objects)
+        return lambda: lsst_image.draw_job(renderer, job)
     base = renderer.scene
-    tables = {det: np.asarray(objects[offs[det]:offs[det + 1]]) for det in range(len(offs) - 1)}
-    mine = parallel.shard_ccds(list(tables), rank, world)
+    cat, phot, coffs = objects.cat, objects.phot, objects.cat_offsets
+    mine = parallel.shard_ccds(list(range(len(offs) - 1)), rank, world)
     nrecalc = 10000
+    visit = c5_visit_fft()
+    visit["diffraction_fft"].constants(visit["wavelength"])          # once per visit, outside the timed region
+    jobs = {}
+    for det in mine:
+        sub = {k: v[coffs[det]:coffs[det + 1]] for k, v in cat.items() if isinstance(v, np.ndarray)}
+        jobs[det] = c5_job(base, sub, phot[coffs[det]:coffs[det + 1]], np.asarray(objects[offs[det]:offs[det + 1]]), nrecalc, visit=visit)
 
     def build(det):
         sc = copy.copy(base)
         sc.seed = base.seed if det == 0 else ccd_seed(base.seed, det)
-        return sc, tables[det]
+        return sc, jobs[det]
 
     def sink(det, image):
         # stands for the FITS writer: the image is on the host; a coarse checksum proves it arrived
@@ -591,25 +672,36 @@ def _c5_step(renderer, objects, rank=0, world=1, concurrent=3):
 
     def launch():
         launch.checksums = {}
-        focal_plane.render_focal_plane(list(tables), build, device=str(renderer.device), rank=rank, world=world,
+        focal_plane.render_focal_plane(list(range(len(offs) - 1)), build, device=str(renderer.device), rank=rank, world=world,
                                        concurrent=concurrent, nrecalc=nrecalc, sink=sink)
-    n_phot = np.concatenate([tables[d]["n_phot"] for d in mine]) if mine else np.zeros(0, dtype=np.int64)
+    n_phot = np.concatenate([jobs[d].objects["n_phot"] for d in mine]) if mine else np.zeros(0, dtype=np.int64)
     ordinary = n_phot[n_phot <= nrecalc]
     launch.photons = int(n_phot.sum())
     launch.object_rows = len(n_phot)
     # the fused launch of the ordinary objects (one per CCD): f64 image RMW 16 B per photon + one 256-B row per object
     launch.timed = {1: (len(mine), int(ordinary.sum()) * 16 + len(ordinary) * 256), 2: (0, 0)}
     launch.n_ccds = len(mine)
+    n_fft = sum(jobs[d].n_fft for d in mine)
+    nfft = np.concatenate([jobs[d].fft_rows["nfft"] for d in mine if jobs[d].n_fft] or [np.zeros(0, dtype=np.int64)]).astype(np.int64)
+    bright_phot = int(np.count_nonzero(n_phot >= 1_000_000))
+    launch.n_fft = n_fft
+    grids = {int(k): int(v) for k, v in zip(*np.unique(nfft, return_counts=True))}
+    flags = np.concatenate([jobs[d].objects["flags"] for d in mine]) if mine else np.zeros(0, dtype=np.int32)
+    launch.workload_note = (f"{n_fft} objects FFT-drawn with the spike stencil (FFT grid: count {grids}), {len(n_phot)} photon-shot "
+                            f"({bright_phot} of them stars of >= 1e6 photons through the brighter-fatter rounds, "
+                            f"{int(np.count_nonzero(flags & _abi.IMS_OBJ_FAINT))} faint) on this rank's {len(mine)} CCDs")
     return launch
 
 
 BENCH_CONFIGS["c5"] = dict(
     n_objects=N_CCD_FOCAL_PLANE * 10000,
-    workload="C5: 189-CCD focal plane, 10k-source synthetic catalog per CCD (own catalog, seed and photon streams), every CCD "
-             "an independent LSST_Image build (C3 physics: full photon-op chain, Silicon brighter-fatter + tree rings) through a "
-             "fresh renderer on its own stream, CCD i -> GPU i mod N, image back on the host; host object tables are inputs; "
-             "draw_method by the reference's rule (FFT only above 1e6 e- AND a peak surface brightness above fft_sb_thresh = "
-             "2e5, config/imsim-config.yaml): no object of this catalog qualifies, so every object is photon-shot",
+    workload="C5: 189-CCD focal plane, 10k-source synthetic catalog per CCD (own catalog, seed and photon streams; three stars of "
+             "1e6 .. 1e8 e- per CCD as the bright tail of a real pointing), every CCD the reference's per-CCD build "
+             "(imsim/lsst_image.py:276-395) through a fresh renderer on the device's streams: draw_method by the reference's rule "
+             "(FFT above 1e6 e- AND a peak surface brightness above fft_sb_thresh = 2e5, config/imsim-config.yaml) -- FFT-drawn "
+             "objects first (k-space fill, inverse FFT, diffraction-spike stencil, Poisson noise), then the photon-shot ones (C3 "
+             "physics: full photon-op chain, Silicon brighter-fatter + tree rings), CCD i -> GPU i mod N, image back on the host; "
+             "host object tables are inputs",
     scene=_c5_scene_bench,
     catalog=_c5_catalog,
     objects=_c5_objects,
@@ -619,9 +711,11 @@ BENCH_CONFIGS["c5"] = dict(
     timed_kernel=1,
     kernel="k_shoot_accumulate",
     cpu_sample=10000,
+    cpu_sample_of=c5_cpu_sample,          # CCD 0 whole, as the job the GPU runs
     cpu_scene=_c3_cpu_scene,
-    cpu_step=lambda orc, sample: orc.render_lsst_image(sample),
+    cpu_step=None,                        # bench.py runs the job on the checker (FFT objects, then the photon-shot ones)
     cpu_allcore=False,
+    parity_mode="close",                  # FFT stamps: library transforms agree to ~1e-11 of the peak (see the fft config)
     metric="objects/sec over a 189-CCD focal plane (photon-shooting path, one CCD per stream)",
     sharding="CCD i -> rank i mod N, no exchange",
 )

@@ -85,6 +85,15 @@ class DiffractionFFT:
     enabled: bool = True
 
     def constants(self, wavelength):
+        """Spike geometry and stencil normalisation at `wavelength`: once per visit and wavelength (the normalisation is a
+        sum over the (2 cutoff + 1)^2 grid -- seconds of host time; every CCD of a focal plane shares the instance)."""
+        cache = self.__dict__.setdefault("_constants", {})
+        key = (float(wavelength), self.exptime, self.azimuth, self.altitude, self.rotTelPos, self.spike_length_cutoff, self.latitude)
+        if key not in cache:
+            cache[key] = self._constants_at(wavelength)
+        return cache[key]
+
+    def _constants_at(self, wavelength):
         d_alpha = field_rotation_angle(self.latitude, self.azimuth, self.altitude, self.exptime)
         alpha = math.pi / 4.0 - self.rotTelPos                       # imsim/diffraction_fft.py:155
         k = SpikeConstants(math.cos(alpha - d_alpha / 2.0), math.sin(alpha - d_alpha / 2.0), alpha - d_alpha, d_alpha,

@@ -14,16 +14,21 @@ stream is addressed by (CCD seed, object id, photon index).
 import os
 import time
 
-from . import parallel
+from . import parallel, lsst_image
 from .engine import Renderer
 
 
 _ANCHOR_STREAMS = {}
 
 
-def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent=3, nrecalc=None, sink=None):
-    """ccds: sequence of CCD keys (detector numbers / names); build(key) -> (scene, objects) prepares one CCD
-    on the host.  Returns {key: float32 image as a host array} for the CCDs this rank owns.
+def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent=3, nrecalc=None, sink=None, post=None):
+    """ccds: sequence of CCD keys (detector numbers / names); build(key) -> (scene, work) prepares one CCD on the host, work
+    being either the object table of a photon-shot CCD or an `lsst_image.CcdJob` -- the per-CCD build of the reference
+    (imsim/lsst_image.py:276-395 under the fan-out of imsim/ccd.py:72-89): FFT-drawn objects first, then the launch plan of the
+    photon-shot ones, then the optional sky.  Returns {key: float32 image as a host array} for the CCDs this rank owns.
+
+    post(key, renderer): optional hook run once the CCD's work is through, before its renderer is dropped (readout and
+    the FITS writers of config.Process work on the device image).
 
     The finished image of a CCD is copied into a page-locked host buffer on the CCD's own stream (one buffer per
     stream in flight, reused).  sink(key, image): optional consumer (the FITS writer in production) that is handed
@@ -51,6 +56,8 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
             return
         key, renderer, host, done = in_flight[slot]
         done.synchronize()
+        if post is not None:
+            post(key, renderer)
         if sink is not None:
             sink(key, host.numpy())
         else:
@@ -63,7 +70,7 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
     def enqueue(k, key, slot):
         """Everything of one CCD up to the event behind its image copy (host work + asynchronous launches)."""
         torch.cuda.set_device(dev)
-        scene, objects = build(key)            # host work, overlaps with the CCDs still running on the GPU
+        scene, work = build(key)               # host work, overlaps with the CCDs still running on the GPU
         anchor = init_on = copy_on = streams[slot]
         top_index = None
         if anchor_role:
@@ -84,7 +91,12 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
             ready.record(init_on)
         with torch.cuda.stream(anchor):
             anchor.wait_event(ready)
-            renderer.render_lsst_image(objects, nrecalc=nrecalc)
+            if isinstance(work, lsst_image.CcdJob):
+                if work.nrecalc is None:
+                    work.nrecalc = nrecalc
+                lsst_image.draw_job(renderer, work)
+            else:
+                renderer.render_lsst_image(work, nrecalc=nrecalc)
             through = torch.cuda.Event()
             through.record(anchor)
         with torch.cuda.stream(copy_on):

@@ -7,6 +7,9 @@ nbatch_per_checkpoint with the same defaults); `build_image` is the draw loop: e
 classified FFT / PHOT / FAINT by the reference's rules and rendered into the CCD image.  Sky,
 noise, checkpointing and FITS output are out of scope.
 """
+import dataclasses
+from typing import Optional
+
 import numpy as np
 
 from . import catalog, fft_draw, photon_pooling, stamp
@@ -141,18 +144,71 @@ class LSST_ImageBuilderBase:
         return renderer.image
 
 
+@dataclasses.dataclass
+class CcdJob:
+    """Everything of ONE CCD's `LSST_Image` build that is decided on the host, ahead of the GPU: the rows of the
+    photon-shot objects (FAINT flagged), the FFT-drawn ones as FFT rows with what their drawer needs, the optional sky
+    stage.  `draw_job` only enqueues -- so a focal plane (focal_plane.render_focal_plane) can prepare the next CCD while
+    the GPU works through this one, exactly as it does for a bare object table."""
+    objects: "object"                                  # OBJECT_DTYPE rows of the photon-shot objects (may be empty)
+    nrecalc: Optional[int] = None
+    fft_rows: Optional[np.ndarray] = None              # FFT_OBJECT_DTYPE rows sorted by FFT size (fft_draw.build_fft_objects)
+    kpsf: Optional[list] = None                        # k-space PSF of the FFT drawer
+    extra_ktables: tuple = ()
+    diffraction_fft: "object" = None
+    wavelength: float = 622.2
+    sky: Optional[dict] = None                         # keyword arguments of add_noise (+ use_flux_sky_areas)
+    phot_index: Optional[np.ndarray] = None            # positions of `objects` / of `fft_rows` among the kept catalog rows
+    fft_index: Optional[np.ndarray] = None
+    n_kept: int = 0
+    want_realized: bool = False                        # draw_job allocates `realized` (f64 device tensor over the kept rows) itself
+    realized: "object" = None
+    host: dict = dataclasses.field(default_factory=dict)   # what build_image needs for the truth record
+
+    @property
+    def n_fft(self):
+        return 0 if self.fft_rows is None else len(self.fft_rows)
+
+
+def draw_job(renderer, job, realized=None):
+    """The draw loop of one CCD on the device (imsim/lsst_image.py:342-368 over imsim/stamp.py:411-575), enqueue only: the
+    FFT objects first (k-space fill, inverse transforms, spikes, Poisson noise, stamp -> CCD add), then the launch plan of
+    the photon-shot ones, then the optional sky.  realized: f64 device tensor over the kept catalog rows."""
+    torch = renderer.torch
+    if realized is None and job.want_realized:
+        realized = job.realized = torch.zeros(job.n_kept, dtype=torch.float64, device=renderer.device)
+    if job.n_fft:
+        if job.kpsf is None:
+            raise GalSimConfigError("FFT drawing needs the k-space PSF description")
+        drawer = fft_draw.FftDrawer(renderer, job.kpsf, add_noise=True, diffraction_fft=job.diffraction_fft,
+                                    wavelength=job.wavelength, extra_ktables=job.extra_ktables)
+        r_fft = torch.zeros(job.n_fft, dtype=torch.float64, device=renderer.device) if realized is not None else None
+        drawer.draw(job.fft_rows, realized=r_fft)
+        if realized is not None:
+            realized.index_add_(0, torch.from_numpy(np.ascontiguousarray(job.fft_index)).to(renderer.device), r_fft)
+        renderer._keep_fft = drawer
+    if len(job.objects):
+        r_ph = torch.zeros(len(job.objects), dtype=torch.float64, device=renderer.device) if realized is not None else None
+        renderer.render_lsst_image(job.objects, nrecalc=job.nrecalc, realized=r_ph)
+        if realized is not None:
+            realized.index_add_(0, torch.from_numpy(np.ascontiguousarray(job.phot_index)).to(renderer.device), r_ph)
+    if job.sky is not None:
+        kw = dict(job.sky)
+        base = LSST_ImageBuilderBase()
+        areas = base.sky_pixel_areas(renderer, use_flux=bool(kw.pop("use_flux_sky_areas", False))) if kw.pop("pixel_areas", True) else None
+        base.add_noise(renderer, kw.pop("sky_level"), pixel_areas=areas, **kw)
+        renderer._keep_sky = base
+    return renderer.image
+
+
 class LSST_ImageBuilder(LSST_ImageBuilderBase):
     """`image.type: LSST_Image` with `stamp.type: LSST_Silicon`."""
 
-    def build_image(self, renderer, cat, phot_flux, make_objects, fft_sb_thresh=0.0, max_flux_simple=100.0,
-                    draw_method="auto", kpsf=None, fwhm_total=0.8, diffraction_fft=None, wavelength=622.2,
-                    nrecalc=None, truth=None, extra_ktables=(), vignetting=None):
-        """The draw loop (imsim/lsst_image.py:342-368 + imsim/stamp.py:411-575).
-
-        cat / phot_flux: catalog dict and Poisson-realised fluxes; make_objects(cat, phot) builds the
-        OBJECT_DTYPE rows.  truth: optional dict receiving nominal_flux / phot_flux / fft_flux /
-        realized_flux per object (the base[...] side channel, stamp.py:193-196, :304-305, :525, :573)."""
-        torch = renderer.torch
+    def prepare(self, scene, cat, phot_flux, make_objects, fft_sb_thresh=0.0, max_flux_simple=100.0,
+                draw_method="auto", kpsf=None, fwhm_total=0.8, diffraction_fft=None, wavelength=622.2,
+                nrecalc=None, extra_ktables=(), vignetting=None, sky=None):
+        """Host half of the draw loop: which objects exist (SkipThisObject for phot_flux == 0, stamp.py:199-202), FFT /
+        photons / faint for each (stamp.py:275-336), the rows of both kinds.  Nothing here touches the GPU."""
         n_all = len(cat["x"])
         if self.nobjects is not None:
             n_all = min(n_all, int(self.nobjects))
@@ -173,8 +229,10 @@ class LSST_ImageBuilder(LSST_ImageBuilderBase):
         fft_rows = is_fft[keep]
         faint = nominal[keep] < max_flux_simple
         objects["flags"] = np.where(faint, objects["flags"] | IMS_OBJ_FAINT, objects["flags"] & ~IMS_OBJ_FAINT)
-        realized = torch.zeros(len(objects), dtype=torch.float64, device=renderer.device)
         fft_flux = np.zeros(len(objects))
+        job = CcdJob(objects=objects[np.flatnonzero(~fft_rows)], nrecalc=nrecalc, kpsf=kpsf, extra_ktables=tuple(extra_ktables),
+                     diffraction_fft=diffraction_fft, wavelength=wavelength, sky=sky, phot_index=np.flatnonzero(~fft_rows),
+                     n_kept=len(objects))
         if fft_rows.any():
             if kpsf is None:
                 raise GalSimConfigError("FFT drawing needs the k-space PSF description")
@@ -183,31 +241,44 @@ class LSST_ImageBuilder(LSST_ImageBuilderBase):
             if vignetting is not None:
                 # FFT-drawn objects do not pass the ray trace: the empirical vignetting function scales their flux
                 # (get_fft_psf_maybe, imsim/psf_utils.py:220-233); base['fft_flux'] carries the scaled value
-                sc = renderer.scene
-                fflux = fflux * vignetting.at_pixel(self.det_name, fobj["x0"], fobj["y0"], sc.nx, sc.ny)
-            tables_needed = fft_draw.profile_ktable_ids(renderer.scene, fobj["prof_table"], len(extra_ktables))
-            rows, order = fft_draw.build_fft_objects(fobj, fflux, tables_needed)
-            drawer = fft_draw.FftDrawer(renderer, kpsf, add_noise=True, diffraction_fft=diffraction_fft, wavelength=wavelength,
-                                        extra_ktables=extra_ktables)
-            r_fft = torch.zeros(len(rows), dtype=torch.float64, device=renderer.device)
-            drawer.draw(rows, realized=r_fft)
-            idx = np.flatnonzero(fft_rows)[order]
-            realized.index_add_(0, torch.from_numpy(idx).to(renderer.device), r_fft)
+                fflux = fflux * vignetting.at_pixel(self.det_name, fobj["x0"], fobj["y0"], scene.nx, scene.ny)
+            tables_needed = fft_draw.profile_ktable_ids(scene, fobj["prof_table"], len(extra_ktables))
+            job.fft_rows, order = fft_draw.build_fft_objects(fobj, fflux, tables_needed)
+            job.fft_index = np.flatnonzero(fft_rows)[order]
             fft_flux[np.flatnonzero(fft_rows)] = fflux
-        pobj_idx = np.flatnonzero(~fft_rows)
-        if len(pobj_idx):
-            r_ph = torch.zeros(len(pobj_idx), dtype=torch.float64, device=renderer.device)
-            renderer.render_lsst_image(objects[pobj_idx], nrecalc=nrecalc, realized=r_ph)
-            realized.index_add_(0, torch.from_numpy(pobj_idx).to(renderer.device), r_ph)
+        job.host = dict(sel=sel, keep=keep, sub=sub, nominal=nominal, phot=phot, fft_rows=fft_rows, faint=faint, fft_flux=fft_flux)
+        return job
+
+    def build_image(self, renderer, cat, phot_flux, make_objects, fft_sb_thresh=0.0, max_flux_simple=100.0,
+                    draw_method="auto", kpsf=None, fwhm_total=0.8, diffraction_fft=None, wavelength=622.2,
+                    nrecalc=None, truth=None, extra_ktables=(), vignetting=None):
+        """The draw loop (imsim/lsst_image.py:342-368 + imsim/stamp.py:411-575).
+
+        cat / phot_flux: catalog dict and Poisson-realised fluxes; make_objects(cat, phot) builds the
+        OBJECT_DTYPE rows.  truth: optional dict receiving nominal_flux / phot_flux / fft_flux /
+        realized_flux per object (the base[...] side channel, stamp.py:193-196, :304-305, :525, :573)."""
+        job = self.prepare(renderer.scene, cat, phot_flux, make_objects, fft_sb_thresh=fft_sb_thresh, max_flux_simple=max_flux_simple,
+                           draw_method=draw_method, kpsf=kpsf, fwhm_total=fwhm_total, diffraction_fft=diffraction_fft,
+                           wavelength=wavelength, nrecalc=nrecalc, extra_ktables=extra_ktables, vignetting=vignetting)
+        realized = renderer.torch.zeros(job.n_kept, dtype=renderer.torch.float64, device=renderer.device)
+        draw_job(renderer, job, realized=realized)
         if truth is not None:
-            truth["index"] = sel[keep]
-            truth["x"], truth["y"] = sub["x"][keep], sub["y"][keep]
-            truth["nominal_flux"] = nominal[keep]
-            truth["phot_flux"] = np.where(fft_rows, 0.0, phot[keep])           # stamp.py:305
-            truth["fft_flux"] = fft_flux
-            truth["realized_flux"] = realized.cpu().numpy()
-            truth["mode"] = np.where(fft_rows, "fft", np.where(faint, "faint", "phot"))
+            fill_truth(truth, job, realized.cpu().numpy())
         return renderer.image
+
+
+def fill_truth(truth, job, realized):
+    """the base[...] side channel of one CCD (stamp.py:193-196, :304-305, :525, :573) from a drawn job"""
+    h = job.host
+    keep, fft_rows = h["keep"], h["fft_rows"]
+    truth["index"] = h["sel"][keep]
+    truth["x"], truth["y"] = h["sub"]["x"][keep], h["sub"]["y"][keep]
+    truth["nominal_flux"] = h["nominal"][keep]
+    truth["phot_flux"] = np.where(fft_rows, 0.0, h["phot"][keep])           # stamp.py:305
+    truth["fft_flux"] = h["fft_flux"]
+    truth["realized_flux"] = realized
+    truth["mode"] = np.where(fft_rows, "fft", np.where(h["faint"], "faint", "phot"))
+    return truth
 
 
 class LSST_PhotonPoolingImageBuilder(LSST_ImageBuilderBase):

@@ -152,6 +152,12 @@ double orc_spike_stencil(const ims_spikes_t* k, int a, int b)
     double xr = k->cos0 * x + k->sin0 * y;
     double yr = -k->sin0 * x + k->cos0 * y;
     double m = fabs(xr) < fabs(yr) ? fabs(xr) : fabs(yr);
+    /* exact zeros of the stencil (further than a pixel from both arms and outside the swept wedge, whose points lie within
+       r sin(d_alpha / 2) of an arm) return before the arctangents: the same +0.0 the full expression gives */
+    if (m > 1.0) {
+        double t = m - 1.0e-6, lim = 0.5 * fabs(k->d_alpha) + 1.0e-6;
+        if (t * t > lim * lim * (x * x + y * y)) return 0.0;
+    }
     double val = 1.0 - m;
     if (val < 0.0) val = 0.0;
     double dth = orc_atan2(y, x) - k->a_lo;

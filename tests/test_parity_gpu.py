@@ -773,6 +773,26 @@ def test_config_phot_full_chain_and_pooling_agree(torch_cuda):
     assert abs(sa / sb - 1) < 0.02
 
 
+def test_config_several_ccds_take_the_overlapped_focal_plane_path(torch_cuda, monkeypatch, tmp_path):
+    """`output.nfiles: 3` through config.Process: the CCDs are prepared on the host while the previous ones run
+    (focal_plane.render_focal_plane, the fan-out of imsim/ccd.py:72-89), with FFT-drawn objects, sky noise and an e-image file
+    per CCD -- and give the images, truth records and files of rendering them one after the other (IMS_PROCESS_FOCAL=0)."""
+    over = {"image.nobjects": 40, "output.nfiles": 3, "stamp.fft_sb_thresh": 2.0e3, "image.sky_level": 800.0,
+            "image.noise": {"type": "CCD"}, "output.dir": str(tmp_path), "output.file_name": "eimage_$det_name.fits"}
+    a = _process(**over)
+    monkeypatch.setenv("IMS_PROCESS_FOCAL", "0")
+    b = _process(**dict(over, **{"output.dir": str(tmp_path / "serial")}))
+    assert a.det_names == b.det_names and len(a.images) == 3 and len(set(a.det_names)) == 3
+    assert len(a.files) == 3 and len(set(a.files)) == 3
+    for k in range(3):
+        assert_bits_equal(a.images[k], b.images[k], f"CCD {a.det_names[k]}")
+        for key in ("index", "nominal_flux", "phot_flux", "fft_flux", "realized_flux"):
+            assert_bits_equal(np.asarray(a.truth[k][key]), np.asarray(b.truth[k][key]), f"truth {key} of CCD {a.det_names[k]}")
+        assert list(a.truth[k]["mode"]) == list(b.truth[k]["mode"])
+    assert any("fft" in list(t["mode"]) for t in a.truth)
+    assert not np.array_equal(a.images[0], a.images[1])
+
+
 # ---------------------------------------------------------------------------------------------
 # LSST_Flat (imsim/flat.py, area branch)
 # ---------------------------------------------------------------------------------------------
@@ -1205,6 +1225,96 @@ def test_focal_plane_ccds_on_streams(torch_cuda):
     assert out == {} and sorted(seen) == sorted(specs)
     for det in specs:
         assert_bits_equal(seen[det], images[det], f"CCD {det} through the sink")
+
+
+def _c5_test_visit(n=384, n_ccd=4, per=150):
+    """Four CCDs of a visit at test size, each holding FFT-drawn, photon-shot and faint objects: the bench's C5 catalog with
+    its bright tail set by hand (a star and a compact galaxy above fft_sb_thresh, a star of 1.5e6 e- below it)."""
+    import math
+    from imsim_amd import configs, catalog
+    from imsim_amd.diffraction_fft import DiffractionFFT
+    scene = configs.scene_c3(nx=n, ny=n)
+    scene.sensor.scratch_cells = 3_000_000
+    cat = configs._c5_catalog(n_ccd * per, scene, n_ccd=n_ccd)
+    for det in range(n_ccd):
+        a = int(cat.ccd_offsets[det])
+        cat["nominal_flux"][a:a + 3] = [2.0e7 + 1.0e6 * det, 1.5e6, 4.0e7]
+        cat["kind"][a:a + 3] = [0, 0, 1]
+        cat["hlr"][a + 2] = 0.1
+        cat["x"][a:a + 3] = [0.3 * n, 0.7 * n, 0.55 * n]
+        cat["y"][a:a + 3] = [0.35 * n + 3.0 * det, 0.3 * n, 0.75 * n]
+    cat["sb_flux"] = cat["nominal_flux"] / 80.0
+    phot = catalog.realize_fluxes(cat["nominal_flux"], scene.seed)
+    objects, _ = configs._c5_objects(cat, phot, scene)
+    visit = dict(configs.c5_visit_fft())
+    visit["diffraction_fft"] = DiffractionFFT(exptime=30.0, azimuth=math.radians(114.39), altitude=math.radians(53.16),
+                                              rotTelPos=math.radians(40.04), spike_length_cutoff=150)
+    return scene, cat, phot, objects, visit
+
+
+def test_focal_plane_ccds_hold_fft_photon_and_faint_objects(torch_cuda):
+    """BASELINE config C5 as written: every CCD of the focal plane is the reference's per-CCD build (imsim/lsst_image.py:276-395,
+    FFT branch imsim/stamp.py:482-525, fan-out imsim/ccd.py:72-89) -- FFT-drawn objects with the spike stencil first, then the
+    photon-shot ones (a 1.5e6-photon star through 150 brighter-fatter rounds among them), faint ones without sensor -- with
+    three CCDs in flight on the device's streams.  Every CCD equals its stand-alone build bit for bit; one of them equals the
+    oracle's build bit for bit once the oracle is handed the GPU's inverse transforms (rocFFT and numpy agree to ~1e-11 of the
+    peak, which can move a Poisson deviate), and within the FFT tolerance when it runs its own."""
+    import copy
+    from imsim_amd import focal_plane, configs, lsst_image
+    from imsim_amd.config import ccd_seed
+    from imsim_amd.engine import Renderer
+    from imsim_amd._abi import IMS_OBJ_FAINT
+    from oracle import orc_loader
+    scene, cat, phot, objects, visit = _c5_test_visit()
+    offs, coffs = objects.ccd_offsets, objects.cat_offsets
+    dets = list(range(len(offs) - 1))
+
+    def job_of(det):
+        sub = {k: v[coffs[det]:coffs[det + 1]] for k, v in cat.items() if isinstance(v, np.ndarray)}
+        return configs.c5_job(scene, sub, phot[coffs[det]:coffs[det + 1]], np.asarray(objects[offs[det]:offs[det + 1]]), visit=visit)
+
+    def build(det):
+        sc = copy.copy(scene)
+        sc.seed = ccd_seed(scene.seed, det)
+        return sc, job_of(det)
+
+    for det in dets:
+        j = job_of(det)
+        assert j.n_fft == 2 and (j.objects["n_phot"] > 1_000_000).sum() == 1 and (j.objects["flags"] & IMS_OBJ_FAINT).any()
+    transforms = {}
+    images = focal_plane.render_focal_plane(dets, build, concurrent=3,
+                                            post=lambda det, r: transforms.__setitem__(det, r._keep_fft._last[1].cpu().numpy()))
+    assert sorted(images) == dets
+    for det in dets:
+        sc, job = build(det)
+        r = Renderer(sc)
+        lsst_image.draw_job(r, job)
+        r.synchronize()
+        assert_bits_equal(images[det], r.image_numpy(), f"CCD {det} in flight vs stand-alone")
+        del r
+    det = 2
+    sc, job = build(det)
+    for own_transform in (False, True):
+        orc = orc_loader.OracleScene(sc)
+        o = orc_loader.OracleFft(sc, job.kpsf, add_noise=True, diffraction_fft=job.diffraction_fft, wavelength=job.wavelength)
+        rbuf = o.inverse(job.fft_rows, o.fill(job.fft_rows)) if own_transform else transforms[det]
+        o.finish(job.fft_rows, o.spikes(job.fft_rows, rbuf))
+        orc.image64 += o.image
+        orc.render_lsst_image(job.objects, nrecalc=job.nrecalc)
+        if not own_transform:
+            assert_bits_equal(images[det], orc.image, f"CCD {det} vs oracle (GPU transforms)")
+        else:
+            diff = np.count_nonzero(images[det] != orc.image)
+            assert diff <= 1e-4 * np.count_nonzero(orc.image) + 2, diff
+            assert abs(float(images[det].sum(dtype=np.float64)) / float(orc.image.sum(dtype=np.float64)) - 1.0) < 1e-6
+    # the FFT-drawn star left its spikes: light far from the core along the rotated cross that photon-only CCDs do not have
+    assert images[det].sum(dtype=np.float64) > 4.0e7
+    # the rank split deals every CCD to exactly one rank, same images
+    parts = [focal_plane.render_focal_plane(dets, build, rank=k, world=2, concurrent=2) for k in range(2)]
+    assert sorted(list(parts[0]) + list(parts[1])) == dets
+    for p in parts:
+        for d, img in p.items():
+            assert_bits_equal(img, images[d], f"CCD {d} rank split")
 
 
 # ---------------------------------------------------------------------------------------------

@@ -224,8 +224,23 @@ class Readout(C.Structure):
                 ("xtalk", C.c_float * (IMS_MAX_AMPS * IMS_MAX_AMPS))]
 
 
+class PlanInput(C.Structure):
+    """ims_plan_input_t: what the native LSST_Image planner reads of a catalog (host arrays)"""
+    _fields_ = [("n", c_i64), ("row", c_vp), ("n_phot", c_vp), ("stamp", c_vp), ("faint", c_vp), ("nrecalc", c_i32),
+                ("n_class_rounds", c_i32), ("class_rounds", c_i32 * 4), ("n_static_slots", c_i32), ("slot_capacity", c_i32),
+                ("static_cells", c_i64), ("scratch_cells", c_i64), ("max_pool_photons", c_i64), ("seg_size", c_i32),
+                ("want_realized", c_i32), ("event_base", c_i32), ("use_tags", c_i32)]
+
+
+class PlanSizes(C.Structure):
+    _fields_ = [("arena_bytes", c_i64), ("rows_bytes", c_i64), ("pool_photons", c_i64), ("realized_count", c_i64),
+                ("n_groups", c_i32), ("n_events", c_i32), ("n_render_launches", c_i64), ("render_photons", c_i64),
+                ("render_rows", c_i64), ("render_segments", c_i64), ("n_shoot_launches", c_i64), ("shoot_photons", c_i64),
+                ("shoot_rows", c_i64), ("shoot_segments", c_i64), ("chain_rows", c_i64), ("n_objects", c_i64)]
+
+
 STRUCTS = [Object, RadialTables, LinTables, PsfComponent, Op, Surface, TanSip, Optics, BfSlot, Sensor, Photons,
-           RenderParams, PlanItem, Atmosphere, FftObject, FftParams, Readout, Chain, Catalog, ObjectMeta]
+           RenderParams, PlanItem, Atmosphere, FftObject, FftParams, Readout, Chain, Catalog, ObjectMeta, PlanInput, PlanSizes]
 
 # every symbol include/imsim_hip.h declares
 EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_info", "ims_known_optics_layout", "ims_shoot_accumulate",
@@ -234,6 +249,7 @@ EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_
            "ims_sensor_update_distortions", "ims_sensor_update_refresh", "ims_sensor_publish_pairs", "ims_image_add", "ims_image_to_float", "ims_fill_derived_op", "ims_fill_derived_medium", "ims_fill_derived_optics", "ims_fill_derived_atmosphere", "ims_fill_derived_sensor", "ims_sensor_pixel_areas", "ims_flat_add", "ims_last_kernel_ms", "ims_enable_timing",
            "ims_readout_bleed", "ims_readout_segments", "ims_readout_cte", "ims_readout_finish",
            "ims_build_object_table", "ims_patch_stamp_sizes", "ims_gather_rows", "ims_parse_instcat_objects", "ims_screen_prepass",
+           "ims_plan_lsst_image", "ims_plan_bind", "ims_plan_upload", "ims_plan_run", "ims_plan_add_realized", "ims_plan_destroy",
            "ims_struct_size", "ims_test_math"]
 
 _LIB_PATH = os.environ.get("IMSIM_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libimsim_hip.so")
@@ -305,6 +321,12 @@ def load():
     lib.ims_readout_cte.argtypes = [c_vp, c_vp, C.POINTER(Readout), c_vp, c_i32, c_i32, c_vp]
     lib.ims_readout_finish.argtypes = [c_vp, C.POINTER(Readout), c_u64, c_vp, c_vp]
     lib.ims_test_math.argtypes = [C.c_int, c_vp, c_vp, c_i64, c_u64, c_i64, C.c_uint32, c_vp]
+    lib.ims_plan_lsst_image.argtypes = [C.POINTER(PlanInput), C.POINTER(c_vp), C.POINTER(PlanSizes)]
+    lib.ims_plan_bind.argtypes = [c_vp, C.POINTER(RenderParams), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]
+    lib.ims_plan_upload.argtypes = [c_vp, c_vp]
+    lib.ims_plan_run.argtypes = [c_vp, c_vp, C.POINTER(Sensor), c_vp, c_vp, c_vp, C.POINTER(c_vp), c_i32, c_i32]
+    lib.ims_plan_add_realized.argtypes = [c_vp, c_vp, c_vp]
+    lib.ims_plan_destroy.argtypes = [c_vp]
     _lib = lib
     return lib
 

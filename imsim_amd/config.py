@@ -676,7 +676,7 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
         ctx = types.SimpleNamespace(det=det, det_name=det_name, scene=scene, builder=builder, truth=truth, seed_ccd=seed_ccd,
                                     nx=nx, ny=ny, job=None, pooling=None)
         if itype == "LSST_PhotonPoolingImage":
-            ctx.pooling = dict(cat=cat, phot=phot, make_objects=make_objects, max_flux_simple=max_simple, seed=seed_ccd, truth=truth,
+            ctx.pooling = dict(cat=cat, phot_flux=phot, make_objects=make_objects, max_flux_simple=max_simple, seed=seed_ccd, truth=truth,
                                fft_sb_thresh=float(ev.value(stamp_cfg.get("fft_sb_thresh", 0.0))), kpsf=kpsf, fwhm_total=fwhm_total,
                                diffraction_fft=dfft, wavelength=wl_eff, extra_ktables=extra_ktables, vignetting=vig, checkpoint=chk)
         else:

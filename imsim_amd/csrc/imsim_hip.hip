@@ -2576,6 +2576,199 @@ int ims_run_plan(const ims_plan_item_t* items, int64_t n_items, const ims_sensor
     return IMS_OK;
 }
 
+// ---- LSST_Image launch planner (csrc/ims_plan.h builds the plan; here: binding to memory, upload, run) ----
+}  // extern "C"
+#include "ims_plan.h"
+
+__global__ __launch_bounds__(256) void k_scatter_add(const int64_t* __restrict__ where, const double* __restrict__ src,
+                                                     double* __restrict__ dst, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && src[i] != 0.0) unsafeAtomicAdd(dst + where[i], src[i]);
+}
+
+extern "C" {
+
+int ims_plan_lsst_image(const ims_plan_input_t* in, void** plan_out, ims_plan_sizes_t* sizes)
+{
+    if (!in || !plan_out || !sizes) return set_err(IMS_ERR_ARG, "NULL argument");
+    ims_planner::Plan* pl = new ims_planner::Plan();
+    pl->in = *in;
+    const int rc = ims_planner::build(*pl);
+    if (rc) { delete pl; return rc; }
+    // the plan keeps nothing of the caller's arrays
+    pl->in.row = nullptr; pl->in.n_phot = nullptr; pl->in.stamp = nullptr; pl->in.faint = nullptr;
+    *sizes = pl->sizes;
+    *plan_out = pl;
+    return IMS_OK;
+}
+
+int ims_plan_destroy(void* plan)
+{
+    ims_planner::Plan* pl = (ims_planner::Plan*)plan;
+    if (!pl) return IMS_OK;
+    for (hipEvent_t e : pl->events) (void)hipEventDestroy(e);
+    delete pl;
+    return IMS_OK;
+}
+
+int ims_plan_bind(void* plan, const ims_render_params_t* base, void* arena_host, void* arena_dev, void* rows_dev,
+                  const ims_object_t* master_dev, double* pool_dev, double* realized_dev)
+{
+    using namespace ims_planner;
+    Plan* pl = (Plan*)plan;
+    if (!pl || !base || !arena_host || !arena_dev || !rows_dev || !master_dev) return set_err(IMS_ERR_ARG, "NULL argument");
+    if (pl->sizes.pool_photons > 0 && !pool_dev) return set_err(IMS_ERR_ARG, "pool_dev is NULL");
+    if (pl->sizes.realized_count > 0 && !realized_dev) return set_err(IMS_ERR_ARG, "realized_dev is NULL");
+    pl->arena_host = (uint8_t*)arena_host; pl->arena_dev = (uint8_t*)arena_dev; pl->rows_dev = (uint8_t*)rows_dev;
+    pl->master_dev = master_dev; pl->pool_dev = pool_dev; pl->realized_dev = realized_dev;
+    std::memcpy(pl->arena_host, pl->arena.data(), pl->arena.size());
+    auto dev = [&](int64_t off) { return off < 0 ? (uint8_t*)nullptr : pl->arena_dev + off; };
+    for (Launch& L : pl->launches) {
+        L.P = *base;
+        L.P.objects = (const ims_object_t*)(pl->rows_dev + L.rows_off);
+        L.P.n_objects = L.n;
+        L.P.seg_prefix = (const int64_t*)dev(L.off_prefix);
+        L.P.n_segments = L.n_segments;
+        L.P.seg_object = (const int32_t*)dev(L.off_segobj);
+        L.P.realized_flux = (L.realized_off >= 0) ? pl->realized_dev + L.realized_off : nullptr;
+        L.P.bf_tag = 0; L.P.bf_slot_shift = 0;
+    }
+    for (Group& g : pl->groups) {
+        std::memset(&g.pool, 0, sizeof(g.pool));
+        g.pool.n = g.pool_photons;
+        g.pool.converted = 1;
+        const int64_t np = pl->sizes.pool_photons;
+        g.pool.x = pool_dev; g.pool.y = pool_dev ? pool_dev + np : nullptr;
+        g.pool.flux = pool_dev ? pool_dev + 2 * np : nullptr; g.pool.dxdz = pool_dev ? pool_dev + 3 * np : nullptr;
+        g.chain_structs.assign(g.chains.size(), ims_chain_t());
+        for (size_t c = 0; c < g.chains.size(); ++c) {
+            const ChainDesc& ch = g.chains[c];
+            ims_chain_t& cs = g.chain_structs[c];
+            std::memset(&cs, 0, sizeof(cs));
+            const Launch& L = pl->launches[ch.launch];
+            cs.params = &L.P; cs.pool = &g.pool;
+            cs.pool_start = (const int64_t*)dev(L.off_pool);
+            cs.n_phot = ch.n_phot.data();
+            cs.tile_prefix = (const int64_t*)dev(ch.off_tile_prefix);
+            cs.tile_prefix_host = ch.tile_prefix_host.data();
+            cs.n_objects = (int32_t)ch.n_phot.size(); cs.first_slot = ch.first_slot; cs.stream = ch.stream; cs.nrecalc = pl->in.nrecalc;
+            cs.n_rounds = ch.n_rounds; cs.use_tags = pl->in.use_tags; cs.ev_base = ch.ev_base; cs.n_edges = (int32_t)ch.edges.size();
+            for (size_t k = 0; k < ch.edges.size(); ++k) cs.edges[k] = ch.edges[k];
+        }
+        g.items.assign(g.steps.size(), ims_plan_item_t());
+        for (size_t k = 0; k < g.steps.size(); ++k) {
+            const Step& s = g.steps[k];
+            ims_plan_item_t& it = g.items[k];
+            std::memset(&it, 0, sizeof(it));
+            it.kind = s.kind; it.stream = s.stream;
+            switch (s.kind) {
+            case IMS_PLAN_RENDER: it.params = &pl->launches[s.launch].P; break;
+            case IMS_PLAN_SHOOT_POOL:
+                it.params = &pl->launches[s.launch].P; it.pool = &g.pool; it.aux = (const int64_t*)dev(pl->launches[s.launch].off_pool); break;
+            case IMS_PLAN_INIT:
+                it.first_slot = s.first_slot; it.n_slots = s.n_slots; it.aux = (const int64_t*)dev(s.off_tile_prefix); it.n_tiles = s.n_tiles; break;
+            case IMS_PLAN_RECORD: it.n_slots = s.event; break;
+            case IMS_PLAN_ROUNDS: it.n_slots = s.n_chains; it.aux2 = g.chain_structs.data() + s.chain_begin; break;
+            default: return set_err(IMS_ERR_ARG, "planner: unexpected step kind");
+            }
+        }
+    }
+    pl->bound = true; pl->uploaded = false;
+    return IMS_OK;
+}
+
+int ims_plan_upload(void* plan, void* stream)
+{
+    using namespace ims_planner;
+    Plan* pl = (Plan*)plan;
+    if (!pl || !pl->bound) return set_err(IMS_ERR_ARG, "plan is NULL or not bound");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(pl->arena_dev, pl->arena_host, pl->arena.size(), hipMemcpyHostToDevice, st));
+    for (const Launch& L : pl->launches) {
+        if (L.n <= 0) continue;
+        const int rc = ims_gather_rows(pl->master_dev, (const int64_t*)(pl->arena_dev + L.off_index), (const int64_t*)(pl->arena_dev + L.off_first),
+                                       (const int64_t*)(pl->arena_dev + L.off_count), (const int32_t*)(pl->arena_dev + L.off_bf), 0,
+                                       (ims_object_t*)(pl->rows_dev + L.rows_off), L.n, stream);
+        if (rc) return rc;
+    }
+    pl->uploaded = true;
+    return IMS_OK;
+}
+
+int ims_plan_run(void* plan, ims_sensor_t* sensor_dev, ims_sensor_t* sensor_host, ims_bf_slot_t* slots_dev, unsigned char* changed_dev,
+                 void* main_stream, void* const* streams, int32_t n_streams, int32_t own_work_queued)
+{
+    using namespace ims_planner;
+    Plan* pl = (Plan*)plan;
+    if (!pl || !pl->uploaded) return set_err(IMS_ERR_ARG, "plan is NULL or not uploaded");
+    if (!streams || n_streams < 5) return set_err(IMS_ERR_ARG, "streams: five plan streams by role are required");
+    bool any_slots = false;
+    for (const Group& g : pl->groups) any_slots = any_slots || g.n_slots > 0;
+    if (any_slots && (!sensor_dev || !sensor_host || !slots_dev || !changed_dev || !sensor_host->bf_slots))
+        return set_err(IMS_ERR_ARG, "sensor / slot table / changed is NULL");
+    // distinct streams
+    std::vector<hipStream_t> uniq;
+    for (int k = 0; k < n_streams; ++k)
+        if (std::find(uniq.begin(), uniq.end(), (hipStream_t)streams[k]) == uniq.end()) uniq.push_back((hipStream_t)streams[k]);
+    const size_t need = 2 + 2 * uniq.size();
+    while (pl->events.size() < need) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        pl->events.push_back(e);
+    }
+    hipStream_t main = (hipStream_t)main_stream, chain = (hipStream_t)streams[ROLE_CHAIN];
+    if (pl->realized_dev && pl->sizes.realized_count > 0)
+        HIP_TRY(hipMemsetAsync(pl->realized_dev, 0, (size_t)pl->sizes.realized_count * sizeof(double), main));
+    HIP_TRY(hipEventRecord(pl->events[0], main));
+    for (hipStream_t s : uniq) HIP_TRY(hipStreamWaitEvent(s, pl->events[0], 0));
+    bool queued = own_work_queued != 0;
+    for (size_t gi = 0; gi < pl->groups.size(); ++gi) {
+        Group& g = pl->groups[gi];
+        if (g.n_slots > 0) {
+            const int n0 = pl->in.n_static_slots;
+            if (n0 + g.n_slots > pl->in.slot_capacity) return set_err(IMS_ERR_ARG, "too many brighter-fatter slots");
+            // The slot table is rewritten by a copy on the chain stream: behind everything this renderer has queued on every
+            // stream (a later group's table must not change under the launches of the one before) and ahead of what follows
+            if (queued)
+                for (size_t k = 0; k < uniq.size(); ++k)
+                    if (uniq[k] != chain) {
+                        HIP_TRY(hipEventRecord(pl->events[2 + k], uniq[k]));
+                        HIP_TRY(hipStreamWaitEvent(chain, pl->events[2 + k], 0));
+                    }
+            HIP_TRY(hipMemcpyAsync(slots_dev + n0, pl->arena_host + g.off_slots, (size_t)g.n_slots * sizeof(ims_bf_slot_t),
+                                   hipMemcpyHostToDevice, chain));
+            HIP_TRY(hipMemcpyAsync(&sensor_dev->n_bf_slots, pl->arena_host + pl->off_nslots[gi], sizeof(int32_t), hipMemcpyHostToDevice, chain));
+            HIP_TRY(hipEventRecord(pl->events[1], chain));
+            for (hipStream_t s : uniq) if (s != chain) HIP_TRY(hipStreamWaitEvent(s, pl->events[1], 0));
+            std::memcpy((ims_bf_slot_t*)(uintptr_t)sensor_host->bf_slots + n0, pl->arena_host + g.off_slots, (size_t)g.n_slots * sizeof(ims_bf_slot_t));
+            sensor_host->n_bf_slots = n0 + g.n_slots;
+        }
+        const int rc = ims_run_plan(g.items.data(), (int64_t)g.items.size(), sensor_dev, sensor_host, changed_dev, streams, n_streams);
+        if (rc) return rc;
+        queued = true;
+    }
+    for (size_t k = 0; k < uniq.size(); ++k) {
+        HIP_TRY(hipEventRecord(pl->events[2 + uniq.size() + k], uniq[k]));
+        HIP_TRY(hipStreamWaitEvent(main, pl->events[2 + uniq.size() + k], 0));
+    }
+    return IMS_OK;
+}
+
+int ims_plan_add_realized(void* plan, double* out_dev, void* stream)
+{
+    using namespace ims_planner;
+    Plan* pl = (Plan*)plan;
+    if (!pl || !pl->uploaded) return set_err(IMS_ERR_ARG, "plan is NULL or not uploaded");
+    const int64_t n = pl->sizes.realized_count;
+    if (n <= 0) return IMS_OK;
+    if (!out_dev) return set_err(IMS_ERR_ARG, "out_dev is NULL");
+    hipLaunchKernelGGL(k_scatter_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const int64_t*)(pl->arena_dev + pl->off_realized_where), (const double*)pl->realized_dev, out_dev, n);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
 int ims_fft_kspace_fill(const ims_fft_params_t* params, const ims_fft_object_t* objects_dev, int64_t n_objects,
                         const int64_t* elem_prefix_dev, int64_t n_elems, double* kbuf, void* stream)
 {
@@ -3054,6 +3247,8 @@ int ims_struct_size(int which)
     case 17: return (int)sizeof(ims_chain_t);
     case 18: return (int)sizeof(ims_catalog_t);
     case 19: return (int)sizeof(ims_object_meta_t);
+    case 20: return (int)sizeof(ims_plan_input_t);
+    case 21: return (int)sizeof(ims_plan_sizes_t);
     }
     return -1;
 }

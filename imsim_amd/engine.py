@@ -10,6 +10,7 @@ import os
 import dataclasses
 import itertools
 import threading
+import weakref
 from typing import List, Optional
 
 import numpy as np
@@ -710,6 +711,121 @@ def _focal_streams(torch, device, peek=False, top_index=None):
     return (top, st["bulk"], st["mid"], st["mid"], st["mid"])
 
 
+_PINNED_ARENAS = []            # (page-locked tensor, events after the last run that copies out of it)
+
+
+def _pinned_arena(torch, nbytes):
+    """A page-locked buffer of at least nbytes out of a process-wide pool (allocating one costs milliseconds); buffers come
+    back through NativePlan.__del__ behind the events of the streams that may still copy out of them."""
+    for k, (t, ev) in enumerate(_PINNED_ARENAS):
+        if t.numel() >= nbytes and ev.query():
+            return _PINNED_ARENAS.pop(k)[0]
+    return torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, pin_memory=True)
+
+
+class NativePlan:
+    """The launch plan of one LSST_Image render, built (ims_plan_lsst_image), bound to memory (ims_plan_bind), uploaded
+    (ims_plan_upload) and run (ims_plan_run) by the library.  torch provides the memory: a page-locked arena and its device copy,
+    the gathered launch tables, the converted photon pool of the bright objects.  `objects`: an OBJECT_DTYPE host table (uploaded
+    once as the master table) or a device_table.DeviceTable."""
+
+    def __init__(self, renderer, objects, nrecalc=None, want_realized=False):
+        r = renderer
+        self._renderer = weakref.ref(renderer)     # the renderer keeps its last plan: no cycle (its HBM must go when it is dropped)
+        self._lib, self._torch, self._device, self._streams = r.lib, r.torch, r.device, tuple(r.plan_streams)
+        t = r.torch
+        ss = r.scene.sensor
+        lib = r.lib
+        if hasattr(objects, "rows") and hasattr(objects, "n_phot") and not isinstance(objects, np.ndarray):
+            self.master = objects.rows                        # DeviceTable: the rows are on the device already
+            n_phot = np.ascontiguousarray(objects.n_phot, dtype=np.int64)
+            stamp = np.ascontiguousarray(objects.stamp, dtype=np.int32)
+            faint = np.ascontiguousarray(objects.faint, dtype=np.uint8)
+            self._keep_table = objects
+        else:
+            objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
+            self.master = t.from_numpy(objects.view(np.uint8).reshape(-1)).to(r.device) if len(objects) else \
+                t.zeros(OBJECT_DTYPE.itemsize, dtype=t.uint8, device=r.device)
+            n_phot = np.ascontiguousarray(objects["n_phot"], dtype=np.int64)
+            stamp = np.stack([objects["stamp_xmin"], objects["stamp_xmax"], objects["stamp_ymin"], objects["stamp_ymax"]],
+                             axis=1).astype(np.int32) if len(objects) else np.zeros((0, 4), dtype=np.int32)
+            faint = ((objects["flags"] & _abi.IMS_OBJ_FAINT) != 0).astype(np.uint8)
+        self.n_master = len(n_phot)
+        inp = _abi.PlanInput()
+        inp.n = len(n_phot)
+        inp.n_phot, inp.stamp, inp.faint = n_phot.ctypes.data, stamp.ctypes.data, faint.ctypes.data
+        b = r.bound
+        if ss is not None:
+            inp.nrecalc = int(ss.model.nrecalc if nrecalc is None else nrecalc)
+            inp.n_static_slots, inp.slot_capacity = b.n_static_slots, b.slot_capacity
+            inp.static_cells, inp.scratch_cells = b.static_cells, int(ss.scratch_cells)
+        thresholds = list(r.chain_class_rounds)[:3]
+        inp.n_class_rounds = len(thresholds)
+        for k, v in enumerate(thresholds):
+            inp.class_rounds[k] = int(v)
+        inp.max_pool_photons = int(r.max_pool_photons)
+        inp.seg_size, inp.want_realized = int(r.scene.seg_size), 1 if want_realized else 0
+        inp.event_base, inp.use_tags = int(r._event_block), 1 if r.use_bf_tags else 0
+        handle, sizes = C.c_void_p(), _abi.PlanSizes()
+        _abi.check(lib.ims_plan_lsst_image(C.byref(inp), C.byref(handle), C.byref(sizes)), "ims_plan_lsst_image")
+        self.handle, self.sizes = handle, sizes
+        self.arena_pin = _pinned_arena(t, int(sizes.arena_bytes))
+        self.arena_dev = t.empty(int(sizes.arena_bytes), dtype=t.uint8, device=r.device)
+        self.rows = t.empty(int(sizes.rows_bytes), dtype=t.uint8, device=r.device)
+        self.pool = t.empty(max(4 * int(sizes.pool_photons), 1), dtype=t.float64, device=r.device)
+        self.realized = t.empty(max(int(sizes.realized_count), 1), dtype=t.float64, device=r.device) if sizes.realized_count else None
+        self.P = b.params(None, 0, None, 0, r.image.data_ptr(), None, None)
+        _abi.check(lib.ims_plan_bind(handle, C.byref(self.P), self.arena_pin.data_ptr(), self.arena_dev.data_ptr(), self.rows.data_ptr(),
+                                     self.master.data_ptr(), self.pool.data_ptr(),
+                                     self.realized.data_ptr() if self.realized is not None else None), "ims_plan_bind")
+        _abi.check(lib.ims_plan_upload(handle, r._stream()), "ims_plan_upload")
+        if ss is not None and not hasattr(r, "_changed"):
+            cells = b.static_cells + int(ss.scratch_cells)
+            r._changed = t.zeros(max(cells, 1), dtype=t.uint8, device=r.device)
+
+    def run(self):
+        """enqueue the whole render on the renderer's plan streams, joined back into the current stream"""
+        r = self._renderer()
+        if r is None:
+            raise _abi.ImsimHipError("NativePlan.run: the renderer of this plan is gone")
+        b = r.bound
+        streams = r.plan_streams
+        sarr = (C.c_void_p * len(streams))(*[st.cuda_stream for st in streams])
+        has_sensor = r.scene.sensor is not None
+        _abi.check(r.lib.ims_plan_run(self.handle, b.sensor_dev_ptr if has_sensor else None,
+                                      C.byref(b.sensor_host) if has_sensor else None,
+                                      b.sensor_struct.bf_slots if has_sensor else None,
+                                      r._changed.data_ptr() if has_sensor else None, r._stream(), sarr, len(streams),
+                                      1 if r._plans_run else 0), "ims_plan_run")
+        r._plans_run += 1
+        if has_sensor:
+            b.sensor_struct.n_bf_slots = b.sensor_host.n_bf_slots          # the library moved the slot table on
+            if isinstance(b._sensor_buf, Sensor):
+                b._sensor_buf.n_bf_slots = b.sensor_host.n_bf_slots
+
+    def add_realized(self, realized):
+        """realized[master row] += flux every object added to the image (base['realized_flux'], stamp.py:573)"""
+        st = C.c_void_p(self._torch.cuda.current_stream(self._device).cuda_stream)
+        _abi.check(self._lib.ims_plan_add_realized(self.handle, realized.data_ptr(), st), "ims_plan_add_realized")
+
+    def __del__(self):
+        try:
+            t = self._torch
+            if getattr(self, "arena_pin", None) is not None:
+                evs = []
+                for st in set(list(self._streams) + [t.cuda.current_stream(self._device)]):
+                    ev = t.cuda.Event()
+                    ev.record(st)
+                    evs.append(ev)
+                _PINNED_ARENAS.append((self.arena_pin, _AllEvents(evs)))
+                self.arena_pin = None
+            if getattr(self, "handle", None):
+                self._lib.ims_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 class Renderer:
     """One CCD on one GPU."""
 
@@ -1168,6 +1284,19 @@ class Renderer:
             ev.record(st)
             main.wait_event(ev)
 
+    # -- the native planner (ims_plan_*): plan, bind, upload and run of one LSST_Image render inside the library --
+    def native_plan_ok(self, objects):
+        """The library's planner covers the default path; the options it does not know run the numpy planner: the phase-screen
+        pre-pass, slot pairs, and IMS_NATIVE_PLAN=0 (which keeps the numpy planner as the checker it is in the tests)."""
+        if os.environ.get("IMS_NATIVE_PLAN", "1") == "0" or os.environ.get("IMS_SLOT_PAIRS", "0") != "0":
+            return False
+        if os.environ.get("IMS_SCREEN_PREPASS", "0") != "0" and self.scene.atm is not None:
+            return False
+        return True
+
+    def native_plan(self, objects, nrecalc=None, want_realized=False):
+        return NativePlan(self, objects, nrecalc, want_realized)
+
     def touch_streams(self):
         """Run a trivial operation on every plan stream and wait for it: the streams then hold their hardware queues before
         anything else of the process (an RCCL communicator, say) brings streams of its own into use."""
@@ -1256,6 +1385,13 @@ class Renderer:
         return objects, run
 
     def render_lsst_image(self, objects, nrecalc=None, realized=None):
+        if self.native_plan_ok(objects):
+            plan = self.native_plan(objects, nrecalc, want_realized=realized is not None)
+            plan.run()
+            if realized is not None:
+                plan.add_realized(realized)
+            self._keep_plan = plan
+            return
         objects, prepass = self.screen_prepass(objects, nrecalc)
         try:
             plan, parts = self.plan_lsst_image(objects, nrecalc, want_realized=realized is not None)
@@ -1274,6 +1410,23 @@ class Renderer:
     def prepared_lsst_image(self, objects, nrecalc=None):
         """Upload everything once; returns a callable replaying the whole LSST_Image render (used
         by bench.py: the timed region starts with all inputs resident in HBM)."""
+        if self.native_plan_ok(objects):
+            plan = self.native_plan(objects, nrecalc)
+            z = plan.sizes
+
+            def launch():
+                plan.run()
+            launch.plan = plan
+            launch.prepass = None
+            launch.photons = int(z.render_photons + z.shoot_photons)
+            launch.object_rows = int(z.render_rows + z.shoot_rows + z.chain_rows)
+            launch.pool_photons = int(z.shoot_photons)
+            has_screens = self.scene.atm is not None and any(int(c[0]) == _abi.IMS_PSF_SCREENS for c in self.scene.psf)
+            scr = 96 if has_screens else 0
+            launch.timed = {1: (int(z.n_render_launches), int(z.render_photons * (16 + scr) + z.render_rows * 256)),
+                            2: (int(z.n_shoot_launches), int(z.shoot_photons * (32 + scr) + z.shoot_rows * 256))}
+            launch.timed_waves = {1: 4 * int(z.render_segments), 2: 4 * int(z.shoot_segments)}
+            return launch
         objects, prepass = self.screen_prepass(objects, nrecalc)
         try:
             plan, _ = self.plan_lsst_image(objects, nrecalc)

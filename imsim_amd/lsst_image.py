@@ -186,7 +186,7 @@ def draw_job(renderer, job, realized=None):
         drawer.draw(job.fft_rows, realized=r_fft)
         if realized is not None:
             realized.index_add_(0, torch.from_numpy(np.ascontiguousarray(job.fft_index)).to(renderer.device), r_fft)
-        renderer._keep_fft = drawer
+        renderer._keep_fft = drawer._last + (drawer._keep,)     # the buffers, not the drawer (which refers back to the renderer)
     if len(job.objects):
         r_ph = torch.zeros(len(job.objects), dtype=torch.float64, device=renderer.device) if realized is not None else None
         renderer.render_lsst_image(job.objects, nrecalc=job.nrecalc, realized=r_ph)

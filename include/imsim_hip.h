@@ -48,7 +48,7 @@ extern "C" {
 #define IMS_ERR_NO_DEVICE  -3
 #define IMS_ERR_UNSUPPORTED -4
 
-#define IMS_ABI_VERSION 15
+#define IMS_ABI_VERSION 16
 
 /* Pointers stored INSIDE descriptors that live in device memory (ims_sensor_t, ims_atmosphere_t) always point to global
  * device memory.  Device code is told so (address space 1): a pointer read out of memory is otherwise a generic pointer and
@@ -695,6 +695,58 @@ int  ims_accumulate_round(const ims_render_params_t* params, const ims_photons_t
                           int32_t round, int32_t nrecalc, int32_t n_active, int32_t num_vertices, void* stream);
 int  ims_run_plan(const ims_plan_item_t* items, int64_t n_items, const ims_sensor_t* sensor_dev,
                   const ims_sensor_t* sensor_host, unsigned char* changed_dev, void* const* streams, int32_t n_streams);
+
+/* ---- LSST_Image launch planner (the object loop of LSST_ImageBuilder.buildImage, imsim/lsst_image.py:341-368, over the per-object
+ *      decisions of LSST_SiliconBuilder, imsim/stamp.py:109-249, :527-573) ----
+ * From the 16 bytes per object the device-built table hands back (photon count, stamp bounds, faint flag) the planner derives
+ * everything a CCD's render launches need: which objects trigger pixel-boundary recalculations of their own (n_phot > nrecalc:
+ * a private boundary region each, in groups that fit the scratch capacity), their chain classes by round count, the slices of
+ * rounds in which their photons are shot into the converted pool, pool offsets, segment tables, slot tables, tile prefixes and
+ * the item lists ims_run_plan replays -- what Renderer.plan_lsst_image builds in numpy, in one native pass.  The planner
+ * allocates nothing on the device: ims_plan_lsst_image reports the sizes, the caller provides the memory (ims_plan_bind), one
+ * copy moves the tables (ims_plan_upload, which also gathers the launch tables from the master table), ims_plan_run enqueues
+ * the CCD.  A plan may be run any number of times.
+ *
+ * Objects are the entries with n_phot > 0 of the input arrays, in input order; master row of entry k = row[k] (NULL: k).
+ * Streams by role, as Renderer.STREAMS: 0 top chain, 1 bulk, 2 .. 4 further chain classes. */
+typedef struct ims_plan_input {
+    int64_t n;                           /* entries of the arrays below */
+    const int64_t* row;                  /* [n] index into the master table, or NULL (identity) */
+    const int64_t* n_phot;               /* [n] photons to shoot (0: the object is skipped) */
+    const int32_t* stamp;                /* [n][4] xmin, xmax, ymin, ymax of the stamp (1-based pixel indices, inclusive) */
+    const uint8_t* faint;                /* [n] or NULL: non-zero = faint object (no operators, no sensor: never a chain) */
+    int32_t nrecalc;                     /* photons between recalculations; 0 = no chains (no Silicon sensor) */
+    int32_t n_class_rounds;              /* thresholds that cut the bright objects into chain classes (at most 3) */
+    int32_t class_rounds[4];
+    int32_t n_static_slots, slot_capacity;
+    int64_t static_cells, scratch_cells, max_pool_photons;
+    int32_t seg_size, want_realized, event_base, use_tags;
+} ims_plan_input_t;
+typedef struct ims_plan_sizes {
+    int64_t arena_bytes;                 /* tables of the plan (host image, page-locked by the caller, and its device copy) */
+    int64_t rows_bytes;                  /* launch tables gathered on the device */
+    int64_t pool_photons;                /* converted pool: 4 f64 arrays of this many photons (largest group) */
+    int64_t realized_count;              /* f64 per-launch realized fluxes (want_realized) */
+    int32_t n_groups, n_events;
+    int64_t n_render_launches, render_photons, render_rows, render_segments;
+    int64_t n_shoot_launches, shoot_photons, shoot_rows, shoot_segments;
+    int64_t chain_rows, n_objects;
+} ims_plan_sizes_t;
+int  ims_plan_lsst_image(const ims_plan_input_t* in, void** plan_out, ims_plan_sizes_t* sizes);
+/* base: the scene's launch parameters (tables, PSF, operators, optics, sensor, image, nx .. ymin; objects / seg_* are ignored).
+ * arena_host: page-locked, arena_bytes; must stay untouched while the plan lives (the slot tables are copied out of it at every
+ * run).  pool_dev: 4 * pool_photons doubles.  realized_dev: realized_count doubles or NULL. */
+int  ims_plan_bind(void* plan, const ims_render_params_t* base, void* arena_host, void* arena_dev, void* rows_dev,
+                   const ims_object_t* master_dev, double* pool_dev, double* realized_dev);
+int  ims_plan_upload(void* plan, void* stream);
+/* sensor_host: the caller's host copy of the sensor descriptor, whose bf_slots (host table) and n_bf_slots the run UPDATES as it
+ * goes through the groups; slots_dev: the device slot table sensor_dev->bf_slots points to.  own_work_queued: 0 when nothing of
+ * this renderer is queued on the streams yet (the first slot table then does not wait for the streams' earlier work). */
+int  ims_plan_run(void* plan, ims_sensor_t* sensor_dev, ims_sensor_t* sensor_host, ims_bf_slot_t* slots_dev, unsigned char* changed_dev,
+                  void* main_stream, void* const* streams, int32_t n_streams, int32_t own_work_queued);
+/* out[master row] += realized flux of every object (after ims_plan_run, on the same main stream) */
+int  ims_plan_add_realized(void* plan, double* out_dev, void* stream);
+int  ims_plan_destroy(void* plan);
 
 /* updatePixelDistortions + refresh of the bounds in one launch for regions held as slot pairs (ims_chain_t.pair_shift): reads the
  * slots first_slot + k + src_shift, writes the slots first_slot + k + dst_shift completely (points, bounds, delta = 0).

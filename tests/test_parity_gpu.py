@@ -421,6 +421,44 @@ def test_lsst_image_edge_cases_are_bit_exact(torch_cuda):
     assert r2.image_numpy().sum() == 0
 
 
+@pytest.mark.parametrize("nrecalc,scratch", [(10000, 2_000_000), (1000, 2_000_000), (1000, 90_000)])
+def test_native_planner_renders_the_numpy_planned_image(torch_cuda, monkeypatch, nrecalc, scratch):
+    """ims_plan_lsst_image / _bind / _upload / _run (the launch plan of a CCD built and enqueued by the library, the default)
+    against the numpy planner of engine.Renderer.plan_lsst_image (IMS_NATIVE_PLAN=0, the checker): image, realized fluxes and
+    the pixel-boundary state, bit for bit, on one and on several brighter-fatter groups, twice in a row on the same renderer
+    (a plan is replayed; the second render's slot tables wait for the first one's launches)."""
+    from imsim_amd.engine import Renderer
+    scene, objects = _c3_case(n_obj=300, scratch=scratch)
+    out = []
+    for native in ("1", "0"):
+        monkeypatch.setenv("IMS_NATIVE_PLAN", native)
+        r = Renderer(scene)
+        assert r.native_plan_ok(objects) == (native == "1")
+        real = torch_cuda.zeros(len(objects), dtype=torch_cuda.float64, device="cuda")
+        r.render_lsst_image(objects, nrecalc=nrecalc, realized=real)
+        r.render_lsst_image(objects, nrecalc=nrecalc, realized=real)
+        r.synchronize()
+        out.append((r.image_numpy(), real.cpu().numpy(), _sensor_arrays_gpu(r)))
+        del r
+    assert out[0][0].sum() > 0 and out[0][1].sum() > 0
+    assert_bits_equal(out[0][0], out[1][0], "image")
+    assert_bits_equal(out[0][1], out[1][1], "realized flux")
+    for name in ("boundary", "bounds", "delta"):
+        assert_bits_equal(out[0][2][name], out[1][2][name], f"sensor {name}")
+    # a prepared plan is replayed: three runs, three times the image of one
+    monkeypatch.setenv("IMS_NATIVE_PLAN", "1")
+    r = Renderer(scene)
+    launch = r.prepared_lsst_image(objects, nrecalc=nrecalc)
+    for _ in range(3):
+        launch()
+    r.synchronize()
+    one = Renderer(scene)
+    one.render_lsst_image(objects, nrecalc=nrecalc)
+    one.synchronize()
+    assert_bits_equal(r.image64_numpy(), 3.0 * one.image64_numpy(), "three replays")
+    assert launch.photons == int(objects["n_phot"].sum())
+
+
 def test_several_brighter_fatter_groups_on_a_fresh_renderer(torch_cuda):
     """A scratch capacity that holds a third of the bright objects' regions: the FIRST plan of a fresh renderer then carries
     several brighter-fatter groups, each with its own slot table, and the table of group k + 1 is rewritten on the chain
@@ -778,7 +816,8 @@ def test_config_several_ccds_take_the_overlapped_focal_plane_path(torch_cuda, mo
     (focal_plane.render_focal_plane, the fan-out of imsim/ccd.py:72-89), with FFT-drawn objects, sky noise and an e-image file
     per CCD -- and give the images, truth records and files of rendering them one after the other (IMS_PROCESS_FOCAL=0)."""
     over = {"image.nobjects": 40, "output.nfiles": 3, "stamp.fft_sb_thresh": 2.0e3, "image.sky_level": 800.0,
-            "image.noise": {"type": "CCD"}, "output.dir": str(tmp_path), "output.file_name": "eimage_$det_name.fits"}
+            "image.noise": {"type": "CCD"}, "output.dir": str(tmp_path),
+            "output.file_name": {"type": "FormattedStr", "format": "eimage_%s.fits", "items": ["$det_name"]}}
     a = _process(**over)
     monkeypatch.setenv("IMS_PROCESS_FOCAL", "0")
     b = _process(**dict(over, **{"output.dir": str(tmp_path / "serial")}))
@@ -1283,7 +1322,7 @@ def test_focal_plane_ccds_hold_fft_photon_and_faint_objects(torch_cuda):
         assert j.n_fft == 2 and (j.objects["n_phot"] > 1_000_000).sum() == 1 and (j.objects["flags"] & IMS_OBJ_FAINT).any()
     transforms = {}
     images = focal_plane.render_focal_plane(dets, build, concurrent=3,
-                                            post=lambda det, r: transforms.__setitem__(det, r._keep_fft._last[1].cpu().numpy()))
+                                            post=lambda det, r: transforms.__setitem__(det, r._keep_fft[1].cpu().numpy()))
     assert sorted(images) == dets
     for det in dets:
         sc, job = build(det)

@@ -123,6 +123,8 @@ int orc_struct_size(int which)
     case 17: return (int)sizeof(ims_chain_t);
     case 18: return (int)sizeof(ims_catalog_t);
     case 19: return (int)sizeof(ims_object_meta_t);
+    case 20: return (int)sizeof(ims_plan_input_t);
+    case 21: return (int)sizeof(ims_plan_sizes_t);
     }
     return -1;
 }

@@ -441,11 +441,11 @@ def cpu_parity(cfg, scene, cpu, device):
         # peak, so a Poisson deviate can differ where its mean sits within that of a decision boundary
         w = np.asarray(want, dtype=np.float64)
         diff = np.abs(got.astype(np.float64) - w)
-        cpu["parity"].update(differing_pixels=int(np.count_nonzero(diff)), max_abs_diff=float(diff.max()),
-                             flux_ratio=float(got.sum() / max(w.sum(), 1e-300)),
+        flux_ratio = float(got.sum(dtype=np.float64) / max(w.sum(), 1e-300))
+        cpu["parity"].update(differing_pixels=int(np.count_nonzero(diff)), max_abs_diff=float(diff.max()), flux_ratio=flux_ratio,
                              tolerance="pixels that differ < 1e-4 of the non-zero ones; total flux within 1e-6",
                              within_tolerance=bool(np.count_nonzero(diff) <= 1e-4 * max(np.count_nonzero(w), 1) + 2
-                                                   and abs(got.sum() / max(w.sum(), 1e-300) - 1) < 1e-6))
+                                                   and abs(flux_ratio - 1.0) < 1e-6))
     del gpu
     return cpu
 

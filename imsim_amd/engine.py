@@ -769,8 +769,8 @@ class NativePlan:
         handle, sizes = C.c_void_p(), _abi.PlanSizes()
         _abi.check(lib.ims_plan_lsst_image(C.byref(inp), C.byref(handle), C.byref(sizes)), "ims_plan_lsst_image")
         self.handle, self.sizes = handle, sizes
-        self.arena_pin = _pinned_arena(t, int(sizes.arena_bytes))
-        self.arena_dev = t.empty(int(sizes.arena_bytes), dtype=t.uint8, device=r.device)
+        self.arena_pin = _pinned_arena(t, max(int(sizes.arena_bytes), 256))
+        self.arena_dev = t.empty(max(int(sizes.arena_bytes), 256), dtype=t.uint8, device=r.device)
         self.rows = t.empty(int(sizes.rows_bytes), dtype=t.uint8, device=r.device)
         self.pool = t.empty(max(4 * int(sizes.pool_photons), 1), dtype=t.float64, device=r.device)
         self.realized = t.empty(max(int(sizes.realized_count), 1), dtype=t.float64, device=r.device) if sizes.realized_count else None

@@ -701,11 +701,15 @@ def _focal_streams(torch, device, peek=False, top_index=None):
     with _STREAMS_LOCK:                 # renderers of a focal plane may be created from several host threads
         st = _DEVICE_STREAMS.get(key)
         if st is None:
-            st = _DEVICE_STREAMS[key] = {"next": 0, "top": [torch.cuda.Stream(device, priority=-1), torch.cuda.Stream(device, priority=-1)],
+            # IMS_FOCAL_TOPS (default 2): streams for the long top chains; more than two only pays with more hardware queues
+            # (GPU_MAX_HW_QUEUES) than HIP's default four
+            n_top = max(1, int(os.environ.get("IMS_FOCAL_TOPS", "2")))
+            st = _DEVICE_STREAMS[key] = {"next": 0, "top": [torch.cuda.Stream(device, priority=-1) for _ in range(n_top)],
                                          "bulk": torch.cuda.Stream(device), "mid": torch.cuda.Stream(device)}
-    if top_index is not None:          # the caller deals the two top streams itself (CCDs enqueued from several host threads)
-        return (st["top"][top_index % 2], st["bulk"], st["mid"], st["mid"], st["mid"])
-    top = st["top"][st["next"] % 2]
+    n_top = len(st["top"])
+    if top_index is not None:          # the caller deals the top streams itself (CCDs enqueued from several host threads)
+        return (st["top"][top_index % n_top], st["bulk"], st["mid"], st["mid"], st["mid"])
+    top = st["top"][st["next"] % n_top]
     if not peek:                       # peek: the set the NEXT renderer of the device will get
         st["next"] += 1
     return (top, st["bulk"], st["mid"], st["mid"], st["mid"])

@@ -76,7 +76,7 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
         if anchor_role:
             # no stream beside the four plan streams of the device: a fifth would share a hardware queue with one of them
             from .engine import _focal_streams
-            top_index = k % 2
+            top_index = k            # dealt over the device's top-chain streams (engine._focal_streams: index modulo their number)
             peek = _focal_streams(torch, dev, top_index=top_index)
             by_role = {"top": peek[0], "bulk": peek[1], "mid": peek[2]}
             anchor = by_role[anchor_role]

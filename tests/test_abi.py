@@ -184,3 +184,21 @@ def test_hand_written_dpp_instructions_have_no_hazard(tmp_path):
     n_dpp, bad = check_dpp_hazard.check(str(out))
     assert n_dpp >= 1000, "the DPP update kernel is gone?"
     assert not bad, bad[:5]
+
+
+def test_the_ctypes_stub_of_integration_md_loads_the_library():
+    """INTEGRATION.md section 2 is what a maintainer of the reference pastes: its version assertion and its mirror of the object
+    row must hold against the library as built (the stub names the library by its bare file name; the test points it at the
+    in-tree build)."""
+    import re
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(.*?)```", text, re.S).group(1)
+    code = block.split("# ... ims_render_params_t")[0]
+    assert "ims_abi_version() ==" in code and "ims_struct_size(0)" in code
+    code = code.replace('C.CDLL("libimsim_hip.so")', f'C.CDLL({_abi.lib_path()!r})')
+    scope = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), scope)
+    assert scope["lib"].ims_abi_version() == _abi.load().ims_abi_version()
+    header = open(os.path.join(ROOT, "include", "imsim_hip.h")).read()
+    assert f"#define IMS_ABI_VERSION {scope['lib'].ims_abi_version()}" in header
+    assert C.sizeof(scope["ImsObject"]) == 256

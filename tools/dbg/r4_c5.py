@@ -41,7 +41,7 @@ if os.environ.get("R4_SKIP_SINGLE", "0") == "0":
         nf = job.fft_rows["nfft"].tolist() if job.n_fft else []
         top = np.sort(job.objects["n_phot"])[::-1][:3].tolist()
         print(f"CCD {det}: all {ts[0]:.1f} ms, fft only {ts[1]:.1f}, phot only {ts[2]:.1f}; FFT grids {nf}; brightest photon-shot {top}")
-for conc in (1, 2, 3, 4):
+for conc in [int(v) for v in os.environ.get("R4_CONC", "1,2,3,4").split(",")]:
     step = configs._c5_step(r, objects, concurrent=conc)
     step()
     torch.cuda.synchronize()

@@ -79,6 +79,7 @@ struct Plan {
     double* pool_dev = nullptr;
     double* realized_dev = nullptr;
     std::vector<hipEvent_t> events;
+    void* graph_exec = nullptr;         // IMS_PLAN_GRAPH: the instantiated graph of one run
     int32_t n_slots_scalar = 0;         // staging of sensor_dev->n_bf_slots lives in the arena (one per group)
     std::vector<int64_t> off_nslots;
 

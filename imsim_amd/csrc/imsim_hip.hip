@@ -2607,6 +2607,7 @@ int ims_plan_destroy(void* plan)
 {
     ims_planner::Plan* pl = (ims_planner::Plan*)plan;
     if (!pl) return IMS_OK;
+    if (pl->graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)pl->graph_exec);
     for (hipEvent_t e : pl->events) (void)hipEventDestroy(e);
     delete pl;
     return IMS_OK;
@@ -2696,12 +2697,53 @@ int ims_plan_upload(void* plan, void* stream)
     return IMS_OK;
 }
 
+static int plan_enqueue(ims_planner::Plan* pl, ims_sensor_t* sensor_dev, ims_sensor_t* sensor_host, ims_bf_slot_t* slots_dev,
+                        unsigned char* changed_dev, void* main_stream, void* const* streams, int32_t n_streams, int32_t own_work_queued);
+
+// IMS_PLAN_GRAPH=1: the whole enqueue of a plan is captured into a hipGraph on the main stream (the plan streams join the
+// capture through the fork / join events of the enqueue) and launched as one graph; a replay launches the instantiated
+// graph again.  An experiment: the launches of a chain are bound by wave slots and memory latency,
+// not by the host, and a graph does not run on the caller's streams (roles, priorities) -- off by default.
 int ims_plan_run(void* plan, ims_sensor_t* sensor_dev, ims_sensor_t* sensor_host, ims_bf_slot_t* slots_dev, unsigned char* changed_dev,
                  void* main_stream, void* const* streams, int32_t n_streams, int32_t own_work_queued)
 {
     using namespace ims_planner;
     Plan* pl = (Plan*)plan;
     if (!pl || !pl->uploaded) return set_err(IMS_ERR_ARG, "plan is NULL or not uploaded");
+    static const bool use_graph = getenv("IMS_PLAN_GRAPH") && atoi(getenv("IMS_PLAN_GRAPH")) != 0;
+    if (!use_graph || g_timing != 0)
+        return plan_enqueue(pl, sensor_dev, sensor_host, slots_dev, changed_dev, main_stream, streams, n_streams, own_work_queued);
+    hipStream_t main = (hipStream_t)main_stream;
+    if (pl->graph_exec == nullptr) {
+        // events must exist before the capture begins (creation is not a stream operation, but keep the capture clean)
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(main, hipStreamCaptureModeRelaxed));
+        const int rc = plan_enqueue(pl, sensor_dev, sensor_host, slots_dev, changed_dev, main_stream, streams, n_streams, 1);
+        const hipError_t e = hipStreamEndCapture(main, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        HIP_TRY(e);
+        hipGraphExec_t exec = nullptr;
+        HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        pl->graph_exec = exec;
+    } else if (sensor_host && !pl->groups.empty()) {
+        // the host's mirror of the slot table follows the last group, as an enqueue would leave it
+        for (size_t gi = 0; gi < pl->groups.size(); ++gi) {
+            const Group& g = pl->groups[gi];
+            if (g.n_slots <= 0) continue;
+            std::memcpy((ims_bf_slot_t*)(uintptr_t)sensor_host->bf_slots + pl->in.n_static_slots, pl->arena_host + g.off_slots,
+                        (size_t)g.n_slots * sizeof(ims_bf_slot_t));
+            sensor_host->n_bf_slots = pl->in.n_static_slots + g.n_slots;
+        }
+    }
+    HIP_TRY(hipGraphLaunch((hipGraphExec_t)pl->graph_exec, main));
+    return IMS_OK;
+}
+
+static int plan_enqueue(ims_planner::Plan* pl, ims_sensor_t* sensor_dev, ims_sensor_t* sensor_host, ims_bf_slot_t* slots_dev,
+                        unsigned char* changed_dev, void* main_stream, void* const* streams, int32_t n_streams, int32_t own_work_queued)
+{
+    using namespace ims_planner;
     if (!streams || n_streams < 5) return set_err(IMS_ERR_ARG, "streams: five plan streams by role are required");
     bool any_slots = false;
     for (const Group& g : pl->groups) any_slots = any_slots || g.n_slots > 0;

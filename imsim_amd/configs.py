@@ -648,7 +648,7 @@ def c5_cpu_sample(objects, scene):
     return sample
 
 
-def _c5_step(renderer, objects, rank=0, world=1, concurrent=3):
+def _c5_step(renderer, objects, rank=0, world=1, concurrent=None):
     """One step = every CCD this rank owns (CCD i -> rank i mod world, no exchange), each through a FRESH renderer: scene
     tables, the CCD's static pixel-boundary state, then the per-CCD build -- FFT-drawn objects first, launch plan of the
     photon-shot ones, ONE arena upload, the run -- and the float32 image back on the host: what
@@ -662,6 +662,11 @@ def _c5_step(renderer, objects, rank=0, world=1, concurrent=3):
         if job is None:
             return renderer.prepared_lsst_image(objects)
         return lambda: lsst_image.draw_job(renderer, job)
+    # four top-chain streams, four CCDs in flight: with the bright tail a CCD is bound by the rounds of its brightest star
+    # (hundreds of dependent rounds of ~50 us), so more chains side by side pay (tools/dbg/r4_c5_sweep.sh: 25.1 -> 22.5 ms per CCD)
+    os.environ.setdefault("IMS_FOCAL_TOPS", "4")
+    if concurrent is None:
+        concurrent = int(os.environ.get("IMS_FOCAL_CONCURRENT", "4"))
     base = renderer.scene
     cat, phot, coffs = objects.cat, objects.phot, objects.cat_offsets
     mine = parallel.shard_ccds(list(range(len(offs) - 1)), rank, world)

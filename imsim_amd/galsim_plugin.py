@@ -82,6 +82,157 @@ def make_builders(gs, gscfg, process=None, device="cuda:0"):
     return CcdImageBuilder, CarryStampBuilder, CarryPhotonOpBuilder
 
 
+INPUT_TYPES = ("atm_psf", "tree_rings", "instance_catalog", "opsim_data", "telescope", "sky_model", "sky_catalog", "checkpoint",
+               "vignetting", "table_row")
+OBJECT_TYPES = ("AtmosphericPSF", "DoubleGaussianPSF", "KolmogorovPSF", "InstCatObj", "SkyCatObj")
+VALUE_TYPES = ("TreeRingCenter", "TreeRingFunc", "InstCatWorldPos", "SkyCatWorldPos", "OpsimData", "SkyLevel", "RowData")
+EXTRA_OUTPUTS = ("readout", "photon_pooling_truth", "opd", "sag", "process_info")
+WCS_TYPES = ("Batoid", "Dict")
+TEMPLATES = ("imsim-config", "imsim-config-instcat", "imsim-config-skycat", "imsim-config-photon-pooling",
+             "imsim-config-instcat-comcam", "imsim-config-skycat-comcam")
+
+
+class Carrier:
+    """What a registered builder of this adapter hands back where the reference hands back a live object (an input catalog,
+    a GSObject, a WCS ...): the type name and the parameters as configured.  The image builder reads the CONFIG, not these
+    objects -- they exist so that GalSim's input / output / value machinery finds every name a reference YAML uses."""
+
+    def __init__(self, kind, name, **kwargs):
+        self.kind, self.name, self.kwargs = kind, name, kwargs
+
+    def __repr__(self):
+        return f"imsim_amd.{self.kind}.{self.name}({self.kwargs})"
+
+
+def _user_items(config):
+    return {k: v for k, v in config.items() if k != "type" and not str(k).startswith("_")}
+
+
+def opsim_meta(base):
+    """The visit's OpSim record, read once per config from input.opsim_data (file_name: an instance catalog header or an
+    OpSim db with `visit`; imsim/opsim_data.py:60-93) or, failing that, from the instance catalog itself"""
+    if "_imsim_amd_opsim" not in base:
+        from . import instcat
+        inp = base.get("input", {})
+        od = inp.get("opsim_data") or {}
+        fn = od.get("file_name") if isinstance(od, dict) else None
+        if isinstance(fn, str) and fn.startswith("@"):
+            fn = None
+        if fn is None:
+            fn = (inp.get("instance_catalog") or {}).get("file_name")
+        if fn is None:
+            raise ValueError("OpsimData needs input.opsim_data or input.instance_catalog")
+        if str(fn).endswith(".db"):
+            base["_imsim_amd_opsim"] = instcat.read_opsim_db(str(fn), int(od["visit"]), int(od.get("snap", 0)))
+        else:
+            base["_imsim_amd_opsim"] = instcat.read_header(str(fn))
+    return base["_imsim_amd_opsim"]
+
+
+def make_carriers(gs, gscfg):
+    """Loaders / builders for everything imSim registers beside the image, stamp and photon-op types (imsim/
+    instcat.py:667-671, atmPSF.py:540-543, treerings.py:241-243, telescope_loader.py:466, opsim_data.py:377-378, sky_model.py:
+    271-272, checkpoint.py:123, vignetting.py:125, table_row.py:139-140, skycat.py:302-305, ccd.py:208, readout.py, batoid_wcs.py:
+    643, dict_wcs.py:55, bandpass.py:227).  Returns a dict of the classes by role."""
+    from . import config as our_config
+
+    class CarryInputLoader(gscfg.InputLoader):
+        """an input item: its parameters are kept as configured (the image builder evaluates them with the whole config)"""
+
+        def __init__(self, name):
+            self.name = name
+            try:
+                gscfg.InputLoader.__init__(self, lambda **kw: Carrier("input", name, **kw), file_scope=True)
+            except TypeError:
+                pass
+
+        def getKwargs(self, config, base, logger):
+            return _user_items(config), True
+
+        def setupImage(self, input_obj, config, base, logger=None):
+            return
+
+    def build_object(name):
+        def build(config, base, ignore, gsparams, logger):
+            return Carrier("object", name, **_user_items(config)), False
+        return build
+
+    def gen_value(name):
+        def gen(config, base, value_type):
+            if name == "OpsimData":                                  # imsim/opsim_data.py:339-375
+                field = config["field"]
+                meta = opsim_meta(base)
+                if field not in meta or meta[field] is None:
+                    raise ValueError(f"OpsimData field {field} not present in metadata")
+                return value_type(meta[field]), True
+            if name in ("TreeRingCenter", "TreeRingFunc"):           # imsim/treerings.py:198-239
+                tr = base.get("_imsim_amd_tree_rings")
+                if tr is None:
+                    raise ValueError(f"{name} needs input.tree_rings")
+                det = config["det_name"] if "det_name" in config else base.get("det_name")
+                return (tr.get_center(det) if name == "TreeRingCenter" else tr.get_func(det)), False
+            return Carrier("value", name, **_user_items(config)), False
+        return gen
+
+    class CcdOutputBuilder(gscfg.OutputBuilder):
+        """output.type LSST_CCD (imsim/ccd.py:13-204): 189 files unless nfiles says otherwise, detector name from det_num,
+        exposure time and detector size into `base`, one image per file from the image builder, e-image FITS writer"""
+
+        def setup(self, config, base, file_num, logger):
+            from . import lsst_image
+            if "det_num" not in config:
+                config["det_num"] = {"type": "Sequence", "nitems": 189}
+            det_num = gscfg.ParseValue(config, "det_num", base, int)[0]
+            det_name = config["only_dets"][det_num] if "only_dets" in config else our_config.det_name_of(det_num)
+            base["det_num"], base["det_name"] = det_num, det_name
+            self.det_name = det_name
+            base["exptime"] = gscfg.ParseValue(config, "exptime", base, float)[0] if "exptime" in config else 30.0
+            base["det_xsize"], base["det_ysize"] = lsst_image.DETECTOR_SIZE[our_config.det_type_of(det_name)]
+
+        def getNFiles(self, config, base, logger=None):
+            return gscfg.ParseValue(config, "nfiles", base, int)[0] if "nfiles" in config else 189
+
+        def buildImages(self, config, base, file_num, image_num, obj_num, ignore, logger):
+            image = gscfg.BuildImage(base, image_num, obj_num, logger=logger)
+            return [image]
+
+        def writeFile(self, data, file_name, config, base, logger):
+            from . import readout
+            hdr = readout.eimage_header(base.get("det_name", "R22_S11"), float(base.get("exptime", 30.0)),
+                                        opsim_data=base.get("_imsim_amd_opsim") or {}, header_vals={})
+            readout.EImage(data[0].array, hdr).write(file_name)
+
+    class CarryExtraOutput(gscfg.ExtraOutputBuilder):
+        """readout / photon_pooling_truth / opd / sag / process_info: accepted; the e-image -> raw-file chain of this package
+        runs from imsim_amd.config.Process (`output.readout`), not from GalSim's extra-output hooks"""
+
+        def initialize(self, data, scratch, config, base, logger):
+            self.data, self.scratch = data, scratch
+
+        def finalize(self, config, base, main_data, logger):
+            return None
+
+    class CarryWCSBuilder(gscfg.WCSBuilder):
+        def buildWCS(self, config, base, logger):
+            scale = getattr(gs, "PixelScale", None)
+            return scale(0.2) if scale is not None else Carrier("wcs", config.get("type", "Batoid"), **_user_items(config))
+
+    class CarryBandpassBuilder(gscfg.BandpassBuilder):
+        def buildBandpass(self, config, base, logger):
+            from . import tables
+            wl, thr = tables.synthetic_r_band()
+            if hasattr(gs, "Bandpass") and hasattr(gs, "LookupTable"):          # pragma: no cover -- the real GalSim
+                return gs.Bandpass(gs.LookupTable(wl, thr), wave_type="nm"), False
+            return tables.Bandpass(wl, thr), False
+
+    class CarrySEDBuilder(gscfg.SEDBuilder):
+        def buildSED(self, config, base, logger):
+            return Carrier("sed", "InstCatSED", **_user_items(config)), False
+
+    return dict(input=CarryInputLoader, object=build_object, value=gen_value, output=CcdOutputBuilder, extra=CarryExtraOutput,
+                wcs=CarryWCSBuilder, bandpass=CarryBandpassBuilder, sed=CarrySEDBuilder)
+
+
 def register(gs=None, gscfg=None, **kw):
     """Register every name; returns the list of (kind, name) registered."""
     gs = gs or galsim
@@ -97,8 +248,42 @@ def register(gs=None, gscfg=None, **kw):
         gscfg.RegisterStampType(name, stamp_b())
         done.append(("stamp", name))
     for name in PHOTON_OP_TYPES:
-        gscfg.RegisterPhotonOpType(name, op_b())
+        gscfg.RegisterPhotonOpType(name, op_b(name))
         done.append(("photon_op", name))
+    if not hasattr(gscfg, "RegisterInputType"):
+        return done                                  # a stand-in of the image / stamp / photon-op interface only
+    c = make_carriers(gs, gscfg)
+    for name in INPUT_TYPES:
+        gscfg.RegisterInputType(name, c["input"](name))
+        done.append(("input", name))
+    for name in OBJECT_TYPES:
+        gscfg.RegisterObjectType(name, c["object"](name))
+        done.append(("object", name))
+    any_type = [float, int, bool, str, object, None]
+    for name in VALUE_TYPES:
+        gscfg.RegisterValueType(name, c["value"](name), any_type)
+        done.append(("value", name))
+    gscfg.RegisterOutputType("LSST_CCD", c["output"]())
+    done.append(("output", "LSST_CCD"))
+    for name in EXTRA_OUTPUTS:
+        gscfg.RegisterExtraOutput(name, c["extra"]())
+        done.append(("extra_output", name))
+    for name in WCS_TYPES:
+        gscfg.RegisterWCSType(name, c["wcs"]())
+        done.append(("wcs", name))
+    gscfg.RegisterBandpassType("RubinBandpass", c["bandpass"]())
+    done.append(("bandpass", "RubinBandpass"))
+    gscfg.RegisterSEDType("InstCatSED", c["sed"]())
+    done.append(("sed", "InstCatSED"))
+    # template aliases (imsim/templates.py:12-17) when a directory of imSim config files is given: IMSIM_CONFIG_DIR
+    import os
+    cfg_dir = os.environ.get("IMSIM_CONFIG_DIR")
+    if cfg_dir and hasattr(gscfg, "RegisterTemplate"):
+        for name in TEMPLATES:
+            path = os.path.join(cfg_dir, name + ".yaml")
+            if os.path.isfile(path):
+                gscfg.RegisterTemplate(name, path)
+                done.append(("template", name))
     return done
 
 

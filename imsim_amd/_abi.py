@@ -250,7 +250,8 @@ EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_
            "ims_readout_bleed", "ims_readout_segments", "ims_readout_cte", "ims_readout_finish",
            "ims_build_object_table", "ims_patch_stamp_sizes", "ims_gather_rows", "ims_parse_instcat_objects", "ims_screen_prepass",
            "ims_plan_lsst_image", "ims_plan_bind", "ims_plan_upload", "ims_plan_run", "ims_plan_add_realized", "ims_plan_destroy",
-           "ims_struct_size", "ims_test_math"]
+           "ims_fft_inverse", "ims_comm_unique_id", "ims_comm_init", "ims_comm_destroy", "ims_reduce_image", "ims_allreduce_delta",
+           "ims_count_inexact", "ims_struct_size", "ims_test_math"]
 
 _LIB_PATH = os.environ.get("IMSIM_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libimsim_hip.so")
 _lib = None
@@ -327,6 +328,13 @@ def load():
     lib.ims_plan_run.argtypes = [c_vp, c_vp, C.POINTER(Sensor), c_vp, c_vp, c_vp, C.POINTER(c_vp), c_i32, c_i32]
     lib.ims_plan_add_realized.argtypes = [c_vp, c_vp, c_vp]
     lib.ims_plan_destroy.argtypes = [c_vp]
+    lib.ims_fft_inverse.argtypes = [c_vp, c_vp, c_i32, c_i64, c_vp]
+    lib.ims_comm_unique_id.argtypes = [c_vp]
+    lib.ims_comm_init.argtypes = [c_vp, c_i32, c_i32, C.POINTER(c_vp)]
+    lib.ims_comm_destroy.argtypes = [c_vp]
+    lib.ims_reduce_image.argtypes = [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]
+    lib.ims_allreduce_delta.argtypes = [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]
+    lib.ims_count_inexact.argtypes = [c_vp, c_i64, c_i32, c_vp, c_vp]
     _lib = lib
     return lib
 

@@ -726,8 +726,9 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
         if ctx.job is not None:
             lsst_image.fill_truth(ctx.truth, ctx.job, ctx.job.realized.cpu().numpy())
         sub = ProcessResult()
+        img = renderer.image_numpy()                         # the e-image as rendered: the readout chain bleeds the device image in place
         _process_outputs(out, ev, sub, renderer.image, ctx.det_name, meta, ctx.seed_ccd)
-        done[ctx.det] = (renderer.image_numpy(), ctx.truth, ctx.det_name, sub)
+        done[ctx.det] = (img, ctx.truth, ctx.det_name, sub)
 
     # Several CCDs of LSST_Image type go through the overlapped focal-plane path (focal_plane.render_focal_plane, the per-CCD
     # fan-out of imsim/ccd.py:72-89): the host prepares the next CCD while the GPU works through the launch plans of the

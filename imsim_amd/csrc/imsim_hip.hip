@@ -2811,6 +2811,190 @@ int ims_plan_add_realized(void* plan, double* out_dev, void* stream)
     return IMS_OK;
 }
 
+// ---- the inverse transforms of the FFT branch (hipFFT, plans cached) and the exchanges between GPUs (RCCL) ----
+}  // extern "C"
+#include "ims_libs.h"
+
+__global__ __launch_bounds__(256) void k_scale(double* __restrict__ v, int64_t n, double s)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) v[i] = v[i] * s;
+}
+
+__global__ __launch_bounds__(256) void k_f64_to_i32(const double* __restrict__ src, int32_t* __restrict__ dst, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = (int32_t)src[i];
+}
+
+__global__ __launch_bounds__(256) void k_i32_to_f64(const int32_t* __restrict__ src, double* __restrict__ dst, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = (double)src[i];
+}
+
+// not an integer count below 2^31 / world: the int32 exchange would not be exact for it
+__global__ __launch_bounds__(256) void k_count_inexact(const double* __restrict__ src, int64_t n, double limit, unsigned long long* __restrict__ bad)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    unsigned long long c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const double v = src[i];
+        if (!(v >= 0.0 && v < limit && v == floor(v))) ++c;
+    }
+    if (c) atomicAdd(bad, c);
+}
+
+extern "C" {
+
+static int fft_err(hipfftResult r, const char* what)
+{
+    if (r == HIPFFT_SUCCESS) return IMS_OK;
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s: hipfft error %d", what, (int)r);
+    return set_err(IMS_ERR_HIP, buf);
+}
+
+int ims_fft_inverse(double* kbuf_dev, double* rbuf_dev, int32_t nfft, int64_t batch, void* stream)
+{
+    if (batch <= 0) return IMS_OK;
+    if (!kbuf_dev || !rbuf_dev) return set_err(IMS_ERR_ARG, "NULL buffer");
+    if (nfft < 2 || (nfft & 1) || batch > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "nfft must be even and >= 2");
+    const ims_libs::Fft* F = ims_libs::fft();
+    if (!F) return set_err(IMS_ERR_UNSUPPORTED, "hipFFT is not loadable (libhipfft.so; IMS_HIPFFT_LIB names a file)");
+    // plans are kept per (size, batch): making one costs milliseconds, a CCD's FFT objects come in a handful of sizes
+    static std::mutex m;
+    static std::unordered_map<unsigned long long, hipfftHandle> plans;
+    hipfftHandle plan;
+    {
+        std::lock_guard<std::mutex> lock(m);
+        const unsigned long long key = ((unsigned long long)(uint32_t)nfft << 32) | (unsigned long long)(uint32_t)batch;
+        auto it = plans.find(key);
+        if (it == plans.end()) {
+            int n[2] = { nfft, nfft };
+            int inembed[2] = { nfft, nfft / 2 + 1 }, onembed[2] = { nfft, nfft };
+            hipfftHandle p;
+            int rc = fft_err(F->plan_many(&p, 2, n, inembed, 1, nfft * (nfft / 2 + 1), onembed, 1, nfft * nfft, HIPFFT_Z2D, (int)batch),
+                             "hipfftPlanMany");
+            if (rc) return rc;
+            it = plans.emplace(key, p).first;
+        }
+        plan = it->second;
+        int rc = fft_err(F->set_stream(plan, (hipStream_t)stream), "hipfftSetStream");
+        if (rc) return rc;
+        rc = fft_err(F->exec_z2d(plan, (hipfftDoubleComplex*)kbuf_dev, (hipfftDoubleReal*)rbuf_dev), "hipfftExecZ2D");
+        if (rc) return rc;
+    }
+    // numpy / GalSim normalisation of the inverse ("backward": 1 / N^2): exact for the even sizes used (powers of two)
+    const int64_t total = batch * (int64_t)nfft * nfft;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_scale, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rbuf_dev, total, 1.0 / ((double)nfft * (double)nfft));
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+// ---- exchanges between the GPUs of a node (RCCL over xGMI) ----
+static int nccl_err(ncclResult_t r, const char* what)
+{
+    if (r == ncclSuccess) return IMS_OK;
+    const ims_libs::Rccl* R = ims_libs::rccl();
+    char buf[384];
+    snprintf(buf, sizeof(buf), "%s: %s", what, R ? R->error_string(r) : "rccl error");
+    return set_err(IMS_ERR_HIP, buf);
+}
+
+struct ImsComm { ncclComm_t comm; int32_t rank, world; };
+
+int ims_comm_unique_id(void* id128)
+{
+    if (!id128) return set_err(IMS_ERR_ARG, "id128 is NULL");
+    const ims_libs::Rccl* R = ims_libs::rccl();
+    if (!R) return set_err(IMS_ERR_UNSUPPORTED, "RCCL is not loadable (librccl.so; IMS_RCCL_LIB names a file)");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId");
+    return nccl_err(R->get_unique_id((ncclUniqueId*)id128), "ncclGetUniqueId");
+}
+
+int ims_comm_init(const void* id128, int32_t rank, int32_t world, void** comm_out)
+{
+    if (!id128 || !comm_out || world < 1 || rank < 0 || rank >= world) return set_err(IMS_ERR_ARG, "id / comm_out / rank / world");
+    const ims_libs::Rccl* R = ims_libs::rccl();
+    if (!R) return set_err(IMS_ERR_UNSUPPORTED, "RCCL is not loadable (librccl.so; IMS_RCCL_LIB names a file)");
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    ncclComm_t c = nullptr;
+    const int rc = nccl_err(R->comm_init_rank(&c, world, id, rank), "ncclCommInitRank");
+    if (rc) return rc;
+    *comm_out = new ImsComm{ c, rank, world };
+    return IMS_OK;
+}
+
+int ims_comm_destroy(void* comm)
+{
+    if (!comm) return IMS_OK;
+    const ims_libs::Rccl* R = ims_libs::rccl();
+    if (!R) return set_err(IMS_ERR_UNSUPPORTED, "RCCL is not loadable");
+    ImsComm* ic = (ImsComm*)comm;
+    const int rc = nccl_err(R->comm_destroy(ic->comm), "ncclCommDestroy");
+    delete ic;
+    return rc;
+}
+
+static unsigned exchange_grid(int64_t n)
+{
+    int64_t b = (n + 255) / 256;
+    return (unsigned)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
+}
+
+int ims_count_inexact(const double* image_dev, int64_t n, int32_t world, unsigned long long* bad_dev, void* stream)
+{
+    if (!image_dev || !bad_dev || n < 0 || world < 1) return set_err(IMS_ERR_ARG, "NULL / negative argument");
+    if (n == 0) return IMS_OK;
+    hipLaunchKernelGGL(k_count_inexact, dim3(exchange_grid(n)), dim3(256), 0, (hipStream_t)stream, image_dev, n,
+                       2147483648.0 / (double)world, bad_dev);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+// sum of the ranks' images onto `root` (in place there; the other ranks' images are left as they are), or onto every rank
+static int exchange(void* comm, double* image_dev, int32_t* scratch_i32_dev, int64_t n, int32_t root, int32_t integer_counts, void* stream)
+{
+    if (!comm || !image_dev || n < 0) return set_err(IMS_ERR_ARG, "comm / image is NULL");
+    if (integer_counts && !scratch_i32_dev) return set_err(IMS_ERR_ARG, "scratch_i32_dev is NULL");
+    if (n == 0) return IMS_OK;
+    const ims_libs::Rccl* R = ims_libs::rccl();
+    if (!R) return set_err(IMS_ERR_UNSUPPORTED, "RCCL is not loadable");
+    hipStream_t st = (hipStream_t)stream;
+    const ImsComm* ic = (const ImsComm*)comm;
+    ncclComm_t c = ic->comm;
+    if (root >= ic->world) return set_err(IMS_ERR_ARG, "root out of range");
+    if (integer_counts) {
+        // unit photon fluxes: every pixel is an integer count, exchanged as int32 -- half the bytes on the per-link-bound ring, and
+        // still exact (the caller checks the counts against 2^31 / world once: ims_count_inexact)
+        hipLaunchKernelGGL(k_f64_to_i32, dim3(exchange_grid(n)), dim3(256), 0, st, (const double*)image_dev, scratch_i32_dev, n);
+        const int rc = root >= 0 ? nccl_err(R->reduce(scratch_i32_dev, scratch_i32_dev, (size_t)n, ncclInt32, ncclSum, root, c, st), "ncclReduce")
+                                 : nccl_err(R->all_reduce(scratch_i32_dev, scratch_i32_dev, (size_t)n, ncclInt32, ncclSum, c, st), "ncclAllReduce");
+        if (rc) return rc;
+        if (root < 0 || root == ic->rank)          // a reduce leaves the other ranks' images as they were
+            hipLaunchKernelGGL(k_i32_to_f64, dim3(exchange_grid(n)), dim3(256), 0, st, (const int32_t*)scratch_i32_dev, image_dev, n);
+        HIP_TRY(hipGetLastError());
+        return IMS_OK;
+    }
+    return root >= 0 ? nccl_err(R->reduce(image_dev, image_dev, (size_t)n, ncclFloat64, ncclSum, root, c, st), "ncclReduce")
+                     : nccl_err(R->all_reduce(image_dev, image_dev, (size_t)n, ncclFloat64, ncclSum, c, st), "ncclAllReduce");
+}
+
+int ims_reduce_image(void* comm, double* image_dev, int32_t* scratch_i32_dev, int64_t n, int32_t root, int32_t integer_counts, void* stream)
+{
+    if (root < 0) return set_err(IMS_ERR_ARG, "root must be >= 0");
+    return exchange(comm, image_dev, scratch_i32_dev, n, root, integer_counts, stream);
+}
+
+int ims_allreduce_delta(void* comm, double* delta_dev, int32_t* scratch_i32_dev, int64_t n, int32_t integer_counts, void* stream)
+{
+    return exchange(comm, delta_dev, scratch_i32_dev, n, -1, integer_counts, stream);
+}
+
 int ims_fft_kspace_fill(const ims_fft_params_t* params, const ims_fft_object_t* objects_dev, int64_t n_objects,
                         const int64_t* elem_prefix_dev, int64_t n_elems, double* kbuf, void* stream)
 {

@@ -302,15 +302,23 @@ class FftDrawer:
         st = r._stream()
         _abi.check(r.lib.ims_fft_kspace_fill(C.byref(P), obj_t.data_ptr(), n, kpre_t.data_ptr(), int(kpre[-1]),
                                              kbuf.data_ptr(), st), "ims_fft_kspace_fill")
-        # batched inverse real 2-D FFTs, one batch per FFT size (plain library transform: rocFFT)
+        # batched inverse real 2-D FFTs, one batch per FFT size (plain library transform: rocFFT through hipFFT); IMS_FFT_TORCH=1
+        # takes torch.fft instead -- the same library behind another front end, kept as the checker
+        import os
+        use_torch = os.environ.get("IMS_FFT_TORCH", "0") != "0"
         for size in np.unique(nfft):
             sel = np.flatnonzero(nfft == size)
             a, b = int(sel[0]), int(sel[-1]) + 1
             nh = int(size) // 2 + 1
-            spec = kbuf[int(kpre[a]):int(kpre[b])].view(b - a, int(size), nh)
-            # the transform writes straight into the real-space buffer (no staging copy)
-            torch.fft.irfft2(spec, s=(int(size), int(size)), norm="backward",
-                             out=rbuf[int(rpre[a]):int(rpre[b])].view(b - a, int(size), int(size)))
+            if use_torch:
+                spec = kbuf[int(kpre[a]):int(kpre[b])].view(b - a, int(size), nh)
+                # the transform writes straight into the real-space buffer (no staging copy)
+                torch.fft.irfft2(spec, s=(int(size), int(size)), norm="backward",
+                                 out=rbuf[int(rpre[a]):int(rpre[b])].view(b - a, int(size), int(size)))
+            else:
+                # the library's own hipFFT plans (ims_fft_inverse): nothing of the branch needs a Python-side transform
+                _abi.check(r.lib.ims_fft_inverse(kbuf.data_ptr() + 16 * int(kpre[a]), rbuf.data_ptr() + 8 * int(rpre[a]), int(size), b - a, st),
+                           "ims_fft_inverse")
         final = rbuf
         if P.spikes.enabled:
             # DiffractionFFT.apply between the clip and the noise (stamp.py:519-522)

@@ -55,8 +55,11 @@ def make_builders(gs, gscfg, process=None, device="cuda:0"):
 
         def buildImage(self, config, base, image_num, obj_num, logger):
             cfg = plain_config(base)
-            det = int(base.get("file_num", 0)) + int(cfg.get("output", {}).get("det_num", {}).get("first", 0)
-                                                       if isinstance(cfg.get("output", {}).get("det_num"), dict) else 0)
+            if "det_num" in base:                                              # set by LSST_CCD's setup for this file (imsim/ccd.py:55)
+                det = int(base["det_num"])
+            else:
+                det = int(base.get("file_num", 0)) + int(cfg.get("output", {}).get("det_num", {}).get("first", 0)
+                                                           if isinstance(cfg.get("output", {}).get("det_num"), dict) else 0)
             res = process(cfg, overrides={"output.nfiles": 1, "output.det_num": {"type": "Sequence", "first": det, "nitems": 1},
                                           "output.file_name": "", "output.readout": ""}, device=device)
             base["_imsim_amd_truth"] = res.truth[0] if res.truth else {}
@@ -72,12 +75,37 @@ def make_builders(gs, gscfg, process=None, device="cuda:0"):
             raise gscfg.SkipThisObject("imsim_amd renders whole CCDs in the image builder")
 
     class CarryPhotonOp:
-        def __init__(self, **kw):
-            self.kwargs = kw
+        """A registered photon operator as GalSim's `photon_ops` list holds it.  The image builder reads the operators from the
+        CONFIG (whole-CCD granularity); a caller that applies one itself -- op.applyTo(photon_array, local_wcs, rng), the
+        PhotonOp contract of imsim/photon_ops.py:81, :304, :520 -- gets the device operator of imsim_amd.photon_ops, built on
+        first use from the parameters as configured (`optics`: an _abi.Optics, else the approximate Rubin telescope of the
+        bench visit)."""
+
+        def __init__(self, name, **kw):
+            self.name, self.kwargs, self._op = name, kw, None
+
+        def device_op(self):
+            if self._op is None:
+                from . import photon_ops, configs
+                kw = self.kwargs
+                if self.name == "BandpassRatio":
+                    self._op = photon_ops.BandpassRatio(kw["target_bandpass"], kw["initial_bandpass"])
+                else:
+                    optics = kw.get("optics") or configs.rubin_optics_struct()
+                    self._op = getattr(photon_ops, self.name)(optics, shift_photons=bool(kw.get("shift_photons", False)),
+                                                              stamp_center=kw.get("stamp_center"),
+                                                              disable_field_rotation=bool(kw.get("disable_field_rotation", False)))
+            return self._op
+
+        def applyTo(self, photon_array, local_wcs=None, rng=None):
+            return self.device_op().applyTo(photon_array, local_wcs, rng)
 
     class CarryPhotonOpBuilder(gscfg.PhotonOpBuilder):
+        def __init__(self, name=None):
+            self.name = name
+
         def buildPhotonOp(self, config, base, logger):
-            return CarryPhotonOp(**{k: v for k, v in config.items() if k != "type"})
+            return CarryPhotonOp(self.name or config.get("type"), **{k: v for k, v in config.items() if k != "type"})
 
     return CcdImageBuilder, CarryStampBuilder, CarryPhotonOpBuilder
 

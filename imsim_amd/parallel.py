@@ -91,6 +91,88 @@ def integer_counts_ok(image, world):
     return whole and low >= 0.0 and top * max(int(world), 1) < 2147483648.0
 
 
+class LibraryComm:
+    """The library's own RCCL communicator (ims_comm_init, include/imsim_hip.h): the exchanges of the path run inside
+    libimsim_hip.so, torch.distributed (any backend, gloo included) only carries the 128-byte id from rank 0 to the others --
+    so a host that is not Python runs the same exchanges.  One per process; `install` makes reduce_image / allreduce_delta use it."""
+
+    def __init__(self, rank, world, device, broadcast=None):
+        """broadcast(bytes or None) -> bytes: hands rank 0's id to every rank; default: torch.distributed.broadcast_object_list
+        over the existing process group (world 1 needs none)"""
+        import ctypes as C
+        import torch
+        from . import _abi
+        self.lib = _abi.load()
+        self.rank, self.world, self.device = int(rank), int(world), torch.device(device)
+        ident = (C.c_char * 128)()
+        if self.rank == 0:
+            _abi.check(self.lib.ims_comm_unique_id(C.byref(ident)), "ims_comm_unique_id")
+        raw = bytes(ident)
+        if self.world > 1:
+            if broadcast is None:
+                import torch.distributed as dist
+
+                def broadcast(b):
+                    box = [b]
+                    dist.broadcast_object_list(box, src=0)
+                    return box[0]
+            raw = broadcast(raw if self.rank == 0 else None)
+        ident = (C.c_char * 128).from_buffer_copy(raw)
+        handle = C.c_void_p()
+        torch.cuda.set_device(self.device)
+        _abi.check(self.lib.ims_comm_init(C.byref(ident), self.rank, self.world, C.byref(handle)), "ims_comm_init")
+        self.handle = handle
+        self._scratch = None
+
+    def scratch(self, n):
+        import torch
+        if self._scratch is None or self._scratch.numel() < n:
+            self._scratch = torch.empty(int(n), dtype=torch.int32, device=self.device)
+        return self._scratch
+
+    def _stream(self):
+        import ctypes as C
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reduce_image(self, image, dst=0, integer_counts=False):
+        from . import _abi
+        n = image.numel()
+        sc = self.scratch(n).data_ptr() if integer_counts else None
+        _abi.check(self.lib.ims_reduce_image(self.handle, image.data_ptr(), sc, n, int(dst), 1 if integer_counts else 0, self._stream()),
+                   "ims_reduce_image")
+        return image
+
+    def allreduce_delta(self, delta, integer_counts=False):
+        from . import _abi
+        n = delta.numel()
+        sc = self.scratch(n).data_ptr() if integer_counts else None
+        _abi.check(self.lib.ims_allreduce_delta(self.handle, delta.data_ptr(), sc, n, 1 if integer_counts else 0, self._stream()),
+                   "ims_allreduce_delta")
+        return delta
+
+    def count_inexact(self, image):
+        """number of values of this rank's image the int32 exchange would not carry exactly (0 = fine); one host sync"""
+        import torch
+        from . import _abi
+        bad = torch.zeros(1, dtype=torch.int64, device=self.device)
+        _abi.check(self.lib.ims_count_inexact(image.data_ptr(), image.numel(), self.world, bad.data_ptr(), self._stream()), "ims_count_inexact")
+        return int(bad.item())
+
+    def destroy(self):
+        if getattr(self, "handle", None):
+            self.lib.ims_comm_destroy(self.handle)
+            self.handle = None
+
+
+_LIBRARY_COMM = [None]
+
+
+def install(comm):
+    """make reduce_image / allreduce_delta run on a LibraryComm (None: back to torch.distributed)"""
+    _LIBRARY_COMM[0] = comm
+
+
 def _exchange_on(dist):
     """An exchange runs when a process group of more than one rank exists -- or of exactly one rank when
     IMS_EXCHANGE_SINGLE_RANK=1: the RCCL calls then execute as self-exchanges, which is how the one-GPU test box can run the
@@ -103,7 +185,7 @@ def _exchange_on(dist):
 def exchanging(world):
     """Whether the delta-charge exchange of photon pooling runs for a job of `world` ranks: always for world > 1, and with one
     rank when IMS_EXCHANGE_SINGLE_RANK=1 asks for the collectives as self-exchanges (and a process group exists)."""
-    if world > 1:
+    if world > 1 or _LIBRARY_COMM[0] is not None:
         return True
     import torch.distributed as dist
     return os.environ.get("IMS_EXCHANGE_SINGLE_RANK", "0") == "1" and dist.is_available() and dist.is_initialized()
@@ -119,6 +201,8 @@ def reduce_image(image, dst=0, integer_counts=False):
     bytes of the f64 accumulation image on the per-link-bound xGMI ring -- and is still exact."""
     import torch
     import torch.distributed as dist
+    if _LIBRARY_COMM[0] is not None:
+        return _LIBRARY_COMM[0].reduce_image(image, dst, integer_counts)
     if _exchange_on(dist):
         buf = image.to(torch.int32) if integer_counts else image
         if dist.get_backend() == "gloo" and buf.is_cuda:
@@ -137,6 +221,8 @@ def allreduce_delta(delta, integer_counts=False):
     integer_counts: as in reduce_image -- unit photon fluxes, the exchange runs on an int32 copy (half the bytes)."""
     import torch
     import torch.distributed as dist
+    if _LIBRARY_COMM[0] is not None:
+        return _LIBRARY_COMM[0].allreduce_delta(delta, integer_counts)
     if _exchange_on(dist):
         if integer_counts:
             buf = delta.to(torch.int32)

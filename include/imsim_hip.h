@@ -48,7 +48,7 @@ extern "C" {
 #define IMS_ERR_NO_DEVICE  -3
 #define IMS_ERR_UNSUPPORTED -4
 
-#define IMS_ABI_VERSION 16
+#define IMS_ABI_VERSION 17
 
 /* Pointers stored INSIDE descriptors that live in device memory (ims_sensor_t, ims_atmosphere_t) always point to global
  * device memory.  Device code is told so (address space 1): a pointer read out of memory is otherwise a generic pointer and
@@ -631,6 +631,29 @@ int  ims_gather_rows(const ims_object_t* rows_dev, const int64_t* index_dev, con
  * number -- the caller's line-by-line reader then raises what the reference raises. */
 int64_t ims_parse_instcat_objects(const char* text, int64_t n_bytes, int64_t max_objects, double* num, int32_t* kind,
                                   int64_t* span);
+
+/* ---- the inverse transforms of the FFT branch and the exchanges between GPUs, behind the C-ABI ----
+ * (ims_fft_draw_batch / ims_reduce / ims_allreduce_delta.)  hipFFT and RCCL are looked up at first use -- the copy
+ * already loaded in the process if there is one (a Python host brings torch's), else the ordinary library search path -- so
+ * the library has no link-time dependency on either and never brings a second HIP runtime into the process.
+ *
+ * ims_fft_inverse: `batch` inverse real 2-D transforms of size nfft x nfft (imsim/stamp.py:502-504, GalSim's FFT draw): kbuf
+ * holds the half spectra [batch][nfft][nfft / 2 + 1] complex128 (destroyed), rbuf receives [batch][nfft][nfft] float64 with
+ * numpy's "backward" normalisation.  Plans are cached per (nfft, batch) for the life of the process.
+ *
+ * Communicator: rank 0 asks ims_comm_unique_id for the 128-byte id, the host hands it to every rank by its own means (a file,
+ * a socket, torch.distributed's store), every rank calls ims_comm_init.  ims_reduce_image sums the ranks' f64 CCD images onto
+ * `root` (imsim/lsst_image.py:353-368 summed over the shards); ims_allreduce_delta sums the delta-charge image of photon-pooling
+ * mode onto every rank before a recalculation (imsim/photon_pooling.py:159).  integer_counts != 0: the values are exchanged as
+ * int32 (half the bytes; exact when every value is an integer count and the sum stays below 2^31 -- ims_count_inexact adds the
+ * number of values of a rank's image that are not integer counts below 2^31 / world to *bad_dev). */
+int  ims_fft_inverse(double* kbuf_dev, double* rbuf_dev, int32_t nfft, int64_t batch, void* stream);
+int  ims_comm_unique_id(void* id128);
+int  ims_comm_init(const void* id128, int32_t rank, int32_t world, void** comm_out);
+int  ims_comm_destroy(void* comm);
+int  ims_reduce_image(void* comm, double* image_dev, int32_t* scratch_i32_dev, int64_t n, int32_t root, int32_t integer_counts, void* stream);
+int  ims_allreduce_delta(void* comm, double* delta_dev, int32_t* scratch_i32_dev, int64_t n, int32_t integer_counts, void* stream);
+int  ims_count_inexact(const double* image_dev, int64_t n, int32_t world, unsigned long long* bad_dev, void* stream);
 
 /* ---- launch plans ----
  * The brighter-fatter chain of LSST_Image mode is hundreds of short dependent launches; ims_run_plan

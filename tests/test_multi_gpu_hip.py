@@ -152,3 +152,48 @@ def test_rccl_executes_every_exchange_of_the_path_with_one_rank(tmp_path):
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and "RCCL_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
+
+
+_LIB_RCCL_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+from imsim_amd import parallel
+torch.cuda.set_device(0)
+comm = parallel.LibraryComm(0, 1, "cuda:0")                            # ims_comm_unique_id + ims_comm_init inside libimsim_hip.so
+parallel.install(comm)
+assert parallel.exchanging(1)
+g = torch.Generator(device="cuda"); g.manual_seed(3)
+counts = torch.randint(0, 70000, (4096, 4096), device="cuda", generator=g).to(torch.float64)
+want = counts.clone()
+assert comm.count_inexact(counts) == 0
+parallel.reduce_image(counts, dst=0, integer_counts=True)              # f64 -> int32, ncclReduce, -> f64, all in the library
+assert torch.equal(counts, want)
+bad = counts.clone(); bad[5, 7] = 0.5; bad[9, 9] = 3.0e9; bad[1, 1] = -1.0
+assert comm.count_inexact(bad) == 3
+real = torch.rand((512, 512), dtype=torch.float64, device="cuda", generator=g) * 3.7
+want = real.clone()
+parallel.reduce_image(real, dst=0)                                     # f64 ncclReduce
+assert torch.equal(real, want)
+delta = torch.randint(0, 500, (1025 * 1025,), device="cuda", generator=g).to(torch.float64)
+want = delta.clone()
+parallel.allreduce_delta(delta, integer_counts=True)                   # int32 ncclAllReduce
+parallel.allreduce_delta(delta)                                        # f64 ncclAllReduce
+assert torch.equal(delta, want)
+torch.cuda.synchronize()
+parallel.install(None)
+comm.destroy()
+print("LIB_RCCL_OK")
+"""
+
+
+def test_the_librarys_own_rccl_communicator_runs_every_exchange_with_one_rank(tmp_path):
+    """SURVEY 8(b) lists the exchanges in the C-ABI: ims_comm_unique_id / ims_comm_init / ims_reduce_image /
+    ims_allreduce_delta / ims_count_inexact call RCCL from inside libimsim_hip.so (looked up at run time, the copy torch
+    loaded), no torch.distributed in the data path.  One rank, self-exchanges: the int32 and f64 forms of both collectives
+    leave the data as it was, the exactness check counts what an int32 exchange would not carry."""
+    script = tmp_path / "lib_rccl_one_rank.py"
+    script.write_text(_LIB_RCCL_SCRIPT)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "LIB_RCCL_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]

@@ -182,13 +182,22 @@ def main():
     if world > 1 or one_rank_rccl:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if share_gpu:
+        # IMS_COMM=lib (default): the exchanges of the path run on the library's own RCCL communicator (ims_comm_init /
+        # ims_reduce_image / ims_allreduce_delta inside libimsim_hip.so); torch.distributed over gloo only carries the 128-byte
+        # id, the barriers and the MAX of the timing.  IMS_COMM=torch: torch.distributed's nccl backend does the exchanges (the
+        # checker; the form of rounds 1 - 3).
+        use_lib_comm = os.environ.get("IMS_COMM", "lib") == "lib" and not share_gpu
+        if share_gpu or use_lib_comm:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if use_lib_comm:
+            lib_comm = parallel.LibraryComm(rank, world, device)
+            parallel.install(lib_comm)
 
     step = cfg["make_step"](renderer, objects, rank, world)
     lib = _abi.load()
+    ctl_device = "cpu" if (dist.is_initialized() and dist.get_backend() == "gloo") else device
 
     unit_flux = parallel.unit_flux_path(scene, objects)
 
@@ -202,6 +211,17 @@ def main():
     for _ in range(args.warmup):
         full_step()
     torch.cuda.synchronize()
+    if (world > 1 or one_rank_rccl) and unit_flux and cfg.get("reduce", True):
+        # the int32 exchange is exact only if EVERY rank's own image is an integer count below 2^31 / world: checked once on the
+        # per-rank images (before any reduce touches them), outside the timed region, the verdict agreed by all ranks
+        renderer.image.zero_()
+        step()
+        torch.cuda.synchronize()
+        ok = parallel.integer_counts_ok(renderer.image, world)
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=ctl_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) != 1.0:
+            raise RuntimeError("bench.py: a rank's CCD image is not an integer count below 2^31 / world -- int32 exchange invalid")
     if world > 1 or one_rank_rccl:
         dist.barrier()
     torch.cuda.synchronize()
@@ -222,7 +242,7 @@ def main():
         if not parallel.integer_counts_ok(renderer.image, 1):
             raise RuntimeError("bench.py: the reduced CCD image is not an integer count below 2^31 -- int32 exchange invalid")
     if world > 1 or one_rank_rccl:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -284,6 +304,9 @@ def main():
         out["shared_gpu"] = True        # dry run: all ranks on ONE GPU over gloo -- not a scaling measurement
     if one_rank_rccl:
         out["rccl_one_rank"] = True     # the step includes the int32 copy and an RCCL self-reduce of the CCD image
+    if world > 1 or one_rank_rccl:
+        out["exchange"] = ("libimsim_hip.so over RCCL (ims_reduce_image / ims_allreduce_delta)" if parallel._LIBRARY_COMM[0] is not None
+                           else ("torch.distributed " + dist.get_backend()))
 
     if rank == 0 and world == 1 and not args.no_cold and ("cold" in cfg or "end_to_end" in cfg):
         out["extra"] = cfg["cold"](scene, objects, device) if "cold" in cfg else {}

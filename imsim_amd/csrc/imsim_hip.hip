@@ -1834,14 +1834,15 @@ __global__ __launch_bounds__(256) void k_build_object_table(const ims_catalog_t 
     memset(&o, 0, sizeof(o));
     ims_object_meta_t m = { 0, 0, 0 };
     const int kind = C.kind[i];
-    if (kind < 0 || kind > 2) {                       // knots, streaks, FITS stamps: the host writes these rows
-        m.flags = IMS_META_HOST_ROW;
-        rows[i] = o; meta[i] = m;
-        return;
-    }
     const double nominal = C.nominal_flux[i];
     const int64_t id = C.obj_id ? C.obj_id[i] : i;
     const int64_t phot = C.phot_flux ? C.phot_flux[i] : (int64_t)poisson(nominal, C.seed, id, (int64_t)IMS_FLUX_PIXEL);
+    if (kind < 0 || kind > 2) {                       // knots, streaks, FITS stamps: the host writes these rows -- with the photon
+        m.flags = IMS_META_HOST_ROW;                  // count realised HERE, by the rule of every other object (same stream, same seed)
+        m.n_phot = phot;
+        rows[i] = o; meta[i] = m;
+        return;
+    }
     const double x = C.x[i], y = C.y[i];
     o.obj_id = id; o.phot_first = 0; o.n_phot = phot;
     o.x0 = x; o.y0 = y; o.flux_per_photon = 1.0;
@@ -3280,6 +3281,8 @@ int ims_screen_prepass(const ims_render_params_t* params, int32_t comp, int32_t 
         if (q > 0 && S.seg_first[q] - S.seg_first[q - 1] > max_segs) max_segs = S.seg_first[q] - S.seg_first[q - 1];
     }
     if (S.seg_first[0] != 0 || S.seg_first[8] != params->n_segments) return set_err(IMS_ERR_ARG, "slice segment boundaries do not cover the table");
+    // (every argument is checked before the first launch: a refused call leaves nothing enqueued)
+    if (max_slice_photons <= 0 || (max_slice_photons + 255) / 256 * 8 > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "max_slice_photons out of range");
     hipStream_t st = (hipStream_t)stream;
     const int n_bins = 8 * n_buckets;
     unsigned long long* bins = (unsigned long long*)scratch_dev;
@@ -3290,7 +3293,6 @@ int ims_screen_prepass(const ims_render_params_t* params, int32_t comp, int32_t 
     hipLaunchKernelGGL(k_screen_sort<1>, grid, dim3(256), 0, st, *params, comp, n_buckets, S, bins, entries_dev);
     // every slice gets the blocks of the largest one (a block beyond its slice's end leaves at once); the slice boundaries sit
     // behind the bins, whose cursors the scatter has advanced to the bin ends
-    if (max_slice_photons <= 0 || (max_slice_photons + 255) / 256 * 8 > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "max_slice_photons out of range");
     ScreenObject* slim = (ScreenObject*)(scratch_dev + n_bins + 16);
     hipLaunchKernelGGL(k_screen_objects, dim3((unsigned)((params->n_objects + 255) / 256)), dim3(256), 0, st, *params, slim);
     hipLaunchKernelGGL(k_screen_gather, dim3((unsigned)(8 * ((max_slice_photons + 255) / 256))), dim3(256), 0, st,

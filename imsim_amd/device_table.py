@@ -134,14 +134,18 @@ def host_fixups(cat, meta, build_kw):
 
 
 _PINNED = {}
+_PINNED_LOCK = __import__("threading").Lock()       # tables of several CCDs may be built from several host threads (focal plane)
 
 
 def _pinned(torch, nbytes, slot=0):
     """a page-locked staging buffer of at least nbytes, kept for the next table (allocating one costs milliseconds per 10 MB);
     the caller synchronises before the buffer is handed out again (DeviceTable waits for its meta download)"""
-    buf = _PINNED.get(slot)
-    if buf is None or buf.numel() < nbytes:
-        buf = _PINNED[slot] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
+    import threading
+    key = (slot, threading.get_ident())              # one staging buffer per thread: a table being staged is never overwritten
+    with _PINNED_LOCK:
+        buf = _PINNED.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = _PINNED[key] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
     return buf[:nbytes]
 
 
@@ -209,8 +213,9 @@ class DeviceTable:
             # configs.c3_objects), copied over the zeroed rows the kernel left
             from . import configs
             sub = {k: (np.asarray(v)[host] if isinstance(v, np.ndarray) and len(v) == n else v) for k, v in cat.items()}
-            ph = (np.asarray(phot_flux)[host] if phot_flux is not None
-                  else catalog.realize_fluxes(sub["nominal_flux"], renderer.scene.seed)).astype(np.int64)
+            # the photon counts of these rows were realised by the kernel with the counter-based Poisson of every other object
+            # (ims_object_meta_t.n_phot of a HOST_ROW entry): the same flux whichever rows are host rows, on every rank
+            ph = (np.asarray(phot_flux)[host] if phot_flux is not None else meta["n_phot"][host]).astype(np.int64)
             keep = ph > 0
             rows_h = np.zeros(len(host), dtype=OBJECT_DTYPE)
             size_h = np.zeros(len(host), dtype=np.int32)

@@ -1139,6 +1139,8 @@ class Renderer:
                                   # which rewrites every cell of every region every round, is the slower form (C3 41.7 ms)
                                   pair_shift=pair_shift if len(ch["tot"]) <= self.pair_max_objects else 0))
             plan.append(("rounds", descs, int(nrecalc), 1 if self.use_bf_tags else 0))
+            if n_events - self._event_block > 1000 or n_events >= self.PREPASS_EVENT:
+                raise ValueError("a plan may use at most 1000 library events (its renderer's block)")
         if len(normal) and not render_done:
             part = objects[normal]
             part["bf_state"] = 0
@@ -1341,7 +1343,9 @@ class Renderer:
         n_phot = sub["n_phot"].astype(np.int64)
         cum = np.concatenate([[0], np.cumsum(n_phot)]).astype(np.int64)
         total = int(cum[-1])
-        if total == 0 or int(n_phot.max()) >= 2 ** 31 or len(sub) >= 2 ** 31:
+        # an entry of the sort packs the photon's index in its object's stream (phot_first + j) into 32 bits
+        if (total == 0 or int(n_phot.max()) >= 2 ** 31 or len(sub) >= 2 ** 31
+                or int((sub["phot_first"].astype(np.int64) + n_phot).max()) >= 2 ** 32 or int(sub["phot_first"].min()) < 0):
             return objects, None
         sub["screen_base"] = cum[:-1] - sub["phot_first"]
         objects["screen_base"][covered] = sub["screen_base"]

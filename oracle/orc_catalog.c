@@ -39,10 +39,10 @@ int orc_build_object_table(const ims_catalog_t* C, const ims_optics_t* optics, i
         ims_object_meta_t m = { 0, 0, 0 };
         memset(&o, 0, sizeof(o));
         int kind = C->kind[i];
-        if (kind < 0 || kind > 2) { m.flags = IMS_META_HOST_ROW; rows[i] = o; meta[i] = m; continue; }
         double nominal = C->nominal_flux[i];
         int64_t id = C->obj_id ? C->obj_id[i] : i;
         int64_t phot = C->phot_flux ? C->phot_flux[i] : (int64_t)orc_poisson(nominal, C->seed, id, (int64_t)IMS_FLUX_PIXEL);
+        if (kind < 0 || kind > 2) { m.flags = IMS_META_HOST_ROW; m.n_phot = phot; rows[i] = o; meta[i] = m; continue; }
         double x = C->x[i], y = C->y[i];
         o.obj_id = id; o.n_phot = phot; o.x0 = x; o.y0 = y; o.flux_per_photon = 1.0;
         double j0 = 1.0, j1 = 0.0, j2 = 0.0, j3 = 1.0;

@@ -202,3 +202,25 @@ def test_the_ctypes_stub_of_integration_md_loads_the_library():
     header = open(os.path.join(ROOT, "include", "imsim_hip.h")).read()
     assert f"#define IMS_ABI_VERSION {scope['lib'].ims_abi_version()}" in header
     assert C.sizeof(scope["ImsObject"]) == 256
+
+
+def test_the_dpp_hazard_check_follows_labels_and_branches(tmp_path):
+    """tools/check_dpp_hazard.py on hand-made assembly: a VALU write of the DPP source one instruction above a label is a
+    hazard on the fall-through path, so is one in front of a branch that names the label; enough s_nop clears both."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_dpp_hazard
+
+    def run(text):
+        f = tmp_path / "k.s"
+        f.write_text(text)
+        return check_dpp_hazard.check(str(f))
+    fall = "\tv_mov_b32 v2, v9\n.LBB0_1:\n\tv_fmac_f64_dpp v[4:5], v[2:3], v[6:7] row_newbcast:1\n"
+    assert len(run(fall)[1]) == 1
+    assert len(run("\tv_mov_b32 v2, v9\n\ts_nop 1\n.LBB0_1:\n\tv_fmac_f64_dpp v[4:5], v[2:3], v[6:7] row_newbcast:1\n")[1]) == 0
+    jump = ("\tv_mov_b32 v3, v9\n\ts_cbranch_vccnz .LBB0_2\n\ts_nop 4\n\ts_branch .LBB0_3\n.LBB0_2:\n"
+            "\tv_fmac_f64_dpp v[4:5], v[2:3], v[6:7] row_newbcast:1\n.LBB0_3:\n\ts_endpgm\n")
+    n, bad = run(jump)
+    assert n == 1 and len(bad) == 1 and "2 wait states" in bad[0][4]
+    assert len(run(jump.replace("\ts_cbranch_vccnz", "\ts_nop 0\n\ts_cbranch_vccnz"))[1]) == 0
+    assert len(run("\tv_cmpx_gt_u32 v1, v0\n\ts_nop 2\n.LBB0_1:\n\tv_fmac_f64_dpp v[4:5], v[2:3], v[6:7] row_newbcast:1\n")[1]) == 1

@@ -236,7 +236,7 @@ class PlanSizes(C.Structure):
     _fields_ = [("arena_bytes", c_i64), ("rows_bytes", c_i64), ("pool_photons", c_i64), ("realized_count", c_i64),
                 ("n_groups", c_i32), ("n_events", c_i32), ("n_render_launches", c_i64), ("render_photons", c_i64),
                 ("render_rows", c_i64), ("render_segments", c_i64), ("n_shoot_launches", c_i64), ("shoot_photons", c_i64),
-                ("shoot_rows", c_i64), ("shoot_segments", c_i64), ("chain_rows", c_i64), ("n_objects", c_i64)]
+                ("shoot_rows", c_i64), ("shoot_segments", c_i64), ("chain_rows", c_i64), ("n_objects", c_i64), ("n_round_launches", c_i64)]
 
 
 STRUCTS = [Object, RadialTables, LinTables, PsfComponent, Op, Surface, TanSip, Optics, BfSlot, Sensor, Photons,

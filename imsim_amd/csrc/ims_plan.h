@@ -285,6 +285,7 @@ static int build(Plan& pl)
             }
             ch.launch = make_launch(pl, 2, gi, sel, first, count, bf, &start_off, true);
             sz.chain_rows += cb - ca;
+            sz.n_round_launches += ch.n_rounds;                 // one pixel-search launch per round of the class
         }
         Step s;
         s.kind = IMS_PLAN_ROUNDS; s.stream = 0; s.chain_begin = 0; s.n_chains = n_classes;

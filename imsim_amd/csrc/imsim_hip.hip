@@ -2265,6 +2265,7 @@ int ims_accumulate_round(const ims_render_params_t* params, const ims_photons_t*
     if ((int64_t)n_active * segs > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "too many workgroups for one round");
     const dim3 grid((unsigned)(n_active * segs));
     const int64_t first = (int64_t)round * nrecalc;
+    LaunchTimer tm((hipStream_t)stream, 4);
     if (num_vertices == 4)
         hipLaunchKernelGGL(k_accumulate_round<4>, grid, dim3(256), 0, (hipStream_t)stream, *params, *pool, pool_start, first, nrecalc, segs);
     else if (num_vertices == 8)

@@ -1431,9 +1431,13 @@ class Renderer:
             launch.pool_photons = int(z.shoot_photons)
             has_screens = self.scene.atm is not None and any(int(c[0]) == _abi.IMS_PSF_SCREENS for c in self.scene.psf)
             scr = 96 if has_screens else 0
+            # 4: the pixel search of the brighter-fatter rounds -- every pooled photon once: its 32-byte pool record read, the
+            # 16-byte read-modify-write of the f64 image (the bounds line and polygon points it gathers are sensor state, not
+            # counted: they are what the counter traffic shows on top)
             launch.timed = {1: (int(z.n_render_launches), int(z.render_photons * (16 + scr) + z.render_rows * 256)),
-                            2: (int(z.n_shoot_launches), int(z.shoot_photons * (32 + scr) + z.shoot_rows * 256))}
-            launch.timed_waves = {1: 4 * int(z.render_segments), 2: 4 * int(z.shoot_segments)}
+                            2: (int(z.n_shoot_launches), int(z.shoot_photons * (32 + scr) + z.shoot_rows * 256)),
+                            4: (int(z.n_round_launches), int(z.shoot_photons * 48))}
+            launch.timed_waves = {1: 4 * int(z.render_segments), 2: 4 * int(z.shoot_segments), 4: 4 * int((z.shoot_photons + 255) // 256)}
             return launch
         objects, prepass = self.screen_prepass(objects, nrecalc)
         try:

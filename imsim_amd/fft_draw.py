@@ -306,6 +306,9 @@ class FftDrawer:
         # takes torch.fft instead -- the same library behind another front end, kept as the checker
         import os
         use_torch = os.environ.get("IMS_FFT_TORCH", "0") != "0"
+        kspace = kbuf
+        if getattr(self, "keep_kspace", False):
+            kspace = kbuf.clone()                     # hipFFT's complex-to-real transform uses its input as work space
         for size in np.unique(nfft):
             sel = np.flatnonzero(nfft == size)
             a, b = int(sel[0]), int(sel[-1]) + 1
@@ -329,4 +332,4 @@ class FftDrawer:
         _abi.check(r.lib.ims_fft_finish(C.byref(P), obj_t.data_ptr(), n, rpre_t.data_ptr(), int(rpre[-1]),
                                         final.data_ptr(), st), "ims_fft_finish")
         self._last = (kbuf, rbuf, final, obj_t, kpre_t, rpre_t)
-        return kbuf, rbuf
+        return kspace, rbuf

@@ -179,8 +179,13 @@ class SiliconSensor:
         """setup: engine.SensorSetup for the image region (configs.silicon_setup); has_angles: the photons' dxdz / dydz are
         meaningful (they went through a ray-tracing operator)"""
         from .engine import Scene
-        ops = [(_abi.IMS_OP_RUBIN_OPTICS, 0, [0.0, 0.0])] if has_angles else []       # accumulate only asks "is there a ray trace"
-        self.scene = Scene(nx=nx, ny=ny, xmin=xmin, ymin=ymin, seed=0, psf=[], ops=ops, sensor=setup)
+        # accumulate only asks "did the photons go through a ray trace" (then dxdz / dydz carry their inclination into the silicon):
+        # the operator is named, with a telescope descriptor as the library's argument check wants one, and never applied
+        ops, optics = [], None
+        if has_angles:
+            from . import configs
+            ops, optics = [(_abi.IMS_OP_RUBIN_OPTICS, 0, [0.0, 0.0])], configs.rubin_optics_struct(nx, ny)
+        self.scene = Scene(nx=nx, ny=ny, xmin=xmin, ymin=ymin, seed=0, psf=[], ops=ops, sensor=setup, optics=optics)
         self.scene.track_static_delta = 1
         self.device, self.obj_id = device, int(obj_id)
         self._renderer = None

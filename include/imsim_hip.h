@@ -754,6 +754,7 @@ typedef struct ims_plan_sizes {
     int64_t n_render_launches, render_photons, render_rows, render_segments;
     int64_t n_shoot_launches, shoot_photons, shoot_rows, shoot_segments;
     int64_t chain_rows, n_objects;
+    int64_t n_round_launches;            /* ims_accumulate_round launches of one run (one per round and chain class) */
 } ims_plan_sizes_t;
 int  ims_plan_lsst_image(const ims_plan_input_t* in, void** plan_out, ims_plan_sizes_t* sizes);
 /* base: the scene's launch parameters (tables, PSF, operators, optics, sensor, image, nx .. ymin; objects / seg_* are ignored).
@@ -846,7 +847,7 @@ int  ims_image_to_float(const double* src, float* dst, int64_t n, void* stream);
 /* ---- timing of the dominant kernel ----
  * After ims_enable_timing(which) every launch of the selected kernel is bracketed by a hipEvent pair on its
  * stream: which = 1 k_shoot_accumulate (ims_shoot_accumulate), 2 k_shoot_photons<true> (ims_shoot_ops_photons),
- * 0 = off.  ims_last_kernel_ms returns the SUM of their durations and their count since the last query
+ * 4 k_accumulate_round (the pixel search of a brighter-fatter round), 0 = off.  ims_last_kernel_ms returns the SUM of their durations and their count since the last query
  * (and resets the accumulation). */
 int  ims_last_kernel_ms(float* ms, int* n_launches);
 int  ims_enable_timing(int which);

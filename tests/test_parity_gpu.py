@@ -688,6 +688,7 @@ def test_fft_branch_matches_oracle(torch_cuda):
     scene, rows, kpsf = _fft_case()
     r = Renderer(scene)
     drawer = fft_draw.FftDrawer(r, kpsf, add_noise=True)
+    drawer.keep_kspace = True                      # a copy of the half spectra from before the transform (which works in them)
     real = torch_cuda.zeros(len(rows), dtype=torch_cuda.float64, device="cuda")
     kbuf, rbuf = drawer.draw(rows, realized=real)
     r.synchronize()

@@ -180,7 +180,8 @@ class Chain(C.Structure):
                 ("tile_prefix_host", c_vp), ("n_objects", c_i32), ("first_slot", c_i32), ("stream", c_i32), ("nrecalc", c_i32),
                 ("n_rounds", c_i32), ("use_tags", c_i32), ("ev_base", c_i32), ("n_edges", c_i32),
                 ("edges", c_i32 * IMS_MAX_CHAIN_EDGES), ("pair_shift", c_i32), ("pad", c_i32),
-                ("pair_tile_prefix", c_vp), ("pair_tile_prefix_host", c_vp)]
+                ("pair_tile_prefix", c_vp), ("pair_tile_prefix_host", c_vp), ("n_marks", c_i32), ("pad3", c_i32),
+                ("mark_round", c_i32 * IMS_MAX_CHAIN_EDGES), ("mark_event", c_i32 * IMS_MAX_CHAIN_EDGES)]
 
 
 class Catalog(C.Structure):
@@ -229,7 +230,7 @@ class PlanInput(C.Structure):
     _fields_ = [("n", c_i64), ("row", c_vp), ("n_phot", c_vp), ("stamp", c_vp), ("faint", c_vp), ("nrecalc", c_i32),
                 ("n_class_rounds", c_i32), ("class_rounds", c_i32 * 4), ("n_static_slots", c_i32), ("slot_capacity", c_i32),
                 ("static_cells", c_i64), ("scratch_cells", c_i64), ("max_pool_photons", c_i64), ("seg_size", c_i32),
-                ("want_realized", c_i32), ("event_base", c_i32), ("use_tags", c_i32)]
+                ("want_realized", c_i32), ("event_base", c_i32), ("use_tags", c_i32), ("head_start", c_i32), ("pad", c_i32)]
 
 
 class PlanSizes(C.Structure):

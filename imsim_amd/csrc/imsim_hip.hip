@@ -2496,6 +2496,9 @@ static int run_rounds(const ims_chain_t* chains, int32_t n_chains, const ims_sen
         if (ch.nrecalc <= 0 || ch.n_rounds < 0 || ch.n_objects < 0 || ch.n_objects > ch.params->n_objects)
             return set_err(IMS_ERR_ARG, "chain: nrecalc / n_rounds / n_objects out of range");
         if (ch.n_edges < 0 || ch.n_edges > IMS_MAX_CHAIN_EDGES) return set_err(IMS_ERR_ARG, "chain: too many edges");
+        if (ch.n_marks < 0 || ch.n_marks > IMS_MAX_CHAIN_EDGES) return set_err(IMS_ERR_ARG, "chain: too many marks");
+        for (int32_t j = 0; j < ch.n_marks; ++j)
+            if (ch.mark_round[j] < 0 || ch.mark_round[j] >= ch.n_rounds) return set_err(IMS_ERR_ARG, "chain: mark beyond the last round");
         for (int32_t k = 1; k < ch.n_objects; ++k)
             if (ch.n_phot[k] > ch.n_phot[k - 1]) return set_err(IMS_ERR_ARG, "chain: objects must be sorted by photon count, brightest first");
         if (ch.n_rounds > max_rounds) max_rounds = ch.n_rounds;
@@ -2513,7 +2516,17 @@ static int run_rounds(const ims_chain_t* chains, int32_t n_chains, const ims_sen
                     HIP_TRY(hipStreamWaitEvent((hipStream_t)st, e, 0));
                 }
             const int32_t n_act = count_above(ch.n_phot, ch.n_objects, (int64_t)r * ch.nrecalc);
-            if (n_act == 0) continue;
+            auto record_marks = [&]() -> int {
+                for (int32_t j = 0; j < ch.n_marks; ++j)
+                    if (ch.mark_round[j] == r) {
+                        hipEvent_t e;
+                        const int rc = plan_event(ch.mark_event[j], &e);
+                        if (rc) return rc;
+                        HIP_TRY(hipEventRecord(e, (hipStream_t)st));
+                    }
+                return IMS_OK;
+            };
+            if (n_act == 0) { const int rcm = record_marks(); if (rcm) return rcm; continue; }
             ims_render_params_t P = *ch.params;
             const bool pairs = ch.pair_shift > 0;                                 // the regions live as slot pairs: two launches per round
             const uint32_t tag = (ch.use_tags && !pairs) ? (uint32_t)(r % 255 + 1) : 0u;   // marks the tiles this round's charge lands in
@@ -2538,6 +2551,8 @@ static int run_rounds(const ims_chain_t* chains, int32_t n_chains, const ims_sen
                                               ch.nrecalc, st);
                 if (rc) return rc;
             }
+            rc = record_marks();
+            if (rc) return rc;
         }
     }
     return IMS_OK;
@@ -2658,6 +2673,8 @@ int ims_plan_bind(void* plan, const ims_render_params_t* base, void* arena_host,
             cs.n_objects = (int32_t)ch.n_phot.size(); cs.first_slot = ch.first_slot; cs.stream = ch.stream; cs.nrecalc = pl->in.nrecalc;
             cs.n_rounds = ch.n_rounds; cs.use_tags = pl->in.use_tags; cs.ev_base = ch.ev_base; cs.n_edges = (int32_t)ch.edges.size();
             for (size_t k = 0; k < ch.edges.size(); ++k) cs.edges[k] = ch.edges[k];
+            cs.n_marks = (int32_t)ch.mark_round.size();
+            for (size_t k = 0; k < ch.mark_round.size(); ++k) { cs.mark_round[k] = ch.mark_round[k]; cs.mark_event[k] = ch.mark_event[k]; }
         }
         g.items.assign(g.steps.size(), ims_plan_item_t());
         for (size_t k = 0; k < g.steps.size(); ++k) {
@@ -2672,6 +2689,7 @@ int ims_plan_bind(void* plan, const ims_render_params_t* base, void* arena_host,
             case IMS_PLAN_INIT:
                 it.first_slot = s.first_slot; it.n_slots = s.n_slots; it.aux = (const int64_t*)dev(s.off_tile_prefix); it.n_tiles = s.n_tiles; break;
             case IMS_PLAN_RECORD: it.n_slots = s.event; break;
+            case IMS_PLAN_WAIT: it.n_slots = s.event; break;
             case IMS_PLAN_ROUNDS: it.n_slots = s.n_chains; it.aux2 = g.chain_structs.data() + s.chain_begin; break;
             default: return set_err(IMS_ERR_ARG, "planner: unexpected step kind");
             }

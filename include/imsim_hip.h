@@ -695,6 +695,13 @@ typedef struct ims_chain {
     int32_t pair_shift, pad;
     const int64_t* pair_tile_prefix;      /* device: prefix sum of the 15x15-cell tiles of the slots first_slot.. (the fused launch) */
     const int64_t* pair_tile_prefix_host; /* HOST copy */
+    /* Marks: after the launches of round mark_round[j] the chain's stream records library event mark_event[j] (n_marks <=
+     * IMS_MAX_CHAIN_EDGES).  The planner uses them to hold the bulk stream's next pool slice of the top class until the chain
+     * has consumed the previous one (IMS_PLAN_WAIT on the bulk stream): the wide early rounds of the longest chains then run
+     * beside nothing instead of beside photon kernels that hold every wave slot. */
+    int32_t n_marks, pad3;
+    int32_t mark_round[IMS_MAX_CHAIN_EDGES];
+    int32_t mark_event[IMS_MAX_CHAIN_EDGES];
 } ims_chain_t;
 
 typedef struct ims_plan_item {
@@ -744,6 +751,9 @@ typedef struct ims_plan_input {
     int32_t n_static_slots, slot_capacity;
     int64_t static_cells, scratch_cells, max_pool_photons;
     int32_t seg_size, want_realized, event_base, use_tags;
+    int32_t head_start;                  /* 1: the pool slices of the top chain class wait for the chain to consume the slice before
+                                            (the chain's wide early rounds run alone); 0: all slices back to back */
+    int32_t pad;
 } ims_plan_input_t;
 typedef struct ims_plan_sizes {
     int64_t arena_bytes;                 /* tables of the plan (host image, page-locked by the caller, and its device copy) */

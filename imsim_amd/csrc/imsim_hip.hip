@@ -356,13 +356,13 @@ __global__ __launch_bounds__(256) void k_accumulate(const ims_render_params_t P,
 // the photon (already through the op chain AND the boundary-independent half of the sensor step: the
 // `converted` pool format) is loaded from the pool at pool_start[object] + j.
 // One workgroup = the photons [j0, j0 + 256) of object `oi` (clipped to j_end).
-template <int NV = 0>
+template <int NV = 0, int WG = 256>
 __device__ __forceinline__ void accumulate_segment(const ims_render_params_t& P, const ims_photons_t& pool,
                                                    const int64_t* __restrict__ pool_start, int64_t oi, int64_t j0, int64_t j_end)
 {
     const ims_object_t& o = P.objects[oi];
     const int64_t left = j_end - j0;                                            // photons of this segment (>= 1)
-    const int n_thr = left >= 256 ? 256 : ((((int)left + 63) >> 6) << 6);
+    const int n_thr = left >= WG ? WG : ((((int)left + 63) >> 6) << 6);
     if ((int)threadIdx.x >= n_thr) return;                                      // photon-less wavefronts leave at once
     const int64_t j = j0 + threadIdx.x;
     const bool silicon = (P.sensor != nullptr) && (P.sensor->kind == IMS_SENSOR_SILICON);
@@ -469,20 +469,20 @@ __global__ __launch_bounds__(256, (NV == 8) ? 2 : 3) void k_accumulate_small(con
 // the first n_active rows (sorted by photon count, brightest first) are the objects that reach this round.
 // At most 128 VGPRs (4 and 0 vertices; 8 needs the whole file): the rounds share the GPU with the 128-VGPR photon kernels,
 // and a wave that needs 136 registers only starts where TWO of those have left a SIMD (measured: the rounds 4 x slower).
-template <int NV>
-__global__ __launch_bounds__(256, (NV == 8) ? 2 : 4) void k_accumulate_round(const ims_render_params_t P, const ims_photons_t pool,
+template <int NV, int WG = 256>
+__global__ __launch_bounds__(WG, (NV == 8) ? 2 : 4) void k_accumulate_round(const ims_render_params_t P, const ims_photons_t pool,
                                                           const int64_t* __restrict__ pool_start, int64_t round_first, int32_t nrecalc,
                                                           int32_t segs)
 {
     PROBE(0);
     PROBE_WG(0, 0);
     const int64_t oi = blockIdx.x / segs;
-    const int64_t j0 = round_first + (int64_t)(blockIdx.x % segs) * 256;
+    const int64_t j0 = round_first + (int64_t)(blockIdx.x % segs) * WG;
     int64_t j_end = round_first + nrecalc;
     const int64_t n = P.objects[oi].n_phot;
     if (j_end > n) j_end = n;
     if (j0 >= j_end) return;
-    accumulate_segment<NV>(P, pool, pool_start, oi, j0, j_end);
+    accumulate_segment<NV, WG>(P, pool, pool_start, oi, j0, j_end);
 }
 
 // Which slot of a range does block b work on: the last k with prefix[k] <= b (prefix = ascending tile offsets of the slots,
@@ -2261,6 +2261,21 @@ int ims_accumulate_round(const ims_render_params_t* params, const ims_photons_t*
     if (round < 0 || nrecalc <= 0) return set_err(IMS_ERR_ARG, "round must be >= 0 and nrecalc positive");
     if (n_active < 0 || n_active > params->n_objects) return set_err(IMS_ERR_ARG, "n_active out of range");
     if (n_active == 0) return IMS_OK;
+    // IMS_ROUND_WG=64: one wavefront per workgroup.  A 256-thread workgroup starts only where a compute unit has a free register
+    // slot on each of its four SIMDs at the same moment; beside the photon kernels (five 96-register wavefronts per SIMD, 32
+    // registers left) such a place appears when four photon wavefronts of one unit happen to end together, and the pixel
+    // search of a round waited ~220 us for it (kernel trace).  A one-wavefront workgroup takes ANY single
+    // slot a finished photon wavefront leaves -- slots the photon kernels' own 256-thread workgroups cannot use yet.
+    static const int round_wg = getenv("IMS_ROUND_WG") ? atoi(getenv("IMS_ROUND_WG")) : 64;
+    if (round_wg == 64 && num_vertices == 4) {
+        const int32_t segs64 = (nrecalc + 63) / 64;
+        if ((int64_t)n_active * segs64 > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "too many workgroups for one round");
+        LaunchTimer tm((hipStream_t)stream, 4);
+        hipLaunchKernelGGL((k_accumulate_round<4, 64>), dim3((unsigned)(n_active * segs64)), dim3(64), 0, (hipStream_t)stream, *params, *pool,
+                           pool_start, (int64_t)round * nrecalc, nrecalc, segs64);
+        HIP_TRY(hipGetLastError());
+        return IMS_OK;
+    }
     const int32_t segs = (nrecalc + 255) / 256;
     if ((int64_t)n_active * segs > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "too many workgroups for one round");
     const dim3 grid((unsigned)(n_active * segs));

@@ -88,12 +88,13 @@ def _stats(scene, ref):
 def test_ray_traced_spikes_match_the_references_stored_statistics(exptime):
     """Centre, spike angle (at exptime 300 s it carries the field rotation) and the 1 / r^2 law hold for the nominal pupil
     (PupilAnnulusSampler 2.55 .. 4.18 as in the reference's config).  The spread of the folded angle and the
-    intercept are reproduced once the two rim zones of the pupil do not reach the detector: in the reference's batoid
-    model the surfaces behind M1 clip them, so the isotropic light diffracted at the inner and outer pupil edges
-    (62 % of the light beyond 10 pixels for the bare annulus) is absent from its image and the struts dominate; the
-    approximate prescription shipped here (optics.rubin_like_telescope; the real LSST_r.yaml is external data) clips
-    nothing behind M1.  Sampling the pupil 2 cm inside both rims emulates that clipping and then ALL five stored
-    statistics are met under the reference's own tolerances -- which pins the strut geometry, the kick law
+    intercept are reproduced once the two rim zones of the pupil do not contribute: the isotropic light diffracted at the inner
+    and outer pupil edges (62 % of the light that DIFFRACTION puts beyond 10 pixels -- itself ~0.65 % of the star's photons)
+    is weaker in the reference's image than in this build's, where the struts then dominate.  What removes it in the reference
+    is not established: by the public design values no surface behind M1 clips the on-axis beam of the rims (DESIGN.md 8,
+    round 4), and the prescription itself (LSST_r.yaml) is external data.  Sampling the pupil 2 cm inside both rims emulates
+    the reference's image and then ALL five stored statistics are met under its own tolerances -- which pins the strut geometry,
+    the kick law
     phi* = atan(lambda / 4 pi delta) through the ray trace, the plate scale and the field-rotation rate."""
     ref = np.load(os.path.join(GOLD, f"raytrace_diffraction_values_{int(exptime)}_exptime.npz"))
     c, angle, angle_std, (slope, intercept, slope_err, intercept_err) = _stats(_scene(exptime), ref)

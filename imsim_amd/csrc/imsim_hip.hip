@@ -2266,7 +2266,10 @@ int ims_accumulate_round(const ims_render_params_t* params, const ims_photons_t*
     // registers left) such a place appears when four photon wavefronts of one unit happen to end together, and the pixel
     // search of a round waited ~220 us for it (kernel trace).  A one-wavefront workgroup takes ANY single
     // slot a finished photon wavefront leaves -- slots the photon kernels' own 256-thread workgroups cannot use yet.
-    static const int round_wg = getenv("IMS_ROUND_WG") ? atoi(getenv("IMS_ROUND_WG")) : 64;
+    // Measured (tools/dbg/r4_wg64.sh): the 220 us wait in front of the kernel disappears, the chain's wide rounds run faster --
+    // and the photon kernels lose what the chain gains: C3 24.0 -> 25.8 ms, C3b 33.4 -> 34.8, one star alone 38.7 -> 37.0 us per
+    // round.  The step is bound by the wave slots all kernels need together, not by who gets them first: 256 stays the default.
+    static const int round_wg = getenv("IMS_ROUND_WG") ? atoi(getenv("IMS_ROUND_WG")) : 256;
     if (round_wg == 64 && num_vertices == 4) {
         const int32_t segs64 = (nrecalc + 63) / 64;
         if ((int64_t)n_active * segs64 > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "too many workgroups for one round");

@@ -172,8 +172,12 @@ def _phot_stamp_size1(n0, xvalue, keep_sb_level, nmax, pixel_scale=PIXEL_SCALE, 
 
 def _edge_max(fn, h):
     """max over the 4 edge midpoints and 4 corners of the square of half-width h (stamp_utils.py:327-331)"""
-    pts = ((h, 0 * h), (-h, 0 * h), (0 * h, h), (0 * h, -h), (h, h), (h, -h), (-h, h), (-h, -h))
-    return np.max([fn(x, y) for x, y in pts], axis=0)
+    # the eight points in ONE call ([8][n] arrays broadcast against the per-object parameters): same elementwise arithmetic,
+    # an eighth of the numpy calls (the surface-brightness loop of the bright galaxies was 4 of the 6 ms of a device table build)
+    z = 0 * h
+    xs = np.stack([h, -h, z, z, h, h, -h, -h])
+    ys = np.stack([z, z, h, -h, h, -h, h, -h])
+    return np.max(fn(xs, ys), axis=0)
 
 
 def double_gaussian_xvalue(x, y, fwhm1=0.6, fwhm2=0.12, wgt1=1.0, wgt2=0.1):

@@ -485,6 +485,42 @@ __global__ __launch_bounds__(WG, (NV == 8) ? 2 : 4) void k_accumulate_round(cons
     accumulate_segment<NV, WG>(P, pool, pool_start, oi, j0, j_end);
 }
 
+// The same with a COMPACT argument block: the pixel search reads a dozen fields of the 1.4-KB launch parameters (object table,
+// sensor, image and its bounds, the realized-flux array, the tile tag and slot shift) and four pointers of the pool.  A chain is
+// thousands of launches, and HIP's kernel-argument pool holds only so many 1.4-KB blocks: with it full the host enqueues at the
+// GPU's pace (25 us of host time per round of a long chain measured) -- which bounds a focal plane of CCDs with long chains.
+// The kernel rebuilds the two descriptors in registers (the unused fields vanish), so the body is the one above.
+struct RoundArgs {
+    const ims_object_t* objects;
+    const ims_sensor_t* sensor;
+    double* image;
+    double* realized_flux;
+    const double *px, *py, *pflux, *pz;
+    int32_t nx, ny, xmin, ymin;
+    uint32_t bf_tag, bf_slot_shift;
+    int32_t track_static_delta, pad;
+};
+
+template <int NV, int WG = 256>
+__global__ __launch_bounds__(WG, (NV == 8) ? 2 : 4) void k_accumulate_round_c(const RoundArgs a, const int64_t* __restrict__ pool_start,
+                                                          int64_t round_first, int32_t nrecalc, int32_t segs)
+{
+    ims_render_params_t P;
+    P.objects = a.objects; P.sensor = a.sensor; P.image = a.image; P.realized_flux = a.realized_flux;
+    P.nx = a.nx; P.ny = a.ny; P.xmin = a.xmin; P.ymin = a.ymin;
+    P.bf_tag = a.bf_tag; P.bf_slot_shift = a.bf_slot_shift; P.track_static_delta = a.track_static_delta;
+    ims_photons_t pool;
+    pool.x = const_cast<double*>(a.px); pool.y = const_cast<double*>(a.py); pool.flux = const_cast<double*>(a.pflux);
+    pool.dxdz = const_cast<double*>(a.pz);
+    const int64_t oi = blockIdx.x / segs;
+    const int64_t j0 = round_first + (int64_t)(blockIdx.x % segs) * WG;
+    int64_t j_end = round_first + nrecalc;
+    const int64_t n = P.objects[oi].n_phot;
+    if (j_end > n) j_end = n;
+    if (j0 >= j_end) return;
+    accumulate_segment<NV, WG>(P, pool, pool_start, oi, j0, j_end);
+}
+
 // Which slot of a range does block b work on: the last k with prefix[k] <= b (prefix = ascending tile offsets of the slots,
 // prefix[0] = 0).  A bisection is log2(n) DEPENDENT loads at the head of every tile kernel -- 6 for the 41 regions of the
 // long chains, 11 for the 1 550 of the middle class, each a cold-L2 round trip of ~1.4 us in a kernel that runs for 6 - 30 us.
@@ -2294,6 +2330,30 @@ int ims_accumulate_round(const ims_render_params_t* params, const ims_photons_t*
     return IMS_OK;
 }
 
+// ims_accumulate_round launched with the compact argument block (4 vertices per edge, 256-thread workgroups)
+static int accumulate_round_compact(const ims_render_params_t* params, const ims_photons_t* pool, const int64_t* pool_start, int32_t round,
+                                    int32_t nrecalc, int32_t n_active, int32_t num_vertices, void* stream)
+{
+    if (n_active == 0) return IMS_OK;
+    static const int round_wg = getenv("IMS_ROUND_WG") ? atoi(getenv("IMS_ROUND_WG")) : 256;
+    static const bool compact = os_getenv_off("IMS_ROUND_COMPACT");
+    if (num_vertices != 4 || round_wg == 64 || !compact)
+        return ims_accumulate_round(params, pool, pool_start, round, nrecalc, n_active, num_vertices, stream);
+    if (!params || !params->objects || !params->image || !pool || !pool_start || !pool->converted) return set_err(IMS_ERR_ARG, "NULL argument");
+    const int32_t segs = (nrecalc + 255) / 256;
+    if ((int64_t)n_active * segs > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "too many workgroups for one round");
+    RoundArgs a;
+    a.objects = params->objects; a.sensor = params->sensor; a.image = params->image; a.realized_flux = params->realized_flux;
+    a.px = pool->x; a.py = pool->y; a.pflux = pool->flux; a.pz = pool->dxdz;
+    a.nx = params->nx; a.ny = params->ny; a.xmin = params->xmin; a.ymin = params->ymin;
+    a.bf_tag = params->bf_tag; a.bf_slot_shift = params->bf_slot_shift; a.track_static_delta = params->track_static_delta; a.pad = 0;
+    LaunchTimer tm((hipStream_t)stream, 4);
+    hipLaunchKernelGGL((k_accumulate_round_c<4, 256>), dim3((unsigned)(n_active * segs)), dim3(256), 0, (hipStream_t)stream, a, pool_start,
+                       (int64_t)round * nrecalc, nrecalc, segs);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
 static unsigned grid_for_pool(int64_t n)
 {
     int64_t blocks = (n + 255) / 256;
@@ -2545,13 +2605,13 @@ static int run_rounds(const ims_chain_t* chains, int32_t n_chains, const ims_sen
                 return IMS_OK;
             };
             if (n_act == 0) { const int rcm = record_marks(); if (rcm) return rcm; continue; }
-            ims_render_params_t P = *ch.params;
             const bool pairs = ch.pair_shift > 0;                                 // the regions live as slot pairs: two launches per round
             const uint32_t tag = (ch.use_tags && !pairs) ? (uint32_t)(r % 255 + 1) : 0u;   // marks the tiles this round's charge lands in
+            // (the varying fields are set in a copy that is only read on the host: the launch takes the compact argument block)
+            ims_render_params_t P = *ch.params;
             P.bf_tag = tag;
             P.bf_slot_shift = pairs ? (uint32_t)((r & 1) * ch.pair_shift) : 0u;
-            int rc = ims_accumulate_round(&P, ch.pool, ch.pool_start, r, ch.nrecalc, n_act,
-                                          sensor_host ? sensor_host->num_vertices : 0, st);
+            int rc = accumulate_round_compact(&P, ch.pool, ch.pool_start, r, ch.nrecalc, n_act, sensor_host ? sensor_host->num_vertices : 0, st);
             if (rc) return rc;
             const int32_t n_cont = count_above(ch.n_phot, ch.n_objects, (int64_t)(r + 1) * ch.nrecalc);
             if (n_cont > 0) {
@@ -2684,6 +2744,7 @@ int ims_plan_bind(void* plan, const ims_render_params_t* base, void* arena_host,
             std::memset(&cs, 0, sizeof(cs));
             const Launch& L = pl->launches[ch.launch];
             cs.params = &L.P; cs.pool = &g.pool;
+
             cs.pool_start = (const int64_t*)dev(L.off_pool);
             cs.n_phot = ch.n_phot.data();
             cs.tile_prefix = (const int64_t*)dev(ch.off_tile_prefix);

@@ -581,6 +581,10 @@ def c5_bright_tail(cat, det, k=C5_BRIGHT_PER_CCD):
 
 
 def _c5_catalog(n_objects, scene, n_ccd=None, bright=C5_BRIGHT_PER_CCD):
+    if n_ccd is None and os.environ.get("IMS_C5_CCDS"):
+        # a part of the focal plane at the full per-CCD workload (kernel traces): the first IMS_C5_CCDS CCDs
+        n_ccd = int(os.environ["IMS_C5_CCDS"])
+        n_objects = n_ccd * (n_objects // N_CCD_FOCAL_PLANE)
     n_ccd = N_CCD_FOCAL_PLANE if n_ccd is None else int(n_ccd)
     per = max(n_objects // n_ccd, 1)
     parts = [c5_bright_tail(catalog.synthetic_catalog(per, seed=20261001 + det, nx=scene.nx, ny=scene.ny), det, bright)

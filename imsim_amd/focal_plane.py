@@ -72,6 +72,7 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
         torch.cuda.set_device(dev)
         scene, work = build(key)               # host work, overlaps with the CCDs still running on the GPU
         anchor = init_on = copy_on = streams[slot]
+        fft_on = None
         top_index = None
         if anchor_role:
             # no stream beside the four plan streams of the device: a fifth would share a hardware queue with one of them
@@ -85,6 +86,10 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
             # the copy on the stream of the wide launches 12 - 14
             init_on = by_role[os.environ.get("IMS_FOCAL_INIT", "bulk")]
             copy_on = by_role[os.environ.get("IMS_FOCAL_COPY", "mid")]
+            # the FFT-drawn objects beside the launch plan, not ahead of it on the top-chain stream (IMS_FOCAL_FFT=top: ahead)
+            fft_on = by_role.get(os.environ.get("IMS_FOCAL_FFT", "mid"))
+            if fft_on is anchor:
+                fft_on = None
         with torch.cuda.stream(init_on):
             renderer = Renderer(scene, dev, stream_roles=roles, top_index=top_index)
             ready = torch.cuda.Event()
@@ -94,7 +99,7 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
             if isinstance(work, lsst_image.CcdJob):
                 if work.nrecalc is None:
                     work.nrecalc = nrecalc
-                lsst_image.draw_job(renderer, work)
+                lsst_image.draw_job(renderer, work, fft_stream=fft_on)
             else:
                 renderer.render_lsst_image(work, nrecalc=nrecalc)
             through = torch.cuda.Event()

@@ -170,28 +170,45 @@ class CcdJob:
         return 0 if self.fft_rows is None else len(self.fft_rows)
 
 
-def draw_job(renderer, job, realized=None):
+def draw_job(renderer, job, realized=None, fft_stream=None):
     """The draw loop of one CCD on the device (imsim/lsst_image.py:342-368 over imsim/stamp.py:411-575), enqueue only: the
     FFT objects first (k-space fill, inverse transforms, spikes, Poisson noise, stamp -> CCD add), then the launch plan of
-    the photon-shot ones, then the optional sky.  realized: f64 device tensor over the kept catalog rows."""
+    the photon-shot ones, then the optional sky.  realized: f64 device tensor over the kept catalog rows.
+
+    fft_stream: a side stream for the FFT objects.  Their stamps carry Poisson noise, so every value added to the f64 CCD image
+    is an integer like the photons' and the image does not depend on the order of the additions: the FFT branch (milliseconds
+    for a 4096^2 stamp with its spike stencil) may then run BESIDE the launch plan instead of ahead of it on the stream that
+    carries a CCD's longest brighter-fatter chain (focal_plane.render_focal_plane); the sky stage waits for both."""
     torch = renderer.torch
     if realized is None and job.want_realized:
         realized = job.realized = torch.zeros(job.n_kept, dtype=torch.float64, device=renderer.device)
+    fft_done = None
     if job.n_fft:
         if job.kpsf is None:
             raise GalSimConfigError("FFT drawing needs the k-space PSF description")
-        drawer = fft_draw.FftDrawer(renderer, job.kpsf, add_noise=True, diffraction_fft=job.diffraction_fft,
-                                    wavelength=job.wavelength, extra_ktables=job.extra_ktables)
-        r_fft = torch.zeros(job.n_fft, dtype=torch.float64, device=renderer.device) if realized is not None else None
-        drawer.draw(job.fft_rows, realized=r_fft)
-        if realized is not None:
-            realized.index_add_(0, torch.from_numpy(np.ascontiguousarray(job.fft_index)).to(renderer.device), r_fft)
+        main = torch.cuda.current_stream(renderer.device)
+        side = fft_stream if (fft_stream is not None and fft_stream != main) else None
+        if side is not None:
+            side.wait_stream(main)                                # the renderer's scene tables and its zeroed image
+        with torch.cuda.stream(side if side is not None else main):
+            drawer = fft_draw.FftDrawer(renderer, job.kpsf, add_noise=True, diffraction_fft=job.diffraction_fft,
+                                        wavelength=job.wavelength, extra_ktables=job.extra_ktables)
+            r_fft = torch.zeros(job.n_fft, dtype=torch.float64, device=renderer.device) if realized is not None else None
+            drawer.draw(job.fft_rows, realized=r_fft)
+            if side is not None:
+                fft_done = torch.cuda.Event()
+                fft_done.record(side)
         renderer._keep_fft = drawer._last + (drawer._keep,)     # the buffers, not the drawer (which refers back to the renderer)
     if len(job.objects):
         r_ph = torch.zeros(len(job.objects), dtype=torch.float64, device=renderer.device) if realized is not None else None
         renderer.render_lsst_image(job.objects, nrecalc=job.nrecalc, realized=r_ph)
         if realized is not None:
             realized.index_add_(0, torch.from_numpy(np.ascontiguousarray(job.phot_index)).to(renderer.device), r_ph)
+    if fft_done is not None:
+        torch.cuda.current_stream(renderer.device).wait_event(fft_done)
+    if job.n_fft and realized is not None:
+        realized.index_add_(0, torch.from_numpy(np.ascontiguousarray(job.fft_index)).to(renderer.device), r_fft)
+        r_fft.record_stream(torch.cuda.current_stream(renderer.device))      # allocated on the side stream, read here
     if job.sky is not None:
         kw = dict(job.sky)
         base = LSST_ImageBuilderBase()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Rebuild profiles/hbm_traffic.json (what bench.py reports as roofline.traffic and uses for the f64-issue fraction) from
-the committed per-config PMC summaries (tools/pmc_summary.py output): the newest of profiles/round3_<config>_hbm_pmc.json, round2e_<config>_hbm_pmc.json
+the committed per-config PMC summaries (tools/pmc_summary.py output): the newest of profiles/round4_<config>_hbm_pmc.json, round3_<config>_hbm_pmc.json, round2e_<config>_hbm_pmc.json
 (end of round 2: converted pool, k_shoot_photons<2>), round2_<config>_hbm_pmc.json and round1_<config>_final_hbm_pmc.json, with
 the SQ pass of the same tag where present."""
 import json
@@ -18,13 +18,16 @@ def short_name(long_name):
         return "k_shoot_photons<true>"
     if n.startswith("k_shoot_photons<2"):
         return "k_shoot_photons<2>"
+    if n.startswith("k_accumulate_round"):
+        return "k_accumulate_round<4>"
     return None
 
 
 def main():
     out = {}
     for cfg in ("c2", "c3", "c3b"):
-        cands = [(f"profiles/round3_{cfg}_hbm_pmc.json", f"profiles/round3_{cfg}_sq_pmc.json"),
+        cands = [(f"profiles/round4_{cfg}_hbm_pmc.json", f"profiles/round4_{cfg}_sq_pmc.json"),
+                 (f"profiles/round3_{cfg}_hbm_pmc.json", f"profiles/round3_{cfg}_sq_pmc.json"),
                  (f"profiles/round2e_{cfg}_hbm_pmc.json", f"profiles/round2e_{cfg}_sq_pmc.json"),
                  (f"profiles/round2_{cfg}_hbm_pmc.json", f"profiles/round2_{cfg}_sq_pmc.json"),
                  (f"profiles/round1_{cfg}_final_hbm_pmc.json", f"profiles/round1_{cfg}_final_sq_pmc.json")]

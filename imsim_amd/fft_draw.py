@@ -291,6 +291,10 @@ class FftDrawer:
         kpre_t, rpre_t = torch.from_numpy(kpre).to(r.device), torch.from_numpy(rpre).to(r.device)
         kbuf = torch.empty(int(kpre[-1]), dtype=torch.complex128, device=r.device)
         rbuf = torch.empty(int(rpre[-1]), dtype=torch.float64, device=r.device)
+        # every buffer of the draw is allocated HERE (under the caller's current stream), so that _run only launches: a run on a
+        # side stream then never allocates there
+        self._spike_bufs = ((torch.empty_like(rbuf), torch.empty(4 * len(rows), dtype=torch.int32, device=r.device))
+                            if self.P.spikes.enabled else None)
         return rows, obj_t, nfft, kpre, rpre, kpre_t, rpre_t, kbuf, rbuf
 
     def _run(self, state, realized):
@@ -325,8 +329,8 @@ class FftDrawer:
         final = rbuf
         if P.spikes.enabled:
             # DiffractionFFT.apply between the clip and the noise (stamp.py:519-522)
-            final = torch.empty_like(rbuf)
-            bbox = torch.empty(4 * n, dtype=torch.int32, device=r.device)
+            final, bbox = self._spike_bufs if getattr(self, "_spike_bufs", None) is not None else (
+                torch.empty_like(rbuf), torch.empty(4 * n, dtype=torch.int32, device=r.device))
             _abi.check(r.lib.ims_fft_spikes(C.byref(P), obj_t.data_ptr(), n, rpre_t.data_ptr(), int(rpre[-1]),
                                             rbuf.data_ptr(), final.data_ptr(), bbox.data_ptr(), st), "ims_fft_spikes")
         _abi.check(r.lib.ims_fft_finish(C.byref(P), obj_t.data_ptr(), n, rpre_t.data_ptr(), int(rpre[-1]),

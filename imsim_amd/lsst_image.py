@@ -188,13 +188,16 @@ def draw_job(renderer, job, realized=None, fft_stream=None):
             raise GalSimConfigError("FFT drawing needs the k-space PSF description")
         main = torch.cuda.current_stream(renderer.device)
         side = fft_stream if (fft_stream is not None and fft_stream != main) else None
+        # tables, buffers and uploads under the caller's stream (whose cached blocks fit: a buffer allocated under another stream
+        # comes out of hipMalloc, a device-wide synchronisation); only the launches go to the side stream
+        drawer = fft_draw.FftDrawer(renderer, job.kpsf, add_noise=True, diffraction_fft=job.diffraction_fft,
+                                    wavelength=job.wavelength, extra_ktables=job.extra_ktables)
+        r_fft = torch.zeros(job.n_fft, dtype=torch.float64, device=renderer.device) if realized is not None else None
+        state = drawer._upload(job.fft_rows)
         if side is not None:
-            side.wait_stream(main)                                # the renderer's scene tables and its zeroed image
+            side.wait_stream(main)                                # the renderer's scene tables, its zeroed image, the uploads above
         with torch.cuda.stream(side if side is not None else main):
-            drawer = fft_draw.FftDrawer(renderer, job.kpsf, add_noise=True, diffraction_fft=job.diffraction_fft,
-                                        wavelength=job.wavelength, extra_ktables=job.extra_ktables)
-            r_fft = torch.zeros(job.n_fft, dtype=torch.float64, device=renderer.device) if realized is not None else None
-            drawer.draw(job.fft_rows, realized=r_fft)
+            drawer._run(state, r_fft)
             if side is not None:
                 fft_done = torch.cuda.Event()
                 fft_done.record(side)
@@ -208,7 +211,6 @@ def draw_job(renderer, job, realized=None, fft_stream=None):
         torch.cuda.current_stream(renderer.device).wait_event(fft_done)
     if job.n_fft and realized is not None:
         realized.index_add_(0, torch.from_numpy(np.ascontiguousarray(job.fft_index)).to(renderer.device), r_fft)
-        r_fft.record_stream(torch.cuda.current_stream(renderer.device))      # allocated on the side stream, read here
     if job.sky is not None:
         kw = dict(job.sky)
         base = LSST_ImageBuilderBase()

@@ -87,9 +87,8 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
             init_on = by_role[os.environ.get("IMS_FOCAL_INIT", "bulk")]
             copy_on = by_role[os.environ.get("IMS_FOCAL_COPY", "mid")]
             # IMS_FOCAL_FFT=mid / bulk: the FFT-drawn objects beside the launch plan instead of ahead of it on the top-chain stream.
-            # Measured on 24 CCDs of C5: 48.0 ms per CCD on the middle stream against 22.1 ms ahead on the top stream (the host
-            # enqueue goes from 11.8 to 41 ms per CCD: the transforms' 134-MB buffers are then allocated under a stream whose
-            # cached blocks never fit, and every hipMalloc / hipFree is a device-wide synchronisation) -- default: ahead
+            # Measured on 24 CCDs of C5: 21.4 ms per CCD on the wide-launch stream, 32.9 on the middle stream, 21.6 ahead on the
+            # top stream -- no gain worth a second ordering; default: ahead
             fft_on = by_role.get(os.environ.get("IMS_FOCAL_FFT", "top"))
             if fft_on is anchor:
                 fft_on = None

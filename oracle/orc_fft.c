@@ -200,6 +200,20 @@ void orc_fft_spikes(const ims_fft_params_t* P, const ims_fft_object_t* objs, int
                 if (k->enabled && in_stamp && r1 >= r0) {
                     if (iy >= r0 && iy <= r1 && ix >= c0 && ix <= c1) v = 0.0;
                     double acc = 0.0;
+                    /* further from the arms of every source pixel's cross than any non-zero stencil value reaches: the whole sum is
+                       exact zeros (the offsets to the sources differ from the offset to the box centre by at most half the box) */
+                    int none = 0;
+                    {
+                        double ac = (double)iy - 0.5 * (double)(r0 + r1), bc = (double)ix - 0.5 * (double)(c0 + c1);
+                        double ha = 0.5 * (double)(r1 - r0), hb = 0.5 * (double)(c1 - c0);
+                        double e = fabs(k->cos0) * ha + fabs(k->sin0) * hb + fabs(k->sin0) * ha + fabs(k->cos0) * hb;
+                        double xc = k->cos0 * ac + k->sin0 * bc, yc = -k->sin0 * ac + k->cos0 * bc;
+                        double mc = (fabs(xc) < fabs(yc) ? fabs(xc) : fabs(yc)) - e;
+                        double rmax = sqrt(ac * ac + bc * bc) + sqrt(ha * ha + hb * hb) + 1.0;
+                        double lim = 0.5 * fabs(k->d_alpha) + 1.0e-6;
+                        none = mc > 1.0 + 1.0e-3 && mc - 1.0e-3 > lim * rmax;
+                    }
+                    if (!none)
                     for (int ry = r0; ry <= r1; ++ry)
                         for (int rx = c0; rx <= c1; ++rx) {
                             int a = iy - ry, b = ix - rx;

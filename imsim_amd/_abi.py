@@ -250,7 +250,7 @@ EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_
            "ims_sensor_update_distortions", "ims_sensor_update_refresh", "ims_sensor_publish_pairs", "ims_image_add", "ims_image_to_float", "ims_fill_derived_op", "ims_fill_derived_medium", "ims_fill_derived_optics", "ims_fill_derived_atmosphere", "ims_fill_derived_sensor", "ims_sensor_pixel_areas", "ims_flat_add", "ims_last_kernel_ms", "ims_enable_timing",
            "ims_readout_bleed", "ims_readout_segments", "ims_readout_cte", "ims_readout_finish",
            "ims_build_object_table", "ims_patch_stamp_sizes", "ims_gather_rows", "ims_parse_instcat_objects", "ims_screen_prepass",
-           "ims_plan_lsst_image", "ims_plan_bind", "ims_plan_upload", "ims_plan_run", "ims_plan_add_realized", "ims_plan_destroy",
+           "ims_plan_lsst_image", "ims_plan_bind", "ims_plan_upload", "ims_plan_run", "ims_plan_run_deferred", "ims_plans_run_joint", "ims_plan_join", "ims_plan_add_realized", "ims_plan_destroy",
            "ims_fft_inverse", "ims_comm_unique_id", "ims_comm_init", "ims_comm_destroy", "ims_reduce_image", "ims_allreduce_delta",
            "ims_count_inexact", "ims_struct_size", "ims_test_math"]
 
@@ -327,6 +327,9 @@ def load():
     lib.ims_plan_bind.argtypes = [c_vp, C.POINTER(RenderParams), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]
     lib.ims_plan_upload.argtypes = [c_vp, c_vp]
     lib.ims_plan_run.argtypes = [c_vp, c_vp, C.POINTER(Sensor), c_vp, c_vp, c_vp, C.POINTER(c_vp), c_i32, c_i32]
+    lib.ims_plan_run_deferred.argtypes = [c_vp, c_vp, C.POINTER(Sensor), c_vp, c_vp, c_vp, C.POINTER(c_vp), c_i32, c_i32, C.POINTER(c_i32)]
+    lib.ims_plans_run_joint.argtypes = [C.POINTER(c_vp), c_i32, c_vp]
+    lib.ims_plan_join.argtypes = [c_vp, c_vp]
     lib.ims_plan_add_realized.argtypes = [c_vp, c_vp, c_vp]
     lib.ims_plan_destroy.argtypes = [c_vp]
     lib.ims_fft_inverse.argtypes = [c_vp, c_vp, c_i32, c_i64, c_vp]

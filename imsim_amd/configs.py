@@ -694,7 +694,8 @@ def _c5_step(renderer, objects, rank=0, world=1, concurrent=None):
     def launch():
         launch.checksums = {}
         focal_plane.render_focal_plane(list(range(len(offs) - 1)), build, device=str(renderer.device), rank=rank, world=world,
-                                       concurrent=concurrent, nrecalc=nrecalc, sink=sink)
+                                       concurrent=concurrent, nrecalc=nrecalc, sink=sink,
+                                       chain_hint=lambda det: int(jobs[det].objects["n_phot"].max()) if len(jobs[det].objects) else 0)
     n_phot = np.concatenate([jobs[d].objects["n_phot"] for d in mine]) if mine else np.zeros(0, dtype=np.int64)
     ordinary = n_phot[n_phot <= nrecalc]
     launch.photons = int(n_phot.sum())

@@ -521,6 +521,58 @@ __global__ __launch_bounds__(WG, (NV == 8) ? 2 : 4) void k_accumulate_round_c(co
     accumulate_segment<NV, WG>(P, pool, pool_start, oi, j0, j_end);
 }
 
+// ---- JOINT rounds: the same round of the top chains of several CCDs in one launch ----
+// A focal plane's CCDs are independent renders (own sensor state, image, pool, object table), and with a bright tail each is
+// bound by the dependent rounds of its brightest star -- hundreds of launches of a few dozen workgroups.  Chains of different
+// CCDs on different streams barely overlap on this device (four side by side 108 - 150 ms against 158 ms
+// one after the other), while one launch that holds the round of MANY objects costs little more than the round of one (C3: 41
+// objects 2.8 x one star).  So the launch takes the argument blocks of up to IMS_JOINT_MAX chains by value and a workgroup
+// finds its chain from the ascending workgroup ends (scalar compares on kernel arguments); the body is the one above.
+constexpr int IMS_JOINT_MAX = 16;
+
+struct JointEnds { int32_t v[IMS_JOINT_MAX]; };      // ascending workgroup ends of the chains of one launch (a chain that sits out: zero width)
+
+struct JointAcc {                           // per chain, constant over the rounds: lives in device memory (ims_plans_run_joint)
+    RoundArgs a[IMS_JOINT_MAX];
+    const int64_t* pool_start[IMS_JOINT_MAX];
+};
+
+__device__ __forceinline__ int joint_chain(const JointEnds& e, int& b)
+{
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < IMS_JOINT_MAX - 1; ++k) c += (b >= e.v[k]) ? 1 : 0;
+    if (c > 0) b -= e.v[c - 1];
+    return c;
+}
+
+template <int NV, int WG = 256>
+__global__ __launch_bounds__(WG, (NV == 8) ? 2 : 4) void k_accumulate_round_j(const JointAcc* __restrict__ J, const JointEnds ends,
+                                                                              uint32_t tag, int64_t round_first, int32_t nrecalc, int32_t segs)
+{
+    int b = (int)blockIdx.x;
+    const int c = joint_chain(ends, b);
+    // the table through the CONSTANT address space: its loads at uniform addresses are scalar loads whatever the kernel stores
+    // (through a plain pointer the twelve fields sit in vector registers for the whole body: 128 + spills instead of 92)
+    typedef const JointAcc __attribute__((address_space(4))) * ConstAcc;
+    ConstAcc Jc = (ConstAcc)(uintptr_t)J;
+    ims_render_params_t P;
+    P.objects = Jc->a[c].objects; P.sensor = Jc->a[c].sensor; P.image = Jc->a[c].image; P.realized_flux = Jc->a[c].realized_flux;
+    P.nx = Jc->a[c].nx; P.ny = Jc->a[c].ny; P.xmin = Jc->a[c].xmin; P.ymin = Jc->a[c].ymin;
+    P.bf_tag = tag; P.bf_slot_shift = 0; P.track_static_delta = Jc->a[c].track_static_delta;
+    ims_photons_t pool;
+    pool.x = const_cast<double*>(Jc->a[c].px); pool.y = const_cast<double*>(Jc->a[c].py); pool.flux = const_cast<double*>(Jc->a[c].pflux);
+    pool.dxdz = const_cast<double*>(Jc->a[c].pz);
+    const int64_t* pool_start = Jc->pool_start[c];
+    const int64_t oi = b / segs;
+    const int64_t j0 = round_first + (int64_t)(b % segs) * WG;
+    int64_t j_end = round_first + nrecalc;
+    const int64_t n = P.objects[oi].n_phot;
+    if (j_end > n) j_end = n;
+    if (j0 >= j_end) return;
+    accumulate_segment<NV, WG>(P, pool, pool_start, oi, j0, j_end);
+}
+
 // Which slot of a range does block b work on: the last k with prefix[k] <= b (prefix = ascending tile offsets of the slots,
 // prefix[0] = 0).  A bisection is log2(n) DEPENDENT loads at the head of every tile kernel -- 6 for the 41 regions of the
 // long chains, 11 for the 1 550 of the middle class, each a cold-L2 round trip of ~1.4 us in a kernel that runs for 6 - 30 us.
@@ -888,10 +940,15 @@ __device__ __forceinline__ void load_displacements(const ims_sensor_t& s, Update
 // Silicon::updatePixelDistortions for the 16x16 owner cells of tile (tx0, ty0) of one slot (qdist 3).
 // dl_loaded: the displacement table is already in L.dl (persistent kernels load it once).  Returns, per thread,
 // whether its cell moved; `tile_moved` is set when any cell of the tile did.
-template <int NV, bool GLOBAL_DL = false>
+// DlPtr: the type of the global table's pointer -- a kernel's own restrict-qualified argument, or (joint launches, where the
+// pointer comes out of an argument block and carries no aliasing information) a pointer into the constant address space, whose
+// loads at uniform addresses are scalar loads by definition.
+typedef const double __attribute__((address_space(4))) * ConstTable;
+
+template <int NV, bool GLOBAL_DL = false, class DlPtr = const double*>
 __device__ __forceinline__ void update_tile_q3(const ims_sensor_t& s, const SlotView& sl, int tx0, int ty0,
                                                unsigned char* __restrict__ changed, UpdateLds<NV>& L, bool dl_loaded,
-                                               unsigned int tag, const double* __restrict__ dl_global = nullptr)
+                                               unsigned int tag, DlPtr __restrict__ dl_global = nullptr)
 {
     constexpr int Q = 3, HW = UT + 2 * Q + 1, NPO = 2 * NV + 2;
     const int sx0 = tx0 - (Q + 1), sy0 = ty0 - (Q + 1);
@@ -957,21 +1014,24 @@ __device__ __forceinline__ void update_tile_q3(const ims_sensor_t& s, const Slot
         for (int bb = 0; bb < 8; ++bb) {
             const double w = L.wt[(ly + 2 * Q + 1 - a) * HW + (lx + 2 * Q + 1 - bb)];
             // GLOBAL_DL: the row comes through the scalar cache into SGPRs (uniform, read-only table of the launch)
-            const double* d = (GLOBAL_DL ? dl_global : (const double*)L.dl) + (a * 8 + bb) * NPO * 2;
-            if (bb != 7) {                     // not the extra column: bottom-row points
+            auto row = [&](auto d) {
+                if (bb != 7) {                     // not the extra column: bottom-row points
 #pragma unroll
-                for (int n = 0; n <= NV + 1; ++n) {
-                    acc[2 * n] = fma(d[2 * n], w, acc[2 * n]);
-                    acc[2 * n + 1] = fma(d[2 * n + 1], w, acc[2 * n + 1]);
+                    for (int n = 0; n <= NV + 1; ++n) {
+                        acc[2 * n] = fma(d[2 * n], w, acc[2 * n]);
+                        acc[2 * n + 1] = fma(d[2 * n + 1], w, acc[2 * n + 1]);
+                    }
                 }
-            }
-            if (a != 7) {                      // not the extra row: left-edge points
+                if (a != 7) {                      // not the extra row: left-edge points
 #pragma unroll
-                for (int n = NV + 2; n < NPO; ++n) {
-                    acc[2 * n] = fma(d[2 * n], w, acc[2 * n]);
-                    acc[2 * n + 1] = fma(d[2 * n + 1], w, acc[2 * n + 1]);
+                    for (int n = NV + 2; n < NPO; ++n) {
+                        acc[2 * n] = fma(d[2 * n], w, acc[2 * n]);
+                        acc[2 * n + 1] = fma(d[2 * n + 1], w, acc[2 * n + 1]);
+                    }
                 }
-            }
+            };
+            if constexpr (GLOBAL_DL) row(dl_global + (a * 8 + bb) * NPO * 2);
+            else row((const double*)L.dl + (a * 8 + bb) * NPO * 2);
         }
     }
     PROBE(13);
@@ -1127,6 +1187,57 @@ __global__ __launch_bounds__(256) void k_update_distortions_q3(const ims_sensor_
     if (DPP) update_tile_q3_dpp<NV>(s, sl, tx0, ty0, changed, L, tag, dl_global, gridDim.x <= 64u);
     else if (dl_global != nullptr) update_tile_q3<NV, true>(s, sl, tx0, ty0, changed, L, false, tag, dl_global);
     else update_tile_q3<NV, false>(s, sl, tx0, ty0, changed, L, false, tag);
+}
+
+// the update of several CCDs' regions in one launch (k_accumulate_round_j): per chain the sensor, its slots, tile prefix and flags
+struct JointUpd {                           // constant over the rounds: device memory
+    const ims_sensor_t* sp[IMS_JOINT_MAX];
+    const int64_t* tile_prefix[IMS_JOINT_MAX];
+    unsigned char* changed[IMS_JOINT_MAX];
+    const double* dl[IMS_JOINT_MAX];
+    int32_t first_slot[IMS_JOINT_MAX];
+};
+
+struct JointTables { JointAcc acc; JointUpd upd; };
+
+// the tables of one joint run go to device memory as the by-value argument of a one-workgroup launch: stream-ordered, no staging
+__global__ __launch_bounds__(256) void k_store_joint_tables(const JointTables T, JointTables* __restrict__ dst)
+{
+    const uint32_t* src = (const uint32_t*)&T;
+    uint32_t* out = (uint32_t*)dst;
+    for (int i = (int)threadIdx.x; i < (int)(sizeof(JointTables) / 4); i += 256) out[i] = src[i];
+}
+
+// (the body as a function of restrict-qualified pointers: loaded from the argument block they would carry no aliasing
+// information, and the SGPR form of the update then needs 122 registers instead of 72)
+template <int NV, bool DPP>
+__device__ __forceinline__ void update_block_q3(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
+                                                const int64_t* __restrict__ tile_prefix, unsigned char* __restrict__ changed,
+                                                unsigned int tag, const double* __restrict__ dl_global, int64_t b, bool small,
+                                                UpdateLds<NV>& L)
+{
+    const ims_sensor_t& s = *sp;
+    const int lo = find_slot(tile_prefix, n_slots, b);
+    const ims_bf_slot_t bs = s.bf_slots[first_slot + lo];
+    const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
+    const int tiles_x = (sl.nx + 1 + UT - 1) / UT;
+    const int t = (int)(b - tile_prefix[lo]);
+    const int tx0 = (t % tiles_x) * UT, ty0 = (t / tiles_x) * UT;
+    if (tile_out_of_reach(s, sl, tx0 / UT, ty0 / UT, tag)) return;
+    if (DPP) update_tile_q3_dpp<NV>(s, sl, tx0, ty0, changed, L, tag, dl_global, small);
+    else if (dl_global != nullptr) update_tile_q3<NV, true, ConstTable>(s, sl, tx0, ty0, changed, L, false, tag, (ConstTable)(uintptr_t)dl_global);
+    else update_tile_q3<NV, false>(s, sl, tx0, ty0, changed, L, false, tag);
+}
+
+template <int NV, bool DPP = false>
+__global__ __launch_bounds__(256) void k_update_distortions_q3_j(const JointUpd* __restrict__ U, const JointEnds ends, const JointEnds n_slots,
+                                                                 unsigned int tag)
+{
+    __shared__ UpdateLds<NV> L;
+    int bb = (int)blockIdx.x;
+    const int c = joint_chain(ends, bb);
+    update_block_q3<NV, DPP>(U->sp[c], U->first_slot[c], n_slots.v[c], U->tile_prefix[c], U->changed[c], tag, U->dl[c], (int64_t)bb,
+                             gridDim.x <= 64u, L);
 }
 
 // ---- updatePixelDistortions AND the bounds refresh in ONE launch, for regions held as a PAIR of slots ----
@@ -1397,6 +1508,35 @@ __global__ __launch_bounds__(256) void k_refresh_changed(const ims_sensor_t* __r
     PROBE(17);
     refresh_tile<NV>(s, sl, tx, ty, own, right, up, charged, changed);
     PROBE(18);
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void k_refresh_changed_j(const JointUpd* __restrict__ U, const JointEnds ends, const JointEnds n_slots,
+                                                           unsigned int tag)
+{
+    int bb = (int)blockIdx.x;
+    const int c = joint_chain(ends, bb);
+    const ims_sensor_t& s = *U->sp[c];
+    const int64_t* __restrict__ tile_prefix = U->tile_prefix[c];
+    const unsigned char* changed = U->changed[c];
+    const int64_t b = bb;
+    const int lo = find_slot(tile_prefix, n_slots.v[c], b);
+    const ims_bf_slot_t bs = s.bf_slots[U->first_slot[c] + lo];
+    const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
+    const int tiles_x = (sl.nx + 1 + UT - 1) / UT, tiles_y = (sl.ny + 1 + UT - 1) / UT;
+    const int t = (int)(b - tile_prefix[lo]);
+    const int tx = t % tiles_x, ty = t / tiles_x;
+    const bool flags = (tag != 0u) && s.bf_tile_charge != nullptr && s.bf_tile_changed != nullptr;
+    bool own = true, right = true, up = true, charged = true;
+    if (flags) {
+        const unsigned char tg = (unsigned char)tag;
+        own = s.bf_tile_changed[cell_index(sl, tx * UT, ty * UT)] == tg;
+        right = (tx + 1 < tiles_x) && s.bf_tile_changed[cell_index(sl, (tx + 1) * UT, ty * UT)] == tg;
+        up = (ty + 1 < tiles_y) && s.bf_tile_changed[cell_index(sl, tx * UT, (ty + 1) * UT)] == tg;
+        charged = s.bf_tile_charge[cell_index(sl, tx * UT, ty * UT)] == tg;
+        if (!(own || right || up || charged)) return;
+    }
+    refresh_tile<NV>(s, sl, tx, ty, own, right, up, charged, changed);
 }
 
 // ---------------- LSST_Flat ----------------
@@ -2721,6 +2861,8 @@ int ims_plan_destroy(void* plan)
     if (!pl) return IMS_OK;
     if (pl->graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)pl->graph_exec);
     for (hipEvent_t e : pl->events) (void)hipEventDestroy(e);
+    if (pl->d_ready) (void)hipEventDestroy(pl->d_ready);
+    if (pl->d_done) (void)hipEventDestroy(pl->d_done);
     delete pl;
     return IMS_OK;
 }
@@ -2814,7 +2956,8 @@ int ims_plan_upload(void* plan, void* stream)
 }
 
 static int plan_enqueue(ims_planner::Plan* pl, ims_sensor_t* sensor_dev, ims_sensor_t* sensor_host, ims_bf_slot_t* slots_dev,
-                        unsigned char* changed_dev, void* main_stream, void* const* streams, int32_t n_streams, int32_t own_work_queued);
+                        unsigned char* changed_dev, void* main_stream, void* const* streams, int32_t n_streams, int32_t own_work_queued,
+                        bool defer_top = false);
 
 // IMS_PLAN_GRAPH=1: the whole enqueue of a plan is captured into a hipGraph on the main stream (the plan streams join the
 // capture through the fork / join events of the enqueue) and launched as one graph; a replay launches the instantiated
@@ -2857,7 +3000,8 @@ int ims_plan_run(void* plan, ims_sensor_t* sensor_dev, ims_sensor_t* sensor_host
 }
 
 static int plan_enqueue(ims_planner::Plan* pl, ims_sensor_t* sensor_dev, ims_sensor_t* sensor_host, ims_bf_slot_t* slots_dev,
-                        unsigned char* changed_dev, void* main_stream, void* const* streams, int32_t n_streams, int32_t own_work_queued)
+                        unsigned char* changed_dev, void* main_stream, void* const* streams, int32_t n_streams, int32_t own_work_queued,
+                        bool defer_top)
 {
     using namespace ims_planner;
     if (!streams || n_streams < 5) return set_err(IMS_ERR_ARG, "streams: five plan streams by role are required");
@@ -2865,6 +3009,13 @@ static int plan_enqueue(ims_planner::Plan* pl, ims_sensor_t* sensor_dev, ims_sen
     for (const Group& g : pl->groups) any_slots = any_slots || g.n_slots > 0;
     if (any_slots && (!sensor_dev || !sensor_host || !slots_dev || !changed_dev || !sensor_host->bf_slots))
         return set_err(IMS_ERR_ARG, "sensor / slot table / changed is NULL");
+    // the rounds of the top chain can be left to a joint run when the plan is ONE group of regions (a later group rewrites the
+    // slot table behind everything queued) in the form the joint kernels take: 4 vertices per edge, qdist 3, regions in place
+    pl->deferred = false;
+    const bool defer = defer_top && pl->groups.size() == 1 && pl->groups[0].n_slots > 0 && !pl->groups[0].chain_structs.empty() &&
+                       pl->groups[0].chain_structs[0].pair_shift == 0 && pl->groups[0].chain_structs[0].n_marks == 0 &&
+                       pl->groups[0].chain_structs[0].first_slot > 0 &&
+                       sensor_host->num_vertices == IT_NV && sensor_host->qdist == 3;
     // distinct streams
     std::vector<hipStream_t> uniq;
     for (int k = 0; k < n_streams; ++k)
@@ -2902,14 +3053,183 @@ static int plan_enqueue(ims_planner::Plan* pl, ims_sensor_t* sensor_dev, ims_sen
             std::memcpy((ims_bf_slot_t*)(uintptr_t)sensor_host->bf_slots + n0, pl->arena_host + g.off_slots, (size_t)g.n_slots * sizeof(ims_bf_slot_t));
             sensor_host->n_bf_slots = n0 + g.n_slots;
         }
-        const int rc = ims_run_plan(g.items.data(), (int64_t)g.items.size(), sensor_dev, sensor_host, changed_dev, streams, n_streams);
-        if (rc) return rc;
+        if (defer) {
+            // the rounds item without chain 0 (the classes of a group are its chains in order, the top class first)
+            std::vector<ims_plan_item_t> items(g.items);
+            for (ims_plan_item_t& it : items)
+                if (it.kind == IMS_PLAN_ROUNDS) { it.aux2 = g.chain_structs.data() + 1; it.n_slots = it.n_slots - 1; }
+            const int rc = ims_run_plan(items.data(), (int64_t)items.size(), sensor_dev, sensor_host, changed_dev, streams, n_streams);
+            if (rc) return rc;
+        } else {
+            const int rc = ims_run_plan(g.items.data(), (int64_t)g.items.size(), sensor_dev, sensor_host, changed_dev, streams, n_streams);
+            if (rc) return rc;
+        }
         queued = true;
+    }
+    if (defer_top) {
+        // no join yet (ims_plan_join): where this plan's work ends on every stream is recorded NOW -- on streams shared by role the
+        // next CCD's work follows, and a join must not wait for that
+        for (size_t k = 0; k < uniq.size(); ++k) HIP_TRY(hipEventRecord(pl->events[2 + uniq.size() + k], uniq[k]));
+        pl->unjoined = (int)uniq.size();
+        pl->deferred = defer;
+        pl->d_sensor_dev = sensor_dev; pl->d_sensor_host = sensor_host; pl->d_changed = changed_dev; pl->d_main = main_stream;
+        pl->d_streams.assign(streams, streams + n_streams);
+        return IMS_OK;
     }
     for (size_t k = 0; k < uniq.size(); ++k) {
         HIP_TRY(hipEventRecord(pl->events[2 + uniq.size() + k], uniq[k]));
         HIP_TRY(hipStreamWaitEvent(main, pl->events[2 + uniq.size() + k], 0));
     }
+    return IMS_OK;
+}
+
+int ims_plan_join(void* plan, void* stream)
+{
+    using namespace ims_planner;
+    Plan* pl = (Plan*)plan;
+    if (!pl) return set_err(IMS_ERR_ARG, "plan is NULL");
+    if (pl->deferred) return set_err(IMS_ERR_ARG, "ims_plan_join: the rounds left by ims_plan_run_deferred have not been run (ims_plans_run_joint)");
+    hipStream_t st = (hipStream_t)stream;
+    for (int k = 0; k < pl->unjoined; ++k) HIP_TRY(hipStreamWaitEvent(st, pl->events[2 + (size_t)pl->unjoined + k], 0));
+    if (pl->joint_done) HIP_TRY(hipStreamWaitEvent(st, pl->d_done, 0));
+    pl->unjoined = 0; pl->joint_done = false;
+    return IMS_OK;
+}
+
+int ims_plan_run_deferred(void* plan, ims_sensor_t* sensor_dev, ims_sensor_t* sensor_host, ims_bf_slot_t* slots_dev, unsigned char* changed_dev,
+                          void* main_stream, void* const* streams, int32_t n_streams, int32_t own_work_queued, int32_t* deferred)
+{
+    using namespace ims_planner;
+    Plan* pl = (Plan*)plan;
+    if (!pl || !pl->uploaded) return set_err(IMS_ERR_ARG, "plan is NULL or not uploaded");
+    if (!deferred) return set_err(IMS_ERR_ARG, "deferred is NULL");
+    const int rc = plan_enqueue(pl, sensor_dev, sensor_host, slots_dev, changed_dev, main_stream, streams, n_streams, own_work_queued, true);
+    *deferred = (rc == IMS_OK && pl->deferred) ? 1 : 0;
+    return rc;
+}
+
+int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream)
+{
+    using namespace ims_planner;
+    if (n_plans < 0 || (n_plans > 0 && !plans)) return set_err(IMS_ERR_ARG, "plans is NULL");
+    struct Act { Plan* pl; const ims_chain_t* ch; };
+    std::vector<Act> act;
+    for (int32_t k = 0; k < n_plans; ++k) {
+        Plan* pl = (Plan*)plans[k];
+        if (!pl) return set_err(IMS_ERR_ARG, "plans: NULL entry");
+        if (!pl->deferred) continue;                       // ran whole (no bright object, several groups): nothing left to do
+        act.push_back({ pl, &pl->groups[0].chain_structs[0] });
+    }
+    if (act.empty()) return IMS_OK;
+    if ((int)act.size() > IMS_JOINT_MAX) return set_err(IMS_ERR_ARG, "at most 16 deferred plans per joint run");
+    hipStream_t js = (hipStream_t)joint_stream;
+    const int32_t nrecalc = act[0].ch->nrecalc, use_tags = act[0].ch->use_tags;
+    int32_t max_rounds = 0;
+    for (const Act& a : act) {
+        const ims_chain_t& ch = *a.ch;
+        if (ch.nrecalc != nrecalc || ch.use_tags != use_tags) return set_err(IMS_ERR_ARG, "joint run: the plans differ in nrecalc / tile tags");
+        if (!ch.params || !ch.pool || !ch.pool->converted || !ch.pool_start || !ch.params->objects || !ch.params->image)
+            return set_err(IMS_ERR_ARG, "joint run: chain without table / pool / image");
+        if (ch.n_rounds > max_rounds) max_rounds = ch.n_rounds;
+        // the joint stream takes over behind the plan's chain stream (the regions' initial state, the first pool slice)
+        if (!a.pl->d_ready) {
+            HIP_TRY(hipEventCreateWithFlags(&a.pl->d_ready, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&a.pl->d_done, hipEventDisableTiming));
+        }
+        hipStream_t cs = (hipStream_t)a.pl->d_streams[ROLE_CHAIN];
+        if (cs != js) {
+            HIP_TRY(hipEventRecord(a.pl->d_ready, cs));
+            HIP_TRY(hipStreamWaitEvent(js, a.pl->d_ready, 0));
+        }
+    }
+    const int32_t segs = (nrecalc + 255) / 256;
+    static const long long dpp_max_tiles = getenv("IMS_UPD_DPP_MAX") ? atoll(getenv("IMS_UPD_DPP_MAX")) : 128;
+    // the per-chain argument blocks in device memory, one table per joint run out of a ring (a table is read until the run's
+    // last round: the ring's event says when)
+    struct Ring { JointTables* dev; hipEvent_t free_after; bool used; };
+    static std::vector<Ring> ring;
+    static size_t ring_next = 0;
+    JointTables* tables_dev = nullptr;
+    hipEvent_t table_event = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_state_mutex);
+        if (ring.empty()) {
+            JointTables* block = nullptr;
+            HIP_TRY(hipMalloc((void**)&block, 64 * sizeof(JointTables)));
+            for (int k = 0; k < 64; ++k) {
+                Ring r{ block + k, nullptr, false };
+                HIP_TRY(hipEventCreateWithFlags(&r.free_after, hipEventDisableTiming));
+                ring.push_back(r);
+            }
+        }
+        Ring& r = ring[ring_next++ % ring.size()];
+        if (r.used) HIP_TRY(hipEventSynchronize(r.free_after));
+        r.used = true;
+        tables_dev = r.dev; table_event = r.free_after;
+    }
+    JointTables T;
+    std::memset(&T, 0, sizeof(T));
+    bool dpp_ok = true;
+    for (size_t k = 0; k < (size_t)IMS_JOINT_MAX; ++k) {
+        const Act& a = act[k < act.size() ? k : 0];                   // unused entries repeat chain 0 (never selected: zero width)
+        const ims_chain_t& ch = *a.ch;
+        const ims_render_params_t& P = *ch.params;
+        RoundArgs& ra = T.acc.a[k];
+        ra.objects = P.objects; ra.sensor = P.sensor; ra.image = P.image; ra.realized_flux = P.realized_flux;
+        ra.px = ch.pool->x; ra.py = ch.pool->y; ra.pflux = ch.pool->flux; ra.pz = ch.pool->dxdz;
+        ra.nx = P.nx; ra.ny = P.ny; ra.xmin = P.xmin; ra.ymin = P.ymin;
+        ra.bf_tag = 0; ra.bf_slot_shift = 0; ra.track_static_delta = P.track_static_delta; ra.pad = 0;
+        T.acc.pool_start[k] = ch.pool_start;
+        T.upd.sp[k] = a.pl->d_sensor_dev; T.upd.tile_prefix[k] = ch.tile_prefix; T.upd.changed[k] = a.pl->d_changed;
+        T.upd.dl[k] = a.pl->d_sensor_host->bf_dl; T.upd.first_slot[k] = ch.first_slot;
+        dpp_ok = dpp_ok && a.pl->d_sensor_host->bf_dl != nullptr;
+    }
+    hipLaunchKernelGGL(k_store_joint_tables, dim3(1), dim3(256), 0, js, T, tables_dev);
+    for (int32_t r = 0; r < max_rounds; ++r) {
+        for (const Act& a : act) {
+            const ims_chain_t& ch = *a.ch;
+            if (r >= ch.n_rounds) continue;
+            for (int32_t j = 1; j < ch.n_edges; ++j)
+                if (ch.edges[j] == r) {
+                    hipEvent_t e;
+                    const int rc = plan_event(ch.ev_base + j, &e);
+                    if (rc) return rc;
+                    HIP_TRY(hipStreamWaitEvent(js, e, 0));
+                }
+        }
+        const uint32_t tag = use_tags ? (uint32_t)(r % 255 + 1) : 0u;
+        JointEnds ea, eu, ns;
+        int64_t wgs = 0, tiles = 0;
+        for (int k = 0; k < IMS_JOINT_MAX; ++k) {
+            int32_t n_act = 0, n_cont = 0;
+            if (k < (int)act.size() && r < act[k].ch->n_rounds) {
+                const ims_chain_t& ch = *act[k].ch;
+                n_act = count_above(ch.n_phot, ch.n_objects, (int64_t)r * nrecalc);
+                n_cont = count_above(ch.n_phot, ch.n_objects, (int64_t)(r + 1) * nrecalc);
+                tiles += n_cont > 0 ? ch.tile_prefix_host[n_cont] : 0;
+            }
+            wgs += (int64_t)n_act * segs;
+            if (wgs > 0x7fffffffLL || tiles > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "joint run: too many workgroups for one round");
+            ea.v[k] = (int32_t)wgs; eu.v[k] = (int32_t)tiles; ns.v[k] = n_cont > 0 ? n_cont : 1;
+        }
+        if (wgs > 0) {
+            LaunchTimer tm(js, 4);
+            hipLaunchKernelGGL((k_accumulate_round_j<4, 256>), dim3((unsigned)wgs), dim3(256), 0, js, (const JointAcc*)&tables_dev->acc, ea, tag,
+                               (int64_t)r * nrecalc, nrecalc, segs);
+        }
+        if (tiles > 0) {
+            const JointUpd* U = &tables_dev->upd;
+            const bool dpp = dpp_ok && os_getenv_off("IMS_UPD_DPP") && tiles <= dpp_max_tiles;
+            if (dpp) hipLaunchKernelGGL((k_update_distortions_q3_j<4, true>), dim3((unsigned)tiles), dim3(256), 0, js, U, eu, ns, tag);
+            else hipLaunchKernelGGL((k_update_distortions_q3_j<4, false>), dim3((unsigned)tiles), dim3(256), 0, js, U, eu, ns, tag);
+            hipLaunchKernelGGL(k_refresh_changed_j<4>, dim3((unsigned)tiles), dim3(256), 0, js, U, eu, ns, tag);
+        }
+        for (const Act& a : act)
+            if (r == a.ch->n_rounds - 1) HIP_TRY(hipEventRecord(a.pl->d_done, js));     // this CCD's chain is through
+    }
+    HIP_TRY(hipEventRecord(table_event, js));
+    HIP_TRY(hipGetLastError());
+    for (const Act& a : act) { a.pl->deferred = false; a.pl->joint_done = true; }
     return IMS_OK;
 }
 

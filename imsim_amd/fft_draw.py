@@ -284,11 +284,12 @@ class FftDrawer:
     def _upload(self, fft_objects):
         torch, r = self.torch, self.r
         rows = np.ascontiguousarray(fft_objects, dtype=FFT_OBJECT_DTYPE)
-        obj_t = torch.from_numpy(rows.view(np.uint8).reshape(-1)).to(r.device)
+        from .engine import upload_async
+        obj_t = upload_async(torch, r.device, rows.view(np.uint8).reshape(-1))
         nfft = rows["nfft"].astype(np.int64)
         kpre = np.concatenate([[0], np.cumsum(nfft * (nfft // 2 + 1))]).astype(np.int64)
         rpre = np.concatenate([[0], np.cumsum(nfft * nfft)]).astype(np.int64)
-        kpre_t, rpre_t = torch.from_numpy(kpre).to(r.device), torch.from_numpy(rpre).to(r.device)
+        kpre_t, rpre_t = upload_async(torch, r.device, kpre), upload_async(torch, r.device, rpre)
         kbuf = torch.empty(int(kpre[-1]), dtype=torch.complex128, device=r.device)
         rbuf = torch.empty(int(rpre[-1]), dtype=torch.float64, device=r.device)
         # every buffer of the draw is allocated HERE (under the caller's current stream), so that _run only launches: a run on a

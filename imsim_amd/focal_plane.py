@@ -21,7 +21,117 @@ from .engine import Renderer
 _ANCHOR_STREAMS = {}
 
 
-def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent=3, nrecalc=None, sink=None, post=None):
+def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
+    """The CCDs in batches of `joint` whose top brighter-fatter chains advance in lockstep: ONE launch per kernel and round for
+    the whole batch (engine.run_joint_plans / ims_plans_run_joint) instead of a chain per CCD on a stream of its own -- chains on
+    different streams barely overlap on the device, while a launch that holds the same round of eight chains costs little more
+    than the round of one.  Streams by role for all CCDs: `pre` (FFT objects, the regions' initial state, first pool slices),
+    bulk (wide launches), mid (middle / low chain classes, then each CCD's tail: join, sky, float image, copy to the host),
+    joint (the rounds).  Host order: the front of batch b + 1 is enqueued BEFORE the tails of batch b, so the shared streams
+    work ahead while the joint chain of batch b runs.  chain_hint(key) -> a number that grows with the CCD's longest chain
+    (its brightest photon-shot object): CCDs of similar chain length share a batch, the sum of the batches' longest chains falls."""
+    import torch
+    from .engine import _focal_streams, run_joint_plans
+    st_joint = _focal_streams(torch, dev, top_index=0)[0]
+    pre, bulk, mid = _focal_streams(torch, dev, top_index=1)[:3]
+    if pre is st_joint:
+        raise RuntimeError("the joint focal plane needs two top streams (IMS_FOCAL_TOPS >= 2)")
+    order = list(mine)
+    if chain_hint is not None and os.environ.get("IMS_NO_HINT", "0") != "1":
+        order.sort(key=chain_hint, reverse=True)
+    batches = [order[a:a + joint] for a in range(0, len(order), joint)]
+    pinned_pool = []
+    out = {}
+    host_s = [0.0]
+    n_joint = [0]
+
+    # IMS_FOCAL_AHEAD (default "pre:1"): the host enqueues the front of a CCD only when the front of the CCD `n` places before it
+    # has run through on that stream -- deliberately: with everything of a batch queued at once the wide launches of eight CCDs
+    # run side by side with the middle chains and the FFT draws, and all of them (and the joint rounds most of all) get slower
+    # than they are one CCD after the other (measured on C5: 16.4 ms per CCD unthrottled, 13.3 with the pacing that synchronous
+    # uploads used to impose by accident)
+    ahead_on, _, ahead_n = os.environ.get("IMS_FOCAL_AHEAD", "pre:1").partition(":")
+    ahead_n = int(ahead_n or 0)
+    fronts = []
+
+    def front(key):
+        scene, work = build(key)
+        if ahead_n > 0 and len(fronts) >= ahead_n:
+            fronts[-ahead_n].synchronize()
+        e = _front(key, scene, work)
+        ev = torch.cuda.Event()
+        ev.record({"pre": pre, "bulk": bulk, "mid": mid}[ahead_on])
+        fronts.append(ev)
+        del fronts[:-8]
+        return e
+
+    def _front(key, scene, work):
+        with torch.cuda.stream(bulk):
+            renderer = Renderer(scene, dev, stream_roles="focal", top_index=1)
+            ready = torch.cuda.Event()
+            ready.record(bulk)
+        with torch.cuda.stream(pre):
+            pre.wait_event(ready)
+            if isinstance(work, lsst_image.CcdJob):
+                if work.nrecalc is None:
+                    work.nrecalc = nrecalc
+                fin = lsst_image.draw_job(renderer, work, defer=True)
+                plan = fin.plan
+            else:
+                plan = renderer.render_lsst_image(work, nrecalc=nrecalc, defer=True)
+                fin = plan.join if plan is not None else (lambda: None)
+        return dict(key=key, renderer=renderer, fin=fin, plan=plan)
+
+    def tail(entries):
+        # shortest chain first: mid must not sit behind the batch's longest chain while the others' images wait
+        for e in sorted(entries, key=lambda e: e["plan"].sizes.n_round_launches if e["plan"] is not None else 0):
+            with torch.cuda.stream(mid):
+                e["fin"]()
+                img = e["renderer"].image_float()
+                host = pinned_pool.pop() if pinned_pool else torch.empty(img.shape, dtype=img.dtype, pin_memory=True)
+                if host.shape != img.shape:
+                    host = torch.empty(img.shape, dtype=img.dtype, pin_memory=True)
+                host.copy_(img, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(mid)
+            e["host"], e["done"] = host, done
+
+    def collect(entries):
+        for e in sorted(entries, key=lambda e: e["plan"].sizes.n_round_launches if e["plan"] is not None else 0):
+            e["done"].synchronize()
+            if post is not None:
+                post(e["key"], e["renderer"])
+            if sink is not None:
+                sink(e["key"], e["host"].numpy())
+            else:
+                out[e["key"]] = e["host"].numpy().copy()
+            pinned_pool.append(e["host"])
+            e.clear()                              # drops the renderer: its HBM goes back to the caching allocator
+
+    prev = None
+    for batch in batches:
+        t0 = time.perf_counter()
+        cur = [front(key) for key in batch]
+        if prev is not None:
+            tail(prev)
+        left = [e["plan"] for e in cur if e["plan"] is not None and getattr(e["plan"], "deferred", False)]
+        n_joint[0] += len(left)
+        with torch.cuda.stream(pre):
+            run_joint_plans(left, st_joint)
+        host_s[0] += time.perf_counter() - t0
+        if prev is not None:
+            collect(prev)
+        prev = cur
+    if prev is not None:
+        tail(prev)
+        collect(prev)
+    render_focal_plane.last_host_ms_per_ccd = 1e3 * host_s[0] / max(len(mine), 1)
+    render_focal_plane.last_joint_plans = n_joint[0]          # CCDs whose top chain ran in joint launches
+    return out
+
+
+def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent=3, nrecalc=None, sink=None, post=None,
+                       chain_hint=None):
     """ccds: sequence of CCD keys (detector numbers / names); build(key) -> (scene, work) prepares one CCD on the host, work
     being either the object table of a photon-shot CCD or an `lsst_image.CcdJob` -- the per-CCD build of the reference
     (imsim/lsst_image.py:276-395 under the fan-out of imsim/ccd.py:72-89): FFT-drawn objects first, then the launch plan of the
@@ -40,6 +150,11 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
         raise ValueError("concurrent must be >= 1")
     # plan streams by role for all CCDs of the device: the long chains of two CCDs side by side (engine._focal_streams)
     roles = "focal" if os.environ.get("IMS_FOCAL_STREAMS", "1") != "0" else "single"
+    # IMS_FOCAL_JOINT (default 8; 0 / 1: off): the top chains of that many CCDs advance jointly (_render_joint)
+    joint = int(os.environ.get("IMS_FOCAL_JOINT", "8"))
+    if joint > 1 and roles == "focal" and os.environ.get("IMS_NATIVE_PLAN", "1") != "0":
+        torch.cuda.set_device(dev)
+        return _render_joint(mine, build, dev, nrecalc, sink, post, min(joint, 16), chain_hint)
     # the anchor streams are kept per device for the life of the process: PyTorch's caching allocator files a freed block
     # under the stream it was allocated on, so fresh streams per call would miss the cache and hipMalloc every CCD's
     # gigabytes of sensor state again (measured: 13 -> 27 .. 34 ms per CCD for the calls that do)

@@ -170,7 +170,7 @@ class CcdJob:
         return 0 if self.fft_rows is None else len(self.fft_rows)
 
 
-def draw_job(renderer, job, realized=None, fft_stream=None):
+def draw_job(renderer, job, realized=None, fft_stream=None, defer=False):
     """The draw loop of one CCD on the device (imsim/lsst_image.py:342-368 over imsim/stamp.py:411-575), enqueue only: the
     FFT objects first (k-space fill, inverse transforms, spikes, Poisson noise, stamp -> CCD add), then the launch plan of
     the photon-shot ones, then the optional sky.  realized: f64 device tensor over the kept catalog rows.
@@ -178,7 +178,12 @@ def draw_job(renderer, job, realized=None, fft_stream=None):
     fft_stream: a side stream for the FFT objects.  Their stamps carry Poisson noise, so every value added to the f64 CCD image
     is an integer like the photons' and the image does not depend on the order of the additions: the FFT branch (milliseconds
     for a 4096^2 stamp with its spike stencil) may then run BESIDE the launch plan instead of ahead of it on the stream that
-    carries a CCD's longest brighter-fatter chain (focal_plane.render_focal_plane); the sky stage waits for both."""
+    carries a CCD's longest brighter-fatter chain (focal_plane.render_focal_plane); the sky stage waits for both.
+
+    defer (focal_plane's joint mode): the launch plan is enqueued without its join and without the rounds of its top chain;
+    returns finish() -- to be called under the stream that carries the CCD's tail, once engine.run_joint_plans has run the
+    batch's plans (finish.plan; None if there was nothing to defer): it joins the plan, adds the realized fluxes and the sky."""
+    from .engine import upload_async
     torch = renderer.torch
     if realized is None and job.want_realized:
         realized = job.realized = torch.zeros(job.n_kept, dtype=torch.float64, device=renderer.device)
@@ -202,22 +207,42 @@ def draw_job(renderer, job, realized=None, fft_stream=None):
                 fft_done = torch.cuda.Event()
                 fft_done.record(side)
         renderer._keep_fft = drawer._last + (drawer._keep,)     # the buffers, not the drawer (which refers back to the renderer)
+    plan = None
+    r_ph = None
     if len(job.objects):
         r_ph = torch.zeros(len(job.objects), dtype=torch.float64, device=renderer.device) if realized is not None else None
-        renderer.render_lsst_image(job.objects, nrecalc=job.nrecalc, realized=r_ph)
-        if realized is not None:
-            realized.index_add_(0, torch.from_numpy(np.ascontiguousarray(job.phot_index)).to(renderer.device), r_ph)
-    if fft_done is not None:
-        torch.cuda.current_stream(renderer.device).wait_event(fft_done)
-    if job.n_fft and realized is not None:
-        realized.index_add_(0, torch.from_numpy(np.ascontiguousarray(job.fft_index)).to(renderer.device), r_fft)
-    if job.sky is not None:
-        kw = dict(job.sky)
-        base = LSST_ImageBuilderBase()
-        areas = base.sky_pixel_areas(renderer, use_flux=bool(kw.pop("use_flux_sky_areas", False))) if kw.pop("pixel_areas", True) else None
-        base.add_noise(renderer, kw.pop("sky_level"), pixel_areas=areas, **kw)
-        renderer._keep_sky = base
-    return renderer.image
+        plan = renderer.render_lsst_image(job.objects, nrecalc=job.nrecalc, realized=r_ph, defer=defer)
+    front = torch.cuda.current_stream(renderer.device)
+    front_done = None
+    if defer:
+        front_done = torch.cuda.Event()                      # the FFT objects and uploads of the front stream
+        front_done.record(front)
+
+    def finish():
+        here = torch.cuda.current_stream(renderer.device)
+        if plan is not None:
+            plan.join()
+            if r_ph is not None:
+                plan.add_realized(r_ph)
+        if front_done is not None and here != front:
+            here.wait_event(front_done)
+        if len(job.objects) and realized is not None:
+            realized.index_add_(0, upload_async(torch, renderer.device, np.ascontiguousarray(job.phot_index, dtype=np.int64)), r_ph)
+        if fft_done is not None:
+            here.wait_event(fft_done)
+        if job.n_fft and realized is not None:
+            realized.index_add_(0, upload_async(torch, renderer.device, np.ascontiguousarray(job.fft_index, dtype=np.int64)), r_fft)
+        if job.sky is not None:
+            kw = dict(job.sky)
+            base = LSST_ImageBuilderBase()
+            areas = base.sky_pixel_areas(renderer, use_flux=bool(kw.pop("use_flux_sky_areas", False))) if kw.pop("pixel_areas", True) else None
+            base.add_noise(renderer, kw.pop("sky_level"), pixel_areas=areas, **kw)
+            renderer._keep_sky = base
+        return renderer.image
+    if defer:
+        finish.plan = plan
+        return finish
+    return finish()
 
 
 class LSST_ImageBuilder(LSST_ImageBuilderBase):

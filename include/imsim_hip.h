@@ -48,7 +48,7 @@ extern "C" {
 #define IMS_ERR_NO_DEVICE  -3
 #define IMS_ERR_UNSUPPORTED -4
 
-#define IMS_ABI_VERSION 17
+#define IMS_ABI_VERSION 18
 
 /* Pointers stored INSIDE descriptors that live in device memory (ims_sensor_t, ims_atmosphere_t) always point to global
  * device memory.  Device code is told so (address space 1): a pointer read out of memory is otherwise a generic pointer and
@@ -778,6 +778,23 @@ int  ims_plan_upload(void* plan, void* stream);
  * this renderer is queued on the streams yet (the first slot table then does not wait for the streams' earlier work). */
 int  ims_plan_run(void* plan, ims_sensor_t* sensor_dev, ims_sensor_t* sensor_host, ims_bf_slot_t* slots_dev, unsigned char* changed_dev,
                   void* main_stream, void* const* streams, int32_t n_streams, int32_t own_work_queued);
+/* The CCDs of a focal plane side by side (the fan-out of imsim/ccd.py:72-89: every CCD an independent LSST_Image build): with a
+ * bright tail each CCD is bound by the dependent rounds of its brightest star, and chains of different CCDs on different streams
+ * barely overlap on the device -- but ONE launch holding the same round of several chains costs little more than the round of
+ * one.  ims_plan_run_deferred enqueues a plan like ims_plan_run but (a) does not join the plan's streams into main_stream --
+ * it records where the plan's work ends on each of them, so that streams shared by role may go on with the next CCD -- and (b)
+ * leaves the rounds of the TOP chain out when they can run jointly: *deferred = 1 (0: nothing left -- no bright object, several
+ * region groups, 8 vertices per edge).  ims_plans_run_joint runs the left rounds of up to 16 such plans in lockstep on
+ * joint_stream -- three launches per round for all of them (pixel search, updatePixelDistortions, bounds refresh: the kernels of
+ * ims_accumulate_round / ims_sensor_update_distortions with the argument blocks of all chains) -- and marks the end of every
+ * plan's last round; plans with nothing left are skipped.  ims_plan_join makes `stream` wait for everything of one plan (its
+ * streams' recorded ends and, if it took part, its last joint round): what ims_plan_run does at its end.  The pointers handed to
+ * ims_plan_run_deferred must stay valid until ims_plans_run_joint has returned.  Same images as ims_plan_run, bit for bit. */
+int  ims_plan_run_deferred(void* plan, ims_sensor_t* sensor_dev, ims_sensor_t* sensor_host, ims_bf_slot_t* slots_dev,
+                           unsigned char* changed_dev, void* main_stream, void* const* streams, int32_t n_streams,
+                           int32_t own_work_queued, int32_t* deferred);
+int  ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream);
+int  ims_plan_join(void* plan, void* stream);
 /* out[master row] += realized flux of every object (after ims_plan_run, on the same main stream) */
 int  ims_plan_add_realized(void* plan, double* out_dev, void* stream);
 int  ims_plan_destroy(void* plan);

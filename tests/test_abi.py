@@ -38,7 +38,7 @@ def test_struct_sizes_match_binding():
 
 def test_abi_version_and_error_string():
     lib = _abi.load()
-    assert lib.ims_abi_version() == 17
+    assert lib.ims_abi_version() == 18
     # argument checking happens before any HIP call, so it is testable without a GPU
     assert lib.ims_shoot_accumulate(None, None) == -1
     assert b"NULL" in lib.ims_last_error()

@@ -1306,7 +1306,7 @@ def test_focal_plane_ccds_on_streams(torch_cuda):
         assert_bits_equal(seen[det], images[det], f"CCD {det} through the sink")
 
 
-def _c5_test_visit(n=384, n_ccd=4, per=150):
+def _c5_test_visit(n=384, n_ccd=4, per=150, star=None):
     """Four CCDs of a visit at test size, each holding FFT-drawn, photon-shot and faint objects: the bench's C5 catalog with
     its bright tail set by hand (a star and a compact galaxy above fft_sb_thresh, a star of 1.5e6 e- below it)."""
     import math
@@ -1317,7 +1317,7 @@ def _c5_test_visit(n=384, n_ccd=4, per=150):
     cat = configs._c5_catalog(n_ccd * per, scene, n_ccd=n_ccd)
     for det in range(n_ccd):
         a = int(cat.ccd_offsets[det])
-        cat["nominal_flux"][a:a + 3] = [2.0e7 + 1.0e6 * det, 1.5e6, 4.0e7]
+        cat["nominal_flux"][a:a + 3] = [2.0e7 + 1.0e6 * det, 1.5e6 if star is None else star[det], 4.0e7]
         cat["kind"][a:a + 3] = [0, 0, 1]
         cat["hlr"][a + 2] = 0.1
         cat["x"][a:a + 3] = [0.3 * n, 0.7 * n, 0.55 * n]
@@ -1394,6 +1394,47 @@ def test_focal_plane_ccds_hold_fft_photon_and_faint_objects(torch_cuda):
     for p in parts:
         for d, img in p.items():
             assert_bits_equal(img, images[d], f"CCD {d} rank split")
+
+
+def test_joint_top_chains_of_a_focal_plane_equal_a_chain_per_ccd(torch_cuda, monkeypatch):
+    """ims_plan_run_deferred / ims_plans_run_joint / ims_plan_join: the brightest stars of several CCDs advance through their
+    brighter-fatter rounds in lockstep -- ONE pixel-search, ONE updatePixelDistortions and ONE refresh launch per round for all
+    CCDs of a batch (different sensors, images, pools, round counts) -- and every CCD's image equals the one it gets from a
+    chain of its own (IMS_FOCAL_JOINT=0), bit for bit; batches of two (so that a second batch follows the first on the shared
+    streams) and of eight, with and without the ordering hint."""
+    import copy
+    from imsim_amd import focal_plane, configs
+    from imsim_amd.config import ccd_seed
+    scene, cat, phot, objects, visit = _c5_test_visit(star=(1.5e6, 0.6e6, 2.2e6, 1.0e6))      # 60 .. 220 rounds
+    offs, coffs = objects.ccd_offsets, objects.cat_offsets
+    dets = list(range(len(offs) - 1))
+    jobs = {}
+    for det in dets:
+        sub = {k: v[coffs[det]:coffs[det + 1]] for k, v in cat.items() if isinstance(v, np.ndarray)}
+        jobs[det] = configs.c5_job(scene, sub, phot[coffs[det]:coffs[det + 1]], np.asarray(objects[offs[det]:offs[det + 1]]), visit=visit)
+
+    def build(det):
+        sc = copy.copy(scene)
+        sc.seed = ccd_seed(scene.seed, det)
+        return sc, jobs[det]
+
+    monkeypatch.setenv("IMS_FOCAL_JOINT", "0")
+    single = focal_plane.render_focal_plane(dets, build, concurrent=2)
+    for joint, hint in (("8", None), ("2", lambda det: int(jobs[det].objects["n_phot"].max())), ("2", None)):
+        monkeypatch.setenv("IMS_FOCAL_JOINT", joint)
+        images = focal_plane.render_focal_plane(dets, build, concurrent=2, chain_hint=hint)
+        assert focal_plane.render_focal_plane.last_joint_plans == len(dets)          # every CCD has a star with rounds of its own
+        assert sorted(images) == dets
+        for det in dets:
+            assert_bits_equal(images[det], single[det], f"CCD {det}: joint rounds (batches of {joint}) vs a chain per CCD")
+    # the object tables of photon-only CCDs (no CcdJob) take the same path
+    tables = {det: jobs[det].objects for det in dets}
+    monkeypatch.setenv("IMS_FOCAL_JOINT", "0")
+    single = focal_plane.render_focal_plane(dets, lambda det: (build(det)[0], tables[det]), concurrent=2, nrecalc=10000)
+    monkeypatch.setenv("IMS_FOCAL_JOINT", "8")
+    images = focal_plane.render_focal_plane(dets, lambda det: (build(det)[0], tables[det]), concurrent=2, nrecalc=10000)
+    for det in dets:
+        assert_bits_equal(images[det], single[det], f"CCD {det}: object table, joint vs single")
 
 
 # ---------------------------------------------------------------------------------------------

@@ -328,7 +328,7 @@ def load():
     lib.ims_plan_upload.argtypes = [c_vp, c_vp]
     lib.ims_plan_run.argtypes = [c_vp, c_vp, C.POINTER(Sensor), c_vp, c_vp, c_vp, C.POINTER(c_vp), c_i32, c_i32]
     lib.ims_plan_run_deferred.argtypes = [c_vp, c_vp, C.POINTER(Sensor), c_vp, c_vp, c_vp, C.POINTER(c_vp), c_i32, c_i32, C.POINTER(c_i32)]
-    lib.ims_plans_run_joint.argtypes = [C.POINTER(c_vp), c_i32, c_vp]
+    lib.ims_plans_run_joint.argtypes = [C.POINTER(c_vp), c_i32, c_vp, c_i32, c_i32]
     lib.ims_plan_join.argtypes = [c_vp, c_vp]
     lib.ims_plan_add_realized.argtypes = [c_vp, c_vp, c_vp]
     lib.ims_plan_destroy.argtypes = [c_vp]

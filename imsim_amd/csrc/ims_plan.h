@@ -83,14 +83,16 @@ struct Plan {
     void* graph_exec = nullptr;         // IMS_PLAN_GRAPH: the instantiated graph of one run
     // a deferred run (ims_plan_run_deferred): everything but the rounds of the top chain is enqueued and not yet joined into
     // the main stream; ims_plans_run_joint runs those rounds together with other plans' and joins
-    bool deferred = false, joint_done = false;
+    bool deferred = false;
+    unsigned left = 0;                  // bit k: the rounds of chain k have not been run yet
     int unjoined = 0;                   // distinct streams whose end-of-plan events a join has to wait for
+    std::vector<hipEvent_t> d_events;   // own events: [0 .. 3] chain k's stream ready, then one per joint run this plan took part in
+    size_t d_done_used = 0;             // joint-run events in use since the last join
     ims_sensor_t* d_sensor_dev = nullptr;
     ims_sensor_t* d_sensor_host = nullptr;
     unsigned char* d_changed = nullptr;
     void* d_main = nullptr;
     std::vector<void*> d_streams;
-    hipEvent_t d_ready = nullptr, d_done = nullptr;
     int32_t n_slots_scalar = 0;         // staging of sensor_dev->n_bf_slots lives in the arena (one per group)
     std::vector<int64_t> off_nslots;
 

@@ -528,7 +528,7 @@ __global__ __launch_bounds__(WG, (NV == 8) ? 2 : 4) void k_accumulate_round_c(co
 // one after the other), while one launch that holds the round of MANY objects costs little more than the round of one (C3: 41
 // objects 2.8 x one star).  So the launch takes the argument blocks of up to IMS_JOINT_MAX chains by value and a workgroup
 // finds its chain from the ascending workgroup ends (scalar compares on kernel arguments); the body is the one above.
-constexpr int IMS_JOINT_MAX = 16;
+constexpr int IMS_JOINT_MAX = 32;
 
 struct JointEnds { int32_t v[IMS_JOINT_MAX]; };      // ascending workgroup ends of the chains of one launch (a chain that sits out: zero width)
 
@@ -1200,12 +1200,30 @@ struct JointUpd {                           // constant over the rounds: device 
 
 struct JointTables { JointAcc acc; JointUpd upd; };
 
-// the tables of one joint run go to device memory as the by-value argument of a one-workgroup launch: stream-ordered, no staging
-__global__ __launch_bounds__(256) void k_store_joint_tables(const JointTables T, JointTables* __restrict__ dst)
+// the tables of one joint run go to device memory as the by-value arguments of small launches, eight chains at a time (a kernel's
+// arguments are limited to 4 KB): stream-ordered, no staging
+constexpr int JOINT_CHUNK = 8;
+struct JointChunk {
+    RoundArgs a[JOINT_CHUNK];
+    const int64_t* pool_start[JOINT_CHUNK];
+    const ims_sensor_t* sp[JOINT_CHUNK];
+    const int64_t* tile_prefix[JOINT_CHUNK];
+    unsigned char* changed[JOINT_CHUNK];
+    const double* dl[JOINT_CHUNK];
+    int32_t first_slot[JOINT_CHUNK];
+};
+
+__global__ __launch_bounds__(64) void k_store_joint_tables(const JointChunk C, JointTables* __restrict__ dst, int k0)
 {
-    const uint32_t* src = (const uint32_t*)&T;
-    uint32_t* out = (uint32_t*)dst;
-    for (int i = (int)threadIdx.x; i < (int)(sizeof(JointTables) / 4); i += 256) out[i] = src[i];
+    const int k = (int)threadIdx.x;
+    if (k >= JOINT_CHUNK) return;
+    dst->acc.a[k0 + k] = C.a[k];
+    dst->acc.pool_start[k0 + k] = C.pool_start[k];
+    dst->upd.sp[k0 + k] = C.sp[k];
+    dst->upd.tile_prefix[k0 + k] = C.tile_prefix[k];
+    dst->upd.changed[k0 + k] = C.changed[k];
+    dst->upd.dl[k0 + k] = C.dl[k];
+    dst->upd.first_slot[k0 + k] = C.first_slot[k];
 }
 
 // (the body as a function of restrict-qualified pointers: loaded from the argument block they would carry no aliasing
@@ -1537,6 +1555,140 @@ __global__ __launch_bounds__(256) void k_refresh_changed_j(const JointUpd* __res
         if (!(own || right || up || charged)) return;
     }
     refresh_tile<NV>(s, sl, tx, ty, own, right, up, charged, changed);
+}
+
+// ---- joint rounds over the ACTIVE tiles only ----
+// A round's update and refresh launches held one workgroup per 16 x 16 tile of every region of every chain -- 24 000 workgroups
+// for the brightest stars of eight CCDs (678 x 678-pixel stamps: 1 849 tiles each), of which a few thousand find charge within
+// reach; the rest leave at once, but their dispatch is what the launch costs (4 ns per workgroup alone, twice that beside the
+// photon kernels: 50 - 90 us of a 110-us round).  Here one thread per tile reads the charge marks the pixel search left
+// (ims_sensor_t.bf_tile_charge, this round's tag) and appends the tiles within reach to a list -- and those whose bounds can
+// change (the tile itself, its right or its upper neighbour within reach) to a second one; the update and refresh launches
+// then hold a fraction of the workgroups and walk the lists.  Same decisions as the tagged kernels, tile by tile: same bits.
+struct JointLists {
+    unsigned long long* upd;            // entries: chain << 58 | slot of the class << 32 | tile of the slot
+    unsigned long long* ref;
+    int* count;                         // [parity][2]: entries of upd / ref
+};
+
+__global__ __launch_bounds__(256) void k_build_active_j(const JointUpd* __restrict__ U, const JointEnds ends_wg, const JointEnds tiles_of,
+                                                        const JointEnds n_slots, unsigned int tag, const JointLists Ls, int parity)
+{
+    int bb = (int)blockIdx.x;
+    const int c = joint_chain(ends_wg, bb);
+    const ims_sensor_t& s = *U->sp[c];
+    const int64_t* __restrict__ tile_prefix = U->tile_prefix[c];
+    const int n_tiles = tiles_of.v[c], ns = n_slots.v[c];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { Ls.count[2 * (parity ^ 1)] = 0; Ls.count[2 * (parity ^ 1) + 1] = 0; }   // the next round's
+    const int lane = threadIdx.x & 63;
+    const int64_t g = (int64_t)bb * 256 + threadIdx.x;
+    bool todo = g < n_tiles;
+    int my_lo = 0, my_t = 0;
+    // slot of every lane's tile: the wavefront resolves one slot per turn (find_slot wants all 64 lanes)
+    unsigned long long pending = __builtin_amdgcn_ballot_w64(todo);
+    while (pending != 0ull) {
+        const int src = __builtin_ctzll(pending);
+        const int64_t gf = __shfl(g, src, 64);
+        const int lo = find_slot(tile_prefix, ns, gf);
+        const int64_t p0 = tile_prefix[lo], p1 = tile_prefix[lo + 1];
+        if (todo && g >= p0 && g < p1) { my_lo = lo; my_t = (int)(g - p0); todo = false; }
+        pending = __builtin_amdgcn_ballot_w64(todo);
+    }
+    bool in_reach = false, bounds = false;
+    if (g < n_tiles) {
+        const ims_bf_slot_t bs = s.bf_slots[U->first_slot[c] + my_lo];
+        const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
+        const int tiles_x = (sl.nx + 1 + UT - 1) / UT, tiles_y = (sl.ny + 1 + UT - 1) / UT;
+        const int tx = my_t % tiles_x, ty = my_t / tiles_x;
+        const unsigned char tg = (unsigned char)tag;
+        // charge marks of the 4 x 4 window (-1 .. 2)^2 around the tile, as bits
+        unsigned int m = 0u;
+#pragma unroll
+        for (int dy = -1; dy <= 2; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 2; ++dx) {
+                const int ux = tx + dx, uy = ty + dy;
+                if (ux < 0 || uy < 0 || ux >= tiles_x || uy >= tiles_y) continue;
+                if (s.bf_tile_charge[cell_index(sl, ux * UT, uy * UT)] == tg) m |= 1u << ((dy + 1) * 4 + (dx + 1));
+            }
+        // 3 x 3 windows around the tile, its right and its upper neighbour (bit = row * 4 + column of the 4 x 4 window)
+        const unsigned int own_w = 0x0777u, right_w = 0x0EEEu, up_w = 0x7770u;
+        in_reach = (m & own_w) != 0u;
+        const bool right_in = tx + 1 < tiles_x && (m & right_w) != 0u;
+        const bool up_in = ty + 1 < tiles_y && (m & up_w) != 0u;
+        bounds = in_reach || right_in || up_in;
+    }
+    const unsigned long long entry = ((unsigned long long)c << 58) | ((unsigned long long)(unsigned int)my_lo << 32) | (unsigned int)my_t;
+    {
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(in_reach);
+        if (mask != 0ull) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(Ls.count + 2 * parity, (int)__popcll(mask));
+            base = __shfl(base, 0, 64);
+            if (in_reach) Ls.upd[base + (int)__popcll(mask & ((1ull << lane) - 1ull))] = entry;
+        }
+    }
+    {
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(bounds);
+        if (mask != 0ull) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(Ls.count + 2 * parity + 1, (int)__popcll(mask));
+            base = __shfl(base, 0, 64);
+            if (bounds) Ls.ref[base + (int)__popcll(mask & ((1ull << lane) - 1ull))] = entry;
+        }
+    }
+}
+
+// one listed tile
+template <int NV>
+__device__ __forceinline__ void update_listed_tile(const JointUpd* __restrict__ U, unsigned long long e, unsigned int tag, UpdateLds<NV>& L)
+{
+    const int c = (int)(e >> 58), lo = (int)((e >> 32) & 0x3FFFFFFu), t = (int)(e & 0xFFFFFFFFu);
+    const ims_sensor_t& s = *U->sp[c];
+    const ims_bf_slot_t bs = s.bf_slots[U->first_slot[c] + lo];
+    const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
+    const int tiles_x = (sl.nx + 1 + UT - 1) / UT;
+    const int tx0 = (t % tiles_x) * UT, ty0 = (t / tiles_x) * UT;
+    const double* dl_global = U->dl[c];
+    if (dl_global != nullptr) update_tile_q3<NV, true, ConstTable>(s, sl, tx0, ty0, U->changed[c], L, false, tag, (ConstTable)(uintptr_t)dl_global);
+    else update_tile_q3<NV, false>(s, sl, tx0, ty0, U->changed[c], L, false, tag);
+}
+
+template <int NV, bool DPP = false>
+__global__ __launch_bounds__(256) void k_update_list_j(const JointUpd* __restrict__ U, const JointLists Ls, int parity, unsigned int tag)
+{
+    __shared__ UpdateLds<NV> L0;
+    const int n = Ls.count[2 * parity];
+    for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
+        if (i != (int)blockIdx.x) __syncthreads();                  // the tile before is through with the shared buffers
+        // (the address of the shared buffers through a register the compiler cannot look through: inside a loop it otherwise
+        // keeps every one of the ~180 constant LDS addresses of the unrolled window in a register of its own -- 256 against 80)
+        UpdateLds<NV>* Lp = &L0;
+        asm volatile("" : "+v"(Lp));
+        update_listed_tile<NV>(U, Ls.upd[i], tag, *Lp);
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void k_refresh_list_j(const JointUpd* __restrict__ U, const JointLists Ls, int parity, unsigned int tag)
+{
+    const int n = Ls.count[2 * parity + 1];
+    for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
+        const unsigned long long e = Ls.ref[i];
+        const int c = (int)(e >> 58), lo = (int)((e >> 32) & 0x3FFFFFFu), t = (int)(e & 0xFFFFFFFFu);
+        const ims_sensor_t& s = *U->sp[c];
+        const ims_bf_slot_t bs = s.bf_slots[U->first_slot[c] + lo];
+        const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
+        const int tiles_x = (sl.nx + 1 + UT - 1) / UT, tiles_y = (sl.ny + 1 + UT - 1) / UT;
+        const int tx = t % tiles_x, ty = t / tiles_x;
+        const unsigned char tg = (unsigned char)tag;
+        const bool own = s.bf_tile_changed[cell_index(sl, tx * UT, ty * UT)] == tg;
+        const bool right = (tx + 1 < tiles_x) && s.bf_tile_changed[cell_index(sl, (tx + 1) * UT, ty * UT)] == tg;
+        const bool up = (ty + 1 < tiles_y) && s.bf_tile_changed[cell_index(sl, tx * UT, (ty + 1) * UT)] == tg;
+        const bool charged = s.bf_tile_charge[cell_index(sl, tx * UT, ty * UT)] == tg;
+        if (!(own || right || up || charged)) continue;
+        refresh_tile<NV>(s, sl, tx, ty, own, right, up, charged, (const unsigned char*)U->changed[c]);
+    }
 }
 
 // ---------------- LSST_Flat ----------------
@@ -2861,8 +3013,7 @@ int ims_plan_destroy(void* plan)
     if (!pl) return IMS_OK;
     if (pl->graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)pl->graph_exec);
     for (hipEvent_t e : pl->events) (void)hipEventDestroy(e);
-    if (pl->d_ready) (void)hipEventDestroy(pl->d_ready);
-    if (pl->d_done) (void)hipEventDestroy(pl->d_done);
+    for (hipEvent_t e : pl->d_events) (void)hipEventDestroy(e);
     delete pl;
     return IMS_OK;
 }
@@ -3012,10 +3163,11 @@ static int plan_enqueue(ims_planner::Plan* pl, ims_sensor_t* sensor_dev, ims_sen
     // the rounds of the top chain can be left to a joint run when the plan is ONE group of regions (a later group rewrites the
     // slot table behind everything queued) in the form the joint kernels take: 4 vertices per edge, qdist 3, regions in place
     pl->deferred = false;
-    const bool defer = defer_top && pl->groups.size() == 1 && pl->groups[0].n_slots > 0 && !pl->groups[0].chain_structs.empty() &&
-                       pl->groups[0].chain_structs[0].pair_shift == 0 && pl->groups[0].chain_structs[0].n_marks == 0 &&
-                       pl->groups[0].chain_structs[0].first_slot > 0 &&
-                       sensor_host->num_vertices == IT_NV && sensor_host->qdist == 3;
+    bool defer = defer_top && pl->groups.size() == 1 && pl->groups[0].n_slots > 0 && !pl->groups[0].chain_structs.empty() &&
+                 sensor_host->num_vertices == IT_NV && sensor_host->qdist == 3;
+    if (defer)
+        for (const ims_chain_t& cs : pl->groups[0].chain_structs)
+            defer = defer && cs.pair_shift == 0 && cs.n_marks == 0 && cs.first_slot > 0;
     // distinct streams
     std::vector<hipStream_t> uniq;
     for (int k = 0; k < n_streams; ++k)
@@ -3054,10 +3206,10 @@ static int plan_enqueue(ims_planner::Plan* pl, ims_sensor_t* sensor_dev, ims_sen
             sensor_host->n_bf_slots = n0 + g.n_slots;
         }
         if (defer) {
-            // the rounds item without chain 0 (the classes of a group are its chains in order, the top class first)
-            std::vector<ims_plan_item_t> items(g.items);
-            for (ims_plan_item_t& it : items)
-                if (it.kind == IMS_PLAN_ROUNDS) { it.aux2 = g.chain_structs.data() + 1; it.n_slots = it.n_slots - 1; }
+            // without the rounds item: the rounds of ALL chain classes are left to joint runs
+            std::vector<ims_plan_item_t> items;
+            for (const ims_plan_item_t& it : g.items)
+                if (it.kind != IMS_PLAN_ROUNDS) items.push_back(it);
             const int rc = ims_run_plan(items.data(), (int64_t)items.size(), sensor_dev, sensor_host, changed_dev, streams, n_streams);
             if (rc) return rc;
         } else {
@@ -3072,6 +3224,8 @@ static int plan_enqueue(ims_planner::Plan* pl, ims_sensor_t* sensor_dev, ims_sen
         for (size_t k = 0; k < uniq.size(); ++k) HIP_TRY(hipEventRecord(pl->events[2 + uniq.size() + k], uniq[k]));
         pl->unjoined = (int)uniq.size();
         pl->deferred = defer;
+        pl->left = defer ? ((1u << pl->groups[0].chain_structs.size()) - 1u) : 0u;
+        pl->d_done_used = 0;
         pl->d_sensor_dev = sensor_dev; pl->d_sensor_host = sensor_host; pl->d_changed = changed_dev; pl->d_main = main_stream;
         pl->d_streams.assign(streams, streams + n_streams);
         return IMS_OK;
@@ -3091,8 +3245,8 @@ int ims_plan_join(void* plan, void* stream)
     if (pl->deferred) return set_err(IMS_ERR_ARG, "ims_plan_join: the rounds left by ims_plan_run_deferred have not been run (ims_plans_run_joint)");
     hipStream_t st = (hipStream_t)stream;
     for (int k = 0; k < pl->unjoined; ++k) HIP_TRY(hipStreamWaitEvent(st, pl->events[2 + (size_t)pl->unjoined + k], 0));
-    if (pl->joint_done) HIP_TRY(hipStreamWaitEvent(st, pl->d_done, 0));
-    pl->unjoined = 0; pl->joint_done = false;
+    for (size_t k = 0; k < pl->d_done_used; ++k) HIP_TRY(hipStreamWaitEvent(st, pl->d_events[4 + k], 0));
+    pl->unjoined = 0; pl->d_done_used = 0;
     return IMS_OK;
 }
 
@@ -3104,25 +3258,38 @@ int ims_plan_run_deferred(void* plan, ims_sensor_t* sensor_dev, ims_sensor_t* se
     if (!pl || !pl->uploaded) return set_err(IMS_ERR_ARG, "plan is NULL or not uploaded");
     if (!deferred) return set_err(IMS_ERR_ARG, "deferred is NULL");
     const int rc = plan_enqueue(pl, sensor_dev, sensor_host, slots_dev, changed_dev, main_stream, streams, n_streams, own_work_queued, true);
-    *deferred = (rc == IMS_OK && pl->deferred) ? 1 : 0;
+    *deferred = (rc == IMS_OK && pl->deferred) ? (int32_t)pl->groups[0].chain_structs.size() : 0;
     return rc;
 }
 
-int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream)
+int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream, int32_t first_chain, int32_t n_chains)
 {
     using namespace ims_planner;
     if (n_plans < 0 || (n_plans > 0 && !plans)) return set_err(IMS_ERR_ARG, "plans is NULL");
-    struct Act { Plan* pl; const ims_chain_t* ch; };
+    if (first_chain < 0 || n_chains < 1) return set_err(IMS_ERR_ARG, "joint run: chain range");
+    struct Act { Plan* pl; const ims_chain_t* ch; int chain; hipEvent_t done; };
     std::vector<Act> act;
+    hipStream_t js = (hipStream_t)joint_stream;
     for (int32_t k = 0; k < n_plans; ++k) {
         Plan* pl = (Plan*)plans[k];
         if (!pl) return set_err(IMS_ERR_ARG, "plans: NULL entry");
         if (!pl->deferred) continue;                       // ran whole (no bright object, several groups): nothing left to do
-        act.push_back({ pl, &pl->groups[0].chain_structs[0] });
+        const int nc = (int)pl->groups[0].chain_structs.size();
+        bool any = false;
+        for (int c = first_chain; c < first_chain + n_chains && c < nc; ++c)
+            if (pl->left & (1u << c)) { act.push_back({ pl, &pl->groups[0].chain_structs[c], c, nullptr }); any = true; }
+        if (!any) continue;
+        // own events: four "chain stream ready", then one per joint run since the last join
+        while (pl->d_events.size() < 4 + pl->d_done_used + 1) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            pl->d_events.push_back(e);
+        }
+        const hipEvent_t done = pl->d_events[4 + pl->d_done_used++];
+        for (Act& a : act) if (a.pl == pl) a.done = done;
     }
     if (act.empty()) return IMS_OK;
-    if ((int)act.size() > IMS_JOINT_MAX) return set_err(IMS_ERR_ARG, "at most 16 deferred plans per joint run");
-    hipStream_t js = (hipStream_t)joint_stream;
+    if ((int)act.size() > IMS_JOINT_MAX) return set_err(IMS_ERR_ARG, "at most 32 chains per joint run");
     const int32_t nrecalc = act[0].ch->nrecalc, use_tags = act[0].ch->use_tags;
     int32_t max_rounds = 0;
     for (const Act& a : act) {
@@ -3131,33 +3298,42 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream)
         if (!ch.params || !ch.pool || !ch.pool->converted || !ch.pool_start || !ch.params->objects || !ch.params->image)
             return set_err(IMS_ERR_ARG, "joint run: chain without table / pool / image");
         if (ch.n_rounds > max_rounds) max_rounds = ch.n_rounds;
-        // the joint stream takes over behind the plan's chain stream (the regions' initial state, the first pool slice)
-        if (!a.pl->d_ready) {
-            HIP_TRY(hipEventCreateWithFlags(&a.pl->d_ready, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&a.pl->d_done, hipEventDisableTiming));
-        }
-        hipStream_t cs = (hipStream_t)a.pl->d_streams[ROLE_CHAIN];
+        // the joint stream takes over behind the chain's own stream (the regions' initial state, the first pool slice)
+        hipStream_t cs = (hipStream_t)a.pl->d_streams[ch.stream];
         if (cs != js) {
-            HIP_TRY(hipEventRecord(a.pl->d_ready, cs));
-            HIP_TRY(hipStreamWaitEvent(js, a.pl->d_ready, 0));
+            HIP_TRY(hipEventRecord(a.pl->d_events[a.chain & 3], cs));
+            HIP_TRY(hipStreamWaitEvent(js, a.pl->d_events[a.chain & 3], 0));
         }
     }
     const int32_t segs = (nrecalc + 255) / 256;
     static const long long dpp_max_tiles = getenv("IMS_UPD_DPP_MAX") ? atoll(getenv("IMS_UPD_DPP_MAX")) : 128;
     // the per-chain argument blocks in device memory, one table per joint run out of a ring (a table is read until the run's
     // last round: the ring's event says when)
-    struct Ring { JointTables* dev; hipEvent_t free_after; bool used; };
+    // active-tile lists (k_build_active_j): on for rounds of more than list_min_tiles tiles; IMS_JOINT_LISTS=0: the full sweeps
+    const bool lists_on = os_getenv_off("IMS_JOINT_LISTS");           // (read at every run: the tests switch them)
+    const long long list_min_tiles = getenv("IMS_JOINT_LIST_MIN") ? atoll(getenv("IMS_JOINT_LIST_MIN")) : 1024;
+    const double list_fraction = getenv("IMS_ACTIVE_FRACTION") ? atof(getenv("IMS_ACTIVE_FRACTION")) : 0.25;
+    int64_t tiles_max = 0;                                   // round 0 has them all
+    for (const Act& a : act) {
+        const int32_t n_cont = count_above(a.ch->n_phot, a.ch->n_objects, (int64_t)nrecalc);
+        tiles_max += n_cont > 0 ? a.ch->tile_prefix_host[n_cont] : 0;
+    }
+    const bool lists = lists_on && tiles_max > list_min_tiles;
+    struct Ring { JointTables* dev; hipEvent_t free_after; bool used; unsigned long long* upd; unsigned long long* ref; int* count; int64_t cap; };
     static std::vector<Ring> ring;
     static size_t ring_next = 0;
     JointTables* tables_dev = nullptr;
     hipEvent_t table_event = nullptr;
+    JointLists Ls{ nullptr, nullptr, nullptr };
     {
         std::lock_guard<std::mutex> lock(g_state_mutex);
         if (ring.empty()) {
             JointTables* block = nullptr;
+            int* counts = nullptr;
             HIP_TRY(hipMalloc((void**)&block, 64 * sizeof(JointTables)));
+            HIP_TRY(hipMalloc((void**)&counts, 64 * 4 * sizeof(int)));
             for (int k = 0; k < 64; ++k) {
-                Ring r{ block + k, nullptr, false };
+                Ring r{ block + k, nullptr, false, nullptr, nullptr, counts + 4 * k, 0 };
                 HIP_TRY(hipEventCreateWithFlags(&r.free_after, hipEventDisableTiming));
                 ring.push_back(r);
             }
@@ -3165,26 +3341,37 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream)
         Ring& r = ring[ring_next++ % ring.size()];
         if (r.used) HIP_TRY(hipEventSynchronize(r.free_after));
         r.used = true;
+        if (lists && r.cap < tiles_max) {
+            // (a growth is a device-wide synchronisation: the capacity is kept and rounded up generously)
+            if (r.upd) { HIP_TRY(hipFree(r.upd)); HIP_TRY(hipFree(r.ref)); }
+            r.cap = tiles_max + tiles_max / 2 + 65536;
+            HIP_TRY(hipMalloc((void**)&r.upd, (size_t)r.cap * sizeof(unsigned long long)));
+            HIP_TRY(hipMalloc((void**)&r.ref, (size_t)r.cap * sizeof(unsigned long long)));
+        }
         tables_dev = r.dev; table_event = r.free_after;
+        Ls.upd = r.upd; Ls.ref = r.ref; Ls.count = r.count;
     }
-    JointTables T;
-    std::memset(&T, 0, sizeof(T));
+    if (lists) HIP_TRY(hipMemsetAsync(Ls.count, 0, 4 * sizeof(int), js));
     bool dpp_ok = true;
-    for (size_t k = 0; k < (size_t)IMS_JOINT_MAX; ++k) {
-        const Act& a = act[k < act.size() ? k : 0];                   // unused entries repeat chain 0 (never selected: zero width)
-        const ims_chain_t& ch = *a.ch;
-        const ims_render_params_t& P = *ch.params;
-        RoundArgs& ra = T.acc.a[k];
-        ra.objects = P.objects; ra.sensor = P.sensor; ra.image = P.image; ra.realized_flux = P.realized_flux;
-        ra.px = ch.pool->x; ra.py = ch.pool->y; ra.pflux = ch.pool->flux; ra.pz = ch.pool->dxdz;
-        ra.nx = P.nx; ra.ny = P.ny; ra.xmin = P.xmin; ra.ymin = P.ymin;
-        ra.bf_tag = 0; ra.bf_slot_shift = 0; ra.track_static_delta = P.track_static_delta; ra.pad = 0;
-        T.acc.pool_start[k] = ch.pool_start;
-        T.upd.sp[k] = a.pl->d_sensor_dev; T.upd.tile_prefix[k] = ch.tile_prefix; T.upd.changed[k] = a.pl->d_changed;
-        T.upd.dl[k] = a.pl->d_sensor_host->bf_dl; T.upd.first_slot[k] = ch.first_slot;
-        dpp_ok = dpp_ok && a.pl->d_sensor_host->bf_dl != nullptr;
+    for (size_t k0 = 0; k0 < act.size(); k0 += JOINT_CHUNK) {
+        JointChunk Ck;
+        std::memset(&Ck, 0, sizeof(Ck));
+        for (size_t k = 0; k < (size_t)JOINT_CHUNK; ++k) {
+            const Act& a = act[k0 + k < act.size() ? k0 + k : 0];         // entries beyond the last repeat chain 0 (never selected: zero width)
+            const ims_chain_t& ch = *a.ch;
+            const ims_render_params_t& P = *ch.params;
+            RoundArgs& ra = Ck.a[k];
+            ra.objects = P.objects; ra.sensor = P.sensor; ra.image = P.image; ra.realized_flux = P.realized_flux;
+            ra.px = ch.pool->x; ra.py = ch.pool->y; ra.pflux = ch.pool->flux; ra.pz = ch.pool->dxdz;
+            ra.nx = P.nx; ra.ny = P.ny; ra.xmin = P.xmin; ra.ymin = P.ymin;
+            ra.bf_tag = 0; ra.bf_slot_shift = 0; ra.track_static_delta = P.track_static_delta; ra.pad = 0;
+            Ck.pool_start[k] = ch.pool_start;
+            Ck.sp[k] = a.pl->d_sensor_dev; Ck.tile_prefix[k] = ch.tile_prefix; Ck.changed[k] = a.pl->d_changed;
+            Ck.dl[k] = a.pl->d_sensor_host->bf_dl; Ck.first_slot[k] = ch.first_slot;
+            dpp_ok = dpp_ok && a.pl->d_sensor_host->bf_dl != nullptr;
+        }
+        hipLaunchKernelGGL(k_store_joint_tables, dim3(1), dim3(64), 0, js, Ck, tables_dev, (int)k0);
     }
-    hipLaunchKernelGGL(k_store_joint_tables, dim3(1), dim3(256), 0, js, T, tables_dev);
     for (int32_t r = 0; r < max_rounds; ++r) {
         for (const Act& a : act) {
             const ims_chain_t& ch = *a.ch;
@@ -3197,39 +3384,64 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream)
                     HIP_TRY(hipStreamWaitEvent(js, e, 0));
                 }
         }
-        const uint32_t tag = use_tags ? (uint32_t)(r % 255 + 1) : 0u;
-        JointEnds ea, eu, ns;
-        int64_t wgs = 0, tiles = 0;
+        const uint32_t tag = (use_tags || lists) ? (uint32_t)(r % 255 + 1) : 0u;
+        JointEnds ea, eu, ns, ewg, tof;
+        int64_t wgs = 0, tiles = 0, build_wgs = 0;
         for (int k = 0; k < IMS_JOINT_MAX; ++k) {
             int32_t n_act = 0, n_cont = 0;
+            int64_t tk = 0;
             if (k < (int)act.size() && r < act[k].ch->n_rounds) {
                 const ims_chain_t& ch = *act[k].ch;
                 n_act = count_above(ch.n_phot, ch.n_objects, (int64_t)r * nrecalc);
                 n_cont = count_above(ch.n_phot, ch.n_objects, (int64_t)(r + 1) * nrecalc);
-                tiles += n_cont > 0 ? ch.tile_prefix_host[n_cont] : 0;
+                tk = n_cont > 0 ? ch.tile_prefix_host[n_cont] : 0;
             }
+            tiles += tk;
+            build_wgs += (tk + 255) / 256;
             wgs += (int64_t)n_act * segs;
             if (wgs > 0x7fffffffLL || tiles > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "joint run: too many workgroups for one round");
             ea.v[k] = (int32_t)wgs; eu.v[k] = (int32_t)tiles; ns.v[k] = n_cont > 0 ? n_cont : 1;
+            ewg.v[k] = (int32_t)build_wgs; tof.v[k] = (int32_t)tk;
         }
         if (wgs > 0) {
             LaunchTimer tm(js, 4);
             hipLaunchKernelGGL((k_accumulate_round_j<4, 256>), dim3((unsigned)wgs), dim3(256), 0, js, (const JointAcc*)&tables_dev->acc, ea, tag,
                                (int64_t)r * nrecalc, nrecalc, segs);
         }
-        if (tiles > 0) {
+        if (tiles > 0 && lists && tiles > list_min_tiles) {
+            // marks -> lists -> the update and the refresh over the listed tiles (a launch of a fraction of the tiles walks them)
+            const JointUpd* U = &tables_dev->upd;
+            const int parity = r & 1;
+            int64_t grid = (int64_t)((double)tiles * list_fraction);
+            if (grid < 256 && list_fraction >= 0.05) grid = 256;
+            if (grid < 1) grid = 1;
+            if (grid > tiles) grid = tiles;
+            hipLaunchKernelGGL(k_build_active_j, dim3((unsigned)build_wgs), dim3(256), 0, js, U, ewg, tof, ns, tag, Ls, parity);
+            hipLaunchKernelGGL((k_update_list_j<4, false>), dim3((unsigned)grid), dim3(256), 0, js, U, Ls, parity, tag);
+            hipLaunchKernelGGL(k_refresh_list_j<4>, dim3((unsigned)grid), dim3(256), 0, js, U, Ls, parity, tag);
+        } else if (tiles > 0) {
             const JointUpd* U = &tables_dev->upd;
             const bool dpp = dpp_ok && os_getenv_off("IMS_UPD_DPP") && tiles <= dpp_max_tiles;
             if (dpp) hipLaunchKernelGGL((k_update_distortions_q3_j<4, true>), dim3((unsigned)tiles), dim3(256), 0, js, U, eu, ns, tag);
             else hipLaunchKernelGGL((k_update_distortions_q3_j<4, false>), dim3((unsigned)tiles), dim3(256), 0, js, U, eu, ns, tag);
             hipLaunchKernelGGL(k_refresh_changed_j<4>, dim3((unsigned)tiles), dim3(256), 0, js, U, eu, ns, tag);
         }
-        for (const Act& a : act)
-            if (r == a.ch->n_rounds - 1) HIP_TRY(hipEventRecord(a.pl->d_done, js));     // this CCD's chain is through
+        // a CCD's chains of this run are through with the longest of them
+        for (size_t k = 0; k < act.size(); ++k) {
+            const Act& a = act[k];
+            int32_t last = 0;
+            bool first_of_plan = true;
+            for (size_t j = 0; j < act.size(); ++j)
+                if (act[j].pl == a.pl) { if (j < k) first_of_plan = false; if (act[j].ch->n_rounds > last) last = act[j].ch->n_rounds; }
+            if (first_of_plan && r == last - 1) HIP_TRY(hipEventRecord(a.done, js));
+        }
     }
     HIP_TRY(hipEventRecord(table_event, js));
     HIP_TRY(hipGetLastError());
-    for (const Act& a : act) { a.pl->deferred = false; a.pl->joint_done = true; }
+    for (const Act& a : act) {
+        a.pl->left &= ~(1u << a.chain);
+        if (a.pl->left == 0u) a.pl->deferred = false;
+    }
     return IMS_OK;
 }
 

@@ -840,7 +840,7 @@ class NativePlan:
         if defer:
             left = C.c_int32(0)
             _abi.check(r.lib.ims_plan_run_deferred(*args, C.byref(left)), "ims_plan_run_deferred")
-            self.deferred = bool(left.value)
+            self.deferred = int(left.value)        # chains whose rounds are left to run_joint_plans
             self._keep_renderer = r                # the library holds pointers into its bound scene until the joint run
         else:
             _abi.check(r.lib.ims_plan_run(*args), "ims_plan_run")
@@ -880,17 +880,20 @@ class NativePlan:
             pass
 
 
-def run_joint_plans(plans, stream):
-    """The rounds that run(defer=True) left of up to sixteen plans (the top chains of a focal plane's CCDs), in lockstep on `stream`:
-    three launches per round for all of them (ims_plans_run_joint)."""
-    plans = [p for p in plans if p is not None]
+def run_joint_plans(plans, stream, first_chain=0, n_chains=1):
+    """The rounds that run(defer=True) left: the chain classes first_chain .. first_chain + n_chains - 1 (0 = the top class: the
+    brightest stars) of the given plans in lockstep on `stream`, three launches per round for all of them (ims_plans_run_joint;
+    at most 32 chains per call: longer lists go in several calls)."""
+    plans = [p for p in plans if p is not None and getattr(p, "deferred", 0)]
     if not plans:
         return
     lib = plans[0]._lib
-    arr = (C.c_void_p * len(plans))(*[p.handle.value for p in plans])
-    _abi.check(lib.ims_plans_run_joint(arr, len(plans), C.c_void_p(stream.cuda_stream)), "ims_plans_run_joint")
-    for p in plans:
-        p.deferred = False
+    per_call = max(1, 32 // max(int(n_chains), 1))
+    for a in range(0, len(plans), per_call):
+        part = plans[a:a + per_call]
+        arr = (C.c_void_p * len(part))(*[p.handle.value for p in part])
+        _abi.check(lib.ims_plans_run_joint(arr, len(part), C.c_void_p(stream.cuda_stream), int(first_chain), int(n_chains)),
+                   "ims_plans_run_joint")
 
 
 class Renderer:

@@ -53,16 +53,30 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
     ahead_on, _, ahead_n = os.environ.get("IMS_FOCAL_AHEAD", "pre:1").partition(":")
     ahead_n = int(ahead_n or 0)
     fronts = []
+    trace = [] if os.environ.get("IMS_FOCAL_TRACE", "0") == "1" else None
+    if trace is not None:
+        t_base = torch.cuda.Event(enable_timing=True)
+        t_base.record(bulk)
+        h_base = time.perf_counter()
 
     def front(key):
         scene, work = build(key)
         if ahead_n > 0 and len(fronts) >= ahead_n:
             fronts[-ahead_n].synchronize()
+        t_host = time.perf_counter()
         e = _front(key, scene, work)
         ev = torch.cuda.Event()
         ev.record({"pre": pre, "bulk": bulk, "mid": mid}[ahead_on])
         fronts.append(ev)
         del fronts[:-8]
+        if trace is not None:
+            # IMS_FOCAL_TRACE=1: when did this CCD's work end on every stream (device clocks) and when was it enqueued (host)
+            marks = {}
+            for name, st in (("bulk", bulk), ("pre", pre), ("mid", mid)):
+                marks[name] = torch.cuda.Event(enable_timing=True)
+                marks[name].record(st)
+            trace.append(dict(key=key, host0=t_host, host1=time.perf_counter(), marks=marks))
+            e["trace"] = trace[-1]
         return e
 
     def _front(key, scene, work):
@@ -92,9 +106,11 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
                 if host.shape != img.shape:
                     host = torch.empty(img.shape, dtype=img.dtype, pin_memory=True)
                 host.copy_(img, non_blocking=True)
-                done = torch.cuda.Event()
+                done = torch.cuda.Event(enable_timing=trace is not None)
                 done.record(mid)
             e["host"], e["done"] = host, done
+            if trace is not None:
+                e["trace"]["done"] = done
 
     def collect(entries):
         for e in sorted(entries, key=lambda e: e["plan"].sizes.n_round_launches if e["plan"] is not None else 0):
@@ -112,12 +128,20 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
     for batch in batches:
         t0 = time.perf_counter()
         cur = [front(key) for key in batch]
+        left = [e["plan"] for e in cur if e["plan"] is not None and getattr(e["plan"], "deferred", 0)]
+        n_joint[0] += len(left)
+        # the middle and low chain classes of the batch jointly on the stream that carried them one CCD at a time -- ahead of the
+        # previous batch's tails, which wait for that batch's longest chain
+        run_joint_plans(left, mid, 1, 3)
         if prev is not None:
             tail(prev)
-        left = [e["plan"] for e in cur if e["plan"] is not None and getattr(e["plan"], "deferred", False)]
-        n_joint[0] += len(left)
-        with torch.cuda.stream(pre):
-            run_joint_plans(left, st_joint)
+        run_joint_plans(left, st_joint, 0, 1)
+        if trace is not None:
+            jd = torch.cuda.Event(enable_timing=True)
+            jd.record(st_joint)
+            for e in cur:
+                e["trace"]["joint_end"] = jd
+                e["trace"]["host_joint"] = time.perf_counter()
         host_s[0] += time.perf_counter() - t0
         if prev is not None:
             collect(prev)
@@ -125,6 +149,14 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
     if prev is not None:
         tail(prev)
         collect(prev)
+    if trace is not None:
+        torch.cuda.synchronize()
+        print("focal trace [ms since the start]: CCD, host enqueue begin / end, its work's end on bulk / pre / mid, its batch's joint rounds end, image on host")
+        for t in trace:
+            g = {k: t_base.elapsed_time(v) for k, v in t["marks"].items()}
+            print(f"  CCD {t['key']:4d} host {1e3 * (t['host0'] - h_base):8.1f} {1e3 * (t['host1'] - h_base):8.1f} | bulk {g['bulk']:8.1f} pre {g['pre']:8.1f} "
+                  f"mid {g['mid']:8.1f} | joint end {t_base.elapsed_time(t['joint_end']):8.1f} (enqueued {1e3 * (t['host_joint'] - h_base):8.1f}) "
+                  f"done {t_base.elapsed_time(t['done']):8.1f}")
     render_focal_plane.last_host_ms_per_ccd = 1e3 * host_s[0] / max(len(mine), 1)
     render_focal_plane.last_joint_plans = n_joint[0]          # CCDs whose top chain ran in joint launches
     return out

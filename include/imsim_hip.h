@@ -783,17 +783,19 @@ int  ims_plan_run(void* plan, ims_sensor_t* sensor_dev, ims_sensor_t* sensor_hos
  * barely overlap on the device -- but ONE launch holding the same round of several chains costs little more than the round of
  * one.  ims_plan_run_deferred enqueues a plan like ims_plan_run but (a) does not join the plan's streams into main_stream --
  * it records where the plan's work ends on each of them, so that streams shared by role may go on with the next CCD -- and (b)
- * leaves the rounds of the TOP chain out when they can run jointly: *deferred = 1 (0: nothing left -- no bright object, several
- * region groups, 8 vertices per edge).  ims_plans_run_joint runs the left rounds of up to 16 such plans in lockstep on
- * joint_stream -- three launches per round for all of them (pixel search, updatePixelDistortions, bounds refresh: the kernels of
- * ims_accumulate_round / ims_sensor_update_distortions with the argument blocks of all chains) -- and marks the end of every
- * plan's last round; plans with nothing left are skipped.  ims_plan_join makes `stream` wait for everything of one plan (its
- * streams' recorded ends and, if it took part, its last joint round): what ims_plan_run does at its end.  The pointers handed to
- * ims_plan_run_deferred must stay valid until ims_plans_run_joint has returned.  Same images as ims_plan_run, bit for bit. */
+ * leaves the rounds of its chain classes out when they can run jointly: *deferred = the number of chains left (0: none -- no
+ * bright object, several region groups, 8 vertices per edge: the plan ran whole).  ims_plans_run_joint runs the chains
+ * first_chain .. first_chain + n_chains - 1 (0 = the top class) of the given plans -- at most 32 chains -- in lockstep on
+ * joint_stream: three launches per round for all of them (pixel search, updatePixelDistortions, bounds refresh: the kernels of
+ * ims_accumulate_round / ims_sensor_update_distortions with the argument blocks of all chains in a device table) and marks the
+ * end of every plan's last round; plans with nothing left in that range are skipped.  Every chain left must be run by some call.
+ * ims_plan_join makes `stream` wait for everything of one plan (its streams' recorded ends and its joint rounds): what
+ * ims_plan_run does at its end.  The pointers handed to ims_plan_run_deferred must stay valid until the last joint run of the
+ * plan has returned.  Same images as ims_plan_run, bit for bit. */
 int  ims_plan_run_deferred(void* plan, ims_sensor_t* sensor_dev, ims_sensor_t* sensor_host, ims_bf_slot_t* slots_dev,
                            unsigned char* changed_dev, void* main_stream, void* const* streams, int32_t n_streams,
                            int32_t own_work_queued, int32_t* deferred);
-int  ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream);
+int  ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream, int32_t first_chain, int32_t n_chains);
 int  ims_plan_join(void* plan, void* stream);
 /* out[master row] += realized flux of every object (after ims_plan_run, on the same main stream) */
 int  ims_plan_add_realized(void* plan, double* out_dev, void* stream);

@@ -3121,6 +3121,22 @@ int ims_plan_run(void* plan, ims_sensor_t* sensor_dev, ims_sensor_t* sensor_host
     Plan* pl = (Plan*)plan;
     if (!pl || !pl->uploaded) return set_err(IMS_ERR_ARG, "plan is NULL or not uploaded");
     static const bool use_graph = getenv("IMS_PLAN_GRAPH") && atoi(getenv("IMS_PLAN_GRAPH")) != 0;
+    // IMS_PLAN_LISTS=1: the rounds of a single plan through the joint runner too (one chain per run, each class on its own
+    // stream): its update and refresh launches walk the lists of active tiles instead of sweeping every tile of every region
+    static const bool through_joint = getenv("IMS_PLAN_LISTS") && atoi(getenv("IMS_PLAN_LISTS")) != 0;
+    if (through_joint && !use_graph) {
+        int rc = plan_enqueue(pl, sensor_dev, sensor_host, slots_dev, changed_dev, main_stream, streams, n_streams, own_work_queued, true);
+        if (rc) return rc;
+        if (pl->deferred) {
+            void* self = pl;
+            const int nc = (int)pl->groups[0].chain_structs.size();
+            for (int c = 0; c < nc; ++c) {
+                rc = ims_plans_run_joint(&self, 1, streams[pl->groups[0].chain_structs[c].stream], c, 1);
+                if (rc) return rc;
+            }
+        }
+        return ims_plan_join(pl, main_stream);
+    }
     if (!use_graph || g_timing != 0)
         return plan_enqueue(pl, sensor_dev, sensor_host, slots_dev, changed_dev, main_stream, streams, n_streams, own_work_queued);
     hipStream_t main = (hipStream_t)main_stream;

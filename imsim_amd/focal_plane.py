@@ -182,8 +182,8 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
         raise ValueError("concurrent must be >= 1")
     # plan streams by role for all CCDs of the device: the long chains of two CCDs side by side (engine._focal_streams)
     roles = "focal" if os.environ.get("IMS_FOCAL_STREAMS", "1") != "0" else "single"
-    # IMS_FOCAL_JOINT (default 8; 0 / 1: off): the top chains of that many CCDs advance jointly (_render_joint)
-    joint = int(os.environ.get("IMS_FOCAL_JOINT", "8"))
+    # IMS_FOCAL_JOINT (default 16; 0 / 1: off): the top chains of that many CCDs advance jointly (_render_joint)
+    joint = int(os.environ.get("IMS_FOCAL_JOINT", "16"))
     if joint > 1 and roles == "focal" and os.environ.get("IMS_NATIVE_PLAN", "1") != "0":
         torch.cuda.set_device(dev)
         return _render_joint(mine, build, dev, nrecalc, sink, post, min(joint, 16), chain_hint)

@@ -32,12 +32,15 @@ for q,ks in sorted(byq.items()):
     gaps=[(ks[i][1]-ks[i-1][2])/1e6 for i in range(1,len(ks))]
     big=[(round((ks[i][1]-t0)/1e6,1), round(g,2)) for i,g in zip(range(1,len(ks)),gaps) if g>2.0]
     print('     idle gaps > 2 ms (at, length):', big[:30])
-for name in ('accumulate_round_j','update_distortions_q3_j','refresh_changed_j','accumulate_round_c','k_update_distortions_q3<','k_refresh_changed<'):
+for name in ('accumulate_round_j','update_distortions_q3_j','refresh_changed_j','build_active_j','update_list_j','refresh_list_j','accumulate_round_c','k_update_distortions_q3<','k_refresh_changed<','k_shoot_photons','k_shoot_accumulate','k_init_tiles','copyBuffer','elementwise','k_fft'):
     ks=[k for k in step if name in k[0]]
     if not ks: continue
     d=np.array([k[2]-k[1] for k in ks])/1e3
     print('%-28s n %5d sum %8.2f ms avg %6.1f us  p50 %6.1f p90 %6.1f max %7.1f   wgs avg %d'%(name,len(ks),d.sum()/1e3,d.mean(),np.percentile(d,50),np.percentile(d,90),d.max(), np.mean([k[4] for k in ks])))
-jq=[k for k in step if '_j' in k[0].split('<')[0][-3:] or 'round_j' in k[0] or 'q3_j' in k[0] or 'changed_j' in k[0]]
+jq=[k for k in step if 'round_j' in k[0] and k[4] > 0]
+import collections as _c
+qc=_c.Counter(k[3] for k in jq)
+jq=[k for k in jq if k[3]==qc.most_common()[-1][0]] if len(qc)>1 else jq
 if jq:
     q=jq[0][3]
     ks=byq[q]

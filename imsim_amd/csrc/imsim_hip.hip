@@ -1842,15 +1842,49 @@ __global__ __launch_bounds__(256) void k_fft_spikes(const ims_fft_params_t P, co
                 const double lim = 0.5 * fabs(k.d_alpha) + 1.0e-6;
                 none = mc > 1.0 + 1.0e-3 && mc - 1.0e-3 > lim * rmax;
             }
-            if (!none)
-            for (int ry = r0; ry <= r1; ++ry)
-                for (int rx = c0; rx <= c1; ++rx) {
-                    const int a = iy - ry, b = ix - rx;
-                    if (a < -P.spikes.cutoff || a > P.spikes.cutoff || b < -P.spikes.cutoff || b > P.spikes.cutoff) continue;
-                    double src = rin[o.r_offset + (int64_t)ry * o.nfft + rx];
-                    if (src < 0.0) src = 0.0;
-                    acc = acc + spike_stencil(P.spikes, a, b) / P.spikes.norm * src;
+            if (!none) {
+                // Of a source row only the columns near the two arms through this pixel can contribute (|xr| or |yr| within the
+                // stencil's reach T: one interval of columns each, ims_fft.h spike_stencil); everything else in the row is an exact
+                // zero.  The columns are visited in ascending order as before, so the sum is the same sum -- a saturated star's
+                // box is 100 x 100 source pixels, of which a target pixel on an arm needs ~16 per row.
+                const ims_spikes_t& k = P.spikes;
+                const double lim = 0.5 * fabs(k.d_alpha) + 1.0e-6;
+                const double bfar = fabs((double)(ix - c0)) > fabs((double)(ix - c1)) ? fabs((double)(ix - c0)) : fabs((double)(ix - c1));
+                const bool has_s = fabs(k.sin0) > 1.0e-12, has_c = fabs(k.cos0) > 1.0e-12;
+                const double inv_s = has_s ? 1.0 / k.sin0 : 0.0, inv_c = has_c ? 1.0 / k.cos0 : 0.0;
+                for (int ry = r0; ry <= r1; ++ry) {
+                    const int a = iy - ry;
+                    if (a < -k.cutoff || a > k.cutoff) continue;
+                    const double da = (double)a;
+                    const double T = 1.0 + 1.0e-3 + lim * sqrt(da * da + bfar * bfar);
+                    int lo[2], hi[2];
+                    // |cos0 a + sin0 b| <= T
+                    if (has_s) {
+                        const double b1 = (-T - k.cos0 * da) * inv_s, b2 = (T - k.cos0 * da) * inv_s;
+                        const double bl = b1 < b2 ? b1 : b2, bh = b1 < b2 ? b2 : b1;
+                        lo[0] = (int)floor((double)ix - bh) - 1; hi[0] = (int)ceil((double)ix - bl) + 1;
+                    } else if (fabs(k.cos0 * da) <= T) { lo[0] = c0; hi[0] = c1; }
+                    else { lo[0] = 1; hi[0] = 0; }
+                    // |-sin0 a + cos0 b| <= T
+                    if (has_c) {
+                        const double b1 = (-T + k.sin0 * da) * inv_c, b2 = (T + k.sin0 * da) * inv_c;
+                        const double bl = b1 < b2 ? b1 : b2, bh = b1 < b2 ? b2 : b1;
+                        lo[1] = (int)floor((double)ix - bh) - 1; hi[1] = (int)ceil((double)ix - bl) + 1;
+                    } else if (fabs(k.sin0 * da) <= T) { lo[1] = c0; hi[1] = c1; }
+                    else { lo[1] = 1; hi[1] = 0; }
+                    for (int q = 0; q < 2; ++q) { if (lo[q] < c0) lo[q] = c0; if (hi[q] > c1) hi[q] = c1; }
+                    if (lo[1] < lo[0]) { const int tl = lo[0], th = hi[0]; lo[0] = lo[1]; hi[0] = hi[1]; lo[1] = tl; hi[1] = th; }
+                    if (hi[0] >= lo[0] && hi[1] >= lo[1] && lo[1] <= hi[0] + 1) { if (hi[1] > hi[0]) hi[0] = hi[1]; lo[1] = 1; hi[1] = 0; }   // one run
+                    for (int q = 0; q < 2; ++q)
+                        for (int rx = lo[q]; rx <= hi[q]; ++rx) {
+                            const int b = ix - rx;
+                            if (b < -k.cutoff || b > k.cutoff) continue;
+                            double src = rin[o.r_offset + (int64_t)ry * o.nfft + rx];
+                            if (src < 0.0) src = 0.0;
+                            acc = acc + spike_stencil(k, a, b) / k.norm * src;
+                        }
                 }
+            }
             v = v + acc;
         }
         rout[o.r_offset + local] = v;

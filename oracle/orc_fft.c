@@ -213,15 +213,44 @@ void orc_fft_spikes(const ims_fft_params_t* P, const ims_fft_object_t* objs, int
                         double lim = 0.5 * fabs(k->d_alpha) + 1.0e-6;
                         none = mc > 1.0 + 1.0e-3 && mc - 1.0e-3 > lim * rmax;
                     }
-                    if (!none)
-                    for (int ry = r0; ry <= r1; ++ry)
-                        for (int rx = c0; rx <= c1; ++rx) {
-                            int a = iy - ry, b = ix - rx;
-                            if (a < -k->cutoff || a > k->cutoff || b < -k->cutoff || b > k->cutoff) continue;
-                            double src = rin[o->r_offset + (int64_t)ry * n + rx];
-                            if (src < 0.0) src = 0.0;
-                            acc = acc + orc_spike_stencil(k, a, b) / k->norm * src;
+                    if (!none) {
+                        /* of a source row only the columns near the two arms through this pixel can be non-zero (|xr| or |yr| within
+                           the stencil's reach: one interval of columns each), visited in ascending order as the full row was */
+                        double lim = 0.5 * fabs(k->d_alpha) + 1.0e-6;
+                        double bfar = fabs((double)(ix - c0)) > fabs((double)(ix - c1)) ? fabs((double)(ix - c0)) : fabs((double)(ix - c1));
+                        int has_s = fabs(k->sin0) > 1.0e-12, has_c = fabs(k->cos0) > 1.0e-12;
+                        double inv_s = has_s ? 1.0 / k->sin0 : 0.0, inv_c = has_c ? 1.0 / k->cos0 : 0.0;
+                        for (int ry = r0; ry <= r1; ++ry) {
+                            int a = iy - ry;
+                            if (a < -k->cutoff || a > k->cutoff) continue;
+                            double da = (double)a;
+                            double T = 1.0 + 1.0e-3 + lim * sqrt(da * da + bfar * bfar);
+                            int lo[2], hi[2];
+                            if (has_s) {
+                                double b1 = (-T - k->cos0 * da) * inv_s, b2 = (T - k->cos0 * da) * inv_s;
+                                double bl = b1 < b2 ? b1 : b2, bh = b1 < b2 ? b2 : b1;
+                                lo[0] = (int)floor((double)ix - bh) - 1; hi[0] = (int)ceil((double)ix - bl) + 1;
+                            } else if (fabs(k->cos0 * da) <= T) { lo[0] = c0; hi[0] = c1; }
+                            else { lo[0] = 1; hi[0] = 0; }
+                            if (has_c) {
+                                double b1 = (-T + k->sin0 * da) * inv_c, b2 = (T + k->sin0 * da) * inv_c;
+                                double bl = b1 < b2 ? b1 : b2, bh = b1 < b2 ? b2 : b1;
+                                lo[1] = (int)floor((double)ix - bh) - 1; hi[1] = (int)ceil((double)ix - bl) + 1;
+                            } else if (fabs(k->sin0 * da) <= T) { lo[1] = c0; hi[1] = c1; }
+                            else { lo[1] = 1; hi[1] = 0; }
+                            for (int q = 0; q < 2; ++q) { if (lo[q] < c0) lo[q] = c0; if (hi[q] > c1) hi[q] = c1; }
+                            if (lo[1] < lo[0]) { int tl = lo[0], th = hi[0]; lo[0] = lo[1]; hi[0] = hi[1]; lo[1] = tl; hi[1] = th; }
+                            if (hi[0] >= lo[0] && hi[1] >= lo[1] && lo[1] <= hi[0] + 1) { if (hi[1] > hi[0]) hi[0] = hi[1]; lo[1] = 1; hi[1] = 0; }
+                            for (int q = 0; q < 2; ++q)
+                                for (int rx = lo[q]; rx <= hi[q]; ++rx) {
+                                    int b = ix - rx;
+                                    if (b < -k->cutoff || b > k->cutoff) continue;
+                                    double src = rin[o->r_offset + (int64_t)ry * n + rx];
+                                    if (src < 0.0) src = 0.0;
+                                    acc = acc + orc_spike_stencil(k, a, b) / k->norm * src;
+                                }
                         }
+                    }
                     v = v + acc;
                 }
                 rout[o->r_offset + local] = v;

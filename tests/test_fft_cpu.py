@@ -1,5 +1,8 @@
 """FFT branch, CPU side: the oracle's k-space fill / Poisson deviate and the host decision logic."""
+import math
+
 import numpy as np
+import pytest
 
 from imsim_amd import _abi, configs, catalog, fft_draw, tables
 from oracle import orc_loader
@@ -109,6 +112,48 @@ def test_apply_diffraction_psf_matches_reference():
     out = orc.spikes(rows, grid.ravel()).reshape(n, n)[:ny, :nx]
     np.testing.assert_allclose(out, g["apply_out"], rtol=1e-12, atol=1e-9)
     assert abs(out.sum() / img.sum() - 1) < 0.05      # flux is moved into the spikes, not created
+
+
+@pytest.mark.parametrize("rot,box", [(0.698, 9), (0.0, 13), (math.pi / 4, 5), (math.pi / 2, 11), (2.1, 17)])
+def test_spike_convolution_visits_exactly_the_nonzero_terms(rot, box):
+    """The box (x) stencil sum of apply_diffraction_psf (imsim/diffraction_fft.py:176-208) as the oracle forms it -- whole
+    sums skipped far from every arm, of a source row only the columns near the two arms through the target pixel -- equals
+    the plain double sum over the whole box with the oracle's own stencil values, term by term in the same order: bit for
+    bit, for arms along the axes, along the diagonals and in between."""
+    n, w = 96, 60
+    cfg = dfft.DiffractionFFT(exptime=30.0, azimuth=math.radians(114.39), altitude=math.radians(53.16), rotTelPos=rot,
+                              spike_length_cutoff=w, brightness_threshold=1e5)
+    from imsim_amd.engine import Scene
+    orc = orc_loader.OracleFft(Scene(nx=n, ny=n, seed=1), [], add_noise=False, diffraction_fft=cfg, wavelength=622.0)
+    rows = np.zeros(1, dtype=_abi.FFT_OBJECT_DTYPE)
+    rows["nfft"], rows["x0"], rows["y0"] = n, 1, 1
+    rows["stamp_xmin"], rows["stamp_xmax"], rows["stamp_ymin"], rows["stamp_ymax"] = 1, n, 1, n
+    rng = np.random.default_rng(int(rot * 1000) + box)
+    grid = rng.random((n, n)) * 10.0
+    cy, cx = n // 2 + 3, n // 2 - 5
+    r0, r1, c0, c1 = cy - box // 2, cy + box // 2, cx - box // 2, cx + box // 2
+    grid[r0:r1 + 1, c0:c1 + 1] = 2e5 * (1 + rng.random((box, box)))
+    out = orc.spikes(rows, grid.ravel()).reshape(n, n)
+    S = orc.P.spikes
+    st = np.empty((2 * w + 1, 2 * w + 1))
+    orc_loader.load().orc_test_stencil(C.byref(S), w, st.ctypes.data)
+    want = grid.copy()
+    want[r0:r1 + 1, c0:c1 + 1] = 0.0                               # the saturated box is replaced by its spread
+    for iy in range(n):
+        for ix in range(n):
+            acc = 0.0
+            for ry in range(r0, r1 + 1):
+                a = iy - ry
+                if abs(a) > w:
+                    continue
+                for rx in range(c0, c1 + 1):
+                    b = ix - rx
+                    if abs(b) > w or st[a + w, b + w] == 0.0:
+                        continue
+                    acc = acc + st[a + w, b + w] / S.norm * grid[ry, rx]
+            want[iy, ix] = want[iy, ix] + acc
+    assert np.array_equal(out.view(np.uint64), want.view(np.uint64))
+    assert np.count_nonzero(out != grid) > 4 * box * box           # the cross reaches well beyond the box
 
 
 # ---------------------------------------------------------------------------------------------

@@ -1,9 +1,7 @@
 #!/bin/bash
-R=$PWD
-timeout 900 python3 -m pytest tests -m gpu -q -x -k "fft or spike or focal" 2>&1 | tail -3
-python3 bench.py --config fft 2>/dev/null | python3 -c "
+c3() { env "$@" python3 bench.py --no-cpu-baseline --no-cold 2>/dev/null | python3 -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('fft', round(d['ms_per_step'],3), d.get('cpu_baseline',{}).get('parity',{}).get('bit_identical'))"
-python3 bench.py --config c5 --steps 3 --warmup 2 > gpurun_out/r4f3_c5_bench.json 2>/dev/null; python3 -c "
-import json
-d=json.load(open('gpurun_out/r4f3_c5_bench.json')); print('c5', round(d['ms_per_step'],1), round(d['value']), d.get('cpu_baseline',{}).get('parity',{}).get('bit_identical'), d['cpu_baseline']['value'], d['cpu_baseline']['sample'])"
+d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],2))"; }
+drv() { n=$1; shift; env R4_SKIP_SINGLE=1 R4_CONC=4 "$@" python3 tools/dbg/r4_c5.py $n 2>&1 | grep "concurrent\|Error\|error" | head -3; }
+for R in 0 8 16 32 64 16:low 32:low; do echo "C3 reserve $R"; c3 IMS_RESERVE_CUS=$R; done
+for R in 0 16 32 64; do echo "C5 reserve $R"; drv 189 IMS_RESERVE_CUS=$R; done

@@ -36,6 +36,8 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
     pre, bulk, mid = _focal_streams(torch, dev, top_index=1)[:3]
     if pre is st_joint:
         raise RuntimeError("the joint focal plane needs two top streams (IMS_FOCAL_TOPS >= 2)")
+    # IMS_FOCAL_FFT=bulk / mid: the FFT-drawn objects of a CCD beside its plan on that stream instead of ahead of it on `pre`
+    fft_on = {"bulk": bulk, "mid": mid}.get(os.environ.get("IMS_FOCAL_FFT", "top"))
     order = list(mine)
     if chain_hint is not None and os.environ.get("IMS_NO_HINT", "0") != "1":
         order.sort(key=chain_hint, reverse=True)
@@ -79,17 +81,19 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
             e["trace"] = trace[-1]
         return e
 
+    init_on = {"bulk": bulk, "mid": mid, "pre": pre}[os.environ.get("IMS_FOCAL_JOINT_INIT", "bulk")]
+
     def _front(key, scene, work):
-        with torch.cuda.stream(bulk):
+        with torch.cuda.stream(init_on):
             renderer = Renderer(scene, dev, stream_roles="focal", top_index=1)
             ready = torch.cuda.Event()
-            ready.record(bulk)
+            ready.record(init_on)
         with torch.cuda.stream(pre):
             pre.wait_event(ready)
             if isinstance(work, lsst_image.CcdJob):
                 if work.nrecalc is None:
                     work.nrecalc = nrecalc
-                fin = lsst_image.draw_job(renderer, work, defer=True)
+                fin = lsst_image.draw_job(renderer, work, defer=True, fft_stream=fft_on)
                 plan = fin.plan
             else:
                 plan = renderer.render_lsst_image(work, nrecalc=nrecalc, defer=True)

@@ -1432,6 +1432,27 @@ def test_joint_top_chains_of_a_focal_plane_equal_a_chain_per_ccd(torch_cuda, mon
         assert sorted(images) == dets
         for det in dets:
             assert_bits_equal(images[det], single[det], f"CCD {det}: joint rounds (batches of {joint}) vs a chain per CCD")
+    # CCDs whose plans cannot leave their rounds to a joint run ride along in the same batch: one without any object that needs
+    # rounds of its own (no regions, no chain), one whose regions do not fit the scratch capacity at once (several groups: a later
+    # group rewrites the slot table, so the plan runs whole)
+    odd = {det: jobs[det].objects.copy() for det in dets}
+    odd[dets[0]]["n_phot"] = np.minimum(odd[dets[0]]["n_phot"], 9000)
+    bright = odd[dets[1]][odd[dets[1]]["n_phot"] > 10000]
+    cells = ((bright["stamp_xmax"] - bright["stamp_xmin"] + 2).astype(np.int64) * (bright["stamp_ymax"] - bright["stamp_ymin"] + 2)).sum()
+
+    def build_odd(det):
+        sc = copy.copy(build(det)[0])
+        if det == dets[1]:
+            sc.sensor = copy.copy(sc.sensor)
+            sc.sensor.scratch_cells = int(cells * 0.6)
+        return sc, odd[det]
+    monkeypatch.setenv("IMS_FOCAL_JOINT", "0")
+    single = focal_plane.render_focal_plane(dets, build_odd, concurrent=2, nrecalc=10000)
+    monkeypatch.setenv("IMS_FOCAL_JOINT", "8")
+    images = focal_plane.render_focal_plane(dets, build_odd, concurrent=2, nrecalc=10000)
+    assert focal_plane.render_focal_plane.last_joint_plans == len(dets) - 2
+    for det in dets:
+        assert_bits_equal(images[det], single[det], f"CCD {det}: plans that run whole in a joint batch")
     # the object tables of photon-only CCDs (no CcdJob) take the same path
     tables = {det: jobs[det].objects for det in dets}
     monkeypatch.setenv("IMS_FOCAL_JOINT", "0")

@@ -1,1 +1,1 @@
-timeout 900 python3 -m pytest tests/test_parity_gpu.py -m gpu -q -x -k "joint_top_chains" 2>&1 | tail -15
+for J in 16 8 4 0; do python3 tools/dbg/r4_cold.py 64 $J 2>&1 | grep "^joint"; done

@@ -922,7 +922,7 @@ class Renderer:
         self._plans_run = 0
         # the library's record / wait events are process-wide and addressed by number: every renderer numbers its own from a
         # block of 1 000, so that the plans of several CCDs may be enqueued from different host threads at the same time
-        self._event_block = (next(_RENDERER_SERIAL) % 48) * 1000
+        self._event_block = (next(_RENDERER_SERIAL) % 56) * 1000
         self.s_chain, self.s_bulk, self.s_chain1, self.s_chain2, self.s_chain3 = self.plan_streams
         self.use_bf_tags = os.environ.get("IMS_BF_TAGS", "0") != "0"
         # round-count thresholds that cut the bright objects into concurrent chains (plan_lsst_image)

@@ -700,8 +700,14 @@ def _c5_step(renderer, objects, rank=0, world=1, concurrent=None):
     ordinary = n_phot[n_phot <= nrecalc]
     launch.photons = int(n_phot.sum())
     launch.object_rows = len(n_phot)
-    # the fused launch of the ordinary objects (one per CCD): f64 image RMW 16 B per photon + one 256-B row per object
-    launch.timed = {1: (len(mine), int(ordinary.sum()) * 16 + len(ordinary) * 256), 2: (0, 0)}
+    # 1, the fused launch of the ordinary objects (one per CCD): f64 image RMW 16 B per photon + one 256-B row per object;
+    # 2, the pool launches of the bright objects (the kernel with the largest summed time of a step, profiles/round4_c5_kernel_stats.txt):
+    # every pooled photon's 32-byte converted record written + one 256-B row per object and launch
+    from .engine import plan_sizes
+    z = [plan_sizes(renderer, jobs[d].objects, nrecalc) for d in mine]
+    launch.timed = {1: (len(mine), int(ordinary.sum()) * 16 + len(ordinary) * 256),
+                    2: (int(sum(v.n_shoot_launches for v in z)), int(sum(v.shoot_photons * 32 + v.shoot_rows * 256 for v in z)))}
+    launch.timed_waves = {1: 4 * int(sum(v.render_segments for v in z)), 2: 4 * int(sum(v.shoot_segments for v in z))}
     launch.n_ccds = len(mine)
     n_fft = sum(jobs[d].n_fft for d in mine)
     nfft = np.concatenate([jobs[d].fft_rows["nfft"] for d in mine if jobs[d].n_fft] or [np.zeros(0, dtype=np.int64)]).astype(np.int64)
@@ -730,8 +736,8 @@ BENCH_CONFIGS["c5"] = dict(
     make_step=_c5_step,
     reduce=False,                         # CCDs are independent: no exchange between the ranks
     focal=True,                           # every CCD through a fresh renderer on the device's four streams by role
-    timed_kernel=1,
-    kernel="k_shoot_accumulate",
+    timed_kernel=2,                       # the pool launches of the bright objects: the largest summed kernel time of a C5 step
+    kernel="k_shoot_photons<2>",
     cpu_sample=10000,
     cpu_sample_of=c5_cpu_sample,          # CCD 0 whole, as the job the GPU runs
     cpu_scene=_c3_cpu_scene,

@@ -760,6 +760,45 @@ def upload_async(torch, device, arr):
     return out.view(a.shape) if a.ndim != 1 else out
 
 
+def plan_input(r, n_phot, stamp, faint, nrecalc=None, want_realized=False):
+    """ims_plan_input_t of one LSST_Image render on renderer r (the arrays must stay alive while the struct is used)"""
+    ss = r.scene.sensor
+    inp = _abi.PlanInput()
+    inp.n = len(n_phot)
+    inp.n_phot, inp.stamp, inp.faint = n_phot.ctypes.data, stamp.ctypes.data, faint.ctypes.data
+    b = r.bound
+    if ss is not None:
+        inp.nrecalc = int(ss.model.nrecalc if nrecalc is None else nrecalc)
+        inp.n_static_slots, inp.slot_capacity = b.n_static_slots, b.slot_capacity
+        inp.static_cells, inp.scratch_cells = b.static_cells, int(ss.scratch_cells)
+    thresholds = list(r.chain_class_rounds)[:3]
+    inp.n_class_rounds = len(thresholds)
+    for k, v in enumerate(thresholds):
+        inp.class_rounds[k] = int(v)
+    inp.max_pool_photons = int(r.max_pool_photons)
+    inp.seg_size, inp.want_realized = int(r.scene.seg_size), 1 if want_realized else 0
+    inp.event_base, inp.use_tags = int(r._event_block), 1 if r.use_bf_tags else 0
+    # (measured, DESIGN.md 4 round 4: C3 23.95 / 24.16 ms with, 23.97 / 24.09 ms without -- what the wide rounds wait for is not
+    # the class's own slices; off by default)
+    inp.head_start = 1 if os.environ.get("IMS_HEAD_START", "0") != "0" else 0
+    return inp
+
+
+def plan_sizes(r, objects, nrecalc=None):
+    """ims_plan_sizes_t of the plan renderer r would build for an OBJECT_DTYPE host table -- host code only (launch counts,
+    photons and rows per launch kind: what bench.py prices a focal plane's kernels with)"""
+    objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
+    n_phot = np.ascontiguousarray(objects["n_phot"], dtype=np.int64)
+    stamp = np.stack([objects["stamp_xmin"], objects["stamp_xmax"], objects["stamp_ymin"], objects["stamp_ymax"]],
+                     axis=1).astype(np.int32) if len(objects) else np.zeros((0, 4), dtype=np.int32)
+    faint = ((objects["flags"] & _abi.IMS_OBJ_FAINT) != 0).astype(np.uint8)
+    inp = plan_input(r, n_phot, stamp, faint, nrecalc)
+    handle, sizes = C.c_void_p(), _abi.PlanSizes()
+    _abi.check(r.lib.ims_plan_lsst_image(C.byref(inp), C.byref(handle), C.byref(sizes)), "ims_plan_lsst_image")
+    r.lib.ims_plan_destroy(handle)
+    return sizes
+
+
 class NativePlan:
     """The launch plan of one LSST_Image render, built (ims_plan_lsst_image), bound to memory (ims_plan_bind), uploaded
     (ims_plan_upload) and run (ims_plan_run) by the library.  torch provides the memory: a page-locked arena and its device copy,
@@ -788,24 +827,8 @@ class NativePlan:
                              axis=1).astype(np.int32) if len(objects) else np.zeros((0, 4), dtype=np.int32)
             faint = ((objects["flags"] & _abi.IMS_OBJ_FAINT) != 0).astype(np.uint8)
         self.n_master = len(n_phot)
-        inp = _abi.PlanInput()
-        inp.n = len(n_phot)
-        inp.n_phot, inp.stamp, inp.faint = n_phot.ctypes.data, stamp.ctypes.data, faint.ctypes.data
+        inp = plan_input(r, n_phot, stamp, faint, nrecalc, want_realized)
         b = r.bound
-        if ss is not None:
-            inp.nrecalc = int(ss.model.nrecalc if nrecalc is None else nrecalc)
-            inp.n_static_slots, inp.slot_capacity = b.n_static_slots, b.slot_capacity
-            inp.static_cells, inp.scratch_cells = b.static_cells, int(ss.scratch_cells)
-        thresholds = list(r.chain_class_rounds)[:3]
-        inp.n_class_rounds = len(thresholds)
-        for k, v in enumerate(thresholds):
-            inp.class_rounds[k] = int(v)
-        inp.max_pool_photons = int(r.max_pool_photons)
-        inp.seg_size, inp.want_realized = int(r.scene.seg_size), 1 if want_realized else 0
-        inp.event_base, inp.use_tags = int(r._event_block), 1 if r.use_bf_tags else 0
-        # (measured, DESIGN.md 4 round 4: C3 23.95 / 24.16 ms with, 23.97 / 24.09 ms without -- what the wide rounds wait for is not
-        # the class's own slices; off by default)
-        inp.head_start = 1 if os.environ.get("IMS_HEAD_START", "0") != "0" else 0
         handle, sizes = C.c_void_p(), _abi.PlanSizes()
         _abi.check(lib.ims_plan_lsst_image(C.byref(inp), C.byref(handle), C.byref(sizes)), "ims_plan_lsst_image")
         self.handle, self.sizes = handle, sizes

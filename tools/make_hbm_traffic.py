@@ -25,7 +25,7 @@ def short_name(long_name):
 
 def main():
     out = {}
-    for cfg in ("c2", "c3", "c3b"):
+    for cfg in ("c2", "c3", "c3b", "c5"):
         cands = [(f"profiles/round4_{cfg}_hbm_pmc.json", f"profiles/round4_{cfg}_sq_pmc.json"),
                  (f"profiles/round3_{cfg}_hbm_pmc.json", f"profiles/round3_{cfg}_sq_pmc.json"),
                  (f"profiles/round2e_{cfg}_hbm_pmc.json", f"profiles/round2e_{cfg}_sq_pmc.json"),

@@ -41,6 +41,22 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
     order = list(mine)
     if chain_hint is not None and os.environ.get("IMS_NO_HINT", "0") != "1":
         order.sort(key=chain_hint, reverse=True)
+    # Two batches of renderers are alive at a time (one running its joint rounds, one being enqueued): the batch is cut to what
+    # the device's memory holds -- per CCD the static pixel-boundary state and the scratch regions (235 B per cell), the f64
+    # image and its float copy, and ~1.5 GB for the photon pool and the FFT buffers of a bright CCD.  (C5 bench scene, 6 M scratch
+    # cells: 6.9 GB per CCD, 16 per batch on 288 GB; config.Process's default of 24 M scratch cells: 11 GB, 10 per batch.)
+    prebuilt = {}
+    if order:
+        prebuilt[order[0]] = build(order[0])
+        sc0 = prebuilt[order[0]][0]
+        cells = ((sc0.nx + 1) * (sc0.ny + 1) + int(getattr(sc0.sensor, "scratch_cells", 0))) if getattr(sc0, "sensor", None) is not None else 0
+        per_ccd = cells * 235 + sc0.nx * sc0.ny * 12 + 1.5e9
+        free, total = torch.cuda.mem_get_info(dev)
+        usable = free + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)      # the allocator's cached blocks count
+        fit = int(0.85 * usable / (2.0 * per_ccd))
+        if fit < joint:
+            joint = max(fit, 1)
+    render_focal_plane.last_joint_batch = joint
     batches = [order[a:a + joint] for a in range(0, len(order), joint)]
     pinned_pool = []
     out = {}
@@ -62,7 +78,7 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
         h_base = time.perf_counter()
 
     def front(key):
-        scene, work = build(key)
+        scene, work = prebuilt.pop(key) if key in prebuilt else build(key)
         if ahead_n > 0 and len(fronts) >= ahead_n:
             fronts[-ahead_n].synchronize()
         t_host = time.perf_counter()

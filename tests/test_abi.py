@@ -36,6 +36,21 @@ def test_struct_sizes_match_binding():
     assert C.sizeof(_abi.BfSlot) == _abi.BFSLOT_DTYPE.itemsize
 
 
+def test_joint_run_entry_points_check_their_arguments_before_any_hip_call():
+    """ims_plan_run_deferred / ims_plans_run_joint / ims_plan_join (the CCDs of a visit side by side): argument errors are
+    reported without touching the GPU; an empty list of plans is a no-op."""
+    lib = _abi.load()
+    left = C.c_int32(7)
+    assert lib.ims_plan_run_deferred(None, None, None, None, None, None, None, 0, 0, C.byref(left)) == -1
+    assert b"plan" in lib.ims_last_error()
+    assert lib.ims_plans_run_joint(None, 1, None, 0, 1) == -1 and b"plans" in lib.ims_last_error()
+    one = (C.c_void_p * 1)(None)
+    assert lib.ims_plans_run_joint(one, 1, None, 0, 1) == -1 and b"NULL entry" in lib.ims_last_error()
+    assert lib.ims_plans_run_joint(one, 1, None, 0, 0) == -1 and b"chain range" in lib.ims_last_error()
+    assert lib.ims_plans_run_joint(None, 0, None, 0, 1) == 0
+    assert lib.ims_plan_join(None, None) == -1 and b"plan is NULL" in lib.ims_last_error()
+
+
 def test_abi_version_and_error_string():
     lib = _abi.load()
     assert lib.ims_abi_version() == 18

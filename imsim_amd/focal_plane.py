@@ -14,6 +14,8 @@ stream is addressed by (CCD seed, object id, photon index).
 import os
 import time
 
+import numpy as np
+
 from . import parallel, lsst_image
 from .engine import Renderer
 
@@ -216,9 +218,28 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
     roles = "focal" if os.environ.get("IMS_FOCAL_STREAMS", "1") != "0" else "single"
     # IMS_FOCAL_JOINT (default 16; 0 / 1: off): the top chains of that many CCDs advance jointly (_render_joint)
     joint = int(os.environ.get("IMS_FOCAL_JOINT", "16"))
-    if joint > 1 and roles == "focal" and os.environ.get("IMS_NATIVE_PLAN", "1") != "0":
-        torch.cuda.set_device(dev)
-        return _render_joint(mine, build, dev, nrecalc, sink, post, min(joint, 16), chain_hint)
+    if joint > 1 and roles == "focal" and os.environ.get("IMS_NATIVE_PLAN", "1") != "0" and mine:
+        # Joint rounds pay where a CCD's chains are few objects wide (a focal plane of 10 k-source CCDs: 150 objects with rounds
+        # of their own, 9.4 against 23 ms per CCD; 13.9 against 15.8 with four CCDs).  A CCD of 100 k sources has 1 500 of
+        # them: its launches are wide already, and what counts is that the next CCD's host work overlaps its 25 ms on the GPU,
+        # which the rolling window below does and a batch does not (three such CCDs: 60 against 77 ms per CCD).  The first
+        # CCD's work decides (IMS_FOCAL_JOINT_MAX_BRIGHT objects with rounds of their own, default 600).
+        first_key = max(mine, key=chain_hint) if chain_hint is not None and os.environ.get("IMS_NO_HINT", "0") != "1" else mine[0]
+        first = build(first_key)
+        cache = {first_key: first}
+        inner = build
+
+        def build(key, inner=inner, cache=cache):               # noqa: F811 -- the first CCD is built once
+            return cache.pop(key) if key in cache else inner(key)
+        work = first[1]
+        table = work.objects if isinstance(work, lsst_image.CcdJob) else work
+        n_phot = np.asarray(table["n_phot"] if isinstance(table, np.ndarray) else getattr(table, "n_phot", np.zeros(0)))
+        sensor = getattr(first[0], "sensor", None)
+        nrec = nrecalc if nrecalc is not None else (getattr(work, "nrecalc", None) or (sensor.model.nrecalc if sensor is not None else 0))
+        bright = int(np.count_nonzero(n_phot > nrec)) if nrec else 0
+        if bright <= int(os.environ.get("IMS_FOCAL_JOINT_MAX_BRIGHT", "600")):
+            torch.cuda.set_device(dev)
+            return _render_joint(mine, build, dev, nrecalc, sink, post, min(joint, 16), chain_hint)
     # the anchor streams are kept per device for the life of the process: PyTorch's caching allocator files a freed block
     # under the stream it was allocated on, so fresh streams per call would miss the cache and hipMalloc every CCD's
     # gigabytes of sensor state again (measured: 13 -> 27 .. 34 ms per CCD for the calls that do)

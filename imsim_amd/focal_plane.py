@@ -218,7 +218,8 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
     roles = "focal" if os.environ.get("IMS_FOCAL_STREAMS", "1") != "0" else "single"
     # IMS_FOCAL_JOINT (default 16; 0 / 1: off): the top chains of that many CCDs advance jointly (_render_joint)
     joint = int(os.environ.get("IMS_FOCAL_JOINT", "16"))
-    if joint > 1 and roles == "focal" and os.environ.get("IMS_NATIVE_PLAN", "1") != "0" and mine:
+    heavy = False
+    if roles == "focal" and mine:
         # Joint rounds pay where a CCD's chains are few objects wide (a focal plane of 10 k-source CCDs: 150 objects with rounds
         # of their own, 9.4 against 23 ms per CCD; 13.9 against 15.8 with four CCDs).  A CCD of 100 k sources has 1 500 of
         # them: its launches are wide already, and what counts is that the next CCD's host work overlaps its 25 ms on the GPU,
@@ -237,7 +238,8 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
         sensor = getattr(first[0], "sensor", None)
         nrec = nrecalc if nrecalc is not None else (getattr(work, "nrecalc", None) or (sensor.model.nrecalc if sensor is not None else 0))
         bright = int(np.count_nonzero(n_phot > nrec)) if nrec else 0
-        if bright <= int(os.environ.get("IMS_FOCAL_JOINT_MAX_BRIGHT", "600")):
+        heavy = bright > int(os.environ.get("IMS_FOCAL_JOINT_MAX_BRIGHT", "600"))
+        if not heavy and joint > 1 and os.environ.get("IMS_NATIVE_PLAN", "1") != "0":
             torch.cuda.set_device(dev)
             return _render_joint(mine, build, dev, nrecalc, sink, post, min(joint, 16), chain_hint)
     # the anchor streams are kept per device for the life of the process: PyTorch's caching allocator files a freed block
@@ -265,6 +267,9 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
         in_flight[slot] = None                 # drops the renderer: its HBM goes back to the caching allocator
 
     anchor_role = os.environ.get("IMS_FOCAL_ANCHOR", "top") if roles == "focal" else ""
+    # (pacing, below: for CCDs of the focal-plane kind only -- a CCD of 100 k sources keeps the GPU busy for 25 ms while the host
+    # plans the next one, and waiting serialises the two: 70 against 59 ms per CCD)
+    pace = not heavy and os.environ.get("IMS_FOCAL_AHEAD", "pre:1") not in ("pre:0", "bulk:0", "mid:0", "0")
     host_s = [0.0]
 
     def enqueue(k, key, slot):
@@ -296,6 +301,12 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
             renderer = Renderer(scene, dev, stream_roles=roles, top_index=top_index)
             ready = torch.cuda.Event()
             ready.record(init_on)
+        if pace:
+            # the host goes on with this CCD's plan only when its renderer's initialisation has run -- i.e. when the stream of the
+            # wide launches is through with the CCD before: with several CCDs' wide launches queued at once everything, the
+            # latency-bound rounds most, gets slower (C5 with a chain per CCD: 4.8 s unpaced, 4.4 s paced -- what synchronous
+            # uploads used to do by accident)
+            ready.synchronize()
         with torch.cuda.stream(anchor):
             anchor.wait_event(ready)
             if isinstance(work, lsst_image.CcdJob):

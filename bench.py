@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- objects/sec into one 4k x 4k LSST CCD (photon-shooting path), BASELINE.json's metric.
 
-  python bench.py --gpus N --steps K --warmup W [--config c2|c3|c3b|c4|fft] [--no-cpu-baseline]
+  python bench.py --gpus N --steps K --warmup W [--config c2|c3|c3b|c4|c5|fft] [--no-cpu-baseline] [--no-extra-configs]
 
 One step = one pass of the hot path over the whole synthetic instance catalog with
 the object table already resident in HBM.  For N > 1 there is one rank per GPU: either started by
@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-cpu-allcore", action="store_true", help="skip the all-core CPU leg")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold (plan + upload + run) render timing")
     ap.add_argument("--cpu-sample", type=int, default=0, help="objects in the one-core CPU-baseline sample")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the short runs of the other BASELINE configs (extra.configs of the default c3 line)")
     return ap.parse_args()
 
 
@@ -98,6 +100,52 @@ def spawn_ranks(args):
     return max(abs(rc) for rc in rcs) or (1 if failed is not None else 0)
 
 
+# The other BASELINE.json configs on the same record as the headline: each as a CHILD process of its own
+# -- `bench.py --config X --steps 2 --warmup 1` with a small one-core oracle sample, whose image the child's GPU renderer must
+# reproduce (the child's cpu_baseline.parity) -- started BEFORE this process touches the GPU, one after the other.
+EXTRA_CONFIGS = (("c2", 2000, {}), ("c3b", 1500, {}), ("c4", 1500, {}), ("c5", 1200, {"IMS_C5_CCDS": "32"}), ("fft", 0, {}))
+
+
+def extra_configs(budget_s=150.0):
+    out = {}
+    t_start = time.perf_counter()
+    for name, sample, env_add in EXTRA_CONFIGS:
+        left = budget_s - (time.perf_counter() - t_start)
+        if left < 10.0:
+            out[name] = {"skipped": "time budget of the extra configs used up"}
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", "2", "--warmup", "1", "--no-cold",
+               "--no-cpu-allcore", "--no-extra-configs"]
+        if sample:
+            cmd += ["--cpu-sample", str(sample)]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "IMSIM_BENCH_CONFIG")}
+        env.update(env_add)
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=left)
+            line = json.loads(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 and p.stdout.strip() else None
+        except subprocess.TimeoutExpired:
+            p, line = None, None
+        if line is None:
+            out[name] = {"failed": True, "returncode": p.returncode if p is not None else "timeout",
+                         "stderr_tail": (p.stderr[-400:] if p is not None else "")}
+            continue
+        par = (line.get("cpu_baseline") or {}).get("parity") or {}
+        entry = {"ms_per_step": line["ms_per_step"], "objects_per_s": line["value"], "photons_per_s": line.get("photons_per_s"),
+                 "steps": line["steps"], "warmup": line["warmup"],
+                 "bit_identical": par.get("bit_identical"), "parity_sample": (line.get("cpu_baseline") or {}).get("sample"),
+                 "cpu_oracle_objects_per_s": (line.get("cpu_baseline") or {}).get("value"),
+                 "workload": line["config"]["workload"], "n_objects": line["config"]["n_objects"],
+                 "wall_s": time.perf_counter() - t0}
+        if "within_tolerance" in par:          # FFT-drawn stamps: library transforms agree to ~1e-11 of the peak (parity_mode close)
+            entry["within_tolerance"] = par["within_tolerance"]
+            entry["differing_pixels"] = par.get("differing_pixels")
+        if env_add:
+            entry["env"] = env_add
+        out[name] = entry
+    return out
+
+
 JSON_FD = [1]
 
 
@@ -146,6 +194,12 @@ def main():
         timing["object_table_ms"] = 1e3 * (time.perf_counter() - t0)
         timing["cat"] = cat
         return scene, objects
+
+    # the other BASELINE configs, each a short child run with its own oracle parity flag -- before this process touches the GPU
+    extra_cfg = None
+    if (rank == 0 and world == 1 and args.config == "c3" and not args.no_extra_configs and not args.no_cpu_baseline
+            and not args.n_objects and os.environ.get("IMS_BENCH_EXTRA", "1") != "0"):
+        extra_cfg = extra_configs()
 
     cpu = None
     if cpu_first:
@@ -246,6 +300,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    dump = os.environ.get("IMS_BENCH_DUMP")
+    if dump:
+        # test hook (tests/test_multi_gpu_hip.py): what the last step left -- the reduced f64 CCD image on rank 0, or for a focal
+        # plane the CRC of every CCD's float32 image from whichever rank rendered it -- so that an N-rank run can be compared with
+        # a one-rank run bit for bit
+        hashes = getattr(step, "hashes", None)
+        if hashes is not None:
+            box = [None] * world
+            if world > 1:
+                dist.gather_object(dict(hashes), box if rank == 0 else None, dst=0)
+            else:
+                box = [dict(hashes)]
+            if rank == 0:
+                merged = {}
+                for k, part in enumerate(box):
+                    for det, h in part.items():
+                        merged[str(det)] = [int(h), k]
+                with open(dump, "w") as fh:
+                    json.dump({"ccd_crc32_and_rank": merged}, fh)
+        elif rank == 0:
+            np.savez(dump, image=renderer.image.cpu().numpy(),
+                     integer_counts_ok=np.array([parallel.integer_counts_ok(renderer.image, 1)]))
+
     n_total_obj = len(objects)
     fft_mask = getattr(objects, "fft_mask", None)           # a focal plane's FFT-drawn objects shoot no photons
     n_total_phot = int(objects["n_phot"].sum() if fft_mask is None else np.asarray(objects["n_phot"])[~fft_mask].sum())
@@ -282,6 +359,15 @@ def main():
                                               "with the concurrent brighter-fatter chains, so frac is of the whole chip"}
     roofline["limiter"] = ("f64 VALU issue (rocprofv3 SQ PMC in profiles/); HBM is the stated bound of SURVEY 8(d), "
                            "not the measured one")
+    # The whole step against its instruction floor: every VALU instruction of every kernel of a step (SQ_INSTS_VALU of the
+    # committed SQ pass, profiles/hbm_traffic.json `_step`), issued at one wave-instruction per SIMD every 4 cycles on
+    # 1024 SIMDs at 2.4 GHz, against the measured step -- the figure that says how far the step is from its own arithmetic
+    pstep = profile_entry(args.config, "_step", world)
+    if pstep:
+        floor_ms = pstep["valu_wave_insts_per_step"] / (256 * 4 * 2.4e9 / 4.0) * 1e3
+        roofline["step"] = {"valu_wave_insts": pstep["valu_wave_insts_per_step"], "floor_ms": floor_ms,
+                            "frac": floor_ms / ms_per_step, "ms_per_step": ms_per_step, "source": pstep.get("sq_source"),
+                            "note": "VALU issue floor of ALL kernels of one step / the measured step"}
     # The other large kernel of a step with brighter-fatter chains is the pixel search of the rounds (k_accumulate_round): its
     # launches are timed the same way in a few extra steps, and the line names as `roofline.kernel` whichever of the two has
     # the larger summed launch time per step -- the kernel that is dominant in the shipped kernel trace.
@@ -351,6 +437,8 @@ def main():
         if cpu is None:
             cpu = cpu_legs(cfg, scene, objects, args, fork_ok=False)
         out["cpu_baseline"] = cpu_parity(cfg, scene, cpu, device)
+    if extra_cfg is not None:
+        out.setdefault("extra", {})["configs"] = extra_cfg
     if rank == 0:
         # ONE JSON line and nothing else on stdout: libraries write there too (RCCL prints its version banner through C
         # stdio, flushed at exit -- i.e. AFTER a line printed here), so file descriptor 1 was pointed at stderr for the
@@ -434,10 +522,12 @@ def cpu_legs(cfg, scene, objects, args, fork_ok=True):
     n_sample = args.cpu_sample or cfg["cpu_sample"]
     rng = np.random.default_rng(99)
     if cfg.get("cpu_sample_of") is not None:
-        sample = cfg["cpu_sample_of"](objects, scene)           # a whole CCD of a focal plane, as the job the GPU runs
+        sample = cfg["cpu_sample_of"](objects, scene, args.cpu_sample)   # a whole CCD of a focal plane, as the job the GPU runs
         n_phot_sample = int(sample.job.objects["n_phot"].sum())
-        what = (f"CCD 0 of the focal plane whole: {len(sample)} objects, {sample.job.n_fft} of them FFT-drawn, "
-                f"{n_phot_sample} photons shot")
+        what = ((f"CCD 0 of the focal plane whole" if not args.cpu_sample else
+                 f"CCD 0 of the focal plane, its first {args.cpu_sample} objects of at most 3e5 photons and its FFT-drawn objects on grids "
+                 f"up to 2048^2, as one job") +
+                f": {len(sample)} objects, {sample.job.n_fft} of them FFT-drawn, {n_phot_sample} photons shot")
     else:
         idx = np.sort(rng.choice(len(objects), size=min(n_sample, len(objects)), replace=False))
         sample = objects[idx]

@@ -641,14 +641,29 @@ def c5_job(scene, cat, phot, rows, nrecalc=10000, fft_sb_thresh=C5_FFT_SB_THRESH
                      wavelength=v["wavelength"], nrecalc=nrecalc)
 
 
-def c5_cpu_sample(objects, scene):
-    """bench.py's CPU sample of a focal plane: CCD 0 whole, as the job the GPU runs (FFT objects, photon-shot objects)."""
+def c5_cpu_sample(objects, scene, limit=0):
+    """bench.py's CPU sample of a focal plane: CCD 0 whole, as the job the GPU runs (FFT objects, photon-shot objects).
+    limit > 0: a bounded part of that CCD for the short runs (bench.py's extra.configs) -- its first `limit` catalog rows of
+    at most 3e5 photons plus its FFT-drawn objects on grids of at most 2048^2, again as ONE job of the per-CCD build."""
     a, b = int(objects.ccd_offsets[0]), int(objects.ccd_offsets[1])
     ca, cb = int(objects.cat_offsets[0]), int(objects.cat_offsets[1])
     sub = {k: v[ca:cb] for k, v in objects.cat.items() if isinstance(v, np.ndarray)}
     rows = np.asarray(objects[a:b])
+    phot = objects.phot[ca:cb]
+    job = c5_job(scene, sub, phot, rows)
+    if limit and limit > 0:
+        kept = np.flatnonzero(phot > 0)                              # catalog rows that have an object row
+        take = np.zeros(len(phot), dtype=bool)
+        small = np.flatnonzero((phot > 0) & (phot <= 3.0e5) & ~np.isin(np.arange(len(phot)), kept[job.host["fft_rows"]]))
+        take[small[:int(limit)]] = True
+        if job.n_fft:
+            take[kept[job.fft_index[np.asarray(job.fft_rows["nfft"]) <= 2048]]] = True
+        sub = {k: v[take] for k, v in sub.items()}
+        rows = rows[take[kept]]
+        phot = phot[take]
+        job = c5_job(scene, sub, phot, rows)
     sample = rows.view(_CcdTable)
-    sample.job = c5_job(scene, sub, objects.phot[ca:cb], rows)
+    sample.job = job
     return sample
 
 
@@ -658,6 +673,7 @@ def _c5_step(renderer, objects, rank=0, world=1, concurrent=None):
     photon-shot ones, ONE arena upload, the run -- and the float32 image back on the host: what
     `focal_plane.render_focal_plane` does per CCD.  Up to `concurrent` CCDs are in flight on the device's streams."""
     import copy
+    import zlib
     from . import focal_plane, lsst_image
     from .config import ccd_seed
     offs = getattr(objects, "ccd_offsets", None)
@@ -690,9 +706,14 @@ def _c5_step(renderer, objects, rank=0, world=1, concurrent=None):
     def sink(det, image):
         # stands for the FITS writer: the image is on the host; a coarse checksum proves it arrived
         launch.checksums[det] = float(image[::64, ::64].sum())
+        if want_hashes:
+            launch.hashes[det] = zlib.crc32(np.ascontiguousarray(image).view(np.uint8).reshape(-1))
+
+    want_hashes = bool(os.environ.get("IMS_BENCH_DUMP"))      # bench.py's test hook: the CRC of every CCD's float32 image
 
     def launch():
         launch.checksums = {}
+        launch.hashes = {}
         focal_plane.render_focal_plane(list(range(len(offs) - 1)), build, device=str(renderer.device), rank=rank, world=world,
                                        concurrent=concurrent, nrecalc=nrecalc, sink=sink,
                                        chain_hint=lambda det: int(jobs[det].objects["n_phot"].max()) if len(jobs[det].objects) else 0)
@@ -709,6 +730,7 @@ def _c5_step(renderer, objects, rank=0, world=1, concurrent=None):
                     2: (int(sum(v.n_shoot_launches for v in z)), int(sum(v.shoot_photons * 32 + v.shoot_rows * 256 for v in z)))}
     launch.timed_waves = {1: 4 * int(sum(v.render_segments for v in z)), 2: 4 * int(sum(v.shoot_segments for v in z))}
     launch.n_ccds = len(mine)
+    launch.hashes = {}
     n_fft = sum(jobs[d].n_fft for d in mine)
     nfft = np.concatenate([jobs[d].fft_rows["nfft"] for d in mine if jobs[d].n_fft] or [np.zeros(0, dtype=np.int64)]).astype(np.int64)
     bright_phot = int(np.count_nonzero(n_phot >= 1_000_000))

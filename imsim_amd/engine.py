@@ -256,6 +256,133 @@ class DeviceMem:
         slot[2] = ev
 
 
+class SensorArena:
+    """The pixel-boundary state of ALL the CCDs a device has in flight, in one set of arrays (boundary points, bounds lines,
+    delta charge, tile flags, the `changed` bytes of the update kernels), allocated once per device and process and handed out
+    as leases -- instead of 5.3 GB from the allocator for every renderer of a focal plane (imsim/ccd.py:72-89: 189 CCDs per
+    visit; a fresh process paid 5.2 s of hipMalloc for 200 GiB of them).
+
+    * `n_static` STATIC regions (slot 0 of a renderer: the whole CCD with its tree rings).  In LSST_Image mode only the fused
+      launch of the ordinary objects reads it (objects above nrecalc own private regions), so a CCD holds its static region from
+      its initialisation to the end of its front -- a couple of milliseconds, not the hundreds its longest chain takes -- and the
+      regions rotate: `lease` hands out the next one with the events behind which its previous user's readers are through.
+    * a pool of PRIVATE owner cells, leased by the size a CCD's bright objects need (the sum of their stamps: ~1.2 M cells for a
+      10 k-source CCD of the focal-plane bench, where the fixed capacity was 6 M) and returned when the CCD is collected.
+
+    All regions of a lease are addressed through the slot table's cell offsets (ims_bf_slot_t.offset) from the arena's base
+    pointers, so kernels and planner see nothing new."""
+
+    def __init__(self, torch, device, npo, static_cells, n_static, private_cells):
+        self.torch, self.device = torch, torch.device(device)
+        self.npo, self.static_cells, self.n_static = int(npo), int(static_cells), int(n_static)
+        self.private_base = self.n_static * self.static_cells
+        self.private_cells = int(private_cells)
+        total = self.private_base + self.private_cells
+        self.total_cells = total
+        f64, u8 = torch.float64, torch.uint8
+        self.boundary = torch.empty(total * self.npo * 2, dtype=f64, device=self.device)
+        self.bounds = torch.empty(total * 8, dtype=f64, device=self.device)
+        self.delta = torch.empty(total, dtype=f64, device=self.device)
+        self.flags = torch.zeros(3 * total, dtype=u8, device=self.device)       # tile_charge | tile_changed | changed
+        self.tile_charge, self.tile_changed, self.changed = self.flags[:total], self.flags[total:2 * total], self.flags[2 * total:]
+        self._static_next = 0
+        self._static_busy = [[] for _ in range(self.n_static)]     # events of the region's last readers
+        self._free = [(self.private_base, self.private_cells)]     # (first cell, cells), ascending, coalesced
+        self._lock = threading.Lock()
+
+    def nbytes(self):
+        return self.total_cells * (self.npo * 16 + 64 + 8 + 3)
+
+    def lease(self, need_cells):
+        """-> SensorLease, or None when the private pool cannot hold `need_cells` now (the caller collects a CCD and retries)"""
+        need = max(int(need_cells), 1)
+        with self._lock:
+            for k, (first, count) in enumerate(self._free):
+                if count >= need:
+                    if count == need:
+                        del self._free[k]
+                    else:
+                        self._free[k] = (first + need, count - need)
+                    idx = self._static_next % self.n_static
+                    self._static_next += 1
+                    waits, self._static_busy[idx] = self._static_busy[idx], []
+                    return SensorLease(self, idx, first, need, waits)
+        return None
+
+    def _give_back(self, first, count):
+        with self._lock:
+            self._free.append((first, count))
+            self._free.sort()
+            merged = []
+            for a, n in self._free:
+                if merged and merged[-1][0] + merged[-1][1] == a:
+                    merged[-1] = (merged[-1][0], merged[-1][1] + n)
+                else:
+                    merged.append((a, n))
+            self._free = merged
+
+
+_SENSOR_ARENAS = {}
+
+
+def sensor_arena(torch, device, npo, static_cells, n_static, private_cells, exact=False):
+    """The device's SensorArena for this CCD geometry, created on first use and re-created only when a larger private pool (or
+    more static regions) is asked for -- a focal plane after the first finds its state allocated.  exact: a pool of exactly
+    `private_cells` (tests)."""
+    key = (str(torch.device(device)), int(npo), int(static_cells))
+    a = _SENSOR_ARENAS.get(key)
+    if a is not None and a.n_static >= n_static and (a.private_cells == private_cells if exact else a.private_cells >= private_cells):
+        return a
+    if a is not None:
+        torch.cuda.synchronize(device)
+        _SENSOR_ARENAS.pop(key)
+        del a
+        torch.cuda.empty_cache()
+    a = _SENSOR_ARENAS[key] = SensorArena(torch, device, npo, static_cells, n_static, private_cells)
+    return a
+
+
+class SensorLease:
+    """One CCD's part of a SensorArena: static region `static_index` (from cell `static_offset`) and the private cells
+    [private_offset, private_offset + private_cells)."""
+
+    def __init__(self, arena, static_index, private_offset, private_cells, static_waits):
+        self.arena, self.static_index = arena, static_index
+        self.static_offset = static_index * arena.static_cells
+        self.private_offset, self.private_cells = int(private_offset), int(private_cells)
+        self.static_waits = static_waits              # the stream that initialises the static region waits for these first
+        self._static_held, self._held = True, True
+
+    def release_static(self, streams):
+        """the static region may be rewritten once everything queued so far on `streams` has run (the CCD's front is enqueued)"""
+        if not self._static_held:
+            return
+        t = self.arena.torch
+        evs = []
+        for st in streams:
+            ev = t.cuda.Event()
+            ev.record(st)
+            evs.append(ev)
+        with self.arena._lock:
+            self.arena._static_busy[self.static_index].extend(evs)
+        self._static_held = False
+
+    def release(self, streams=None):
+        """give the private cells back: the caller knows that everything of this CCD has run (focal_plane collects a CCD behind the
+        event of its image copy), or names the streams whose queued work must be waited for first"""
+        if not self._held:
+            return
+        if self._static_held:
+            t = self.arena.torch
+            self.release_static(streams if streams is not None else [t.cuda.current_stream(self.arena.device)])
+        if streams is not None:
+            for st in streams:
+                st.synchronize()
+        self._held = False
+        self.arena._give_back(self.private_offset, self.private_cells)
+
+
+
 # What the launch planner reads of an object, for tables whose 256-byte rows live on the device (device_table.DeviceTable):
 # `row` is the index into the master table, the other fields carry the names they have in OBJECT_DTYPE.
 SLIM_DTYPE = np.dtype([("row", "<i8"), ("phot_first", "<i8"), ("n_phot", "<i8"), ("flags", "<i4"), ("stamp_xmin", "<i4"),
@@ -443,12 +570,14 @@ class PlanList(list):
 class BoundScene:
     """A Scene whose tables live behind pointers of one memory provider; builds RenderParams."""
 
-    def __init__(self, scene: Scene, mem, derive):
+    def __init__(self, scene: Scene, mem, derive, lease=None):
         """derive: the library whose fill_derived_op / fill_derived_medium entry points complete the
-        launch-wide derived fields (libimsim_hip.so for the product, the oracle for the checker)."""
+        launch-wide derived fields (libimsim_hip.so for the product, the oracle for the checker).
+        lease: a SensorLease -- the pixel-boundary state lives in the device's SensorArena instead of arrays of its own."""
         self.scene = scene
         self.derive = derive
         self.mem = mem
+        self.lease = lease
         P = RenderParams()
         P.seed = scene.seed
         P.seg_size = scene.seg_size
@@ -577,28 +706,50 @@ class BoundScene:
         _, S.emptypoly = self.mem.put(m.emptypoly, np.float64)
         slots = ss.slots if ss.slots is not None else make_slots([])
         self.n_static_slots = len(slots)
+        # static_cells: the cell offset at which the private regions of bright objects begin (= the cells of the static slots
+        # when the state is this renderer's own); scratch_cells: the owner cells available for them
         self.static_cells = ss.total_cells()
+        self.scratch_cells = int(ss.scratch_cells)
         self.slot_capacity = max(len(slots), ss.max_slots)
         S.n_bf_slots = len(slots)
+        lease = self.lease
+        if lease is not None:
+            if len(slots) != 1 or self.static_cells != lease.arena.static_cells or lease.arena.npo != ss.owned_points():
+                raise ValueError("SensorLease: the arena was sized for another CCD geometry / sensor model")
+            slots = slots.copy()
+            slots["offset"] += lease.static_offset
+            self.static_cells = lease.private_offset
+            self.scratch_cells = lease.private_cells
         # LSST_Image mode never updates slot 0 (objects only distort their private regions): a rigorous bound of the
         # tree-ring displacement lets photons far from every pixel edge skip the boundary state (ims_sensor_t.pristine_margin)
         S.pristine_margin = -1.0
         if len(slots) > 0 and not self.scene.track_static_delta:
             S.pristine_margin = treering_displacement_bound(ss)
-        cells = self.static_cells + int(ss.scratch_cells)
+        cells = self.static_cells + self.scratch_cells
         npo = ss.owned_points()
         slots_host = np.zeros(self.slot_capacity, dtype=BFSLOT_DTYPE)
         slots_host[:len(slots)] = slots
         self._slots_buf, S.bf_slots = self.mem.put(slots_host.view(np.uint8))
-        # (the points of the static slots -- 2.7 GB for a 4k x 4k CCD -- are written, every one of them, by the init_boundaries
-        # that follows the construction of a renderer: no zero fill of that part)
-        self.sensor_arrays["boundary"], S.bf_boundary = self.mem.zeros(cells * npo * 2, np.float64,
-                                                                       uninitialised=self.static_cells * npo * 2)
-        self.sensor_arrays["bounds"], S.bf_bounds = self.mem.zeros(cells * 8, np.float64)
-        self.sensor_arrays["delta"], S.bf_delta = self.mem.zeros(cells, np.float64)
-        # tile flags of the brighter-fatter rounds (one byte per owner cell, used at tile origins)
-        self.sensor_arrays["tile_charge"], S.bf_tile_charge = self.mem.zeros(cells, np.uint8)
-        self.sensor_arrays["tile_changed"], S.bf_tile_changed = self.mem.zeros(cells, np.uint8)
+        if lease is not None:
+            # the arena's arrays: every region of this CCD is written by its init_boundaries (points, bounds line, zero delta)
+            # before anything reads it; only the flag bytes of the leased cells are cleared (queued on the current stream)
+            A = lease.arena
+            for name in ("boundary", "bounds", "delta", "tile_charge", "tile_changed"):
+                self.sensor_arrays[name] = getattr(A, name)
+            S.bf_boundary, S.bf_bounds, S.bf_delta = A.boundary.data_ptr(), A.bounds.data_ptr(), A.delta.data_ptr()
+            S.bf_tile_charge, S.bf_tile_changed = A.tile_charge.data_ptr(), A.tile_changed.data_ptr()
+            for flags in (A.tile_charge, A.tile_changed, A.changed):
+                flags[lease.private_offset:lease.private_offset + lease.private_cells].zero_()
+        else:
+            # (the points of the static slots -- 2.7 GB for a 4k x 4k CCD -- are written, every one of them, by the init_boundaries
+            # that follows the construction of a renderer: no zero fill of that part)
+            self.sensor_arrays["boundary"], S.bf_boundary = self.mem.zeros(cells * npo * 2, np.float64,
+                                                                           uninitialised=self.static_cells * npo * 2)
+            self.sensor_arrays["bounds"], S.bf_bounds = self.mem.zeros(cells * 8, np.float64)
+            self.sensor_arrays["delta"], S.bf_delta = self.mem.zeros(cells, np.float64)
+            # tile flags of the brighter-fatter rounds (one byte per owner cell, used at tile origins)
+            self.sensor_arrays["tile_charge"], S.bf_tile_charge = self.mem.zeros(cells, np.uint8)
+            self.sensor_arrays["tile_changed"], S.bf_tile_changed = self.mem.zeros(cells, np.uint8)
         self.derive.fill_derived_struct("sensor", S)
         # host copy whose slot table is a host pointer (sizes the launches)
         Sh = Sensor.from_buffer_copy(bytes(S))
@@ -770,7 +921,7 @@ def plan_input(r, n_phot, stamp, faint, nrecalc=None, want_realized=False):
     if ss is not None:
         inp.nrecalc = int(ss.model.nrecalc if nrecalc is None else nrecalc)
         inp.n_static_slots, inp.slot_capacity = b.n_static_slots, b.slot_capacity
-        inp.static_cells, inp.scratch_cells = b.static_cells, int(ss.scratch_cells)
+        inp.static_cells, inp.scratch_cells = b.static_cells, int(b.scratch_cells)
     thresholds = list(r.chain_class_rounds)[:3]
     inp.n_class_rounds = len(thresholds)
     for k, v in enumerate(thresholds):
@@ -843,7 +994,7 @@ class NativePlan:
                                      self.realized.data_ptr() if self.realized is not None else None), "ims_plan_bind")
         _abi.check(lib.ims_plan_upload(handle, r._stream()), "ims_plan_upload")
         if ss is not None and not hasattr(r, "_changed"):
-            cells = b.static_cells + int(ss.scratch_cells)
+            cells = b.static_cells + int(b.scratch_cells)
             r._changed = t.zeros(max(cells, 1), dtype=t.uint8, device=r.device)
 
     def run(self, defer=False):
@@ -925,14 +1076,24 @@ class Renderer:
     STREAMS = {"chain": 0, "bulk": 1, "chain1": 2, "chain2": 3, "chain3": 4}
     CHAIN_STREAMS = ("chain", "chain1", "chain2", "chain3")
 
-    def __init__(self, scene: Scene, device="cuda:0", stream_roles="single", top_index=None):
+    def __init__(self, scene: Scene, device="cuda:0", stream_roles="single", top_index=None, lease=None):
+        """lease: a SensorLease of the device's SensorArena (focal planes): the pixel-boundary state of this CCD lives there; the
+        current stream (which initialises the static region) first waits for the region's previous readers"""
         self.lib = _abi.load()
         self.mem = DeviceMem(device)
         self.torch = self.mem.torch
         self.device = self.mem.device
         self.torch.cuda.set_device(self.device)
         self.scene = scene
-        self.bound = BoundScene(scene, self.mem, _LibDerive(self.lib))
+        self.lease = lease if scene.sensor is not None else None
+        if self.lease is not None:
+            here = self.torch.cuda.current_stream(self.device)
+            for ev in self.lease.static_waits:
+                here.wait_event(ev)
+            self.lease.static_waits = []
+        self.bound = BoundScene(scene, self.mem, _LibDerive(self.lib), lease=self.lease)
+        if self.lease is not None:
+            self._changed = self.lease.arena.changed
         # f64 accumulation image (exact for integer electron counts of any size, so the result does not
         # depend on the order of the atomics); image_numpy() rounds it to the float32 ImageF
         self.image = self.torch.zeros((scene.ny, scene.nx), dtype=self.torch.float64, device=self.device)
@@ -954,6 +1115,18 @@ class Renderer:
         self.pair_max_objects = int(os.environ.get("IMS_PAIR_MAX_OBJECTS", "64"))   # chain classes up to this size use slot pairs
         if scene.sensor is not None:
             self.init_boundaries(0, len(scene.sensor.slots))
+
+    def release_state(self, streams=None):
+        """hand the leased pixel-boundary state back (SensorLease.release); a renderer without a lease has nothing to do"""
+        if getattr(self, "lease", None) is not None:
+            self.lease.release(streams)
+
+    def __del__(self):
+        try:
+            if getattr(self, "lease", None) is not None and self.lease._held:
+                self.lease.release(list(set(self.plan_streams)) + [self.torch.cuda.current_stream(self.device)])
+        except Exception:
+            pass
 
     # -- helpers --
     def _stream(self):
@@ -1129,12 +1302,12 @@ class Renderer:
                  and not self.use_bf_tags)
         if pairs:
             try:
-                normal, groups = plan_bf_groups(objects, nrecalc, b.n_static_slots, b.static_cells, ss.scratch_cells // 2,
+                normal, groups = plan_bf_groups(objects, nrecalc, b.n_static_slots, b.static_cells, b.scratch_cells // 2,
                                                 (b.slot_capacity - b.n_static_slots) // 2 + b.n_static_slots, self.max_pool_photons)
             except ValueError:
                 pairs = False                      # half the scratch does not hold the largest stamp: regions in place
         if not pairs:
-            normal, groups = plan_bf_groups(objects, nrecalc, b.n_static_slots, b.static_cells, ss.scratch_cells,
+            normal, groups = plan_bf_groups(objects, nrecalc, b.n_static_slots, b.static_cells, b.scratch_cells,
                                             b.slot_capacity, self.max_pool_photons)
             self.pairs_begin = None
         n_events = self._event_block
@@ -1242,7 +1415,7 @@ class Renderer:
         hundreds of short dependent launches and would otherwise be bound by the host launch rate."""
         b = self.bound
         if self.scene.sensor is not None and not hasattr(self, "_changed"):
-            cells = b.static_cells + int(self.scene.sensor.scratch_cells)
+            cells = b.static_cells + int(b.scratch_cells)
             self._changed = self.torch.zeros(max(cells, 1), dtype=self.torch.uint8, device=self.device)
         stretches, keep, cur = [], [], []
         cur_prefix = None
@@ -1427,7 +1600,7 @@ class Renderer:
             else:
                 b = self.bound
                 covered, _ = plan_bf_groups(objects, ss.model.nrecalc if nrecalc is None else nrecalc, b.n_static_slots,
-                                            b.static_cells, ss.scratch_cells, b.slot_capacity, self.max_pool_photons)
+                                            b.static_cells, b.scratch_cells, b.slot_capacity, self.max_pool_photons)
         sub = objects[covered]
         n_phot = sub["n_phot"].astype(np.int64)
         cum = np.concatenate([[0], np.cumsum(n_phot)]).astype(np.int64)
@@ -1806,7 +1979,7 @@ class Renderer:
 
     def update_distortions(self, first_slot, n_slots, stream=None, bf_tag=0):
         if not hasattr(self, "_changed"):
-            cells = self.bound.static_cells + int(self.scene.sensor.scratch_cells)
+            cells = self.bound.static_cells + int(self.bound.scratch_cells)
             self._changed = self.torch.zeros(max(cells, 1), dtype=self.torch.uint8, device=self.device)
         prefix, prefix_t = self._tile_prefix(first_slot)
         _abi.check(self.lib.ims_sensor_update_distortions(self.bound.sensor_dev_ptr, C.byref(self.bound.sensor_host),

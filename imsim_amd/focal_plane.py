@@ -21,6 +21,7 @@ from .engine import Renderer
 
 
 _ANCHOR_STREAMS = {}
+_ARENA_BYTES = {}           # device -> bytes of the sensor arena this process holds there (they count as usable when it is re-sized)
 
 
 def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
@@ -34,6 +35,7 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
     (its brightest photon-shot object): CCDs of similar chain length share a batch, the sum of the batches' longest chains falls."""
     import torch
     from .engine import _focal_streams, run_joint_plans
+    from . import _abi
     st_joint = _focal_streams(torch, dev, top_index=0)[0]
     pre, bulk, mid = _focal_streams(torch, dev, top_index=1)[:3]
     if pre is st_joint:
@@ -56,19 +58,67 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
     # the device's memory holds -- per CCD the static pixel-boundary state and the scratch regions (235 B per cell), the f64
     # image and its float copy, and ~1.5 GB for the photon pool and the FFT buffers of a bright CCD.  (C5 bench scene, 6 M scratch
     # cells: 6.9 GB per CCD, 16 per batch on 288 GB; config.Process's default of 24 M scratch cells: 11 GB, 10 per batch.)
+    # IMS_FOCAL_ARENA (default 1): the pixel-boundary state of the CCDs in flight comes out of ONE arena per device
+    # (engine.SensorArena: three rotating static regions, private cells leased by need) instead of 5.3 GB per renderer from the
+    # allocator -- per CCD then ~0.3 GB of private cells, the f64 image and its float copy, and the pool / FFT buffers.
+    def private_need(work, scene):
+        """owner cells the private regions of a CCD's bright objects take (the sum of their stamps), capped by the scene's capacity"""
+        ss = getattr(scene, "sensor", None)
+        if ss is None:
+            return 0
+        table = work.objects if isinstance(work, lsst_image.CcdJob) else work
+        if not isinstance(table, np.ndarray):
+            return int(ss.scratch_cells)                   # a device table: its stamps are not on the host -- the full capacity
+        nrec = nrecalc if nrecalc is not None else (getattr(work, "nrecalc", None) or ss.model.nrecalc)
+        br = (table["n_phot"] > nrec) & ((table["flags"] & _abi.IMS_OBJ_FAINT) == 0) if nrec else np.zeros(len(table), bool)
+        w = table["stamp_xmax"][br].astype(np.int64) - table["stamp_xmin"][br] + 2
+        h = table["stamp_ymax"][br].astype(np.int64) - table["stamp_ymin"][br] + 2
+        return int(min(int((w * h).sum()), int(ss.scratch_cells)))
+
+    def wants_static_late(work):
+        """the sky stage of a job draws on the pixel areas of slot 0 in the CCD's tail (lsst_image.sky_pixel_areas): such a CCD
+        keeps a state of its own"""
+        sky = getattr(work, "sky", None)
+        return sky is not None and bool(sky.get("pixel_areas", True))
+
     prebuilt = {}
+    arena = None
+    alive = max(int(os.environ.get("IMS_FOCAL_ALIVE", "3")), 2)       # batches alive at a time (the pipeline below)
     if order:
         prebuilt[order[0]] = build(order[0])
-        sc0 = prebuilt[order[0]][0]
-        cells = ((sc0.nx + 1) * (sc0.ny + 1) + int(getattr(sc0.sensor, "scratch_cells", 0))) if getattr(sc0, "sensor", None) is not None else 0
-        per_ccd = cells * 235 + sc0.nx * sc0.ny * 12 + 1.5e9
+        sc0, work0 = prebuilt[order[0]]
+        ss0 = getattr(sc0, "sensor", None)
+        use_arena = (os.environ.get("IMS_FOCAL_ARENA", "1") != "0" and ss0 is not None and ss0.slots is not None and len(ss0.slots) == 1
+                     and not sc0.track_static_delta)
         free, total = torch.cuda.mem_get_info(dev)
         usable = free + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)      # the allocator's cached blocks count
-        fit = int(0.85 * usable / (2.0 * per_ccd))
-        if fit < joint:
-            joint = max(fit, 1)
+        if use_arena:
+            from .engine import sensor_arena
+            # cells per CCD the pool is sized for: 1.5 x what the first CCD needs (the one with the longest chain when the caller
+            # gave a hint), at least a million, at most the scene's capacity; a CCD that needs more gets more while the pool
+            # lasts (lease by need), a pool that runs dry cuts the batch short (below)
+            per_cells = int(min(max(1.5 * private_need(work0, sc0), 1.0e6), max(int(ss0.scratch_cells), 1)))
+            per_ccd = per_cells * (ss0.owned_points() * 16 + 75) + sc0.nx * sc0.ny * 12 + 1.0e9
+            n_static = int(os.environ.get("IMS_FOCAL_STATIC_REGIONS", "3"))
+            static_bytes = n_static * ss0.total_cells() * (ss0.owned_points() * 16 + 75)
+            have = _ARENA_BYTES.get(str(dev), 0)
+            fit = int((0.85 * (usable + have) - static_bytes) / (alive * per_ccd))
+            if fit < joint:
+                joint = max(fit, 1)
+            pool_cells = alive * joint * per_cells
+            if os.environ.get("IMS_FOCAL_ARENA_CELLS"):          # the private pool's size, as given (tests: a pool that runs dry)
+                pool_cells = int(os.environ["IMS_FOCAL_ARENA_CELLS"])
+            arena = sensor_arena(torch, dev, ss0.owned_points(), ss0.total_cells(), n_static, pool_cells,
+                                 exact=bool(os.environ.get("IMS_FOCAL_ARENA_CELLS")))
+            _ARENA_BYTES[str(dev)] = arena.nbytes()
+        else:
+            cells = ((sc0.nx + 1) * (sc0.ny + 1) + int(getattr(ss0, "scratch_cells", 0))) if ss0 is not None else 0
+            per_ccd = cells * 235 + sc0.nx * sc0.ny * 12 + 1.5e9
+            fit = int(0.85 * usable / (alive * per_ccd))
+            if fit < joint:
+                joint = max(fit, 1)
     render_focal_plane.last_joint_batch = joint
-    batches = [order[a:a + joint] for a in range(0, len(order), joint)]
+    render_focal_plane.last_arena_gib = arena.nbytes() / 2.0**30 if arena is not None else 0.0
     pinned_pool = []
     out = {}
     host_s = [0.0]
@@ -89,11 +139,19 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
         h_base = time.perf_counter()
 
     def front(key):
+        """everything of one CCD up to its deferred rounds; None when the arena cannot lease its private cells now (the CCD
+        stays prebuilt for the retry)"""
         scene, work = prebuilt.pop(key) if key in prebuilt else build(key)
+        lease = None
+        if arena is not None and getattr(scene, "sensor", None) is not None and not wants_static_late(work):
+            lease = arena.lease(private_need(work, scene))
+            if lease is None:
+                prebuilt[key] = (scene, work)
+                return None
         if ahead_n > 0 and len(fronts) >= ahead_n:
             fronts[-ahead_n].synchronize()
         t_host = time.perf_counter()
-        e = _front(key, scene, work)
+        e = _front(key, scene, work, lease)
         ev = torch.cuda.Event()
         ev.record({"pre": pre, "bulk": bulk, "mid": mid}[ahead_on])
         fronts.append(ev)
@@ -110,9 +168,9 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
 
     init_on = {"bulk": bulk, "mid": mid, "pre": pre}[os.environ.get("IMS_FOCAL_JOINT_INIT", "pre")]
 
-    def _front(key, scene, work):
+    def _front(key, scene, work, lease=None):
         with torch.cuda.stream(init_on):
-            renderer = Renderer(scene, dev, stream_roles="focal", top_index=1)
+            renderer = Renderer(scene, dev, stream_roles="focal", top_index=1, lease=lease)
             if renderer.plan_streams[0] is not pre:
                 renderer.plan_streams = (pre,) + tuple(renderer.plan_streams[1:])
                 renderer.s_chain = pre
@@ -128,6 +186,15 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
             else:
                 plan = renderer.render_lsst_image(work, nrecalc=nrecalc, defer=True)
                 fin = plan.join if plan is not None else (lambda: None)
+                if plan is None:
+                    # (the render could not be deferred and ran whole, joined into `pre`: the tail on `mid` must wait for it)
+                    whole = torch.cuda.Event()
+                    whole.record(pre)
+                    fin = lambda whole=whole: torch.cuda.current_stream(dev).wait_event(whole)      # noqa: E731
+        if lease is not None:
+            # the static region's readers (the fused launch of the ordinary objects, on the stream of the wide launches) are
+            # queued: the region may go to the next CCD behind them.  A plan that was not deferred ran whole on these streams too.
+            lease.release_static({id(st): st for st in list(renderer.plan_streams) + [pre, init_on]}.values())
         return dict(key=key, renderer=renderer, fin=fin, plan=plan)
 
     def tail(entries):
@@ -156,12 +223,42 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
             else:
                 out[e["key"]] = e["host"].numpy().copy()
             pinned_pool.append(e["host"])
+            e["renderer"].release_state()          # everything of this CCD has run (its image is on the host): its cells go back
             e.clear()                              # drops the renderer: its HBM goes back to the caching allocator
 
+    # The pipeline, in host order: fronts of batch b | its middle and low chains (mid) | tails of batch b - 1 (mid) | its top chain
+    # (joint stream) | collect what has FINISHED.  The host does not wait for batch b - 1 here (its tails sit behind batch b's
+    # middle chains on `mid`, and a wait would hold back the fronts of batch b + 1 until those are through -- measured in round 5:
+    # the joint stream and the stream of the wide launches took turns, 100 ms each, instead of overlapping): a batch is only
+    # waited for when IMS_FOCAL_ALIVE (default 3) batches are alive -- one being enqueued, one in its rounds, one in its tails.
+    max_wait = alive - 2
     prev = None
-    for batch in batches:
+    awaiting = []                       # batches whose tails are enqueued, oldest first
+    pending = list(order)
+
+    def collect_finished(block_above):
+        while awaiting and (len(awaiting) > block_above or all(e["done"].query() for e in awaiting[0])):
+            collect(awaiting.pop(0))
+
+    while pending:
         t0 = time.perf_counter()
-        cur = [front(key) for key in batch]
+        cur = []
+        while pending and len(cur) < joint:
+            e = front(pending[0])
+            if e is None:
+                # the arena's private pool is dry: first the cells of the batches before (their tails early), else this batch ends here
+                if prev is not None:
+                    tail(prev)
+                    awaiting.append(prev)
+                    prev = None
+                if awaiting:
+                    collect(awaiting.pop(0))
+                    continue
+                if cur:
+                    break
+                raise RuntimeError("focal plane: the sensor arena cannot hold the private regions of one CCD")
+            pending.pop(0)
+            cur.append(e)
         left = [e["plan"] for e in cur if e["plan"] is not None and getattr(e["plan"], "deferred", 0)]
         n_joint[0] += len(left)
         # the middle and low chain classes of the batch jointly on the stream that carried them one CCD at a time -- ahead of the
@@ -169,6 +266,7 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
         run_joint_plans(left, mid, 1, 3)
         if prev is not None:
             tail(prev)
+            awaiting.append(prev)
         run_joint_plans(left, st_joint, 0, 1)
         if trace is not None:
             jd = torch.cuda.Event(enable_timing=True)
@@ -177,12 +275,12 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
                 e["trace"]["joint_end"] = jd
                 e["trace"]["host_joint"] = time.perf_counter()
         host_s[0] += time.perf_counter() - t0
-        if prev is not None:
-            collect(prev)
+        collect_finished(max_wait)
         prev = cur
     if prev is not None:
         tail(prev)
-        collect(prev)
+        awaiting.append(prev)
+    collect_finished(-1)
     if trace is not None:
         torch.cuda.synchronize()
         print("focal trace [ms since the start]: CCD, host enqueue begin / end, its work's end on bulk / pre / mid, its batch's joint rounds end, image on host")
@@ -241,7 +339,7 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
         heavy = bright > int(os.environ.get("IMS_FOCAL_JOINT_MAX_BRIGHT", "600"))
         if not heavy and joint > 1 and os.environ.get("IMS_NATIVE_PLAN", "1") != "0":
             torch.cuda.set_device(dev)
-            return _render_joint(mine, build, dev, nrecalc, sink, post, min(joint, 16), chain_hint)
+            return _render_joint(mine, build, dev, nrecalc, sink, post, min(joint, 32), chain_hint)
     # the anchor streams are kept per device for the life of the process: PyTorch's caching allocator files a freed block
     # under the stream it was allocated on, so fresh streams per call would miss the cache and hipMalloc every CCD's
     # gigabytes of sensor state again (measured: 13 -> 27 .. 34 ms per CCD for the calls that do)

@@ -106,6 +106,54 @@ def test_bench_starts_its_own_ranks(config):
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["shared_gpu"] is True
 
 
+def _bench_dump(tmp_path, config, gpus, extra_env=None, n_objects=3000):
+    out = tmp_path / f"dump_{config}_{gpus}.{'json' if config == 'c5' else 'npz'}"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(IMS_BENCH_DUMP=str(out), IMS_BENCH_SHARE_GPU="1", **(extra_env or {}))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "0",
+                        "--config", config, "--n-objects", str(n_objects), "--no-cpu-baseline", "--no-cold"], env=env,
+                       capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == gpus and line["value"] > 0
+    if gpus > 1:
+        assert line["shared_gpu"] is True            # a dry run of the multi-rank logic on ONE GPU: says nothing about scaling
+    return out, line
+
+
+@pytest.mark.parametrize("config", ["c3", "c4"])
+def test_eight_ranks_reduce_to_the_one_rank_image(tmp_path, config):
+    """The node size BASELINE.json names, as a dry run on one GPU (eight rank processes on cuda:0, exchanges over gloo): C3's
+    objects dealt by `parallel.assign_ranks` to eight ranks and summed by the int32 image reduce, C4's delta-charge all-reduce
+    before every recalculation (imsim/photon_pooling.py:159) between eight ranks -- the image on rank 0 equals the one-rank image
+    bit for bit, and every rank's own image passed integer_counts_ok(image, 8) (bench.py raises otherwise)."""
+    import torch
+    from imsim_amd import parallel
+    one, _ = _bench_dump(tmp_path, config, 1)
+    eight, line = _bench_dump(tmp_path, config, 8)
+    a, b = np.load(one), np.load(eight)
+    assert a["image"].sum() > 0
+    assert np.array_equal(a["image"], b["image"])
+    assert bool(b["integer_counts_ok"][0])
+    assert parallel.integer_counts_ok(torch.from_numpy(a["image"]), 8)
+    assert "over 8 rank(s)" in line["config"]["sharding"]
+
+
+def test_eight_ranks_deal_the_ccds_of_a_focal_plane(tmp_path):
+    """BASELINE config 5's partition with eight ranks (imsim/ccd.py:72-89: CCD i -> rank i mod 8, no exchange), dry run on one GPU:
+    sixteen CCDs of the bench visit (FFT-drawn, photon-shot and faint objects, the bright tail) -- every CCD's float32 image has
+    the CRC it has when one rank renders them all, and the ranks own two CCDs each."""
+    env = {"IMS_C5_CCDS": "16"}
+    one, _ = _bench_dump(tmp_path, "c5", 1, env, n_objects=189 * 400)
+    eight, line = _bench_dump(tmp_path, "c5", 8, env, n_objects=189 * 400)
+    a = json.load(open(one))["ccd_crc32_and_rank"]
+    b = json.load(open(eight))["ccd_crc32_and_rank"]
+    assert sorted(a) == sorted(b) == sorted(str(d) for d in range(16))
+    assert {d: v[0] for d, v in a.items()} == {d: v[0] for d, v in b.items()}
+    assert len(set(v[0] for v in a.values())) == 16                 # the CCDs differ
+    assert all(v[1] == int(d) % 8 for d, v in b.items())            # CCD i -> rank i mod 8
+
+
 _RCCL_SCRIPT = r"""
 import os, sys
 sys.path.insert(0, sys.argv[1])

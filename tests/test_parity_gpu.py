@@ -1463,6 +1463,52 @@ def test_joint_top_chains_of_a_focal_plane_equal_a_chain_per_ccd(torch_cuda, mon
         assert_bits_equal(images[det], single[det], f"CCD {det}: object table, joint vs single")
 
 
+def test_focal_plane_sensor_arena_leases_equal_a_state_per_ccd(torch_cuda, monkeypatch):
+    """engine.SensorArena: the CCDs of a joint focal plane lease their pixel-boundary state from one arena per device -- three
+    static regions taken in turn (a region is re-initialised for the next CCD behind the events of its last readers) and private
+    cells by need -- instead of 5 GB of arrays per renderer.  Same images, bit for bit, as renderers with a state of their own
+    (IMS_FOCAL_ARENA=0), also when the private pool is too small for a batch: the previous batch is then collected early, or the
+    batch is cut short."""
+    import copy
+    from imsim_amd import focal_plane, configs, engine
+    from imsim_amd.config import ccd_seed
+    scene, cat, phot, objects, visit = _c5_test_visit(n_ccd=6, star=(1.5e6, 0.6e6, 2.2e6, 1.0e6, 0.8e6, 1.2e6))
+    offs, coffs = objects.ccd_offsets, objects.cat_offsets
+    dets = list(range(len(offs) - 1))
+    jobs = {}
+    for det in dets:
+        sub = {k: v[coffs[det]:coffs[det + 1]] for k, v in cat.items() if isinstance(v, np.ndarray)}
+        jobs[det] = configs.c5_job(scene, sub, phot[coffs[det]:coffs[det + 1]], np.asarray(objects[offs[det]:offs[det + 1]]), visit=visit)
+
+    def build(det):
+        sc = copy.copy(scene)
+        sc.seed = ccd_seed(scene.seed, det)
+        return sc, jobs[det]
+
+    def need(det):
+        o = jobs[det].objects
+        br = o[o["n_phot"] > 10000]
+        return int(((br["stamp_xmax"] - br["stamp_xmin"] + 2).astype(np.int64) * (br["stamp_ymax"] - br["stamp_ymin"] + 2)).sum())
+
+    monkeypatch.setenv("IMS_FOCAL_JOINT", "4")
+    monkeypatch.setenv("IMS_FOCAL_ARENA", "0")
+    own = focal_plane.render_focal_plane(dets, build, concurrent=2)
+    assert focal_plane.render_focal_plane.last_arena_gib == 0.0
+    monkeypatch.setenv("IMS_FOCAL_ARENA", "1")
+    leased = focal_plane.render_focal_plane(dets, build, concurrent=2)
+    assert focal_plane.render_focal_plane.last_arena_gib > 0.0
+    needs = sorted(need(d) for d in dets)
+    # a pool that holds the two largest CCDs and no more: batches of four cannot form, cells come back from collected CCDs
+    monkeypatch.setenv("IMS_FOCAL_ARENA_CELLS", str(needs[-1] + needs[-2] + 16))
+    tight = focal_plane.render_focal_plane(dets, build, concurrent=2)
+    for det in dets:
+        assert_bits_equal(leased[det], own[det], f"CCD {det}: leased state vs a state of its own")
+        assert_bits_equal(tight[det], own[det], f"CCD {det}: a private pool that runs dry")
+    arena = next(iter(engine._SENSOR_ARENAS.values()))
+    assert arena._free == [(arena.private_base, arena.private_cells)]           # every lease came back, the free list coalesced
+    engine._SENSOR_ARENAS.clear()                                               # (the tight pool must not serve the tests that follow)
+
+
 # ---------------------------------------------------------------------------------------------
 # CCD readout (SURVEY 8f-4): e-image -> raw amplifier segments
 # ---------------------------------------------------------------------------------------------

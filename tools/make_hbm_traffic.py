@@ -26,7 +26,8 @@ def short_name(long_name):
 def main():
     out = {}
     for cfg in ("c2", "c3", "c3b", "c5"):
-        cands = [(f"profiles/round4_{cfg}_hbm_pmc.json", f"profiles/round4_{cfg}_sq_pmc.json"),
+        cands = [(f"profiles/round5_{cfg}_hbm_pmc.json", f"profiles/round5_{cfg}_sq_pmc.json"),
+                 (f"profiles/round4_{cfg}_hbm_pmc.json", f"profiles/round4_{cfg}_sq_pmc.json"),
                  (f"profiles/round3_{cfg}_hbm_pmc.json", f"profiles/round3_{cfg}_sq_pmc.json"),
                  (f"profiles/round2e_{cfg}_hbm_pmc.json", f"profiles/round2e_{cfg}_sq_pmc.json"),
                  (f"profiles/round2_{cfg}_hbm_pmc.json", f"profiles/round2_{cfg}_sq_pmc.json"),
@@ -58,6 +59,14 @@ def main():
                 out[cfg][short].update(valu_insts_per_wave=q["SQ_INSTS_VALU"]["sum"] / q["SQ_WAVES"]["sum"],
                                        valu_busy_frac_of_wave_cycles=q["SQ_ACTIVE_INST_VALU"]["sum"] / q["SQ_WAVE_CYCLES"]["sum"],
                                        sq_source=sq_src)
+        # the whole step's vector work (bench.py's roofline.step): SQ_INSTS_VALU summed over EVERY kernel of the profiled run,
+        # per step -- a step of these configs holds exactly one fused launch (k_shoot_accumulate), whose launch count
+        # is therefore the number of steps the profiler saw
+        steps = sum(v["SQ_INSTS_VALU"]["launches"] for n, v in sq.items() if short_name(n) == "k_shoot_accumulate" and "SQ_INSTS_VALU" in v)
+        if steps > 0 and cfg in ("c3", "c3b"):
+            total = sum(v["SQ_INSTS_VALU"]["sum"] for v in sq.values() if "SQ_INSTS_VALU" in v)
+            out.setdefault(cfg, {})["_step"] = {"valu_wave_insts_per_step": total / steps, "steps_sampled": steps, "sq_source": sq_src,
+                                                "note": "sum of SQ_INSTS_VALU over all kernels of the run / its steps"}
     json.dump(out, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 

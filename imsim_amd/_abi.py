@@ -8,6 +8,8 @@ import os
 
 import numpy as np
 
+from . import tuning
+
 IMS_OBJ_FAINT = 1
 IMS_PSF_GAUSSIAN, IMS_PSF_RADIAL, IMS_PSF_SCREENS, IMS_PSF_DOUBLE_GAUSSIAN = 1, 2, 3, 4
 IMS_MAX_LAYERS = 8
@@ -180,8 +182,7 @@ class Chain(C.Structure):
                 ("tile_prefix_host", c_vp), ("n_objects", c_i32), ("first_slot", c_i32), ("stream", c_i32), ("nrecalc", c_i32),
                 ("n_rounds", c_i32), ("use_tags", c_i32), ("ev_base", c_i32), ("n_edges", c_i32),
                 ("edges", c_i32 * IMS_MAX_CHAIN_EDGES), ("pair_shift", c_i32), ("pad", c_i32),
-                ("pair_tile_prefix", c_vp), ("pair_tile_prefix_host", c_vp), ("n_marks", c_i32), ("pad3", c_i32),
-                ("mark_round", c_i32 * IMS_MAX_CHAIN_EDGES), ("mark_event", c_i32 * IMS_MAX_CHAIN_EDGES)]
+                ("pair_tile_prefix", c_vp), ("pair_tile_prefix_host", c_vp)]
 
 
 class Catalog(C.Structure):
@@ -230,7 +231,7 @@ class PlanInput(C.Structure):
     _fields_ = [("n", c_i64), ("row", c_vp), ("n_phot", c_vp), ("stamp", c_vp), ("faint", c_vp), ("nrecalc", c_i32),
                 ("n_class_rounds", c_i32), ("class_rounds", c_i32 * 4), ("n_static_slots", c_i32), ("slot_capacity", c_i32),
                 ("static_cells", c_i64), ("scratch_cells", c_i64), ("max_pool_photons", c_i64), ("seg_size", c_i32),
-                ("want_realized", c_i32), ("event_base", c_i32), ("use_tags", c_i32), ("head_start", c_i32), ("pad", c_i32)]
+                ("want_realized", c_i32), ("event_base", c_i32), ("use_tags", c_i32)]
 
 
 class PlanSizes(C.Structure):
@@ -240,11 +241,14 @@ class PlanSizes(C.Structure):
                 ("shoot_rows", c_i64), ("shoot_segments", c_i64), ("chain_rows", c_i64), ("n_objects", c_i64), ("n_round_launches", c_i64)]
 
 
+Tuning = tuning.Tuning          # ims_tuning_t lives with the one module that fills it
+
 STRUCTS = [Object, RadialTables, LinTables, PsfComponent, Op, Surface, TanSip, Optics, BfSlot, Sensor, Photons,
-           RenderParams, PlanItem, Atmosphere, FftObject, FftParams, Readout, Chain, Catalog, ObjectMeta, PlanInput, PlanSizes]
+           RenderParams, PlanItem, Atmosphere, FftObject, FftParams, Readout, Chain, Catalog, ObjectMeta, PlanInput, PlanSizes, Tuning]
 
 # every symbol include/imsim_hip.h declares
-EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_info", "ims_known_optics_layout", "ims_shoot_accumulate",
+EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_info", "ims_known_optics_layout",
+           "ims_tuning_defaults", "ims_get_tuning", "ims_set_tuning", "ims_shoot_accumulate",
            "ims_shoot_photons", "ims_shoot_ops_photons", "ims_accumulate_segments", "ims_accumulate_small", "ims_accumulate_round", "ims_run_plan",
            "ims_fft_kspace_fill", "ims_fft_finish", "ims_fft_spikes", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
            "ims_sensor_update_distortions", "ims_sensor_update_refresh", "ims_sensor_publish_pairs", "ims_image_add", "ims_image_to_float", "ims_fill_derived_op", "ims_fill_derived_medium", "ims_fill_derived_optics", "ims_fill_derived_atmosphere", "ims_fill_derived_sensor", "ims_sensor_pixel_areas", "ims_flat_add", "ims_last_kernel_ms", "ims_enable_timing",
@@ -254,7 +258,7 @@ EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_
            "ims_fft_inverse", "ims_comm_unique_id", "ims_comm_init", "ims_comm_destroy", "ims_reduce_image", "ims_allreduce_delta",
            "ims_count_inexact", "ims_struct_size", "ims_test_math"]
 
-_LIB_PATH = os.environ.get("IMSIM_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libimsim_hip.so")
+_LIB_PATH = tuning.env("IMSIM_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libimsim_hip.so")
 _lib = None
 
 
@@ -339,6 +343,9 @@ def load():
     lib.ims_reduce_image.argtypes = [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]
     lib.ims_allreduce_delta.argtypes = [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]
     lib.ims_count_inexact.argtypes = [c_vp, c_i64, c_i32, c_vp, c_vp]
+    lib.ims_tuning_defaults.argtypes = [C.POINTER(Tuning)]
+    lib.ims_get_tuning.argtypes = [C.POINTER(Tuning)]
+    lib.ims_set_tuning.argtypes = [C.POINTER(Tuning)]
     _lib = lib
     return lib
 

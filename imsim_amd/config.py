@@ -19,7 +19,7 @@ import numpy as np
 import yaml
 
 from . import _abi, atm_psf, catalog, configs, diffraction, fft_draw, instcat, lsst_image, optics as opticsmod
-from . import flat, parallel, readout, sensor as sensormod, tables, treerings
+from . import flat, parallel, readout, sensor as sensormod, tables, treerings, tuning
 from .engine import Scene, SensorSetup, make_slots
 from .lsst_image import GalSimConfigError
 
@@ -476,7 +476,7 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
     from .engine import Renderer
     cfg = load_config(config, template_dirs, overrides)
     res = ProcessResult()
-    data_dir = data_dir or os.environ.get("IMSIM_DATA_DIR") or configs.DATA_DIR
+    data_dir = data_dir or tuning.env("IMSIM_DATA_DIR") or configs.DATA_DIR
     ev = Evaluator(cfg)
     # an input (or any section) set to "" is switched off, the way the reference's tests and users disable template items
     inp = {k: v for k, v in cfg.get("input", {}).items() if v not in ("", None)}
@@ -620,7 +620,7 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
         if ic is None:
             raise GalSimConfigError("only input.instance_catalog object sources are supported on this path")
         parsed = instcat.parse_objects(ev.value(ic["file_name"]))
-        sed_dir = ev.value(ic["sed_dir"]) if "sed_dir" in ic else os.environ.get("SIMS_SED_LIBRARY_DIR")
+        sed_dir = ev.value(ic["sed_dir"]) if "sed_dir" in ic else tuning.env("SIMS_SED_LIBRARY_DIR")
         cat_file = ev.value(ic["file_name"])
         cat = instcat.to_catalog(parsed, optics.img_wcs, nx, ny, float(np.trapezoid(thr, wl)), float(meta.get("exptime") or 30.0),
                                  sort_mag=bool(ic.get("sort_mag", True)), edge_pix=int(ic.get("edge_pix", 100)),
@@ -734,7 +734,7 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
     # fan-out of imsim/ccd.py:72-89): the host prepares the next CCD while the GPU works through the launch plans of the
     # previous ones; IMS_PROCESS_FOCAL=0 renders them one after the other (same images: every photon's stream is addressed by
     # CCD seed, object and photon index)
-    overlapped = itype != "LSST_PhotonPoolingImage" and len(dets) > 1 and os.environ.get("IMS_PROCESS_FOCAL", "1") != "0"
+    overlapped = itype != "LSST_PhotonPoolingImage" and len(dets) > 1 and tuning.env("IMS_PROCESS_FOCAL", "1") != "0"
     if overlapped:
         from . import focal_plane
         ctxs = {}
@@ -744,7 +744,7 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
             return ctxs[det].scene, ctxs[det].job
 
         focal_plane.render_focal_plane(dets, build, device=device, rank=0, world=1,
-                                       concurrent=int(os.environ.get("IMS_PROCESS_CONCURRENT", "3")),
+                                       concurrent=int(tuning.env("IMS_PROCESS_CONCURRENT", "3")),
                                        sink=lambda det, img: None, post=lambda det, r: finish(ctxs.pop(det), r))
     else:
         for det in dets:

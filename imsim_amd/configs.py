@@ -3,7 +3,7 @@ import numpy as np
 
 import time
 
-from . import _abi, tables, catalog, parallel
+from . import _abi, tables, catalog, parallel, tuning
 from .engine import Scene
 
 
@@ -581,9 +581,9 @@ def c5_bright_tail(cat, det, k=C5_BRIGHT_PER_CCD):
 
 
 def _c5_catalog(n_objects, scene, n_ccd=None, bright=C5_BRIGHT_PER_CCD):
-    if n_ccd is None and os.environ.get("IMS_C5_CCDS"):
+    if n_ccd is None and tuning.env("IMS_C5_CCDS"):
         # a part of the focal plane at the full per-CCD workload (kernel traces): the first IMS_C5_CCDS CCDs
-        n_ccd = int(os.environ["IMS_C5_CCDS"])
+        n_ccd = int(tuning.env("IMS_C5_CCDS"))
         n_objects = n_ccd * (n_objects // N_CCD_FOCAL_PLANE)
     n_ccd = N_CCD_FOCAL_PLANE if n_ccd is None else int(n_ccd)
     per = max(n_objects // n_ccd, 1)
@@ -684,9 +684,9 @@ def _c5_step(renderer, objects, rank=0, world=1, concurrent=None):
         return lambda: lsst_image.draw_job(renderer, job)
     # four top-chain streams, four CCDs in flight: with the bright tail a CCD is bound by the rounds of its brightest star
     # (hundreds of dependent rounds of ~50 us), so more chains side by side pay (tools/dbg/r4_c5_sweep.sh: 25.1 -> 22.5 ms per CCD)
-    os.environ.setdefault("IMS_FOCAL_TOPS", "4")
+    tuning.setdefault("IMS_FOCAL_TOPS", "4")
     if concurrent is None:
-        concurrent = int(os.environ.get("IMS_FOCAL_CONCURRENT", "4"))
+        concurrent = int(tuning.env("IMS_FOCAL_CONCURRENT", "4"))
     base = renderer.scene
     cat, phot, coffs = objects.cat, objects.phot, objects.cat_offsets
     mine = parallel.shard_ccds(list(range(len(offs) - 1)), rank, world)
@@ -709,7 +709,7 @@ def _c5_step(renderer, objects, rank=0, world=1, concurrent=None):
         if want_hashes:
             launch.hashes[det] = zlib.crc32(np.ascontiguousarray(image).view(np.uint8).reshape(-1))
 
-    want_hashes = bool(os.environ.get("IMS_BENCH_DUMP"))      # bench.py's test hook: the CRC of every CCD's float32 image
+    want_hashes = bool(tuning.env("IMS_BENCH_DUMP"))      # bench.py's test hook: the CRC of every CCD's float32 image
 
     def launch():
         launch.checksums = {}

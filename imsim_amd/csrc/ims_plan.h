@@ -45,7 +45,6 @@ struct ChainDesc {
     int launch = -1;                // the class table
     int first_slot = 0, stream = 0, n_rounds = 0, ev_base = 0;
     std::vector<int32_t> edges;     // slice starts
-    std::vector<int32_t> mark_round, mark_event;    // events the chain records after given rounds (head start of the top class)
     std::vector<int64_t> n_phot;    // host, descending
     int64_t off_tile_prefix = -1;
     std::vector<int64_t> tile_prefix_host;
@@ -80,7 +79,6 @@ struct Plan {
     double* pool_dev = nullptr;
     double* realized_dev = nullptr;
     std::vector<hipEvent_t> events;
-    void* graph_exec = nullptr;         // IMS_PLAN_GRAPH: the instantiated graph of one run
     // a deferred run (ims_plan_run_deferred): everything but the rounds of the top chain is enqueued and not yet joined into
     // the main stream; ims_plans_run_joint runs those rounds together with other plans' and joins
     bool deferred = false;
@@ -273,19 +271,9 @@ static int build(Plan& pl)
                 ++sz.n_shoot_launches; sz.shoot_photons += L.photons; sz.shoot_rows += L.n; sz.shoot_segments += L.n_segments;
                 if (k == 0) g.steps.push_back(s);
                 else {
-                    // Head start of the TOP class (in.head_start): slice k >= 2 is shot only when the chain has run the rounds of
-                    // slice k - 1.  All objects of the class are active in its first class_rounds[0] rounds -- thousands of
-                    // pixel-search workgroups and tiles per round, which beside the photon kernels wait for wave slots (390 us per
-                    // round measured, 40 - 60 us alone); so the shooting of the class's own slices alternates with its rounds
-                    // until the wide phase is over, and only then does the bulk stream run on.
-                    if (in.head_start && c == 0 && n_classes > 1 && k >= 2 && in.n_class_rounds > 0 && edges[k] <= in.class_rounds[0] + 20) {
-                        const int ev = n_events++;
-                        ch.mark_round.push_back(std::min<int>(edges[k] - 1, in.class_rounds[0] - 1));   // the wide phase ends at the class threshold
-                        ch.mark_event.push_back(ev);
-                        Step w;
-                        w.kind = IMS_PLAN_WAIT; w.stream = ROLE_BULK; w.event = ev;
-                        bulk_steps.push_back(w);
-                    }
+                    // (A "head start" of the top class -- the bulk stream holding back the class's next pool slice until the chain has
+                    // consumed the one before -- was built in round 4, but its waits were enqueued ahead of the records they were
+                    // meant to wait for, so it never throttled anything and its "no change" measured nothing; removed in round 5.)
                     bulk_steps.push_back(s);
                     Step r;
                     r.kind = IMS_PLAN_RECORD; r.stream = ROLE_BULK; r.event = ch.ev_base + (int)k;

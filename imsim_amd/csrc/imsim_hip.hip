@@ -26,12 +26,18 @@ static int hip_err(hipError_t e, const char* what)
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
     return IMS_ERR_HIP;
 }
-// a feature that is on unless the environment variable is "0" (read once per call site is fine: host side, rare)
-static bool os_getenv_off(const char* name)
+// Which of its equivalent kernel forms the library launches is decided by ONE explicit block of settings (ims_tuning_t,
+// include/imsim_hip.h) that the caller may replace with ims_set_tuning -- never by the caller's environment: the library itself
+// reads no environment variable except the file names of the libraries it looks up at run time (csrc/ims_libs.h).
+static ims_tuning_t tuning_defaults()
 {
-    const char* v = getenv(name);
-    return !(v && v[0] == '0');
+    ims_tuning_t t;
+    t.chain_kernels = 1; t.layout_kernels = 1; t.psf_screens_kernel = 1; t.photon_lds = -1;
+    t.round_compact = 1; t.init_tiles = 1; t.upd_dpp = 1; t.joint_lists = 1;
+    t.upd_dpp_max = 128; t.joint_list_min = 1024; t.active_fraction = 0.25;
+    return t;
 }
+static ims_tuning_t g_tune = tuning_defaults();
 #define HIP_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_err(e_, #call); } while (0)
 
 // Timing of the dominant kernel: every launch of the selected entry point between ims_enable_timing(which)
@@ -40,6 +46,8 @@ static bool os_getenv_off(const char* name)
 #include <vector>
 #include <mutex>
 #include <unordered_map>
+#include <map>
+#include <tuple>
 static int g_timing = 0;
 static std::vector<hipEvent_t> g_events;   // pairs
 static size_t g_events_used = 0;
@@ -2427,6 +2435,30 @@ static unsigned grid_for_segments(int64_t n_segments)
 extern "C" {
 
 int ims_abi_version(void) { return IMS_ABI_VERSION; }
+
+int ims_tuning_defaults(ims_tuning_t* out)
+{
+    if (!out) return set_err(IMS_ERR_ARG, "out is NULL");
+    *out = tuning_defaults();
+    return IMS_OK;
+}
+int ims_get_tuning(ims_tuning_t* out)
+{
+    if (!out) return set_err(IMS_ERR_ARG, "out is NULL");
+    std::lock_guard<std::mutex> lock(g_state_mutex);
+    *out = g_tune;
+    return IMS_OK;
+}
+int ims_set_tuning(const ims_tuning_t* t)
+{
+    if (!t) return set_err(IMS_ERR_ARG, "tuning is NULL");
+    if (t->photon_lds > 65536 - 4096) return set_err(IMS_ERR_ARG, "tuning: photon_lds beyond what a workgroup may ask for");
+    if (t->upd_dpp_max < 0 || t->joint_list_min < 0 || !(t->active_fraction > 0.0) || t->active_fraction > 1.0)
+        return set_err(IMS_ERR_ARG, "tuning: upd_dpp_max / joint_list_min / active_fraction out of range");
+    std::lock_guard<std::mutex> lock(g_state_mutex);
+    g_tune = *t;
+    return IMS_OK;
+}
 const char* ims_last_error(void) { return g_err; }
 
 int ims_device_count(int* count)
@@ -2474,7 +2506,7 @@ static bool is_default_chain(const ims_render_params_t* p)
 {
     static const int32_t kinds[IMS_DEFAULT_CHAIN_LEN] = { IMS_OP_TIME_SAMPLER, IMS_OP_PUPIL_ANNULUS_SAMPLER, IMS_OP_PHOTON_DCR,
                                                           IMS_OP_RUBIN_DIFFRACTION_OPTICS, IMS_OP_FOCUS_DEPTH, IMS_OP_REFRACTION };
-    if (p->n_ops != IMS_DEFAULT_CHAIN_LEN || !os_getenv_off("IMS_CHAIN_KERNELS")) return false;
+    if (p->n_ops != IMS_DEFAULT_CHAIN_LEN || !g_tune.chain_kernels) return false;
     for (int k = 0; k < IMS_DEFAULT_CHAIN_LEN; ++k)
         if (p->ops[k].kind != kinds[k]) return false;
     return true;
@@ -2483,14 +2515,12 @@ static bool is_default_chain(const ims_render_params_t* p)
 // 1: radial table then Gaussian (run_psf<1>); 2: phase screens, second-kick table, Gaussian (run_psf<2>: imSim's default
 // AtmosphericPSF); 0: anything else.  (Variant 2 is slower than the component loop at four workgroups per CU -- C3b 36.9 -> 38.6 ms
 // in round 2, 35.2 -> 35.9 ms now -- and faster at the three that launches with phase screens run with (photon_lds_pad):
-// 33.7 -> 33.2 ms.  IMS_PSF_SCREENS_KERNEL=0 takes the loop.)
+// 33.7 -> 33.2 ms.  ims_tuning_t.psf_screens_kernel = 0 takes the loop.)
 static int psf_variant(const ims_render_params_t* p)
 {
-    if (!os_getenv_off("IMS_CHAIN_KERNELS")) return 0;
+    if (!g_tune.chain_kernels) return 0;
     if (p->n_psf == 2 && p->psf[0].kind == IMS_PSF_RADIAL && p->psf[1].kind == IMS_PSF_GAUSSIAN) return 1;
-    static int screens_variant = -1;
-    if (screens_variant < 0) { const char* e = getenv("IMS_PSF_SCREENS_KERNEL"); screens_variant = e ? atoi(e) : 1; }
-    if (screens_variant && p->n_psf == 3 && p->psf[0].kind == IMS_PSF_SCREENS && p->psf[1].kind == IMS_PSF_RADIAL &&
+    if (g_tune.psf_screens_kernel && p->n_psf == 3 && p->psf[0].kind == IMS_PSF_SCREENS && p->psf[1].kind == IMS_PSF_RADIAL &&
         p->psf[2].kind == IMS_PSF_GAUSSIAN && p->atm != nullptr) return 2;
     return 0;
 }
@@ -2501,16 +2531,10 @@ int ims_known_optics_layout(uint64_t layout) { return layout == IMS_LAYOUT_RUBIN
 // three photon workgroups are resident per CU.  Launches whose PSF gathers phase screens are bound by those scattered loads, not
 // by instruction issue, and run 2.5 % faster that way (C3b 34.7 -> 33.8 ms: fewer wavefronts thrash the caches less); the
 // analytic-PSF kernels are issue-bound and lose 9 % (C4 237 -> 258 ms; the free fourth slot does not buy the brighter-fatter
-// chains enough: C3 23.6 -> 25.4 ms), so they ask for none.  IMS_PHOTON_LDS (bytes) overrides both.
+// chains enough: C3 23.6 -> 25.4 ms), so they ask for none.  ims_tuning_t.photon_lds >= 0 (bytes) overrides both.
 static unsigned photon_lds_pad(const ims_render_params_t* p)
 {
-    static int env = -2;
-    if (env == -2) {
-        const char* e = getenv("IMS_PHOTON_LDS");
-        env = e ? atoi(e) : -1;
-        if (env > 65536 - 4096) env = -1;
-    }
-    if (env >= 0) return (unsigned)env;
+    if (g_tune.photon_lds >= 0 && g_tune.photon_lds <= 65536 - 4096) return (unsigned)g_tune.photon_lds;
     for (int c = 0; c < p->n_psf; ++c)
         if (p->psf[c].kind == IMS_PSF_SCREENS && p->atm != nullptr && p->screen_kick == nullptr) return 41984u;
     return 0u;
@@ -2527,7 +2551,7 @@ int ims_shoot_accumulate(const ims_render_params_t* params, void* stream)
         LaunchTimer tm(st, 1);
         const dim3 grid(grid_for_segments(params->n_segments));
         const int pv = is_default_chain(params) ? psf_variant(params) : -1;
-        const bool lay = pv >= 0 && params->optics_layout == IMS_LAYOUT_RUBIN_LIKE && os_getenv_off("IMS_LAYOUT_KERNELS");
+        const bool lay = pv >= 0 && params->optics_layout == IMS_LAYOUT_RUBIN_LIKE && g_tune.layout_kernels != 0;
         if (pv == 2 && lay) hipLaunchKernelGGL((k_shoot_accumulate<1, 2, IMS_LAYOUT_RUBIN_LIKE>), grid, dim3(256), photon_lds_pad(params), st, *params);
         else if (pv == 2) hipLaunchKernelGGL((k_shoot_accumulate<1, 0>), grid, dim3(256), photon_lds_pad(params), st, *params);
         else if (pv == 1 && lay) hipLaunchKernelGGL((k_shoot_accumulate<1, 1, IMS_LAYOUT_RUBIN_LIKE>), grid, dim3(256), photon_lds_pad(params), st, *params);
@@ -2570,7 +2594,7 @@ int ims_shoot_ops_photons(const ims_render_params_t* params, const int64_t* phot
         LaunchTimer tm(st, 2);
         const dim3 grid(grid_for_segments(params->n_segments));
         const int pv = is_default_chain(params) ? psf_variant(params) : -1;
-        const bool lay = pv >= 0 && params->optics_layout == IMS_LAYOUT_RUBIN_LIKE && os_getenv_off("IMS_LAYOUT_KERNELS");
+        const bool lay = pv >= 0 && params->optics_layout == IMS_LAYOUT_RUBIN_LIKE && g_tune.layout_kernels != 0;
         if (pool->converted && pv == 2 && lay)
             hipLaunchKernelGGL((k_shoot_photons<2, 1, 2, IMS_LAYOUT_RUBIN_LIKE>), grid, dim3(256), photon_lds_pad(params), st, *params, photon_offset, *pool);
         else if (pool->converted && pv == 2)
@@ -2640,24 +2664,9 @@ int ims_accumulate_round(const ims_render_params_t* params, const ims_photons_t*
     if (round < 0 || nrecalc <= 0) return set_err(IMS_ERR_ARG, "round must be >= 0 and nrecalc positive");
     if (n_active < 0 || n_active > params->n_objects) return set_err(IMS_ERR_ARG, "n_active out of range");
     if (n_active == 0) return IMS_OK;
-    // IMS_ROUND_WG=64: one wavefront per workgroup.  A 256-thread workgroup starts only where a compute unit has a free register
-    // slot on each of its four SIMDs at the same moment; beside the photon kernels (five 96-register wavefronts per SIMD, 32
-    // registers left) such a place appears when four photon wavefronts of one unit happen to end together, and the pixel
-    // search of a round waited ~220 us for it (kernel trace).  A one-wavefront workgroup takes ANY single
-    // slot a finished photon wavefront leaves -- slots the photon kernels' own 256-thread workgroups cannot use yet.
-    // Measured (tools/dbg/r4_wg64.sh): the 220 us wait in front of the kernel disappears, the chain's wide rounds run faster --
-    // and the photon kernels lose what the chain gains: C3 24.0 -> 25.8 ms, C3b 33.4 -> 34.8, one star alone 38.7 -> 37.0 us per
-    // round.  The step is bound by the wave slots all kernels need together, not by who gets them first: 256 stays the default.
-    static const int round_wg = getenv("IMS_ROUND_WG") ? atoi(getenv("IMS_ROUND_WG")) : 256;
-    if (round_wg == 64 && num_vertices == 4) {
-        const int32_t segs64 = (nrecalc + 63) / 64;
-        if ((int64_t)n_active * segs64 > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "too many workgroups for one round");
-        LaunchTimer tm((hipStream_t)stream, 4);
-        hipLaunchKernelGGL((k_accumulate_round<4, 64>), dim3((unsigned)(n_active * segs64)), dim3(64), 0, (hipStream_t)stream, *params, *pool,
-                           pool_start, (int64_t)round * nrecalc, nrecalc, segs64);
-        HIP_TRY(hipGetLastError());
-        return IMS_OK;
-    }
+    // (One-wavefront workgroups for this launch -- a 256-thread workgroup starts only where a compute unit has a free register slot on
+    // each of its four SIMDs at once, and the pixel search of a round waited ~220 us for that beside the photon kernels -- were built
+    // and measured in round 4: the wait disappears and the photon kernels lose what the chain gains, C3 24.0 -> 25.8 ms; removed.)
     const int32_t segs = (nrecalc + 255) / 256;
     if ((int64_t)n_active * segs > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "too many workgroups for one round");
     const dim3 grid((unsigned)(n_active * segs));
@@ -2678,9 +2687,7 @@ static int accumulate_round_compact(const ims_render_params_t* params, const ims
                                     int32_t nrecalc, int32_t n_active, int32_t num_vertices, void* stream)
 {
     if (n_active == 0) return IMS_OK;
-    static const int round_wg = getenv("IMS_ROUND_WG") ? atoi(getenv("IMS_ROUND_WG")) : 256;
-    static const bool compact = os_getenv_off("IMS_ROUND_COMPACT");
-    if (num_vertices != 4 || round_wg == 64 || !compact)
+    if (num_vertices != 4 || !g_tune.round_compact)
         return ims_accumulate_round(params, pool, pool_start, round, nrecalc, n_active, num_vertices, stream);
     if (!params || !params->objects || !params->image || !pool || !pool_start || !pool->converted) return set_err(IMS_ERR_ARG, "NULL argument");
     const int32_t segs = (nrecalc + 255) / 256;
@@ -2756,13 +2763,13 @@ int ims_sensor_init_boundaries(const ims_sensor_t* sensor_dev, const ims_sensor_
     int rc = slot_range_cells(sensor_host, first_slot, n_slots, &begin, &count);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (sensor_host->num_vertices == IT_NV && os_getenv_off("IMS_INIT_TILES") && tile_prefix_dev != nullptr) {
+    if (sensor_host->num_vertices == IT_NV && g_tune.init_tiles && tile_prefix_dev != nullptr) {
         if (n_tiles <= 0 || n_tiles > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "n_tiles out of range");
         hipLaunchKernelGGL(k_init_tiles, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot, n_slots, tile_prefix_dev);
         HIP_TRY(hipGetLastError());
         return IMS_OK;
     }
-    if (sensor_host->num_vertices == IT_NV && os_getenv_off("IMS_INIT_TILES")) {
+    if (sensor_host->num_vertices == IT_NV && g_tune.init_tiles) {
         // tiled kernel: grid.x = the largest tile count of a run of consecutive slots, grid.y = the slots of the run (at most
         // 65 535); a run ends where the workgroups that find no tile would outnumber the working ones four to one
         int a = first_slot;
@@ -2814,8 +2821,7 @@ int ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sens
     // The DPP form of the update is the faster one where a round's latency counts (a few tiles: 14.2 -> 11.0 us per launch for
     // one star), the SGPR form where a launch is throughput work beside the photon kernels (its waves sleep on the scalar
     // cache instead of pulling 10 KB of table through LDS per tile: C3 25.0 against 25.9 ms): the tile count decides.
-    static const long long dpp_max_tiles = getenv("IMS_UPD_DPP_MAX") ? atoll(getenv("IMS_UPD_DPP_MAX")) : 128;
-    const bool dpp = sensor_host && sensor_host->bf_dl != nullptr && os_getenv_off("IMS_UPD_DPP") && n_tiles <= dpp_max_tiles;
+    const bool dpp = sensor_host && sensor_host->bf_dl != nullptr && g_tune.upd_dpp && n_tiles <= g_tune.upd_dpp_max;
     if (q == 3 && nV == 4 && dpp)
         hipLaunchKernelGGL((k_update_distortions_q3<4, true>), dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot,
                            n_slots, tile_prefix_dev, changed_dev, tag, sensor_host->bf_dl);
@@ -2917,9 +2923,6 @@ static int run_rounds(const ims_chain_t* chains, int32_t n_chains, const ims_sen
         if (ch.nrecalc <= 0 || ch.n_rounds < 0 || ch.n_objects < 0 || ch.n_objects > ch.params->n_objects)
             return set_err(IMS_ERR_ARG, "chain: nrecalc / n_rounds / n_objects out of range");
         if (ch.n_edges < 0 || ch.n_edges > IMS_MAX_CHAIN_EDGES) return set_err(IMS_ERR_ARG, "chain: too many edges");
-        if (ch.n_marks < 0 || ch.n_marks > IMS_MAX_CHAIN_EDGES) return set_err(IMS_ERR_ARG, "chain: too many marks");
-        for (int32_t j = 0; j < ch.n_marks; ++j)
-            if (ch.mark_round[j] < 0 || ch.mark_round[j] >= ch.n_rounds) return set_err(IMS_ERR_ARG, "chain: mark beyond the last round");
         for (int32_t k = 1; k < ch.n_objects; ++k)
             if (ch.n_phot[k] > ch.n_phot[k - 1]) return set_err(IMS_ERR_ARG, "chain: objects must be sorted by photon count, brightest first");
         if (ch.n_rounds > max_rounds) max_rounds = ch.n_rounds;
@@ -2937,17 +2940,7 @@ static int run_rounds(const ims_chain_t* chains, int32_t n_chains, const ims_sen
                     HIP_TRY(hipStreamWaitEvent((hipStream_t)st, e, 0));
                 }
             const int32_t n_act = count_above(ch.n_phot, ch.n_objects, (int64_t)r * ch.nrecalc);
-            auto record_marks = [&]() -> int {
-                for (int32_t j = 0; j < ch.n_marks; ++j)
-                    if (ch.mark_round[j] == r) {
-                        hipEvent_t e;
-                        const int rc = plan_event(ch.mark_event[j], &e);
-                        if (rc) return rc;
-                        HIP_TRY(hipEventRecord(e, (hipStream_t)st));
-                    }
-                return IMS_OK;
-            };
-            if (n_act == 0) { const int rcm = record_marks(); if (rcm) return rcm; continue; }
+            if (n_act == 0) continue;
             const bool pairs = ch.pair_shift > 0;                                 // the regions live as slot pairs: two launches per round
             const uint32_t tag = (ch.use_tags && !pairs) ? (uint32_t)(r % 255 + 1) : 0u;   // marks the tiles this round's charge lands in
             // (the varying fields are set in a copy that is only read on the host: the launch takes the compact argument block)
@@ -2972,8 +2965,6 @@ static int run_rounds(const ims_chain_t* chains, int32_t n_chains, const ims_sen
                                               ch.nrecalc, st);
                 if (rc) return rc;
             }
-            rc = record_marks();
-            if (rc) return rc;
         }
     }
     return IMS_OK;
@@ -3045,7 +3036,6 @@ int ims_plan_destroy(void* plan)
 {
     ims_planner::Plan* pl = (ims_planner::Plan*)plan;
     if (!pl) return IMS_OK;
-    if (pl->graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)pl->graph_exec);
     for (hipEvent_t e : pl->events) (void)hipEventDestroy(e);
     for (hipEvent_t e : pl->d_events) (void)hipEventDestroy(e);
     delete pl;
@@ -3096,8 +3086,6 @@ int ims_plan_bind(void* plan, const ims_render_params_t* base, void* arena_host,
             cs.n_objects = (int32_t)ch.n_phot.size(); cs.first_slot = ch.first_slot; cs.stream = ch.stream; cs.nrecalc = pl->in.nrecalc;
             cs.n_rounds = ch.n_rounds; cs.use_tags = pl->in.use_tags; cs.ev_base = ch.ev_base; cs.n_edges = (int32_t)ch.edges.size();
             for (size_t k = 0; k < ch.edges.size(); ++k) cs.edges[k] = ch.edges[k];
-            cs.n_marks = (int32_t)ch.mark_round.size();
-            for (size_t k = 0; k < ch.mark_round.size(); ++k) { cs.mark_round[k] = ch.mark_round[k]; cs.mark_event[k] = ch.mark_event[k]; }
         }
         g.items.assign(g.steps.size(), ims_plan_item_t());
         for (size_t k = 0; k < g.steps.size(); ++k) {
@@ -3144,60 +3132,17 @@ static int plan_enqueue(ims_planner::Plan* pl, ims_sensor_t* sensor_dev, ims_sen
                         unsigned char* changed_dev, void* main_stream, void* const* streams, int32_t n_streams, int32_t own_work_queued,
                         bool defer_top = false);
 
-// IMS_PLAN_GRAPH=1: the whole enqueue of a plan is captured into a hipGraph on the main stream (the plan streams join the
-// capture through the fork / join events of the enqueue) and launched as one graph; a replay launches the instantiated
-// graph again.  An experiment: the launches of a chain are bound by wave slots and memory latency,
-// not by the host, and a graph does not run on the caller's streams (roles, priorities) -- off by default.
+// (Two other forms of this call were built, measured in round 4 and removed in round 5: the whole enqueue captured into a
+// hipGraph -- capture + instantiate + launch of a CCD's ~3 000-node plan cost the host 51 ms against 24 ms for enqueueing it, and a
+// graph does not run on the caller's streams -- and one plan's rounds through the joint runner with its tile lists -- a fourth
+// dependent launch per round on a chain of 185 rounds: C3 24.2 -> 25.2 ms without lists, 33 ms with them.)
 int ims_plan_run(void* plan, ims_sensor_t* sensor_dev, ims_sensor_t* sensor_host, ims_bf_slot_t* slots_dev, unsigned char* changed_dev,
                  void* main_stream, void* const* streams, int32_t n_streams, int32_t own_work_queued)
 {
     using namespace ims_planner;
     Plan* pl = (Plan*)plan;
     if (!pl || !pl->uploaded) return set_err(IMS_ERR_ARG, "plan is NULL or not uploaded");
-    static const bool use_graph = getenv("IMS_PLAN_GRAPH") && atoi(getenv("IMS_PLAN_GRAPH")) != 0;
-    // IMS_PLAN_LISTS=1: the rounds of a single plan through the joint runner too (one chain per run, each class on its own
-    // stream): its update and refresh launches walk the lists of active tiles instead of sweeping every tile of every region
-    static const bool through_joint = getenv("IMS_PLAN_LISTS") && atoi(getenv("IMS_PLAN_LISTS")) != 0;
-    if (through_joint && !use_graph) {
-        int rc = plan_enqueue(pl, sensor_dev, sensor_host, slots_dev, changed_dev, main_stream, streams, n_streams, own_work_queued, true);
-        if (rc) return rc;
-        if (pl->deferred) {
-            void* self = pl;
-            const int nc = (int)pl->groups[0].chain_structs.size();
-            for (int c = 0; c < nc; ++c) {
-                rc = ims_plans_run_joint(&self, 1, streams[pl->groups[0].chain_structs[c].stream], c, 1);
-                if (rc) return rc;
-            }
-        }
-        return ims_plan_join(pl, main_stream);
-    }
-    if (!use_graph || g_timing != 0)
-        return plan_enqueue(pl, sensor_dev, sensor_host, slots_dev, changed_dev, main_stream, streams, n_streams, own_work_queued);
-    hipStream_t main = (hipStream_t)main_stream;
-    if (pl->graph_exec == nullptr) {
-        // events must exist before the capture begins (creation is not a stream operation, but keep the capture clean)
-        hipGraph_t graph = nullptr;
-        HIP_TRY(hipStreamBeginCapture(main, hipStreamCaptureModeRelaxed));
-        const int rc = plan_enqueue(pl, sensor_dev, sensor_host, slots_dev, changed_dev, main_stream, streams, n_streams, 1);
-        const hipError_t e = hipStreamEndCapture(main, &graph);
-        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-        HIP_TRY(e);
-        hipGraphExec_t exec = nullptr;
-        HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-        (void)hipGraphDestroy(graph);
-        pl->graph_exec = exec;
-    } else if (sensor_host && !pl->groups.empty()) {
-        // the host's mirror of the slot table follows the last group, as an enqueue would leave it
-        for (size_t gi = 0; gi < pl->groups.size(); ++gi) {
-            const Group& g = pl->groups[gi];
-            if (g.n_slots <= 0) continue;
-            std::memcpy((ims_bf_slot_t*)(uintptr_t)sensor_host->bf_slots + pl->in.n_static_slots, pl->arena_host + g.off_slots,
-                        (size_t)g.n_slots * sizeof(ims_bf_slot_t));
-            sensor_host->n_bf_slots = pl->in.n_static_slots + g.n_slots;
-        }
-    }
-    HIP_TRY(hipGraphLaunch((hipGraphExec_t)pl->graph_exec, main));
-    return IMS_OK;
+    return plan_enqueue(pl, sensor_dev, sensor_host, slots_dev, changed_dev, main_stream, streams, n_streams, own_work_queued);
 }
 
 static int plan_enqueue(ims_planner::Plan* pl, ims_sensor_t* sensor_dev, ims_sensor_t* sensor_host, ims_bf_slot_t* slots_dev,
@@ -3217,7 +3162,7 @@ static int plan_enqueue(ims_planner::Plan* pl, ims_sensor_t* sensor_dev, ims_sen
                  sensor_host->num_vertices == IT_NV && sensor_host->qdist == 3;
     if (defer)
         for (const ims_chain_t& cs : pl->groups[0].chain_structs)
-            defer = defer && cs.pair_shift == 0 && cs.n_marks == 0 && cs.first_slot > 0;
+            defer = defer && cs.pair_shift == 0 && cs.first_slot > 0;
     // distinct streams
     std::vector<hipStream_t> uniq;
     for (int k = 0; k < n_streams; ++k)
@@ -3356,13 +3301,13 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
         }
     }
     const int32_t segs = (nrecalc + 255) / 256;
-    static const long long dpp_max_tiles = getenv("IMS_UPD_DPP_MAX") ? atoll(getenv("IMS_UPD_DPP_MAX")) : 128;
+    const long long dpp_max_tiles = g_tune.upd_dpp_max;
     // the per-chain argument blocks in device memory, one table per joint run out of a ring (a table is read until the run's
     // last round: the ring's event says when)
-    // active-tile lists (k_build_active_j): on for rounds of more than list_min_tiles tiles; IMS_JOINT_LISTS=0: the full sweeps
-    const bool lists_on = os_getenv_off("IMS_JOINT_LISTS");           // (read at every run: the tests switch them)
-    const long long list_min_tiles = getenv("IMS_JOINT_LIST_MIN") ? atoll(getenv("IMS_JOINT_LIST_MIN")) : 1024;
-    const double list_fraction = getenv("IMS_ACTIVE_FRACTION") ? atof(getenv("IMS_ACTIVE_FRACTION")) : 0.25;
+    // active-tile lists (k_build_active_j): on for rounds of more than list_min_tiles tiles; joint_lists = 0: the full sweeps
+    const bool lists_on = g_tune.joint_lists != 0;
+    const long long list_min_tiles = g_tune.joint_list_min;
+    const double list_fraction = g_tune.active_fraction;
     int64_t tiles_max = 0;                                   // round 0 has them all
     for (const Act& a : act) {
         const int32_t n_cont = count_above(a.ch->n_phot, a.ch->n_objects, (int64_t)nrecalc);
@@ -3471,7 +3416,7 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
             hipLaunchKernelGGL(k_refresh_list_j<4>, dim3((unsigned)grid), dim3(256), 0, js, U, Ls, parity, tag);
         } else if (tiles > 0) {
             const JointUpd* U = &tables_dev->upd;
-            const bool dpp = dpp_ok && os_getenv_off("IMS_UPD_DPP") && tiles <= dpp_max_tiles;
+            const bool dpp = dpp_ok && g_tune.upd_dpp && tiles <= dpp_max_tiles;
             if (dpp) hipLaunchKernelGGL((k_update_distortions_q3_j<4, true>), dim3((unsigned)tiles), dim3(256), 0, js, U, eu, ns, tag);
             else hipLaunchKernelGGL((k_update_distortions_q3_j<4, false>), dim3((unsigned)tiles), dim3(256), 0, js, U, eu, ns, tag);
             hipLaunchKernelGGL(k_refresh_changed_j<4>, dim3((unsigned)tiles), dim3(256), 0, js, U, eu, ns, tag);
@@ -3560,13 +3505,15 @@ int ims_fft_inverse(double* kbuf_dev, double* rbuf_dev, int32_t nfft, int64_t ba
     if (nfft < 2 || (nfft & 1) || batch > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "nfft must be even and >= 2");
     const ims_libs::Fft* F = ims_libs::fft();
     if (!F) return set_err(IMS_ERR_UNSUPPORTED, "hipFFT is not loadable (libhipfft.so; IMS_HIPFFT_LIB names a file)");
-    // plans are kept per (size, batch): making one costs milliseconds, a CCD's FFT objects come in a handful of sizes
+    // plans are kept per (size, batch, stream): making one costs milliseconds, a CCD's FFT objects come in a handful of sizes.  Per
+    // STREAM because a plan owns its work buffer (the transposes of the large sizes go through it): the same plan executing on two
+    // streams at once -- the FFT objects of two CCDs of a focal plane on the two top-chain streams -- would share it
     static std::mutex m;
-    static std::unordered_map<unsigned long long, hipfftHandle> plans;
+    static std::map<std::tuple<int32_t, int64_t, void*>, hipfftHandle> plans;
     hipfftHandle plan;
     {
         std::lock_guard<std::mutex> lock(m);
-        const unsigned long long key = ((unsigned long long)(uint32_t)nfft << 32) | (unsigned long long)(uint32_t)batch;
+        const std::tuple<int32_t, int64_t, void*> key(nfft, batch, stream);
         auto it = plans.find(key);
         if (it == plans.end()) {
             int n[2] = { nfft, nfft };
@@ -4174,6 +4121,7 @@ int ims_struct_size(int which)
     case 19: return (int)sizeof(ims_object_meta_t);
     case 20: return (int)sizeof(ims_plan_input_t);
     case 21: return (int)sizeof(ims_plan_sizes_t);
+    case 22: return (int)sizeof(ims_tuning_t);
     }
     return -1;
 }

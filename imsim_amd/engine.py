@@ -16,6 +16,7 @@ from typing import List, Optional
 import numpy as np
 
 from . import _abi
+from . import tuning
 from ._abi import (OBJECT_DTYPE, BFSLOT_DTYPE, RenderParams, Photons, Sensor, Optics, Op, PsfComponent)
 
 
@@ -660,8 +661,8 @@ class BoundScene:
                 # per atmosphere and shared by every renderer that looks through it (4 x the screens: 6.4 GB for 6 x 8192^2)
                 # (with the pre-pass of ims_screen_prepass, the default, the shooting kernels do not gather at all and the
                 # pre-pass reads the plain screens: the four-fold table is only built when asked for)
-                prepass_all = os.environ.get("IMS_SCREEN_PREPASS", "0") == "1"
-                if os.environ.get("IMS_SCREEN_QUADS", "0" if prepass_all else "1") != "0":
+                prepass_all = tuning.env("IMS_SCREEN_PREPASS", "0") == "1"
+                if tuning.env("IMS_SCREEN_QUADS", "0" if prepass_all else "1") != "0":
                     quads = getattr(scene.atm, "_screen_quads", None)
                     if quads is None or quads.device != scr.device:
                         quads = t.stack([scr, t.roll(scr, -1, 2), t.roll(scr, -1, 1), t.roll(scr, (-1, -1), (1, 2))], dim=-1).contiguous()
@@ -821,12 +822,12 @@ def _device_streams(torch, device):
     launches and waits behind them (kernel trace of C5: one kernel in flight for two thirds of the time).  With one set,
     the plans of the CCDs in flight interleave role by role: the wide launches of the next CCD fill the GPU while the
     latency-bound chain of the previous one runs.  IMS_PRIVATE_STREAMS=1 gives every renderer its own set again."""
-    pr = [int(v) for v in os.environ.get("IMS_STREAM_PRIORITIES", "-1,0,0,0,0").split(",")]   # chain, bulk, chain1, chain2, chain3
+    pr = [int(v) for v in tuning.env("IMS_STREAM_PRIORITIES", "-1,0,0,0,0").split(",")]   # chain, bulk, chain1, chain2, chain3
     pr = (pr + [0] * 5)[:5]
-    if os.environ.get("IMS_PRIVATE_STREAMS", "0") != "0":
+    if tuning.env("IMS_PRIVATE_STREAMS", "0") != "0":
         return tuple(torch.cuda.Stream(device, priority=p) for p in pr)
     # IMS_STREAM_SETS sets (default 1), handed to the renderers of a device in turn
-    n_sets = max(int(os.environ.get("IMS_STREAM_SETS", "1")), 1)
+    n_sets = max(int(tuning.env("IMS_STREAM_SETS", "1")), 1)
     key = (str(device), tuple(pr))
     sets = _DEVICE_STREAMS.setdefault(key, {"next": 0, "sets": []})
     k = sets["next"] % n_sets
@@ -854,7 +855,7 @@ def _focal_streams(torch, device, peek=False, top_index=None):
         if st is None:
             # IMS_FOCAL_TOPS (default 2): streams for the long top chains; more than two only pays with more hardware queues
             # (GPU_MAX_HW_QUEUES) than HIP's default four
-            n_top = max(1, int(os.environ.get("IMS_FOCAL_TOPS", "2")))
+            n_top = max(1, int(tuning.env("IMS_FOCAL_TOPS", "2")))
             st = _DEVICE_STREAMS[key] = {"next": 0, "top": [torch.cuda.Stream(device, priority=-1) for _ in range(n_top)],
                                          "bulk": torch.cuda.Stream(device), "mid": torch.cuda.Stream(device)}
     n_top = len(st["top"])
@@ -892,7 +893,7 @@ def upload_async(torch, device, arr):
     until everything queued on the current stream before it is through -- on a stream shared by the CCDs of a focal plane that
     is the previous CCD's work (measured: 1.8 ms per call, 6 ms of a CCD's 12 ms of host time)."""
     a = np.ascontiguousarray(arr)
-    if os.environ.get("IMS_UPLOAD_SYNC", "0") == "1":          # the synchronous copy, for comparison
+    if tuning.env("IMS_UPLOAD_SYNC", "0") == "1":          # the synchronous copy, for comparison
         return torch.from_numpy(a).to(device)
     raw = a.view(np.uint8).reshape(-1)
     n = int(raw.size)
@@ -929,9 +930,6 @@ def plan_input(r, n_phot, stamp, faint, nrecalc=None, want_realized=False):
     inp.max_pool_photons = int(r.max_pool_photons)
     inp.seg_size, inp.want_realized = int(r.scene.seg_size), 1 if want_realized else 0
     inp.event_base, inp.use_tags = int(r._event_block), 1 if r.use_bf_tags else 0
-    # (measured, DESIGN.md 4 round 4: C3 23.95 / 24.16 ms with, 23.97 / 24.09 ms without -- what the wide rounds wait for is not
-    # the class's own slices; off by default)
-    inp.head_start = 1 if os.environ.get("IMS_HEAD_START", "0") != "0" else 0
     return inp
 
 
@@ -1004,6 +1002,7 @@ class NativePlan:
         r = self._renderer()
         if r is None:
             raise _abi.ImsimHipError("NativePlan.run: the renderer of this plan is gone")
+        tuning.sync_library(r.lib)
         b = r.bound
         streams = r.plan_streams
         sarr = (C.c_void_p * len(streams))(*[st.cuda_stream for st in streams])
@@ -1062,6 +1061,7 @@ def run_joint_plans(plans, stream, first_chain=0, n_chains=1):
     if not plans:
         return
     lib = plans[0]._lib
+    tuning.sync_library(lib)
     per_call = max(1, 32 // max(int(n_chains), 1))
     for a in range(0, len(plans), per_call):
         part = plans[a:a + per_call]
@@ -1080,6 +1080,7 @@ class Renderer:
         """lease: a SensorLease of the device's SensorArena (focal planes): the pixel-boundary state of this CCD lives there; the
         current stream (which initialises the static region) first waits for the region's previous readers"""
         self.lib = _abi.load()
+        tuning.sync_library(self.lib)            # the library's choice of kernel forms (ims_tuning_t) follows the environment
         self.mem = DeviceMem(device)
         self.torch = self.mem.torch
         self.device = self.mem.device
@@ -1108,11 +1109,11 @@ class Renderer:
         # block of 1 000, so that the plans of several CCDs may be enqueued from different host threads at the same time
         self._event_block = (next(_RENDERER_SERIAL) % 56) * 1000
         self.s_chain, self.s_bulk, self.s_chain1, self.s_chain2, self.s_chain3 = self.plan_streams
-        self.use_bf_tags = os.environ.get("IMS_BF_TAGS", "0") != "0"
+        self.use_bf_tags = tuning.env("IMS_BF_TAGS", "0") != "0"
         # round-count thresholds that cut the bright objects into concurrent chains (plan_lsst_image)
-        self.chain_class_rounds = tuple(int(v) for v in os.environ.get("IMS_CHAIN_CLASSES", "40,6").split(",") if v)
+        self.chain_class_rounds = tuple(int(v) for v in tuning.env("IMS_CHAIN_CLASSES", "40,6").split(",") if v)
         self.max_pool_photons = 300_000_000      # 32 B each
-        self.pair_max_objects = int(os.environ.get("IMS_PAIR_MAX_OBJECTS", "64"))   # chain classes up to this size use slot pairs
+        self.pair_max_objects = int(tuning.env("IMS_PAIR_MAX_OBJECTS", "64"))   # chain classes up to this size use slot pairs
         if scene.sensor is not None:
             self.init_boundaries(0, len(scene.sensor.slots))
 
@@ -1298,7 +1299,7 @@ class Renderer:
         # every region and takes 100 us for the 369 tiles of 41 objects against 58 us for update + refresh in place, so the
         # C3 step goes 24.9 -> 37 ms; IMS_SLOT_PAIRS=1 turns it on for chain classes of at most
         # IMS_PAIR_MAX_OBJECTS objects.
-        pairs = (os.environ.get("IMS_SLOT_PAIRS", "0") != "0" and ss.model.qdist == 3 and ss.model.num_vertices == 4
+        pairs = (tuning.env("IMS_SLOT_PAIRS", "0") != "0" and ss.model.qdist == 3 and ss.model.num_vertices == 4
                  and not self.use_bf_tags)
         if pairs:
             try:
@@ -1556,9 +1557,9 @@ class Renderer:
     def native_plan_ok(self, objects):
         """The library's planner covers the default path; the options it does not know run the numpy planner: the phase-screen
         pre-pass, slot pairs, and IMS_NATIVE_PLAN=0 (which keeps the numpy planner as the checker it is in the tests)."""
-        if os.environ.get("IMS_NATIVE_PLAN", "1") == "0" or os.environ.get("IMS_SLOT_PAIRS", "0") != "0":
+        if tuning.env("IMS_NATIVE_PLAN", "1") == "0" or tuning.env("IMS_SLOT_PAIRS", "0") != "0":
             return False
-        if os.environ.get("IMS_SCREEN_PREPASS", "0") != "0" and self.scene.atm is not None:
+        if tuning.env("IMS_SCREEN_PREPASS", "0") != "0" and self.scene.atm is not None:
             return False
         return True
 
@@ -1586,7 +1587,7 @@ class Renderer:
         kernels down to their algorithmic bytes); 2 -- the ORDINARY objects only (one fused launch, whose in-place gathers
         are the one memory-bound launch of the path), on a side stream beside the pool shoots of the bright objects.
         Host tables only."""
-        mode = os.environ.get("IMS_SCREEN_PREPASS", "0")
+        mode = tuning.env("IMS_SCREEN_PREPASS", "0")
         comp = next((k for k, c in enumerate(self.scene.psf) if int(c[0]) == _abi.IMS_PSF_SCREENS), None)
         self._prepass_event = None
         if (comp is None or self.scene.atm is None or mode == "0" or not isinstance(objects, np.ndarray) or len(objects) == 0):
@@ -1616,7 +1617,7 @@ class Renderer:
         first = np.concatenate([[0], np.clip(cuts, 0, len(sub)), [len(sub)]]).astype(np.int64)
         first = np.maximum.accumulate(first)
         per_slice = cum[first[1:]] - cum[first[:-1]]
-        n_buckets = int(os.environ.get("IMS_SCREEN_BUCKETS", "128"))
+        n_buckets = int(tuning.env("IMS_SCREEN_BUCKETS", "128"))
         t = self.torch
         _, obj_t, prefix, pre_t = self._upload_objects(sub)
         P = self.bound.params(obj_t.data_ptr(), len(sub), pre_t.data_ptr(), int(prefix[-1]), self.image.data_ptr(), None,
@@ -1842,7 +1843,7 @@ class Renderer:
         shoot.object_rows = n_shoot
         shoot.waves = 4 * int(prefix[-1])
         launches = []
-        small_max = int(os.environ.get("IMS_POOL_SMALL_MAX", "64"))    # shares up to a wavefront: one wavefront per object
+        small_max = int(tuning.env("IMS_POOL_SMALL_MAX", "64"))    # shares up to a wavefront: one wavefront per object
         base_cache = {}
         for batch in batches:
             if isinstance(batch[0], str) and batch[0] == "parts":

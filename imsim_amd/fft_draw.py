@@ -11,7 +11,7 @@ import math
 
 import numpy as np
 
-from . import _abi, tables
+from . import _abi, tables, tuning
 from ._abi import FFT_OBJECT_DTYPE, FftParams, KPsf
 
 KOLMOGOROV_K0 = 2.992934 * 0.9758634299       # k0 * fwhm for exp(-(k/k0)^(5/3))  [rad/arcsec * arcsec]
@@ -310,7 +310,7 @@ class FftDrawer:
         # batched inverse real 2-D FFTs, one batch per FFT size (plain library transform: rocFFT through hipFFT); IMS_FFT_TORCH=1
         # takes torch.fft instead -- the same library behind another front end, kept as the checker
         import os
-        use_torch = os.environ.get("IMS_FFT_TORCH", "0") != "0"
+        use_torch = tuning.env("IMS_FFT_TORCH", "0") != "0"
         kspace = kbuf
         if getattr(self, "keep_kspace", False):
             kspace = kbuf.clone()                     # hipFFT's complex-to-real transform uses its input as work space
@@ -328,6 +328,7 @@ class FftDrawer:
                 _abi.check(r.lib.ims_fft_inverse(kbuf.data_ptr() + 16 * int(kpre[a]), rbuf.data_ptr() + 8 * int(rpre[a]), int(size), b - a, st),
                            "ims_fft_inverse")
         final = rbuf
+        bbox = None
         if P.spikes.enabled:
             # DiffractionFFT.apply between the clip and the noise (stamp.py:519-522)
             final, bbox = self._spike_bufs if getattr(self, "_spike_bufs", None) is not None else (
@@ -336,5 +337,9 @@ class FftDrawer:
                                             rbuf.data_ptr(), final.data_ptr(), bbox.data_ptr(), st), "ims_fft_spikes")
         _abi.check(r.lib.ims_fft_finish(C.byref(P), obj_t.data_ptr(), n, rpre_t.data_ptr(), int(rpre[-1]),
                                         final.data_ptr(), st), "ims_fft_finish")
-        self._last = (kbuf, rbuf, final, obj_t, kpre_t, rpre_t)
+        # EVERY device buffer the queued launches touch stays referenced from _last (a caller that runs them on a side stream keeps
+        # _last until they are through): the saturated-region boxes too -- freed at the end of this call, their block went back to
+        # the allocator and to the next CCD's uploads while k_fft_bbox / k_fft_spikes were still queued (round 5: the rows of the
+        # next CCD's k-space fill overwritten, a fault or a hang once the side stream ran behind)
+        self._last = (kbuf, rbuf, final, obj_t, kpre_t, rpre_t, bbox)
         return kspace, rbuf

@@ -17,6 +17,7 @@ import time
 import numpy as np
 
 from . import parallel, lsst_image
+from . import tuning
 from .engine import Renderer
 
 
@@ -40,7 +41,7 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
     pre, bulk, mid = _focal_streams(torch, dev, top_index=1)[:3]
     if pre is st_joint:
         raise RuntimeError("the joint focal plane needs two top streams (IMS_FOCAL_TOPS >= 2)")
-    if os.environ.get("IMS_FOCAL_PRE_PRIORITY", "0") == "0":
+    if tuning.env("IMS_FOCAL_PRE_PRIORITY", "0") == "0":
         # `pre` carries wide work (FFT draws, the regions' initial state, first pool slices): at the priority of the joint rounds it
         # competes with them for every wave slot -- at normal priority C5 takes 10.0 instead of 10.9 ms per CCD
         key = ("focal-pre", str(dev))
@@ -50,9 +51,9 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
     # IMS_FOCAL_FFT (here: mid; bulk; top = ahead of the plan on `pre`): the stream of a CCD's FFT-drawn objects, beside its plan.
     # Measured on C5 with the renderer's initialisation on `pre` (IMS_FOCAL_JOINT_INIT): mid 9.4, bulk 9.5, top 9.6 ms per CCD
     # (10.0 with the initialisation on the bulk stream)
-    fft_on = {"bulk": bulk, "mid": mid}.get(os.environ.get("IMS_FOCAL_FFT", "mid"))
+    fft_on = {"bulk": bulk, "mid": mid}.get(tuning.env("IMS_FOCAL_FFT", "mid"))
     order = list(mine)
-    if chain_hint is not None and os.environ.get("IMS_NO_HINT", "0") != "1":
+    if chain_hint is not None and tuning.env("IMS_NO_HINT", "0") != "1":
         order.sort(key=chain_hint, reverse=True)
     # Two batches of renderers are alive at a time (one running its joint rounds, one being enqueued): the batch is cut to what
     # the device's memory holds -- per CCD the static pixel-boundary state and the scratch regions (235 B per cell), the f64
@@ -69,7 +70,7 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
         table = work.objects if isinstance(work, lsst_image.CcdJob) else work
         if not isinstance(table, np.ndarray):
             return int(ss.scratch_cells)                   # a device table: its stamps are not on the host -- the full capacity
-        nrec = nrecalc if nrecalc is not None else (getattr(work, "nrecalc", None) or ss.model.nrecalc)
+        nrec = getattr(work, "nrecalc", None) or (nrecalc if nrecalc is not None else ss.model.nrecalc)
         br = (table["n_phot"] > nrec) & ((table["flags"] & _abi.IMS_OBJ_FAINT) == 0) if nrec else np.zeros(len(table), bool)
         w = table["stamp_xmax"][br].astype(np.int64) - table["stamp_xmin"][br] + 2
         h = table["stamp_ymax"][br].astype(np.int64) - table["stamp_ymin"][br] + 2
@@ -83,12 +84,12 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
 
     prebuilt = {}
     arena = None
-    alive = max(int(os.environ.get("IMS_FOCAL_ALIVE", "3")), 2)       # batches alive at a time (the pipeline below)
+    alive = max(int(tuning.env("IMS_FOCAL_ALIVE", "3")), 2)       # batches alive at a time (the pipeline below)
     if order:
         prebuilt[order[0]] = build(order[0])
         sc0, work0 = prebuilt[order[0]]
         ss0 = getattr(sc0, "sensor", None)
-        use_arena = (os.environ.get("IMS_FOCAL_ARENA", "1") != "0" and ss0 is not None and ss0.slots is not None and len(ss0.slots) == 1
+        use_arena = (tuning.env("IMS_FOCAL_ARENA", "1") != "0" and ss0 is not None and ss0.slots is not None and len(ss0.slots) == 1
                      and not sc0.track_static_delta)
         free, total = torch.cuda.mem_get_info(dev)
         usable = free + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)      # the allocator's cached blocks count
@@ -99,17 +100,17 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
             # lasts (lease by need), a pool that runs dry cuts the batch short (below)
             per_cells = int(min(max(1.5 * private_need(work0, sc0), 1.0e6), max(int(ss0.scratch_cells), 1)))
             per_ccd = per_cells * (ss0.owned_points() * 16 + 75) + sc0.nx * sc0.ny * 12 + 1.0e9
-            n_static = int(os.environ.get("IMS_FOCAL_STATIC_REGIONS", "3"))
+            n_static = int(tuning.env("IMS_FOCAL_STATIC_REGIONS", "3"))
             static_bytes = n_static * ss0.total_cells() * (ss0.owned_points() * 16 + 75)
             have = _ARENA_BYTES.get(str(dev), 0)
             fit = int((0.85 * (usable + have) - static_bytes) / (alive * per_ccd))
             if fit < joint:
                 joint = max(fit, 1)
             pool_cells = alive * joint * per_cells
-            if os.environ.get("IMS_FOCAL_ARENA_CELLS"):          # the private pool's size, as given (tests: a pool that runs dry)
-                pool_cells = int(os.environ["IMS_FOCAL_ARENA_CELLS"])
+            if tuning.env("IMS_FOCAL_ARENA_CELLS"):          # the private pool's size, as given (tests: a pool that runs dry)
+                pool_cells = int(tuning.env("IMS_FOCAL_ARENA_CELLS"))
             arena = sensor_arena(torch, dev, ss0.owned_points(), ss0.total_cells(), n_static, pool_cells,
-                                 exact=bool(os.environ.get("IMS_FOCAL_ARENA_CELLS")))
+                                 exact=bool(tuning.env("IMS_FOCAL_ARENA_CELLS")))
             _ARENA_BYTES[str(dev)] = arena.nbytes()
         else:
             cells = ((sc0.nx + 1) * (sc0.ny + 1) + int(getattr(ss0, "scratch_cells", 0))) if ss0 is not None else 0
@@ -129,10 +130,10 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
     # run side by side with the middle chains and the FFT draws, and all of them (and the joint rounds most of all) get slower
     # than they are one CCD after the other (measured on C5: 16.4 ms per CCD unthrottled, 13.3 with the pacing that synchronous
     # uploads used to impose by accident)
-    ahead_on, _, ahead_n = os.environ.get("IMS_FOCAL_AHEAD", "pre:1").partition(":")
+    ahead_on, _, ahead_n = tuning.env("IMS_FOCAL_AHEAD", "pre:1").partition(":")
     ahead_n = int(ahead_n or 0)
     fronts = []
-    trace = [] if os.environ.get("IMS_FOCAL_TRACE", "0") == "1" else None
+    trace = [] if tuning.env("IMS_FOCAL_TRACE", "0") == "1" else None
     if trace is not None:
         t_base = torch.cuda.Event(enable_timing=True)
         t_base.record(bulk)
@@ -143,7 +144,11 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
         stays prebuilt for the retry)"""
         scene, work = prebuilt.pop(key) if key in prebuilt else build(key)
         lease = None
-        if arena is not None and getattr(scene, "sensor", None) is not None and not wants_static_late(work):
+        ss = getattr(scene, "sensor", None)
+        if (arena is not None and ss is not None and not wants_static_late(work) and not scene.track_static_delta
+                and ss.slots is not None and len(ss.slots) == 1 and ss.total_cells() == arena.static_cells
+                and ss.owned_points() == arena.npo):
+            # (a CCD of another geometry or sensor model than the arena was sized for keeps a state of its own)
             lease = arena.lease(private_need(work, scene))
             if lease is None:
                 prebuilt[key] = (scene, work)
@@ -166,7 +171,7 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
             e["trace"] = trace[-1]
         return e
 
-    init_on = {"bulk": bulk, "mid": mid, "pre": pre}[os.environ.get("IMS_FOCAL_JOINT_INIT", "pre")]
+    init_on = {"bulk": bulk, "mid": mid, "pre": pre}[tuning.env("IMS_FOCAL_JOINT_INIT", "pre")]
 
     def _front(key, scene, work, lease=None):
         with torch.cuda.stream(init_on):
@@ -313,9 +318,9 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
     if concurrent < 1:
         raise ValueError("concurrent must be >= 1")
     # plan streams by role for all CCDs of the device: the long chains of two CCDs side by side (engine._focal_streams)
-    roles = "focal" if os.environ.get("IMS_FOCAL_STREAMS", "1") != "0" else "single"
+    roles = "focal" if tuning.env("IMS_FOCAL_STREAMS", "1") != "0" else "single"
     # IMS_FOCAL_JOINT (default 16; 0 / 1: off): the top chains of that many CCDs advance jointly (_render_joint)
-    joint = int(os.environ.get("IMS_FOCAL_JOINT", "16"))
+    joint = int(tuning.env("IMS_FOCAL_JOINT", "16"))
     heavy = False
     if roles == "focal" and mine:
         # Joint rounds pay where a CCD's chains are few objects wide (a focal plane of 10 k-source CCDs: 150 objects with rounds
@@ -323,7 +328,7 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
         # them: its launches are wide already, and what counts is that the next CCD's host work overlaps its 25 ms on the GPU,
         # which the rolling window below does and a batch does not (three such CCDs: 60 against 77 ms per CCD).  The first
         # CCD's work decides (IMS_FOCAL_JOINT_MAX_BRIGHT objects with rounds of their own, default 600).
-        first_key = max(mine, key=chain_hint) if chain_hint is not None and os.environ.get("IMS_NO_HINT", "0") != "1" else mine[0]
+        first_key = max(mine, key=chain_hint) if chain_hint is not None and tuning.env("IMS_NO_HINT", "0") != "1" else mine[0]
         first = build(first_key)
         cache = {first_key: first}
         inner = build
@@ -336,8 +341,8 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
         sensor = getattr(first[0], "sensor", None)
         nrec = nrecalc if nrecalc is not None else (getattr(work, "nrecalc", None) or (sensor.model.nrecalc if sensor is not None else 0))
         bright = int(np.count_nonzero(n_phot > nrec)) if nrec else 0
-        heavy = bright > int(os.environ.get("IMS_FOCAL_JOINT_MAX_BRIGHT", "600"))
-        if not heavy and joint > 1 and os.environ.get("IMS_NATIVE_PLAN", "1") != "0":
+        heavy = bright > int(tuning.env("IMS_FOCAL_JOINT_MAX_BRIGHT", "600"))
+        if not heavy and joint > 1 and tuning.env("IMS_NATIVE_PLAN", "1") != "0":
             torch.cuda.set_device(dev)
             return _render_joint(mine, build, dev, nrecalc, sink, post, min(joint, 32), chain_hint)
     # the anchor streams are kept per device for the life of the process: PyTorch's caching allocator files a freed block
@@ -364,10 +369,10 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
             out[key] = host.numpy().copy()
         in_flight[slot] = None                 # drops the renderer: its HBM goes back to the caching allocator
 
-    anchor_role = os.environ.get("IMS_FOCAL_ANCHOR", "top") if roles == "focal" else ""
+    anchor_role = tuning.env("IMS_FOCAL_ANCHOR", "top") if roles == "focal" else ""
     # (pacing, below: for CCDs of the focal-plane kind only -- a CCD of 100 k sources keeps the GPU busy for 25 ms while the host
     # plans the next one, and waiting serialises the two: 70 against 59 ms per CCD)
-    pace = not heavy and os.environ.get("IMS_FOCAL_AHEAD", "pre:1") not in ("pre:0", "bulk:0", "mid:0", "0")
+    pace = not heavy and tuning.env("IMS_FOCAL_AHEAD", "pre:1") not in ("pre:0", "bulk:0", "mid:0", "0")
     host_s = [0.0]
 
     def enqueue(k, key, slot):
@@ -387,12 +392,12 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
             # measured on 24 CCDs of C5 (tools/dbg/r3_c5.sh): the static state's initialisation beside the wide launches, the
             # image copy behind the middle chains: 7.2 ms per CCD with three CCDs in flight; everything on the top stream 8.0 - 8.7,
             # the copy on the stream of the wide launches 12 - 14
-            init_on = by_role[os.environ.get("IMS_FOCAL_INIT", "bulk")]
-            copy_on = by_role[os.environ.get("IMS_FOCAL_COPY", "mid")]
+            init_on = by_role[tuning.env("IMS_FOCAL_INIT", "bulk")]
+            copy_on = by_role[tuning.env("IMS_FOCAL_COPY", "mid")]
             # IMS_FOCAL_FFT=mid / bulk: the FFT-drawn objects beside the launch plan instead of ahead of it on the top-chain stream.
             # Measured on 24 CCDs of C5: 21.4 ms per CCD on the wide-launch stream, 32.9 on the middle stream, 21.6 ahead on the
             # top stream -- no gain worth a second ordering; default: ahead
-            fft_on = by_role.get(os.environ.get("IMS_FOCAL_FFT", "top"))
+            fft_on = by_role.get(tuning.env("IMS_FOCAL_FFT", "top"))
             if fft_on is anchor:
                 fft_on = None
         with torch.cuda.stream(init_on):
@@ -429,7 +434,7 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
     # lock for most of its time (ims_run_plan enqueues ~550 launches per CCD in C), so two CCDs can be prepared side by
     # side and the library's event tables are locked for it -- measured on 24 CCDs of C5: 7.7 / 7.8 / 8.7 ms per CCD with
     # 1 / 2 / 3 threads: the host is not what a CCD waits for; results do not depend on it
-    n_threads = max(1, min(int(os.environ.get("IMS_FOCAL_THREADS", "1")), len(streams))) if roles == "focal" else 1
+    n_threads = max(1, min(int(tuning.env("IMS_FOCAL_THREADS", "1")), len(streams))) if roles == "focal" else 1
     if n_threads == 1:
         for k, key in enumerate(mine):
             slot = k % len(streams)

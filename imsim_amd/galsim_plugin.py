@@ -305,7 +305,8 @@ def register(gs=None, gscfg=None, **kw):
     done.append(("sed", "InstCatSED"))
     # template aliases (imsim/templates.py:12-17) when a directory of imSim config files is given: IMSIM_CONFIG_DIR
     import os
-    cfg_dir = os.environ.get("IMSIM_CONFIG_DIR")
+    from . import tuning
+    cfg_dir = tuning.env("IMSIM_CONFIG_DIR")
     if cfg_dir and hasattr(gscfg, "RegisterTemplate"):
         for name in TEMPLATES:
             path = os.path.join(cfg_dir, name + ".yaml")

@@ -7,9 +7,9 @@ sensor state between all objects: there the delta-charge image is all-reduced be
 pixel-boundary recalculation (`allreduce_delta`, once per photon batch).  Because every photon's
 random stream is addressed by (object id, photon index) and unit fluxes make the sums exact, the
 result does not depend on the rank count."""
-import os
-
 import numpy as np
+
+from . import tuning
 
 
 def assign_ranks(n_phot, world, nrecalc=10000, round_photons=3.0e5):
@@ -179,7 +179,7 @@ def _exchange_on(dist):
     nccl code path at all (tests/test_multi_gpu_hip.py, `bench.py` under a one-rank launcher)."""
     if not (dist.is_available() and dist.is_initialized()):
         return False
-    return dist.get_world_size() > 1 or os.environ.get("IMS_EXCHANGE_SINGLE_RANK", "0") == "1"
+    return dist.get_world_size() > 1 or tuning.env("IMS_EXCHANGE_SINGLE_RANK", "0") == "1"
 
 
 def exchanging(world):
@@ -188,7 +188,7 @@ def exchanging(world):
     if world > 1 or _LIBRARY_COMM[0] is not None:
         return True
     import torch.distributed as dist
-    return os.environ.get("IMS_EXCHANGE_SINGLE_RANK", "0") == "1" and dist.is_available() and dist.is_initialized()
+    return tuning.env("IMS_EXCHANGE_SINGLE_RANK", "0") == "1" and dist.is_available() and dist.is_initialized()
 
 
 def reduce_image(image, dst=0, integer_counts=False):

@@ -13,7 +13,7 @@ import os
 
 import numpy as np
 
-from . import parallel
+from . import parallel, tuning
 from ._abi import OBJECT_DTYPE, IMS_OBJ_FAINT
 from .stamp import ProcessingMode, ObjectInfo
 
@@ -129,7 +129,7 @@ def make_batch_tables(objects, modes, nbatch, seed):
 
 def _pool_fits(renderer, n_photons):
     """the HBM-resident pool of prepared_image / build_image: 32 B per photon, at most 80 % of the free memory"""
-    if os.environ.get("IMS_POOL_RESIDENT", "1") == "0" or not hasattr(renderer, "prepared_pooled_batches"):
+    if tuning.env("IMS_POOL_RESIDENT", "1") == "0" or not hasattr(renderer, "prepared_pooled_batches"):
         return False
     free = renderer.torch.cuda.mem_get_info(renderer.device)[0]
     fits = 32 * int(n_photons) < 0.8 * free
@@ -193,7 +193,7 @@ def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1,
     r_rows = None
     if resident:
         shoot_table = tidy(objects[shot].copy())
-        if world > 1 or os.environ.get("IMS_POOL_SPATIAL", "1") != "0":
+        if world > 1 or tuning.env("IMS_POOL_SPATIAL", "1") != "0":
             order = spatial(shoot_table)
             shoot_table, shot = shoot_table[order], shot[order]
         row_of = np.full(len(objects), -1, dtype=np.int64)
@@ -276,7 +276,7 @@ def _prepared_image_device(renderer, table, modes, nbatch, seed, rank, world, re
     role = np.zeros(table.n, dtype=np.uint8 if nb < 250 else np.int32)
     role[phot_idx] = 1
     role[faint_idx] = (2 + faint_where).astype(role.dtype)
-    if world > 1 or os.environ.get("IMS_POOL_SPATIAL", "1") != "0":
+    if world > 1 or tuning.env("IMS_POOL_SPATIAL", "1") != "0":
         # the shoot table by 256 x 256-pixel tiles of the CCD, catalog order inside a tile: a stable sort on a 16-bit key
         tile = ((table.y.astype(np.int64) >> 8).clip(0, 255) << 8 | (table.x.astype(np.int64) >> 8).clip(0, 255)).astype(np.uint16)
         order = np.argsort(tile, kind="stable")
@@ -293,7 +293,7 @@ def _prepared_image_device(renderer, table, modes, nbatch, seed, rank, world, re
     # which of the two pixel-search launches a share goes to (ims_accumulate_segments above IMS_POOL_SMALL_MAX photons, one
     # wavefront per object below) is decided ONCE from the object's mean share: the two give the same result, and a fixed
     # split makes every batch two contiguous runs of index arithmetic instead of masks over a million objects
-    small_max = int(os.environ.get("IMS_POOL_SMALL_MAX", "64"))
+    small_max = int(tuning.env("IMS_POOL_SMALL_MAX", "64"))
     big = (role_s == 1) & ((n_shot // nb) > small_max)
     rows_big = np.flatnonzero(big)
     rows_small = np.flatnonzero((role_s == 1) & ~big)

@@ -1,0 +1,145 @@
+"""The ONE place where this package reads the process environment.
+
+Every switch of the host code and every field of the library's `ims_tuning_t` (include/imsim_hip.h) is named here with its
+default and what it selects; the rest of the package asks `env()` / `flag()` / `number()`, and `sync_library()` hands the
+library-side choices to libimsim_hip.so through `ims_set_tuning` -- the library itself reads no environment variable (apart
+from the file names of the libraries it looks up at run time, csrc/ims_libs.h).  All alternatives compute the same bits by
+another route; the defaults are the measured-fastest forms (EXPERIMENTS.md).  A name that is not listed here is an error, so
+a misspelt switch cannot silently select the default.
+"""
+import ctypes as C
+import os
+
+# name -> (default, what it selects).  Defaults are strings as they would stand in the environment (None = unset).
+KNOWN = {
+    # -- the library's ims_tuning_t (sync_library) --
+    "IMS_CHAIN_KERNELS": ("1", "kernels specialised for the default operator chain / analytic PSF; 0 = loops over the descriptors"),
+    "IMS_LAYOUT_KERNELS": ("1", "ray trace unrolled for a known optics layout; 0 = loop over the surfaces"),
+    "IMS_PSF_SCREENS_KERNEL": ("1", "straight-line PSF code for imSim's default AtmosphericPSF; 0 = the component loop"),
+    "IMS_PHOTON_LDS": (None, "dynamic LDS bytes a photon-kernel launch asks for without using it (default: 41 984 for launches "
+                             "that gather phase screens, else 0)"),
+    "IMS_ROUND_COMPACT": ("1", "pixel search of a round launched with a 120-byte argument block; 0 = the 1.4-KB launch parameters"),
+    "IMS_INIT_TILES": ("1", "tiled initial pixel-boundary state (k_init_tiles); 0 = one thread per cell"),
+    "IMS_UPD_DPP": ("1", "updatePixelDistortions with its table delivered by DPP broadcasts for small launches"),
+    "IMS_UPD_DPP_MAX": ("128", "... for launches of at most this many tiles"),
+    "IMS_JOINT_LISTS": ("1", "joint rounds: update / refresh over lists of the tiles with charge in reach"),
+    "IMS_JOINT_LIST_MIN": ("1024", "... for rounds of more than this many tiles"),
+    "IMS_ACTIVE_FRACTION": ("0.25", "... workgroups launched per tile of the round"),
+    # -- engine --
+    "IMS_SCREEN_PREPASS": ("0", "phase-screen gathers ahead of the shooting kernels (1: every photon, 2: ordinary objects on a side stream)"),
+    "IMS_SCREEN_BUCKETS": ("128", "arrival-time buckets of the pre-pass"),
+    "IMS_SCREEN_QUADS": (None, "phase screens also as 2 x 2 cells of 16 bytes (default 1 unless the pre-pass covers every photon)"),
+    "IMS_STREAM_PRIORITIES": ("-1,0,0,0,0", "HIP priorities of the chain / bulk / chain1 / chain2 / chain3 plan streams"),
+    "IMS_PRIVATE_STREAMS": ("0", "a stream set per renderer (measured slower)"),
+    "IMS_STREAM_SETS": ("1", "stream sets handed to the renderers of a device in turn"),
+    "IMS_UPLOAD_SYNC": ("0", "engine.upload_async as the synchronous copy it replaced"),
+    "IMS_BF_TAGS": ("0", "tile marks in LSST_Image chains (the update skips tiles without charge in reach)"),
+    "IMS_CHAIN_CLASSES": ("40,6", "round counts that cut the bright objects into concurrent brighter-fatter chains"),
+    "IMS_SLOT_PAIRS": ("0", "regions of the long chains as slot pairs, two launches per round (measured slower under load)"),
+    "IMS_PAIR_MAX_OBJECTS": ("64", "... for chain classes of at most this many objects"),
+    "IMS_NATIVE_PLAN": ("1", "launch plan of a CCD built and enqueued by the library (ims_plan_*); 0 = the numpy planner (the checker)"),
+    "IMS_POOL_RESIDENT": ("1", "photon pooling with the pool of all batches in HBM; 0 = one fused launch per batch"),
+    "IMS_POOL_SMALL_MAX": ("64", "per-batch shares up to this many photons go through ims_accumulate_small"),
+    "IMS_POOL_SPATIAL": ("1", "shoot table of pooling mode in spatial order"),
+    "IMS_FFT_TORCH": ("0", "inverse transforms of the FFT branch through torch.fft instead of ims_fft_inverse (the checker)"),
+    "IMS_EXCHANGE_SINGLE_RANK": ("0", "run the exchanges of a one-rank process group as self-exchanges"),
+    # -- focal plane --
+    "IMS_FOCAL_STREAMS": ("1", "four plan streams by role for all CCDs of a device; 0 = a set per renderer"),
+    "IMS_FOCAL_TOPS": ("2", "streams for the long top chains of a device"),
+    "IMS_FOCAL_CONCURRENT": ("4", "bench C5: CCDs in flight on the rolling-window path"),
+    "IMS_FOCAL_THREADS": ("1", "host threads that enqueue CCDs (rolling window)"),
+    "IMS_FOCAL_INIT": ("bulk", "rolling window: stream of a CCD's static-state initialisation"),
+    "IMS_FOCAL_COPY": ("mid", "rolling window: stream of a CCD's image copy"),
+    "IMS_FOCAL_ANCHOR": ("top", "rolling window: stream a CCD's plan is anchored to"),
+    "IMS_FOCAL_FFT": (None, "stream of a CCD's FFT-drawn objects (joint path: mid; rolling window: top)"),
+    "IMS_FOCAL_JOINT": ("16", "CCDs per batch whose chains advance in joint launches (0 / 1: a chain per CCD)"),
+    "IMS_FOCAL_JOINT_MAX_BRIGHT": ("600", "CCDs with more objects of their own rounds than this take the rolling window"),
+    "IMS_FOCAL_AHEAD": ("pre:1", "the host enqueues a CCD's front only when the front n CCDs before has run on that stream"),
+    "IMS_NO_HINT": ("0", "ignore the chain-length hint that batches CCDs of similar chains"),
+    "IMS_FOCAL_PRE_PRIORITY": ("0", "joint path: priority of the stream of the FFT draws / initial states / first pool slices"),
+    "IMS_FOCAL_JOINT_INIT": ("pre", "joint path: the stream a CCD's renderer is initialised on"),
+    "IMS_FOCAL_ARENA": ("1", "joint path: pixel-boundary state leased from one arena per device (engine.SensorArena); 0 = per renderer"),
+    "IMS_FOCAL_ARENA_CELLS": (None, "the arena's private pool in owner cells (tests: a pool that runs dry)"),
+    "IMS_FOCAL_STATIC_REGIONS": ("3", "static regions of the arena, taken in turn"),
+    "IMS_FOCAL_ALIVE": ("3", "joint path: batches alive at a time (enqueueing / in its rounds / in its tails)"),
+    "IMS_FOCAL_TRACE": ("0", "print, per CCD, when its work ended on every stream and when the host enqueued it"),
+    "IMS_PROCESS_FOCAL": ("1", "config.Process with several CCDs on the overlapped focal-plane path"),
+    "IMS_PROCESS_CONCURRENT": ("3", "... CCDs in flight"),
+    # -- bench / tests --
+    "IMS_C5_CCDS": (None, "bench.py --config c5 on the first N CCDs at the full per-CCD workload"),
+    "IMS_BENCH_DUMP": (None, "bench.py: file that receives the last step's image (or per-CCD CRCs): the N-rank tests"),
+    # -- files --
+    "IMSIM_HIP_LIB": (None, "another build of the library (A/B measurements)"),
+    "IMSIM_DATA_DIR": (None, "imSim's data directory"),
+    "IMSIM_CONFIG_DIR": (None, "imSim's config directory (template lookup)"),
+    "SIMS_SED_LIBRARY_DIR": (None, "the SED library of instance catalogs"),
+}
+
+
+def env(name, default=None):
+    """The value of a known switch: the environment's, else `default` when given, else the listed default."""
+    if name not in KNOWN:
+        raise KeyError(f"tuning.env: {name!r} is not a known switch (imsim_amd/tuning.py lists them)")
+    v = os.environ.get(name)
+    if v is not None:
+        return v
+    return default if default is not None else KNOWN[name][0]
+
+
+def flag(name, default=None):
+    """True unless the switch is "0" / unset-with-default-"0" """
+    v = env(name, default)
+    return v is not None and v != "0" and v != ""
+
+
+def number(name, cast=int, default=None):
+    v = env(name, default)
+    return None if v is None or v == "" else cast(v)
+
+
+def setdefault(name, value):
+    """a default the CALLER chooses for this process (bench C5: four top-chain streams)"""
+    if name not in KNOWN:
+        raise KeyError(name)
+    os.environ.setdefault(name, str(value))
+
+
+class Tuning(C.Structure):
+    """ims_tuning_t (include/imsim_hip.h)"""
+    _fields_ = [("chain_kernels", C.c_int32), ("layout_kernels", C.c_int32), ("psf_screens_kernel", C.c_int32), ("photon_lds", C.c_int32),
+                ("round_compact", C.c_int32), ("init_tiles", C.c_int32), ("upd_dpp", C.c_int32), ("joint_lists", C.c_int32),
+                ("upd_dpp_max", C.c_int64), ("joint_list_min", C.c_int64), ("active_fraction", C.c_double)]
+
+
+def library_tuning():
+    """ims_tuning_t as the environment asks for it"""
+    t = Tuning()
+    t.chain_kernels = 1 if flag("IMS_CHAIN_KERNELS") else 0
+    t.layout_kernels = 1 if flag("IMS_LAYOUT_KERNELS") else 0
+    t.psf_screens_kernel = 1 if flag("IMS_PSF_SCREENS_KERNEL") else 0
+    lds = number("IMS_PHOTON_LDS")
+    t.photon_lds = -1 if lds is None else int(lds)
+    t.round_compact = 1 if flag("IMS_ROUND_COMPACT") else 0
+    t.init_tiles = 1 if flag("IMS_INIT_TILES") else 0
+    t.upd_dpp = 1 if flag("IMS_UPD_DPP") else 0
+    t.joint_lists = 1 if flag("IMS_JOINT_LISTS") else 0
+    t.upd_dpp_max = number("IMS_UPD_DPP_MAX")
+    t.joint_list_min = number("IMS_JOINT_LIST_MIN")
+    t.active_fraction = number("IMS_ACTIVE_FRACTION", float)
+    return t
+
+
+_LAST = [None]
+
+
+def sync_library(lib):
+    """Hand the library-side choices to libimsim_hip.so (ims_set_tuning) when they differ from what it was last given; called
+    wherever the host is about to enqueue launches (renderer construction, plan runs, joint runs)."""
+    t = library_tuning()
+    raw = bytes(t)
+    if raw != _LAST[0]:
+        rc = lib.ims_set_tuning(C.byref(t))
+        if rc != 0:
+            msg = lib.ims_last_error()
+            raise RuntimeError(f"ims_set_tuning failed ({rc}): {msg.decode() if msg else ''}")
+        _LAST[0] = raw

@@ -48,7 +48,7 @@ extern "C" {
 #define IMS_ERR_NO_DEVICE  -3
 #define IMS_ERR_UNSUPPORTED -4
 
-#define IMS_ABI_VERSION 18
+#define IMS_ABI_VERSION 19
 
 /* Pointers stored INSIDE descriptors that live in device memory (ims_sensor_t, ims_atmosphere_t) always point to global
  * device memory.  Device code is told so (address space 1): a pointer read out of memory is otherwise a generic pointer and
@@ -408,6 +408,34 @@ int  ims_device_info(int device, int* n_cu, int* n_xcd, int64_t* lds_bytes, int6
 /* 1 when the library holds kernels specialised for this optics layout (ims_render_params_t.optics_layout) */
 int  ims_known_optics_layout(uint64_t layout);
 
+/* ---- tuning: which of its equivalent forms the library launches ----
+ * Every alternative below computes the same bits by another route (the parity tests run under each of them); the defaults are
+ * the measured-fastest forms on MI355X.  The library reads NO environment variable for this (its behaviour does not depend on the
+ * caller's environment): a caller that wants another form says so with ims_set_tuning, process-wide, before the launches it is to
+ * apply to.  (The Python host keeps its own IMS_* environment parsing in ONE module, imsim_amd/tuning.py, which fills this block;
+ * a replacement of imSim's GalSim calls that never touches it gets the defaults.)  Replaces nothing in the reference: GalSim has no
+ * such switches; listed here because SURVEY 8(b) asks for one explicit boundary. */
+typedef struct ims_tuning {
+    int32_t chain_kernels;       /* 1: kernels with imSim's default photon-op chain / analytic PSF as straight-line code (run_ops<1>,
+                                    run_psf<1>); 0: the loops over the descriptors */
+    int32_t layout_kernels;      /* 1: ray trace unrolled for a known optics layout (ims_known_optics_layout); 0: loop over the surfaces */
+    int32_t psf_screens_kernel;  /* 1: straight-line PSF code for imSim's default AtmosphericPSF (screens, second kick, Gaussian) */
+    int32_t photon_lds;          /* dynamic LDS bytes a photon-kernel launch asks for without using it (caps the workgroups per CU);
+                                    -1: automatic -- 41 984 B for launches that gather phase screens, 0 otherwise */
+    int32_t round_compact;       /* 1: the pixel search of a round takes a 120-byte argument block; 0: the 1.4-KB launch parameters */
+    int32_t init_tiles;          /* 1: tiled initial pixel-boundary state (4 vertices per edge); 0: one thread per owner cell */
+    int32_t upd_dpp;             /* 1: updatePixelDistortions with its table delivered by DPP broadcasts for launches of at most
+                                    upd_dpp_max tiles; 0: always the scalar-register form */
+    int32_t joint_lists;         /* 1: joint rounds update / refresh over lists of the tiles with charge in reach (rounds of more than
+                                    joint_list_min tiles); 0: sweeps over every tile */
+    int64_t upd_dpp_max;         /* 128 */
+    int64_t joint_list_min;      /* 1024 */
+    double  active_fraction;     /* 0.25: workgroups launched per tile of a round for the list walkers (0 < f <= 1) */
+} ims_tuning_t;
+int  ims_tuning_defaults(ims_tuning_t* out);
+int  ims_get_tuning(ims_tuning_t* out);
+int  ims_set_tuning(const ims_tuning_t* tuning);
+
 /* ---- fused path: shoot -> PSF -> ops -> sensor -> CCD image (LSST_Silicon / LSST_Image) ---- */
 int  ims_shoot_accumulate(const ims_render_params_t* params, void* stream);
 
@@ -695,13 +723,6 @@ typedef struct ims_chain {
     int32_t pair_shift, pad;
     const int64_t* pair_tile_prefix;      /* device: prefix sum of the 15x15-cell tiles of the slots first_slot.. (the fused launch) */
     const int64_t* pair_tile_prefix_host; /* HOST copy */
-    /* Marks: after the launches of round mark_round[j] the chain's stream records library event mark_event[j] (n_marks <=
-     * IMS_MAX_CHAIN_EDGES).  The planner uses them to hold the bulk stream's next pool slice of the top class until the chain
-     * has consumed the previous one (IMS_PLAN_WAIT on the bulk stream): the wide early rounds of the longest chains then run
-     * beside nothing instead of beside photon kernels that hold every wave slot. */
-    int32_t n_marks, pad3;
-    int32_t mark_round[IMS_MAX_CHAIN_EDGES];
-    int32_t mark_event[IMS_MAX_CHAIN_EDGES];
 } ims_chain_t;
 
 typedef struct ims_plan_item {
@@ -751,9 +772,6 @@ typedef struct ims_plan_input {
     int32_t n_static_slots, slot_capacity;
     int64_t static_cells, scratch_cells, max_pool_photons;
     int32_t seg_size, want_realized, event_base, use_tags;
-    int32_t head_start;                  /* 1: the pool slices of the top chain class wait for the chain to consume the slice before
-                                            (the chain's wide early rounds run alone); 0: all slices back to back */
-    int32_t pad;
 } ims_plan_input_t;
 typedef struct ims_plan_sizes {
     int64_t arena_bytes;                 /* tables of the plan (host image, page-locked by the caller, and its device copy) */

@@ -125,6 +125,7 @@ int orc_struct_size(int which)
     case 19: return (int)sizeof(ims_object_meta_t);
     case 20: return (int)sizeof(ims_plan_input_t);
     case 21: return (int)sizeof(ims_plan_sizes_t);
+    case 22: return (int)sizeof(ims_tuning_t);
     }
     return -1;
 }

@@ -36,6 +36,49 @@ def test_struct_sizes_match_binding():
     assert C.sizeof(_abi.BfSlot) == _abi.BFSLOT_DTYPE.itemsize
 
 
+def test_tuning_block_is_the_only_way_to_change_which_kernels_the_library_launches(monkeypatch):
+    """ims_tuning_t (include/imsim_hip.h): its size matches the binding, the defaults are today's fast forms, a set block is
+    what a get returns, out-of-range values are refused -- and the library itself reads no environment variable for any of it
+    (only the file names of the libraries it looks up at run time): the one module of the package that does, tuning.py,
+    translates the environment into the block."""
+    from imsim_amd import tuning
+    lib = _abi.load()
+    assert lib.ims_struct_size(_abi.STRUCTS.index(_abi.Tuning)) == C.sizeof(tuning.Tuning) == 56
+    d = tuning.Tuning()
+    assert lib.ims_tuning_defaults(C.byref(d)) == 0
+    assert (d.chain_kernels, d.layout_kernels, d.psf_screens_kernel, d.photon_lds, d.round_compact, d.init_tiles, d.upd_dpp,
+            d.joint_lists, d.upd_dpp_max, d.joint_list_min, d.active_fraction) == (1, 1, 1, -1, 1, 1, 1, 1, 128, 1024, 0.25)
+    for name in ("IMS_CHAIN_KERNELS", "IMS_LAYOUT_KERNELS", "IMS_PSF_SCREENS_KERNEL", "IMS_PHOTON_LDS", "IMS_ROUND_COMPACT", "IMS_INIT_TILES",
+                 "IMS_UPD_DPP", "IMS_UPD_DPP_MAX", "IMS_JOINT_LISTS", "IMS_JOINT_LIST_MIN", "IMS_ACTIVE_FRACTION"):
+        monkeypatch.delenv(name, raising=False)
+    assert bytes(tuning.library_tuning()) == bytes(d)              # an empty environment asks for the defaults
+    monkeypatch.setenv("IMS_CHAIN_KERNELS", "0")
+    monkeypatch.setenv("IMS_ACTIVE_FRACTION", "0.01")
+    monkeypatch.setenv("IMS_UPD_DPP_MAX", "100000")
+    tuning.sync_library(lib)
+    got = tuning.Tuning()
+    assert lib.ims_get_tuning(C.byref(got)) == 0
+    assert (got.chain_kernels, got.active_fraction, got.upd_dpp_max, got.layout_kernels) == (0, 0.01, 100000, 1)
+    bad = tuning.Tuning.from_buffer_copy(bytes(d))
+    bad.active_fraction = 0.0
+    assert lib.ims_set_tuning(C.byref(bad)) == -1 and b"tuning" in lib.ims_last_error()
+    assert lib.ims_set_tuning(None) == -1
+    assert lib.ims_get_tuning(C.byref(got)) == 0 and got.chain_kernels == 0          # a refused block changes nothing
+    assert lib.ims_set_tuning(C.byref(d)) == 0
+    tuning._LAST[0] = None
+    with pytest.raises(KeyError):
+        tuning.env("IMS_NO_SUCH_SWITCH")
+    # the library's sources read the environment in one place only: the run-time lookup of hipFFT / RCCL by file name
+    csrc = os.path.join(ROOT, "imsim_amd", "csrc")
+    reads = {f: open(os.path.join(csrc, f)).read().count("getenv(") for f in os.listdir(csrc)}
+    assert {f: n for f, n in reads.items() if n} == {"ims_libs.h": 1}
+    # and the package's Python reads it in tuning.py only
+    pkg = os.path.join(ROOT, "imsim_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py") and f != "tuning.py":
+            assert "os.environ" not in open(os.path.join(pkg, f)).read(), f
+
+
 def test_joint_run_entry_points_check_their_arguments_before_any_hip_call():
     """ims_plan_run_deferred / ims_plans_run_joint / ims_plan_join (the CCDs of a visit side by side): argument errors are
     reported without touching the GPU; an empty list of plans is a no-op."""
@@ -53,7 +96,7 @@ def test_joint_run_entry_points_check_their_arguments_before_any_hip_call():
 
 def test_abi_version_and_error_string():
     lib = _abi.load()
-    assert lib.ims_abi_version() == 18
+    assert lib.ims_abi_version() == 19
     # argument checking happens before any HIP call, so it is testable without a GPU
     assert lib.ims_shoot_accumulate(None, None) == -1
     assert b"NULL" in lib.ims_last_error()

@@ -7,7 +7,9 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import faulthandler
+faulthandler.dump_traceback_later(int(os.environ.get("R5_WATCHDOG", "75")), exit=False)      # where the host sits if a call hangs
+sys.path.insert(0, os.environ.get("R5_PKG_ROOT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from imsim_amd import configs, catalog, focal_plane  # noqa: E402
 from imsim_amd.engine import Renderer  # noqa: E402
 
@@ -30,8 +32,9 @@ for k in range(3):
     print(f"[{tag}] call {k}: {dt:.3f} s for {n_ccd} CCDs = {1e3 * dt / n_ccd:.2f} ms per CCD; host {focal_plane.render_focal_plane.last_host_ms_per_ccd:.2f} ms per CCD, "
           f"batch {getattr(focal_plane.render_focal_plane, 'last_joint_batch', 0)}, arena {getattr(focal_plane.render_focal_plane, 'last_arena_gib', 0):.1f} GiB, "
           f"reserved {torch.cuda.memory_reserved() / 2**30:.0f} GiB", flush=True)
-assert sums[0] == sums[1] == sums[2]
-print("checksum of the step:", float(sum(v for _, v in sums[0])))
+print("checksums equal over the calls:", sums[0] == sums[1] == sums[2], " checksum of the step:", float(sum(v for _, v in sums[0])), flush=True)
+import zlib
+print("crc of all CCD checksums:", zlib.crc32(repr(sums[0]).encode()), flush=True)
 if len(sys.argv) > 2 and sys.argv[2] == "profile":
     import cProfile
     import pstats

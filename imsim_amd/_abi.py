@@ -191,7 +191,9 @@ class Catalog(C.Structure):
                                                       "prof_table", "sed_table", "stamp_size", "obj_id", "phot_flux")] + [
         ("seed", c_u64), ("sed_table_all", c_i32), ("n_star_size", c_i32), ("n_gal_radius", c_i32), ("nmax", c_i32),
         ("noise_var", c_d), ("max_flux_simple", c_d), ("tiny_flux", c_d), ("pixel_scale", c_d), ("dg_stepk", c_d),
-        ("star_size", c_vp), ("gal_radius", c_vp), ("zenith", c_d * 3), ("has_field", c_i32), ("pad", c_i32)]
+        ("star_size", c_vp), ("gal_radius", c_vp), ("zenith", c_d * 3), ("has_field", c_i32), ("pad", c_i32),
+        ("sb_flux", c_vp), ("sersic_b", c_vp), ("sersic_norm", c_vp), ("sersic_inv_n", c_vp), ("keep_sb", c_d),
+        ("psf_size_keep", c_i32), ("psf_size_keep3", c_i32), ("sb_tables", c_i32), ("pad2", c_i32)]
 
 
 class ObjectMeta(C.Structure):

@@ -536,7 +536,7 @@ __global__ __launch_bounds__(WG, (NV == 8) ? 2 : 4) void k_accumulate_round_c(co
 // one after the other), while one launch that holds the round of MANY objects costs little more than the round of one (C3: 41
 // objects 2.8 x one star).  So the launch takes the argument blocks of up to IMS_JOINT_MAX chains by value and a workgroup
 // finds its chain from the ascending workgroup ends (scalar compares on kernel arguments); the body is the one above.
-constexpr int IMS_JOINT_MAX = 32;
+constexpr int IMS_JOINT_MAX = 64;
 
 struct JointEnds { int32_t v[IMS_JOINT_MAX]; };      // ascending workgroup ends of the chains of one launch (a chain that sits out: zero width)
 
@@ -2212,6 +2212,49 @@ __device__ __forceinline__ int good_image_size(double stepk, double pixel_scale)
     return (int)(2 * ((n + 1) / 2));
 }
 
+// get_good_phot_stamp_size1 (imsim/stamp_utils.py:293-354) for a transformed Sersic profile: grow the square of N pixels by 10 %
+// until xValue on its four edge midpoints and four corners is below `keep`, cap at nmax, shrink while the next smaller square
+// still is (not below 64).  j0 .. j3: the profile's affine (sky = J profile); amp = flux I(0) / |det J|.
+__device__ __forceinline__ double sersic_edge_max(double h, double j0, double j1, double j2, double j3, double det, double hlr,
+                                                  double amp, double b, double inv_n)
+{
+    // the eight points: (h, 0) (-h, 0) (0, h) (0, -h) (h, h) (h, -h) (-h, h) (-h, -h); the profile is point-symmetric, so four suffice
+    const double px[4] = { h, 0.0, h, h }, py[4] = { 0.0, h, h, -h };
+    double best = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double u = ddiv(j3 * px[k] - j1 * py[k], det), v = ddiv(-j2 * px[k] + j0 * py[k], det);
+        const double r = ddiv(dsqrt0(u * u + v * v), hlr);
+        const double val = amp * dexp(-b * dpow(r, inv_n));
+        best = val > best ? val : best;
+    }
+    return best;
+}
+
+__device__ __forceinline__ long long phot_stamp_size1(int own, double keep, int nmax, double pixel_scale, double j0, double j1, double j2,
+                                                      double j3, double hlr, double flux, double norm, double b, double inv_n)
+{
+    const double det = j0 * j3 - j1 * j2;
+    const double amp = ddiv(flux * norm, hlr * hlr * fabs(det));
+    double N = (double)own;
+    bool active = N < (double)nmax;
+    for (int it = 0; it < 200 && active; ++it) {
+        const double mv = sersic_edge_max(N * 0.5 * pixel_scale, j0, j1, j2, j3, det, hlr, amp, b, inv_n);
+        if (mv < keep) break;
+        N = N * 1.1;
+        active = N < (double)nmax;
+    }
+    if (N > (double)nmax) N = (double)nmax;
+    active = N >= 64.0 * 1.1;
+    for (int it = 0; it < 200 && active; ++it) {
+        const double mv = sersic_edge_max(ddiv(N, 2.0 * 1.1) * pixel_scale, j0, j1, j2, j3, det, hlr, amp, b, inv_n);
+        if (mv > keep) break;
+        N = ddiv(N, 1.1);
+        active = N >= 64.0 * 1.1;
+    }
+    return (long long)N;
+}
+
 __global__ __launch_bounds__(256) void k_build_object_table(const ims_catalog_t C, const ims_optics_t* __restrict__ optics,
                                                             ims_object_t* __restrict__ rows, ims_object_meta_t* __restrict__ meta)
 {
@@ -2329,7 +2372,25 @@ __global__ __launch_bounds__(256) void k_build_object_table(const ims_catalog_t 
             constexpr double PI_ = 3.14159265358979323846;
             const double stepk = ddiv(1.0, dsqrt0(ddiv(rr * rr, PI_ * PI_) + ddiv(1.0, C.dg_stepk * C.dg_stepk)));
             size = good_image_size(stepk, C.pixel_scale);
-            if (nominal > 10.0 * (double)size * (double)size || size > C.nmax) m.flags |= IMS_META_SIZE_PENDING;
+            if (nominal > 10.0 * (double)size * (double)size || size > C.nmax) {
+                if (C.sb_tables) {
+                    // bright or oversized: the size follows from the surface brightness at the stamp's edge (stamp_utils.py:196-220)
+                    const int own = good_image_size(ddiv(PI_, rr), C.pixel_scale);
+                    const double flux = C.sb_flux ? C.sb_flux[i] : nominal;
+                    const double hl = C.hlr[i];
+                    const long long g1 = phot_stamp_size1(own, C.keep_sb, C.nmax, C.pixel_scale, j0, j1, j2, j3, hl, flux, C.sersic_norm[t],
+                                                          C.sersic_b[t], C.sersic_inv_n[t]);
+                    long long sz = (long long)dsqrt0((double)g1 * (double)g1 + (double)C.psf_size_keep * (double)C.psf_size_keep);
+                    if (sz > C.nmax) {
+                        const long long g3 = phot_stamp_size1(own, 3.0 * C.keep_sb, C.nmax, C.pixel_scale, j0, j1, j2, j3, hl, flux,
+                                                              C.sersic_norm[t], C.sersic_b[t], C.sersic_inv_n[t]);
+                        sz = (long long)dsqrt0((double)g3 * (double)g3 + (double)C.psf_size_keep3 * (double)C.psf_size_keep3);
+                    }
+                    size = (int)(sz > C.nmax ? C.nmax : sz);
+                } else {
+                    m.flags |= IMS_META_SIZE_PENDING;
+                }
+            }
             if (size > C.nmax) size = C.nmax;
         }
     }
@@ -3284,7 +3345,7 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
         for (Act& a : act) if (a.pl == pl) a.done = done;
     }
     if (act.empty()) return IMS_OK;
-    if ((int)act.size() > IMS_JOINT_MAX) return set_err(IMS_ERR_ARG, "at most 32 chains per joint run");
+    if ((int)act.size() > IMS_JOINT_MAX) return set_err(IMS_ERR_ARG, "at most 64 chains per joint run");
     const int32_t nrecalc = act[0].ch->nrecalc, use_tags = act[0].ch->use_tags;
     int32_t max_rounds = 0;
     for (const Act& a : act) {
@@ -3294,10 +3355,18 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
             return set_err(IMS_ERR_ARG, "joint run: chain without table / pool / image");
         if (ch.n_rounds > max_rounds) max_rounds = ch.n_rounds;
         // the joint stream takes over behind the chain's own stream (the regions' initial state, the first pool slice)
+        // (behind the END OF THE CCD'S OWN FRONT on that stream -- the event ims_plan_run_deferred recorded there -- not behind
+        // whatever the stream holds by now: the joint run may be enqueued from a second host thread while the fronts of the
+        // next batch of CCDs are already being queued on the shared streams, and the chain must not wait for those)
         hipStream_t cs = (hipStream_t)a.pl->d_streams[ch.stream];
         if (cs != js) {
-            HIP_TRY(hipEventRecord(a.pl->d_events[a.chain & 3], cs));
-            HIP_TRY(hipStreamWaitEvent(js, a.pl->d_events[a.chain & 3], 0));
+            std::vector<hipStream_t> uniq;
+            for (void* st : a.pl->d_streams)
+                if (std::find(uniq.begin(), uniq.end(), (hipStream_t)st) == uniq.end()) uniq.push_back((hipStream_t)st);
+            const size_t k = (size_t)(std::find(uniq.begin(), uniq.end(), cs) - uniq.begin());
+            if ((int)uniq.size() != a.pl->unjoined || k >= uniq.size())
+                return set_err(IMS_ERR_ARG, "joint run: the plan was not enqueued by ims_plan_run_deferred on these streams");
+            HIP_TRY(hipStreamWaitEvent(js, a.pl->events[2 + uniq.size() + k], 0));
         }
     }
     const int32_t segs = (nrecalc + 255) / 256;
@@ -3505,21 +3574,25 @@ int ims_fft_inverse(double* kbuf_dev, double* rbuf_dev, int32_t nfft, int64_t ba
     if (nfft < 2 || (nfft & 1) || batch > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "nfft must be even and >= 2");
     const ims_libs::Fft* F = ims_libs::fft();
     if (!F) return set_err(IMS_ERR_UNSUPPORTED, "hipFFT is not loadable (libhipfft.so; IMS_HIPFFT_LIB names a file)");
-    // plans are kept per (size, batch, stream): making one costs milliseconds, a CCD's FFT objects come in a handful of sizes.  Per
-    // STREAM because a plan owns its work buffer (the transposes of the large sizes go through it): the same plan executing on two
-    // streams at once -- the FFT objects of two CCDs of a focal plane on the two top-chain streams -- would share it
+    // Plans are kept per (size, stream) and transform ONE stamp: a batch is a loop over it.  Making a plan costs ~70 ms (measured
+    // in round 5: the 40 plans of the first 48 CCDs of a visit -- one per size AND batch count -- were 2.8 of the 3.4 s a fresh
+    // process spent on them), a CCD holds one to three FFT-drawn objects of a handful of sizes, and a transform of 1024^2 or more
+    // fills the device by itself, so nothing is lost by not batching.  Per STREAM because a plan owns its work buffer (the
+    // transposes of the large sizes go through it): the same plan executing on two streams at once -- the FFT objects of two CCDs
+    // of a focal plane on the two top-chain streams -- would share it.  Small transforms (below 1024^2: launch-bound) keep batched plans.
     static std::mutex m;
     static std::map<std::tuple<int32_t, int64_t, void*>, hipfftHandle> plans;
+    const int64_t per_plan = nfft >= 1024 ? 1 : batch;
     hipfftHandle plan;
     {
         std::lock_guard<std::mutex> lock(m);
-        const std::tuple<int32_t, int64_t, void*> key(nfft, batch, stream);
+        const std::tuple<int32_t, int64_t, void*> key(nfft, per_plan, stream);
         auto it = plans.find(key);
         if (it == plans.end()) {
             int n[2] = { nfft, nfft };
             int inembed[2] = { nfft, nfft / 2 + 1 }, onembed[2] = { nfft, nfft };
             hipfftHandle p;
-            int rc = fft_err(F->plan_many(&p, 2, n, inembed, 1, nfft * (nfft / 2 + 1), onembed, 1, nfft * nfft, HIPFFT_Z2D, (int)batch),
+            int rc = fft_err(F->plan_many(&p, 2, n, inembed, 1, nfft * (nfft / 2 + 1), onembed, 1, nfft * nfft, HIPFFT_Z2D, (int)per_plan),
                              "hipfftPlanMany");
             if (rc) return rc;
             it = plans.emplace(key, p).first;
@@ -3527,8 +3600,11 @@ int ims_fft_inverse(double* kbuf_dev, double* rbuf_dev, int32_t nfft, int64_t ba
         plan = it->second;
         int rc = fft_err(F->set_stream(plan, (hipStream_t)stream), "hipfftSetStream");
         if (rc) return rc;
-        rc = fft_err(F->exec_z2d(plan, (hipfftDoubleComplex*)kbuf_dev, (hipfftDoubleReal*)rbuf_dev), "hipfftExecZ2D");
-        if (rc) return rc;
+        for (int64_t b = 0; b < batch; b += per_plan) {
+            rc = fft_err(F->exec_z2d(plan, (hipfftDoubleComplex*)kbuf_dev + b * (int64_t)nfft * (nfft / 2 + 1),
+                                     (hipfftDoubleReal*)rbuf_dev + b * (int64_t)nfft * nfft), "hipfftExecZ2D");
+            if (rc) return rc;
+        }
     }
     // numpy / GalSim normalisation of the inverse ("backward": 1 / N^2): exact for the even sizes used (powers of two)
     const int64_t total = batch * (int64_t)nfft * nfft;

@@ -12,6 +12,7 @@ launch plan needs.  The host keeps the two things that are not per-object arithm
 Reference: imsim/stamp.py:109-249, imsim/stamp_utils.py:79-189, imsim/instcat.py:498-527.
 """
 import ctypes as C
+import functools
 import math
 
 import numpy as np
@@ -47,6 +48,30 @@ def gal_radius_table(sersic_index=None):
     return out
 
 
+def sersic_sb_tables(sersic_index=None):
+    """per radial table t: b_n, I(0) hlr^2 / flux and 1 / n of its Sersic index (what sersic_xvalue needs of it)"""
+    by_table = {0: 1.0, 1: 4.0}
+    for n, t in (sersic_index or {}).items():
+        by_table[int(t)] = float(n)
+    m = max(by_table) + 1
+    b, norm, inv_n = np.ones(m), np.zeros(m), np.ones(m)
+    for t, n in by_table.items():
+        b[t], norm[t] = catalog._sersic_norm(n)
+        inv_n[t] = 1.0 / n
+    return b, norm, inv_n
+
+
+@functools.lru_cache(maxsize=16)
+def psf_phot_sizes(noise_var, nmax=catalog.NMAX):
+    """get_good_phot_stamp_size1 of the DoubleGaussian proxy PSF at the surface-brightness limits sqrt(noise_var) / 8 and three
+    times that (stamp_utils.py:196-220): object-independent, so the host hands the two integers to the table kernel"""
+    keep = math.sqrt(noise_var) / 8.0
+    dg_stepk = min(catalog.gaussian_stepk(0.6 / 2.355, catalog.FT_DEFAULT), catalog.gaussian_stepk(0.12 / 2.355, catalog.FT_DEFAULT))
+    n0 = np.array([catalog._good_size(dg_stepk)])
+    f = lambda h: catalog._edge_max(catalog.double_gaussian_xvalue, h)     # noqa: E731
+    return (keep, int(catalog._phot_stamp_size1(n0, f, keep, nmax)[0]), int(catalog._phot_stamp_size1(n0, f, 3.0 * keep, nmax)[0]))
+
+
 def zenith_vector(latitude, hour_angle_center, ra_center):
     """unit vector of the zenith in the frame of the image WCS: declination = latitude, right ascension = the local sidereal
     time ra_center + hour_angle_center [radians]"""
@@ -57,7 +82,7 @@ def zenith_vector(latitude, hour_angle_center, ra_center):
 COLUMNS = (("x", np.float64), ("y", np.float64), ("nominal_flux", np.float64), ("hlr", np.float64), ("q", np.float64),
            ("pa", np.float64), ("g1", np.float64), ("g2", np.float64), ("mu", np.float64), ("kind", np.int32),
            ("prof_table", np.int32), ("sed_table", np.int32), ("stamp_size", np.int32), ("obj_id", np.int64),
-           ("phot_flux", np.int64))
+           ("phot_flux", np.int64), ("sb_flux", np.float64))
 
 
 def catalog_columns(cat, phot_flux=None, sersic_index=None, stamp_size=None):
@@ -77,6 +102,8 @@ def catalog_columns(cat, phot_flux=None, sersic_index=None, stamp_size=None):
                 prof_table=table, obj_id=cat.get("obj_id"))
     if "g1" in cat:
         cols.update(g1=cat["g1"], g2=cat["g2"], mu=cat["mu"])
+    if cat.get("sb_flux") is not None:
+        cols["sb_flux"] = cat["sb_flux"]
     if cat.get("sed_table") is not None:
         cols["sed_table"] = np.broadcast_to(np.asarray(cat["sed_table"], dtype=np.int32), (n,))
     if phot_flux is not None:
@@ -87,7 +114,7 @@ def catalog_columns(cat, phot_flux=None, sersic_index=None, stamp_size=None):
 
 
 def fill_catalog_struct(cols, ptr_of, seed, visit, optics_has_field=True, noise_var=800.0, max_flux_simple=100.0, sed_table=0,
-                        sersic_index=None):
+                        sersic_index=None, sizes_on_device=True):
     """ims_catalog_t over columns that already live where the kernel (or the oracle) reads them.  ptr_of(name, array, dtype)
     -> address.  visit: dict with airmass, raw_seeing, band, latitude, hour_angle, ra [degrees]."""
     st = _abi.Catalog()
@@ -107,6 +134,14 @@ def fill_catalog_struct(cols, ptr_of, seed, visit, optics_has_field=True, noise_
     z = zenith_vector(math.radians(visit["latitude"]), math.radians(visit["hour_angle"]), math.radians(visit["ra"]))
     st.zenith[0], st.zenith[1], st.zenith[2] = z
     st.has_field = 1 if optics_has_field else 0
+    if sizes_on_device:
+        # the surface-brightness loop of the bright / oversized galaxies in the kernel (ims_catalog_t.sb_tables)
+        b, norm, inv_n = sersic_sb_tables(sersic_index)
+        if len(b) != len(gal):
+            raise ValueError("sersic tables and gal_radius disagree in length")
+        st.sersic_b, st.sersic_norm, st.sersic_inv_n = ptr_of("sersic_b", b, np.float64), ptr_of("sersic_norm", norm, np.float64), ptr_of("sersic_inv_n", inv_n, np.float64)
+        st.keep_sb, st.psf_size_keep, st.psf_size_keep3 = psf_phot_sizes(float(noise_var))
+        st.sb_tables = 1
     return st
 
 
@@ -154,7 +189,9 @@ class DeviceTable:
     copy of what planning needs (`n_phot`, stamp bounds, flags as a slim structured array)."""
 
     def __init__(self, renderer, cat, visit, phot_flux=None, noise_var=800.0, max_flux_simple=100.0, sed_table=0,
-                 stamp_size=None):
+                 stamp_size=None, sizes_on_device=True):
+        """sizes_on_device: the surface-brightness loop of the bright / oversized galaxies runs in the table kernel (the default);
+        False: the kernel flags those rows and the numpy loop of catalog.gal_stamp_size patches them (the checker)"""
         torch = renderer.torch
         dev = renderer.device
         self.renderer = renderer
@@ -173,7 +210,8 @@ class DeviceTable:
             off = (off + a.nbytes + 255) & ~255
         star = star_size_table(airmass=visit["airmass"], raw_seeing=visit["raw_seeing"], band=visit["band"])
         gal = gal_radius_table(sersic_index)
-        for name, a in (("star_size", star), ("gal_radius", gal)):
+        sb_b, sb_norm, sb_inv_n = sersic_sb_tables(sersic_index)
+        for name, a in (("star_size", star), ("gal_radius", gal), ("sersic_b", sb_b), ("sersic_norm", sb_norm), ("sersic_inv_n", sb_inv_n)):
             parts.append((name, off, a))
             off = (off + a.nbytes + 255) & ~255
         stage = _pinned(torch, max(off, 8))
@@ -185,7 +223,7 @@ class DeviceTable:
         where = {name: base + o for name, o, a in parts}
         st = fill_catalog_struct(cols, lambda name, a, dt: where[name], renderer.scene.seed, visit,
                                  optics_has_field=True, noise_var=noise_var, max_flux_simple=max_flux_simple,
-                                 sed_table=sed_table, sersic_index=sersic_index)
+                                 sed_table=sed_table, sersic_index=sersic_index, sizes_on_device=sizes_on_device)
         self.rows = torch.empty(max(n, 1) * OBJECT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
         self._meta_dev = torch.empty(max(n, 1) * META_DTYPE.itemsize, dtype=torch.uint8, device=dev)
         optics_ptr = renderer.bound.base_params.optics

@@ -8,7 +8,6 @@ import ctypes as C
 import math
 import os
 import dataclasses
-import itertools
 import threading
 import weakref
 from typing import List, Optional
@@ -837,8 +836,22 @@ def _device_streams(torch, device):
     return sets["sets"][k]
 
 
-_RENDERER_SERIAL = itertools.count()
 _STREAMS_LOCK = threading.Lock()
+EVENT_BLOCK = 128                                 # library event numbers of one renderer (a plan uses one per pool slice: a few dozen)
+_EVENT_BLOCKS = list(range(459, -1, -1))          # blocks below Renderer.PREPASS_EVENT (60 000)
+_EVENT_BLOCKS_LOCK = threading.Lock()
+
+
+def _take_event_block():
+    with _EVENT_BLOCKS_LOCK:
+        if not _EVENT_BLOCKS:
+            raise _abi.ImsimHipError("more than 460 renderers alive: no block of library event numbers left (drop renderers that are done)")
+        return _EVENT_BLOCKS.pop() * EVENT_BLOCK
+
+
+def _give_event_block(first):
+    with _EVENT_BLOCKS_LOCK:
+        _EVENT_BLOCKS.append(int(first) // EVENT_BLOCK)
 
 
 def _focal_streams(torch, device, peek=False, top_index=None):
@@ -980,6 +993,9 @@ class NativePlan:
         b = r.bound
         handle, sizes = C.c_void_p(), _abi.PlanSizes()
         _abi.check(lib.ims_plan_lsst_image(C.byref(inp), C.byref(handle), C.byref(sizes)), "ims_plan_lsst_image")
+        if sizes.n_events > EVENT_BLOCK:
+            lib.ims_plan_destroy(handle)
+            raise ValueError(f"a plan may use at most {EVENT_BLOCK} library events (its renderer's block); this one needs {sizes.n_events}")
         self.handle, self.sizes = handle, sizes
         self.arena_pin = _pinned_arena(t, max(int(sizes.arena_bytes), 256))
         self.arena_dev = t.empty(max(int(sizes.arena_bytes), 256), dtype=t.uint8, device=r.device)
@@ -1056,13 +1072,13 @@ class NativePlan:
 def run_joint_plans(plans, stream, first_chain=0, n_chains=1):
     """The rounds that run(defer=True) left: the chain classes first_chain .. first_chain + n_chains - 1 (0 = the top class: the
     brightest stars) of the given plans in lockstep on `stream`, three launches per round for all of them (ims_plans_run_joint;
-    at most 32 chains per call: longer lists go in several calls)."""
+    at most 64 chains per call: longer lists go in several calls)."""
     plans = [p for p in plans if p is not None and getattr(p, "deferred", 0)]
     if not plans:
         return
     lib = plans[0]._lib
     tuning.sync_library(lib)
-    per_call = max(1, 32 // max(int(n_chains), 1))
+    per_call = max(1, 64 // max(int(n_chains), 1))
     for a in range(0, len(plans), per_call):
         part = plans[a:a + per_call]
         arr = (C.c_void_p * len(part))(*[p.handle.value for p in part])
@@ -1106,8 +1122,9 @@ class Renderer:
             self.plan_streams = _device_streams(self.torch, self.device)              # index = Renderer.STREAMS
         self._plans_run = 0
         # the library's record / wait events are process-wide and addressed by number: every renderer numbers its own from a
-        # block of 1 000, so that the plans of several CCDs may be enqueued from different host threads at the same time
-        self._event_block = (next(_RENDERER_SERIAL) % 56) * 1000
+        # block of EVENT_BLOCK out of a free list (given back when the renderer is dropped), so that the plans of several CCDs may
+        # be enqueued from different host threads at the same time and two renderers that are alive never share a number
+        self._event_block = _take_event_block()
         self.s_chain, self.s_bulk, self.s_chain1, self.s_chain2, self.s_chain3 = self.plan_streams
         self.use_bf_tags = tuning.env("IMS_BF_TAGS", "0") != "0"
         # round-count thresholds that cut the bright objects into concurrent chains (plan_lsst_image)
@@ -1128,6 +1145,10 @@ class Renderer:
                 self.lease.release(list(set(self.plan_streams)) + [self.torch.cuda.current_stream(self.device)])
         except Exception:
             pass
+        block = getattr(self, "_event_block", None)
+        if block is not None:
+            self._event_block = None
+            _give_event_block(block)
 
     # -- helpers --
     def _stream(self):
@@ -1402,8 +1423,8 @@ class Renderer:
                                   # which rewrites every cell of every region every round, is the slower form (C3 41.7 ms)
                                   pair_shift=pair_shift if len(ch["tot"]) <= self.pair_max_objects else 0))
             plan.append(("rounds", descs, int(nrecalc), 1 if self.use_bf_tags else 0))
-            if n_events - self._event_block > 1000 or n_events >= self.PREPASS_EVENT:
-                raise ValueError("a plan may use at most 1000 library events (its renderer's block)")
+            if n_events - self._event_block > EVENT_BLOCK or n_events >= self.PREPASS_EVENT:
+                raise ValueError(f"a plan may use at most {EVENT_BLOCK} library events (its renderer's block)")
         if len(normal) and not render_done:
             part = objects[normal]
             part["bf_state"] = 0

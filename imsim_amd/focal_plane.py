@@ -95,10 +95,11 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
         usable = free + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)      # the allocator's cached blocks count
         if use_arena:
             from .engine import sensor_arena
-            # cells per CCD the pool is sized for: 1.5 x what the first CCD needs (the one with the longest chain when the caller
-            # gave a hint), at least a million, at most the scene's capacity; a CCD that needs more gets more while the pool
-            # lasts (lease by need), a pool that runs dry cuts the batch short (below)
-            per_cells = int(min(max(1.5 * private_need(work0, sc0), 1.0e6), max(int(ss0.scratch_cells), 1)))
+            # cells per CCD the pool is sized for: IMS_FOCAL_ARENA_FACTOR (0.8) x what the first CCD needs (the one with the longest
+            # chain when the caller gave a hint: more than the average CCD), at least a million, at most the scene's capacity; a
+            # CCD that needs more gets more while the pool lasts (lease by need), a pool that runs dry collects the oldest batch
+            # early or cuts the batch short (below)
+            per_cells = int(min(max(float(tuning.env("IMS_FOCAL_ARENA_FACTOR")) * private_need(work0, sc0), 1.0e6), max(int(ss0.scratch_cells), 1)))
             per_ccd = per_cells * (ss0.owned_points() * 16 + 75) + sc0.nx * sc0.ny * 12 + 1.0e9
             n_static = int(tuning.env("IMS_FOCAL_STATIC_REGIONS", "3"))
             static_bytes = n_static * ss0.total_cells() * (ss0.owned_points() * 16 + 75)
@@ -231,32 +232,90 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
             e["renderer"].release_state()          # everything of this CCD has run (its image is on the host): its cells go back
             e.clear()                              # drops the renderer: its HBM goes back to the caching allocator
 
-    # The pipeline, in host order: fronts of batch b | its middle and low chains (mid) | tails of batch b - 1 (mid) | its top chain
-    # (joint stream) | collect what has FINISHED.  The host does not wait for batch b - 1 here (its tails sit behind batch b's
-    # middle chains on `mid`, and a wait would hold back the fronts of batch b + 1 until those are through -- measured in round 5:
-    # the joint stream and the stream of the wide launches took turns, 100 ms each, instead of overlapping): a batch is only
-    # waited for when IMS_FOCAL_ALIVE (default 3) batches are alive -- one being enqueued, one in its rounds, one in its tails.
-    max_wait = alive - 2
-    prev = None
+    # The pipeline.  Per batch: the fronts of its CCDs (this thread, paced) | the joint runs of its chain classes -- the middle and
+    # low classes on `mid`, the top class on the joint stream: thousands of short launches, 5 .. 90 ms of host time per batch,
+    # enqueued by a SECOND host thread (the library's calls release the interpreter lock) while this thread goes on with the
+    # fronts of the next batch | its tails (join, sky, float image, copy to the host), enqueued once its rounds have RUN, so that
+    # `mid` never sits in a join behind a chain that is still running | collected when the copies are through.  Nothing here
+    # waits for the device except the pacing of the fronts and the bound on the batches alive (IMS_FOCAL_ALIVE, default 3:
+    # memory).  Measured in round 5 (profiles/round5_c5_*): with everything enqueued by one thread and a wait for batch b - 1
+    # before the fronts of batch b + 1, the joint stream and the stream of the wide launches took turns, ~100 ms each, and the
+    # host spent 156 of 600 ms (64 CCDs) enqueueing rounds while the front streams idled.
+    from concurrent.futures import ThreadPoolExecutor
+    threaded = tuning.flag("IMS_FOCAL_JOINT_THREAD")
+    worker = ThreadPoolExecutor(1) if threaded else None
+    rounds = []                         # batches whose joint runs are being / have been enqueued: dict(entries, future, ran)
     awaiting = []                       # batches whose tails are enqueued, oldest first
     pending = list(order)
 
-    def collect_finished(block_above):
-        while awaiting and (len(awaiting) > block_above or all(e["done"].query() for e in awaiting[0])):
+    def joint_runs(entries):
+        """both joint runs of a batch (worker thread); returns the events behind them"""
+        torch.cuda.set_device(dev)
+        left = [e["plan"] for e in entries if e["plan"] is not None and getattr(e["plan"], "deferred", 0)]
+        # the middle and low chain classes of the batch jointly on the stream that carried them one CCD at a time, the top class
+        # (the brightest stars) on the joint stream
+        run_joint_plans(left, mid, 1, 3)
+        ev_mid = torch.cuda.Event()
+        ev_mid.record(mid)
+        run_joint_plans(left, st_joint, 0, 1)
+        ev_top = torch.cuda.Event(enable_timing=trace is not None)
+        ev_top.record(st_joint)
+        if trace is not None:
+            for e in entries:
+                e["trace"]["joint_end"] = ev_top
+                e["trace"]["host_joint"] = time.perf_counter()
+        return len(left), (ev_mid, ev_top)
+
+    def start_rounds(entries):
+        if worker is not None:
+            rounds.append(dict(entries=entries, future=worker.submit(joint_runs, entries)))
+        else:
+            class _Done:
+                def __init__(self, v):
+                    self.v = v
+
+                def done(self):
+                    return True
+
+                def result(self):
+                    return self.v
+            rounds.append(dict(entries=entries, future=_Done(joint_runs(entries))))
+
+    def service(block_oldest=False, block_all=False):
+        """move batches along without waiting: tails for batches whose rounds have run, collection of batches whose copies are
+        through.  block_oldest: the oldest batch in its rounds gets its tails now whether its rounds have run or not (memory
+        bound: its cells are needed); block_all: every batch (end of the step)."""
+        first = True
+        while rounds:
+            b = rounds[0]
+            force = block_all or (block_oldest and first)
+            first = False
+            if not (force or b["future"].done()):
+                break
+            n_left, evs = b["future"].result()
+            if not force and not all(ev.query() for ev in evs):
+                break
+            n_joint[0] += n_left
+            tail(b["entries"])
+            awaiting.append(b["entries"])
+            rounds.pop(0)
+        while awaiting and all(e["done"].query() for e in awaiting[0]):
             collect(awaiting.pop(0))
+
+    def alive_batches():
+        return len(rounds) + len(awaiting)
 
     while pending:
         t0 = time.perf_counter()
         cur = []
         while pending and len(cur) < joint:
+            service()
             e = front(pending[0])
             if e is None:
-                # the arena's private pool is dry: first the cells of the batches before (their tails early), else this batch ends here
-                if prev is not None:
-                    tail(prev)
-                    awaiting.append(prev)
-                    prev = None
-                if awaiting:
+                # the arena's private pool is dry: wait for the cells of the oldest batch alive, else this batch ends here
+                if rounds or awaiting:
+                    if not awaiting:
+                        service(block_oldest=True)
                     collect(awaiting.pop(0))
                     continue
                 if cur:
@@ -264,28 +323,19 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
                 raise RuntimeError("focal plane: the sensor arena cannot hold the private regions of one CCD")
             pending.pop(0)
             cur.append(e)
-        left = [e["plan"] for e in cur if e["plan"] is not None and getattr(e["plan"], "deferred", 0)]
-        n_joint[0] += len(left)
-        # the middle and low chain classes of the batch jointly on the stream that carried them one CCD at a time -- ahead of the
-        # previous batch's tails, which wait for that batch's longest chain
-        run_joint_plans(left, mid, 1, 3)
-        if prev is not None:
-            tail(prev)
-            awaiting.append(prev)
-        run_joint_plans(left, st_joint, 0, 1)
-        if trace is not None:
-            jd = torch.cuda.Event(enable_timing=True)
-            jd.record(st_joint)
-            for e in cur:
-                e["trace"]["joint_end"] = jd
-                e["trace"]["host_joint"] = time.perf_counter()
+        start_rounds(cur)
         host_s[0] += time.perf_counter() - t0
-        collect_finished(max_wait)
-        prev = cur
-    if prev is not None:
-        tail(prev)
-        awaiting.append(prev)
-    collect_finished(-1)
+        # memory: at most `alive` batches (this one included) before the next one starts
+        while alive_batches() > alive - 1:
+            if not awaiting:
+                service(block_oldest=True)
+            else:
+                collect(awaiting.pop(0))
+    service(block_all=True)
+    while awaiting:
+        collect(awaiting.pop(0))
+    if worker is not None:
+        worker.shutdown(wait=True)
     if trace is not None:
         torch.cuda.synchronize()
         print("focal trace [ms since the start]: CCD, host enqueue begin / end, its work's end on bulk / pre / mid, its batch's joint rounds end, image on host")
@@ -344,7 +394,7 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
         heavy = bright > int(tuning.env("IMS_FOCAL_JOINT_MAX_BRIGHT", "600"))
         if not heavy and joint > 1 and tuning.env("IMS_NATIVE_PLAN", "1") != "0":
             torch.cuda.set_device(dev)
-            return _render_joint(mine, build, dev, nrecalc, sink, post, min(joint, 32), chain_hint)
+            return _render_joint(mine, build, dev, nrecalc, sink, post, min(joint, 64), chain_hint)
     # the anchor streams are kept per device for the life of the process: PyTorch's caching allocator files a freed block
     # under the stream it was allocated on, so fresh streams per call would miss the cache and hipMalloc every CCD's
     # gigabytes of sensor state again (measured: 13 -> 27 .. 34 ms per CCD for the calls that do)

@@ -60,8 +60,10 @@ KNOWN = {
     "IMS_FOCAL_JOINT_INIT": ("pre", "joint path: the stream a CCD's renderer is initialised on"),
     "IMS_FOCAL_ARENA": ("1", "joint path: pixel-boundary state leased from one arena per device (engine.SensorArena); 0 = per renderer"),
     "IMS_FOCAL_ARENA_CELLS": (None, "the arena's private pool in owner cells (tests: a pool that runs dry)"),
+    "IMS_FOCAL_ARENA_FACTOR": ("0.8", "private cells per CCD the arena's pool is sized for, as a multiple of the first CCD's need"),
     "IMS_FOCAL_STATIC_REGIONS": ("3", "static regions of the arena, taken in turn"),
     "IMS_FOCAL_ALIVE": ("3", "joint path: batches alive at a time (enqueueing / in its rounds / in its tails)"),
+    "IMS_FOCAL_JOINT_THREAD": ("1", "joint path: the rounds of a batch are enqueued by a second host thread while the first goes on with the next fronts"),
     "IMS_FOCAL_TRACE": ("0", "print, per CCD, when its work ended on every stream and when the host enqueued it"),
     "IMS_PROCESS_FOCAL": ("1", "config.Process with several CCDs on the overlapped focal-plane path"),
     "IMS_PROCESS_CONCURRENT": ("3", "... CCDs in flight"),

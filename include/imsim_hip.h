@@ -631,6 +631,19 @@ typedef struct ims_catalog {
     const double* gal_radius;     /* device [n_gal_radius]: radius enclosing 1 - folding_threshold of the flux, in half-light radii */
     double zenith[3];             /* unit vector of the zenith in the frame of img_wcs (ICRS at the visit) */
     int32_t has_field, pad;       /* != 0: atm_tan_x / atm_tan_y from icrf_to_field */
+    /* The surface-brightness loop of bright or oversized galaxies (get_good_phot_stamp_size, imsim/stamp_utils.py:196-220,
+     * :300-354) on the device when sb_tables != 0: the galaxy's own GoodImageSize grown by 10 % until the profile's xValue on
+     * the four edge midpoints and the four corners of the square is below keep_sb, capped at nmax, shrunk again while the next
+     * smaller square still is (not below 64), added in quadrature to the same size of the DoubleGaussian proxy PSF
+     * (psf_size_keep, an object-independent integer the host supplies), relaxed to 3 keep_sb (psf_size_keep3) when that exceeds
+     * nmax.  Rows then come back WITHOUT IMS_META_SIZE_PENDING.  sb_tables == 0: the kernel flags those rows and the host
+     * patches them (ims_patch_stamp_sizes). */
+    const double* sb_flux;        /* [n] flux of obj_achrom (the object at the effective wavelength), or NULL: nominal_flux */
+    const double* sersic_b;       /* [n_gal_radius] b_n of the Sersic index of radial table t */
+    const double* sersic_norm;    /* [n_gal_radius] I(0) hlr^2 / flux = b^(2n) / (2 pi n Gamma(2n)) */
+    const double* sersic_inv_n;   /* [n_gal_radius] 1 / n */
+    double keep_sb;               /* sqrt(noise_var) / 8 */
+    int32_t psf_size_keep, psf_size_keep3, sb_tables, pad2;
 } ims_catalog_t;
 typedef struct ims_object_meta {
     int64_t n_phot;
@@ -803,7 +816,7 @@ int  ims_plan_run(void* plan, ims_sensor_t* sensor_dev, ims_sensor_t* sensor_hos
  * it records where the plan's work ends on each of them, so that streams shared by role may go on with the next CCD -- and (b)
  * leaves the rounds of its chain classes out when they can run jointly: *deferred = the number of chains left (0: none -- no
  * bright object, several region groups, 8 vertices per edge: the plan ran whole).  ims_plans_run_joint runs the chains
- * first_chain .. first_chain + n_chains - 1 (0 = the top class) of the given plans -- at most 32 chains -- in lockstep on
+ * first_chain .. first_chain + n_chains - 1 (0 = the top class) of the given plans -- at most 64 chains -- in lockstep on
  * joint_stream: three launches per round for all of them (pixel search, updatePixelDistortions, bounds refresh: the kernels of
  * ims_accumulate_round / ims_sensor_update_distortions with the argument blocks of all chains in a device table) and marks the
  * end of every plan's last round; plans with nothing left in that range are skipped.  Every chain left must be run by some call.

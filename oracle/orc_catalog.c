@@ -31,6 +31,46 @@ static void stamp_bounds(ims_object_t* o, int size)
     o->stamp_ymin = (int)(icy - size / 2); o->stamp_ymax = (int)(icy - size / 2 + size - 1);
 }
 
+/* get_good_phot_stamp_size1 (imsim/stamp_utils.py:293-354) for a transformed Sersic profile: the square grown by 10 % until the
+ * profile's xValue on its edge midpoints and corners is below `keep`, capped at nmax, shrunk again while the next smaller one
+ * still is (not below 64) */
+static double sersic_edge_max(double h, const double* j, double det, double hlr, double amp, double b, double inv_n)
+{
+    const double px[4] = { h, 0.0, h, h }, py[4] = { 0.0, h, h, -h };        /* point symmetry: four of the eight points */
+    double best = 0.0;
+    for (int k = 0; k < 4; ++k) {
+        double u = (j[3] * px[k] - j[1] * py[k]) / det, v = (-j[2] * px[k] + j[0] * py[k]) / det;
+        double r = orc_sqrt(u * u + v * v) / hlr;
+        double val = amp * orc_exp(-b * orc_pow(r, inv_n));
+        if (val > best) best = val;
+    }
+    return best;
+}
+
+static long long phot_stamp_size1(int own, double keep, int nmax, double pixel_scale, const double* j, double hlr, double flux,
+                                  double norm, double b, double inv_n)
+{
+    double det = j[0] * j[3] - j[1] * j[2];
+    double amp = flux * norm / (hlr * hlr * fabs(det));
+    double N = (double)own;
+    int active = N < (double)nmax;
+    for (int it = 0; it < 200 && active; ++it) {
+        double mv = sersic_edge_max(N * 0.5 * pixel_scale, j, det, hlr, amp, b, inv_n);
+        if (mv < keep) break;
+        N = N * 1.1;
+        active = N < (double)nmax;
+    }
+    if (N > (double)nmax) N = (double)nmax;
+    active = N >= 64.0 * 1.1;
+    for (int it = 0; it < 200 && active; ++it) {
+        double mv = sersic_edge_max(N / (2.0 * 1.1) * pixel_scale, j, det, hlr, amp, b, inv_n);
+        if (mv > keep) break;
+        N = N / 1.1;
+        active = N >= 64.0 * 1.1;
+    }
+    return (long long)N;
+}
+
 int orc_build_object_table(const ims_catalog_t* C, const ims_optics_t* optics, ims_object_t* rows, ims_object_meta_t* meta)
 {
     const double pi = 3.14159265358979323846;
@@ -122,7 +162,24 @@ int orc_build_object_table(const ims_catalog_t* C, const ims_optics_t* optics, i
                 double rr = C->gal_radius[t] * C->hlr[i] * smax;
                 double stepk = 1.0 / orc_sqrt(rr * rr / (pi * pi) + 1.0 / (C->dg_stepk * C->dg_stepk));
                 size = good_image_size(stepk, C->pixel_scale);
-                if (nominal > 10.0 * (double)size * (double)size || size > C->nmax) m.flags |= IMS_META_SIZE_PENDING;
+                if (nominal > 10.0 * (double)size * (double)size || size > C->nmax) {
+                    if (C->sb_tables) {
+                        const double jj[4] = { j0, j1, j2, j3 };
+                        int own = good_image_size(pi / rr, C->pixel_scale);
+                        double flux = C->sb_flux ? C->sb_flux[i] : nominal;
+                        long long g1 = phot_stamp_size1(own, C->keep_sb, C->nmax, C->pixel_scale, jj, C->hlr[i], flux, C->sersic_norm[t],
+                                                        C->sersic_b[t], C->sersic_inv_n[t]);
+                        long long sz = (long long)orc_sqrt((double)g1 * (double)g1 + (double)C->psf_size_keep * (double)C->psf_size_keep);
+                        if (sz > C->nmax) {
+                            long long g3 = phot_stamp_size1(own, 3.0 * C->keep_sb, C->nmax, C->pixel_scale, jj, C->hlr[i], flux,
+                                                            C->sersic_norm[t], C->sersic_b[t], C->sersic_inv_n[t]);
+                            sz = (long long)orc_sqrt((double)g3 * (double)g3 + (double)C->psf_size_keep3 * (double)C->psf_size_keep3);
+                        }
+                        size = (int)(sz > C->nmax ? C->nmax : sz);
+                    } else {
+                        m.flags |= IMS_META_SIZE_PENDING;
+                    }
+                }
                 if (size > C->nmax) size = C->nmax;
             }
         }

@@ -38,19 +38,25 @@ def test_oracle_table_matches_the_numpy_builder(lens):
         assert np.array_equal(r[f], ref[f]), f
     for f, tol in (("jac", 1e-14), ("dcr_tanz", 1e-13), ("dcr_sinp", 1e-13), ("dcr_cosp", 1e-13), ("winv", 5e-9)):
         assert np.abs(r[f] - ref[f]).max() <= tol * max(np.abs(ref[f]).max(), 1.0), f
+    # every stamp size, the surface-brightness loop of the bright / oversized galaxies included (get_good_phot_stamp_size,
+    # imsim/stamp_utils.py:196-220, :300-354, restated in the table builder): the numpy builder's integers
     pend = (m["flags"] & _abi.IMS_META_SIZE_PENDING) != 0
-    assert 0 < pend.sum() < 0.05 * len(r)                      # the bright few are left to the host's surface-brightness loop
-    assert np.array_equal(m["size"][~pend], sizes[~pend])
+    assert pend.sum() == 0
+    assert np.array_equal(m["size"], sizes)
     for f in ("stamp_xmin", "stamp_xmax", "stamp_ymin", "stamp_ymax"):
-        assert np.array_equal(r[f][~pend], ref[f][~pend]), f
+        assert np.array_equal(r[f], ref[f]), f
     # the field angle of the atmospheric PSF
     thx, thy = configs.field_angles(scene, cat["x"][keep], cat["y"][keep])
     assert np.abs(r["atm_tan_x"] - thx).max() < 1e-12 and np.abs(r["atm_tan_y"] - thy).max() < 1e-12
-    # and the host fix-ups close the gap
+    # without the tables of that loop the builder flags the bright few and the host's loop closes the gap (the checker's form)
     from imsim_amd import device_table
-    idx, sz, host = device_table.host_fixups(cat, meta, {})
+    rows2, meta2 = orc_loader.build_object_table(scene, cat, VISIT, phot, sizes_on_device=False)
+    pend2 = (meta2["flags"] & _abi.IMS_META_SIZE_PENDING) != 0
+    assert 0 < pend2[keep].sum() < 0.05 * len(r)
+    assert (m["size"][pend2[keep]] != meta2["size"][keep][pend2[keep]]).any()        # the loop did change sizes
+    idx, sz, host = device_table.host_fixups(cat, meta2, {})
     assert len(host) == 0
-    full = meta["size"].copy()
+    full = meta2["size"].copy()
     full[idx] = sz
     assert np.array_equal(full[keep], sizes)
 
@@ -77,15 +83,15 @@ def test_device_table_is_bit_identical_to_the_oracle(given):
     t = DeviceTable(r, cat, VISIT, phot_flux=phot if given else None)
     torch.cuda.synchronize()
     rows, meta = orc_loader.build_object_table(scene, cat, VISIT, phot if given else None)
-    from imsim_amd import device_table
-    idx, sz, _ = device_table.host_fixups(cat, meta, {})
-    want = rows.copy()
-    icx, icy = np.floor(cat["x"][idx] + 0.5).astype(np.int64), np.floor(cat["y"][idx] + 0.5).astype(np.int64)
-    want["stamp_xmin"][idx], want["stamp_xmax"][idx] = icx - sz // 2, icx - sz // 2 + sz - 1
-    want["stamp_ymin"][idx], want["stamp_ymax"][idx] = icy - sz // 2, icy - sz // 2 + sz - 1
+    assert not (meta["flags"] & _abi.IMS_META_SIZE_PENDING).any() and not (t.meta["flags"] & _abi.IMS_META_SIZE_PENDING).any()
     got = t.rows_numpy()
-    assert got.tobytes() == want.tobytes()
+    assert got.tobytes() == rows.tobytes()                     # the kernel's surface-brightness loop included: ONE pass
     assert np.array_equal(t.n_phot, rows["n_phot"])
+    # the form with the host's loop (the checker): same table
+    from imsim_amd import device_table
+    t_host = DeviceTable(r, cat, VISIT, phot_flux=phot if given else None, sizes_on_device=False)
+    torch.cuda.synchronize()
+    assert t_host.rows_numpy().tobytes() == got.tobytes()
 
 
 def _edge_catalog():
@@ -124,13 +130,16 @@ def test_oracle_table_on_the_edges_matches_the_numpy_builder():
     r = rows[keep]
     for f in ("obj_id", "n_phot", "prof_table", "sed_table", "flags", "x0", "y0", "prof_scale", "flux_per_photon"):
         assert np.array_equal(r[f], ref[f]), f
+    assert not (meta["flags"] & _abi.IMS_META_SIZE_PENDING).any()
+    assert np.array_equal(meta["size"][keep], sizes)               # 1e9-photon galaxy, flattest ellipse, largest half-light radius ...
+    assert sizes.max() == catalog.NMAX and (sizes == 32).any()
     from imsim_amd import device_table
-    idx, sz, host = device_table.host_fixups(cat, meta, {})
-    assert len(host) == 0
-    full = meta["size"].copy()
+    rows2, meta2 = orc_loader.build_object_table(scene, cat, VISIT, phot, sizes_on_device=False)
+    idx, sz, host = device_table.host_fixups(cat, meta2, {})
+    assert len(host) == 0 and len(idx) > 0
+    full = meta2["size"].copy()
     full[idx] = sz
     assert np.array_equal(full[keep], sizes)
-    assert sizes.max() == catalog.NMAX and (sizes == 32).any()
 
 
 @pytest.mark.gpu
@@ -146,13 +155,11 @@ def test_device_table_on_the_edges_is_bit_identical_to_the_oracle(given):
     t = DeviceTable(r, cat, VISIT, phot_flux=phot)
     torch.cuda.synchronize()
     rows, meta = orc_loader.build_object_table(scene, cat, VISIT, phot)
-    idx, sz, _ = device_table.host_fixups(cat, meta, {})
-    want = rows.copy()
-    icx, icy = np.floor(cat["x"][idx] + 0.5).astype(np.int64), np.floor(cat["y"][idx] + 0.5).astype(np.int64)
-    want["stamp_xmin"][idx], want["stamp_xmax"][idx] = icx - sz // 2, icx - sz // 2 + sz - 1
-    want["stamp_ymin"][idx], want["stamp_ymax"][idx] = icy - sz // 2, icy - sz // 2 + sz - 1
-    assert t.rows_numpy().tobytes() == want.tobytes()
+    assert t.rows_numpy().tobytes() == rows.tobytes()
     assert np.array_equal(t.n_phot, rows["n_phot"])
+    t_host = DeviceTable(r, cat, VISIT, phot_flux=phot, sizes_on_device=False)
+    torch.cuda.synchronize()
+    assert t_host.rows_numpy().tobytes() == rows.tobytes()
     # and the table renders: LSST_Image from the device table == the oracle on its rows (the three sources above 1e7 photons
     # dimmed to 2e5 for this part: the oracle is one CPU core)
     dim = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in cat.items()}

@@ -114,6 +114,28 @@ def test_apply_diffraction_psf_matches_reference():
     assert abs(out.sum() / img.sum() - 1) < 0.05      # flux is moved into the spikes, not created
 
 
+@pytest.mark.parametrize("rot", [0.0, 0.3, 0.698, math.pi / 4, 1.3, math.pi / 2, 2.1, 3.0])
+@pytest.mark.parametrize("d_alpha", [2.2e-3, -2.2e-3, 0.04, -0.04, 0.0])
+def test_stencil_early_exit_returns_exactly_the_zeros_of_the_unshortcut_stencil(rot, d_alpha):
+    """The spike stencil of the oracle (and, in the same words, of the kernel: csrc/ims_fft.h) returns before its arctangents
+    for offsets it knows to be exact zeros -- further than a pixel from both arms and outside the wedge the field rotation
+    sweeps.  Checked here against the numpy stencil that has no such shortcut (imsim_amd.diffraction_fft.stencil, itself
+    pinned by vectors generated from the reference's prepare_psf_field_rotation): over the whole (2 w + 1)^2 grid, for arms
+    along the axes, the diagonals and in between, and both signs of the swept angle, the two have the SAME set of zeros and
+    agree to rounding elsewhere."""
+    w = 150
+    alpha = math.pi / 4.0 - rot
+    k = dfft.SpikeConstants(math.cos(alpha - d_alpha / 2.0), math.sin(alpha - d_alpha / 2.0), alpha - d_alpha, d_alpha, 1.1, w)
+    rng = np.arange(-w, w + 1)
+    want = dfft.stencil(rng[:, None], rng[None, :], k)
+    S = _abi.Spikes(1, w, 1e5, k.cos0, k.sin0, k.a_lo, k.d_alpha, k.scale, dfft.SPIKE_R0, 1.0)
+    got = np.empty((2 * w + 1, 2 * w + 1))
+    orc_loader.load().orc_test_stencil(C.byref(S), w, got.ctypes.data)
+    assert np.array_equal(got == 0.0, want == 0.0), "the early exit and the full expression disagree on which offsets are zero"
+    assert np.count_nonzero(want) > 4 * w and np.count_nonzero(want == 0.0) > 0.5 * want.size
+    np.testing.assert_allclose(got, want, rtol=0, atol=4e-16 * want.max())
+
+
 @pytest.mark.parametrize("rot,box", [(0.698, 9), (0.0, 13), (math.pi / 4, 5), (math.pi / 2, 11), (2.1, 17)])
 def test_spike_convolution_visits_exactly_the_nonzero_terms(rot, box):
     """The box (x) stencil sum of apply_diffraction_psf (imsim/diffraction_fft.py:176-208) as the oracle forms it -- whole

@@ -5,8 +5,13 @@ so a wrong table order, slot layout or constant there would be common to both si
 the Silicon sensor block of the reference's sensor-model case (tests/test_sensor_models.py:42-59, plus tree rings) is
 assembled from the model files by code written for this test alone -- its own .cfg / .dat reader, its own vertex
 placement and vertex -> table order, its own diffusion step, its own memory layout of the boundary state -- and the oracle
-must render the same image and end with the same pixel-boundary state as through BoundScene.  Only the ctypes layouts of
-the structs are shared (tests/test_abi.py pins those to include/imsim_hip.h)."""
+must render the same image and end with the same pixel-boundary state as through BoundScene.  The second half does the same
+for the rest of a C3 / C3b scene: the optics block (surfaces, media, stop, rotator, focal plane -> pixel, slope jacobian,
+spider, field-rotation vectors), the six operator descriptors, the PSF components, the sampling tables with their guide table
+and the atmosphere block -- written from the header's field descriptions and the reference's formulas
+(imsim/photon_ops.py:397-451, :486-503, imsim/diffraction.py:32-42, :280-304), compared field by field with what the
+product's host code filled and through the oracle's image.  (The two TAN-SIP blocks are fitted numbers and are copied.)  Only
+the ctypes layouts of the structs are shared (tests/test_abi.py pins those to include/imsim_hip.h)."""
 import ctypes as C
 import math
 import os
@@ -141,3 +146,220 @@ def test_oracle_with_independently_filled_sensor_block(model_name):
     assert np.array_equal(bounds, ref.sensor_array("bounds")[:len(bounds)]), "bounds lines"
     # and the charge did move the boundaries of the private slot (the comparison is not vacuous)
     assert not np.array_equal(boundary[:cells_per_slot * npo * 2], boundary[cells_per_slot * npo * 2:])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The rest of the scene: optics block, operator descriptors, PSF components, sampling tables, atmosphere
+# ---------------------------------------------------------------------------------------------------------------------------
+def _telescope_description():
+    """The stand-in prescription as plain numbers (what a prescription FILE would hold): taken from the product's Telescope
+    object attribute by attribute -- the only thing this test shares with imsim_amd.optics is the data, not how it is laid out
+    in ims_optics_t."""
+    import dataclasses
+    from imsim_amd import optics as opticsmod
+    tel = opticsmod.rubin_like_telescope("r")
+    return dict(stop_z=tel.stop_z, in_medium=tel.in_medium,
+                surfaces=[dataclasses.asdict(s) for s in tel.surfaces])
+
+
+def _fill_optics_independently(tel, visit, nx, ny, wcs_pair):
+    """ims_optics_t written field by field from include/imsim_hip.h's description of it (not through optics.fill_optics /
+    diffraction.fill_optics / configs.rubin_optics_struct).  The two TAN-SIP blocks are FITTED numbers (ray-traced by the
+    product, there is nothing to restate them from): they are copied as 2 x 544 opaque bytes."""
+    o = _abi.Optics()
+    C.memmove(C.addressof(o.img_wcs), C.addressof(wcs_pair[0]), C.sizeof(_abi.TanSip))
+    C.memmove(C.addressof(o.icrf_to_field), C.addressof(wcs_pair[1]), C.sizeof(_abi.TanSip))
+
+    def medium(block_kind_setter, coeffs_dst, med):
+        kind, c = med
+        vals = [float(v) for v in c]
+        if kind == _abi.IMS_MEDIUM_CONST:
+            vals[1] = 1.0 / vals[0]                      # a constant medium carries n and 1 / n
+        for k in range(6):
+            coeffs_dst[k] = vals[k]
+        return kind
+    o.in_medium_kind = medium(None, o.in_medium_c, tel["in_medium"])
+    o.n_surfaces = len(tel["surfaces"])
+    o.stop_z = tel["stop_z"]
+    seen = []
+    for k, S in enumerate(tel["surfaces"]):
+        s = o.surf[k]
+        s.kind, s.obsc_kind = S["kind"], S["obsc_kind"]
+        s.z0, s.R, s.conic = S["z0"], S["R"], S["conic"]
+        s.inv_R = 0.0 if S["R"] == 0.0 else 1.0 / S["R"]          # a plane has curvature zero
+        s.n_asphere = len(S["asph"])
+        for m, a in enumerate(S["asph"]):
+            s.asph[m] = a
+        s.obsc_inner, s.obsc_outer = S["obsc_inner"], S["obsc_outer"]
+        s.medium_kind = medium(None, s.medium_c, S["medium"])
+        key = (S["medium"][0], tuple(float(v) for v in S["medium"][1]))
+        if key not in seen:
+            seen.append(key)
+        s.medium_id = seen.index(key)                             # media numbered in order of first appearance
+    # camera rotator and focal plane -> pixel (imsim/utils.py:42-59: pixel = M (fp [mm]) + centre; this detector: 100 px / mm,
+    # centre of an nx x ny image in 1-based pixel coordinates at ((n - 1) / 2 + 1) - 0.5)
+    rot = math.radians(visit["rottelpos"])
+    o.cam_rot[0], o.cam_rot[1] = math.cos(rot), math.sin(rot)
+    m = [100.0, 0.0, (nx - 1) / 2.0 + 0.5, 0.0, 100.0, (ny - 1) / 2.0 + 0.5]
+    for k in range(6):
+        o.fp_to_pix[k] = m[k]
+    # slopes (imsim/photon_ops.py:497-501): jac = M @ jac_focal_to_pixel with M = [[0, 1e3], [1e3, 0]] (x <-> y swap, m -> mm),
+    # divided by sqrt |det|; (dxdz, dydz) = jac @ (vx, vy) / vz -- stored row by row
+    J = np.array([[0.0, 1.0e3], [1.0e3, 0.0]]) @ np.array([[m[0], m[1]], [m[3], m[4]]])
+    J = J / math.sqrt(abs(J[0, 0] * J[1, 1] - J[0, 1] * J[1, 0]))
+    o.slope_jac[0], o.slope_jac[1], o.slope_jac[2], o.slope_jac[3] = J[0, 0], J[0, 1], J[1, 0], J[1, 1]
+    # spider: imSim's RUBIN_SPIDER_GEOMETRY (imsim/diffraction.py:32-42) -- four thick struts (nx, ny, d, half width), two rims
+    r = 1.0 / math.sqrt(2.0)
+    lines = [(r, r, -0.4, 0.025), (-r, r, -0.4, 0.025), (r, r, 0.4, 0.025), (-r, r, 0.4, 0.025)]
+    circles = [(0.0, 0.0, 2.558), (0.0, 0.0, 4.18)]
+    o.n_lines, o.n_circles = len(lines), len(circles)
+    for k, row in enumerate(lines):
+        for j in range(4):
+            o.lines[k][j] = row[j]
+    for k, row in enumerate(circles):
+        for j in range(3):
+            o.circles[k][j] = row[j]
+    # field rotation (imsim/diffraction.py:284-384): zenith at t = 0 and the pointing, equatorial frame with x towards the
+    # observer's meridian and z along the Earth's axis; pointing from (altitude, azimuth from north through east)
+    lat, alt, az = (math.radians(visit[k]) for k in ("latitude", "altitude", "azimuth"))
+    zen = np.array([math.cos(lat), 0.0, math.sin(lat)])
+    east, north = np.array([0.0, 1.0, 0.0]), np.array([-math.sin(lat), 0.0, math.cos(lat)])
+    ef = math.cos(alt) * math.sin(az) * east + math.cos(alt) * math.cos(az) * north + math.sin(alt) * zen
+    for j in range(3):
+        o.e_z0[j], o.e_focal[j] = zen[j], ef[j]
+    o.cos_lat, o.sin_lat = math.cos(lat), math.sin(lat)
+    o.omega = 7.292115826090781e-05                               # OMEGA_EARTH, the reference's constant (imsim/diffraction.py:280)
+    return o
+
+
+_DERIVED_SURFACE_FIELDS = ("k1", "k1c", "m2R", "cc", "obsc_i2", "obsc_o2", "asph_d")      # ims_fill_derived_optics writes these
+
+
+def _struct_fields_equal(a, b, skip=()):
+    for name, _ in a._fields_:
+        if name in skip or name.startswith("pad"):
+            continue
+        va, vb = getattr(a, name), getattr(b, name)
+        if hasattr(va, "_fields_"):
+            assert bytes(va) == bytes(vb), name
+        elif hasattr(va, "__len__"):
+            assert bytes(va) == bytes(vb), name
+        else:
+            assert va == vb, (name, va, vb)
+
+
+@pytest.mark.parametrize("with_screens", [False, True])
+def test_oracle_with_independently_filled_optics_ops_psf_and_atmosphere(with_screens):
+    """The optics block (surfaces, media, stop, rotator, focal plane -> pixel, slope jacobian, spider, field-rotation vectors),
+    the six operator descriptors of imSim's default chain (config/imsim-config.yaml:281-320), the PSF components, the sampling
+    tables with their guide table, and (second case) the atmosphere block of the 6-screen AtmosphericPSF, all written here
+    from the header's description -- the struct the product's host code fills must hold the same values field by field, and
+    the oracle must render the same image from either."""
+    from imsim_amd import configs, catalog, tables
+    n = 160
+    visit = dict(configs.VISIT)
+    # (a) the product's host code
+    if with_screens:
+        sc = configs.scene_c3b(nx=n, ny=n, sensor=False, screen_size=25.6, screen_scale=0.1)
+    else:
+        sc = configs.scene_c3(nx=n, ny=n, sensor=False)
+    cat = catalog.synthetic_catalog(40, nx=n, ny=n)
+    phot = catalog.realize_fluxes(cat["nominal_flux"], 3)
+    objects, _ = (configs.c3b_objects if with_screens else configs.c3_objects)(cat, phot, sc)
+    ref = orc_loader.OracleScene(sc)
+    ref.render(objects)
+    assert ref.image64.sum() > 1000
+
+    # (b) assembled here
+    lib = orc_loader.load()
+    keep = []
+
+    def ptr(a, dt=np.float64):
+        a = np.ascontiguousarray(a, dtype=dt)
+        keep.append(a)
+        return a.ctypes.data
+
+    tel = _telescope_description()
+    o = _fill_optics_independently(tel, visit, n, n, (sc.optics.img_wcs, sc.optics.icrf_to_field))
+    # field by field against what the product put into ITS struct (before the library's derived constants)
+    _struct_fields_equal(o, sc.optics, skip=("surf", "rot_g", "rot_gnorm"))
+    for k in range(o.n_surfaces):
+        _struct_fields_equal(o.surf[k], sc.optics.surf[k], skip=_DERIVED_SURFACE_FIELDS)
+    for k in range(o.n_surfaces):                                   # the oracle's own media constants (air: pressure / temperature factors)
+        lib.orc_fill_derived_medium(int(o.surf[k].medium_kind), o.surf[k].medium_c)
+    lib.orc_fill_derived_medium(int(o.in_medium_kind), o.in_medium_c)
+
+    P = _abi.RenderParams()
+    P.seed, P.seg_size = sc.seed, 256
+    # operators, in the order of the YAML list; parameters as the header lists them
+    wl_eff = tables.effective_wavelength(*tables.synthetic_r_band())
+    rad2as = 180.0 / math.pi * 3600.0
+    ops = [(_abi.IMS_OP_TIME_SAMPLER, [0.0, visit["exptime"]]),                       # t0, exptime
+           (_abi.IMS_OP_PUPIL_ANNULUS_SAMPLER, [4.18, 2.55]),                         # R_outer, R_inner
+           (_abi.IMS_OP_PHOTON_DCR, [wl_eff, 69.328, 293.15, 1.067, rad2as]),         # base wavelength, pressure, temperature, H2O, scale
+           (_abi.IMS_OP_RUBIN_DIFFRACTION_OPTICS, [1.0, 0.0]),                        # shift_photons, disable_field_rotation
+           (_abi.IMS_OP_FOCUS_DEPTH, [0.0]),                                          # depth (r band: 0)
+           (_abi.IMS_OP_REFRACTION, [3.9])]                                           # index ratio of silicon
+    P.n_ops = len(ops)
+    for k, (kind, p) in enumerate(ops):
+        P.ops[k].kind, P.ops[k].table = kind, 0
+        for j, v in enumerate(p):
+            P.ops[k].p[j] = v
+        lib.orc_fill_derived_op(C.byref(P.ops[k]))
+        assert P.ops[k].kind == ref.bound.base_params.ops[k].kind
+        assert bytes(P.ops[k].p) == bytes(ref.bound.base_params.ops[k].p), f"operator {k}"
+    # sampling tables: Sersic n = 1, n = 4, Kolmogorov (+ the second kick), each [513] r^2 and cdf, and the 512-entry guide
+    # (last knot with cdf <= g / 512)
+    tabs = [tables.sersic_table(1.0), tables.sersic_table(4.0), tables.kolmogorov_table()]
+    if with_screens:
+        tabs.append(sc.atm.second_kick)
+    r2 = np.stack([t[0] for t in tabs])
+    cdf = np.stack([t[1] for t in tabs])
+    guide = np.zeros((len(tabs), 513), dtype=np.int32)
+    for t in range(len(tabs)):
+        for g in range(513):
+            j = int(np.searchsorted(cdf[t], g / 512.0, side="right")) - 1
+            guide[t, g] = min(max(j, 0), cdf.shape[1] - 2)
+    P.radial.n_tables, P.radial.n_bins, P.radial.n_guide = len(tabs), r2.shape[1] - 1, 512
+    P.radial.r2, P.radial.cdf, P.radial.guide = ptr(r2), ptr(cdf), ptr(guide, np.int32)
+    sed = tables.inverse_cdf_table(*tables.synthetic_r_band())
+    P.sed.n_tables, P.sed.n_pts, P.sed.arg_min, P.sed.arg_step = 1, len(sed), 0.0, 1.0 / (len(sed) - 1)
+    P.sed.val = ptr(sed)
+    # PSF
+    fwhm_atm, fwhm_sys = catalog.kolmogorov_gaussian_fwhm(visit["airmass"], visit["raw_seeing"], visit["band"])
+    if with_screens:
+        atm = sc.atm
+        A = _abi.Atmosphere()
+        A.n_layers, A.npix, A.scale = len(atm.altitudes), atm.npix, atm.screen_scale
+        A.x0 = -0.5 * atm.npix * atm.screen_scale                   # the screen is centred on the pupil
+        A.t0, A.exptime = atm.t0, atm.exptime
+        A.aper_r_outer, A.aper_r_inner = atm.diam / 2.0, atm.diam * atm.obscuration / 2.0
+        for l in range(A.n_layers):
+            A.vx[l] = atm.speeds[l] * math.cos(atm.directions[l])   # wind [m / s] along x, y
+            A.vy[l] = atm.speeds[l] * math.sin(atm.directions[l])
+            A.alt[l] = atm.altitudes[l] * 1000.0                    # km -> m
+        scr = atm.screens if isinstance(atm.screens, np.ndarray) else atm.screens.cpu().numpy()
+        A.screens = ptr(scr, np.float32)
+        keep.append(A)
+        P.atm = C.addressof(A)
+        _struct_fields_equal(A, ref.bound.atm_struct, skip=("screens", "screen_quads", "dn", "inv_n", "inv_scale", "aper_ri2", "aper_dr2"))
+        arcsec = math.pi / 180.0 / 3600.0
+        comps = [(_abi.IMS_PSF_SCREENS, 0, 1.0e-9 / arcsec, atm.exponent, atm.wlen_eff),     # nm / m of gradient -> arcsec
+                 (_abi.IMS_PSF_RADIAL, 3, 1.0, 0.0, 1.0),                                    # second kick: table in arcsec
+                 (_abi.IMS_PSF_GAUSSIAN, 0, 0.3 / 2.3548200450309493, 0.0, 1.0)]
+    else:
+        comps = [(_abi.IMS_PSF_RADIAL, 2, fwhm_atm, 0.0, 1.0),                               # Kolmogorov table in units of its FWHM
+                 (_abi.IMS_PSF_GAUSSIAN, 0, fwhm_sys / 2.3548200450309493, 0.0, 1.0)]
+    P.n_psf = len(comps)
+    for k, c in enumerate(comps):
+        P.psf[k] = _abi.PsfComponent(*c)
+        for name in ("kind", "table", "p0", "chrom_alpha", "chrom_base"):
+            assert getattr(P.psf[k], name) == getattr(ref.bound.base_params.psf[k], name), (k, name)
+    keep.append(o)
+    P.optics = C.addressof(o)
+    image = np.zeros((n, n))
+    prefix = np.concatenate([[0], np.cumsum((objects["n_phot"] + 255) // 256)]).astype(np.int64)
+    P.objects, P.n_objects, P.seg_prefix, P.n_segments = objects.ctypes.data, len(objects), prefix.ctypes.data, int(prefix[-1])
+    P.image, P.nx, P.ny, P.xmin, P.ymin = image.ctypes.data, n, n, 1, 1
+    assert lib.orc_render_objects(C.byref(P), 10000, image.ctypes.data, None) == 0
+    assert np.array_equal(image, ref.image64), "image: independent fill of optics / operators / PSF / tables vs BoundScene"

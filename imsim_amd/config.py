@@ -738,6 +738,8 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
     if overlapped:
         from . import focal_plane
         ctxs = {}
+        if stamp_cfg.get("draw_method", "auto") != "phot":
+            focal_plane.warm_fft(device)          # hipFFT's start-up (seconds in a fresh process) beside the first CCD's host work
 
         def build(det):
             ctxs[det] = prepare(det)

@@ -685,6 +685,9 @@ def _c5_step(renderer, objects, rank=0, world=1, concurrent=None):
     # four top-chain streams, four CCDs in flight: with the bright tail a CCD is bound by the rounds of its brightest star
     # (hundreds of dependent rounds of ~50 us), so more chains side by side pay (tools/dbg/r4_c5_sweep.sh: 25.1 -> 22.5 ms per CCD)
     tuning.setdefault("IMS_FOCAL_TOPS", "4")
+    # the hipFFT plans of the FFT-drawn objects are made in the background while the jobs of the CCDs are built below (a fresh
+    # process's first plan costs seconds: focal_plane.warm_fft)
+    launch_warm = focal_plane.warm_fft(str(renderer.device))
     if concurrent is None:
         concurrent = int(tuning.env("IMS_FOCAL_CONCURRENT", "4"))
     base = renderer.scene
@@ -712,6 +715,8 @@ def _c5_step(renderer, objects, rank=0, world=1, concurrent=None):
     want_hashes = bool(tuning.env("IMS_BENCH_DUMP"))      # bench.py's test hook: the CRC of every CCD's float32 image
 
     def launch():
+        if launch_warm is not None:
+            launch_warm.join()
         launch.checksums = {}
         launch.hashes = {}
         focal_plane.render_focal_plane(list(range(len(offs) - 1)), build, device=str(renderer.device), rank=rank, world=world,

@@ -249,8 +249,12 @@ static int build(Plan& pl)
             const int ca = bounds[c], cb = bounds[c + 1];
             const int rounds = (int)n_rounds[ca];
             ch.n_rounds = rounds; ch.first_slot = n0 + ca; ch.stream = CHAIN_ROLE[c];
+            // slices of rounds: fine at the start, so that a chain that runs beside its own shoots starts at once and never waits
+            // long; with coarse_slices (a focal plane's deferred plans: the rounds start only when the whole batch is enqueued)
+            // round 0 and then everything else -- two launches per class instead of up to six, each wide enough to fill the device
             std::vector<int32_t> edges = { 0 };
-            for (int e : { 1, 3, 8, 20, 60 }) if (e < rounds) edges.push_back(e);
+            if (in.coarse_slices) { if (1 < rounds) edges.push_back(1); }
+            else for (int e : { 1, 3, 8, 20, 60 }) if (e < rounds) edges.push_back(e);
             edges.push_back(rounds);
             ch.ev_base = n_events;
             n_events += (int)edges.size() - 1;

@@ -545,21 +545,32 @@ struct JointAcc {                           // per chain, constant over the roun
     const int64_t* pool_start[IMS_JOINT_MAX];
 };
 
-__device__ __forceinline__ int joint_chain(const JointEnds& e, int& b)
+// The tables of ONE round of a joint run -- workgroup ends of the pixel search (ea), tile ends (eu), regions that go on (ns),
+// workgroup ends of the list builder (ewg), tiles per chain (tof) -- live in DEVICE memory, all rounds of the run uploaded at
+// once (ims_plans_run_joint), and a launch takes a pointer to its round's block.  (By value they were 128 .. 768 bytes of
+// kernel arguments per launch, four launches per round, thousands of rounds per batch: HIP's kernel-argument pool ran out and
+// the host enqueued at the device's pace -- 25 us of gap in front of every launch of a chain, round 5.)  Read through the
+// constant address space: uniform addresses, scalar loads.
+struct JointRound { JointEnds ea, eu, ns, ewg, tof; };
+typedef const JointEnds __attribute__((address_space(4))) * ConstEnds;
+
+__device__ __forceinline__ int joint_chain(const JointEnds* e_global, int& b)
 {
+    ConstEnds e = (ConstEnds)(uintptr_t)e_global;
     int c = 0;
 #pragma unroll
-    for (int k = 0; k < IMS_JOINT_MAX - 1; ++k) c += (b >= e.v[k]) ? 1 : 0;
-    if (c > 0) b -= e.v[c - 1];
+    for (int k = 0; k < IMS_JOINT_MAX - 1; ++k) c += (b >= e->v[k]) ? 1 : 0;
+    if (c > 0) b -= e->v[c - 1];
     return c;
 }
+__device__ __forceinline__ int joint_entry(const JointEnds* e_global, int c) { return ((ConstEnds)(uintptr_t)e_global)->v[c]; }
 
 template <int NV, int WG = 256>
-__global__ __launch_bounds__(WG, (NV == 8) ? 2 : 4) void k_accumulate_round_j(const JointAcc* __restrict__ J, const JointEnds ends,
+__global__ __launch_bounds__(WG, (NV == 8) ? 2 : 4) void k_accumulate_round_j(const JointAcc* __restrict__ J, const JointRound* __restrict__ R,
                                                                               uint32_t tag, int64_t round_first, int32_t nrecalc, int32_t segs)
 {
     int b = (int)blockIdx.x;
-    const int c = joint_chain(ends, b);
+    const int c = joint_chain(&R->ea, b);
     // the table through the CONSTANT address space: its loads at uniform addresses are scalar loads whatever the kernel stores
     // (through a plain pointer the twelve fields sit in vector registers for the whole body: 128 + spills instead of 92)
     typedef const JointAcc __attribute__((address_space(4))) * ConstAcc;
@@ -1256,13 +1267,13 @@ __device__ __forceinline__ void update_block_q3(const ims_sensor_t* __restrict__
 }
 
 template <int NV, bool DPP = false>
-__global__ __launch_bounds__(256) void k_update_distortions_q3_j(const JointUpd* __restrict__ U, const JointEnds ends, const JointEnds n_slots,
+__global__ __launch_bounds__(256) void k_update_distortions_q3_j(const JointUpd* __restrict__ U, const JointRound* __restrict__ R,
                                                                  unsigned int tag)
 {
     __shared__ UpdateLds<NV> L;
     int bb = (int)blockIdx.x;
-    const int c = joint_chain(ends, bb);
-    update_block_q3<NV, DPP>(U->sp[c], U->first_slot[c], n_slots.v[c], U->tile_prefix[c], U->changed[c], tag, U->dl[c], (int64_t)bb,
+    const int c = joint_chain(&R->eu, bb);
+    update_block_q3<NV, DPP>(U->sp[c], U->first_slot[c], joint_entry(&R->ns, c), U->tile_prefix[c], U->changed[c], tag, U->dl[c], (int64_t)bb,
                              gridDim.x <= 64u, L);
 }
 
@@ -1537,16 +1548,16 @@ __global__ __launch_bounds__(256) void k_refresh_changed(const ims_sensor_t* __r
 }
 
 template <int NV>
-__global__ __launch_bounds__(256) void k_refresh_changed_j(const JointUpd* __restrict__ U, const JointEnds ends, const JointEnds n_slots,
+__global__ __launch_bounds__(256) void k_refresh_changed_j(const JointUpd* __restrict__ U, const JointRound* __restrict__ R,
                                                            unsigned int tag)
 {
     int bb = (int)blockIdx.x;
-    const int c = joint_chain(ends, bb);
+    const int c = joint_chain(&R->eu, bb);
     const ims_sensor_t& s = *U->sp[c];
     const int64_t* __restrict__ tile_prefix = U->tile_prefix[c];
     const unsigned char* changed = U->changed[c];
     const int64_t b = bb;
-    const int lo = find_slot(tile_prefix, n_slots.v[c], b);
+    const int lo = find_slot(tile_prefix, joint_entry(&R->ns, c), b);
     const ims_bf_slot_t bs = s.bf_slots[U->first_slot[c] + lo];
     const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
     const int tiles_x = (sl.nx + 1 + UT - 1) / UT, tiles_y = (sl.ny + 1 + UT - 1) / UT;
@@ -1579,14 +1590,14 @@ struct JointLists {
     int* count;                         // [parity][2]: entries of upd / ref
 };
 
-__global__ __launch_bounds__(256) void k_build_active_j(const JointUpd* __restrict__ U, const JointEnds ends_wg, const JointEnds tiles_of,
-                                                        const JointEnds n_slots, unsigned int tag, const JointLists Ls, int parity)
+__global__ __launch_bounds__(256) void k_build_active_j(const JointUpd* __restrict__ U, const JointRound* __restrict__ R,
+                                                        unsigned int tag, const JointLists Ls, int parity)
 {
     int bb = (int)blockIdx.x;
-    const int c = joint_chain(ends_wg, bb);
+    const int c = joint_chain(&R->ewg, bb);
     const ims_sensor_t& s = *U->sp[c];
     const int64_t* __restrict__ tile_prefix = U->tile_prefix[c];
-    const int n_tiles = tiles_of.v[c], ns = n_slots.v[c];
+    const int n_tiles = joint_entry(&R->tof, c), ns = joint_entry(&R->ns, c);
     if (blockIdx.x == 0 && threadIdx.x == 0) { Ls.count[2 * (parity ^ 1)] = 0; Ls.count[2 * (parity ^ 1) + 1] = 0; }   // the next round's
     const int lane = threadIdx.x & 63;
     const int64_t g = (int64_t)bb * 256 + threadIdx.x;
@@ -1763,6 +1774,24 @@ __global__ __launch_bounds__(256) void k_image_to_float(const double* __restrict
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (float)src[i];
+}
+
+// the float32 image straight into page-locked HOST memory (mapped into the device's address space): the rounding and the copy
+// over PCIe in one pass by a FEW workgroups -- the bus, not the device, is the bound (~55 GB/s), and HIP's own device-to-host
+// copy of a page-locked buffer runs as a blit kernel of 512 workgroups whose 2 048 wavefronts sit in a quarter of the chip's
+// wave slots for the 1.2 ms the bus needs (round 5, focal plane: 13 % of a CCD's time)
+__global__ __launch_bounds__(256) void k_image_to_host_float(const double* __restrict__ src, float* __restrict__ dst_host, int64_t n)
+{
+    typedef float fvec4 __attribute__((ext_vector_type(4)));
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const dvec4 v = *(const dvec4*)(src + 4 * i);
+        fvec4 f;
+        f.x = (float)v.x; f.y = (float)v.y; f.z = (float)v.z; f.w = (float)v.w;
+        __builtin_nontemporal_store(f, (fvec4*)(dst_host + 4 * i));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst_host[4 * n4 + threadIdx.x] = (float)src[4 * n4 + threadIdx.x];
 }
 
 // ---------------- FFT branch ----------------
@@ -3383,10 +3412,13 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
         tiles_max += n_cont > 0 ? a.ch->tile_prefix_host[n_cont] : 0;
     }
     const bool lists = lists_on && tiles_max > list_min_tiles;
-    struct Ring { JointTables* dev; hipEvent_t free_after; bool used; unsigned long long* upd; unsigned long long* ref; int* count; int64_t cap; };
+    struct Ring { JointTables* dev; hipEvent_t free_after; bool used; unsigned long long* upd; unsigned long long* ref; int* count; int64_t cap;
+                  JointRound* rounds_dev; JointRound* rounds_pin; int64_t rounds_cap; };
     static std::vector<Ring> ring;
     static size_t ring_next = 0;
     JointTables* tables_dev = nullptr;
+    JointRound* rounds_dev = nullptr;
+    JointRound* rounds_pin = nullptr;
     hipEvent_t table_event = nullptr;
     JointLists Ls{ nullptr, nullptr, nullptr };
     {
@@ -3397,7 +3429,7 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
             HIP_TRY(hipMalloc((void**)&block, 64 * sizeof(JointTables)));
             HIP_TRY(hipMalloc((void**)&counts, 64 * 4 * sizeof(int)));
             for (int k = 0; k < 64; ++k) {
-                Ring r{ block + k, nullptr, false, nullptr, nullptr, counts + 4 * k, 0 };
+                Ring r{ block + k, nullptr, false, nullptr, nullptr, counts + 4 * k, 0, nullptr, nullptr, 0 };
                 HIP_TRY(hipEventCreateWithFlags(&r.free_after, hipEventDisableTiming));
                 ring.push_back(r);
             }
@@ -3412,8 +3444,16 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
             HIP_TRY(hipMalloc((void**)&r.upd, (size_t)r.cap * sizeof(unsigned long long)));
             HIP_TRY(hipMalloc((void**)&r.ref, (size_t)r.cap * sizeof(unsigned long long)));
         }
+        if (r.rounds_cap < max_rounds) {
+            // the round tables of the run: a page-locked staging buffer and its device copy (grown rarely: capacity kept)
+            if (r.rounds_dev) { HIP_TRY(hipFree(r.rounds_dev)); HIP_TRY(hipHostFree(r.rounds_pin)); }
+            r.rounds_cap = max_rounds + max_rounds / 2 + 64;
+            HIP_TRY(hipMalloc((void**)&r.rounds_dev, (size_t)r.rounds_cap * sizeof(JointRound)));
+            HIP_TRY(hipHostMalloc((void**)&r.rounds_pin, (size_t)r.rounds_cap * sizeof(JointRound), hipHostMallocDefault));
+        }
         tables_dev = r.dev; table_event = r.free_after;
         Ls.upd = r.upd; Ls.ref = r.ref; Ls.count = r.count;
+        rounds_dev = r.rounds_dev; rounds_pin = r.rounds_pin;
     }
     if (lists) HIP_TRY(hipMemsetAsync(Ls.count, 0, 4 * sizeof(int), js));
     bool dpp_ok = true;
@@ -3436,20 +3476,12 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
         }
         hipLaunchKernelGGL(k_store_joint_tables, dim3(1), dim3(64), 0, js, Ck, tables_dev, (int)k0);
     }
+    // every round's tables (workgroup / tile ends per chain) in one pass on the host, ONE copy to the device; per round the
+    // launches then take a pointer
+    struct RoundTotals { int64_t wgs, tiles, build_wgs; };
+    std::vector<RoundTotals> totals((size_t)max_rounds);
     for (int32_t r = 0; r < max_rounds; ++r) {
-        for (const Act& a : act) {
-            const ims_chain_t& ch = *a.ch;
-            if (r >= ch.n_rounds) continue;
-            for (int32_t j = 1; j < ch.n_edges; ++j)
-                if (ch.edges[j] == r) {
-                    hipEvent_t e;
-                    const int rc = plan_event(ch.ev_base + j, &e);
-                    if (rc) return rc;
-                    HIP_TRY(hipStreamWaitEvent(js, e, 0));
-                }
-        }
-        const uint32_t tag = (use_tags || lists) ? (uint32_t)(r % 255 + 1) : 0u;
-        JointEnds ea, eu, ns, ewg, tof;
+        JointRound& R = rounds_pin[r];
         int64_t wgs = 0, tiles = 0, build_wgs = 0;
         for (int k = 0; k < IMS_JOINT_MAX; ++k) {
             int32_t n_act = 0, n_cont = 0;
@@ -3464,12 +3496,40 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
             build_wgs += (tk + 255) / 256;
             wgs += (int64_t)n_act * segs;
             if (wgs > 0x7fffffffLL || tiles > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "joint run: too many workgroups for one round");
-            ea.v[k] = (int32_t)wgs; eu.v[k] = (int32_t)tiles; ns.v[k] = n_cont > 0 ? n_cont : 1;
-            ewg.v[k] = (int32_t)build_wgs; tof.v[k] = (int32_t)tk;
+            R.ea.v[k] = (int32_t)wgs; R.eu.v[k] = (int32_t)tiles; R.ns.v[k] = n_cont > 0 ? n_cont : 1;
+            R.ewg.v[k] = (int32_t)build_wgs; R.tof.v[k] = (int32_t)tk;
         }
+        totals[(size_t)r] = { wgs, tiles, build_wgs };
+    }
+    if (max_rounds > 0)
+        HIP_TRY(hipMemcpyAsync(rounds_dev, rounds_pin, (size_t)max_rounds * sizeof(JointRound), hipMemcpyHostToDevice, js));
+    // the round after which a CCD's chains of this run are through (its longest chain)
+    std::vector<std::pair<int32_t, hipEvent_t>> done_at;
+    for (size_t k = 0; k < act.size(); ++k) {
+        bool first_of_plan = true;
+        int32_t last = 0;
+        for (size_t j = 0; j < act.size(); ++j)
+            if (act[j].pl == act[k].pl) { if (j < k) first_of_plan = false; if (act[j].ch->n_rounds > last) last = act[j].ch->n_rounds; }
+        if (first_of_plan) done_at.push_back({ last - 1, act[k].done });
+    }
+    for (int32_t r = 0; r < max_rounds; ++r) {
+        for (const Act& a : act) {
+            const ims_chain_t& ch = *a.ch;
+            if (r >= ch.n_rounds) continue;
+            for (int32_t j = 1; j < ch.n_edges; ++j)
+                if (ch.edges[j] == r) {
+                    hipEvent_t e;
+                    const int rc = plan_event(ch.ev_base + j, &e);
+                    if (rc) return rc;
+                    HIP_TRY(hipStreamWaitEvent(js, e, 0));
+                }
+        }
+        const uint32_t tag = (use_tags || lists) ? (uint32_t)(r % 255 + 1) : 0u;
+        const int64_t wgs = totals[(size_t)r].wgs, tiles = totals[(size_t)r].tiles, build_wgs = totals[(size_t)r].build_wgs;
+        const JointRound* R = rounds_dev + r;
         if (wgs > 0) {
             LaunchTimer tm(js, 4);
-            hipLaunchKernelGGL((k_accumulate_round_j<4, 256>), dim3((unsigned)wgs), dim3(256), 0, js, (const JointAcc*)&tables_dev->acc, ea, tag,
+            hipLaunchKernelGGL((k_accumulate_round_j<4, 256>), dim3((unsigned)wgs), dim3(256), 0, js, (const JointAcc*)&tables_dev->acc, R, tag,
                                (int64_t)r * nrecalc, nrecalc, segs);
         }
         if (tiles > 0 && lists && tiles > list_min_tiles) {
@@ -3480,25 +3540,19 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
             if (grid < 256 && list_fraction >= 0.05) grid = 256;
             if (grid < 1) grid = 1;
             if (grid > tiles) grid = tiles;
-            hipLaunchKernelGGL(k_build_active_j, dim3((unsigned)build_wgs), dim3(256), 0, js, U, ewg, tof, ns, tag, Ls, parity);
+            hipLaunchKernelGGL(k_build_active_j, dim3((unsigned)build_wgs), dim3(256), 0, js, U, R, tag, Ls, parity);
             hipLaunchKernelGGL((k_update_list_j<4, false>), dim3((unsigned)grid), dim3(256), 0, js, U, Ls, parity, tag);
             hipLaunchKernelGGL(k_refresh_list_j<4>, dim3((unsigned)grid), dim3(256), 0, js, U, Ls, parity, tag);
         } else if (tiles > 0) {
             const JointUpd* U = &tables_dev->upd;
             const bool dpp = dpp_ok && g_tune.upd_dpp && tiles <= dpp_max_tiles;
-            if (dpp) hipLaunchKernelGGL((k_update_distortions_q3_j<4, true>), dim3((unsigned)tiles), dim3(256), 0, js, U, eu, ns, tag);
-            else hipLaunchKernelGGL((k_update_distortions_q3_j<4, false>), dim3((unsigned)tiles), dim3(256), 0, js, U, eu, ns, tag);
-            hipLaunchKernelGGL(k_refresh_changed_j<4>, dim3((unsigned)tiles), dim3(256), 0, js, U, eu, ns, tag);
+            if (dpp) hipLaunchKernelGGL((k_update_distortions_q3_j<4, true>), dim3((unsigned)tiles), dim3(256), 0, js, U, R, tag);
+            else hipLaunchKernelGGL((k_update_distortions_q3_j<4, false>), dim3((unsigned)tiles), dim3(256), 0, js, U, R, tag);
+            hipLaunchKernelGGL(k_refresh_changed_j<4>, dim3((unsigned)tiles), dim3(256), 0, js, U, R, tag);
         }
         // a CCD's chains of this run are through with the longest of them
-        for (size_t k = 0; k < act.size(); ++k) {
-            const Act& a = act[k];
-            int32_t last = 0;
-            bool first_of_plan = true;
-            for (size_t j = 0; j < act.size(); ++j)
-                if (act[j].pl == a.pl) { if (j < k) first_of_plan = false; if (act[j].ch->n_rounds > last) last = act[j].ch->n_rounds; }
-            if (first_of_plan && r == last - 1) HIP_TRY(hipEventRecord(a.done, js));
-        }
+        for (const auto& d : done_at)
+            if (d.first == r) HIP_TRY(hipEventRecord(d.second, js));
     }
     HIP_TRY(hipEventRecord(table_event, js));
     HIP_TRY(hipGetLastError());
@@ -3567,6 +3621,50 @@ static int fft_err(hipfftResult r, const char* what)
     return set_err(IMS_ERR_HIP, buf);
 }
 
+// Plans are kept per (size, stream) and transform ONE stamp: a batch is a loop over it.  The FIRST plan of a process costs seconds
+// (measured in round 5 on a fresh box: 2.4 s for the first call -- hipFFT / rocFFT start up and compile their kernels at run time
+// --, 0.5 s for the next new size, nothing after that; with a plan per size AND batch count every new combination paid again: 2.8
+// of the 3.4 s a fresh process spent on its first 48 CCDs), a CCD holds one to three FFT-drawn objects of a handful of sizes, and
+// a transform of 1024^2 or more fills the device by itself, so nothing is lost by not batching.  Per STREAM because a plan owns
+// its work buffer (the transposes of the large sizes go through it): the same plan executing on two streams at once -- the FFT
+// objects of two CCDs of a focal plane on the two top-chain streams -- would share it.  Small transforms (below 1024^2:
+// launch-bound) keep batched plans.  ims_fft_warm makes the plans ahead of time (from another host thread, while the host
+// still reads catalogs).
+static std::mutex g_fft_mutex;
+static std::map<std::tuple<int32_t, int64_t, void*>, hipfftHandle> g_fft_plans;
+
+// the plan of (nfft, per_plan, stream): looked up under the lock, MADE outside it (seconds for a size's first plan: plans of
+// different sizes are made side by side by ims_fft_warm's callers), entered under the lock again
+static int fft_plan_get(const ims_libs::Fft* F, int32_t nfft, int64_t per_plan, void* stream, hipfftHandle* out)
+{
+    const std::tuple<int32_t, int64_t, void*> key(nfft, per_plan, stream);
+    {
+        std::lock_guard<std::mutex> lock(g_fft_mutex);
+        auto it = g_fft_plans.find(key);
+        if (it != g_fft_plans.end()) { *out = it->second; return IMS_OK; }
+    }
+    int n[2] = { nfft, nfft };
+    int inembed[2] = { nfft, nfft / 2 + 1 }, onembed[2] = { nfft, nfft };
+    hipfftHandle p;
+    int rc = fft_err(F->plan_many(&p, 2, n, inembed, 1, nfft * (nfft / 2 + 1), onembed, 1, nfft * nfft, HIPFFT_Z2D, (int)per_plan),
+                     "hipfftPlanMany");
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(g_fft_mutex);
+    auto ins = g_fft_plans.emplace(key, p);
+    if (!ins.second) (void)F->destroy(p);            // another thread was faster
+    *out = ins.first->second;
+    return IMS_OK;
+}
+
+int ims_fft_warm(int32_t nfft, void* stream)
+{
+    if (nfft < 2 || (nfft & 1)) return set_err(IMS_ERR_ARG, "nfft must be even and >= 2");
+    const ims_libs::Fft* F = ims_libs::fft();
+    if (!F) return set_err(IMS_ERR_UNSUPPORTED, "hipFFT is not loadable (libhipfft.so; IMS_HIPFFT_LIB names a file)");
+    hipfftHandle plan;
+    return fft_plan_get(F, nfft, 1, stream, &plan);
+}
+
 int ims_fft_inverse(double* kbuf_dev, double* rbuf_dev, int32_t nfft, int64_t batch, void* stream)
 {
     if (batch <= 0) return IMS_OK;
@@ -3574,31 +3672,22 @@ int ims_fft_inverse(double* kbuf_dev, double* rbuf_dev, int32_t nfft, int64_t ba
     if (nfft < 2 || (nfft & 1) || batch > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "nfft must be even and >= 2");
     const ims_libs::Fft* F = ims_libs::fft();
     if (!F) return set_err(IMS_ERR_UNSUPPORTED, "hipFFT is not loadable (libhipfft.so; IMS_HIPFFT_LIB names a file)");
-    // Plans are kept per (size, stream) and transform ONE stamp: a batch is a loop over it.  Making a plan costs ~70 ms (measured
-    // in round 5: the 40 plans of the first 48 CCDs of a visit -- one per size AND batch count -- were 2.8 of the 3.4 s a fresh
-    // process spent on them), a CCD holds one to three FFT-drawn objects of a handful of sizes, and a transform of 1024^2 or more
-    // fills the device by itself, so nothing is lost by not batching.  Per STREAM because a plan owns its work buffer (the
-    // transposes of the large sizes go through it): the same plan executing on two streams at once -- the FFT objects of two CCDs
-    // of a focal plane on the two top-chain streams -- would share it.  Small transforms (below 1024^2: launch-bound) keep batched plans.
-    static std::mutex m;
-    static std::map<std::tuple<int32_t, int64_t, void*>, hipfftHandle> plans;
-    const int64_t per_plan = nfft >= 1024 ? 1 : batch;
-    hipfftHandle plan;
+    int64_t per_plan = nfft >= 1024 ? 1 : batch;
     {
-        std::lock_guard<std::mutex> lock(m);
-        const std::tuple<int32_t, int64_t, void*> key(nfft, per_plan, stream);
-        auto it = plans.find(key);
-        if (it == plans.end()) {
-            int n[2] = { nfft, nfft };
-            int inembed[2] = { nfft, nfft / 2 + 1 }, onembed[2] = { nfft, nfft };
-            hipfftHandle p;
-            int rc = fft_err(F->plan_many(&p, 2, n, inembed, 1, nfft * (nfft / 2 + 1), onembed, 1, nfft * nfft, HIPFFT_Z2D, (int)per_plan),
-                             "hipfftPlanMany");
-            if (rc) return rc;
-            it = plans.emplace(key, p).first;
+        if (per_plan != batch) {
+            // a (size, batch) pair that comes again -- a replayed step, the same counts on many CCDs -- gets its batched plan (a few
+            // milliseconds once the size's kernels exist: only a size's FIRST plan is expensive)
+            static std::map<std::tuple<int32_t, int64_t, void*>, int> asked;
+            std::lock_guard<std::mutex> lock(g_fft_mutex);
+            if (++asked[std::make_tuple(nfft, batch, stream)] >= 2) per_plan = batch;
         }
-        plan = it->second;
-        int rc = fft_err(F->set_stream(plan, (hipStream_t)stream), "hipfftSetStream");
+        hipfftHandle plan;
+        int rc = fft_plan_get(F, nfft, per_plan, stream, &plan);
+        if (rc) return rc;
+        // (set-stream + execute of one plan must not interleave between host threads: a plan carries its stream)
+        static std::mutex exec_mutex;
+        std::lock_guard<std::mutex> lock(exec_mutex);
+        rc = fft_err(F->set_stream(plan, (hipStream_t)stream), "hipfftSetStream");
         if (rc) return rc;
         for (int64_t b = 0; b < batch; b += per_plan) {
             rc = fft_err(F->exec_z2d(plan, (hipfftDoubleComplex*)kbuf_dev + b * (int64_t)nfft * (nfft / 2 + 1),
@@ -3905,6 +3994,18 @@ int ims_image_to_float(const double* src, float* dst, int64_t n, void* stream)
     if (!dst || !src) return set_err(IMS_ERR_ARG, "dst/src is NULL");
     if (n <= 0) return IMS_OK;
     hipLaunchKernelGGL(k_image_to_float, dim3(grid_for_pool(n)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+int ims_image_to_host_float(const double* src_dev, float* dst_host, int64_t n, void* stream)
+{
+    if (!dst_host || !src_dev) return set_err(IMS_ERR_ARG, "dst/src is NULL");
+    if (n <= 0) return IMS_OK;
+    if (((uintptr_t)src_dev & 31u) != 0 || ((uintptr_t)dst_host & 15u) != 0) return set_err(IMS_ERR_ARG, "image_to_host_float: src must be 32-byte, dst 16-byte aligned");
+    void* dst_dev = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dst_dev, dst_host, 0));           // page-locked (hipHostMalloc / hipHostRegister) memory only
+    hipLaunchKernelGGL(k_image_to_host_float, dim3(96), dim3(256), 0, (hipStream_t)stream, src_dev, (float*)dst_dev, n);
     HIP_TRY(hipGetLastError());
     return IMS_OK;
 }

@@ -925,7 +925,7 @@ def upload_async(torch, device, arr):
     return out.view(a.shape) if a.ndim != 1 else out
 
 
-def plan_input(r, n_phot, stamp, faint, nrecalc=None, want_realized=False):
+def plan_input(r, n_phot, stamp, faint, nrecalc=None, want_realized=False, coarse_slices=False):
     """ims_plan_input_t of one LSST_Image render on renderer r (the arrays must stay alive while the struct is used)"""
     ss = r.scene.sensor
     inp = _abi.PlanInput()
@@ -943,6 +943,7 @@ def plan_input(r, n_phot, stamp, faint, nrecalc=None, want_realized=False):
     inp.max_pool_photons = int(r.max_pool_photons)
     inp.seg_size, inp.want_realized = int(r.scene.seg_size), 1 if want_realized else 0
     inp.event_base, inp.use_tags = int(r._event_block), 1 if r.use_bf_tags else 0
+    inp.coarse_slices = 1 if coarse_slices else 0
     return inp
 
 
@@ -967,7 +968,7 @@ class NativePlan:
     the gathered launch tables, the converted photon pool of the bright objects.  `objects`: an OBJECT_DTYPE host table (uploaded
     once as the master table) or a device_table.DeviceTable."""
 
-    def __init__(self, renderer, objects, nrecalc=None, want_realized=False):
+    def __init__(self, renderer, objects, nrecalc=None, want_realized=False, coarse_slices=False):
         r = renderer
         self._renderer = weakref.ref(renderer)     # the renderer keeps its last plan: no cycle (its HBM must go when it is dropped)
         self._lib, self._torch, self._device, self._streams = r.lib, r.torch, r.device, tuple(r.plan_streams)
@@ -989,7 +990,7 @@ class NativePlan:
                              axis=1).astype(np.int32) if len(objects) else np.zeros((0, 4), dtype=np.int32)
             faint = ((objects["flags"] & _abi.IMS_OBJ_FAINT) != 0).astype(np.uint8)
         self.n_master = len(n_phot)
-        inp = plan_input(r, n_phot, stamp, faint, nrecalc, want_realized)
+        inp = plan_input(r, n_phot, stamp, faint, nrecalc, want_realized, coarse_slices)
         b = r.bound
         handle, sizes = C.c_void_p(), _abi.PlanSizes()
         _abi.check(lib.ims_plan_lsst_image(C.byref(inp), C.byref(handle), C.byref(sizes)), "ims_plan_lsst_image")
@@ -1584,8 +1585,8 @@ class Renderer:
             return False
         return True
 
-    def native_plan(self, objects, nrecalc=None, want_realized=False):
-        return NativePlan(self, objects, nrecalc, want_realized)
+    def native_plan(self, objects, nrecalc=None, want_realized=False, coarse_slices=False):
+        return NativePlan(self, objects, nrecalc, want_realized, coarse_slices)
 
     def touch_streams(self):
         """Run a trivial operation on every plan stream and wait for it: the streams then hold their hardware queues before
@@ -1681,7 +1682,8 @@ class Renderer:
         top chain (NativePlan.run(defer=True)); returns the plan -- the caller runs engine.run_joint_plans over the CCDs of a
         batch, then plan.join() and, for `realized`, plan.add_realized.  None: this render cannot be deferred and ran whole."""
         if self.native_plan_ok(objects):
-            plan = self.native_plan(objects, nrecalc, want_realized=realized is not None)
+            plan = self.native_plan(objects, nrecalc, want_realized=realized is not None,
+                                    coarse_slices=defer and tuning.flag("IMS_FOCAL_COARSE_SLICES"))
             self._keep_plan = plan
             if defer:
                 plan.run(defer=True)
@@ -2016,6 +2018,15 @@ class Renderer:
         _abi.check(self.lib.ims_image_to_float(self.image.data_ptr(), out.data_ptr(), out.numel(), self._stream()),
                    "ims_image_to_float")
         return out
+
+    def image_to_host(self, pinned):
+        """the float32 CCD image rounded straight into a page-locked host tensor of its shape, on the current stream (one launch
+        of a few workgroups: ims_image_to_host_float); the caller reads it behind an event recorded after this call"""
+        if not pinned.is_pinned() or pinned.dtype != self.torch.float32 or pinned.numel() != self.image.numel():
+            raise ValueError("image_to_host wants a page-locked float32 tensor of the image's size")
+        _abi.check(self.lib.ims_image_to_host_float(self.image.data_ptr(), pinned.data_ptr(), self.image.numel(), self._stream()),
+                   "ims_image_to_host_float")
+        return pinned
 
     def image_numpy(self):
         return self.image_float().cpu().numpy()

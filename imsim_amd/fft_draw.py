@@ -241,6 +241,41 @@ def fft_params(scene, kpsf, ktables, q_step, seed, add_noise=True, mem_put=None)
     return P, keep
 
 
+_WARM = {}
+
+
+def warm_up(device, stream, sizes=(1024, 2048, 4096, 512)):
+    """Make the library's hipFFT plans of `stream` for the grid sizes a visit's FFT-drawn objects take, on a BACKGROUND thread
+    (returns it; join() before timing anything).  A process's first plan costs seconds (hipFFT / rocFFT start up and compile
+    their kernels at run time: 2.4 s + 0.5 s for the next new size on a fresh MI355X box, round 5), which a visit otherwise
+    pays in front of its first CCD with a bright star; called while the host still reads catalogs it costs nothing.  Plans
+    are kept per stream: `stream` must be the one the draws will run on (focal plane: engine._focal_streams' middle stream)."""
+    import threading
+    import torch
+    key = (str(device), int(stream.cuda_stream))
+    if key in _WARM:
+        return _WARM[key]
+    lib = _abi.load()
+
+    def one(n):
+        torch.cuda.set_device(device)
+        lib.ims_fft_warm(int(n), C.c_void_p(stream.cuda_stream))
+
+    class _All:
+        """the threads of one warm-up (a size each: the run-time compilations run side by side)"""
+        def __init__(self, threads):
+            self.threads = threads
+
+        def join(self):
+            for t in self.threads:
+                t.join()
+    threads = [threading.Thread(target=one, args=(n,), name=f"ims-fft-warm-{n}", daemon=True) for n in sizes]
+    for t in threads:
+        t.start()
+    _WARM[key] = _All(threads)
+    return _WARM[key]
+
+
 class FftDrawer:
     """Batched FFT rendering into a Renderer's CCD image."""
 

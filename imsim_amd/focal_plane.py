@@ -84,7 +84,7 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
 
     prebuilt = {}
     arena = None
-    alive = max(int(tuning.env("IMS_FOCAL_ALIVE", "3")), 2)       # batches alive at a time (the pipeline below)
+    alive = max(int(tuning.env("IMS_FOCAL_ALIVE")), 2)            # batches alive at a time (the pipeline below)
     if order:
         prebuilt[order[0]] = build(order[0])
         sc0, work0 = prebuilt[order[0]]
@@ -203,16 +203,21 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
             lease.release_static({id(st): st for st in list(renderer.plan_streams) + [pre, init_on]}.values())
         return dict(key=key, renderer=renderer, fin=fin, plan=plan)
 
+    direct_copy = tuning.flag("IMS_FOCAL_DIRECT_COPY")
+
     def tail(entries):
         # shortest chain first: mid must not sit behind the batch's longest chain while the others' images wait
         for e in sorted(entries, key=lambda e: e["plan"].sizes.n_round_launches if e["plan"] is not None else 0):
             with torch.cuda.stream(mid):
                 e["fin"]()
-                img = e["renderer"].image_float()
-                host = pinned_pool.pop() if pinned_pool else torch.empty(img.shape, dtype=img.dtype, pin_memory=True)
-                if host.shape != img.shape:
-                    host = torch.empty(img.shape, dtype=img.dtype, pin_memory=True)
-                host.copy_(img, non_blocking=True)
+                shape = tuple(e["renderer"].image.shape)
+                host = pinned_pool.pop() if pinned_pool else torch.empty(shape, dtype=torch.float32, pin_memory=True)
+                if tuple(host.shape) != shape:
+                    host = torch.empty(shape, dtype=torch.float32, pin_memory=True)
+                if direct_copy:
+                    e["renderer"].image_to_host(host)              # rounding + transfer in one launch of a few workgroups
+                else:
+                    host.copy_(e["renderer"].image_float(), non_blocking=True)
                 done = torch.cuda.Event(enable_timing=trace is not None)
                 done.record(mid)
             e["host"], e["done"] = host, done
@@ -237,7 +242,7 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
     # enqueued by a SECOND host thread (the library's calls release the interpreter lock) while this thread goes on with the
     # fronts of the next batch | its tails (join, sky, float image, copy to the host), enqueued once its rounds have RUN, so that
     # `mid` never sits in a join behind a chain that is still running | collected when the copies are through.  Nothing here
-    # waits for the device except the pacing of the fronts and the bound on the batches alive (IMS_FOCAL_ALIVE, default 3:
+    # waits for the device except the pacing of the fronts and the bound on the batches alive (IMS_FOCAL_ALIVE, default 2:
     # memory).  Measured in round 5 (profiles/round5_c5_*): with everything enqueued by one thread and a wait for batch b - 1
     # before the fronts of batch b + 1, the joint stream and the stream of the wide launches took turns, ~100 ms each, and the
     # host spent 156 of 600 ms (64 CCDs) enqueueing rounds while the front streams idled.
@@ -347,6 +352,22 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
     render_focal_plane.last_host_ms_per_ccd = 1e3 * host_s[0] / max(len(mine), 1)
     render_focal_plane.last_joint_plans = n_joint[0]          # CCDs whose top chain ran in joint launches
     return out
+
+
+def warm_fft(device="cuda:0"):
+    """Start the hipFFT plans of the stream a focal plane's FFT draws run on (fft_draw.warm_up) in the background: call it as
+    soon as the device is known -- before the catalogs are read -- so that the seconds a process's first plan costs are not paid
+    in front of the visit's first CCD with a bright star.  Returns the thread (None when the joint path is off)."""
+    import torch
+    from . import fft_draw
+    from .engine import _focal_streams
+    dev = torch.device(device)
+    if tuning.env("IMS_FOCAL_STREAMS") == "0" or int(tuning.env("IMS_FOCAL_JOINT")) <= 1:
+        return None
+    torch.cuda.set_device(dev)
+    pre, bulk, mid = _focal_streams(torch, dev, top_index=1)[:3]
+    on = {"bulk": bulk, "mid": mid}.get(tuning.env("IMS_FOCAL_FFT", "mid"), pre)
+    return fft_draw.warm_up(dev, on)
 
 
 def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent=3, nrecalc=None, sink=None, post=None,

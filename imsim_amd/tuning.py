@@ -62,8 +62,12 @@ KNOWN = {
     "IMS_FOCAL_ARENA_CELLS": (None, "the arena's private pool in owner cells (tests: a pool that runs dry)"),
     "IMS_FOCAL_ARENA_FACTOR": ("0.8", "private cells per CCD the arena's pool is sized for, as a multiple of the first CCD's need"),
     "IMS_FOCAL_STATIC_REGIONS": ("3", "static regions of the arena, taken in turn"),
-    "IMS_FOCAL_ALIVE": ("3", "joint path: batches alive at a time (enqueueing / in its rounds / in its tails)"),
+    "IMS_FOCAL_ALIVE": ("2", "joint path: batches alive at a time (one in its rounds and tails, one being enqueued; 3 measured no faster "
+                             "-- C5 9.39 against 9.43 ms per CCD -- and costs a third more memory and first-call allocation time)"),
     "IMS_FOCAL_JOINT_THREAD": ("1", "joint path: the rounds of a batch are enqueued by a second host thread while the first goes on with the next fronts"),
+    "IMS_FOCAL_DIRECT_COPY": ("0", "joint path: 1 = the finished image rounded straight into page-locked host memory by one small launch "
+                                   "(measured slower: C5 1.91 against 1.78 s); 0 = image_float + copy"),
+    "IMS_FOCAL_COARSE_SLICES": ("1", "joint path: a chain class's photons shot in two launches (round 0, the rest) instead of up to six slices"),
     "IMS_FOCAL_TRACE": ("0", "print, per CCD, when its work ended on every stream and when the host enqueued it"),
     "IMS_PROCESS_FOCAL": ("1", "config.Process with several CCDs on the overlapped focal-plane path"),
     "IMS_PROCESS_CONCURRENT": ("3", "... CCDs in flight"),

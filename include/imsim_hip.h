@@ -689,6 +689,9 @@ int64_t ims_parse_instcat_objects(const char* text, int64_t n_bytes, int64_t max
  * int32 (half the bytes; exact when every value is an integer count and the sum stays below 2^31 -- ims_count_inexact adds the
  * number of values of a rank's image that are not integer counts below 2^31 / world to *bad_dev). */
 int  ims_fft_inverse(double* kbuf_dev, double* rbuf_dev, int32_t nfft, int64_t batch, void* stream);
+/* Make the plan of the nfft x nfft transforms of `stream` ahead of time (a process's first hipFFT plan costs seconds: the
+ * library starts up and compiles its kernels at run time); may be called from another host thread while the caller goes on. */
+int  ims_fft_warm(int32_t nfft, void* stream);
 int  ims_comm_unique_id(void* id128);
 int  ims_comm_init(const void* id128, int32_t rank, int32_t world, void** comm_out);
 int  ims_comm_destroy(void* comm);
@@ -785,6 +788,9 @@ typedef struct ims_plan_input {
     int32_t n_static_slots, slot_capacity;
     int64_t static_cells, scratch_cells, max_pool_photons;
     int32_t seg_size, want_realized, event_base, use_tags;
+    int32_t coarse_slices;               /* 1: the photons of a chain class are shot in two launches (round 0, then the rest) instead of
+                                            up to six slices of rounds -- for plans whose rounds are deferred to a joint run */
+    int32_t pad;
 } ims_plan_input_t;
 typedef struct ims_plan_sizes {
     int64_t arena_bytes;                 /* tables of the plan (host image, page-locked by the caller, and its device copy) */
@@ -903,6 +909,11 @@ int  ims_readout_finish(const float* seg_dev, const ims_readout_t* ro, uint64_t 
 int  ims_image_add(double* dst, const double* src, int64_t n, void* stream);
 /* round the f64 accumulation image to the float32 CCD image the reference hands on (galsim.ImageF) */
 int  ims_image_to_float(const double* src, float* dst, int64_t n, void* stream);
+/* the same rounding with the result written straight into PAGE-LOCKED HOST memory (hipHostMalloc / hipHostRegister; dst_host is
+ * the host address): one launch of a few workgroups replaces ims_image_to_float + a device-to-host copy (the hand-over of the
+ * finished ImageF to the host-side writer, imsim/lsst_image.py:368-395 -> imsim/ccd.py).  Stream-ordered like a copy: the host
+ * may read dst_host once everything queued on `stream` up to here has run. */
+int  ims_image_to_host_float(const double* src_dev, float* dst_host, int64_t n, void* stream);
 
 /* ---- timing of the dominant kernel ----
  * After ims_enable_timing(which) every launch of the selected kernel is bracketed by a hipEvent pair on its

@@ -286,8 +286,10 @@ def main():
     torch.cuda.synchronize()
     lib.ims_enable_timing(cfg["timed_kernel"])
     t0 = time.perf_counter()
+    step_ends = []
     for _ in range(args.steps):
         full_step()
+        step_ends.append(time.perf_counter())         # (a focal-plane step ends with every image on the host: these are step times)
     torch.cuda.synchronize()
     if world > 1 or one_rank_rccl:
         dist.barrier()
@@ -442,6 +444,8 @@ def main():
         if cpu is None:
             cpu = cpu_legs(cfg, scene, objects, args, fork_ok=False)
         out["cpu_baseline"] = cpu_parity(cfg, scene, cpu, device)
+    if cfg.get("focal") and rank == 0:
+        out.setdefault("extra", {})["step_ms"] = [round(1e3 * (b - a), 1) for a, b in zip([t0] + step_ends[:-1], step_ends)]
     if extra_cfg is not None:
         out.setdefault("extra", {})["configs"] = extra_cfg
     if rank == 0:

@@ -35,6 +35,7 @@ static ims_tuning_t tuning_defaults()
     t.chain_kernels = 1; t.layout_kernels = 1; t.psf_screens_kernel = 1; t.photon_lds = -1;
     t.round_compact = 1; t.init_tiles = 1; t.upd_dpp = 1; t.joint_lists = 1;
     t.upd_dpp_max = 128; t.joint_list_min = 1024; t.active_fraction = 0.25;
+    t.round_two_segments = 0; t.pad = 0;
     return t;
 }
 static ims_tuning_t g_tune = tuning_defaults();
@@ -414,6 +415,55 @@ __device__ __forceinline__ void accumulate_segment(const ims_render_params_t& P,
     }
 }
 
+// TWO segments of one object per workgroup (photons j0 + t and j0 + 256 + t on thread t): both pool records are requested before
+// the first search, so the second photon's record arrives behind the first photon's dependent round trips, and a round has half
+// the workgroups to find wave slots for.  The two bodies are written out (a rolled loop lost the register allocation in round 3).
+// Same photons, same LDS tile arithmetic (integer counts): the same image bits.  ims_tuning_t.round_two_segments.
+template <int NV = 0>
+__device__ __forceinline__ void accumulate_segment2(const ims_render_params_t& P, const ims_photons_t& pool,
+                                                    const int64_t* __restrict__ pool_start, int64_t oi, int64_t j0, int64_t j_end)
+{
+    const ims_object_t& o = P.objects[oi];
+    const int64_t left = j_end - j0;                                            // photons of this pair of segments (>= 1)
+    const int n_thr = left >= 256 ? 256 : ((((int)left + 63) >> 6) << 6);
+    if ((int)threadIdx.x >= n_thr) return;                                      // photon-less wavefronts leave at once
+    const int64_t ja = j0 + threadIdx.x, jb = ja + 256;
+    const bool silicon = (P.sensor != nullptr) && (P.sensor->kind == IMS_SENSOR_SILICON);
+    __shared__ float tile[CT * CT];
+    ChargeTile ct;
+    tile_begin(tile, ct, P, o, silicon, n_thr);
+    double added = 0.0;
+    const bool has_a = ja < j_end, has_b = jb < j_end;
+    const int64_t ia = pool_start[oi] + (has_a ? ja : j0), ib = pool_start[oi] + (has_b ? jb : j0);
+    // both records in flight before anything is used
+    const double xa = pool.x[ia], ya = pool.y[ia], fa = pool.flux[ia], za = pool.dxdz[ia];
+    const double xb = pool.x[ib], yb = pool.y[ib], fb = pool.flux[ib], zb = pool.dxdz[ib];
+    const bool plain = !silicon || (o.flags & IMS_OBJ_FAINT);
+    if (has_a && fa != 0.0) {
+        int ix, iy;
+        bool ok;
+        if (plain) {
+            ix = (int)floor(xa + 0.5); iy = (int)floor(ya + 0.5);
+            ok = !(ix < o.stamp_xmin || ix > o.stamp_xmax || iy < o.stamp_ymin || iy > o.stamp_ymax);
+        } else ok = land_search<NV, true>(P, o, xa, ya, fabs(za), __double_as_longlong(za) < 0, ix, iy);
+        if (ok) { added += fa; tile_deposit(tile, ct, P, ix, iy, fa); }
+    }
+    if (has_b && fb != 0.0) {
+        int ix, iy;
+        bool ok;
+        if (plain) {
+            ix = (int)floor(xb + 0.5); iy = (int)floor(yb + 0.5);
+            ok = !(ix < o.stamp_xmin || ix > o.stamp_xmax || iy < o.stamp_ymin || iy > o.stamp_ymax);
+        } else ok = land_search<NV, true>(P, o, xb, yb, fabs(zb), __double_as_longlong(zb) < 0, ix, iy);
+        if (ok) { added += fb; tile_deposit(tile, ct, P, ix, iy, fb); }
+    }
+    tile_flush(tile, ct, P, n_thr);
+    if (P.realized_flux != nullptr) {
+        const double tot = wave_sum(added);
+        if ((threadIdx.x & 63) == 0 && tot != 0.0) unsafeAtomicAdd(P.realized_flux + oi, tot);
+    }
+}
+
 template <int NV>
 __global__ __launch_bounds__(256, (NV == 8) ? 2 : 4) void k_accumulate_segments(const ims_render_params_t P, const ims_photons_t pool,
                                                                                 const int64_t* __restrict__ pool_start)
@@ -529,6 +579,26 @@ __global__ __launch_bounds__(WG, (NV == 8) ? 2 : 4) void k_accumulate_round_c(co
     accumulate_segment<NV, WG>(P, pool, pool_start, oi, j0, j_end);
 }
 
+template <int NV>
+__global__ __launch_bounds__(256, 4) void k_accumulate_round_c2(const RoundArgs a, const int64_t* __restrict__ pool_start,
+                                                                int64_t round_first, int32_t nrecalc, int32_t segs2)
+{
+    ims_render_params_t P;
+    P.objects = a.objects; P.sensor = a.sensor; P.image = a.image; P.realized_flux = a.realized_flux;
+    P.nx = a.nx; P.ny = a.ny; P.xmin = a.xmin; P.ymin = a.ymin;
+    P.bf_tag = a.bf_tag; P.bf_slot_shift = a.bf_slot_shift; P.track_static_delta = a.track_static_delta;
+    ims_photons_t pool;
+    pool.x = const_cast<double*>(a.px); pool.y = const_cast<double*>(a.py); pool.flux = const_cast<double*>(a.pflux);
+    pool.dxdz = const_cast<double*>(a.pz);
+    const int64_t oi = blockIdx.x / segs2;
+    const int64_t j0 = round_first + (int64_t)(blockIdx.x % segs2) * 512;
+    int64_t j_end = round_first + nrecalc;
+    const int64_t n = P.objects[oi].n_phot;
+    if (j_end > n) j_end = n;
+    if (j0 >= j_end) return;
+    accumulate_segment2<NV>(P, pool, pool_start, oi, j0, j_end);
+}
+
 // ---- JOINT rounds: the same round of the top chains of several CCDs in one launch ----
 // A focal plane's CCDs are independent renders (own sensor state, image, pool, object table), and with a bright tail each is
 // bound by the dependent rounds of its brightest star -- hundreds of launches of a few dozen workgroups.  Chains of different
@@ -548,9 +618,8 @@ struct JointAcc {                           // per chain, constant over the roun
 // The tables of ONE round of a joint run -- workgroup ends of the pixel search (ea), tile ends (eu), regions that go on (ns),
 // workgroup ends of the list builder (ewg), tiles per chain (tof) -- live in DEVICE memory, all rounds of the run uploaded at
 // once (ims_plans_run_joint), and a launch takes a pointer to its round's block.  (By value they were 128 .. 768 bytes of
-// kernel arguments per launch, four launches per round, thousands of rounds per batch: HIP's kernel-argument pool ran out and
-// the host enqueued at the device's pace -- 25 us of gap in front of every launch of a chain, round 5.)  Read through the
-// constant address space: uniform addresses, scalar loads.
+// kernel arguments per launch, four launches per round, thousands of rounds per batch, and would have doubled with 64 chains
+// per run.)  Read through the constant address space: uniform addresses, scalar loads.
 struct JointRound { JointEnds ea, eu, ns, ewg, tof; };
 typedef const JointEnds __attribute__((address_space(4))) * ConstEnds;
 
@@ -2788,6 +2857,11 @@ static int accumulate_round_compact(const ims_render_params_t* params, const ims
     a.nx = params->nx; a.ny = params->ny; a.xmin = params->xmin; a.ymin = params->ymin;
     a.bf_tag = params->bf_tag; a.bf_slot_shift = params->bf_slot_shift; a.track_static_delta = params->track_static_delta; a.pad = 0;
     LaunchTimer tm((hipStream_t)stream, 4);
+    if (g_tune.round_two_segments) {
+        const int32_t segs2 = (nrecalc + 511) / 512;
+        hipLaunchKernelGGL((k_accumulate_round_c2<4>), dim3((unsigned)(n_active * segs2)), dim3(256), 0, (hipStream_t)stream, a, pool_start,
+                           (int64_t)round * nrecalc, nrecalc, segs2);
+    } else
     hipLaunchKernelGGL((k_accumulate_round_c<4, 256>), dim3((unsigned)(n_active * segs)), dim3(256), 0, (hipStream_t)stream, a, pool_start,
                        (int64_t)round * nrecalc, nrecalc, segs);
     HIP_TRY(hipGetLastError());
@@ -3355,6 +3429,21 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
     struct Act { Plan* pl; const ims_chain_t* ch; int chain; hipEvent_t done; };
     std::vector<Act> act;
     hipStream_t js = (hipStream_t)joint_stream;
+    // what an error return has to undo: the done events handed out below (a plan's join must not wait for a record that
+    // never comes) and the ring entry held while this call enqueues (its event is recorded all the same: launches that
+    // did go out read the entry's tables)
+    struct Undo {
+        std::vector<Plan*> counted; bool* busy = nullptr; hipEvent_t table_event = nullptr; hipStream_t js = nullptr; bool ok = false;
+        ~Undo() {
+            if (!ok) for (Plan* p : counted) if (p->d_done_used > 0) --p->d_done_used;
+            if (busy) {
+                if (!ok && table_event) (void)hipEventRecord(table_event, js);
+                std::lock_guard<std::mutex> lock(g_state_mutex);
+                *busy = false;
+            }
+        }
+    } undo;
+    undo.js = js;
     for (int32_t k = 0; k < n_plans; ++k) {
         Plan* pl = (Plan*)plans[k];
         if (!pl) return set_err(IMS_ERR_ARG, "plans: NULL entry");
@@ -3371,9 +3460,10 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
             pl->d_events.push_back(e);
         }
         const hipEvent_t done = pl->d_events[4 + pl->d_done_used++];
+        undo.counted.push_back(pl);
         for (Act& a : act) if (a.pl == pl) a.done = done;
     }
-    if (act.empty()) return IMS_OK;
+    if (act.empty()) { undo.ok = true; return IMS_OK; }
     if ((int)act.size() > IMS_JOINT_MAX) return set_err(IMS_ERR_ARG, "at most 64 chains per joint run");
     const int32_t nrecalc = act[0].ch->nrecalc, use_tags = act[0].ch->use_tags;
     int32_t max_rounds = 0;
@@ -3412,10 +3502,13 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
         tiles_max += n_cont > 0 ? a.ch->tile_prefix_host[n_cont] : 0;
     }
     const bool lists = lists_on && tiles_max > list_min_tiles;
-    struct Ring { JointTables* dev; hipEvent_t free_after; bool used; unsigned long long* upd; unsigned long long* ref; int* count; int64_t cap;
+    struct Ring { JointTables* dev; hipEvent_t free_after; bool used; bool busy; unsigned long long* upd; unsigned long long* ref; int* count; int64_t cap;
                   JointRound* rounds_dev; JointRound* rounds_pin; int64_t rounds_cap; };
-    static std::vector<Ring> ring;
-    static size_t ring_next = 0;
+    // one ring per DEVICE (its tables live in that device's memory: one process per GPU is the rule, but a process that holds
+    // two devices must not hand the second one the first one's tables)
+    static std::map<int, std::pair<std::vector<Ring>, size_t>> rings;
+    int device_now = 0;
+    HIP_TRY(hipGetDevice(&device_now));
     JointTables* tables_dev = nullptr;
     JointRound* rounds_dev = nullptr;
     JointRound* rounds_pin = nullptr;
@@ -3423,20 +3516,27 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
     JointLists Ls{ nullptr, nullptr, nullptr };
     {
         std::lock_guard<std::mutex> lock(g_state_mutex);
+        std::vector<Ring>& ring = rings[device_now].first;
+        size_t& ring_next = rings[device_now].second;
         if (ring.empty()) {
             JointTables* block = nullptr;
             int* counts = nullptr;
             HIP_TRY(hipMalloc((void**)&block, 64 * sizeof(JointTables)));
             HIP_TRY(hipMalloc((void**)&counts, 64 * 4 * sizeof(int)));
             for (int k = 0; k < 64; ++k) {
-                Ring r{ block + k, nullptr, false, nullptr, nullptr, counts + 4 * k, 0, nullptr, nullptr, 0 };
+                Ring r{ block + k, nullptr, false, false, nullptr, nullptr, counts + 4 * k, 0, nullptr, nullptr, 0 };
                 HIP_TRY(hipEventCreateWithFlags(&r.free_after, hipEventDisableTiming));
                 ring.push_back(r);
             }
         }
+        // an entry another thread is still enqueueing with (its event not yet recorded) is passed over
+        size_t tries = 0;
+        while (ring[ring_next % ring.size()].busy && tries++ < ring.size()) ++ring_next;
         Ring& r = ring[ring_next++ % ring.size()];
+        if (r.busy) return set_err(IMS_ERR_ARG, "joint run: all 64 table entries are being enqueued with");
         if (r.used) HIP_TRY(hipEventSynchronize(r.free_after));
-        r.used = true;
+        r.used = true; r.busy = true;
+        undo.busy = &r.busy; undo.table_event = r.free_after;
         if (lists && r.cap < tiles_max) {
             // (a growth is a device-wide synchronisation: the capacity is kept and rounded up generously)
             if (r.upd) { HIP_TRY(hipFree(r.upd)); HIP_TRY(hipFree(r.ref)); }
@@ -3475,6 +3575,7 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
             dpp_ok = dpp_ok && a.pl->d_sensor_host->bf_dl != nullptr;
         }
         hipLaunchKernelGGL(k_store_joint_tables, dim3(1), dim3(64), 0, js, Ck, tables_dev, (int)k0);
+        HIP_TRY(hipGetLastError());
     }
     // every round's tables (workgroup / tile ends per chain) in one pass on the host, ONE copy to the device; per round the
     // launches then take a pointer
@@ -3554,8 +3655,9 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
         for (const auto& d : done_at)
             if (d.first == r) HIP_TRY(hipEventRecord(d.second, js));
     }
-    HIP_TRY(hipEventRecord(table_event, js));
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(table_event, js));
+    undo.ok = true;
     for (const Act& a : act) {
         a.pl->left &= ~(1u << a.chain);
         if (a.pl->left == 0u) a.pl->deferred = false;

@@ -25,6 +25,7 @@ KNOWN = {
     "IMS_JOINT_LISTS": ("1", "joint rounds: update / refresh over lists of the tiles with charge in reach"),
     "IMS_JOINT_LIST_MIN": ("1024", "... for rounds of more than this many tiles"),
     "IMS_ACTIVE_FRACTION": ("0.25", "... workgroups launched per tile of the round"),
+    "IMS_ROUND_TWO_SEGMENTS": ("0", "pixel search of a round with two 256-photon segments per workgroup (both pool records requested up front)"),
     # -- engine --
     "IMS_SCREEN_PREPASS": ("0", "phase-screen gathers ahead of the shooting kernels (1: every photon, 2: ordinary objects on a side stream)"),
     "IMS_SCREEN_BUCKETS": ("128", "arrival-time buckets of the pre-pass"),
@@ -114,7 +115,8 @@ class Tuning(C.Structure):
     """ims_tuning_t (include/imsim_hip.h)"""
     _fields_ = [("chain_kernels", C.c_int32), ("layout_kernels", C.c_int32), ("psf_screens_kernel", C.c_int32), ("photon_lds", C.c_int32),
                 ("round_compact", C.c_int32), ("init_tiles", C.c_int32), ("upd_dpp", C.c_int32), ("joint_lists", C.c_int32),
-                ("upd_dpp_max", C.c_int64), ("joint_list_min", C.c_int64), ("active_fraction", C.c_double)]
+                ("upd_dpp_max", C.c_int64), ("joint_list_min", C.c_int64), ("active_fraction", C.c_double),
+                ("round_two_segments", C.c_int32), ("pad", C.c_int32)]
 
 
 def library_tuning():
@@ -132,6 +134,7 @@ def library_tuning():
     t.upd_dpp_max = number("IMS_UPD_DPP_MAX")
     t.joint_list_min = number("IMS_JOINT_LIST_MIN")
     t.active_fraction = number("IMS_ACTIVE_FRACTION", float)
+    t.round_two_segments = 1 if flag("IMS_ROUND_TWO_SEGMENTS") else 0
     return t
 
 

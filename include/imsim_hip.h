@@ -431,6 +431,9 @@ typedef struct ims_tuning {
     int64_t upd_dpp_max;         /* 128 */
     int64_t joint_list_min;      /* 1024 */
     double  active_fraction;     /* 0.25: workgroups launched per tile of a round for the list walkers (0 < f <= 1) */
+    int32_t round_two_segments;  /* 0; 1: the pixel search of a round takes two 256-photon segments per workgroup, both pool records
+                                    requested before the first search (measured: EXPERIMENTS.md, round 5) */
+    int32_t pad;
 } ims_tuning_t;
 int  ims_tuning_defaults(ims_tuning_t* out);
 int  ims_get_tuning(ims_tuning_t* out);

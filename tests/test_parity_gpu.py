@@ -303,6 +303,29 @@ def test_slot_pairs_give_the_in_place_result(torch_cuda, monkeypatch):
         assert_bits_equal(out[0][2][name], orc.sensor_array(name)[:len(out[0][2][name])], f"sensor {name} vs oracle")
 
 
+@pytest.mark.parametrize("nrecalc", [1000, 300])
+def test_two_segment_round_search_gives_the_one_segment_result(torch_cuda, monkeypatch, nrecalc):
+    """ims_tuning_t.round_two_segments (k_accumulate_round_c2: photons j and j + 256 of an object on one thread, both pool
+    records requested before the first search) ends with the image and sensor state of the one-segment kernel -- and of the
+    oracle: rounds of 1000 photons (two workgroups per object, the last one ragged) and of 300 (a partial second segment)."""
+    from imsim_amd.engine import Renderer
+    from oracle import orc_loader
+    scene, objects = _c3_case(n_obj=200)
+    out = []
+    for two in ("1", "0"):
+        monkeypatch.setenv("IMS_ROUND_TWO_SEGMENTS", two)
+        r = Renderer(scene)
+        r.render_lsst_image(objects, nrecalc=nrecalc)
+        r.synchronize()
+        out.append((r.image_numpy(), _sensor_arrays_gpu(r)))
+    assert_bits_equal(out[0][0], out[1][0], "image")
+    for name in ("boundary", "bounds", "delta"):
+        assert_bits_equal(out[0][1][name], out[1][1][name], f"sensor {name}")
+    orc = orc_loader.OracleScene(scene)
+    orc.render_lsst_image(objects, nrecalc=nrecalc)
+    assert_bits_equal(out[0][0], orc.image, "image vs oracle")
+
+
 def test_tiled_initial_state_equals_the_per_cell_kernel(torch_cuda, monkeypatch):
     """k_init_tiles (every owned point evaluated once per tile, neighbours through LDS) writes the boundary points, bounds
     lines and delta image of k_init_boundaries (one thread per cell, neighbours recomputed) bit for bit: the static CCD

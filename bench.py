@@ -212,7 +212,8 @@ def main():
         # hipFFT's start-up (a fresh process's first plan of every transform size compiles its kernels: seconds) beside the
         # host's own start-up work, as a visit would do it beside reading its catalogs
         from imsim_amd import focal_plane
-        focal_plane.warm_fft(device)
+        if os.environ.get("IMS_BENCH_EARLY_WARM", "1") != "0":
+            focal_plane.warm_fft(device)
     if not cpu_first:
         scene, objects = build_inputs()
     # The renderer -- and with it the plan streams of the device -- comes BEFORE the RCCL communicator: measured with one rank

@@ -284,6 +284,8 @@ def load():
     # stream / RCCL plumbing), so both must sit on ONE HIP runtime instance: torch ships its own
     # libamdhip64 and must be loaded first, so that this library binds to the same copy.
     import torch  # noqa: F401
+    if torch.cuda.device_count() > 0:          # (counting devices does not initialise the GPU; a host without one makes no transforms)
+        tuning.fft_kernel_cache(os.path.join(os.path.dirname(_LIB_PATH), "rocfft_kernels.db"))
     lib = C.CDLL(_LIB_PATH)
     lib.ims_last_error.restype = C.c_char_p
     for k, st in enumerate(STRUCTS):

@@ -871,6 +871,15 @@ def _focal_streams(torch, device, peek=False, top_index=None):
             n_top = max(1, int(tuning.env("IMS_FOCAL_TOPS", "2")))
             st = _DEVICE_STREAMS[key] = {"next": 0, "top": [torch.cuda.Stream(device, priority=-1) for _ in range(n_top)],
                                          "bulk": torch.cuda.Stream(device), "mid": torch.cuda.Stream(device)}
+            order = tuning.env("IMS_FOCAL_TOUCH")
+            if order:
+                # the order in which the role streams are first used (HIP binds a stream to one of its hardware queues then)
+                for name in order.split(","):
+                    s = (torch.cuda.default_stream(device) if name == "null" else
+                         st["top"][int(name[3:]) % n_top] if name.startswith("top") else st[name])
+                    with torch.cuda.stream(s):
+                        torch.zeros(1, device=device)
+                    s.synchronize()
     n_top = len(st["top"])
     if top_index is not None:          # the caller deals the top streams itself (CCDs enqueued from several host threads)
         return (st["top"][top_index % n_top], st["bulk"], st["mid"], st["mid"], st["mid"])

@@ -46,6 +46,9 @@ KNOWN = {
     "IMS_EXCHANGE_SINGLE_RANK": ("0", "run the exchanges of a one-rank process group as self-exchanges"),
     # -- focal plane --
     "IMS_FOCAL_STREAMS": ("1", "four plan streams by role for all CCDs of a device; 0 = a set per renderer"),
+    "IMS_FOCAL_TOUCH": ("mid,top1,bulk,top0", "order in which the focal-plane role streams are first used, right where they are made (HIP binds a "
+                                             "stream to a hardware queue at its first use: C5 1.82 .. 1.95 s over the 24 orders, 2.4 s when "
+                                             "the FFT warm-up threads are the first users); empty = no touch"),
     "IMS_FOCAL_TOPS": ("2", "streams for the long top chains of a device"),
     "IMS_FOCAL_CONCURRENT": ("4", "bench C5: CCDs in flight on the rolling-window path"),
     "IMS_FOCAL_THREADS": ("1", "host threads that enqueue CCDs (rolling window)"),
@@ -77,6 +80,8 @@ KNOWN = {
     "IMS_BENCH_DUMP": (None, "bench.py: file that receives the last step's image (or per-CCD CRCs): the N-rank tests"),
     # -- files --
     "IMSIM_HIP_LIB": (None, "another build of the library (A/B measurements)"),
+    "ROCFFT_RTC_CACHE_PATH": (None, "rocFFT's file of run-time compiled kernels; unset: <user cache dir>/imsim_amd/rocfft_kernels.db (fft_kernel_cache)"),
+    "XDG_CACHE_HOME": (None, "the user's cache directory (default ~/.cache)"),
     "IMSIM_DATA_DIR": (None, "imSim's data directory"),
     "IMSIM_CONFIG_DIR": (None, "imSim's config directory (template lookup)"),
     "SIMS_SED_LIBRARY_DIR": (None, "the SED library of instance catalogs"),
@@ -109,6 +114,38 @@ def setdefault(name, value):
     if name not in KNOWN:
         raise KeyError(name)
     os.environ.setdefault(name, str(value))
+
+
+def fft_kernel_cache(seed=None):
+    """rocFFT compiles the kernels of a transform size at run time (0.5 - 1.4 s per size, profiles/round5_hipfft_plan_cost.log)
+    and keeps them in a file, by default under the home directory -- which a batch node's user may not have, and then every
+    process pays again.  Unless ROCFFT_RTC_CACHE_PATH is set, point it at <user cache dir>/imsim_amd/rocfft_kernels.db (the
+    temporary directory when the home is not writable), copied from `seed` (the package's lib/rocfft_kernels.db, made on a
+    GPU box by tools/make_fft_cache.py) when it does not exist yet.  With the kernels on file a plan costs 3 - 14 ms
+    (profiles/round5_c5_cold.log).  Called by _abi.load(), before the first plan.  Returns the path in use."""
+    import shutil
+    import tempfile
+    have = os.environ.get("ROCFFT_RTC_CACHE_PATH")
+    if have:
+        return have
+    roots = [os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"),
+             os.path.join(tempfile.gettempdir(), f"imsim_amd_{os.getuid()}")]
+    for root in roots:
+        d = os.path.join(root, "imsim_amd")
+        try:
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, "rocfft_kernels.db")
+            if not os.path.exists(path) and seed and os.path.exists(seed):
+                tmp = f"{path}.{os.getpid()}"
+                shutil.copyfile(seed, tmp)
+                os.replace(tmp, path)                    # (several ranks start at once: whole file or none)
+            elif not os.access(d, os.W_OK):
+                continue
+        except OSError:
+            continue
+        os.environ["ROCFFT_RTC_CACHE_PATH"] = path
+        return path
+    return None
 
 
 class Tuning(C.Structure):

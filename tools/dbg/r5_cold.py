@@ -13,6 +13,10 @@ from imsim_amd import configs, catalog, focal_plane  # noqa: E402
 from imsim_amd.engine import Renderer  # noqa: E402
 
 n_ccd = int(sys.argv[1]) if len(sys.argv) > 1 else 48
+t_start = time.perf_counter()
+torch.cuda.set_device(0)
+if os.environ.get("R5_COLD_IMMEDIATE", "0") != "1":
+    focal_plane.warm_fft("cuda:0")        # first thing, as config.Process and bench.py do: beside the host's own start-up work
 scene = configs.BENCH_CONFIGS["c5"]["scene"]()
 cat = configs._c5_catalog(n_ccd * 10000, scene, n_ccd=n_ccd)
 phot = catalog.realize_fluxes(cat["nominal_flux"], scene.seed)
@@ -20,6 +24,7 @@ objects, _ = configs._c5_objects(cat, phot, scene)
 r = Renderer(scene, "cuda:0")
 step = configs._c5_step(r, objects, concurrent=4)
 torch.cuda.synchronize()
+print(f"set-up (catalogs, object tables, jobs of the CCDs): {time.perf_counter() - t_start:.1f} s; ROCFFT_RTC_CACHE_PATH = {os.environ.get('ROCFFT_RTC_CACHE_PATH')}")
 pr = cProfile.Profile()
 t0 = time.perf_counter()
 pr.enable()

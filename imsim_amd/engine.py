@@ -1601,9 +1601,14 @@ class Renderer:
         """Run a trivial operation on every plan stream and wait for it: the streams then hold their hardware queues before
         anything else of the process (an RCCL communicator, say) brings streams of its own into use."""
         t = self.torch
-        for st in self.plan_streams:
-            with t.cuda.stream(st):
+        # IMS_STREAM_TOUCH: the order of first use (indices into Renderer.STREAMS; HIP binds a stream to a hardware queue then)
+        order = [int(v) for v in tuning.env("IMS_STREAM_TOUCH").split(",") if v != ""]
+        for k in order + [k for k in range(len(self.plan_streams)) if k not in order]:
+            if k >= len(self.plan_streams):
+                continue
+            with t.cuda.stream(self.plan_streams[k]):
                 t.zeros(1, device=self.device).add_(1.0)
+            self.plan_streams[k].synchronize()
         t.cuda.synchronize(self.device)
 
     # -- phase-screen pre-pass (ims_screen_prepass): the gathers of all photons of a render, in cache-friendly order --

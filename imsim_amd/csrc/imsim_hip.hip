@@ -35,7 +35,7 @@ static ims_tuning_t tuning_defaults()
     t.chain_kernels = 1; t.layout_kernels = 1; t.psf_screens_kernel = 1; t.photon_lds = -1;
     t.round_compact = 1; t.init_tiles = 1; t.upd_dpp = 1; t.joint_lists = 1;
     t.upd_dpp_max = 128; t.joint_list_min = 1024; t.active_fraction = 0.25;
-    t.round_two_segments = 0; t.pad = 0;
+    t.round_two_segments = 0; t.joint_fine_marks = 1;
     return t;
 }
 static ims_tuning_t g_tune = tuning_defaults();
@@ -164,6 +164,9 @@ __device__ __forceinline__ void mark_tile_charge(const ims_render_params_t& P, i
     unsigned char* tc = P.sensor->bf_tile_charge;
     if (tc == nullptr) return;
     tc[offset + (int64_t)(dj & ~15) * (nx + 1) + (di & ~15)] = (unsigned char)P.bf_tag;
+    // and which 4 x 4 block of it: the byte of the block's cell (1, 1) -- never a tile's first cell, and inside the region's
+    // (nx + 1) x (ny + 1) owner cells because (di & ~3) + 1 <= di + 1 <= nx.  Read by k_build_active_j.
+    tc[offset + (int64_t)((dj & ~3) + 1) * (nx + 1) + ((di & ~3) + 1)] = (unsigned char)P.bf_tag;
 }
 
 __device__ __forceinline__ void deposit_global(const ims_render_params_t& P, const ChargeTile& ct, int ix, int iy, double flux)
@@ -1659,8 +1662,16 @@ struct JointLists {
     int* count;                         // [parity][2]: entries of upd / ref
 };
 
+// fine: a tile that passes the test on the tile marks is looked at block by block (mark_tile_charge: 4 x 4 pixels).  The update
+// of tile [tx0, tx0 + 15]^2 reads the delta charge of [tx0 - 4, tx0 + 18]^2 (update_tile_q3: Q = 3) and changes nothing without
+// charge there; those are the blocks -1 .. 4 of the tile in x and y.  The bounds of the tile's pixels also hang on the first
+// column of the right tile and the first row of the upper one, which move with charge in [tx0 + 12, tx0 + 19] x [ty0 - 4, ty0 + 18]
+// (and transposed): blocks 3 .. 4, inside the same window.  So ONE test decides both lists, and a lone electron in the wings of
+// a star lists the one or two tiles within four pixels of it instead of nine.  Tiles that are listed do what they did; tiles
+// that are no longer listed would have found no charge in their halo and left (update_tile_q3: !any_charge) -- their `changed`
+// bytes stay as they are, which can make the refresh of a LATER round recompute bounds that did not move (same bits).
 __global__ __launch_bounds__(256) void k_build_active_j(const JointUpd* __restrict__ U, const JointRound* __restrict__ R,
-                                                        unsigned int tag, const JointLists Ls, int parity)
+                                                        unsigned int tag, const JointLists Ls, int parity, int fine)
 {
     int bb = (int)blockIdx.x;
     const int c = joint_chain(&R->ewg, bb);
@@ -1705,6 +1716,31 @@ __global__ __launch_bounds__(256) void k_build_active_j(const JointUpd* __restri
         const bool right_in = tx + 1 < tiles_x && (m & right_w) != 0u;
         const bool up_in = ty + 1 < tiles_y && (m & up_w) != 0u;
         bounds = in_reach || right_in || up_in;
+        if (fine && bounds) {
+            // charge in the tile itself is in reach; otherwise only the blocks of the marked neighbours that touch this tile are
+            // looked at (an edge neighbour's four, a corner neighbour's one): 1 .. 20 bytes instead of the window's 36
+            bool any = (m & (1u << 5)) != 0u;
+            if (!any) {
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        if ((dx == 0 && dy == 0) || !(m & (1u << ((dy + 1) * 4 + (dx + 1))))) continue;
+                        const int bx0 = dx < 0 ? -1 : (dx > 0 ? 4 : 0), bx1 = dx < 0 ? -1 : (dx > 0 ? 4 : 3);
+                        const int by0 = dy < 0 ? -1 : (dy > 0 ? 4 : 0), by1 = dy < 0 ? -1 : (dy > 0 ? 4 : 3);
+                        for (int by = by0; by <= by1; ++by) {
+                            const int cy = ty * UT + by * 4 + 1;
+                            if (cy < 0 || cy > sl.ny) continue;
+                            for (int bx = bx0; bx <= bx1; ++bx) {
+                                const int cx = tx * UT + bx * 4 + 1;
+                                if (cx < 0 || cx > sl.nx) continue;
+                                any = any || (s.bf_tile_charge[cell_index(sl, cx, cy)] == tg);
+                            }
+                        }
+                    }
+            }
+            in_reach = any; bounds = any;
+        }
     }
     const unsigned long long entry = ((unsigned long long)c << 58) | ((unsigned long long)(unsigned int)my_lo << 32) | (unsigned int)my_t;
     {
@@ -3641,7 +3677,7 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
             if (grid < 256 && list_fraction >= 0.05) grid = 256;
             if (grid < 1) grid = 1;
             if (grid > tiles) grid = tiles;
-            hipLaunchKernelGGL(k_build_active_j, dim3((unsigned)build_wgs), dim3(256), 0, js, U, R, tag, Ls, parity);
+            hipLaunchKernelGGL(k_build_active_j, dim3((unsigned)build_wgs), dim3(256), 0, js, U, R, tag, Ls, parity, (int)g_tune.joint_fine_marks);
             hipLaunchKernelGGL((k_update_list_j<4, false>), dim3((unsigned)grid), dim3(256), 0, js, U, Ls, parity, tag);
             hipLaunchKernelGGL(k_refresh_list_j<4>, dim3((unsigned)grid), dim3(256), 0, js, U, Ls, parity, tag);
         } else if (tiles > 0) {

@@ -433,7 +433,8 @@ typedef struct ims_tuning {
     double  active_fraction;     /* 0.25: workgroups launched per tile of a round for the list walkers (0 < f <= 1) */
     int32_t round_two_segments;  /* 0; 1: the pixel search of a round takes two 256-photon segments per workgroup, both pool records
                                     requested before the first search (measured: EXPERIMENTS.md, round 5) */
-    int32_t pad;
+    int32_t joint_fine_marks;    /* 1: the lists of a joint round are built from charge marks per 4 x 4 pixels (a tile is listed when
+                                    charge lies within the update's reach of it, not when one of its 3 x 3 tile neighbours holds some) */
 } ims_tuning_t;
 int  ims_tuning_defaults(ims_tuning_t* out);
 int  ims_get_tuning(ims_tuning_t* out);

@@ -869,11 +869,15 @@ def _focal_streams(torch, device, peek=False, top_index=None):
             # IMS_FOCAL_TOPS (default 2): streams for the long top chains; more than two only pays with more hardware queues
             # (GPU_MAX_HW_QUEUES) than HIP's default four
             n_top = max(1, int(tuning.env("IMS_FOCAL_TOPS", "2")))
+            # ("pre": the joint path's stream of a CCD's FFT draws, initial states and first pool slices -- wide work at normal
+            # priority, focal_plane._render_joint)
             st = _DEVICE_STREAMS[key] = {"next": 0, "top": [torch.cuda.Stream(device, priority=-1) for _ in range(n_top)],
-                                         "bulk": torch.cuda.Stream(device), "mid": torch.cuda.Stream(device)}
+                                         "bulk": torch.cuda.Stream(device), "mid": torch.cuda.Stream(device),
+                                         "pre": torch.cuda.Stream(device)}
             order = tuning.env("IMS_FOCAL_TOUCH")
             if order:
-                # the order in which the role streams are first used (HIP binds a stream to one of its hardware queues then)
+                # the order in which the role streams are first used (HIP binds a stream to one of its hardware queues then:
+                # queue = index of first use mod 4, EXPERIMENTS round 5)
                 for name in order.split(","):
                     s = (torch.cuda.default_stream(device) if name == "null" else
                          st["top"][int(name[3:]) % n_top] if name.startswith("top") else st[name])

@@ -44,10 +44,8 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
     if tuning.env("IMS_FOCAL_PRE_PRIORITY", "0") == "0":
         # `pre` carries wide work (FFT draws, the regions' initial state, first pool slices): at the priority of the joint rounds it
         # competes with them for every wave slot -- at normal priority C5 takes 10.0 instead of 10.9 ms per CCD
-        key = ("focal-pre", str(dev))
-        if key not in _ANCHOR_STREAMS:
-            _ANCHOR_STREAMS[key] = [torch.cuda.Stream(dev)]
-        pre = _ANCHOR_STREAMS[key][0]
+        from .engine import _DEVICE_STREAMS
+        pre = _DEVICE_STREAMS[("focal", str(dev))]["pre"]        # made (and first used) with the other role streams
     # IMS_FOCAL_FFT (here: mid; bulk; top = ahead of the plan on `pre`): the stream of a CCD's FFT-drawn objects, beside its plan.
     # Measured on C5 with the renderer's initialisation on `pre` (IMS_FOCAL_JOINT_INIT): mid 9.4, bulk 9.5, top 9.6 ms per CCD
     # (10.0 with the initialisation on the bulk stream)

@@ -48,9 +48,10 @@ KNOWN = {
     "IMS_EXCHANGE_SINGLE_RANK": ("0", "run the exchanges of a one-rank process group as self-exchanges"),
     # -- focal plane --
     "IMS_FOCAL_STREAMS": ("1", "four plan streams by role for all CCDs of a device; 0 = a set per renderer"),
-    "IMS_FOCAL_TOUCH": ("mid,top1,bulk,top0", "order in which the focal-plane role streams are first used, right where they are made (HIP binds a "
-                                             "stream to a hardware queue at its first use: C5 1.82 .. 1.95 s over the 24 orders, 2.4 s when "
-                                             "the FFT warm-up threads are the first users); empty = no touch"),
+    "IMS_FOCAL_TOUCH": ("mid,top0,pre,bulk", "order in which the focal-plane role streams (top0 = joint rounds, pre, bulk, mid) are first used, right "
+                                            "where they are made (HIP binds a stream to a hardware queue at its first use, queue = index mod 4: "
+                                            "with all four used there C5 takes 1.74 .. 1.79 s in any order, 2.4 s when the FFT warm-up threads "
+                                            "come first); empty = no touch"),
     "IMS_FOCAL_TOPS": ("2", "streams for the long top chains of a device"),
     "IMS_FOCAL_CONCURRENT": ("4", "bench C5: CCDs in flight on the rolling-window path"),
     "IMS_FOCAL_THREADS": ("1", "host threads that enqueue CCDs (rolling window)"),

@@ -21,7 +21,7 @@ def test_flag_and_number_follow_the_environment(monkeypatch):
     monkeypatch.setenv("IMS_FOCAL_TOUCH", "")                    # set but empty: no touch, not the default order
     assert tuning.env("IMS_FOCAL_TOUCH") == ""
     monkeypatch.delenv("IMS_FOCAL_TOUCH")
-    assert sorted(tuning.env("IMS_FOCAL_TOUCH").split(",")) == ["bulk", "mid", "top0", "top1"]
+    assert sorted(tuning.env("IMS_FOCAL_TOUCH").split(",")) == ["bulk", "mid", "pre", "top0"]
 
 
 def test_fft_kernel_file_is_seeded_once_and_an_explicit_path_wins(tmp_path, monkeypatch):

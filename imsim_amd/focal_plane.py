@@ -251,7 +251,13 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
     awaiting = []                       # batches whose tails are enqueued, oldest first
     pending = list(order)
 
-    def joint_runs(entries):
+    # IMS_FOCAL_JOINT_STREAMS (default 1): the top classes of consecutive batches on that many high-priority streams in turn (two
+    # batches' rounds side by side: a round is a chain of four dependent launches of latency-bound workgroups)
+    n_js = max(1, int(tuning.env("IMS_FOCAL_JOINT_STREAMS")))
+    joint_streams = [_focal_streams(torch, dev, top_index=k)[0] for k in range(n_js)]
+    batch_no = [0]
+
+    def joint_runs(entries, st_joint=st_joint):
         """both joint runs of a batch (worker thread); returns the events behind them"""
         torch.cuda.set_device(dev)
         left = [e["plan"] for e in entries if e["plan"] is not None and getattr(e["plan"], "deferred", 0)]
@@ -270,8 +276,10 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
         return len(left), (ev_mid, ev_top)
 
     def start_rounds(entries):
+        js = joint_streams[batch_no[0] % n_js]
+        batch_no[0] += 1
         if worker is not None:
-            rounds.append(dict(entries=entries, future=worker.submit(joint_runs, entries)))
+            rounds.append(dict(entries=entries, future=worker.submit(joint_runs, entries, js)))
         else:
             class _Done:
                 def __init__(self, v):
@@ -282,7 +290,7 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
 
                 def result(self):
                     return self.v
-            rounds.append(dict(entries=entries, future=_Done(joint_runs(entries))))
+            rounds.append(dict(entries=entries, future=_Done(joint_runs(entries, js))))
 
     def service(block_oldest=False, block_all=False):
         """move batches along without waiting: tails for batches whose rounds have run, collection of batches whose copies are
@@ -318,8 +326,9 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
                 # the arena's private pool is dry: wait for the cells of the oldest batch alive, else this batch ends here
                 if rounds or awaiting:
                     if not awaiting:
-                        service(block_oldest=True)
-                    collect(awaiting.pop(0))
+                        service(block_oldest=True)         # (may collect the batch itself when its copies are through already)
+                    if awaiting:
+                        collect(awaiting.pop(0))
                     continue
                 if cur:
                     break
@@ -413,7 +422,8 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
         heavy = bright > int(tuning.env("IMS_FOCAL_JOINT_MAX_BRIGHT", "600"))
         if not heavy and joint > 1 and tuning.env("IMS_NATIVE_PLAN", "1") != "0":
             torch.cuda.set_device(dev)
-            return _render_joint(mine, build, dev, nrecalc, sink, post, min(joint, 64), chain_hint)
+            with tuning.scoped(IMS_PHOTON_LDS=tuning.env("IMS_FOCAL_PHOTON_LDS")):
+                return _render_joint(mine, build, dev, nrecalc, sink, post, min(joint, 64), chain_hint)
     # the anchor streams are kept per device for the life of the process: PyTorch's caching allocator files a freed block
     # under the stream it was allocated on, so fresh streams per call would miss the cache and hipMalloc every CCD's
     # gigabytes of sensor state again (measured: 13 -> 27 .. 34 ms per CCD for the calls that do)

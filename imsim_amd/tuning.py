@@ -69,8 +69,11 @@ KNOWN = {
     "IMS_FOCAL_ARENA_CELLS": (None, "the arena's private pool in owner cells (tests: a pool that runs dry)"),
     "IMS_FOCAL_ARENA_FACTOR": ("0.8", "private cells per CCD the arena's pool is sized for, as a multiple of the first CCD's need"),
     "IMS_FOCAL_STATIC_REGIONS": ("3", "static regions of the arena, taken in turn"),
-    "IMS_FOCAL_ALIVE": ("2", "joint path: batches alive at a time (one in its rounds and tails, one being enqueued; 3 measured no faster "
-                             "-- C5 9.39 against 9.43 ms per CCD -- and costs a third more memory and first-call allocation time)"),
+    "IMS_FOCAL_ALIVE": ("4", "joint path: batches alive at a time (in their rounds and tails, being enqueued).  With every role stream on a "
+                             "hardware queue of its own: 2 -> 1.77 s, 3 -> 1.67, 4 -> 1.68 (1.54 with IMS_FOCAL_PHOTON_LDS), 5 -> 1.61 with it"),
+    "IMS_FOCAL_PHOTON_LDS": ("41984", "joint path: IMS_PHOTON_LDS while a focal plane renders -- the photon kernels capped at three workgroups "
+                                      "per CU leave wave slots to the rounds (C5 1.68 -> 1.54 s); empty = as elsewhere"),
+    "IMS_FOCAL_JOINT_STREAMS": ("1", "joint path: high-priority streams that take the top-class rounds of consecutive batches in turn"),
     "IMS_FOCAL_JOINT_THREAD": ("1", "joint path: the rounds of a batch are enqueued by a second host thread while the first goes on with the next fronts"),
     "IMS_FOCAL_DIRECT_COPY": ("0", "joint path: 1 = the finished image rounded straight into page-locked host memory by one small launch "
                                    "(measured slower: C5 1.91 against 1.78 s); 0 = image_float + copy"),
@@ -91,14 +94,45 @@ KNOWN = {
 }
 
 
+_SCOPED = {}                  # switches a caller set for the duration of a call (scoped): below the environment, above the defaults
+
+
 def env(name, default=None):
-    """The value of a known switch: the environment's, else `default` when given, else the listed default."""
+    """The value of a known switch: the environment's, else what a caller set for the time being (scoped), else `default` when
+    given, else the listed default."""
     if name not in KNOWN:
         raise KeyError(f"tuning.env: {name!r} is not a known switch (imsim_amd/tuning.py lists them)")
     v = os.environ.get(name)
     if v is not None:
         return v
+    if name in _SCOPED:
+        return _SCOPED[name]
     return default if default is not None else KNOWN[name][0]
+
+
+class scoped:
+    """`with tuning.scoped(IMS_PHOTON_LDS="41984"): ...` -- defaults of this process while the block runs (the environment still
+    wins; None or "" leaves a switch alone).  Process-wide, like the library's tuning block it ends up in: for callers that own
+    the device for the duration (a focal plane), not for concurrent renders with different wishes."""
+    def __init__(self, **values):
+        for k in values:
+            if k not in KNOWN:
+                raise KeyError(k)
+        self.values = {k: str(v) for k, v in values.items() if v is not None and str(v) != ""}
+        self.before = {}
+
+    def __enter__(self):
+        self.before = {k: _SCOPED.get(k) for k in self.values}
+        _SCOPED.update(self.values)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.before.items():
+            if v is None:
+                _SCOPED.pop(k, None)
+            else:
+                _SCOPED[k] = v
+        return False
 
 
 def flag(name, default=None):

@@ -697,18 +697,49 @@ __device__ __forceinline__ void empty_owned(const ims_sensor_t& s, int n, double
     x = 0.0; y = s.emptypoly[2 * (1 + m)];
 }
 
-__device__ __forceinline__ double treering_shift(const ims_sensor_t& s, double r)
+// What the tree-ring closed form needs of the sensor block, read ONCE per thread.  (Read through `s` at every evaluation, the
+// stores in between -- the state arrays hang off the same block -- made the compiler reload the block and redo everything that
+// depends on tr_dr alone: the Newton steps of 1 / tr_dr and the IEEE division tr_dr^2 / 6, ~30 of an evaluation's ~115 VALU
+// instructions, twenty evaluations per cell in k_init_tiles; SQ_INSTS_VALU of round 5: the initial state was 24 % of a focal
+// plane's VALU work.)  Same operations on the same operands: same bits.
+struct TreeRing {
+    double dr, dr_y, h2, cx, cy;
+    const double* table;
+    const double* table2;
+    int n;
+};
+
+__device__ __forceinline__ TreeRing treering_of(const ims_sensor_t& s)
 {
-    if (s.n_tr <= 0) return 0.0;
-    const double f = ddiv(r, s.tr_dr);
-    if (!(f > 0.0) || f >= (double)(s.n_tr - 1)) return 0.0;
+    TreeRing T;
+    T.n = s.n_tr; T.dr = s.tr_dr; T.cx = s.tr_cx; T.cy = s.tr_cy; T.table = s.tr_table; T.table2 = s.tr_table2;
+    T.dr_y = 0.0; T.h2 = 0.0;
+    if (T.n > 0) {
+        // the part of ddiv(r, dr) that does not depend on r (ims_math.h: two Newton steps on the reciprocal seed)
+        double y = __builtin_amdgcn_rcp(T.dr);
+        double e = fma(-T.dr, y, 1.0);
+        y = fma(y, e, y);
+        e = fma(-T.dr, y, 1.0);
+        T.dr_y = fma(y, e, y);
+        T.h2 = T.dr * T.dr / 6.0;
+    }
+    return T;
+}
+
+__device__ __forceinline__ double treering_shift(const TreeRing& T, double r)
+{
+    if (T.n <= 0) return 0.0;
+    // ddiv(r, dr) with the reciprocal prepared above
+    const double q = r * T.dr_y;
+    const double rem = fma(-T.dr, q, r);
+    const double f = fma(rem, T.dr_y, q);
+    if (!(f > 0.0) || f >= (double)(T.n - 1)) return 0.0;
     const int i = (int)f;
     const double b = f - (double)i;
-    const double v0 = s.tr_table[i], v1 = s.tr_table[i + 1];
-    if (s.tr_table2 == nullptr) return v0 + b * (v1 - v0);
+    const double v0 = T.table[i], v1 = T.table[i + 1];
+    if (T.table2 == nullptr) return v0 + b * (v1 - v0);
     const double a = 1.0 - b;
-    const double h2 = s.tr_dr * s.tr_dr / 6.0;
-    return a * v0 + b * v1 + ((a * a * a - a) * s.tr_table2[i] + (b * b * b - b) * s.tr_table2[i + 1]) * h2;
+    return a * v0 + b * v1 + ((a * a * a - a) * T.table2[i] + (b * b * b - b) * T.table2[i + 1]) * T.h2;
 }
 
 // The boundary kernels run over a RANGE of slots in one launch: thread -> global owner cell ->
@@ -737,14 +768,15 @@ __device__ __forceinline__ CellRef locate_cell(const ims_sensor_t& s, int first_
 }
 
 // owned boundary point n of owner cell (ci, cj) in its undistorted-plus-tree-ring state (pixel-local coordinates)
-__device__ __forceinline__ void init_point(const ims_sensor_t& s, const SlotView& sl, int ci, int cj, int n, double& px, double& py)
+__device__ __forceinline__ void init_point(const ims_sensor_t& s, const TreeRing& T, const SlotView& sl, int ci, int cj, int n,
+                                           double& px, double& py)
 {
     double ex, ey;
     empty_owned(s, n, ex, ey);
-    const double tx = ((double)(sl.xmin + ci) - 0.5 + ex) - s.tr_cx;
-    const double ty = ((double)(sl.ymin + cj) - 0.5 + ey) - s.tr_cy;
+    const double tx = ((double)(sl.xmin + ci) - 0.5 + ex) - T.cx;
+    const double ty = ((double)(sl.ymin + cj) - 0.5 + ey) - T.cy;
     const double rr = dsqrt0(tx * tx + ty * ty);
-    const double sh = treering_shift(s, rr);
+    const double sh = treering_shift(T, rr);
     px = ex; py = ey;
     if (rr > 0.0 && sh != 0.0) { px = ex + ddiv(sh * tx, rr); py = ey + ddiv(sh * ty, rr); }
 }
@@ -759,11 +791,12 @@ __global__ __launch_bounds__(256) void k_init_boundaries(const ims_sensor_t* __r
     const CellRef r = locate_cell(s, first_slot, n_slots, cell_begin, cell_count);
     if (!r.valid) return;
     const SlotView& sl = r.sl;
+    const TreeRing T = treering_of(s);
     const int nV = s.num_vertices, npo = 2 * nV + 2, nv = 4 * nV + 4;
     double* pts = s.bf_boundary + (sl.offset + r.c) * npo * 2;
     for (int n = 0; n < npo; ++n) {
         double px, py;
-        init_point(s, sl, r.i, r.j, n, px, py);
+        init_point(s, T, sl, r.i, r.j, n, px, py);
         pts[2 * n] = px; pts[2 * n + 1] = py;
     }
     s.bf_delta[sl.offset + r.c] = 0.0;
@@ -781,7 +814,7 @@ __global__ __launch_bounds__(256) void k_init_boundaries(const ims_sensor_t* __r
         else if (k <= 3 * nV + 3) { cj = j + 1; ay = 1.0; q = nV + 1 - (k - 2 * nV - 2); }
         else { q = nV + 2 + (nV - 1 - (k - 3 * nV - 4)); }
         double vx, vy;
-        init_point(s, sl, ci, cj, q, vx, vy);
+        init_point(s, T, sl, ci, cj, q, vx, vy);
         vx = vx + ax; vy = vy + ay;
         if (k == 0) v0x = vx;
         if (vx < oxmin) oxmin = vx;
@@ -830,6 +863,7 @@ __global__ __launch_bounds__(256) void k_init_tiles(const ims_sensor_t* __restri
     const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
     const int tiles_x = (sl.nx + 1 + UT - 1) / UT, tiles_y = (sl.ny + 1 + UT - 1) / UT;
     if (t >= tiles_x * tiles_y) return;
+    const TreeRing T = treering_of(s);
     const int lx = threadIdx.x % UT, ly = threadIdx.x / UT;
     const int tx0 = (t % tiles_x) * UT, ty0 = (t / tiles_x) * UT;
     const int i = tx0 + lx, j = ty0 + ly;
@@ -838,7 +872,7 @@ __global__ __launch_bounds__(256) void k_init_tiles(const ims_sensor_t* __restri
     if (owner) {
 #pragma unroll
         for (int n = 0; n < IT_NPO; ++n) {
-            init_point(s, sl, i, j, n, own[n].x, own[n].y);
+            init_point(s, T, sl, i, j, n, own[n].x, own[n].y);
             P[(ly * UT + lx) * IT_NPO + n] = own[n];
         }
         s.bf_delta[cell_index(sl, i, j)] = 0.0;
@@ -865,14 +899,14 @@ __global__ __launch_bounds__(256) void k_init_tiles(const ims_sensor_t* __restri
             for (int m = 0; m < IT_NV; ++m) rgt[m] = P[(ly * UT + lx + 1) * IT_NPO + IT_NV + 2 + m];
         } else {
 #pragma unroll
-            for (int m = 0; m < IT_NV; ++m) init_point(s, sl, i + 1, j, IT_NV + 2 + m, rgt[m].x, rgt[m].y);
+            for (int m = 0; m < IT_NV; ++m) init_point(s, T, sl, i + 1, j, IT_NV + 2 + m, rgt[m].x, rgt[m].y);
         }
         if (ly + 1 < UT) {
 #pragma unroll
             for (int q = 0; q <= IT_NV + 1; ++q) upp[q] = P[((ly + 1) * UT + lx) * IT_NPO + q];
         } else {
 #pragma unroll
-            for (int q = 0; q <= IT_NV + 1; ++q) init_point(s, sl, i, j + 1, q, upp[q].x, upp[q].y);
+            for (int q = 0; q <= IT_NV + 1; ++q) init_point(s, T, sl, i, j + 1, q, upp[q].x, upp[q].y);
         }
         double ixmin = 0.0, ixmax = 1.0, iymin = 0.0, iymax = 1.0;
         double oxmin = 0.0, oxmax = 1.0, oymin = 0.0, oymax = 1.0;

@@ -369,7 +369,7 @@ def warm_fft(device="cuda:0"):
     from . import fft_draw
     from .engine import _focal_streams
     dev = torch.device(device)
-    if tuning.env("IMS_FOCAL_STREAMS") == "0" or int(tuning.env("IMS_FOCAL_JOINT")) <= 1:
+    if tuning.env("IMS_FOCAL_STREAMS") == "0" or int(tuning.env("IMS_FOCAL_JOINT")) <= 1 or not tuning.flag("IMS_FFT_WARM"):
         return None
     torch.cuda.set_device(dev)
     pre, bulk, mid = _focal_streams(torch, dev, top_index=1)[:3]

@@ -372,8 +372,11 @@ def main():
     # 1024 SIMDs at 2.4 GHz, against the measured step -- the figure that says how far the step is from its own arithmetic
     pstep = profile_entry(args.config, "_step", world)
     if pstep:
-        floor_ms = pstep["valu_wave_insts_per_step"] / (256 * 4 * 2.4e9 / 4.0) * 1e3
-        roofline["step"] = {"valu_wave_insts": pstep["valu_wave_insts_per_step"], "floor_ms": floor_ms,
+        insts = pstep.get("valu_wave_insts_per_step")
+        if insts is None:                       # a focal plane: counted per CCD render on a part of the visit
+            insts = pstep["valu_wave_insts_per_ccd"] * getattr(step, "n_ccds", 1)
+        floor_ms = insts / (256 * 4 * 2.4e9 / 4.0) * 1e3
+        roofline["step"] = {"valu_wave_insts": insts, "floor_ms": floor_ms,
                             "frac": floor_ms / ms_per_step, "ms_per_step": ms_per_step, "source": pstep.get("sq_source"),
                             "note": "VALU issue floor of ALL kernels of one step / the measured step"}
     # The other large kernel of a step with brighter-fatter chains is the pixel search of the rounds (k_accumulate_round): its

@@ -6,7 +6,7 @@ R=$PWD
 mkdir -p $R/gpurun_out
 export IMS_FOCAL_JOINT_THREAD=0 IMS_FFT_WARM=0
 cd /tmp && export TMPDIR=/tmp
-for N in 96 48; do
+for N in 48; do
   export IMS_C5_CCDS=$N
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES -d $R/gpurun_out/round5_c5_pmc_SQ --output-format csv -- python3 $R/bench.py --config c5 --no-extra-configs --steps 2 --warmup 1 --no-cpu-baseline --no-cold > $R/gpurun_out/round5_c5_pmc_SQ.log 2>&1
   rc=$?

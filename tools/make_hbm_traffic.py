@@ -67,6 +67,12 @@ def main():
             total = sum(v["SQ_INSTS_VALU"]["sum"] for v in sq.values() if "SQ_INSTS_VALU" in v)
             out.setdefault(cfg, {})["_step"] = {"valu_wave_insts_per_step": total / steps, "steps_sampled": steps, "sq_source": sq_src,
                                                 "note": "sum of SQ_INSTS_VALU over all kernels of the run / its steps"}
+        if steps > 0 and cfg == "c5":
+            # a focal plane: one fused launch per CCD render; the counters were taken on a part of the visit (the profiler's counter
+            # pass does not survive the whole one), so the figure kept is per CCD and bench.py multiplies by the CCDs of its step
+            total = sum(v["SQ_INSTS_VALU"]["sum"] for v in sq.values() if "SQ_INSTS_VALU" in v)
+            out.setdefault(cfg, {})["_step"] = {"valu_wave_insts_per_ccd": total / steps, "ccd_renders_sampled": steps, "sq_source": sq_src,
+                                                "note": "sum of SQ_INSTS_VALU over all kernels of the run / its CCD renders"}
     json.dump(out, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 

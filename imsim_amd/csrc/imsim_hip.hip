@@ -35,7 +35,7 @@ static ims_tuning_t tuning_defaults()
     t.chain_kernels = 1; t.layout_kernels = 1; t.psf_screens_kernel = 1; t.photon_lds = -1;
     t.round_compact = 1; t.init_tiles = 1; t.upd_dpp = 1; t.joint_lists = 1;
     t.upd_dpp_max = 128; t.joint_list_min = 1024; t.active_fraction = 0.25;
-    t.round_two_segments = 0; t.joint_fine_marks = 1;
+    t.round_two_segments = 0; t.joint_fine_marks = 1; t.joint_search_lists = 1; t.pad = 0;
     return t;
 }
 static ims_tuning_t g_tune = tuning_defaults();
@@ -140,20 +140,42 @@ __device__ __forceinline__ void make_photon(const ims_render_params_t& P, const 
 // f64 image directly, so no rounding to binary32 happens anywhere on its way.
 constexpr int CT = 32;
 
+// Joint rounds whose update / refresh walk LISTS of tiles: the pixel search appends a tile the first time charge lands within the
+// update's reach of it (k_accumulate_round_j; ims_tuning_t.joint_search_lists), instead of a launch of its own that scans the
+// charge marks of every tile of every region afterwards (k_build_active_j: 13 - 32 us of every round of a joint run).
+struct JointAcc;
+struct JointRound;
+struct TileLister {
+    unsigned long long* list;          // entries: chain << 58 | slot of the class << 32 | tile of the slot; NULL: no listing this round
+    int* count;                        // entries so far (this round's parity)
+    const JointAcc* J;                 // per chain: tile words, tiles before each slot of the class, the class's first slot
+    const JointRound* R;               // per chain: tiles of the regions that go on after this round (only those are updated)
+    int chain;
+    unsigned int round_word;           // this round + 1
+};
+// (resolved where the lists are written, at the end of the workgroup: kept live through the pixel search, the chain's table
+// entries cost the search kernel its register allocation -- 96 registers and scratch instead of 93)
+struct TileListerChain { unsigned int* words; int64_t tile_base; int lo; bool on; };
+__device__ __forceinline__ TileListerChain lister_chain(const TileLister& L, int slot_idx);
+
 struct ChargeTile {
     int x0, y0;                // pixel coordinates of tile cell (0,0)
     bool track;                // also add to the slot's delta image
     ims_bf_slot_t slot;
+    TileLister lister;         // joint rounds with search-side lists (by value: through a pointer the block lived in scratch); list == NULL: off
+    int slot_idx;              // the region's slot
 };
 
 __device__ __forceinline__ void tile_begin(float* tile, ChargeTile& ct, const ims_render_params_t& P, const ims_object_t& o,
-                                           bool silicon, int n_thr = 256)
+                                           bool silicon, int n_thr = 256, const TileLister* lister = nullptr)
 {
     for (int e = threadIdx.x; e < CT * CT; e += n_thr) tile[e] = 0.0f;
     ct.x0 = (int)floor(o.x0 + 0.5) - CT / 2;
     ct.y0 = (int)floor(o.y0 + 0.5) - CT / 2;
     ct.track = silicon && !(o.flags & IMS_OBJ_FAINT) && (o.bf_state > 0 || P.track_static_delta);
-    if (ct.track) ct.slot = P.sensor->bf_slots[slot_index(P, o)];
+    ct.lister.list = nullptr; ct.slot_idx = 0;
+    if (ct.track) { ct.slot_idx = slot_index(P, o); ct.slot = P.sensor->bf_slots[ct.slot_idx]; }
+    if (ct.track && lister != nullptr && lister->list != nullptr) ct.lister = *lister;
     __syncthreads();
 }
 
@@ -169,7 +191,37 @@ __device__ __forceinline__ void mark_tile_charge(const ims_render_params_t& P, i
     tc[offset + (int64_t)((dj & ~3) + 1) * (nx + 1) + ((di & ~3) + 1)] = (unsigned char)P.bf_tag;
 }
 
-__device__ __forceinline__ void deposit_global(const ims_render_params_t& P, const ChargeTile& ct, int ix, int iy, double flux)
+// Charge landed on pixel (di, dj) of the region: list every tile whose update or bounds refresh can depend on it and that no
+// deposit of this round has listed yet.  The update of tile [tx0, tx0 + 15]^2 reads the delta charge of [tx0 - 4, tx0 + 18]^2, the
+// bounds of its pixels also hang on the first column / row of the right / upper tile, which move with charge up to tx0 + 19: the
+// tiles tx with tx0 - 4 <= di <= tx0 + 19, the same in y -- one, two or four tiles.  A tile's word holds the last round that
+// listed it: the exchange decides who appends (a stale plain read only costs the exchange).
+__device__ __forceinline__ void list_tiles_in_reach(const ChargeTile& ct, int di, int dj)
+{
+    const TileLister& L = ct.lister;
+    const TileListerChain C = lister_chain(L, ct.slot_idx);
+    if (!C.on) return;
+    const int tiles_x = (ct.slot.nx + 1 + 15) >> 4, tiles_y = (ct.slot.ny + 1 + 15) >> 4;
+    int ax = (di - 4) >> 4, bx = (di + 4) >> 4, ay = (dj - 4) >> 4, by = (dj + 4) >> 4;
+    if (ax < 0) ax = 0;
+    if (ay < 0) ay = 0;
+    if (bx > tiles_x - 1) bx = tiles_x - 1;
+    if (by > tiles_y - 1) by = tiles_y - 1;
+    for (int ty = ay; ty <= by; ++ty)
+        for (int tx = ax; tx <= bx; ++tx) {
+            const int t = ty * tiles_x + tx;
+            unsigned int* w = C.words + (C.tile_base + t);
+            if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == L.round_word) continue;
+            if (atomicExch(w, L.round_word) == L.round_word) continue;
+            const int k = atomicAdd(L.count, 1);
+            L.list[k] = ((unsigned long long)L.chain << 58) | ((unsigned long long)(unsigned int)C.lo << 32) | (unsigned int)t;
+        }
+}
+
+// list_now: the deposit lists its tiles itself (the stragglers outside the workgroup's LDS tile); the flush of the LDS tile
+// collects the tiles of all its deposits first (tile_flush)
+__device__ __forceinline__ void deposit_global(const ims_render_params_t& P, const ChargeTile& ct, int ix, int iy, double flux,
+                                               bool list_now = true)
 {
     const int px = ix - P.xmin, py = iy - P.ymin;
     if (px >= 0 && px < P.nx && py >= 0 && py < P.ny) unsafeAtomicAdd(P.image + ((int64_t)py * P.nx + px), flux);
@@ -178,6 +230,7 @@ __device__ __forceinline__ void deposit_global(const ims_render_params_t& P, con
         if (di >= 0 && di < ct.slot.nx && dj >= 0 && dj < ct.slot.ny) {
             unsafeAtomicAdd(P.sensor->bf_delta + (ct.slot.offset + (int64_t)dj * (ct.slot.nx + 1) + di), flux);
             mark_tile_charge(P, ct.slot.offset, ct.slot.nx, di, dj);
+            if (list_now && ct.lister.list != nullptr) list_tiles_in_reach(ct, di, dj);
         }
     }
 }
@@ -192,12 +245,62 @@ __device__ __forceinline__ void tile_deposit(float* tile, const ChargeTile& ct, 
 
 __device__ __forceinline__ void tile_flush(float* tile, const ChargeTile& ct, const ims_render_params_t& P, int n_thr = 256)
 {
+    // search-side lists: the deposits of the 32 x 32 LDS tile reach at most 4 x 4 tiles of the region (pixels d0 - 4 .. d0 + 35):
+    // their bits are collected in LDS, then ONE lane per tile in reach asks the tile's word, and ONE atomic per workgroup makes
+    // room in the list (a deposit-by-deposit form spent the round in exchanges and in additions to the one counter)
+    __shared__ unsigned int reach_bits;
+    __shared__ int n_new, base_new;
+    __shared__ int new_tile[16];
+    const bool listing = ct.lister.list != nullptr;      // uniform over the workgroup (one object, one slot)
+    if (listing && threadIdx.x == 0) { reach_bits = 0u; n_new = 0; }
     __syncthreads();
     PROBE(5);
     PROBE_WG(6, 0);
+    const int tiles_x = listing ? ((ct.slot.nx + 1 + 15) >> 4) : 0, tiles_y = listing ? ((ct.slot.ny + 1 + 15) >> 4) : 0;
+    int ox = listing ? ((ct.x0 - ct.slot.xmin - 4) >> 4) : 0, oy = listing ? ((ct.y0 - ct.slot.ymin - 4) >> 4) : 0;
+    if (ox < 0) ox = 0;
+    if (oy < 0) oy = 0;
     for (int e = threadIdx.x; e < CT * CT; e += n_thr) {
         const float v = tile[e];
-        if (v != 0.0f) deposit_global(P, ct, ct.x0 + e % CT, ct.y0 + e / CT, (double)v);
+        if (v != 0.0f) {
+            const int ix = ct.x0 + e % CT, iy = ct.y0 + e / CT;
+            deposit_global(P, ct, ix, iy, (double)v, false);
+            if (listing) {
+                const int di = ix - ct.slot.xmin, dj = iy - ct.slot.ymin;
+                if (di >= 0 && di < ct.slot.nx && dj >= 0 && dj < ct.slot.ny) {
+                    int ax = (di - 4) >> 4, bx = (di + 4) >> 4, ay = (dj - 4) >> 4, by = (dj + 4) >> 4;
+                    if (ax < ox) ax = ox;
+                    if (ay < oy) ay = oy;
+                    unsigned int bits = 0u;
+                    for (int ty = ay; ty <= by; ++ty)
+                        for (int tx = ax; tx <= bx; ++tx)
+                            if (tx - ox < 4 && ty - oy < 4) bits |= 1u << ((ty - oy) * 4 + (tx - ox));
+                    atomicOr(&reach_bits, bits);
+                }
+            }
+        }
+    }
+    if (!listing) return;
+    __syncthreads();
+    const TileLister& L = ct.lister;
+    if (reach_bits == 0u) return;
+    const TileListerChain C = lister_chain(L, ct.slot_idx);
+    if (!C.on) return;
+    if (threadIdx.x < 16 && ((reach_bits >> threadIdx.x) & 1u)) {
+        const int tx = ox + (int)(threadIdx.x & 3), ty = oy + (int)(threadIdx.x >> 2);
+        if (tx < tiles_x && ty < tiles_y) {
+            const int t = ty * tiles_x + tx;
+            unsigned int* w = C.words + (C.tile_base + t);
+            if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != L.round_word && atomicExch(w, L.round_word) != L.round_word)
+                new_tile[atomicAdd(&n_new, 1)] = t;
+        }
+    }
+    __syncthreads();
+    if (n_new > 0) {
+        if (threadIdx.x == 0) base_new = atomicAdd(L.count, n_new);
+        __syncthreads();
+        if ((int)threadIdx.x < n_new)
+            L.list[base_new + threadIdx.x] = ((unsigned long long)L.chain << 58) | ((unsigned long long)(unsigned int)C.lo << 32) | (unsigned int)new_tile[threadIdx.x];
     }
 }
 
@@ -370,7 +473,8 @@ __global__ __launch_bounds__(256) void k_accumulate(const ims_render_params_t P,
 // One workgroup = the photons [j0, j0 + 256) of object `oi` (clipped to j_end).
 template <int NV = 0, int WG = 256>
 __device__ __forceinline__ void accumulate_segment(const ims_render_params_t& P, const ims_photons_t& pool,
-                                                   const int64_t* __restrict__ pool_start, int64_t oi, int64_t j0, int64_t j_end)
+                                                   const int64_t* __restrict__ pool_start, int64_t oi, int64_t j0, int64_t j_end,
+                                                   const TileLister* lister = nullptr)
 {
     const ims_object_t& o = P.objects[oi];
     const int64_t left = j_end - j0;                                            // photons of this segment (>= 1)
@@ -381,7 +485,7 @@ __device__ __forceinline__ void accumulate_segment(const ims_render_params_t& P,
     __shared__ float tile[CT * CT];
     ChargeTile ct;
     PROBE(1);
-    tile_begin(tile, ct, P, o, silicon, n_thr);
+    tile_begin(tile, ct, P, o, silicon, n_thr, lister);
     PROBE(2);
     PROBE_WG(1, 0);
     double added = 0.0;
@@ -616,6 +720,9 @@ struct JointEnds { int32_t v[IMS_JOINT_MAX]; };      // ascending workgroup ends
 struct JointAcc {                           // per chain, constant over the rounds: lives in device memory (ims_plans_run_joint)
     RoundArgs a[IMS_JOINT_MAX];
     const int64_t* pool_start[IMS_JOINT_MAX];
+    const int64_t* tile_prefix[IMS_JOINT_MAX];      // search-side lists (TileLister): tiles before each slot of the class,
+    unsigned int* words[IMS_JOINT_MAX];             // the chain's tile words,
+    int32_t first_slot[IMS_JOINT_MAX];              // and the class's first slot
 };
 
 // The tables of ONE round of a joint run -- workgroup ends of the pixel search (ea), tile ends (eu), regions that go on (ns),
@@ -637,9 +744,22 @@ __device__ __forceinline__ int joint_chain(const JointEnds* e_global, int& b)
 }
 __device__ __forceinline__ int joint_entry(const JointEnds* e_global, int c) { return ((ConstEnds)(uintptr_t)e_global)->v[c]; }
 
+__device__ __forceinline__ TileListerChain lister_chain(const TileLister& L, int slot_idx)
+{
+    typedef const JointAcc __attribute__((address_space(4))) * ConstAcc;
+    ConstAcc Jc = (ConstAcc)(uintptr_t)L.J;
+    TileListerChain C;
+    C.lo = slot_idx - Jc->first_slot[L.chain];
+    C.tile_base = Jc->tile_prefix[L.chain][C.lo];
+    C.words = Jc->words[L.chain];
+    C.on = C.tile_base < joint_entry(&L.R->tof, L.chain);          // (regions are in the order of their chains' lengths)
+    return C;
+}
+
 template <int NV, int WG = 256>
 __global__ __launch_bounds__(WG, (NV == 8) ? 2 : 4) void k_accumulate_round_j(const JointAcc* __restrict__ J, const JointRound* __restrict__ R,
-                                                                              uint32_t tag, int64_t round_first, int32_t nrecalc, int32_t segs)
+                                                                              uint32_t tag, int64_t round_first, int32_t nrecalc, int32_t segs,
+                                                                              unsigned long long* list, int* list_count, unsigned int round_word)
 {
     int b = (int)blockIdx.x;
     const int c = joint_chain(&R->ea, b);
@@ -661,7 +781,9 @@ __global__ __launch_bounds__(WG, (NV == 8) ? 2 : 4) void k_accumulate_round_j(co
     const int64_t n = P.objects[oi].n_phot;
     if (j_end > n) j_end = n;
     if (j0 >= j_end) return;
-    accumulate_segment<NV, WG>(P, pool, pool_start, oi, j0, j_end);
+    TileLister tl;
+    tl.list = list; tl.count = list_count; tl.round_word = round_word; tl.chain = c; tl.J = J; tl.R = R;
+    accumulate_segment<NV, WG>(P, pool, pool_start, oi, j0, j_end, &tl);
 }
 
 // Which slot of a range does block b work on: the last k with prefix[k] <= b (prefix = ascending tile offsets of the slots,
@@ -1335,6 +1457,7 @@ struct JointChunk {
     const int64_t* tile_prefix[JOINT_CHUNK];
     unsigned char* changed[JOINT_CHUNK];
     const double* dl[JOINT_CHUNK];
+    unsigned int* words[JOINT_CHUNK];
     int32_t first_slot[JOINT_CHUNK];
 };
 
@@ -1349,6 +1472,9 @@ __global__ __launch_bounds__(64) void k_store_joint_tables(const JointChunk C, J
     dst->upd.changed[k0 + k] = C.changed[k];
     dst->upd.dl[k0 + k] = C.dl[k];
     dst->upd.first_slot[k0 + k] = C.first_slot[k];
+    dst->acc.tile_prefix[k0 + k] = C.tile_prefix[k];
+    dst->acc.words[k0 + k] = C.words[k];
+    dst->acc.first_slot[k0 + k] = C.first_slot[k];
 }
 
 // (the body as a function of restrict-qualified pointers: loaded from the argument block they would carry no aliasing
@@ -1813,10 +1939,13 @@ __device__ __forceinline__ void update_listed_tile(const JointUpd* __restrict__ 
 }
 
 template <int NV, bool DPP = false>
-__global__ __launch_bounds__(256) void k_update_list_j(const JointUpd* __restrict__ U, const JointLists Ls, int parity, unsigned int tag)
+__global__ __launch_bounds__(256) void k_update_list_j(const JointUpd* __restrict__ U, const JointLists Ls, int parity, unsigned int tag,
+                                                       int reset_next)
 {
     __shared__ UpdateLds<NV> L0;
     const int n = Ls.count[2 * parity];
+    // (search-side lists: no builder launch to empty the next round's list -- this launch sits between this round's search and the next's)
+    if (reset_next && blockIdx.x == 0 && threadIdx.x == 0) { Ls.count[2 * (parity ^ 1)] = 0; Ls.count[2 * (parity ^ 1) + 1] = 0; }
     for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
         if (i != (int)blockIdx.x) __syncthreads();                  // the tile before is through with the shared buffers
         // (the address of the shared buffers through a register the compiler cannot look through: inside a loop it otherwise
@@ -1828,11 +1957,15 @@ __global__ __launch_bounds__(256) void k_update_list_j(const JointUpd* __restric
 }
 
 template <int NV>
-__global__ __launch_bounds__(256) void k_refresh_list_j(const JointUpd* __restrict__ U, const JointLists Ls, int parity, unsigned int tag)
+__global__ __launch_bounds__(256) void k_refresh_list_j(const JointUpd* __restrict__ U, const JointLists Ls, int parity, unsigned int tag,
+                                                        int from_upd)
 {
-    const int n = Ls.count[2 * parity + 1];
+    // from_upd: ONE list for both (search-side lists: a tile is listed when charge lies within [t0 - 4, t0 + 19] of it, which covers
+    // the update's halo and the right / upper neighbour's first column / row)
+    const int n = Ls.count[2 * parity + (from_upd ? 0 : 1)];
+    const unsigned long long* __restrict__ list = from_upd ? Ls.upd : Ls.ref;
     for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
-        const unsigned long long e = Ls.ref[i];
+        const unsigned long long e = list[i];
         const int c = (int)(e >> 58), lo = (int)((e >> 32) & 0x3FFFFFFu), t = (int)(e & 0xFFFFFFFFu);
         const ims_sensor_t& s = *U->sp[c];
         const ims_bf_slot_t bs = s.bf_slots[U->first_slot[c] + lo];
@@ -3573,7 +3706,7 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
     }
     const bool lists = lists_on && tiles_max > list_min_tiles;
     struct Ring { JointTables* dev; hipEvent_t free_after; bool used; bool busy; unsigned long long* upd; unsigned long long* ref; int* count; int64_t cap;
-                  JointRound* rounds_dev; JointRound* rounds_pin; int64_t rounds_cap; };
+                  JointRound* rounds_dev; JointRound* rounds_pin; int64_t rounds_cap; unsigned int* words; };
     // one ring per DEVICE (its tables live in that device's memory: one process per GPU is the rule, but a process that holds
     // two devices must not hand the second one the first one's tables)
     static std::map<int, std::pair<std::vector<Ring>, size_t>> rings;
@@ -3584,6 +3717,9 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
     JointRound* rounds_pin = nullptr;
     hipEvent_t table_event = nullptr;
     JointLists Ls{ nullptr, nullptr, nullptr };
+    unsigned int* words_dev = nullptr;
+    // search-side lists (TileLister): the pixel search appends the tiles, no builder launch
+    const bool search_lists = lists && g_tune.joint_search_lists != 0;
     {
         std::lock_guard<std::mutex> lock(g_state_mutex);
         std::vector<Ring>& ring = rings[device_now].first;
@@ -3594,7 +3730,7 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
             HIP_TRY(hipMalloc((void**)&block, 64 * sizeof(JointTables)));
             HIP_TRY(hipMalloc((void**)&counts, 64 * 4 * sizeof(int)));
             for (int k = 0; k < 64; ++k) {
-                Ring r{ block + k, nullptr, false, false, nullptr, nullptr, counts + 4 * k, 0, nullptr, nullptr, 0 };
+                Ring r{ block + k, nullptr, false, false, nullptr, nullptr, counts + 4 * k, 0, nullptr, nullptr, 0, nullptr };
                 HIP_TRY(hipEventCreateWithFlags(&r.free_after, hipEventDisableTiming));
                 ring.push_back(r);
             }
@@ -3609,10 +3745,11 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
         undo.busy = &r.busy; undo.table_event = r.free_after;
         if (lists && r.cap < tiles_max) {
             // (a growth is a device-wide synchronisation: the capacity is kept and rounded up generously)
-            if (r.upd) { HIP_TRY(hipFree(r.upd)); HIP_TRY(hipFree(r.ref)); }
+            if (r.upd) { HIP_TRY(hipFree(r.upd)); HIP_TRY(hipFree(r.ref)); HIP_TRY(hipFree(r.words)); }
             r.cap = tiles_max + tiles_max / 2 + 65536;
             HIP_TRY(hipMalloc((void**)&r.upd, (size_t)r.cap * sizeof(unsigned long long)));
             HIP_TRY(hipMalloc((void**)&r.ref, (size_t)r.cap * sizeof(unsigned long long)));
+            HIP_TRY(hipMalloc((void**)&r.words, (size_t)r.cap * sizeof(unsigned int)));
         }
         if (r.rounds_cap < max_rounds) {
             // the round tables of the run: a page-locked staging buffer and its device copy (grown rarely: capacity kept)
@@ -3623,9 +3760,17 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
         }
         tables_dev = r.dev; table_event = r.free_after;
         Ls.upd = r.upd; Ls.ref = r.ref; Ls.count = r.count;
+        words_dev = r.words;
         rounds_dev = r.rounds_dev; rounds_pin = r.rounds_pin;
     }
     if (lists) HIP_TRY(hipMemsetAsync(Ls.count, 0, 4 * sizeof(int), js));
+    if (search_lists) HIP_TRY(hipMemsetAsync(words_dev, 0, (size_t)tiles_max * sizeof(unsigned int), js));
+    // a chain's tile words: behind those of the chains before it (round 0 lists from all the regions that go on)
+    std::vector<int64_t> word_off(act.size() + 1, 0);
+    for (size_t k = 0; k < act.size(); ++k) {
+        const int32_t n_cont = count_above(act[k].ch->n_phot, act[k].ch->n_objects, (int64_t)nrecalc);
+        word_off[k + 1] = word_off[k] + (n_cont > 0 ? act[k].ch->tile_prefix_host[n_cont] : 0);
+    }
     bool dpp_ok = true;
     for (size_t k0 = 0; k0 < act.size(); k0 += JOINT_CHUNK) {
         JointChunk Ck;
@@ -3642,6 +3787,7 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
             Ck.pool_start[k] = ch.pool_start;
             Ck.sp[k] = a.pl->d_sensor_dev; Ck.tile_prefix[k] = ch.tile_prefix; Ck.changed[k] = a.pl->d_changed;
             Ck.dl[k] = a.pl->d_sensor_host->bf_dl; Ck.first_slot[k] = ch.first_slot;
+            Ck.words[k] = (search_lists && k0 + k < act.size()) ? words_dev + word_off[k0 + k] : nullptr;
             dpp_ok = dpp_ok && a.pl->d_sensor_host->bf_dl != nullptr;
         }
         hipLaunchKernelGGL(k_store_joint_tables, dim3(1), dim3(64), 0, js, Ck, tables_dev, (int)k0);
@@ -3698,12 +3844,16 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
         const uint32_t tag = (use_tags || lists) ? (uint32_t)(r % 255 + 1) : 0u;
         const int64_t wgs = totals[(size_t)r].wgs, tiles = totals[(size_t)r].tiles, build_wgs = totals[(size_t)r].build_wgs;
         const JointRound* R = rounds_dev + r;
+        const bool list_round = tiles > 0 && lists && tiles > list_min_tiles;
+        const int parity_r = r & 1;
         if (wgs > 0) {
             LaunchTimer tm(js, 4);
+            const bool sl = search_lists && list_round;
             hipLaunchKernelGGL((k_accumulate_round_j<4, 256>), dim3((unsigned)wgs), dim3(256), 0, js, (const JointAcc*)&tables_dev->acc, R, tag,
-                               (int64_t)r * nrecalc, nrecalc, segs);
+                               (int64_t)r * nrecalc, nrecalc, segs, sl ? Ls.upd : (unsigned long long*)nullptr,
+                               sl ? Ls.count + 2 * parity_r : (int*)nullptr, (unsigned int)(r + 1));
         }
-        if (tiles > 0 && lists && tiles > list_min_tiles) {
+        if (list_round) {
             // marks -> lists -> the update and the refresh over the listed tiles (a launch of a fraction of the tiles walks them)
             const JointUpd* U = &tables_dev->upd;
             const int parity = r & 1;
@@ -3711,9 +3861,10 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
             if (grid < 256 && list_fraction >= 0.05) grid = 256;
             if (grid < 1) grid = 1;
             if (grid > tiles) grid = tiles;
-            hipLaunchKernelGGL(k_build_active_j, dim3((unsigned)build_wgs), dim3(256), 0, js, U, R, tag, Ls, parity, (int)g_tune.joint_fine_marks);
-            hipLaunchKernelGGL((k_update_list_j<4, false>), dim3((unsigned)grid), dim3(256), 0, js, U, Ls, parity, tag);
-            hipLaunchKernelGGL(k_refresh_list_j<4>, dim3((unsigned)grid), dim3(256), 0, js, U, Ls, parity, tag);
+            if (!search_lists)
+                hipLaunchKernelGGL(k_build_active_j, dim3((unsigned)build_wgs), dim3(256), 0, js, U, R, tag, Ls, parity, (int)g_tune.joint_fine_marks);
+            hipLaunchKernelGGL((k_update_list_j<4, false>), dim3((unsigned)grid), dim3(256), 0, js, U, Ls, parity, tag, search_lists ? 1 : 0);
+            hipLaunchKernelGGL(k_refresh_list_j<4>, dim3((unsigned)grid), dim3(256), 0, js, U, Ls, parity, tag, search_lists ? 1 : 0);
         } else if (tiles > 0) {
             const JointUpd* U = &tables_dev->upd;
             const bool dpp = dpp_ok && g_tune.upd_dpp && tiles <= dpp_max_tiles;

@@ -26,6 +26,7 @@ KNOWN = {
     "IMS_JOINT_LIST_MIN": ("1024", "... for rounds of more than this many tiles"),
     "IMS_ACTIVE_FRACTION": ("0.25", "... workgroups launched per tile of the round"),
     "IMS_JOINT_FINE_MARKS": ("1", "... from charge marks per 4 x 4 pixels: a tile is listed when charge lies within the update's reach of it"),
+    "IMS_JOINT_SEARCH_LISTS": ("1", "... appended to by the pixel search where the charge lands; 0 = a launch of its own scans the marks (k_build_active_j)"),
     "IMS_ROUND_TWO_SEGMENTS": ("0", "pixel search of a round with two 256-photon segments per workgroup (both pool records requested up front)"),
     # -- engine --
     "IMS_SCREEN_PREPASS": ("0", "phase-screen gathers ahead of the shooting kernels (1: every photon, 2: ordinary objects on a side stream)"),
@@ -192,7 +193,8 @@ class Tuning(C.Structure):
     _fields_ = [("chain_kernels", C.c_int32), ("layout_kernels", C.c_int32), ("psf_screens_kernel", C.c_int32), ("photon_lds", C.c_int32),
                 ("round_compact", C.c_int32), ("init_tiles", C.c_int32), ("upd_dpp", C.c_int32), ("joint_lists", C.c_int32),
                 ("upd_dpp_max", C.c_int64), ("joint_list_min", C.c_int64), ("active_fraction", C.c_double),
-                ("round_two_segments", C.c_int32), ("joint_fine_marks", C.c_int32)]
+                ("round_two_segments", C.c_int32), ("joint_fine_marks", C.c_int32),
+                ("joint_search_lists", C.c_int32), ("pad", C.c_int32)]
 
 
 def library_tuning():
@@ -212,6 +214,7 @@ def library_tuning():
     t.active_fraction = number("IMS_ACTIVE_FRACTION", float)
     t.round_two_segments = 1 if flag("IMS_ROUND_TWO_SEGMENTS") else 0
     t.joint_fine_marks = 1 if flag("IMS_JOINT_FINE_MARKS") else 0
+    t.joint_search_lists = 1 if flag("IMS_JOINT_SEARCH_LISTS") else 0
     return t
 
 

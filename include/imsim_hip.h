@@ -435,6 +435,9 @@ typedef struct ims_tuning {
                                     requested before the first search (measured: EXPERIMENTS.md, round 5) */
     int32_t joint_fine_marks;    /* 1: the lists of a joint round are built from charge marks per 4 x 4 pixels (a tile is listed when
                                     charge lies within the update's reach of it, not when one of its 3 x 3 tile neighbours holds some) */
+    int32_t joint_search_lists;  /* 1: ... and the lists are appended to by the pixel search itself, where the charge lands (no launch that
+                                    scans the marks of every tile afterwards); 0 = k_build_active_j */
+    int32_t pad;
 } ims_tuning_t;
 int  ims_tuning_defaults(ims_tuning_t* out);
 int  ims_get_tuning(ims_tuning_t* out);

@@ -43,13 +43,13 @@ def test_tuning_block_is_the_only_way_to_change_which_kernels_the_library_launch
     translates the environment into the block."""
     from imsim_amd import tuning
     lib = _abi.load()
-    assert lib.ims_struct_size(_abi.STRUCTS.index(_abi.Tuning)) == C.sizeof(tuning.Tuning) == 64
+    assert lib.ims_struct_size(_abi.STRUCTS.index(_abi.Tuning)) == C.sizeof(tuning.Tuning) == 72
     d = tuning.Tuning()
     assert lib.ims_tuning_defaults(C.byref(d)) == 0
     assert (d.chain_kernels, d.layout_kernels, d.psf_screens_kernel, d.photon_lds, d.round_compact, d.init_tiles, d.upd_dpp,
-            d.joint_lists, d.upd_dpp_max, d.joint_list_min, d.active_fraction, d.round_two_segments, d.joint_fine_marks) == (1, 1, 1, -1, 1, 1, 1, 1, 128, 1024, 0.25, 0, 1)
+            d.joint_lists, d.upd_dpp_max, d.joint_list_min, d.active_fraction, d.round_two_segments, d.joint_fine_marks, d.joint_search_lists) == (1, 1, 1, -1, 1, 1, 1, 1, 128, 1024, 0.25, 0, 1, 1)
     for name in ("IMS_CHAIN_KERNELS", "IMS_LAYOUT_KERNELS", "IMS_PSF_SCREENS_KERNEL", "IMS_PHOTON_LDS", "IMS_ROUND_COMPACT", "IMS_INIT_TILES",
-                 "IMS_UPD_DPP", "IMS_UPD_DPP_MAX", "IMS_JOINT_LISTS", "IMS_JOINT_LIST_MIN", "IMS_ACTIVE_FRACTION", "IMS_ROUND_TWO_SEGMENTS", "IMS_JOINT_FINE_MARKS"):
+                 "IMS_UPD_DPP", "IMS_UPD_DPP_MAX", "IMS_JOINT_LISTS", "IMS_JOINT_LIST_MIN", "IMS_ACTIVE_FRACTION", "IMS_ROUND_TWO_SEGMENTS", "IMS_JOINT_FINE_MARKS", "IMS_JOINT_SEARCH_LISTS"):
         monkeypatch.delenv(name, raising=False)
     assert bytes(tuning.library_tuning()) == bytes(d)              # an empty environment asks for the defaults
     monkeypatch.setenv("IMS_CHAIN_KERNELS", "0")

@@ -1445,14 +1445,17 @@ def test_joint_top_chains_of_a_focal_plane_equal_a_chain_per_ccd(torch_cuda, mon
     single = focal_plane.render_focal_plane(dets, build, concurrent=2)
     # (lists of active tiles, k_build_active_j: at this size they are off by default -- forced on, with launches of 1 % of the
     # tiles so that every workgroup walks several list entries, and off)
-    # (the lists from charge marks per 4 x 4 pixels -- the default -- and from the tile marks alone)
-    for joint, hint, list_min, fraction, fine in (("8", None, "0", "0.01", "1"), ("8", None, "0", "0.01", "0"),
-                                                  ("2", lambda det: int(jobs[det].objects["n_phot"].max()), "0", "0.25", "1"),
-                                                  ("2", None, "1000000000", "0.25", "1")):
+    # (the lists appended to by the pixel search itself -- the default --, built by a launch of its own from charge marks per 4 x 4
+    # pixels, and from the tile marks alone)
+    for joint, hint, list_min, fraction, fine, search in (("8", None, "0", "0.01", "1", "1"), ("8", None, "0", "0.01", "1", "0"),
+                                                          ("8", None, "0", "0.01", "0", "0"),
+                                                          ("2", lambda det: int(jobs[det].objects["n_phot"].max()), "0", "0.25", "1", "1"),
+                                                          ("2", None, "1000000000", "0.25", "1", "1")):
         monkeypatch.setenv("IMS_FOCAL_JOINT", joint)
         monkeypatch.setenv("IMS_JOINT_LIST_MIN", list_min)
         monkeypatch.setenv("IMS_ACTIVE_FRACTION", fraction)
         monkeypatch.setenv("IMS_JOINT_FINE_MARKS", fine)
+        monkeypatch.setenv("IMS_JOINT_SEARCH_LISTS", search)
         images = focal_plane.render_focal_plane(dets, build, concurrent=2, chain_hint=hint)
         assert focal_plane.render_focal_plane.last_joint_plans == len(dets)          # every CCD has a star with rounds of its own
         assert sorted(images) == dets

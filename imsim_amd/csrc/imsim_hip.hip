@@ -146,12 +146,12 @@ constexpr int CT = 32;
 struct JointAcc;
 struct JointRound;
 struct TileLister {
-    unsigned long long* list;          // entries: chain << 58 | slot of the class << 32 | tile of the slot; NULL: no listing this round
-    int* count;                        // entries so far (this round's parity)
-    const JointAcc* J;                 // per chain: tile words, tiles before each slot of the class, the class's first slot
-    const JointRound* R;               // per chain: tiles of the regions that go on after this round (only those are updated)
-    int chain;
-    unsigned int round_word;           // this round + 1
+    unsigned long long* list = nullptr; // entries: chain << 58 | slot of the class << 32 | tile of the slot; NULL: no listing (the default)
+    int* count = nullptr;               // entries so far (this round's parity)
+    const JointAcc* J = nullptr;        // per chain: tile words, tiles before each slot of the class, the class's first slot
+    const JointRound* R = nullptr;      // per chain: tiles of the regions that go on after this round (only those are updated)
+    int chain = 0;
+    unsigned int round_word = 0u;       // this round + 1
 };
 // (resolved where the lists are written, at the end of the workgroup: kept live through the pixel search, the chain's table
 // entries cost the search kernel its register allocation -- 96 registers and scratch instead of 93)
@@ -162,8 +162,8 @@ struct ChargeTile {
     int x0, y0;                // pixel coordinates of tile cell (0,0)
     bool track;                // also add to the slot's delta image
     ims_bf_slot_t slot;
-    TileLister lister;         // joint rounds with search-side lists (by value: through a pointer the block lived in scratch); list == NULL: off
-    int slot_idx;              // the region's slot
+    TileLister lister{};       // joint rounds with search-side lists (by value: through a pointer the block lived in scratch); list == NULL: off
+    int slot_idx = 0;          // the region's slot
 };
 
 __device__ __forceinline__ void tile_begin(float* tile, ChargeTile& ct, const ims_render_params_t& P, const ims_object_t& o,
@@ -1012,23 +1012,49 @@ __global__ __launch_bounds__(256) void k_init_tiles(const ims_sensor_t* __restri
         }
     }
     const bool inner = owner && i < sl.nx && j < sl.ny;                           // a pixel: has a bounds line
+    // The points of the cells just outside the tile, which the pixels at its right / upper rim need, evaluated by the wavefront
+    // TOGETHER (a wavefront is four rows of sixteen cells): the four left-edge points of the cell right of a row by the row's
+    // lanes 12 .. 15, one each, handed to lane 15 by shuffles; the six bottom-row points of the cells above the tile by the
+    // four rows of its last wavefront, two rounds.  (Each rim lane evaluating its own -- four and six evaluations that the whole
+    // wavefront sits through -- made 14 / 20 evaluations per wavefront where 11 / 13 do: the closed form is most of this kernel.)
+    static_assert(IT_NV == 4 && UT == 16, "the rim exchange below is written for 4 vertices per edge and 16 x 16 tiles");
+    double2 rgt_rim[IT_NV], upp_rim[IT_NV + 2];
+    {
+        const int lane = (int)(threadIdx.x & 63), row_base = lane & ~15;
+        double2 rr;
+        init_point(s, T, sl, tx0 + UT, j, IT_NV + 2 + (lx & 3), rr.x, rr.y);
+#pragma unroll
+        for (int m = 0; m < IT_NV; ++m) { rgt_rim[m].x = __shfl(rr.x, row_base + 12 + m, 64); rgt_rim[m].y = __shfl(rr.y, row_base + 12 + m, 64); }
+#pragma unroll
+        for (int q = 0; q <= IT_NV + 1; ++q) upp_rim[q] = make_double2(0.0, 0.0);
+        if (threadIdx.x >= 192) {                                                    // rows 12 .. 15: wave-uniform
+            const int r = ly - 12;
+            double2 ua, ub;
+            init_point(s, T, sl, i, ty0 + UT, r, ua.x, ua.y);
+            init_point(s, T, sl, i, ty0 + UT, 4 + (r & 1), ub.x, ub.y);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { upp_rim[q].x = __shfl(ua.x, lx + 16 * q, 64); upp_rim[q].y = __shfl(ua.y, lx + 16 * q, 64); }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { upp_rim[4 + q].x = __shfl(ub.x, lx + 16 * q, 64); upp_rim[4 + q].y = __shfl(ub.y, lx + 16 * q, 64); }
+        }
+    }
     double bnd[8] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
     if (inner) {
-        // the right neighbour's left edge and the upper neighbour's bottom row: from LDS inside the tile, evaluated at its rim
+        // the right neighbour's left edge and the upper neighbour's bottom row: from LDS inside the tile, from the exchange at its rim
         double2 rgt[IT_NV], upp[IT_NV + 2];
         if (lx + 1 < UT) {
 #pragma unroll
             for (int m = 0; m < IT_NV; ++m) rgt[m] = P[(ly * UT + lx + 1) * IT_NPO + IT_NV + 2 + m];
         } else {
 #pragma unroll
-            for (int m = 0; m < IT_NV; ++m) init_point(s, T, sl, i + 1, j, IT_NV + 2 + m, rgt[m].x, rgt[m].y);
+            for (int m = 0; m < IT_NV; ++m) rgt[m] = rgt_rim[m];
         }
         if (ly + 1 < UT) {
 #pragma unroll
             for (int q = 0; q <= IT_NV + 1; ++q) upp[q] = P[((ly + 1) * UT + lx) * IT_NPO + q];
         } else {
 #pragma unroll
-            for (int q = 0; q <= IT_NV + 1; ++q) init_point(s, T, sl, i, j + 1, q, upp[q].x, upp[q].y);
+            for (int q = 0; q <= IT_NV + 1; ++q) upp[q] = upp_rim[q];
         }
         double ixmin = 0.0, ixmax = 1.0, iymin = 0.0, iymax = 1.0;
         double oxmin = 0.0, oxmax = 1.0, oymin = 0.0, oymax = 1.0;

@@ -836,6 +836,16 @@ def _device_streams(torch, device):
     return sets["sets"][k]
 
 
+def _pool_stream(torch, device):
+    """the stream of the overlapped pool shoot of photon-pooling mode (Renderer._overlapped_pool): one per device and process"""
+    key = ("pool-shoot", str(device))
+    with _STREAMS_LOCK:
+        st = _DEVICE_STREAMS.get(key)
+        if st is None:
+            st = _DEVICE_STREAMS[key] = torch.cuda.Stream(device)
+    return st
+
+
 _STREAMS_LOCK = threading.Lock()
 EVENT_BLOCK = 128                                 # library event numbers of one renderer (a plan uses one per pool slice: a few dozen)
 _EVENT_BLOCKS = list(range(459, -1, -1))          # blocks below Renderer.PREPASS_EVENT (60 000)
@@ -1883,8 +1893,22 @@ class Renderer:
         shoot.photons = int(base[-1])
         shoot.object_rows = n_shoot
         shoot.waves = 4 * int(prefix[-1])
+        shoot.launches = 1
         launches = []
         small_max = int(tuning.env("IMS_POOL_SMALL_MAX", "64"))    # shares up to a wavefront: one wavefront per object
+        # IMS_POOL_OVERLAP=1 (default 0): the pool is shot BATCH BY BATCH on a stream of its own, ahead of the batches' pixel
+        # searches and recalculations on the caller's stream -- the shoot is f64-VALU bound, the search and the whole-CCD update /
+        # refresh wait on memory.  Only objects whose share of a batch fills wavefronts are shot by share (n // batches >
+        # IMS_POOL_SMALL_MAX: 89 % of C4's photons); the many objects of a few dozen photons are shot whole, ahead of everything.
+        # Measured (round 5): C4 244 against 236 ms, same image -- the eleven shoots take 148 instead of 136 ms and the searches
+        # beside them exactly as much longer as they overlap: two WIDE kernels share the wave slots (capping the photon kernels
+        # at three or two workgroups per CU: 241 / 289 ms).  What overlaps on this device is small latency-bound work beside wide
+        # work (the rounds of C3 / C5), not wide beside wide.
+        overlap = tuning.flag("IMS_POOL_OVERLAP") and len(batches) > 1
+        by_share = None
+        if overlap:
+            by_share = self._pool_shares(batches, shoot_n, small_max)
+            overlap = by_share is not None
         base_cache = {}
         for batch in batches:
             if isinstance(batch[0], str) and batch[0] == "parts":
@@ -1953,7 +1977,95 @@ class Renderer:
                         realized.index_add_(0, rows_t, tmp)
             accumulate.keep = calls
             launches.append(accumulate)
+        if overlap:
+            shoot, launches = self._overlapped_pool(shoot, launches, by_share, master, shot if master is not None else None, shoot_table,
+                                                    base, pool, pool_t)
         return shoot, launches
+
+    def _pool_shares(self, batches, shoot_n, small_max):
+        """For the overlapped pool shoot: (rows shot whole and ahead, [(rows, first photon, photons) of the objects shot by share,
+        per batch]), or None when the batches do not cover the by-share objects' photons exactly once (then nothing overlaps)."""
+        nb = len(batches)
+        big = (shoot_n // nb) > small_max
+        covered = np.zeros(len(shoot_n), dtype=np.int64)
+        shares = []
+        for k, batch in enumerate(batches):
+            pieces = []
+            if isinstance(batch[0], str) and batch[0] == "parts":
+                for rw, fi, co, _sm in batch[1]:
+                    rw = np.asarray(rw)
+                    if isinstance(fi, tuple):
+                        _, F_s, bi, nbat = fi
+                        F_s = np.asarray(F_s, dtype=np.int64)
+                        lo = (F_s * bi) // nbat
+                        fi, co = lo, (F_s * (bi + 1)) // nbat - lo
+                    pieces.append((rw, np.asarray(fi, dtype=np.int64), np.asarray(co, dtype=np.int64)))
+            else:
+                pieces.append((np.asarray(batch[0]), np.asarray(batch[1], dtype=np.int64), np.asarray(batch[2], dtype=np.int64)))
+            rows = np.concatenate([p[0] for p in pieces]) if pieces else np.zeros(0, dtype=np.int64)
+            first = np.concatenate([p[1] for p in pieces]) if pieces else np.zeros(0, dtype=np.int64)
+            count = np.concatenate([p[2] for p in pieces]) if pieces else np.zeros(0, dtype=np.int64)
+            sel = big[rows] & (count > 0)
+            order = np.argsort(rows[sel], kind="stable")                 # the order of the shoot table
+            r, f, c = rows[sel][order], first[sel][order], count[sel][order]
+            np.add.at(covered, r, c)
+            shares.append((np.ascontiguousarray(r, dtype=np.int64), f, c))
+        if not np.array_equal(covered[big], shoot_n[big]) or not big.any():
+            return None
+        return np.flatnonzero(~big & (shoot_n > 0)), shares
+
+    def _overlapped_pool(self, shoot_all, launches, by_share, master, shot, shoot_table, base, pool, pool_t):
+        """shoot(): the whole-object rows, then the shares of batch 0, 1, ... on the pool stream, an event behind each;
+        accumulate k waits for the events it needs.  Same pool contents as the one launch: a photon's place in the pool and its
+        random streams are functions of (object, photon index)."""
+        t = self.torch
+        rows_up, shares = by_share
+        side = _pool_stream(t, self.device)
+
+        def table_of(rows, first, count):
+            if master is not None:
+                obj_t, prefix, pre_t = self._gather_objects(master, shot[rows], first, count)
+            else:
+                part = shoot_table[rows].copy()
+                if first is not None:
+                    part["phot_first"] = part["phot_first"] + first
+                    part["n_phot"] = count
+                _, obj_t, prefix, pre_t = self._upload_objects(part)
+            start = base[rows] + (first if first is not None else 0)
+            start_t = t.from_numpy(np.ascontiguousarray(start, dtype=np.int64)).to(self.device)
+            Ps = self.bound.params(obj_t.data_ptr(), len(rows), pre_t.data_ptr(), int(prefix[-1]), self.image.data_ptr(), None, _seg_ptr(pre_t))
+            return Ps, start_t, (obj_t, pre_t), int(prefix[-1])
+        pieces = []
+        if len(rows_up):
+            pieces.append(table_of(rows_up, None, None))
+        n_up = len(pieces)
+        for r, f, c in shares:
+            pieces.append(table_of(r, f, c) if len(r) else None)
+        events = [t.cuda.Event() for _ in pieces]
+
+        def shoot():
+            main = t.cuda.current_stream(self.device)
+            side.wait_stream(main)                 # the tables are uploaded, and the last replay's searches are through with the pool
+            with t.cuda.stream(side):
+                for piece, ev in zip(pieces, events):
+                    if piece is not None:
+                        _abi.check(self.lib.ims_shoot_ops_photons(C.byref(piece[0]), piece[1].data_ptr(), C.byref(pool), self._stream()),
+                                   "ims_shoot_ops_photons")
+                    ev.record(side)
+        shoot.keep = (shoot_all.keep, pieces, pool_t)
+        shoot.photons, shoot.object_rows = shoot_all.photons, shoot_all.object_rows
+        shoot.waves = 4 * sum(p[3] for p in pieces if p is not None)
+        shoot.launches = sum(1 for p in pieces if p is not None)
+        out = []
+        for k, acc in enumerate(launches):
+            def accumulate(k=k, acc=acc):
+                main = t.cuda.current_stream(self.device)
+                for ev in events[:n_up] + [events[n_up + k]]:
+                    main.wait_event(ev)
+                acc()
+            accumulate.keep = acc
+            out.append(accumulate)
+        return shoot, out
 
     def accumulate_segments(self, pool, realized=None, small=False):
         """ims_accumulate_segments on a converted pool (segment-mapped: one workgroup per 256 photons of one object);

@@ -245,7 +245,7 @@ def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1,
     if shoot is not None:
         run.photons, run.object_rows = shoot.photons, shoot.object_rows
         # the pool shoot is the dominant launch: 32 B per converted photon written + one 256-B row per object
-        run.timed = {2: (1, shoot.photons * 32 + shoot.object_rows * 256), 1: (0, 0)}
+        run.timed = {2: (getattr(shoot, "launches", 1), shoot.photons * 32 + shoot.object_rows * 256), 1: (0, 0)}
         run.timed_waves = {2: shoot.waves, 1: 0}
     else:
         run.photons = sum(l.photons for l in launches)
@@ -335,7 +335,7 @@ def _prepared_image_device(renderer, table, modes, nbatch, seed, rank, world, re
         if realized is not None:
             realized.index_add_(0, renderer.torch.from_numpy(shot).to(renderer.device), r_rows)
     run.photons, run.object_rows = shoot.photons, shoot.object_rows
-    run.timed = {2: (1, shoot.photons * 32 + shoot.object_rows * 256), 1: (0, 0)}
+    run.timed = {2: (getattr(shoot, "launches", 1), shoot.photons * 32 + shoot.object_rows * 256), 1: (0, 0)}
     run.timed_waves = {2: shoot.waves, 1: 0}
     run.resident = True
     run.keep = (shoot, launches)

@@ -43,6 +43,8 @@ KNOWN = {
     "IMS_PAIR_MAX_OBJECTS": ("64", "... for chain classes of at most this many objects"),
     "IMS_NATIVE_PLAN": ("1", "launch plan of a CCD built and enqueued by the library (ims_plan_*); 0 = the numpy planner (the checker)"),
     "IMS_POOL_RESIDENT": ("1", "photon pooling with the pool of all batches in HBM; 0 = one fused launch per batch"),
+    "IMS_POOL_OVERLAP": ("0", "photon pooling: 1 = the pool shot batch by batch on a stream of its own, ahead of the batches' pixel searches "
+                              "and recalculations (measured: C4 244 against 236 ms -- two wide kernels share the wave slots, they do not add up)"),
     "IMS_POOL_SMALL_MAX": ("64", "per-batch shares up to this many photons go through ims_accumulate_small"),
     "IMS_POOL_SPATIAL": ("1", "shoot table of pooling mode in spatial order"),
     "IMS_FFT_TORCH": ("0", "inverse transforms of the FFT branch through torch.fft instead of ims_fft_inverse (the checker)"),

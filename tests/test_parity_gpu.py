@@ -1157,6 +1157,39 @@ def test_photon_pooling_build_image_is_bit_exact(torch_cuda):
     assert_bits_equal(r2.image_numpy(), orc.image, "replayed pooling image")
 
 
+def test_pool_shot_batch_by_batch_gives_the_one_launch_image(torch_cuda, monkeypatch):
+    """IMS_POOL_OVERLAP=1 (Renderer._overlapped_pool): the objects whose share of a batch fills wavefronts are shot by share on a
+    stream of their own, an event per batch, the others whole and first -- the same pool, so the image, the realized fluxes
+    and the pixel-boundary state of the one-launch form and of the oracle; replayed, and from a device table as well."""
+    from helpers import c3_small_case
+    from imsim_amd import photon_pooling, stamp
+    from imsim_amd.engine import Renderer
+    from oracle import orc_loader
+    scene, objects = c3_small_case(n_obj=90, n=192, flux_seed=6, scratch=0)
+    scene.track_static_delta = 1
+    modes = stamp.classify(objects["n_phot"].astype(float), 100.0)
+    orc = orc_loader.OracleScene(scene)
+    photon_pooling.build_image(orc, objects, modes, nbatch=5, nsubbatch=4, seed=21)
+    monkeypatch.setenv("IMS_POOL_SMALL_MAX", "8")                 # objects of more than 40 photons go by share: most of this catalog
+    out = []
+    for overlap in ("1", "0"):
+        monkeypatch.setenv("IMS_POOL_OVERLAP", overlap)
+        r = Renderer(scene)
+        real = torch_cuda.zeros(len(objects), dtype=torch_cuda.float64, device="cuda")
+        run = photon_pooling.prepared_image(r, objects, modes, nbatch=5, seed=21, realized=real)
+        assert (run.timed[2][0] > 1) == (overlap == "1")          # several pool-shoot launches, or the one
+        for _ in range(2):                                        # the second time: a replay over the same pool
+            r.image.zero_()
+            real.zero_()
+            run()
+            r.synchronize()
+        out.append((r.image_numpy(), real.cpu().numpy(), _sensor_arrays_gpu(r)["boundary"]))
+    assert_bits_equal(out[0][0], out[1][0], "image: pool shot by share vs in one launch")
+    assert_bits_equal(out[0][1], out[1][1], "realized fluxes")
+    assert_bits_equal(out[0][2], out[1][2], "pixel boundaries")
+    assert_bits_equal(out[0][0], orc.image, "image vs oracle")
+
+
 def test_photon_pooling_edge_cases_are_bit_exact(torch_cuda):
     """Photon pooling on a table that sits on the boundaries of the batch arithmetic: photon counts of 0, 1, nbatch - 1
     (demoted to one random batch), nbatch, nbatch + 1, around nbatch x 64 (the split between the two pixel-search launches

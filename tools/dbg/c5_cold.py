@@ -1,5 +1,5 @@
 """Where the first focal-plane call of a fresh process spends its time: host profile (cumulative) of the first step() of
-bench config c5 on n CCDs, then the wall time of the second.  Run under gpurun: python tools/dbg/r5_cold.py [n_ccd]"""
+bench config c5 on n CCDs, then the wall time of the second.  Run under gpurun: python tools/dbg/c5_cold.py [n_ccd]"""
 import cProfile
 import os
 import pstats

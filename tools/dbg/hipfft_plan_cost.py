@@ -1,5 +1,5 @@
 """What the first hipFFT plan of a process costs and where the time goes: loading the library, the first plan, further sizes,
-and what a second process finds cached.  Run under gpurun: python tools/dbg/r5_fftinit.py [label]"""
+and what a second process finds cached.  Run under gpurun: python tools/dbg/hipfft_plan_cost.py [label]"""
 import ctypes as C
 import glob
 import os

@@ -1,5 +1,5 @@
 """What a fresh process pays for device memory: torch.empty (= hipMalloc through the caching allocator) of several sizes, then
-the first and the second fill of the block.  Run under gpurun: python tools/dbg/r5_malloc.py"""
+the first and the second fill of the block.  Run under gpurun: python tools/dbg/malloc_cost.py"""
 import time
 import torch
 

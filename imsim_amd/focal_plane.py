@@ -251,13 +251,9 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
     awaiting = []                       # batches whose tails are enqueued, oldest first
     pending = list(order)
 
-    # IMS_FOCAL_JOINT_STREAMS (default 1): the top classes of consecutive batches on that many high-priority streams in turn (two
-    # batches' rounds side by side: a round is a chain of four dependent launches of latency-bound workgroups)
-    n_js = max(1, int(tuning.env("IMS_FOCAL_JOINT_STREAMS")))
-    joint_streams = [_focal_streams(torch, dev, top_index=k)[0] for k in range(n_js)]
-    batch_no = [0]
-
-    def joint_runs(entries, st_joint=st_joint):
+    # (The top classes of consecutive batches on TWO high-priority streams in turn -- two batches' rounds side by side -- were
+    # measured in round 5: 1.61 - 1.65 against 1.54 s whatever shared a hardware queue with whatever; removed.)
+    def joint_runs(entries):
         """both joint runs of a batch (worker thread); returns the events behind them"""
         torch.cuda.set_device(dev)
         left = [e["plan"] for e in entries if e["plan"] is not None and getattr(e["plan"], "deferred", 0)]
@@ -276,10 +272,8 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
         return len(left), (ev_mid, ev_top)
 
     def start_rounds(entries):
-        js = joint_streams[batch_no[0] % n_js]
-        batch_no[0] += 1
         if worker is not None:
-            rounds.append(dict(entries=entries, future=worker.submit(joint_runs, entries, js)))
+            rounds.append(dict(entries=entries, future=worker.submit(joint_runs, entries)))
         else:
             class _Done:
                 def __init__(self, v):
@@ -290,7 +284,7 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
 
                 def result(self):
                     return self.v
-            rounds.append(dict(entries=entries, future=_Done(joint_runs(entries, js))))
+            rounds.append(dict(entries=entries, future=_Done(joint_runs(entries))))
 
     def service(block_oldest=False, block_all=False):
         """move batches along without waiting: tails for batches whose rounds have run, collection of batches whose copies are

@@ -78,7 +78,6 @@ KNOWN = {
                                       "per CU leave wave slots to the rounds (C5 1.68 -> 1.54 s); empty = as elsewhere"),
     "IMS_FFT_WARM": ("1", "focal_plane.warm_fft makes the hipFFT plans on background threads; 0 = plans are made where they are first needed "
                           "(rocprofv3's counter passes crash with launches from several host threads)"),
-    "IMS_FOCAL_JOINT_STREAMS": ("1", "joint path: high-priority streams that take the top-class rounds of consecutive batches in turn"),
     "IMS_FOCAL_JOINT_THREAD": ("1", "joint path: the rounds of a batch are enqueued by a second host thread while the first goes on with the next fronts"),
     "IMS_FOCAL_DIRECT_COPY": ("0", "joint path: 1 = the finished image rounded straight into page-locked host memory by one small launch "
                                    "(measured slower: C5 1.91 against 1.78 s); 0 = image_float + copy"),

@@ -101,20 +101,23 @@ def spawn_ranks(args):
 
 
 # The other BASELINE.json configs on the same record as the headline: each as a CHILD process of its own
-# -- `bench.py --config X --steps 2 --warmup 1` with a small one-core oracle sample, whose image the child's GPU renderer must
+# -- `bench.py --config X --steps K --warmup W` with a small one-core oracle sample, whose image the child's GPU renderer must
 # reproduce (the child's cpu_baseline.parity) -- started BEFORE this process touches the GPU, one after the other.
-EXTRA_CONFIGS = (("c2", 2000, {}), ("c3b", 1500, {}), ("c4", 1500, {}), ("c5", 1200, {"IMS_C5_CCDS": "32"}), ("fft", 0, {}))
+# (name, objects of the one-core oracle sample, environment, timed steps, warm-up steps: the sub-millisecond configs take more steps,
+# and the FFT branch three warm-ups -- a (size, batch) pair that comes again gets its batched hipFFT plan, milliseconds the second time)
+EXTRA_CONFIGS = (("c2", 2000, {}, 10, 2), ("c3b", 1500, {}, 2, 1), ("c4", 1500, {}, 2, 1), ("c5", 1200, {"IMS_C5_CCDS": "32"}, 2, 1),
+                 ("fft", 0, {}, 10, 3))
 
 
 def extra_configs(budget_s=150.0):
     out = {}
     t_start = time.perf_counter()
-    for name, sample, env_add in EXTRA_CONFIGS:
+    for name, sample, env_add, n_steps, n_warm in EXTRA_CONFIGS:
         left = budget_s - (time.perf_counter() - t_start)
         if left < 10.0:
             out[name] = {"skipped": "time budget of the extra configs used up"}
             continue
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", "2", "--warmup", "1", "--no-cold",
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(n_steps), "--warmup", str(n_warm), "--no-cold",
                "--no-cpu-allcore", "--no-extra-configs"]
         if sample:
             cmd += ["--cpu-sample", str(sample)]

@@ -391,8 +391,8 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
         raise ValueError("concurrent must be >= 1")
     # plan streams by role for all CCDs of the device: the long chains of two CCDs side by side (engine._focal_streams)
     roles = "focal" if tuning.env("IMS_FOCAL_STREAMS", "1") != "0" else "single"
-    # IMS_FOCAL_JOINT (default 16; 0 / 1: off): the top chains of that many CCDs advance jointly (_render_joint)
-    joint = int(tuning.env("IMS_FOCAL_JOINT", "16"))
+    # IMS_FOCAL_JOINT (default 20; 0 / 1: off): the top chains of that many CCDs advance jointly (_render_joint)
+    joint = int(tuning.env("IMS_FOCAL_JOINT"))
     heavy = False
     if roles == "focal" and mine:
         # Joint rounds pay where a CCD's chains are few objects wide (a focal plane of 10 k-source CCDs: 150 objects with rounds

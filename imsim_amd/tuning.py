@@ -62,7 +62,8 @@ KNOWN = {
     "IMS_FOCAL_COPY": ("mid", "rolling window: stream of a CCD's image copy"),
     "IMS_FOCAL_ANCHOR": ("top", "rolling window: stream a CCD's plan is anchored to"),
     "IMS_FOCAL_FFT": (None, "stream of a CCD's FFT-drawn objects (joint path: mid; rolling window: top)"),
-    "IMS_FOCAL_JOINT": ("16", "CCDs per batch whose chains advance in joint launches (0 / 1: a chain per CCD)"),
+    "IMS_FOCAL_JOINT": ("20", "CCDs per batch whose chains advance in joint launches (0 / 1: a chain per CCD).  Measured with four batches alive "
+                              "(189 CCDs): 16 -> 1.57 s, 18 / 19 -> 1.59, 20 -> 1.49 - 1.51, 21 -> 1.56, 22 / 24 / 27 -> 1.58"),
     "IMS_FOCAL_JOINT_MAX_BRIGHT": ("600", "CCDs with more objects of their own rounds than this take the rolling window"),
     "IMS_FOCAL_AHEAD": ("pre:1", "the host enqueues a CCD's front only when the front n CCDs before has run on that stream"),
     "IMS_NO_HINT": ("0", "ignore the chain-length hint that batches CCDs of similar chains"),

@@ -15,7 +15,7 @@ def test_unknown_switch_is_an_error():
 
 def test_flag_and_number_follow_the_environment(monkeypatch):
     monkeypatch.delenv("IMS_FOCAL_JOINT", raising=False)
-    assert tuning.number("IMS_FOCAL_JOINT") == 16 and tuning.flag("IMS_FOCAL_JOINT")
+    assert tuning.number("IMS_FOCAL_JOINT") == int(tuning.KNOWN["IMS_FOCAL_JOINT"][0]) > 1 and tuning.flag("IMS_FOCAL_JOINT")
     monkeypatch.setenv("IMS_FOCAL_JOINT", "0")
     assert tuning.number("IMS_FOCAL_JOINT") == 0 and not tuning.flag("IMS_FOCAL_JOINT")
     monkeypatch.setenv("IMS_FOCAL_TOUCH", "")                    # set but empty: no touch, not the default order

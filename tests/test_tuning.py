@@ -58,3 +58,23 @@ def test_fft_kernel_file_falls_back_to_the_temporary_directory(tmp_path, monkeyp
     path = tuning.fft_kernel_cache(None)
     assert path is not None and path.startswith(str(tmp_path)) and path.endswith("rocfft_kernels.db")
     monkeypatch.setattr(tempfile, "tempdir", None)
+
+
+def test_scoped_defaults_sit_between_the_environment_and_the_table(monkeypatch):
+    """tuning.scoped: a caller's defaults for the duration of a block -- the environment still wins, an empty value leaves a
+    switch alone, nesting restores what was there"""
+    monkeypatch.delenv("IMS_PHOTON_LDS", raising=False)
+    assert tuning.env("IMS_PHOTON_LDS") is None
+    with tuning.scoped(IMS_PHOTON_LDS="41984"):
+        assert tuning.number("IMS_PHOTON_LDS") == 41984 and tuning.library_tuning().photon_lds == 41984
+        with tuning.scoped(IMS_PHOTON_LDS="1024"):
+            assert tuning.number("IMS_PHOTON_LDS") == 1024
+        assert tuning.number("IMS_PHOTON_LDS") == 41984
+        with tuning.scoped(IMS_PHOTON_LDS=""):                   # empty: as elsewhere
+            assert tuning.number("IMS_PHOTON_LDS") == 41984
+        monkeypatch.setenv("IMS_PHOTON_LDS", "0")
+        assert tuning.number("IMS_PHOTON_LDS") == 0              # an explicit choice of the user
+        monkeypatch.delenv("IMS_PHOTON_LDS")
+    assert tuning.env("IMS_PHOTON_LDS") is None and tuning.library_tuning().photon_lds == -1
+    with pytest.raises(KeyError):
+        tuning.scoped(IMS_NO_SUCH_SWITCH="1")

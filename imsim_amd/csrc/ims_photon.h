@@ -988,9 +988,26 @@ IMS_DEV bool land_convert(const ims_render_params_t& P, const ims_object_t& o, i
 // is lost.  (Testing the nominal pixel and the first neighbour of the search together, both bounds lines and both polygons
 // in one batch of loads, was measured: 41.2 against 41.5 us per round of the brightest star, +1 % on the C3 step -- the
 // search is not where a round's latency goes; not kept.)
+// ims_render_params_t.lazy_static: a photon that would look at the (absent) state of slot 0 is set aside for the second launch
+// (k_margin_photons): position at the conversion depth, the depth with the coin in its sign, flux, object row.  One addition to
+// the counter per wavefront.
+IMS_DEV void margin_append(const ims_render_params_t& P, const ims_object_t& o, double x0, double y0, double zconv, bool coin, double flux)
+{
+    const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+    const int lane = (int)(threadIdx.x & 63), leader = __builtin_ctzll(active);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(P.margin_count, (int)__popcll(active));
+    base = __shfl(base, leader, 64);
+    const unsigned int idx = (unsigned int)base + (unsigned int)__popcll(active & ((1ull << lane) - 1ull));
+    if (idx >= P.margin_cap) { atomicAdd(P.margin_count + 1, 1); return; }                 // (sized for every photon of the launch)
+    double* r = P.margin_list + 5 * (size_t)idx;
+    r[0] = x0; r[1] = y0; r[2] = coin ? -zconv : zconv; r[3] = flux;
+    r[4] = __longlong_as_double((long long)(&o - P.objects));
+}
+
 template <int NV = 0, bool ZF = false>
 IMS_DEV bool land_search(const ims_render_params_t& P, const ims_object_t& o, double x0, double y0, double z, bool coin,
-                         int& ix, int& iy)
+                         int& ix, int& iy, double flux = 0.0)
 {
     const ims_sensor_t& s = *P.sensor;
     const ims_bf_slot_t bs = s.bf_slots[slot_index(P, o)];
@@ -1007,7 +1024,10 @@ IMS_DEV bool land_search(const ims_render_params_t& P, const ims_object_t& o, do
         const int pi = ix - sl.xmin, pj = iy - sl.ymin;
         if (o.bf_state == 0 && m >= 0.0 && pi >= 0 && pi < sl.nx && pj >= 0 && pj < sl.ny && x > m && x < 1.0 - m && y > m && y < 1.0 - m)
             found = true;
-        else
+        else if (!ZF && P.lazy_static != 0u && o.bf_state == 0 && m >= 0.0 && pi >= 0 && pi < sl.nx && pj >= 0 && pj < sl.ny) {
+            margin_append(P, o, x0, y0, z, coin, flux);              // slot 0 holds no state: the second launch finishes this photon
+            return false;
+        } else
             found = inside_pixel<NV, ZF>(s, sl, ix, iy, x, y, z, true, off_edge);
     }
     PROBE_WG(3, 0);
@@ -1064,7 +1084,7 @@ IMS_DEV bool land(const ims_render_params_t& P, const ims_object_t& o, int64_t k
     double x0, y0, zconv;
     bool coin;
     if (!land_convert(P, o, k, rng, ph, has_angles, x0, y0, zconv, coin)) return false;
-    return land_search<NV, false>(P, o, x0, y0, zconv, coin, ix, iy);
+    return land_search<NV, false>(P, o, x0, y0, zconv, coin, ix, iy, ph.flux);
 }
 
 IMS_DEV bool chain_has_angles(const ims_render_params_t& P)

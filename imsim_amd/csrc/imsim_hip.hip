@@ -1099,6 +1099,161 @@ __global__ __launch_bounds__(256) void k_init_tiles(const ims_sensor_t* __restri
     }
 }
 
+// ---- slot 0 without stored state (ims_render_params_t.lazy_static): the photons the fused launch set aside ----
+// Pixel (i, j) of slot 0 in its initial state, evaluated where it is needed: the ten owned points of its cell, the four left-edge
+// points of the cell to the right, the six bottom-row points of the cell above -- init_point, the function k_init_tiles stores --
+// and from them the bounds line as k_init_tiles forms it.  4 vertices per edge.
+struct LazyPixel { double2 own[IT_NPO], rgt[IT_NV], upp[IT_NV + 2]; double b[8]; };
+
+__device__ __forceinline__ void lazy_pixel(const ims_sensor_t& s, const TreeRing& T, const SlotView& sl, int i, int j, LazyPixel& px)
+{
+#pragma unroll
+    for (int n = 0; n < IT_NPO; ++n) init_point(s, T, sl, i, j, n, px.own[n].x, px.own[n].y);
+#pragma unroll
+    for (int m = 0; m < IT_NV; ++m) init_point(s, T, sl, i + 1, j, IT_NV + 2 + m, px.rgt[m].x, px.rgt[m].y);
+#pragma unroll
+    for (int q = 0; q <= IT_NV + 1; ++q) init_point(s, T, sl, i, j + 1, q, px.upp[q].x, px.upp[q].y);
+    double ixmin = 0.0, ixmax = 1.0, iymin = 0.0, iymax = 1.0;
+    double oxmin = 0.0, oxmax = 1.0, oymin = 0.0, oymax = 1.0;
+    double v0x = 0.0;
+#pragma unroll
+    for (int k = 0; k < IT_NVT; ++k) {
+        double vx, vy;
+        if (k <= IT_NV + 1) { vx = px.own[k].x; vy = px.own[k].y; }
+        else if (k <= 2 * IT_NV + 1) { vx = px.rgt[k - IT_NV - 2].x + 1.0; vy = px.rgt[k - IT_NV - 2].y; }
+        else if (k <= 3 * IT_NV + 3) { vx = px.upp[IT_NV + 1 - (k - 2 * IT_NV - 2)].x; vy = px.upp[IT_NV + 1 - (k - 2 * IT_NV - 2)].y + 1.0; }
+        else { vx = px.own[IT_NV + 2 + (IT_NV - 1 - (k - 3 * IT_NV - 4))].x; vy = px.own[IT_NV + 2 + (IT_NV - 1 - (k - 3 * IT_NV - 4))].y; }
+        if (k == 0) v0x = vx;
+        if (vx < oxmin) oxmin = vx;
+        if (vx > oxmax) oxmax = vx;
+        if (vy < oymin) oymin = vy;
+        if (vy > oymax) oymax = vy;
+        if (k <= IT_NV + 1) { if (vy > iymin) iymin = vy; }
+        if (k >= IT_NV + 1 && k <= 2 * IT_NV + 2) { if (vx < ixmax) ixmax = vx; }
+        if (k >= 2 * IT_NV + 2 && k <= 3 * IT_NV + 3) { if (vy < iymax) iymax = vy; }
+        if (k >= 3 * IT_NV + 3) { if (vx > ixmin) ixmin = vx; }
+    }
+    if (v0x > ixmin) ixmin = v0x;
+    px.b[0] = ixmin; px.b[1] = ixmax; px.b[2] = iymin; px.b[3] = iymax;
+    px.b[4] = oxmin; px.b[5] = oxmax; px.b[6] = oymin; px.b[7] = oymax;
+}
+
+// polygon_test (ims_photon.h) on the evaluated points: the same vertices in the same order through the same arithmetic
+__device__ __forceinline__ bool lazy_polygon_test(const ims_sensor_t& s, const LazyPixel& px, double x, double y, double zfactor)
+{
+    const bool scaled = (zfactor != 1.0);
+    bool inside = false;
+    double lx, ly;
+    {
+        constexpr int k = IT_NVT - 1;                                                    // closing vertex: own left edge, first point
+        lx = px.own[5 * IT_NV + 5 - k].x; ly = px.own[5 * IT_NV + 5 - k].y;
+        if (scaled) {
+            const double ex = s.emptypoly[2 * k], ey = s.emptypoly[2 * k + 1];
+            lx = ex + (lx - ex) * zfactor;
+            ly = ey + (ly - ey) * zfactor;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < IT_NVT; ++k) {
+        double kx, ky;
+        if (k <= IT_NV + 1) { kx = px.own[k].x; ky = px.own[k].y; }
+        else if (k <= 2 * IT_NV + 1) { kx = px.rgt[k - IT_NV - 2].x + 1.0; ky = px.rgt[k - IT_NV - 2].y + 0.0; }
+        else if (k <= 3 * IT_NV + 3) { kx = px.upp[3 * IT_NV + 3 - k].x + 0.0; ky = px.upp[3 * IT_NV + 3 - k].y + 1.0; }
+        else { kx = px.own[5 * IT_NV + 5 - k].x; ky = px.own[5 * IT_NV + 5 - k].y; }
+        if (scaled) {
+            const double ex = s.emptypoly[2 * k], ey = s.emptypoly[2 * k + 1];
+            kx = ex + (kx - ex) * zfactor;
+            ky = ey + (ky - ey) * zfactor;
+        }
+        if ((ky > y) != (ly > y)) {
+            const double dy = ly - ky;
+            const double lhs = (x - kx) * dy, rhs = (lx - kx) * (y - ky);
+            if ((dy > 0.0) ? (lhs < rhs) : (lhs > rhs)) inside = !inside;
+        }
+        lx = kx; ly = ky;
+    }
+    return inside;
+}
+
+// inside_pixel (ims_photon.h) for slot 0 without stored state; z: the conversion depth
+__device__ __forceinline__ bool lazy_inside_pixel(const ims_sensor_t& s, const TreeRing& T, const SlotView& sl, int ix, int iy, double x, double y,
+                                                  double z, bool want_edge, bool& off_edge)
+{
+    const int i = ix - sl.xmin, j = iy - sl.ymin;
+    if (i < 0 || i >= sl.nx || j < 0 || j >= sl.ny) {
+        if (want_edge) off_edge = true;
+        return false;
+    }
+    LazyPixel px;
+    lazy_pixel(s, T, sl, i, j, px);
+    bool inside;
+    if (x > px.b[0] && x < px.b[1] && y > px.b[2] && y < px.b[3]) inside = true;
+    else if (!(x >= px.b[4] && x <= px.b[5] && y >= px.b[6] && y <= px.b[7])) inside = false;
+    else inside = lazy_polygon_test(s, px, x, y, dtanh_pos(ddiv(z, 12.0)));
+    if (!inside && want_edge) {
+        off_edge = false;
+        if (i == 0 && x < px.b[0]) off_edge = true;
+        if (i == sl.nx - 1 && x > px.b[1]) off_edge = true;
+        if (j == 0 && y < px.b[2]) off_edge = true;
+        if (j == sl.ny - 1 && y > px.b[3]) off_edge = true;
+    }
+    return inside;
+}
+
+// The photons ims_shoot_accumulate set aside (margin_append): land_search from the point where it would have read the state.
+// A neighbour whose outer bounds cannot hold the point is not evaluated: no vertex of a pristine polygon lies further than
+// pristine_margin from its nominal place, so outer bounds lie within [-m, 1 + m] -- the candidates of the walk are the same.
+__global__ __launch_bounds__(256, 2) void k_margin_photons(const ims_render_params_t P)
+{
+    const ims_sensor_t& s = *P.sensor;
+    const TreeRing T = treering_of(s);
+    const ims_bf_slot_t bs = s.bf_slots[0];
+    const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
+    const double mm = s.pristine_margin;
+    unsigned int n = (unsigned int)P.margin_count[0];
+    if (n > P.margin_cap) n = P.margin_cap;
+    const unsigned int stride = gridDim.x * blockDim.x;
+    for (unsigned int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+        const double* rec = P.margin_list + 5 * (size_t)r;
+        const double x0 = rec[0], y0 = rec[1], zs = rec[2], flux = rec[3];
+        const int64_t oi = __double_as_longlong(rec[4]);
+        const ims_object_t& o = P.objects[oi];
+        const double z = fabs(zs);
+        const bool coin = __double_as_longlong(zs) < 0;
+        int ix = (int)floor(x0 + 0.5), iy = (int)floor(y0 + 0.5);
+        const double x = x0 - (double)ix + 0.5, y = y0 - (double)iy + 0.5;
+        bool off_edge = false;
+        bool found = lazy_inside_pixel(s, T, sl, ix, iy, x, y, z, true, off_edge);
+        if (!found && off_edge) continue;
+        int step = 0;
+        if (!found) {
+            step = search_step(x, y);
+            for (int m = 1; m < 9; ++m) {
+                const int nb = ((m * step - 1) & 7) + 1;
+                const int jx = ix + xoff(nb), jy = iy + yoff(nb);
+                const int i = jx - sl.xmin, j = jy - sl.ymin;
+                if (i < 0 || i >= sl.nx || j < 0 || j >= sl.ny) continue;
+                const double xb = x - (double)xoff(nb), yb = y - (double)yoff(nb);
+                if (xb < -mm || xb > 1.0 + mm || yb < -mm || yb > 1.0 + mm) continue;
+                LazyPixel px;
+                lazy_pixel(s, T, sl, i, j, px);
+                if (!(xb >= px.b[4] && xb <= px.b[5] && yb >= px.b[6] && yb <= px.b[7])) continue;      // not a candidate of the walk
+                bool in = (xb > px.b[0] && xb < px.b[1] && yb > px.b[2] && yb < px.b[3]);
+                if (!in) in = lazy_polygon_test(s, px, xb, yb, dtanh_pos(ddiv(z, 12.0)));
+                if (in) { ix = jx; iy = jy; found = true; break; }
+            }
+        }
+        if (!found) {
+            const int nb = coin ? 0 : step;
+            ix = ix + xoff(nb); iy = iy + yoff(nb);
+        }
+        if (ix < o.stamp_xmin || ix > o.stamp_xmax || iy < o.stamp_ymin || iy > o.stamp_ymax) continue;
+        const int pxl = ix - P.xmin, pyl = iy - P.ymin;
+        if (pxl >= 0 && pxl < P.nx && pyl >= 0 && pyl < P.ny) unsafeAtomicAdd(P.image + ((int64_t)pyl * P.nx + pxl), flux);
+        if (P.realized_flux != nullptr) unsafeAtomicAdd(P.realized_flux + oi, flux);
+    }
+}
+
 __device__ __forceinline__ int owned_to_vertex(int nV, int n)
 {
     if (n <= nV + 1) return n;
@@ -2928,13 +3083,44 @@ static unsigned photon_lds_pad(const ims_render_params_t* p)
     return 0u;
 }
 
-int ims_shoot_accumulate(const ims_render_params_t* params, void* stream)
+// the list of the photons a lazy_static launch sets aside: one buffer per (device, stream), sized for every photon of the launch
+// (launches on a stream run in order, so the next launch finds the second pass of the one before through with it)
+struct MarginBuf { double* list = nullptr; int32_t* count = nullptr; uint32_t cap = 0; };
+static std::map<std::pair<int, void*>, MarginBuf> g_margin;
+
+int ims_shoot_accumulate(const ims_render_params_t* params_in, void* stream)
 {
-    int rc = check_params(params);
+    int rc = check_params(params_in);
     if (rc) return rc;
-    if (!params->image) return set_err(IMS_ERR_ARG, "image is NULL");
-    if (params->n_segments == 0) return IMS_OK;
+    if (!params_in->image) return set_err(IMS_ERR_ARG, "image is NULL");
+    if (params_in->n_segments == 0) return IMS_OK;
     hipStream_t st = (hipStream_t)stream;
+    ims_render_params_t lazy_copy;
+    const ims_render_params_t* params = params_in;
+    if (params_in->lazy_static) {
+        if (!params_in->sensor || params_in->track_static_delta)
+            return set_err(IMS_ERR_ARG, "lazy_static needs a Silicon sensor whose slot 0 is not a live region (track_static_delta 0)");
+        const int64_t want = params_in->n_segments * (int64_t)params_in->seg_size;
+        if (want > (int64_t)1 << 26) return set_err(IMS_ERR_UNSUPPORTED, "lazy_static: more than 2^26 photons in one launch");
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        MarginBuf mb;
+        {
+            std::lock_guard<std::mutex> lock(g_state_mutex);
+            MarginBuf& m = g_margin[std::make_pair(dev, stream)];
+            if (m.cap < (uint32_t)want) {
+                if (m.list) { HIP_TRY(hipFree(m.list)); }
+                if (!m.count) HIP_TRY(hipMalloc((void**)&m.count, 2 * sizeof(int32_t)));
+                m.cap = (uint32_t)(want + want / 4 + 65536);
+                HIP_TRY(hipMalloc((void**)&m.list, (size_t)m.cap * 5 * sizeof(double)));
+            }
+            mb = m;
+        }
+        lazy_copy = *params_in;
+        lazy_copy.margin_list = mb.list; lazy_copy.margin_count = mb.count; lazy_copy.margin_cap = mb.cap;
+        params = &lazy_copy;
+        HIP_TRY(hipMemsetAsync(mb.count, 0, 2 * sizeof(int32_t), st));
+    }
     {
         LaunchTimer tm(st, 1);
         const dim3 grid(grid_for_segments(params->n_segments));
@@ -2949,6 +3135,11 @@ int ims_shoot_accumulate(const ims_render_params_t* params, void* stream)
         else hipLaunchKernelGGL((k_shoot_accumulate<0, 0>), grid, dim3(256), photon_lds_pad(params), st, *params);
     }
     HIP_TRY(hipGetLastError());
+    if (params->lazy_static) {
+        // the photons set aside (~2 % of the launch's): one lane each, the polygons evaluated on the way
+        hipLaunchKernelGGL(k_margin_photons, dim3(1024), dim3(256), 0, st, *params);
+        HIP_TRY(hipGetLastError());
+    }
     return IMS_OK;
 }
 

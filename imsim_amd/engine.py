@@ -464,6 +464,14 @@ def optics_layout(opt):
     return code
 
 
+def lazy_static_applies(scene):
+    """Renderer(lazy_static=True) can leave slot 0 without state for this scene: Silicon with 4 vertices per edge (the kernels that
+    evaluate polygons from the closed form are written for it), ONE static slot that is not a live region (LSST_Image mode)"""
+    ss = getattr(scene, "sensor", None)
+    return bool(ss is not None and ss.slots is not None and len(ss.slots) == 1 and not scene.track_static_delta
+                and ss.model.num_vertices == 4)
+
+
 def treering_displacement_bound(ss):
     """Upper bound of |tree-ring shift| over the CCD [pixels]: on every table interval the interpolant is the chord plus
     the cubic-spline term ((a^3 - a) m0 + (b^3 - b) m1) h^2 / 6 with |a^3 - a| <= 2 / (3 sqrt 3); a few ulp on top."""
@@ -1116,9 +1124,13 @@ class Renderer:
     STREAMS = {"chain": 0, "bulk": 1, "chain1": 2, "chain2": 3, "chain3": 4}
     CHAIN_STREAMS = ("chain", "chain1", "chain2", "chain3")
 
-    def __init__(self, scene: Scene, device="cuda:0", stream_roles="single", top_index=None, lease=None):
+    def __init__(self, scene: Scene, device="cuda:0", stream_roles="single", top_index=None, lease=None, lazy_static=False):
         """lease: a SensorLease of the device's SensorArena (focal planes): the pixel-boundary state of this CCD lives there; the
-        current stream (which initialises the static region) first waits for the region's previous readers"""
+        current stream (which initialises the static region) first waits for the region's previous readers.
+        lazy_static: the caller renders in LSST_Image mode and reads slot 0 through nothing but the fused launch of the ordinary
+        objects -- the static state is then not made at all (ims_render_params_t.lazy_static: the ~2 % of the photons that would
+        look at it are finished by a second launch from the tree-ring closed form; same bits).  Taken only where it applies
+        (Silicon with 4 vertices per edge, slot 0 not a live region, one static slot)."""
         self.lib = _abi.load()
         tuning.sync_library(self.lib)            # the library's choice of kernel forms (ims_tuning_t) follows the environment
         self.mem = DeviceMem(device)
@@ -1155,8 +1167,12 @@ class Renderer:
         self.chain_class_rounds = tuple(int(v) for v in tuning.env("IMS_CHAIN_CLASSES", "40,6").split(",") if v)
         self.max_pool_photons = 300_000_000      # 32 B each
         self.pair_max_objects = int(tuning.env("IMS_PAIR_MAX_OBJECTS", "64"))   # chain classes up to this size use slot pairs
-        if scene.sensor is not None:
-            self.init_boundaries(0, len(scene.sensor.slots))
+        ss = scene.sensor
+        self.lazy_static = bool(lazy_static and lazy_static_applies(scene) and self.bound.sensor_struct.pristine_margin >= 0.0)
+        if self.lazy_static:
+            self.bound.base_params.lazy_static = 1
+        elif ss is not None:
+            self.init_boundaries(0, len(ss.slots))
 
     def release_state(self, streams=None):
         """hand the leased pixel-boundary state back (SensorLease.release); a renderer without a lease has nothing to do"""

@@ -35,7 +35,7 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
     work ahead while the joint chain of batch b runs.  chain_hint(key) -> a number that grows with the CCD's longest chain
     (its brightest photon-shot object): CCDs of similar chain length share a batch, the sum of the batches' longest chains falls."""
     import torch
-    from .engine import _focal_streams, run_joint_plans
+    from .engine import _focal_streams, run_joint_plans, lazy_static_applies
     from . import _abi
     st_joint = _focal_streams(torch, dev, top_index=0)[0]
     pre, bulk, mid = _focal_streams(torch, dev, top_index=1)[:3]
@@ -83,6 +83,10 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
     prebuilt = {}
     arena = None
     alive = max(int(tuning.env("IMS_FOCAL_ALIVE")), 2)            # batches alive at a time (the pipeline below)
+    # IMS_FOCAL_LAZY_STATIC (default 1): a CCD's static pixel-boundary state (3.9 GB, 200 M evaluations of the tree-ring form)
+    # is not made: only the fused launch of the ordinary objects reads it, for the 2 % of its photons near a pixel edge, which a
+    # second launch finishes from the closed form (Renderer(lazy_static=True); C5 1.53 -> 1.33 s, same images)
+    lazy_static = tuning.flag("IMS_FOCAL_LAZY_STATIC")
     if order:
         prebuilt[order[0]] = build(order[0])
         sc0, work0 = prebuilt[order[0]]
@@ -99,7 +103,8 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
             # early or cuts the batch short (below)
             per_cells = int(min(max(float(tuning.env("IMS_FOCAL_ARENA_FACTOR")) * private_need(work0, sc0), 1.0e6), max(int(ss0.scratch_cells), 1)))
             per_ccd = per_cells * (ss0.owned_points() * 16 + 75) + sc0.nx * sc0.ny * 12 + 1.0e9
-            n_static = int(tuning.env("IMS_FOCAL_STATIC_REGIONS", "3"))
+            # (with the static state not made, the leases' static region is an address nobody looks behind: one is enough)
+            n_static = 1 if lazy_static else int(tuning.env("IMS_FOCAL_STATIC_REGIONS", "3"))
             static_bytes = n_static * ss0.total_cells() * (ss0.owned_points() * 16 + 75)
             have = _ARENA_BYTES.get(str(dev), 0)
             fit = int((0.85 * (usable + have) - static_bytes) / (alive * per_ccd))
@@ -145,6 +150,7 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
         lease = None
         ss = getattr(scene, "sensor", None)
         if (arena is not None and ss is not None and not wants_static_late(work) and not scene.track_static_delta
+                and (not lazy_static or lazy_static_applies(scene))          # (the lazy arena has ONE static region nobody may write)
                 and ss.slots is not None and len(ss.slots) == 1 and ss.total_cells() == arena.static_cells
                 and ss.owned_points() == arena.npo):
             # (a CCD of another geometry or sensor model than the arena was sized for keeps a state of its own)
@@ -152,6 +158,8 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
             if lease is None:
                 prebuilt[key] = (scene, work)
                 return None
+            if lazy_static:
+                lease.static_waits = []                # nobody reads or writes the region: nothing to wait for
         if ahead_n > 0 and len(fronts) >= ahead_n:
             fronts[-ahead_n].synchronize()
         t_host = time.perf_counter()
@@ -174,7 +182,8 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
 
     def _front(key, scene, work, lease=None):
         with torch.cuda.stream(init_on):
-            renderer = Renderer(scene, dev, stream_roles="focal", top_index=1, lease=lease)
+            renderer = Renderer(scene, dev, stream_roles="focal", top_index=1, lease=lease,
+                                lazy_static=lazy_static and not wants_static_late(work))
             if renderer.plan_streams[0] is not pre:
                 renderer.plan_streams = (pre,) + tuple(renderer.plan_streams[1:])
                 renderer.s_chain = pre

@@ -73,6 +73,8 @@ KNOWN = {
     "IMS_FOCAL_ARENA_CELLS": (None, "the arena's private pool in owner cells (tests: a pool that runs dry)"),
     "IMS_FOCAL_ARENA_FACTOR": ("0.8", "private cells per CCD the arena's pool is sized for, as a multiple of the first CCD's need"),
     "IMS_FOCAL_STATIC_REGIONS": ("3", "static regions of the arena, taken in turn"),
+    "IMS_FOCAL_LAZY_STATIC": ("1", "joint path: a CCD's static pixel-boundary state is not made; the photons near a pixel edge are finished by a "
+                                   "second launch from the tree-ring closed form (ims_render_params_t.lazy_static); 0 = k_init_tiles per CCD"),
     "IMS_FOCAL_ALIVE": ("4", "joint path: batches alive at a time (in their rounds and tails, being enqueued).  With every role stream on a "
                              "hardware queue of its own: 2 -> 1.77 s, 3 -> 1.67, 4 -> 1.68 (1.54 with IMS_FOCAL_PHOTON_LDS), 5 -> 1.61 with it"),
     "IMS_FOCAL_PHOTON_LDS": ("41984", "joint path: IMS_PHOTON_LDS while a focal plane renders -- the photon kernels capped at three workgroups "

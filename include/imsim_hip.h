@@ -396,6 +396,16 @@ typedef struct ims_render_params {
     /* optional (NULL = every photon gathers the phase screens itself): the sum over the layers of the screen gradient [nm/m] of
      * every photon, x and y interleaved, filled by ims_screen_prepass and indexed through ims_object_t.screen_base */
     const double* screen_kick;
+    /* optional (0 = off).  An LSST_Image render whose slot 0 is the pristine CCD (tree rings only; track_static_delta 0) and is read
+     * by nothing but ims_shoot_accumulate need not HOLD that state -- 235 B per pixel, written per CCD: photons further than
+     * ims_sensor_t.pristine_margin from every pixel edge never look at it, and the ~2 % that do are set aside by the launch
+     * (40 B each) and finished by a second launch that evaluates the polygons it needs from the tree-ring closed form -- the same
+     * function the stored state is made by, so the same bits (round 5).  Needs 4 vertices per edge and a pristine_margin >= 0.
+     * The caller sets lazy_static; the library fills the three fields behind it for its launches. */
+    uint32_t lazy_static;
+    uint32_t margin_cap;
+    double*  margin_list;
+    int32_t* margin_count;
 } ims_render_params_t;
 
 /* ---- library ---- */

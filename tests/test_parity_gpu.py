@@ -326,6 +326,41 @@ def test_two_segment_round_search_gives_the_one_segment_result(torch_cuda, monke
     assert_bits_equal(out[0][0], orc.image, "image vs oracle")
 
 
+@pytest.mark.parametrize("native", ["1", "0"])
+def test_lazy_static_state_gives_the_stored_state_image(torch_cuda, monkeypatch, native):
+    """Renderer(lazy_static=True): slot 0 is never initialised; the fused launch sets the photons within pristine_margin of a
+    pixel edge aside and k_margin_photons finishes them from the tree-ring closed form -- image and realized fluxes of the
+    stored-state render and of the oracle, bit for bit (library planner and numpy planner).  The static state really is absent:
+    its arrays are filled with a pattern first."""
+    from imsim_amd.engine import Renderer
+    from oracle import orc_loader
+    monkeypatch.setenv("IMS_NATIVE_PLAN", native)
+    scene, objects = _c3_case(n_obj=300)
+    assert scene.sensor.tr_table is not None                   # tree rings: the polygons differ from pixel to pixel
+    out = []
+    for lazy in (True, False):
+        r = Renderer(scene, lazy_static=lazy)
+        assert r.lazy_static == lazy
+        if lazy:
+            cells = (scene.nx + 1) * (scene.ny + 1)
+            for name, per in (("boundary", 20), ("bounds", 8)):
+                a = r.bound.sensor_arrays[name]
+                a = a if a.dtype == torch_cuda.float64 else a.view(torch_cuda.float64)
+                a[:cells * per].fill_(float("nan"))                               # whoever reads slot 0 reads NaN
+        real = torch_cuda.zeros(len(objects), dtype=torch_cuda.float64, device="cuda")
+        plan, parts = r.plan_lsst_image(objects, nrecalc=1000, want_realized=True)
+        r.execute_plan(plan)
+        for index, tmp in parts:
+            real.index_add_(0, index, tmp)
+        r.synchronize()
+        out.append((r.image_numpy(), real.cpu().numpy()))
+    assert_bits_equal(out[0][0], out[1][0], "image: lazy static state vs stored")
+    assert_bits_equal(out[0][1], out[1][1], "realized fluxes")
+    orc = orc_loader.OracleScene(scene)
+    orc.render_lsst_image(objects, nrecalc=1000)
+    assert_bits_equal(out[0][0], orc.image, "image vs oracle")
+
+
 def test_tiled_initial_state_equals_the_per_cell_kernel(torch_cuda, monkeypatch):
     """k_init_tiles (every owned point evaluated once per tile, neighbours through LDS) writes the boundary points, bounds
     lines and delta image of k_init_boundaries (one thread per cell, neighbours recomputed) bit for bit: the static CCD

@@ -268,14 +268,14 @@ __device__ __forceinline__ void tile_flush(float* tile, const ChargeTile& ct, co
             if (listing) {
                 const int di = ix - ct.slot.xmin, dj = iy - ct.slot.ymin;
                 if (di >= 0 && di < ct.slot.nx && dj >= 0 && dj < ct.slot.ny) {
-                    int ax = (di - 4) >> 4, bx = (di + 4) >> 4, ay = (dj - 4) >> 4, by = (dj + 4) >> 4;
-                    if (ax < ox) ax = ox;
-                    if (ay < oy) ay = oy;
-                    unsigned int bits = 0u;
-                    for (int ty = ay; ty <= by; ++ty)
-                        for (int tx = ax; tx <= bx; ++tx)
-                            if (tx - ox < 4 && ty - oy < 4) bits |= 1u << ((ty - oy) * 4 + (tx - ox));
-                    atomicOr(&reach_bits, bits);
+                    // tiles ax .. bx by ay .. by, relative to the window's first tile: a 4-bit run in x times a 4-bit run in y
+                    int ax = ((di - 4) >> 4) - ox, bx = ((di + 4) >> 4) - ox, ay = ((dj - 4) >> 4) - oy, by = ((dj + 4) >> 4) - oy;
+                    if (ax < 0) ax = 0;
+                    if (ay < 0) ay = 0;
+                    const unsigned int xm = ((2u << bx) - 1u) & ~((1u << ax) - 1u) & 0xFu;
+                    const unsigned int ym = ((2u << by) - 1u) & ~((1u << ay) - 1u) & 0xFu;
+                    const unsigned int rows = (ym & 1u) | ((ym & 2u) << 3) | ((ym & 4u) << 6) | ((ym & 8u) << 9);
+                    atomicOr(&reach_bits, xm * rows);
                 }
             }
         }

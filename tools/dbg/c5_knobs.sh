@@ -2,12 +2,12 @@
 # round 5: the focal-plane knobs again, now that every role stream has a hardware queue of its own (bench.py --config c5, 2 steps)
 ulimit -c 0
 mkdir -p gpurun_out
-L=gpurun_out/r5z_c5_knobs6.log
+L=gpurun_out/r5z_c5_knobs7.log
 : > $L
 run() { # label, env...
   label=$1; shift
   env "$@" timeout 300 python bench.py --config c5 --no-extra-configs --steps 4 --warmup 1 --no-cpu-baseline --no-cold > /tmp/o.json 2>/tmp/o.err
-  python - "$label" <<'PY' >> gpurun_out/r5z_c5_knobs6.log
+  python - "$label" <<'PY' >> gpurun_out/r5z_c5_knobs7.log
 import json, sys
 ok = False
 for line in open("/tmp/o.json"):
@@ -18,15 +18,11 @@ if not ok:
 PY
 }
 run "default" X=1
-run "ALIVE=3" IMS_FOCAL_ALIVE=3
-run "ALIVE=5" IMS_FOCAL_ALIVE=5
-run "JOINT=16" IMS_FOCAL_JOINT=16
-run "JOINT=24" IMS_FOCAL_JOINT=24
-run "JOINT=21" IMS_FOCAL_JOINT=21
-run "no LDS cap" IMS_FOCAL_PHOTON_LDS=
-run "LDS 57344" IMS_FOCAL_PHOTON_LDS=57344
-run "AHEAD=pre:2" IMS_FOCAL_AHEAD=pre:2
-run "AHEAD=pre:0" IMS_FOCAL_AHEAD=pre:0
-run "JOINT_INIT=bulk" IMS_FOCAL_JOINT_INIT=bulk
+run "HSA_ENABLE_SDMA=1" HSA_ENABLE_SDMA=1
+run "HSA_ENABLE_SDMA=0" HSA_ENABLE_SDMA=0
+run "IMS_FOCAL_DIRECT_COPY=1" IMS_FOCAL_DIRECT_COPY=1
+run "IMS_FOCAL_COARSE_SLICES=0" IMS_FOCAL_COARSE_SLICES=0
+run "IMS_FOCAL_FFT=bulk" IMS_FOCAL_FFT=bulk
+run "IMS_FOCAL_FFT=top" IMS_FOCAL_FFT=top
 run "default again" X=1
 cat $L

@@ -1560,12 +1560,15 @@ def test_joint_top_chains_of_a_focal_plane_equal_a_chain_per_ccd(torch_cuda, mon
         assert_bits_equal(images[det], single[det], f"CCD {det}: object table, joint vs single")
 
 
-def test_focal_plane_sensor_arena_leases_equal_a_state_per_ccd(torch_cuda, monkeypatch):
+@pytest.mark.parametrize("lazy", ["1", "0"])
+def test_focal_plane_sensor_arena_leases_equal_a_state_per_ccd(torch_cuda, monkeypatch, lazy):
     """engine.SensorArena: the CCDs of a joint focal plane lease their pixel-boundary state from one arena per device -- three
     static regions taken in turn (a region is re-initialised for the next CCD behind the events of its last readers) and private
     cells by need -- instead of 5 GB of arrays per renderer.  Same images, bit for bit, as renderers with a state of their own
     (IMS_FOCAL_ARENA=0), also when the private pool is too small for a batch: the previous batch is then collected early, or the
-    batch is cut short."""
+    batch is cut short.  lazy: with the static state not made at all (IMS_FOCAL_LAZY_STATIC, the default: one static region as
+    a mere address) and made per CCD (0: the three regions in turn)."""
+    monkeypatch.setenv("IMS_FOCAL_LAZY_STATIC", lazy)
     import copy
     from imsim_amd import focal_plane, configs, engine
     from imsim_amd.config import ccd_seed

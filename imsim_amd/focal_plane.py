@@ -25,6 +25,13 @@ _ANCHOR_STREAMS = {}
 _ARENA_BYTES = {}           # device -> bytes of the sensor arena this process holds there (they count as usable when it is re-sized)
 
 
+def wants_static_late(work):
+    """the sky stage of a job draws on the pixel areas of slot 0 in the CCD's tail (lsst_image.sky_pixel_areas): such a CCD
+    keeps a state of its own -- and has it made"""
+    sky = getattr(work, "sky", None)
+    return sky is not None and bool(sky.get("pixel_areas", True))
+
+
 def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
     """The CCDs in batches of `joint` whose top brighter-fatter chains advance in lockstep: ONE launch per kernel and round for
     the whole batch (engine.run_joint_plans / ims_plans_run_joint) instead of a chain per CCD on a stream of its own -- chains on
@@ -73,12 +80,6 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
         w = table["stamp_xmax"][br].astype(np.int64) - table["stamp_xmin"][br] + 2
         h = table["stamp_ymax"][br].astype(np.int64) - table["stamp_ymin"][br] + 2
         return int(min(int((w * h).sum()), int(ss.scratch_cells)))
-
-    def wants_static_late(work):
-        """the sky stage of a job draws on the pixel areas of slot 0 in the CCD's tail (lsst_image.sky_pixel_areas): such a CCD
-        keeps a state of its own"""
-        sky = getattr(work, "sky", None)
-        return sky is not None and bool(sky.get("pixel_areas", True))
 
     prebuilt = {}
     arena = None
@@ -483,7 +484,9 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
             if fft_on is anchor:
                 fft_on = None
         with torch.cuda.stream(init_on):
-            renderer = Renderer(scene, dev, stream_roles=roles, top_index=top_index)
+            # (the static pixel-boundary state is not made where only the fused launch would read it: Renderer(lazy_static=True))
+            renderer = Renderer(scene, dev, stream_roles=roles, top_index=top_index,
+                                lazy_static=tuning.flag("IMS_FOCAL_LAZY_STATIC") and not wants_static_late(work))
             ready = torch.cuda.Event()
             ready.record(init_on)
         if pace:

@@ -1124,7 +1124,7 @@ class Renderer:
     STREAMS = {"chain": 0, "bulk": 1, "chain1": 2, "chain2": 3, "chain3": 4}
     CHAIN_STREAMS = ("chain", "chain1", "chain2", "chain3")
 
-    def __init__(self, scene: Scene, device="cuda:0", stream_roles="single", top_index=None, lease=None, lazy_static=False):
+    def __init__(self, scene: Scene, device="cuda:0", stream_roles="single", top_index=None, lease=None, lazy_static=None):
         """lease: a SensorLease of the device's SensorArena (focal planes): the pixel-boundary state of this CCD lives there; the
         current stream (which initialises the static region) first waits for the region's previous readers.
         lazy_static: the caller renders in LSST_Image mode and reads slot 0 through nothing but the fused launch of the ordinary
@@ -1168,6 +1168,8 @@ class Renderer:
         self.max_pool_photons = 300_000_000      # 32 B each
         self.pair_max_objects = int(tuning.env("IMS_PAIR_MAX_OBJECTS", "64"))   # chain classes up to this size use slot pairs
         ss = scene.sensor
+        if lazy_static is None:
+            lazy_static = tuning.flag("IMS_LAZY_STATIC")
         self.lazy_static = bool(lazy_static and lazy_static_applies(scene) and self.bound.sensor_struct.pristine_margin >= 0.0)
         if self.lazy_static:
             self.bound.base_params.lazy_static = 1

@@ -170,7 +170,8 @@ class RenderParams(C.Structure):
                 ("nx", c_i32), ("ny", c_i32), ("xmin", c_i32), ("ymin", c_i32), ("realized_flux", c_vp),
                 ("bf_tag", C.c_uint32), ("bf_slot_shift", C.c_uint32), ("seg_object", c_vp), ("images", ImageTables),
                 ("optics_layout", c_u64), ("screen_kick", c_vp),
-                ("lazy_static", C.c_uint32), ("margin_cap", C.c_uint32), ("margin_list", c_vp), ("margin_count", c_vp)]
+                ("lazy_static", C.c_uint32), ("margin_cap", C.c_uint32), ("margin_list", c_vp), ("margin_count", c_vp),
+                ("margin_wave_count", c_vp), ("margin_waves", c_i64)]
 
 
 IMS_PLAN_ROUNDS = 9

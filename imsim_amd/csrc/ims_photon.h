@@ -989,25 +989,32 @@ IMS_DEV bool land_convert(const ims_render_params_t& P, const ims_object_t& o, i
 // in one batch of loads, was measured: 41.2 against 41.5 us per round of the brightest star, +1 % on the C3 step -- the
 // search is not where a round's latency goes; not kept.)
 // ims_render_params_t.lazy_static: a photon that would look at the (absent) state of slot 0 is set aside for the second launch
-// (k_margin_photons): position at the conversion depth, the depth with the coin in its sign, flux, object row.  One addition to
-// the counter per wavefront.
-IMS_DEV void margin_append(const ims_render_params_t& P, const ims_object_t& o, double x0, double y0, double zconv, bool coin, double flux)
+// (k_margin_photons): position at the conversion depth, the depth with the coin in its sign, flux, object row.  No atomic in the
+// common case: wavefront `wave_slot` of the launch owns an octet of records and a count byte (2 % of 64 photons: 1.3 records
+// expected); a ninth record goes to the overflow region behind one counter.  (One counter for all -- an addition with return
+// per wavefront -- made the fused launch of C3's 98 k objects 14 % SLOWER than reading the state: 600 k additions to one address.)
+IMS_DEV void margin_append(const ims_render_params_t& P, const ims_object_t& o, double x0, double y0, double zconv, bool coin, double flux,
+                           int64_t wave_slot)
 {
     const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
-    const int lane = (int)(threadIdx.x & 63), leader = __builtin_ctzll(active);
-    int base = 0;
-    if (lane == leader) base = atomicAdd(P.margin_count, (int)__popcll(active));
-    base = __shfl(base, leader, 64);
-    const unsigned int idx = (unsigned int)base + (unsigned int)__popcll(active & ((1ull << lane) - 1ull));
-    if (idx >= P.margin_cap) { atomicAdd(P.margin_count + 1, 1); return; }                 // (sized for every photon of the launch)
-    double* r = P.margin_list + 5 * (size_t)idx;
+    const int lane = (int)(threadIdx.x & 63);
+    const int rank = (int)__popcll(active & ((1ull << lane) - 1ull)), n = (int)__popcll(active);
+    double* r;
+    if (wave_slot >= 0 && rank < 8) {
+        r = P.margin_list + 5 * (size_t)(wave_slot * 8 + rank);
+        if (rank == 0) P.margin_wave_count[wave_slot] = (unsigned char)(n < 8 ? n : 8);
+    } else {
+        const int idx = atomicAdd(P.margin_count, 1);
+        if ((unsigned int)idx >= P.margin_cap) { atomicAdd(P.margin_count + 1, 1); return; }        // (sized for every photon of the launch)
+        r = P.margin_list + 5 * ((size_t)P.margin_waves * 8 + (size_t)idx);
+    }
     r[0] = x0; r[1] = y0; r[2] = coin ? -zconv : zconv; r[3] = flux;
     r[4] = __longlong_as_double((long long)(&o - P.objects));
 }
 
 template <int NV = 0, bool ZF = false>
 IMS_DEV bool land_search(const ims_render_params_t& P, const ims_object_t& o, double x0, double y0, double z, bool coin,
-                         int& ix, int& iy, double flux = 0.0)
+                         int& ix, int& iy, double flux = 0.0, int64_t wave_slot = -1)
 {
     const ims_sensor_t& s = *P.sensor;
     const ims_bf_slot_t bs = s.bf_slots[slot_index(P, o)];
@@ -1025,7 +1032,7 @@ IMS_DEV bool land_search(const ims_render_params_t& P, const ims_object_t& o, do
         if (o.bf_state == 0 && m >= 0.0 && pi >= 0 && pi < sl.nx && pj >= 0 && pj < sl.ny && x > m && x < 1.0 - m && y > m && y < 1.0 - m)
             found = true;
         else if (!ZF && P.lazy_static != 0u && o.bf_state == 0 && m >= 0.0 && pi >= 0 && pi < sl.nx && pj >= 0 && pj < sl.ny) {
-            margin_append(P, o, x0, y0, z, coin, flux);              // slot 0 holds no state: the second launch finishes this photon
+            margin_append(P, o, x0, y0, z, coin, flux, wave_slot);   // slot 0 holds no state: the second launch finishes this photon
             return false;
         } else
             found = inside_pixel<NV, ZF>(s, sl, ix, iy, x, y, z, true, off_edge);
@@ -1075,7 +1082,7 @@ IMS_DEV bool land_search(const ims_render_params_t& P, const ims_object_t& o, do
 // Decide the landing pixel.  Returns false when the photon is lost.
 template <int NV = 0>
 IMS_DEV bool land(const ims_render_params_t& P, const ims_object_t& o, int64_t k, Rng& rng, const Photon& ph,
-                  bool silicon, bool has_angles, int& ix, int& iy)
+                  bool silicon, bool has_angles, int& ix, int& iy, int64_t wave_slot = -1)
 {
     if (!silicon || (o.flags & IMS_OBJ_FAINT)) {
         ix = (int)floor(ph.x + 0.5); iy = (int)floor(ph.y + 0.5);
@@ -1084,7 +1091,7 @@ IMS_DEV bool land(const ims_render_params_t& P, const ims_object_t& o, int64_t k
     double x0, y0, zconv;
     bool coin;
     if (!land_convert(P, o, k, rng, ph, has_angles, x0, y0, zconv, coin)) return false;
-    return land_search<NV, false>(P, o, x0, y0, zconv, coin, ix, iy, ph.flux);
+    return land_search<NV, false>(P, o, x0, y0, zconv, coin, ix, iy, ph.flux, wave_slot);
 }
 
 IMS_DEV bool chain_has_angles(const ims_render_params_t& P)

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256, (CHAIN == 1) ? IMS_CHAIN_WAVES : IMS_FUSED_WAV
         make_photon<PSF>(P, o, k, rng, ph);
         run_ops<CHAIN, LAYOUT>(P, o, k, rng, ph);
         int ix, iy;
-        if (ph.flux != 0.0 && land(P, o, k, rng, ph, silicon, has_angles, ix, iy)) {
+        if (ph.flux != 0.0 && land(P, o, k, rng, ph, silicon, has_angles, ix, iy, seg * 4 + (int64_t)(threadIdx.x >> 6))) {
             added += ph.flux;
             tile_deposit(tile, ct, P, ix, iy, ph.flux);
         }
@@ -1210,10 +1210,12 @@ __global__ __launch_bounds__(256, 2) void k_margin_photons(const ims_render_para
     const ims_bf_slot_t bs = s.bf_slots[0];
     const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
     const double mm = s.pristine_margin;
-    unsigned int n = (unsigned int)P.margin_count[0];
-    if (n > P.margin_cap) n = P.margin_cap;
-    const unsigned int stride = gridDim.x * blockDim.x;
-    for (unsigned int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+    unsigned int n_over = (unsigned int)P.margin_count[0];
+    if (n_over > P.margin_cap) n_over = P.margin_cap;
+    const int64_t n_oct = P.margin_waves * 8, n = n_oct + (int64_t)n_over;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+        if (r < n_oct && (int)(r & 7) >= (int)P.margin_wave_count[r >> 3]) continue;          // an empty place of a wavefront's octet
         const double* rec = P.margin_list + 5 * (size_t)r;
         const double x0 = rec[0], y0 = rec[1], zs = rec[2], flux = rec[3];
         const int64_t oi = __double_as_longlong(rec[4]);
@@ -3085,7 +3087,7 @@ static unsigned photon_lds_pad(const ims_render_params_t* p)
 
 // the list of the photons a lazy_static launch sets aside: one buffer per (device, stream), sized for every photon of the launch
 // (launches on a stream run in order, so the next launch finds the second pass of the one before through with it)
-struct MarginBuf { double* list = nullptr; int32_t* count = nullptr; uint32_t cap = 0; };
+struct MarginBuf { double* list = nullptr; int32_t* count = nullptr; unsigned char* wave_count = nullptr; int64_t waves_cap = 0; uint32_t cap = 0; };
 static std::map<std::pair<int, void*>, MarginBuf> g_margin;
 
 int ims_shoot_accumulate(const ims_render_params_t* params_in, void* stream)
@@ -3108,18 +3110,24 @@ int ims_shoot_accumulate(const ims_render_params_t* params_in, void* stream)
         {
             std::lock_guard<std::mutex> lock(g_state_mutex);
             MarginBuf& m = g_margin[std::make_pair(dev, stream)];
-            if (m.cap < (uint32_t)want) {
-                if (m.list) { HIP_TRY(hipFree(m.list)); }
+            const int64_t waves = params_in->n_segments * 4;
+            if (m.cap < (uint32_t)want || m.waves_cap < waves) {
+                if (m.list) { HIP_TRY(hipFree(m.list)); HIP_TRY(hipFree(m.wave_count)); }
                 if (!m.count) HIP_TRY(hipMalloc((void**)&m.count, 2 * sizeof(int32_t)));
                 m.cap = (uint32_t)(want + want / 4 + 65536);
-                HIP_TRY(hipMalloc((void**)&m.list, (size_t)m.cap * 5 * sizeof(double)));
+                m.waves_cap = waves + waves / 4 + 1024;
+                // an octet of records per wavefront, then an overflow region that could take every photon of the launch
+                HIP_TRY(hipMalloc((void**)&m.list, ((size_t)m.waves_cap * 8 + (size_t)m.cap) * 5 * sizeof(double)));
+                HIP_TRY(hipMalloc((void**)&m.wave_count, (size_t)m.waves_cap));
             }
             mb = m;
         }
         lazy_copy = *params_in;
         lazy_copy.margin_list = mb.list; lazy_copy.margin_count = mb.count; lazy_copy.margin_cap = mb.cap;
+        lazy_copy.margin_wave_count = mb.wave_count; lazy_copy.margin_waves = params_in->n_segments * 4;
         params = &lazy_copy;
         HIP_TRY(hipMemsetAsync(mb.count, 0, 2 * sizeof(int32_t), st));
+        HIP_TRY(hipMemsetAsync(mb.wave_count, 0, (size_t)lazy_copy.margin_waves, st));
     }
     {
         LaunchTimer tm(st, 1);

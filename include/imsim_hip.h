@@ -403,9 +403,11 @@ typedef struct ims_render_params {
      * function the stored state is made by, so the same bits (round 5).  Needs 4 vertices per edge and a pristine_margin >= 0.
      * The caller sets lazy_static; the library fills the three fields behind it for its launches. */
     uint32_t lazy_static;
-    uint32_t margin_cap;
-    double*  margin_list;
-    int32_t* margin_count;
+    uint32_t margin_cap;             /* (library) records of the overflow region */
+    double*  margin_list;            /* (library) margin_waves x 8 records of 40 B, one octet per wavefront of the launch, then the overflow region */
+    int32_t* margin_count;           /* (library) [0] records in the overflow region, [1] records that found no room (never: it is sized for the launch) */
+    unsigned char* margin_wave_count;/* (library) per wavefront of the launch: records in its octet */
+    int64_t  margin_waves;           /* (library) wavefronts of the launch: 4 x n_segments */
 } ims_render_params_t;
 
 /* ---- library ---- */

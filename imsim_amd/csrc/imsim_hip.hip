@@ -1203,8 +1203,56 @@ __device__ __forceinline__ bool lazy_inside_pixel(const ims_sensor_t& s, const T
 // The photons ims_shoot_accumulate set aside (margin_append): land_search from the point where it would have read the state.
 // A neighbour whose outer bounds cannot hold the point is not evaluated: no vertex of a pristine polygon lies further than
 // pristine_margin from its nominal place, so outer bounds lie within [-m, 1 + m] -- the candidates of the walk are the same.
+__device__ __forceinline__ void margin_photon(const ims_render_params_t& P, const ims_sensor_t& s, const TreeRing& T, const SlotView& sl, double mm,
+                                              int64_t r)
+{
+    const double* rec = P.margin_list + 5 * (size_t)r;
+    const double x0 = rec[0], y0 = rec[1], zs = rec[2], flux = rec[3];
+    const int64_t oi = __double_as_longlong(rec[4]);
+    const ims_object_t& o = P.objects[oi];
+    const double z = fabs(zs);
+    const bool coin = __double_as_longlong(zs) < 0;
+    int ix = (int)floor(x0 + 0.5), iy = (int)floor(y0 + 0.5);
+    const double x = x0 - (double)ix + 0.5, y = y0 - (double)iy + 0.5;
+    bool off_edge = false;
+    bool found = lazy_inside_pixel(s, T, sl, ix, iy, x, y, z, true, off_edge);
+    if (!found && off_edge) return;
+    int step = 0;
+    if (!found) {
+        step = search_step(x, y);
+        for (int m = 1; m < 9; ++m) {
+            const int nb = ((m * step - 1) & 7) + 1;
+            const int jx = ix + xoff(nb), jy = iy + yoff(nb);
+            const int i = jx - sl.xmin, j = jy - sl.ymin;
+            if (i < 0 || i >= sl.nx || j < 0 || j >= sl.ny) continue;
+            const double xb = x - (double)xoff(nb), yb = y - (double)yoff(nb);
+            if (xb < -mm || xb > 1.0 + mm || yb < -mm || yb > 1.0 + mm) continue;
+            LazyPixel px;
+            lazy_pixel(s, T, sl, i, j, px);
+            if (!(xb >= px.b[4] && xb <= px.b[5] && yb >= px.b[6] && yb <= px.b[7])) continue;      // not a candidate of the walk
+            bool in = (xb > px.b[0] && xb < px.b[1] && yb > px.b[2] && yb < px.b[3]);
+            if (!in) in = lazy_polygon_test(s, px, xb, yb, dtanh_pos(ddiv(z, 12.0)));
+            if (in) { ix = jx; iy = jy; found = true; break; }
+        }
+    }
+    if (!found) {
+        const int nb = coin ? 0 : step;
+        ix = ix + xoff(nb); iy = iy + yoff(nb);
+    }
+    if (ix < o.stamp_xmin || ix > o.stamp_xmax || iy < o.stamp_ymin || iy > o.stamp_ymax) return;
+    const int pxl = ix - P.xmin, pyl = iy - P.ymin;
+    if (pxl >= 0 && pxl < P.nx && pyl >= 0 && pyl < P.ny) unsafeAtomicAdd(P.image + ((int64_t)pyl * P.nx + pxl), flux);
+    if (P.realized_flux != nullptr) unsafeAtomicAdd(P.realized_flux + oi, flux);
+}
+
+// A workgroup takes 2 048 places of the list at a time (the wavefronts' octets, then the overflow region), collects the filled ones
+// in LDS -- one place in six is -- and then works on them with every lane busy (a lane per place sat through the search with a sixth
+// of its lanes: 0.97 ms for C3's launch where 0.25 do).  The order of the photons does not matter: integer counts, atomics.
+constexpr int MARGIN_CHUNK = 2048;
 __global__ __launch_bounds__(256, 2) void k_margin_photons(const ims_render_params_t P)
 {
+    __shared__ int q[MARGIN_CHUNK];
+    __shared__ int qn;
     const ims_sensor_t& s = *P.sensor;
     const TreeRing T = treering_of(s);
     const ims_bf_slot_t bs = s.bf_slots[0];
@@ -1213,46 +1261,18 @@ __global__ __launch_bounds__(256, 2) void k_margin_photons(const ims_render_para
     unsigned int n_over = (unsigned int)P.margin_count[0];
     if (n_over > P.margin_cap) n_over = P.margin_cap;
     const int64_t n_oct = P.margin_waves * 8, n = n_oct + (int64_t)n_over;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
-        if (r < n_oct && (int)(r & 7) >= (int)P.margin_wave_count[r >> 3]) continue;          // an empty place of a wavefront's octet
-        const double* rec = P.margin_list + 5 * (size_t)r;
-        const double x0 = rec[0], y0 = rec[1], zs = rec[2], flux = rec[3];
-        const int64_t oi = __double_as_longlong(rec[4]);
-        const ims_object_t& o = P.objects[oi];
-        const double z = fabs(zs);
-        const bool coin = __double_as_longlong(zs) < 0;
-        int ix = (int)floor(x0 + 0.5), iy = (int)floor(y0 + 0.5);
-        const double x = x0 - (double)ix + 0.5, y = y0 - (double)iy + 0.5;
-        bool off_edge = false;
-        bool found = lazy_inside_pixel(s, T, sl, ix, iy, x, y, z, true, off_edge);
-        if (!found && off_edge) continue;
-        int step = 0;
-        if (!found) {
-            step = search_step(x, y);
-            for (int m = 1; m < 9; ++m) {
-                const int nb = ((m * step - 1) & 7) + 1;
-                const int jx = ix + xoff(nb), jy = iy + yoff(nb);
-                const int i = jx - sl.xmin, j = jy - sl.ymin;
-                if (i < 0 || i >= sl.nx || j < 0 || j >= sl.ny) continue;
-                const double xb = x - (double)xoff(nb), yb = y - (double)yoff(nb);
-                if (xb < -mm || xb > 1.0 + mm || yb < -mm || yb > 1.0 + mm) continue;
-                LazyPixel px;
-                lazy_pixel(s, T, sl, i, j, px);
-                if (!(xb >= px.b[4] && xb <= px.b[5] && yb >= px.b[6] && yb <= px.b[7])) continue;      // not a candidate of the walk
-                bool in = (xb > px.b[0] && xb < px.b[1] && yb > px.b[2] && yb < px.b[3]);
-                if (!in) in = lazy_polygon_test(s, px, xb, yb, dtanh_pos(ddiv(z, 12.0)));
-                if (in) { ix = jx; iy = jy; found = true; break; }
-            }
+    for (int64_t c0 = (int64_t)blockIdx.x * MARGIN_CHUNK; c0 < n; c0 += (int64_t)gridDim.x * MARGIN_CHUNK) {
+        if (threadIdx.x == 0) qn = 0;
+        __syncthreads();
+        for (int k = (int)threadIdx.x; k < MARGIN_CHUNK; k += 256) {
+            const int64_t r = c0 + k;
+            const bool filled = r < n && (r >= n_oct || (int)(r & 7) < (int)P.margin_wave_count[r >> 3]);
+            if (filled) q[atomicAdd(&qn, 1)] = k;
         }
-        if (!found) {
-            const int nb = coin ? 0 : step;
-            ix = ix + xoff(nb); iy = iy + yoff(nb);
-        }
-        if (ix < o.stamp_xmin || ix > o.stamp_xmax || iy < o.stamp_ymin || iy > o.stamp_ymax) continue;
-        const int pxl = ix - P.xmin, pyl = iy - P.ymin;
-        if (pxl >= 0 && pxl < P.nx && pyl >= 0 && pyl < P.ny) unsafeAtomicAdd(P.image + ((int64_t)pyl * P.nx + pxl), flux);
-        if (P.realized_flux != nullptr) unsafeAtomicAdd(P.realized_flux + oi, flux);
+        __syncthreads();
+        const int m = qn;
+        for (int k = (int)threadIdx.x; k < m; k += 256) margin_photon(P, s, T, sl, mm, c0 + q[k]);
+        __syncthreads();
     }
 }
 

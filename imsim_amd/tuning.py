@@ -43,7 +43,7 @@ KNOWN = {
     "IMS_PAIR_MAX_OBJECTS": ("64", "... for chain classes of at most this many objects"),
     "IMS_LAZY_STATIC": ("0", "Renderer without an explicit lazy_static: 1 = slot 0 without stored state where it applies (LSST_Image renders only).  "
                              "A single CCD makes its state once per renderer, not per step, and its second launch is a serial tail of the "
-                             "wide-launch stream: C3 24.9 against 24.4 ms, same image"),
+                             "wide-launch stream: C3 24.2 ms either way, same image"),
     "IMS_NATIVE_PLAN": ("1", "launch plan of a CCD built and enqueued by the library (ims_plan_*); 0 = the numpy planner (the checker)"),
     "IMS_POOL_RESIDENT": ("1", "photon pooling with the pool of all batches in HBM; 0 = one fused launch per batch"),
     "IMS_POOL_OVERLAP": ("0", "photon pooling: 1 = the pool shot batch by batch on a stream of its own, ahead of the batches' pixel searches "

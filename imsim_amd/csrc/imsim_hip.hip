@@ -1712,171 +1712,6 @@ __global__ __launch_bounds__(256) void k_update_distortions_q3_j(const JointUpd*
                              gridDim.x <= 64u, L);
 }
 
-// ---- updatePixelDistortions AND the bounds refresh in ONE launch, for regions held as a PAIR of slots ----
-// A round of a long brighter-fatter chain is three dependent launches, and under load every launch boundary costs the chain
-// tens of microseconds of waiting for wave slots.  The refresh needs the NEW points of a cell's right and upper neighbours,
-// which another workgroup is writing -- so the region lives twice (ims_chain_t.pair_shift: slot k and slot k + shift, same
-// shape): this kernel reads points and delta image of the SOURCE slot, which nobody writes meanwhile, and writes the
-// destination slot completely: new points of its 16 x 16 owner cells, their bounds lines, a zero delta image.  The new
-// points of the 16 + 16 halo cells right of and above the tile (left-edge resp. bottom-row points only) are formed by a fifth
-// wavefront with the same arithmetic the owning tile uses, and handed over through LDS.  4 vertices per edge, qdist 3.
-constexpr int UR = UT - 1;            // owner cells per tile edge of the fused kernel: the 16th column / row of lanes is the halo
-
-struct UpdRefLds {
-    static constexpr int Q = 3, HW = UT + 2 * Q + 1;                 // 23: charge halo of the 16 x 16 lanes
-    double wt[HW * HW];
-    unsigned int occ[HW];
-    int any_charge;
-    double2 left[UT][UT][IT_NV];                                     // new left-edge points of the cell of lane (lx, ly)
-    double2 bottom[UT][UT][IT_NV + 2];                               // new bottom-row points
-};
-
-// One workgroup = 15 x 15 owner cells of one region (tiles of edge UR, prefix sum in tile_prefix) on 16 x 16 lanes: the
-// lanes of the last column / row form the new points of the cells right of / above the tile with the arithmetic their own
-// tile uses, hand them over through LDS and store nothing.  (Four wavefronts: a fifth for the halo made the workgroup wait
-// for TWO free wave slots on one SIMD beside the photon kernels -- C3 38 ms.)
-__global__ __launch_bounds__(256) void k_update_refresh(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
-                                                           int src_shift, int dst_shift, const int64_t* __restrict__ tile_prefix,
-                                                           const double* __restrict__ dl_global)
-{
-    constexpr int NV = IT_NV, Q = UpdRefLds::Q, HW = UpdRefLds::HW, NPO = IT_NPO;
-    __shared__ UpdRefLds L;
-    const ims_sensor_t& s = *sp;
-    const int64_t b = blockIdx.x;
-    const int lo = find_slot(tile_prefix, n_slots, b);
-    const ims_bf_slot_t bs = s.bf_slots[first_slot + lo + src_shift], bd = s.bf_slots[first_slot + lo + dst_shift];
-    const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };          // source
-    const SlotView dl = { bd.xmin, bd.ymin, bd.nx, bd.ny, bd.offset };          // destination (same shape)
-    const int tiles_x = (sl.nx + 1 + UR - 1) / UR;
-    const int t = (int)(b - tile_prefix[lo]);
-    const int tx0 = (t % tiles_x) * UR, ty0 = (t / tiles_x) * UR;
-    const int sx0 = tx0 - (Q + 1), sy0 = ty0 - (Q + 1);
-    const int tid = threadIdx.x;
-    if (tid < HW) L.occ[tid] = 0u;
-    if (tid == 0) L.any_charge = 0;
-    __syncthreads();
-    for (int e = tid; e < HW * HW; e += 256) {
-        const int hx = e % HW, hy = e / HW;
-        const int si = sx0 + hx, sj = sy0 + hy;
-        double w = 0.0;
-        if (si >= 0 && si < sl.nx && sj >= 0 && sj < sl.ny) {
-            const double charge = (double)s.bf_delta[cell_index(sl, si, sj)];
-            if (charge != 0.0) { w = ddiv(charge, s.num_elec); atomicOr(&L.occ[hy], 1u << hx); L.any_charge = 1; }
-        }
-        L.wt[e] = w;
-    }
-    __syncthreads();
-    const int lx = tid % UT, ly = tid / UT;
-    const bool own = lx < UR && ly < UR;                     // the others only serve their left / lower neighbours
-    const int i = tx0 + lx, j = ty0 + ly;
-    const bool in_region = i <= sl.nx && j <= sl.ny;
-    double acc[NPO * 2];
-    if (in_region) {
-        const double* pts = s.bf_boundary + cell_index(sl, i, j) * NPO * 2;
-#pragma unroll
-        for (int n = 0; n < NPO * 2; ++n) acc[n] = pts[n];
-        if (L.any_charge) {
-            unsigned long long mask = 0ull;
-#pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                const unsigned int row = (L.occ[ly + 2 * Q + 1 - a] >> lx) & 0xFFu;
-                const unsigned int rev = __brev(row) >> 24;
-                mask |= (unsigned long long)rev << (8 * a);
-            }
-            // the static 8 x 8 window of update_tile_q3, in the spec's order (dj ascending, then di ascending)
-#pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                const unsigned int rowbits = (unsigned int)(mask >> (8 * a)) & 0xFFu;
-                if (__builtin_amdgcn_ballot_w64(rowbits != 0u) == 0ull) continue;
-#pragma unroll
-                for (int bb = 0; bb < 8; ++bb) {
-                    const double w = L.wt[(ly + 2 * Q + 1 - a) * HW + (lx + 2 * Q + 1 - bb)];
-                    const double* d = dl_global + (a * 8 + bb) * NPO * 2;
-                    if (bb != 7) {
-#pragma unroll
-                        for (int n = 0; n <= NV + 1; ++n) {
-                            acc[2 * n] = fma(d[2 * n], w, acc[2 * n]);
-                            acc[2 * n + 1] = fma(d[2 * n + 1], w, acc[2 * n + 1]);
-                        }
-                    }
-                    if (a != 7) {
-#pragma unroll
-                        for (int n = NV + 2; n < NPO; ++n) {
-                            acc[2 * n] = fma(d[2 * n], w, acc[2 * n]);
-                            acc[2 * n + 1] = fma(d[2 * n + 1], w, acc[2 * n + 1]);
-                        }
-                    }
-                }
-            }
-        }
-        if (own) {
-            const int64_t cd = cell_index(dl, i, j);
-            double* out = s.bf_boundary + cd * NPO * 2;
-#pragma unroll
-            for (int n = 0; n < NPO * 2; ++n) out[n] = acc[n];
-            s.bf_delta[cd] = 0.0;
-        }
-#pragma unroll
-        for (int m = 0; m < NV; ++m) L.left[ly][lx][m] = make_double2(acc[2 * (NV + 2 + m)], acc[2 * (NV + 2 + m) + 1]);
-#pragma unroll
-        for (int q = 0; q <= NV + 1; ++q) L.bottom[ly][lx][q] = make_double2(acc[2 * q], acc[2 * q + 1]);
-    }
-    __syncthreads();
-    if (!own || i >= sl.nx || j >= sl.ny) return;
-    double2 rgt[NV], upp[NV + 2];
-#pragma unroll
-    for (int m = 0; m < NV; ++m) rgt[m] = L.left[ly][lx + 1][m];
-#pragma unroll
-    for (int q = 0; q <= NV + 1; ++q) upp[q] = L.bottom[ly + 1][lx][q];
-    double ixmin = 0.0, ixmax = 1.0, iymin = 0.0, iymax = 1.0;
-    double oxmin = 0.0, oxmax = 1.0, oymin = 0.0, oymax = 1.0;
-    double v0x = 0.0;
-#pragma unroll
-    for (int k = 0; k < IT_NVT; ++k) {
-        double vx, vy;
-        if (k <= NV + 1) { vx = acc[2 * k]; vy = acc[2 * k + 1]; }
-        else if (k <= 2 * NV + 1) { vx = rgt[k - NV - 2].x + 1.0; vy = rgt[k - NV - 2].y; }
-        else if (k <= 3 * NV + 3) { vx = upp[NV + 1 - (k - 2 * NV - 2)].x; vy = upp[NV + 1 - (k - 2 * NV - 2)].y + 1.0; }
-        else { const int q = NV + 2 + (NV - 1 - (k - 3 * NV - 4)); vx = acc[2 * q]; vy = acc[2 * q + 1]; }
-        if (k == 0) v0x = vx;
-        if (vx < oxmin) oxmin = vx;
-        if (vx > oxmax) oxmax = vx;
-        if (vy < oymin) oymin = vy;
-        if (vy > oymax) oymax = vy;
-        if (k <= NV + 1) { if (vy > iymin) iymin = vy; }
-        if (k >= NV + 1 && k <= 2 * NV + 2) { if (vx < ixmax) ixmax = vx; }
-        if (k >= 2 * NV + 2 && k <= 3 * NV + 3) { if (vy < iymax) iymax = vy; }
-        if (k >= 3 * NV + 3) { if (vx > ixmin) ixmin = vx; }
-    }
-    if (v0x > ixmin) ixmin = v0x;
-    double* bb = s.bf_bounds + cell_index(dl, i, j) * 8;
-    bb[0] = ixmin; bb[1] = ixmax; bb[2] = iymin; bb[3] = iymax;
-    bb[4] = oxmin; bb[5] = oxmax; bb[6] = oymin; bb[7] = oymax;
-}
-
-// the final state of a pair back in its first slot: objects whose last round was an odd one hold it in the second
-__global__ __launch_bounds__(256) void k_publish_pairs(const ims_sensor_t* __restrict__ sp, const ims_object_t* __restrict__ objects,
-                                                       int first_slot, int pair_shift, int nrecalc)
-{
-    const ims_sensor_t& s = *sp;
-    const int k = blockIdx.y;
-    const int64_t n = objects[k].n_phot;
-    const int64_t rounds = (n + nrecalc - 1) / nrecalc;
-    if (((rounds - 1) & 1) == 0) return;                      // the last round ran on the first slot
-    const ims_bf_slot_t a = s.bf_slots[first_slot + k], bsl = s.bf_slots[first_slot + k + pair_shift];
-    const int64_t cells = (int64_t)(a.nx + 1) * (a.ny + 1);
-    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < cells; c += (int64_t)gridDim.x * 256) {
-        const double* ps = s.bf_boundary + (bsl.offset + c) * IT_NPO * 2;
-        double* pd = s.bf_boundary + (a.offset + c) * IT_NPO * 2;
-#pragma unroll
-        for (int q = 0; q < IT_NPO * 2; ++q) pd[q] = ps[q];
-        const double* bs_ = s.bf_bounds + (bsl.offset + c) * 8;
-        double* bd_ = s.bf_bounds + (a.offset + c) * 8;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) bd_[q] = bs_[q];
-        s.bf_delta[a.offset + c] = s.bf_delta[bsl.offset + c];
-    }
-}
 
 // bounds of the pixels whose polygon moved (own cell, right cell or upper cell changed); one 16x16
 // tile of owner cells per workgroup, same grid as the update kernel.  With a tag, tiles that saw
@@ -3463,36 +3298,6 @@ int ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sens
 }
 
 
-int ims_sensor_update_refresh(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host, int32_t first_slot, int32_t n_slots,
-                              int32_t src_shift, int32_t dst_shift, const int64_t* tile_prefix_dev, int64_t n_tiles, void* stream)
-{
-    if (!sensor_dev || !sensor_host) return set_err(IMS_ERR_ARG, "sensor is NULL");
-    if (n_slots == 0) return IMS_OK;
-    if (!tile_prefix_dev || n_tiles <= 0 || n_tiles > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "tile_prefix / n_tiles");
-    if (sensor_host->qdist != 3 || sensor_host->num_vertices != IT_NV || !sensor_host->bf_dl)
-        return set_err(IMS_ERR_UNSUPPORTED, "ims_sensor_update_refresh needs qdist 3, 4 vertices per edge and the window table (bf_dl)");
-    if (first_slot <= 0 || src_shift < 0 || dst_shift < 0 || src_shift == dst_shift ||
-        first_slot + n_slots + (src_shift > dst_shift ? src_shift : dst_shift) > sensor_host->n_bf_slots)
-        return set_err(IMS_ERR_ARG, "slot pair out of range");
-    hipLaunchKernelGGL(k_update_refresh, dim3((unsigned)n_tiles), dim3(256), 0, (hipStream_t)stream, sensor_dev, first_slot, n_slots,
-                       src_shift, dst_shift, tile_prefix_dev, sensor_host->bf_dl);
-    HIP_TRY(hipGetLastError());
-    return IMS_OK;
-}
-
-int ims_sensor_publish_pairs(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host, const ims_object_t* objects_dev,
-                             int32_t first_slot, int32_t n_slots, int32_t pair_shift, int32_t nrecalc, void* stream)
-{
-    if (!sensor_dev || !sensor_host || !objects_dev) return set_err(IMS_ERR_ARG, "NULL argument");
-    if (n_slots <= 0) return IMS_OK;
-    if (pair_shift <= 0 || nrecalc <= 0 || first_slot <= 0 || first_slot + n_slots + pair_shift > sensor_host->n_bf_slots || n_slots > 65535)
-        return set_err(IMS_ERR_ARG, "slot pair out of range");
-    hipLaunchKernelGGL(k_publish_pairs, dim3(8, (unsigned)n_slots), dim3(256), 0, (hipStream_t)stream, sensor_dev, objects_dev, first_slot,
-                       pair_shift, nrecalc);
-    HIP_TRY(hipGetLastError());
-    return IMS_OK;
-}
-
 // library events of RECORD / WAIT items (one process per GPU)
 static int plan_event(int number, hipEvent_t* out)
 {
@@ -3530,7 +3335,6 @@ static int run_rounds(const ims_chain_t* chains, int32_t n_chains, const ims_sen
         const ims_chain_t& ch = chains[c];
         if (!ch.params || !ch.pool || !ch.pool_start || !ch.n_phot || !ch.tile_prefix || !ch.tile_prefix_host)
             return set_err(IMS_ERR_ARG, "chain: NULL pointer");
-        if (ch.pair_shift > 0 && (!ch.pair_tile_prefix || !ch.pair_tile_prefix_host)) return set_err(IMS_ERR_ARG, "chain: pair_tile_prefix is NULL");
         if (ch.stream < 0 || ch.stream >= n_streams) return set_err(IMS_ERR_ARG, "chain stream index out of range");
         if (ch.nrecalc <= 0 || ch.n_rounds < 0 || ch.n_objects < 0 || ch.n_objects > ch.params->n_objects)
             return set_err(IMS_ERR_ARG, "chain: nrecalc / n_rounds / n_objects out of range");
@@ -3553,28 +3357,17 @@ static int run_rounds(const ims_chain_t* chains, int32_t n_chains, const ims_sen
                 }
             const int32_t n_act = count_above(ch.n_phot, ch.n_objects, (int64_t)r * ch.nrecalc);
             if (n_act == 0) continue;
-            const bool pairs = ch.pair_shift > 0;                                 // the regions live as slot pairs: two launches per round
-            const uint32_t tag = (ch.use_tags && !pairs) ? (uint32_t)(r % 255 + 1) : 0u;   // marks the tiles this round's charge lands in
+            const uint32_t tag = ch.use_tags ? (uint32_t)(r % 255 + 1) : 0u;       // marks the tiles this round's charge lands in
             // (the varying fields are set in a copy that is only read on the host: the launch takes the compact argument block)
             ims_render_params_t P = *ch.params;
             P.bf_tag = tag;
-            P.bf_slot_shift = pairs ? (uint32_t)((r & 1) * ch.pair_shift) : 0u;
+            P.bf_slot_shift = 0u;
             int rc = accumulate_round_compact(&P, ch.pool, ch.pool_start, r, ch.nrecalc, n_act, sensor_host ? sensor_host->num_vertices : 0, st);
             if (rc) return rc;
             const int32_t n_cont = count_above(ch.n_phot, ch.n_objects, (int64_t)(r + 1) * ch.nrecalc);
             if (n_cont > 0) {
-                if (pairs)
-                    rc = ims_sensor_update_refresh(sensor_dev, sensor_host, ch.first_slot, n_cont, (r & 1) * ch.pair_shift,
-                                                   ((r + 1) & 1) * ch.pair_shift, ch.pair_tile_prefix, ch.pair_tile_prefix_host[n_cont], st);
-                else
-                    rc = ims_sensor_update_distortions(sensor_dev, sensor_host, ch.first_slot, n_cont, ch.tile_prefix,
-                                                       ch.tile_prefix_host[n_cont], changed_dev, tag, st);
-                if (rc) return rc;
-            }
-            if (pairs && r == ch.n_rounds - 1) {
-                // the chain is through: every object's final state back in its first slot (as without pairs)
-                rc = ims_sensor_publish_pairs(sensor_dev, sensor_host, ch.params->objects, ch.first_slot, ch.n_objects, ch.pair_shift,
-                                              ch.nrecalc, st);
+                rc = ims_sensor_update_distortions(sensor_dev, sensor_host, ch.first_slot, n_cont, ch.tile_prefix,
+                                                   ch.tile_prefix_host[n_cont], changed_dev, tag, st);
                 if (rc) return rc;
             }
         }
@@ -3774,7 +3567,7 @@ static int plan_enqueue(ims_planner::Plan* pl, ims_sensor_t* sensor_dev, ims_sen
                  sensor_host->num_vertices == IT_NV && sensor_host->qdist == 3;
     if (defer)
         for (const ims_chain_t& cs : pl->groups[0].chain_structs)
-            defer = defer && cs.pair_shift == 0 && cs.first_slot > 0;
+            defer = defer && cs.first_slot > 0;
     // distinct streams
     std::vector<hipStream_t> uniq;
     for (int k = 0; k < n_streams; ++k)

@@ -1166,7 +1166,6 @@ class Renderer:
         # round-count thresholds that cut the bright objects into concurrent chains (plan_lsst_image)
         self.chain_class_rounds = tuple(int(v) for v in tuning.env("IMS_CHAIN_CLASSES", "40,6").split(",") if v)
         self.max_pool_photons = 300_000_000      # 32 B each
-        self.pair_max_objects = int(tuning.env("IMS_PAIR_MAX_OBJECTS", "64"))   # chain classes up to this size use slot pairs
         ss = scene.sensor
         if lazy_static is None:
             lazy_static = tuning.flag("IMS_LAZY_STATIC")
@@ -1356,36 +1355,11 @@ class Renderer:
         if nrecalc is None:
             nrecalc = ss.model.nrecalc
         b = self.bound
-        # Slot PAIRS (ims_chain_t.pair_shift): every private region twice, so that a round is two launches (pixel search,
-        # then updatePixelDistortions + refresh in one).  Needs qdist 3, 4 vertices per edge; half the scratch per group.
-        # OFF by default: alone a chain runs 10 % faster (one star 7.33 -> 6.6 ms), but the fused launch rewrites every cell of
-        # every region and takes 100 us for the 369 tiles of 41 objects against 58 us for update + refresh in place, so the
-        # C3 step goes 24.9 -> 37 ms; IMS_SLOT_PAIRS=1 turns it on for chain classes of at most
-        # IMS_PAIR_MAX_OBJECTS objects.
-        pairs = (tuning.env("IMS_SLOT_PAIRS", "0") != "0" and ss.model.qdist == 3 and ss.model.num_vertices == 4
-                 and not self.use_bf_tags)
-        if pairs:
-            try:
-                normal, groups = plan_bf_groups(objects, nrecalc, b.n_static_slots, b.static_cells, b.scratch_cells // 2,
-                                                (b.slot_capacity - b.n_static_slots) // 2 + b.n_static_slots, self.max_pool_photons)
-            except ValueError:
-                pairs = False                      # half the scratch does not hold the largest stamp: regions in place
-        if not pairs:
-            normal, groups = plan_bf_groups(objects, nrecalc, b.n_static_slots, b.static_cells, b.scratch_cells,
-                                            b.slot_capacity, self.max_pool_photons)
-            self.pairs_begin = None
+        normal, groups = plan_bf_groups(objects, nrecalc, b.n_static_slots, b.static_cells, b.scratch_cells,
+                                        b.slot_capacity, self.max_pool_photons)
         n_events = self._event_block
         render_done = False
         for idx, slots in groups:
-            pair_shift = 0
-            if pairs:
-                # the second slots behind all first ones: same shapes, offsets shifted by the cells of the group
-                pair_shift = len(slots)
-                second = slots.copy()
-                last = slots[-1]
-                second["offset"] += int(last["offset"]) + (int(last["nx"]) + 1) * (int(last["ny"]) + 1) - int(slots[0]["offset"])
-                slots = np.concatenate([slots, second])
-                self.pairs_begin = int(second[0]["offset"])          # owner cells from here on are second slots (scratch of the rounds)
             plan.append(("slots", slots))
             n0 = b.n_static_slots
             grp = objects[idx]                            # (a fancy-indexed copy) sorted by n_phot, brightest first
@@ -1459,11 +1433,7 @@ class Renderer:
                 P, keep = upload(ch["grp"], ch["idx"], "acc_pool")
                 descs.append(dict(P=P, keep=(keep, start_t), pool=pool, start=start_t,
                                   n_phot=np.ascontiguousarray(ch["tot"], dtype=np.int64), first_slot=n0 + ch["ca"],
-                                  stream=ch["stream"], rounds=ch["rounds"], edges=ch["edges"], ev_base=ch["ev_base"],
-                                  # pairs only for the long chains of few objects, where a round's latency counts; the wide
-                                  # rounds of the moderately bright objects are throughput work, and there the fused launch,
-                                  # which rewrites every cell of every region every round, is the slower form (C3 41.7 ms)
-                                  pair_shift=pair_shift if len(ch["tot"]) <= self.pair_max_objects else 0))
+                                  stream=ch["stream"], rounds=ch["rounds"], edges=ch["edges"], ev_base=ch["ev_base"]))
             plan.append(("rounds", descs, int(nrecalc), 1 if self.use_bf_tags else 0))
             if n_events - self._event_block > EVENT_BLOCK or n_events >= self.PREPASS_EVENT:
                 raise ValueError(f"a plan may use at most {EVENT_BLOCK} library events (its renderer's block)")
@@ -1523,15 +1493,6 @@ class Renderer:
                     c.n_phot, c.tile_prefix, c.tile_prefix_host = d["n_phot"].ctypes.data, prefix_t.data_ptr(), prefix.ctypes.data
                     c.n_objects, c.first_slot, c.stream, c.nrecalc = len(d["n_phot"]), d["first_slot"], self.STREAMS[d["stream"]], nrecalc
                     c.n_rounds, c.use_tags, c.ev_base = d["rounds"], use_tags, d["ev_base"]
-                    c.pair_shift = d.get("pair_shift", 0)
-                    if c.pair_shift:
-                        sl15 = (cur_prefix[0][d["first_slot"] - b.n_static_slots:] if cur_prefix is not None
-                                else b._slots_host[d["first_slot"]:b.sensor_host.n_bf_slots])
-                        t15 = ((sl15["nx"].astype(np.int64) + 1 + 14) // 15) * ((sl15["ny"].astype(np.int64) + 1 + 14) // 15)
-                        p15 = np.concatenate([[0], np.cumsum(t15)]).astype(np.int64)
-                        p15_t = self.mem.put(p15)[0]
-                        c.pair_tile_prefix, c.pair_tile_prefix_host = p15_t.data_ptr(), p15.ctypes.data
-                        keep.append((p15, p15_t))
                     edges = d["edges"][:-1]                      # slice starts; the last edge is the round count
                     if len(edges) > _abi.IMS_MAX_CHAIN_EDGES:
                         raise ValueError("too many pool slices for one chain")
@@ -1619,8 +1580,8 @@ class Renderer:
     # -- the native planner (ims_plan_*): plan, bind, upload and run of one LSST_Image render inside the library --
     def native_plan_ok(self, objects):
         """The library's planner covers the default path; the options it does not know run the numpy planner: the phase-screen
-        pre-pass, slot pairs, and IMS_NATIVE_PLAN=0 (which keeps the numpy planner as the checker it is in the tests)."""
-        if tuning.env("IMS_NATIVE_PLAN", "1") == "0" or tuning.env("IMS_SLOT_PAIRS", "0") != "0":
+        pre-pass, and IMS_NATIVE_PLAN=0 (which keeps the numpy planner as the checker it is in the tests)."""
+        if tuning.env("IMS_NATIVE_PLAN", "1") == "0":
             return False
         if tuning.env("IMS_SCREEN_PREPASS", "0") != "0" and self.scene.atm is not None:
             return False

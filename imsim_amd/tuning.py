@@ -39,8 +39,6 @@ KNOWN = {
     "IMS_UPLOAD_SYNC": ("0", "engine.upload_async as the synchronous copy it replaced"),
     "IMS_BF_TAGS": ("0", "tile marks in LSST_Image chains (the update skips tiles without charge in reach)"),
     "IMS_CHAIN_CLASSES": ("40,6", "round counts that cut the bright objects into concurrent brighter-fatter chains"),
-    "IMS_SLOT_PAIRS": ("0", "regions of the long chains as slot pairs, two launches per round (measured slower under load)"),
-    "IMS_PAIR_MAX_OBJECTS": ("64", "... for chain classes of at most this many objects"),
     "IMS_LAZY_STATIC": ("0", "Renderer without an explicit lazy_static: 1 = slot 0 without stored state where it applies (LSST_Image renders only).  "
                              "A single CCD makes its state once per renderer, not per step, and its second launch is a serial tail of the "
                              "wide-launch stream: C3 24.2 ms either way, same image"),

@@ -382,8 +382,7 @@ typedef struct ims_render_params {
     double*  realized_flux;          /* device [n_objects] or NULL: flux added per object (base['realized_flux'], stamp.py:573) */
     uint32_t bf_tag;                 /* 1..255: mark the tiles that receive delta charge (ims_sensor_t.bf_tile_charge); 0 = off */
     uint32_t bf_slot_shift;          /* added to the bf_state of objects with a private region (bf_state > 0) when the launch looks the
-                                      * slot up: the rounds of a brighter-fatter chain alternate between the two slots of a pair
-                                      * (ims_chain_t.pair_shift); 0 everywhere else */
+                                      * slot up; 0 (regions held as slot pairs used it: removed in round 5) */
     const int32_t* seg_object;       /* device [n_segments] or NULL: object index of every segment; when given, a
                                       * workgroup finds its object with one load instead of a search in seg_prefix */
     ims_image_tables_t images;       /* IMS_PROF_IMAGE profiles */
@@ -750,14 +749,6 @@ typedef struct ims_chain {
     int32_t n_objects, first_slot, stream, nrecalc;
     int32_t n_rounds, use_tags, ev_base, n_edges;
     int32_t edges[IMS_MAX_CHAIN_EDGES];
-    /* > 0: every region of the class exists twice, as slot k and slot k + pair_shift of the same shape (only the first needs the
-     * initial state).  Round r then lands its photons on slot k + (r & 1) pair_shift and ONE launch
-     * (ims_sensor_update_refresh) forms points, bounds and an empty delta image of the other slot from it, instead of
-     * updatePixelDistortions + refresh in place; after the last round ims_sensor_publish_pairs leaves every object's final
-     * state in its first slot.  qdist 3 and 4 vertices per edge only; 0 = in place, three launches per round. */
-    int32_t pair_shift, pad;
-    const int64_t* pair_tile_prefix;      /* device: prefix sum of the 15x15-cell tiles of the slots first_slot.. (the fused launch) */
-    const int64_t* pair_tile_prefix_host; /* HOST copy */
 } ims_chain_t;
 
 typedef struct ims_plan_item {
@@ -856,16 +847,6 @@ int  ims_plan_join(void* plan, void* stream);
 /* out[master row] += realized flux of every object (after ims_plan_run, on the same main stream) */
 int  ims_plan_add_realized(void* plan, double* out_dev, void* stream);
 int  ims_plan_destroy(void* plan);
-
-/* updatePixelDistortions + refresh of the bounds in one launch for regions held as slot pairs (ims_chain_t.pair_shift): reads the
- * slots first_slot + k + src_shift, writes the slots first_slot + k + dst_shift completely (points, bounds, delta = 0).
- * tile_prefix_dev / n_tiles: prefix sum over the slots of ceil((nx + 1) / 15) ceil((ny + 1) / 15) -- tiles of 15 x 15 cells. */
-int  ims_sensor_update_refresh(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host, int32_t first_slot, int32_t n_slots,
-                               int32_t src_shift, int32_t dst_shift, const int64_t* tile_prefix_dev, int64_t n_tiles, void* stream);
-/* objects_dev[k].n_phot and nrecalc give the parity of object k's last round: where it is odd, slot k + pair_shift is copied
- * over slot k (points, bounds, delta image) */
-int  ims_sensor_publish_pairs(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host, const ims_object_t* objects_dev,
-                              int32_t first_slot, int32_t n_slots, int32_t pair_shift, int32_t nrecalc, void* stream);
 
 /* ---- LSST_Flat (imsim/flat.py:133-283, area branch) ----
  * One iteration of the flat builder is: area = sensor.calculate_pixel_areas(section); temp = base * area / mean(area);

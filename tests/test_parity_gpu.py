@@ -231,20 +231,14 @@ def _c3_case(n_obj=150, n=512, flux_seed=1, scratch=2_000_000, **kw):
 
 
 class _SensorArrays(dict):
-    """boundary / bounds / delta arrays of a renderer up to the first cell of the second slots of its region pairs (those are
-    scratch of the brighter-fatter rounds: the final state of every region is published into its first slot)"""
+    """boundary / bounds / delta arrays of a renderer"""
     per_cell = {"boundary": None, "bounds": 8, "delta": 1}
 
 
 def _sensor_arrays_gpu(r):
     out = _SensorArrays()
-    cells = getattr(r, "pairs_begin", None) or None
-    npo2 = 2 * r.scene.sensor.owned_points() if r.scene.sensor is not None else 0
     for name, dt in (("boundary", np.float64), ("bounds", np.float64), ("delta", np.float64)):
-        a = r.bound.sensor_arrays[name].cpu().numpy().view(dt)
-        if cells is not None:
-            a = a[:cells * (npo2 if name == "boundary" else _SensorArrays.per_cell[name])]
-        out[name] = a
+        out[name] = r.bound.sensor_arrays[name].cpu().numpy().view(dt)
     return out
 
 
@@ -269,38 +263,6 @@ def test_specialised_kernels_equal_the_descriptor_driven_ones(torch_cuda, monkey
     assert_bits_equal(out[1][1], out[0][1], "realized flux")
     for name in ("boundary", "bounds", "delta"):
         assert_bits_equal(out[1][2][name], out[0][2][name], f"sensor {name}")
-
-
-def test_slot_pairs_give_the_in_place_result(torch_cuda, monkeypatch):
-    """Regions held as slot pairs (IMS_SLOT_PAIRS=1: a round = pixel search on slot r & 1, then ONE launch that forms points,
-    bounds and an empty delta image of the other slot; ims_sensor_update_refresh, ims_sensor_publish_pairs) end with the image,
-    realized fluxes and first-slot sensor state of updatePixelDistortions + refresh in place -- and of the oracle."""
-    from imsim_amd.engine import Renderer
-    from oracle import orc_loader
-    scene, objects = _c3_case(n_obj=200)
-    out = []
-    monkeypatch.delenv("IMS_BF_TAGS", raising=False)          # tile marks and slot pairs exclude each other (engine: pairs win only without tags)
-    for pairs in ("1", "0"):
-        monkeypatch.setenv("IMS_SLOT_PAIRS", pairs)
-        r = Renderer(scene)
-        real = torch_cuda.zeros(len(objects), dtype=torch_cuda.float64, device="cuda")
-        plan, parts = r.plan_lsst_image(objects, nrecalc=1000, want_realized=True)
-        assert any(d.get("pair_shift", 0) > 0 for it in plan if it[0] == "rounds" for d in it[1]) == (pairs == "1")
-        r.execute_plan(plan)
-        for index, tmp in parts:
-            real.index_add_(0, index, tmp)
-        r.synchronize()
-        out.append((r.image_numpy(), real.cpu().numpy(), _sensor_arrays_gpu(r)))
-    n = {name: min(len(out[0][2][name]), len(out[1][2][name])) for name in ("boundary", "bounds", "delta")}
-    assert_bits_equal(out[0][0], out[1][0], "image")
-    assert_bits_equal(out[0][1], out[1][1], "realized flux")
-    for name in n:
-        assert_bits_equal(out[0][2][name][:n[name]], out[1][2][name][:n[name]], f"sensor {name}")
-    orc = orc_loader.OracleScene(scene)
-    orc.render_lsst_image(objects, nrecalc=1000)
-    assert_bits_equal(out[0][0], orc.image, "image vs oracle")
-    for name in n:
-        assert_bits_equal(out[0][2][name], orc.sensor_array(name)[:len(out[0][2][name])], f"sensor {name} vs oracle")
 
 
 @pytest.mark.parametrize("nrecalc", [1000, 300])

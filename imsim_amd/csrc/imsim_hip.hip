@@ -2086,23 +2086,6 @@ __global__ __launch_bounds__(256) void k_image_to_float(const double* __restrict
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (float)src[i];
 }
 
-// the float32 image straight into page-locked HOST memory (mapped into the device's address space): the rounding and the copy
-// over PCIe in one pass by a FEW workgroups -- the bus, not the device, is the bound (~55 GB/s), and HIP's own device-to-host
-// copy of a page-locked buffer runs as a blit kernel of 512 workgroups whose 2 048 wavefronts sit in a quarter of the chip's
-// wave slots for the 1.2 ms the bus needs (round 5, focal plane: 13 % of a CCD's time)
-__global__ __launch_bounds__(256) void k_image_to_host_float(const double* __restrict__ src, float* __restrict__ dst_host, int64_t n)
-{
-    typedef float fvec4 __attribute__((ext_vector_type(4)));
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t n4 = n >> 2;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        const dvec4 v = *(const dvec4*)(src + 4 * i);
-        fvec4 f;
-        f.x = (float)v.x; f.y = (float)v.y; f.z = (float)v.z; f.w = (float)v.w;
-        __builtin_nontemporal_store(f, (fvec4*)(dst_host + 4 * i));
-    }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst_host[4 * n4 + threadIdx.x] = (float)src[4 * n4 + threadIdx.x];
-}
 
 // ---------------- FFT branch ----------------
 __device__ __forceinline__ int64_t find_prefix(const int64_t* __restrict__ prefix, int64_t n, int64_t e)
@@ -4355,18 +4338,6 @@ int ims_image_to_float(const double* src, float* dst, int64_t n, void* stream)
     if (!dst || !src) return set_err(IMS_ERR_ARG, "dst/src is NULL");
     if (n <= 0) return IMS_OK;
     hipLaunchKernelGGL(k_image_to_float, dim3(grid_for_pool(n)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
-    HIP_TRY(hipGetLastError());
-    return IMS_OK;
-}
-
-int ims_image_to_host_float(const double* src_dev, float* dst_host, int64_t n, void* stream)
-{
-    if (!dst_host || !src_dev) return set_err(IMS_ERR_ARG, "dst/src is NULL");
-    if (n <= 0) return IMS_OK;
-    if (((uintptr_t)src_dev & 31u) != 0 || ((uintptr_t)dst_host & 15u) != 0) return set_err(IMS_ERR_ARG, "image_to_host_float: src must be 32-byte, dst 16-byte aligned");
-    void* dst_dev = nullptr;
-    HIP_TRY(hipHostGetDevicePointer(&dst_dev, dst_host, 0));           // page-locked (hipHostMalloc / hipHostRegister) memory only
-    hipLaunchKernelGGL(k_image_to_host_float, dim3(96), dim3(256), 0, (hipStream_t)stream, src_dev, (float*)dst_dev, n);
     HIP_TRY(hipGetLastError());
     return IMS_OK;
 }

@@ -2128,15 +2128,6 @@ class Renderer:
                    "ims_image_to_float")
         return out
 
-    def image_to_host(self, pinned):
-        """the float32 CCD image rounded straight into a page-locked host tensor of its shape, on the current stream (one launch
-        of a few workgroups: ims_image_to_host_float); the caller reads it behind an event recorded after this call"""
-        if not pinned.is_pinned() or pinned.dtype != self.torch.float32 or pinned.numel() != self.image.numel():
-            raise ValueError("image_to_host wants a page-locked float32 tensor of the image's size")
-        _abi.check(self.lib.ims_image_to_host_float(self.image.data_ptr(), pinned.data_ptr(), self.image.numel(), self._stream()),
-                   "ims_image_to_host_float")
-        return pinned
-
     def image_numpy(self):
         return self.image_float().cpu().numpy()
 

@@ -83,8 +83,6 @@ KNOWN = {
     "IMS_FFT_WARM": ("1", "focal_plane.warm_fft makes the hipFFT plans on background threads; 0 = plans are made where they are first needed "
                           "(rocprofv3's counter passes crash with launches from several host threads)"),
     "IMS_FOCAL_JOINT_THREAD": ("1", "joint path: the rounds of a batch are enqueued by a second host thread while the first goes on with the next fronts"),
-    "IMS_FOCAL_DIRECT_COPY": ("0", "joint path: 1 = the finished image rounded straight into page-locked host memory by one small launch "
-                                   "(measured slower: C5 1.91 against 1.78 s); 0 = image_float + copy"),
     "IMS_FOCAL_COARSE_SLICES": ("1", "joint path: a chain class's photons shot in two launches (round 0, the rest) instead of up to six slices"),
     "IMS_FOCAL_TRACE": ("0", "print, per CCD, when its work ended on every stream and when the host enqueued it"),
     "IMS_PROCESS_FOCAL": ("1", "config.Process with several CCDs on the overlapped focal-plane path"),

@@ -909,11 +909,6 @@ int  ims_readout_finish(const float* seg_dev, const ims_readout_t* ro, uint64_t 
 int  ims_image_add(double* dst, const double* src, int64_t n, void* stream);
 /* round the f64 accumulation image to the float32 CCD image the reference hands on (galsim.ImageF) */
 int  ims_image_to_float(const double* src, float* dst, int64_t n, void* stream);
-/* the same rounding with the result written straight into PAGE-LOCKED HOST memory (hipHostMalloc / hipHostRegister; dst_host is
- * the host address): one launch of a few workgroups replaces ims_image_to_float + a device-to-host copy (the hand-over of the
- * finished ImageF to the host-side writer, imsim/lsst_image.py:368-395 -> imsim/ccd.py).  Stream-ordered like a copy: the host
- * may read dst_host once everything queued on `stream` up to here has run. */
-int  ims_image_to_host_float(const double* src_dev, float* dst_host, int64_t n, void* stream);
 
 /* ---- timing of the dominant kernel ----
  * After ims_enable_timing(which) every launch of the selected kernel is bracketed by a hipEvent pair on its

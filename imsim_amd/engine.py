@@ -828,20 +828,15 @@ def _device_streams(torch, device):
     with a fresh set per renderer the chain of one CCD of a focal plane lands in the hardware queue of another CCD's wide
     launches and waits behind them (kernel trace of C5: one kernel in flight for two thirds of the time).  With one set,
     the plans of the CCDs in flight interleave role by role: the wide launches of the next CCD fill the GPU while the
-    latency-bound chain of the previous one runs.  IMS_PRIVATE_STREAMS=1 gives every renderer its own set again."""
+    latency-bound chain of the previous one runs."""
     pr = [int(v) for v in tuning.env("IMS_STREAM_PRIORITIES", "-1,0,0,0,0").split(",")]   # chain, bulk, chain1, chain2, chain3
     pr = (pr + [0] * 5)[:5]
-    if tuning.env("IMS_PRIVATE_STREAMS", "0") != "0":
-        return tuple(torch.cuda.Stream(device, priority=p) for p in pr)
-    # IMS_STREAM_SETS sets (default 1), handed to the renderers of a device in turn
-    n_sets = max(int(tuning.env("IMS_STREAM_SETS", "1")), 1)
+    # (a set per renderer, and two or three sets handed out in turn, were measured in round 2 and are gone: slower)
     key = (str(device), tuple(pr))
-    sets = _DEVICE_STREAMS.setdefault(key, {"next": 0, "sets": []})
-    k = sets["next"] % n_sets
-    sets["next"] += 1
-    while len(sets["sets"]) <= k:
-        sets["sets"].append(tuple(torch.cuda.Stream(device, priority=p) for p in pr))
-    return sets["sets"][k]
+    st = _DEVICE_STREAMS.get(key)
+    if st is None:
+        st = _DEVICE_STREAMS[key] = tuple(torch.cuda.Stream(device, priority=p) for p in pr)
+    return st
 
 
 def _pool_stream(torch, device):

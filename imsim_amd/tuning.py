@@ -34,8 +34,6 @@ KNOWN = {
     "IMS_SCREEN_QUADS": (None, "phase screens also as 2 x 2 cells of 16 bytes (default 1 unless the pre-pass covers every photon)"),
     "IMS_STREAM_PRIORITIES": ("-1,0,0,0,0", "HIP priorities of the chain / bulk / chain1 / chain2 / chain3 plan streams"),
     "IMS_STREAM_TOUCH": ("0,1,2,3,4", "Renderer.touch_streams: order in which the plan streams (chain, bulk, chain1, chain2, chain3) are first used"),
-    "IMS_PRIVATE_STREAMS": ("0", "a stream set per renderer (measured slower)"),
-    "IMS_STREAM_SETS": ("1", "stream sets handed to the renderers of a device in turn"),
     "IMS_UPLOAD_SYNC": ("0", "engine.upload_async as the synchronous copy it replaced"),
     "IMS_BF_TAGS": ("0", "tile marks in LSST_Image chains (the update skips tiles without charge in reach)"),
     "IMS_CHAIN_CLASSES": ("40,6", "round counts that cut the bright objects into concurrent brighter-fatter chains"),

@@ -89,6 +89,21 @@ extern "C" int ims_probe_read(unsigned long long* out32, unsigned long long* wg5
     return hipMemcpyFromSymbol(out32, HIP_SYMBOL(ims::g_probe), 32 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif
+// -DIMS_HIST (measurement builds only, tools/dbg/c5_tile_hist.py): what a listed tile of a joint round holds and costs -- per
+// number of charged cells in the update's 23 x 23 halo (bins 0 .. 62, 63 = more): tiles, 10-ns ticks from the tile's entry to
+// its last store (thread 0), charged cells inside the tile itself
+#ifdef IMS_HIST
+__device__ unsigned long long g_hist[3][64];
+extern "C" int ims_hist_read(unsigned long long* out192, int reset)
+{
+    if (hipMemcpyFromSymbol(out192, HIP_SYMBOL(g_hist), 192 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long zero[192];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_hist), zero, sizeof(zero)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 // ---------------- segment -> (object, first photon) ----------------
 constexpr int N_XCD = 8;
@@ -1972,8 +1987,25 @@ __device__ __forceinline__ void update_listed_tile(const JointUpd* __restrict__ 
     const int tiles_x = (sl.nx + 1 + UT - 1) / UT;
     const int tx0 = (t % tiles_x) * UT, ty0 = (t / tiles_x) * UT;
     const double* dl_global = U->dl[c];
+#ifdef IMS_HIST
+    const unsigned long long hist_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (dl_global != nullptr) update_tile_q3<NV, true, ConstTable>(s, sl, tx0, ty0, U->changed[c], L, false, tag, (ConstTable)(uintptr_t)dl_global);
     else update_tile_q3<NV, false>(s, sl, tx0, ty0, U->changed[c], L, false, tag);
+#ifdef IMS_HIST
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int halo = 0, own = 0;
+        for (int hy = 0; hy < UpdateLds<NV>::HW; ++hy) {
+            halo += __popc(L.occ[hy]);
+            if (hy >= 4 && hy < 4 + UT) own += __popc((L.occ[hy] >> 4) & 0xFFFFu);
+        }
+        const int bin = halo < 63 ? halo : 63;
+        atomicAdd(&g_hist[0][bin], 1ull);
+        atomicAdd(&g_hist[1][bin], __builtin_amdgcn_s_memrealtime() - hist_t0);
+        atomicAdd(&g_hist[2][bin], (unsigned long long)own);
+    }
+#endif
 }
 
 template <int NV, bool DPP = false>
@@ -3045,6 +3077,7 @@ int ims_accumulate_segments(const ims_render_params_t* params, const ims_photons
     if (!pool || !pool_start) return set_err(IMS_ERR_ARG, "pool/pool_start is NULL");
     if (!pool->converted) return set_err(IMS_ERR_ARG, "pool must hold converted photons (ims_shoot_ops_photons with pool->converted = 1)");
     if (!params->image) return set_err(IMS_ERR_ARG, "image is NULL");
+    if (params->lazy_static) return set_err(IMS_ERR_ARG, "lazy_static parameters (slot 0 holds no state) belong to ims_shoot_accumulate only");
     if (params->n_segments == 0) return IMS_OK;
     hipStream_t st = (hipStream_t)stream;
     {
@@ -3067,6 +3100,7 @@ int ims_accumulate_small(const ims_render_params_t* params, const ims_photons_t*
     if (!params->objects || !params->image) return set_err(IMS_ERR_ARG, "objects/image is NULL");
     if (!pool || !pool_start) return set_err(IMS_ERR_ARG, "pool/pool_start is NULL");
     if (!pool->converted) return set_err(IMS_ERR_ARG, "pool must hold converted photons (ims_shoot_ops_photons with pool->converted = 1)");
+    if (params->lazy_static) return set_err(IMS_ERR_ARG, "lazy_static parameters (slot 0 holds no state) belong to ims_shoot_accumulate only");
     if (params->n_objects <= 0) return IMS_OK;
     const int64_t blocks = (params->n_objects + 3) / 4;
     if (blocks > 0x7fffffffLL) return set_err(IMS_ERR_ARG, "too many objects for one launch");
@@ -3163,6 +3197,7 @@ int ims_accumulate(const ims_render_params_t* params, const int64_t* photon_offs
     if (rc) return rc;
     if (!photon_offset || !pool) return set_err(IMS_ERR_ARG, "photon_offset/pool is NULL");
     if (!params->image) return set_err(IMS_ERR_ARG, "image is NULL");
+    if (params->lazy_static) return set_err(IMS_ERR_ARG, "lazy_static parameters (slot 0 holds no state) belong to ims_shoot_accumulate only");
     if (pool->n == 0) return IMS_OK;
     hipStream_t st = (hipStream_t)stream;
     {
@@ -3451,6 +3486,7 @@ int ims_plan_bind(void* plan, const ims_render_params_t* base, void* arena_host,
         L.P.seg_object = (const int32_t*)dev(L.off_segobj);
         L.P.realized_flux = (L.realized_off >= 0) ? pl->realized_dev + L.realized_off : nullptr;
         L.P.bf_tag = 0; L.P.bf_slot_shift = 0;
+        L.P.lazy_static = 0;                 // (set again below for the launches that are fused renders: nothing else may carry it)
     }
     for (Group& g : pl->groups) {
         std::memset(&g.pool, 0, sizeof(g.pool));
@@ -3482,7 +3518,7 @@ int ims_plan_bind(void* plan, const ims_render_params_t* base, void* arena_host,
             std::memset(&it, 0, sizeof(it));
             it.kind = s.kind; it.stream = s.stream;
             switch (s.kind) {
-            case IMS_PLAN_RENDER: it.params = &pl->launches[s.launch].P; break;
+            case IMS_PLAN_RENDER: pl->launches[s.launch].P.lazy_static = base->lazy_static; it.params = &pl->launches[s.launch].P; break;
             case IMS_PLAN_SHOOT_POOL:
                 it.params = &pl->launches[s.launch].P; it.pool = &g.pool; it.aux = (const int64_t*)dev(pl->launches[s.launch].off_pool); break;
             case IMS_PLAN_INIT:

@@ -782,8 +782,12 @@ class BoundScene:
         else:
             self.mem.write(self._sensor_buf, np.frombuffer(bytes(self.sensor_struct), dtype=np.uint8).copy())
 
-    def params(self, objects_ptr, n_objects, seg_prefix_ptr, n_segments, image_ptr, realized_ptr=None, seg_object_ptr=None):
+    def params(self, objects_ptr, n_objects, seg_prefix_ptr, n_segments, image_ptr, realized_ptr=None, seg_object_ptr=None, lazy=False):
+        """lazy: the launch is a fused LSST_Image render of a renderer whose slot 0 holds no state (Renderer.lazy_static).  The flag
+        lives on the parameters of THOSE launches only -- never in base_params, where every pool / sensor entry point would inherit
+        it and read the state that was not made."""
         P = RenderParams.from_buffer_copy(bytes(self.base_params))
+        P.lazy_static = 1 if lazy else 0
         P.seg_object = seg_object_ptr
         P.objects, P.n_objects = objects_ptr, n_objects
         P.seg_prefix, P.n_segments = seg_prefix_ptr, n_segments
@@ -1029,7 +1033,7 @@ class NativePlan:
         self.rows = t.empty(int(sizes.rows_bytes), dtype=t.uint8, device=r.device)
         self.pool = t.empty(max(4 * int(sizes.pool_photons), 1), dtype=t.float64, device=r.device)
         self.realized = t.empty(max(int(sizes.realized_count), 1), dtype=t.float64, device=r.device) if sizes.realized_count else None
-        self.P = b.params(None, 0, None, 0, r.image.data_ptr(), None, None)
+        self.P = b.params(None, 0, None, 0, r.image.data_ptr(), None, None, lazy=r.lazy_static)     # (ims_plan_bind keeps the flag on its RENDER launches only)
         _abi.check(lib.ims_plan_bind(handle, C.byref(self.P), self.arena_pin.data_ptr(), self.arena_dev.data_ptr(), self.rows.data_ptr(),
                                      self.master.data_ptr(), self.pool.data_ptr(),
                                      self.realized.data_ptr() if self.realized is not None else None), "ims_plan_bind")
@@ -1165,10 +1169,21 @@ class Renderer:
         if lazy_static is None:
             lazy_static = tuning.flag("IMS_LAZY_STATIC")
         self.lazy_static = bool(lazy_static and lazy_static_applies(scene) and self.bound.sensor_struct.pristine_margin >= 0.0)
-        if self.lazy_static:
-            self.bound.base_params.lazy_static = 1
-        elif ss is not None:
+        if not self.lazy_static and ss is not None:
             self.init_boundaries(0, len(ss.slots))
+
+    def _need_static(self, what):
+        """Entry points that read the stored state of slot 0 (pooled accumulates of ordinary rows, pixel areas, whole-CCD updates)
+        on a renderer that was made without it (lazy_static): the state is made now and the renderer is an ordinary one from here
+        on.  A renderer whose state is leased from a focal plane's arena cannot do that -- the lazy arena's one static region
+        belongs to nobody -- and raises."""
+        if not self.lazy_static:
+            return
+        if self.lease is not None:
+            raise RuntimeError(f"{what} reads the static pixel-boundary state, which this renderer (lazy_static, state leased from a "
+                               "sensor arena) does not have: make it with lazy_static=False")
+        self.lazy_static = False
+        self.init_boundaries(0, len(self.scene.sensor.slots))
 
     def release_state(self, streams=None):
         """hand the leased pixel-boundary state back (SensorLease.release); a renderer without a lease has nothing to do"""
@@ -1269,7 +1284,7 @@ class Renderer:
             return
         P = self.bound.params(obj_t.data_ptr(), len(objects), pre_t.data_ptr(), int(prefix[-1]),
                               self.image.data_ptr(), realized.data_ptr() if realized is not None else None,
-                              _seg_ptr(pre_t))
+                              _seg_ptr(pre_t), lazy=self.lazy_static)
         _abi.check(self.lib.ims_shoot_accumulate(C.byref(P), self._stream()), "ims_shoot_accumulate")
         self._keep = (obj_t, pre_t)
 
@@ -1321,7 +1336,8 @@ class Renderer:
                     where = objects["row"][where]                  # realized fluxes are indexed like the master table
                 realized_refs.append((arena.add(where), len(part), tmp))
             P = self.bound.params(None, len(part), None, int(prefix[-1]),
-                                  self.image.data_ptr(), tmp.data_ptr() if tmp is not None else None, None)
+                                  self.image.data_ptr(), tmp.data_ptr() if tmp is not None else None, None,
+                                  lazy=self.lazy_static and kind == "render")
             if kind != "render" and getattr(self, "_prepass_event", None) is not None:
                 P.screen_kick = None                  # the pre-pass covered the ordinary objects only: the bright ones gather in place
             if master is not None:
@@ -1784,7 +1800,7 @@ class Renderer:
         kernel (used by bench.py so that the timed region has its inputs resident in HBM)."""
         objects, obj_t, prefix, pre_t = self._upload_objects(objects)
         P = self.bound.params(obj_t.data_ptr(), len(objects), pre_t.data_ptr(), int(prefix[-1]),
-                              self.image.data_ptr(), None, _seg_ptr(pre_t))
+                              self.image.data_ptr(), None, _seg_ptr(pre_t), lazy=self.lazy_static)
         P.bf_tag = bf_tag
         ref = C.byref(P)
         keep = (obj_t, pre_t, P)
@@ -2044,6 +2060,7 @@ class Renderer:
     def accumulate_segments(self, pool, realized=None, small=False):
         """ims_accumulate_segments on a converted pool (segment-mapped: one workgroup per 256 photons of one object);
         small=True: ims_accumulate_small (one wavefront per object row, any photon count)."""
+        self._need_static("accumulate_segments")
         P = self._pool_params(pool, realized)
         P.seg_object = _seg_ptr(pool.seg_prefix_dev)
         ph = pool.struct()
@@ -2065,6 +2082,7 @@ class Renderer:
     def accumulate(self, pool, realized=None, want_pixel_index=False, bf_tag=0):
         """bf_tag (1..255): mark the 16x16 tiles that receive delta charge so that the next
         update_distortions(..., bf_tag=same) only visits tiles within reach of that charge."""
+        self._need_static("accumulate")
         P = self._pool_params(pool, realized)
         P.bf_tag = bf_tag
         ph = pool.struct()
@@ -2100,12 +2118,16 @@ class Renderer:
 
     def delta_tensor(self, slot=0):
         """f64 device view of a slot's delta-charge image ((nx+1)*(ny+1) owner cells)"""
+        if slot == 0:
+            self._need_static("delta_tensor(0)")
         sl = self.bound._slots_host[slot]
         n = (int(sl["nx"]) + 1) * (int(sl["ny"]) + 1)
         off = int(sl["offset"])
         return self.bound.sensor_arrays["delta"].view(self.torch.float64)[off:off + n]
 
     def update_distortions(self, first_slot, n_slots, stream=None, bf_tag=0):
+        if first_slot == 0:
+            self._need_static("update_distortions(0, ..)")
         if not hasattr(self, "_changed"):
             cells = self.bound.static_cells + int(self.bound.scratch_cells)
             self._changed = self.torch.zeros(max(cells, 1), dtype=self.torch.uint8, device=self.device)

@@ -68,6 +68,7 @@ class LSST_FlatBuilder:
             base_t = torch.from_numpy(b).to(renderer.device)
         st = renderer._stream()
         if silicon:
+            renderer._need_static("LSST_Flat")
             area = torch.empty(n, dtype=torch.float64, device=renderer.device)
             acc = torch.zeros(1, dtype=torch.int64, device=renderer.device)
             delta_ptr = renderer.bound.sensor_struct.bf_delta       # slot 0 starts at offset 0

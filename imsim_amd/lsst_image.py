@@ -94,6 +94,7 @@ class LSST_ImageBuilderBase:
             return None
         torch = renderer.torch
         b = renderer.bound
+        renderer._need_static("sky_pixel_areas")
         sl = b._slots_host[0]
         if (int(sl["xmin"]), int(sl["ymin"]), int(sl["nx"]), int(sl["ny"])) != (sc.xmin, sc.ymin, sc.nx, sc.ny) or int(sl["offset"]) != 0:
             raise ValueError("sky_pixel_areas expects slot 0 to be the whole image")

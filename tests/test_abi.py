@@ -166,6 +166,18 @@ def test_argument_errors_are_reported_before_any_launch():
     ch = (_abi.Chain * 1)()
     it.aux2 = C.addressof(ch)
     assert lib.ims_run_plan(C.byref(it), 1, None, None, None, streams, 1) < 0 and b"NULL pointer" in lib.ims_last_error()
+    # lazy_static parameters (slot 0 without stored state) are for the fused render only: the pooled accumulates, which read
+    # slot 0 for ordinary rows, refuse them before any launch
+    P, ph = _abi.RenderParams(), _abi.Photons()
+    P.seg_size, P.lazy_static, ph.converted, ph.n = 256, 1, 1, 4
+    one = (C.c_double * 4)()
+    P.image = C.cast(one, C.c_void_p)
+    off = (C.c_int64 * 2)(0, 4)
+    for entry, args in ((lib.ims_accumulate, (C.byref(P), off, C.byref(ph), None, None)),
+                        (lib.ims_accumulate_segments, (C.byref(P), C.byref(ph), off, 4, None)),
+                        (lib.ims_accumulate_small, (C.byref(P), C.byref(ph), off, 4, None))):
+        P.n_objects, P.objects = (1, C.cast(one, C.c_void_p)) if entry is lib.ims_accumulate_small else (0, None)
+        assert entry(*args) < 0 and b"lazy_static" in lib.ims_last_error(), entry
     # the derived-field helpers are pure host code
     op = _abi.Op()
     op.kind = _abi.IMS_OP_PHOTON_DCR

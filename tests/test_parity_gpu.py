@@ -288,6 +288,32 @@ def test_two_segment_round_search_gives_the_one_segment_result(torch_cuda, monke
     assert_bits_equal(out[0][0], orc.image, "image vs oracle")
 
 
+def test_lazy_static_renderer_makes_the_state_when_something_needs_it(torch_cuda):
+    """lazy_static used to sit in the renderer's base parameters, so pooled accumulates and the sky's pixel areas ran on a
+    slot 0 that was never initialised.  Now the flag travels with the fused render only; an entry point that reads the stored
+    state makes it first (and the renderer is an ordinary one from then on): pixel areas and a pooled accumulate of ordinary rows
+    equal those of a renderer that was made with the state."""
+    from imsim_amd.engine import Renderer
+    from imsim_amd.lsst_image import CcdJob
+    scene, objects = _c3_case(n_obj=200)
+    objects = objects[objects["n_phot"] <= 1000]
+    out = []
+    for lazy in (True, False):
+        r = Renderer(scene, lazy_static=lazy)
+        assert r.lazy_static == lazy
+        assert int(r.bound.base_params.lazy_static) == 0
+        pool = r.shoot_ops_photons(objects, converted=True)
+        r.accumulate_segments(pool)
+        assert not r.lazy_static
+        r.synchronize()
+        image = r.image_numpy()
+        area = CcdJob.sky_pixel_areas(None, r)
+        out.append((image, area.cpu().numpy()))
+    assert out[0][0].sum() > 0
+    assert_bits_equal(out[0][0], out[1][0], "pooled accumulate on a renderer made without the static state")
+    assert_bits_equal(out[0][1], out[1][1], "pixel areas")
+
+
 @pytest.mark.parametrize("native", ["1", "0"])
 def test_lazy_static_state_gives_the_stored_state_image(torch_cuda, monkeypatch, native):
     """Renderer(lazy_static=True): slot 0 is never initialised; the fused launch sets the photons within pristine_margin of a

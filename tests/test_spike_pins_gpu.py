@@ -3,114 +3,81 @@ hold the spike statistics of imSim's own ray-traced (batoid + GalSim) rendering 
 RubinDiffractionOptics (generate_reference_data_from_raytracing, tests/test_diffraction_fft.py:275-291): centre,
 folded spike angle and its spread, log-log slope and intercept of the radial brightness.  The same star is rendered
 here by the HIP photon path and by the FFT spike path, the statistics are computed with the reference's estimators
-(restated below from tests/test_diffraction_fft.py:515-607) and compared with the stored values under the reference's
-own tolerances (:363-420)."""
+(tests/spike_stats.py, restated from tests/test_diffraction_fft.py:515-607) and compared with the stored values under the
+reference's own tolerances (:363-420).
+
+THE ONE DISAGREEMENT WITH REFERENCE-HELD NUMBERS IS IN THIS FILE, and it is an `xfailed` in the GPU suite, not a green: with the
+pupil the reference's config samples (PupilAnnulusSampler 2.55 .. 4.18, :85) the spread of the folded angle and the intercept are
+NOT met (15.9 deg against the stored 2.73, -1.59 against -2.69 at exptime 0; profiles/round6_spike_sweep.log has every number).
+The sweep bounds it: the photon count does not matter (1e6 .. 2e7), the wavelength mix does not (flat r band, 577.6 nm, Vega-like),
+sampling inside ONE rim does not (inner rim: nothing; outer rim by >= 10 mm: slope and intercept, not the spread), sampling >= 10 mm
+inside BOTH rims meets all five, and at 20 mm the stored numbers are reproduced to 0.2 deg / 0.02 / 0.07 for both exposure times."""
 import math
-import os
 
 import numpy as np
 import pytest
-from scipy import stats
 
-from imsim_amd import _abi, configs, catalog
+import spike_stats as ss
+from imsim_amd import _abi
 
 pytestmark = pytest.mark.gpu
-GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fft-diffraction")
-XSIZE = YSIZE = 3500          # tests/test_diffraction_fft.py:294-295
-STAMP = 1000
-ROTTELPOS, ALT, AZ = 20.0, 88.0, 73.7707957
-R_MIN = 5.0
+ROTTELPOS, ALT, AZ = ss.ROTTELPOS, ss.ALT, ss.AZ
+_scene, _star = ss.scene, ss.star
+center_of_brightness, folded_spike_angle, radial_brightness_asymptotics = (ss.center_of_brightness, ss.folded_spike_angle,
+                                                                           ss.radial_brightness_asymptotics)
+GOLD = ss.GOLD
+_CACHE = {}
 
 
-def center_of_brightness(image):
-    return np.array([np.sum(image * np.arange(image.shape[0])[:, None]), np.sum(image * np.arange(image.shape[1]))]) / np.sum(image)
-
-
-def folded_spike_angle(image, x_center, y_center, r_min):
-    x, y = np.mgrid[0:image.shape[0], 0:image.shape[1]]
-    r = np.hypot(y - y_center, x - x_center)
-    m = r > r_min
-    alpha = np.arctan2(y[m] - y_center, x[m] - x_center) % (np.pi / 2.0)
-    w = image[m] / np.sum(image[m])
-    xm, ym = np.sum(np.cos(4 * alpha) * w), np.sum(np.sin(4 * alpha) * w)
-    R = math.hypot(xm, ym)
-    return math.atan2(ym, xm) / 4, math.sqrt(-2 * math.log(R)) / 4
-
-
-def radial_brightness_asymptotics(image, x_center, y_center, r_min=R_MIN, num_bins=25):
-    x, y = np.mgrid[0:image.shape[0], 0:image.shape[1]]
-    r = np.hypot(y - y_center, x - x_center)
-    r_max = np.max(r[image > 0.0])
-    b, r = image[r <= r_max], r[r <= r_max]
-    bins = np.geomspace(r_min, np.max(r), num=num_bins)
-    dist, _ = np.histogram(r, bins=bins, weights=b)
-    dist = dist / (np.diff(bins) * np.sum(b))
-    reg = stats.linregress(np.log((bins[1:] + bins[:-1]) / 2.0), np.log(dist))
-    return reg.slope, reg.intercept, reg.stderr, reg.intercept_stderr
-
-
-def _scene(exptime, r_outer=4.18, r_inner=2.55):
-    optics = configs.rubin_optics_struct(XSIZE, YSIZE, rottelpos=ROTTELPOS, altitude=ALT, azimuth=AZ)
-    sc = configs.scene_c2(nx=XSIZE, ny=YSIZE)
-    sc.optics = optics
-    sc.psf = [(_abi.IMS_PSF_GAUSSIAN, 0, 0.3 / 2.3548200450309493, 0.0, 1.0)]
-    sc.ops = [(_abi.IMS_OP_TIME_SAMPLER, 0, [0.0, exptime]), (_abi.IMS_OP_PUPIL_ANNULUS_SAMPLER, 0, [r_outer, r_inner]),
-              (_abi.IMS_OP_RUBIN_DIFFRACTION_OPTICS, 0, [1.0, 1.0 if exptime == 0.0 else 0.0])]
-    return sc
-
-
-def _star(scene, ref_c, n_phot):
-    """the star at the stored centre: c = (row, column) array indices -> 1-based image coordinates"""
-    cat = catalog.synthetic_catalog(1, nx=XSIZE, ny=YSIZE)
-    cat["x"][:], cat["y"][:] = ref_c[1] + 1.0, ref_c[0] + 1.0
-    cat["kind"][:] = 0
-    cat["nominal_flux"][:] = float(n_phot)
-    objects, _ = configs.c3_objects(cat, np.array([n_phot]), scene)
-    icx, icy = int(math.floor(cat["x"][0] + 0.5)), int(math.floor(cat["y"][0] + 0.5))
-    objects["stamp_xmin"], objects["stamp_xmax"] = icx - STAMP // 2, icx - STAMP // 2 + STAMP - 1
-    objects["stamp_ymin"], objects["stamp_ymax"] = icy - STAMP // 2, icy - STAMP // 2 + STAMP - 1
-    return objects
-
-
-def _stats(scene, ref):
-    from imsim_amd.engine import Renderer
-    r = Renderer(scene)
-    r.render(_star(scene, ref["c"], 6_000_000))
-    r.synchronize()
-    img = r.image.cpu().numpy()
-    assert img.sum() > 4.0e6
-    c = center_of_brightness(img)
-    angle, angle_std = folded_spike_angle(img, c[0], c[1], r_min=10.0)
-    return c, angle, angle_std, radial_brightness_asymptotics(img, c[0], c[1])
+def _stats(exptime, r_outer=ss.R_OUTER, r_inner=ss.R_INNER):
+    key = (exptime, r_outer, r_inner)
+    if key not in _CACHE:
+        ref = ss.stored(exptime)
+        img = ss.render(ss.scene(exptime, r_outer, r_inner), ref)
+        assert img.sum() > 4.0e6
+        _CACHE[key] = (ss.image_stats(img), ss.stored_stats(ref))
+    return _CACHE[key]
 
 
 @pytest.mark.parametrize("exptime", [0.0, 300.0])
-def test_ray_traced_spikes_match_the_references_stored_statistics(exptime):
-    """Centre, spike angle (at exptime 300 s it carries the field rotation) and the 1 / r^2 law hold for the nominal pupil
-    (PupilAnnulusSampler 2.55 .. 4.18 as in the reference's config).  The spread of the folded angle and the
-    intercept are reproduced once the two rim zones of the pupil do not contribute: the isotropic light diffracted at the inner
-    and outer pupil edges (62 % of the light that DIFFRACTION puts beyond 10 pixels -- itself ~0.65 % of the star's photons)
-    is weaker in the reference's image than in this build's, where the struts then dominate.  What removes it in the reference
-    is not established: by the public design values no surface behind M1 clips the on-axis beam of the rims (DESIGN.md 8,
-    round 4), and the prescription itself (LSST_r.yaml) is external data.  Sampling the pupil 2 cm inside both rims emulates
-    the reference's image and then ALL five stored statistics are met under its own tolerances -- which pins the strut geometry,
-    the kick law
-    phi* = atan(lambda / 4 pi delta) through the ray trace, the plate scale and the field-rotation rate."""
-    ref = np.load(os.path.join(GOLD, f"raytrace_diffraction_values_{int(exptime)}_exptime.npz"))
-    c, angle, angle_std, (slope, intercept, slope_err, intercept_err) = _stats(_scene(exptime), ref)
-    np.testing.assert_allclose(c, ref["c"], atol=2.0, rtol=0.0)                         # :383-386 (2 pixel tolerance)
+def test_nominal_pupil_meets_the_stored_centre_and_angle_and_the_inverse_square_law(exptime):
+    """With the pupil of the reference's config: the stored centre (2 px, :383-386), the stored spike angle (1 deg; at exptime 300 s
+    it carries the field rotation) and at exptime 0 the expected 45 deg - rotTelPos (:388-396), brightness ~ 1 / r^2 (:314: slope
+    -2 +- 0.2; the reference holds its stored slope to -2 +- 0.6, :408-409) with bounded standard errors (:419-420)."""
+    got, want = _stats(exptime)
+    np.testing.assert_allclose(got["c"], want["c"], atol=2.0, rtol=0.0)
     if exptime == 0.0:
-        np.testing.assert_allclose(np.rad2deg(angle), 45.0 - ROTTELPOS, atol=1.0)       # :388-396
-    np.testing.assert_allclose(np.rad2deg(angle), np.rad2deg(ref["angle"]), atol=1.0)
-    np.testing.assert_allclose(slope, -2.0, atol=0.2)                                   # :314 brightness ~ 1 / r^2
-    assert slope_err < 0.2 and intercept_err < 0.8
-    c, angle, angle_std, (slope, intercept, slope_err, intercept_err) = _stats(_scene(exptime, 4.16, 2.58), ref)
-    np.testing.assert_allclose(c, ref["c"], atol=2.0, rtol=0.0)
-    np.testing.assert_allclose(np.rad2deg(angle), np.rad2deg(ref["angle"]), atol=1.0)
-    np.testing.assert_allclose(np.rad2deg(angle_std), np.rad2deg(ref["angle_stddev"]), atol=2.0)     # :400-405
-    np.testing.assert_allclose(slope, ref["slope"], atol=0.1)
-    np.testing.assert_allclose(intercept, ref["intercept"], atol=0.5)                   # :417-418
-    assert slope_err < 0.2 and intercept_err < 0.8
+        np.testing.assert_allclose(got["angle_deg"], 45.0 - ROTTELPOS, atol=1.0)
+    np.testing.assert_allclose(got["angle_deg"], want["angle_deg"], atol=1.0)
+    np.testing.assert_allclose(got["slope"], -2.0, atol=0.2)
+    np.testing.assert_allclose(want["slope"], -2.0, atol=0.6)
+    assert got["slope_stderr"] < 0.2 and got["intercept_stderr"] < 0.8
+
+
+@pytest.mark.xfail(strict=True, reason="KNOWN DISAGREEMENT with reference-held numbers: the rim zones of the pupil put an isotropic 1 / r^2 "
+                                       "halo into this build's image that the reference's stored statistics do not show "
+                                       "(profiles/round6_spike_sweep.log; README, 'Open question')")
+@pytest.mark.parametrize("stat,tol", [("angle_stddev_deg", 2.0), ("intercept", 0.5)])
+@pytest.mark.parametrize("exptime", [0.0, 300.0])
+def test_nominal_pupil_against_the_stored_spread_and_intercept(exptime, stat, tol):
+    """The two stored statistics that are NOT met with the nominal pupil, under the reference's tolerances (:400-405 spread of the
+    folded angle 2 deg, :417-418 intercept 0.5).  strict: the day this passes, the disagreement is gone and the marker must go."""
+    got, want = _stats(exptime)
+    np.testing.assert_allclose(got[stat], want[stat], atol=tol, rtol=0.0)
+
+
+@pytest.mark.parametrize("exptime", [0.0, 300.0])
+def test_pupil_sampled_two_centimetres_inside_both_rims_meets_all_five_stored_statistics(exptime):
+    """What the stored numbers ARE consistent with: no light from within ~2 cm of either pupil rim.  Sampling 2.58 .. 4.16 all five
+    are met under the reference's tolerances (and the slope to 0.1) -- which pins the strut geometry, the kick law
+    phi* = atan(lambda / 4 pi delta) through the ray trace, the plate scale and the field-rotation rate.  This is an EMULATION of
+    the reference's image, not the configured pupil; what removes the rim light in the reference is not established (by the
+    public design values no surface behind M1 clips the on-axis beam of the rims; LSST_r.yaml is external data; the stored files
+    are written once and kept, tests/test_diffraction_fft.py:363-365, so they may also predate the present geometry)."""
+    got, want = _stats(exptime, 4.16, 2.58)
+    ok = ss.within(got, want)
+    assert all(ok.values()), (ok, got, want)
+    assert got["slope_stderr"] < 0.2 and got["intercept_stderr"] < 0.8
 
 
 def test_fft_spikes_match_the_references_ray_tracing(tmp_path):
@@ -118,7 +85,7 @@ def test_fft_spikes_match_the_references_ray_tracing(tmp_path):
     from imsim_amd import fft_draw
     from imsim_amd.diffraction_fft import DiffractionFFT
     from imsim_amd.engine import Renderer
-    ref = np.load(os.path.join(GOLD, "raytrace_diffraction_values_0_exptime.npz"))
+    ref = ss.stored(0.0)
     scene = _scene(0.0)
     scene.ops = []
     objects = _star(scene, ref["c"], 6_000_000)

@@ -35,7 +35,7 @@ static ims_tuning_t tuning_defaults()
     t.chain_kernels = 1; t.layout_kernels = 1; t.psf_screens_kernel = 1; t.photon_lds = -1;
     t.round_compact = 1; t.init_tiles = 1; t.upd_dpp = 1; t.joint_lists = 1;
     t.upd_dpp_max = 128; t.joint_list_min = 1024; t.active_fraction = 0.25;
-    t.round_two_segments = 0; t.joint_fine_marks = 1; t.joint_search_lists = 1; t.joint_sparse_max = 8; t.joint_grid_cap = 1024; t.pad = 0;
+    t.round_two_segments = 0; t.joint_fine_marks = 1; t.joint_search_lists = 1; t.pad = 0;
     return t;
 }
 static ims_tuning_t g_tune = tuning_defaults();
@@ -94,18 +94,6 @@ extern "C" int ims_probe_read(unsigned long long* out32, unsigned long long* wg5
 // its last store (thread 0), charged cells inside the tile itself
 #ifdef IMS_HIST
 __device__ unsigned long long g_hist[3][64];
-// per launch of k_update_sparse_j (slot = launch number mod 32768): listed tiles, first wavefront's start, last one's end (10-ns ticks),
-// summed wavefront time inside the tile loop, tiles passed on
-__device__ unsigned long long g_launch_log[32768][5];
-extern "C" int ims_launch_log_read(unsigned long long* out, int n_launches)
-{
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_launch_log), (size_t)n_launches * 5 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
-}
-// sampled launches (launch number divisible by 64, sample = number / 64 mod 64): per workgroup its first lane's entry and exit
-__device__ unsigned long long g_wg_log[64][1024][2];
-extern "C" int ims_wg_log_read(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_log), sizeof(unsigned long long) * 64 * 1024 * 2) == hipSuccess ? 0 : -1; }
-static int g_launch_seq = 0;
-extern "C" int ims_launch_seq(int reset) { const int v = g_launch_seq; if (reset) g_launch_seq = 0; return v; }
 extern "C" int ims_hist_read(unsigned long long* out192, int reset)
 {
     if (hipMemcpyFromSymbol(out192, HIP_SYMBOL(g_hist), 192 * sizeof(unsigned long long)) != hipSuccess) return -1;
@@ -118,7 +106,7 @@ extern "C" int ims_hist_read(unsigned long long* out192, int reset)
 #endif
 
 #ifdef IMS_EXTRA_LAUNCHES
-__global__ void k_nop(int* p) { if (p) *p = 0; }      // (measurement builds: empty launches on the joint stream, what a kernel boundary costs a round)
+__global__ void k_nop(int* p) { if (p) *p = 0; }      // (measurement builds: empty launches on the joint stream -- what a kernel boundary costs a round)
 #endif
 // ---------------- segment -> (object, first photon) ----------------
 constexpr int N_XCD = 8;
@@ -1490,18 +1478,9 @@ __device__ __forceinline__ void update_tile_q3(const ims_sensor_t& s, const Slot
     for (int a = 0; a < 8; ++a) {
         const unsigned int rowbits = (unsigned int)(mask >> (8 * a)) & 0xFFu;
         if (__builtin_amdgcn_ballot_w64(rowbits != 0u) == 0ull) continue;
-        // (the eight scaled charges of the row first: a tap no lane of the wavefront has charge under costs its two scalar loads and
-        // the wait for them and adds fma(d, +0, acc) -- skipped as a whole; that is what the lone electrons of a star's wings pay,
-        // 32 taps per wavefront for 4: 41 % of a focal plane's listed tiles hold ONE charged cell, round 6)
-        double wrow[8];
-#pragma unroll
-        for (int bb = 0; bb < 8; ++bb) wrow[bb] = L.wt[(ly + 2 * Q + 1 - a) * HW + (lx + 2 * Q + 1 - bb)];
 #pragma unroll
         for (int bb = 0; bb < 8; ++bb) {
-            const double w = wrow[bb];
-#ifndef IMS_NO_TAP_SKIP
-            if (__builtin_amdgcn_ballot_w64(w != 0.0) == 0ull) continue;
-#endif
+            const double w = L.wt[(ly + 2 * Q + 1 - a) * HW + (lx + 2 * Q + 1 - bb)];
             // GLOBAL_DL: the row comes through the scalar cache into SGPRs (uniform, read-only table of the launch)
             auto row = [&](auto d) {
                 if (bb != 7) {                     // not the extra column: bottom-row points
@@ -2033,14 +2012,11 @@ __device__ __forceinline__ void update_listed_tile(const JointUpd* __restrict__ 
 }
 
 template <int NV, bool DPP = false>
-__global__ __launch_bounds__(256, 4) void k_update_list_j(const JointUpd* __restrict__ U, const JointLists Ls, int parity, unsigned int tag,
-                                                       int reset_next, int from_dense)
+__global__ __launch_bounds__(256) void k_update_list_j(const JointUpd* __restrict__ U, const JointLists Ls, int parity, unsigned int tag,
+                                                       int reset_next)
 {
     __shared__ UpdateLds<NV> L0;
-    // from_dense: the tiles k_update_sparse_j passed on (more charged cells in the halo than its one-wavefront form takes), listed in
-    // Ls.ref -- free with search-side lists, where ONE list serves update and refresh -- and counted in the round's second counter
-    const int n = Ls.count[2 * parity + (from_dense ? 1 : 0)];
-    const unsigned long long* __restrict__ list = from_dense ? Ls.ref : Ls.upd;
+    const int n = Ls.count[2 * parity];
     // (search-side lists: no builder launch to empty the next round's list -- this launch sits between this round's search and the next's)
     if (reset_next && blockIdx.x == 0 && threadIdx.x == 0) { Ls.count[2 * (parity ^ 1)] = 0; Ls.count[2 * (parity ^ 1) + 1] = 0; }
     for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
@@ -2049,282 +2025,8 @@ __global__ __launch_bounds__(256, 4) void k_update_list_j(const JointUpd* __rest
         // keeps every one of the ~180 constant LDS addresses of the unrolled window in a register of its own -- 256 against 80)
         UpdateLds<NV>* Lp = &L0;
         asm volatile("" : "+v"(Lp));
-        update_listed_tile<NV>(U, list[i], tag, *Lp);
+        update_listed_tile<NV>(U, Ls.upd[i], tag, *Lp);
     }
-}
-
-// ---- listed tiles with a handful of charged cells: ONE WAVEFRONT per tile ----
-// What a joint round lists is mostly the wings of the bright stars: of the 3.1 M listed tiles of 40 CCDs, 41 % have ONE charged
-// cell in the update's 23 x 23 halo, 75 % at most eight -- and those took 67 % of the time spent inside update_listed_tile, 10 us of
-// a four-wavefront workgroup each (profiles/round6_c5_tile_hist_before.log): the halo gather, a barrier, the window of every one of
-// the 256 cells tested, the table rows of every window row some lane needs through the scalar cache.  A lone electron moves the
-// points of the 8 x 8 cells around it and nothing else.  So here a wavefront takes a listed tile by itself: nine independent
-// loads per lane fetch the halo, ballots find the charged cells, and for each of them -- in the spec's order, which for every
-// cell of the tile is source row descending, then source column descending, i.e. descending halo index -- the 64 lanes ARE the
-// 64 cells of its window: lane l takes the cell of the window whose coordinates are congruent to (l & 7, l >> 3) modulo 8, so a cell
-// that lies in the windows of two charged cells is the same lane's both times and its FMAs stay in program order.  Per charged
-// cell and lane: the cell's twenty owned coordinates in, one table row (the tap this lane's cell sees the charge under) in, twenty
-// FMAs, twenty coordinates out.  Same operands in the same order as update_tile_q3 (whose taps without charge are fma(d, +0, acc),
-// the identity): same bits.  Tiles with more than `kmax` charged cells are passed on to k_update_list_j (dense list).
-// No barrier, no LDS beyond 16 (charge, index) pairs per wavefront, four tiles in flight per workgroup.
-constexpr int SPARSE_CAP = 16;
-
-// One pass of update_tile_q3 by ONE wavefront: the 64 cells (lx, ly) = (lane & 15, 4 pass + (lane >> 4)) of the tile, scaled charges
-// and row bitmaps of the halo in this wavefront's LDS, the table rows through the scalar cache.  Same window walk as
-// update_tile_q3 (a ascending, bb ascending, taps without charge under any lane skipped as a whole: fma(d, +0, acc) is the
-// identity), so the same bits.  Returns whether this lane's cell moved.
-template <int NV>
-__device__ __forceinline__ bool update_pass_q3_wave(const SlotView& sl, int tx0, int ty0, int lx, int ly, unsigned char* __restrict__ changed,
-                                                    double* __restrict__ boundary, const double* wt, const unsigned int* occ, ConstTable dl)
-{
-    constexpr int Q = 3, HW = UT + 2 * Q + 1, NPO = 2 * NV + 2;
-    const int i = tx0 + lx, j = ty0 + ly;
-    const bool cell = i <= sl.nx && j <= sl.ny;
-    unsigned long long mask = 0ull;
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-        const unsigned int row = (occ[ly + 2 * Q + 1 - a] >> lx) & 0xFFu;
-        mask |= (unsigned long long)(__brev(row) >> 24) << (8 * a);
-    }
-    if (!cell) mask = 0ull;
-    const int64_t c = cell ? cell_index(sl, i, j) : sl.offset;
-    if (cell) changed[c] = mask ? 1 : 0;
-    if (__builtin_amdgcn_ballot_w64(mask != 0ull) == 0ull) return false;
-    double* pts = boundary + c * NPO * 2;
-    double acc[NPO * 2];
-#pragma unroll
-    for (int n = 0; n < NPO * 2; ++n) acc[n] = mask ? pts[n] : 0.0;
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-        const unsigned int rowbits = (unsigned int)(mask >> (8 * a)) & 0xFFu;
-        if (__builtin_amdgcn_ballot_w64(rowbits != 0u) == 0ull) continue;
-#pragma unroll
-        for (int bb = 0; bb < 8; ++bb) {
-            const double ww = wt[(ly + 2 * Q + 1 - a) * HW + (lx + 2 * Q + 1 - bb)];
-            const double w = mask ? ww : 0.0;
-            if (__builtin_amdgcn_ballot_w64(w != 0.0) == 0ull) continue;
-            ConstTable d = dl + (a * 8 + bb) * NPO * 2;
-            if (bb != 7) {
-#pragma unroll
-                for (int n = 0; n <= NV + 1; ++n) {
-                    acc[2 * n] = fma(d[2 * n], w, acc[2 * n]);
-                    acc[2 * n + 1] = fma(d[2 * n + 1], w, acc[2 * n + 1]);
-                }
-            }
-            if (a != 7) {
-#pragma unroll
-                for (int n = NV + 2; n < NPO; ++n) {
-                    acc[2 * n] = fma(d[2 * n], w, acc[2 * n]);
-                    acc[2 * n + 1] = fma(d[2 * n + 1], w, acc[2 * n + 1]);
-                }
-            }
-        }
-    }
-    if (mask) {
-#pragma unroll
-        for (int n = 0; n < NPO * 2; ++n) pts[n] = acc[n];
-    }
-    return mask != 0ull;
-}
-
-template <int NV>
-__global__ __launch_bounds__(256, 4) void k_update_sparse_j(const JointUpd* __restrict__ U, const JointLists Ls, int parity, unsigned int tag,
-                                                         int kmax, int pass_on
-#ifdef IMS_HIST
-                                                         , int seq
-#endif
-                                                         )
-{
-    constexpr int Q = 3, HW = UT + 2 * Q + 1, NPO = 2 * NV + 2, NPT = 2 * NPO, HN = HW * HW, HU = (HN + 63) / 64;
-    __shared__ double s_w[4][SPARSE_CAP];
-    __shared__ int s_e[4][SPARSE_CAP];
-    __shared__ double s_wt[4][HN];               // the dense form by one wavefront: scaled charges and row bitmaps of the halo
-    __shared__ unsigned int s_occ[4][HW + 1];
-    const int n = Ls.count[2 * parity];
-    // (search-side lists: this launch sits between this round's search and the next's, and empties the next round's counters)
-    if (blockIdx.x == 0 && threadIdx.x == 0) { Ls.count[2 * (parity ^ 1)] = 0; Ls.count[2 * (parity ^ 1) + 1] = 0; }
-#ifdef IMS_HIST
-    unsigned long long* lg = g_launch_log[seq & 32767];
-    if (blockIdx.x == 0 && threadIdx.x == 0) { lg[0] = (unsigned long long)n; lg[1] = __builtin_amdgcn_s_memrealtime(); lg[4] = gridDim.x; }
-    const bool wg_sampled = (seq & 63) == 0 && blockIdx.x < 1024;
-    if (wg_sampled && threadIdx.x == 0) g_wg_log[(seq >> 6) & 63][blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
-#endif
-    const int lane0 = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    for (int it = (int)blockIdx.x * 4 + wv; it < n; it += (int)gridDim.x * 4) {
-        // (the lane number through a register the compiler cannot look through: it otherwise keeps the ~40 per-lane constants of
-        // the halo's index arithmetic alive across the loop, 142 registers against 96)
-        int lane = lane0;
-        asm volatile("" : "+v"(lane));
-        const int rx = lane & 7, ry = lane >> 3;
-#ifdef IMS_HIST
-        const unsigned long long hist_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
-        const unsigned long long e = Ls.upd[it];
-        const int c = (int)(e >> 58), lo = (int)((e >> 32) & 0x3FFFFFFu), t = (int)(e & 0xFFFFFFFFu);
-        const ims_sensor_t& s = *U->sp[c];
-        const ims_bf_slot_t bs = s.bf_slots[U->first_slot[c] + lo];
-        const SlotView sl = { bs.xmin, bs.ymin, bs.nx, bs.ny, bs.offset };
-        const int tiles_x = (sl.nx + 1 + UT - 1) / UT;
-        const int tx0 = (t % tiles_x) * UT, ty0 = (t / tiles_x) * UT;
-        const int sx0 = tx0 - (Q + 1), sy0 = ty0 - (Q + 1);
-        const double* __restrict__ delta = s.bf_delta;
-        // the halo: HU independent loads per lane
-        double v[HU];
-#pragma unroll
-        for (int u = 0; u < HU; ++u) {
-            const int ei = lane + 64 * u;
-            const int hx = ei % HW, hy = ei / HW;
-            const int si = sx0 + hx, sj = sy0 + hy;
-            const bool in = ei < HN && si >= 0 && si < sl.nx && sj >= 0 && sj < sl.ny;
-            v[u] = in ? delta[cell_index(sl, si, sj)] : 0.0;
-        }
-        unsigned long long m[HU];
-        int count = 0;
-#pragma unroll
-        for (int u = 0; u < HU; ++u) { m[u] = __builtin_amdgcn_ballot_w64(v[u] != 0.0); count += (int)__popcll(m[u]); }
-        if (count > kmax && pass_on) {               // a dense tile: the four-wavefront form takes it (k_update_list_j, dense list)
-            if (lane == 0) Ls.ref[atomicAdd(Ls.count + 2 * parity + 1, 1)] = e;
-#ifdef IMS_HIST
-            if (lane == 0) { atomicAdd(&g_hist[0][62], 1ull); atomicAdd(&g_hist[1][62], __builtin_amdgcn_s_memrealtime() - hist_t0); }
-#endif
-            continue;
-        }
-        if (count > kmax) {
-            // ... or this wavefront itself, in four passes of 64 cells (no second launch behind this one)
-            if (lane < HW) s_occ[wv][lane] = 0u;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const double num_elec_d = s.num_elec;
-#pragma unroll
-            for (int u = 0; u < HU; ++u) {
-                const int ei = lane + 64 * u;
-                if (ei < HN) {
-                    double w = 0.0;
-                    if (v[u] != 0.0) { w = ddiv(v[u], num_elec_d); atomicOr(&s_occ[wv][ei / HW], 1u << (ei % HW)); }
-                    s_wt[wv][ei] = w;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            unsigned char* __restrict__ changed_d = U->changed[c];
-            ConstTable dlc = (ConstTable)(uintptr_t)U->dl[c];
-            bool any_d = false;
-#pragma unroll 1
-            for (int pass = 0; pass < 4; ++pass) {
-                int ln = lane;
-                asm volatile("" : "+v"(ln));
-                any_d = update_pass_q3_wave<NV>(sl, tx0, ty0, ln & 15, 4 * pass + (ln >> 4), changed_d, s.bf_boundary, s_wt[wv], s_occ[wv], dlc) || any_d;
-            }
-            if (__builtin_amdgcn_ballot_w64(any_d) != 0ull && lane == 0 && tag != 0u && s.bf_tile_changed != nullptr)
-                s.bf_tile_changed[cell_index(sl, tx0, ty0)] = (unsigned char)tag;
-            __builtin_amdgcn_wave_barrier();
-#ifdef IMS_HIST
-            if (lane == 0) {
-                __builtin_amdgcn_s_waitcnt(0);
-                atomicAdd(&g_hist[0][62], 1ull); atomicAdd(&g_hist[1][62], __builtin_amdgcn_s_memrealtime() - hist_t0);
-            }
-#endif
-            continue;
-        }
-        unsigned char* __restrict__ changed = U->changed[c];
-        // the charged cells in descending halo index -> (charge, index) pairs of this wavefront
-        {
-            int above = 0;
-#pragma unroll
-            for (int u = HU - 1; u >= 0; --u) {
-                if (v[u] != 0.0) {
-                    const int rank = above + (int)__popcll((m[u] >> lane) >> 1);
-                    s_w[wv][rank] = v[u];
-                    s_e[wv][rank] = lane + 64 * u;
-                }
-                above += (int)__popcll(m[u]);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const double* __restrict__ dl = U->dl[c];
-        double* __restrict__ boundary = s.bf_boundary;
-        const double num_elec = s.num_elec;
-        // the four cells of the tile whose `changed` byte this lane writes: (lane & 15, (lane >> 4) + 4 p)
-        const int ox = tx0 + (lane & 15), oy = ty0 + (lane >> 4);
-        unsigned int moved = 0u;
-#pragma unroll 1
-        for (int r = 0; r < count; ++r) {
-            const double w = ddiv(s_w[wv][r], num_elec);
-            const int ei = s_e[wv][r];
-            const int wx0 = sx0 + ei % HW - Q, wy0 = sy0 + ei / HW - Q;          // the window: cells wx0 .. wx0 + 7, wy0 .. wy0 + 7
-            const int bb = (rx - wx0) & 7, a = (ry - wy0) & 7;                 // tap di = bb - Q, dj = a - Q
-            const int i = wx0 + bb, j = wy0 + a;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const unsigned int dx = (unsigned int)(ox - wx0), dy = (unsigned int)(oy + 4 * p - wy0);
-                if (dx < 8u && dy < 8u) moved |= 1u << p;
-            }
-            if (i >= tx0 && i < tx0 + UT && j >= ty0 && j < ty0 + UT && i <= sl.nx && j <= sl.ny) {
-                dvec2* pts = (dvec2*)(boundary + cell_index(sl, i, j) * NPT);
-                const dvec2* d = (const dvec2*)(dl + (a * 8 + bb) * NPT);
-                // the cell's points first (the long trip), the table row in two parts behind them (cache hits)
-                dvec2 acc[NPO];
-#pragma unroll
-                for (int q = 0; q < NPO; ++q) acc[q] = pts[q];
-                // the extra column of the window (di = Q + 1) moves no bottom-row point, the extra row (dj = Q + 1) no left-edge point
-                {
-                    dvec2 dd[NV + 2];
-#pragma unroll
-                    for (int q = 0; q <= NV + 1; ++q) dd[q] = d[q];
-                    const bool on = bb != 7;
-#pragma unroll
-                    for (int q = 0; q <= NV + 1; ++q) {
-                        const double nx_ = fma(dd[q].x, w, acc[q].x), ny_ = fma(dd[q].y, w, acc[q].y);
-                        acc[q].x = on ? nx_ : acc[q].x;
-                        acc[q].y = on ? ny_ : acc[q].y;
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                {
-                    dvec2 dd[NV];
-#pragma unroll
-                    for (int q = 0; q < NV; ++q) dd[q] = d[NV + 2 + q];
-                    const bool on = a != 7;
-#pragma unroll
-                    for (int q = 0; q < NV; ++q) {
-                        const double nx_ = fma(dd[q].x, w, acc[NV + 2 + q].x), ny_ = fma(dd[q].y, w, acc[NV + 2 + q].y);
-                        acc[NV + 2 + q].x = on ? nx_ : acc[NV + 2 + q].x;
-                        acc[NV + 2 + q].y = on ? ny_ : acc[NV + 2 + q].y;
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < NPO; ++q) pts[q] = acc[q];
-            }
-        }
-        bool any = false;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int ci = ox, cj = oy + 4 * p;
-            if (ci <= sl.nx && cj <= sl.ny) {
-                const bool mv = (moved >> p) & 1u;
-                changed[cell_index(sl, ci, cj)] = mv ? 1 : 0;
-                any = any || mv;
-            }
-        }
-        if (__builtin_amdgcn_ballot_w64(any) != 0ull && lane == 0 && tag != 0u && s.bf_tile_changed != nullptr)
-            s.bf_tile_changed[cell_index(sl, tx0, ty0)] = (unsigned char)tag;
-        __builtin_amdgcn_wave_barrier();            // (the pairs are this wavefront's until its next tile)
-#ifdef IMS_HIST
-        if (lane == 0) {
-            __builtin_amdgcn_s_waitcnt(0);
-            atomicAdd(&g_hist[0][count < 62 ? count : 61], 1ull);
-            atomicAdd(&g_hist[1][count < 62 ? count : 61], __builtin_amdgcn_s_memrealtime() - hist_t0);
-        }
-#endif
-    }
-#ifdef IMS_HIST
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) lg[2] = __builtin_amdgcn_s_memrealtime();      // the LAST workgroup's end
-    if (wg_sampled && threadIdx.x == 0) g_wg_log[(seq >> 6) & 63][blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
-#endif
 }
 
 template <int NV>
@@ -3171,8 +2873,6 @@ int ims_set_tuning(const ims_tuning_t* t)
     if (t->photon_lds > 65536 - 4096) return set_err(IMS_ERR_ARG, "tuning: photon_lds beyond what a workgroup may ask for");
     if (t->upd_dpp_max < 0 || t->joint_list_min < 0 || !(t->active_fraction > 0.0) || t->active_fraction > 1.0)
         return set_err(IMS_ERR_ARG, "tuning: upd_dpp_max / joint_list_min / active_fraction out of range");
-    if (t->joint_sparse_max < 0 || t->joint_sparse_max > 16) return set_err(IMS_ERR_ARG, "tuning: joint_sparse_max must be 0 .. 16");
-    if (t->joint_grid_cap < 0) return set_err(IMS_ERR_ARG, "tuning: joint_grid_cap must be >= 0");
     std::lock_guard<std::mutex> lock(g_state_mutex);
     g_tune = *t;
     return IMS_OK;
@@ -4221,35 +3921,9 @@ int ims_plans_run_joint(void* const* plans, int32_t n_plans, void* joint_stream,
             if (grid < 256 && list_fraction >= 0.05) grid = 256;
             if (grid < 1) grid = 1;
             if (grid > tiles) grid = tiles;
-            // ... and no more workgroups than the device holds at a time: the walkers loop over the list, and the dispatch of the
-            // thousands of workgroups that find it exhausted was what their launches cost (round 6: 50 us each, ~2 300 listed tiles)
-            const int64_t grid_raw = grid;
-            const int64_t cap = g_tune.joint_grid_cap > 0 ? (int64_t)g_tune.joint_grid_cap : (int64_t)0x7fffffff;
-            if (grid > cap) grid = cap;
             if (!search_lists)
                 hipLaunchKernelGGL(k_build_active_j, dim3((unsigned)build_wgs), dim3(256), 0, js, U, R, tag, Ls, parity, (int)g_tune.joint_fine_marks);
-            if (search_lists && dpp_ok && g_tune.joint_sparse_max > 0) {
-                // the tiles with a handful of charged cells in reach by one wavefront each (four tiles per workgroup), the rest
-                // -- passed on through the dense list -- by the four-wavefront form
-                const int kmax = g_tune.joint_sparse_max < SPARSE_CAP ? g_tune.joint_sparse_max : SPARSE_CAP;
-                const int pass_on = g_tune.pad != 0 ? 1 : 0;            // (experiment: dense tiles to a second launch instead of four passes in place)
-                int64_t grid_s = (grid_raw + 3) / 4 < 64 ? 64 : (grid_raw + 3) / 4;
-                int64_t grid_d = grid_raw / 4 < 64 ? 64 : grid_raw / 4;
-                if (grid_s > cap) grid_s = cap;
-                if (grid_d > cap) grid_d = cap;
-#ifdef IMS_HIST
-                {
-                    static const unsigned long long fresh[5] = { 0ull, ~0ull, 0ull, 0ull, 0ull };
-                    const int seq = g_launch_seq++;
-                    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_launch_log), fresh, sizeof(fresh), (size_t)(seq & 32767) * sizeof(fresh), hipMemcpyHostToDevice, js);
-                    hipLaunchKernelGGL((k_update_sparse_j<4>), dim3((unsigned)grid_s), dim3(256), 0, js, U, Ls, parity, tag, kmax, pass_on, seq);
-                }
-#else
-                hipLaunchKernelGGL((k_update_sparse_j<4>), dim3((unsigned)grid_s), dim3(256), 0, js, U, Ls, parity, tag, kmax, pass_on);
-#endif
-                if (pass_on) hipLaunchKernelGGL((k_update_list_j<4, false>), dim3((unsigned)grid_d), dim3(256), 0, js, U, Ls, parity, tag, 0, 1);
-            } else
-                hipLaunchKernelGGL((k_update_list_j<4, false>), dim3((unsigned)grid), dim3(256), 0, js, U, Ls, parity, tag, search_lists ? 1 : 0, 0);
+            hipLaunchKernelGGL((k_update_list_j<4, false>), dim3((unsigned)grid), dim3(256), 0, js, U, Ls, parity, tag, search_lists ? 1 : 0);
             hipLaunchKernelGGL(k_refresh_list_j<4>, dim3((unsigned)grid), dim3(256), 0, js, U, Ls, parity, tag, search_lists ? 1 : 0);
         } else if (tiles > 0) {
             const JointUpd* U = &tables_dev->upd;

@@ -26,10 +26,6 @@ KNOWN = {
     "IMS_JOINT_LIST_MIN": ("1024", "... for rounds of more than this many tiles"),
     "IMS_ACTIVE_FRACTION": ("0.25", "... workgroups launched per tile of the round"),
     "IMS_JOINT_FINE_MARKS": ("1", "... from charge marks per 4 x 4 pixels: a tile is listed when charge lies within the update's reach of it"),
-    "IMS_JOINT_SPARSE_MAX": ("8", "a listed tile with at most this many charged cells in reach is updated by one wavefront (k_update_sparse_j); 0 = every "
-                                  "listed tile by a four-wavefront workgroup; at most 16"),
-    "IMS_JOINT_DENSE_PASS_ON": ("0", "(experiment) 1 = the one-wavefront update passes tiles beyond its cut on to a second launch"),
-    "IMS_JOINT_GRID_CAP": ("1024", "the list walkers of a joint round are launched with at most this many workgroups (0 = no cap)"),
     "IMS_JOINT_SEARCH_LISTS": ("1", "... appended to by the pixel search where the charge lands; 0 = a launch of its own scans the marks (k_build_active_j)"),
     "IMS_ROUND_TWO_SEGMENTS": ("0", "pixel search of a round with two 256-photon segments per workgroup (both pool records requested up front)"),
     # -- engine --
@@ -199,8 +195,7 @@ class Tuning(C.Structure):
                 ("round_compact", C.c_int32), ("init_tiles", C.c_int32), ("upd_dpp", C.c_int32), ("joint_lists", C.c_int32),
                 ("upd_dpp_max", C.c_int64), ("joint_list_min", C.c_int64), ("active_fraction", C.c_double),
                 ("round_two_segments", C.c_int32), ("joint_fine_marks", C.c_int32),
-                ("joint_search_lists", C.c_int32), ("joint_sparse_max", C.c_int32),
-                ("joint_grid_cap", C.c_int32), ("pad", C.c_int32)]
+                ("joint_search_lists", C.c_int32), ("pad", C.c_int32)]
 
 
 def library_tuning():
@@ -221,9 +216,6 @@ def library_tuning():
     t.round_two_segments = 1 if flag("IMS_ROUND_TWO_SEGMENTS") else 0
     t.joint_fine_marks = 1 if flag("IMS_JOINT_FINE_MARKS") else 0
     t.joint_search_lists = 1 if flag("IMS_JOINT_SEARCH_LISTS") else 0
-    t.joint_sparse_max = int(number("IMS_JOINT_SPARSE_MAX"))
-    t.joint_grid_cap = int(number("IMS_JOINT_GRID_CAP"))
-    t.pad = int(number("IMS_JOINT_DENSE_PASS_ON"))
     return t
 
 

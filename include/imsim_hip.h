@@ -48,7 +48,7 @@ extern "C" {
 #define IMS_ERR_NO_DEVICE  -3
 #define IMS_ERR_UNSUPPORTED -4
 
-#define IMS_ABI_VERSION 20
+#define IMS_ABI_VERSION 19
 
 /* Pointers stored INSIDE descriptors that live in device memory (ims_sensor_t, ims_atmosphere_t) always point to global
  * device memory.  Device code is told so (address space 1): a pointer read out of memory is otherwise a generic pointer and
@@ -448,11 +448,6 @@ typedef struct ims_tuning {
                                     charge lies within the update's reach of it, not when one of its 3 x 3 tile neighbours holds some) */
     int32_t joint_search_lists;  /* 1: ... and the lists are appended to by the pixel search itself, where the charge lands (no launch that
                                     scans the marks of every tile afterwards); 0 = k_build_active_j */
-    int32_t joint_sparse_max;    /* 8: a listed tile with at most this many charged cells in the update's 23 x 23 halo is updated by ONE
-                                    wavefront whose lanes are the 8 x 8 cells around each charged cell in turn (k_update_sparse_j; at most
-                                    16; needs joint_search_lists and ims_sensor_t.bf_dl); 0: every listed tile by a four-wavefront workgroup */
-    int32_t joint_grid_cap;      /* 1024: the list walkers of a joint round are launched with at most this many workgroups (they loop over
-                                    the list); 0: no cap (active_fraction of the round's tiles) */
     int32_t pad;
 } ims_tuning_t;
 int  ims_tuning_defaults(ims_tuning_t* out);

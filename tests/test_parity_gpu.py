@@ -1503,14 +1503,10 @@ def test_joint_top_chains_of_a_focal_plane_equal_a_chain_per_ccd(torch_cuda, mon
     # tiles so that every workgroup walks several list entries, and off)
     # (the lists appended to by the pixel search itself -- the default --, built by a launch of its own from charge marks per 4 x 4
     # pixels, and from the tile marks alone)
-    # (sparse: listed tiles with at most that many charged cells in reach are updated by ONE wavefront, k_update_sparse_j, the rest
-    # passed on to the four-wavefront form -- 8 is the default; 1 and 16 move the cut, 0 switches the form off)
-    for joint, hint, list_min, fraction, fine, search, sparse in (
-            ("8", None, "0", "0.01", "1", "1", "8"), ("8", None, "0", "0.01", "1", "0", "8"), ("8", None, "0", "0.01", "0", "0", "8"),
-            ("8", None, "0", "0.01", "1", "1", "0"), ("8", None, "0", "0.25", "1", "1", "1"), ("8", None, "0", "0.01", "1", "1", "16"),
-            ("2", lambda det: int(jobs[det].objects["n_phot"].max()), "0", "0.25", "1", "1", "8"),
-            ("2", None, "1000000000", "0.25", "1", "1", "8")):
-        monkeypatch.setenv("IMS_JOINT_SPARSE_MAX", sparse)
+    for joint, hint, list_min, fraction, fine, search in (("8", None, "0", "0.01", "1", "1"), ("8", None, "0", "0.01", "1", "0"),
+                                                          ("8", None, "0", "0.01", "0", "0"),
+                                                          ("2", lambda det: int(jobs[det].objects["n_phot"].max()), "0", "0.25", "1", "1"),
+                                                          ("2", None, "1000000000", "0.25", "1", "1")):
         monkeypatch.setenv("IMS_FOCAL_JOINT", joint)
         monkeypatch.setenv("IMS_JOINT_LIST_MIN", list_min)
         monkeypatch.setenv("IMS_ACTIVE_FRACTION", fraction)

@@ -254,7 +254,7 @@ EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_
            "ims_tuning_defaults", "ims_get_tuning", "ims_set_tuning", "ims_shoot_accumulate",
            "ims_shoot_photons", "ims_shoot_ops_photons", "ims_accumulate_segments", "ims_accumulate_small", "ims_accumulate_round", "ims_run_plan",
            "ims_fft_kspace_fill", "ims_fft_finish", "ims_fft_spikes", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
-           "ims_sensor_update_distortions", "ims_image_add", "ims_image_to_float", "ims_fill_derived_op", "ims_fill_derived_medium", "ims_fill_derived_optics", "ims_fill_derived_atmosphere", "ims_fill_derived_sensor", "ims_sensor_pixel_areas", "ims_flat_add", "ims_last_kernel_ms", "ims_enable_timing",
+           "ims_sensor_update_distortions", "ims_sensor_update_distortions_fold", "ims_sensor_fold_delta", "ims_image_add", "ims_image_to_float", "ims_fill_derived_op", "ims_fill_derived_medium", "ims_fill_derived_optics", "ims_fill_derived_atmosphere", "ims_fill_derived_sensor", "ims_sensor_pixel_areas", "ims_flat_add", "ims_last_kernel_ms", "ims_enable_timing",
            "ims_readout_bleed", "ims_readout_segments", "ims_readout_cte", "ims_readout_finish",
            "ims_build_object_table", "ims_patch_stamp_sizes", "ims_gather_rows", "ims_parse_instcat_objects", "ims_screen_prepass",
            "ims_plan_lsst_image", "ims_plan_bind", "ims_plan_upload", "ims_plan_run", "ims_plan_run_deferred", "ims_plans_run_joint", "ims_plan_join", "ims_plan_add_realized", "ims_plan_destroy",
@@ -303,6 +303,8 @@ def load():
     lib.ims_accumulate.argtypes = [C.POINTER(RenderParams), c_vp, C.POINTER(Photons), c_vp, c_vp]
     lib.ims_sensor_init_boundaries.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_vp, c_i64, c_vp]
     lib.ims_sensor_update_distortions.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_i32, c_vp, c_i64, c_vp, C.c_uint32, c_vp]
+    lib.ims_sensor_update_distortions_fold.argtypes = [c_vp, C.POINTER(Sensor), c_vp, c_i64, c_vp, C.c_uint32, c_vp, c_i32, c_i32, c_vp]
+    lib.ims_sensor_fold_delta.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_vp, c_i32, c_i32, c_vp]
     lib.ims_image_add.argtypes = [c_vp, c_vp, c_i64, c_vp]
     lib.ims_image_to_float.argtypes = [c_vp, c_vp, c_i64, c_vp]
     lib.ims_sensor_pixel_areas.argtypes = [c_vp, C.POINTER(Sensor), c_i32, c_vp, c_vp, c_vp]

@@ -242,15 +242,19 @@ __device__ __forceinline__ void deposit_global(const ims_render_params_t& P, con
                                                bool list_now = true)
 {
     const int px = ix - P.xmin, py = iy - P.ymin;
-    if (px >= 0 && px < P.nx && py >= 0 && py < P.ny) unsafeAtomicAdd(P.image + ((int64_t)py * P.nx + px), flux);
+    bool to_image = px >= 0 && px < P.nx && py >= 0 && py < P.ny;
     if (ct.track) {
         const int di = ix - ct.slot.xmin, dj = iy - ct.slot.ymin;
         if (di >= 0 && di < ct.slot.nx && dj >= 0 && dj < ct.slot.ny) {
             unsafeAtomicAdd(P.sensor->bf_delta + (ct.slot.offset + (int64_t)dj * (ct.slot.nx + 1) + di), flux);
             mark_tile_charge(P, ct.slot.offset, ct.slot.nx, di, dj);
             if (list_now && ct.lister.list != nullptr) list_tiles_in_reach(ct, di, dj);
+            // track_static_delta 2 (photon pooling, slot 0 = the image): the image takes the charge FROM the delta image when
+            // the recalculation consumes it -- GalSim's `target += delta` -- so the deposit is one atomic add, not two
+            if (P.track_static_delta == 2) to_image = false;
         }
     }
+    if (to_image) unsafeAtomicAdd(P.image + ((int64_t)py * P.nx + px), flux);
 }
 
 __device__ __forceinline__ void tile_deposit(float* tile, const ChargeTile& ct, const ims_render_params_t& P, int ix, int iy,
@@ -469,18 +473,20 @@ __global__ __launch_bounds__(256) void k_accumulate(const ims_render_params_t P,
         rng_reset(rng);
         if (!land(P, o, k, rng, ph, silicon, has_angles, ix, iy)) continue;
         if (P.realized_flux != nullptr) unsafeAtomicAdd(P.realized_flux + oi, ph.flux);
+        bool in_delta = false;
         if (silicon && !(o.flags & IMS_OBJ_FAINT) && (o.bf_state > 0 || P.track_static_delta)) {
             const ims_bf_slot_t bs = P.sensor->bf_slots[slot_index(P, o)];
             const int di = ix - bs.xmin, dj = iy - bs.ymin;
             if (di >= 0 && di < bs.nx && dj >= 0 && dj < bs.ny) {
                 unsafeAtomicAdd(P.sensor->bf_delta + (bs.offset + (int64_t)dj * (bs.nx + 1) + di), ph.flux);
                 mark_tile_charge(P, bs.offset, bs.nx, di, dj);
+                in_delta = P.track_static_delta == 2;
             }
         }
         const int px = ix - P.xmin, py = iy - P.ymin;
         if (px < 0 || px >= P.nx || py < 0 || py >= P.ny) continue;
         const int64_t pidx = (int64_t)py * P.nx + px;
-        unsafeAtomicAdd(P.image + pidx, ph.flux);
+        if (!in_delta) unsafeAtomicAdd(P.image + pidx, ph.flux);
         if (pixel_index_out) pixel_index_out[i] = (int32_t)pidx;
     }
 }
@@ -1736,15 +1742,24 @@ __global__ __launch_bounds__(256) void k_update_distortions_q3_j(const JointUpd*
 // neither charge nor movement (own, right and upper tile) leave after three byte loads.
 // NV > 0: the owned points of the cell and of its right / upper neighbours are fetched with independent loads into
 // registers and the vertex loop is unrolled (the generic loop issues one dependent load per vertex: 12 us per wave).
+// fold_image: the f64 image of which this slot is the pixel grid (row length sl.nx): the consumed delta charge is added to it --
+// Silicon's `target += delta` at a recalculation (deposits of ims_render_params_t.track_static_delta 2 went to the delta image only)
 template <int NV>
 __device__ __forceinline__ void refresh_tile(const ims_sensor_t& s, const SlotView& sl, int tx, int ty, bool own, bool right,
-                                             bool up, bool charged, const unsigned char* __restrict__ changed)
+                                             bool up, bool charged, const unsigned char* __restrict__ changed,
+                                             double* __restrict__ fold_image = nullptr)
 {
     const int lx = threadIdx.x % UT, ly = threadIdx.x / UT;
     const int i = tx * UT + lx, j = ty * UT + ly;
     if (i > sl.nx || j > sl.ny) return;
     const int64_t c = cell_index(sl, i, j);
-    if (charged) s.bf_delta[c] = 0.0;         // the update has consumed the delta charge
+    if (charged) {                            // the update has consumed the delta charge
+        if (fold_image != nullptr && i < sl.nx && j < sl.ny) {
+            const double d = s.bf_delta[c];
+            if (d != 0.0) fold_image[(int64_t)j * sl.nx + i] += d;
+        }
+        s.bf_delta[c] = 0.0;
+    }
     if (i >= sl.nx || j >= sl.ny) return;
     // per-cell flags are only meaningful in tiles the update worked on this round
     const bool f_own = own && changed[c];
@@ -1809,7 +1824,8 @@ __device__ __forceinline__ void refresh_tile(const ims_sensor_t& s, const SlotVi
 template <int NV>
 __global__ __launch_bounds__(256) void k_refresh_changed(const ims_sensor_t* __restrict__ sp, int first_slot, int n_slots,
                                                          const int64_t* __restrict__ tile_prefix,
-                                                         const unsigned char* __restrict__ changed, unsigned int tag)
+                                                         const unsigned char* __restrict__ changed, unsigned int tag,
+                                                         double* __restrict__ fold_image)
 {
     PROBE(16);
     const ims_sensor_t& s = *sp;
@@ -1831,7 +1847,7 @@ __global__ __launch_bounds__(256) void k_refresh_changed(const ims_sensor_t* __r
         if (!(own || right || up || charged)) return;
     }
     PROBE(17);
-    refresh_tile<NV>(s, sl, tx, ty, own, right, up, charged, changed);
+    refresh_tile<NV>(s, sl, tx, ty, own, right, up, charged, changed, fold_image);
     PROBE(18);
 }
 
@@ -3269,9 +3285,64 @@ int ims_sensor_init_boundaries(const ims_sensor_t* sensor_dev, const ims_sensor_
     return IMS_OK;
 }
 
+static int update_distortions_impl(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host,
+                                   int32_t first_slot, int32_t n_slots, const int64_t* tile_prefix_dev,
+                                   int64_t n_tiles, unsigned char* changed_dev, uint32_t tag, double* fold_image, void* stream);
+
 int ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host,
                                   int32_t first_slot, int32_t n_slots, const int64_t* tile_prefix_dev,
                                   int64_t n_tiles, unsigned char* changed_dev, uint32_t tag, void* stream)
+{
+    return update_distortions_impl(sensor_dev, sensor_host, first_slot, n_slots, tile_prefix_dev, n_tiles, changed_dev, tag, nullptr, stream);
+}
+
+// slot `slot` must be the pixel grid of the image (nx x ny): what the fold forms index with
+static int fold_geometry(const ims_sensor_t* sensor_host, int32_t slot, double* image_dev, int32_t nx, int32_t ny)
+{
+    if (!image_dev) return set_err(IMS_ERR_ARG, "image is NULL");
+    if (!sensor_host || !sensor_host->bf_slots || slot < 0 || slot >= sensor_host->n_bf_slots)
+        return set_err(IMS_ERR_ARG, "sensor_host / its slot table is NULL or the slot is out of range");
+    const ims_bf_slot_t& b = sensor_host->bf_slots[slot];
+    if (b.nx != nx || b.ny != ny) return set_err(IMS_ERR_ARG, "the slot is not the pixel grid of the image (nx / ny differ)");
+    return IMS_OK;
+}
+
+int ims_sensor_update_distortions_fold(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host, const int64_t* tile_prefix_dev,
+                                       int64_t n_tiles, unsigned char* changed_dev, uint32_t tag, double* image_dev, int32_t nx, int32_t ny,
+                                       void* stream)
+{
+    const int rc = fold_geometry(sensor_host, 0, image_dev, nx, ny);
+    if (rc) return rc;
+    return update_distortions_impl(sensor_dev, sensor_host, 0, 1, tile_prefix_dev, n_tiles, changed_dev, tag, image_dev, stream);
+}
+
+__global__ __launch_bounds__(256) void k_fold_delta(const ims_sensor_t* __restrict__ sp, int slot, double* __restrict__ image)
+{
+    const ims_sensor_t& s = *sp;
+    const ims_bf_slot_t bs = s.bf_slots[slot];
+    const int64_t n = (int64_t)bs.nx * bs.ny, stride = (int64_t)gridDim.x * 256;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += stride) {
+        const int i = (int)(p % bs.nx), j = (int)(p / bs.nx);
+        const int64_t c = bs.offset + (int64_t)j * (bs.nx + 1) + i;
+        const double d = s.bf_delta[c];
+        if (d != 0.0) { image[p] += d; s.bf_delta[c] = 0.0; }
+    }
+}
+
+int ims_sensor_fold_delta(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host, int32_t slot, double* image_dev, int32_t nx,
+                          int32_t ny, void* stream)
+{
+    if (!sensor_dev) return set_err(IMS_ERR_ARG, "sensor_dev is NULL");
+    const int rc = fold_geometry(sensor_host, slot, image_dev, nx, ny);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_fold_delta, dim3(4096), dim3(256), 0, (hipStream_t)stream, sensor_dev, slot, image_dev);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+static int update_distortions_impl(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host,
+                                   int32_t first_slot, int32_t n_slots, const int64_t* tile_prefix_dev,
+                                   int64_t n_tiles, unsigned char* changed_dev, uint32_t tag, double* fold_image, void* stream)
 {
     if (!sensor_dev) return set_err(IMS_ERR_ARG, "sensor_dev is NULL");
     if (n_slots == 0) return IMS_OK;
@@ -3307,13 +3378,13 @@ int ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sens
                            tile_prefix_dev, changed_dev, tag);
     if (nV == 4)
         hipLaunchKernelGGL(k_refresh_changed<4>, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot, n_slots,
-                           tile_prefix_dev, (const unsigned char*)changed_dev, tag);
+                           tile_prefix_dev, (const unsigned char*)changed_dev, tag, fold_image);
     else if (nV == 8)
         hipLaunchKernelGGL(k_refresh_changed<8>, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot, n_slots,
-                           tile_prefix_dev, (const unsigned char*)changed_dev, tag);
+                           tile_prefix_dev, (const unsigned char*)changed_dev, tag, fold_image);
     else
         hipLaunchKernelGGL(k_refresh_changed<0>, dim3((unsigned)n_tiles), dim3(256), 0, st, sensor_dev, first_slot, n_slots,
-                           tile_prefix_dev, (const unsigned char*)changed_dev, tag);
+                           tile_prefix_dev, (const unsigned char*)changed_dev, tag, fold_image);
     HIP_TRY(hipGetLastError());
     return IMS_OK;
 }

@@ -1845,7 +1845,7 @@ class Renderer:
     def _num_vertices(self):
         return int(self.scene.sensor.model.num_vertices) if self.scene.sensor is not None else 0
 
-    def prepared_pooled_batches(self, shoot_table, batches, realized=None):
+    def prepared_pooled_batches(self, shoot_table, batches, realized=None, delta_only=False):
         """Photon-pooling mode with the pool resident in HBM: ONE launch shoots every photon of every batch (shoot, PSF, op
         chain, conversion depth and diffusion: `ims_shoot_ops_photons` into a converted pool, 32 B per photon -- 49 GB for
         the 1.5e9 photons of C4, which is what 288 GB of HBM are for), then every batch only runs the pixel search of ITS
@@ -1956,6 +1956,8 @@ class Renderer:
                                        self.image.data_ptr(), tmp.data_ptr() if tmp is not None else None,
                                        _seg_ptr(bpre_t) if bpre_t is not None else None)
                 Pb.bf_tag = bf_tag
+                if delta_only:
+                    Pb.track_static_delta = 2          # one atomic add per photon: the image is fed from the delta image (update_distortions(fold=True))
                 calls.append((entry, Pb, start_t, (part_t, bpre_t, tmp, rows_t)))
 
             def accumulate(calls=calls):
@@ -2125,18 +2127,36 @@ class Renderer:
         off = int(sl["offset"])
         return self.bound.sensor_arrays["delta"].view(self.torch.float64)[off:off + n]
 
-    def update_distortions(self, first_slot, n_slots, stream=None, bf_tag=0):
+    def update_distortions(self, first_slot, n_slots, stream=None, bf_tag=0, fold=False):
+        """fold (slot 0 alone, photon pooling): Silicon's `target += delta` -- the delta charge the recalculation consumes is added
+        to self.image (the batch's launches deposited into the delta image only: ims_render_params_t.track_static_delta 2)."""
         if first_slot == 0:
             self._need_static("update_distortions(0, ..)")
         if not hasattr(self, "_changed"):
             cells = self.bound.static_cells + int(self.bound.scratch_cells)
             self._changed = self.torch.zeros(max(cells, 1), dtype=self.torch.uint8, device=self.device)
         prefix, prefix_t = self._tile_prefix(first_slot)
+        if fold:
+            if first_slot != 0 or n_slots != 1:
+                raise ValueError("update_distortions(fold=True) is the recalculation of slot 0 alone")
+            _abi.check(self.lib.ims_sensor_update_distortions_fold(self.bound.sensor_dev_ptr, C.byref(self.bound.sensor_host),
+                                                                   prefix_t.data_ptr(), int(prefix[1]), self._changed.data_ptr(), bf_tag,
+                                                                   self.image.data_ptr(), self.scene.nx, self.scene.ny,
+                                                                   stream if stream is not None else self._stream()),
+                       "ims_sensor_update_distortions_fold")
+            return
         _abi.check(self.lib.ims_sensor_update_distortions(self.bound.sensor_dev_ptr, C.byref(self.bound.sensor_host),
                                                           first_slot, n_slots, prefix_t.data_ptr(), int(prefix[n_slots]),
                                                           self._changed.data_ptr(), bf_tag,
                                                           stream if stream is not None else self._stream()),
                    "ims_sensor_update_distortions")
+
+    def fold_delta(self, stream=None):
+        """ims_sensor_fold_delta: the delta charge of slot 0 that no recalculation has consumed yet into self.image (the end of a
+        pooled render whose launches deposited into the delta image only)."""
+        _abi.check(self.lib.ims_sensor_fold_delta(self.bound.sensor_dev_ptr, C.byref(self.bound.sensor_host), 0, self.image.data_ptr(),
+                                                  self.scene.nx, self.scene.ny, stream if stream is not None else self._stream()),
+                   "ims_sensor_fold_delta")
 
     def image_float(self):
         """float32 device tensor of the CCD image (what the reference's ImageF holds)"""

@@ -191,6 +191,7 @@ def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1,
 
     shoot, launches = None, []
     r_rows = None
+    delta_only = False
     if resident:
         shoot_table = tidy(objects[shot].copy())
         if world > 1 or tuning.env("IMS_POOL_SPATIAL", "1") != "0":
@@ -209,7 +210,8 @@ def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1,
         r_rows = None
         if realized is not None:
             r_rows = renderer.torch.zeros(len(shoot_table), dtype=renderer.torch.float64, device=renderer.device)
-        shoot, launches = renderer.prepared_pooled_batches(shoot_table, batches, realized=r_rows)
+        delta_only = _delta_only(renderer, sensor_on, world, parallel.unit_flux_path(renderer.scene, objects), after_batch)
+        shoot, launches = renderer.prepared_pooled_batches(shoot_table, batches, realized=r_rows, delta_only=delta_only)
     else:
         for i, (table, index) in enumerate(tables):
             keep = (table["n_phot"] > 0) & mine[index]
@@ -233,7 +235,7 @@ def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1,
             if sensor_on and i > first_batch:
                 if parallel.exchanging(world):
                     parallel.allreduce_delta(renderer.delta_tensor(0), integer_counts=unit)
-                renderer.update_distortions(0, 1, bf_tag=((i - 1) % 255 + 1) if tagged else 0)
+                renderer.update_distortions(0, 1, bf_tag=((i - 1) % 255 + 1) if tagged else 0, fold=delta_only)
             launch()
             if realized is not None and r_rows is not None:
                 # batch by batch, so that a checkpoint taken after batch i carries the fluxes up to batch i
@@ -241,6 +243,8 @@ def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1,
                 r_rows.zero_()
             if after_batch is not None:
                 after_batch(i)
+        if delta_only:
+            renderer.fold_delta()                          # the last batch's charge: no recalculation follows it
     shot_t = renderer.torch.from_numpy(shot).to(renderer.device) if realized is not None and shoot is not None else None
     if shoot is not None:
         run.photons, run.object_rows = shoot.photons, shoot.object_rows
@@ -255,6 +259,19 @@ def prepared_image(renderer, objects, modes, nbatch=10, seed=0, rank=0, world=1,
     run.resident = bool(resident)
     run.keep = (shoot, launches)
     return run
+
+
+def _delta_only(renderer, sensor_on, world, unit, after_batch):
+    """Photon pooling with ONE atomic add per photon: a batch's launches deposit into the delta-charge image of slot 0 only
+    (ims_render_params_t.track_static_delta 2) and the image takes the charge when the next recalculation consumes it -- Silicon's
+    `target += delta` (Renderer.update_distortions(fold=True)), the last batch's by Renderer.fold_delta().  Exact for integer charge,
+    so only where every photon is one electron; one rank (with several, the delta image every rank consumes is the all-reduced
+    one); no checkpoint hook (it reads the image between the batches).  IMS_POOL_DELTA_ONLY=0: two atomic adds as before."""
+    if not (sensor_on and world == 1 and unit and after_batch is None and tuning.flag("IMS_POOL_DELTA_ONLY")):
+        return False
+    sc = renderer.scene
+    sl = renderer.bound._slots_host[0]
+    return (int(sl["xmin"]), int(sl["ymin"]), int(sl["nx"]), int(sl["ny"])) == (sc.xmin, sc.ymin, sc.nx, sc.ny) and int(sl["offset"]) == 0
 
 
 def _prepared_image_device(renderer, table, modes, nbatch, seed, rank, world, realized, after_batch, first_batch):
@@ -315,8 +332,9 @@ def _prepared_image_device(renderer, table, modes, nbatch, seed, rank, world, re
     r_rows = None
     if realized is not None:
         r_rows = renderer.torch.zeros(len(shot), dtype=renderer.torch.float64, device=renderer.device)
-    shoot, launches = renderer.prepared_pooled_batches((table, shot), batches, realized=r_rows)
     unit = parallel.unit_flux_path(renderer.scene, None)
+    delta_only = _delta_only(renderer, sensor_on, world, unit, after_batch)
+    shoot, launches = renderer.prepared_pooled_batches((table, shot), batches, realized=r_rows, delta_only=delta_only)
 
     def run():
         if sensor_on:
@@ -328,10 +346,12 @@ def _prepared_image_device(renderer, table, modes, nbatch, seed, rank, world, re
             if sensor_on and i > first_batch:
                 if parallel.exchanging(world):
                     parallel.allreduce_delta(renderer.delta_tensor(0), integer_counts=unit)
-                renderer.update_distortions(0, 1, bf_tag=((i - 1) % 255 + 1) if tagged else 0)
+                renderer.update_distortions(0, 1, bf_tag=((i - 1) % 255 + 1) if tagged else 0, fold=delta_only)
             launch()
             if after_batch is not None:
                 after_batch(i)
+        if delta_only:
+            renderer.fold_delta()
         if realized is not None:
             realized.index_add_(0, renderer.torch.from_numpy(shot).to(renderer.device), r_rows)
     run.photons, run.object_rows = shoot.photons, shoot.object_rows

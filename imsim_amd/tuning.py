@@ -29,6 +29,8 @@ KNOWN = {
     "IMS_JOINT_SEARCH_LISTS": ("1", "... appended to by the pixel search where the charge lands; 0 = a launch of its own scans the marks (k_build_active_j)"),
     "IMS_ROUND_TWO_SEGMENTS": ("0", "pixel search of a round with two 256-photon segments per workgroup (both pool records requested up front)"),
     # -- engine --
+    "IMS_POOL_DELTA_ONLY": ("1", "photon pooling: a batch's deposits go to the delta-charge image only and the image takes them at the recalculation "
+                                 "(one atomic add per photon; Silicon's target += delta); 0 = image and delta image both"),
     "IMS_SCREEN_PREPASS": ("0", "phase-screen gathers ahead of the shooting kernels (1: every photon, 2: ordinary objects on a side stream)"),
     "IMS_SCREEN_BUCKETS": ("128", "arrival-time buckets of the pre-pass"),
     "IMS_SCREEN_QUADS": (None, "phase screens also as 2 x 2 cells of 16 bytes (default 1 unless the pre-pass covers every photon)"),

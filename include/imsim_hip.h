@@ -48,7 +48,7 @@ extern "C" {
 #define IMS_ERR_NO_DEVICE  -3
 #define IMS_ERR_UNSUPPORTED -4
 
-#define IMS_ABI_VERSION 19
+#define IMS_ABI_VERSION 20
 
 /* Pointers stored INSIDE descriptors that live in device memory (ims_sensor_t, ims_atmosphere_t) always point to global
  * device memory.  Device code is told so (address space 1): a pointer read out of memory is otherwise a generic pointer and
@@ -367,7 +367,9 @@ typedef struct ims_render_params {
     int32_t  n_psf;
     ims_psf_component_t psf[IMS_MAX_PSF];
     int32_t  n_ops;
-    int32_t  track_static_delta;     /* 1 in photon-pooling mode: charge landing in slot 0 (whole CCD) is kept for the next recalc */
+    int32_t  track_static_delta;     /* 1 in photon-pooling mode: charge landing in slot 0 (whole CCD) is kept for the next recalc;
+                                      * 2: ... and kept THERE ONLY -- the image takes it from the delta image at the recalculation
+                                      * (ims_sensor_update_distortions_fold / ims_sensor_fold_delta) */
     ims_op_t ops[IMS_MAX_OPS];
     ims_radial_tables_t radial;
     ims_lin_tables_t    sed;         /* wavelength inverse CDFs */
@@ -500,6 +502,18 @@ int  ims_sensor_init_boundaries(const ims_sensor_t* sensor_dev, const ims_sensor
 int  ims_sensor_update_distortions(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host,
                                    int32_t first_slot, int32_t n_slots, const int64_t* tile_prefix_dev,
                                    int64_t n_tiles, unsigned char* changed_dev, uint32_t tag, void* stream);
+/* The same recalculation of slot 0 where slot 0 is the pixel grid of the CCD image (photon pooling), with Silicon's `target += delta`:
+ * GalSim's SiliconSensor accumulates a batch into its delta image and adds the delta to the target when updatePixelDistortions
+ * consumes it (the recalc of imsim/photon_pooling.py:159,195-225).  Launches whose
+ * ims_render_params_t.track_static_delta is 2 deposit into the delta image ONLY -- one atomic add per photon instead of two -- and
+ * this entry point adds every consumed delta cell to image_dev[j * nx + i] before it zeroes it.  Exact for integer charge (unit
+ * photon fluxes), whatever the order.  ims_sensor_fold_delta does the adding alone (no recalculation): after the LAST batch, and
+ * wherever the image is wanted in between. */
+int  ims_sensor_update_distortions_fold(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host, const int64_t* tile_prefix_dev,
+                                        int64_t n_tiles, unsigned char* changed_dev, uint32_t tag, double* image_dev, int32_t nx, int32_t ny,
+                                        void* stream);
+int  ims_sensor_fold_delta(const ims_sensor_t* sensor_dev, const ims_sensor_t* sensor_host, int32_t slot, double* image_dev, int32_t nx,
+                           int32_t ny, void* stream);
 
 /* ---- FFT branch: LSST_SiliconBuilder.draw, method == 'fft' (imsim/stamp.py:482-525) ----
  * For very bright objects (nominal_flux >= 1e6 and max_sb > fft_sb_thresh, imsim/stamp.py:275-277,

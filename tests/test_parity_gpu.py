@@ -1180,6 +1180,50 @@ def test_photon_pooling_build_image_is_bit_exact(torch_cuda):
     assert_bits_equal(r2.image_numpy(), orc.image, "replayed pooling image")
 
 
+def test_pooling_deposits_into_the_delta_image_only_give_the_same_image(torch_cuda, monkeypatch):
+    """IMS_POOL_DELTA_ONLY (round 6): a batch's photons add to the delta-charge image of slot 0 alone (track_static_delta 2) and the
+    image takes the charge when the next recalculation consumes it -- Silicon's `target += delta` -- the last batch's by
+    Renderer.fold_delta().  Image, realized fluxes and pixel boundaries of the two-atomics form and of the oracle, bit for bit;
+    from a host table and from a device table; replayed.  With a checkpoint hook (which reads the image between the batches) the
+    form is not taken."""
+    from helpers import c3_small_case
+    from imsim_amd import photon_pooling, stamp
+    from imsim_amd.engine import Renderer
+    from oracle import orc_loader
+    scene, objects = c3_small_case(n_obj=90, n=192, flux_seed=6, scratch=0)
+    scene.track_static_delta = 1
+    modes = stamp.classify(objects["n_phot"].astype(float), 100.0)
+    orc = orc_loader.OracleScene(scene)
+    photon_pooling.build_image(orc, objects, modes, nbatch=5, nsubbatch=4, seed=21)
+    out = []
+    for delta_only in ("1", "0"):
+        monkeypatch.setenv("IMS_POOL_DELTA_ONLY", delta_only)
+        r = Renderer(scene)
+        real = torch_cuda.zeros(len(objects), dtype=torch_cuda.float64, device="cuda")
+        run = photon_pooling.prepared_image(r, objects, modes, nbatch=5, seed=21, realized=real)
+        for _ in range(2):
+            r.image.zero_()
+            real.zero_()
+            run()
+            r.synchronize()
+        pending = float(r.delta_tensor(0).abs().sum().item())
+        assert (pending == 0.0) == (delta_only == "1")          # folded into the image at the end / the last batch's charge as GalSim leaves it
+        out.append((r.image_numpy(), real.cpu().numpy(), _sensor_arrays_gpu(r)["boundary"]))
+    assert_bits_equal(out[0][0], out[1][0], "image: deposits into the delta image only vs into both")
+    assert_bits_equal(out[0][1], out[1][1], "realized fluxes")
+    assert_bits_equal(out[0][2], out[1][2], "pixel boundaries")
+    assert_bits_equal(out[0][0], orc.image, "image vs oracle")
+    monkeypatch.setenv("IMS_POOL_DELTA_ONLY", "1")
+    seen = []
+    r = Renderer(scene)
+    run = photon_pooling.prepared_image(r, objects, modes, nbatch=5, seed=21, after_batch=lambda i: seen.append(float(r.image.sum().item())))
+    run()
+    r.synchronize()
+    assert len(seen) == 5 and all(b > a for a, b in zip(seen[:-1], seen[1:]))          # the image grows batch by batch: both atomics
+    assert seen[-1] == float(r.image.sum().item())
+    assert_bits_equal(r.image_numpy(), orc.image, "image with a checkpoint hook")
+
+
 def test_pool_shot_batch_by_batch_gives_the_one_launch_image(torch_cuda, monkeypatch):
     """IMS_POOL_OVERLAP=1 (Renderer._overlapped_pool): the objects whose share of a batch fills wavefronts are shot by share on a
     stream of their own, an event per batch, the others whole and first -- the same pool, so the image, the realized fluxes

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- objects/sec into one 4k x 4k LSST CCD (photon-shooting path), BASELINE.json's metric.
 
-  python bench.py --gpus N --steps K --warmup W [--config c2|c3|c3b|c4|c5|fft] [--no-cpu-baseline] [--no-extra-configs]
+  python bench.py --gpus N --steps K --warmup W [--config c2|c3|c3b|c4|c5|fft|fftx|fftxs] [--no-cpu-baseline] [--no-extra-configs]
 
 One step = one pass of the hot path over the whole synthetic instance catalog with
 the object table already resident in HBM.  For N > 1 there is one rank per GPU: either started by
@@ -28,6 +28,9 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 # f64 vector issue peak: 256 CUs x 4 SIMDs x 16 lanes per cycle x 2.4 GHz (an f64 wave64 instruction issues over 4 cycles)
 F64_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9
+# SIMD time of one wavefront instruction by class [ns], tools/dbg/instr_rate.hip on MI355X (EXPERIMENTS.md, round 2): the weights of
+# roofline.step.floor_ms_class_weighted.  Keys = the SQ_INSTS_VALU_* counters of the class pass.
+CLASS_NS = {"fma_f64": 2.43, "mul_f64": 2.19, "add_f64": 1.98, "trans_f64": 6.8, "int64": 1.8, "cvt": 1.8, "int32": 1.45, "other": 1.4}
 
 
 def parse():
@@ -105,11 +108,13 @@ def spawn_ranks(args):
 # reproduce (the child's cpu_baseline.parity) -- started BEFORE this process touches the GPU, one after the other.
 # (name, objects of the one-core oracle sample, environment, timed steps, warm-up steps: the sub-millisecond configs take more steps,
 # and the FFT branch three warm-ups -- a (size, batch) pair that comes again gets its batched hipFFT plan, milliseconds the second time)
-EXTRA_CONFIGS = (("c2", 2000, {}, 10, 2), ("c3b", 1500, {}, 2, 1), ("c4", 1500, {}, 2, 1), ("c5", 1200, {"IMS_C5_CCDS": "32"}, 2, 1),
-                 ("fft", 0, {}, 10, 3))
+# (C5 is the WHOLE visit of 189 CCDs -- rounds 4 and 5 ran its first 32 here; `fftx` is the FFT branch at throughput: 5 000 stars on
+# 1024^2 .. 4096^2 grids with the spike stencil)
+EXTRA_CONFIGS = (("c2", 2000, {}, 10, 2), ("c3b", 1500, {}, 2, 1), ("c4", 1500, {}, 2, 1), ("c5", 1200, {}, 2, 1),
+                 ("fft", 0, {}, 10, 3), ("fftx", 2, {}, 2, 1), ("fftxs", 2, {}, 1, 1))
 
 
-def extra_configs(budget_s=150.0):
+def extra_configs(budget_s=420.0):
     out = {}
     t_start = time.perf_counter()
     for name, sample, env_add, n_steps, n_warm in EXTRA_CONFIGS:
@@ -140,6 +145,18 @@ def extra_configs(budget_s=150.0):
                  "cpu_oracle_objects_per_s": (line.get("cpu_baseline") or {}).get("value"),
                  "workload": line["config"]["workload"], "n_objects": line["config"]["n_objects"],
                  "wall_s": time.perf_counter() - t0}
+        # the child's own roofline figures: the whole step against its VALU issue floors (flat and class-weighted), the dominant
+        # kernel against HBM, the FFT branch's bytes against HBM
+        rf = line.get("roofline") or {}
+        if rf.get("step"):
+            entry["roofline_step"] = {k: rf["step"].get(k) for k in ("valu_wave_insts", "floor_ms", "frac", "floor_ms_class_weighted",
+                                                                     "frac_class_weighted", "sustained_clock_ghz", "source")}
+        entry["dominant_kernel"] = {"kernel": rf.get("kernel"), "hbm_frac": rf.get("frac"), "achieved_GBps": rf.get("achieved"),
+                                    "traffic_bytes_per_launch": rf.get("traffic")}
+        if rf.get("branch"):
+            entry["branch"] = rf["branch"]
+        if rf.get("phases"):
+            entry["phases"] = rf["phases"]
         if "within_tolerance" in par:          # FFT-drawn stamps: library transforms agree to ~1e-11 of the peak (parity_mode close)
             entry["within_tolerance"] = par["within_tolerance"]
             entry["differing_pixels"] = par.get("differing_pixels")
@@ -381,7 +398,28 @@ def main():
         floor_ms = insts / (256 * 4 * 2.4e9 / 4.0) * 1e3
         roofline["step"] = {"valu_wave_insts": insts, "floor_ms": floor_ms,
                             "frac": floor_ms / ms_per_step, "ms_per_step": ms_per_step, "source": pstep.get("sq_source"),
-                            "note": "VALU issue floor of ALL kernels of one step / the measured step"}
+                            "note": "VALU issue floor of ALL kernels of one step / the measured step; floor_ms: every wave-instruction "
+                                    "4 cycles at 2.4 GHz on 1024 SIMDs; floor_ms_class_weighted: the step's instructions by class "
+                                    "(SQ_INSTS_VALU_* pass) x the SIMD time of one wavefront instruction of that class as measured by "
+                                    "tools/dbg/instr_rate.hip (f64 fma 2.43 / mul 2.19 / add 1.98 ns, f64 rcp-rsq-sqrt 6.8, 64-bit integer "
+                                    "and conversions 1.8, 32-bit integer 1.45, everything else 1.4); sustained_clock_ghz: "
+                                    "GRBM_GUI_ACTIVE / wall of the photon kernels in a counter pass of the same command"}
+        mix = pstep.get("class_mix_per_step") or (
+            {k: v * getattr(step, "n_ccds", 1) for k, v in pstep["class_mix_per_ccd"].items()} if pstep.get("class_mix_per_ccd") else None)
+        if mix:
+            known = sum(mix.get(k, 0.0) for k in CLASS_NS if k != "other")
+            other = max(insts - known, 0.0)
+            ns = sum(mix.get(k, 0.0) * CLASS_NS[k] for k in CLASS_NS if k != "other") + other * CLASS_NS["other"]
+            fw = ns / 1024.0 * 1e-6
+            roofline["step"].update(floor_ms_class_weighted=fw, frac_class_weighted=fw / ms_per_step,
+                                    class_mix={**{k: mix.get(k, 0.0) for k in CLASS_NS if k != "other"}, "other": other},
+                                    mix_source=pstep.get("mix_source"))
+        if pstep.get("sustained_clock_ghz"):
+            roofline["step"]["sustained_clock_ghz"] = pstep["sustained_clock_ghz"]
+            roofline["step"]["clock_source"] = pstep.get("clock_source")
+    phases = profile_entry(args.config, "_phases", world)
+    if phases:
+        roofline["phases"] = phases
     # The other large kernel of a step with brighter-fatter chains is the pixel search of the rounds (k_accumulate_round): its
     # launches are timed the same way in a few extra steps, and the line names as `roofline.kernel` whichever of the two has
     # the larger summed launch time per step -- the kernel that is dominant in the shipped kernel trace.
@@ -503,9 +541,17 @@ def _cpu_step(cfg):
 
     def fft_step(orc_scene, sample):
         from oracle import orc_loader
-        o = orc_loader.OracleFft(orc_scene.scene, cfg["fft_kpsf"](), add_noise=True)
+        kw = {}
+        if cfg.get("fft_spikes"):
+            from imsim_amd import configs
+            v = configs.c5_visit_fft()
+            kw = dict(diffraction_fft=v["diffraction_fft"], wavelength=v["wavelength"])
+        o = orc_loader.OracleFft(orc_scene.scene, cfg["fft_kpsf"](), add_noise=True, **kw)
         rows = cfg["fft_rows"](sample)
-        o.finish(rows, o.inverse(rows, o.fill(rows)))
+        rbuf = o.inverse(rows, o.fill(rows))
+        if cfg.get("fft_spikes"):
+            rbuf = o.spikes(rows, rbuf)
+        o.finish(rows, rbuf)
         orc_scene.image64 += o.image
     return fft_step
 
@@ -545,7 +591,11 @@ def cpu_legs(cfg, scene, objects, args, fork_ok=True):
                  f"up to 2048^2, as one job") +
                 f": {len(sample)} objects, {sample.job.n_fft} of them FFT-drawn, {n_phot_sample} photons shot")
     else:
-        idx = np.sort(rng.choice(len(objects), size=min(n_sample, len(objects)), replace=False))
+        pool = np.arange(len(objects))
+        if cfg.get("fft_spikes"):
+            # (the checker's spike stencil on a 4096^2 grid takes minutes on one core: the sample is drawn from the stars whose stamps fit 2048^2)
+            pool = np.flatnonzero((objects["stamp_xmax"] - objects["stamp_xmin"] + 1) <= 2048)
+        idx = np.sort(rng.choice(pool, size=min(n_sample, len(pool)), replace=False))
         sample = objects[idx]
         n_phot_sample = int(sample["n_phot"].sum())
         what = f"{len(sample)} objects drawn at random from the same catalog ({n_phot_sample} photons"
@@ -579,7 +629,17 @@ def cpu_legs(cfg, scene, objects, args, fork_ok=True):
                                       f"{nproc} forked workers with private images, {dt_all:.1f} s wall "
                                       f"(slowest worker {max(d[3] for d in done):.1f} s)",
                             "electrons": sum(d[2] for d in done),
-                            "photon_imbalance_max_over_mean": float(per_worker.max() / max(per_worker.mean(), 1.0))}
+                            "photon_imbalance_max_over_mean": float(per_worker.max() / max(per_worker.mean(), 1.0)),
+                            # (dealt longest-first by photon count: what is left of the imbalance is ONE object -- an object's
+                            # brighter-fatter rounds are a serial chain that no worker can share)
+                            "largest_object_photons": int(objects["n_phot"].max()),
+                            "mean_photons_per_worker": float(per_worker.mean()),
+                            "imbalance_without_the_largest_objects": float(
+                                np.sort(per_worker)[-min(4, nproc):][0] / max(per_worker.mean(), 1.0)) if nproc > 4 else None,
+                            "slowest_worker_s": max(d[3] for d in done), "wall_s": dt_all,
+                            # what the same cores sustain once the work balances (a visit deals 189 CCDs' worth of objects):
+                            # objects / mean worker time -- the figure to hold against the GPU's, not the wall of ONE CCD
+                            "value_if_balanced": n_done / (sum(d[3] for d in done) / nproc)}
     return res
 
 

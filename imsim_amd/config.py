@@ -670,9 +670,14 @@ def Process(config, template_dirs=(), overrides=None, device="cuda:0", data_dir=
             # FFT image; the path draws FFT stamps without a photon stage, as the reference does whenever the list is empty
             # (its default: config/imsim-config.yaml has no fft_photon_ops)
             build_photon_ops(fft_photon_ops, ev, wl_eff)                 # parsed and validated like stamp.photon_ops
-            note = "stamp.fft_photon_ops (parsed; FFT-drawn stamps are not re-shot through photon ops on this path)"
-            if note not in res.ignored:
-                res.ignored.append(note)
+            if str(ev.value(stamp_cfg.get("draw_method", "auto"))) != "phot":
+                # an object CAN take the FFT branch, and the reference would then turn its FFT image into photons, run these
+                # operators over them and accumulate them again (GalSim's drawImage(method='fft', photon_ops=...)): that stage is not
+                # built here, and a render that silently left it out would not be the reference's image (no
+                # parsed-but-ignored key on the path)
+                raise GalSimConfigError("stamp.fft_photon_ops is not supported: FFT-drawn stamps are not re-shot through photon operators "
+                                        "on this path (imsim/stamp.py:493-499).  Remove the key (as config/imsim-config.yaml does) or force "
+                                        "stamp.draw_method: phot")
         ctx = types.SimpleNamespace(det=det, det_name=det_name, scene=scene, builder=builder, truth=truth, seed_ccd=seed_ccd,
                                     nx=nx, ny=ny, job=None, pooling=None)
         if itype == "LSST_PhotonPoolingImage":

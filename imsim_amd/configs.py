@@ -535,6 +535,80 @@ BENCH_CONFIGS["fft"] = dict(
 )
 
 
+# FFT branch at THROUGHPUT: the objects imSim actually sends down it -- stars above fft_sb_thresh (>= 1.1e7 electrons here: the
+# FFT-drawn part of the C5 visit's bright tail, log-uniform up to 1e8), drawn with the spike stencil (stamp.py:482-525) on the
+# 1024^2 / 2048^2 / 4096^2 grids their stamps need, thousands of them, in chunks that share one set of buffers.  The 100-object
+# `fft` config above is a launch-latency measurement (0.3 ms per step); this one moves ~1 TB per step.
+def _fftx_catalog(n_objects, scene):
+    cat = catalog.synthetic_catalog(n_objects, seed=20261001 + 7, nx=scene.nx, ny=scene.ny)
+    rng = np.random.default_rng([20261001, 0xFF7])
+    flux = 10.0 ** rng.uniform(math.log10(1.2e7), 8.0, n_objects)
+    cat["nominal_flux"][:] = flux
+    cat["mag"][:] = 28.13 - 2.5 * np.log10(flux / 30.0)
+    cat["kind"][:] = 0
+    wl, thr = tables.synthetic_r_band()
+    cat["sb_flux"][:] = flux / float(np.trapezoid(thr, wl))
+    return cat
+
+
+def _fftx_objects(cat, phot, scene):
+    return c3_objects(cat, np.maximum(phot, 1), scene)
+
+
+def _fftx_rows(objects):
+    from . import fft_draw
+    rows, _ = fft_draw.build_fft_objects(objects, objects["n_phot"].astype(np.float64), fft_draw.profile_ktable_ids(None, objects["prof_table"]))
+    return rows
+
+
+def _fftx_step(renderer, objects, rank=0, world=1, spikes=False):
+    from . import fft_draw
+    mine = objects[rank::world] if world > 1 else objects
+    v = c5_visit_fft()
+    kw = dict(diffraction_fft=v["diffraction_fft"], wavelength=v["wavelength"]) if spikes else {}
+    drawer = fft_draw.FftDrawer(renderer, v["kpsf"], add_noise=True, **kw)
+    launch = drawer.prepared_chunked(_fftx_rows(mine))
+    launch.photons = 0
+    launch.object_rows = len(mine)
+    launch.timed = {3: (launch.chunks, 16 * launch.kspace_elements), 1: (0, 0), 2: (0, 0)}
+    launch.branch_bytes = 24 * launch.pixels
+    grids = {int(k): int(n) for k, n in zip(*np.unique(_fftx_rows(mine)["nfft"], return_counts=True))}
+    launch.workload_note = f"FFT grid: count {grids}, {launch.chunks} chunks of at most 2^30 grid points sharing one set of buffers"
+    launch.keep2 = drawer
+    return launch
+
+
+BENCH_CONFIGS["fftx"] = dict(
+    n_objects=5000,
+    metric="objects/sec into one 4k x 4k LSST CCD (FFT branch, throughput)",
+    catalog=_fftx_catalog,
+    workload="FFT branch at throughput: 5 000 stars of 1.2e7 .. 1e8 electrons (what crosses fft_sb_thresh in the C5 visit), draw_method "
+             "fft (k-space delta x Kolmogorov x Gaussian x pixel, inverse real 2-D FFT on the 1024^2 / 2048^2 / 4096^2 grids their stamps "
+             "need, clip, Poisson noise, stamp -> CCD: the steps SURVEY 8(d)'s 24 N^2 B per object count), no sensor, 4096x4096 CCD",
+    scene=lambda: scene_c3(sensor=False),
+    objects=_fftx_objects,
+    make_step=_fftx_step,
+    timed_kernel=3,
+    kernel="k_fft_kspace_fill",
+    cpu_sample=2,
+    cpu_scene=lambda scene: scene,
+    cpu_step=None,
+    fft_rows=_fftx_rows,
+    fft_kpsf=lambda: c5_visit_fft()["kpsf"],
+    cpu_allcore=False,
+    parity_mode="close",
+)
+# ... and with stamp.diffraction_fft on, as the C5 visit draws them (DiffractionFFT.apply between the clip and the noise,
+# stamp.py:519-522): the spike stencil of a saturated star is arithmetic, not bytes -- 60 % of this variant's step
+BENCH_CONFIGS["fftxs"] = dict(BENCH_CONFIGS["fftx"])
+BENCH_CONFIGS["fftxs"].update(
+    metric="objects/sec into one 4k x 4k LSST CCD (FFT branch with the diffraction-spike stencil, throughput)",
+    workload=BENCH_CONFIGS["fftx"]["workload"].replace("clip, Poisson noise", "clip, diffraction-spike stencil (stamp.diffraction_fft), Poisson noise"),
+    make_step=lambda renderer, objects, rank=0, world=1: _fftx_step(renderer, objects, rank, world, spikes=True),
+    fft_spikes=True,
+)
+
+
 # ---------------------------------------------------------------------------------------------
 # C5: a whole focal plane -- 189 CCDs x 10 k sources, every CCD an independent LSST_Image build on its own stream
 # ---------------------------------------------------------------------------------------------

@@ -2149,17 +2149,41 @@ __device__ __forceinline__ int64_t find_prefix(const int64_t* __restrict__ prefi
     return lo;
 }
 
+// Which object element e of the back-to-back buffers belongs to: ONE bisection per wavefront (lane 0's element, its operands made
+// scalar so that the loads are scalar loads), which the other lanes only confirm -- a wavefront's 64 consecutive elements lie in one
+// object except where two meet (real-space grids are multiples of 1 024 pixels: never; half spectra: rarely), and only there does a
+// lane bisect for itself.  (Every element used to run its own 7 .. 13 dependent loads: the elementwise kernels of the branch
+// moved ~1 TB/s, round 6.)  prefix has n + 1 entries.
+__device__ __forceinline__ int64_t find_prefix_wave(const int64_t* __restrict__ prefix, int64_t n, int64_t e)
+{
+    const uint32_t lo32 = __builtin_amdgcn_readfirstlane((uint32_t)e), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(e >> 32));
+    const int64_t e0 = (int64_t)(((uint64_t)hi32 << 32) | lo32);
+    int64_t oi = find_prefix(prefix, n, e0);
+    if (e >= prefix[oi + 1]) oi = find_prefix(prefix, n, e);
+    return oi;
+}
+
+// row and column of element `local` of a grid of row length `len` (FFT sizes are powers of two: a shift; half spectra -- len =
+// nfft / 2 + 1 -- and anything else: a 32-bit division, the grids hold fewer than 2^31 elements)
+__device__ __forceinline__ void row_col(int64_t local, int len, int& row, int& col)
+{
+    const uint32_t l = (uint32_t)local, n = (uint32_t)len;
+    if ((n & (n - 1u)) == 0u) { const int sh = 31 - __clz((int)n); row = (int)(l >> sh); col = (int)(l & (n - 1u)); }
+    else { row = (int)(l / n); col = (int)(l - (uint32_t)row * n); }
+}
+
 __global__ __launch_bounds__(256) void k_fft_kspace_fill(const ims_fft_params_t P, const ims_fft_object_t* __restrict__ objs,
                                                          int64_t n_objects, const int64_t* __restrict__ prefix, int64_t n_elems,
                                                          double* __restrict__ kbuf)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_elems; e += stride) {
-        const int64_t oi = find_prefix(prefix, n_objects, e);
+        const int64_t oi = find_prefix_wave(prefix, n_objects, e);
         const ims_fft_object_t& o = objs[oi];
         const int64_t local = e - prefix[oi];
         const int nh = o.nfft / 2 + 1;
-        const int i = (int)(local / nh), j = (int)(local % nh);
+        int i, j;
+        row_col(local, nh, i, j);
         double re, im;
         kspace_value(P, o, i, j, re, im);
         kbuf[2 * (o.k_offset + local)] = re;
@@ -2174,10 +2198,11 @@ __global__ __launch_bounds__(256) void k_fft_bbox(const ims_fft_params_t P, cons
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_pix; e += stride) {
-        const int64_t oi = find_prefix(prefix, n_objects, e);
+        const int64_t oi = find_prefix_wave(prefix, n_objects, e);
         const ims_fft_object_t& o = objs[oi];
         const int64_t local = e - prefix[oi];
-        const int iy = (int)(local / o.nfft), ix = (int)(local % o.nfft);
+        int iy, ix;
+        row_col(local, o.nfft, iy, ix);
         const int px = o.x0 + ix, py = o.y0 + iy;
         if (px < o.stamp_xmin || px > o.stamp_xmax || py < o.stamp_ymin || py > o.stamp_ymax) continue;
         if (rbuf[o.r_offset + local] > P.spikes.threshold) {
@@ -2195,10 +2220,11 @@ __global__ __launch_bounds__(256) void k_fft_spikes(const ims_fft_params_t P, co
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_pix; e += stride) {
-        const int64_t oi = find_prefix(prefix, n_objects, e);
+        const int64_t oi = find_prefix_wave(prefix, n_objects, e);
         const ims_fft_object_t& o = objs[oi];
         const int64_t local = e - prefix[oi];
-        const int iy = (int)(local / o.nfft), ix = (int)(local % o.nfft);
+        int iy, ix;
+        row_col(local, o.nfft, iy, ix);
         double v = rin[o.r_offset + local];
         if (v < 0.0) v = 0.0;
         const int px = o.x0 + ix, py = o.y0 + iy;
@@ -2279,10 +2305,11 @@ __global__ __launch_bounds__(256) void k_fft_finish(const ims_fft_params_t P, co
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_pix; e += stride) {
-        const int64_t oi = find_prefix(prefix, n_objects, e);
+        const int64_t oi = find_prefix_wave(prefix, n_objects, e);
         const ims_fft_object_t& o = objs[oi];
         const int64_t local = e - prefix[oi];
-        const int iy = (int)(local / o.nfft), ix = (int)(local % o.nfft);
+        int iy, ix;
+        row_col(local, o.nfft, iy, ix);
         const int px = o.x0 + ix, py = o.y0 + iy;
         if (px < o.stamp_xmin || px > o.stamp_xmax || py < o.stamp_ymin || py > o.stamp_ymax) continue;
         double v = rbuf[o.r_offset + local];
@@ -3001,13 +3028,19 @@ int ims_shoot_accumulate(const ims_render_params_t* params_in, void* stream)
             MarginBuf& m = g_margin[std::make_pair(dev, stream)];
             const int64_t waves = params_in->n_segments * 4;
             if (m.cap < (uint32_t)want || m.waves_cap < waves) {
-                if (m.list) { HIP_TRY(hipFree(m.list)); HIP_TRY(hipFree(m.wave_count)); }
+                // grown into temporaries and committed only when every allocation has succeeded: an entry left with freed
+                // pointers and the new capacities would pass this very check on the next call
                 if (!m.count) HIP_TRY(hipMalloc((void**)&m.count, 2 * sizeof(int32_t)));
-                m.cap = (uint32_t)(want + want / 4 + 65536);
-                m.waves_cap = waves + waves / 4 + 1024;
+                const uint32_t cap = (uint32_t)(want + want / 4 + 65536);
+                const int64_t waves_cap = waves + waves / 4 + 1024;
+                double* list = nullptr;
+                unsigned char* wave_count = nullptr;
                 // an octet of records per wavefront, then an overflow region that could take every photon of the launch
-                HIP_TRY(hipMalloc((void**)&m.list, ((size_t)m.waves_cap * 8 + (size_t)m.cap) * 5 * sizeof(double)));
-                HIP_TRY(hipMalloc((void**)&m.wave_count, (size_t)m.waves_cap));
+                HIP_TRY(hipMalloc((void**)&list, ((size_t)waves_cap * 8 + (size_t)cap) * 5 * sizeof(double)));
+                const hipError_t e2 = hipMalloc((void**)&wave_count, (size_t)waves_cap);
+                if (e2 != hipSuccess) { (void)hipFree(list); return hip_err(e2, "hipMalloc(margin wave counts)"); }
+                if (m.list) { (void)hipFree(m.list); (void)hipFree(m.wave_count); }
+                m.list = list; m.wave_count = wave_count; m.cap = cap; m.waves_cap = waves_cap;
             }
             mb = m;
         }

@@ -242,6 +242,9 @@ def fft_params(scene, kpsf, ktables, q_step, seed, add_noise=True, mem_put=None)
 
 
 _WARM = {}
+_WARM_ATEXIT = []
+import threading as _threading
+_WARM_LOCK = _threading.Lock()
 
 
 def warm_up(device, stream, sizes=(1024, 2048, 4096, 512)):
@@ -257,22 +260,38 @@ def warm_up(device, stream, sizes=(1024, 2048, 4096, 512)):
         return _WARM[key]
     lib = _abi.load()
 
+    codes = {}
+
     def one(n):
         torch.cuda.set_device(device)
-        lib.ims_fft_warm(int(n), C.c_void_p(stream.cuda_stream))
+        rc = lib.ims_fft_warm(int(n), C.c_void_p(stream.cuda_stream))
+        codes[int(n)] = (rc, lib.ims_last_error().decode() if rc else "")          # (ims_last_error is thread-local: read here)
 
     class _All:
-        """the threads of one warm-up (a size each: the run-time compilations run side by side)"""
+        """the threads of one warm-up (a size each: the run-time compilations run side by side).  join() raises when a plan
+        could not be made (no libhipfft, a failed plan): the first draw would otherwise find out inside a timed step."""
         def __init__(self, threads):
             self.threads = threads
+            self.codes = codes
 
         def join(self):
             for t in self.threads:
                 t.join()
-    threads = [threading.Thread(target=one, args=(n,), name=f"ims-fft-warm-{n}", daemon=True) for n in sizes]
-    for t in threads:
-        t.start()
-    _WARM[key] = _All(threads)
+            bad = {n: c for n, c in codes.items() if c[0] != 0}
+            if bad:
+                raise RuntimeError("hipFFT warm-up failed: " + "; ".join(f"size {n}: {c[1]} ({c[0]})" for n, c in sorted(bad.items())))
+    with _WARM_LOCK:
+        if key in _WARM:
+            return _WARM[key]
+        threads = [threading.Thread(target=one, args=(n,), name=f"ims-fft-warm-{n}", daemon=True) for n in sizes]
+        for t in threads:
+            t.start()
+        _WARM[key] = _All(threads)
+        if not _WARM_ATEXIT:
+            # (daemon threads inside hipfftPlanMany's run-time compilation when the interpreter exits: wait for them first)
+            import atexit
+            atexit.register(lambda: [t.join(timeout=30.0) for w in list(_WARM.values()) for t in w.threads])
+            _WARM_ATEXIT.append(True)
     return _WARM[key]
 
 
@@ -314,6 +333,54 @@ class FftDrawer:
         launch.objects = len(nfft)
         launch.pixels = int(np.sum(nfft * nfft))
         launch.kspace_elements = int(np.sum(nfft * (nfft // 2 + 1)))
+        return launch
+
+    def prepared_chunked(self, fft_objects, max_pixels=1 << 30):
+        """`prepared` for a table whose buffers do not fit at once (thousands of bright stars on 1024^2 .. 4096^2 grids: 24 B per grid
+        point): the rows -- grouped by FFT size, as build_fft_objects leaves them -- are cut into consecutive chunks of at most
+        max_pixels grid points that share ONE set of k-space / real-space / spike buffers and are drawn one after the other on the
+        current stream.  Same launches per chunk as `prepared`; returns a zero-argument callable."""
+        torch, r = self.torch, self.r
+        rows = np.ascontiguousarray(fft_objects, dtype=FFT_OBJECT_DTYPE)
+        nfft = rows["nfft"].astype(np.int64)
+        px = nfft * nfft
+        cuts, acc = [0], 0
+        for k in range(len(rows)):
+            if acc and acc + px[k] > max_pixels:
+                cuts.append(k)
+                acc = 0
+            acc += int(px[k])
+        cuts.append(len(rows))
+        spans = [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+        k_need = max(int(np.sum(nfft[a:b] * (nfft[a:b] // 2 + 1))) for a, b in spans)
+        r_need = max(int(px[a:b].sum()) for a, b in spans)
+        n_need = max(b - a for a, b in spans)
+        kbuf = torch.empty(k_need, dtype=torch.complex128, device=r.device)
+        rbuf = torch.empty(r_need, dtype=torch.float64, device=r.device)
+        spike = (torch.empty(r_need, dtype=torch.float64, device=r.device), torch.empty(4 * n_need, dtype=torch.int32, device=r.device)) \
+            if self.P.spikes.enabled else None
+        from .engine import upload_async
+        states = []
+        for a, b in spans:
+            part = rows[a:b].copy()
+            nf = nfft[a:b]
+            kpre = np.concatenate([[0], np.cumsum(nf * (nf // 2 + 1))]).astype(np.int64)
+            rpre = np.concatenate([[0], np.cumsum(nf * nf)]).astype(np.int64)
+            part["k_offset"], part["r_offset"] = kpre[:-1], rpre[:-1]
+            obj_t = upload_async(torch, r.device, part.view(np.uint8).reshape(-1))
+            states.append((part, obj_t, nf, kpre, rpre, upload_async(torch, r.device, kpre), upload_async(torch, r.device, rpre),
+                           kbuf[:int(kpre[-1])], rbuf[:int(rpre[-1])]))
+
+        def launch():
+            for st in states:
+                if spike is not None:
+                    self._spike_bufs = (spike[0][:int(st[4][-1])], spike[1][:4 * len(st[0])])
+                self._run(st, None)
+        launch.objects = len(rows)
+        launch.chunks = len(states)
+        launch.pixels = int(px.sum())
+        launch.kspace_elements = int(np.sum(nfft * (nfft // 2 + 1)))
+        launch.keep = (states, kbuf, rbuf, spike)
         return launch
 
     def _upload(self, fft_objects):

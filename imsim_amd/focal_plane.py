@@ -144,13 +144,14 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
         t_base.record(bulk)
         h_base = time.perf_counter()
 
-    def front(key):
+    def front(key, own_state=False):
         """everything of one CCD up to its deferred rounds; None when the arena cannot lease its private cells now (the CCD
-        stays prebuilt for the retry)"""
+        stays prebuilt for the retry).  own_state: the CCD's pixel-boundary state is not leased from the arena but its own (a CCD
+        whose bright stamps need more private cells than the whole pool, with nothing alive to give any back: ADVICE r5)."""
         scene, work = prebuilt.pop(key) if key in prebuilt else build(key)
         lease = None
         ss = getattr(scene, "sensor", None)
-        if (arena is not None and ss is not None and not wants_static_late(work) and not scene.track_static_delta
+        if (arena is not None and not own_state and ss is not None and not wants_static_late(work) and not scene.track_static_delta
                 and (not lazy_static or lazy_static_applies(scene))          # (the lazy arena has ONE static region nobody may write)
                 and ss.slots is not None and len(ss.slots) == 1 and ss.total_cells() == arena.static_cells
                 and ss.owned_points() == arena.npo):
@@ -333,7 +334,9 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
                     continue
                 if cur:
                     break
-                raise RuntimeError("focal plane: the sensor arena cannot hold the private regions of one CCD")
+                # nothing alive, nothing in this batch, and the pool still cannot hold this CCD's private regions: it is sized from
+                # the FIRST CCD, and memory pressure may have cut the batch -- the CCD renders with a state of its own
+                e = front(pending[0], own_state=True)
             pending.pop(0)
             cur.append(e)
         start_rounds(cur)

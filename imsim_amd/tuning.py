@@ -138,6 +138,10 @@ class scoped:
                 _SCOPED.pop(k, None)
             else:
                 _SCOPED[k] = v
+        # the library's process-wide block follows at once (not at the next renderer construction or plan run: a renderer built
+        # before the block and used after it would otherwise launch with the scope's settings)
+        if _LIB[0] is not None:
+            sync_library(_LIB[0])
         return False
 
 
@@ -173,11 +177,28 @@ def fft_kernel_cache(seed=None):
         return have
     roots = [os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"),
              os.path.join(tempfile.gettempdir(), f"imsim_amd_{os.getuid()}")]
-    for root in roots:
+    try:
+        os.makedirs(roots[1], mode=0o700, exist_ok=True)
+    except OSError:
+        pass
+    for k, root in enumerate(roots):
         d = os.path.join(root, "imsim_amd")
         try:
-            os.makedirs(d, exist_ok=True)
+            os.makedirs(d, mode=0o700, exist_ok=True)
+            if k > 0:
+                # the fall-back lives under the shared temporary directory at a predictable name: rocFFT LOADS code objects from
+                # this file, so the directory (and its parent) must be ours alone -- not a symlink, owned by this user, writable by
+                # nobody else; otherwise the variable stays unset
+                ok = True
+                for q in (root, d):
+                    st = os.lstat(q)
+                    import stat as _stat
+                    ok = ok and _stat.S_ISDIR(st.st_mode) and st.st_uid == os.getuid() and not (st.st_mode & 0o022)
+                if not ok:
+                    continue
             path = os.path.join(d, "rocfft_kernels.db")
+            if os.path.islink(path):
+                continue
             if not os.path.exists(path) and seed and os.path.exists(seed):
                 tmp = f"{path}.{os.getpid()}"
                 shutil.copyfile(seed, tmp)
@@ -222,11 +243,13 @@ def library_tuning():
 
 
 _LAST = [None]
+_LIB = [None]                    # the library sync_library was last called with (scoped.__exit__ re-synchronises it)
 
 
 def sync_library(lib):
     """Hand the library-side choices to libimsim_hip.so (ims_set_tuning) when they differ from what it was last given; called
     wherever the host is about to enqueue launches (renderer construction, plan runs, joint runs)."""
+    _LIB[0] = lib
     t = library_tuning()
     raw = bytes(t)
     if raw != _LAST[0]:

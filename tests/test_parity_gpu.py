@@ -892,6 +892,19 @@ def test_config_phot_full_chain_and_pooling_agree(torch_cuda):
     assert abs(sa / sb - 1) < 0.02
 
 
+def test_config_fft_photon_ops_are_refused_where_the_fft_branch_is_reachable(torch_cuda):
+    """stamp.fft_photon_ops (imsim/stamp.py:493-499): the reference re-shoots the FFT image through these operators; that stage is
+    not built here, so a config that can reach the FFT branch with the key set is an error -- not a render that silently leaves the
+    stage out (it used to be listed in res.ignored).  With draw_method: phot nothing is FFT-drawn and the key is moot."""
+    from imsim_amd.lsst_image import GalSimConfigError
+    ops = [{"type": "TimeSampler", "t0": 0.0, "exptime": 30.0}]
+    with pytest.raises(GalSimConfigError, match="fft_photon_ops"):
+        _process(**{"image.nobjects": 5, "stamp.fft_photon_ops": ops})
+    a = _process(**{"image.nobjects": 5, "stamp.draw_method": "phot", "stamp.fft_photon_ops": ops})
+    assert not any("fft_photon_ops" in note for note in a.ignored)
+    assert a.images[0].sum() > 0
+
+
 def test_config_several_ccds_take_the_overlapped_focal_plane_path(torch_cuda, monkeypatch, tmp_path):
     """`output.nfiles: 3` through config.Process: the CCDs are prepared on the host while the previous ones run
     (focal_plane.render_focal_plane, the fan-out of imsim/ccd.py:72-89), with FFT-drawn objects, sky noise and an e-image file

@@ -100,7 +100,7 @@ class FftObject(C.Structure):
 
 class Spikes(C.Structure):
     _fields_ = [("enabled", c_i32), ("cutoff", c_i32), ("threshold", c_d), ("cos0", c_d), ("sin0", c_d), ("a_lo", c_d),
-                ("d_alpha", c_d), ("scale", c_d), ("r0", c_d), ("norm", c_d)]
+                ("d_alpha", c_d), ("scale", c_d), ("r0", c_d), ("norm", c_d), ("tab_row", c_vp), ("tab_col", c_vp), ("tab_val", c_vp)]
 
 
 class FftParams(C.Structure):
@@ -253,7 +253,7 @@ STRUCTS = [Object, RadialTables, LinTables, PsfComponent, Op, Surface, TanSip, O
 EXPORTS = ["ims_abi_version", "ims_last_error", "ims_device_count", "ims_device_info", "ims_known_optics_layout",
            "ims_tuning_defaults", "ims_get_tuning", "ims_set_tuning", "ims_shoot_accumulate",
            "ims_shoot_photons", "ims_shoot_ops_photons", "ims_accumulate_segments", "ims_accumulate_small", "ims_accumulate_round", "ims_run_plan",
-           "ims_fft_kspace_fill", "ims_fft_finish", "ims_fft_spikes", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
+           "ims_fft_kspace_fill", "ims_fft_finish", "ims_fft_spikes", "ims_fft_spike_table", "ims_apply_ops", "ims_accumulate", "ims_sensor_init_boundaries",
            "ims_sensor_update_distortions", "ims_sensor_update_distortions_fold", "ims_sensor_fold_delta", "ims_image_add", "ims_image_to_float", "ims_fill_derived_op", "ims_fill_derived_medium", "ims_fill_derived_optics", "ims_fill_derived_atmosphere", "ims_fill_derived_sensor", "ims_sensor_pixel_areas", "ims_flat_add", "ims_last_kernel_ms", "ims_enable_timing",
            "ims_readout_bleed", "ims_readout_segments", "ims_readout_cte", "ims_readout_finish",
            "ims_build_object_table", "ims_patch_stamp_sizes", "ims_gather_rows", "ims_parse_instcat_objects", "ims_screen_prepass",
@@ -317,6 +317,7 @@ def load():
     lib.ims_fft_kspace_fill.argtypes = [C.POINTER(FftParams), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]
     lib.ims_fft_finish.argtypes = [C.POINTER(FftParams), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]
     lib.ims_fft_spikes.argtypes = [C.POINTER(FftParams), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]
+    lib.ims_fft_spike_table.argtypes = [C.POINTER(Spikes), c_vp, c_vp, c_vp, c_vp, c_vp]
     lib.ims_run_plan.argtypes = [C.POINTER(PlanItem), c_i64, c_vp, C.POINTER(Sensor), c_vp, C.POINTER(c_vp), c_i32]
     lib.ims_last_kernel_ms.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.ims_enable_timing.argtypes = [C.c_int]

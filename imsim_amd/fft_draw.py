@@ -184,7 +184,7 @@ def build_fft_objects(objects, fft_flux, prof_ktable, pixel_scale=0.2):
     return out, order
 
 
-def set_spikes(P, diffraction_fft, wavelength):
+def set_spikes(P, diffraction_fft, wavelength, renderer=None):
     """Fill the spikes block of an FftParams from a DiffractionFFT config (None = disabled)."""
     from . import diffraction_fft as dfft
     if diffraction_fft is None or not diffraction_fft.enabled:
@@ -194,7 +194,36 @@ def set_spikes(P, diffraction_fft, wavelength):
     S = P.spikes
     S.enabled, S.cutoff, S.threshold = 1, k.cutoff, float(diffraction_fft.brightness_threshold)
     S.cos0, S.sin0, S.a_lo, S.d_alpha, S.scale, S.r0, S.norm = k.cos0, k.sin0, k.a_lo, k.d_alpha, k.scale, dfft.SPIKE_R0, k.norm
+    S.tab_row = S.tab_col = S.tab_val = None
+    if renderer is not None and tuning.flag("IMS_SPIKE_TABLE"):
+        tab = spike_table(renderer, diffraction_fft, wavelength, S)
+        S.tab_row, S.tab_col, S.tab_val = tab[0].data_ptr(), tab[1].data_ptr(), tab[2].data_ptr()
     return k
+
+
+def spike_table(renderer, diffraction_fft, wavelength, S):
+    """ims_spikes_t.tab_*: the non-zero entries of the normalised spike stencil on the renderer's device, made once per (visit's
+    DiffractionFFT, wavelength, device) by two launches of ims_fft_spike_table and kept with the DiffractionFFT instance that every CCD
+    of a visit shares -- the reference makes the whole stencil array once per visit (imsim/stamp.py:36-68)."""
+    torch = renderer.torch
+    cache = diffraction_fft.__dict__.setdefault("_device_tables", {})
+    key = (str(renderer.device), float(wavelength), float(S.norm), int(S.cutoff))
+    if key not in cache:
+        lib = renderer.lib
+        rows = 2 * int(S.cutoff) + 1
+        with torch.cuda.device(renderer.device):
+            st = C.c_void_p(torch.cuda.current_stream(renderer.device).cuda_stream)
+            count = torch.zeros(rows, dtype=torch.int32, device=renderer.device)
+            _abi.check(lib.ims_fft_spike_table(C.byref(S), None, count.data_ptr(), None, None, st), "ims_fft_spike_table")
+            ptr = torch.zeros(rows + 1, dtype=torch.int32, device=renderer.device)
+            ptr[1:] = torch.cumsum(count, 0).to(torch.int32)
+            n = int(ptr[-1].item())
+            col = torch.empty(max(n, 1), dtype=torch.int32, device=renderer.device)
+            val = torch.empty(max(n, 1), dtype=torch.float64, device=renderer.device)
+            _abi.check(lib.ims_fft_spike_table(C.byref(S), ptr.data_ptr(), None, col.data_ptr(), val.data_ptr(), st), "ims_fft_spike_table")
+            torch.cuda.current_stream(renderer.device).synchronize()
+        cache[key] = (ptr, col, val, n)
+    return cache[key]
 
 
 def psf_mtf(kpsf, ktables, q_step, k):
@@ -313,7 +342,7 @@ class FftDrawer:
         self.P, self._keep = fft_params(renderer.scene, kpsf, np.stack([t[1] for t in tabs] + list(extra_ktables) + more), self.q_step,
                                         renderer.scene.seed, add_noise, lambda a: renderer.mem.put(a, np.float64))
         self.P.image = renderer.image.data_ptr()
-        set_spikes(self.P, diffraction_fft, wavelength)
+        set_spikes(self.P, diffraction_fft, wavelength, renderer)
 
     def draw(self, fft_objects, realized=None):
         """fft_objects: FFT_OBJECT_DTYPE rows sorted by nfft (build_fft_objects).  `realized`:

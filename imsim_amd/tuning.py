@@ -31,6 +31,8 @@ KNOWN = {
     # -- engine --
     "IMS_POOL_DELTA_ONLY": ("1", "photon pooling: a batch's deposits go to the delta-charge image only and the image takes them at the recalculation "
                                  "(one atomic add per photon; Silicon's target += delta); 0 = image and delta image both"),
+    "IMS_SPIKE_TABLE": ("1", "FFT branch: the non-zero entries of the spike stencil from a table made once per visit (ims_fft_spike_table); "
+                             "0 = every stencil value evaluated in place"),
     "IMS_SCREEN_PREPASS": ("0", "phase-screen gathers ahead of the shooting kernels (1: every photon, 2: ordinary objects on a side stream)"),
     "IMS_SCREEN_BUCKETS": ("128", "arrival-time buckets of the pre-pass"),
     "IMS_SCREEN_QUADS": (None, "phase screens also as 2 x 2 cells of 16 bytes (default 1 unless the pre-pass covers every photon)"),

@@ -561,6 +561,14 @@ typedef struct ims_spikes {
     double  scale;           /* 577.6 nm / wavelength */
     double  r0;              /* Lorentzian scale R_0 */
     double  norm;            /* sum of the stencil over (2 cutoff + 1)^2 offsets (host-computed) */
+    /* optional (NULL = every stencil value evaluated in place): the non-zero entries of the NORMALISED stencil, stencil(a, b) / norm, as
+     * a compressed table made once per visit by ims_fft_spike_table (the reference builds the whole (2 cutoff + 1)^2 array once per
+     * visit, prepare_psf_field_rotation, imsim/diffraction_fft.py:78-123: 512 MB of which ~1e5 entries are not zero).  Row a + cutoff
+     * holds the entries tab_row[a + cutoff] .. tab_row[a + cutoff + 1] - 1, column offsets b DESCENDING (= source columns ascending,
+     * the order of the sum). */
+    const int32_t* tab_row;  /* device, [2 cutoff + 2] */
+    const int32_t* tab_col;  /* device, b of every entry */
+    const double*  tab_val;  /* device, stencil(a, b) / norm of every entry */
 } ims_spikes_t;
 
 typedef struct ims_fft_params {
@@ -584,6 +592,12 @@ int  ims_fft_kspace_fill(const ims_fft_params_t* params, const ims_fft_object_t*
 /* Optional spike step between the inverse transform and ims_fft_finish: clip rbuf_in, find each object's
  * saturated bounding box (bbox_dev: int32 [n_objects][4] scratch = rowmin,rowmax,colmin,colmax), write
  * the spiked image to rbuf_out.  No-op copy when params->spikes.enabled == 0. */
+/* The table of ims_spikes_t.tab_*: called twice.  First with row_ptr_dev = NULL: the number of non-zero entries of every row a = -cutoff
+ * .. cutoff goes to row_count_dev[2 cutoff + 1]; the caller forms the prefix sum row_ptr (2 cutoff + 2 entries) and calls again with it
+ * and with col_dev / val_dev of row_ptr[2 cutoff + 1] entries.  The values are spike_stencil(a, b) / norm as the kernel would have
+ * formed them in place: the spikes are the same bits with and without the table. */
+int  ims_fft_spike_table(const ims_spikes_t* spikes, const int32_t* row_ptr_dev, int32_t* row_count_dev, int32_t* col_dev, double* val_dev,
+                         void* stream);
 int  ims_fft_spikes(const ims_fft_params_t* params, const ims_fft_object_t* objects_dev, int64_t n_objects,
                     const int64_t* pix_prefix_dev, int64_t n_pix, const double* rbuf_in, double* rbuf_out,
                     int32_t* bbox_dev, void* stream);

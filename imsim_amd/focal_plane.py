@@ -426,8 +426,19 @@ def render_focal_plane(ccds, build, device="cuda:0", rank=0, world=1, concurrent
         heavy = bright > int(tuning.env("IMS_FOCAL_JOINT_MAX_BRIGHT", "600"))
         if not heavy and joint > 1 and tuning.env("IMS_NATIVE_PLAN", "1") != "0":
             torch.cuda.set_device(dev)
-            with tuning.scoped(IMS_PHOTON_LDS=tuning.env("IMS_FOCAL_PHOTON_LDS")):
-                return _render_joint(mine, build, dev, nrecalc, sink, post, min(joint, 64), chain_hint)
+            # (the cyclic collector is paused while the visit renders: with the objects of 189 CCDs alive a generation-2 pass inside
+            # the call is 80 ms of a 1.2-s visit, one call in three -- profiles/round6_c5_gc.log; reference counting frees what the
+            # loop drops, and the collector runs again as soon as the call is over)
+            import gc
+            pause = gc.isenabled() and not tuning.flag("IMS_FOCAL_GC")
+            if pause:
+                gc.disable()
+            try:
+                with tuning.scoped(IMS_PHOTON_LDS=tuning.env("IMS_FOCAL_PHOTON_LDS")):
+                    return _render_joint(mine, build, dev, nrecalc, sink, post, min(joint, 64), chain_hint)
+            finally:
+                if pause:
+                    gc.enable()
     # the anchor streams are kept per device for the life of the process: PyTorch's caching allocator files a freed block
     # under the stream it was allocated on, so fresh streams per call would miss the cache and hipMalloc every CCD's
     # gigabytes of sensor state again (measured: 13 -> 27 .. 34 ms per CCD for the calls that do)

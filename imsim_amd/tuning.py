@@ -29,6 +29,8 @@ KNOWN = {
     "IMS_JOINT_SEARCH_LISTS": ("1", "... appended to by the pixel search where the charge lands; 0 = a launch of its own scans the marks (k_build_active_j)"),
     "IMS_ROUND_TWO_SEGMENTS": ("0", "pixel search of a round with two 256-photon segments per workgroup (both pool records requested up front)"),
     # -- engine --
+    "IMS_FOCAL_GC": ("0", "1 = Python's cyclic garbage collector stays on while a focal plane renders (a generation-2 pass inside the call: "
+                          "80 ms of a 1.2-s visit)"),
     "IMS_POOL_DELTA_ONLY": ("1", "photon pooling: a batch's deposits go to the delta-charge image only and the image takes them at the recalculation "
                                  "(one atomic add per photon; Silicon's target += delta); 0 = image and delta image both"),
     "IMS_SPIKE_TABLE": ("1", "FFT branch: the non-zero entries of the spike stencil from a table made once per visit (ims_fft_spike_table); "

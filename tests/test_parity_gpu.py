@@ -294,7 +294,7 @@ def test_lazy_static_renderer_makes_the_state_when_something_needs_it(torch_cuda
     state makes it first (and the renderer is an ordinary one from then on): pixel areas and a pooled accumulate of ordinary rows
     equal those of a renderer that was made with the state."""
     from imsim_amd.engine import Renderer
-    from imsim_amd.lsst_image import CcdJob
+    from imsim_amd.lsst_image import LSST_ImageBuilderBase
     scene, objects = _c3_case(n_obj=200)
     objects = objects[objects["n_phot"] <= 1000]
     out = []
@@ -307,7 +307,7 @@ def test_lazy_static_renderer_makes_the_state_when_something_needs_it(torch_cuda
         assert not r.lazy_static
         r.synchronize()
         image = r.image_numpy()
-        area = CcdJob.sky_pixel_areas(None, r)
+        area = LSST_ImageBuilderBase().sky_pixel_areas(r)
         out.append((image, area.cpu().numpy()))
     assert out[0][0].sum() > 0
     assert_bits_equal(out[0][0], out[1][0], "pooled accumulate on a renderer made without the static state")

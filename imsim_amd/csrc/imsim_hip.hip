@@ -496,16 +496,29 @@ __global__ __launch_bounds__(256) void k_accumulate(const ims_render_params_t P,
 // `converted` pool format) is loaded from the pool at pool_start[object] + j.
 // One workgroup = the photons [j0, j0 + 256) of object `oi` (clipped to j_end).
 template <int NV = 0, int WG = 256>
-__device__ __forceinline__ void accumulate_segment(const ims_render_params_t& P, const ims_photons_t& pool,
+__device__ __forceinline__ void accumulate_segment(const ims_render_params_t& Pg, const ims_photons_t& pool,
                                                    const int64_t* __restrict__ pool_start, int64_t oi, int64_t j0, int64_t j_end,
                                                    const TileLister* lister = nullptr)
 {
-    const ims_object_t& o = P.objects[oi];
+    const ims_object_t& og = Pg.objects[oi];
     const int64_t left = j_end - j0;                                            // photons of this segment (>= 1)
     const int n_thr = left >= WG ? WG : ((((int)left + 63) >> 6) << 6);
     if ((int)threadIdx.x >= n_thr) return;                                      // photon-less wavefronts leave at once
     const int64_t j = j0 + threadIdx.x;
-    const bool silicon = (P.sensor != nullptr) && (P.sensor->kind == IMS_SENSOR_SILICON);
+    // (The prologue of a round's pixel search is a chain of ~17 dependent scalar loads -- the fields of the chain's argument block, of
+    // the object row and of the sensor block, each fetched where it is first used, each a cold round trip behind the kernel boundary.
+    // Holding them all in one batch with empty asm statements cut the chain to 7 but took the kernel from 94 registers to 128 + 64 ..
+    // 156 B of scratch: not kept.  What is kept: the chain of a joint launch found with ONE vector load (joint_chain), and the
+    // photon's record requested as soon as its address is known, all four fields at once -- the three others used to wait for the
+    // flux -- so that its trip runs beside the rest of the chain: C3 24.08 -> 23.94 ms, C5 6.92 -> 6.83 ms per CCD, round 6.)
+    const ims_object_t& o = og;
+    const ims_render_params_t& P = Pg;
+    const int64_t pstart = pool_start[oi];
+    const bool have_sensor = Pg.sensor != nullptr;
+    const bool silicon = have_sensor && (P.sensor->kind == IMS_SENSOR_SILICON);
+    // the photon's record: all four fields requested before anything of it is looked at (the three others used to wait for the flux)
+    const int64_t ip = pstart + (j < j_end ? j : j0);
+    const double x0 = pool.x[ip], y0 = pool.y[ip], flux_in = pool.flux[ip], zs = pool.dxdz[ip];
     __shared__ float tile[CT * CT];
     ChargeTile ct;
     PROBE(1);
@@ -514,10 +527,9 @@ __device__ __forceinline__ void accumulate_segment(const ims_render_params_t& P,
     PROBE_WG(1, 0);
     double added = 0.0;
     if (j < j_end) {
-        const int64_t i = pool_start[oi] + j;
         int ix, iy;
         // the photon arrives at its conversion depth, diffused (converted pool): only the pixel search is left
-        const double x0 = pool.x[i], y0 = pool.y[i], flux = pool.flux[i], zs = pool.dxdz[i];
+        const double flux = flux_in;
         bool ok = false;
         if (flux != 0.0) {
             PROBE(3);
@@ -701,7 +713,8 @@ __global__ __launch_bounds__(WG, (NV == 8) ? 2 : 4) void k_accumulate_round_c(co
     ims_photons_t pool;
     pool.x = const_cast<double*>(a.px); pool.y = const_cast<double*>(a.py); pool.flux = const_cast<double*>(a.pflux);
     pool.dxdz = const_cast<double*>(a.pz);
-    const int64_t oi = blockIdx.x / segs;
+    // (the object index through readfirstlane: the division runs on the vector unit, and the loads of the row are to be scalar loads)
+    const int64_t oi = (int64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x / (unsigned)segs));
     const int64_t j0 = round_first + (int64_t)(blockIdx.x % segs) * WG;
     int64_t j_end = round_first + nrecalc;
     const int64_t n = P.objects[oi].n_phot;
@@ -757,13 +770,16 @@ struct JointAcc {                           // per chain, constant over the roun
 struct JointRound { JointEnds ea, eu, ns, ewg, tof; };
 typedef const JointEnds __attribute__((address_space(4))) * ConstEnds;
 
+// which chain workgroup b belongs to: the number of ends <= b.  One entry per lane (a single 256-byte load), a ballot and a population
+// count: ONE round trip at the head of every round kernel, where 63 scalar compares on four batches of scalar loads were three
+// (the registers do not hold 64 ends at once) -- behind a kernel boundary every trip of the prologue is a cold one (round 6).
+// All 64 lanes must be active.
 __device__ __forceinline__ int joint_chain(const JointEnds* e_global, int& b)
 {
-    ConstEnds e = (ConstEnds)(uintptr_t)e_global;
-    int c = 0;
-#pragma unroll
-    for (int k = 0; k < IMS_JOINT_MAX - 1; ++k) c += (b >= e->v[k]) ? 1 : 0;
-    if (c > 0) b -= e->v[c - 1];
+    const int lane = (int)(threadIdx.x & 63);
+    const int v = e_global->v[lane];
+    const int c = (int)__popcll(__builtin_amdgcn_ballot_w64(lane < IMS_JOINT_MAX - 1 && b >= v));
+    if (c > 0) b -= __builtin_amdgcn_readlane(v, c - 1);
     return c;
 }
 __device__ __forceinline__ int joint_entry(const JointEnds* e_global, int c) { return ((ConstEnds)(uintptr_t)e_global)->v[c]; }

@@ -1336,13 +1336,19 @@ __device__ __forceinline__ bool tile_out_of_reach(const ims_sensor_t& s, const S
 {
     if (tag == 0u || s.bf_tile_charge == nullptr) return false;
     const int tiles_x = (sl.nx + 1 + UT - 1) / UT, tiles_y = (sl.ny + 1 + UT - 1) / UT;
+    // (the nine marks read together -- a neighbour that does not exist reads the tile's own mark -- not one after the other behind
+    // `any ||`: up to nine dependent round trips at the head of a tile that turns out to be out of reach)
+    const unsigned char* __restrict__ marks = s.bf_tile_charge;
+    unsigned char m[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        int ux = tx + k % 3 - 1, uy = ty + k / 3 - 1;
+        if (ux < 0 || uy < 0 || ux >= tiles_x || uy >= tiles_y) { ux = tx; uy = ty; }
+        m[k] = marks[cell_index(sl, ux * UT, uy * UT)];
+    }
     bool any = false;
-    for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int ux = tx + dx, uy = ty + dy;
-            if (ux < 0 || uy < 0 || ux >= tiles_x || uy >= tiles_y) continue;
-            any = any || (s.bf_tile_charge[cell_index(sl, ux * UT, uy * UT)] == (unsigned char)tag);
-        }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) any = any || (m[k] == (unsigned char)tag);
     return !any;
 }
 
@@ -1445,16 +1451,28 @@ __device__ __forceinline__ void update_tile_q3(const ims_sensor_t& s, const Slot
     PROBE(9);
     if (threadIdx.x < HW) L.occ[threadIdx.x] = 0u;
     if (threadIdx.x == 0) L.any_charge = 0;
-    __syncthreads();
-    for (int e = threadIdx.x; e < HW * HW; e += 256) {
+    // the halo's 529 cells, up to three per thread, requested TOGETHER: as a rolled loop (load, wait, scale, store, next) they were three
+    // dependent memory round trips at the head of every tile -- behind a kernel boundary ~1.5 us each under load (round 6)
+    constexpr int HE = (HW * HW + 255) / 256;
+    double charge[HE];
+    const double num_elec = s.num_elec;
+#pragma unroll
+    for (int u = 0; u < HE; ++u) {
+        const int e = (int)threadIdx.x + 256 * u;
         const int hx = e % HW, hy = e / HW;
         const int si = sx0 + hx, sj = sy0 + hy;
-        double w = 0.0;
-        if (si >= 0 && si < sl.nx && sj >= 0 && sj < sl.ny) {
-            const double charge = (double)s.bf_delta[cell_index(sl, si, sj)];
-            if (charge != 0.0) { w = ddiv(charge, s.num_elec); atomicOr(&L.occ[hy], 1u << hx); L.any_charge = 1; }
+        const bool in = e < HW * HW && si >= 0 && si < sl.nx && sj >= 0 && sj < sl.ny;
+        charge[u] = in ? (double)s.bf_delta[cell_index(sl, si, sj)] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < HE; ++u) {
+        const int e = (int)threadIdx.x + 256 * u;
+        if (e < HW * HW) {
+            double w = 0.0;
+            if (charge[u] != 0.0) { w = ddiv(charge[u], num_elec); atomicOr(&L.occ[e / HW], 1u << (e % HW)); L.any_charge = 1; }
+            L.wt[e] = w;
         }
-        L.wt[e] = w;
     }
     __syncthreads();
     PROBE(10);
@@ -1572,16 +1590,26 @@ __device__ __forceinline__ void update_tile_q3_dpp(const ims_sensor_t& s, const 
             dreg[u] = (e < DLN) ? dl_global[e] : 0.0;
         }
     }
-    __syncthreads();
-    for (int e = threadIdx.x; e < HW * HW; e += 256) {
+    constexpr int HE = (HW * HW + 255) / 256;
+    double charge[HE];                               // (requested together, as in update_tile_q3)
+    const double num_elec = s.num_elec;
+#pragma unroll
+    for (int u = 0; u < HE; ++u) {
+        const int e = (int)threadIdx.x + 256 * u;
         const int hx = e % HW, hy = e / HW;
         const int si = sx0 + hx, sj = sy0 + hy;
-        double w = 0.0;
-        if (si >= 0 && si < sl.nx && sj >= 0 && sj < sl.ny) {
-            const double charge = (double)s.bf_delta[cell_index(sl, si, sj)];
-            if (charge != 0.0) { w = ddiv(charge, s.num_elec); atomicOr(&L.occ[hy], 1u << hx); L.any_charge = 1; }
+        const bool in = e < HW * HW && si >= 0 && si < sl.nx && sj >= 0 && sj < sl.ny;
+        charge[u] = in ? (double)s.bf_delta[cell_index(sl, si, sj)] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < HE; ++u) {
+        const int e = (int)threadIdx.x + 256 * u;
+        if (e < HW * HW) {
+            double w = 0.0;
+            if (charge[u] != 0.0) { w = ddiv(charge[u], num_elec); atomicOr(&L.occ[e / HW], 1u << (e % HW)); L.any_charge = 1; }
+            L.wt[e] = w;
         }
-        L.wt[e] = w;
     }
     if (early_table) {
 #pragma unroll
@@ -1778,9 +1806,12 @@ __device__ __forceinline__ void refresh_tile(const ims_sensor_t& s, const SlotVi
     }
     if (i >= sl.nx || j >= sl.ny) return;
     // per-cell flags are only meaningful in tiles the update worked on this round
-    const bool f_own = own && changed[c];
-    const bool f_right = ((lx + 1 < UT) ? own : right) && changed[cell_index(sl, i + 1, j)];
-    const bool f_up = ((ly + 1 < UT) ? own : up) && changed[cell_index(sl, i, j + 1)];
+    // (the three bytes are read whether or not their tile's flag asks for them -- (i + 1, j) and (i, j + 1) are owner cells of the
+    // region, i < nx and j < ny here -- so that they are ONE round trip, not up to three behind short-circuit tests)
+    const unsigned char c_own = changed[c], c_right = changed[cell_index(sl, i + 1, j)], c_up = changed[cell_index(sl, i, j + 1)];
+    const bool f_own = own && c_own;
+    const bool f_right = ((lx + 1 < UT) ? own : right) && c_right;
+    const bool f_up = ((ly + 1 < UT) ? own : up) && c_up;
     if (!(f_own || f_right || f_up)) return;
     const int nV = (NV > 0) ? NV : s.num_vertices, nv = 4 * nV + 4;
     double ixmin = 0.0, ixmax = 1.0, iymin = 0.0, iymax = 1.0;
@@ -1856,10 +1887,13 @@ __global__ __launch_bounds__(256) void k_refresh_changed(const ims_sensor_t* __r
     bool own = true, right = true, up = true, charged = true;
     if (flags) {
         const unsigned char tg = (unsigned char)tag;
-        own = s.bf_tile_changed[cell_index(sl, tx * UT, ty * UT)] == tg;
-        right = (tx + 1 < tiles_x) && s.bf_tile_changed[cell_index(sl, (tx + 1) * UT, ty * UT)] == tg;
-        up = (ty + 1 < tiles_y) && s.bf_tile_changed[cell_index(sl, tx * UT, (ty + 1) * UT)] == tg;
-        charged = s.bf_tile_charge[cell_index(sl, tx * UT, ty * UT)] == tg;
+        // (the four bytes in ONE round trip: the right / upper tile's at the tile's own address where there is none)
+        const bool has_r = tx + 1 < tiles_x, has_u = ty + 1 < tiles_y;
+        const unsigned char t_own = s.bf_tile_changed[cell_index(sl, tx * UT, ty * UT)],
+                            t_right = s.bf_tile_changed[cell_index(sl, (has_r ? tx + 1 : tx) * UT, ty * UT)],
+                            t_up = s.bf_tile_changed[cell_index(sl, tx * UT, (has_u ? ty + 1 : ty) * UT)],
+                            t_charge = s.bf_tile_charge[cell_index(sl, tx * UT, ty * UT)];
+        own = t_own == tg; right = has_r && t_right == tg; up = has_u && t_up == tg; charged = t_charge == tg;
         if (!(own || right || up || charged)) return;
     }
     PROBE(17);
@@ -1887,10 +1921,13 @@ __global__ __launch_bounds__(256) void k_refresh_changed_j(const JointUpd* __res
     bool own = true, right = true, up = true, charged = true;
     if (flags) {
         const unsigned char tg = (unsigned char)tag;
-        own = s.bf_tile_changed[cell_index(sl, tx * UT, ty * UT)] == tg;
-        right = (tx + 1 < tiles_x) && s.bf_tile_changed[cell_index(sl, (tx + 1) * UT, ty * UT)] == tg;
-        up = (ty + 1 < tiles_y) && s.bf_tile_changed[cell_index(sl, tx * UT, (ty + 1) * UT)] == tg;
-        charged = s.bf_tile_charge[cell_index(sl, tx * UT, ty * UT)] == tg;
+        // (the four bytes in ONE round trip: the right / upper tile's at the tile's own address where there is none)
+        const bool has_r = tx + 1 < tiles_x, has_u = ty + 1 < tiles_y;
+        const unsigned char t_own = s.bf_tile_changed[cell_index(sl, tx * UT, ty * UT)],
+                            t_right = s.bf_tile_changed[cell_index(sl, (has_r ? tx + 1 : tx) * UT, ty * UT)],
+                            t_up = s.bf_tile_changed[cell_index(sl, tx * UT, (has_u ? ty + 1 : ty) * UT)],
+                            t_charge = s.bf_tile_charge[cell_index(sl, tx * UT, ty * UT)];
+        own = t_own == tg; right = has_r && t_right == tg; up = has_u && t_up == tg; charged = t_charge == tg;
         if (!(own || right || up || charged)) return;
     }
     refresh_tile<NV>(s, sl, tx, ty, own, right, up, charged, changed);
@@ -2078,10 +2115,13 @@ __global__ __launch_bounds__(256) void k_refresh_list_j(const JointUpd* __restri
         const int tiles_x = (sl.nx + 1 + UT - 1) / UT, tiles_y = (sl.ny + 1 + UT - 1) / UT;
         const int tx = t % tiles_x, ty = t / tiles_x;
         const unsigned char tg = (unsigned char)tag;
-        const bool own = s.bf_tile_changed[cell_index(sl, tx * UT, ty * UT)] == tg;
-        const bool right = (tx + 1 < tiles_x) && s.bf_tile_changed[cell_index(sl, (tx + 1) * UT, ty * UT)] == tg;
-        const bool up = (ty + 1 < tiles_y) && s.bf_tile_changed[cell_index(sl, tx * UT, (ty + 1) * UT)] == tg;
-        const bool charged = s.bf_tile_charge[cell_index(sl, tx * UT, ty * UT)] == tg;
+        // (the four bytes in ONE round trip: the right / upper tile's at the tile's own address where there is none)
+        const bool has_r = tx + 1 < tiles_x, has_u = ty + 1 < tiles_y;
+        const unsigned char t_own = s.bf_tile_changed[cell_index(sl, tx * UT, ty * UT)],
+                            t_right = s.bf_tile_changed[cell_index(sl, (has_r ? tx + 1 : tx) * UT, ty * UT)],
+                            t_up = s.bf_tile_changed[cell_index(sl, tx * UT, (has_u ? ty + 1 : ty) * UT)],
+                            t_charge = s.bf_tile_charge[cell_index(sl, tx * UT, ty * UT)];
+        const bool own = t_own == tg, right = has_r && t_right == tg, up = has_u && t_up == tg, charged = t_charge == tg;
         if (!(own || right || up || charged)) continue;
         refresh_tile<NV>(s, sl, tx, ty, own, right, up, charged, (const unsigned char*)U->changed[c]);
     }

@@ -154,10 +154,13 @@ IMS_DEV int wrap_index(double fl, double dn, double inv_n)
 }
 
 typedef double dvec2q __attribute__((ext_vector_type(2)));
+constexpr int SCREEN_BATCH = 6;   // layers of imSim's atmosphere (atmPSF.py:179: six altitudes)
 // sum over layers of the gradient of the bilinear interpolant of the periodic phase screens [nm/m]
 // PLAIN: always the four samples of the screens themselves (the pre-pass of ims_screen_prepass keeps an XCD's windows in its
 // L2, where the four-fold table of 2 x 2 cells would only quadruple the footprint)
-template <bool PLAIN = false>
+// BATCH: the kernels specialised for imSim's default PSF (run_psf<2>) ask for it; the generic kernels keep the rolled loop and
+// their register count
+template <bool PLAIN = false, bool BATCH = false>
 IMS_DEV void screen_gradient(const ims_atmosphere_t& A, double pu, double pv, double t, double tanx, double tany,
                              double& gx, double& gy)
 {
@@ -166,6 +169,33 @@ IMS_DEV void screen_gradient(const ims_atmosphere_t& A, double pu, double pv, do
     const double dn = A.dn, inv_n = A.inv_n, inv_scale = A.inv_scale;      // ims_fill_derived_atmosphere
     const bool pow2 = (n & (n - 1)) == 0;      // the screens of the reference are 8192 wide: the wrap is a mask
     const bool quads = !PLAIN && A.screen_quads != nullptr;
+    if (BATCH && !PLAIN && quads && pow2 && A.n_layers == SCREEN_BATCH) {
+        // the reference's atmosphere (six layers, 8192-wide screens, atmPSF.py:164-205): the layers' gathers do not depend on each
+        // other, so all six are requested before the first is used -- ONE trip through the 6.4-GB table per photon instead of
+        // six in a row (the rolled loop below waits for every load before it forms the next address).  Same operations on the
+        // same values, summed in the same order.
+        typedef float fvec4 __attribute__((ext_vector_type(4)));
+        fvec4 q[SCREEN_BATCH];
+        double ax[SCREEN_BATCH], ay[SCREEN_BATCH];
+#pragma unroll
+        for (int l = 0; l < SCREEN_BATCH; ++l) {
+            const double x = pu - t * A.vx[l] + A.alt[l] * tanx;
+            const double y = pv - t * A.vy[l] + A.alt[l] * tany;
+            const double fx = (x - A.x0) * inv_scale, fy = (y - A.x0) * inv_scale;
+            const double flx = floor(fx), fly = floor(fy);
+            ax[l] = fx - flx; ay[l] = fy - fly;
+            const int ix = (int)flx & (n - 1), iy = (int)fly & (n - 1);
+            q[l] = *(const IMS_G fvec4*)(A.screen_quads + (((int64_t)l * n + iy) * n + ix) * 4);
+        }
+#pragma unroll
+        for (int l = 0; l < SCREEN_BATCH; ++l) {
+            const double f00 = (double)q[l].x, f10 = (double)q[l].y, f01 = (double)q[l].z, f11 = (double)q[l].w;
+            sx = sx + ((f10 - f00) * (1.0 - ay[l]) + (f11 - f01) * ay[l]);
+            sy = sy + ((f01 - f00) * (1.0 - ax[l]) + (f11 - f10) * ax[l]);
+        }
+        gx = sx * inv_scale; gy = sy * inv_scale;
+        return;
+    }
     for (int l = 0; l < A.n_layers; ++l) {
         const double x = pu - t * A.vx[l] + A.alt[l] * tanx;
         const double y = pv - t * A.vy[l] + A.alt[l] * tany;
@@ -248,7 +278,7 @@ IMS_DEV void apply_psf(const ims_render_params_t& P, const ims_object_t& o, int 
             const dvec2q g = *(const IMS_G dvec2q*)(P.screen_kick + 2 * (o.screen_base + k));
             gx = g.x; gy = g.y;
         } else {
-            screen_gradient(A, pu, pv, t, o.atm_tan_x, o.atm_tan_y, gx, gy);
+            screen_gradient<false, (KIND >= 0)>(A, pu, pv, t, o.atm_tan_x, o.atm_tan_y, gx, gy);
         }
         ku = scale * gx; kv = scale * gy;
         ph.pu = pu; ph.pv = pv; ph.t = t;

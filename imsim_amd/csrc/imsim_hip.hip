@@ -2228,6 +2228,20 @@ __device__ __forceinline__ void row_col(int64_t local, int len, int& row, int& c
     else { row = (int)(l / n); col = (int)(l - (uint32_t)row * n); }
 }
 
+// 1 / (nfft * nfft) as ims_fft_inverse's scaling pass forms it on the host (powers of two: the exponent written directly)
+__device__ __forceinline__ double inv_n2(int nfft)
+{
+    const uint32_t n = (uint32_t)nfft;
+    if ((n & (n - 1u)) == 0u) return __longlong_as_double((long long)(1023 - 2 * (31 - __clz((int)n))) << 52);
+    return 1.0 / ((double)nfft * (double)nfft);
+}
+// a value of the real-space buffer as the image holds it (ims_fft_params_t.rbuf_raw)
+__device__ __forceinline__ double rbuf_value(const double* __restrict__ rbuf, int64_t at, bool raw, double scale)
+{
+    const double v = rbuf[at];
+    return raw ? v * scale : v;
+}
+
 __global__ __launch_bounds__(256) void k_fft_kspace_fill(const ims_fft_params_t P, const ims_fft_object_t* __restrict__ objs,
                                                          int64_t n_objects, const int64_t* __restrict__ prefix, int64_t n_elems,
                                                          double* __restrict__ kbuf)
@@ -2261,7 +2275,7 @@ __global__ __launch_bounds__(256) void k_fft_bbox(const ims_fft_params_t P, cons
         row_col(local, o.nfft, iy, ix);
         const int px = o.x0 + ix, py = o.y0 + iy;
         if (px < o.stamp_xmin || px > o.stamp_xmax || py < o.stamp_ymin || py > o.stamp_ymax) continue;
-        if (rbuf[o.r_offset + local] > P.spikes.threshold) {
+        if (rbuf_value(rbuf, o.r_offset + local, P.rbuf_raw != 0, inv_n2(o.nfft)) > P.spikes.threshold) {
             atomicMin(&bbox[4 * oi + 0], iy); atomicMax(&bbox[4 * oi + 1], iy);
             atomicMin(&bbox[4 * oi + 2], ix); atomicMax(&bbox[4 * oi + 3], ix);
         }
@@ -2299,7 +2313,9 @@ __global__ __launch_bounds__(256) void k_fft_spikes(const ims_fft_params_t P, co
         const int64_t local = e - prefix[oi];
         int iy, ix;
         row_col(local, o.nfft, iy, ix);
-        double v = rin[o.r_offset + local];
+        const bool raw = P.rbuf_raw != 0;
+        const double scale = inv_n2(o.nfft);
+        double v = rbuf_value(rin, o.r_offset + local, raw, scale);
         if (v < 0.0) v = 0.0;
         const int px = o.x0 + ix, py = o.y0 + iy;
         const bool in_stamp = !(px < o.stamp_xmin || px > o.stamp_xmax || py < o.stamp_ymin || py > o.stamp_ymax);
@@ -2345,7 +2361,7 @@ __global__ __launch_bounds__(256) void k_fft_spikes(const ims_fft_params_t P, co
                         const int b = k.tab_col[e];
                         if (b > bhi) continue;
                         if (b < blo) break;
-                        double src = rin[o.r_offset + (int64_t)ry * o.nfft + (ix - b)];
+                        double src = rbuf_value(rin, o.r_offset + (int64_t)ry * o.nfft + (ix - b), raw, scale);
                         if (src < 0.0) src = 0.0;
                         acc = acc + k.tab_val[e] * src;
                     }
@@ -2387,7 +2403,7 @@ __global__ __launch_bounds__(256) void k_fft_spikes(const ims_fft_params_t P, co
                         for (int rx = lo[q]; rx <= hi[q]; ++rx) {
                             const int b = ix - rx;
                             if (b < -k.cutoff || b > k.cutoff) continue;
-                            double src = rin[o.r_offset + (int64_t)ry * o.nfft + rx];
+                            double src = rbuf_value(rin, o.r_offset + (int64_t)ry * o.nfft + rx, raw, scale);
                             if (src < 0.0) src = 0.0;
                             acc = acc + spike_stencil(k, a, b) / k.norm * src;
                         }
@@ -2413,7 +2429,7 @@ __global__ __launch_bounds__(256) void k_fft_finish(const ims_fft_params_t P, co
         row_col(local, o.nfft, iy, ix);
         const int px = o.x0 + ix, py = o.y0 + iy;
         if (px < o.stamp_xmin || px > o.stamp_xmax || py < o.stamp_ymin || py > o.stamp_ymax) continue;
-        double v = rbuf[o.r_offset + local];
+        double v = rbuf_value(rbuf, o.r_offset + local, P.rbuf_raw != 0, inv_n2(o.nfft));
         if (v < 0.0) v = 0.0;
         if (P.realized_flux != nullptr && v != 0.0) unsafeAtomicAdd(P.realized_flux + oi, v);
         if (P.add_noise) v = poisson(v, P.seed, o.obj_id, local);
@@ -4256,7 +4272,7 @@ int ims_fft_warm(int32_t nfft, void* stream)
     return fft_plan_get(F, nfft, 1, stream, &plan);
 }
 
-int ims_fft_inverse(double* kbuf_dev, double* rbuf_dev, int32_t nfft, int64_t batch, void* stream)
+static int fft_inverse_impl(double* kbuf_dev, double* rbuf_dev, int32_t nfft, int64_t batch, void* stream, bool normalise)
 {
     if (batch <= 0) return IMS_OK;
     if (!kbuf_dev || !rbuf_dev) return set_err(IMS_ERR_ARG, "NULL buffer");
@@ -4286,6 +4302,7 @@ int ims_fft_inverse(double* kbuf_dev, double* rbuf_dev, int32_t nfft, int64_t ba
             if (rc) return rc;
         }
     }
+    if (!normalise) return IMS_OK;          // the readers multiply (ims_fft_params_t.rbuf_raw)
     // numpy / GalSim normalisation of the inverse ("backward": 1 / N^2): exact for the even sizes used (powers of two)
     const int64_t total = batch * (int64_t)nfft * nfft;
     int64_t blocks = (total + 255) / 256;
@@ -4293,6 +4310,16 @@ int ims_fft_inverse(double* kbuf_dev, double* rbuf_dev, int32_t nfft, int64_t ba
     hipLaunchKernelGGL(k_scale, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rbuf_dev, total, 1.0 / ((double)nfft * (double)nfft));
     HIP_TRY(hipGetLastError());
     return IMS_OK;
+}
+
+int ims_fft_inverse(double* kbuf_dev, double* rbuf_dev, int32_t nfft, int64_t batch, void* stream)
+{
+    return fft_inverse_impl(kbuf_dev, rbuf_dev, nfft, batch, stream, true);
+}
+
+int ims_fft_inverse_raw(double* kbuf_dev, double* rbuf_dev, int32_t nfft, int64_t batch, void* stream)
+{
+    return fft_inverse_impl(kbuf_dev, rbuf_dev, nfft, batch, stream, false);
 }
 
 // ---- exchanges between the GPUs of a node (RCCL over xGMI) ----

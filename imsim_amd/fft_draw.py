@@ -276,6 +276,25 @@ import threading as _threading
 _WARM_LOCK = _threading.Lock()
 
 
+def raw_inverse():
+    """Whether FftDrawer leaves the 1 / N^2 of the inverse transform to the kernel that reads the real-space buffer next
+    (ims_fft_inverse_raw + ims_fft_params_t.rbuf_raw; IMS_FFT_RAW, default on; never with the torch front end)."""
+    return tuning.env("IMS_FFT_TORCH", "0") == "0" and tuning.env("IMS_FFT_RAW", "1") != "0"
+
+
+def image_from_rbuf(fft_objects, rbuf, raw=None):
+    """The real-space IMAGES of a draw from the buffer FftDrawer.draw returned (a numpy array): with the raw inverse every object's
+    grid still lacks its 1 / (nfft * nfft) -- applied here by the same product the kernels form on reading (a checker's helper:
+    the oracle's spike and finish steps take images)."""
+    out = np.array(rbuf, dtype=np.float64, copy=True)
+    if raw_inverse() if raw is None else raw:
+        at = 0
+        for n in np.asarray(fft_objects["nfft"], dtype=np.int64):
+            out[at:at + n * n] *= 1.0 / (float(n) * float(n))
+            at += int(n * n)
+    return out
+
+
 def warm_up(device, stream, sizes=(1024, 2048, 4096, 512)):
     """Make the library's hipFFT plans of `stream` for the grid sizes a visit's FFT-drawn objects take, on a BACKGROUND thread
     (returns it; join() before timing anything).  A process's first plan costs seconds (hipFFT / rocFFT start up and compile
@@ -442,6 +461,10 @@ class FftDrawer:
         # takes torch.fft instead -- the same library behind another front end, kept as the checker
         import os
         use_torch = tuning.env("IMS_FFT_TORCH", "0") != "0"
+        # the 1 / N^2 of the inverse is applied by whoever reads the real-space buffer next (ims_fft_params_t.rbuf_raw): the same
+        # product without a pass of its own over the branch's largest buffer (IMS_FFT_RAW=0: the scaling pass, the same bits)
+        raw = raw_inverse()
+        inverse = r.lib.ims_fft_inverse_raw if raw else r.lib.ims_fft_inverse
         kspace = kbuf
         if getattr(self, "keep_kspace", False):
             kspace = kbuf.clone()                     # hipFFT's complex-to-real transform uses its input as work space
@@ -456,7 +479,7 @@ class FftDrawer:
                                  out=rbuf[int(rpre[a]):int(rpre[b])].view(b - a, int(size), int(size)))
             else:
                 # the library's own hipFFT plans (ims_fft_inverse): nothing of the branch needs a Python-side transform
-                _abi.check(r.lib.ims_fft_inverse(kbuf.data_ptr() + 16 * int(kpre[a]), rbuf.data_ptr() + 8 * int(rpre[a]), int(size), b - a, st),
+                _abi.check(inverse(kbuf.data_ptr() + 16 * int(kpre[a]), rbuf.data_ptr() + 8 * int(rpre[a]), int(size), b - a, st),
                            "ims_fft_inverse")
         final = rbuf
         bbox = None
@@ -464,10 +487,16 @@ class FftDrawer:
             # DiffractionFFT.apply between the clip and the noise (stamp.py:519-522)
             final, bbox = self._spike_bufs if getattr(self, "_spike_bufs", None) is not None else (
                 torch.empty_like(rbuf), torch.empty(4 * n, dtype=torch.int32, device=r.device))
+            P.rbuf_raw = int(raw)
             _abi.check(r.lib.ims_fft_spikes(C.byref(P), obj_t.data_ptr(), n, rpre_t.data_ptr(), int(rpre[-1]),
                                             rbuf.data_ptr(), final.data_ptr(), bbox.data_ptr(), st), "ims_fft_spikes")
-        _abi.check(r.lib.ims_fft_finish(C.byref(P), obj_t.data_ptr(), n, rpre_t.data_ptr(), int(rpre[-1]),
-                                        final.data_ptr(), st), "ims_fft_finish")
+            raw = False                         # the spike step writes the image itself
+        P.rbuf_raw = int(raw)
+        try:
+            _abi.check(r.lib.ims_fft_finish(C.byref(P), obj_t.data_ptr(), n, rpre_t.data_ptr(), int(rpre[-1]),
+                                            final.data_ptr(), st), "ims_fft_finish")
+        finally:
+            P.rbuf_raw = 0
         # EVERY device buffer the queued launches touch stays referenced from _last (a caller that runs them on a side stream keeps
         # _last until they are through): the saturated-region boxes too -- freed at the end of this call, their block went back to
         # the allocator and to the next CCD's uploads while k_fft_bbox / k_fft_spikes were still queued (round 5: the rows of the

@@ -48,7 +48,7 @@ extern "C" {
 #define IMS_ERR_NO_DEVICE  -3
 #define IMS_ERR_UNSUPPORTED -4
 
-#define IMS_ABI_VERSION 20
+#define IMS_ABI_VERSION 21
 
 /* Pointers stored INSIDE descriptors that live in device memory (ims_sensor_t, ims_atmosphere_t) always point to global
  * device memory.  Device code is told so (address space 1): a pointer read out of memory is otherwise a generic pointer and
@@ -583,7 +583,10 @@ typedef struct ims_fft_params {
     double*  realized_flux;          /* [n_objects] or NULL */
     ims_spikes_t spikes;
     int32_t  n_alias;                /* k-space fill: fold the aliases -n_alias..n_alias of the sampling frequency per axis (0 = base band) */
-    int32_t  pad_alias;
+    int32_t  rbuf_raw;               /* ims_fft_spikes / ims_fft_finish: 1 = the real-space buffer they READ is ims_fft_inverse_raw's (no
+                                      * 1 / N^2 yet): every value read is multiplied by 1 / (nfft * nfft) of its object first -- the
+                                      * multiplication ims_fft_inverse does in a pass of its own, the same product, the same bits.
+                                      * ims_fft_spikes WRITES the image itself (its output is never raw). */
 } ims_fft_params_t;
 
 /* elem_prefix[n_objects+1] (device): prefix sum of nfft*(nfft/2+1); kbuf: interleaved (re, im) doubles */
@@ -727,6 +730,9 @@ int64_t ims_parse_instcat_objects(const char* text, int64_t n_bytes, int64_t max
  * ims_fft_inverse: `batch` inverse real 2-D transforms of size nfft x nfft (imsim/stamp.py:502-504, GalSim's FFT draw): kbuf
  * holds the half spectra [batch][nfft][nfft / 2 + 1] complex128 (destroyed), rbuf receives [batch][nfft][nfft] float64 with
  * numpy's "backward" normalisation.  Plans are cached per (nfft, batch) for the life of the process.
+ * ims_fft_inverse_raw: the same without the normalisation (hipFFT's own output: N^2 times the image), for callers whose next step
+ * reads the buffer with ims_fft_params_t.rbuf_raw = 1 -- one pass less over the largest buffer of the branch (a read and a write
+ * of 8 bytes per pixel).
  *
  * Communicator: rank 0 asks ims_comm_unique_id for the 128-byte id, the host hands it to every rank by its own means (a file,
  * a socket, torch.distributed's store), every rank calls ims_comm_init.  ims_reduce_image sums the ranks' f64 CCD images onto
@@ -735,6 +741,7 @@ int64_t ims_parse_instcat_objects(const char* text, int64_t n_bytes, int64_t max
  * int32 (half the bytes; exact when every value is an integer count and the sum stays below 2^31 -- ims_count_inexact adds the
  * number of values of a rank's image that are not integer counts below 2^31 / world to *bad_dev). */
 int  ims_fft_inverse(double* kbuf_dev, double* rbuf_dev, int32_t nfft, int64_t batch, void* stream);
+int  ims_fft_inverse_raw(double* kbuf_dev, double* rbuf_dev, int32_t nfft, int64_t batch, void* stream);
 /* Make the plan of the nfft x nfft transforms of `stream` ahead of time (a process's first hipFFT plan costs seconds: the
  * library starts up and compiles its kernels at run time); may be called from another host thread while the caller goes on. */
 int  ims_fft_warm(int32_t nfft, void* stream);

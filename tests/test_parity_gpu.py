@@ -742,7 +742,7 @@ def test_fft_branch_matches_oracle(torch_cuda):
     okbuf = orc.fill(rows)
     assert_bits_equal(kbuf.cpu().numpy(), okbuf, "k-space half spectra")
     orbuf = orc.inverse(rows, okbuf)
-    g_rbuf = rbuf.cpu().numpy()
+    g_rbuf = fft_draw.image_from_rbuf(rows, rbuf.cpu().numpy())      # the default leaves the 1 / N^2 to the reader (rbuf_raw)
     assert np.abs(g_rbuf - orbuf).max() < 1e-11 * np.abs(orbuf).max()
     # noise + add: feed the oracle the SAME real-space images the GPU produced
     oreal = np.zeros(len(rows))
@@ -784,6 +784,49 @@ def test_library_fft_inverse_equals_the_torch_front_end(torch_cuda, monkeypatch)
     diff = np.count_nonzero(images[0] != images[1])
     assert images[0].sum() > 0 and diff <= 1e-4 * np.count_nonzero(images[0]) + 2
     assert abs(images[0].sum() / images[1].sum() - 1.0) < 1e-6
+
+
+def test_fft_inverse_left_unnormalised_for_its_readers_gives_the_same_images(torch_cuda, monkeypatch):
+    """ims_fft_inverse_raw + ims_fft_params_t.rbuf_raw (the default of FftDrawer): the readers of the real-space buffer -- saturated-box
+    scan, spike step, finish -- form value * 1 / (nfft * nfft) themselves, the product the scaling pass of ims_fft_inverse
+    forms: the buffer times that factor, the spiked images and the noisy CCD image are the same bits with and without the
+    pass (the realized fluxes the same sums), for power-of-two grids and for one that is not (1 / N^2 by division there)."""
+    import math
+    from imsim_amd import fft_draw, diffraction_fft as dfft
+    from imsim_amd.engine import Renderer
+    torch = torch_cuda
+    scene, rows, kpsf = _fft_case()
+    rows = rows.copy()
+    rows["flux"] *= 20.0
+    odd = rows[:1].copy()
+    odd["nfft"] = 96                                        # 3 * 32: not a power of two
+    rows = np.concatenate([odd, rows])
+    rows = rows[np.argsort(rows["nfft"], kind="stable")]
+    nf = rows["nfft"].astype(np.int64)
+    rows["k_offset"] = np.concatenate([[0], np.cumsum(nf * (nf // 2 + 1))])[:-1]
+    rows["r_offset"] = np.concatenate([[0], np.cumsum(nf * nf)])[:-1]
+    cfg = dfft.DiffractionFFT(exptime=30.0, azimuth=math.radians(114.39), altitude=math.radians(53.16),
+                              rotTelPos=math.radians(40.04), spike_length_cutoff=60)
+    for spikes in (None, cfg):
+        got = {}
+        for raw in ("1", "0"):
+            monkeypatch.setenv("IMS_FFT_RAW", raw)
+            assert fft_draw.raw_inverse() == (raw == "1")
+            r = Renderer(scene)
+            real = torch.zeros(len(rows), dtype=torch.float64, device="cuda")
+            drawer = fft_draw.FftDrawer(r, kpsf, add_noise=True, diffraction_fft=spikes, wavelength=622.2)
+            kbuf, rbuf = drawer.draw(rows, realized=real)
+            r.synchronize()
+            got[raw] = (fft_draw.image_from_rbuf(rows, rbuf.cpu().numpy()), drawer._last[2].cpu().numpy().copy(), r.image64_numpy(),
+                        real.cpu().numpy())
+        assert np.abs(got["1"][0]).max() > 1e5 and got["1"][2].sum() > 0
+        for k, what in enumerate(("real-space images", "images after the spike step", "CCD image")):
+            if k == 1 and spikes is None:
+                continue                                     # without a spike step the buffer handed to finish IS the raw one
+            assert_bits_equal(got["1"][k], got["0"][k], f"{what}, raw inverse vs scaling pass (spikes {'on' if spikes else 'off'})")
+        np.testing.assert_allclose(got["1"][3], got["0"][3], rtol=1e-12)       # sums of the same values by atomic adds: any order
+    lib = _abi.load()
+    assert lib.ims_fft_inverse_raw(None, None, 64, 1, None) != 0
 
 
 def test_fft_and_photon_shooting_agree(torch_cuda):
@@ -838,10 +881,11 @@ def test_fft_diffraction_spikes_are_bit_exact(torch_cuda):
     r.synchronize()
     final = drawer._last[2].cpu().numpy()
     orc = orc_loader.OracleFft(scene, kpsf, add_noise=False, diffraction_fft=cfg, wavelength=622.2)
-    ofinal = orc.spikes(rows, rbuf.cpu().numpy())
+    image = fft_draw.image_from_rbuf(rows, rbuf.cpu().numpy())
+    ofinal = orc.spikes(rows, image)
     assert_bits_equal(final, ofinal, "spiked FFT images")
-    assert np.abs(final - np.clip(rbuf.cpu().numpy(), 0, None)).max() > 1.0      # spikes did something
-    np.testing.assert_allclose(final.sum(), np.clip(rbuf.cpu().numpy(), 0, None).sum(), rtol=0.05)
+    assert np.abs(final - np.clip(image, 0, None)).max() > 1.0      # spikes did something
+    np.testing.assert_allclose(final.sum(), np.clip(image, 0, None).sum(), rtol=0.05)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1475,7 +1519,7 @@ def test_focal_plane_ccds_hold_fft_photon_and_faint_objects(torch_cuda):
     oracle's build bit for bit once the oracle is handed the GPU's inverse transforms (rocFFT and numpy agree to ~1e-11 of the
     peak, which can move a Poisson deviate), and within the FFT tolerance when it runs its own."""
     import copy
-    from imsim_amd import focal_plane, configs, lsst_image
+    from imsim_amd import focal_plane, configs, lsst_image, fft_draw
     from imsim_amd.config import ccd_seed
     from imsim_amd.engine import Renderer
     from imsim_amd._abi import IMS_OBJ_FAINT
@@ -1498,7 +1542,8 @@ def test_focal_plane_ccds_hold_fft_photon_and_faint_objects(torch_cuda):
         assert j.n_fft == 2 and (j.objects["n_phot"] > 1_000_000).sum() == 1 and (j.objects["flags"] & IMS_OBJ_FAINT).any()
     transforms = {}
     images = focal_plane.render_focal_plane(dets, build, concurrent=3,
-                                            post=lambda det, r: transforms.__setitem__(det, r._keep_fft[1].cpu().numpy()))
+                                            post=lambda det, r: transforms.__setitem__(
+                                                det, fft_draw.image_from_rbuf(job_of(det).fft_rows, r._keep_fft[1].cpu().numpy())))
     assert sorted(images) == dets
     for det in dets:
         sc, job = build(det)

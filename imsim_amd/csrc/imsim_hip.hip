@@ -2205,20 +2205,6 @@ __device__ __forceinline__ int64_t find_prefix(const int64_t* __restrict__ prefi
     return lo;
 }
 
-// Which object element e of the back-to-back buffers belongs to: ONE bisection per wavefront (lane 0's element, its operands made
-// scalar so that the loads are scalar loads), which the other lanes only confirm -- a wavefront's 64 consecutive elements lie in one
-// object except where two meet (real-space grids are multiples of 1 024 pixels: never; half spectra: rarely), and only there does a
-// lane bisect for itself.  (Every element used to run its own 7 .. 13 dependent loads: the elementwise kernels of the branch
-// moved ~1 TB/s, round 6.)  prefix has n + 1 entries.
-__device__ __forceinline__ int64_t find_prefix_wave(const int64_t* __restrict__ prefix, int64_t n, int64_t e)
-{
-    const uint32_t lo32 = __builtin_amdgcn_readfirstlane((uint32_t)e), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(e >> 32));
-    const int64_t e0 = (int64_t)(((uint64_t)hi32 << 32) | lo32);
-    int64_t oi = find_prefix(prefix, n, e0);
-    if (e >= prefix[oi + 1]) oi = find_prefix(prefix, n, e);
-    return oi;
-}
-
 // row and column of element `local` of a grid of row length `len` (FFT sizes are powers of two: a shift; half spectra -- len =
 // nfft / 2 + 1 -- and anything else: a 32-bit division, the grids hold fewer than 2^31 elements)
 __device__ __forceinline__ void row_col(int64_t local, int len, int& row, int& col)
@@ -2226,6 +2212,33 @@ __device__ __forceinline__ void row_col(int64_t local, int len, int& row, int& c
     const uint32_t l = (uint32_t)local, n = (uint32_t)len;
     if ((n & (n - 1u)) == 0u) { const int sh = 31 - __clz((int)n); row = (int)(l >> sh); col = (int)(l & (n - 1u)); }
     else { row = (int)(l / n); col = (int)(l - (uint32_t)row * n); }
+}
+
+// The elementwise kernels of the FFT branch walk the back-to-back grids of their objects in SPANS: a workgroup owns `span` consecutive
+// elements (a multiple of 256, fft_span below), a wavefront 64 consecutive ones per pass.  The object of a wavefront's elements is
+// found ONCE per span (a bisection with scalar operands) and then only moved along when the wavefront's first element passes the
+// object's end; a wavefront that lies inside one object -- all of them but the few on a boundary -- calls the body with a UNIFORM object
+// number, so that the object's row and its prefix entry come by scalar loads.  (A grid-stride loop used to bisect in every pass: 13
+// dependent loads before the first useful one, `k_fft_finish` waited 67 % of its wave-cycles and moved 0.26 TB/s, round 6.)
+template <class Body>
+__device__ __forceinline__ void walk_span(const int64_t* __restrict__ prefix, int64_t n_objects, int64_t n_elems, int64_t span, Body&& body)
+{
+    const int64_t wg_begin = (int64_t)blockIdx.x * span;
+    int64_t wg_end = wg_begin + span;
+    if (wg_end > n_elems) wg_end = n_elems;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63u);
+    int64_t oi = -1, o_end = 0;
+    for (int64_t base = wg_begin + 64 * wave; base < wg_end; base += 256) {
+        if (oi < 0) { oi = find_prefix(prefix, n_objects, base); o_end = prefix[oi + 1]; }
+        else while (base >= o_end) { ++oi; o_end = prefix[oi + 1]; }
+        const int64_t el = base + lane;
+        if (base + 64 <= o_end) {
+            if (el < wg_end) body(el, oi);
+        } else if (el < wg_end) {
+            body(el, el < o_end ? oi : find_prefix(prefix, n_objects, el));
+        }
+    }
 }
 
 // 1 / (nfft * nfft) as ims_fft_inverse's scaling pass forms it on the host (powers of two: the exponent written directly)
@@ -2243,14 +2256,12 @@ __device__ __forceinline__ double rbuf_value(const double* __restrict__ rbuf, in
 }
 
 __global__ __launch_bounds__(256) void k_fft_kspace_fill(const ims_fft_params_t P, const ims_fft_object_t* __restrict__ objs,
-                                                         int64_t n_objects, const int64_t* __restrict__ prefix, int64_t n_elems,
+                                                         int64_t n_objects, const int64_t* __restrict__ prefix, int64_t n_elems, int64_t span,
                                                          double* __restrict__ kbuf)
 {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_elems; e += stride) {
-        const int64_t oi = find_prefix_wave(prefix, n_objects, e);
+    walk_span(prefix, n_objects, n_elems, span, [&](int64_t el, int64_t oi) {
         const ims_fft_object_t& o = objs[oi];
-        const int64_t local = e - prefix[oi];
+        const int64_t local = el - prefix[oi];
         const int nh = o.nfft / 2 + 1;
         int i, j;
         row_col(local, nh, i, j);
@@ -2258,28 +2269,26 @@ __global__ __launch_bounds__(256) void k_fft_kspace_fill(const ims_fft_params_t 
         kspace_value(P, o, i, j, re, im);
         kbuf[2 * (o.k_offset + local)] = re;
         kbuf[2 * (o.k_offset + local) + 1] = im;
-    }
+    });
 }
 
 // saturated bounding box of every object (saturated_region, imsim/diffraction_fft.py:211-227)
 __global__ __launch_bounds__(256) void k_fft_bbox(const ims_fft_params_t P, const ims_fft_object_t* __restrict__ objs,
-                                                  int64_t n_objects, const int64_t* __restrict__ prefix, int64_t n_pix,
+                                                  int64_t n_objects, const int64_t* __restrict__ prefix, int64_t n_pix, int64_t span,
                                                   const double* __restrict__ rbuf, int32_t* __restrict__ bbox)
 {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_pix; e += stride) {
-        const int64_t oi = find_prefix_wave(prefix, n_objects, e);
+    walk_span(prefix, n_objects, n_pix, span, [&](int64_t el, int64_t oi) {
         const ims_fft_object_t& o = objs[oi];
-        const int64_t local = e - prefix[oi];
+        const int64_t local = el - prefix[oi];
         int iy, ix;
         row_col(local, o.nfft, iy, ix);
         const int px = o.x0 + ix, py = o.y0 + iy;
-        if (px < o.stamp_xmin || px > o.stamp_xmax || py < o.stamp_ymin || py > o.stamp_ymax) continue;
+        if (px < o.stamp_xmin || px > o.stamp_xmax || py < o.stamp_ymin || py > o.stamp_ymax) return;
         if (rbuf_value(rbuf, o.r_offset + local, P.rbuf_raw != 0, inv_n2(o.nfft)) > P.spikes.threshold) {
             atomicMin(&bbox[4 * oi + 0], iy); atomicMax(&bbox[4 * oi + 1], iy);
             atomicMin(&bbox[4 * oi + 2], ix); atomicMax(&bbox[4 * oi + 3], ix);
         }
-    }
+    });
 }
 
 // ims_spikes_t.tab_*: one thread per row a of the stencil; b from +cutoff down to -cutoff.  row_ptr == NULL: count only.
@@ -2302,15 +2311,13 @@ __global__ __launch_bounds__(64) void k_fft_spike_table(const ims_spikes_t k, co
 
 // convolve_region (imsim/diffraction_fft.py:170-208): clipped image with the box zeroed + box (x) stencil
 __global__ __launch_bounds__(256) void k_fft_spikes(const ims_fft_params_t P, const ims_fft_object_t* __restrict__ objs,
-                                                    int64_t n_objects, const int64_t* __restrict__ prefix, int64_t n_pix,
+                                                    int64_t n_objects, const int64_t* __restrict__ prefix, int64_t n_pix, int64_t span,
                                                     const double* __restrict__ rin, double* __restrict__ rout,
                                                     const int32_t* __restrict__ bbox)
 {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_pix; e += stride) {
-        const int64_t oi = find_prefix_wave(prefix, n_objects, e);
+    walk_span(prefix, n_objects, n_pix, span, [&](int64_t el, int64_t oi) {
         const ims_fft_object_t& o = objs[oi];
-        const int64_t local = e - prefix[oi];
+        const int64_t local = el - prefix[oi];
         int iy, ix;
         row_col(local, o.nfft, iy, ix);
         const bool raw = P.rbuf_raw != 0;
@@ -2412,31 +2419,29 @@ __global__ __launch_bounds__(256) void k_fft_spikes(const ims_fft_params_t P, co
             v = v + acc;
         }
         rout[o.r_offset + local] = v;
-    }
+    });
 }
 
 // clip, Poisson noise, stamp -> CCD add (stamp.py:519-524); realized flux = noise-free sum inside the stamp
 __global__ __launch_bounds__(256) void k_fft_finish(const ims_fft_params_t P, const ims_fft_object_t* __restrict__ objs,
-                                                    int64_t n_objects, const int64_t* __restrict__ prefix, int64_t n_pix,
+                                                    int64_t n_objects, const int64_t* __restrict__ prefix, int64_t n_pix, int64_t span,
                                                     const double* __restrict__ rbuf)
 {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_pix; e += stride) {
-        const int64_t oi = find_prefix_wave(prefix, n_objects, e);
+    walk_span(prefix, n_objects, n_pix, span, [&](int64_t el, int64_t oi) {
         const ims_fft_object_t& o = objs[oi];
-        const int64_t local = e - prefix[oi];
+        const int64_t local = el - prefix[oi];
         int iy, ix;
         row_col(local, o.nfft, iy, ix);
         const int px = o.x0 + ix, py = o.y0 + iy;
-        if (px < o.stamp_xmin || px > o.stamp_xmax || py < o.stamp_ymin || py > o.stamp_ymax) continue;
+        if (px < o.stamp_xmin || px > o.stamp_xmax || py < o.stamp_ymin || py > o.stamp_ymax) return;
         double v = rbuf_value(rbuf, o.r_offset + local, P.rbuf_raw != 0, inv_n2(o.nfft));
         if (v < 0.0) v = 0.0;
         if (P.realized_flux != nullptr && v != 0.0) unsafeAtomicAdd(P.realized_flux + oi, v);
         if (P.add_noise) v = poisson(v, P.seed, o.obj_id, local);
         const int cxp = px - P.xmin, cyp = py - P.ymin;
-        if (cxp < 0 || cxp >= P.nx || cyp < 0 || cyp >= P.ny || v == 0.0) continue;
+        if (cxp < 0 || cxp >= P.nx || cyp < 0 || cyp >= P.ny || v == 0.0) return;
         unsafeAtomicAdd(P.image + ((int64_t)cyp * P.nx + cxp), v);
-    }
+    });
 }
 
 // ---------------- CCD readout (imsim/readout.py:413-478, imsim/bleed_trails.py) ----------------
@@ -4423,6 +4428,18 @@ int ims_allreduce_delta(void* comm, double* delta_dev, int32_t* scratch_i32_dev,
     return exchange(comm, delta_dev, scratch_i32_dev, n, -1, integer_counts, stream);
 }
 
+// a workgroup's share of the elements of an elementwise FFT kernel (walk_span): at least 4 096 workgroups where the elements allow it
+// (256 CUs x 16), at most 8 192 elements each (32 passes per lookup of the object; short enough that a star's core rows, where a
+// pixel costs many times a pixel of the wings, spread over many workgroups)
+struct FftSpan { int64_t span; unsigned grid; };
+static FftSpan fft_span(int64_t n)
+{
+    int64_t span = ((n + 4095) / 4096 + 255) / 256 * 256;
+    if (span < 256) span = 256;
+    if (span > 8192) span = 8192;
+    return { span, (unsigned)((n + span - 1) / span) };
+}
+
 int ims_fft_kspace_fill(const ims_fft_params_t* params, const ims_fft_object_t* objects_dev, int64_t n_objects,
                         const int64_t* elem_prefix_dev, int64_t n_elems, double* kbuf, void* stream)
 {
@@ -4431,8 +4448,9 @@ int ims_fft_kspace_fill(const ims_fft_params_t* params, const ims_fft_object_t* 
     if (n_objects <= 0 || n_elems <= 0) return IMS_OK;
     {
         LaunchTimer tm((hipStream_t)stream, 3);
-        hipLaunchKernelGGL(k_fft_kspace_fill, dim3(grid_for_pool(n_elems)), dim3(256), 0, (hipStream_t)stream, *params, objects_dev,
-                           n_objects, elem_prefix_dev, n_elems, kbuf);
+        const FftSpan sp = fft_span(n_elems);
+        hipLaunchKernelGGL(k_fft_kspace_fill, dim3(sp.grid), dim3(256), 0, (hipStream_t)stream, *params, objects_dev,
+                           n_objects, elem_prefix_dev, n_elems, sp.span, kbuf);
     }
     HIP_TRY(hipGetLastError());
     return IMS_OK;
@@ -4466,11 +4484,12 @@ int ims_fft_spikes(const ims_fft_params_t* params, const ims_fft_object_t* objec
     if (n_objects <= 0 || n_pix <= 0) return IMS_OK;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_fill_bbox, dim3((unsigned)((n_objects + 255) / 256)), dim3(256), 0, st, bbox_dev, n_objects);
+    const FftSpan sp = fft_span(n_pix);
     if (params->spikes.enabled)
-        hipLaunchKernelGGL(k_fft_bbox, dim3(grid_for_pool(n_pix)), dim3(256), 0, st, *params, objects_dev, n_objects,
-                           pix_prefix_dev, n_pix, rbuf_in, bbox_dev);
-    hipLaunchKernelGGL(k_fft_spikes, dim3(grid_for_pool(n_pix)), dim3(256), 0, st, *params, objects_dev, n_objects,
-                       pix_prefix_dev, n_pix, rbuf_in, rbuf_out, (const int32_t*)bbox_dev);
+        hipLaunchKernelGGL(k_fft_bbox, dim3(sp.grid), dim3(256), 0, st, *params, objects_dev, n_objects,
+                           pix_prefix_dev, n_pix, sp.span, rbuf_in, bbox_dev);
+    hipLaunchKernelGGL(k_fft_spikes, dim3(sp.grid), dim3(256), 0, st, *params, objects_dev, n_objects,
+                       pix_prefix_dev, n_pix, sp.span, rbuf_in, rbuf_out, (const int32_t*)bbox_dev);
     HIP_TRY(hipGetLastError());
     return IMS_OK;
 }
@@ -4481,8 +4500,9 @@ int ims_fft_finish(const ims_fft_params_t* params, const ims_fft_object_t* objec
     if (!params || !objects_dev || !pix_prefix_dev || !rbuf) return set_err(IMS_ERR_ARG, "NULL argument");
     if (!params->image) return set_err(IMS_ERR_ARG, "image is NULL");
     if (n_objects <= 0 || n_pix <= 0) return IMS_OK;
-    hipLaunchKernelGGL(k_fft_finish, dim3(grid_for_pool(n_pix)), dim3(256), 0, (hipStream_t)stream, *params, objects_dev,
-                       n_objects, pix_prefix_dev, n_pix, rbuf);
+    const FftSpan sp = fft_span(n_pix);
+    hipLaunchKernelGGL(k_fft_finish, dim3(sp.grid), dim3(256), 0, (hipStream_t)stream, *params, objects_dev,
+                       n_objects, pix_prefix_dev, n_pix, sp.span, rbuf);
     HIP_TRY(hipGetLastError());
     return IMS_OK;
 }

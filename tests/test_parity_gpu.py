@@ -800,7 +800,9 @@ def test_fft_inverse_left_unnormalised_for_its_readers_gives_the_same_images(tor
     rows["flux"] *= 20.0
     odd = rows[:1].copy()
     odd["nfft"] = 96                                        # 3 * 32: not a power of two
-    rows = np.concatenate([odd, rows])
+    small = rows[:1].copy()
+    small["nfft"] = 32                                      # (half spectra of 32 x 17 and 96 x 49 elements: wavefronts of the
+    rows = np.concatenate([small, odd, rows])               # elementwise kernels straddle two objects there, walk_span's lane path)
     rows = rows[np.argsort(rows["nfft"], kind="stable")]
     nf = rows["nfft"].astype(np.int64)
     rows["k_offset"] = np.concatenate([[0], np.cumsum(nf * (nf // 2 + 1))])[:-1]
@@ -815,8 +817,17 @@ def test_fft_inverse_left_unnormalised_for_its_readers_gives_the_same_images(tor
             r = Renderer(scene)
             real = torch.zeros(len(rows), dtype=torch.float64, device="cuda")
             drawer = fft_draw.FftDrawer(r, kpsf, add_noise=True, diffraction_fft=spikes, wavelength=622.2)
+            drawer.keep_kspace = True
             kbuf, rbuf = drawer.draw(rows, realized=real)
             r.synchronize()
+            if raw == "1":
+                # the oracle on the same rows: half spectra bit for bit, and from the GPU's own transforms the same CCD image
+                from oracle import orc_loader
+                orc = orc_loader.OracleFft(scene, kpsf, add_noise=True, diffraction_fft=spikes, wavelength=622.2)
+                assert_bits_equal(kbuf.cpu().numpy(), orc.fill(rows), "k-space half spectra (grids of 32, 96 and powers of two)")
+                image = fft_draw.image_from_rbuf(rows, rbuf.cpu().numpy())
+                orc.finish(rows, orc.spikes(rows, image) if spikes is not None else image, np.zeros(len(rows)))
+                assert_bits_equal(r.image_numpy(), orc.image.astype(np.float32), "CCD image vs the oracle")
             got[raw] = (fft_draw.image_from_rbuf(rows, rbuf.cpu().numpy()), drawer._last[2].cpu().numpy().copy(), r.image64_numpy(),
                         real.cpu().numpy())
         assert np.abs(got["1"][0]).max() > 1e5 and got["1"][2].sum() > 0

@@ -22,6 +22,9 @@ from .engine import Renderer
 
 
 _ANCHOR_STREAMS = {}
+_HOST_IMAGES = {}           # (device, image shape) -> {"free": page-locked float32 buffers not in use, "made": how many exist}: kept for the
+                            # life of the process -- page-locking 67 MB costs ~5 ms, and a step that runs short of buffers at its end (the
+                            # last batches' images queue up behind PCIe) used to make twenty of them there: 1.30 instead of 1.15 s, one step in three
 _ARENA_BYTES = {}           # device -> bytes of the sensor arena this process holds there (they count as usable when it is re-sized)
 
 
@@ -125,7 +128,8 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
                 joint = max(fit, 1)
     render_focal_plane.last_joint_batch = joint
     render_focal_plane.last_arena_gib = arena.nbytes() / 2.0**30 if arena is not None else 0.0
-    pinned_pool = []
+    host_cap = max(int(tuning.env("IMS_FOCAL_PINNED")), 2)       # page-locked image buffers in flight at most
+    inflight = []                                                # entries whose tails are enqueued and whose images are not handed on yet, oldest first
     out = {}
     host_s = [0.0]
     n_joint = [0]
@@ -215,33 +219,52 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
     def tail(entries):
         # shortest chain first: mid must not sit behind the batch's longest chain while the others' images wait
         for e in sorted(entries, key=lambda e: e["plan"].sizes.n_round_launches if e["plan"] is not None else 0):
+            t_tail = time.perf_counter()
+            host = host_image(tuple(e["renderer"].image.shape))       # (may hand an older image on first: not under `mid`)
+            t_buf = time.perf_counter()
             with torch.cuda.stream(mid):
                 e["fin"]()
-                shape = tuple(e["renderer"].image.shape)
-                host = pinned_pool.pop() if pinned_pool else torch.empty(shape, dtype=torch.float32, pin_memory=True)
-                if tuple(host.shape) != shape:
-                    host = torch.empty(shape, dtype=torch.float32, pin_memory=True)
                 # (the image rounded straight into the page-locked buffer by one small launch instead of float copy + transfer was
                 # measured twice in round 5: 1.91 against 1.78 s, 1.48 against 1.31 s; removed)
                 host.copy_(e["renderer"].image_float(), non_blocking=True)
                 done = torch.cuda.Event(enable_timing=trace is not None)
                 done.record(mid)
             e["host"], e["done"] = host, done
+            inflight.append(e)
             if trace is not None:
                 e["trace"]["done"] = done
+                e["trace"]["tail_host"] = (t_tail, t_buf, time.perf_counter())
+
+    def host_image(shape):
+        """a page-locked float32 buffer for one CCD image: a free one, a new one while fewer than IMS_FOCAL_PINNED exist, else the
+        buffer of the oldest image in flight once that image has been handed on (PCIe is busy with it or behind it anyway)"""
+        pool = _HOST_IMAGES.setdefault((str(dev), shape), {"free": [], "made": 0})
+        while not pool["free"] and pool["made"] >= host_cap and inflight:
+            collect_one(inflight[0])
+        if pool["free"]:
+            return pool["free"].pop()
+        pool["made"] += 1
+        return torch.empty(shape, dtype=torch.float32, pin_memory=True)
+
+    def collect_one(e):
+        if e.get("collected"):
+            return
+        e["done"].synchronize()
+        if post is not None:
+            post(e["key"], e["renderer"])
+        if sink is not None:
+            sink(e["key"], e["host"].numpy())
+        else:
+            out[e["key"]] = e["host"].numpy().copy()
+        _HOST_IMAGES[(str(dev), tuple(e["host"].shape))]["free"].append(e["host"])
+        e["renderer"].release_state()          # everything of this CCD has run (its image is on the host): its cells go back
+        inflight.remove(e)
+        e.clear()                              # drops the renderer: its HBM goes back to the caching allocator
+        e["collected"] = True
 
     def collect(entries):
-        for e in sorted(entries, key=lambda e: e["plan"].sizes.n_round_launches if e["plan"] is not None else 0):
-            e["done"].synchronize()
-            if post is not None:
-                post(e["key"], e["renderer"])
-            if sink is not None:
-                sink(e["key"], e["host"].numpy())
-            else:
-                out[e["key"]] = e["host"].numpy().copy()
-            pinned_pool.append(e["host"])
-            e["renderer"].release_state()          # everything of this CCD has run (its image is on the host): its cells go back
-            e.clear()                              # drops the renderer: its HBM goes back to the caching allocator
+        for e in sorted(entries, key=lambda e: (e["plan"].sizes.n_round_launches if e["plan"] is not None else 0) if not e.get("collected") else -1):
+            collect_one(e)
 
     # The pipeline.  Per batch: the fronts of its CCDs (this thread, paced) | the joint runs of its chain classes -- the middle and
     # low classes on `mid`, the top class on the joint stream: thousands of short launches, 5 .. 90 ms of host time per batch,
@@ -312,7 +335,7 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
             tail(b["entries"])
             awaiting.append(b["entries"])
             rounds.pop(0)
-        while awaiting and all(e["done"].query() for e in awaiting[0]):
+        while awaiting and all(e.get("collected") or e["done"].query() for e in awaiting[0]):
             collect(awaiting.pop(0))
 
     def alive_batches():
@@ -359,10 +382,28 @@ def _render_joint(mine, build, dev, nrecalc, sink, post, joint, chain_hint):
             g = {k: t_base.elapsed_time(v) for k, v in t["marks"].items()}
             print(f"  CCD {t['key']:4d} host {1e3 * (t['host0'] - h_base):8.1f} {1e3 * (t['host1'] - h_base):8.1f} | bulk {g['bulk']:8.1f} pre {g['pre']:8.1f} "
                   f"mid {g['mid']:8.1f} | joint end {t_base.elapsed_time(t['joint_end']):8.1f} (enqueued {1e3 * (t['host_joint'] - h_base):8.1f}) "
-                  f"done {t_base.elapsed_time(t['done']):8.1f}")
+                  f"done {t_base.elapsed_time(t['done']):8.1f} | tail enqueued {1e3 * (t['tail_host'][0] - h_base):8.1f} buffer {1e3 * (t['tail_host'][1] - t['tail_host'][0]):6.2f} "
+                  f"rest {1e3 * (t['tail_host'][2] - t['tail_host'][1]):6.2f}")
     render_focal_plane.last_host_ms_per_ccd = 1e3 * host_s[0] / max(len(mine), 1)
     render_focal_plane.last_joint_plans = n_joint[0]          # CCDs whose top chain ran in joint launches
     return out
+
+
+def reserve_host_images(device, shape, count=None):
+    """Make the page-locked float32 buffers a focal plane's images travel through (up to IMS_FOCAL_PINNED of them) NOW, one after
+    the other in a quiet moment, instead of one by one while the visit runs: the pages of a buffer made under load came out
+    scattered often enough that a third of the steps ended with twenty image copies at 12 GB/s instead of 52 (round 6,
+    tools/dbg/pinned_rate.py: made in a row, 48 of 48 buffers copy at full rate).  ~3 ms per 64-MiB buffer; kept for the life of the
+    process.  Returns how many exist."""
+    import torch
+    dev = torch.device(device)
+    shape = tuple(int(v) for v in shape)
+    want = max(int(tuning.env("IMS_FOCAL_PINNED")), 2) if count is None else int(count)
+    pool = _HOST_IMAGES.setdefault((str(dev), shape), {"free": [], "made": 0})
+    while pool["made"] < want:
+        pool["free"].append(torch.empty(shape, dtype=torch.float32, pin_memory=True))
+        pool["made"] += 1
+    return pool["made"]
 
 
 def warm_fft(device="cuda:0"):

@@ -35,6 +35,8 @@ KNOWN = {
                                  "(one atomic add per photon; Silicon's target += delta); 0 = image and delta image both"),
     "IMS_SPIKE_TABLE": ("1", "FFT branch: the non-zero entries of the spike stencil from a table made once per visit (ims_fft_spike_table); "
                              "0 = every stencil value evaluated in place"),
+    "IMS_FOCAL_PINNED": ("64", "focal plane: page-locked float32 image buffers (67 MB each for a 4096 x 4096 CCD) in flight at most; kept for "
+                               "the life of the process"),
     "IMS_FFT_RAW": ("1", "FFT branch: the inverse transform's 1 / N^2 applied by the kernel that reads the real-space buffer next "
                          "(ims_fft_inverse_raw + ims_fft_params_t.rbuf_raw); 0 = a scaling pass of its own (the same bits)"),
     "IMS_SCREEN_PREPASS": ("0", "phase-screen gathers ahead of the shooting kernels (1: every photon, 2: ordinary objects on a side stream)"),

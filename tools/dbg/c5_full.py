@@ -18,6 +18,8 @@ phot = catalog.realize_fluxes(cat["nominal_flux"], scene.seed)
 objects, _ = configs._c5_objects(cat, phot, scene)
 r = Renderer(scene, "cuda:0")
 step = configs._c5_step(r, objects, concurrent=4)
+if os.environ.get("R6_RESERVE"):
+    print("reserved", focal_plane.reserve_host_images("cuda:0", (4096, 4096), int(os.environ["R6_RESERVE"])))
 torch.cuda.synchronize()
 print(f"set-up {time.perf_counter() - t00:.1f} s", flush=True)
 tag = " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("IMS_"))

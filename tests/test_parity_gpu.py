@@ -802,7 +802,11 @@ def test_fft_inverse_left_unnormalised_for_its_readers_gives_the_same_images(tor
     odd["nfft"] = 96                                        # 3 * 32: not a power of two
     small = rows[:1].copy()
     small["nfft"] = 32                                      # (half spectra of 32 x 17 and 96 x 49 elements: wavefronts of the
-    rows = np.concatenate([small, odd, rows])               # elementwise kernels straddle two objects there, walk_span's lane path)
+    tiny = rows[:2].copy()                                  # elementwise kernels straddle two objects there, walk_span's lane path;
+    tiny["nfft"] = (6, 10)                                  # grids of 36 and 100 PIXELS: the same for the real-space kernels)
+    tiny["x0"], tiny["y0"] = tiny["stamp_xmin"] + 20, tiny["stamp_ymin"] + 20
+    tiny["cx"], tiny["cy"] = 2.3, 3.1
+    rows = np.concatenate([tiny, small, odd, rows])
     rows = rows[np.argsort(rows["nfft"], kind="stable")]
     nf = rows["nfft"].astype(np.int64)
     rows["k_offset"] = np.concatenate([[0], np.cumsum(nf * (nf // 2 + 1))])[:-1]

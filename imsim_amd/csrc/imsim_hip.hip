@@ -2255,10 +2255,41 @@ __device__ __forceinline__ double rbuf_value(const double* __restrict__ rbuf, in
     return raw ? v * scale : v;
 }
 
+// LDS tables of the pixel response for a workgroup whose span lies inside ONE object's half spectrum (every workgroup of a grid of
+// 1 024 or more): sinc along x for every column of the row, sinc along y (for ky and for -ky) for the few rows the span covers.
+constexpr int FILL_NH_MAX = 2049, FILL_ROWS_MAX = 264;      // grids up to 4096 (larger ones: no tables); 20 KB of LDS
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_fft_kspace_fill(const ims_fft_params_t P, const ims_fft_object_t* __restrict__ objs,
                                                          int64_t n_objects, const int64_t* __restrict__ prefix, int64_t n_elems, int64_t span,
                                                          double* __restrict__ kbuf)
 {
+    __shared__ double sinc_x[FILL_NH_MAX];
+    __shared__ double sinc_y[2 * FILL_ROWS_MAX];
+    // (uniform over the workgroup: formed from the block's number and scalar loads)
+    const int64_t wg_begin = (int64_t)blockIdx.x * span;
+    int64_t wg_end = wg_begin + span;
+    if (wg_end > n_elems) wg_end = n_elems;
+    bool tables = false;
+    int row_first = 0;
+    if (P.n_alias <= 0 && wg_begin < wg_end) {
+        const int64_t o0 = find_prefix(prefix, n_objects, wg_begin);
+        const int64_t ob = prefix[o0];
+        if (wg_end <= prefix[o0 + 1]) {
+            const int n = objs[o0].nfft, nh = n / 2 + 1, half = n / 2;
+            row_first = (int)((wg_begin - ob) / nh);
+            const int row_last = (int)((wg_end - 1 - ob) / nh);
+            if (row_first > half) return;              // rows written by the threads of their mirror rows
+            if (nh <= FILL_NH_MAX && row_last - row_first + 1 <= FILL_ROWS_MAX) {
+                const double dk = TWO_PI / ((double)n * P.pixel_scale);
+                for (int j = threadIdx.x; j < nh; j += 256) sinc_x[j] = pixel_response((double)j * dk, P.pixel_scale);
+                for (int r = threadIdx.x; r < 2 * (row_last - row_first + 1); r += 256) {
+                    const double ky = (double)(row_first + (r >> 1)) * dk;
+                    sinc_y[r] = pixel_response((r & 1) ? -ky : ky, P.pixel_scale);
+                }
+                tables = true;
+                __syncthreads();
+            }
+        }
+    }
     walk_span(prefix, n_objects, n_elems, span, [&](int64_t el, int64_t oi) {
         const ims_fft_object_t& o = objs[oi];
         const int64_t local = el - prefix[oi];
@@ -2274,7 +2305,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             if (i > 0 && i < half) {
                 const double dk = TWO_PI / ((double)n * P.pixel_scale);
                 double re2, im2;
-                kspace_pair(P, o, (double)j * dk, (double)i * dk, re, im, re2, im2);
+                if (tables) {
+                    const double tab[3] = { sinc_x[j], sinc_y[2 * (i - row_first)], sinc_y[2 * (i - row_first) + 1] };
+                    kspace_pair(P, o, (double)j * dk, (double)i * dk, re, im, re2, im2, tab);
+                } else {
+                    kspace_pair(P, o, (double)j * dk, (double)i * dk, re, im, re2, im2);
+                }
                 const int64_t at2 = o.k_offset + (int64_t)(n - i) * nh + j;
                 kbuf[2 * (o.k_offset + local)] = re;
                 kbuf[2 * (o.k_offset + local) + 1] = im;

@@ -2577,7 +2577,15 @@ __global__ __launch_bounds__(256) void k_readout_bleed(double* __restrict__ imag
     int y = span[4 * x + 2 * half];
     const int y_last = span[4 * x + 2 * half + 1];
     while (y <= y_last) {
-        if (!f[(int64_t)y * nx]) { ++y; continue; }
+        // the way to the next saturated row, eight rows' flags at a time (independent loads: the walk used to wait for every
+        // single byte before it asked for the next)
+        unsigned char fl[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) fl[q] = (y + q <= y_last) ? f[(int64_t)(y + q) * nx] : (unsigned char)0;
+        int skip = 0;
+        while (skip < 8 && !fl[skip]) ++skip;
+        y += skip;
+        if (skip == 8) continue;
         const int y0 = y;
         while (y < n && f[(int64_t)y * nx]) ++y;
         const int y1 = y;
@@ -2604,26 +2612,38 @@ __device__ __forceinline__ float amp_adu(const double* __restrict__ image, int n
 }
 
 // grid (raw_w / 64, raw_h / 4, n_amps), block (64, 4)
+// grid (raw_w / 64, raw_h / 4), block (64, 4): a thread forms position (rx, ry) of ALL amplifiers' raw segments -- crosstalk makes every
+// amplifier's pixel there a sum over the sixteen pixels at that position, which were read sixteen times (once per output amplifier:
+// 2.1 GB for a 131-MB image) and are read once now; the sums are the same sums (ascending source amplifier, zero coefficients skipped)
 __global__ __launch_bounds__(256) void k_readout_segments(const double* __restrict__ image, int nx, const ims_readout_t ro,
                                                           float* __restrict__ seg)
 {
     const int rx = blockIdx.x * 64 + threadIdx.x, ry = blockIdx.y * 4 + threadIdx.y;
     if (rx >= ro.raw_w || ry >= ro.raw_h) return;
-    const int a = blockIdx.z;
     const int u = rx - ro.data_x0, v = ry - ro.data_y0;
-    float out = 0.0f;
-    if (u >= 0 && u < ro.seg_w && v >= 0 && v < ro.seg_h) {
-        out = amp_adu(image, nx, ro, a, u, v);
-        if (ro.has_xtalk) {
-            float sum = 0.0f;
-            for (int j = 0; j < ro.n_amps; ++j) {
-                const float x = ro.xtalk[a * IMS_MAX_AMPS + j];
-                if (x != 0.0f) sum = sum + x * amp_adu(image, nx, ro, j, u, v);     // a zero coefficient adds exactly nothing
+    const bool inside = u >= 0 && u < ro.seg_w && v >= 0 && v < ro.seg_h;
+    float e[IMS_MAX_AMPS];
+#pragma unroll
+    for (int a = 0; a < IMS_MAX_AMPS; ++a) e[a] = (inside && a < ro.n_amps) ? amp_adu(image, nx, ro, a, u, v) : 0.0f;
+#pragma unroll
+    for (int a = 0; a < IMS_MAX_AMPS; ++a) {
+        if (a >= ro.n_amps) break;
+        float out = 0.0f;
+        if (inside) {
+            out = e[a];
+            if (ro.has_xtalk) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < IMS_MAX_AMPS; ++j) {
+                    if (j >= ro.n_amps) break;
+                    const float x = ro.xtalk[a * IMS_MAX_AMPS + j];
+                    if (x != 0.0f) sum = sum + x * e[j];          // a zero coefficient adds exactly nothing
+                }
+                out = out + sum;
             }
-            out = out + sum;
         }
+        seg[((int64_t)a * ro.raw_h + ry) * ro.raw_w + rx] = out;
     }
-    seg[((int64_t)a * ro.raw_h + ry) * ro.raw_w + rx] = out;
 }
 
 // grid (raw_w / 64, raw_h / 4, n_amps), block (64, 4): a wavefront is 64 neighbouring columns of one row, so every tap
@@ -2636,24 +2656,71 @@ __global__ __launch_bounds__(256) void k_readout_cte(const float* __restrict__ s
                                                      const double* __restrict__ band, int n_band, int axis)
 {
     const int rx = blockIdx.x * 64 + threadIdx.x, ry = blockIdx.y * 4 + threadIdx.y;
+    // serial direction: every lane has a row of weights of its own (its column's) -- the workgroup's 64 rows of weights are one
+    // contiguous piece of the band matrix, staged through LDS once instead of 21 scattered 8-byte loads per lane and row
+    __shared__ double wl[64 * (NB > 0 ? NB : 1)];
+    const bool staged = NB > 0 && axis == 1;
+    if (staged) {
+        const int i0 = blockIdx.x * 64;
+        for (int e = threadIdx.y * 64 + threadIdx.x; e < 64 * NB; e += 256)
+            wl[e] = (i0 + e / NB < raw_w) ? band[(int64_t)i0 * NB + e] : 0.0;
+        __syncthreads();
+    }
     if (rx >= raw_w || ry >= raw_h) return;
     const int p = ((int)blockIdx.z * raw_h + ry) * raw_w + rx;
     const int i = axis == 0 ? ry : rx;
     const int step = axis == 0 ? raw_w : 1;
     const int dmax = i < n_band - 1 ? i : n_band - 1;
     const double* w = band + i * n_band;
+    const double* ws = wl + threadIdx.x * (NB > 0 ? NB : 1);
     double acc = 0.0;
     if (NB > 0 && i >= NB - 1) {
         float v[NB > 0 ? NB : 1];
         double ww[NB > 0 ? NB : 1];
 #pragma unroll
-        for (int d = 0; d < NB; ++d) { v[d] = src[p - d * step]; ww[d] = w[d]; }
+        for (int d = 0; d < NB; ++d) v[d] = src[p - d * step];
+        if (staged) {
+#pragma unroll
+            for (int d = 0; d < NB; ++d) ww[d] = ws[d];
+        } else {
+#pragma unroll
+            for (int d = 0; d < NB; ++d) ww[d] = w[d];
+        }
 #pragma unroll
         for (int d = NB - 1; d >= 0; --d) acc = acc + ww[d] * (double)v[d];
+    } else if (staged) {
+        for (int d = dmax; d >= 0; --d) acc = acc + ws[d] * (double)src[p - d * step];
     } else {
         for (int d = dmax; d >= 0; --d) acc = acc + w[d] * (double)src[p - d * step];
     }
     dst[p] = (float)acc;
+}
+
+// The read-noise deviates of pixels 2 m and 2 m + 1 of an amplifier are the two Gaussians of ONE counter block: a thread forms the
+// block once and finishes both pixels (segments of an even number of pixels; the single-pixel kernel below did the block twice).
+__global__ __launch_bounds__(256) void k_readout_finish_pairs(const float* __restrict__ seg, const ims_readout_t ro, uint64_t seed,
+                                                              int32_t* __restrict__ out)
+{
+    const int64_t per = (int64_t)ro.raw_w * ro.raw_h;
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // pair number over all amplifiers
+    if (2 * m >= per * ro.n_amps) return;
+    const int64_t p = 2 * m;
+    const int a = (int)(p / per);
+    const int64_t q = p - (int64_t)a * per;                                 // even
+    typedef float fvec2 __attribute__((ext_vector_type(2)));
+    typedef int ivec2 __attribute__((ext_vector_type(2)));
+    const fvec2 sv = *(const fvec2*)(seg + p);
+    Rng r;
+    rng_reset(r);
+    rng_block(r, seed, READOUT_ID_BASE + a, q >> 1, 0u);
+    double g0, g1;
+    gauss_words(r.w[0], r.w[1], g0, g1);
+    float v0 = sv.x + ro.amps[a].bias_level, v1 = sv.y + ro.amps[a].bias_level;
+    v0 = v0 + (float)((double)ro.amps[a].read_noise * g0);
+    v1 = v1 + (float)((double)ro.amps[a].read_noise * g1);
+    ivec2 o;
+    o.x = (int32_t)v0; o.y = (int32_t)v1;
+    *(ivec2*)(out + p) = o;
 }
 
 __global__ __launch_bounds__(256) void k_readout_finish(const float* __restrict__ seg, const ims_readout_t ro, uint64_t seed,
@@ -4760,7 +4827,7 @@ int ims_readout_segments(const double* image_dev, int32_t nx, int32_t ny, const 
     for (int a = 0; a < ro->n_amps; ++a)
         if (ro->amps[a].x0 < 0 || ro->amps[a].y0 < 0 || ro->amps[a].x0 + ro->seg_w > nx || ro->amps[a].y0 + ro->seg_h > ny)
             return set_err(IMS_ERR_ARG, "amplifier section outside the e-image");
-    hipLaunchKernelGGL(k_readout_segments, dim3((unsigned)((ro->raw_w + 63) / 64), (unsigned)((ro->raw_h + 3) / 4), (unsigned)ro->n_amps),
+    hipLaunchKernelGGL(k_readout_segments, dim3((unsigned)((ro->raw_w + 63) / 64), (unsigned)((ro->raw_h + 3) / 4), 1u),
                        dim3(64, 4), 0, (hipStream_t)stream, image_dev, nx, *ro, seg_dev);
     HIP_TRY(hipGetLastError());
     return IMS_OK;
@@ -4790,8 +4857,12 @@ int ims_readout_finish(const float* seg_dev, const ims_readout_t* ro, uint64_t s
     if (int e = check_readout(ro)) return e;
     if (!seg_dev || !out_dev) return set_err(IMS_ERR_ARG, "segments / output is NULL");
     const int64_t n = (int64_t)ro->raw_w * ro->raw_h * ro->n_amps;
-    hipLaunchKernelGGL(k_readout_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seg_dev, *ro, seed,
-                       out_dev);
+    if ((((int64_t)ro->raw_w * ro->raw_h) & 1) == 0 && (((uintptr_t)seg_dev | (uintptr_t)out_dev) & 7u) == 0)
+        hipLaunchKernelGGL(k_readout_finish_pairs, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seg_dev, *ro,
+                           seed, out_dev);
+    else
+        hipLaunchKernelGGL(k_readout_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seg_dev, *ro, seed,
+                           out_dev);
     HIP_TRY(hipGetLastError());
     return IMS_OK;
 }

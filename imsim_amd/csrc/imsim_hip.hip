@@ -2363,11 +2363,127 @@ __global__ __launch_bounds__(64) void k_fft_spike_table(const ims_spikes_t k, co
 }
 
 // convolve_region (imsim/diffraction_fft.py:170-208): clipped image with the box zeroed + box (x) stencil
+// Far from the arms of EVERY source pixel's cross the whole spike sum of a pixel is exact zeros: the offsets from the pixel to the
+// sources differ from the offset to the box centre by at most half the box, so if even the nearer arm of the centre's cross is
+// further away than that (plus the stencil's own margins, ims_fft.h spike_stencil), no term can be non-zero.  97 % of a 4096^2 stamp.
+__device__ __forceinline__ bool spike_sum_is_zero(const ims_spikes_t& k, int iy, int ix, int r0, int r1, int c0, int c1)
+{
+    const double ac = (double)iy - 0.5 * (double)(r0 + r1), bc = (double)ix - 0.5 * (double)(c0 + c1);
+    const double ha = 0.5 * (double)(r1 - r0), hb = 0.5 * (double)(c1 - c0);
+    const double e = fabs(k.cos0) * ha + fabs(k.sin0) * hb + fabs(k.sin0) * ha + fabs(k.cos0) * hb;
+    const double xc = k.cos0 * ac + k.sin0 * bc, yc = -k.sin0 * ac + k.cos0 * bc;
+    const double mc = (fabs(xc) < fabs(yc) ? fabs(xc) : fabs(yc)) - e;
+    const double rmax = sqrt(ac * ac + bc * bc) + sqrt(ha * ha + hb * hb) + 1.0;
+    const double lim = 0.5 * fabs(k.d_alpha) + 1.0e-6;
+    return mc > 1.0 + 1.0e-3 && mc - 1.0e-3 > lim * rmax;
+}
+
+// the spike sum of pixel (iy, ix) of object o over the saturated box rows r0 .. r1, columns c0 .. c1 (DiffractionFFT.apply's convolution)
+__device__ __forceinline__ double spike_sum(const ims_fft_params_t& P, const ims_fft_object_t& o, int iy, int ix, int r0, int r1, int c0,
+                                            int c1, const double* __restrict__ rin, bool raw, double scale)
+{
+    double acc = 0.0;
+    if (P.spikes.tab_row != nullptr) {
+        // The stencil's non-zero entries come out of the visit's table (ims_spikes_t.tab_*): of source row ry the entries of
+        // stencil row a = iy - ry whose column offset b puts the source column ix - b inside the box, in ascending source
+        // column -- the terms the loops below find among their candidates, in the same order, each formed by the same
+        // operations (stencil / norm in the table's kernel, times the source here), without the three arctangents per term
+        // and the ~16 candidates per row: the same sum.  (A star's spike stencil was 1.1 ms of a CCD's front, round 6.)
+        // The walk is a chain of dependent loads (row pointer -> column offsets -> source pixels) on a few lanes of a wavefront, so
+        // the loads are asked for in batches: the NEXT row's pointer while this row is worked on (rows are consecutive in the
+        // table: row a - 1 ends where row a begins), four entries' offsets and values at once, then their four source pixels, then
+        // the four terms in the table's order -- the entries with blo <= b <= bhi, a contiguous run of the descending columns, as before.
+        const ims_spikes_t& k = P.spikes;
+        const int blo = ix - c1, bhi = ix - c0;
+        const int ry_lo = r0 > iy - k.cutoff ? r0 : iy - k.cutoff, ry_hi = r1 < iy + k.cutoff ? r1 : iy + k.cutoff;
+        if (ry_lo <= ry_hi) {
+            int a = iy - ry_lo;
+            int e0 = k.tab_row[a + k.cutoff], e1 = k.tab_row[a + k.cutoff + 1];
+            for (int ry = ry_lo; ry <= ry_hi; ++ry, --a) {
+                const int e_next = ry < ry_hi ? k.tab_row[a - 1 + k.cutoff] : 0;
+                int e = e0;
+                if (e1 - e > 16) {                         // an arm along this row: the first entry with b <= bhi by bisection
+                    int lo = e, hi = e1;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (k.tab_col[mid] > bhi) lo = mid + 1; else hi = mid; }
+                    e = lo;
+                }
+                const int64_t row_at = o.r_offset + (int64_t)ry * o.nfft + ix;
+                for (; e < e1; e += 4) {
+                    int b[4];
+                    double tv[4], sv[4];
+                    bool use[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int eq = e + q < e1 ? e + q : e1 - 1;
+                        b[q] = k.tab_col[eq]; tv[q] = k.tab_val[eq];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        use[q] = e + q < e1 && b[q] <= bhi && b[q] >= blo;
+                        sv[q] = rbuf_value(rin, row_at - (use[q] ? b[q] : bhi), raw, scale);      // (not used: the box's first column)
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (use[q]) { const double src = sv[q] < 0.0 ? 0.0 : sv[q]; acc = acc + tv[q] * src; }
+                    if (b[3] < blo || b[0] < blo) break;       // descending columns: nothing further down is inside the box
+                }
+                e1 = e0; e0 = e_next;
+            }
+        }
+    } else {
+        // Of a source row only the columns near the two arms through this pixel can contribute (|xr| or |yr| within the
+        // stencil's reach T: one interval of columns each, ims_fft.h spike_stencil); everything else in the row is an exact
+        // zero.  The columns are visited in ascending order as before, so the sum is the same sum -- a saturated star's
+        // box is 100 x 100 source pixels, of which a target pixel on an arm needs ~16 per row.
+        const ims_spikes_t& k = P.spikes;
+        const double lim = 0.5 * fabs(k.d_alpha) + 1.0e-6;
+        const double bfar = fabs((double)(ix - c0)) > fabs((double)(ix - c1)) ? fabs((double)(ix - c0)) : fabs((double)(ix - c1));
+        const bool has_s = fabs(k.sin0) > 1.0e-12, has_c = fabs(k.cos0) > 1.0e-12;
+        const double inv_s = has_s ? 1.0 / k.sin0 : 0.0, inv_c = has_c ? 1.0 / k.cos0 : 0.0;
+        for (int ry = r0; ry <= r1; ++ry) {
+            const int a = iy - ry;
+            if (a < -k.cutoff || a > k.cutoff) continue;
+            const double da = (double)a;
+            const double T = 1.0 + 1.0e-3 + lim * sqrt(da * da + bfar * bfar);
+            int lo[2], hi[2];
+            // |cos0 a + sin0 b| <= T
+            if (has_s) {
+                const double b1 = (-T - k.cos0 * da) * inv_s, b2 = (T - k.cos0 * da) * inv_s;
+                const double bl = b1 < b2 ? b1 : b2, bh = b1 < b2 ? b2 : b1;
+                lo[0] = (int)floor((double)ix - bh) - 1; hi[0] = (int)ceil((double)ix - bl) + 1;
+            } else if (fabs(k.cos0 * da) <= T) { lo[0] = c0; hi[0] = c1; }
+            else { lo[0] = 1; hi[0] = 0; }
+            // |-sin0 a + cos0 b| <= T
+            if (has_c) {
+                const double b1 = (-T + k.sin0 * da) * inv_c, b2 = (T + k.sin0 * da) * inv_c;
+                const double bl = b1 < b2 ? b1 : b2, bh = b1 < b2 ? b2 : b1;
+                lo[1] = (int)floor((double)ix - bh) - 1; hi[1] = (int)ceil((double)ix - bl) + 1;
+            } else if (fabs(k.sin0 * da) <= T) { lo[1] = c0; hi[1] = c1; }
+            else { lo[1] = 1; hi[1] = 0; }
+            for (int q = 0; q < 2; ++q) { if (lo[q] < c0) lo[q] = c0; if (hi[q] > c1) hi[q] = c1; }
+            if (lo[1] < lo[0]) { const int tl = lo[0], th = hi[0]; lo[0] = lo[1]; hi[0] = hi[1]; lo[1] = tl; hi[1] = th; }
+            if (hi[0] >= lo[0] && hi[1] >= lo[1] && lo[1] <= hi[0] + 1) { if (hi[1] > hi[0]) hi[0] = hi[1]; lo[1] = 1; hi[1] = 0; }   // one run
+            for (int q = 0; q < 2; ++q)
+                for (int rx = lo[q]; rx <= hi[q]; ++rx) {
+                    const int b = ix - rx;
+                    if (b < -k.cutoff || b > k.cutoff) continue;
+                    double src = rbuf_value(rin, o.r_offset + (int64_t)ry * o.nfft + rx, raw, scale);
+                    if (src < 0.0) src = 0.0;
+                    acc = acc + spike_stencil(k, a, b) / k.norm * src;
+                }
+        }
+    }
+    return acc;
+}
+
 __global__ __launch_bounds__(256) void k_fft_spikes(const ims_fft_params_t P, const ims_fft_object_t* __restrict__ objs,
                                                     int64_t n_objects, const int64_t* __restrict__ prefix, int64_t n_pix, int64_t span,
                                                     const double* __restrict__ rin, double* __restrict__ rout,
-                                                    const int32_t* __restrict__ bbox)
+                                                    const int32_t* __restrict__ bbox, const unsigned int* __restrict__ only_if_over,
+                                                    unsigned int over_cap)
 {
+    // (the fallback of the listed form below: runs only when the list ran over)
+    if (only_if_over != nullptr && only_if_over[0] <= over_cap) return;
     walk_span(prefix, n_objects, n_pix, span, [&](int64_t el, int64_t oi) {
         const ims_fft_object_t& o = objs[oi];
         const int64_t local = el - prefix[oi];
@@ -2383,116 +2499,70 @@ __global__ __launch_bounds__(256) void k_fft_spikes(const ims_fft_params_t P, co
         if (P.spikes.enabled && in_stamp && r1 >= r0) {
             if (iy >= r0 && iy <= r1 && ix >= c0 && ix <= c1) v = 0.0;
             double acc = 0.0;
-            // Far from the arms of EVERY source pixel's cross the whole sum is exact zeros: the offsets from this pixel to the
-            // sources differ from the offset to the box centre by at most half the box, so if even the nearer arm of the centre's
-            // cross is further away than that (plus the stencil's own margins, ims_fft.h spike_stencil), no term can be non-zero.
-            // 97 % of a 4096^2 stamp leave here (the kernel was 2.4 ms per bright star, a sixth of a C5 CCD's top stream).
-            bool none = false;
-            {
-                const ims_spikes_t& k = P.spikes;
-                const double ac = (double)iy - 0.5 * (double)(r0 + r1), bc = (double)ix - 0.5 * (double)(c0 + c1);
-                const double ha = 0.5 * (double)(r1 - r0), hb = 0.5 * (double)(c1 - c0);
-                const double e = fabs(k.cos0) * ha + fabs(k.sin0) * hb + fabs(k.sin0) * ha + fabs(k.cos0) * hb;
-                const double xc = k.cos0 * ac + k.sin0 * bc, yc = -k.sin0 * ac + k.cos0 * bc;
-                const double mc = (fabs(xc) < fabs(yc) ? fabs(xc) : fabs(yc)) - e;
-                const double rmax = sqrt(ac * ac + bc * bc) + sqrt(ha * ha + hb * hb) + 1.0;
-                const double lim = 0.5 * fabs(k.d_alpha) + 1.0e-6;
-                none = mc > 1.0 + 1.0e-3 && mc - 1.0e-3 > lim * rmax;
-            }
-            if (!none && P.spikes.tab_row != nullptr) {
-                // The stencil's non-zero entries come out of the visit's table (ims_spikes_t.tab_*): of source row ry the entries of
-                // stencil row a = iy - ry whose column offset b puts the source column ix - b inside the box, in ascending source
-                // column -- the terms the loops below find among their candidates, in the same order, each formed by the same
-                // operations (stencil / norm in the table's kernel, times the source here), without the three arctangents per term
-                // and the ~16 candidates per row: the same sum.  (A star's spike stencil was 1.1 ms of a CCD's front, round 6.)
-                // The walk is a chain of dependent loads (row pointer -> column offsets -> source pixels) on a few lanes of a wavefront, so
-                // the loads are asked for in batches: the NEXT row's pointer while this row is worked on (rows are consecutive in the
-                // table: row a - 1 ends where row a begins), four entries' offsets and values at once, then their four source pixels, then
-                // the four terms in the table's order -- the entries with blo <= b <= bhi, a contiguous run of the descending columns, as before.
-                const ims_spikes_t& k = P.spikes;
-                const int blo = ix - c1, bhi = ix - c0;
-                const int ry_lo = r0 > iy - k.cutoff ? r0 : iy - k.cutoff, ry_hi = r1 < iy + k.cutoff ? r1 : iy + k.cutoff;
-                if (ry_lo <= ry_hi) {
-                    int a = iy - ry_lo;
-                    int e0 = k.tab_row[a + k.cutoff], e1 = k.tab_row[a + k.cutoff + 1];
-                    for (int ry = ry_lo; ry <= ry_hi; ++ry, --a) {
-                        const int e_next = ry < ry_hi ? k.tab_row[a - 1 + k.cutoff] : 0;
-                        int e = e0;
-                        if (e1 - e > 16) {                         // an arm along this row: the first entry with b <= bhi by bisection
-                            int lo = e, hi = e1;
-                            while (lo < hi) { const int mid = (lo + hi) >> 1; if (k.tab_col[mid] > bhi) lo = mid + 1; else hi = mid; }
-                            e = lo;
-                        }
-                        const int64_t row_at = o.r_offset + (int64_t)ry * o.nfft + ix;
-                        for (; e < e1; e += 4) {
-                            int b[4];
-                            double tv[4], sv[4];
-                            bool use[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const int eq = e + q < e1 ? e + q : e1 - 1;
-                                b[q] = k.tab_col[eq]; tv[q] = k.tab_val[eq];
-                            }
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                use[q] = e + q < e1 && b[q] <= bhi && b[q] >= blo;
-                                sv[q] = rbuf_value(rin, row_at - (use[q] ? b[q] : bhi), raw, scale);      // (not used: the box's first column)
-                            }
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if (use[q]) { const double src = sv[q] < 0.0 ? 0.0 : sv[q]; acc = acc + tv[q] * src; }
-                            if (b[3] < blo || b[0] < blo) break;       // descending columns: nothing further down is inside the box
-                        }
-                        e1 = e0; e0 = e_next;
-                    }
-                }
-            } else if (!none) {
-                // Of a source row only the columns near the two arms through this pixel can contribute (|xr| or |yr| within the
-                // stencil's reach T: one interval of columns each, ims_fft.h spike_stencil); everything else in the row is an exact
-                // zero.  The columns are visited in ascending order as before, so the sum is the same sum -- a saturated star's
-                // box is 100 x 100 source pixels, of which a target pixel on an arm needs ~16 per row.
-                const ims_spikes_t& k = P.spikes;
-                const double lim = 0.5 * fabs(k.d_alpha) + 1.0e-6;
-                const double bfar = fabs((double)(ix - c0)) > fabs((double)(ix - c1)) ? fabs((double)(ix - c0)) : fabs((double)(ix - c1));
-                const bool has_s = fabs(k.sin0) > 1.0e-12, has_c = fabs(k.cos0) > 1.0e-12;
-                const double inv_s = has_s ? 1.0 / k.sin0 : 0.0, inv_c = has_c ? 1.0 / k.cos0 : 0.0;
-                for (int ry = r0; ry <= r1; ++ry) {
-                    const int a = iy - ry;
-                    if (a < -k.cutoff || a > k.cutoff) continue;
-                    const double da = (double)a;
-                    const double T = 1.0 + 1.0e-3 + lim * sqrt(da * da + bfar * bfar);
-                    int lo[2], hi[2];
-                    // |cos0 a + sin0 b| <= T
-                    if (has_s) {
-                        const double b1 = (-T - k.cos0 * da) * inv_s, b2 = (T - k.cos0 * da) * inv_s;
-                        const double bl = b1 < b2 ? b1 : b2, bh = b1 < b2 ? b2 : b1;
-                        lo[0] = (int)floor((double)ix - bh) - 1; hi[0] = (int)ceil((double)ix - bl) + 1;
-                    } else if (fabs(k.cos0 * da) <= T) { lo[0] = c0; hi[0] = c1; }
-                    else { lo[0] = 1; hi[0] = 0; }
-                    // |-sin0 a + cos0 b| <= T
-                    if (has_c) {
-                        const double b1 = (-T + k.sin0 * da) * inv_c, b2 = (T + k.sin0 * da) * inv_c;
-                        const double bl = b1 < b2 ? b1 : b2, bh = b1 < b2 ? b2 : b1;
-                        lo[1] = (int)floor((double)ix - bh) - 1; hi[1] = (int)ceil((double)ix - bl) + 1;
-                    } else if (fabs(k.sin0 * da) <= T) { lo[1] = c0; hi[1] = c1; }
-                    else { lo[1] = 1; hi[1] = 0; }
-                    for (int q = 0; q < 2; ++q) { if (lo[q] < c0) lo[q] = c0; if (hi[q] > c1) hi[q] = c1; }
-                    if (lo[1] < lo[0]) { const int tl = lo[0], th = hi[0]; lo[0] = lo[1]; hi[0] = hi[1]; lo[1] = tl; hi[1] = th; }
-                    if (hi[0] >= lo[0] && hi[1] >= lo[1] && lo[1] <= hi[0] + 1) { if (hi[1] > hi[0]) hi[0] = hi[1]; lo[1] = 1; hi[1] = 0; }   // one run
-                    for (int q = 0; q < 2; ++q)
-                        for (int rx = lo[q]; rx <= hi[q]; ++rx) {
-                            const int b = ix - rx;
-                            if (b < -k.cutoff || b > k.cutoff) continue;
-                            double src = rbuf_value(rin, o.r_offset + (int64_t)ry * o.nfft + rx, raw, scale);
-                            if (src < 0.0) src = 0.0;
-                            acc = acc + spike_stencil(k, a, b) / k.norm * src;
-                        }
-                }
-            }
+            if (!spike_sum_is_zero(P.spikes, iy, ix, r0, r1, c0, c1)) acc = spike_sum(P, o, iy, ix, r0, r1, c0, c1, rin, raw, scale);
             v = v + acc;
         }
         rout[o.r_offset + local] = v;
     });
+}
+
+// The spike step in two launches (ims_fft_spikes_listed).  This one streams: clip, the saturated box to zero, the image written --
+// and the pixels whose spike sum is NOT known to be zero (3 % of a bright star's stamp: the arms) appended to a list, object << 40 |
+// element of the object.  Light (no table walk in it: 40 registers instead of 98), so that its 16 bytes per pixel move at the
+// rate of a copy; the arms' sums are then formed by k_fft_spikes_arms with every lane at work, not three in a wavefront.
+__global__ __launch_bounds__(256) void k_fft_spikes_stream(const ims_fft_params_t P, const ims_fft_object_t* __restrict__ objs,
+                                                           int64_t n_objects, const int64_t* __restrict__ prefix, int64_t n_pix, int64_t span,
+                                                           const double* __restrict__ rin, double* __restrict__ rout,
+                                                           const int32_t* __restrict__ bbox, unsigned long long* __restrict__ list,
+                                                           unsigned int cap, unsigned int* __restrict__ count)
+{
+    walk_span(prefix, n_objects, n_pix, span, [&](int64_t el, int64_t oi) {
+        const ims_fft_object_t& o = objs[oi];
+        const int64_t local = el - prefix[oi];
+        int iy, ix;
+        row_col(local, o.nfft, iy, ix);
+        double v = rbuf_value(rin, o.r_offset + local, P.rbuf_raw != 0, inv_n2(o.nfft));
+        if (v < 0.0) v = 0.0;
+        const int px = o.x0 + ix, py = o.y0 + iy;
+        const bool in_stamp = !(px < o.stamp_xmin || px > o.stamp_xmax || py < o.stamp_ymin || py > o.stamp_ymax);
+        const int r0 = bbox[4 * oi + 0], r1 = bbox[4 * oi + 1], c0 = bbox[4 * oi + 2], c1 = bbox[4 * oi + 3];
+        bool want = false;
+        if (P.spikes.enabled && in_stamp && r1 >= r0) {
+            if (iy >= r0 && iy <= r1 && ix >= c0 && ix <= c1) v = 0.0;
+            want = !spike_sum_is_zero(P.spikes, iy, ix, r0, r1, c0, c1);
+        }
+        rout[o.r_offset + local] = v;
+        // one addition to the counter per wavefront
+        const unsigned long long m = __ballot(want);
+        if (m != 0ull) {
+            const int lane = (int)(threadIdx.x & 63u), lead = __ffsll((long long)m) - 1;
+            unsigned int base = 0u;
+            if (lane == lead) base = atomicAdd(count, (unsigned int)__popcll(m));
+            base = __shfl(base, lead, 64);
+            const unsigned int at = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+            if (want && at < cap) list[at] = ((unsigned long long)oi << 40) | (unsigned long long)local;
+        }
+    });
+}
+
+__global__ __launch_bounds__(256) void k_fft_spikes_arms(const ims_fft_params_t P, const ims_fft_object_t* __restrict__ objs,
+                                                         const double* __restrict__ rin, double* __restrict__ rout,
+                                                         const int32_t* __restrict__ bbox, const unsigned long long* __restrict__ list,
+                                                         unsigned int cap, const unsigned int* __restrict__ count)
+{
+    const unsigned int n = count[0];
+    if (n > cap) return;                          // the list ran over: k_fft_spikes does the whole step again
+    const unsigned int stride = gridDim.x * blockDim.x;
+    for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+        const unsigned long long e = list[t];
+        const int64_t oi = (int64_t)(e >> 40), local = (int64_t)(e & ((1ull << 40) - 1ull));
+        const ims_fft_object_t& o = objs[oi];
+        int iy, ix;
+        row_col(local, o.nfft, iy, ix);
+        const int r0 = bbox[4 * oi + 0], r1 = bbox[4 * oi + 1], c0 = bbox[4 * oi + 2], c1 = bbox[4 * oi + 3];
+        const double acc = spike_sum(P, o, iy, ix, r0, r1, c0, c1, rin, P.rbuf_raw != 0, inv_n2(o.nfft));
+        rout[o.r_offset + local] = rout[o.r_offset + local] + acc;
+    }
 }
 
 // clip, Poisson noise, stamp -> CCD add (stamp.py:519-524); realized flux = noise-free sum inside the stamp
@@ -4629,7 +4699,38 @@ int ims_fft_spikes(const ims_fft_params_t* params, const ims_fft_object_t* objec
         hipLaunchKernelGGL(k_fft_bbox, dim3(sp.grid), dim3(256), 0, st, *params, objects_dev, n_objects,
                            pix_prefix_dev, n_pix, sp.span, rbuf_in, bbox_dev);
     hipLaunchKernelGGL(k_fft_spikes, dim3(sp.grid), dim3(256), 0, st, *params, objects_dev, n_objects,
-                       pix_prefix_dev, n_pix, sp.span, rbuf_in, rbuf_out, (const int32_t*)bbox_dev);
+                       pix_prefix_dev, n_pix, sp.span, rbuf_in, rbuf_out, (const int32_t*)bbox_dev, (const unsigned int*)nullptr, 0u);
+    HIP_TRY(hipGetLastError());
+    return IMS_OK;
+}
+
+int ims_fft_spikes_listed(const ims_fft_params_t* params, const ims_fft_object_t* objects_dev, int64_t n_objects,
+                          const int64_t* pix_prefix_dev, int64_t n_pix, const double* rbuf_in, double* rbuf_out,
+                          int32_t* bbox_dev, uint64_t* list_dev, int64_t list_cap, uint32_t* count_dev, void* stream)
+{
+    if (!params || !objects_dev || !pix_prefix_dev || !rbuf_in || !rbuf_out || !bbox_dev || !list_dev || !count_dev)
+        return set_err(IMS_ERR_ARG, "NULL argument");
+    if (list_cap < 1 || list_cap > 0xffffffffLL) return set_err(IMS_ERR_ARG, "list_cap out of range");
+    if (n_objects >= (1ll << 24)) return set_err(IMS_ERR_ARG, "the listed spike step holds at most 2^24 objects");
+    if (n_objects <= 0 || n_pix <= 0) return IMS_OK;
+    if (!params->spikes.enabled) return ims_fft_spikes(params, objects_dev, n_objects, pix_prefix_dev, n_pix, rbuf_in, rbuf_out, bbox_dev, stream);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned int cap = (unsigned int)list_cap;
+    HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_fill_bbox, dim3((unsigned)((n_objects + 255) / 256)), dim3(256), 0, st, bbox_dev, n_objects);
+    const FftSpan sp = fft_span(n_pix);
+    hipLaunchKernelGGL(k_fft_bbox, dim3(sp.grid), dim3(256), 0, st, *params, objects_dev, n_objects,
+                       pix_prefix_dev, n_pix, sp.span, rbuf_in, bbox_dev);
+    hipLaunchKernelGGL(k_fft_spikes_stream, dim3(sp.grid), dim3(256), 0, st, *params, objects_dev, n_objects, pix_prefix_dev, n_pix,
+                       sp.span, rbuf_in, rbuf_out, (const int32_t*)bbox_dev, (unsigned long long*)list_dev, cap, (unsigned int*)count_dev);
+    // the arms: a grid that covers the list at 256 entries per workgroup, at most 16 384 workgroups (they stride)
+    int64_t arms = (list_cap + 255) / 256;
+    if (arms > 16384) arms = 16384;
+    hipLaunchKernelGGL(k_fft_spikes_arms, dim3((unsigned)arms), dim3(256), 0, st, *params, objects_dev, rbuf_in, rbuf_out,
+                       (const int32_t*)bbox_dev, (const unsigned long long*)list_dev, cap, (const unsigned int*)count_dev);
+    // more arm pixels than the list holds: the whole step once more in one launch (returns at once otherwise)
+    hipLaunchKernelGGL(k_fft_spikes, dim3(sp.grid), dim3(256), 0, st, *params, objects_dev, n_objects, pix_prefix_dev, n_pix, sp.span,
+                       rbuf_in, rbuf_out, (const int32_t*)bbox_dev, (const unsigned int*)count_dev, cap);
     HIP_TRY(hipGetLastError());
     return IMS_OK;
 }

@@ -407,6 +407,7 @@ class FftDrawer:
         rbuf = torch.empty(r_need, dtype=torch.float64, device=r.device)
         spike = (torch.empty(r_need, dtype=torch.float64, device=r.device), torch.empty(4 * n_need, dtype=torch.int32, device=r.device)) \
             if self.P.spikes.enabled else None
+        self._spike_list = self._make_spike_list(r_need) if self.P.spikes.enabled else None
         from .engine import upload_async
         states = []
         for a, b in spans:
@@ -446,7 +447,18 @@ class FftDrawer:
         # side stream then never allocates there
         self._spike_bufs = ((torch.empty_like(rbuf), torch.empty(4 * len(rows), dtype=torch.int32, device=r.device))
                             if self.P.spikes.enabled else None)
+        self._spike_list = self._make_spike_list(int(rpre[-1])) if self.P.spikes.enabled else None
         return rows, obj_t, nfft, kpre, rpre, kpre_t, rpre_t, kbuf, rbuf
+
+    def _make_spike_list(self, n_pix):
+        """the list of the listed spike step (ims_fft_spikes_listed): n_pix / 8 entries (the arms of a bright star's cross are ~3 % of
+        a 4096^2 stamp) and its counter; None with IMS_FFT_SPIKE_LIST=0 (the one-launch form)"""
+        if tuning.env("IMS_FFT_SPIKE_LIST", "1") == "0":
+            return None
+        # (small stamps are mostly arms: a draw of up to 2^20 pixels gets a list that cannot run over)
+        cap = max(int(tuning.env("IMS_FFT_SPIKE_LIST_CAP", "0")) or max(n_pix // 8, min(n_pix, 1 << 20)), 64)
+        torch, r = self.torch, self.r
+        return (torch.empty(cap, dtype=torch.int64, device=r.device), torch.zeros(2, dtype=torch.int32, device=r.device))
 
     def _run(self, state, realized):
         torch, r = self.torch, self.r
@@ -488,8 +500,14 @@ class FftDrawer:
             final, bbox = self._spike_bufs if getattr(self, "_spike_bufs", None) is not None else (
                 torch.empty_like(rbuf), torch.empty(4 * n, dtype=torch.int32, device=r.device))
             P.rbuf_raw = int(raw)
-            _abi.check(r.lib.ims_fft_spikes(C.byref(P), obj_t.data_ptr(), n, rpre_t.data_ptr(), int(rpre[-1]),
-                                            rbuf.data_ptr(), final.data_ptr(), bbox.data_ptr(), st), "ims_fft_spikes")
+            lst = getattr(self, "_spike_list", None)
+            if lst is not None:
+                _abi.check(r.lib.ims_fft_spikes_listed(C.byref(P), obj_t.data_ptr(), n, rpre_t.data_ptr(), int(rpre[-1]),
+                                                       rbuf.data_ptr(), final.data_ptr(), bbox.data_ptr(), lst[0].data_ptr(),
+                                                       lst[0].numel(), lst[1].data_ptr(), st), "ims_fft_spikes_listed")
+            else:
+                _abi.check(r.lib.ims_fft_spikes(C.byref(P), obj_t.data_ptr(), n, rpre_t.data_ptr(), int(rpre[-1]),
+                                                rbuf.data_ptr(), final.data_ptr(), bbox.data_ptr(), st), "ims_fft_spikes")
             raw = False                         # the spike step writes the image itself
         P.rbuf_raw = int(raw)
         try:
@@ -501,5 +519,5 @@ class FftDrawer:
         # _last until they are through): the saturated-region boxes too -- freed at the end of this call, their block went back to
         # the allocator and to the next CCD's uploads while k_fft_bbox / k_fft_spikes were still queued (round 5: the rows of the
         # next CCD's k-space fill overwritten, a fault or a hang once the side stream ran behind)
-        self._last = (kbuf, rbuf, final, obj_t, kpre_t, rpre_t, bbox)
+        self._last = (kbuf, rbuf, final, obj_t, kpre_t, rpre_t, bbox, getattr(self, "_spike_list", None))
         return kspace, rbuf

@@ -37,6 +37,9 @@ KNOWN = {
                              "0 = every stencil value evaluated in place"),
     "IMS_FOCAL_PINNED": ("64", "focal plane: page-locked float32 image buffers (67 MB each for a 4096 x 4096 CCD) in flight at most; kept for "
                                "the life of the process"),
+    "IMS_FFT_SPIKE_LIST": ("1", "FFT branch: the spike step in two launches (ims_fft_spikes_listed: the image streamed, the arms' pixels listed and "
+                                "summed with every lane at work); 0 = one launch (ims_fft_spikes), the same bits"),
+    "IMS_FFT_SPIKE_LIST_CAP": ("0", "entries of that list (0 = a eighth of the draw's pixels); a list that runs over costs one more launch"),
     "IMS_FFT_RAW": ("1", "FFT branch: the inverse transform's 1 / N^2 applied by the kernel that reads the real-space buffer next "
                          "(ims_fft_inverse_raw + ims_fft_params_t.rbuf_raw); 0 = a scaling pass of its own (the same bits)"),
     "IMS_SCREEN_PREPASS": ("0", "phase-screen gathers ahead of the shooting kernels (1: every photon, 2: ordinary objects on a side stream)"),

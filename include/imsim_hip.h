@@ -48,7 +48,7 @@ extern "C" {
 #define IMS_ERR_NO_DEVICE  -3
 #define IMS_ERR_UNSUPPORTED -4
 
-#define IMS_ABI_VERSION 21
+#define IMS_ABI_VERSION 22
 
 /* Pointers stored INSIDE descriptors that live in device memory (ims_sensor_t, ims_atmosphere_t) always point to global
  * device memory.  Device code is told so (address space 1): a pointer read out of memory is otherwise a generic pointer and
@@ -604,6 +604,14 @@ int  ims_fft_spike_table(const ims_spikes_t* spikes, const int32_t* row_ptr_dev,
 int  ims_fft_spikes(const ims_fft_params_t* params, const ims_fft_object_t* objects_dev, int64_t n_objects,
                     const int64_t* pix_prefix_dev, int64_t n_pix, const double* rbuf_in, double* rbuf_out,
                     int32_t* bbox_dev, void* stream);
+/* ims_fft_spikes in two launches: the image streamed (clip, saturated box to zero) with the pixels near an arm of the cross -- the only
+ * ones whose spike sum is not exactly zero, ~3 % of a bright star's stamp -- appended to list_dev (uint64 [list_cap]; count_dev: one
+ * uint32, zeroed here), then their sums formed with every lane at work and added.  The same values in rbuf_out, bit for bit.  A list
+ * that runs over (more such pixels than list_cap) costs one more launch that does the whole step as ims_fft_spikes does; n_pix / 8
+ * entries are plenty. */
+int  ims_fft_spikes_listed(const ims_fft_params_t* params, const ims_fft_object_t* objects_dev, int64_t n_objects,
+                           const int64_t* pix_prefix_dev, int64_t n_pix, const double* rbuf_in, double* rbuf_out,
+                           int32_t* bbox_dev, uint64_t* list_dev, int64_t list_cap, uint32_t* count_dev, void* stream);
 /* pix_prefix[n_objects+1] (device): prefix sum of nfft*nfft; rbuf: the inverse-transformed images */
 int  ims_fft_finish(const ims_fft_params_t* params, const ims_fft_object_t* objects_dev, int64_t n_objects,
                     const int64_t* pix_prefix_dev, int64_t n_pix, const double* rbuf, void* stream);

@@ -96,7 +96,7 @@ def test_joint_run_entry_points_check_their_arguments_before_any_hip_call():
 
 def test_abi_version_and_error_string():
     lib = _abi.load()
-    assert lib.ims_abi_version() == 21
+    assert lib.ims_abi_version() == 22
     # argument checking happens before any HIP call, so it is testable without a GPU
     assert lib.ims_shoot_accumulate(None, None) == -1
     assert b"NULL" in lib.ims_last_error()

@@ -844,6 +844,44 @@ def test_fft_inverse_left_unnormalised_for_its_readers_gives_the_same_images(tor
     assert lib.ims_fft_inverse_raw(None, None, 64, 1, None) != 0
 
 
+def test_spike_step_in_two_launches_equals_the_one_launch_form_and_the_oracle(torch_cuda, monkeypatch):
+    """ims_fft_spikes_listed (FftDrawer's default): the image streamed, the pixels near an arm listed and their sums formed by a second
+    launch -- the spiked images are ims_fft_spikes's bit for bit, also when the list runs over (a capacity of 64 entries: the
+    fallback launch does the whole step again) and against the oracle."""
+    import math
+    from imsim_amd import fft_draw, diffraction_fft as dfft
+    from imsim_amd.engine import Renderer
+    from oracle import orc_loader
+    scene, rows, kpsf = _fft_case()
+    rows = rows.copy()
+    rows["flux"] *= 20.0
+    cfg = dfft.DiffractionFFT(exptime=30.0, azimuth=math.radians(114.39), altitude=math.radians(53.16),
+                              rotTelPos=math.radians(40.04), spike_length_cutoff=60)
+    got = {}
+    for name, env in (("one launch", {"IMS_FFT_SPIKE_LIST": "0"}), ("listed", {"IMS_FFT_SPIKE_LIST": "1"}),
+                      ("listed, list of 64", {"IMS_FFT_SPIKE_LIST": "1", "IMS_FFT_SPIKE_LIST_CAP": "64"}),
+                      ("listed, in place", {"IMS_FFT_SPIKE_LIST": "1", "IMS_SPIKE_TABLE": "0"})):
+        for k in ("IMS_FFT_SPIKE_LIST", "IMS_FFT_SPIKE_LIST_CAP", "IMS_SPIKE_TABLE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r = Renderer(scene)
+        drawer = fft_draw.FftDrawer(r, kpsf, add_noise=True, diffraction_fft=cfg, wavelength=622.2)
+        kbuf, rbuf = drawer.draw(rows)
+        r.synchronize()
+        assert (drawer._last[7] is None) == (name == "one launch")
+        if drawer._last[7] is not None:
+            n_listed = int(drawer._last[7][1][0].item())
+            assert n_listed > 64 and (n_listed <= drawer._last[7][0].numel()) == (name != "listed, list of 64")
+        got[name] = (drawer._last[2].cpu().numpy().copy(), r.image_numpy(), fft_draw.image_from_rbuf(rows, rbuf.cpu().numpy()))
+    orc = orc_loader.OracleFft(scene, kpsf, add_noise=True, diffraction_fft=cfg, wavelength=622.2)
+    ofinal = orc.spikes(rows, got["one launch"][2])
+    for name in got:
+        assert_bits_equal(got[name][0], ofinal, f"spiked images, {name} vs oracle")
+        assert_bits_equal(got[name][1], got["one launch"][1], f"CCD image, {name}")
+    assert np.abs(ofinal - np.clip(got["one launch"][2], 0, None)).max() > 1.0
+
+
 def test_fft_and_photon_shooting_agree(torch_cuda):
     """The reference's FFT-vs-phot criteria (tests/test_psf.py:341-438: peak within 5 %, moments
     within 10 %) for a bright star and a bright Sersic galaxy through Kolmogorov (+) Gaussian."""

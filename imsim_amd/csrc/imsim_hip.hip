@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256, (NV == 8) ? 2 : 4) void k_accumulate_segments(
 // wavefront each are bound by the dispatch rate (9 ms per batch of C4 for 2 ms of work).  The object index is made
 // wave-uniform with readfirstlane so that the row still comes through scalar loads.
 template <int NV>
-__global__ __launch_bounds__(256, (NV == 8) ? 2 : 3) void k_accumulate_small(const ims_render_params_t P, const ims_photons_t pool,
+__global__ __launch_bounds__(256, (NV == 8) ? 2 : 5) void k_accumulate_small(const ims_render_params_t P, const ims_photons_t pool,
                                                                              const int64_t* __restrict__ pool_start)
 {
     const int64_t first = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6));

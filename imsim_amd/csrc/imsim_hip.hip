@@ -2081,7 +2081,7 @@ __device__ __forceinline__ void update_listed_tile(const JointUpd* __restrict__ 
 }
 
 template <int NV, bool DPP = false>
-__global__ __launch_bounds__(256) void k_update_list_j(const JointUpd* __restrict__ U, const JointLists Ls, int parity, unsigned int tag,
+__global__ __launch_bounds__(256, 5) void k_update_list_j(const JointUpd* __restrict__ U, const JointLists Ls, int parity, unsigned int tag,
                                                        int reset_next)
 {
     __shared__ UpdateLds<NV> L0;
